@@ -1,0 +1,427 @@
+"""NumPy restatement of the DeepEP dispatch/combine arithmetic of sgl-kernel-npu.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  All ranks of the EP group are
+simulated inside one process: functions take per-rank lists and return per-rank
+lists.  Integer/index results are the bit-exact target for the HIP kernels; the
+INT8 payload / scales and the BF16 combine are bit-exact targets too (fp32
+arithmetic with the rounding modes of the reference, stated per function).
+
+Notation: W ranks, E experts, L = E // W local experts,
+T tokens (per rank), K = top-k, H = hidden.  "idx i" over [L*W] means
+i = local_expert * W + src_rank (reference: cam_moe_dispatch_normal.h:723-724).
+
+bf16 tensors are carried as uint16 bit patterns (oracle/bf16.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .bf16 import bf16_bits_to_f32, f32_to_bf16_bits_rne
+
+
+# --------------------------------------------------------------------------------------
+# A1  dispatch layout
+# --------------------------------------------------------------------------------------
+def dispatch_layout(topk_idx: np.ndarray, num_experts: int, num_ranks: int) -> dict:
+    """Reference: csrc/deepep/ops/op_kernel/dispatch_layout.h:159-213 (+ host
+    csrc/deepep/deep_ep.cpp:111-180).
+
+    For every token row: ids < 0 or >= E are skipped (:166); num_tokens_per_expert[e]++
+    (:169-170); the first hit of rank e // L sets is_token_in_rank[t, r] = 1 and bumps
+    num_tokens_per_rank[r] (:171-177).  Second pass (:203-213): send_token_idx_small[t, k] =
+    number of earlier (row-major) valid (t', k') pairs with the same expert.  Entries of
+    send_token_idx_small at invalid ids are unspecified in the reference (UB scratch written
+    back); this restatement (and the HIP kernel) define them as 0.
+    """
+    topk_idx = np.ascontiguousarray(topk_idx, dtype=np.int64)
+    T, K = topk_idx.shape
+    E, W = int(num_experts), int(num_ranks)
+    L = E // W
+    flat = topk_idx.reshape(-1)
+    valid = (flat >= 0) & (flat < E)
+    vidx = np.nonzero(valid)[0]
+    ve = flat[vidx]
+    num_tokens_per_expert = np.bincount(ve, minlength=E).astype(np.int32)
+    # rank among same-expert pairs in row-major order == position inside the stable sort group
+    order = np.argsort(ve, kind="stable")
+    starts = np.zeros(E + 1, dtype=np.int64)
+    np.cumsum(num_tokens_per_expert, out=starts[1:])
+    pos_sorted = np.arange(ve.size, dtype=np.int64) - starts[ve[order]]
+    small = np.zeros(T * K, dtype=np.int32)
+    small[vidx[order]] = pos_sorted.astype(np.int32)
+    # token -> rank membership (dedup over k)
+    is_in = np.zeros((T, W), dtype=np.int32)
+    if vidx.size:
+        is_in[vidx // K, ve // L] = 1
+    num_tokens_per_rank = is_in.sum(axis=0).astype(np.int32)
+    return dict(
+        num_tokens_per_rank=num_tokens_per_rank,
+        num_tokens_per_expert=num_tokens_per_expert,
+        is_token_in_rank=is_in,
+        send_token_idx_small=small.reshape(T, K),
+    )
+
+
+def dispatch_layout_loops(topk_idx: np.ndarray, num_experts: int, num_ranks: int) -> dict:
+    """Literal (slow) transcription of the same two passes with Python loops; used to
+    cross-check the vectorised version on small cases."""
+    T, K = topk_idx.shape
+    E, W = num_experts, num_ranks
+    L = E // W
+    per_e = np.zeros(E, np.int32)
+    per_r = np.zeros(W, np.int32)
+    is_in = np.zeros((T, W), np.int32)
+    for t in range(T):
+        seen = [False] * W
+        for k in range(K):
+            e = int(topk_idx[t, k])
+            if e < 0 or e >= E:
+                continue
+            per_e[e] += 1
+            r = e // L
+            if not seen[r]:
+                seen[r] = True
+                is_in[t, r] = 1
+                per_r[r] += 1
+    run = np.zeros(E, np.int32)
+    small = np.zeros((T, K), np.int32)
+    for t in range(T):
+        for k in range(K):
+            e = int(topk_idx[t, k])
+            if e < 0 or e >= E:
+                continue
+            small[t, k] = run[e]
+            run[e] += 1
+    return dict(num_tokens_per_rank=per_r, num_tokens_per_expert=per_e, is_token_in_rank=is_in,
+                send_token_idx_small=small)
+
+
+# --------------------------------------------------------------------------------------
+# A2  notify dispatch (counts exchange + derived index tables)
+# --------------------------------------------------------------------------------------
+def send_data_offset(num_tokens_per_expert: np.ndarray) -> np.ndarray:
+    """Exclusive prefix over global expert id of this rank's per-expert counts
+    (reference: notify_dispatch.h:185-198, `sendDataOffsetTensor(i) = prefixSum`)."""
+    c = np.asarray(num_tokens_per_expert, dtype=np.int64)
+    out = np.zeros_like(c)
+    np.cumsum(c[:-1], out=out[1:])
+    return out.astype(np.int32)
+
+
+def notify_dispatch(cnt: np.ndarray, num_tokens: Sequence[int], rank: int) -> dict:
+    """Tables rank `rank` derives after the all-to-all of (count, send-prefix, roundTokens)
+    triples.  `cnt[src, e]` = num_tokens_per_expert of rank src (all ranks), round = 1.
+
+    Reference: csrc/deepep/ops/op_kernel/notify_dispatch.h
+      recv_count  :473-482  inclusive running sum over idx i = le*W+src of cnt[src, me*L+le]
+      recv_offset :386-407  the sender's exclusive prefix for that expert
+      recv_tokens_per_expert :606-615, expert_global_offset :665-669 (exclusive scan),
+      srcrank_in_expert_offset :715-721 (exclusive scan over src inside one le),
+      r_in_srcrank_offset :759-780 (0 for round 1), total_recv_token :434-450,
+      max_bs :553-577 (max over src of that src's token count).
+    """
+    cnt = np.asarray(cnt, dtype=np.int64)
+    W, E = cnt.shape
+    L = E // W
+    me = int(rank)
+    c = cnt[:, me * L:(me + 1) * L].T.copy()          # [L, W]  c[le, src]
+    send_off = np.zeros_like(cnt)
+    np.cumsum(cnt[:, :-1], axis=1, out=send_off[:, 1:])
+    recv_count = np.cumsum(c.reshape(-1)).astype(np.int32)                       # [L*W]
+    recv_offset = send_off[:, me * L:(me + 1) * L].T.reshape(-1).astype(np.int32)  # [L*W]
+    per_e = c.sum(axis=1)
+    ego = np.zeros(L, np.int64)
+    np.cumsum(per_e[:-1], out=ego[1:])
+    sie = np.zeros((L, W), np.int64)
+    np.cumsum(c[:, :-1], axis=1, out=sie[:, 1:])
+    return dict(
+        send_data_offset=send_off[me].astype(np.int32),
+        recv_count=recv_count,
+        recv_offset=recv_offset,
+        recv_tokens_per_expert=per_e.astype(np.int32),
+        expert_global_offset=ego.astype(np.int32),
+        srcrank_in_expert_offset=sie.reshape(-1).astype(np.int32),
+        r_in_srcrank_offset=np.zeros(L * W, np.int32),
+        total_recv_token=np.int32(c.sum()),
+        max_bs=np.int32(max(int(t) for t in num_tokens) if len(num_tokens) else 0),
+    )
+
+
+# --------------------------------------------------------------------------------------
+# per-token dynamic INT8 quantisation
+# --------------------------------------------------------------------------------------
+def quant_int8_rows(x_bits: np.ndarray, eps: Optional[float]) -> tuple:
+    """Per-row symmetric INT8 quantisation of bf16 rows.
+
+    Normal mode (eps = 1e-12): cam_moe_dispatch_normal.h:326-363
+        s = 127.0f / (max_j |x_j| + 1e-12f);  q_j = int8(rint_half_even(float(x_j) * s));
+        scale_out = 1.0f / s
+      (bf16->f32 exact; f32 multiply; f32->i32 CAST_RINT = round half to even; the later
+       i32->f16->i8 casts are exact for |v| <= 127.)
+    Low-latency mode (eps = None): moe_distribute_dispatch_v2.h:1006-1033, same but
+        s = 127.0f / max_j |x_j| with no epsilon.  An all-zero row gives s = inf and
+        0 * inf = NaN in the reference (result unspecified); here (and in the HIP kernel)
+        such a row quantises to q = 0, scale = 0.
+    Returns (q int8 [N,H], scale f32 [N]).
+    """
+    xf = bf16_bits_to_f32(x_bits)
+    amax = np.max(np.abs(xf), axis=1).astype(np.float32) if xf.shape[1] else np.zeros(xf.shape[0], np.float32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        if eps is None:
+            s = np.float32(127.0) / amax
+        else:
+            s = np.float32(127.0) / (amax + np.float32(eps))
+        y = xf * s[:, None]
+        q = np.rint(y)                       # round half to even
+        scale = (np.float32(1.0) / s).astype(np.float32)
+    if eps is None:
+        zero = amax == 0
+        if zero.any():
+            q[zero] = 0
+            scale[zero] = 0
+    return q.astype(np.int8), scale
+
+
+def per_token_cast_back(q: np.ndarray, scale: np.ndarray) -> np.ndarray:
+    """De-quantisation convention of the reference tests (float32-scale branch of
+    tests/python/deepep/utils.py:182-188): bf16(float(q) * scale).  Returns bf16 bits."""
+    return f32_to_bf16_bits_rne(q.astype(np.float32) * scale.astype(np.float32)[:, None])
+
+
+# --------------------------------------------------------------------------------------
+# A3  normal dispatch
+# --------------------------------------------------------------------------------------
+@dataclass
+class DispatchResult:
+    recv_x: np.ndarray                 # [max(R,1), H] int8 or bf16 bits
+    recv_x_scales: Optional[np.ndarray]  # [max(R,1)] f32 (int8 mode)
+    recv_src_idx: np.ndarray           # [3*max(R,1)] i32 triples (src_rank, token, k)
+    num_recv_tokens_per_expert_list: List[int]
+    send_head: np.ndarray              # [E] i32 == recv_count (round = 1)
+    total_recv: int
+    layout: dict = field(default_factory=dict)
+    notify: dict = field(default_factory=dict)
+
+
+def normal_dispatch(xs_bits: Sequence[np.ndarray], topk_idxs: Sequence[np.ndarray], num_experts: int,
+                    quant: bool, expert_token_nums_type: int = 1) -> List[DispatchResult]:
+    """All ranks' `Buffer.dispatch` results (default strategy, round = 1).
+
+    Reference: host csrc/deepep/deep_ep.cpp:197-416; kernel cam_moe_dispatch_normal.h
+      sender   :440-473  slot = send_data_offset[e] + send_token_idx_small[t,k] in own window,
+                         row payload + scale + triple (src_rank, t, k) (:366-375)
+      receiver :717-760  for idx i: count = recv_count[i] - recv_count[i-1]; rows
+                         recv_offset[i] .. +count of rank src's window go to output rows
+                         expert_global_offset[le] + srcrank_in_expert_offset[i] + r_in_srcrank_offset[i] + j
+    => received rows are ordered (local expert, src rank, source row-major (t,k) order).
+    Output sizes use max(R, 1) rows (deep_ep.cpp:327-328).  recv_topk_idx / recv_topk_weights are
+    allocated but never written by the reference (deep_ep.cpp:371-374) and are not modelled.
+    num_recv_tokens_per_expert_list: counts, or inclusive cumsum when MOE_EXPERT_TOKEN_NUMS_TYPE=0
+    (deep_ep.cpp:384-401).
+    """
+    W = len(xs_bits)
+    E = int(num_experts)
+    L = E // W
+    layouts = [dispatch_layout(topk_idxs[r], E, W) for r in range(W)]
+    cnt = np.stack([l["num_tokens_per_expert"] for l in layouts]).astype(np.int64)
+    Ts = [int(x.shape[0]) for x in xs_bits]
+    H = int(xs_bits[0].shape[1])
+    # ---- sender side: stage rows sorted by expert in the own window
+    windows = []
+    for r in range(W):
+        x = np.ascontiguousarray(xs_bits[r]).view(np.uint16)
+        ti = np.ascontiguousarray(topk_idxs[r], dtype=np.int64)
+        T, K = ti.shape
+        so = send_data_offset(cnt[r]).astype(np.int64)
+        flat = ti.reshape(-1)
+        vidx = np.nonzero((flat >= 0) & (flat < E))[0]
+        slot = so[flat[vidx]] + layouts[r]["send_token_idx_small"].reshape(-1)[vidx]
+        n = int(cnt[r].sum())
+        tok = (vidx // K).astype(np.int32)
+        kk = (vidx % K).astype(np.int32)
+        if quant:
+            q_all, s_all = quant_int8_rows(x, 1e-12)
+            payload = np.zeros((n, H), np.int8)
+            payload[slot] = q_all[tok]
+            scales = np.zeros(n, np.float32)
+            scales[slot] = s_all[tok]
+        else:
+            payload = np.zeros((n, H), np.uint16)
+            payload[slot] = x[tok]
+            scales = None
+        triple = np.zeros((n, 3), np.int32)
+        triple[slot, 0] = r
+        triple[slot, 1] = tok
+        triple[slot, 2] = kk
+        windows.append((payload, scales, triple))
+    # ---- receiver side
+    out = []
+    for me in range(W):
+        nt = notify_dispatch(cnt, Ts, me)
+        R = int(nt["total_recv_token"])
+        rows = max(R, 1)
+        recv_x = np.zeros((rows, H), np.int8 if quant else np.uint16)
+        recv_s = np.zeros(rows, np.float32) if quant else None
+        recv_t = np.zeros((rows, 3), np.int32)
+        prev = 0
+        for i in range(L * W):
+            le, src = divmod(i, W)
+            c = int(nt["recv_count"][i]) - prev
+            prev = int(nt["recv_count"][i])
+            if c == 0:
+                continue
+            so = int(nt["recv_offset"][i])
+            dst = int(nt["expert_global_offset"][le]) + int(nt["srcrank_in_expert_offset"][i]) \
+                + int(nt["r_in_srcrank_offset"][i])
+            p, s, t3 = windows[src]
+            recv_x[dst:dst + c] = p[so:so + c]
+            if quant:
+                recv_s[dst:dst + c] = s[so:so + c]
+            recv_t[dst:dst + c] = t3[so:so + c]
+        per_e = nt["recv_tokens_per_expert"].astype(np.int64)
+        lst = (np.cumsum(per_e) if expert_token_nums_type == 0 else per_e).tolist()
+        out.append(DispatchResult(recv_x, recv_s, recv_t.reshape(-1), [int(v) for v in lst],
+                                  nt["recv_count"].copy(), R, layouts[me], nt))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# A4 / A6  combine (normal and low-latency share the arithmetic)
+# --------------------------------------------------------------------------------------
+def weighted_reduce(rows_f32_by_k: np.ndarray, valid: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """acc = 0; for k ascending, valid only: acc = acc + (float(row_k) * w_k) with a separate fp32
+    multiply and fp32 add (no FMA), then bf16 round-to-nearest-even.
+    Reference: cam_moe_combine_normal.h:372-396 (Muls, Add, Cast CAST_RINT);
+    moe_distribute_combine_v2.h:1102-1130,1192-1218,1252.
+    rows_f32_by_k [T,K,H] f32, valid [T,K] bool, w [T,K] f32 -> bf16 bits [T,H]."""
+    T, K, H = rows_f32_by_k.shape
+    acc = np.zeros((T, H), np.float32)
+    for k in range(K):
+        prod = (rows_f32_by_k[:, k, :] * w[:, k].astype(np.float32)[:, None]).astype(np.float32)
+        acc = np.where(valid[:, k][:, None], (acc + prod).astype(np.float32), acc)
+    return f32_to_bf16_bits_rne(acc)
+
+
+def combine(xs_bits: Sequence[np.ndarray], src_idx: Sequence[np.ndarray], total_rows: Sequence[int],
+            topk_idxs: Sequence[np.ndarray], topk_weights: Sequence[Optional[np.ndarray]],
+            num_experts: int) -> List[np.ndarray]:
+    """All ranks' combine.  xs_bits[r] = expert-side rows [R_r, H] bf16 bits in dispatch order,
+    src_idx[r] = the (src_rank, token, k) triples dispatch produced, total_rows[r] = R_r
+    (= send_head[E-1], cam_moe_combine_normal.h:225).  topk_idxs / topk_weights are the ORIGINAL
+    tensors of each source rank (handle[6], handle[7]; `combine(topk_weights=...)` is ignored by the
+    reference, normal_strategy.py:407-420; None -> ones, deep_ep.cpp:568-572).
+
+    Expert side pushes row r to rank `src`, slot t*K+k (cam_moe_combine_normal.h:291-321); the
+    owner reduces the K slots of a token (weighted_reduce)."""
+    W = len(xs_bits)
+    H = int(xs_bits[0].shape[1])
+    E = int(num_experts)
+    slots = []
+    for r in range(W):
+        T, K = topk_idxs[r].shape
+        slots.append(np.zeros((T * K, H), np.uint16))
+    for r in range(W):
+        n = int(total_rows[r])
+        if n == 0:
+            continue
+        tri = np.asarray(src_idx[r], np.int32).reshape(-1, 3)[:n]
+        x = np.ascontiguousarray(xs_bits[r]).view(np.uint16)[:n]
+        for src in range(W):
+            m = tri[:, 0] == src
+            if not m.any():
+                continue
+            K = topk_idxs[src].shape[1]
+            slots[src][tri[m, 1].astype(np.int64) * K + tri[m, 2]] = x[m]
+    out = []
+    for r in range(W):
+        ti = np.asarray(topk_idxs[r], np.int64)
+        T, K = ti.shape
+        w = np.ones((T, K), np.float32) if topk_weights[r] is None else np.asarray(topk_weights[r], np.float32)
+        valid = (ti >= 0) & (ti < E)
+        rows = bf16_bits_to_f32(slots[r]).reshape(T, K, H)
+        out.append(weighted_reduce(rows, valid, w))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# A5  low-latency dispatch
+# --------------------------------------------------------------------------------------
+@dataclass
+class LLDispatchResult:
+    packed_recv_x: np.ndarray            # [M, H] int8 / bf16 bits; rows >= total are unspecified (0 here)
+    packed_recv_x_scales: Optional[np.ndarray]  # [M] f32
+    packed_recv_count: np.ndarray        # [L] int64
+    src_info: np.ndarray                 # [3*total] meaningful prefix of the triples
+    layout_range: np.ndarray             # [L*W] i32 inclusive cumsum over idx i
+    total: int
+
+
+def low_latency_dispatch(xs_bits: Sequence[np.ndarray], topk_idxs: Sequence[np.ndarray],
+                         num_max_dispatch_tokens_per_rank: int, num_experts: int, quant: bool,
+                         expert_token_nums_type: int = 1) -> List[LLDispatchResult]:
+    """Reference: host csrc/deepep/deep_ep.cpp:850-1012; kernel moe_distribute_dispatch_v2.h
+      sender :607-696   position among earlier (row-major) pairs of the same expert; row goes to the
+                        destination rank's window region (src_rank, le) at that position
+      counts :918-960   per (le, src) count + flag
+      receiver :1253-1309  cumsum over idx i = le*W+src, rows packed back-to-back in that order;
+                        layout_range (epRecvCounts) = inclusive cumsum; triples -> src_info
+      counts out :1415-1455  packed_recv_count[le] = count (type 1) or cumulative (type 0), int64
+    Output capacity M = W * max_tokens * min(K, L) (deep_ep.cpp:867-873).  INT8 quantisation as
+    quant_int8_rows(eps=None)."""
+    W = len(xs_bits)
+    E = int(num_experts)
+    L = E // W
+    H = int(xs_bits[0].shape[1])
+    K = int(topk_idxs[0].shape[1])
+    M = W * int(num_max_dispatch_tokens_per_rank) * min(K, L)
+    layouts = [dispatch_layout(np.asarray(topk_idxs[r], np.int64), E, W) for r in range(W)]
+    cnt = np.stack([l["num_tokens_per_expert"] for l in layouts]).astype(np.int64)
+    pre = []
+    for r in range(W):
+        x = np.ascontiguousarray(xs_bits[r]).view(np.uint16)
+        pre.append(quant_int8_rows(x, None) if quant else (x, None))
+    out = []
+    for me in range(W):
+        rx = np.zeros((M, H), np.int8 if quant else np.uint16)
+        rs = np.zeros(M, np.float32) if quant else None
+        tri = []
+        rng = np.zeros(L * W, np.int32)
+        pos = 0
+        for le in range(L):
+            e = me * L + le
+            for src in range(W):
+                ti = np.asarray(topk_idxs[src], np.int64)
+                tt, kk = np.nonzero(ti == e)     # row-major order == sender position order
+                c = tt.size
+                assert c == int(cnt[src, e])
+                if c:
+                    rx[pos:pos + c] = pre[src][0][tt]
+                    if quant:
+                        rs[pos:pos + c] = pre[src][1][tt]
+                    tri.append(np.stack([np.full(c, src, np.int32), tt.astype(np.int32), kk.astype(np.int32)], 1))
+                pos += c
+                rng[le * W + src] = pos
+        per_e = cnt[:, me * L:(me + 1) * L].sum(axis=0)
+        prc = (np.cumsum(per_e) if expert_token_nums_type == 0 else per_e).astype(np.int64)
+        src_info = np.concatenate(tri).reshape(-1) if tri else np.zeros(0, np.int32)
+        out.append(LLDispatchResult(rx, rs, prc, src_info, rng, pos))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# closed-form goldens asserted by the reference tests (used to pin this oracle)
+# --------------------------------------------------------------------------------------
+def golden_combined(x_bits: np.ndarray, topk_idx: np.ndarray, topk_weights: np.ndarray) -> np.ndarray:
+    """tests/python/deepep/test_intranode.py:431-436: x * sum_k w[k] * [topk_idx[k] != -1] (float)."""
+    w = np.where(np.asarray(topk_idx) == -1, 0.0, np.asarray(topk_weights, np.float32)).sum(axis=1)
+    return bf16_bits_to_f32(x_bits) * w.astype(np.float32)[:, None]
+
+
+def calc_diff(x: np.ndarray, y: np.ndarray) -> float:
+    """tests/python/deepep/utils.py:191-195."""
+    x = x.astype(np.float64) + 1
+    y = y.astype(np.float64) + 1
+    return float(1 - 2 * (x * y).sum() / (x * x + y * y).sum())

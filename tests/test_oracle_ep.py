@@ -1,0 +1,187 @@
+"""Pins the CPU oracle (oracle/ep.py) against the closed-form goldens the reference's own
+tests assert.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ep
+from oracle.bf16 import bf16_bits_to_f32, f32_to_bf16_bits_rne, torch_to_bits, bits_to_torch
+
+
+def make_topk(rng, T, K, E, drop=0.0):
+    scores = np.abs(rng.standard_normal((T, E))) + 1
+    idx = np.argsort(-scores, axis=1)[:, :K].astype(np.int64)
+    if drop > 0:
+        idx[rng.random((T, K)) < drop] = -1
+    return idx
+
+
+def ref_test_layout_golden(topk_idx, num_experts, num_ranks):
+    """Restates the golden built in tests/python/deepep/test_intranode.py:152-154,188-222
+    (rank_idx + inplace_unique from utils.py:43-55) with torch ops on CPU."""
+    t = torch.from_numpy(topk_idx)
+    T, K = t.shape
+    L = num_experts // num_ranks
+    rank_idx = t // L
+    rank_idx.masked_fill_(t == -1, -1)
+    # inplace_unique
+    x = rank_idx
+    mask = x < 0
+    x_padded = x.masked_fill(mask, num_ranks)
+    bin_count = torch.zeros((T, num_ranks + 1), dtype=x.dtype)
+    bin_count.scatter_add_(1, x_padded, torch.ones_like(x_padded))
+    bin_count = bin_count[:, :num_ranks]
+    sorted_bin_count, sorted_bin_idx = torch.sort(bin_count, dim=-1, descending=True)
+    sorted_bin_idx.masked_fill_(sorted_bin_count == 0, -1)
+    sorted_bin_idx = torch.sort(sorted_bin_idx, descending=True, dim=-1).values
+    x[:, :].fill_(-1)
+    valid_len = min(num_ranks, K)
+    x[:, :valid_len] = sorted_bin_idx[:, :valid_len]
+    per_e = torch.stack([(t == e).sum() for e in range(num_experts)]).to(torch.int)
+    per_r = torch.empty(num_ranks, dtype=torch.int)
+    tir = torch.full((num_ranks, T), -1, dtype=torch.long)
+    for i in range(num_ranks):
+        sel = (rank_idx == i).max(dim=-1)[0]
+        ind = torch.nonzero(sel, as_tuple=True)[0]
+        per_r[i] = ind.numel()
+        if ind.numel():
+            tir[i][ind] = torch.arange(ind.numel())
+    is_in = (tir.T.contiguous() >= 0).to(torch.int)
+    return per_r.numpy(), per_e.numpy(), is_in.numpy()
+
+
+@pytest.mark.parametrize("T,K,E,W,drop", [(1, 1, 2, 2, 0), (4, 2, 8, 2, 0), (33, 8, 64, 8, 0.3),
+                                          (256, 2, 8, 1, 0), (257, 8, 256, 8, 0.1), (0, 4, 16, 4, 0)])
+def test_layout_vs_reference_test_golden(T, K, E, W, drop):
+    rng = np.random.default_rng(T * 7 + K)
+    idx = make_topk(rng, T, K, E, drop) if T else np.zeros((0, K), np.int64)
+    got = ep.dispatch_layout(idx, E, W)
+    slow = ep.dispatch_layout_loops(idx, E, W)
+    for k in got:
+        assert np.array_equal(got[k], slow[k]), k
+    if T and K <= W:   # the reference golden's inplace_unique keeps at most min(W, K) ranks per token
+        per_r, per_e, is_in = ref_test_layout_golden(idx.copy(), E, W)
+        assert np.array_equal(got["num_tokens_per_rank"], per_r)
+        assert np.array_equal(got["num_tokens_per_expert"], per_e)
+        assert np.array_equal(got["is_token_in_rank"], is_in)
+
+
+def _rand_bf16(rng, shape):
+    return f32_to_bf16_bits_rne(rng.standard_normal(shape).astype(np.float32))
+
+
+@pytest.mark.parametrize("W,T,H,K,E,quant,drop", [
+    (1, 256, 1024, 2, 8, False, 0.0),      # BASELINE C1 shape
+    (2, 33, 128, 2, 4, True, 0.0),
+    (4, 64, 256, 8, 32, True, 0.2),
+    (8, 40, 128, 8, 64, False, 0.3),
+    (8, 17, 128, 4, 8, True, 0.0),
+])
+def test_dispatch_combine_closed_form(W, T, H, K, E, quant, drop):
+    rng = np.random.default_rng(1234)
+    xs = [_rand_bf16(rng, (T + r, H)) for r in range(W)]           # ragged token counts
+    idxs = [make_topk(rng, T + r, K, E, drop) for r in range(W)]
+    ws = [np.abs(rng.standard_normal((T + r, K))).astype(np.float32) for r in range(W)]
+    res = ep.normal_dispatch(xs, idxs, E, quant)
+    L = E // W
+    # (3) per-expert recv counts == all-reduced histogram (test_intranode.py:401-411)
+    gbl = sum(np.bincount(i[i >= 0].ravel(), minlength=E) for i in idxs)
+    for r in range(W):
+        assert res[r].num_recv_tokens_per_expert_list == gbl[r * L:(r + 1) * L].tolist()
+        assert res[r].total_recv == int(gbl[r * L:(r + 1) * L].sum())
+        assert res[r].send_head[-1] == res[r].total_recv
+    # expert side = identity (per_token_cast_back for int8), then combine
+    ys = []
+    for r in range(W):
+        n = res[r].total_recv
+        if quant:
+            ys.append(ep.per_token_cast_back(res[r].recv_x[:max(n, 1)], res[r].recv_x_scales[:max(n, 1)]))
+        else:
+            ys.append(res[r].recv_x)
+    comb = ep.combine(ys, [r_.recv_src_idx for r_ in res], [r_.total_recv for r_ in res], idxs, ws, E)
+    for r in range(W):
+        golden = ep.golden_combined(xs[r], idxs[r], ws[r])
+        d = ep.calc_diff(bf16_bits_to_f32(comb[r]), golden)
+        assert d < (3e-3 if quant else 1e-5), d   # tests/python/deepep/utils.py:198-215
+    # ordering contract: rows sorted by (local expert, src rank, source row-major order)
+    for r in range(W):
+        tri = res[r].recv_src_idx.reshape(-1, 3)[:res[r].total_recv]
+        e_of = np.array([idxs[s][t, k] for s, t, k in tri], dtype=np.int64)
+        key = (e_of - r * L) * (W * 10 ** 7) + tri[:, 0].astype(np.int64) * 10 ** 7 + tri[:, 1] * 32 + tri[:, 2]
+        assert np.all(np.diff(key) > 0)
+
+
+def test_dispatch_integer_routing_is_exact_for_rank_constant_inputs():
+    """tests/python/deepep/test_intranode.py:256 uses x = rank so routing errors show as integer
+    mismatches: every received row must carry the source rank's constant."""
+    W, T, H, K, E = 4, 32, 64, 4, 16
+    rng = np.random.default_rng(0)
+    xs = [f32_to_bf16_bits_rne(np.full((T, H), float(r), np.float32)) for r in range(W)]
+    idxs = [make_topk(rng, T, K, E) for _ in range(W)]
+    res = ep.normal_dispatch(xs, idxs, E, quant=False)
+    for r in range(W):
+        tri = res[r].recv_src_idx.reshape(-1, 3)[:res[r].total_recv]
+        vals = bf16_bits_to_f32(res[r].recv_x[:res[r].total_recv])
+        assert np.array_equal(vals[:, 0], tri[:, 0].astype(np.float32))
+
+
+def test_quant_int8_known_answers():
+    # hand-checked vectors: amax=2 -> s = 63.5; 0.5*63.5 = 31.75 -> 32; ties to even: 2.5 -> 2
+    x = np.array([[2.0, -2.0, 0.5, 1.0, 0.0, -0.25]], np.float32)
+    q, s = ep.quant_int8_rows(f32_to_bf16_bits_rne(x), 1e-12)
+    assert q.tolist() == [[127, -127, 32, 64, 0, -16]]
+    assert s[0] == np.float32(1.0) / (np.float32(127.0) / (np.float32(2.0) + np.float32(1e-12)))
+    x = np.array([[127.0, 2.5, 3.5, -2.5, 0.5, 1.5]], np.float32)       # s == 1 exactly
+    q, _ = ep.quant_int8_rows(f32_to_bf16_bits_rne(x), 1e-12)
+    assert q.tolist() == [[127, 2, 4, -2, 0, 2]]
+    q, s = ep.quant_int8_rows(np.zeros((1, 8), np.uint16), 1e-12)       # all-zero row
+    assert not q.any() and np.isfinite(s[0])
+    q, s = ep.quant_int8_rows(np.zeros((1, 8), np.uint16), None)        # LL: defined as zeros
+    assert not q.any() and s[0] == 0
+
+
+def test_cast_back_matches_torch():
+    rng = np.random.default_rng(5)
+    q = rng.integers(-127, 128, (7, 256)).astype(np.int8)
+    s = rng.random(7).astype(np.float32)
+    want = (torch.from_numpy(q).float().view(7, -1, 128) * torch.from_numpy(s).view(7, -1, 1)).view(7, 256).to(torch.bfloat16)
+    assert np.array_equal(ep.per_token_cast_back(q, s), torch_to_bits(want))
+
+
+def test_bf16_helpers_match_torch():
+    rng = np.random.default_rng(9)
+    f = (rng.standard_normal(10000) * 10.0 ** rng.integers(-20, 20, 10000)).astype(np.float32)
+    assert np.array_equal(f32_to_bf16_bits_rne(f), torch_to_bits(torch.from_numpy(f).to(torch.bfloat16)))
+    b = rng.integers(0, 65536, 10000).astype(np.uint16)
+    a = bf16_bits_to_f32(b)
+    t = bits_to_torch(b).float().numpy()
+    assert np.array_equal(a.view(np.uint32), t.view(np.uint32))
+
+
+@pytest.mark.parametrize("W,T,K,E,quant,drop", [(2, 16, 2, 8, True, 0.0), (8, 128, 8, 64, True, 0.3),
+                                                (4, 1, 4, 16, False, 0.0)])
+def test_low_latency_dispatch_contract(W, T, K, E, quant, drop):
+    H = 128
+    rng = np.random.default_rng(77)
+    xs = [_rand_bf16(rng, (T, H)) for _ in range(W)]
+    idxs = [make_topk(rng, T, K, E, drop) for _ in range(W)]
+    ws = [np.abs(rng.standard_normal((T, K))).astype(np.float32) for _ in range(W)]
+    res = ep.low_latency_dispatch(xs, idxs, T, E, quant)
+    L = E // W
+    allidx = np.concatenate(idxs)
+    for r in range(W):
+        # test_low_latency.py:186-192 per-expert recv counts vs all-gathered topk_idx
+        want = [(allidx == r * L + le).sum() for le in range(L)]
+        assert res[r].packed_recv_count.tolist() == want
+        # :178-189 cumsum relation of layout_range
+        assert res[r].layout_range[-1] == sum(want)
+        assert np.all(np.diff(np.concatenate([[0], res[r].layout_range])) >= 0)
+    ys = [ep.per_token_cast_back(r_.packed_recv_x, r_.packed_recv_x_scales) if quant else r_.packed_recv_x
+          for r_ in res]
+    comb = ep.combine(ys, [r_.src_info for r_ in res], [r_.total for r_ in res], idxs, ws, E)
+    for r in range(W):
+        d = ep.calc_diff(bf16_bits_to_f32(comb[r]), ep.golden_combined(xs[r], idxs[r], ws[r]))
+        assert d < (3e-3 if quant else 1e-5)
+    # determinism (test_low_latency.py:448-484): identical inputs -> identical bytes
+    res2 = ep.low_latency_dispatch(xs, idxs, T, E, quant)
+    assert all(np.array_equal(a.packed_recv_x, b.packed_recv_x) for a, b in zip(res, res2))
