@@ -1,0 +1,158 @@
+/*
+ * mi_ep.h -- C-ABI of the MI355X (gfx950) expert-parallel dispatch/combine kernels.
+ *
+ * This is the drop-in boundary that replaces the reference's device-operator layer
+ * (sgl-kernel-npu, Ascend `aclnn*` two-phase C API):
+ *
+ *   mi_ep_dispatch_layout      <- aclnnDispatchLayout        csrc/deepep/ops/op_host/op_api/aclnn_dispatch_layout.h:29-41
+ *                                 (kernel csrc/deepep/ops/op_kernel/dispatch_layout.h:81-219)
+ *   mi_ep_notify_post/_wait,
+ *   mi_ep_notify_tables        <- aclnnNotifyDispatch        csrc/deepep/ops/op_host/op_api/aclnn_notify_dispatch.h:36-52
+ *                                 (kernel csrc/deepep/ops/op_kernel/notify_dispatch.h:110-132)
+ *   mi_ep_dispatch_stage,
+ *   mi_ep_dispatch_pull        <- aclnnCamMoeDispatchNormal  csrc/deepep/ops/op_host/op_api/aclnn_cam_moe_dispatch_normal.h:10-21
+ *                                 (kernel csrc/deepep/ops/op_kernel/cam_moe_dispatch_normal.h:764-783)
+ *   mi_ep_combine_push,
+ *   mi_ep_combine_reduce       <- aclnnCamMoeCombineNormal   csrc/deepep/ops/op_host/op_api/aclnn_cam_moe_combine_normal.h:30-45
+ *                                 (kernel csrc/deepep/ops/op_kernel/cam_moe_combine_normal.h:446-452)
+ *                                 and aclnnMoeLowLatencyCombineV2 (csrc/deepep/deep_ep.cpp:1080)
+ *   mi_ep_ll_dispatch_send,
+ *   mi_ep_ll_dispatch_recv     <- aclnnMoeLowLatencyDispatchV2 csrc/deepep/deep_ep.cpp:983
+ *                                 (kernel csrc/deepep/ops/op_kernel/moe_distribute_dispatch_v2.h:1477-1490)
+ *   mi_ep_signal / mi_ep_wait  <- the window flag protocol   csrc/deepep/ops/op_kernel/cam_moe_dispatch_normal.h:496-502,584-631
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every pointer is a DEVICE pointer
+ * unless its name ends in `_host`.  Every call only enqueues work on `stream` (a hipStream_t passed
+ * as void*), never allocates, never synchronises and never throws.  Return value: 0 = enqueued,
+ * negative = MI_EP_E* argument / launch error (nothing enqueued).
+ *
+ * Cross-rank data movement is one-sided through "windows": every rank owns a buffer that all
+ * peers can address (hipIpc-mapped over xGMI, or plain pointers when several ranks live in one
+ * process).  A kernel never spins on a peer inside a data-moving launch: hand-offs are
+ * post-kernel -> mi_ep_signal -> (peer) mi_ep_wait -> consume-kernel, so kernel boundaries carry the
+ * release/acquire and only the 8-byte flag words need system-scope atomics.
+ */
+#ifndef MI_EP_H_
+#define MI_EP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_EP_MAX_RANKS 64
+#define MI_EP_MAX_TOPK 16
+#define MI_EP_MAX_HIDDEN 8192 /* reference limit, cam_moe_dispatch_normal_tiling.cc:75-87 */
+#define MI_EP_ROW_META_BYTES 16 /* {f32 scale, i32 token, i32 k, i32 src_rank} appended to every staged row */
+
+#define MI_EP_OK 0
+#define MI_EP_EINVAL (-1)
+#define MI_EP_ELAUNCH (-2)
+
+/* payload modes of the dispatch kernels */
+#define MI_EP_QUANT_NONE 0      /* bf16 rows */
+#define MI_EP_QUANT_INT8 1      /* s = 127/(amax + 1e-12)   (normal mode, cam_moe_dispatch_normal.h:326-363) */
+#define MI_EP_QUANT_INT8_NOEPS 2 /* s = 127/amax             (low-latency, moe_distribute_dispatch_v2.h:1006-1033) */
+
+/* library / build identification ("gfx950") */
+const char *mi_ep_version(void);
+
+/* bytes of one staged dispatch row: hidden * (1 or 2) + MI_EP_ROW_META_BYTES */
+size_t mi_ep_dispatch_row_bytes(int hidden, int quant_mode);
+/* bytes of one combine slot row: hidden * 2 rounded up to 16 */
+size_t mi_ep_combine_row_bytes(int hidden);
+
+/* ---- A1 layout ------------------------------------------------------------------------------
+ * topk_idx [T,K] int64 (ids < 0 or >= E are "no selection").  Outputs (int32):
+ *   num_tokens_per_rank [W], num_tokens_per_expert [E], is_token_in_rank [T,W],
+ *   send_token_idx_small [T,K]  (rank of the pair among earlier row-major pairs of the same expert; 0 at invalid ids),
+ *   send_data_offset [E]        (exclusive prefix of num_tokens_per_expert; reference notify_dispatch.h:185-198).
+ * workspace: mi_ep_dispatch_layout_workspace(T,K,E) bytes, contents irrelevant.  idx_is_i32 != 0: topk_idx is int32. */
+size_t mi_ep_dispatch_layout_workspace(int num_tokens, int num_topk, int num_experts);
+int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int num_tokens, int num_topk, int num_experts,
+                          int num_ranks, int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
+                          int32_t *is_token_in_rank, int32_t *send_token_idx_small, int32_t *send_data_offset,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- flags ----------------------------------------------------------------------------------
+ * Each rank owns `uint64_t flags[nslots]`; slot s of rank d is written only by rank s.
+ * mi_ep_signal: for every d < W store `epoch` into peer_flags[d][my_rank] (system-scope release).
+ * mi_ep_wait:   spin until my_flags[s] >= epoch for all s < W (system-scope), at most timeout_ms;
+ *               on timeout status[0] = 1 + first late slot and the kernel returns (never hangs). */
+int mi_ep_signal(uint64_t *const *peer_flags_host, int num_ranks, int my_rank, uint64_t epoch, void *stream);
+int mi_ep_wait(const uint64_t *my_flags, int num_ranks, uint64_t epoch, int32_t *status, int timeout_ms,
+               void *stream);
+
+/* ---- A2 notify ------------------------------------------------------------------------------
+ * Counts all-gather through windows.  Every rank owns `uint64_t notify[W][E+1]` granules
+ * {epoch << 32 | value}; post writes row `my_rank` of every peer (E counts + its token count T),
+ * wait sweeps all W*(E+1) granules until every tag == epoch and emits cnt_matrix [W, E+1] int32. */
+int mi_ep_notify_post(uint64_t *const *peer_notify_host, int num_ranks, int my_rank, int num_experts,
+                      const int32_t *num_tokens_per_expert, int num_tokens, uint32_t epoch, void *stream);
+int mi_ep_notify_wait(const uint64_t *my_notify, int num_ranks, int num_experts, uint32_t epoch,
+                      int32_t *cnt_matrix, int32_t *status, int timeout_ms, void *stream);
+/* Derived tables of rank `my_rank` from cnt_matrix [W, E+1] (last column = that rank's token count).
+ * All int32: recv_count [L*W] (inclusive cumsum over i = le*W+src), recv_offset [L*W] (sender's
+ * exclusive prefix), recv_tokens_per_expert [L], expert_global_offset [L], srcrank_in_expert_offset [L*W],
+ * r_in_srcrank_offset [L*W] (zeros: round 1), total_recv_token [1], max_bs [1].
+ * pull_offset [L*W]: row offset the pull kernel adds to src_base[src]; == recv_offset when
+ * relative_pull == 0, recv_offset - send_prefix_src[my_rank*L] when relative_pull != 0 (per-source
+ * contiguous staging, RCCL transport).  summary_host (may be NULL): pinned host int32[2 + L] =
+ * {total_recv, max_bs, recv_tokens_per_expert...}, written with system scope so the host can poll it. */
+int mi_ep_notify_tables(const int32_t *cnt_matrix, int num_ranks, int num_experts, int my_rank,
+                        int relative_pull, int32_t *recv_count, int32_t *recv_offset,
+                        int32_t *recv_tokens_per_expert, int32_t *expert_global_offset,
+                        int32_t *srcrank_in_expert_offset, int32_t *r_in_srcrank_offset,
+                        int32_t *total_recv_token, int32_t *max_bs, int32_t *pull_offset,
+                        int32_t *summary_host, void *stream);
+
+/* ---- A3 normal dispatch -----------------------------------------------------------------------
+ * stage: quantise (per mode) every token once and write one row per valid (t,k) into `rows`
+ *   (the rank's own send window) at slot send_data_offset[e] + send_token_idx_small[t,k];
+ *   row = payload | {scale, t, k, my_rank}.  x [T,H] bf16, topk_idx [T,K] int64/int32.
+ * pull: for every output row r < total (= recv_count[L*W-1], read on device): find segment i,
+ *   copy row pull_offset[i] + j of src_base[src] into recv_x[r] / recv_x_scales[r] / recv_src_idx[3r..].
+ *   `rows_hint` only sizes the grid (>= total).  recv_x_scales may be NULL for bf16. */
+int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                         const int32_t *send_data_offset, int num_tokens, int num_topk, int hidden,
+                         int num_experts, int my_rank, int quant_mode, void *rows, void *stream);
+int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset,
+                        int num_ranks, int num_local_experts, int hidden, int quant_mode, int rows_hint,
+                        void *recv_x, float *recv_x_scales, int32_t *recv_src_idx, void *stream);
+
+/* ---- A4/A6 combine ---------------------------------------------------------------------------
+ * push: row r < total (= *total_rows_dev if non-NULL else rows_hint) of x [R,H] bf16 with triple
+ *   (src, t, k) = src_idx[3r..3r+2] is copied to dst_base[src] + (t*K + k) * mi_ep_combine_row_bytes(H).
+ * reduce: out[t] = bf16_rne( sum_{k asc, 0 <= idx[t,k] < E} float(slot[t*K+k]) * w[t,k] ) with separate fp32
+ *   multiply and add (cam_moe_combine_normal.h:372-396).  topk_weights NULL -> ones. */
+int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
+                       int hidden, int num_topk, void *const *dst_base_host, int num_ranks, void *stream);
+int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
+                         int num_tokens, int num_topk, int hidden, int num_experts, void *out, void *stream);
+
+/* ---- A5 low-latency dispatch -------------------------------------------------------------------
+ * Window of a rank: rows [L][W][max_tokens] of mi_ep_dispatch_row_bytes(), counts granules
+ * uint64 [L*W] {epoch<<32|count}.
+ * send: quantise + write the row of every valid (t,k) straight into the destination rank's region
+ *   (le, my_rank) at position send_token_idx_small[t,k].
+ * post_counts: after `send` (stream order) publish count[le][my_rank] granules to every destination.
+ * recv: sweep my L*W granules (bounded spin) -> layout_range [L*W] inclusive cumsum, packed_recv_count [L]
+ *   int64 (count, or cumulative when count_type == 0), then compact window rows into packed_recv_x /
+ *   packed_recv_x_scales / src_info triples in idx-i order. */
+int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                           int num_tokens, int num_topk, int hidden, int num_experts, int num_ranks, int my_rank,
+                           int max_tokens, int quant_mode, void *const *peer_rows_host, void *stream);
+int mi_ep_ll_post_counts(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int num_experts,
+                         int num_ranks, int my_rank, uint32_t epoch, void *stream);
+int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint32_t epoch, int num_ranks,
+                           int num_local_experts, int max_tokens, int hidden, int quant_mode, int count_type,
+                           void *packed_recv_x, float *packed_recv_x_scales, int64_t *packed_recv_count,
+                           int32_t *src_info, int32_t *layout_range, int32_t *status, int timeout_ms,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_EP_H_ */

@@ -1,0 +1,159 @@
+// A4 / A6 combine for gfx950: push (expert side writes each BF16 row into the source rank's slot
+// t*K+k) and reduce (owner: fp32 weighted sum of the K slots of a token, k ascending, -> bf16).
+// Replaces aclnnCamMoeCombineNormal / aclnnMoeLowLatencyCombineV2 (reference kernels
+// csrc/deepep/ops/op_kernel/cam_moe_combine_normal.h:291-321 (push), :359-400 (weighted sum);
+// csrc/deepep/ops/op_kernel/moe_distribute_combine_v2.h:818-851,1102-1256).
+//
+// MI355X design: one wave64 per row for the push (16-B/lane stores, 8 in flight per lane; rows are in
+// (local expert, src rank) order so consecutive workgroups target different peers / xGMI links);
+// the reduce gives each wave a (token, 512-element segment) tile: K x 16-B loads in flight per lane,
+// separate v_mul_f32 / v_add_f32 (file is built with -ffp-contract=off) to reproduce the reference's
+// Muls + Add ordering bit for bit.  Per-rank HBM traffic: push R*2H read + R*2H write, reduce
+// T*K*2H read + T*2H write.
+#include "ep_common.h"
+
+namespace mi_ep {
+
+constexpr int kPushWaves = 4;
+constexpr int kPushRowsPerWave = 2;
+
+__global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
+    const uint8_t *__restrict__ x, const int32_t *__restrict__ src_idx, const int32_t *__restrict__ total_dev,
+    int rows_hint, int row_bytes /*2H*/, size_t slot_stride, int K, int W, PeerPtrs dsts)
+{
+    const int total = total_dev ? *total_dev : rows_hint;
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    const int n16 = row_bytes / 16;
+    const long long rows_per_block = kPushWaves * kPushRowsPerWave;
+    for (long long r0 = (long long)blockIdx.x * rows_per_block; r0 < total; r0 += (long long)gridDim.x * rows_per_block) {
+#pragma unroll 1
+        for (int rr = 0; rr < kPushRowsPerWave; ++rr) {
+            const long long r = r0 + wave * kPushRowsPerWave + rr;
+            if (r >= total) break;
+            const int src = src_idx[r * 3 + 0];
+            const int t = src_idx[r * 3 + 1];
+            const int k = src_idx[r * 3 + 2];
+            if (src < 0 || src >= W) continue;        // corrupted handle: drop instead of a wild store
+            const u32x4 *s16 = (const u32x4 *)(x + (size_t)r * row_bytes);
+            u32x4 *d16 = (u32x4 *)((uint8_t *)dsts.p[src] + ((size_t)t * K + k) * slot_stride);
+            for (int base = 0; base < n16; base += kWave * 8) {
+                u32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * kWave + lane;
+                    if (item < n16) v[u] = __builtin_nontemporal_load(s16 + item);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * kWave + lane;
+                    if (item < n16) d16[item] = v[u];
+                }
+            }
+        }
+    }
+}
+
+template <bool I32>
+__global__ __launch_bounds__(256) void combine_reduce_kernel(
+    const uint8_t *__restrict__ slots, size_t slot_stride, const void *__restrict__ topk_idx,
+    const float *__restrict__ topk_w, int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out)
+{
+    const int lane = lane_id();
+    const long long wid = (long long)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const long long t = wid / segs_per_token;
+    const int seg0 = (int)(wid % segs_per_token);
+    if (t >= T) return;
+    // routing + weights of this token (lane k < K)
+    float w_l = 0.f;
+    bool valid_l = false;
+    if (lane < K) {
+        long long e = I32 ? (long long)((const int32_t *)topk_idx)[t * K + lane] : ((const long long *)topk_idx)[t * K + lane];
+        valid_l = (e >= 0 && e < E);
+        w_l = topk_w ? topk_w[t * K + lane] : 1.0f;
+    }
+    const unsigned long long vmask = __ballot(valid_l);
+    float w[MI_EP_MAX_TOPK];
+#pragma unroll
+    for (int k = 0; k < MI_EP_MAX_TOPK; ++k) w[k] = __shfl(w_l, k, kWave);
+    const int nchunks = H / 8;          // 16-B chunks of 8 bf16
+    for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) {
+        u32x4 v[MI_EP_MAX_TOPK];
+#pragma unroll
+        for (int k = 0; k < MI_EP_MAX_TOPK; ++k)
+            if (k < K && ((vmask >> k) & 1ull))
+                v[k] = *(const u32x4 *)(slots + ((size_t)t * K + k) * slot_stride + (size_t)c * 16);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < MI_EP_MAX_TOPK; ++k) {
+            if (k < K && ((vmask >> k) & 1ull)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = bf16_to_f32(v[k][j] & 0xFFFFu) * w[k];
+                    const float hi = __uint_as_float(v[k][j] & 0xFFFF0000u) * w[k];
+                    acc[2 * j] = acc[2 * j] + lo;
+                    acc[2 * j + 1] = acc[2 * j + 1] + hi;
+                }
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16_rne(acc[2 * j]) | (f32_to_bf16_rne(acc[2 * j + 1]) << 16);
+        *(u32x4 *)(out + (size_t)t * H + (size_t)c * 8) = o;
+    }
+}
+
+}  // namespace mi_ep
+
+using namespace mi_ep;
+
+extern "C" size_t mi_ep_combine_row_bytes(int hidden) { return ((size_t)hidden * 2 + 15) / 16 * 16; }
+
+extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
+                                  int H, int K, void *const *dst_base_host, int W, void *stream)
+{
+    if (H <= 0 || H % 8 || K <= 0 || K > MI_EP_MAX_TOPK || W <= 0 || W > MI_EP_MAX_RANKS || !dst_base_host)
+        return MI_EP_EINVAL;
+    if (rows_hint <= 0) return MI_EP_OK;
+    if (!x || !src_idx) return MI_EP_EINVAL;
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) {
+        if (!dst_base_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = dst_base_host[i];
+    }
+    const int rpb = kPushWaves * kPushRowsPerWave;
+    long long blocks = ((long long)rows_hint + rpb - 1) / rpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    combine_push_kernel<<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
+        (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp);
+    return launch_status();
+}
+
+extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
+                                    int T, int K, int H, int E, void *out, void *stream)
+{
+    if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 8 || E <= 0) return MI_EP_EINVAL;
+    if (T == 0) return MI_EP_OK;
+    if (!slots || !topk_idx || !out) return MI_EP_EINVAL;
+    const int nchunks = H / 8;
+    const int max_segs = (nchunks + kWave - 1) / kWave;
+    // enough waves to fill 256 CUs x 8 waves even for decode-size T
+    int segs = 1;
+    while (segs < max_segs && (long long)T * segs < 2048) segs <<= 1;
+    if (segs > max_segs) segs = max_segs;
+    const long long waves = (long long)T * segs;
+    const int wpb = 4;
+    const long long blocks = (waves + wpb - 1) / wpb;
+    hipStream_t s = (hipStream_t)stream;
+    if (idx_is_i32)
+        combine_reduce_kernel<true><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H),
+                                                                        topk_idx, topk_weights, T, K, H, E, segs,
+                                                                        (uint16_t *)out);
+    else
+        combine_reduce_kernel<false><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H),
+                                                                         topk_idx, topk_weights, T, K, H, E, segs,
+                                                                         (uint16_t *)out);
+    return launch_status();
+}

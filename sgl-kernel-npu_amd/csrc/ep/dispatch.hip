@@ -1,0 +1,445 @@
+// A3 normal dispatch for gfx950: stage (quantise + pack into the own send window) and pull
+// (receiver gathers its segments from every source's window straight into the output tensors).
+// Replaces aclnnCamMoeDispatchNormal (reference kernel csrc/deepep/ops/op_kernel/cam_moe_dispatch_normal.h:
+// QuantProcess :326-363, FillTriple :366-375, InputToShare :440-473, ShareToOutputLongSeq :717-760).
+//
+// MI355X design
+//  * one wave64 per token: the 14 KB bf16 row is read once with 16-B loads (all of it in flight at
+//    once, 56 VGPRs), |max| is a 6-step wave shuffle (no LDS, no barrier), the row is quantised once and
+//    the K copies are written as 16-B/lane stores (1 KiB per wave-instruction, fully coalesced) --
+//    the reference re-reads and re-quantises the row for every k;
+//  * every staged row carries its 16-byte meta {scale, token, k, src_rank} so one contiguous pull
+//    moves payload + scale + triple; rows are 16-B aligned (H % 16 == 0);
+//  * pull = one wave per output row, segment lookup by binary search in an LDS copy of recv_count;
+//    consecutive workgroups walk the (local expert, src rank) order, so all 7 xGMI links carry reads
+//    at the same time; 8 x 16 B per lane in flight.
+// HBM roofline (per rank, algorithmic): stage reads T*H*2 and writes n_pairs*(H+16); pull reads and
+// writes n_recv*(H+16).
+#include "ep_common.h"
+
+namespace mi_ep {
+
+constexpr int kStageWaves = 4;      // tokens per workgroup
+constexpr int kMaxItems = MI_EP_MAX_HIDDEN / 16 / kWave;   // 16-element items per lane (8)
+
+template <bool I32>
+__device__ __forceinline__ long long ld_idx(const void *p, long long i)
+{
+    if (I32) return (long long)((const int32_t *)p)[i];
+    return ((const long long *)p)[i];
+}
+
+// Where a (t,k) row goes.  Normal mode (L == 0): own send window (dsts.p[0]), slot = send_data_offset[e] +
+// send_token_idx_small (cam_moe_dispatch_normal.h:445-448).  Low-latency mode: the destination rank's window,
+// region (le, my_rank), position send_token_idx_small (moe_distribute_dispatch_v2.h:668-672).
+struct LLGeom {
+    int L, W, max_tokens;
+};
+__device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const int32_t *send_off, int my_rank,
+                                      int &slot, int &dst)
+{
+    if (ll.L == 0) {
+        slot = send_off[e] + small;
+        dst = 0;
+    } else {
+        dst = e / ll.L;
+        slot = ((e % ll.L) * ll.W + my_rank) * ll.max_tokens + small;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage, INT8: item = 16 consecutive elements = two 16-B loads -> one 16-B store
+// ---------------------------------------------------------------------------------------------
+template <bool I32, bool EPS>
+__global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
+    const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll)
+{
+    const int lane = lane_id();
+    const int t = blockIdx.x * kStageWaves + threadIdx.x / kWave;
+    if (t >= T) return;
+    const int nitems = H / 16;
+    const size_t stride = (size_t)H + MI_EP_ROW_META_BYTES;
+    // routing of this token: lane k < K owns pair (t,k)
+    long long e_l = -1;
+    int slot_l = 0, dst_l = 0;
+    if (lane < K) {
+        e_l = ld_idx<I32>(topk_idx, (long long)t * K + lane);
+        if (e_l >= 0 && e_l < E) route(ll, (int)e_l, idx_small[(long long)t * K + lane], send_off, my_rank, slot_l, dst_l);
+        else e_l = -1;
+    }
+    const unsigned long long vmask = __ballot(e_l >= 0);
+    if (vmask == 0ull) return;      // token selects nothing: no row is produced
+    const u32x4 *src = (const u32x4 *)(x + (size_t)t * H);
+    u32x4 raw[kMaxItems][2];
+    float amax = 0.f;
+#pragma unroll
+    for (int it = 0; it < kMaxItems; ++it) {
+        const int item = it * kWave + lane;
+        if (item < nitems) {
+            raw[it][0] = src[item * 2];
+            raw[it][1] = src[item * 2 + 1];
+        } else {
+            raw[it][0] = raw[it][1] = u32x4{0, 0, 0, 0};
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kMaxItems; ++it)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = raw[it][h][j];
+                amax = fmaxf(amax, fabsf(bf16_to_f32(w & 0xFFFFu)));
+                amax = fmaxf(amax, fabsf(__uint_as_float(w & 0xFFFF0000u)));
+            }
+    amax = wave_max(amax);
+    float s, scale_out;
+    if (EPS) {
+        s = 127.0f / (amax + 1e-12f);
+        scale_out = 1.0f / s;
+    } else {
+        s = (amax == 0.f) ? 0.f : 127.0f / amax;       // all-zero row: q = 0, scale = 0 (see oracle)
+        scale_out = (amax == 0.f) ? 0.f : 1.0f / s;
+    }
+    u32x4 q[kMaxItems];
+#pragma unroll
+    for (int it = 0; it < kMaxItems; ++it) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const uint32_t w = raw[it][h][jj * 2 + b];
+                    const int lo = (int)rintf(bf16_to_f32(w & 0xFFFFu) * s);
+                    const int hi = (int)rintf(__uint_as_float(w & 0xFFFF0000u) * s);
+                    packed |= ((uint32_t)(lo & 0xFF) | ((uint32_t)(hi & 0xFF) << 8)) << (16 * b);
+                }
+                q[it][h * 2 + jj] = packed;
+            }
+    }
+    for (int k = 0; k < K; ++k) {
+        if (!((vmask >> k) & 1ull)) continue;          // wave-uniform
+        const int slot = __shfl(slot_l, k, kWave);
+        const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
+        uint8_t *row = (uint8_t *)dsts.p[drank] + (size_t)slot * stride;
+        u32x4 *dst = (u32x4 *)row;
+#pragma unroll
+        for (int it = 0; it < kMaxItems; ++it) {
+            const int item = it * kWave + lane;
+            if (item < nitems) dst[item] = q[it];
+        }
+        if (lane == 0)
+            *(u32x4 *)(row + H) = u32x4{__float_as_uint(scale_out), (uint32_t)t, (uint32_t)k, (uint32_t)my_rank};
+    }
+}
+
+// stage, BF16 (no quantisation): item = one 16-B chunk
+template <bool I32>
+__global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
+    const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll)
+{
+    const int lane = lane_id();
+    const int t = blockIdx.x * kStageWaves + threadIdx.x / kWave;
+    if (t >= T) return;
+    const int nitems = H / 8;
+    const size_t stride = (size_t)H * 2 + MI_EP_ROW_META_BYTES;
+    long long e_l = -1;
+    int slot_l = 0, dst_l = 0;
+    if (lane < K) {
+        e_l = ld_idx<I32>(topk_idx, (long long)t * K + lane);
+        if (e_l >= 0 && e_l < E) route(ll, (int)e_l, idx_small[(long long)t * K + lane], send_off, my_rank, slot_l, dst_l);
+        else e_l = -1;
+    }
+    const unsigned long long vmask = __ballot(e_l >= 0);
+    if (vmask == 0ull) return;
+    const u32x4 *src = (const u32x4 *)(x + (size_t)t * H);
+    constexpr int kIt = kMaxItems * 2;
+    u32x4 raw[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int item = it * kWave + lane;
+        if (item < nitems) raw[it] = src[item];
+    }
+    for (int k = 0; k < K; ++k) {
+        if (!((vmask >> k) & 1ull)) continue;
+        const int slot = __shfl(slot_l, k, kWave);
+        const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
+        uint8_t *row = (uint8_t *)dsts.p[drank] + (size_t)slot * stride;
+        u32x4 *dst = (u32x4 *)row;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int item = it * kWave + lane;
+            if (item < nitems) dst[item] = raw[it];
+        }
+        if (lane == 0) *(u32x4 *)(row + (size_t)H * 2) = u32x4{0u, (uint32_t)t, (uint32_t)k, (uint32_t)my_rank};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pull
+// ---------------------------------------------------------------------------------------------
+constexpr int kPullWaves = 4;
+constexpr int kPullRowsPerWave = 4;
+constexpr int kPullRowsPerBlock = kPullWaves * kPullRowsPerWave;
+
+__global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
+    PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int seg_capacity,
+    int W, int LW, int payload_bytes /*H or 2H*/, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
+    int32_t *__restrict__ recv_src_idx)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
+    for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
+    __syncthreads();
+    const int total = cum[LW - 1];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
+    const int n16 = payload_bytes / 16;
+    for (long long r0 = (long long)blockIdx.x * kPullRowsPerBlock; r0 < total;
+         r0 += (long long)gridDim.x * kPullRowsPerBlock) {
+#pragma unroll 1
+        for (int rr = 0; rr < kPullRowsPerWave; ++rr) {
+            const long long r = r0 + wave * kPullRowsPerWave + rr;
+            if (r >= total) break;
+            // first i with cum[i] > r
+            int lo = 0, hi = LW - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cum[mid] > r) hi = mid; else lo = mid + 1;
+            }
+            const int i = lo;
+            const int j = (int)(r - (i ? cum[i - 1] : 0));
+            const int src = i % W;
+            const size_t off = pull_offset ? (size_t)pull_offset[i] : (size_t)i * seg_capacity;
+            const uint8_t *srow = (const uint8_t *)srcs.p[src] + (off + j) * stride;
+            const u32x4 *s16 = (const u32x4 *)srow;
+            u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
+            for (int base = 0; base < n16; base += kWave * 8) {
+                u32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * kWave + lane;
+                    if (item < n16) v[u] = __builtin_nontemporal_load(s16 + item);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * kWave + lane;
+                    if (item < n16) d16[item] = v[u];
+                }
+            }
+            if (lane == 0) {
+                const u32x4 m = *(const u32x4 *)(srow + payload_bytes);
+                if (recv_scales) recv_scales[r] = __uint_as_float(m[0]);
+                recv_src_idx[r * 3 + 0] = (int32_t)m[3];
+                recv_src_idx[r * 3 + 1] = (int32_t)m[1];
+                recv_src_idx[r * 3 + 2] = (int32_t)m[2];
+            }
+        }
+    }
+}
+
+}  // namespace mi_ep
+
+using namespace mi_ep;
+
+extern "C" size_t mi_ep_dispatch_row_bytes(int hidden, int quant_mode)
+{
+    return (size_t)hidden * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1) + MI_EP_ROW_META_BYTES;
+}
+
+extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx_is_i32,
+                                    const int32_t *send_token_idx_small, const int32_t *send_data_offset, int T, int K,
+                                    int H, int E, int my_rank, int quant_mode, void *rows, void *stream)
+{
+    if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0) return MI_EP_EINVAL;
+    if (T == 0) return MI_EP_OK;
+    if (!x || !topk_idx || !send_token_idx_small || !send_data_offset || !rows) return MI_EP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (T + kStageWaves - 1) / kStageWaves;
+    const int threads = kWave * kStageWaves;
+    const uint16_t *xp = (const uint16_t *)x;
+    uint8_t *rp = (uint8_t *)rows;
+    PeerPtrs pp;
+    pp.p[0] = rp;
+    const LLGeom ll{0, 0, 0};
+#define MI_EP_STAGE(KERNEL) \
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll)
+    switch (quant_mode) {
+        case MI_EP_QUANT_NONE:
+            if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
+            break;
+        case MI_EP_QUANT_INT8:
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, true>)); else MI_EP_STAGE((stage_int8_kernel<false, true>));
+            break;
+        case MI_EP_QUANT_INT8_NOEPS:
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, false>)); else MI_EP_STAGE((stage_int8_kernel<false, false>));
+            break;
+        default:
+            return MI_EP_EINVAL;
+    }
+#undef MI_EP_STAGE
+    return launch_status();
+}
+
+extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_count,
+                                   const int32_t *pull_offset, int W, int L, int H, int quant_mode, int rows_hint,
+                                   void *recv_x, float *recv_x_scales, int32_t *recv_src_idx, void *stream)
+{
+    if (!src_base_host || !recv_count || !pull_offset || W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || H <= 0 || H % 16 ||
+        !recv_x || !recv_src_idx)
+        return MI_EP_EINVAL;
+    if (rows_hint <= 0) return MI_EP_OK;
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) {
+        if (!src_base_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = const_cast<void *>(src_base_host[i]);
+    }
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    long long blocks = ((long long)rows_hint + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const size_t lds = (size_t)L * W * sizeof(int32_t);
+    pull_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
+        pp, recv_count, pull_offset, 0, W, L * W, payload, (uint8_t *)recv_x, recv_x_scales, recv_src_idx);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// A5 low-latency dispatch (same stage / pull kernels, different geometry; no host sync anywhere)
+// ---------------------------------------------------------------------------------------------
+namespace mi_ep {
+
+__global__ void ll_post_counts_kernel(PeerPtrs peers, const int32_t *__restrict__ cnt, int L, int W, int my_rank,
+                                      uint32_t epoch)
+{
+    const int d = blockIdx.x;
+    uint64_t *g = (uint64_t *)peers.p[d];
+    for (int le = threadIdx.x; le < L; le += blockDim.x)
+        sys_store_u64(g + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)cnt[d * L + le]);
+}
+
+// one workgroup: wait for the L*W count granules, inclusive cumsum in idx-i order, per-expert counts
+__global__ __launch_bounds__(256) void ll_counts_kernel(const uint64_t *__restrict__ granules, uint32_t epoch, int L, int W,
+                                                        int count_type, int32_t *__restrict__ layout_range,
+                                                        int64_t *__restrict__ packed_recv_count, int32_t *status,
+                                                        uint64_t timeout_ticks)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t c[];   // [L*W] then per-expert sums [L]
+    const int LW = L * W;
+    int32_t *per_e = c + LW;
+    const uint64_t t0 = ticks_100mhz();
+    for (int i = threadIdx.x; i < LW; i += blockDim.x) {
+        uint64_t g;
+        while (((g = sys_load_u64(granules + i)) >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                atomicCAS(status, 0, 2000 + i);
+                g = 0;
+                break;
+            }
+        }
+        c[i] = (int32_t)(uint32_t)g;
+    }
+    __syncthreads();
+    for (int le = threadIdx.x; le < L; le += blockDim.x) {
+        int32_t s = 0;
+        for (int src = 0; src < W; ++src) s += c[le * W + src];
+        per_e[le] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        int64_t cum = 0;
+        for (int le = 0; le < L; ++le) {
+            for (int src = 0; src < W; ++src) {
+                run += c[le * W + src];
+                layout_range[le * W + src] = run;
+            }
+            cum = (count_type == 0) ? cum + per_e[le] : (int64_t)per_e[le];
+            packed_recv_count[le] = cum;
+        }
+    }
+}
+
+}  // namespace mi_ep
+
+extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int idx_is_i32,
+                                      const int32_t *send_token_idx_small, int T, int K, int H, int E, int W, int my_rank,
+                                      int max_tokens, int quant_mode, void *const *peer_rows_host, void *stream)
+{
+    if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0 || W <= 0 ||
+        W > MI_EP_MAX_RANKS || E % W || T > max_tokens || !peer_rows_host)
+        return MI_EP_EINVAL;
+    if (T == 0) return MI_EP_OK;
+    if (!x || !topk_idx || !send_token_idx_small) return MI_EP_EINVAL;
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_rows_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = peer_rows_host[i];
+    }
+    const LLGeom ll{E / W, W, max_tokens};
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (T + kStageWaves - 1) / kStageWaves;
+    const int threads = kWave * kStageWaves;
+    const uint16_t *xp = (const uint16_t *)x;
+#define MI_EP_STAGE(KERNEL) \
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll)
+    switch (quant_mode) {
+        case MI_EP_QUANT_NONE:
+            if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
+            break;
+        case MI_EP_QUANT_INT8:
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, true>)); else MI_EP_STAGE((stage_int8_kernel<false, true>));
+            break;
+        case MI_EP_QUANT_INT8_NOEPS:
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, false>)); else MI_EP_STAGE((stage_int8_kernel<false, false>));
+            break;
+        default:
+            return MI_EP_EINVAL;
+    }
+#undef MI_EP_STAGE
+    return launch_status();
+}
+
+extern "C" int mi_ep_ll_post_counts(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int E, int W,
+                                    int my_rank, uint32_t epoch, void *stream)
+{
+    if (!peer_counts_host || !num_tokens_per_expert || E <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E % W || epoch == 0)
+        return MI_EP_EINVAL;
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_counts_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = peer_counts_host[i];
+    }
+    ll_post_counts_kernel<<<W, 64, 0, (hipStream_t)stream>>>(pp, num_tokens_per_expert, E / W, W, my_rank, epoch);
+    return launch_status();
+}
+
+extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint32_t epoch, int W, int L,
+                                      int max_tokens, int H, int quant_mode, int count_type, void *packed_recv_x,
+                                      float *packed_recv_x_scales, int64_t *packed_recv_count, int32_t *src_info,
+                                      int32_t *layout_range, int32_t *status, int timeout_ms, void *stream)
+{
+    if (!my_rows || !my_counts || !packed_recv_x || !packed_recv_count || !src_info || !layout_range || !status ||
+        W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || L * W > 2048 || H <= 0 || H % 16 || max_tokens <= 0 || epoch == 0)
+        return MI_EP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
+    ll_counts_kernel<<<1, 256, (size_t)(L * W + L) * 4, s>>>(my_counts, epoch, L, W, count_type, layout_range,
+                                                            packed_recv_count, status, ticks);
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) pp.p[i] = const_cast<void *>(my_rows);
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    // worst case rows = W * max_tokens * min(K, L) is not known here (K); size the grid for W * max_tokens rows per
+    // 16-row block, capped: the kernel grid-strides over the device-side total.
+    long long blocks = ((long long)W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, s>>>(pp, layout_range, nullptr, max_tokens, W, L * W,
+                                                                         payload, (uint8_t *)packed_recv_x,
+                                                                         packed_recv_x_scales, src_info);
+    return launch_status();
+}

@@ -1,0 +1,57 @@
+// Device-side helpers shared by the expert-parallel kernels (gfx950 / wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi_ep.h"
+
+namespace mi_ep {
+
+constexpr int kWave = 64;
+
+struct PeerPtrs {          // W <= MI_EP_MAX_RANKS base pointers, passed by value in the kernarg segment
+    void *p[MI_EP_MAX_RANKS];
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+
+// float -> bf16 bits, round to nearest even; NaN -> 0x7FC0 (same as torch / the CPU oracle)
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f)
+{
+    uint32_t x = __float_as_uint(f);
+    if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
+    return (x + 0x7FFFu + ((x >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// 8-byte words other GPUs write/poll: always system-scope atomics, never plain accesses.
+__device__ __forceinline__ void sys_store_u64(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint64_t sys_load_u64(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ~100 MHz constant-rate counter (s_memrealtime); used only to bound spins.
+__device__ __forceinline__ uint64_t ticks_100mhz() { return wall_clock64(); }
+
+inline int launch_status()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MI_EP_OK : MI_EP_ELAUNCH;
+}
+
+}  // namespace mi_ep

@@ -1,0 +1,208 @@
+// A1 dispatch layout for gfx950.
+// Replaces aclnnDispatchLayout (reference kernel csrc/deepep/ops/op_kernel/dispatch_layout.h:81-219).
+//
+// MI355X design: the (token,k) pairs are cut into units of 64 tokens, one wave64 per unit.
+//   pass 1  per-unit expert histogram in LDS (LDS atomics) + token->rank bitmask,
+//   pass 2  one workgroup: per-expert exclusive scan over units (coalesced over experts),
+//           totals, exclusive scan over experts (send_data_offset), per-rank token counts,
+//   pass 3  per unit, pairs are walked in row-major order 64 at a time; the rank of a pair among
+//           equal experts inside the 64-wide step comes from ballots (no serial loop), the running
+//           base lives in LDS.  Results are order-deterministic (no global atomics).
+#include "ep_common.h"
+
+namespace mi_ep {
+
+constexpr int kUnitTokens = 64;
+constexpr int kWavesPerBlock = 4;
+
+template <bool I32>
+__device__ __forceinline__ long long load_idx(const void *p, long long i)
+{
+    if (I32) return (long long)((const int32_t *)p)[i];
+    return ((const long long *)p)[i];
+}
+
+// lanes holding the same key as this lane (key < 2^nbits), via nbits ballots
+__device__ __forceinline__ unsigned long long match_any_bits(unsigned key, bool active, int nbits)
+{
+    unsigned long long m = __ballot(active);
+    for (int b = 0; b < nbits; ++b) {
+        unsigned long long s = __ballot(active && ((key >> b) & 1u));
+        m &= ((key >> b) & 1u) ? s : ~s;
+    }
+    return m;
+}
+
+template <bool I32>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void layout_hist_kernel(
+    const void *__restrict__ topk_idx, int T, int K, int E, int W, int32_t *__restrict__ is_token_in_rank,
+    int32_t *__restrict__ unit_hist /*[U][E]*/, int32_t *__restrict__ unit_rank /*[U][W]*/)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int wave = threadIdx.x / kWave, lane = lane_id();
+    const int unit = blockIdx.x * kWavesPerBlock + wave;
+    int32_t *hist = smem + wave * E;                                       // [E]
+    unsigned long long *rmask = (unsigned long long *)(smem + kWavesPerBlock * E) + wave * kUnitTokens;
+    const int U = (T + kUnitTokens - 1) / kUnitTokens;
+    if (unit >= U) return;   // whole wave exits; no block barriers are used below
+    for (int e = lane; e < E; e += kWave) hist[e] = 0;
+    rmask[lane] = 0ull;
+    const int t0 = unit * kUnitTokens;
+    const int ntok = min(kUnitTokens, T - t0);
+    const int L = E / W;
+    const long long p0 = (long long)t0 * K;
+    const int npairs = ntok * K;
+    for (int c = 0; c < npairs; c += kWave) {
+        int p = c + lane;
+        if (p < npairs) {
+            long long e = load_idx<I32>(topk_idx, p0 + p);
+            if (e >= 0 && e < E) {
+                atomicAdd(&hist[(int)e], 1);
+                atomicOr(&rmask[p / K], 1ull << ((int)e / L));
+            }
+        }
+    }
+    // single wave: LDS operations above are complete in program order
+    for (int e = lane; e < E; e += kWave) unit_hist[(long long)unit * E + e] = hist[e];
+    unsigned long long m = (lane < ntok) ? rmask[lane] : 0ull;
+    if (lane < ntok) {
+        int32_t *row = is_token_in_rank + (long long)(t0 + lane) * W;
+        for (int r = 0; r < W; ++r) row[r] = (int32_t)((m >> r) & 1ull);
+    }
+    for (int r = 0; r < W; ++r) {
+        unsigned long long b = __ballot((m >> r) & 1ull);
+        if (lane == 0) unit_rank[(long long)unit * W + r] = __popcll(b);
+    }
+}
+
+__global__ __launch_bounds__(1024) void layout_scan_kernel(int U, int E, int W, int32_t *__restrict__ unit_hist,
+                                                           const int32_t *__restrict__ unit_rank,
+                                                           int32_t *__restrict__ num_tokens_per_rank,
+                                                           int32_t *__restrict__ num_tokens_per_expert,
+                                                           int32_t *__restrict__ send_data_offset)
+{
+    __shared__ int32_t wave_tot[16];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / kWave;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < E; base += blockDim.x) {
+        const int e = base + tid;
+        int32_t run = 0;
+        if (e < E) {
+            for (int u = 0; u < U; ++u) {
+                int32_t v = unit_hist[(long long)u * E + e];
+                unit_hist[(long long)u * E + e] = run;   // becomes the unit's base for expert e
+                run += v;
+            }
+            num_tokens_per_expert[e] = run;
+        }
+        // block exclusive scan of `run` over experts
+        int32_t inc = run;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            int32_t n = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += n;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        int32_t wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+        const int32_t c = carry;
+        if (e < E) send_data_offset[e] = c + wbase + inc - run;
+        __syncthreads();
+        if (tid == blockDim.x - 1) carry = c + wbase + inc;
+        __syncthreads();
+    }
+    for (int r = tid; r < W; r += blockDim.x) {
+        int32_t s = 0;
+        for (int u = 0; u < U; ++u) s += unit_rank[(long long)u * W + r];
+        num_tokens_per_rank[r] = s;
+    }
+}
+
+template <bool I32>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void layout_assign_kernel(
+    const void *__restrict__ topk_idx, int T, int K, int E, int nbits, const int32_t *__restrict__ unit_base /*[U][E]*/,
+    int32_t *__restrict__ send_token_idx_small)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int wave = threadIdx.x / kWave, lane = lane_id();
+    const int unit = blockIdx.x * kWavesPerBlock + wave;
+    const int U = (T + kUnitTokens - 1) / kUnitTokens;
+    if (unit >= U) return;
+    int32_t *cnt = smem + wave * E;
+    for (int e = lane; e < E; e += kWave) cnt[e] = unit_base[(long long)unit * E + e];
+    const int t0 = unit * kUnitTokens;
+    const int npairs = min(kUnitTokens, T - t0) * K;
+    const long long p0 = (long long)t0 * K;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int c = 0; c < npairs; c += kWave) {
+        const int p = c + lane;
+        long long e = -1;
+        if (p < npairs) e = load_idx<I32>(topk_idx, p0 + p);
+        const bool valid = (e >= 0 && e < E);
+        const unsigned long long same = match_any_bits(valid ? (unsigned)e : 0u, valid, nbits);
+        int32_t out = 0;
+        if (valid) {
+            const int before = __popcll(same & lt);
+            const int32_t base = cnt[(int)e];
+            out = base + before;
+            // the highest lane of the group publishes the new running count (LDS ops of one wave are in order,
+            // but the read above and this write belong to different lanes of the same instruction pair:
+            // every lane reads first because the write below is a later instruction)
+            if ((same >> lane) == 1ull) cnt[(int)e] = base + before + 1;
+        }
+        if (p < npairs) send_token_idx_small[p0 + p] = out;
+    }
+}
+
+}  // namespace mi_ep
+
+using namespace mi_ep;
+
+extern "C" size_t mi_ep_dispatch_layout_workspace(int T, int K, int E)
+{
+    (void)K;
+    size_t U = (size_t)(T + kUnitTokens - 1) / kUnitTokens;
+    if (U == 0) U = 1;
+    return U * ((size_t)E + MI_EP_MAX_RANKS) * sizeof(int32_t);
+}
+
+extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T, int K, int E, int W,
+                                     int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
+                                     int32_t *is_token_in_rank, int32_t *send_token_idx_small,
+                                     int32_t *send_data_offset, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || E <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E % W != 0 || E > 2048)
+        return MI_EP_EINVAL;
+    if (workspace_bytes < mi_ep_dispatch_layout_workspace(T, K, E) || !workspace) return MI_EP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int U = (T + kUnitTokens - 1) / kUnitTokens;
+    int32_t *unit_hist = (int32_t *)workspace;
+    int32_t *unit_rank = unit_hist + (size_t)(U ? U : 1) * E;
+    const int blocks = (U + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t lds1 = (size_t)kWavesPerBlock * E * 4 + (size_t)kWavesPerBlock * kUnitTokens * 8;
+    const size_t lds3 = (size_t)kWavesPerBlock * E * 4;
+    int nbits = 1;
+    while ((1 << nbits) < E) ++nbits;
+    if (U > 0) {
+        if (idx_is_i32)
+            layout_hist_kernel<true><<<blocks, kWave * kWavesPerBlock, lds1, s>>>(topk_idx, T, K, E, W, is_token_in_rank,
+                                                                                  unit_hist, unit_rank);
+        else
+            layout_hist_kernel<false><<<blocks, kWave * kWavesPerBlock, lds1, s>>>(topk_idx, T, K, E, W, is_token_in_rank,
+                                                                                   unit_hist, unit_rank);
+    }
+    layout_scan_kernel<<<1, 1024, 0, s>>>(U, E, W, unit_hist, unit_rank, num_tokens_per_rank, num_tokens_per_expert,
+                                          send_data_offset);
+    if (U > 0) {
+        if (idx_is_i32)
+            layout_assign_kernel<true><<<blocks, kWave * kWavesPerBlock, lds3, s>>>(topk_idx, T, K, E, nbits, unit_hist,
+                                                                                    send_token_idx_small);
+        else
+            layout_assign_kernel<false><<<blocks, kWave * kWavesPerBlock, lds3, s>>>(topk_idx, T, K, E, nbits, unit_hist,
+                                                                                     send_token_idx_small);
+    }
+    return launch_status();
+}

@@ -1,0 +1,212 @@
+// Window flag protocol + the notify (counts all-gather) exchange for gfx950.
+// Replaces the reference's 32-byte float flag lines and magic-tagged notify flags
+// (csrc/deepep/ops/op_kernel/cam_moe_dispatch_normal.h:496-502,584-631; notify_dispatch.h:247-338).
+//
+// MI355X design: flags are 8-byte monotonically increasing epochs (no clear pass, no ping-pong of the
+// flag words); notify values travel as 8-byte {epoch, value} granules so the data is its own flag.
+// Only these 8-byte words are touched with system-scope atomics; bulk payload hand-off is ordered by
+// kernel boundaries (post kernel -> signal kernel | wait kernel -> consume kernel).
+#include "ep_common.h"
+
+namespace mi_ep {
+
+__global__ void signal_kernel(PeerPtrs peers, int W, int my_rank, uint64_t epoch)
+{
+    const int d = threadIdx.x;
+    if (d < W) sys_store_u64((uint64_t *)peers.p[d] + my_rank, epoch);
+}
+
+__global__ void wait_kernel(const uint64_t *__restrict__ flags, int W, uint64_t epoch, int32_t *status,
+                            uint64_t timeout_ticks)
+{
+    const int s = threadIdx.x;
+    if (s >= W) return;
+    const uint64_t t0 = ticks_100mhz();
+    while (sys_load_u64(flags + s) < epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        if (ticks_100mhz() - t0 > timeout_ticks) {
+            atomicCAS(status, 0, 1 + s);
+            return;
+        }
+    }
+}
+
+__global__ void notify_post_kernel(PeerPtrs peers, int W, int my_rank, int E, const int32_t *__restrict__ cnt,
+                                   int num_tokens, uint32_t epoch)
+{
+    // grid.x = W destinations, threads sweep the E+1 values
+    const int d = blockIdx.x;
+    uint64_t *row = (uint64_t *)peers.p[d] + (size_t)my_rank * (E + 1);
+    for (int e = threadIdx.x; e <= E; e += blockDim.x) {
+        const uint32_t v = (e < E) ? (uint32_t)cnt[e] : (uint32_t)num_tokens;
+        sys_store_u64(row + e, ((uint64_t)epoch << 32) | v);
+    }
+}
+
+__global__ void notify_wait_kernel(const uint64_t *__restrict__ notify, int n, uint32_t epoch,
+                                   int32_t *__restrict__ cnt_matrix, int32_t *status, uint64_t timeout_ticks)
+{
+    const uint64_t t0 = ticks_100mhz();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint64_t g;
+        while (((g = sys_load_u64(notify + i)) >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                atomicCAS(status, 0, 1000 + i);
+                g = 0;
+                break;
+            }
+        }
+        cnt_matrix[i] = (int32_t)(uint32_t)g;
+    }
+}
+
+// One workgroup; L*W <= 2048 entries.  See mi_ep.h for the table definitions
+// (reference notify_dispatch.h:386-407,434-450,473-482,553-577,606-615,665-669,715-721,759-780).
+__global__ __launch_bounds__(256) void notify_tables_kernel(
+    const int32_t *__restrict__ cnt /*[W][E+1]*/, int W, int E, int me, int relative_pull,
+    int32_t *__restrict__ recv_count, int32_t *__restrict__ recv_offset, int32_t *__restrict__ recv_tokens_per_expert,
+    int32_t *__restrict__ expert_global_offset, int32_t *__restrict__ srcrank_in_expert_offset,
+    int32_t *__restrict__ r_in_srcrank_offset, int32_t *__restrict__ total_recv_token, int32_t *__restrict__ max_bs,
+    int32_t *__restrict__ pull_offset, int32_t *summary_host)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
+    const int L = E / W;
+    const int LW = L * W;
+    int32_t *c = sm;                 // [L*W] counts in idx-i order
+    int32_t *pre = sm + LW;          // [W] sender prefix at my first expert
+    int32_t *ego = pre + W;          // [L+1]
+    const int tid = threadIdx.x;
+    // sender-side exclusive prefixes: for each src, prefix over its experts up to (me*L + le)
+    for (int src = tid; src < W; src += blockDim.x) {
+        const int32_t *row = cnt + (size_t)src * (E + 1);
+        int32_t run = 0;
+        for (int e = 0; e < me * L; ++e) run += row[e];
+        pre[src] = run;
+        for (int le = 0; le < L; ++le) {
+            const int i = le * W + src;
+            const int32_t v = row[me * L + le];
+            c[i] = v;
+            recv_offset[i] = run;
+            pull_offset[i] = relative_pull ? run - pre[src] : run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    for (int le = tid; le < L; le += blockDim.x) {
+        int32_t s = 0;
+        for (int src = 0; src < W; ++src) {
+            srcrank_in_expert_offset[le * W + src] = s;
+            r_in_srcrank_offset[le * W + src] = 0;
+            s += c[le * W + src];
+        }
+        recv_tokens_per_expert[le] = s;
+        ego[le] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t run = 0;
+        for (int le = 0; le < L; ++le) {
+            const int32_t v = ego[le];
+            expert_global_offset[le] = run;
+            ego[le] = run;
+            run += v;
+        }
+        ego[L] = run;
+        total_recv_token[0] = run;
+        int32_t mb = 0;
+        for (int src = 0; src < W; ++src) mb = max(mb, cnt[(size_t)src * (E + 1) + E]);
+        max_bs[0] = mb;
+    }
+    __syncthreads();
+    for (int i = tid; i < LW; i += blockDim.x) {
+        const int le = i / W;
+        recv_count[i] = ego[le] + srcrank_in_expert_offset[i] + c[i];
+    }
+    if (summary_host) {
+        // per-expert counts first, the total last so a polling host sees a complete record
+        __syncthreads();
+        for (int le = tid; le < L; le += blockDim.x)
+            __hip_atomic_store(summary_host + 2 + le, recv_tokens_per_expert[le], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(summary_host + 1, max_bs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(summary_host + 0, total_recv_token[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+}  // namespace mi_ep
+
+using namespace mi_ep;
+
+static uint64_t ms_to_ticks(int ms) { return (uint64_t)(ms > 0 ? ms : 10000) * 100000ull; }
+
+static int fill_peers(PeerPtrs &pp, const void *const *host, int W)
+{
+    if (!host || W <= 0 || W > MI_EP_MAX_RANKS) return MI_EP_EINVAL;
+    for (int i = 0; i < W; ++i) {
+        if (!host[i]) return MI_EP_EINVAL;
+        pp.p[i] = const_cast<void *>(host[i]);
+    }
+    return MI_EP_OK;
+}
+
+extern "C" const char *mi_ep_version(void) { return "mi_ep 0.1 gfx950"; }
+
+extern "C" int mi_ep_signal(uint64_t *const *peer_flags_host, int W, int my_rank, uint64_t epoch, void *stream)
+{
+    PeerPtrs pp;
+    if (fill_peers(pp, (const void *const *)peer_flags_host, W) || my_rank < 0 || my_rank >= W) return MI_EP_EINVAL;
+    signal_kernel<<<1, kWave, 0, (hipStream_t)stream>>>(pp, W, my_rank, epoch);
+    return launch_status();
+}
+
+extern "C" int mi_ep_wait(const uint64_t *my_flags, int W, uint64_t epoch, int32_t *status, int timeout_ms,
+                          void *stream)
+{
+    if (!my_flags || !status || W <= 0 || W > MI_EP_MAX_RANKS) return MI_EP_EINVAL;
+    wait_kernel<<<1, kWave, 0, (hipStream_t)stream>>>(my_flags, W, epoch, status, ms_to_ticks(timeout_ms));
+    return launch_status();
+}
+
+extern "C" int mi_ep_notify_post(uint64_t *const *peer_notify_host, int W, int my_rank, int E,
+                                 const int32_t *num_tokens_per_expert, int num_tokens, uint32_t epoch, void *stream)
+{
+    PeerPtrs pp;
+    if (fill_peers(pp, (const void *const *)peer_notify_host, W) || my_rank < 0 || my_rank >= W || E <= 0 ||
+        !num_tokens_per_expert || epoch == 0)
+        return MI_EP_EINVAL;
+    notify_post_kernel<<<W, 256, 0, (hipStream_t)stream>>>(pp, W, my_rank, E, num_tokens_per_expert, num_tokens, epoch);
+    return launch_status();
+}
+
+extern "C" int mi_ep_notify_wait(const uint64_t *my_notify, int W, int E, uint32_t epoch, int32_t *cnt_matrix,
+                                 int32_t *status, int timeout_ms, void *stream)
+{
+    if (!my_notify || !cnt_matrix || !status || W <= 0 || E <= 0 || epoch == 0) return MI_EP_EINVAL;
+    const int n = W * (E + 1);
+    const int blocks = (n + 255) / 256 < 8 ? (n + 255) / 256 : 8;
+    notify_wait_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(my_notify, n, epoch, cnt_matrix, status,
+                                                               ms_to_ticks(timeout_ms));
+    return launch_status();
+}
+
+extern "C" int mi_ep_notify_tables(const int32_t *cnt_matrix, int W, int E, int my_rank, int relative_pull,
+                                   int32_t *recv_count, int32_t *recv_offset, int32_t *recv_tokens_per_expert,
+                                   int32_t *expert_global_offset, int32_t *srcrank_in_expert_offset,
+                                   int32_t *r_in_srcrank_offset, int32_t *total_recv_token, int32_t *max_bs,
+                                   int32_t *pull_offset, int32_t *summary_host, void *stream)
+{
+    if (!cnt_matrix || W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048 || my_rank < 0 || my_rank >= W)
+        return MI_EP_EINVAL;
+    const int L = E / W;
+    const size_t lds = (size_t)(L * W + W + L + 1) * sizeof(int32_t);
+    notify_tables_kernel<<<1, 256, lds, (hipStream_t)stream>>>(cnt_matrix, W, E, my_rank, relative_pull, recv_count,
+                                                              recv_offset, recv_tokens_per_expert, expert_global_offset,
+                                                              srcrank_in_expert_offset, r_in_srcrank_offset,
+                                                              total_recv_token, max_bs, pull_offset, summary_host);
+    return launch_status();
+}

@@ -1,0 +1,209 @@
+"""W expert-parallel ranks simulated inside ONE process on ONE GPU, driving the HIP kernels through the
+C-ABI of include/mi_ep.h (ctypes).  Each simulated rank owns its windows (plain device buffers); "peer
+pointers" are the other ranks' buffers, exactly what hipIpc-mapped windows are on a real 8-GPU node.
+Post-kernels of all ranks are enqueued before any wait-kernel, so a single stream cannot deadlock.
+Test infrastructure only."""
+import ctypes
+from ctypes import c_int, c_int32, c_size_t, c_uint32, c_uint64, c_void_p
+
+import torch
+
+from capi import load, ptr, ptr_array, stream_ptr
+
+QUANT_NONE, QUANT_INT8, QUANT_INT8_NOEPS = 0, 1, 2
+
+
+def _lib():
+    lib = load("libmi_ep.so")
+    V, I = c_void_p, c_int
+    lib.mi_ep_version.restype = ctypes.c_char_p
+    lib.mi_ep_dispatch_row_bytes.restype = c_size_t
+    lib.mi_ep_dispatch_row_bytes.argtypes = [I, I]
+    lib.mi_ep_combine_row_bytes.restype = c_size_t
+    lib.mi_ep_combine_row_bytes.argtypes = [I]
+    lib.mi_ep_dispatch_layout_workspace.restype = c_size_t
+    lib.mi_ep_dispatch_layout_workspace.argtypes = [I, I, I]
+    lib.mi_ep_dispatch_layout.argtypes = [V, I, I, I, I, I, V, V, V, V, V, V, c_size_t, V]
+    lib.mi_ep_signal.argtypes = [V, I, I, c_uint64, V]
+    lib.mi_ep_wait.argtypes = [V, I, c_uint64, V, I, V]
+    lib.mi_ep_notify_post.argtypes = [V, I, I, I, V, I, c_uint32, V]
+    lib.mi_ep_notify_wait.argtypes = [V, I, I, c_uint32, V, V, I, V]
+    lib.mi_ep_notify_tables.argtypes = [V, I, I, I, I] + [V] * 10 + [V]
+    lib.mi_ep_dispatch_stage.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, V]
+    lib.mi_ep_dispatch_pull.argtypes = [V, V, V, I, I, I, I, I, V, V, V, V]
+    lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, V]
+    lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, I, I, I, I, V, V]
+    lib.mi_ep_ll_dispatch_send.argtypes = [V, V, I, V, I, I, I, I, I, I, I, I, V, V]
+    lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
+    lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, V, I, V]
+    for n in ("mi_ep_dispatch_layout mi_ep_signal mi_ep_wait mi_ep_notify_post mi_ep_notify_wait mi_ep_notify_tables "
+              "mi_ep_dispatch_stage mi_ep_dispatch_pull mi_ep_combine_push mi_ep_combine_reduce mi_ep_ll_dispatch_send "
+              "mi_ep_ll_post_counts mi_ep_ll_dispatch_recv").split():
+        getattr(lib, n).restype = c_int
+    return lib
+
+
+LIB = None
+
+
+def lib():
+    global LIB
+    if LIB is None:
+        LIB = _lib()
+    return LIB
+
+
+def ck(rc):
+    assert rc == 0, f"mi_ep call failed rc={rc}"
+
+
+def layout(topk_idx, E, W):
+    """-> dict of device tensors (A1)."""
+    T, K = topk_idx.shape
+    dev = topk_idx.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    out = dict(num_tokens_per_rank=torch.empty(W, **i32), num_tokens_per_expert=torch.empty(E, **i32),
+               is_token_in_rank=torch.empty((T, W), **i32), send_token_idx_small=torch.empty((T, K), **i32),
+               send_data_offset=torch.empty(E, **i32))
+    wsb = lib().mi_ep_dispatch_layout_workspace(T, K, E)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ck(lib().mi_ep_dispatch_layout(ptr(topk_idx), int(topk_idx.dtype == torch.int32), T, K, E, W,
+                                   ptr(out["num_tokens_per_rank"]), ptr(out["num_tokens_per_expert"]),
+                                   ptr(out["is_token_in_rank"]), ptr(out["send_token_idx_small"]),
+                                   ptr(out["send_data_offset"]), ptr(ws), wsb, stream_ptr()))
+    out["_ws"] = ws
+    return out
+
+
+class InProcEP:
+    """Normal + low-latency dispatch/combine for W simulated ranks."""
+
+    def __init__(self, W, E, max_tokens, K, H, device="cuda"):
+        self.W, self.E, self.L, self.K, self.H = W, E, E // W, K, H
+        self.max_tokens = max_tokens
+        self.dev = torch.device(device)
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        rb = max(lib().mi_ep_dispatch_row_bytes(H, QUANT_NONE), lib().mi_ep_dispatch_row_bytes(H, QUANT_INT8))
+        self.send_win = [torch.zeros(max(max_tokens * K, 1) * rb, **u8) for _ in range(W)]
+        self.comb_win = [torch.zeros(max(max_tokens * K, 1) * lib().mi_ep_combine_row_bytes(H), **u8) for _ in range(W)]
+        self.ll_win = [torch.zeros(self.L * W * max_tokens * rb, **u8) for _ in range(W)]
+        u64 = dict(dtype=torch.int64, device=self.dev)
+        self.flags = [torch.zeros(4 * 64, **u64) for _ in range(W)]      # 4 flag groups of 64 slots
+        self.notify = [torch.zeros(W * (E + 1), **u64) for _ in range(W)]
+        self.ll_counts = [torch.zeros(self.L * W, **u64) for _ in range(W)]
+        self.status = [torch.zeros(4, dtype=torch.int32, device=self.dev) for _ in range(W)]
+        self.epoch = 0
+
+    # ---- normal dispatch (A1 + A2 + A3) for all ranks; returns per-rank dicts
+    def dispatch(self, xs, topk_idxs, quant_mode):
+        W, E, L, K, H = self.W, self.E, self.L, self.K, self.H
+        L_ = lib()
+        self.epoch += 1
+        ep = self.epoch
+        st = stream_ptr()
+        lay = [layout(topk_idxs[r], E, W) for r in range(W)]
+        # post side of every rank first
+        notify_ptrs = ptr_array([t.data_ptr() for t in self.notify])
+        flag_ptrs = ptr_array([t.data_ptr() for t in self.flags])
+        for r in range(W):
+            T = xs[r].shape[0]
+            ck(L_.mi_ep_dispatch_stage(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                       ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K, H, E,
+                                       r, quant_mode, ptr(self.send_win[r]), st))
+            ck(L_.mi_ep_notify_post(notify_ptrs, W, r, E, ptr(lay[r]["num_tokens_per_expert"]), T, ep, st))
+            ck(L_.mi_ep_signal(flag_ptrs, W, r, ep, st))
+        outs = []
+        src_ptrs = ptr_array([t.data_ptr() for t in self.send_win])
+        for r in range(W):
+            i32 = dict(dtype=torch.int32, device=self.dev)
+            cnt = torch.empty((W, E + 1), **i32)
+            ck(L_.mi_ep_notify_wait(ptr(self.notify[r]), W, E, ep, ptr(cnt), ptr(self.status[r]), 2000, st))
+            tb = dict(recv_count=torch.empty(L * W, **i32), recv_offset=torch.empty(L * W, **i32),
+                      recv_tokens_per_expert=torch.empty(L, **i32), expert_global_offset=torch.empty(L, **i32),
+                      srcrank_in_expert_offset=torch.empty(L * W, **i32), r_in_srcrank_offset=torch.empty(L * W, **i32),
+                      total_recv_token=torch.empty(1, **i32), max_bs=torch.empty(1, **i32),
+                      pull_offset=torch.empty(L * W, **i32))
+            ck(L_.mi_ep_notify_tables(ptr(cnt), W, E, r, 0, ptr(tb["recv_count"]), ptr(tb["recv_offset"]),
+                                      ptr(tb["recv_tokens_per_expert"]), ptr(tb["expert_global_offset"]),
+                                      ptr(tb["srcrank_in_expert_offset"]), ptr(tb["r_in_srcrank_offset"]),
+                                      ptr(tb["total_recv_token"]), ptr(tb["max_bs"]), ptr(tb["pull_offset"]), None, st))
+            ck(L_.mi_ep_wait(ptr(self.flags[r]), W, ep, ptr(self.status[r]), 2000, st))
+            R = int(tb["total_recv_token"].item())       # the host sync the reference also performs
+            rows = max(R, 1)
+            if quant_mode == QUANT_NONE:
+                recv_x = torch.zeros((rows, H), dtype=torch.bfloat16, device=self.dev)
+                recv_s = None
+            else:
+                recv_x = torch.zeros((rows, H), dtype=torch.int8, device=self.dev)
+                recv_s = torch.zeros(rows, dtype=torch.float32, device=self.dev)
+            src_idx = torch.zeros(rows * 3, **i32)
+            ck(L_.mi_ep_dispatch_pull(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, quant_mode, R,
+                                      ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
+            outs.append(dict(recv_x=recv_x, recv_x_scales=recv_s, recv_src_idx=src_idx, total=R, layout=lay[r], tables=tb,
+                             cnt=cnt))
+        torch.cuda.synchronize()
+        for r in range(W):
+            assert int(self.status[r][0].item()) == 0, f"rank {r} wait timed out: {self.status[r].tolist()}"
+        return outs
+
+    # ---- combine (A4 / A6)
+    def combine(self, ys, src_idxs, totals, topk_idxs, topk_weights):
+        W, E, K, H = self.W, self.E, self.K, self.H
+        L_ = lib()
+        self.epoch += 1
+        ep = self.epoch
+        st = stream_ptr()
+        dst_ptrs = ptr_array([t.data_ptr() for t in self.comb_win])
+        flag_ptrs = ptr_array([t.data_ptr() + 64 * 8 for t in self.flags])
+        for r in range(W):
+            ck(L_.mi_ep_combine_push(ptr(ys[r]), ptr(src_idxs[r]), None, int(totals[r]), H, K, dst_ptrs, W, st))
+            ck(L_.mi_ep_signal(flag_ptrs, W, r, ep, st))
+        outs = []
+        for r in range(W):
+            T = topk_idxs[r].shape[0]
+            ck(L_.mi_ep_wait(c_void_p(self.flags[r].data_ptr() + 64 * 8), W, ep, ptr(self.status[r]), 2000, st))
+            out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
+            ck(L_.mi_ep_combine_reduce(ptr(self.comb_win[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                       ptr(topk_weights[r]), T, K, H, E, ptr(out), st))
+            outs.append(out)
+        torch.cuda.synchronize()
+        return outs
+
+    # ---- low-latency dispatch (A5)
+    def ll_dispatch(self, xs, topk_idxs, quant_mode, count_type=1):
+        W, E, L, K, H, MT = self.W, self.E, self.L, self.K, self.H, self.max_tokens
+        L_ = lib()
+        self.epoch += 1
+        ep = self.epoch
+        st = stream_ptr()
+        row_ptrs = ptr_array([t.data_ptr() for t in self.ll_win])
+        cnt_ptrs = ptr_array([t.data_ptr() for t in self.ll_counts])
+        lay = []
+        for r in range(W):
+            T = xs[r].shape[0]
+            lay.append(layout(topk_idxs[r], E, W))
+            ck(L_.mi_ep_ll_dispatch_send(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                         ptr(lay[r]["send_token_idx_small"]), T, K, H, E, W, r, MT, quant_mode, row_ptrs, st))
+            ck(L_.mi_ep_ll_post_counts(cnt_ptrs, ptr(lay[r]["num_tokens_per_expert"]), E, W, r, ep, st))
+        outs = []
+        M = W * MT * min(K, L)
+        for r in range(W):
+            i32 = dict(dtype=torch.int32, device=self.dev)
+            if quant_mode == QUANT_NONE:
+                px = torch.zeros((M, H), dtype=torch.bfloat16, device=self.dev)
+                ps = None
+            else:
+                px = torch.zeros((M, H), dtype=torch.int8, device=self.dev)
+                ps = torch.zeros(M, dtype=torch.float32, device=self.dev)
+            prc = torch.zeros(L, dtype=torch.int64, device=self.dev)
+            src_info = torch.zeros(max(xs[r].shape[0] * K, M * 128), **i32)
+            rng = torch.zeros(L * W, **i32)
+            ck(L_.mi_ep_ll_dispatch_recv(ptr(self.ll_win[r]), ptr(self.ll_counts[r]), ep, W, L, MT, H, quant_mode,
+                                         count_type, ptr(px), ptr(ps), ptr(prc), ptr(src_info), ptr(rng),
+                                         ptr(self.status[r]), 2000, st))
+            outs.append(dict(packed_recv_x=px, packed_recv_x_scales=ps, packed_recv_count=prc, src_info=src_info,
+                             layout_range=rng))
+        torch.cuda.synchronize()
+        for r in range(W):
+            assert int(self.status[r][0].item()) == 0
+        return outs

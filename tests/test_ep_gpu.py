@@ -1,0 +1,229 @@
+"""GPU parity tests: HIP dispatch/combine kernels (through the C-ABI) vs the CPU oracle, bit-exact.
+W ranks are simulated in one process on one GPU (tests/ep_harness.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ep as O
+from oracle.bf16 import bf16_bits_to_f32, f32_to_bf16_bits_rne, torch_to_bits, bits_to_torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_topk(rng, T, K, E, drop=0.0, active=None):
+    scores = np.abs(rng.standard_normal((T, E))) + 1
+    if active is not None:
+        mask = np.zeros(E, bool)
+        mask[active] = True
+        scores[:, ~mask] = 0
+    idx = np.argsort(-scores, axis=1, kind="stable")[:, :K].astype(np.int64)
+    if drop > 0:
+        idx[rng.random((T, K)) < drop] = -1
+    return idx
+
+
+def rand_bits(rng, shape, scale=1.0):
+    return f32_to_bf16_bits_rne((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def dev_bf16(bits):
+    return bits_to_torch(bits).cuda()
+
+
+LAYOUT_CASES = [(0, 4, 16, 4, 0), (1, 1, 2, 2, 0), (4, 2, 8, 2, 0), (33, 8, 64, 8, 0.3), (256, 2, 8, 1, 0),
+                (257, 8, 256, 8, 0.1), (4096, 8, 256, 8, 0.0), (1000, 16, 1024, 16, 0.2), (8192, 8, 256, 8, 0.05),
+                (129, 3, 24, 4, 0.5)]
+
+
+@pytest.mark.parametrize("T,K,E,W,drop", LAYOUT_CASES)
+@pytest.mark.parametrize("i32", [False, True])
+def test_dispatch_layout_bit_exact(T, K, E, W, drop, i32):
+    import ep_harness as Hh
+    rng = np.random.default_rng(T * 31 + K + E)
+    idx = make_topk(rng, T, K, E, drop) if T else np.zeros((0, K), np.int64)
+    if T > 5:
+        idx[3, :] = -1                     # a token selecting nothing
+        idx[4, 0] = E + 5                  # out-of-range id is skipped like -1 (dispatch_layout.h:166)
+    want = O.dispatch_layout(idx, E, W)
+    t = torch.from_numpy(idx).cuda()
+    if i32:
+        t = t.int()
+    got = Hh.layout(t, E, W)
+    torch.cuda.synchronize()
+    for k in ("num_tokens_per_rank", "num_tokens_per_expert", "is_token_in_rank", "send_token_idx_small"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    assert np.array_equal(got["send_data_offset"].cpu().numpy(), O.send_data_offset(want["num_tokens_per_expert"]))
+
+
+DISPATCH_CASES = [
+    # W, T, H, K, E, drop, active
+    (1, 256, 1024, 2, 8, 0.0, None),        # BASELINE C1 shape
+    (2, 33, 128, 2, 4, 0.0, None),
+    (4, 64, 256, 8, 32, 0.2, None),
+    (8, 40, 7168, 8, 256, 0.0, None),       # C2 row format (H=7168, E=256), few tokens
+    (8, 17, 128, 4, 8, 0.3, None),          # L = 1
+    (8, 64, 512, 8, 64, 0.0, [0, 1, 2, 3, 8, 9]),   # skewed routing (--active-ranks style)
+    (3, 50, 2048, 6, 12, 0.1, None),        # non power-of-two world
+    (2, 5, 8192, 16, 32, 0.0, None),        # max hidden, max top-k
+]
+
+
+def _run_dispatch(W, T, H, K, E, drop, active, quant_mode, ragged=True):
+    import ep_harness as Hh
+    rng = np.random.default_rng(W * 1000 + T)
+    Ts = [T + (r if ragged else 0) for r in range(W)]
+    if ragged and W > 1:
+        Ts[-1] = 0                                    # an empty rank
+    xs = [rand_bits(rng, (t, H), 3.0) for t in Ts]
+    for x in xs:
+        if x.shape[0] > 2:
+            x[1, :] = 0                               # an all-zero row (amax = 0)
+    idxs = [make_topk(rng, t, K, E, drop, active) if t else np.zeros((0, K), np.int64) for t in Ts]
+    ws = [rng.standard_normal((t, K)).astype(np.float32) for t in Ts]
+    h = Hh.InProcEP(W, E, max(Ts) + 1, K, H)
+    got = h.dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).cuda() for i in idxs], quant_mode)
+    return h, xs, idxs, ws, got
+
+
+@pytest.mark.parametrize("W,T,H,K,E,drop,active", DISPATCH_CASES)
+@pytest.mark.parametrize("quant", [False, True])
+def test_normal_dispatch_combine_bit_exact(W, T, H, K, E, drop, active, quant):
+    import ep_harness as Hh
+    qm = Hh.QUANT_INT8 if quant else Hh.QUANT_NONE
+    h, xs, idxs, ws, got = _run_dispatch(W, T, H, K, E, drop, active, qm)
+    want = O.normal_dispatch(xs, idxs, E, quant)
+    for r in range(W):
+        g, w = got[r], want[r]
+        assert g["total"] == w.total_recv
+        for k in ("recv_count", "recv_offset", "recv_tokens_per_expert", "expert_global_offset",
+                  "srcrank_in_expert_offset", "r_in_srcrank_offset", "total_recv_token", "max_bs"):
+            assert np.array_equal(g["tables"][k].cpu().numpy().reshape(-1), np.asarray(w.notify[k]).reshape(-1)), (r, k)
+        n = w.total_recv
+        assert np.array_equal(g["recv_src_idx"].cpu().numpy()[:3 * n], w.recv_src_idx[:3 * n])
+        if quant:
+            assert np.array_equal(g["recv_x"].cpu().numpy()[:n], w.recv_x[:n])
+            assert np.array_equal(g["recv_x_scales"].cpu().numpy()[:n].view(np.uint32), w.recv_x_scales[:n].view(np.uint32))
+        else:
+            assert np.array_equal(torch_to_bits(g["recv_x"])[:n], w.recv_x[:n])
+    # expert side: de-quantise (reference test convention) and combine
+    if quant:
+        ys_np = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) for w in want]
+    else:
+        ys_np = [w.recv_x for w in want]
+    comb_want = O.combine(ys_np, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)
+    comb_got = h.combine([dev_bf16(y) for y in ys_np], [g["recv_src_idx"] for g in got], [g["total"] for g in got],
+                         [torch.from_numpy(i).cuda() for i in idxs], [torch.from_numpy(w_).cuda() for w_ in ws])
+    for r in range(W):
+        assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r]), r
+        if xs[r].shape[0]:
+            d = O.calc_diff(bf16_bits_to_f32(comb_want[r]), O.golden_combined(xs[r], idxs[r], ws[r]))
+            assert d < (3e-3 if quant else 1e-5)
+
+
+def test_combine_without_weights_uses_ones():
+    import ep_harness as Hh
+    W, T, H, K, E = 2, 16, 128, 4, 8
+    h, xs, idxs, ws, got = _run_dispatch(W, T, H, K, E, 0.2, None, Hh.QUANT_NONE, ragged=False)
+    want = O.normal_dispatch(xs, idxs, E, False)
+    comb_want = O.combine([w.recv_x for w in want], [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs,
+                          [None] * W, E)
+    comb_got = h.combine([g["recv_x"] for g in got], [g["recv_src_idx"] for g in got], [g["total"] for g in got],
+                         [torch.from_numpy(i).cuda() for i in idxs], [None] * W)
+    for r in range(W):
+        assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r])
+
+
+LL_CASES = [(2, 16, 128, 2, 8, 0.0), (8, 128, 7168, 8, 256, 0.0), (8, 128, 512, 8, 64, 0.3), (4, 1, 256, 4, 16, 0.0),
+            (8, 2, 1024, 8, 8, 0.0)]
+
+
+@pytest.mark.parametrize("W,T,H,K,E,drop", LL_CASES)
+@pytest.mark.parametrize("quant", [False, True])
+@pytest.mark.parametrize("count_type", [1, 0])
+def test_low_latency_dispatch_combine_bit_exact(W, T, H, K, E, drop, quant, count_type):
+    import ep_harness as Hh
+    rng = np.random.default_rng(W * 77 + T)
+    Ts = [T] * W
+    if T > 1:
+        Ts[0] = T - 1                                   # fewer tokens than num_max_dispatch_tokens_per_rank
+    xs = [rand_bits(rng, (t, H), 2.0) for t in Ts]
+    idxs = [make_topk(rng, t, K, E, drop) for t in Ts]
+    ws = [np.abs(rng.standard_normal((t, K))).astype(np.float32) for t in Ts]
+    h = Hh.InProcEP(W, E, T, K, H)
+    qm = Hh.QUANT_INT8_NOEPS if quant else Hh.QUANT_NONE
+    # the reference casts topk_idx to int32 for LL (low_latency_strategy.py:57)
+    got = h.ll_dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).int().cuda() for i in idxs], qm, count_type)
+    want = O.low_latency_dispatch(xs, idxs, T, E, quant, expert_token_nums_type=count_type)
+    for r in range(W):
+        g, w = got[r], want[r]
+        n = w.total
+        assert np.array_equal(g["layout_range"].cpu().numpy(), w.layout_range)
+        assert np.array_equal(g["packed_recv_count"].cpu().numpy(), w.packed_recv_count)
+        assert np.array_equal(g["src_info"].cpu().numpy()[:3 * n], w.src_info)
+        if quant:
+            assert np.array_equal(g["packed_recv_x"].cpu().numpy()[:n], w.packed_recv_x[:n])
+            assert np.array_equal(g["packed_recv_x_scales"].cpu().numpy()[:n].view(np.uint32),
+                                  w.packed_recv_x_scales[:n].view(np.uint32))
+        else:
+            assert np.array_equal(torch_to_bits(g["packed_recv_x"])[:n], w.packed_recv_x[:n])
+    ys_np = [O.per_token_cast_back(w.packed_recv_x, w.packed_recv_x_scales) if quant else w.packed_recv_x for w in want]
+    comb_want = O.combine(ys_np, [w.src_info for w in want], [w.total for w in want], idxs, ws, E)
+    comb_got = h.combine([dev_bf16(y) for y in ys_np], [g["src_info"] for g in got], [w.total for w in want],
+                         [torch.from_numpy(i).int().cuda() for i in idxs], [torch.from_numpy(w_).cuda() for w_ in ws])
+    for r in range(W):
+        assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r])
+
+
+@pytest.mark.parametrize("quant", [True, False])
+def test_full_size_c2_properties(quant):
+    """BASELINE C2 sizes (W=8, 4096 tok/rank, H=7168, top-8, E=256): size-independent properties --
+    counts == global histogram, ordering contract, int8 payload == quantised source row, round trip
+    closed form (reference tests' golden) and run-to-run determinism."""
+    import ep_harness as Hh
+    W, T, H, K, E = 8, 4096, 7168, 8, 256
+    L = E // W
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    xs = [torch.randn((T, H), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16) for _ in range(W)]
+    idxs = [torch.topk(torch.randn((T, E), generator=g, device="cuda").abs() + 1, K, dim=-1, sorted=False)[1] for _ in range(W)]
+    ws = [torch.randn((T, K), generator=g, device="cuda") for _ in range(W)]
+    h = Hh.InProcEP(W, E, T, K, H)
+    qm = Hh.QUANT_INT8 if quant else Hh.QUANT_NONE
+    got = h.dispatch(xs, idxs, qm)
+    hist = sum(torch.bincount(i.reshape(-1), minlength=E) for i in idxs)
+    for r in range(W):
+        per_e = got[r]["tables"]["recv_tokens_per_expert"].long()
+        assert torch.equal(per_e, hist[r * L:(r + 1) * L])
+    for r in range(W):
+        n = got[r]["total"]
+        tri = got[r]["recv_src_idx"][:3 * n].view(-1, 3).long()
+        e_row = torch.empty(n, dtype=torch.long, device="cuda")
+        src_x = torch.empty((n, H), dtype=torch.bfloat16, device="cuda")
+        for s in range(W):
+            m = tri[:, 0] == s
+            e_row[m] = idxs[s][tri[m, 1], tri[m, 2]]
+            src_x[m] = xs[s][tri[m, 1]]
+        key = ((e_row - r * L) * W + tri[:, 0]) * (T * K) + tri[:, 1] * K + tri[:, 2]
+        assert bool((key[1:] > key[:-1]).all())           # (local expert, src rank, row-major (t,k)) order
+        if quant:
+            # payload == oracle quantisation of the source row (sampled: oracle on 2048 rows)
+            sel = torch.randperm(n, device="cuda")[:2048]
+            q_want, s_want = O.quant_int8_rows(torch_to_bits(src_x[sel]), 1e-12)
+            assert np.array_equal(got[r]["recv_x"][sel].cpu().numpy(), q_want)
+            assert np.array_equal(got[r]["recv_x_scales"][sel].cpu().numpy().view(np.uint32), s_want.view(np.uint32))
+        else:
+            assert torch.equal(got[r]["recv_x"][:n], src_x)
+    # round trip
+    if quant:
+        ys = [(g_["recv_x"].float() * g_["recv_x_scales"][:, None]).to(torch.bfloat16) for g_ in got]
+    else:
+        ys = [g_["recv_x"] for g_ in got]
+    comb = h.combine(ys, [g_["recv_src_idx"] for g_ in got], [g_["total"] for g_ in got], idxs, ws)
+    for r in range(W):
+        golden = xs[r].float() * ws[r].sum(dim=1, keepdim=True)
+        a, b = comb[r].double() + 1, golden.double() + 1
+        diff = 1 - 2 * (a * b).sum() / (a * a + b * b).sum()
+        assert diff.item() < (3e-3 if quant else 1e-5)
+    # determinism: a second dispatch gives identical bytes
+    got2 = h.dispatch(xs, idxs, qm)
+    for r in range(W):
+        assert torch.equal(got[r]["recv_x"], got2[r]["recv_x"]) and torch.equal(got[r]["recv_src_idx"], got2[r]["recv_src_idx"])
