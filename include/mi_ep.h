@@ -126,11 +126,20 @@ int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_co
  * push: row r < total (= *total_rows_dev if non-NULL else rows_hint) of x [R,H] bf16 with triple
  *   (src, t, k) = src_idx[3r..3r+2] is copied to dst_base[src] + (t*K + k) * mi_ep_combine_row_bytes(H).
  * reduce: out[t] = bf16_rne( sum_{k asc, 0 <= idx[t,k] < E} float(slot[t*K+k]) * w[t,k] ) with separate fp32
- *   multiply and add (cam_moe_combine_normal.h:372-396).  topk_weights NULL -> ones. */
+ *   multiply and add (cam_moe_combine_normal.h:372-396).  topk_weights NULL -> ones.
+ *   send_data_offset / send_token_idx_small: both NULL for the window layout above. */
 int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
                        int hidden, int num_topk, void *const *dst_base_host, int num_ranks, void *stream);
 int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
-                         int num_tokens, int num_topk, int hidden, int num_experts, void *out, void *stream);
+                         const int32_t *send_data_offset, const int32_t *send_token_idx_small, int num_tokens,
+                         int num_topk, int hidden, int num_experts, void *out, void *stream);
+/* All-to-all (RCCL) transport helper: reorder x [R,H] bf16 from dispatch order (local expert, src, j) into
+ * per-source blocks (src, local expert, j) -- each block is what that source staged for this rank, in its
+ * send-slot order, so it can be returned as one contiguous message.  send_head [L*W] = recv_count of the
+ * dispatch.  rows_per_src [W] (may be NULL) receives the block sizes.  With this transport the reducer reads
+ * slot send_data_offset[e] + send_token_idx_small[t,k] (pass both to mi_ep_combine_reduce) instead of t*K+k. */
+int mi_ep_combine_pack(const void *x, const int32_t *send_head, int num_ranks, int num_local_experts, int hidden,
+                       int rows_hint, void *packed, int32_t *rows_per_src, void *stream);
 
 /* ---- A5 low-latency dispatch -------------------------------------------------------------------
  * Window of a rank: rows [L][W][max_tokens] of mi_ep_dispatch_row_bytes(), counts granules

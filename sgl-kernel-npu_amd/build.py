@@ -76,7 +76,7 @@ def build_host_ext(out_name, srcs, libs, python_module=False):
         inc.append(f"-I{pybind11.get_include()}")
         link.append("-ltorch_python")
         defs.append(f"-DTORCH_EXTENSION_NAME={out_name.split('.')[0]}")
-    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", f"-I{INC}",
+    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", "-Wno-unused-result", f"-I{INC}",
           f"-I{os.path.join(HERE, 'csrc')}", *inc, *defs, *srcs, "-o", out, *link, *[f"-l{l}" for l in libs], *extra])
     return out
 

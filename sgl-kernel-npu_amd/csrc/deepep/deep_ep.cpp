@@ -1,0 +1,718 @@
+// MI355X host runtime of deep_ep (see deep_ep.hpp).  Behaviour follows the reference host runtime
+// csrc/deepep/deep_ep.cpp (cited per function); the implementation is HIP-native:
+//   * one fine-grained device allocation per rank is the symmetric window, mapped into every peer with hipIpc;
+//   * every op is a short chain of launches on the CALLER'S current stream (post -> signal | wait -> consume);
+//   * the one unavoidable host sync of normal dispatch (output size) is a spin on a pinned host word the
+//     notify kernel writes, instead of the reference's two .item() calls + a .to(CPU).
+#include "deep_ep.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include "mi_ep.h"
+
+namespace deep_ep {
+
+namespace {
+constexpr int64_t kCtrlBytes = 4ll << 20;          // flags + notify granules + LL count granules
+constexpr int kFlagGroupSlots = 64;                // MI_EP_MAX_RANKS
+constexpr int64_t kOffFlags = 0;                   // 8 groups x 64 x u64
+constexpr int64_t kOffNotify = 64 << 10;           // 2 parities x W x (E+1) u64  (<= 2 x 64 x 2049 x 8 = 2.1 MB)
+constexpr int64_t kNotifyParityBytes = 1100 << 10;
+constexpr int64_t kOffLLCounts = kOffNotify + 2 * kNotifyParityBytes;   // 2 parities x 2048 u64
+constexpr int64_t kLLCountsParityBytes = 2048 * 8;
+enum Family { kDispatch = 0, kCombine = 1, kLLDispatch = 2 };
+enum FlagGroup { kFlagDispatch = 0, kFlagCombine = 1 };
+constexpr int kMaxTotalTokens = 131072;            // reference MAX_TOTAL_TOKENS (deep_ep.cpp:37)
+
+hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+
+int quant_mode_of(bool use_quant, const std::string &quant_type)
+{
+    if (!use_quant) return MI_EP_QUANT_NONE;
+    if (quant_type == "int8_ll") return MI_EP_QUANT_INT8_NOEPS;     // low-latency rounding (no epsilon), a2a strategy only
+    // MXFP8 / MXFP4 / per-token FP8 are Ascend950-only in the reference too (deep_ep.cpp:338-343)
+    EP_HOST_ASSERT_S(quant_type == "int8", quant_type, " is not supported on this device, please use int8 or bf16 instead.");
+    return MI_EP_QUANT_INT8;
+}
+}  // namespace
+
+EventHandle::EventHandle()
+{
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) hipEventRecord(ev, cur_stream());
+}
+void EventHandle::current_stream_wait() const
+{
+    if (ev) hipStreamWaitEvent(cur_stream(), ev, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t num_rdma_bytes, bool low_latency_mode,
+               std::string moe_all_to_all_group_name)
+    : rank(rank),
+      num_ranks(num_ranks),
+      num_nvl_bytes(num_nvl_bytes),
+      num_rdma_bytes(num_rdma_bytes),
+      low_latency_mode(low_latency_mode),
+      group_name(std::move(moe_all_to_all_group_name))
+{
+    EP_HOST_ASSERT(0 <= rank and rank < num_ranks);
+    EP_HOST_ASSERT_S(num_ranks <= MI_EP_MAX_RANKS, "one xGMI domain holds at most ", MI_EP_MAX_RANKS, " ranks");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw EPException("HIP Assertion", __FILE__, __LINE__,
+                          "no HIP device visible: deep_ep_cpp needs an AMD GPU (there is no CPU fallback)");
+    HIP_CHECK(hipGetDevice(&device_id));
+    timeout_ms = get_value_from_env("DEEPEP_TIMEOUT_MS", 30000);
+
+    // Window budget.  The reference sizes its HCCL window with HCCL_BUFFSIZE (MB); DEEPEP_WINDOW_BYTES plays that
+    // role here.  Default 6 GiB = six 1-GiB regions: dispatch x2, combine x2, low-latency dispatch x2 (ping-pong),
+    // enough for 8192 tok x top-8 x 7168 BF16 per region; MI355X has 288 GB.
+    long long want = get_ll_from_env("DEEPEP_WINDOW_BYTES", 0);
+    if (want <= 0) want = std::max<long long>(6ll << 30, std::max(num_nvl_bytes, num_rdma_bytes));
+    region_bytes = (size_t)((want - kCtrlBytes) / 6) & ~(size_t)4095;
+    EP_HOST_ASSERT_S(region_bytes >= (1u << 20), "DEEPEP_WINDOW_BYTES too small: ", want);
+    window_bytes = kCtrlBytes + 6 * (int64_t)region_bytes;
+    void *p = nullptr;
+    const bool want_fine = get_value_from_env("DEEPEP_WINDOW_FINEGRAINED", 1) != 0;
+    if (want_fine && hipExtMallocWithFlags(&p, (size_t)window_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+        window_fine_grained = true;
+    } else {
+        (void)hipGetLastError();
+        HIP_CHECK(hipMalloc(&p, (size_t)window_bytes));
+    }
+    window = (uint8_t *)p;
+    HIP_CHECK(hipMemset(window, 0, (size_t)kCtrlBytes));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipHostMalloc((void **)&summary_host, sizeof(int32_t) * (4 + 2048), hipHostMallocMapped));
+    HIP_CHECK(hipHostMalloc((void **)&status_host, sizeof(int32_t) * 4, hipHostMallocMapped));
+    std::memset(summary_host, 0, sizeof(int32_t) * (4 + 2048));
+    std::memset(status_host, 0, sizeof(int32_t) * 4);
+    HIP_CHECK(hipHostGetDevicePointer((void **)&summary_dev, summary_host, 0));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&status_dev, status_host, 0));
+    peer_base.assign((size_t)num_ranks, nullptr);
+    peer_opened.assign((size_t)num_ranks, false);
+    peer_base[(size_t)rank] = window;
+    if (num_ranks == 1) available = true;      // nothing to exchange
+}
+
+Buffer::~Buffer() noexcept(false)
+{
+    hipDeviceSynchronize();
+    for (size_t r = 0; r < peer_base.size(); ++r)
+        if (peer_opened[r] && peer_base[r]) hipIpcCloseMemHandle(peer_base[r]);
+    if (window) hipFree(window);
+    if (summary_host) hipHostFree(summary_host);
+    if (status_host) hipHostFree(status_host);
+}
+
+std::string Buffer::get_local_ipc_handle() const
+{
+    hipIpcMemHandle_t h;
+    HIP_CHECK(hipIpcGetMemHandle(&h, window));
+    return std::string((const char *)&h, sizeof(h));
+}
+
+void Buffer::sync(const std::vector<std::string> &handles, const std::vector<int64_t> &local_ptrs)
+{
+    EP_HOST_ASSERT((int64_t)handles.size() == num_ranks and (int64_t)local_ptrs.size() == num_ranks);
+    for (int64_t r = 0; r < num_ranks; ++r) {
+        if (r == rank) continue;
+        if (local_ptrs[(size_t)r] != 0) {
+            peer_base[(size_t)r] = (uint8_t *)local_ptrs[(size_t)r];
+            continue;
+        }
+        EP_HOST_ASSERT_S(handles[(size_t)r].size() == sizeof(hipIpcMemHandle_t), "bad ipc handle from rank ", r);
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles[(size_t)r].data(), sizeof(h));
+        void *p = nullptr;
+        HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        peer_base[(size_t)r] = (uint8_t *)p;
+        peer_opened[(size_t)r] = true;
+    }
+    available = true;
+}
+
+void Buffer::require_available() const
+{
+    if (!available)
+        throw EPException("Assertion", __FILE__, __LINE__,
+                          "deep_ep_cpp.Buffer used before sync(): peers' windows are not mapped");
+}
+
+uint8_t *Buffer::region(int family, uint64_t epoch) const
+{
+    return window + kCtrlBytes + (size_t)(family * 2 + (int)(epoch & 1)) * region_bytes;
+}
+
+std::vector<void *> Buffer::peer_ptrs(size_t offset) const
+{
+    std::vector<void *> v((size_t)num_ranks);
+    for (size_t r = 0; r < (size_t)num_ranks; ++r) v[r] = peer_base[r] + offset;
+    return v;
+}
+
+void Buffer::check_status(const char *where)
+{
+    const int32_t s = __atomic_load_n(status_host, __ATOMIC_ACQUIRE);
+    if (s != 0) {
+        __atomic_store_n(status_host, 0, __ATOMIC_RELEASE);
+        throw EPException("Timeout", __FILE__, __LINE__,
+                          ep_concat(where, ": a peer did not arrive within DEEPEP_TIMEOUT_MS=", timeout_ms, " (code ", s,
+                                    ", rank ", rank, ")"));
+    }
+}
+
+int64_t Buffer::wait_summary(const char *where)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+        const int32_t v = __atomic_load_n(summary_host, __ATOMIC_ACQUIRE);
+        if (v >= 0) return v;
+        if ((spins & 0xFFF) == 0xFFF) {
+            check_status(where);
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > 2ll * timeout_ms)
+                throw EPException("Timeout", __FILE__, __LINE__, ep_concat(where, ": notify summary never arrived"));
+            hipError_t q = hipStreamQuery(cur_stream());
+            if (q != hipSuccess && q != hipErrorNotReady) HIP_CHECK(q);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1  get_dispatch_layout  (reference deep_ep.cpp:111-180)
+// ------------------------------------------------------------------------------------------------
+Buffer::Layout Buffer::run_layout(const at::Tensor &topk_idx, int num_experts)
+{
+    EP_HOST_ASSERT(topk_idx.dim() == 2);
+    EP_HOST_ASSERT(topk_idx.is_contiguous());
+    EP_HOST_ASSERT(topk_idx.is_cuda());
+    EP_HOST_ASSERT(topk_idx.scalar_type() == at::kLong or topk_idx.scalar_type() == at::kInt);
+    EP_HOST_ASSERT(num_experts > 0);
+    EP_HOST_ASSERT_S(num_experts % num_ranks == 0, "num_experts (", num_experts, ") must be a multiple of num_ranks (",
+                     num_ranks, ")");
+    const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1);
+    EP_HOST_ASSERT_S(T >= 0 && T <= kMaxTotalTokens, "num_tokens (", T, ") must be in the range [0, ", kMaxTotalTokens, "].");
+    EP_HOST_ASSERT_S(K >= 1 && K <= MI_EP_MAX_TOPK, "num_topk (", K, ") must be in [1, ", MI_EP_MAX_TOPK, "]");
+    auto i32 = at::dtype(at::kInt).device(topk_idx.device());
+    Layout l;
+    l.T = T, l.K = K, l.E = num_experts, l.idx_ptr = topk_idx.data_ptr();
+    l.num_tokens_per_expert = at::empty({num_experts}, i32);
+    l.num_tokens_per_rank = at::empty({num_ranks}, i32);
+    l.is_token_in_rank = at::empty({T, num_ranks}, i32);
+    l.send_token_idx_small = at::empty({T, K}, i32);
+    l.send_data_offset = at::empty({num_experts}, i32);
+    const size_t wsb = mi_ep_dispatch_layout_workspace(T, K, num_experts);
+    l.workspace = at::empty({(int64_t)wsb}, at::dtype(at::kByte).device(topk_idx.device()));
+    MI_EP_CHECK(mi_ep_dispatch_layout(topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, T, K, num_experts,
+                                      (int)num_ranks, l.num_tokens_per_rank.data_ptr<int>(),
+                                      l.num_tokens_per_expert.data_ptr<int>(), l.is_token_in_rank.data_ptr<int>(),
+                                      l.send_token_idx_small.data_ptr<int>(), l.send_data_offset.data_ptr<int>(),
+                                      l.workspace.data_ptr(), wsb, cur_stream()));
+    return l;
+}
+
+const Buffer::Layout &Buffer::layout_for(const at::Tensor &topk_idx, int num_experts)
+{
+    // The reference silently reuses whatever get_dispatch_layout stashed last (deep_ep.cpp:170-172,321).  We reuse the
+    // stash only when it was computed for this very tensor; otherwise the layout is recomputed (one extra ~30 us
+    // kernel chain), which removes the hidden ordering requirement without changing results.
+    if (stash.idx_ptr != topk_idx.data_ptr() || stash.T != topk_idx.size(0) || stash.K != topk_idx.size(1) ||
+        stash.E != num_experts)
+        stash = run_layout(topk_idx, num_experts);
+    return stash;
+}
+
+std::tuple<at::Tensor, std::optional<at::Tensor>, at::Tensor, at::Tensor, std::optional<EventHandle>>
+Buffer::get_dispatch_layout(const at::Tensor &topk_idx, int num_experts, std::optional<EventHandle> &, bool, bool)
+{
+    stash = run_layout(topk_idx, num_experts);
+    return {stash.num_tokens_per_rank, std::nullopt, stash.num_tokens_per_expert, stash.is_token_in_rank, std::nullopt};
+}
+
+at::Tensor Buffer::get_notify_send_data()
+{
+    // The reference returns an Ascend910B-only staging payload (deep_ep.cpp:142-164,182-185).  The part of it that is
+    // meaningful on a single xGMI node -- "the number of tokens every expert receives from this rank" -- is returned.
+    EP_HOST_ASSERT_S(stash.T >= 0, "get_dispatch_layout has not been called");
+    return stash.num_tokens_per_expert;
+}
+
+void Buffer::clean_low_latency_buffer(int, int, int) {}   // no-op, as in the reference (buffer.py:267-283)
+
+// ------------------------------------------------------------------------------------------------
+// A2 + A3  intranode_dispatch  (reference deep_ep.cpp:197-416)
+// ------------------------------------------------------------------------------------------------
+std::tuple<at::Tensor, std::optional<at::Tensor>, std::optional<at::Tensor>, std::optional<at::Tensor>, std::vector<int>,
+           at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::optional<EventHandle>>
+Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> &x_scales,
+                           const std::optional<at::Tensor> &topk_idx, const std::optional<at::Tensor> &topk_weights,
+                           const std::optional<at::Tensor> &num_tokens_per_rank, const at::Tensor &is_token_in_rank,
+                           const std::optional<at::Tensor> &num_tokens_per_expert, int, const std::optional<at::Tensor> &,
+                           const std::optional<at::Tensor> &, const std::optional<at::Tensor> &dispatch_wait_recv_cost_stats,
+                           int expert_alignment, int num_worst_tokens, const Config &config,
+                           std::optional<EventHandle> &, bool, bool, bool use_quant, const std::string &quant_type)
+{
+    require_available();
+    EP_HOST_ASSERT(config.num_sms % 2 == 0);
+    const int num_channels = config.num_sms / 2;
+    EP_HOST_ASSERT(num_tokens_per_rank.has_value());
+    EP_HOST_ASSERT(num_tokens_per_expert.has_value());
+    EP_HOST_ASSERT(num_tokens_per_expert->scalar_type() == at::kInt);
+    EP_HOST_ASSERT(num_tokens_per_rank->scalar_type() == at::kInt);
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous());
+    EP_HOST_ASSERT(x.scalar_type() == at::kBFloat16);
+    EP_HOST_ASSERT(!x_scales.has_value());      // pre-quantised MXFP8 input is Ascend950-only
+    EP_HOST_ASSERT(num_tokens_per_expert->dim() == 1 and num_tokens_per_expert->is_contiguous());
+    EP_HOST_ASSERT(num_tokens_per_expert->size(0) % num_ranks == 0);
+    EP_HOST_ASSERT(num_tokens_per_rank->dim() == 1 and num_tokens_per_rank->is_contiguous());
+    EP_HOST_ASSERT(num_tokens_per_rank->size(0) == num_ranks);
+    EP_HOST_ASSERT(expert_alignment == 1);
+    (void)is_token_in_rank;
+    const int T = (int)x.size(0), H = (int)x.size(1);
+    const int E = (int)num_tokens_per_expert->size(0);
+    const int W = (int)num_ranks, L = E / W;
+    EP_HOST_ASSERT(topk_idx.has_value());
+    EP_HOST_ASSERT(topk_weights.has_value());
+    EP_HOST_ASSERT(topk_idx->dim() == 2 and topk_idx->is_contiguous());
+    EP_HOST_ASSERT(topk_weights->dim() == 2 and topk_weights->is_contiguous());
+    EP_HOST_ASSERT(T == topk_idx->size(0));
+    const int K = (int)topk_idx->size(1);
+    EP_HOST_ASSERT(K == topk_weights->size(1));
+    EP_HOST_ASSERT(topk_weights->scalar_type() == at::kFloat);
+    EP_HOST_ASSERT_S(H % 16 == 0 && H <= MI_EP_MAX_HIDDEN, "hidden (", H, ") must be a multiple of 16 and <= ", MI_EP_MAX_HIDDEN);
+    EP_HOST_ASSERT_S(E <= 2048, "num_experts (", E, ") must be <= 2048");
+    const int qm = quant_mode_of(use_quant, quant_type);
+    const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
+    EP_HOST_ASSERT_S((size_t)T * K * rb <= region_bytes, "dispatch window too small: need ", (size_t)T * K * rb,
+                     " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
+    check_status("intranode_dispatch");
+    const Layout &lay = layout_for(*topk_idx, E);
+    hipStream_t st = cur_stream();
+    auto dev = x.device();
+    auto i32 = at::dtype(at::kInt).device(dev);
+    const uint64_t ep = ++dispatch_epoch;
+    const int par = (int)(ep & 1);
+
+    // sender side: stage into the own window, publish counts, raise the "staged" flag on every peer
+    uint8_t *my_rows = region(kDispatch, ep);
+    MI_EP_CHECK(mi_ep_dispatch_stage(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
+                                     lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
+                                     H, E, (int)rank, qm, my_rows, st));
+    auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
+    MI_EP_CHECK(mi_ep_notify_post((uint64_t *const *)notify_peers.data(), W, (int)rank, E,
+                                  lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, st));
+    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
+    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
+
+    // receiver side: counts -> tables (+ pinned summary for the host)
+    auto cnt = at::empty({W, E + 1}, i32);
+    MI_EP_CHECK(mi_ep_notify_wait((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), W, E, (uint32_t)ep,
+                                  cnt.data_ptr<int>(), status_dev, timeout_ms, st));
+    auto recv_count = at::empty({E}, i32), recv_offset = at::empty({E}, i32);
+    auto recv_tokens_per_expert = at::empty({L}, i32), expert_global_offset = at::empty({L}, i32);
+    auto srcrank_in_expert_offset = at::empty({E}, i32), r_in_srcrank_offset = at::empty({E}, i32);
+    auto total_recv_token = at::empty({1}, i32), max_bs = at::empty({1}, i32), pull_offset = at::empty({E}, i32);
+    const bool host_sync = num_worst_tokens <= 0;
+    if (host_sync) __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
+    MI_EP_CHECK(mi_ep_notify_tables(cnt.data_ptr<int>(), W, E, (int)rank, 0, recv_count.data_ptr<int>(),
+                                    recv_offset.data_ptr<int>(), recv_tokens_per_expert.data_ptr<int>(),
+                                    expert_global_offset.data_ptr<int>(), srcrank_in_expert_offset.data_ptr<int>(),
+                                    r_in_srcrank_offset.data_ptr<int>(), total_recv_token.data_ptr<int>(),
+                                    max_bs.data_ptr<int>(), pull_offset.data_ptr<int>(), host_sync ? summary_dev : nullptr, st));
+    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), W, ep, status_dev,
+                           timeout_ms, st));
+
+    int64_t trt;
+    std::vector<int> num_recv_tokens_per_expert_list;
+    if (host_sync) {
+        trt = wait_summary("intranode_dispatch");
+        real_max_bs = __atomic_load_n(summary_host + 1, __ATOMIC_RELAXED);
+        // counts, or inclusive cumsum when MOE_EXPERT_TOKEN_NUMS_TYPE=0 (deep_ep.cpp:311-312,384-401)
+        const int type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
+        EP_HOST_ASSERT(type == 1 or type == 0);
+        int run = 0;
+        for (int le = 0; le < L; ++le) {
+            const int c = __atomic_load_n(summary_host + 2 + le, __ATOMIC_RELAXED);
+            run = (type == 0) ? run + c : c;
+            num_recv_tokens_per_expert_list.push_back(run);
+        }
+    } else {
+        // DeepEP's graph-friendly mode: worst-case sized outputs, no host sync, empty list (buffer.py:337-338,356-358)
+        trt = num_worst_tokens;
+        real_max_bs = std::max<int64_t>(real_max_bs, num_worst_tokens);
+    }
+    const int64_t rows = trt == 0 ? 1 : trt;      // deep_ep.cpp:327-328
+    at::Tensor expandx_out = use_quant ? at::empty({rows, H}, at::dtype(at::kChar).device(dev)) : at::empty({rows, H}, x.options());
+    at::Tensor dynamic_scales_out = at::empty({rows}, at::dtype(at::kFloat).device(dev));
+    at::Tensor expand_idx_out = at::empty({rows * 3}, i32);
+    std::optional<at::Tensor> recv_topk_idx = at::empty({trt, K}, topk_idx->options());       // allocated, never written
+    std::optional<at::Tensor> recv_topk_weights = at::empty({trt, K}, topk_weights->options());  // (deep_ep.cpp:371-374)
+    auto src_peers = peer_ptrs((size_t)(region(kDispatch, ep) - window));
+    MI_EP_CHECK(mi_ep_dispatch_pull((const void *const *)src_peers.data(), recv_count.data_ptr<int>(),
+                                    pull_offset.data_ptr<int>(), W, L, H, qm, (int)trt, expandx_out.data_ptr(),
+                                    use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr,
+                                    expand_idx_out.data_ptr<int>(), st));
+    if (dispatch_wait_recv_cost_stats.has_value()) {
+        EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->scalar_type() == at::kInt);
+        EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->dim() == 1 and dispatch_wait_recv_cost_stats->size(0) == num_ranks);
+    }
+    // placeholders kept for handle-shape compatibility (uninitialised in the reference, deep_ep.cpp:220-222)
+    auto rank_prefix_matrix = at::zeros({W, W}, i32);
+    auto channel_prefix_matrix = at::zeros({W, num_channels}, i32);
+    auto recv_channel_prefix_matrix = at::zeros({W, num_channels}, i32);
+    return {expandx_out, dynamic_scales_out, recv_topk_idx, recv_topk_weights, num_recv_tokens_per_expert_list,
+            rank_prefix_matrix, channel_prefix_matrix, recv_channel_prefix_matrix, expand_idx_out, recv_count, std::nullopt};
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>
+Buffer::notify_verify(const at::Tensor &x, const std::optional<at::Tensor> &, const std::optional<at::Tensor> &topk_idx,
+                      const std::optional<at::Tensor> &, const std::optional<at::Tensor> &, const at::Tensor &,
+                      const std::optional<at::Tensor> &num_tokens_per_expert, int, const std::optional<at::Tensor> &,
+                      const std::optional<at::Tensor> &, const std::optional<at::Tensor> &, int, int, const Config &,
+                      std::optional<EventHandle> &, bool, bool, bool)
+{
+    // Test-only entry of the reference (deep_ep.cpp:418-550): run the notify exchange alone and return its tables
+    // (recv_data, recv_count, recv_offset, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset,
+    //  total_recv_token, max_bs, recv_tokens_per_expert).
+    require_available();
+    EP_HOST_ASSERT(topk_idx.has_value() and num_tokens_per_expert.has_value());
+    const int T = (int)x.size(0);
+    const int E = (int)num_tokens_per_expert->size(0), W = (int)num_ranks, L = E / W;
+    const Layout &lay = layout_for(*topk_idx, E);
+    hipStream_t st = cur_stream();
+    auto i32 = at::dtype(at::kInt).device(x.device());
+    const uint64_t ep = ++dispatch_epoch;
+    const int par = (int)(ep & 1);
+    auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
+    MI_EP_CHECK(mi_ep_notify_post((uint64_t *const *)notify_peers.data(), W, (int)rank, E,
+                                  lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, st));
+    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
+    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
+    auto cnt = at::empty({W, E + 1}, i32);
+    MI_EP_CHECK(mi_ep_notify_wait((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), W, E, (uint32_t)ep,
+                                  cnt.data_ptr<int>(), status_dev, timeout_ms, st));
+    auto recv_count = at::empty({E}, i32), recv_offset = at::empty({E}, i32);
+    auto recv_tokens_per_expert = at::empty({L}, i32), expert_global_offset = at::empty({L}, i32);
+    auto srcrank_in_expert_offset = at::empty({E}, i32), r_in_srcrank_offset = at::empty({E}, i32);
+    auto total_recv_token = at::empty({1}, i32), max_bs = at::empty({1}, i32), pull_offset = at::empty({E}, i32);
+    MI_EP_CHECK(mi_ep_notify_tables(cnt.data_ptr<int>(), W, E, (int)rank, 0, recv_count.data_ptr<int>(),
+                                    recv_offset.data_ptr<int>(), recv_tokens_per_expert.data_ptr<int>(),
+                                    expert_global_offset.data_ptr<int>(), srcrank_in_expert_offset.data_ptr<int>(),
+                                    r_in_srcrank_offset.data_ptr<int>(), total_recv_token.data_ptr<int>(),
+                                    max_bs.data_ptr<int>(), pull_offset.data_ptr<int>(), nullptr, st));
+    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), W, ep, status_dev,
+                           timeout_ms, st));
+    return {cnt, recv_count, recv_offset, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset,
+            total_recv_token, max_bs, recv_tokens_per_expert};
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4  intranode_combine  (reference deep_ep.cpp:552-608)
+// ------------------------------------------------------------------------------------------------
+std::tuple<at::Tensor, std::optional<at::Tensor>, std::optional<EventHandle>>
+Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const std::optional<at::Tensor> &topk_weights,
+                          const at::Tensor &src_idx, const at::Tensor &send_head,
+                          const std::optional<at::Tensor> &combine_send_cost_stats)
+{
+    require_available();
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous());
+    EP_HOST_ASSERT(x.scalar_type() == at::kBFloat16);
+    EP_HOST_ASSERT(topk_idx.dim() == 2 and topk_idx.is_contiguous());
+    EP_HOST_ASSERT(src_idx.scalar_type() == at::kInt and send_head.scalar_type() == at::kInt);
+    const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), H = (int)x.size(1);
+    const int W = (int)num_ranks, E = (int)send_head.size(0);
+    if (topk_weights.has_value()) {
+        EP_HOST_ASSERT(topk_weights->scalar_type() == at::kFloat and topk_weights->is_contiguous());
+        EP_HOST_ASSERT(topk_weights->size(0) == T and topk_weights->size(1) == K);
+    }
+    if (combine_send_cost_stats.has_value()) {
+        EP_HOST_ASSERT(combine_send_cost_stats->scalar_type() == at::kInt);
+        EP_HOST_ASSERT(combine_send_cost_stats->dim() == 1 and combine_send_cost_stats->size(0) == num_ranks);
+    }
+    const size_t cb = mi_ep_combine_row_bytes(H);
+    // every rank's slot area must fit the largest per-rank batch (real_max_bs from the matching dispatch)
+    const int64_t max_rows = std::max<int64_t>((int64_t)T, real_max_bs) * K;
+    EP_HOST_ASSERT_S((size_t)max_rows * cb <= region_bytes, "combine window too small: need ", (size_t)max_rows * cb,
+                     " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
+    check_status("intranode_combine");
+    hipStream_t st = cur_stream();
+    const uint64_t ep = ++combine_epoch;
+    auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
+    // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
+    MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1),
+                                   (int)x.size(0), H, K, dst_peers.data(), W, st));
+    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
+    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
+    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, ep, status_dev,
+                           timeout_ms, st));
+    auto combined_x = at::empty({T, H}, x.options());
+    MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                     topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, nullptr, nullptr,
+                                     T, K, H, E, combined_x.data_ptr(), st));
+    return {combined_x, std::nullopt, std::nullopt};
+}
+
+// ------------------------------------------------------------------------------------------------
+// A5  low_latency_dispatch  (reference deep_ep.cpp:850-1012)
+// ------------------------------------------------------------------------------------------------
+std::tuple<at::Tensor, std::optional<at::Tensor>, at::Tensor, at::Tensor, at::Tensor, std::optional<EventHandle>,
+           std::optional<std::function<void()>>>
+Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, const std::optional<at::Tensor> &,
+                             int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts, bool, bool, bool, bool, bool,
+                             bool, const std::string &quant_mode_name)
+{
+    require_available();
+    EP_HOST_ASSERT(low_latency_mode);
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
+    EP_HOST_ASSERT(num_max_dispatch_tokens_per_rank >= x.size(0));
+    EP_HOST_ASSERT(topk_idx.dim() == 2 and topk_idx.is_contiguous() and topk_idx.size(0) == x.size(0));
+    EP_HOST_ASSERT(num_experts % num_ranks == 0);
+    const int T = (int)x.size(0), H = (int)x.size(1), K = (int)topk_idx.size(1);
+    const int W = (int)num_ranks, E = (int)num_experts, L = E / W, MT = (int)num_max_dispatch_tokens_per_rank;
+    int qm;
+    if (quant_mode_name == "int8") qm = MI_EP_QUANT_INT8_NOEPS;
+    else {
+        const bool a5_only = quant_mode_name == "mx_fp8_e4m3" || quant_mode_name == "mx_fp8_e5m2" ||
+                             quant_mode_name == "mx_fp4_e2m1" || quant_mode_name == "pertoken_fp8_e4m3";
+        EP_HOST_ASSERT_S(!a5_only, quant_mode_name, " is not supported on this device, please use int8 or bf16 instead.");
+        EP_HOST_ASSERT(quant_mode_name == "none");
+        qm = MI_EP_QUANT_NONE;
+    }
+    EP_HOST_ASSERT_S(H % 16 == 0 && H <= MI_EP_MAX_HIDDEN, "hidden (", H, ") must be a multiple of 16 and <= ", MI_EP_MAX_HIDDEN);
+    EP_HOST_ASSERT_S(E <= 2048 && K <= MI_EP_MAX_TOPK, "num_experts <= 2048 and num_topk <= ", MI_EP_MAX_TOPK);
+    const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
+    EP_HOST_ASSERT_S((size_t)L * W * MT * rb <= region_bytes, "low-latency window too small: need ", (size_t)L * W * MT * rb,
+                     " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
+    check_status("low_latency_dispatch");
+    const int64_t num_max_tokens = (int64_t)MT * W * std::min(K, L);       // deep_ep.cpp:867-873
+    const int64_t max_size = std::max<int64_t>((int64_t)T * K, num_max_tokens * 128);   // deep_ep.cpp:875
+    auto dev = x.device();
+    auto i32 = at::dtype(at::kInt).device(dev);
+    at::Tensor packed_recv_x, packed_recv_x_scales;
+    if (qm == MI_EP_QUANT_NONE) {
+        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(at::kBFloat16).device(dev));
+        packed_recv_x_scales = at::empty({1}, at::dtype(at::kFloat).device(dev));
+    } else {
+        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(at::kChar).device(dev));
+        packed_recv_x_scales = at::empty({num_max_tokens}, at::dtype(at::kFloat).device(dev));
+    }
+    auto expand_idx = at::empty({max_size}, i32);
+    auto ep_recv_count = at::empty({(int64_t)L * W}, i32);
+    auto packed_recv_count = at::empty({L}, at::dtype(at::kLong).device(dev));
+    const int count_type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
+    hipStream_t st = cur_stream();
+    const Layout lay = run_layout(topk_idx, E);
+    const uint64_t ep = ++ll_epoch;
+    const int par = (int)(ep & 1);
+    auto row_peers = peer_ptrs((size_t)(region(kLLDispatch, ep) - window));
+    MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                       lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm,
+                                       row_peers.data(), st));
+    auto cnt_peers = peer_ptrs((size_t)(kOffLLCounts + par * kLLCountsParityBytes));
+    MI_EP_CHECK(mi_ep_ll_post_counts((uint64_t *const *)cnt_peers.data(), lay.num_tokens_per_expert.data_ptr<int>(), E, W,
+                                     (int)rank, (uint32_t)ep, st));
+    MI_EP_CHECK(mi_ep_ll_dispatch_recv(region(kLLDispatch, ep), (const uint64_t *)(window + kOffLLCounts + par * kLLCountsParityBytes),
+                                       (uint32_t)ep, W, L, MT, H, qm, count_type, packed_recv_x.data_ptr(),
+                                       qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(),
+                                       (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(),
+                                       ep_recv_count.data_ptr<int>(), status_dev, timeout_ms, st));
+    real_max_bs = std::max<int64_t>(real_max_bs, MT);
+    return {packed_recv_x, packed_recv_x_scales, packed_recv_count, expand_idx, ep_recv_count, std::nullopt,
+            std::function<void()>([] {})};
+}
+
+// ------------------------------------------------------------------------------------------------
+// A6  low_latency_combine  (reference deep_ep.cpp:1014-1087)
+// ------------------------------------------------------------------------------------------------
+std::tuple<at::Tensor, std::optional<EventHandle>, std::optional<std::function<void()>>>
+Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, const at::Tensor &topk_weights,
+                            const at::Tensor &src_info, const at::Tensor &layout_range,
+                            int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts, const at::Tensor &, bool, bool,
+                            bool, const std::optional<at::Tensor> &)
+{
+    require_available();
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
+    EP_HOST_ASSERT(num_max_dispatch_tokens_per_rank >= topk_idx.size(0));
+    EP_HOST_ASSERT(topk_idx.dim() == 2 and topk_idx.is_contiguous());
+    EP_HOST_ASSERT(topk_weights.dim() == 2 and topk_weights.is_contiguous() and topk_weights.scalar_type() == at::kFloat);
+    EP_HOST_ASSERT(topk_weights.size(0) == topk_idx.size(0) and topk_weights.size(1) == topk_idx.size(1));
+    EP_HOST_ASSERT(src_info.scalar_type() == at::kInt and layout_range.scalar_type() == at::kInt);
+    const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), H = (int)x.size(1);
+    const int W = (int)num_ranks, E = (int)num_experts;
+    const size_t cb = mi_ep_combine_row_bytes(H);
+    EP_HOST_ASSERT_S((size_t)num_max_dispatch_tokens_per_rank * K * cb <= region_bytes, "combine window too small; raise DEEPEP_WINDOW_BYTES");
+    check_status("low_latency_combine");
+    hipStream_t st = cur_stream();
+    const uint64_t ep = ++combine_epoch;
+    auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
+    // valid packed rows = layout_range[L*W-1], read on device
+    MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
+                                   (int)x.size(0), H, K, dst_peers.data(), W, st));
+    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
+    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
+    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, ep, status_dev,
+                           timeout_ms, st));
+    // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
+    auto combined_x = at::empty({T, H}, x.options());
+    MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                     topk_weights.data_ptr<float>(), nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), st));
+    return {combined_x, std::nullopt, std::function<void()>([] {})};
+}
+
+void Buffer::internode_unsupported() const
+{
+    throw EPException("Assertion", __FILE__, __LINE__,
+                      "internode (multi-node RDMA) dispatch/combine is out of scope: one MI355X xGMI node is a single rdma rank");
+}
+
+std::vector<at::Tensor> Buffer::fused_deep_moe(const at::Tensor &, const at::Tensor &, const at::Tensor &, const at::Tensor &,
+                                               const at::Tensor &, const at::Tensor &, const std::optional<at::Tensor> &,
+                                               int64_t, int64_t, int64_t, bool)
+{
+    throw EPException("Assertion", __FILE__, __LINE__, "fused_deep_moe: not implemented in this build (SURVEY.md section 8(f) N1)");
+}
+
+std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &, const at::Tensor &, const at::Tensor &, const at::Tensor &,
+                                                     const at::Tensor &, const at::Tensor &, const std::optional<at::Tensor> &,
+                                                     int64_t, int64_t, int64_t)
+{
+    throw EPException("Assertion", __FILE__, __LINE__, "dispatch_ffn_combine: not implemented in this build (SURVEY.md section 8(f) N1)");
+}
+
+void Buffer::begin_profile(int64_t skip, int64_t active, const std::string &)
+{
+    // The reference's stage profiler is Ascend950-only (deep_ep.cpp:1237-1252).  On MI355X use rocprofv3; the call is
+    // accepted so callers need no change.
+    profile_skip = (int)skip, profile_active = (int)active, profiling = true;
+}
+void Buffer::end_profile() { profiling = false; }
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level entry points for the `alltoall` strategies
+// ------------------------------------------------------------------------------------------------
+std::tuple<at::Tensor, at::Tensor> Buffer::a2a_dispatch_stage(const at::Tensor &x, const at::Tensor &topk_idx,
+                                                              int64_t num_experts, const std::string &quant_type)
+{
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
+    const int T = (int)x.size(0), H = (int)x.size(1), K = (int)topk_idx.size(1), E = (int)num_experts;
+    const int qm = quant_mode_of(quant_type != "bf16", quant_type);
+    const Layout &lay = layout_for(topk_idx, E);
+    const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
+    auto rows = at::empty({std::max<int64_t>((int64_t)T * K, 1), (int64_t)rb}, at::dtype(at::kByte).device(x.device()));
+    MI_EP_CHECK(mi_ep_dispatch_stage(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                     lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K, H,
+                                     E, (int)rank, qm, rows.data_ptr(), cur_stream()));
+    auto cnt_vec = at::empty({E + 1}, at::dtype(at::kInt).device(x.device()));
+    cnt_vec.narrow(0, 0, E).copy_(lay.num_tokens_per_expert);
+    cnt_vec.narrow(0, E, 1).fill_(T);
+    return {rows, cnt_vec};
+}
+
+std::tuple<at::Tensor, at::Tensor, std::vector<int64_t>, std::vector<int64_t>, std::vector<int>, int64_t, int64_t>
+Buffer::a2a_dispatch_tables(const at::Tensor &cnt_matrix)
+{
+    EP_HOST_ASSERT(cnt_matrix.dim() == 2 and cnt_matrix.is_contiguous() and cnt_matrix.scalar_type() == at::kInt);
+    const int W = (int)num_ranks, E = (int)cnt_matrix.size(1) - 1, L = E / W;
+    EP_HOST_ASSERT(cnt_matrix.size(0) == W and E % W == 0);
+    auto i32 = at::dtype(at::kInt).device(cnt_matrix.device());
+    auto recv_count = at::empty({E}, i32), recv_offset = at::empty({E}, i32), per_e = at::empty({L}, i32);
+    auto ego = at::empty({L}, i32), sie = at::empty({E}, i32), ris = at::empty({E}, i32), total = at::empty({1}, i32);
+    auto max_bs = at::empty({1}, i32), pull_offset = at::empty({E}, i32);
+    MI_EP_CHECK(mi_ep_notify_tables(cnt_matrix.data_ptr<int>(), W, E, (int)rank, 1, recv_count.data_ptr<int>(),
+                                    recv_offset.data_ptr<int>(), per_e.data_ptr<int>(), ego.data_ptr<int>(),
+                                    sie.data_ptr<int>(), ris.data_ptr<int>(), total.data_ptr<int>(), max_bs.data_ptr<int>(),
+                                    pull_offset.data_ptr<int>(), nullptr, cur_stream()));
+    auto host = cnt_matrix.to(at::kCPU);          // the one host sync of this transport
+    const int32_t *c = host.data_ptr<int32_t>();
+    std::vector<int64_t> send_rows((size_t)W, 0), recv_rows((size_t)W, 0);
+    std::vector<int> per_expert((size_t)L, 0);
+    int64_t tot = 0, mb = 0;
+    for (int r = 0; r < W; ++r) {
+        for (int le = 0; le < L; ++le) {
+            send_rows[(size_t)r] += c[(size_t)rank * (E + 1) + r * L + le];
+            const int v = c[(size_t)r * (E + 1) + (int)rank * L + le];
+            recv_rows[(size_t)r] += v;
+            per_expert[(size_t)le] += v;
+            tot += v;
+        }
+        mb = std::max<int64_t>(mb, c[(size_t)r * (E + 1) + E]);
+    }
+    real_max_bs = mb;
+    return {recv_count, pull_offset, send_rows, recv_rows, per_expert, tot, mb};
+}
+
+std::tuple<at::Tensor, std::optional<at::Tensor>, at::Tensor>
+Buffer::a2a_dispatch_unpack(const at::Tensor &staging, const std::vector<int64_t> &recv_rows_per_rank,
+                            const at::Tensor &recv_count, const at::Tensor &pull_offset, int64_t hidden, int64_t total_recv,
+                            const std::string &quant_type, int64_t min_rows, int64_t src_idx_len)
+{
+    const int W = (int)num_ranks, E = (int)recv_count.size(0), L = E / W, H = (int)hidden;
+    const bool use_quant = quant_type != "bf16";
+    const int qm = quant_mode_of(use_quant, quant_type);
+    const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
+    EP_HOST_ASSERT((int64_t)recv_rows_per_rank.size() == W);
+    std::vector<const void *> bases((size_t)W);
+    int64_t off = 0;
+    for (int r = 0; r < W; ++r) {
+        bases[(size_t)r] = (const uint8_t *)staging.data_ptr() + (size_t)off * rb;
+        off += recv_rows_per_rank[(size_t)r];
+    }
+    EP_HOST_ASSERT(off == total_recv);
+    const int64_t rows = std::max<int64_t>(total_recv == 0 ? 1 : total_recv, min_rows);
+    auto dev = staging.device();
+    at::Tensor recv_x = use_quant ? at::empty({rows, H}, at::dtype(at::kChar).device(dev))
+                                  : at::empty({rows, H}, at::dtype(at::kBFloat16).device(dev));
+    at::Tensor scales = at::empty({rows}, at::dtype(at::kFloat).device(dev));
+    at::Tensor src_idx = at::empty({std::max<int64_t>(rows * 3, src_idx_len)}, at::dtype(at::kInt).device(dev));
+    MI_EP_CHECK(mi_ep_dispatch_pull(bases.data(), recv_count.data_ptr<int>(), pull_offset.data_ptr<int>(), W, L, H, qm,
+                                    (int)total_recv, recv_x.data_ptr(), use_quant ? scales.data_ptr<float>() : nullptr,
+                                    src_idx.data_ptr<int>(), cur_stream()));
+    return {recv_x, use_quant ? std::optional<at::Tensor>(scales) : std::nullopt, src_idx};
+}
+
+std::tuple<at::Tensor, std::vector<int64_t>> Buffer::a2a_combine_pack(const at::Tensor &x, const at::Tensor &send_head)
+{
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
+    const int W = (int)num_ranks, E = (int)send_head.size(0), L = E / W, H = (int)x.size(1);
+    auto packed = at::empty_like(x);
+    auto rows_per_src = at::empty({W}, at::dtype(at::kInt).device(x.device()));
+    MI_EP_CHECK(mi_ep_combine_pack(x.data_ptr(), send_head.data_ptr<int>(), W, L, H, (int)x.size(0), packed.data_ptr(),
+                                   rows_per_src.data_ptr<int>(), cur_stream()));
+    auto host = rows_per_src.to(at::kCPU);
+    std::vector<int64_t> v((size_t)W);
+    for (int r = 0; r < W; ++r) v[(size_t)r] = host.data_ptr<int32_t>()[r];
+    return {packed, v};
+}
+
+std::tuple<at::Tensor, at::Tensor, std::vector<int64_t>> Buffer::a2a_combine_prepare(const at::Tensor &topk_idx,
+                                                                                     int64_t num_experts)
+{
+    const Layout &lay = layout_for(topk_idx, (int)num_experts);
+    const int W = (int)num_ranks, L = (int)num_experts / W;
+    auto host = lay.num_tokens_per_expert.to(at::kCPU);
+    std::vector<int64_t> v((size_t)W, 0);
+    for (int r = 0; r < W; ++r)
+        for (int le = 0; le < L; ++le) v[(size_t)r] += host.data_ptr<int32_t>()[r * L + le];
+    return {lay.send_data_offset, lay.send_token_idx_small, v};
+}
+
+at::Tensor Buffer::a2a_combine_reduce(const at::Tensor &returned_rows, const at::Tensor &topk_idx,
+                                      const std::optional<at::Tensor> &topk_weights, const at::Tensor &send_data_offset,
+                                      const at::Tensor &send_token_idx_small, int64_t hidden, int64_t num_experts)
+{
+    const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), H = (int)hidden;
+    auto out = at::empty({T, H}, at::dtype(at::kBFloat16).device(topk_idx.device()));
+    MI_EP_CHECK(mi_ep_combine_reduce(returned_rows.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                     topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr,
+                                     send_data_offset.data_ptr<int>(), send_token_idx_small.data_ptr<int>(), T, K, H,
+                                     (int)num_experts, out.data_ptr(), cur_stream()));
+    return out;
+}
+
+}  // namespace deep_ep

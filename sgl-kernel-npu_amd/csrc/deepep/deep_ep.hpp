@@ -1,0 +1,173 @@
+// MI355X host runtime behind `deep_ep.Buffer` (pybind module deep_ep_cpp).
+// Drop-in for the reference's deep_ep::Buffer (csrc/deepep/deep_ep.hpp:18-143, pybind_extension.cpp:31-55): same
+// constructor, same method names, same positional argument orders and return tuples.  Device work is the HIP kernels
+// of include/mi_ep.h; the HCCL window is replaced by a hipIpc-mapped symmetric window over xGMI.
+#pragma once
+#include <array>
+#include <functional>
+#include <optional>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include <ATen/ATen.h>
+#include <hip/hip_runtime_api.h>
+
+#include "config.hpp"
+#include "exception.hpp"
+
+namespace deep_ep {
+
+class Buffer {
+public:
+    Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t num_rdma_bytes, bool low_latency_mode,
+           std::string moe_all_to_all_group_name);
+    ~Buffer() noexcept(false);
+
+    // ---- MI355X bootstrap of the symmetric window (the reference gets its window from HCCL by group name,
+    // buffer.py:67-83; here Python all-gathers these handles over the ProcessGroup, like upstream DeepEP's
+    // get_local_ipc_handle()/sync()).
+    int get_local_device_id() const { return device_id; }
+    std::string get_local_ipc_handle() const;         // hipIpcMemHandle_t bytes
+    int64_t get_local_window_ptr() const { return (int64_t)window; }
+    int64_t get_window_bytes() const { return window_bytes; }
+    // handles[r]: ipc handle bytes of rank r (ignored for r == rank or when local_ptrs[r] != 0);
+    // local_ptrs[r]: window base of rank r when it lives in this process, else 0.
+    void sync(const std::vector<std::string> &handles, const std::vector<int64_t> &local_ptrs);
+
+    bool is_available() const { return available; }
+    int get_num_rdma_ranks() const { return 1; }
+    int get_rdma_rank() const { return 0; }
+
+    std::tuple<at::Tensor, std::optional<at::Tensor>, at::Tensor, at::Tensor, std::optional<EventHandle>>
+    get_dispatch_layout(const at::Tensor &topk_idx, int num_experts, std::optional<EventHandle> &previous_event,
+                        bool async, bool allocate_on_comm_stream);
+    at::Tensor get_notify_send_data();
+    void clean_low_latency_buffer(int num_max_dispatch_tokens_per_rank, int hidden, int num_experts);
+
+    std::tuple<at::Tensor, std::optional<at::Tensor>, std::optional<at::Tensor>, std::optional<at::Tensor>,
+               std::vector<int>, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::optional<EventHandle>>
+    intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> &x_scales,
+                       const std::optional<at::Tensor> &topk_idx, const std::optional<at::Tensor> &topk_weights,
+                       const std::optional<at::Tensor> &num_tokens_per_rank, const at::Tensor &is_token_in_rank,
+                       const std::optional<at::Tensor> &num_tokens_per_expert, int cached_num_recv_tokens,
+                       const std::optional<at::Tensor> &cached_rank_prefix_matrix,
+                       const std::optional<at::Tensor> &cached_channel_prefix_matrix,
+                       const std::optional<at::Tensor> &dispatch_wait_recv_cost_stats, int expert_alignment,
+                       int num_worst_tokens, const Config &config, std::optional<EventHandle> &previous_event, bool async,
+                       bool allocate_on_comm_stream, bool use_quant, const std::string &quant_type);
+
+    std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>
+    notify_verify(const at::Tensor &x, const std::optional<at::Tensor> &x_scales, const std::optional<at::Tensor> &topk_idx,
+                  const std::optional<at::Tensor> &topk_weights, const std::optional<at::Tensor> &num_tokens_per_rank,
+                  const at::Tensor &is_token_in_rank, const std::optional<at::Tensor> &num_tokens_per_expert,
+                  int cached_num_recv_tokens, const std::optional<at::Tensor> &cached_rank_prefix_matrix,
+                  const std::optional<at::Tensor> &cached_channel_prefix_matrix,
+                  const std::optional<at::Tensor> &dispatch_wait_recv_cost_stats, int expert_alignment,
+                  int num_worst_tokens, const Config &config, std::optional<EventHandle> &previous_event, bool async,
+                  bool allocate_on_comm_stream, bool use_quant);
+
+    std::tuple<at::Tensor, std::optional<at::Tensor>, std::optional<EventHandle>>
+    intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const std::optional<at::Tensor> &topk_weights,
+                      const at::Tensor &src_idx, const at::Tensor &send_head,
+                      const std::optional<at::Tensor> &combine_send_cost_stats);
+
+    std::tuple<at::Tensor, std::optional<at::Tensor>, at::Tensor, at::Tensor, at::Tensor, std::optional<EventHandle>,
+               std::optional<std::function<void()>>>
+    low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx,
+                         const std::optional<at::Tensor> &cumulative_local_expert_recv_stats,
+                         int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts, bool use_fp8, bool round_scale,
+                         bool use_ue8m0, bool use_mxfp4, bool async, bool return_recv_hook,
+                         const std::string &quant_mode_name);
+
+    std::tuple<at::Tensor, std::optional<EventHandle>, std::optional<std::function<void()>>>
+    low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, const at::Tensor &topk_weights,
+                        const at::Tensor &src_info, const at::Tensor &layout_range,
+                        int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts,
+                        const at::Tensor &packed_recv_count, bool zero_copy, bool async, bool return_recv_hook,
+                        const std::optional<at::Tensor> &out);
+
+    // Multi-node entry points of the reference (Ascend910B layered HCCS+RDMA): one 8-GPU xGMI node has a single
+    // "rdma rank", so these are never reached through deep_ep.Buffer; calling them directly is an error.
+    void internode_unsupported() const;
+
+    std::vector<at::Tensor> fused_deep_moe(const at::Tensor &x, const at::Tensor &expert_ids,
+                                           const at::Tensor &gmm1_permuted_weight,
+                                           const at::Tensor &gmm1_permuted_weight_scale, const at::Tensor &gmm2_weight,
+                                           const at::Tensor &gmm2_weight_scale,
+                                           const std::optional<at::Tensor> &expert_scales_optional,
+                                           int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts,
+                                           int64_t quant_mode, bool profile_enable);
+    std::vector<at::Tensor> dispatch_ffn_combine(const at::Tensor &x, const at::Tensor &expert_ids,
+                                                 const at::Tensor &gmm1_weight, const at::Tensor &gmm1_scale,
+                                                 const at::Tensor &gmm2_weight, const at::Tensor &gmm2_scale,
+                                                 const std::optional<at::Tensor> &expert_scales, int64_t max_output_size,
+                                                 int64_t num_experts, int64_t quant_mode);
+    void begin_profile(int64_t num_profile_skip_launches, int64_t num_profile_active_launches,
+                       const std::string &profile_trace_dir);
+    void end_profile();
+
+    // ---- kernel-level entry points used by the `alltoall` strategies (torch.distributed / RCCL moves the bytes,
+    // these pack and unpack them).  Mirrors what the reference's AlltoAll strategies get from torch_npu routing ops
+    // (strategies/normal_strategy.py:481-790).
+    std::tuple<at::Tensor, at::Tensor> a2a_dispatch_stage(const at::Tensor &x, const at::Tensor &topk_idx,
+                                                          int64_t num_experts, const std::string &quant_type);
+    // cnt_matrix [W, E+1] int32 on device -> (recv_count, pull_offset, send_rows_per_rank, recv_rows_per_rank,
+    //                                        recv_tokens_per_expert(list), total_recv, max_bs)
+    std::tuple<at::Tensor, at::Tensor, std::vector<int64_t>, std::vector<int64_t>, std::vector<int>, int64_t, int64_t>
+    a2a_dispatch_tables(const at::Tensor &cnt_matrix);
+    std::tuple<at::Tensor, std::optional<at::Tensor>, at::Tensor>
+    a2a_dispatch_unpack(const at::Tensor &staging, const std::vector<int64_t> &recv_rows_per_rank,
+                        const at::Tensor &recv_count, const at::Tensor &pull_offset, int64_t hidden, int64_t total_recv,
+                        const std::string &quant_type, int64_t min_rows, int64_t src_idx_len);
+    std::tuple<at::Tensor, std::vector<int64_t>> a2a_combine_pack(const at::Tensor &x, const at::Tensor &send_head);
+    // -> (send_data_offset, send_token_idx_small, rows_sent_to_rank)
+    std::tuple<at::Tensor, at::Tensor, std::vector<int64_t>> a2a_combine_prepare(const at::Tensor &topk_idx,
+                                                                                 int64_t num_experts);
+    at::Tensor a2a_combine_reduce(const at::Tensor &returned_rows, const at::Tensor &topk_idx,
+                                  const std::optional<at::Tensor> &topk_weights, const at::Tensor &send_data_offset,
+                                  const at::Tensor &send_token_idx_small, int64_t hidden, int64_t num_experts);
+
+private:
+    struct Layout {
+        at::Tensor num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank, send_token_idx_small, send_data_offset,
+            workspace;
+        int64_t T = -1, K = -1, E = -1;
+        const void *idx_ptr = nullptr;
+    };
+    Layout run_layout(const at::Tensor &topk_idx, int num_experts);
+    const Layout &layout_for(const at::Tensor &topk_idx, int num_experts);
+
+    void check_status(const char *where);
+    int64_t wait_summary(const char *where);     // host spin on the pinned summary word written by notify_tables
+    uint8_t *region(int family, uint64_t epoch) const;
+    std::vector<void *> peer_ptrs(size_t offset) const;
+    void require_available() const;
+
+    int64_t rank, num_ranks, num_nvl_bytes, num_rdma_bytes;
+    bool low_latency_mode;
+    std::string group_name;
+    int device_id = 0;
+    bool available = false;
+    int timeout_ms = 30000;
+
+    // symmetric window
+    uint8_t *window = nullptr;
+    int64_t window_bytes = 0;
+    bool window_fine_grained = false;
+    std::vector<uint8_t *> peer_base;      // [W] mapped base of every rank's window (own = window)
+    std::vector<bool> peer_opened;         // true when mapped through hipIpcOpenMemHandle
+    size_t region_bytes = 0;               // each of the 6 data regions
+    // pinned host words the kernels write with system scope
+    int32_t *summary_host = nullptr;       // [2 + L] see mi_ep_notify_tables
+    int32_t *status_host = nullptr;        // [4]
+    int32_t *summary_dev = nullptr, *status_dev = nullptr;
+
+    uint64_t dispatch_epoch = 0, combine_epoch = 0, ll_epoch = 0;
+    Layout stash;                          // hidden state coupling of the reference (deep_ep.cpp:170-172,321)
+    int64_t real_max_bs = 0;
+    int profile_skip = 0, profile_active = 0;
+    bool profiling = false;
+};
+
+}  // namespace deep_ep

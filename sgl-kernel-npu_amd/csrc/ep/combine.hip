@@ -57,7 +57,8 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
 template <bool I32>
 __global__ __launch_bounds__(256) void combine_reduce_kernel(
     const uint8_t *__restrict__ slots, size_t slot_stride, const void *__restrict__ topk_idx,
-    const float *__restrict__ topk_w, int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out)
+    const float *__restrict__ topk_w, const int32_t *__restrict__ send_off, const int32_t *__restrict__ idx_small,
+    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out)
 {
     const int lane = lane_id();
     const long long wid = (long long)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
@@ -67,22 +68,28 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
     // routing + weights of this token (lane k < K)
     float w_l = 0.f;
     bool valid_l = false;
+    long long slot_l = t * K + lane;      // slot mode: t*K+k (window push) or the dispatch send slot (all-to-all return)
     if (lane < K) {
         long long e = I32 ? (long long)((const int32_t *)topk_idx)[t * K + lane] : ((const long long *)topk_idx)[t * K + lane];
         valid_l = (e >= 0 && e < E);
         w_l = topk_w ? topk_w[t * K + lane] : 1.0f;
+        if (send_off && valid_l) slot_l = (long long)send_off[e] + idx_small[t * K + lane];
     }
     const unsigned long long vmask = __ballot(valid_l);
     float w[MI_EP_MAX_TOPK];
+    long long slot[MI_EP_MAX_TOPK];
 #pragma unroll
-    for (int k = 0; k < MI_EP_MAX_TOPK; ++k) w[k] = __shfl(w_l, k, kWave);
+    for (int k = 0; k < MI_EP_MAX_TOPK; ++k) {
+        w[k] = __shfl(w_l, k, kWave);
+        slot[k] = __shfl((int)slot_l, k, kWave);
+    }
     const int nchunks = H / 8;          // 16-B chunks of 8 bf16
     for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) {
         u32x4 v[MI_EP_MAX_TOPK];
 #pragma unroll
         for (int k = 0; k < MI_EP_MAX_TOPK; ++k)
             if (k < K && ((vmask >> k) & 1ull))
-                v[k] = *(const u32x4 *)(slots + ((size_t)t * K + k) * slot_stride + (size_t)c * 16);
+                v[k] = *(const u32x4 *)(slots + (size_t)slot[k] * slot_stride + (size_t)c * 16);
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -105,9 +112,90 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
     }
 }
 
+// Expert side of the all-to-all transport: reorder rows from dispatch order (local expert, src rank, j) into
+// per-source contiguous blocks (src rank, local expert, j) -- the order in which that source staged them, so the
+// block can travel back as one message and lands slot-aligned in the source's return buffer.
+__global__ __launch_bounds__(256) void combine_pack_kernel(const uint8_t *__restrict__ x, const int32_t *__restrict__ send_head,
+                                                           int W, int L, int row_bytes, uint8_t *__restrict__ packed,
+                                                           int32_t *__restrict__ rows_per_src)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
+    const int LW = L * W;
+    int32_t *cum = sm;            // [LW] inclusive cumsum (dispatch order)
+    int32_t *dstoff = sm + LW;    // [LW] first packed row of segment i
+    int32_t *blk = dstoff + LW;   // [W+1] block start per src
+    for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = send_head[i];
+    __syncthreads();
+    if (threadIdx.x < W) {
+        const int src = threadIdx.x;
+        int32_t s = 0;
+        for (int le = 0; le < L; ++le) {
+            const int i = le * W + src;
+            s += cum[i] - (i ? cum[i - 1] : 0);
+        }
+        blk[src + 1] = s;
+        if (blockIdx.x == 0 && rows_per_src) rows_per_src[src] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk[0] = 0;
+        for (int src = 0; src < W; ++src) blk[src + 1] += blk[src];
+    }
+    __syncthreads();
+    if (threadIdx.x < W) {
+        const int src = threadIdx.x;
+        int32_t run = blk[src];
+        for (int le = 0; le < L; ++le) {
+            const int i = le * W + src;
+            dstoff[i] = run;
+            run += cum[i] - (i ? cum[i - 1] : 0);
+        }
+    }
+    __syncthreads();
+    const int total = cum[LW - 1];
+    const int lane = lane_id(), wave = threadIdx.x / kWave, nw = blockDim.x / kWave;
+    const int n16 = row_bytes / 16;
+    for (long long r = (long long)blockIdx.x * nw + wave; r < total; r += (long long)gridDim.x * nw) {
+        int lo = 0, hi = LW - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] > r) hi = mid; else lo = mid + 1;
+        }
+        const int j = (int)(r - (lo ? cum[lo - 1] : 0));
+        const u32x4 *s16 = (const u32x4 *)(x + (size_t)r * row_bytes);
+        u32x4 *d16 = (u32x4 *)(packed + ((size_t)dstoff[lo] + j) * row_bytes);
+        for (int base = 0; base < n16; base += kWave * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = base + u * kWave + lane;
+                if (item < n16) v[u] = __builtin_nontemporal_load(s16 + item);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = base + u * kWave + lane;
+                if (item < n16) d16[item] = v[u];
+            }
+        }
+    }
+}
+
 }  // namespace mi_ep
 
 using namespace mi_ep;
+
+extern "C" int mi_ep_combine_pack(const void *x, const int32_t *send_head, int W, int L, int H, int rows_hint,
+                                  void *packed, int32_t *rows_per_src, void *stream)
+{
+    if (!send_head || W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || L * W > 2048 || H <= 0 || H % 8) return MI_EP_EINVAL;
+    if (rows_hint > 0 && (!x || !packed)) return MI_EP_EINVAL;
+    long long blocks = rows_hint > 0 ? ((long long)rows_hint + 3) / 4 : 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const size_t lds = (size_t)(2 * L * W + W + 1) * sizeof(int32_t);
+    combine_pack_kernel<<<(int)blocks, 256, lds, (hipStream_t)stream>>>((const uint8_t *)x, send_head, W, L, H * 2,
+                                                                      (uint8_t *)packed, rows_per_src);
+    return launch_status();
+}
 
 extern "C" size_t mi_ep_combine_row_bytes(int hidden) { return ((size_t)hidden * 2 + 15) / 16 * 16; }
 
@@ -132,8 +220,10 @@ extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const i
 }
 
 extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
-                                    int T, int K, int H, int E, void *out, void *stream)
+                                    const int32_t *send_data_offset, const int32_t *send_token_idx_small, int T, int K,
+                                    int H, int E, void *out, void *stream)
 {
+    if ((send_data_offset == nullptr) != (send_token_idx_small == nullptr)) return MI_EP_EINVAL;
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 8 || E <= 0) return MI_EP_EINVAL;
     if (T == 0) return MI_EP_OK;
     if (!slots || !topk_idx || !out) return MI_EP_EINVAL;
@@ -149,11 +239,11 @@ extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int
     hipStream_t s = (hipStream_t)stream;
     if (idx_is_i32)
         combine_reduce_kernel<true><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H),
-                                                                        topk_idx, topk_weights, T, K, H, E, segs,
+                                                                        topk_idx, topk_weights, send_data_offset, send_token_idx_small, T, K, H, E, segs,
                                                                         (uint16_t *)out);
     else
         combine_reduce_kernel<false><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H),
-                                                                         topk_idx, topk_weights, T, K, H, E, segs,
+                                                                         topk_idx, topk_weights, send_data_offset, send_token_idx_small, T, K, H, E, segs,
                                                                          (uint16_t *)out);
     return launch_status();
 }

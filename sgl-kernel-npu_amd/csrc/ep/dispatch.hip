@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void ll_counts_kernel(const uint64_t *__restri
         while (((g = sys_load_u64(granules + i)) >> 32) != epoch) {
             __builtin_amdgcn_s_sleep(4);
             if (ticks_100mhz() - t0 > timeout_ticks) {
-                atomicCAS(status, 0, 2000 + i);
+                report_status(status, 2000 + i);
                 g = 0;
                 break;
             }

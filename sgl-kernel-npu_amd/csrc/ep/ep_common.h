@@ -45,6 +45,12 @@ __device__ __forceinline__ uint64_t sys_load_u64(const uint64_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// error reporting word (device or pinned-host memory): first writer wins is not required, any code is enough
+__device__ __forceinline__ void report_status(int32_t *status, int32_t code)
+{
+    __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ~100 MHz constant-rate counter (s_memrealtime); used only to bound spins.
 __device__ __forceinline__ uint64_t ticks_100mhz() { return wall_clock64(); }
 

@@ -25,7 +25,7 @@ __global__ void wait_kernel(const uint64_t *__restrict__ flags, int W, uint64_t 
     while (sys_load_u64(flags + s) < epoch) {
         __builtin_amdgcn_s_sleep(8);
         if (ticks_100mhz() - t0 > timeout_ticks) {
-            atomicCAS(status, 0, 1 + s);
+            report_status(status, 1 + s);
             return;
         }
     }
@@ -52,7 +52,7 @@ __global__ void notify_wait_kernel(const uint64_t *__restrict__ notify, int n, u
         while (((g = sys_load_u64(notify + i)) >> 32) != epoch) {
             __builtin_amdgcn_s_sleep(8);
             if (ticks_100mhz() - t0 > timeout_ticks) {
-                atomicCAS(status, 0, 1000 + i);
+                report_status(status, 1000 + i);
                 g = 0;
                 break;
             }

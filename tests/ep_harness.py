@@ -32,7 +32,9 @@ def _lib():
     lib.mi_ep_dispatch_stage.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, V]
     lib.mi_ep_dispatch_pull.argtypes = [V, V, V, I, I, I, I, I, V, V, V, V]
     lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, V]
-    lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, I, I, I, I, V, V]
+    lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, V, V, I, I, I, I, V, V]
+    lib.mi_ep_combine_pack.argtypes = [V, V, I, I, I, I, V, V, V]
+    lib.mi_ep_combine_pack.restype = c_int
     lib.mi_ep_ll_dispatch_send.argtypes = [V, V, I, V, I, I, I, I, I, I, I, I, V, V]
     lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
     lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, V, I, V]
@@ -164,7 +166,7 @@ class InProcEP:
             ck(L_.mi_ep_wait(c_void_p(self.flags[r].data_ptr() + 64 * 8), W, ep, ptr(self.status[r]), 2000, st))
             out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
             ck(L_.mi_ep_combine_reduce(ptr(self.comb_win[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
-                                       ptr(topk_weights[r]), T, K, H, E, ptr(out), st))
+                                       ptr(topk_weights[r]), None, None, T, K, H, E, ptr(out), st))
             outs.append(out)
         torch.cuda.synchronize()
         return outs

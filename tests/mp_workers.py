@@ -1,0 +1,178 @@
+"""Worker functions for the multi-process tests (torch.multiprocessing.spawn needs importable top-level functions)."""
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "sgl-kernel-npu_amd", "python")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def make_topk(rng, T, K, E, drop=0.0):
+    scores = np.abs(rng.standard_normal((T, E))) + 1
+    idx = np.argsort(-scores, axis=1, kind="stable")[:, :K].astype(np.int64)
+    if drop > 0:
+        idx[rng.random((T, K)) < drop] = -1
+    return idx
+
+
+def make_inputs(W, T, H, K, E, drop, seed=1234):
+    from oracle.bf16 import f32_to_bf16_bits_rne
+    rng = np.random.default_rng(seed)
+    Ts = [T + r for r in range(W)]
+    xs = [f32_to_bf16_bits_rne((rng.standard_normal((t, H)) * 2).astype(np.float32)) for t in Ts]
+    idxs = [make_topk(rng, t, K, E, drop) for t in Ts]
+    ws = [rng.standard_normal((t, K)).astype(np.float32) for t in Ts]
+    return xs, idxs, ws
+
+
+def _init(rank, world, port, backend="gloo"):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist.group.WORLD
+
+
+def run_guarded(fn, rank, *args):
+    try:
+        fn(rank, *args)
+    except Exception:
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(17)
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU / gloo: host plumbing of deep_ep.Buffer + alltoall strategies with the oracle-backed test double
+# ----------------------------------------------------------------------------------------------
+def cpu_alltoall_worker(rank, world, port, cfg):
+    run_guarded(_cpu_alltoall, rank, world, port, cfg)
+
+
+def _cpu_alltoall(rank, world, port, cfg):
+    import deep_ep
+    from fake_runtime import FakeRuntime
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits
+    group = _init(rank, world, port)
+    W, T, H, K, E, drop, quant = cfg
+    assert W == world
+    deep_ep.Buffer._runtime_factory = staticmethod(lambda *a: FakeRuntime(*a))
+    buf = deep_ep.Buffer(group, normal_strategy="alltoall", low_latency_strategy="alltoall", low_latency_mode=True)
+    assert buf.normal_strategy.get_name() == "alltoall"
+    xs, idxs, ws = make_inputs(W, T, H, K, E, drop)
+    x, ti, tw = bits_to_torch(xs[rank]), torch.from_numpy(idxs[rank]), torch.from_numpy(ws[rank])
+    per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+    want = O.normal_dispatch(xs, idxs, E, quant)
+    assert np.array_equal(per_expert.numpy(), want[rank].layout["num_tokens_per_expert"])
+    recv_x, _, _, lst, handle, ev = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                 num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
+                                                 quant_mode="int8" if quant else None)
+    ev.current_stream_wait()
+    n = want[rank].total_recv
+    assert lst == want[rank].num_recv_tokens_per_expert_list
+    assert len(handle) == 8 and handle[7] is tw and handle[6] is ti
+    assert np.array_equal(handle[3].numpy()[:3 * n], want[rank].recv_src_idx[:3 * n])
+    assert np.array_equal(handle[5].numpy(), want[rank].send_head)
+    if quant:
+        assert np.array_equal(recv_x[0].numpy()[:n], want[rank].recv_x[:n])
+        assert np.array_equal(recv_x[1].numpy()[:n], want[rank].recv_x_scales[:n])
+        y = bits_to_torch(O.per_token_cast_back(want[rank].recv_x, want[rank].recv_x_scales))
+    else:
+        assert np.array_equal(torch_to_bits(recv_x)[:n], want[rank].recv_x[:n])
+        y = recv_x
+    ys = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) if quant else w.recv_x for w in want]
+    comb_want = O.combine(ys, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)
+    out, _, _ = buf.combine(y, handle)
+    assert np.array_equal(torch_to_bits(out), comb_want[rank])
+    # low-latency pair through the same transport
+    MT = T + W
+    llw = O.low_latency_dispatch(xs, idxs, MT, E, quant)
+    rx, cnt, h, _, hook = buf.low_latency_dispatch(x, ti, MT, E, use_fp8=quant)
+    hook()
+    assert np.array_equal(cnt.numpy(), llw[rank].packed_recv_count)
+    assert np.array_equal(h[1].numpy(), llw[rank].layout_range)
+    nn = llw[rank].total
+    if quant:
+        assert np.array_equal(rx[0].numpy()[:nn], llw[rank].packed_recv_x[:nn])
+    else:
+        assert np.array_equal(torch_to_bits(rx)[:nn], llw[rank].packed_recv_x[:nn])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: W processes sharing ONE GPU, real deep_ep_cpp runtime, hipIpc-mapped windows
+# ----------------------------------------------------------------------------------------------
+def gpu_buffer_worker(rank, world, port, cfg):
+    run_guarded(_gpu_buffer, rank, world, port, cfg)
+
+
+def _gpu_buffer(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits
+    torch.cuda.set_device(0)
+    W, T, H, K, E, drop, quant, strategy, iters = cfg
+    # RCCL refuses several ranks on one GPU, so the multi-process cases bootstrap over gloo; the alltoall strategy
+    # needs a real RCCL group for its device collectives and is exercised at world size 1 here
+    group = _init(rank, world, port, "nccl" if strategy == "alltoall" else "gloo")
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(768 << 20))
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "20000")
+    buf = deep_ep.Buffer(group, low_latency_mode=True, normal_strategy=strategy, low_latency_strategy=strategy)
+    assert buf.normal_strategy.get_name() == strategy, (buf.normal_strategy.get_name(), buf.p2p_available)
+    for it in range(iters):
+        xs, idxs, ws = make_inputs(W, T, H, K, E, drop, seed=100 + it)
+        x = bits_to_torch(xs[rank]).cuda()
+        ti = torch.from_numpy(idxs[rank]).cuda()
+        tw = torch.from_numpy(ws[rank]).cuda()
+        want = O.normal_dispatch(xs, idxs, E, quant)
+        per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+        recv_x, _, _, lst, handle, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                    num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
+                                                    quant_mode="int8" if quant else None)
+        n = want[rank].total_recv
+        assert lst == want[rank].num_recv_tokens_per_expert_list, (lst, want[rank].num_recv_tokens_per_expert_list)
+        assert np.array_equal(handle[3].cpu().numpy()[:3 * n], want[rank].recv_src_idx[:3 * n])
+        assert np.array_equal(handle[5].cpu().numpy(), want[rank].send_head)
+        if quant:
+            assert np.array_equal(recv_x[0].cpu().numpy()[:n], want[rank].recv_x[:n])
+            assert np.array_equal(recv_x[1].cpu().numpy()[:n], want[rank].recv_x_scales[:n])
+            y = bits_to_torch(O.per_token_cast_back(want[rank].recv_x, want[rank].recv_x_scales)).cuda()
+        else:
+            assert np.array_equal(torch_to_bits(recv_x)[:n], want[rank].recv_x[:n])
+            y = recv_x
+        ys = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) if quant else w.recv_x for w in want]
+        comb_want = O.combine(ys, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)
+        out, _, _ = buf.combine(y, handle)
+        assert np.array_equal(torch_to_bits(out), comb_want[rank]), "combine mismatch"
+        # low latency
+        MT = T + W
+        llw = O.low_latency_dispatch(xs, idxs, MT, E, quant)
+        rx, cnt, h, _, hook = buf.low_latency_dispatch(x, ti, MT, E, use_fp8=quant)
+        hook()
+        assert np.array_equal(cnt.cpu().numpy(), llw[rank].packed_recv_count)
+        assert np.array_equal(h[1].cpu().numpy(), llw[rank].layout_range)
+        nn = llw[rank].total
+        assert np.array_equal(h[0].cpu().numpy()[:3 * nn], llw[rank].src_info)
+        if quant:
+            assert np.array_equal(rx[0].cpu().numpy()[:nn], llw[rank].packed_recv_x[:nn])
+            assert np.array_equal(rx[1].cpu().numpy()[:nn], llw[rank].packed_recv_x_scales[:nn])
+            yl = bits_to_torch(O.per_token_cast_back(llw[rank].packed_recv_x, llw[rank].packed_recv_x_scales)).cuda()
+        else:
+            assert np.array_equal(torch_to_bits(rx)[:nn], llw[rank].packed_recv_x[:nn])
+            yl = rx
+        yls = [O.per_token_cast_back(w.packed_recv_x, w.packed_recv_x_scales) if quant else w.packed_recv_x for w in llw]
+        wabs = [np.abs(w_) for w_ in ws]
+        llc_want = O.combine(yls, [w.src_info for w in llw], [w.total for w in llw], idxs, wabs, E)
+        outl, _, hook = buf.low_latency_combine(yl, ti, torch.from_numpy(wabs[rank]).cuda(), h)
+        hook()
+        assert np.array_equal(torch_to_bits(outl), llc_want[rank]), "LL combine mismatch"
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()

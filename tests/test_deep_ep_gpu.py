@@ -1,0 +1,22 @@
+"""GPU tests of the full boundary: deep_ep.Buffer -> deep_ep_cpp (C++ runtime) -> HIP kernels, with W ranks as W
+processes sharing ONE GPU and their windows mapped through hipIpc (the same code path 8 GPUs take over xGMI)."""
+import pytest
+
+import mp_workers
+from test_deep_ep_plumbing_cpu import _spawn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg", [
+    # W, T, H, K, E, drop, quant, strategy, iterations
+    (1, 256, 1024, 2, 8, 0.0, False, "default", 2),      # BASELINE C1 on a GPU
+    (1, 64, 7168, 8, 256, 0.1, True, "default", 2),
+    (2, 48, 512, 4, 16, 0.2, True, "default", 3),
+    (4, 33, 7168, 8, 256, 0.0, True, "default", 3),
+    (4, 40, 1024, 8, 64, 0.3, False, "default", 2),
+    (8, 16, 2048, 8, 256, 0.1, True, "default", 3),
+    (1, 64, 1024, 4, 16, 0.1, True, "alltoall", 1),
+])
+def test_buffer_multi_process_one_gpu(cfg):
+    _spawn(mp_workers.gpu_buffer_worker, cfg[0], cfg)
