@@ -7,6 +7,7 @@
 #include "deep_ep.hpp"
 
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -292,6 +293,7 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     EP_HOST_ASSERT_S((size_t)T * K * rb <= region_bytes, "dispatch window too small: need ", (size_t)T * K * rb,
                      " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
     check_status("intranode_dispatch");
+    ++profile_calls;
     const Layout &lay = layout_for(*topk_idx, E);
     hipStream_t st = cur_stream();
     auto dev = x.device();
@@ -301,9 +303,9 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
 
     // sender side: stage into the own window, publish counts, raise the "staged" flag on every peer
     uint8_t *my_rows = region(kDispatch, ep);
-    MI_EP_CHECK(mi_ep_dispatch_stage(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
+    { ProfScope ps_(this, "dispatch_stage", st); MI_EP_CHECK(mi_ep_dispatch_stage(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
                                      lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
-                                     H, E, (int)rank, qm, my_rows, st));
+                                     H, E, (int)rank, qm, my_rows, st)); }
     auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
     MI_EP_CHECK(mi_ep_notify_post((uint64_t *const *)notify_peers.data(), W, (int)rank, E,
                                   lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, st));
@@ -354,10 +356,10 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     std::optional<at::Tensor> recv_topk_idx = at::empty({trt, K}, topk_idx->options());       // allocated, never written
     std::optional<at::Tensor> recv_topk_weights = at::empty({trt, K}, topk_weights->options());  // (deep_ep.cpp:371-374)
     auto src_peers = peer_ptrs((size_t)(region(kDispatch, ep) - window));
-    MI_EP_CHECK(mi_ep_dispatch_pull((const void *const *)src_peers.data(), recv_count.data_ptr<int>(),
+    { ProfScope ps_(this, "dispatch_pull", st); MI_EP_CHECK(mi_ep_dispatch_pull((const void *const *)src_peers.data(), recv_count.data_ptr<int>(),
                                     pull_offset.data_ptr<int>(), W, L, H, qm, (int)trt, expandx_out.data_ptr(),
                                     use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr,
-                                    expand_idx_out.data_ptr<int>(), st));
+                                    expand_idx_out.data_ptr<int>(), st)); }
     if (dispatch_wait_recv_cost_stats.has_value()) {
         EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->scalar_type() == at::kInt);
         EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->dim() == 1 and dispatch_wait_recv_cost_stats->size(0) == num_ranks);
@@ -445,16 +447,16 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
     const uint64_t ep = ++combine_epoch;
     auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
     // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
-    MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1),
-                                   (int)x.size(0), H, K, dst_peers.data(), W, st));
+    { ProfScope ps_(this, "combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1),
+                                   (int)x.size(0), H, K, dst_peers.data(), W, st)); }
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
     MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
     MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, ep, status_dev,
                            timeout_ms, st));
     auto combined_x = at::empty({T, H}, x.options());
-    MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+    { ProfScope ps_(this, "combine_reduce", st); MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                      topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, nullptr, nullptr,
-                                     T, K, H, E, combined_x.data_ptr(), st));
+                                     T, K, H, E, combined_x.data_ptr(), st)); }
     return {combined_x, std::nullopt, std::nullopt};
 }
 
@@ -490,6 +492,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     EP_HOST_ASSERT_S((size_t)L * W * MT * rb <= region_bytes, "low-latency window too small: need ", (size_t)L * W * MT * rb,
                      " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
     check_status("low_latency_dispatch");
+    ++profile_calls;
     const int64_t num_max_tokens = (int64_t)MT * W * std::min(K, L);       // deep_ep.cpp:867-873
     const int64_t max_size = std::max<int64_t>((int64_t)T * K, num_max_tokens * 128);   // deep_ep.cpp:875
     auto dev = x.device();
@@ -511,17 +514,17 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     const uint64_t ep = ++ll_epoch;
     const int par = (int)(ep & 1);
     auto row_peers = peer_ptrs((size_t)(region(kLLDispatch, ep) - window));
-    MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+    { ProfScope ps_(this, "ll_dispatch_send", st); MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                        lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm,
-                                       row_peers.data(), st));
+                                       row_peers.data(), st)); }
     auto cnt_peers = peer_ptrs((size_t)(kOffLLCounts + par * kLLCountsParityBytes));
     MI_EP_CHECK(mi_ep_ll_post_counts((uint64_t *const *)cnt_peers.data(), lay.num_tokens_per_expert.data_ptr<int>(), E, W,
                                      (int)rank, (uint32_t)ep, st));
-    MI_EP_CHECK(mi_ep_ll_dispatch_recv(region(kLLDispatch, ep), (const uint64_t *)(window + kOffLLCounts + par * kLLCountsParityBytes),
+    { ProfScope ps_(this, "ll_dispatch_recv", st); MI_EP_CHECK(mi_ep_ll_dispatch_recv(region(kLLDispatch, ep), (const uint64_t *)(window + kOffLLCounts + par * kLLCountsParityBytes),
                                        (uint32_t)ep, W, L, MT, H, qm, count_type, packed_recv_x.data_ptr(),
                                        qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(),
                                        (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(),
-                                       ep_recv_count.data_ptr<int>(), status_dev, timeout_ms, st));
+                                       ep_recv_count.data_ptr<int>(), status_dev, timeout_ms, st)); }
     real_max_bs = std::max<int64_t>(real_max_bs, MT);
     return {packed_recv_x, packed_recv_x_scales, packed_recv_count, expand_idx, ep_recv_count, std::nullopt,
             std::function<void()>([] {})};
@@ -552,16 +555,16 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     const uint64_t ep = ++combine_epoch;
     auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
     // valid packed rows = layout_range[L*W-1], read on device
-    MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
-                                   (int)x.size(0), H, K, dst_peers.data(), W, st));
+    { ProfScope ps_(this, "ll_combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
+                                   (int)x.size(0), H, K, dst_peers.data(), W, st)); }
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
     MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
     MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, ep, status_dev,
                            timeout_ms, st));
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
     auto combined_x = at::empty({T, H}, x.options());
-    MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
-                                     topk_weights.data_ptr<float>(), nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), st));
+    { ProfScope ps_(this, "ll_combine_reduce", st); MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                     topk_weights.data_ptr<float>(), nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), st)); }
     return {combined_x, std::nullopt, std::function<void()>([] {})};
 }
 
@@ -585,13 +588,71 @@ std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &, const a
     throw EPException("Assertion", __FILE__, __LINE__, "dispatch_ffn_combine: not implemented in this build (SURVEY.md section 8(f) N1)");
 }
 
-void Buffer::begin_profile(int64_t skip, int64_t active, const std::string &)
+// The reference's stage profiler (device timestamp ring + host exporter -> chrome trace_view.json, Ascend950 fused op
+// only: deep_ep.cpp:1237-1252, profiling/core/profile_exporter.cpp:421-427) becomes HIP event pairs around every
+// kernel of the dispatch/combine chains, on the caller's stream.  Calls = dispatch/combine API calls; the first
+// `skip` are ignored, the next `active` are recorded.  end_profile() drains the events, fills get_profile_summary()
+// and, if a directory was given, writes <dir>/trace_view_rank<r>.json (chrome://tracing "X" events).
+ProfScope::ProfScope(Buffer *b, const char *name, hipStream_t st) : b(b), st(st)
 {
-    // The reference's stage profiler is Ascend950-only (deep_ep.cpp:1237-1252).  On MI355X use rocprofv3; the call is
-    // accepted so callers need no change.
-    profile_skip = (int)skip, profile_active = (int)active, profiling = true;
+    if (!b->profile_now()) return;
+    Buffer::ProfRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    hipEventRecord(r.a, st);
+    idx = b->profile_recs.size();
+    b->profile_recs.push_back(r);
 }
-void Buffer::end_profile() { profiling = false; }
+ProfScope::~ProfScope()
+{
+    if (idx != (size_t)-1) hipEventRecord(b->profile_recs[idx].b, st);
+}
+
+void Buffer::begin_profile(int64_t skip, int64_t active, const std::string &dir)
+{
+    profile_skip = skip, profile_active = active, profile_calls = 0, profiling = true, profile_dir = dir;
+    profile_recs.clear();
+    profile_summary.clear();
+}
+
+void Buffer::end_profile()
+{
+    profiling = false;
+    if (profile_recs.empty()) return;
+    HIP_CHECK(hipEventSynchronize(profile_recs.back().b));
+    std::vector<std::tuple<std::string, int64_t, double>> sum;
+    std::string trace = "[";
+    const hipEvent_t origin = profile_recs.front().a;
+    for (auto &r : profile_recs) {
+        float ms = 0.f, t0 = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
+        if (hipEventElapsedTime(&t0, origin, r.a) != hipSuccess) t0 = 0.f;
+        bool found = false;
+        for (auto &s : sum)
+            if (std::get<0>(s) == r.name) {
+                std::get<1>(s) += 1;
+                std::get<2>(s) += ms;
+                found = true;
+            }
+        if (!found) sum.emplace_back(r.name, 1, (double)ms);
+        if (trace.size() > 1) trace += ",";
+        trace += ep_concat("{\"name\":\"", r.name, "\",\"ph\":\"X\",\"pid\":", rank, ",\"tid\":0,\"ts\":", t0 * 1000.0,
+                           ",\"dur\":", ms * 1000.0, "}");
+    }
+    for (auto &r : profile_recs) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    trace += "]";
+    profile_recs.clear();
+    profile_summary = sum;
+    if (!profile_dir.empty()) {
+        const std::string path = profile_dir + "/trace_view_rank" + std::to_string(rank) + ".json";
+        if (FILE *f = std::fopen(path.c_str(), "w")) {
+            std::fwrite(trace.data(), 1, trace.size(), f);
+            std::fclose(f);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // kernel-level entry points for the `alltoall` strategies

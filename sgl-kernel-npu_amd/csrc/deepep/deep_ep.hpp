@@ -106,6 +106,9 @@ public:
     void begin_profile(int64_t num_profile_skip_launches, int64_t num_profile_active_launches,
                        const std::string &profile_trace_dir);
     void end_profile();
+    // MI355X: per-kernel device time (HIP events on the caller's stream) gathered between begin_profile/end_profile:
+    // name -> (launch count, total milliseconds).  Valid after end_profile().
+    std::vector<std::tuple<std::string, int64_t, double>> get_profile_summary() const { return profile_summary; }
 
     // ---- kernel-level entry points used by the `alltoall` strategies (torch.distributed / RCCL moves the bytes,
     // these pack and unpack them).  Mirrors what the reference's AlltoAll strategies get from torch_npu routing ops
@@ -166,8 +169,26 @@ private:
     uint64_t dispatch_epoch = 0, combine_epoch = 0, ll_epoch = 0;
     Layout stash;                          // hidden state coupling of the reference (deep_ep.cpp:170-172,321)
     int64_t real_max_bs = 0;
-    int profile_skip = 0, profile_active = 0;
+    int64_t profile_skip = 0, profile_active = 0, profile_calls = 0;
     bool profiling = false;
+    std::string profile_dir;
+    struct ProfRec {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    std::vector<ProfRec> profile_recs;
+    std::vector<std::tuple<std::string, int64_t, double>> profile_summary;
+    bool profile_now() const { return profiling && profile_calls > profile_skip && profile_calls <= profile_skip + profile_active; }
+    friend struct ProfScope;
+};
+
+// RAII: records a HIP event pair around one kernel launch chain when profiling is active
+struct ProfScope {
+    Buffer *b;
+    size_t idx = (size_t)-1;
+    hipStream_t st;
+    ProfScope(Buffer *b, const char *name, hipStream_t st);
+    ~ProfScope();
 };
 
 }  // namespace deep_ep

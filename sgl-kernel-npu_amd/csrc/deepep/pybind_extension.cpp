@@ -60,6 +60,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         .def("begin_profile", &deep_ep::Buffer::begin_profile, py::arg("num_profile_skip_launches"),
              py::arg("num_profile_active_launches"), py::arg("profile_trace_dir") = "")
         .def("end_profile", &deep_ep::Buffer::end_profile)
+        .def("get_profile_summary", &deep_ep::Buffer::get_profile_summary)
         .def("dispatch_ffn_combine", &deep_ep::Buffer::dispatch_ffn_combine)
         // alltoall-strategy kernel entry points
         .def("a2a_dispatch_stage", &deep_ep::Buffer::a2a_dispatch_stage)

@@ -260,6 +260,11 @@ class Buffer:
     def end_profile(self) -> None:
         self.runtime.end_profile()
 
+    def get_profile_summary(self) -> dict:
+        """MI355X extension: {kernel name: (launches, total_ms)} recorded between begin_profile / end_profile
+        (HIP event pairs on the caller's stream around every kernel of the dispatch / combine chains)."""
+        return {name: (int(n), float(ms)) for name, n, ms in self.runtime.get_profile_summary()}
+
     def fused_deep_moe(self, x: torch.Tensor, topk_idx: torch.Tensor, topk_weights: torch.Tensor,
                        gmm1_permuted_weight: torch.Tensor, gmm1_permuted_weight_scale: torch.Tensor,
                        gmm2_weight: torch.Tensor, gmm2_weight_scale: torch.Tensor, num_max_dispatch_tokens_per_rank: int,
