@@ -107,6 +107,26 @@ def kernel_bytes(name, T, K, H, n_pairs, n_recv):
     }[name]
 
 
+PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatch_pull": "pull_kernel",
+                    "combine_push": "combine_push_kernel", "combine_reduce": "combine_reduce_kernel<false>"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r*_pmc_traffic.json, produced by tools/summarize_prof.py with the gfx950 FETCH_SIZE x2 correction);
+    None when no PMC summary is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(PMC_KERNEL_NAMES.get(kernel, kernel))
+        return k["hbm_bytes_per_launch"] if k else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(sample_tokens):
     """The oracle (a port of the reference arithmetic, NumPy, 1 thread of compute) on a bounded sample of the same
     workload: W = 1, `sample_tokens` tokens, same hidden / top-k / experts; dispatch(int8) + cast-back + combine."""
@@ -224,7 +244,8 @@ def main():
         alg = kernel_bytes(dom, T, TOPK, HIDDEN, n_pairs, n_recv)
         achieved = alg / (per[dom]["avg_us"] * 1e-6) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes": alg,
+                              "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom) if world == 1 else None,
+                              "algorithmic_bytes": alg,
                               "avg_launch_us": per[dom]["avg_us"]}
         result["kernels"] = {k: dict(v, GBps=kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv) / (v["avg_us"] * 1e-6) / 1e9)
                              for k, v in per.items() if k in ("dispatch_stage", "dispatch_pull", "combine_push", "combine_reduce")}
