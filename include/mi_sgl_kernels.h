@@ -1,0 +1,60 @@
+/*
+ * mi_sgl_kernels.h -- C-ABI of the MI355X (gfx950) fused inference primitives that sit either side of the
+ * DeepEP dispatch/combine path: paged MLA / GQA decode attention, SwiGLU + INT8 quantisation, fused Add+RMSNorm
+ * (+bias, +static INT8 quantisation), split-QKV RMSNorm + RoPE.
+ *
+ * These replace the reference's Triton-Ascend kernels (python/sgl_kernel_npu/sgl_kernel_npu/...):
+ *   mi_mla_decode            <- attention/decode_attention.py:5-230   (_paged_mla_fwd_kernel / decode_mla)
+ *   mi_swiglu_quant          <- activation/swiglu_quant.py:8-127      (_swiglu_quant_kernel / swiglu_quant)
+ *   mi_add_rmsnorm_bias      <- norm/add_rmsnorm_bias.py:8-147        (add_rmsnorm_bias_kernel / add_rmsnorm_bias)
+ *                               norm/add_rmsnorm_bias.py:150-232      (add_gemma_rms_norm)
+ *   mi_split_qkv_rmsnorm_rope<- norm/split_qkv_rmsnorm_rope.py:8-438  (split_qkv_rmsnorm_rope)
+ * and are what `torch.ops.npu.*` (csrc/pytorch_extensions.cpp) and the `sgl_kernel_npu` Python functions bind.
+ *
+ * Conventions: plain DEVICE pointers and sizes; every call only enqueues work on `stream` (hipStream_t as void*),
+ * never allocates or synchronises; returns 0 on success, negative on bad arguments / launch failure.
+ */
+#ifndef MI_SGL_KERNELS_H_
+#define MI_SGL_KERNELS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_SGL_OK 0
+#define MI_SGL_EINVAL (-1)
+#define MI_SGL_ELAUNCH (-2)
+
+#define MI_DTYPE_BF16 0
+#define MI_DTYPE_F16 1
+
+const char *mi_sgl_kernels_version(void);
+
+/* ---- paged MLA decode attention ----------------------------------------------------------------------------
+ * out[b,h,:] = softmax_n( (q_nope[b,h]·k_nope[n] + q_rope[b,h]·k_rope[n]) * sm_scale ) · k_nope[n],  n < kv_seq_lens[b]
+ * (V aliases K_nope; fp32 scores / softmax / accumulation, P rounded to the KV dtype before P·V, as in the
+ *  reference kernel decode_attention.py:110-163).
+ *   q          [batch, q_heads, 576]            strides (q_stride_b, q_stride_h) in elements, last dim contiguous
+ *   k_nope     [num_blocks, page_size, kv_heads, 512]   strides (kn_stride_blk, kn_stride_row, kn_stride_h)
+ *   k_rope     [num_blocks, page_size, kv_heads, 64]    strides (kr_stride_blk, kr_stride_row, kr_stride_h)
+ *   out        [batch, q_heads, 512]            strides (o_stride_b, o_stride_h)
+ *   kv_seq_lens int32 [batch]; block_table int32 [batch, bt_stride] (logical page -> physical block)
+ * q_heads % kv_heads == 0; any page_size >= 1.  num_splits >= 1 partitions the KV range of every sequence
+ * (flash-decoding); num_splits > 1 needs `workspace` of mi_mla_decode_workspace() bytes.  Pass num_splits = 0 to
+ * let the library choose (mi_mla_decode_num_splits). */
+size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
+int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
+int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
+                  const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
+                  int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk, int64_t kn_stride_row,
+                  int64_t kn_stride_h, int64_t kr_stride_blk, int64_t kr_stride_row, int64_t kr_stride_h,
+                  int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SGL_KERNELS_H_ */

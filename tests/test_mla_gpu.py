@@ -1,0 +1,112 @@
+"""GPU parity: HIP paged MLA decode (through the C-ABI of include/mi_sgl_kernels.h) vs the CPU oracle, the committed
+reference-kernel outputs, and (at BASELINE C4 size) an fp32 torch evaluation on the GPU.  Tolerance: 1e-3 absolute
+(BASELINE.json north_star: "MLA decode matching reference within 1e-3") plus one output-dtype ulp."""
+import ctypes
+import glob
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import pytest
+import torch
+
+from capi import load, ptr, stream_ptr
+from oracle import kernels as OK
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load("libmi_sgl_kernels.so")
+        _lib.mi_mla_decode_workspace.restype = c_size_t
+        _lib.mi_mla_decode_workspace.argtypes = [c_int, c_int, c_int]
+        _lib.mi_mla_decode_num_splits.argtypes = [c_int] * 4
+        _lib.mi_mla_decode.argtypes = [c_void_p] * 6 + [c_int] * 6 + [c_int64] * 10 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]
+    return _lib
+
+
+def run_mla(q, kn, kr, lens, bt, sm_scale, num_splits=0):
+    B, Hq, _ = q.shape
+    Hkv = kn.shape[2]
+    out = torch.empty((B, Hq, 512), dtype=q.dtype, device=q.device)
+    max_len = int(lens.max().item()) if B else 0
+    L = lib()
+    if num_splits == 0:
+        num_splits = L.mi_mla_decode_num_splits(B, Hq, Hkv, max_len)
+    wsb = L.mi_mla_decode_workspace(B, Hq, num_splits)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=q.device)
+    rc = L.mi_mla_decode(ptr(q), ptr(kn), ptr(kr), ptr(out), ptr(lens), ptr(bt), B, Hq, Hkv, kn.shape[1], bt.stride(0), max_len,
+                         q.stride(0), q.stride(1), kn.stride(0), kn.stride(1), kn.stride(2), kr.stride(0), kr.stride(1),
+                         kr.stride(2), out.stride(0), out.stride(1), sm_scale, 0 if q.dtype == torch.bfloat16 else 1,
+                         num_splits, ptr(ws), wsb, stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return out
+
+
+def tol(dtype):
+    return dict(atol=1e-3, rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -10)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mla_ref_fp16_*.npz"))))
+@pytest.mark.parametrize("splits", [1, 3])
+def test_against_reference_kernel_outputs(path, splits):
+    z = np.load(path)
+    t = lambda k: torch.from_numpy(z[k]).cuda()
+    got = run_mla(t("q"), t("k_nope"), t("k_rope"), t("kv_seq_lens"), t("block_table"), float(z["sm_scale"]), splits)
+    want = torch.from_numpy(z["out"]).cuda()
+    assert torch.allclose(got.float(), want.float(), **tol(torch.float16)), (got.float() - want.float()).abs().max()
+
+
+CASES = [  # B, Hq, Hkv, S, page, ragged
+    (2, 16, 1, 200, 64, True), (4, 128, 1, 700, 64, True), (3, 32, 1, 129, 16, True), (2, 8, 1, 64, 128, False),
+    (1, 64, 1, 1, 64, False), (2, 128, 1, 1314, 128, True), (2, 64, 8, 333, 32, True), (1, 256, 1, 150, 64, False),
+]
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,S,page,ragged", CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("splits", [0, 1, 2])
+def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits):
+    torch.manual_seed(2)
+    maxp = (S + page - 1) // page
+    nb = B * maxp + 3
+    q = torch.randn((B, Hq, 576)).to(dtype)
+    kn = torch.randn((nb, page, Hkv, 512)).to(dtype)
+    kr = torch.randn((nb, page, Hkv, 64)).to(dtype)
+    bt = torch.randperm(nb)[:B * maxp].to(torch.int32).reshape(B, maxp)
+    lens = torch.tensor([max(1, S - 37 * i) if ragged else S for i in range(B)], dtype=torch.int32)
+    sm = 1.0 / 576 ** 0.5
+    want = OK.decode_mla(q, kn, kr, lens, bt, sm)
+    got = run_mla(q.cuda(), kn.cuda(), kr.cuda(), lens.cuda(), bt.cuda(), sm, splits).cpu()
+    assert torch.allclose(got.float(), want.float(), **tol(dtype)), (got.float() - want.float()).abs().max()
+
+
+def test_full_size_c4_vs_fp32():
+    """BASELINE C4: B=128, 128 q-heads, one latent KV head, D=576, page 64, seqlen 4096 (+ a ragged copy)."""
+    torch.manual_seed(0)
+    B, Hq, S, page = 128, 128, 4096, 64
+    maxp = S // page
+    nb = B * maxp
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(torch.bfloat16)
+    kn = torch.randn((nb, page, 1, 512), generator=g, device="cuda").to(torch.bfloat16)
+    kr = torch.randn((nb, page, 1, 64), generator=g, device="cuda").to(torch.bfloat16)
+    bt = torch.randperm(nb, device="cuda").to(torch.int32).reshape(B, maxp)
+    for ragged in (False, True):
+        lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+        if ragged:
+            lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+        got = run_mla(q, kn, kr, lens, bt, 576 ** -0.5)
+        for b in (0, 17, 127):
+            L = int(lens[b])
+            idx = bt[b, :(L + page - 1) // page].long()
+            K = torch.cat([kn[idx].reshape(-1, 512), kr[idx].reshape(-1, 64)], dim=1)[:L].float()
+            s = (q[b].float() @ K.T) * 576 ** -0.5
+            p = torch.softmax(s, dim=-1)
+            ref = p @ K[:, :512]
+            assert torch.allclose(got[b].float(), ref, atol=1e-3, rtol=2 ** -7), (got[b].float() - ref).abs().max()
