@@ -54,6 +54,33 @@ int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *o
                   int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits, void *workspace,
                   size_t workspace_bytes, void *stream);
 
+/* ---- SwiGLU + per-row INT8 quantisation (swiglu_quant.py:87-127) -------------------------------------------------
+ * x [rows, cols] (cols = 2I; gate = x[:, :I], up = x[:, I:]); only the first `total` rows are processed, where total =
+ * group_list[num_groups-1] (group_list_type 0, cumulative) or sum(group_list) (type 1, counts), read on the device.
+ * need_quant: out int8 [rows, I] + scale f32 [rows] (scale = max|v|/127, q = clamp(floor(v/scale + 0.5), -128, 127));
+ * else out [rows, I] in the input dtype.  do_limit clamps gate <= limit and up to [-limit, limit]. */
+int mi_swiglu_quant(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type,
+                    int rows, int cols, int need_quant, int do_limit, float limit, int dtype, void *out, float *scale,
+                    void *stream);
+
+/* ---- Add + RMSNorm (+bias) (+static INT8 quant) and the Gemma variant (add_rmsnorm_bias.py:83-147,194-232) ----------
+ * y = input (+ residual) in the I/O dtype -> out2 (may be NULL when residual is NULL);
+ * v = float(y) * rstd * weight (+ bias)            [gemma != 0: rstd = rsqrt(var + eps), v = float(y)*rstd*(weight + 1)]
+ * out = v in the I/O dtype, or int8 saturate(rint(v * quant_scale + quant_offset)) when quant_scale/offset are given.
+ * weight / bias / quant_* are [hidden] in the I/O dtype; hidden % 8 == 0, hidden <= 8192. */
+int mi_add_rmsnorm_bias(const void *input, const void *residual, const void *weight, const void *bias, float eps,
+                        const void *quant_scale, const void *quant_offset, int gemma, int rows, int hidden,
+                        int64_t input_row_stride, int dtype, void *out, void *out2, void *stream);
+
+/* ---- split QKV + per-head RMSNorm (+bias) + RoPE (split_qkv_rmsnorm_rope.py:374-438) ---------------------------------
+ * qkv [rows, q_hidden + 2*kv_hidden]; sin / cos [rows, rope_dim]; q/k/v outputs contiguous.  has_norm == 0 skips the
+ * norm (reference: eps is None); biases optional (both or neither); rope_dim <= head_dim (partial RoPE); neox != 0 =
+ * rotate-half layout, else interleaved pairs.  head_dim power of two. */
+int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const void *cos, int rows, int q_hidden, int kv_hidden,
+                              int head_dim, int rope_dim, int has_norm, float eps, const void *q_weight,
+                              const void *k_weight, const void *q_bias, const void *k_bias, int neox, int dtype, void *q,
+                              void *k, void *v, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,3 +72,102 @@ def decode_mla_golden(q, k_nope, k_rope, kv_seq_lens, block_table, sm_scale):
         score = torch.softmax(qk, dim=-1).to(kn.dtype)
         outs.append(torch.einsum("hqk,khd->qhd", score, kn))
     return torch.cat(outs, dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# A11  SwiGLU + per-row INT8 quantisation
+# --------------------------------------------------------------------------------------
+def swiglu_quant(x, group_list, group_list_type, need_quant=True, do_limit=False, limit=7.0):
+    """Restates _swiglu_quant_kernel (python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_quant.py:26-84):
+    rows < total only (total = last cumulative entry for type 0 -- the reference indexes one past the end there, :27 --
+    or sum of counts for type 1); out = x1*sigmoid(x1)*x2 in fp32 (optional clamps :52-56); scale = max|out|/127;
+    q = clamp(floor(out/scale + 0.5), -128, 127) (:62-72).  Rows >= total are left zero here (uninitialised there).
+    Returns (out int8/ dtype [S, I], scale f32 [S], total)."""
+    S, h = x.shape
+    I = h // 2
+    gl = group_list.to(torch.int64)
+    total = int(gl[-1]) if group_list_type == 0 else int(gl.sum())
+    total = min(total, S)
+    xf = x[:total].float()
+    x1, x2 = xf[:, :I], xf[:, I:]
+    gate = x1 * torch.sigmoid(x1)
+    if do_limit:
+        gate = torch.minimum(gate, torch.tensor(float(limit)))
+        up = torch.clamp(x2, -limit, limit)
+        o = gate * up
+    else:
+        o = gate * x2
+    scale = torch.zeros(S, dtype=torch.float32)
+    if not need_quant:
+        out = torch.zeros((S, I), dtype=x.dtype)
+        out[:total] = o.to(x.dtype)
+        return out, scale, total
+    sc = o.abs().amax(dim=1) / 127.0
+    scale[:total] = sc
+    q = torch.floor(o / sc[:, None] + 0.5).clamp(-128, 127)
+    q = torch.where(sc[:, None] > 0, q, torch.zeros_like(q))
+    out = torch.zeros((S, I), dtype=torch.int8)
+    out[:total] = q.to(torch.int8)
+    return out, scale, total
+
+
+# --------------------------------------------------------------------------------------
+# A12  Add + RMSNorm (+bias) (+static quant) and the Gemma variant
+# --------------------------------------------------------------------------------------
+def add_rmsnorm_bias(input, residual, norm_weight, norm_bias, eps, quant_scale=None, quant_offset=None, gemma=False):
+    """Restates add_rmsnorm_bias_kernel (python/sgl_kernel_npu/sgl_kernel_npu/norm/add_rmsnorm_bias.py:25-77): the sum is
+    formed and stored in the input dtype (:33-37), then fp32: y * (1/sqrt(mean(y^2)+eps)) * w + b (:39-47), optional
+    int8_saturate(v*quant_scale + quant_offset) (:56-68; rounding = nearest-even, the test golden uses np.round with a
+    +-1 tolerance).  gemma=True: add_gemma_rms_norm_kernel (:173-190): rsqrt, weight + 1, no bias."""
+    y = input if residual is None else (input + residual)          # dtype add == round(float add)
+    yf = y.float()
+    var = (yf * yf).mean(dim=-1, keepdim=True)
+    rstd = torch.rsqrt(var + eps) if gemma else 1.0 / torch.sqrt(var + eps)
+    w = norm_weight.float() + 1.0 if gemma else norm_weight.float()
+    v = (yf * rstd) * w
+    if norm_bias is not None:
+        v = v + norm_bias.float()
+    if quant_scale is not None:
+        v = torch.round(v * quant_scale.float() + quant_offset.float()).clamp(-128, 127).to(torch.int8)
+    else:
+        v = v.to(input.dtype)
+    return v, y
+
+
+# --------------------------------------------------------------------------------------
+# A13  split QKV + per-head RMSNorm + RoPE
+# --------------------------------------------------------------------------------------
+def split_qkv_rmsnorm_rope(qkv, sin, cos, q_hidden, kv_hidden, head_dim, eps=None, q_weight=None, k_weight=None, q_bias=None,
+                           k_bias=None, is_neox_style=True):
+    """Restates split_qkv_rmsnorm_rope_kernel (python/sgl_kernel_npu/sgl_kernel_npu/norm/split_qkv_rmsnorm_rope.py:38-198)
+    in fp32: per head optional RMSNorm*w(+b) (:55-69), RoPE on the first rope_dim dims: cat(-x2, x1)*sin + x*cos with the
+    rotate-half (:137-160) or interleaved (:161-182, sin/cos = first half duplicated pairwise :75-99) layout, remaining
+    dims pass through (:184-197); V is copied."""
+    B = qkv.shape[0]
+    rope_dim = sin.shape[-1]
+    half = rope_dim // 2
+    q, k, v = qkv.split([q_hidden, kv_hidden, kv_hidden], dim=-1)
+    s = sin.reshape(B, 1, rope_dim).float()
+    c = cos.reshape(B, 1, rope_dim).float()
+
+    def one(x, w, b):
+        x = x.reshape(B, -1, head_dim).float()
+        if eps is not None:
+            rstd = 1.0 / torch.sqrt((x * x).mean(dim=-1, keepdim=True) + eps)
+            x = (x * rstd) * w.float()
+            if b is not None:
+                x = x + b.float()
+        rot, rest = x[..., :rope_dim], x[..., rope_dim:]
+        if is_neox_style:
+            x1, x2 = rot[..., :half], rot[..., half:]
+            cat = torch.cat([-x2, x1], dim=-1)
+            out = cat * s + rot * c
+        else:
+            x1, x2 = rot[..., 0::2], rot[..., 1::2]
+            sh, ch = s[..., :half], c[..., :half]
+            out = torch.empty_like(rot)
+            out[..., 0::2] = (-x2) * sh + x1 * ch
+            out[..., 1::2] = x1 * sh + x2 * ch
+        return torch.cat([out, rest], dim=-1).reshape(B, -1).to(qkv.dtype)
+
+    return one(q, q_weight, q_bias), one(k, k_weight, k_bias), v.clone()

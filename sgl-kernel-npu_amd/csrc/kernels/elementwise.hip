@@ -1,0 +1,370 @@
+// HBM-bound fused elementwise primitives for gfx950: SwiGLU + per-row INT8 quantisation, Add + RMSNorm (+bias, +static
+// INT8 quantisation, Gemma variant), split-QKV + per-head RMSNorm + RoPE.
+// Replace the reference's Triton-Ascend kernels:
+//   swiglu_quant            python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_quant.py:8-127
+//   add_rmsnorm_bias        python/sgl_kernel_npu/sgl_kernel_npu/norm/add_rmsnorm_bias.py:8-147
+//   add_gemma_rms_norm      python/sgl_kernel_npu/sgl_kernel_npu/norm/add_rmsnorm_bias.py:150-232
+//   split_qkv_rmsnorm_rope  python/sgl_kernel_npu/sgl_kernel_npu/norm/split_qkv_rmsnorm_rope.py:8-438
+// MI355X design: every row is read once with 16-B loads and held in registers in fp32 (no second pass over HBM for the
+// reduction), one wave64 per row / head where the row fits 64 registers, one 256-thread workgroup per row for hidden
+// sizes up to 8192; reductions are wave shuffles (+ one LDS hop across waves).  Algorithmic bytes are listed per op.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi_sgl_kernels.h"
+
+namespace mi_sgl {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool BF16>
+__device__ __forceinline__ float ld16(uint32_t bits)
+{
+    if constexpr (BF16) return __uint_as_float(bits << 16);
+    else return (float)__builtin_bit_cast(_Float16, (uint16_t)bits);
+}
+template <bool BF16>
+__device__ __forceinline__ uint32_t st16(float f)
+{
+    if constexpr (BF16) {
+        uint32_t x = __float_as_uint(f);
+        if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
+        return (x + 0x7FFFu + ((x >> 16) & 1u)) >> 16;
+    } else {
+        return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void unpack8(const u32x4 &v, float *f)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = ld16<BF16>(v[j] & 0xFFFFu);
+        f[2 * j + 1] = ld16<BF16>(v[j] >> 16);
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ u32x4 pack8(const float *f)
+{
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = st16<BF16>(f[2 * j]) | (st16<BF16>(f[2 * j + 1]) << 16);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int sat_i8(float v)
+{
+    const float r = rintf(v);
+    return (int)fminf(fmaxf(r, -128.f), 127.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU + per-row symmetric INT8:  out = x1 * sigmoid(x1) * x2 (fp32), scale = max|out| / 127,
+// q = clamp(floor(out / scale + 0.5), -128, 127)      (swiglu_quant.py:49-72; note floor(x+0.5), not rint)
+// bytes per row: 2I*2 read + I (+4) written.  One wave per row, I <= 4096.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSwigluItems = 8;   // 8 x (64 lanes x 8 elements) = 4096 columns
+
+template <bool BF16, bool I64>
+__global__ __launch_bounds__(256) void swiglu_quant_kernel(const uint16_t *__restrict__ x, const void *__restrict__ group_list,
+                                                          int num_groups, int group_list_type, int rows, int I,
+                                                          int need_quant, int do_limit, float limit, void *__restrict__ out,
+                                                          float *__restrict__ scale)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // number of valid rows: last cumulative entry (type 0) or the sum of the per-group counts (type 1)
+    long long total;
+    if (group_list_type == 0) {
+        // the reference indexes one past the end here (swiglu_quant.py:27); the cumulative total is the last entry
+        total = I64 ? ((const long long *)group_list)[num_groups - 1] : (long long)((const int *)group_list)[num_groups - 1];
+    } else {
+        long long s = 0;
+        for (int i = lane; i < num_groups; i += 64) s += I64 ? ((const long long *)group_list)[i] : (long long)((const int *)group_list)[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        total = s;
+    }
+    if (row >= rows || row >= total) return;
+    const u32x4 *xr = (const u32x4 *)(x + row * 2 * (long long)I);
+    const int nitems = I / 8;
+    float v[kSwigluItems][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int it = 0; it < kSwigluItems; ++it) {
+        const int item = it * 64 + lane;
+        if (item < nitems) {
+            float a[8], b[8];
+            unpack8<BF16>(xr[item], a);
+            unpack8<BF16>(xr[nitems + item], b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gate = a[j] * (1.0f / (1.0f + __expf(-a[j])));
+                float up = b[j];
+                if (do_limit) {
+                    gate = fminf(gate, limit);
+                    up = fmaxf(fminf(up, limit), -limit);
+                }
+                v[it][j] = gate * up;
+                amax = fmaxf(amax, fabsf(v[it][j]));
+            }
+        }
+    }
+    if (!need_quant) {
+        u32x4 *orow = (u32x4 *)((uint16_t *)out + row * (long long)I);
+#pragma unroll
+        for (int it = 0; it < kSwigluItems; ++it) {
+            const int item = it * 64 + lane;
+            if (item < nitems) orow[item] = pack8<BF16>(v[it]);
+        }
+        return;
+    }
+    amax = wave_max(amax);
+    const float s = amax / 127.0f;
+    if (lane == 0) scale[row] = s;
+    u32x2 *orow = (u32x2 *)((int8_t *)out + row * (long long)I);
+#pragma unroll
+    for (int it = 0; it < kSwigluItems; ++it) {
+        const int item = it * 64 + lane;
+        if (item < nitems) {
+            uint32_t w[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float q = (s > 0.f) ? floorf(v[it][j] / s + 0.5f) : 0.f;
+                q = fminf(fmaxf(q, -128.f), 127.f);
+                w[j >> 2] |= ((uint32_t)((int)q & 0xFF)) << (8 * (j & 3));
+            }
+            orow[item] = u32x2{w[0], w[1]};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Add + RMSNorm (+ bias) (+ static INT8 quantisation) / Gemma variant.  One 256-thread workgroup per row, H <= 8192.
+//   y = in (+ res) rounded to the I/O dtype (stored as out2);  v = float(y) * rstd * w (+ b)   [gemma: * (w + 1)]
+//   out = v in the I/O dtype, or int8_sat(rint(v * qscale + qoffset))      (add_rmsnorm_bias.py:33-68,185-190)
+// bytes per row: 2H in (+2H res) + 2H out2 + 2H (or H) out.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNormItems = 4;     // 4 x (256 threads x 8 elements) = 8192 columns
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(const uint16_t *__restrict__ in, const uint16_t *__restrict__ res,
+                                                         const uint16_t *__restrict__ w, const uint16_t *__restrict__ bias,
+                                                         const uint16_t *__restrict__ qs, const uint16_t *__restrict__ qo,
+                                                         float eps, int gemma, int H, long long in_stride,
+                                                         void *__restrict__ out, uint16_t *__restrict__ out2)
+{
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nitems = H / 8;
+    const u32x4 *ir = (const u32x4 *)(in + row * in_stride);
+    const u32x4 *rr = res ? (const u32x4 *)(res + row * in_stride) : nullptr;
+    float y[kNormItems][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNormItems; ++it) {
+        const int item = it * 256 + tid;
+        if (item < nitems) {
+            float a[8];
+            unpack8<BF16>(ir[item], a);
+            if (rr) {
+                float b[8];
+                unpack8<BF16>(rr[item], b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = ld16<BF16>(st16<BF16>(a[j] + b[j]));   // the sum lives in the I/O dtype
+                if (out2) ((u32x4 *)(out2 + row * (long long)H))[item] = pack8<BF16>(a);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                y[it][j] = a[j];
+                ss += a[j] * a[j];
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)H;
+    const float rstd = gemma ? rsqrtf(var + eps) : 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int it = 0; it < kNormItems; ++it) {
+        const int item = it * 256 + tid;
+        if (item < nitems) {
+            float wv[8], o[8];
+            unpack8<BF16>(((const u32x4 *)w)[item], wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (y[it][j] * rstd) * (gemma ? wv[j] + 1.0f : wv[j]);
+            if (bias) {
+                float bv[8];
+                unpack8<BF16>(((const u32x4 *)bias)[item], bv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = o[j] + bv[j];
+            }
+            if (qs) {
+                float sv[8], ov[8];
+                unpack8<BF16>(((const u32x4 *)qs)[item], sv);
+                unpack8<BF16>(((const u32x4 *)qo)[item], ov);
+                uint32_t wq[2] = {0, 0};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wq[j >> 2] |= ((uint32_t)(sat_i8(o[j] * sv[j] + ov[j]) & 0xFF)) << (8 * (j & 3));
+                ((u32x2 *)((int8_t *)out + row * (long long)H))[item] = u32x2{wq[0], wq[1]};
+            } else {
+                ((u32x4 *)((uint16_t *)out + row * (long long)H))[item] = pack8<BF16>(o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split QKV + per-head RMSNorm (+bias) + RoPE on the first rope_dim dims; V is copied.  One wave per (row, head).
+//   neox:        out[p] = x[p]*cos[p] - x[p+h]*sin[p],  out[p+h] = x[p+h]*cos[p+h] + x[p]*sin[p+h]          (h = rope_dim/2)
+//   interleaved: out[2i] = x[2i]*cos[i] - x[2i+1]*sin[i], out[2i+1] = x[2i+1]*cos[i] + x[2i]*sin[i]
+// (split_qkv_rmsnorm_rope.py:38-198; sin / cos rows are [rope_dim] per batch row)
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_kernel(
+    const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ sin, const uint16_t *__restrict__ cos, int rows, int q_hidden,
+    int kv_hidden, int head_dim, int rope_dim, int has_norm, float eps, const uint16_t *__restrict__ qw,
+    const uint16_t *__restrict__ kw, const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kb, int neox,
+    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v)
+{
+    const int lane = threadIdx.x & 63;
+    const int q_heads = q_hidden / head_dim, kv_heads = kv_hidden / head_dim;
+    const int heads_total = q_heads + 2 * kv_heads;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long row = wid / heads_total;
+    const int h = (int)(wid % heads_total);
+    if (row >= rows) return;
+    const long long total_hidden = (long long)q_hidden + 2ll * kv_hidden;
+    const uint16_t *src = qkv + row * total_hidden + (long long)h * head_dim;
+    if (h >= q_heads + kv_heads) {      // V: plain copy
+        uint16_t *dst = v + row * (long long)kv_hidden + (long long)(h - q_heads - kv_heads) * head_dim;
+        for (int i = lane; i < head_dim; i += 64) dst[i] = src[i];
+        return;
+    }
+    const bool is_q = h < q_heads;
+    uint16_t *dst = is_q ? q + row * (long long)q_hidden + (long long)h * head_dim
+                         : k + row * (long long)kv_hidden + (long long)(h - q_heads) * head_dim;
+    const uint16_t *wt = is_q ? qw : kw, *bs = is_q ? qb : kb;
+    float ss = 0.f;
+    if (has_norm)
+        for (int i = lane; i < head_dim; i += 64) {
+            const float a = ld16<BF16>(src[i]);
+            ss += a * a;
+        }
+    float rstd = 1.f;
+    if (has_norm) rstd = 1.0f / sqrtf(wave_sum(ss) / (float)head_dim + eps);
+    auto nrm = [&](int i) -> float {
+        float a = ld16<BF16>(src[i]);
+        if (has_norm) {
+            a = (a * rstd) * ld16<BF16>(wt[i]);
+            if (bs) a = a + ld16<BF16>(bs[i]);
+        }
+        return a;
+    };
+    const int half = rope_dim / 2;
+    const uint16_t *sr = sin + row * (long long)rope_dim, *cr = cos + row * (long long)rope_dim;
+    for (int p = lane; p < half; p += 64) {
+        if (neox) {
+            const float x1 = nrm(p), x2 = nrm(p + half);
+            dst[p] = (uint16_t)st16<BF16>((-x2) * ld16<BF16>(sr[p]) + x1 * ld16<BF16>(cr[p]));
+            dst[p + half] = (uint16_t)st16<BF16>(x1 * ld16<BF16>(sr[p + half]) + x2 * ld16<BF16>(cr[p + half]));
+        } else {
+            const float x1 = nrm(2 * p), x2 = nrm(2 * p + 1);
+            const float s = ld16<BF16>(sr[p]), c = ld16<BF16>(cr[p]);
+            dst[2 * p] = (uint16_t)st16<BF16>((-x2) * s + x1 * c);
+            dst[2 * p + 1] = (uint16_t)st16<BF16>(x1 * s + x2 * c);
+        }
+    }
+    for (int i = rope_dim + lane; i < head_dim; i += 64) dst[i] = (uint16_t)st16<BF16>(nrm(i));
+}
+
+}  // namespace mi_sgl
+
+using namespace mi_sgl;
+
+static int launch_ok() { return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH; }
+
+extern "C" int mi_swiglu_quant(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type,
+                               int rows, int cols, int need_quant, int do_limit, float limit, int dtype, void *out, float *scale,
+                               void *stream)
+{
+    if (rows < 0 || cols <= 0 || cols % 16 || cols / 2 > kSwigluItems * 512 || num_groups <= 0 ||
+        (group_list_type != 0 && group_list_type != 1) || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!x || !group_list || !out || (need_quant && !scale)) return MI_SGL_EINVAL;
+    const int blocks = (rows + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_LAUNCH(B, L)                                                                                                          \
+    swiglu_quant_kernel<B, L><<<blocks, 256, 0, st>>>((const uint16_t *)x, group_list, num_groups, group_list_type, rows, cols / 2, \
+                                                      need_quant, do_limit, limit, out, scale)
+    if (dtype == MI_DTYPE_BF16) { if (group_list_is_i64) MI_LAUNCH(true, true); else MI_LAUNCH(true, false); }
+    else { if (group_list_is_i64) MI_LAUNCH(false, true); else MI_LAUNCH(false, false); }
+#undef MI_LAUNCH
+    return launch_ok();
+}
+
+extern "C" int mi_add_rmsnorm_bias(const void *input, const void *residual, const void *weight, const void *bias, float eps,
+                                   const void *quant_scale, const void *quant_offset, int gemma, int rows, int hidden,
+                                   int64_t input_row_stride, int dtype, void *out, void *out2, void *stream)
+{
+    if (rows < 0 || hidden <= 0 || hidden % 8 || hidden > kNormItems * 2048 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) ||
+        ((quant_scale == nullptr) != (quant_offset == nullptr)) || input_row_stride % 8)
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!input || !weight || !out) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI_DTYPE_BF16)
+        add_rmsnorm_kernel<true><<<rows, 256, 0, st>>>((const uint16_t *)input, (const uint16_t *)residual, (const uint16_t *)weight,
+                                                      (const uint16_t *)bias, (const uint16_t *)quant_scale,
+                                                      (const uint16_t *)quant_offset, eps, gemma, hidden, input_row_stride, out,
+                                                      (uint16_t *)out2);
+    else
+        add_rmsnorm_kernel<false><<<rows, 256, 0, st>>>((const uint16_t *)input, (const uint16_t *)residual, (const uint16_t *)weight,
+                                                       (const uint16_t *)bias, (const uint16_t *)quant_scale,
+                                                       (const uint16_t *)quant_offset, eps, gemma, hidden, input_row_stride, out,
+                                                       (uint16_t *)out2);
+    return launch_ok();
+}
+
+extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const void *cos, int rows, int q_hidden, int kv_hidden,
+                                         int head_dim, int rope_dim, int has_norm, float eps, const void *q_weight,
+                                         const void *k_weight, const void *q_bias, const void *k_bias, int neox, int dtype,
+                                         void *q, void *k, void *v, void *stream)
+{
+    if (rows < 0 || head_dim <= 0 || (head_dim & (head_dim - 1)) || q_hidden % head_dim || kv_hidden % head_dim ||
+        kv_hidden <= 0 || q_hidden % kv_hidden || rope_dim <= 0 || rope_dim > head_dim || rope_dim % 2 ||
+        (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!qkv || !sin || !cos || !q || !k || !v || (has_norm && (!q_weight || !k_weight)) || ((q_bias == nullptr) != (k_bias == nullptr)))
+        return MI_SGL_EINVAL;
+    const long long waves = (long long)rows * ((q_hidden + 2 * kv_hidden) / head_dim);
+    const int blocks = (int)((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI_DTYPE_BF16)
+        split_qkv_rmsnorm_rope_kernel<true><<<blocks, 256, 0, st>>>(
+            (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm,
+            eps, (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox,
+            (uint16_t *)q, (uint16_t *)k, (uint16_t *)v);
+    else
+        split_qkv_rmsnorm_rope_kernel<false><<<blocks, 256, 0, st>>>(
+            (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm,
+            eps, (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox,
+            (uint16_t *)q, (uint16_t *)k, (uint16_t *)v);
+    return launch_ok();
+}

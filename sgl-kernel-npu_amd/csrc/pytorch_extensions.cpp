@@ -58,6 +58,89 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
     TORCH_CHECK(rc == 0, "mi_mla_decode failed with code ", rc);
 }
 
+// SwiGLU + per-row INT8 quantisation; same arguments / returns as swiglu_quant (activation/swiglu_quant.py:87-127).
+std::tuple<at::Tensor, at::Tensor> swiglu_quant(const at::Tensor &x, const at::Tensor &group_list, int64_t group_list_type,
+                                                bool need_quant, bool do_limit, double limit)
+{
+    TORCH_CHECK(group_list_type == 0 || group_list_type == 1, "group_list_type must be 0 or 1, but got ", group_list_type);
+    TORCH_CHECK(x.dim() == 2 && x.is_contiguous(), "swiglu_quant: x must be a contiguous [s, h] tensor");
+    TORCH_CHECK(group_list.scalar_type() == at::kInt || group_list.scalar_type() == at::kLong,
+                "group_list dtype must be torch.int32 or torch.int64, but got ", group_list.scalar_type());
+    TORCH_CHECK(group_list.dim() == 1 && group_list.is_contiguous(), "swiglu_quant: group_list must be 1-D contiguous");
+    const int64_t s = x.size(0), h = x.size(1);
+    at::Tensor out = at::empty({s, h / 2}, x.options().dtype(need_quant ? at::kChar : x.scalar_type()));
+    at::Tensor scale = at::empty({s}, x.options().dtype(at::kFloat));
+    const int rc = mi_swiglu_quant(x.data_ptr(), group_list.data_ptr(), group_list.scalar_type() == at::kLong,
+                                   (int)group_list.size(0), (int)group_list_type, (int)s, (int)h, need_quant, do_limit,
+                                   (float)limit, dtype_code(x), out.data_ptr(), scale.data_ptr<float>(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_swiglu_quant failed with code ", rc, " (h must be a multiple of 16 and <= 8192)");
+    return {out, scale};
+}
+
+// Fused Add + RMSNorm (+bias) (+static INT8 quant); returns (output, residual_sum) like add_rmsnorm_bias
+// (norm/add_rmsnorm_bias.py:83-147).  gemma = true gives add_gemma_rms_norm (:194-232) which returns (norm, add_output).
+std::tuple<at::Tensor, at::Tensor> add_rmsnorm_bias(const at::Tensor &input, const std::optional<at::Tensor> &residual,
+                                                    const at::Tensor &norm_weight, const std::optional<at::Tensor> &norm_bias,
+                                                    double eps, const std::optional<at::Tensor> &quant_scale,
+                                                    const std::optional<at::Tensor> &quant_offset, bool gemma)
+{
+    TORCH_CHECK(input.dim() == 2 && input.stride(1) == 1, "add_rmsnorm_bias: input must be [batch, hidden] with contiguous rows");
+    const int64_t B = input.size(0), H = input.size(1);
+    TORCH_CHECK(norm_weight.numel() == H && norm_weight.is_contiguous() && norm_weight.scalar_type() == input.scalar_type(),
+                "add_rmsnorm_bias: weight must be [hidden] in the input dtype");
+    TORCH_CHECK(quant_scale.has_value() == quant_offset.has_value(), "quant_scale and quant_offset go together");
+    at::Tensor res_c;
+    if (residual.has_value()) {
+        TORCH_CHECK(residual->sizes() == input.sizes() && residual->scalar_type() == input.scalar_type(), "residual shape/dtype");
+        res_c = (residual->stride(0) == input.stride(0) && residual->stride(1) == 1) ? *residual : residual->contiguous();
+    }
+    at::Tensor in_c = input;
+    if (residual.has_value() && res_c.stride(0) != input.stride(0)) in_c = input.contiguous(), res_c = res_c.contiguous();
+    at::Tensor out = at::empty({B, H}, input.options().dtype(quant_scale.has_value() ? at::kChar : input.scalar_type()));
+    at::Tensor out2 = residual.has_value() ? at::empty({B, H}, input.options()) : input;
+    auto opt_ptr = [&](const std::optional<at::Tensor> &t) -> const void * {
+        if (!t.has_value()) return nullptr;
+        TORCH_CHECK(t->numel() == H && t->is_contiguous() && t->scalar_type() == input.scalar_type(),
+                    "add_rmsnorm_bias: per-column vectors must be [hidden] in the input dtype");
+        return t->data_ptr();
+    };
+    const int rc = mi_add_rmsnorm_bias(in_c.data_ptr(), residual.has_value() ? res_c.data_ptr() : nullptr, norm_weight.data_ptr(),
+                                       opt_ptr(norm_bias), (float)eps, opt_ptr(quant_scale), opt_ptr(quant_offset), gemma, (int)B,
+                                       (int)H, in_c.stride(0), dtype_code(input), out.data_ptr(),
+                                       residual.has_value() ? out2.data_ptr() : nullptr, cur_stream());
+    TORCH_CHECK(rc == 0, "mi_add_rmsnorm_bias failed with code ", rc, " (hidden must be a multiple of 8 and <= 8192)");
+    return {out, out2};
+}
+
+// split QKV + per-head RMSNorm + RoPE; arguments as split_qkv_rmsnorm_rope (norm/split_qkv_rmsnorm_rope.py:374-438).
+std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
+    const at::Tensor &input, const at::Tensor &sin, const at::Tensor &cos, int64_t q_hidden_size, int64_t kv_hidden_size,
+    int64_t head_dim, std::optional<double> eps, const std::optional<at::Tensor> &q_weight,
+    const std::optional<at::Tensor> &k_weight, const std::optional<at::Tensor> &q_bias, const std::optional<at::Tensor> &k_bias,
+    bool is_neox_style)
+{
+    TORCH_CHECK(input.dim() == 2 && input.is_contiguous(), "split_qkv_rmsnorm_rope: input must be contiguous [batch, q+2kv]");
+    TORCH_CHECK((head_dim & (head_dim - 1)) == 0, "head_dim must be a power of two");        // reference :390-391
+    TORCH_CHECK(q_hidden_size % kv_hidden_size == 0, "q_hidden_size % kv_hidden_size != 0");   // reference :392
+    TORCH_CHECK(input.size(1) == q_hidden_size + 2 * kv_hidden_size, "split_qkv_rmsnorm_rope: input width");
+    const int64_t B = input.size(0);
+    const int64_t rope_dim = sin.size(-1);
+    TORCH_CHECK(sin.numel() == B * rope_dim && cos.numel() == B * rope_dim && sin.is_contiguous() && cos.is_contiguous() &&
+                    sin.scalar_type() == input.scalar_type() && cos.scalar_type() == input.scalar_type(),
+                "split_qkv_rmsnorm_rope: sin/cos must be contiguous [batch, ..., rope_dim] in the input dtype");
+    if (eps.has_value()) TORCH_CHECK(q_weight.has_value() && k_weight.has_value(), "norm weights are required when eps is given");
+    TORCH_CHECK(q_bias.has_value() == k_bias.has_value(), "q_bias and k_bias go together");
+    at::Tensor q = at::empty({B, q_hidden_size}, input.options()), k = at::empty({B, kv_hidden_size}, input.options()),
+               v = at::empty({B, kv_hidden_size}, input.options());
+    auto p = [](const std::optional<at::Tensor> &t) -> const void * { return t.has_value() ? t->data_ptr() : nullptr; };
+    const int rc = mi_split_qkv_rmsnorm_rope(input.data_ptr(), sin.data_ptr(), cos.data_ptr(), (int)B, (int)q_hidden_size,
+                                             (int)kv_hidden_size, (int)head_dim, (int)rope_dim, eps.has_value(),
+                                             (float)eps.value_or(0.0), p(q_weight), p(k_weight), p(q_bias), p(k_bias),
+                                             is_neox_style, dtype_code(input), q.data_ptr(), k.data_ptr(), v.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_split_qkv_rmsnorm_rope failed with code ", rc);
+    return {q, k, v};
+}
+
 }  // namespace npu_kernel
 }  // namespace sglang
 
@@ -66,9 +149,19 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("sgl_kernel_npu_version() -> str", &sglang::npu_kernel::sgl_kernel_npu_version);
     m.def("decode_mla(Tensor q, Tensor k_nope_buffer, Tensor k_rope_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
           "float sm_scale, int page_size, Tensor block_table, int num_splits=0) -> ()");
+    m.def("swiglu_quant(Tensor x, Tensor group_list, int group_list_type, bool need_quant=True, bool do_limit=False, "
+          "float limit=7.0) -> (Tensor, Tensor)");
+    m.def("add_rmsnorm_bias(Tensor input, Tensor? residual, Tensor norm_weight, Tensor? norm_bias, float eps, "
+          "Tensor? quant_scale=None, Tensor? quant_offset=None, bool gemma=False) -> (Tensor, Tensor)");
+    m.def("split_qkv_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
+          "float? eps=None, Tensor? q_weight=None, Tensor? k_weight=None, Tensor? q_bias=None, Tensor? k_bias=None, "
+          "bool is_neox_style=True) -> (Tensor, Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(npu, CUDA, m)
 {
     m.impl("decode_mla", TORCH_FN(sglang::npu_kernel::decode_mla));
+    m.impl("swiglu_quant", TORCH_FN(sglang::npu_kernel::swiglu_quant));
+    m.impl("add_rmsnorm_bias", TORCH_FN(sglang::npu_kernel::add_rmsnorm_bias));
+    m.impl("split_qkv_rmsnorm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope));
 }
