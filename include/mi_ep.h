@@ -161,6 +161,24 @@ int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint3
                            int32_t *src_info, int32_t *layout_range, int32_t *status, int timeout_ms,
                            void *stream);
 
+/* ---- A8 fused_deep_moe building blocks (reference: aclnnFusedDeepMoe, csrc/deepep/deep_ep.cpp:1223;
+ * kernel csrc/deepep/ops/op_kernel/fused_deep_moe.h:336-427) -------------------------------------------------------
+ * Rows are the packed output of the low-latency dispatch; expert e owns rows [cum[e*s-1], cum[(e+1)*s-1]) of the
+ * inclusive cumulative table `row_cumsum` (s = cum_stride; pass layout_range with s = W).  rows_cap bounds the rows.
+ * gemm1_swiglu: a int8 [rows, hidden] (per-token scales a_scale), w int8 [L, two_i, hidden] (K contiguous; columns of every
+ *   128-wide tile are 64 gate then 64 up, i.e. reshape_fusion_gmm_weight of tests/python/deepep/test_fused_deep_moe.py:75-86),
+ *   w_scale f32 [L, two_i] permuted alike.  out f32 [rows, two_i/2]: up * silu(gate), gate/up = (i32 * w_scale[col]) * a_scale[row].
+ * rowquant: q = int8 rint((v * 127) * (1 / rowmax)), scale = rowmax / 127 for rows < *total_rows_dev.
+ * gemm2: a int8 [rows, inter] with scales, w int8 [L, hidden, inter], w_scale f32 [L, hidden]; out bf16 [rows, hidden].
+ * hidden, inter multiples of 128; two_i multiple of 128. */
+int mi_ep_moe_gemm1_swiglu(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale,
+                           const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap, int hidden,
+                           int two_i, float *out, void *stream);
+int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_cap, int inter, int8_t *q, float *scale,
+                       void *stream);
+int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,
+                    int cum_stride, int num_local_experts, int rows_cap, int inter, int hidden, void *out_bf16, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -425,3 +425,56 @@ def calc_diff(x: np.ndarray, y: np.ndarray) -> float:
     x = x.astype(np.float64) + 1
     y = y.astype(np.float64) + 1
     return float(1 - 2 * (x * y).sum() / (x * x + y * y).sum())
+
+
+# --------------------------------------------------------------------------------------
+# A8  fused_deep_moe (dispatch -> INT8 grouped GEMM1 + SwiGLU -> requant -> GEMM2 -> combine)
+# --------------------------------------------------------------------------------------
+def permute_fusion_cols(n: int, tile: int = 128) -> np.ndarray:
+    """Column permutation of reshape_fusion_gmm_weight / permute_weight (tests/python/deepep/test_fused_deep_moe.py:63-86):
+    permuted column j*tile + h*(tile/2) + i  <-  original column h*(n/2) + j*(tile/2) + i  (h = 0 gate half, 1 up half)."""
+    half = tile // 2
+    j, h, i = np.meshgrid(np.arange(n // tile), np.arange(2), np.arange(half), indexing="ij")
+    return (h * (n // 2) + j * half + i).reshape(-1)
+
+
+def fused_deep_moe(xs_bits, topk_idxs, topk_weights, w13, w13_scale, w2, w2_scale, num_max_dispatch_tokens_per_rank,
+                   num_experts) -> List[np.ndarray]:
+    """All ranks' fused_deep_moe.  w13[r] int8 [L, 2I, H] / w13_scale[r] f32 [L, 2I] in ORIGINAL column order (first half gate,
+    second half up; the permutation only changes where a column sits, not the math), w2[r] int8 [L, H, I], w2_scale[r] f32 [L, H].
+    Arithmetic: INT8 per-token dispatch without epsilon; d = (float(c) * w_scale[col]) * tok_scale[row]
+    (block_epilogue_per_token_dequant_swiglu.h:250-269); v = up * gate / (1 + exp(-gate)); q = rint((v*127) * (1/rowmax)),
+    scale = rowmax/127 (...swiglu_quant_multistage_workspace.h:199-265); y = bf16((float(c2) * w2_scale[col]) * scale[row]);
+    combine as A6.  Returns bf16 bits per rank."""
+    W = len(xs_bits)
+    E = int(num_experts)
+    L = E // W
+    disp = low_latency_dispatch(xs_bits, topk_idxs, num_max_dispatch_tokens_per_rank, E, quant=True)
+    ys = []
+    for r in range(W):
+        d = disp[r]
+        n = d.total
+        H = d.packed_recv_x.shape[1]
+        y = np.zeros((d.packed_recv_x.shape[0], H), np.uint16)
+        start = 0
+        for le in range(L):
+            end = int(d.layout_range[(le + 1) * W - 1])
+            if end > start:
+                a = d.packed_recv_x[start:end].astype(np.int32)
+                asc = d.packed_recv_x_scales[start:end].astype(np.float32)
+                c = a @ w13[r][le].astype(np.int32).T                                   # [rows, 2I] exact
+                dd = (c.astype(np.float32) * w13_scale[r][le].astype(np.float32)[None, :]) * asc[:, None]
+                I = dd.shape[1] // 2
+                gate, up = dd[:, :I], dd[:, I:]
+                with np.errstate(over="ignore"):
+                    v = (up * (gate / (np.float32(1.0) + np.exp(-gate).astype(np.float32)))).astype(np.float32)
+                rowmax = np.abs(v).max(axis=1).astype(np.float32)
+                inv = np.where(rowmax > 0, np.float32(1.0) / np.where(rowmax > 0, rowmax, 1), 0).astype(np.float32)
+                q = np.rint((v * np.float32(127.0)) * inv[:, None]).astype(np.int32)
+                sc = (rowmax / np.float32(127.0)).astype(np.float32)
+                c2 = q @ w2[r][le].astype(np.int32).T                                    # [rows, H]
+                out = (c2.astype(np.float32) * w2_scale[r][le].astype(np.float32)[None, :]) * sc[:, None]
+                y[start:end] = f32_to_bf16_bits_rne(out)
+            start = end
+        ys.append(y)
+    return combine(ys, [d.src_info for d in disp], [d.total for d in disp], topk_idxs, topk_weights, E)

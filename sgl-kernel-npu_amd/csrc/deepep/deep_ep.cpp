@@ -574,11 +574,75 @@ void Buffer::internode_unsupported() const
                       "internode (multi-node RDMA) dispatch/combine is out of scope: one MI355X xGMI node is a single rdma rank");
 }
 
-std::vector<at::Tensor> Buffer::fused_deep_moe(const at::Tensor &, const at::Tensor &, const at::Tensor &, const at::Tensor &,
-                                               const at::Tensor &, const at::Tensor &, const std::optional<at::Tensor> &,
-                                               int64_t, int64_t, int64_t, bool)
+// ------------------------------------------------------------------------------------------------
+// A8  fused_deep_moe  (reference deep_ep.cpp:1089-1113,1214-1233; kernel ops/op_kernel/fused_deep_moe.h)
+// dispatch (INT8 per token, low-latency layout) -> grouped GEMM1 + dequant + SwiGLU -> per-row requant -> grouped GEMM2 +
+// dequant -> weighted combine.  The reference runs this as ONE Ascend MIX kernel; here it is a chain of launches on the
+// caller's stream sharing buffers (no host synchronisation anywhere), each stage a HIP kernel of include/mi_ep.h.
+// Weight layout on MI355X: gmm1_permuted_weight int8 [L, 2I, H] and gmm2_weight int8 [L, H, I] (output channel major,
+// K contiguous; the Ascend NZ fractal format does not exist here).  The reference's logical shapes [L, H, 2I] / [L, I, H]
+// are accepted and transposed on the fly.
+// ------------------------------------------------------------------------------------------------
+std::vector<at::Tensor> Buffer::fused_deep_moe(const at::Tensor &x, const at::Tensor &expert_ids,
+                                               const at::Tensor &gmm1_permuted_weight,
+                                               const at::Tensor &gmm1_permuted_weight_scale, const at::Tensor &gmm2_weight,
+                                               const at::Tensor &gmm2_weight_scale,
+                                               const std::optional<at::Tensor> &expert_scales_optional,
+                                               int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts,
+                                               int64_t quant_mode, bool)
 {
-    throw EPException("Assertion", __FILE__, __LINE__, "fused_deep_moe: not implemented in this build (SURVEY.md section 8(f) N1)");
+    require_available();
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
+    EP_HOST_ASSERT(expert_ids.dim() == 2 and expert_ids.is_contiguous() and expert_ids.size(0) == x.size(0));
+    EP_HOST_ASSERT_S(quant_mode == 1, "fused_deep_moe: only quant_mode=1 (INT8 weights) is implemented on this device");
+    EP_HOST_ASSERT(expert_scales_optional.has_value());
+    const int W = (int)num_ranks, E = (int)num_experts, L = E / W, H = (int)x.size(1), T = (int)x.size(0), K = (int)expert_ids.size(1);
+    EP_HOST_ASSERT(gmm1_permuted_weight.dim() == 3 and gmm2_weight.dim() == 3);
+    EP_HOST_ASSERT(gmm1_permuted_weight.scalar_type() == at::kChar and gmm2_weight.scalar_type() == at::kChar);
+    EP_HOST_ASSERT(gmm1_permuted_weight.size(0) == L and gmm2_weight.size(0) == L);
+    at::Tensor w1 = gmm1_permuted_weight, w2 = gmm2_weight;
+    if (w1.size(2) != H) {                       // reference logical shape [L, H, 2I]
+        EP_HOST_ASSERT(w1.size(1) == H);
+        w1 = w1.transpose(1, 2).contiguous();
+    }
+    const int N1 = (int)w1.size(1), I = N1 / 2;
+    if (w2.size(1) != H) {                       // reference logical shape [L, I, H]
+        EP_HOST_ASSERT(w2.size(2) == H and w2.size(1) == I);
+        w2 = w2.transpose(1, 2).contiguous();
+    }
+    EP_HOST_ASSERT(w1.is_contiguous() and w2.is_contiguous() and w2.size(2) == I);
+    EP_HOST_ASSERT_S(H % 128 == 0 && I % 128 == 0, "hidden (", H, ") and intermediate (", I, ") must be multiples of 128");
+    at::Tensor s1 = gmm1_permuted_weight_scale.to(at::kFloat).reshape({L, N1}).contiguous();
+    at::Tensor s2 = gmm2_weight_scale.to(at::kFloat).reshape({L, H}).contiguous();
+    at::Tensor topk_weights = expert_scales_optional->to(at::kFloat).contiguous();
+    EP_HOST_ASSERT(topk_weights.size(0) == T and topk_weights.size(1) == K);
+
+    std::optional<at::Tensor> none;
+    auto disp = low_latency_dispatch(x, expert_ids, none, num_max_dispatch_tokens_per_rank, num_experts, true, false, false,
+                                     false, false, false, "int8");
+    const at::Tensor &rx = std::get<0>(disp);
+    const at::Tensor &rs = *std::get<1>(disp);
+    const at::Tensor &src_info = std::get<3>(disp);
+    const at::Tensor &layout_range = std::get<4>(disp);
+    const int M = (int)rx.size(0);
+    hipStream_t st = cur_stream();
+    auto dev = x.device();
+    at::Tensor v = at::empty({M, I}, at::dtype(at::kFloat).device(dev));
+    at::Tensor q2 = at::empty({M, I}, at::dtype(at::kChar).device(dev));
+    at::Tensor sc2 = at::empty({M}, at::dtype(at::kFloat).device(dev));
+    at::Tensor y = at::empty({M, H}, at::dtype(at::kBFloat16).device(dev));
+    const int32_t *cum = layout_range.data_ptr<int>();
+    { ProfScope ps_(this, "moe_gemm1_swiglu", st);
+      MI_EP_CHECK(mi_ep_moe_gemm1_swiglu((const int8_t *)rx.data_ptr(), rs.data_ptr<float>(), (const int8_t *)w1.data_ptr(),
+                                         s1.data_ptr<float>(), cum, W, L, M, H, N1, v.data_ptr<float>(), st)); }
+    { ProfScope ps_(this, "moe_rowquant", st);
+      MI_EP_CHECK(mi_ep_moe_rowquant(v.data_ptr<float>(), cum + (L * W - 1), M, I, (int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), st)); }
+    { ProfScope ps_(this, "moe_gemm2", st);
+      MI_EP_CHECK(mi_ep_moe_gemm2((const int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), (const int8_t *)w2.data_ptr(),
+                                  s2.data_ptr<float>(), cum, W, L, M, I, H, y.data_ptr(), st)); }
+    auto comb = low_latency_combine(y, expert_ids, topk_weights, src_info, layout_range, num_max_dispatch_tokens_per_rank,
+                                    num_experts, std::get<2>(disp), false, false, false, none);
+    return {std::get<0>(comb), layout_range};
 }
 
 std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &, const at::Tensor &, const at::Tensor &, const at::Tensor &,

@@ -176,3 +176,57 @@ def _gpu_buffer(rank, world, port, cfg):
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: fused_deep_moe through deep_ep.Buffer vs the oracle
+# ----------------------------------------------------------------------------------------------
+def gpu_fused_moe_worker(rank, world, port, cfg):
+    run_guarded(_gpu_fused_moe, rank, world, port, cfg)
+
+
+def _gpu_fused_moe(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits, bf16_bits_to_f32
+    torch.cuda.set_device(0)
+    W, T, H, I, K, E, layout = cfg
+    group = _init(rank, world, port)
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(1 << 30))
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    L = E // W
+    rng = np.random.default_rng(7)
+    xs, idxs, _ = make_inputs(W, T, H, K, E, 0.1, seed=5)
+    xs = [x[:T] for x in xs]
+    idxs = [i[:T] for i in idxs]
+    ws = [np.abs(rng.standard_normal((T, K))).astype(np.float32) for _ in range(W)]
+    # weights as in tests/python/deepep/test_fused_deep_moe.py:32-44 (randint(-16,16), scales U*4e-4+1.5e-3), per rank
+    w13 = [rng.integers(-16, 16, (L, 2 * I, H)).astype(np.int8) for _ in range(W)]
+    w2 = [rng.integers(-16, 16, (L, H, I)).astype(np.int8) for _ in range(W)]
+    s13 = [(rng.random((L, 2 * I)) * 4e-4 + 1.5e-3).astype(np.float32) for _ in range(W)]
+    s2 = [(rng.random((L, H)) * 4e-4 + 1.5e-3).astype(np.float32) for _ in range(W)]
+    want = O.fused_deep_moe(xs, idxs, ws, w13, s13, w2, s2, T, E)[rank]
+    perm = O.permute_fusion_cols(2 * I)
+    w13_p = torch.from_numpy(np.ascontiguousarray(w13[rank][:, perm, :])).cuda()          # [L, 2I, H], fusion-tile order
+    s13_p = torch.from_numpy(np.ascontiguousarray(s13[rank][:, perm])).cuda()
+    w2_t = torch.from_numpy(w2[rank]).cuda()
+    if layout == "reference":        # logical shapes of the reference: [L, H, 2I] and [L, I, H]
+        w13_p = w13_p.transpose(1, 2).contiguous()
+        w2_t = w2_t.transpose(1, 2).contiguous()
+    x = bits_to_torch(xs[rank]).cuda()
+    ti = torch.from_numpy(idxs[rank]).cuda()
+    tw = torch.from_numpy(ws[rank]).cuda()
+    for _ in range(2):
+        out, ep_recv_count = buf.fused_deep_moe(x, ti, tw, w13_p, s13_p, w2_t, torch.from_numpy(s2[rank]).cuda(), T, E)
+    assert out.shape == (T, H) and out.dtype == torch.bfloat16
+    ll = O.low_latency_dispatch(xs, idxs, T, E, True)[rank]
+    assert np.array_equal(ep_recv_count.cpu().numpy(), ll.layout_range)               # recv counts exact (test :519-521)
+    got = bf16_bits_to_f32(torch_to_bits(out))
+    ref = bf16_bits_to_f32(want)
+    diff = O.calc_diff(got, ref)
+    denom = np.maximum(np.abs(ref), 1e-2)
+    assert diff < 1e-5, diff
+    assert np.mean(np.abs(got - ref) / denom) < 4e-4, np.mean(np.abs(got - ref) / denom)   # reference: avg_diff < 4e-4 (:470)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()

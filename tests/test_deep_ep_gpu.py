@@ -20,3 +20,14 @@ pytestmark = pytest.mark.gpu
 ])
 def test_buffer_multi_process_one_gpu(cfg):
     _spawn(mp_workers.gpu_buffer_worker, cfg[0], cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    # W, T, H, I, K, E, weight layout
+    (1, 24, 512, 128, 4, 8, "native"),
+    (2, 40, 512, 128, 4, 8, "reference"),     # (square H == I would be ambiguous: native layout is assumed)
+    (4, 16, 1024, 128, 8, 32, "native"),
+    (1, 64, 7168, 2048, 8, 8, "native"),          # DeepSeek-V3 hidden / intermediate, 8 local experts
+])
+def test_fused_deep_moe(cfg):
+    _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)
