@@ -435,7 +435,9 @@ extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_co
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
     // worst case rows = W * max_tokens * min(K, L) is not known here (K); size the grid for W * max_tokens rows per
     // 16-row block, capped: the kernel grid-strides over the device-side total.
-    long long blocks = ((long long)W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
+    // worst case rows = every (local expert, source) slab full; the kernel grid-strides over the device-side total, so
+    // size the grid to fill the chip even for decode-size batches (a 128-token call has ~1 K rows = 7 MB to move)
+    long long blocks = ((long long)L * W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, s>>>(pp, layout_range, nullptr, max_tokens, W, L * W,

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void layout_hist_kernel(
     }
 }
 
-__global__ __launch_bounds__(1024) void layout_scan_kernel(int U, int E, int W, int32_t *__restrict__ unit_hist,
-                                                           const int32_t *__restrict__ unit_rank,
+__global__ __launch_bounds__(1024) void layout_scan_kernel(int U, int E, int W, const int32_t *__restrict__ unit_hist,
+                                                           int32_t *__restrict__ unit_base, const int32_t *__restrict__ unit_rank,
                                                            int32_t *__restrict__ num_tokens_per_rank,
                                                            int32_t *__restrict__ num_tokens_per_expert,
                                                            int32_t *__restrict__ send_data_offset)
@@ -90,9 +90,9 @@ __global__ __launch_bounds__(1024) void layout_scan_kernel(int U, int E, int W, 
         const int e = base + tid;
         int32_t run = 0;
         if (e < E) {
-            for (int u = 0; u < U; ++u) {
-                int32_t v = unit_hist[(long long)u * E + e];
-                unit_hist[(long long)u * E + e] = run;   // becomes the unit's base for expert e
+            for (int u = 0; u < U; ++u) {            // loads are independent of the stores (distinct buffers): they pipeline
+                const int32_t v = unit_hist[(long long)u * E + e];
+                unit_base[(long long)u * E + e] = run;   // the unit's first slot for expert e
                 run += v;
             }
             num_tokens_per_expert[e] = run;
@@ -166,7 +166,7 @@ extern "C" size_t mi_ep_dispatch_layout_workspace(int T, int K, int E)
     (void)K;
     size_t U = (size_t)(T + kUnitTokens - 1) / kUnitTokens;
     if (U == 0) U = 1;
-    return U * ((size_t)E + MI_EP_MAX_RANKS) * sizeof(int32_t);
+    return U * (2 * (size_t)E + MI_EP_MAX_RANKS) * sizeof(int32_t);
 }
 
 extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T, int K, int E, int W,
@@ -180,7 +180,8 @@ extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T
     hipStream_t s = (hipStream_t)stream;
     const int U = (T + kUnitTokens - 1) / kUnitTokens;
     int32_t *unit_hist = (int32_t *)workspace;
-    int32_t *unit_rank = unit_hist + (size_t)(U ? U : 1) * E;
+    int32_t *unit_base = unit_hist + (size_t)(U ? U : 1) * E;
+    int32_t *unit_rank = unit_base + (size_t)(U ? U : 1) * E;
     const int blocks = (U + kWavesPerBlock - 1) / kWavesPerBlock;
     const size_t lds1 = (size_t)kWavesPerBlock * E * 4 + (size_t)kWavesPerBlock * kUnitTokens * 8;
     const size_t lds3 = (size_t)kWavesPerBlock * E * 4;
@@ -194,14 +195,14 @@ extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T
             layout_hist_kernel<false><<<blocks, kWave * kWavesPerBlock, lds1, s>>>(topk_idx, T, K, E, W, is_token_in_rank,
                                                                                    unit_hist, unit_rank);
     }
-    layout_scan_kernel<<<1, 1024, 0, s>>>(U, E, W, unit_hist, unit_rank, num_tokens_per_rank, num_tokens_per_expert,
+    layout_scan_kernel<<<1, 1024, 0, s>>>(U, E, W, unit_hist, unit_base, unit_rank, num_tokens_per_rank, num_tokens_per_expert,
                                           send_data_offset);
     if (U > 0) {
         if (idx_is_i32)
-            layout_assign_kernel<true><<<blocks, kWave * kWavesPerBlock, lds3, s>>>(topk_idx, T, K, E, nbits, unit_hist,
+            layout_assign_kernel<true><<<blocks, kWave * kWavesPerBlock, lds3, s>>>(topk_idx, T, K, E, nbits, unit_base,
                                                                                     send_token_idx_small);
         else
-            layout_assign_kernel<false><<<blocks, kWave * kWavesPerBlock, lds3, s>>>(topk_idx, T, K, E, nbits, unit_hist,
+            layout_assign_kernel<false><<<blocks, kWave * kWavesPerBlock, lds3, s>>>(topk_idx, T, K, E, nbits, unit_base,
                                                                                      send_token_idx_small);
     }
     return launch_status();

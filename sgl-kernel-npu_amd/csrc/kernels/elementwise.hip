@@ -292,6 +292,99 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_kernel(
     for (int i = rope_dim + lane; i < head_dim; i += 64) dst[i] = (uint16_t)st16<BF16>(nrm(i));
 }
 
+// Vectorised variant: a head is spread over head_dim/8 lanes holding 8 consecutive elements each (16-B loads / stores),
+// so a wave handles 64*8/head_dim heads.  The RoPE partner (p +- rope_dim/2) lives rope_dim/16 lanes away and is fetched
+// with one shuffle per element; the RMS reduction is an xor-shuffle tree inside the head's lane group.
+// Needs rope_dim % 16 == 0 (neox) or % 8 == 0 (interleaved); otherwise the scalar kernel above runs.
+template <bool BF16>
+__global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
+    const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ sin, const uint16_t *__restrict__ cos, int rows, int q_hidden,
+    int kv_hidden, int head_dim, int rope_dim, int has_norm, float eps, const uint16_t *__restrict__ qw,
+    const uint16_t *__restrict__ kw, const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kb, int neox,
+    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v)
+{
+    const int lane = threadIdx.x & 63;
+    const int gl = head_dim >> 3;                      // lanes per head (8 .. 32)
+    const int heads_per_wave = 64 / gl;
+    const int q_heads = q_hidden / head_dim, kv_heads = kv_hidden / head_dim;
+    const int heads_total = q_heads + 2 * kv_heads;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long hglobal = wid * heads_per_wave + lane / gl;
+    const long long row = hglobal / heads_total;
+    const int h = (int)(hglobal % heads_total);
+    const int j = lane % gl;                           // chunk of 8 elements inside the head
+    const bool active = row < rows;
+    const long long total_hidden = (long long)q_hidden + 2ll * kv_hidden;
+    float x[8];
+    if (active) unpack8<BF16>(*(const u32x4 *)(qkv + row * total_hidden + (long long)h * head_dim + j * 8), x);
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    }
+    const bool is_v = h >= q_heads + kv_heads, is_q = h < q_heads;
+    if (has_norm) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+        for (int off = gl >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if (active && !is_v) {
+            const float rstd = 1.0f / sqrtf(ss / (float)head_dim + eps);
+            float wv[8];
+            unpack8<BF16>(*(const u32x4 *)((is_q ? qw : kw) + j * 8), wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (x[e] * rstd) * wv[e];
+            if (qb) {
+                float bv[8];
+                unpack8<BF16>(*(const u32x4 *)((is_q ? qb : kb) + j * 8), bv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = x[e] + bv[e];
+            }
+        }
+    }
+    const int half = rope_dim >> 1;
+    float o[8];
+    if (neox) {
+        const int dl = half >> 3;                      // partner distance in lanes
+        const bool lower = (j * 8) < half;
+        const int partner = lower ? lane + dl : lane - dl;
+        float px[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) px[e] = __shfl(x[e], partner & 63, 64);
+        if (active && !is_v && j * 8 < rope_dim) {
+            float sv[8], cv[8];
+            unpack8<BF16>(*(const u32x4 *)(sin + row * (long long)rope_dim + j * 8), sv);
+            unpack8<BF16>(*(const u32x4 *)(cos + row * (long long)rope_dim + j * 8), cv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (lower ? -px[e] : px[e]) * sv[e] + x[e] * cv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = x[e];
+        }
+    } else {
+        if (active && !is_v && j * 8 < rope_dim) {
+            // pairs (2i, 2i+1) use sin/cos[i]; this lane's 4 pairs are i = 4j .. 4j+3
+            const u32x2 sraw = *(const u32x2 *)(sin + row * (long long)rope_dim + j * 4);
+            const u32x2 craw = *(const u32x2 *)(cos + row * (long long)rope_dim + j * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sv = ld16<BF16>((sraw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+                const float cv = ld16<BF16>((craw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+                const float x1 = x[2 * i], x2 = x[2 * i + 1];
+                o[2 * i] = (-x2) * sv + x1 * cv;
+                o[2 * i + 1] = x1 * sv + x2 * cv;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = x[e];
+        }
+    }
+    if (!active) return;
+    uint16_t *dst = is_q ? q + row * (long long)q_hidden + (long long)h * head_dim
+                  : (!is_v ? k + row * (long long)kv_hidden + (long long)(h - q_heads) * head_dim
+                           : v + row * (long long)kv_hidden + (long long)(h - q_heads - kv_heads) * head_dim);
+    *(u32x4 *)(dst + j * 8) = is_v ? *(const u32x4 *)(qkv + row * total_hidden + (long long)h * head_dim + j * 8) : pack8<BF16>(o);
+}
+
 }  // namespace mi_sgl
 
 using namespace mi_sgl;
@@ -353,9 +446,24 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
     if (rows == 0) return MI_SGL_OK;
     if (!qkv || !sin || !cos || !q || !k || !v || (has_norm && (!q_weight || !k_weight)) || ((q_bias == nullptr) != (k_bias == nullptr)))
         return MI_SGL_EINVAL;
-    const long long waves = (long long)rows * ((q_hidden + 2 * kv_hidden) / head_dim);
-    const int blocks = (int)((waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
+    const int heads_total = (q_hidden + 2 * kv_hidden) / head_dim;
+    const bool vec_ok = head_dim >= 64 && head_dim <= 256 && (neox ? rope_dim % 16 == 0 : rope_dim % 8 == 0);
+    if (vec_ok) {
+        const long long heads = (long long)rows * heads_total;
+        const int hpw = 64 / (head_dim / 8);
+        const int blocks = (int)(((heads + hpw - 1) / hpw + 3) / 4);
+#define MI_VEC(B)                                                                                                                   \
+    split_qkv_rmsnorm_rope_vec_kernel<B><<<blocks, 256, 0, st>>>(                                                                   \
+        (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
+        (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox, (uint16_t *)q,   \
+        (uint16_t *)k, (uint16_t *)v)
+        if (dtype == MI_DTYPE_BF16) MI_VEC(true); else MI_VEC(false);
+#undef MI_VEC
+        return launch_ok();
+    }
+    const long long waves = (long long)rows * heads_total;
+    const int blocks = (int)((waves + 3) / 4);
     if (dtype == MI_DTYPE_BF16)
         split_qkv_rmsnorm_rope_kernel<true><<<blocks, 256, 0, st>>>(
             (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm,

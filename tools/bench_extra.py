@@ -1,0 +1,80 @@
+"""Supplementary single-GPU measurements (BASELINE configs C3 / C5 shapes per rank, elementwise primitives).
+Writes one JSON object to stdout; W = 1 so all EP traffic is local (HBM), E = 32 experts = the per-rank expert count at EP=8."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sgl-kernel-npu_amd", "python"))
+import torch, torch.distributed as dist
+
+def ev_time(fn, n=30, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    return {"p50_us": ts[len(ts) // 2], "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "min_us": ts[0]}
+
+def main():
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    import deep_ep, sgl_kernel_npu
+    from sgl_kernel_npu.activation.swiglu_quant import swiglu_quant
+    from sgl_kernel_npu.norm.add_rmsnorm_bias import add_rmsnorm_bias
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope import split_qkv_rmsnorm_rope
+    out = {}
+    H, K, E = 7168, 8, 32
+    buf = deep_ep.Buffer(dist.group.WORLD, low_latency_mode=True)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    # ---- C3 shapes per rank: low-latency dispatch / combine, 128 tokens
+    T = 128
+    x = torch.randn((T, H), generator=g, device="cuda").to(torch.bfloat16)
+    idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), K, dim=-1)[1]
+    w = torch.rand((T, K), generator=g, device="cuda")
+    (rx, rs), cnt, handle, _, _ = buf.low_latency_dispatch(x, idx, T, E, use_fp8=True)
+    y = (rx.float() * rs[:, None]).to(torch.bfloat16)
+    out["ll_dispatch_128tok"] = ev_time(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
+    out["ll_combine_128tok"] = ev_time(lambda: buf.low_latency_combine(y, idx, w, handle))
+    # ---- C5 shapes per rank: fused_deep_moe, DeepSeek-V3 (H=7168, 2I=4096), 32 local experts
+    I = 2048
+    w13 = torch.randint(-16, 16, (E, 2 * I, H), generator=g, device="cuda", dtype=torch.int8)
+    w2 = torch.randint(-16, 16, (E, H, I), generator=g, device="cuda", dtype=torch.int8)
+    s13 = torch.rand((E, 2 * I), generator=g, device="cuda") * 4e-4 + 1.5e-3
+    s2 = torch.rand((E, H), generator=g, device="cuda") * 4e-4 + 1.5e-3
+    for T in (128, 4096):
+        x = torch.randn((T, H), generator=g, device="cuda").to(torch.bfloat16)
+        idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), K, dim=-1)[1]
+        w = torch.rand((T, K), generator=g, device="cuda")
+        f = lambda: buf.fused_deep_moe(x, idx, w, w13, s13, w2, s2, T, E)
+        f()
+        buf.begin_profile(0, 10, "")
+        for _ in range(10): f()
+        buf.end_profile()
+        prof = {k: ms / n * 1e3 for k, (n, ms) in buf.get_profile_summary().items()}
+        r = ev_time(f, n=10, warm=2)
+        ops = T * K * (H * 2 * I + I * H) * 2
+        r["int8_TOPs"] = ops / (r["p50_us"] * 1e-6) / 1e12
+        r["kernels_avg_us"] = prof
+        r["gemm_TOPs"] = ops / ((prof.get("moe_gemm1_swiglu", 0) + prof.get("moe_gemm2", 0)) * 1e-6) / 1e12
+        out[f"fused_deep_moe_{T}tok_32experts"] = r
+    # ---- elementwise primitives (HBM-bound): GB/s on algorithmic bytes
+    S, h = 32768, 4096
+    xs = torch.randn((S, h), generator=g, device="cuda").to(torch.bfloat16)
+    gl = torch.full((32,), S // 32, dtype=torch.int64, device="cuda")
+    t = ev_time(lambda: swiglu_quant(xs, gl, 1))
+    out["swiglu_quant_32768x4096"] = dict(t, GBps=S * (h * 2 + h // 2 + 4) / t["p50_us"] / 1e3)
+    B = 4096
+    a, r_ = torch.randn((B, H), generator=g, device="cuda").to(torch.bfloat16), torch.randn((B, H), generator=g, device="cuda").to(torch.bfloat16)
+    wt, bs = torch.randn(H, device="cuda").to(torch.bfloat16), torch.randn(H, device="cuda").to(torch.bfloat16)
+    t = ev_time(lambda: add_rmsnorm_bias(a, r_, wt, bs, 1e-6))
+    out["add_rmsnorm_bias_4096x7168"] = dict(t, GBps=B * H * 8 / t["p50_us"] / 1e3)
+    qkv = torch.randn((B, 6144 + 2048), generator=g, device="cuda").to(torch.bfloat16)
+    sn, cs = torch.rand((B, 1, 1, 128), device="cuda").to(torch.bfloat16), torch.rand((B, 1, 1, 128), device="cuda").to(torch.bfloat16)
+    hw = torch.randn(128, device="cuda").to(torch.bfloat16)
+    t = ev_time(lambda: split_qkv_rmsnorm_rope(qkv, sn, cs, 6144, 1024, 128, 1e-6, hw, hw, hw, hw))
+    out["split_qkv_rmsnorm_rope_4096x8192"] = dict(t, GBps=B * 8192 * 4 / t["p50_us"] / 1e3)
+    print(json.dumps(out))
+
+main()
