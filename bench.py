@@ -174,6 +174,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import deep_ep
 
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "10000")     # bounded spins: a broken peer mapping fails fast, then falls back
     T = args.tokens
     x, topk_idx, topk_w = make_inputs(rank, T)
     group = dist.group.WORLD

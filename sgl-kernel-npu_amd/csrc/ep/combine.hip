@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     }
 }
 
-template <bool I32>
+template <bool I32, int KMAX>
 __global__ __launch_bounds__(256) void combine_reduce_kernel(
     const uint8_t *__restrict__ slots, size_t slot_stride, const void *__restrict__ topk_idx,
     const float *__restrict__ topk_w, const int32_t *__restrict__ send_off, const int32_t *__restrict__ idx_small,
@@ -76,25 +76,25 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
         if (send_off && valid_l) slot_l = (long long)send_off[e] + idx_small[t * K + lane];
     }
     const unsigned long long vmask = __ballot(valid_l);
-    float w[MI_EP_MAX_TOPK];
-    long long slot[MI_EP_MAX_TOPK];
+    float w[KMAX];
+    long long slot[KMAX];
 #pragma unroll
-    for (int k = 0; k < MI_EP_MAX_TOPK; ++k) {
+    for (int k = 0; k < KMAX; ++k) {
         w[k] = __shfl(w_l, k, kWave);
         slot[k] = __shfl((int)slot_l, k, kWave);
     }
     const int nchunks = H / 8;          // 16-B chunks of 8 bf16
     for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) {
-        u32x4 v[MI_EP_MAX_TOPK];
+        u32x4 v[KMAX];
 #pragma unroll
-        for (int k = 0; k < MI_EP_MAX_TOPK; ++k)
+        for (int k = 0; k < KMAX; ++k)
             if (k < K && ((vmask >> k) & 1ull))
                 v[k] = *(const u32x4 *)(slots + (size_t)slot[k] * slot_stride + (size_t)c * 16);
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-        for (int k = 0; k < MI_EP_MAX_TOPK; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             if (k < K && ((vmask >> k) & 1ull)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -237,13 +237,13 @@ extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int
     const int wpb = 4;
     const long long blocks = (waves + wpb - 1) / wpb;
     hipStream_t s = (hipStream_t)stream;
-    if (idx_is_i32)
-        combine_reduce_kernel<true><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H),
-                                                                        topk_idx, topk_weights, send_data_offset, send_token_idx_small, T, K, H, E, segs,
-                                                                        (uint16_t *)out);
-    else
-        combine_reduce_kernel<false><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H),
-                                                                         topk_idx, topk_weights, send_data_offset, send_token_idx_small, T, K, H, E, segs,
-                                                                         (uint16_t *)out);
+    // top-k <= 8 (DeepSeek-V3) gets its own instantiation: half the row registers, twice the waves per SIMD
+#define MI_EP_REDUCE(I32, KMAX)                                                                                                    \
+    combine_reduce_kernel<I32, KMAX><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H), topk_idx, \
+                                                                         topk_weights, send_data_offset, send_token_idx_small, T, K, H,  \
+                                                                         E, segs, (uint16_t *)out)
+    if (K <= 8) { if (idx_is_i32) MI_EP_REDUCE(true, 8); else MI_EP_REDUCE(false, 8); }
+    else { if (idx_is_i32) MI_EP_REDUCE(true, MI_EP_MAX_TOPK); else MI_EP_REDUCE(false, MI_EP_MAX_TOPK); }
+#undef MI_EP_REDUCE
     return launch_status();
 }

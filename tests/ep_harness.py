@@ -209,3 +209,95 @@ class InProcEP:
         for r in range(W):
             assert int(self.status[r][0].item()) == 0
         return outs
+
+
+class InProcA2A:
+    """The all-to-all (RCCL) transport of the `alltoall` strategies, simulated for W ranks in one process: the kernels are the
+    real HIP ones through the C-ABI (stage -> tables(relative_pull=1) -> pull from per-source staging; combine_pack -> reduce
+    in gather mode), the collective itself is replaced by device copies that move exactly the blocks all_to_all_single would."""
+
+    def __init__(self, W, E, K, H, device="cuda"):
+        self.W, self.E, self.L, self.K, self.H = W, E, E // W, K, H
+        self.dev = torch.device(device)
+
+    def dispatch(self, xs, topk_idxs, quant_mode):
+        W, E, L, K, H = self.W, self.E, self.L, self.K, self.H
+        L_ = lib()
+        st = stream_ptr()
+        rb = L_.mi_ep_dispatch_row_bytes(H, quant_mode)
+        lay, rows, cnts = [], [], []
+        for r in range(W):
+            T = xs[r].shape[0]
+            lay.append(layout(topk_idxs[r], E, W))
+            buf = torch.zeros(max(T * K, 1) * rb, dtype=torch.uint8, device=self.dev)
+            ck(L_.mi_ep_dispatch_stage(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                       ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K, H, E, r,
+                                       quant_mode, ptr(buf), st))
+            rows.append(buf)
+            cnts.append(torch.cat([lay[r]["num_tokens_per_expert"], torch.tensor([T], dtype=torch.int32, device=self.dev)]))
+        cnt = torch.stack(cnts).contiguous()                       # == all_gather_into_tensor
+        ch = cnt.cpu().numpy()
+        outs = []
+        for me in range(W):
+            i32 = dict(dtype=torch.int32, device=self.dev)
+            tb = [torch.empty(max(E, 1), **i32) for _ in range(9)]
+            ck(L_.mi_ep_notify_tables(ptr(cnt), W, E, me, 1, *[ptr(t) for t in tb], None, st))
+            recv_count, pull_off = tb[0], tb[8]
+            recv_rows = [int(ch[src, me * L:(me + 1) * L].sum()) for src in range(W)]
+            R = sum(recv_rows)
+            staging = torch.zeros(max(R, 1) * rb, dtype=torch.uint8, device=self.dev)
+            off = 0
+            bases = []
+            for src in range(W):                                   # == all_to_all_single with uneven row splits
+                so = int(ch[src, :me * L].sum())
+                n = recv_rows[src]
+                staging[off * rb:(off + n) * rb] = rows[src][so * rb:(so + n) * rb]
+                bases.append(staging.data_ptr() + off * rb)
+                off += n
+            if quant_mode == QUANT_NONE:
+                rx, rs = torch.zeros((max(R, 1), H), dtype=torch.bfloat16, device=self.dev), None
+            else:
+                rx = torch.zeros((max(R, 1), H), dtype=torch.int8, device=self.dev)
+                rs = torch.zeros(max(R, 1), dtype=torch.float32, device=self.dev)
+            src_idx = torch.zeros(max(R, 1) * 3, **i32)
+            ck(L_.mi_ep_dispatch_pull(ptr_array(bases), ptr(recv_count), ptr(pull_off), W, L, H, quant_mode, R, ptr(rx), ptr(rs),
+                                      ptr(src_idx), st))
+            outs.append(dict(recv_x=rx, recv_x_scales=rs, recv_src_idx=src_idx, total=R, send_head=recv_count, layout=lay[me],
+                             _keep=staging))
+        torch.cuda.synchronize()
+        self._cnt_host = ch
+        return outs
+
+    def combine(self, ys, disp, topk_idxs, topk_weights):
+        W, E, L, K, H = self.W, self.E, self.L, self.K, self.H
+        L_ = lib()
+        st = stream_ptr()
+        ch = self._cnt_host
+        packed, per_src = [], []
+        for r in range(W):
+            pk = torch.zeros_like(ys[r])
+            rps = torch.zeros(W, dtype=torch.int32, device=self.dev)
+            ck(L_.mi_ep_combine_pack(ptr(ys[r]), ptr(disp[r]["send_head"]), W, L, H, ys[r].shape[0], ptr(pk), ptr(rps), st))
+            packed.append(pk)
+            per_src.append(rps)
+        torch.cuda.synchronize()
+        outs = []
+        for me in range(W):
+            T = topk_idxs[me].shape[0]
+            n_pairs = int(ch[me, :E].sum())
+            ret = torch.zeros((max(n_pairs, 1), H), dtype=torch.bfloat16, device=self.dev)
+            off = 0
+            for d in range(W):                                     # block d of my return buffer comes from expert rank d
+                n = int(ch[me, d * L:(d + 1) * L].sum())
+                rps = per_src[d].cpu().numpy()
+                so = int(rps[:me].sum())
+                assert int(rps[me]) == n
+                ret[off:off + n] = packed[d][so:so + n]
+                off += n
+            out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
+            lay = disp[me]["layout"]
+            ck(L_.mi_ep_combine_reduce(ptr(ret), ptr(topk_idxs[me]), int(topk_idxs[me].dtype == torch.int32), ptr(topk_weights[me]),
+                                       ptr(lay["send_data_offset"]), ptr(lay["send_token_idx_small"]), T, K, H, E, ptr(out), st))
+            outs.append(out)
+        torch.cuda.synchronize()
+        return outs

@@ -227,3 +227,35 @@ def test_full_size_c2_properties(quant):
     got2 = h.dispatch(xs, idxs, qm)
     for r in range(W):
         assert torch.equal(got[r]["recv_x"], got2[r]["recv_x"]) and torch.equal(got[r]["recv_src_idx"], got2[r]["recv_src_idx"])
+
+
+@pytest.mark.parametrize("W,T,H,K,E,drop,active", DISPATCH_CASES[:7])
+@pytest.mark.parametrize("quant", [False, True])
+def test_alltoall_transport_kernels_bit_exact(W, T, H, K, E, drop, active, quant):
+    """The RCCL-fallback pipeline (per-source staging + relative pull offsets, combine_pack, gather-mode reduce) at W > 1."""
+    import ep_harness as Hh
+    rng = np.random.default_rng(W * 31 + T)
+    Ts = [T + r for r in range(W)]
+    xs = [rand_bits(rng, (t, H), 3.0) for t in Ts]
+    idxs = [make_topk(rng, t, K, E, drop, active) for t in Ts]
+    ws = [rng.standard_normal((t, K)).astype(np.float32) for t in Ts]
+    a2a = Hh.InProcA2A(W, E, K, H)
+    qm = Hh.QUANT_INT8 if quant else Hh.QUANT_NONE
+    got = a2a.dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).cuda() for i in idxs], qm)
+    want = O.normal_dispatch(xs, idxs, E, quant)
+    for r in range(W):
+        n = want[r].total_recv
+        assert got[r]["total"] == n
+        assert np.array_equal(got[r]["send_head"].cpu().numpy()[:E], want[r].send_head)
+        assert np.array_equal(got[r]["recv_src_idx"].cpu().numpy()[:3 * n], want[r].recv_src_idx[:3 * n])
+        if quant:
+            assert np.array_equal(got[r]["recv_x"].cpu().numpy()[:n], want[r].recv_x[:n])
+            assert np.array_equal(got[r]["recv_x_scales"].cpu().numpy()[:n].view(np.uint32), want[r].recv_x_scales[:n].view(np.uint32))
+        else:
+            assert np.array_equal(torch_to_bits(got[r]["recv_x"])[:n], want[r].recv_x[:n])
+    ys_np = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) if quant else w.recv_x for w in want]
+    comb_want = O.combine(ys_np, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)
+    comb_got = a2a.combine([dev_bf16(y) for y in ys_np], got, [torch.from_numpy(i).cuda() for i in idxs],
+                           [torch.from_numpy(w_).cuda() for w_ in ws])
+    for r in range(W):
+        assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r]), r
