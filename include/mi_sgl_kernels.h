@@ -81,6 +81,23 @@ int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const void *cos,
                               const void *k_weight, const void *q_bias, const void *k_bias, int neox, int dtype, void *q,
                               void *k, void *v, void *stream);
 
+/* ---- mla_preprocess glue (everything that is not a plain GEMM; reference csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704,
+ * arithmetic per tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483) -------------------------------------------
+ * pre_quant:  out int8 = round(clamp(fp16(x / scale + zero_point), -128, 127)), numel % 8 == 0.
+ * pre_mid:    gemm1_i32 [tokens, 2112] (+bias0) * descale0 -> I/O dtype -> [512 k_nope | 64 k_pe | 1536 q];
+ *             kv_cache[slot, :512] = rms_norm(k_nope) * gamma2, kv_cache_rope[slot, :64] = rope_half(k_pe, cos, sin),
+ *             q_int8 [tokens, 1536] = per-tensor quant of rms_norm(q) * gamma1 + beta1.  cos / sin [tokens, 64].
+ * pre_qsplit: gemm2_i32 [tokens, q_heads*192] (+bias1) * descale1 -> per head [128 | 64]: q_nope [tokens, q_heads, 128],
+ *             q_pe [tokens, q_heads, 64] = rope_half.  bias pointers may be NULL. */
+int mi_mla_pre_quant(const void *x, const void *scale /*[1], I/O dtype*/, const int8_t *zero_point /*[1]*/, int64_t numel, int dtype,
+                     int8_t *out, void *stream);
+int mi_mla_pre_mid(const int32_t *gemm1_i32, const int32_t *bias0, const float *descale0, const void *gamma1, const void *beta1,
+                   const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping, const void *quant_scale1,
+                   const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8, void *kv_cache, void *kv_cache_rope,
+                   void *stream);
+int mi_mla_pre_qsplit(const int32_t *gemm2_i32, const int32_t *bias1, const float *descale1, const void *cos, const void *sin,
+                      int tokens, int q_heads, int dtype, void *q_nope, void *q_pe, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,3 +171,55 @@ def split_qkv_rmsnorm_rope(qkv, sin, cos, q_hidden, kv_hidden, head_dim, eps=Non
         return torch.cat([out, rest], dim=-1).reshape(B, -1).to(qkv.dtype)
 
     return one(q, q_weight, q_bias), one(k, k_weight, k_bias), v.clone()
+
+
+# --------------------------------------------------------------------------------------
+# A14  mla_preprocess
+# --------------------------------------------------------------------------------------
+def _rotate_half(x):
+    a, b = torch.chunk(x, 2, dim=-1)
+    return torch.cat([-b, a], dim=-1)
+
+
+def _quant_per_tensor(x, scale, zp):
+    """tests/python/sgl_kernel_npu/test_mla_preprocess.py:77-83."""
+    x = x / scale.float() + zp.float()
+    x = torch.clamp(x.to(torch.float16), -128, 127)
+    return torch.round(x).to(torch.int8)
+
+
+def _int8_gemm_dequant(a, w, descale, bias, dtype):
+    """:95-107 (bf16 branch): exact int32 GEMM + bias, * float descale, to dtype."""
+    y = a.to(torch.int32) @ w.to(torch.int32).t()
+    if bias is not None and bias.numel():
+        y = y + bias
+    return (y.to(torch.float32) * descale.float()).to(dtype)
+
+
+def mla_preprocess(hidden, wdqkv, descale0, bias0, gamma1, beta1, gamma2, wuq, descale1, bias1, wuk, cos, sin, qscale0, qoff0,
+                   qscale1, qoff1, eps=1e-6):
+    """Transcription of golden2_pytorch, cache_mode 'krope_ctkv' (tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483):
+    quant -> INT8 GEMM [N,H]x[H,2112] -> split [512 k_nope | 64 k_pe | 1536 q] -> rms_norm(q)*gamma1+beta1,
+    rms_norm(k_nope)*gamma2 -> quant -> INT8 GEMM [N,1536]x[1536,Hq*192] -> per head [128|64] -> bmm(q_nope, wuk) ->
+    rotate-half RoPE on q_pe / k_pe.  Weights are [out, in] row-major.  Returns (q_nope_out [N,Hq,512], q_pe [N,Hq,64],
+    k_nope [N,512], k_pe [N,64]) in hidden.dtype (what the op writes to q_out0, q_out1 and the two caches)."""
+    dtype = hidden.dtype
+    N = hidden.shape[0]
+    Hq = wuq.shape[0] // 192
+
+    def rms(x, g):
+        xf = x.float()
+        return xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * g.float()
+
+    fused = _int8_gemm_dequant(_quant_per_tensor(hidden, qscale0, qoff0), wdqkv, descale0, bias0, dtype)
+    latent, q = fused.split([576, 1536], dim=-1)
+    k_nope, k_pe = latent[..., :512], latent[..., 512:].unsqueeze(1)
+    q = rms(q, gamma1) + beta1
+    k_nope = rms(k_nope, gamma2)
+    q_out = _int8_gemm_dequant(_quant_per_tensor(q, qscale1, qoff1), wuq, descale1, bias1, dtype).view(N, Hq, 192)
+    q_nope, q_pe = q_out.split([128, 64], dim=-1)
+    q_nope_out = torch.bmm(q_nope.transpose(0, 1), wuk).transpose(0, 1)
+    c, s = cos.unsqueeze(1).float(), sin.unsqueeze(1).float()
+    q_pe_r = (q_pe.float() * c + _rotate_half(q_pe.float()) * s).to(dtype)
+    k_pe_r = (k_pe.float() * c + _rotate_half(k_pe.float()) * s).to(dtype)
+    return q_nope_out.to(dtype), q_pe_r, k_nope.to(dtype), k_pe_r.squeeze(1)

@@ -1,0 +1,191 @@
+// mla_preprocess glue kernels for gfx950: everything of torch.ops.npu.mla_preprocess that is NOT a plain GEMM.
+// Reference: csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704 + op_kernel/mla_preprocess_mix_bf16.hpp (AscendC MIX kernel);
+// arithmetic pinned by the test golden golden2_pytorch (tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483):
+//   q8  = int8(round(clamp(fp16(h / qscale0 + qoff0))))                                   -> mi_mla_pre_quant
+//   f   = bf16((i32 GEMM1 + bias0) * descale0), split [512 k_nope | 64 k_pe | 1536 q]
+//   k_nope = bf16(rms_norm(k_nope) * gamma2) -> kv_cache[slot];  k_pe = rope_half(k_pe) -> kv_cache_rope[slot]
+//   q8' = int8(round(clamp(fp16((rms_norm(q) * gamma1 + beta1) / qscale1 + qoff1))))        -> mi_mla_pre_mid
+//   qo  = bf16((i32 GEMM2 + bias1) * descale1) per head [128 nope | 64 pe]; q_pe = rope_half -> q_out1 -> mi_mla_pre_qsplit
+// The three GEMMs (INT8 x2 through hipBLASLt, the per-head bf16 BMM with wuk) are plain library GEMMs issued by the host op
+// (csrc/pytorch_extensions.cpp); at decode sizes the op is weight-bandwidth bound (15 MB + 1536*Hq*192 B of INT8 weights).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "mi_sgl_kernels.h"
+
+namespace mi_sgl {
+
+template <bool BF16>
+__device__ __forceinline__ float ldh(uint16_t bits)
+{
+    if constexpr (BF16) return __uint_as_float((uint32_t)bits << 16);
+    else return (float)__builtin_bit_cast(_Float16, bits);
+}
+template <bool BF16>
+__device__ __forceinline__ uint16_t sth(float f)
+{
+    if constexpr (BF16) {
+        uint32_t x = __float_as_uint(f);
+        if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
+        return (uint16_t)((x + 0x7FFFu + ((x >> 16) & 1u)) >> 16);
+    } else {
+        return __builtin_bit_cast(uint16_t, (_Float16)f);
+    }
+}
+// quant_per_tensor of the golden (:77-83): fp32 divide + add, round to fp16, clamp, round half to even, int8
+__device__ __forceinline__ int8_t quant_pt(float x, float scale, float zp)
+{
+    float v = (float)(_Float16)(x / scale + zp);
+    v = fminf(fmaxf(v, -128.f), 127.f);
+    return (int8_t)(int)rintf(v);
+}
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void pre_quant_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ scale_p,
+                                                       const int8_t *__restrict__ zp_p, long long n, int8_t *__restrict__ out)
+{
+    const float scale = ldh<BF16>(scale_p[0]), zp = (float)zp_p[0];
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const uint4 v = *(const uint4 *)(x + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float f = ldh<BF16>((uint16_t)(w[j >> 1] >> (16 * (j & 1))));
+        o[j >> 2] |= ((uint32_t)(uint8_t)quant_pt(f, scale, zp)) << (8 * (j & 3));
+    }
+    *(uint2 *)(out + i) = uint2{o[0], o[1]};
+}
+
+constexpr int kKN = 512, kKR = 64, kQ = 1536, kMid = kKN + kKR + kQ;     // 2112
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void pre_mid_kernel(const int32_t *__restrict__ c1, const int32_t *__restrict__ bias0,
+                                                     const float *__restrict__ descale0, const uint16_t *__restrict__ gamma1,
+                                                     const uint16_t *__restrict__ beta1, const uint16_t *__restrict__ gamma2,
+                                                     const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
+                                                     const int32_t *__restrict__ slotmapping, const uint16_t *__restrict__ qscale1_p,
+                                                     const int8_t *__restrict__ qoff1_p, float eps, int8_t *__restrict__ q8, uint16_t *__restrict__ kv_cache,
+                                                     uint16_t *__restrict__ kv_cache_rope)
+{
+    __shared__ float f[kMid];
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float qscale1 = ldh<BF16>(qscale1_p[0]), qoff1 = (float)qoff1_p[0];
+    const int32_t *row = c1 + (long long)n * kMid;
+    for (int j = tid; j < kMid; j += 256) {
+        const float y = (float)(row[j] + (bias0 ? bias0[j] : 0)) * descale0[j];
+        f[j] = ldh<BF16>(sth<BF16>(y));                      // the GEMM output is materialised in the I/O dtype (golden :95-107)
+    }
+    __syncthreads();
+    // k_nope: RMSNorm * gamma2 -> cache
+    float ss = 0.f;
+    for (int j = tid; j < kKN; j += 256) ss += f[j] * f[j];
+    const float rk = rsqrtf(block_sum(ss, red) / (float)kKN + eps);
+    const long long slot = slotmapping[n];
+    for (int j = tid; j < kKN; j += 256) kv_cache[slot * kKN + j] = sth<BF16>((f[j] * rk) * ldh<BF16>(gamma2[j]));
+    // k_pe: rotate-half RoPE -> rope cache
+    if (tid < kKR) {
+        const float x = f[kKN + tid];
+        const float rot = tid < kKR / 2 ? -f[kKN + tid + kKR / 2] : f[kKN + tid - kKR / 2];
+        const float c = ldh<BF16>(cosv[(long long)n * kKR + tid]), s = ldh<BF16>(sinv[(long long)n * kKR + tid]);
+        kv_cache_rope[slot * kKR + tid] = sth<BF16>(x * c + rot * s);
+    }
+    // q: RMSNorm * gamma1 + beta1 -> per-tensor INT8
+    ss = 0.f;
+    for (int j = tid; j < kQ; j += 256) ss += f[kKN + kKR + j] * f[kKN + kKR + j];
+    const float rq = rsqrtf(block_sum(ss, red) / (float)kQ + eps);
+    for (int j = tid; j < kQ; j += 256) {
+        const float y = (f[kKN + kKR + j] * rq) * ldh<BF16>(gamma1[j]) + ldh<BF16>(beta1[j]);
+        q8[(long long)n * kQ + j] = quant_pt(y, qscale1, qoff1);
+    }
+}
+
+// one wave per (token, head): 192 = 128 nope + 64 pe
+template <bool BF16>
+__global__ __launch_bounds__(256) void pre_qsplit_kernel(const int32_t *__restrict__ c2, const int32_t *__restrict__ bias1,
+                                                        const float *__restrict__ descale1, const uint16_t *__restrict__ cosv,
+                                                        const uint16_t *__restrict__ sinv, int N, int Hq,
+                                                        uint16_t *__restrict__ q_nope, uint16_t *__restrict__ q_pe)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)N * Hq) return;
+    const int n = (int)(wid / Hq), h = (int)(wid % Hq);
+    const long long base = (long long)n * Hq * 192 + (long long)h * 192;
+    auto val = [&](int j) -> float {
+        const int col = h * 192 + j;
+        const float y = (float)(c2[base + j] + (bias1 ? bias1[col] : 0)) * descale1[col];
+        return ldh<BF16>(sth<BF16>(y));
+    };
+    q_nope[wid * 128 + lane] = sth<BF16>(val(lane));
+    q_nope[wid * 128 + 64 + lane] = sth<BF16>(val(64 + lane));
+    const float x = val(128 + lane);
+    const float rot = lane < 32 ? -val(128 + lane + 32) : val(128 + lane - 32);
+    const float c = ldh<BF16>(cosv[(long long)n * 64 + lane]), s = ldh<BF16>(sinv[(long long)n * 64 + lane]);
+    q_pe[wid * 64 + lane] = sth<BF16>(x * c + rot * s);
+}
+
+}  // namespace mi_sgl
+
+using namespace mi_sgl;
+
+extern "C" int mi_mla_pre_quant(const void *x, const void *scale, const int8_t *zero_point, int64_t numel, int dtype, int8_t *out,
+                                void *stream)
+{
+    if (numel < 0 || numel % 8 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16)) return MI_SGL_EINVAL;
+    if (numel == 0) return MI_SGL_OK;
+    if (!x || !out || !scale || !zero_point) return MI_SGL_EINVAL;
+    const int blocks = (int)((numel / 8 + 255) / 256);
+    if (dtype == MI_DTYPE_BF16) pre_quant_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, (const uint16_t *)scale, zero_point, numel, out);
+    else pre_quant_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, (const uint16_t *)scale, zero_point, numel, out);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_mla_pre_mid(const int32_t *gemm1_i32, const int32_t *bias0, const float *descale0, const void *gamma1,
+                              const void *beta1, const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping,
+                              const void *quant_scale1, const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8,
+                              void *kv_cache, void *kv_cache_rope, void *stream)
+{
+    if (tokens < 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || !quant_scale1 || !quant_offset1) return MI_SGL_EINVAL;
+    if (tokens == 0) return MI_SGL_OK;
+    if (!gemm1_i32 || !descale0 || !gamma1 || !beta1 || !gamma2 || !cos || !sin || !slotmapping || !q_int8 || !kv_cache || !kv_cache_rope)
+        return MI_SGL_EINVAL;
+#define MI_MID(B)                                                                                                                  \
+    pre_mid_kernel<B><<<tokens, 256, 0, (hipStream_t)stream>>>(gemm1_i32, bias0, descale0, (const uint16_t *)gamma1,                 \
+                                                               (const uint16_t *)beta1, (const uint16_t *)gamma2, (const uint16_t *)cos, \
+                                                               (const uint16_t *)sin, slotmapping, (const uint16_t *)quant_scale1, quant_offset1, eps,  \
+                                                               q_int8, (uint16_t *)kv_cache, (uint16_t *)kv_cache_rope)
+    if (dtype == MI_DTYPE_BF16) MI_MID(true); else MI_MID(false);
+#undef MI_MID
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_mla_pre_qsplit(const int32_t *gemm2_i32, const int32_t *bias1, const float *descale1, const void *cos,
+                                 const void *sin, int tokens, int q_heads, int dtype, void *q_nope, void *q_pe, void *stream)
+{
+    if (tokens < 0 || q_heads <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16)) return MI_SGL_EINVAL;
+    if (tokens == 0) return MI_SGL_OK;
+    if (!gemm2_i32 || !descale1 || !cos || !sin || !q_nope || !q_pe) return MI_SGL_EINVAL;
+    const int blocks = (int)(((long long)tokens * q_heads + 3) / 4);
+    if (dtype == MI_DTYPE_BF16)
+        pre_qsplit_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(gemm2_i32, bias1, descale1, (const uint16_t *)cos,
+                                                                        (const uint16_t *)sin, tokens, q_heads, (uint16_t *)q_nope,
+                                                                        (uint16_t *)q_pe);
+    else
+        pre_qsplit_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(gemm2_i32, bias1, descale1, (const uint16_t *)cos,
+                                                                         (const uint16_t *)sin, tokens, q_heads, (uint16_t *)q_nope,
+                                                                         (uint16_t *)q_pe);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}

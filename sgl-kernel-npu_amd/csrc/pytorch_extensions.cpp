@@ -5,6 +5,7 @@
 // The implementations are thin host functions (namespace sglang::npu_kernel, like include/sgl_kenel_npu_ops.h:14-239)
 // that validate arguments, allocate outputs and call the C-ABI of include/mi_sgl_kernels.h on the current stream.
 #include <ATen/ATen.h>
+#include <c10/util/string_view.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -141,6 +142,75 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
     return {q, k, v};
 }
 
+// torch.ops.npu.mla_preprocess: same schema as the reference (csrc/pytorch_extensions.cpp:105-115; host
+// csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704).  MI355X layouts: wdqkv int8 [2112, hidden] and wuq int8
+// [q_heads*192, 1536] are plain row-major (output channel major, K contiguous) instead of the Ascend NZ fractal format;
+// wuk [q_heads, 128, 512]; kv_cache [blocks, block_size, 1, 512] + kv_cache_rope [blocks, block_size, 1, 64]
+// (cache_mode "krope_ctkv").  gamma0 / beta0 are accepted and unused, as in the reference's bf16 kernel (stage 1 is
+// quant-only).  The INT8 GEMMs and the per-head BMM are plain library GEMMs (hipBLASLt via at::_int_mm / at::bmm); the
+// quantisation, dequant + split + RMSNorm + RoPE + cache write stages are the HIP kernels of csrc/kernels/mla_preprocess.hip.
+std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preprocess(
+    const at::Tensor &hiddenState, const at::Tensor &gamma0, const at::Tensor &beta0, const at::Tensor &wdqkv,
+    const at::Tensor &descale0, const at::Tensor &gamma1, const at::Tensor &beta1, const at::Tensor &wuq,
+    const at::Tensor &descale1, const at::Tensor &gamma2, const at::Tensor &cos, const at::Tensor &sin, const at::Tensor &wuk,
+    const at::Tensor &kv_cache, const at::Tensor &kv_cache_rope, const at::Tensor &slotmapping, const at::Tensor &quant_scale0,
+    const at::Tensor &quant_offset0, const at::Tensor &bias0, const at::Tensor &quant_scale1, const at::Tensor &quant_offset1,
+    const at::Tensor &bias1, const std::optional<at::Tensor> &ctkv_scale, const std::optional<at::Tensor> &q_nope_scale,
+    std::optional<c10::string_view> cache_mode, std::optional<c10::string_view> quant_mode, at::Tensor &q_out0,
+    at::Tensor &kv_cache_out0, at::Tensor &q_out1, at::Tensor &kv_cache_out1)
+{
+    (void)gamma0, (void)beta0, (void)ctkv_scale, (void)q_nope_scale;
+    TORCH_CHECK(!cache_mode.has_value() || *cache_mode == "krope_ctkv", "mla_preprocess: only cache_mode='krope_ctkv' is implemented "
+                "(the int8 / NZ cache modes are Ascend layouts), got ", cache_mode.value_or(""));
+    TORCH_CHECK(!quant_mode.has_value() || *quant_mode == "per_tensor_quant_asymm", "mla_preprocess: only quant_mode="
+                "'per_tensor_quant_asymm' is implemented, got ", quant_mode.value_or(""));
+    TORCH_CHECK(hiddenState.dim() == 2 && hiddenState.is_contiguous(), "hiddenState must be contiguous [tokens, hidden]");
+    const int64_t N = hiddenState.size(0), hidden = hiddenState.size(1);
+    TORCH_CHECK(N <= 1024, "mla_preprocess: tokenNum <= 1024 (csrc/mla_preprocess/README.md)");
+    TORCH_CHECK(wdqkv.scalar_type() == at::kChar && wdqkv.dim() == 2 && wdqkv.size(0) == 2112 && wdqkv.size(1) == hidden &&
+                    wdqkv.is_contiguous(), "wdqkv must be int8 [2112, hidden] row-major");
+    TORCH_CHECK(wuq.scalar_type() == at::kChar && wuq.dim() == 2 && wuq.size(1) == 1536 && wuq.size(0) % 192 == 0 && wuq.is_contiguous(),
+                "wuq must be int8 [q_heads*192, 1536] row-major");
+    const int64_t Hq = wuq.size(0) / 192;
+    TORCH_CHECK(wuk.dim() == 3 && wuk.size(0) == Hq && wuk.size(1) == 128 && wuk.size(2) == 512, "wuk must be [q_heads, 128, 512]");
+    TORCH_CHECK(descale0.scalar_type() == at::kFloat && descale0.numel() == 2112 && descale1.scalar_type() == at::kFloat &&
+                    descale1.numel() == Hq * 192, "descale0 / descale1 must be float32 [2112] / [q_heads*192]");
+    TORCH_CHECK(slotmapping.scalar_type() == at::kInt && slotmapping.numel() == N, "slotmapping must be int32 [tokens]");
+    TORCH_CHECK(cos.numel() == N * 64 && sin.numel() == N * 64 && cos.is_contiguous() && sin.is_contiguous(), "cos / sin must be [tokens, 64]");
+    TORCH_CHECK(kv_cache.is_contiguous() && kv_cache.size(-1) == 512 && kv_cache_rope.is_contiguous() && kv_cache_rope.size(-1) == 64,
+                "kv_cache [..., 512] and kv_cache_rope [..., 64] must be contiguous");
+    TORCH_CHECK(q_out0.is_contiguous() && q_out0.numel() == N * Hq * 512 && q_out1.is_contiguous() && q_out1.numel() == N * Hq * 64,
+                "q_out0 [tokens, q_heads, 512] / q_out1 [tokens, q_heads, 64]");
+    const int dt = dtype_code(hiddenState);
+    auto dev = hiddenState.device();
+    void *st = cur_stream();
+    TORCH_CHECK(quant_scale0.numel() == 1 && quant_scale1.numel() == 1 && quant_scale0.scalar_type() == hiddenState.scalar_type() &&
+                    quant_scale1.scalar_type() == hiddenState.scalar_type() && quant_offset0.numel() == 1 && quant_offset1.numel() == 1 &&
+                    quant_offset0.scalar_type() == at::kChar && quant_offset1.scalar_type() == at::kChar,
+                "quant_scale0/1 must be [1] in the input dtype, quant_offset0/1 int8 [1]");
+    // hipBLASLt's INT8 GEMM (at::_int_mm) wants more than 16 rows: pad the token dimension to a multiple of 32
+    const int64_t Np = (N + 31) / 32 * 32;
+    at::Tensor a8 = at::zeros({Np, hidden}, at::dtype(at::kChar).device(dev));
+    TORCH_CHECK(0 == mi_mla_pre_quant(hiddenState.data_ptr(), quant_scale0.data_ptr(), (const int8_t *)quant_offset0.data_ptr(), N * hidden, dt, (int8_t *)a8.data_ptr(), st), "mi_mla_pre_quant failed");
+    at::Tensor c1 = at::_int_mm(a8, wdqkv.t());                                   // [Np, 2112] int32
+    at::Tensor q8 = at::zeros({Np, 1536}, at::dtype(at::kChar).device(dev));
+    auto iptr = [](const at::Tensor &t) -> const int32_t * { return t.numel() ? t.data_ptr<int32_t>() : nullptr; };
+    TORCH_CHECK(0 == mi_mla_pre_mid(c1.data_ptr<int32_t>(), iptr(bias0), descale0.data_ptr<float>(), gamma1.data_ptr(), beta1.data_ptr(),
+                                    gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(), quant_scale1.data_ptr(),
+                                    (const int8_t *)quant_offset1.data_ptr(), 1e-6f,
+                                    (int)N, dt, (int8_t *)q8.data_ptr(), kv_cache.data_ptr(), kv_cache_rope.data_ptr(), st),
+                "mi_mla_pre_mid failed");
+    at::Tensor c2 = at::_int_mm(q8, wuq.t());                                     // [Np, q_heads*192] int32
+    at::Tensor q_nope = at::empty({N, Hq, 128}, hiddenState.options());
+    TORCH_CHECK(0 == mi_mla_pre_qsplit(c2.data_ptr<int32_t>(), iptr(bias1), descale1.data_ptr<float>(), cos.data_ptr(), sin.data_ptr(),
+                                       (int)N, (int)Hq, dt, q_nope.data_ptr(), q_out1.data_ptr(), st), "mi_mla_pre_qsplit failed");
+    at::Tensor o = at::bmm(q_nope.transpose(0, 1), wuk);                          // [q_heads, N, 512]
+    q_out0.view({N, Hq, 512}).copy_(o.transpose(0, 1));
+    if (kv_cache_out0.data_ptr() != kv_cache.data_ptr()) kv_cache_out0.copy_(kv_cache);
+    if (kv_cache_out1.data_ptr() != kv_cache_rope.data_ptr()) kv_cache_out1.copy_(kv_cache_rope);
+    return {q_out0, kv_cache_out0, q_out1, kv_cache_out1};
+}
+
 }  // namespace npu_kernel
 }  // namespace sglang
 
@@ -149,6 +219,16 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("sgl_kernel_npu_version() -> str", &sglang::npu_kernel::sgl_kernel_npu_version);
     m.def("decode_mla(Tensor q, Tensor k_nope_buffer, Tensor k_rope_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
           "float sm_scale, int page_size, Tensor block_table, int num_splits=0) -> ()");
+    m.def("mla_preprocess(Tensor hiddenState, Tensor gamma0, Tensor beta0, Tensor wdqkv, "
+          "Tensor descale0, Tensor gamma1, Tensor beta1, Tensor wuq, "
+          "Tensor descale1, Tensor gamma2, Tensor cos, Tensor sin, Tensor wuk,"
+          "Tensor kv_cache, Tensor kv_cache_rope, Tensor slotmapping, "
+          "Tensor quant_scale0, Tensor quant_offset0, Tensor bias0, "
+          "Tensor quant_scale1, Tensor quant_offset1, Tensor bias1, *, "
+          "Tensor? ctkv_scale=None, Tensor? q_nope_scale=None, "
+          "str? cache_mode=None, str? quant_mode=None, "
+          "Tensor(a!) q_out0, Tensor(b!) kv_cache_out0, Tensor(c!) q_out1, Tensor(d!) kv_cache_out1) "
+          "-> (Tensor(a!), Tensor(b!), Tensor(c!), Tensor(d!))");
     m.def("swiglu_quant(Tensor x, Tensor group_list, int group_list_type, bool need_quant=True, bool do_limit=False, "
           "float limit=7.0) -> (Tensor, Tensor)");
     m.def("add_rmsnorm_bias(Tensor input, Tensor? residual, Tensor norm_weight, Tensor? norm_bias, float eps, "
@@ -161,6 +241,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
 TORCH_LIBRARY_IMPL(npu, CUDA, m)
 {
     m.impl("decode_mla", TORCH_FN(sglang::npu_kernel::decode_mla));
+    m.impl("mla_preprocess", TORCH_FN(sglang::npu_kernel::mla_preprocess));
     m.impl("swiglu_quant", TORCH_FN(sglang::npu_kernel::swiglu_quant));
     m.impl("add_rmsnorm_bias", TORCH_FN(sglang::npu_kernel::add_rmsnorm_bias));
     m.impl("split_qkv_rmsnorm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope));

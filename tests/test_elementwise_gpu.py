@@ -89,3 +89,49 @@ def test_split_qkv_rmsnorm_rope(rope_dim, neox, norm, bias, hd, qh, kvh, B):
     # fp32 math on both sides: at most one bf16 ulp apart (reference tolerance: atol 5e-2)
     assert torch.allclose(q.cpu().float(), wq.float(), rtol=2 ** -7, atol=1e-3)
     assert torch.allclose(k.cpu().float(), wk.float(), rtol=2 ** -7, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,Hq,hidden", [(1, 32, 7168), (16, 64, 7168), (31, 128, 7168), (31, 128, 6144), (70, 16, 2048)])
+def test_mla_preprocess(N, Hq, hidden):
+    """torch.ops.npu.mla_preprocess vs the transcription of the reference golden (seed 42, shapes of
+    tests/python/sgl_kernel_npu/test_mla_preprocess.py:487-498)."""
+    torch.manual_seed(42)
+    dt = torch.bfloat16
+    block_size, nblocks = 128, 4
+    hid = (torch.randn(N, hidden) * 0.5).to(dt)
+    wdqkv = torch.randint(-8, 8, (2112, hidden), dtype=torch.int8)
+    wuq = torch.randint(-8, 8, (Hq * 192, 1536), dtype=torch.int8)
+    descale0 = (torch.rand(2112) * 1e-3 + 5e-4).float()
+    descale1 = (torch.rand(Hq * 192) * 1e-3 + 5e-4).float()
+    bias0 = torch.randint(-50, 50, (2112,), dtype=torch.int32)
+    bias1 = torch.randint(-50, 50, (Hq * 192,), dtype=torch.int32)
+    gamma0, beta0 = torch.randn(hidden).to(dt), torch.randn(hidden).to(dt)
+    gamma1, beta1 = torch.randn(1536).to(dt), (torch.randn(1536) * 0.1).to(dt)
+    gamma2 = torch.randn(512).to(dt)
+    wuk = (torch.randn(Hq, 128, 512) * 0.1).to(dt)
+    cos, sin = torch.rand(N, 64).to(dt), torch.rand(N, 64).to(dt)
+    qs0, qo0 = torch.tensor([0.02]).to(dt), torch.tensor([3], dtype=torch.int8)
+    qs1, qo1 = torch.tensor([0.03]).to(dt), torch.tensor([-2], dtype=torch.int8)
+    slots = torch.randperm(nblocks * block_size)[:N].to(torch.int32)
+    want = OK.mla_preprocess(hid, wdqkv, descale0, bias0, gamma1, beta1, gamma2, wuq, descale1, bias1, wuk, cos, sin, qs0, qo0, qs1, qo1)
+    d = lambda t: t.cuda()
+    kv = torch.zeros((nblocks, block_size, 1, 512), dtype=dt, device="cuda")
+    kr = torch.zeros((nblocks, block_size, 1, 64), dtype=dt, device="cuda")
+    q0 = torch.empty((N, Hq, 512), dtype=dt, device="cuda")
+    q1 = torch.empty((N, Hq, 64), dtype=dt, device="cuda")
+    out = torch.ops.npu.mla_preprocess(d(hid), d(gamma0), d(beta0), d(wdqkv), d(descale0), d(gamma1), d(beta1), d(wuq), d(descale1),
+                                       d(gamma2), d(cos), d(sin), d(wuk), kv, kr, d(slots), d(qs0), d(qo0), d(bias0), d(qs1), d(qo1),
+                                       d(bias1), cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", q_out0=q0,
+                                       kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr)
+    assert out[0].data_ptr() == q0.data_ptr() and out[1].data_ptr() == kv.data_ptr()
+    k_nope = kv.view(-1, 512)[slots.long().cuda()].cpu()
+    k_pe = kr.view(-1, 64)[slots.long().cuda()].cpu()
+    tol = dict(rtol=2 ** -6, atol=2e-2)      # bf16 outputs: one ulp on either side of the golden
+    assert torch.allclose(k_nope.float(), want[2].float(), **tol)
+    assert torch.allclose(k_pe.float(), want[3].float(), **tol)
+    assert torch.allclose(q1.cpu().float(), want[1].float(), **tol)
+    assert torch.allclose(q0.cpu().float(), want[0].float(), rtol=2 ** -5, atol=5e-2)      # through a K=128 bf16 BMM
+    # untouched cache rows stay zero
+    mask = torch.ones(nblocks * block_size, dtype=torch.bool)
+    mask[slots.long()] = False
+    assert not kv.view(-1, 512).cpu()[mask].any()
