@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
 
     TileRowsRaw raw_next = tile_rows_load(p, b, seq_len, t_begin, lane);
     TileRows rows_nxt{0, 0};
-    StageRegs st;
+    StageRegs st, st2;
     if (t_begin < t_end) {
         if (MLA_STAGE) {
             const TileRows r0 = tile_rows_finish(p, kvh, raw_next);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[pre][mt] = lda(pre, mt);
 #pragma unroll
-        for (int ks = 0; ks < 18; ++ks) {
+        for (int ks = 0; ks < (MLA_EXP == 5 ? 0 : 18); ++ks) {
             __builtin_amdgcn_sched_barrier(0);
             if (ks + kAhead < 18) {
 #pragma unroll
@@ -310,8 +310,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         }
         __builtin_amdgcn_sched_barrier(0);
         if (MLA_STAGE && more) {
-            stage_store(nbuf, 0, wave, lane, st);
-            stage_load(p, rows_nxt, 1, wave, lane, st);       // second half travels under softmax + PV
+            stage_load(p, rows_nxt, 1, wave, lane, st2);      // second half travels under softmax + PV
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- online softmax; lane owns head c16 and keys mt*16 + 4g + r.  Scores stay unscaled: with
@@ -365,6 +364,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         l_run += psum;
+        if (MLA_STAGE && more) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage_store(nbuf, 0, wave, lane, st);             // first half had QK + softmax to arrive
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // P^T fragments: k-step kk covers key tiles (2kk, 2kk+1); slots 0..3 / 4..7 of lane group g
         s16x8 pf[2];
 #pragma unroll
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         };
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2 * kAccTiles; ++i) {
+        for (int i = 0; i < (MLA_EXP == 5 ? 0 : 2 * kAccTiles); ++i) {
             const s16x4 lo = ldv(i, 0), hi = ldv(i, 1);
             const s16x8 a = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             acc[i % kAccTiles] = mfma16<BF16>(a, pf[i / kAccTiles], acc[i % kAccTiles]);
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kPvAhead, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (MLA_STAGE && more) stage_store(nbuf, 1, wave, lane, st);
+        if (MLA_STAGE && more) stage_store(nbuf, 1, wave, lane, st2);
     }
 
     // ---- epilogue: lane holds O^T[d = dt*16 + 4g + r][head c16]

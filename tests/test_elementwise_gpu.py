@@ -62,6 +62,10 @@ def test_add_rmsnorm_bias(B, H, dtype):
     gn, ga = OK.add_rmsnorm_bias(x, r, w, None, 1e-6, gemma=True)
     n, a = add_gemma_rms_norm(x.cuda(), w.cuda(), r.cuda(), 1e-6)
     assert torch.equal(a.cpu(), ga) and torch.allclose(n.cpu().float(), gn.float(), rtol=ulp, atol=1e-3)
+    from sgl_kernel_npu.norm.rmsnorm_bias import rmsnorm_bias
+    p1 = rmsnorm_bias(x.cuda(), w.cuda(), b.cuda(), 1e-6)                         # no residual (rmsnorm_bias.py:78-120)
+    wp1, _ = OK.add_rmsnorm_bias(x, None, w, b, 1e-6)
+    assert torch.allclose(p1.cpu().float(), wp1.float(), rtol=ulp, atol=1e-3)
     n2, a2 = add_gemma_rms_norm(x.cuda(), w.cuda(), None, 1e-6)                  # no residual
     gn2, _ = OK.add_rmsnorm_bias(x, None, w, None, 1e-6, gemma=True)
     assert torch.allclose(n2.cpu().float(), gn2.float(), rtol=ulp, atol=1e-3)
