@@ -365,9 +365,9 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
         EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->dim() == 1 and dispatch_wait_recv_cost_stats->size(0) == num_ranks);
     }
     // placeholders kept for handle-shape compatibility (uninitialised in the reference, deep_ep.cpp:220-222)
-    auto rank_prefix_matrix = at::zeros({W, W}, i32);
-    auto channel_prefix_matrix = at::zeros({W, num_channels}, i32);
-    auto recv_channel_prefix_matrix = at::zeros({W, num_channels}, i32);
+    auto rank_prefix_matrix = at::empty({W, W}, i32);
+    auto channel_prefix_matrix = at::empty({W, num_channels}, i32);
+    auto recv_channel_prefix_matrix = at::empty({W, num_channels}, i32);
     return {expandx_out, dynamic_scales_out, recv_topk_idx, recv_topk_weights, num_recv_tokens_per_expert_list,
             rank_prefix_matrix, channel_prefix_matrix, recv_channel_prefix_matrix, expand_idx_out, recv_count, std::nullopt};
 }
