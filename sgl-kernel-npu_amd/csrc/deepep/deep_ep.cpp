@@ -583,38 +583,30 @@ void Buffer::internode_unsupported() const
 // K contiguous; the Ascend NZ fractal format does not exist here).  The reference's logical shapes [L, H, 2I] / [L, I, H]
 // are accepted and transposed on the fly.
 // ------------------------------------------------------------------------------------------------
-std::vector<at::Tensor> Buffer::fused_deep_moe(const at::Tensor &x, const at::Tensor &expert_ids,
-                                               const at::Tensor &gmm1_permuted_weight,
-                                               const at::Tensor &gmm1_permuted_weight_scale, const at::Tensor &gmm2_weight,
-                                               const at::Tensor &gmm2_weight_scale,
-                                               const std::optional<at::Tensor> &expert_scales_optional,
-                                               int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts,
-                                               int64_t quant_mode, bool)
+// Weights are layer constants: any re-layout (transpose to K-contiguous, fusion-tile row permutation) is done once per
+// (storage, version) and kept, like the reference's one-off npu_format_cast to NZ (test_fused_deep_moe.py:63-119).
+at::Tensor Buffer::prepared_weight(const at::Tensor &w, int kind, const std::function<at::Tensor()> &make)
 {
-    require_available();
-    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
-    EP_HOST_ASSERT(expert_ids.dim() == 2 and expert_ids.is_contiguous() and expert_ids.size(0) == x.size(0));
-    EP_HOST_ASSERT_S(quant_mode == 1, "fused_deep_moe: only quant_mode=1 (INT8 weights) is implemented on this device");
-    EP_HOST_ASSERT(expert_scales_optional.has_value());
+    const WeightKey key{w.data_ptr(), kind};
+    auto it = weight_cache_.find(key);
+    if (it != weight_cache_.end() && it->second.version == (int64_t)w._version() && it->second.numel == w.numel()) return it->second.t;
+    if (weight_cache_.size() >= 512) weight_cache_.clear();
+    at::Tensor t = make();
+    weight_cache_[key] = WeightEntry{(int64_t)w._version(), w.numel(), t};
+    return t;
+}
+
+std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
+                                           const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,
+                                           const at::Tensor &topk_weights, int64_t num_max_dispatch_tokens_per_rank,
+                                           int64_t num_experts)
+{
     const int W = (int)num_ranks, E = (int)num_experts, L = E / W, H = (int)x.size(1), T = (int)x.size(0), K = (int)expert_ids.size(1);
-    EP_HOST_ASSERT(gmm1_permuted_weight.dim() == 3 and gmm2_weight.dim() == 3);
-    EP_HOST_ASSERT(gmm1_permuted_weight.scalar_type() == at::kChar and gmm2_weight.scalar_type() == at::kChar);
-    EP_HOST_ASSERT(gmm1_permuted_weight.size(0) == L and gmm2_weight.size(0) == L);
-    at::Tensor w1 = gmm1_permuted_weight, w2 = gmm2_weight;
-    if (w1.size(2) != H) {                       // reference logical shape [L, H, 2I]
-        EP_HOST_ASSERT(w1.size(1) == H);
-        w1 = w1.transpose(1, 2).contiguous();
-    }
     const int N1 = (int)w1.size(1), I = N1 / 2;
-    if (w2.size(1) != H) {                       // reference logical shape [L, I, H]
-        EP_HOST_ASSERT(w2.size(2) == H and w2.size(1) == I);
-        w2 = w2.transpose(1, 2).contiguous();
-    }
-    EP_HOST_ASSERT(w1.is_contiguous() and w2.is_contiguous() and w2.size(2) == I);
+    EP_HOST_ASSERT(w1.is_contiguous() and w2.is_contiguous() and w1.size(0) == L and w2.size(0) == L);
+    EP_HOST_ASSERT(w1.size(2) == H and w2.size(1) == H and w2.size(2) == I);
+    EP_HOST_ASSERT(s1.numel() == (int64_t)L * N1 and s2.numel() == (int64_t)L * H);
     EP_HOST_ASSERT_S(H % 128 == 0 && I % 128 == 0, "hidden (", H, ") and intermediate (", I, ") must be multiples of 128");
-    at::Tensor s1 = gmm1_permuted_weight_scale.to(at::kFloat).reshape({L, N1}).contiguous();
-    at::Tensor s2 = gmm2_weight_scale.to(at::kFloat).reshape({L, H}).contiguous();
-    at::Tensor topk_weights = expert_scales_optional->to(at::kFloat).contiguous();
     EP_HOST_ASSERT(topk_weights.size(0) == T and topk_weights.size(1) == K);
 
     std::optional<at::Tensor> none;
@@ -645,11 +637,86 @@ std::vector<at::Tensor> Buffer::fused_deep_moe(const at::Tensor &x, const at::Te
     return {std::get<0>(comb), layout_range};
 }
 
-std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &, const at::Tensor &, const at::Tensor &, const at::Tensor &,
-                                                     const at::Tensor &, const at::Tensor &, const std::optional<at::Tensor> &,
-                                                     int64_t, int64_t, int64_t)
+static void fused_common_checks(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1, const at::Tensor &w2,
+                                int64_t quant_mode, const std::optional<at::Tensor> &expert_scales, const char *what)
 {
-    throw EPException("Assertion", __FILE__, __LINE__, "dispatch_ffn_combine: not implemented in this build (SURVEY.md section 8(f) N1)");
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
+    EP_HOST_ASSERT(expert_ids.dim() == 2 and expert_ids.is_contiguous() and expert_ids.size(0) == x.size(0));
+    EP_HOST_ASSERT_S(quant_mode == 1, what, ": only quant_mode=1 (INT8 weights) is implemented on this device");
+    EP_HOST_ASSERT(expert_scales.has_value() and expert_scales->dim() == 2);
+    EP_HOST_ASSERT(w1.dim() == 3 and w2.dim() == 3);
+    EP_HOST_ASSERT_S(w1.scalar_type() == at::kChar and w2.scalar_type() == at::kChar, what, ": INT8 weights required");
+}
+
+std::vector<at::Tensor> Buffer::fused_deep_moe(const at::Tensor &x, const at::Tensor &expert_ids,
+                                               const at::Tensor &gmm1_permuted_weight,
+                                               const at::Tensor &gmm1_permuted_weight_scale, const at::Tensor &gmm2_weight,
+                                               const at::Tensor &gmm2_weight_scale,
+                                               const std::optional<at::Tensor> &expert_scales_optional,
+                                               int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts,
+                                               int64_t quant_mode, bool)
+{
+    require_available();
+    fused_common_checks(x, expert_ids, gmm1_permuted_weight, gmm2_weight, quant_mode, expert_scales_optional, "fused_deep_moe");
+    const int W = (int)num_ranks, L = (int)num_experts / W, H = (int)x.size(1);
+    EP_HOST_ASSERT(gmm1_permuted_weight.size(0) == L and gmm2_weight.size(0) == L);
+    at::Tensor w1 = gmm1_permuted_weight, w2 = gmm2_weight;
+    if (w1.size(2) != H) {                       // reference logical shape [L, H, 2I]
+        EP_HOST_ASSERT(w1.size(1) == H);
+        w1 = prepared_weight(gmm1_permuted_weight, 0, [&] { return gmm1_permuted_weight.transpose(1, 2).contiguous(); });
+    }
+    const int N1 = (int)w1.size(1), I = N1 / 2;
+    if (w2.size(1) != H) {                       // reference logical shape [L, I, H]
+        EP_HOST_ASSERT(w2.size(2) == H and w2.size(1) == I);
+        w2 = prepared_weight(gmm2_weight, 1, [&] { return gmm2_weight.transpose(1, 2).contiguous(); });
+    }
+    at::Tensor s1 = gmm1_permuted_weight_scale.to(at::kFloat).reshape({L, N1}).contiguous();
+    at::Tensor s2 = gmm2_weight_scale.to(at::kFloat).reshape({L, H}).contiguous();
+    at::Tensor topk_weights = expert_scales_optional->to(at::kFloat).contiguous();
+    return fused_core(x, expert_ids, w1, s1, w2, s2, topk_weights, num_max_dispatch_tokens_per_rank, num_experts);
+}
+
+// N1  FuseMode.DISPATCH_FFN_COMBINE (reference deep_ep.cpp:1254-1287; buffer.py:854-869).  Differences from fused_deep_moe that
+// matter to a caller: weights arrive in their plain logical shapes [L, H, 2I] / [L, I, H] with gate = columns [0, I) and
+// up = [I, 2I) (no fusion-tile permutation; activate_left swish, tests/python/deepep/test_dispatch_ffn_combine.py:168-178),
+// scales are fp32 bit patterns widened to int64 (:60-69), `max_output_size` bounds the rows a rank can receive, and the
+// second output is the per-local-expert row count [L].  Here the weights are re-laid-out once (cached) into the fusion-tile,
+// K-contiguous form the grouped GEMM consumes, then the same launch chain runs.
+std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &weight1,
+                                                     const at::Tensor &scale1, const at::Tensor &weight2, const at::Tensor &scale2,
+                                                     const std::optional<at::Tensor> &expert_scales, int64_t max_output_size,
+                                                     int64_t num_experts, int64_t quant_mode)
+{
+    require_available();
+    EP_HOST_ASSERT(max_output_size > 0);
+    EP_HOST_ASSERT_S(weight1.scalar_type() == at::kChar, "BF16 mode not yet supported for dispatch_ffn_combine");
+    fused_common_checks(x, expert_ids, weight1, weight2, quant_mode, expert_scales, "dispatch_ffn_combine");
+    const int W = (int)num_ranks, L = (int)num_experts / W, H = (int)x.size(1), T = (int)x.size(0), K = (int)expert_ids.size(1);
+    EP_HOST_ASSERT(weight1.size(0) == L and weight2.size(0) == L);
+    EP_HOST_ASSERT_S(weight1.size(1) == H and weight2.size(2) == H and weight2.size(1) * 2 == weight1.size(2),
+                     "dispatch_ffn_combine expects weight1 [L, hidden, 2*inter] and weight2 [L, inter, hidden]");
+    const int64_t N1 = weight1.size(2), I = N1 / 2;
+    auto fusion_perm = [&]() {                   // fused row p -> logical output channel: 64 gate channels then their 64 up channels
+        at::Tensor p = at::arange(N1, at::dtype(at::kLong).device(x.device()));
+        at::Tensor within = p.remainder(128), blk = p.div(128, "floor");
+        return at::where(within < 64, blk * 64 + within, blk * 64 + within - 64 + I);
+    };
+    at::Tensor w1 = prepared_weight(weight1, 2, [&] { return weight1.transpose(1, 2).index_select(1, fusion_perm()).contiguous(); });
+    at::Tensor w2 = prepared_weight(weight2, 1, [&] { return weight2.transpose(1, 2).contiguous(); });
+    auto as_f32 = [](const at::Tensor &s) {
+        if (s.scalar_type() == at::kLong) return s.to(at::kInt).contiguous().view(at::kFloat);   // fp32 bits carried in int64
+        return s.to(at::kFloat).contiguous();
+    };
+    at::Tensor s1 = as_f32(scale1).reshape({L, N1}).index_select(1, fusion_perm()).contiguous();
+    at::Tensor s2 = as_f32(scale2).reshape({L, H}).contiguous();
+    at::Tensor topk_weights = expert_scales->to(at::kFloat).contiguous();
+    // every rank may send at most max(T over ranks) tokens; the caller's bound is rows received = max_bs * W * K
+    int64_t per_rank = (max_output_size + (int64_t)W * K - 1) / ((int64_t)W * K);
+    EP_HOST_ASSERT_S(T <= per_rank, "dispatch_ffn_combine: max_output_size (", max_output_size, ") < tokens * num_ranks * topk");
+    auto r = fused_core(x, expert_ids, w1, s1, w2, s2, topk_weights, per_rank, num_experts);
+    at::Tensor ends = r[1].reshape({L, W}).select(1, W - 1);                     // inclusive cumulative rows at each expert's end
+    at::Tensor counts = ends - at::cat({at::zeros({1}, ends.options()), ends.slice(0, 0, L - 1)});
+    return {r[0], counts.to(expert_ids.scalar_type())};
 }
 
 // The reference's stage profiler (device timestamp ring + host exporter -> chrome trace_view.json, Ascend950 fused op

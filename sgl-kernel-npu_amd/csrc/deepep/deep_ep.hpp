@@ -5,6 +5,7 @@
 #pragma once
 #include <array>
 #include <functional>
+#include <map>
 #include <optional>
 #include <string>
 #include <tuple>
@@ -172,6 +173,23 @@ private:
     int64_t profile_skip = 0, profile_active = 0, profile_calls = 0;
     bool profiling = false;
     std::string profile_dir;
+    // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
+    std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
+                                       const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,
+                                       const at::Tensor &topk_weights, int64_t num_max_dispatch_tokens_per_rank,
+                                       int64_t num_experts);
+    at::Tensor prepared_weight(const at::Tensor &w, int kind, const std::function<at::Tensor()> &make);
+    struct WeightKey {
+        const void *ptr;
+        int kind;
+        bool operator<(const WeightKey &o) const { return ptr != o.ptr ? ptr < o.ptr : kind < o.kind; }
+    };
+    struct WeightEntry {
+        int64_t version, numel;
+        at::Tensor t;
+    };
+    std::map<WeightKey, WeightEntry> weight_cache_;
+
     struct ProfRec {
         const char *name;
         hipEvent_t a, b;

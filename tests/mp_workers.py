@@ -216,11 +216,22 @@ def _gpu_fused_moe(rank, world, port, cfg):
     x = bits_to_torch(xs[rank]).cuda()
     ti = torch.from_numpy(idxs[rank]).cuda()
     tw = torch.from_numpy(ws[rank]).cuda()
-    for _ in range(2):
-        out, ep_recv_count = buf.fused_deep_moe(x, ti, tw, w13_p, s13_p, w2_t, torch.from_numpy(s2[rank]).cuda(), T, E)
-    assert out.shape == (T, H) and out.dtype == torch.bfloat16
     ll = O.low_latency_dispatch(xs, idxs, T, E, True)[rank]
-    assert np.array_equal(ep_recv_count.cpu().numpy(), ll.layout_range)               # recv counts exact (test :519-521)
+    if layout == "ffn":
+        # FuseMode.DISPATCH_FFN_COMBINE (tests/python/deepep/test_dispatch_ffn_combine.py:72-88,390-405): plain [L, H, 2I] /
+        # [L, I, H] weights (gate = first I columns), fp32 scale bits widened to int64, max_output_size = T*K*W
+        as_i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32).astype(np.int64)).cuda()
+        w13_f2 = torch.from_numpy(np.ascontiguousarray(w13[rank].transpose(0, 2, 1))).cuda()
+        w2_f2 = torch.from_numpy(np.ascontiguousarray(w2[rank].transpose(0, 2, 1))).cuda()
+        for _ in range(2):
+            out, nums = buf.fused_deep_moe(x, ti, tw, w13_f2, as_i64(s13[rank]), w2_f2, as_i64(s2[rank]), T * K * W, E, 1, 2)
+        per_expert = np.diff(np.concatenate([[0], ll.layout_range.reshape(L, W)[:, -1]]))
+        assert nums.shape == (L,) and np.array_equal(nums.cpu().numpy(), per_expert)   # test_dispatch_ffn_combine.py:425-440
+    else:
+        for _ in range(2):
+            out, ep_recv_count = buf.fused_deep_moe(x, ti, tw, w13_p, s13_p, w2_t, torch.from_numpy(s2[rank]).cuda(), T, E)
+        assert np.array_equal(ep_recv_count.cpu().numpy(), ll.layout_range)           # recv counts exact (test :519-521)
+    assert out.shape == (T, H) and out.dtype == torch.bfloat16
     got = bf16_bits_to_f32(torch_to_bits(out))
     ref = bf16_bits_to_f32(want)
     diff = O.calc_diff(got, ref)

@@ -28,6 +28,8 @@ def test_buffer_multi_process_one_gpu(cfg):
     (2, 40, 512, 128, 4, 8, "reference"),     # (square H == I would be ambiguous: native layout is assumed)
     (4, 16, 1024, 128, 8, 32, "native"),
     (1, 64, 7168, 2048, 8, 8, "native"),          # DeepSeek-V3 hidden / intermediate, 8 local experts
+    (2, 24, 512, 256, 4, 8, "ffn"),               # FuseMode.DISPATCH_FFN_COMBINE: plain weights, int64 scale bits
+    (1, 32, 1024, 384, 8, 16, "ffn"),
 ])
 def test_fused_deep_moe(cfg):
     _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)
