@@ -5,6 +5,7 @@
  *
  * These replace the reference's Triton-Ascend kernels (python/sgl_kernel_npu/sgl_kernel_npu/...):
  *   mi_mla_decode            <- attention/decode_attention.py:5-230   (_paged_mla_fwd_kernel / decode_mla)
+ *   mi_gqa_decode            <- attention/decode_attention.py:233-450,646-760 (decode_gqa, decode_gqa_high_performance)
  *   mi_swiglu_quant          <- activation/swiglu_quant.py:8-127      (_swiglu_quant_kernel / swiglu_quant)
  *   mi_add_rmsnorm_bias      <- norm/add_rmsnorm_bias.py:8-147        (add_rmsnorm_bias_kernel / add_rmsnorm_bias)
  *                               norm/add_rmsnorm_bias.py:150-232      (add_gemma_rms_norm)
@@ -51,6 +52,21 @@ int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *o
                   const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
                   int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk, int64_t kn_stride_row,
                   int64_t kn_stride_h, int64_t kr_stride_blk, int64_t kr_stride_row, int64_t kr_stride_h,
+                  int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+/* ---- paged GQA decode attention with a separate V cache (decode_attention.py:233-450) -----------------------------
+ * out[b,h,:] = softmax_n( q[b,h]·k[n] * sm_scale ) · v[n],  n < kv_seq_lens[b]; kv head of query head h = h / (q_heads / kv_heads).
+ *   q [batch, q_heads, k_dim]; k [num_blocks, page_size, kv_heads, k_dim]; v [num_blocks, page_size, kv_heads, v_dim]
+ *   (v may alias k); out [batch, q_heads, v_dim]; strides in elements, last dims contiguous.
+ * k_dim, v_dim multiples of 8 with (k_dim, v_dim) <= one of (64,64) (128,128) (192,128) (256,256) (288,256) (576,512).
+ * num_splits as for mi_mla_decode. */
+size_t mi_gqa_decode_workspace(int batch, int q_heads, int v_dim, int num_splits);
+int mi_gqa_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
+int mi_gqa_decode(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
+                  const int32_t *block_table, int batch, int q_heads, int kv_heads, int k_dim, int v_dim, int page_size,
+                  int bt_stride, int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_blk,
+                  int64_t k_stride_row, int64_t k_stride_h, int64_t v_stride_blk, int64_t v_stride_row, int64_t v_stride_h,
                   int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits, void *workspace,
                   size_t workspace_bytes, void *stream);
 

@@ -75,6 +75,69 @@ def decode_mla_golden(q, k_nope, k_rope, kv_seq_lens, block_table, sm_scale):
 
 
 # --------------------------------------------------------------------------------------
+# A10  paged GQA decode (separate V cache)
+# --------------------------------------------------------------------------------------
+def decode_gqa(q, k_buffer, v_buffer, kv_seq_lens, block_table, sm_scale):
+    """Restates _paged_gqa_fwd_kernel (python/sgl_kernel_npu/sgl_kernel_npu/attention/decode_attention.py:292-375):
+    per page S = (q.K^T) * sm_scale (fp32 accumulation of low-precision products), mask beyond kv_seq_lens, online
+    softmax, P cast to the V dtype (:362), acc += P.V, out = acc / l.  q [B,Hq,Lk]; k_buffer [blocks,page,Hkv,Lk];
+    v_buffer [blocks,page,Hkv,Lv] (may be a view of k_buffer); returns [B,Hq,Lv] in q.dtype."""
+    B, Hq, Lk = q.shape
+    nb, page, Hkv, _ = k_buffer.shape
+    Lv = v_buffer.shape[-1]
+    group = Hq // Hkv
+    out = torch.zeros((B, Hq, Lv), dtype=q.dtype)
+    qf = q.float()
+    for b in range(B):
+        L = int(kv_seq_lens[b])
+        npages = (L + page - 1) // page
+        for kvh in range(Hkv):
+            hs = slice(kvh * group, (kvh + 1) * group)
+            m = torch.full((group,), -float("inf"))
+            l = torch.zeros(group)
+            acc = torch.zeros((group, Lv))
+            for pg in range(npages):
+                blk = int(block_table[b, pg])
+                k = k_buffer[blk, :, kvh, :].float()
+                v = v_buffer[blk, :, kvh, :].float()
+                s = (qf[b, hs] @ k.T) * sm_scale
+                valid = (pg * page + torch.arange(page)) < L
+                s = torch.where(valid[None, :], s, torch.tensor(-float("inf")))
+                m_new = torch.maximum(s.max(dim=1).values, m)
+                alpha = torch.exp(m - m_new)
+                p = torch.exp(s - m_new[:, None])
+                l = l * alpha + p.sum(dim=1)
+                acc = acc * alpha[:, None] + p.to(q.dtype).float() @ v
+                m = m_new
+            out[b, hs] = (acc / l[:, None]).to(q.dtype)
+    return out
+
+
+def decode_gqa_golden(q, k_buffer, v_buffer, kv_seq_lens, block_table, sm_scale):
+    """Transcription of the reference TEST golden decode_gqa_golden (tests/python/sgl_kernel_npu/test_decode_attention.py:18-60):
+    q scaled in its own dtype first (`q *= scale`, :40), one-shot fp32 softmax, scores cast to the V dtype, einsum with V."""
+    B, Hq, Lk = q.shape
+    nb, page, Hkv, _ = k_buffer.shape
+    Lv = v_buffer.shape[-1]
+    rep = Hq // Hkv
+    outs = []
+    for b in range(B):
+        L = int(kv_seq_lens[b])
+        npages = (L + page - 1) // page
+        idx = block_table[b, :npages].long()
+        k = k_buffer[idx].reshape(-1, Hkv, Lk)[:L]
+        v = v_buffer[idx].reshape(-1, Hkv, Lv)[:L]
+        if rep != 1:
+            k = torch.repeat_interleave(k, rep, dim=1)
+            v = torch.repeat_interleave(v, rep, dim=1)
+        qq = q[b:b + 1] * sm_scale
+        qk = torch.einsum("qhd,khd->hqk", qq, k).float()
+        score = torch.softmax(qk, dim=-1).to(v.dtype)
+        outs.append(torch.einsum("hqk,khd->qhd", score, v))
+    return torch.cat(outs, dim=0)
+
+
+# --------------------------------------------------------------------------------------
 # A11  SwiGLU + per-row INT8 quantisation
 # --------------------------------------------------------------------------------------
 def swiglu_quant(x, group_list, group_list_type, need_quant=True, do_limit=False, limit=7.0):

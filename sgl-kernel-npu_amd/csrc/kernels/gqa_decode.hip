@@ -1,0 +1,415 @@
+// Paged grouped-query decode attention with separate K / V caches for gfx950 -- the generic sibling of mla_decode.hip.
+// Replaces the reference's Triton-Ascend `_paged_gqa_fwd_kernel` / `decode_gqa` and `decode_gqa_high_performance`
+// (python/sgl_kernel_npu/sgl_kernel_npu/attention/decode_attention.py:233-450, :646-760): one query token per sequence,
+// q [B, Hq, Lk], K cache [blocks, page, Hkv, Lk], V cache [blocks, page, Hkv, Lv], fp32 scores / online softmax, P rounded
+// to the cache dtype before P.V (`p_exp.to(v.dtype)`, :362).
+//
+// MI355X design (HBM-bound: every K/V byte is used once per kv head): a workgroup of 4 waves owns one (sequence, kv head,
+// KV split) and ALL query heads of the group (wave w takes head blocks w, w+4, ...; 16 heads = the N dimension of the MFMA),
+// so K and V leave HBM once -- the reference re-reads them per 32-head block.  Tiles of 64 (or 32) keys are staged
+// global -> VGPR -> LDS (8 threads per key row = 128 contiguous bytes per row per instruction), double buffered, one
+// barrier per tile; the next tile's loads are in flight during the current tile's MFMAs.  Both GEMMs are transposed as in
+// the MLA kernel: S^T = K.Q^T (A = K rows, ds_read_b128; B = Q^T resident in registers), O^T += V^T.P^T (A = V^T through
+// ds_read_b64_tr_b16, B = P^T = the S^T accumulator layout packed in place) -- no cross-lane traffic between the GEMMs.
+// LDS rows are padded to an odd number of 32-byte units, which makes both read patterns conflict-free.
+// Flash-decoding split over the KV range + a merge kernel fill the 256 CUs for small batch x kv_heads.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mi_sgl_kernels.h"
+
+namespace mi_gqa {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct GqaParams {
+    const uint16_t *q, *k, *v;
+    uint16_t *out;
+    const int32_t *seq_lens, *block_table;
+    float *ws_o;      // [B][Hq][S][DVP] fp32 partial (unnormalised) outputs
+    float *ws_ml;     // [B][Hq][S][2]   running max (scaled log2 domain), running sum
+    int batch, q_heads, kv_heads, group, page_size, bt_stride, num_splits, lk, lv;
+    int64_t q_sb, q_sh, k_sblk, k_srow, k_sh, v_sblk, v_srow, v_sh, o_sb, o_sh;
+    float sm_scale;
+};
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)
+{
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi)
+{
+    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+
+constexpr int row_stride(int dim) { return dim * 2 + 32; }      // dim % 16 == 0 and (dim / 16) even -> odd count of 32-B units
+
+// DKP / DVP: compile-time padded head dims (DKP % 32 == 0, DVP % 32 == 0); TILE keys per tile (64 or 32);
+// HB head blocks of 16 per wave (a workgroup covers 64 * HB heads of the group).
+template <bool BF16, int DKP, int DVP, int TILE, int HB>
+__global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
+{
+    constexpr int KS = row_stride(DKP), VS = row_stride(DVP);
+    constexpr int kBuf = TILE * (KS + VS);
+    constexpr int MT = TILE / 16, KK = TILE / 32, QS = DKP / 32, DT = DVP / 16;
+    constexpr int KC = DKP / 8, VC = DVP / 8;                    // 16-B chunks per row
+    constexpr int RP = TILE / 32;                                // row passes: 8 threads per row, 32 rows per pass
+    constexpr int KJ = (KC + 7) / 8, VJ = (VC + 7) / 8;          // chunk passes per row
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    constexpr int kHeadsPerWg = 64 * HB;
+    const int head_blocks = (p.group + kHeadsPerWg - 1) / kHeadsPerWg;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;         // sibling head blocks of a unit share an XCD (L2 reuse)
+    const int unit = (jj / head_blocks) * 8 + xcd;
+    const int hblk = jj % head_blocks;
+    if (unit >= p.batch * p.kv_heads * p.num_splits) return;
+    const int split = unit % p.num_splits;
+    const int kvh = (unit / p.num_splits) % p.kv_heads;
+    const int b = unit / (p.num_splits * p.kv_heads);
+    const int seq_len = p.seq_lens[b];
+    const int ntiles = (seq_len + TILE - 1) / TILE;
+    const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
+    const int t_begin = split * tps;
+    const int t_end = min(ntiles, t_begin + tps);
+
+    // Q^T fragments: lane (g, c16) holds q[head][ks*32 + g*8 .. +8] of head block hb
+    s16x8 qf[HB][QS];
+    int hg[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        hg[hb] = hblk * kHeadsPerWg + (hb * 4 + wave) * 16 + c16;
+        const bool ok = hg[hb] < p.group;
+        const uint16_t *qrow = p.q + (int64_t)b * p.q_sb + (int64_t)(kvh * p.group + (ok ? hg[hb] : 0)) * p.q_sh;
+#pragma unroll
+        for (int ks = 0; ks < QS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            qf[hb][ks] = (ok && d < p.lk) ? *(const s16x8 *)(qrow + d) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    // does this wave have any real head?  (waves without one still help to stage tiles)
+    bool wave_has[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) wave_has[hb] = hblk * kHeadsPerWg + (hb * 4 + wave) * 16 < p.group;
+
+    f32x4 acc[HB][DT];
+    float m_run[HB], l_run[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        m_run[hb] = -INFINITY, l_run[hb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) acc[hb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- tile staging: thread owns rows (tid >> 3) [+32] and chunks (tid & 7) + 8 j
+    u32x4 kreg[RP][KJ], vreg[RP][VJ];
+    const int srow = tid >> 3, sch = tid & 7;
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) {
+            int n = tile * TILE + rp * 32 + srow;
+            n = n < seq_len ? n : seq_len - 1;                    // rows past the end are masked later; keep the address valid
+            n = n < 0 ? 0 : n;
+            const int page = n / p.page_size;
+            const int64_t blk = p.block_table[(int64_t)b * p.bt_stride + page], r = n - page * p.page_size;
+            const uint16_t *kr = p.k + blk * p.k_sblk + r * p.k_srow + (int64_t)kvh * p.k_sh;
+            const uint16_t *vr = p.v + blk * p.v_sblk + r * p.v_srow + (int64_t)kvh * p.v_sh;
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                const int c = sch + 8 * j;
+                kreg[rp][j] = (c * 8 < p.lk) ? *(const u32x4 *)(kr + c * 8) : u32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < VJ; ++j) {
+                const int c = sch + 8 * j;
+                vreg[rp][j] = (c * 8 < p.lv) ? *(const u32x4 *)(vr + c * 8) : u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    auto stage_store = [&](uint8_t *buf) {
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) {
+            const int row = rp * 32 + srow;
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                const int c = sch + 8 * j;
+                if (c < KC) *(u32x4 *)(buf + row * KS + c * 16) = kreg[rp][j];
+            }
+#pragma unroll
+            for (int j = 0; j < VJ; ++j) {
+                const int c = sch + 8 * j;
+                if (c < VC) *(u32x4 *)(buf + TILE * KS + row * VS + c * 16) = vreg[rp][j];
+            }
+        }
+    };
+
+    if (t_begin < t_end) {
+        stage_load(t_begin);
+        stage_store(lds);
+    }
+    const float cs = p.sm_scale * 1.4426950408889634f;
+    for (int t = t_begin; t < t_end; ++t) {
+        uint8_t *buf = lds + ((t - t_begin) & 1) * kBuf;
+        uint8_t *nbuf = lds + ((t + 1 - t_begin) & 1) * kBuf;
+        const bool more = t + 1 < t_end;
+        __syncthreads();                                          // tile t complete in LDS; tile t-1 no longer read
+        if (more) stage_load(t + 1);                              // travels under this tile's MFMAs
+
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            if (!wave_has[hb]) continue;                          // wave-uniform
+            // ---- S^T[key, head] = K . Q^T
+            f32x4 s[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) s[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < QS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const s16x8 a = *(const s16x8 *)(buf + (mt * 16 + c16) * KS + ks * 64 + g * 16);
+                    s[mt] = mfma16<BF16>(a, qf[hb][ks], s[mt]);
+                }
+            // ---- online softmax in the scaled log2 domain; lane owns head c16 and keys mt*16 + 4g + r
+            if ((t + 1) * TILE > seq_len) {
+                const int kbase = t * TILE + 4 * g;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kbase + mt * 16 + r >= seq_len) s[mt][r] = -INFINITY;
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) tmax = fmaxf(fmaxf(tmax, fmaxf(s[mt][0], s[mt][1])), fmaxf(s[mt][2], s[mt][3]));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax *= cs;                                           // sm_scale > 0: max commutes with the scaling
+            if (__any(tmax > m_run[hb])) {
+                const float m_new = fmaxf(m_run[hb], tmax);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run[hb] - m_new);
+                l_run[hb] *= alpha;
+                m_run[hb] = m_new;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) acc[hb][i] *= alpha;
+            }
+            const float nm = (m_run[hb] == -INFINITY) ? 0.f : -m_run[hb];
+            float psum = 0.f;
+            uint32_t pk[MT * 2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mt][r], cs, nm));
+                    psum += e[r];
+                }
+                pk[mt * 2 + 0] = pack2<BF16>(e[0], e[1]);
+                pk[mt * 2 + 1] = pack2<BF16>(e[2], e[3]);
+            }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[hb] += psum;
+            // ---- O^T[d, head] += V^T . P^T ; k-step kk covers key tiles (2kk, 2kk+1): slots 0..3 / 4..7 of lane group g
+            const uint8_t *vrow = buf + TILE * KS + (4 * g + (c16 >> 2)) * VS + (c16 & 3) * 8;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const s16x8 pf = __builtin_bit_cast(s16x8, u32x4{pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]});
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3))) *)(vrow + (2 * kk) * 16 * VS + dt * 32));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3))) *)(vrow + (2 * kk + 1) * 16 * VS + dt * 32));
+                    const s16x8 a = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[hb][dt] = mfma16<BF16>(a, pf, acc[hb][dt]);
+                }
+            }
+        }
+        if (more) stage_store(nbuf);
+    }
+
+    // ---- epilogue: lane holds O^T[d = dt*16 + 4g + r][head c16]
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        if (hg[hb] >= p.group) continue;
+        const int head = kvh * p.group + hg[hb];
+        if (p.num_splits == 1) {
+            const float inv = l_run[hb] > 0.f ? 1.f / l_run[hb] : 0.f;
+            uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                if (dt * 16 + 4 * g >= p.lv) continue;            // lv % 8 == 0: the 4 dims are in or out together
+                const uint32_t w0 = pack2<BF16>(acc[hb][dt][0] * inv, acc[hb][dt][1] * inv);
+                const uint32_t w1 = pack2<BF16>(acc[hb][dt][2] * inv, acc[hb][dt][3] * inv);
+                *(uint2 *)(orow + dt * 16) = uint2{w0, w1};
+            }
+        } else {
+            const int64_t idx = ((int64_t)b * p.q_heads + head) * p.num_splits + split;
+            float *po = p.ws_o + idx * DVP + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *(f32x4 *)(po + dt * 16) = acc[hb][dt];
+            if (g == 0) {
+                p.ws_ml[idx * 2 + 0] = m_run[hb];
+                p.ws_ml[idx * 2 + 1] = l_run[hb];
+            }
+        }
+    }
+}
+
+// merge the flash-decoding partials: one wave per (b, head); lane handles dims lane*4 + 256 i
+template <bool BF16>
+__global__ __launch_bounds__(256) void gqa_merge_kernel(GqaParams p, int dvp)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t bh = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (bh >= (int64_t)p.batch * p.q_heads) return;
+    const int S = p.num_splits;
+    const float *ml = p.ws_ml + bh * S * 2;
+    float M = -INFINITY;
+    for (int s = 0; s < S; ++s) M = fmaxf(M, ml[s * 2]);
+    float L = 0.f;
+    for (int s = 0; s < S; ++s)
+        if (ml[s * 2] != -INFINITY) L += __builtin_amdgcn_exp2f(ml[s * 2] - M) * ml[s * 2 + 1];
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
+    uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
+    for (int d = lane * 4; d < p.lv; d += 256) {
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            const float m = ml[s * 2];
+            if (m == -INFINITY) continue;
+            const float w = __builtin_amdgcn_exp2f(m - M);
+            o += w * *(const f32x4 *)(p.ws_o + (bh * S + s) * dvp + d);
+        }
+        *(uint2 *)(orow + d) = uint2{pack2<BF16>(o[0] * inv, o[1] * inv), pack2<BF16>(o[2] * inv, o[3] * inv)};
+    }
+}
+
+struct Shape {
+    int dkp, dvp, tile;
+};
+// first entry that fits is used; (576, 512) covers DeepSeek-style K = nope|rope caches whose V is NOT a view of K
+static const Shape kShapes[] = {{64, 64, 64}, {128, 128, 64}, {192, 128, 64}, {256, 256, 64}, {288, 256, 64}, {576, 512, 32}};
+
+static const Shape *pick_shape(int lk, int lv)
+{
+    for (const Shape &s : kShapes)
+        if (lk <= s.dkp && lv <= s.dvp) return &s;
+    return nullptr;
+}
+
+template <bool BF16, int DKP, int DVP, int TILE, int HB>
+static void launch_one(const GqaParams &p, dim3 grid, hipStream_t st)
+{
+    constexpr size_t lds = 2 * (size_t)TILE * (row_stride(DKP) + row_stride(DVP));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)gqa_decode_kernel<BF16, DKP, DVP, TILE, HB>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gqa_decode_kernel<BF16, DKP, DVP, TILE, HB><<<grid, 256, lds, st>>>(p);
+}
+
+template <bool BF16, int HB>
+static bool launch_shape(const Shape &s, const GqaParams &p, dim3 grid, hipStream_t st)
+{
+    if (s.dkp == 64) launch_one<BF16, 64, 64, 64, HB>(p, grid, st);
+    else if (s.dkp == 128) launch_one<BF16, 128, 128, 64, HB>(p, grid, st);
+    else if (s.dkp == 192) launch_one<BF16, 192, 128, 64, HB>(p, grid, st);
+    else if (s.dkp == 256) launch_one<BF16, 256, 256, 64, HB>(p, grid, st);
+    else if (s.dkp == 288) launch_one<BF16, 288, 256, 64, HB>(p, grid, st);
+    else if (s.dkp == 576) launch_one<BF16, 576, 512, 32, 1>(p, grid, st);
+    else return false;
+    return true;
+}
+
+static int heads_per_wg(const Shape &s, int group) { return (s.dkp == 576 || group <= 64) ? 64 : 128; }
+
+}  // namespace mi_gqa
+
+using namespace mi_gqa;
+
+extern "C" size_t mi_gqa_decode_workspace(int batch, int q_heads, int v_dim, int num_splits)
+{
+    if (num_splits <= 1) return 0;
+    const Shape *s = pick_shape(8, v_dim);
+    if (!s) return 0;
+    // the padded V width depends on the (k_dim, v_dim) pair; 512 bounds every supported shape
+    return (size_t)batch * q_heads * num_splits * (512 + 2) * sizeof(float);
+}
+
+extern "C" int mi_gqa_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
+{
+    if (batch <= 0 || q_heads <= 0 || kv_heads <= 0 || max_seq_len <= 0) return 1;
+    const long long wgs = (long long)batch * kv_heads * ((q_heads / kv_heads + 127) / 128);
+    const int ntiles = (max_seq_len + 63) / 64;
+    int s = (int)((512 + wgs - 1) / wgs);              // about two workgroups per CU
+    const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;   // keep >= 4 tiles (256 keys) per split
+    if (s > cap) s = cap;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int mi_gqa_decode(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
+                             const int32_t *block_table, int batch, int q_heads, int kv_heads, int k_dim, int v_dim, int page_size,
+                             int bt_stride, int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_blk,
+                             int64_t k_stride_row, int64_t k_stride_h, int64_t v_stride_blk, int64_t v_stride_row,
+                             int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (batch < 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads || page_size <= 0 || bt_stride <= 0) return MI_SGL_EINVAL;
+    if (k_dim <= 0 || v_dim <= 0 || (k_dim % 8) || (v_dim % 8)) return MI_SGL_EINVAL;
+    const Shape *shape = pick_shape(k_dim, v_dim);
+    if (!shape) return MI_SGL_EINVAL;
+    if (batch == 0) return MI_SGL_OK;
+    if (!q || !k || !v || !out || !kv_seq_lens || !block_table) return MI_SGL_EINVAL;
+    if (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) return MI_SGL_EINVAL;
+    if ((q_stride_h % 8) || (q_stride_b % 8) || (k_stride_row % 8) || (k_stride_blk % 8) || (k_stride_h % 8) || (v_stride_row % 8) ||
+        (v_stride_blk % 8) || (v_stride_h % 8) || (o_stride_h % 4) || (o_stride_b % 4))
+        return MI_SGL_EINVAL;      // 16-byte loads, 8-byte stores
+    if (num_splits <= 0) num_splits = mi_gqa_decode_num_splits(batch, q_heads, kv_heads, max_seq_len);
+    if (num_splits > 1 && (!workspace || workspace_bytes < mi_gqa_decode_workspace(batch, q_heads, v_dim, num_splits))) return MI_SGL_EINVAL;
+    GqaParams p;
+    p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v;
+    p.out = (uint16_t *)out, p.seq_lens = kv_seq_lens, p.block_table = block_table;
+    p.ws_o = (float *)workspace;
+    p.ws_ml = p.ws_o ? p.ws_o + (size_t)batch * q_heads * num_splits * shape->dvp : nullptr;
+    p.batch = batch, p.q_heads = q_heads, p.kv_heads = kv_heads, p.group = q_heads / kv_heads, p.page_size = page_size;
+    p.bt_stride = bt_stride, p.num_splits = num_splits, p.lk = k_dim, p.lv = v_dim;
+    p.q_sb = q_stride_b, p.q_sh = q_stride_h, p.k_sblk = k_stride_blk, p.k_srow = k_stride_row, p.k_sh = k_stride_h;
+    p.v_sblk = v_stride_blk, p.v_srow = v_stride_row, p.v_sh = v_stride_h, p.o_sb = o_stride_b, p.o_sh = o_stride_h;
+    p.sm_scale = sm_scale;
+    hipStream_t st = (hipStream_t)stream;
+    const int hpw = heads_per_wg(*shape, p.group);
+    const int head_blocks = (p.group + hpw - 1) / hpw;
+    const long long units = (long long)batch * kv_heads * num_splits;
+    dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
+    bool ok;
+    if (dtype == MI_DTYPE_BF16) ok = hpw == 64 ? launch_shape<true, 1>(*shape, p, grid, st) : launch_shape<true, 2>(*shape, p, grid, st);
+    else ok = hpw == 64 ? launch_shape<false, 1>(*shape, p, grid, st) : launch_shape<false, 2>(*shape, p, grid, st);
+    if (!ok) return MI_SGL_EINVAL;
+    if (num_splits > 1) {
+        const long long bh = (long long)batch * q_heads;
+        const int blocks = (int)((bh + 3) / 4);
+        if (dtype == MI_DTYPE_BF16) gqa_merge_kernel<true><<<blocks, 256, 0, st>>>(p, shape->dvp);
+        else gqa_merge_kernel<false><<<blocks, 256, 0, st>>>(p, shape->dvp);
+    }
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}

@@ -59,6 +59,58 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
     TORCH_CHECK(rc == 0, "mi_mla_decode failed with code ", rc);
 }
 
+// Paged GQA decode with a separate V cache; argument meaning of decode_gqa (decode_attention.py:378-387); writes att_out in place.
+// A DeepSeek-style cache where V is the first 512 columns of the 576-wide K rows (the reference special-cases Lk == 576,
+// :404-407, and its test builds exactly that view, test_decode_attention.py:74) goes to the MLA kernel, which reads each K
+// row once for both GEMMs; everything else runs the generic kernel (csrc/kernels/gqa_decode.hip).
+void decode_gqa(const at::Tensor &q, const at::Tensor &k_buffer, const at::Tensor &v_buffer, at::Tensor &att_out,
+                const at::Tensor &kv_seq_lens, double sm_scale, int64_t page_size, const at::Tensor &block_table, int64_t num_splits)
+{
+    TORCH_CHECK(q.dim() == 3 && k_buffer.dim() == 4 && v_buffer.dim() == 4 && att_out.dim() == 3 && block_table.dim() == 2,
+                "decode_gqa: bad ranks");
+    TORCH_CHECK(q.stride(2) == 1 && k_buffer.stride(3) == 1 && v_buffer.stride(3) == 1 && att_out.stride(2) == 1,
+                "decode_gqa: innermost dimension must be contiguous");
+    TORCH_CHECK(k_buffer.size(1) == page_size && v_buffer.size(1) == page_size, "decode_gqa: page_size mismatch");
+    TORCH_CHECK(q.scalar_type() == k_buffer.scalar_type() && q.scalar_type() == v_buffer.scalar_type() &&
+                    q.scalar_type() == att_out.scalar_type(), "decode_gqa: dtype mismatch");
+    TORCH_CHECK(kv_seq_lens.scalar_type() == at::kInt && block_table.scalar_type() == at::kInt && kv_seq_lens.is_contiguous(),
+                "decode_gqa: kv_seq_lens / block_table must be int32");
+    TORCH_CHECK(block_table.stride(1) == 1, "decode_gqa: block_table rows must be contiguous");
+    const int B = (int)q.size(0), Hq = (int)q.size(1), Hkv = (int)k_buffer.size(2);
+    const int Lk = (int)k_buffer.size(3), Lv = (int)v_buffer.size(3);
+    TORCH_CHECK(Hq % Hkv == 0, "head_num must be divisible by kv_head_num");
+    TORCH_CHECK(v_buffer.size(2) == Hkv && q.size(2) == Lk && att_out.size(2) == Lv && att_out.size(0) == B && att_out.size(1) == Hq,
+                "decode_gqa: shape mismatch");
+    const int max_len = (int)std::min<int64_t>(block_table.size(1) * page_size, INT32_MAX);   // upper bound, no host sync
+    int splits = (int)num_splits;
+    const bool v_is_k_prefix = Lk == 576 && Lv == 512 && v_buffer.data_ptr() == k_buffer.data_ptr() &&
+                               v_buffer.stride(0) == k_buffer.stride(0) && v_buffer.stride(1) == k_buffer.stride(1) &&
+                               v_buffer.stride(2) == k_buffer.stride(2);
+    if (v_is_k_prefix) {
+        if (splits <= 0) splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
+        const size_t wsb = mi_mla_decode_workspace(B, Hq, splits);
+        at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(q.device()));
+        const char *kb = (const char *)k_buffer.data_ptr();
+        const int rc = mi_mla_decode(q.data_ptr(), kb, kb + 512 * 2, att_out.data_ptr(), kv_seq_lens.data_ptr<int>(),
+                                     block_table.data_ptr<int>(), B, Hq, Hkv, (int)page_size, (int)block_table.stride(0), max_len,
+                                     q.stride(0), q.stride(1), k_buffer.stride(0), k_buffer.stride(1), k_buffer.stride(2),
+                                     k_buffer.stride(0), k_buffer.stride(1), k_buffer.stride(2), att_out.stride(0),
+                                     att_out.stride(1), (float)sm_scale, dtype_code(q), splits, ws.data_ptr(), wsb, cur_stream());
+        TORCH_CHECK(rc == 0, "mi_mla_decode failed with code ", rc);
+        return;
+    }
+    if (splits <= 0) splits = mi_gqa_decode_num_splits(B, Hq, Hkv, max_len);
+    const size_t wsb = mi_gqa_decode_workspace(B, Hq, Lv, splits);
+    at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(q.device()));
+    const int rc = mi_gqa_decode(q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), att_out.data_ptr(), kv_seq_lens.data_ptr<int>(),
+                                 block_table.data_ptr<int>(), B, Hq, Hkv, Lk, Lv, (int)page_size, (int)block_table.stride(0), max_len,
+                                 q.stride(0), q.stride(1), k_buffer.stride(0), k_buffer.stride(1), k_buffer.stride(2),
+                                 v_buffer.stride(0), v_buffer.stride(1), v_buffer.stride(2), att_out.stride(0), att_out.stride(1),
+                                 (float)sm_scale, dtype_code(q), splits, ws.data_ptr(), wsb, cur_stream());
+    TORCH_CHECK(rc == 0, "mi_gqa_decode failed with code ", rc,
+                " (head dims must be multiples of 8 with (k, v) <= (64,64) (128,128) (192,128) (256,256) (288,256) or (576,512))");
+}
+
 // SwiGLU + per-row INT8 quantisation; same arguments / returns as swiglu_quant (activation/swiglu_quant.py:87-127).
 std::tuple<at::Tensor, at::Tensor> swiglu_quant(const at::Tensor &x, const at::Tensor &group_list, int64_t group_list_type,
                                                 bool need_quant, bool do_limit, double limit)
@@ -219,6 +271,8 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("sgl_kernel_npu_version() -> str", &sglang::npu_kernel::sgl_kernel_npu_version);
     m.def("decode_mla(Tensor q, Tensor k_nope_buffer, Tensor k_rope_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
           "float sm_scale, int page_size, Tensor block_table, int num_splits=0) -> ()");
+    m.def("decode_gqa(Tensor q, Tensor k_buffer, Tensor v_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
+          "float sm_scale, int page_size, Tensor block_table, int num_splits=0) -> ()");
     m.def("mla_preprocess(Tensor hiddenState, Tensor gamma0, Tensor beta0, Tensor wdqkv, "
           "Tensor descale0, Tensor gamma1, Tensor beta1, Tensor wuq, "
           "Tensor descale1, Tensor gamma2, Tensor cos, Tensor sin, Tensor wuk,"
@@ -241,6 +295,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
 TORCH_LIBRARY_IMPL(npu, CUDA, m)
 {
     m.impl("decode_mla", TORCH_FN(sglang::npu_kernel::decode_mla));
+    m.impl("decode_gqa", TORCH_FN(sglang::npu_kernel::decode_gqa));
     m.impl("mla_preprocess", TORCH_FN(sglang::npu_kernel::mla_preprocess));
     m.impl("swiglu_quant", TORCH_FN(sglang::npu_kernel::swiglu_quant));
     m.impl("add_rmsnorm_bias", TORCH_FN(sglang::npu_kernel::add_rmsnorm_bias));
