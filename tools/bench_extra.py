@@ -75,6 +75,22 @@ def main():
     hw = torch.randn(128, device="cuda").to(torch.bfloat16)
     t = ev_time(lambda: split_qkv_rmsnorm_rope(qkv, sn, cs, 6144, 1024, 128, 1e-6, hw, hw, hw, hw))
     out["split_qkv_rmsnorm_rope_4096x8192"] = dict(t, GBps=B * 8192 * 4 / t["p50_us"] / 1e3)
+    # ---- paged GQA decode (HBM-bound): Llama-70B-like (64 q / 8 kv heads, D=128) and the reference's 288/256 config
+    from sgl_kernel_npu.attention.decode_attention import decode_gqa
+    for name, Bq, Hq, Hkv, D, Dv, Sq in (("gqa_decode_b64_h64kv8_d128_s4096", 64, 64, 8, 128, 128, 4096),
+                                          ("gqa_decode_b256_h64kv8_d128_s4096", 256, 64, 8, 128, 128, 4096),
+                                          ("gqa_decode_b128_h128kv1_d288_s4096", 128, 128, 1, 288, 256, 4096)):
+        page = 64
+        nb = Bq * Sq // page
+        q = torch.randn((Bq, Hq, D), generator=g, device="cuda").to(torch.bfloat16)
+        kc = torch.randn((nb, page, Hkv, D), generator=g, device="cuda").to(torch.bfloat16)
+        vc = kc[..., :Dv] if D != Dv else torch.randn((nb, page, Hkv, Dv), generator=g, device="cuda").to(torch.bfloat16)
+        bt = torch.randperm(nb, device="cuda").to(torch.int32).reshape(Bq, Sq // page)
+        lens = torch.full((Bq,), Sq, dtype=torch.int32, device="cuda")
+        o = torch.empty((Bq, Hq, Dv), device="cuda", dtype=torch.bfloat16)
+        t = ev_time(lambda: decode_gqa(q, kc, vc, o, lens, D ** -0.5, page, bt), n=20, warm=3)
+        kv_bytes = Bq * Sq * Hkv * (D if D != Dv else D + Dv) * 2
+        out[name] = dict(t, GBps=kv_bytes / t["p50_us"] / 1e3)
     print(json.dumps(out))
 
 main()
