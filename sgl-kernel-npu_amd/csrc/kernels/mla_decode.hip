@@ -28,11 +28,10 @@
 
 #include "mi_sgl_kernels.h"
 
-#ifndef MLA_EXP
-#define MLA_EXP 0
-#endif
+// Tile fill: 0 = LDS-DMA (global_load_lds) with one 1-KiB piece issued per QK k-step (default, fastest);
+// 1 = register-staged (global_load_dwordx4 -> VGPR -> ds_write_b128), kept as the measured alternative.
 #ifndef MLA_STAGE
-#define MLA_STAGE (MLA_WAVES == 4)
+#define MLA_STAGE 0
 #endif
 
 namespace mi_sgl {
@@ -42,6 +41,9 @@ constexpr int kNopeStride = kDN * 2 + 32;          // bytes per key row in LDS: 
                                                    // ds_read_b128 (16 keys x 16 B) and the tr-read (8 keys x 32 B) footprints conflict-free
 constexpr int kRopeStride = kDR * 2;               // 128 B, swizzled
 constexpr int kBufBytes = kTile * kNopeStride + kTile * kRopeStride;   // 74752
+#ifndef MLA_QK_AHEAD
+#define MLA_QK_AHEAD 3
+#endif
 #ifndef MLA_WAVES
 #define MLA_WAVES 4
 #endif
@@ -52,6 +54,7 @@ constexpr int kMaxWaves = MLA_WAVES;
 //                 fits 256 registers WITH operand prefetch and the SIMD always has a second wave to issue from.
 constexpr int kDSplit = kMaxWaves / 4;
 constexpr int kHeadWaves = 4;
+constexpr bool kDmaInterleaved = !MLA_STAGE && MLA_WAVES == 4;   // 18 DMA pieces per wave per tile = 18 QK k-steps
 constexpr int kHeadsPerBlock = kHeadWaves * 16;
 constexpr int kAccTiles = 32 / kDSplit;
 
@@ -157,6 +160,28 @@ __device__ __forceinline__ void issue_tile(const MlaParams &p, const TileRows &r
     for (int j = wave; j < kTile / 8; j += nwaves) {   // 8 keys x 128 B of rope per instruction
         const int key = j * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (key & 7);       // XOR swizzle on the source side
+        const uint16_t *src = p.k_rope + lane_i64(rows.rope, key);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + chunk * 8),
+                                         (void __attribute__((address_space(3))) *)(buf + kTile * kNopeStride + j * 8 * kRopeStride),
+                                         16, 0, 0);
+    }
+}
+
+// one of the 18 DMA instructions a wave contributes to a tile (4-wave build): pieces 0..15 are nope rows wave + 4*idx,
+// pieces 16..17 are the rope blocks wave + 4*(idx - 16).  Lets the caller spread the issue over its MFMA stream.
+__device__ __forceinline__ void issue_piece(const MlaParams &p, const TileRows &rows, uint8_t *buf, int wave, int lane, int idx)
+{
+    if (idx < 16) {
+        const int i = wave + 4 * idx;
+        const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), i);
+        const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), i);
+        const uint16_t *src = p.k_nope + (((int64_t)hi << 32) | (uint32_t)lo);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane * 8),
+                                         (void __attribute__((address_space(3))) *)(buf + i * kNopeStride), 16, 0, 0);
+    } else {
+        const int j = wave + 4 * (idx - 16);
+        const int key = j * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (key & 7);
         const uint16_t *src = p.k_rope + lane_i64(rows.rope, key);
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + chunk * 8),
                                          (void __attribute__((address_space(3))) *)(buf + kTile * kNopeStride + j * 8 * kRopeStride),
@@ -272,12 +297,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
                 stage_load(p, rows_nxt, 0, wave, lane, st);   // first half of tile t+1 travels under the QK MFMAs
                 raw_next = tile_rows_load(p, b, seq_len, t + 2, lane);
             }
-        } else if (more && MLA_EXP != 2) {
+        } else if (kDmaInterleaved) {
+            rows_nxt = tile_rows_finish(p, kvh, raw_next);     // past the last tile the rows are clamped: a harmless dummy fill
+        } else if (more) {
             issue_tile(p, tile_rows_finish(p, kvh, raw_next), nbuf, wave, nwaves, lane);
             raw_next = tile_rows_load(p, b, seq_len, t + 2, lane);      // consumed one iteration later, after the wait above
         }
 
-        if (MLA_EXP == 1) continue;
         // ---- S^T[key, head] = K · Q^T  (4 m-tiles of 16 keys, 18 k-steps of 32 dims)
         f32x4 s[4];
 #pragma unroll
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         };
         // Explicit software pipeline, fenced with sched_barrier so the machine scheduler cannot sink the prefetch back
         // next to its use: operands of k-step ks + kAhead are issued before the MFMAs of k-step ks.
-        constexpr int kAhead = 2;
+        constexpr int kAhead = MLA_QK_AHEAD;
         s16x8 af[kAhead + 1][4];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) af[pre][mt] = lda(pre, mt);
 #pragma unroll
-        for (int ks = 0; ks < (MLA_EXP == 5 ? 0 : 18); ++ks) {
+        for (int ks = 0; ks < 18; ++ks) {
             __builtin_amdgcn_sched_barrier(0);
             if (ks + kAhead < 18) {
 #pragma unroll
@@ -307,8 +333,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) s[mt] = mfma16<BF16>(af[ks % (kAhead + 1)][mt], qf[ks], s[mt]);
+            if (kDmaInterleaved) issue_piece(p, rows_nxt, nbuf, wave, lane, ks);    // tile t+1 trickles in under the MFMAs
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (kDmaInterleaved) raw_next = tile_rows_load(p, b, seq_len, t + 2, lane);
         if (MLA_STAGE && more) {
             stage_load(p, rows_nxt, 1, wave, lane, st2);      // second half travels under softmax + PV
             __builtin_amdgcn_sched_barrier(0);
@@ -385,7 +413,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         };
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < (MLA_EXP == 5 ? 0 : 2 * kAccTiles); ++i) {
+        for (int i = 0; i < 2 * kAccTiles; ++i) {
             const s16x4 lo = ldv(i, 0), hi = ldv(i, 1);
             const s16x8 a = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             acc[i % kAccTiles] = mfma16<BF16>(a, pf[i / kAccTiles], acc[i % kAccTiles]);
@@ -402,6 +430,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         if (MLA_STAGE && more) stage_store(nbuf, 1, wave, lane, st2);
     }
 
+    if (kDmaInterleaved) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy fill issued under the last tile
     // ---- epilogue: lane holds O^T[d = dt*16 + 4g + r][head c16]
     if (!head_ok) return;
     if (p.num_splits == 1) {
