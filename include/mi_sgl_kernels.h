@@ -44,8 +44,8 @@ const char *mi_sgl_kernels_version(void);
  *   out        [batch, q_heads, 512]            strides (o_stride_b, o_stride_h)
  *   kv_seq_lens int32 [batch]; block_table int32 [batch, bt_stride] (logical page -> physical block)
  * q_heads % kv_heads == 0; any page_size >= 1.  num_splits >= 1 partitions the KV range of every sequence
- * (flash-decoding); num_splits > 1 needs `workspace` of mi_mla_decode_workspace() bytes.  Pass num_splits = 0 to
- * let the library choose (mi_mla_decode_num_splits). */
+ * (flash-decoding).  `workspace` of mi_mla_decode_workspace() bytes (device memory, contents irrelevant) is needed when
+ * num_splits > 1 or q_heads / kv_heads > 64.  Pass num_splits = 0 to let the library choose (mi_mla_decode_num_splits). */
 size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
 int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
 int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,

@@ -36,14 +36,36 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def _file_flags(src):
+    """Per-file compiler flags: an optional first line `// hipcc-flags: ...` in the source."""
+    with open(src) as f:
+        first = f.readline()
+    return first.split(":", 1)[1].split() if first.startswith("// hipcc-flags:") else []
+
+
 def build_hip_lib(name, subdir, extra=()):
+    """Each .hip is compiled to an object on its own (in parallel, with its own flags), then linked."""
     os.makedirs(LIB, exist_ok=True)
+    objdir = os.path.join(LIB, "obj", subdir)
+    os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(HERE, "csrc", subdir, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(HERE, "csrc", subdir, "*.h")) + glob.glob(os.path.join(INC, "*.h"))
+    hdrs = glob.glob(os.path.join(HERE, "csrc", subdir, "*.h")) + glob.glob(os.path.join(INC, "*.h"))
     out = os.path.join(LIB, name)
-    if srcs and _newer(deps, out):
-        _run([hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              f"-I{INC}", f"-I{os.path.join(HERE, 'csrc', subdir)}", *extra, *srcs, "-o", out])
+    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{INC}",
+              f"-I{os.path.join(HERE, 'csrc', subdir)}", *extra]
+    objs, procs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if _newer([src] + hdrs, obj):
+            cmd = common + _file_flags(src) + ["-c", src, "-o", obj]
+            print("[build]", " ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    if srcs and _newer(objs, out):
+        _run([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out])
     return out
 
 

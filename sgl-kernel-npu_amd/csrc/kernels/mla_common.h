@@ -1,0 +1,112 @@
+// Shared pieces of the two MLA decode kernels (mla_decode.hip: 64 heads per workgroup on 16x16x32 MFMAs;
+// mla_decode_wide.hip: 128 heads per workgroup on 32x32x16 MFMAs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi_sgl {
+
+constexpr int kDN = 512, kDR = 64, kTile = 64;
+constexpr int kNopeStride = kDN * 2 + 32;          // bytes per key row in LDS: 66 x 16-B slots, 66 mod 16 = 2 makes both the
+                                                   // ds_read_b128 (16 keys x 16 B) and the tr-read (8 keys x 32 B) footprints conflict-free
+constexpr int kRopeStride = kDR * 2;               // 128 B, swizzled
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct MlaParams {
+    const uint16_t *q, *k_nope, *k_rope;
+    uint16_t *out;
+    const int32_t *seq_lens, *block_table;
+    float *ws_o;      // [B][Hq][S][512] fp32 partial (unnormalised) outputs
+    float *ws_ml;     // [B][Hq][S][2]   running max, running sum
+    int batch, q_heads, kv_heads, group, page_size, bt_stride, num_splits;
+    int64_t q_sb, q_sh, kn_sblk, kn_srow, kn_sh, kr_sblk, kr_srow, kr_sh, o_sb, o_sh;
+    float sm_scale;
+    // wide kernel -> merge kernel hand-off: sequences whose softmax reference was outgrown (see mla_decode_wide.hip)
+    uint32_t *fix_flags;      // [batch * kv_heads], entry == fix_epoch means "recompute"
+    uint32_t fix_epoch;
+    int fix_only;             // merge kernel: check the hand-off words and recompute flagged sequences
+};
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)
+{
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <bool BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi)
+{
+    // one v_cvt_pk_{bf16,f16}_f32 (round to nearest even)
+    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint16_t cvt_out(float f)
+{
+    if constexpr (BF16) {
+        uint32_t x = __float_as_uint(f);
+        if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
+        return (uint16_t)((x + 0x7FFFu + ((x >> 16) & 1u)) >> 16);
+    } else {
+        _Float16 a = (_Float16)f;
+        return __builtin_bit_cast(uint16_t, a);
+    }
+}
+
+// Per-tile row addressing.  Lane l owns key l of a tile: tile_rows() turns its token index into byte offsets of the
+// key's nope / rope rows (one block-table load per lane per tile, issued a whole tile ahead of its use so the load
+// latency never sits in front of the LDS-DMA).  issue_tile() then fetches row addresses from lanes with readlane /
+// shuffle, so no vector-memory wait separates consecutive DMA instructions.
+struct TileRows {
+    int64_t nope, rope;     // element offsets into k_nope / k_rope
+};
+struct TileRowsRaw {        // result of the block-table load, not yet consumed (so no wait is placed at the load)
+    int blk, row;
+};
+
+__device__ __forceinline__ TileRowsRaw tile_rows_load(const MlaParams &p, int b, int seq_len, int tile, int lane)
+{
+    int n = tile * kTile + lane;
+    n = n < seq_len ? n : seq_len - 1;                 // rows past the end are masked later; keep the address valid
+    n = n < 0 ? 0 : n;
+    const int page = n / p.page_size;
+    TileRowsRaw r;
+    r.row = n - page * p.page_size;
+    r.blk = p.block_table[(int64_t)b * p.bt_stride + page];
+    return r;
+}
+
+__device__ __forceinline__ TileRows tile_rows_finish(const MlaParams &p, int kvh, const TileRowsRaw &raw)
+{
+    TileRows r;
+    r.nope = (int64_t)raw.blk * p.kn_sblk + (int64_t)raw.row * p.kn_srow + (int64_t)kvh * p.kn_sh;
+    r.rope = (int64_t)raw.blk * p.kr_sblk + (int64_t)raw.row * p.kr_srow + (int64_t)kvh * p.kr_sh;
+    return r;
+}
+
+__device__ __forceinline__ int64_t lane_i64(int64_t v, int src_lane)
+{
+    const int lo = __shfl((int)(v & 0xFFFFFFFFll), src_lane, 64), hi = __shfl((int)(v >> 32), src_lane, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+
+// wide kernel (mla_decode_wide.hip): launch for kv groups of more than 64 heads
+constexpr int kWideTile = 32;
+void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t st);
+
+}  // namespace mi_sgl

@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include "mi_sgl_kernels.h"
+#include "mla_common.h"
 
 // Tile fill: 0 = LDS-DMA (global_load_lds) with one 1-KiB piece issued per QK k-step (default, fastest);
 // 1 = register-staged (global_load_dwordx4 -> VGPR -> ds_write_b128), kept as the measured alternative.
@@ -36,10 +37,6 @@
 
 namespace mi_sgl {
 
-constexpr int kDN = 512, kDR = 64, kTile = 64;
-constexpr int kNopeStride = kDN * 2 + 32;          // bytes per key row in LDS: 66 x 16-B slots, 66 mod 16 = 2 makes both the
-                                                   // ds_read_b128 (16 keys x 16 B) and the tr-read (8 keys x 32 B) footprints conflict-free
-constexpr int kRopeStride = kDR * 2;               // 128 B, swizzled
 constexpr int kBufBytes = kTile * kNopeStride + kTile * kRopeStride;   // 74752
 #ifndef MLA_QK_AHEAD
 #define MLA_QK_AHEAD 3
@@ -57,95 +54,6 @@ constexpr int kHeadWaves = 4;
 constexpr bool kDmaInterleaved = !MLA_STAGE && MLA_WAVES == 4;   // 18 DMA pieces per wave per tile = 18 QK k-steps
 constexpr int kHeadsPerBlock = kHeadWaves * 16;
 constexpr int kAccTiles = 32 / kDSplit;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-struct MlaParams {
-    const uint16_t *q, *k_nope, *k_rope;
-    uint16_t *out;
-    const int32_t *seq_lens, *block_table;
-    float *ws_o;      // [B][Hq][S][512] fp32 partial (unnormalised) outputs
-    float *ws_ml;     // [B][Hq][S][2]   running max, running sum
-    int batch, q_heads, kv_heads, group, page_size, bt_stride, num_splits;
-    int64_t q_sb, q_sh, kn_sblk, kn_srow, kn_sh, kr_sblk, kr_srow, kr_sh, o_sb, o_sh;
-    float sm_scale;
-};
-
-template <bool BF16>
-__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)
-{
-    if constexpr (BF16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-template <bool BF16>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi)
-{
-    // one v_cvt_pk_{bf16,f16}_f32 (round to nearest even)
-    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
-    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
-}
-
-template <bool BF16>
-__device__ __forceinline__ uint16_t cvt_out(float f)
-{
-    if constexpr (BF16) {
-        uint32_t x = __float_as_uint(f);
-        if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
-        return (uint16_t)((x + 0x7FFFu + ((x >> 16) & 1u)) >> 16);
-    } else {
-        _Float16 a = (_Float16)f;
-        return __builtin_bit_cast(uint16_t, a);
-    }
-}
-
-// Per-tile row addressing.  Lane l owns key l of a tile: tile_rows() turns its token index into byte offsets of the
-// key's nope / rope rows (one block-table load per lane per tile, issued a whole tile ahead of its use so the load
-// latency never sits in front of the LDS-DMA).  issue_tile() then fetches row addresses from lanes with readlane /
-// shuffle, so no vector-memory wait separates consecutive DMA instructions.
-struct TileRows {
-    int64_t nope, rope;     // element offsets into k_nope / k_rope
-};
-struct TileRowsRaw {        // result of the block-table load, not yet consumed (so no wait is placed at the load)
-    int blk, row;
-};
-
-__device__ __forceinline__ TileRowsRaw tile_rows_load(const MlaParams &p, int b, int seq_len, int tile, int lane)
-{
-    int n = tile * kTile + lane;
-    n = n < seq_len ? n : seq_len - 1;                 // rows past the end are masked later; keep the address valid
-    n = n < 0 ? 0 : n;
-    const int page = n / p.page_size;
-    TileRowsRaw r;
-    r.row = n - page * p.page_size;
-    r.blk = p.block_table[(int64_t)b * p.bt_stride + page];
-    return r;
-}
-
-__device__ __forceinline__ TileRows tile_rows_finish(const MlaParams &p, int kvh, const TileRowsRaw &raw)
-{
-    TileRows r;
-    r.nope = (int64_t)raw.blk * p.kn_sblk + (int64_t)raw.row * p.kn_srow + (int64_t)kvh * p.kn_sh;
-    r.rope = (int64_t)raw.blk * p.kr_sblk + (int64_t)raw.row * p.kr_srow + (int64_t)kvh * p.kr_sh;
-    return r;
-}
-
-__device__ __forceinline__ int64_t lane_i64(int64_t v, int src_lane)
-{
-    const int lo = __shfl((int)(v & 0xFFFFFFFFll), src_lane, 64), hi = __shfl((int)(v >> 32), src_lane, 64);
-    return ((int64_t)hi << 32) | (uint32_t)lo;
-}
 
 // issue the LDS-DMA of one KV tile into `buf`; the 72 wave-instructions are dealt round-robin to the waves
 __device__ __forceinline__ void issue_tile(const MlaParams &p, const TileRows &rows, uint8_t *buf, int wave, int nwaves, int lane)
@@ -454,7 +362,74 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-// merge the flash-decoding partials: one wave per (b, head); lane handles 8 of the 512 dims
+// Slow path behind the wide kernel (mla_decode_wide.hip): a sequence whose scores outgrew the fixed softmax reference is
+// recomputed here, one wave per (b, head), with plain loads and fp32 VALU math -- exact two-pass softmax (max first), P
+// rounded to the KV dtype before P.V like the MFMA kernels.  Lane l owns output dims 8 l .. 8 l + 7.  Rare by construction
+// (bf16: a later tile must beat the first by 2^64), so it is written for clarity, not speed.
+template <bool BF16>
+__device__ __forceinline__ float ld_elem(const uint16_t *ptr)
+{
+    if constexpr (BF16) return __uint_as_float((uint32_t)*ptr << 16);
+    else return (float)__builtin_bit_cast(_Float16, *ptr);
+}
+
+template <bool BF16>
+__device__ void mla_recompute_head(const MlaParams &p, int b, int h, int lane)
+{
+    const int kvh = h / p.group, seq_len = p.seq_lens[b];
+    const uint16_t *qrow = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    float qv[9];                                               // lane holds q dims lane + 64 j
+#pragma unroll
+    for (int j = 0; j < 9; ++j) qv[j] = ld_elem<BF16>(qrow + lane + 64 * j);
+    auto key_ptrs = [&](int n, const uint16_t *&kn, const uint16_t *&kr) {
+        const int page = n / p.page_size, row = n - page * p.page_size;
+        const int64_t blk = p.block_table[(int64_t)b * p.bt_stride + page];
+        kn = p.k_nope + blk * p.kn_sblk + (int64_t)row * p.kn_srow + (int64_t)kvh * p.kn_sh;
+        kr = p.k_rope + blk * p.kr_sblk + (int64_t)row * p.kr_srow + (int64_t)kvh * p.kr_sh;
+    };
+    auto score = [&](int n) -> float {
+        const uint16_t *kn, *kr;
+        key_ptrs(n, kn, kr);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += qv[j] * ld_elem<BF16>(kn + lane + 64 * j);
+        d += qv[8] * ld_elem<BF16>(kr + lane);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        return d * p.sm_scale;
+    };
+    float m = -INFINITY;
+    for (int n = 0; n < seq_len; ++n) m = fmaxf(m, score(n));
+    float l = 0.f, o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int n = 0; n < seq_len; ++n) {
+        const float pr = __expf(score(n) - m);
+        l += pr;
+        float prq;                                             // P in the KV dtype
+        if constexpr (BF16) prq = __uint_as_float((uint32_t)cvt_out<true>(pr) << 16);
+        else prq = (float)(_Float16)pr;
+        const uint16_t *kn, *kr;
+        key_ptrs(n, kn, kr);
+        const u32x4 v = *(const u32x4 *)(kn + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint16_t lo = (uint16_t)(v[j] & 0xFFFFu), hi = (uint16_t)(v[j] >> 16);
+            o[2 * j] += prq * ld_elem<BF16>(&lo);
+            o[2 * j + 1] += prq * ld_elem<BF16>(&hi);
+        }
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh + lane * 8;
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        w[j] = (uint32_t)cvt_out<BF16>(o[2 * j] * inv) | ((uint32_t)cvt_out<BF16>(o[2 * j + 1] * inv) << 16);
+    *(u32x4 *)orow = w;
+}
+
+// merge the flash-decoding partials: one wave per (b, head); lane handles 8 of the 512 dims.  With fix_only set (wide
+// kernel launches) it first checks the sequence's hand-off word and takes the slow path above instead.
 template <bool BF16>
 __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
 {
@@ -462,6 +437,12 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
     const int64_t bh = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (bh >= (int64_t)p.batch * p.q_heads) return;
     const int S = p.num_splits;
+    const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
+    if (p.fix_only && p.fix_flags[b * p.kv_heads + h / p.group] == p.fix_epoch) {
+        mla_recompute_head<BF16>(p, b, h, lane);
+        return;
+    }
+    if (S == 1) return;
     const float *ml = p.ws_ml + bh * S * 2;
     float M = -INFINITY;
     for (int s = 0; s < S; ++s) M = fmaxf(M, ml[s * 2]);
@@ -483,7 +464,6 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
         }
     }
     const float inv = L > 0.f ? 1.f / L : 0.f;
-    const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
     uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh + lane * 8;
     u32x4 w;
 #pragma unroll
@@ -498,20 +478,30 @@ using namespace mi_sgl;
 
 extern "C" const char *mi_sgl_kernels_version(void) { return "mi_sgl_kernels 0.1 gfx950"; }
 
+// workspace = [flash-decoding partials (num_splits > 1)] [one flag word per (sequence, kv head) for the wide kernel's hand-off]
+static size_t partial_bytes(int batch, int q_heads, int num_splits)
+{
+    return num_splits <= 1 ? 0 : (size_t)batch * q_heads * num_splits * (kDN + 2) * sizeof(float);
+}
+
 extern "C" size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits)
 {
-    if (num_splits <= 1) return 0;
-    return (size_t)batch * q_heads * num_splits * (kDN + 2) * sizeof(float);
+    if (batch <= 0 || q_heads <= 0) return 0;
+    return partial_bytes(batch, q_heads, num_splits) + (size_t)batch * q_heads * sizeof(uint32_t);   // q_heads >= kv_heads
 }
+
+static bool use_wide(int group) { return group > kHeadsPerBlock && MLA_WAVES == 4; }
 
 extern "C" int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
 {
     if (batch <= 0 || q_heads <= 0 || kv_heads <= 0 || max_seq_len <= 0) return 1;
     const int group = q_heads / kv_heads;
-    const long long wgs = (long long)batch * kv_heads * ((group + kHeadsPerBlock - 1) / kHeadsPerBlock);
-    const int ntiles = (max_seq_len + kTile - 1) / kTile;
+    const int hpb = use_wide(group) ? 128 : kHeadsPerBlock, tile = use_wide(group) ? kWideTile : kTile;
+    const long long wgs = (long long)batch * kv_heads * ((group + hpb - 1) / hpb);
+    const int ntiles = (max_seq_len + tile - 1) / tile;
     int s = (int)((256 + wgs - 1) / wgs);          // at least one workgroup per CU
-    const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;   // keep >= 4 tiles (256 keys) per split
+    const int min_tiles = 256 / tile;                  // keep >= 256 keys per split
+    const int cap = ntiles / min_tiles > 1 ? ntiles / min_tiles : 1;
     if (s > cap) s = cap;
     if (s > 64) s = 64;
     return s < 1 ? 1 : s;
@@ -532,33 +522,44 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
         (kr_stride_row % 8) || (kr_stride_blk % 8) || (kr_stride_h % 8) || (o_stride_h % 8) || (o_stride_b % 8))
         return MI_SGL_EINVAL;      // 16-byte vector accesses
     if (num_splits <= 0) num_splits = mi_mla_decode_num_splits(batch, q_heads, kv_heads, max_seq_len);
-    if (num_splits > 1 && (!workspace || workspace_bytes < mi_mla_decode_workspace(batch, q_heads, num_splits))) return MI_SGL_EINVAL;
+    const bool wide = use_wide(q_heads / kv_heads);
+    if ((num_splits > 1 || wide) && (!workspace || workspace_bytes < mi_mla_decode_workspace(batch, q_heads, num_splits)))
+        return MI_SGL_EINVAL;
     MlaParams p;
     p.q = (const uint16_t *)q, p.k_nope = (const uint16_t *)k_nope, p.k_rope = (const uint16_t *)k_rope;
     p.out = (uint16_t *)out, p.seq_lens = kv_seq_lens, p.block_table = block_table;
     p.ws_o = (float *)workspace;
     p.ws_ml = p.ws_o ? p.ws_o + (size_t)batch * q_heads * num_splits * kDN : nullptr;
+    static uint32_t epoch = 0;
+    p.fix_flags = workspace ? (uint32_t *)((char *)workspace + partial_bytes(batch, q_heads, num_splits)) : nullptr;
+    p.fix_epoch = ++epoch ? epoch : ++epoch;          // a stale word equal to the epoch only causes a redundant recompute
+    p.fix_only = 0;
     p.batch = batch, p.q_heads = q_heads, p.kv_heads = kv_heads, p.group = q_heads / kv_heads, p.page_size = page_size;
     p.bt_stride = bt_stride, p.num_splits = num_splits;
     p.q_sb = q_stride_b, p.q_sh = q_stride_h, p.kn_sblk = kn_stride_blk, p.kn_srow = kn_stride_row, p.kn_sh = kn_stride_h;
     p.kr_sblk = kr_stride_blk, p.kr_srow = kr_stride_row, p.kr_sh = kr_stride_h, p.o_sb = o_stride_b, p.o_sh = o_stride_h;
     p.sm_scale = sm_scale;
     hipStream_t st = (hipStream_t)stream;
-    const int head_blocks = (p.group + kHeadsPerBlock - 1) / kHeadsPerBlock;
-    const int heads_in_block = p.group < kHeadsPerBlock ? p.group : kHeadsPerBlock;
-    const int nwaves = kHeadWaves * kDSplit;      // head waves beyond the group size only help with the DMA
     const long long units = (long long)batch * kv_heads * num_splits;
-    dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
-    const size_t lds = 2 * (size_t)kBufBytes;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)mla_decode_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)mla_decode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int lds1 = 2 * kBufBytes;
+        (void)hipFuncSetAttribute((const void *)mla_decode_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+        (void)hipFuncSetAttribute((const void *)mla_decode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
         attr_set = true;
     }
-    if (dtype == MI_DTYPE_BF16) mla_decode_kernel<true><<<grid, 64 * nwaves, lds, st>>>(p);
-    else mla_decode_kernel<false><<<grid, 64 * nwaves, lds, st>>>(p);
-    if (num_splits > 1) {
+    if (wide) {
+        launch_mla_wide(p, dtype, units, st);
+        p.fix_only = 1;                                // the merge kernel also serves as the slow path for flagged sequences
+    } else {
+        const int head_blocks = (p.group + kHeadsPerBlock - 1) / kHeadsPerBlock;
+        const int nwaves = kHeadWaves * kDSplit;      // head waves beyond the group size only help with the DMA
+        dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
+        const size_t lds = 2 * (size_t)kBufBytes;
+        if (dtype == MI_DTYPE_BF16) mla_decode_kernel<true><<<grid, 64 * nwaves, lds, st>>>(p);
+        else mla_decode_kernel<false><<<grid, 64 * nwaves, lds, st>>>(p);
+    }
+    if (num_splits > 1 || wide) {
         const long long bh = (long long)batch * q_heads;
         const int blocks = (int)((bh + 3) / 4);
         if (dtype == MI_DTYPE_BF16) mla_merge_kernel<true><<<blocks, 256, 0, st>>>(p);

@@ -1,0 +1,408 @@
+// Paged MLA decode, wide variant (see mla_decode.hip for the shared scheme and the reference it replaces:
+// python/sgl_kernel_npu/sgl_kernel_npu/attention/decode_attention.py:5-230).
+// Register plan: the compiler's MFMA selection writes every MFMA result to AGPRs once a kernel needs them, and the 256
+// fp32 output accumulators already fill that half of the register file -- so the S^T = K.Q^T MFMAs are emitted through
+// inline asm with a VGPR destination (16 registers), next to the 144 VGPRs of resident Q^T.  The hazards the compiler
+// cannot see for them are covered by hand: dependent MFMAs on one accumulator issue back to back (hardware interlock),
+// and 18 wait states separate the last one from the first VALU read of S^T.
+#include "mi_sgl_kernels.h"
+#include "mla_common.h"
+
+#ifndef MLAW_QK_AHEAD
+#define MLAW_QK_AHEAD 8
+#endif
+#ifndef MLAW_PV_AHEAD
+#define MLAW_PV_AHEAD 6
+#endif
+
+namespace mi_sgl {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide variant: kv groups of more than 64 heads (DeepSeek DP-attention decode: 128 heads on one latent head, BASELINE C4).
+// One workgroup = ALL 128 heads of a (sequence, KV split): 4 waves x 32 heads on v_mfma_f32_32x32x16 -- twice the FLOPs per
+// LDS operand byte and per issue slot of the 16x16x32 form, and each KV tile enters a CU's LDS once for 128 heads instead
+// of once per 64 (the 64-head kernel above relies on L2 for its second reader; here L2->LDS traffic = HBM traffic).
+//  * registers: 16 accumulator blocks x 16 = 256 AGPRs, Q^T resident in 144 VGPRs; nothing is staged through registers:
+//    tiles of 32 keys arrive by LDS-DMA, one 1-KiB piece per 4 QK k-steps, into a ring of 4 LDS slots (3 tiles = 111 KB in
+//    flight per CU).  Block-table entries travel the same way (4-byte LDS-DMA into a small per-wave ring), so no vector
+//    load result is ever waited on: the only vmcnt wait is the explicit one at the top of a tile, which leaves the two
+//    youngest tiles in flight;
+//  * layouts (lane = (c32 = lane & 31, kg = lane >> 5)): S^T[key, head] = K.Q^T with A = K rows (lane: key c32, dims
+//    16 ks + 8 kg ..+8), B = Q^T (lane: head c32, same dims), C regs r -> key 8 (r>>2) + 4 kg + (r&3); O^T[d, head] += V^T.P^T
+//    with B = P^T straight from the packed C registers and A = V^T via ds_read_b64_tr_b16.  MFMA row m of output block db
+//    is d = 128 (db>>2) + 64 (m>>4) + 16 (db&3) + (m&15), which makes the 32-lane tr-read footprint (4 keys x 2 x 32 B)
+//    tile the 64 banks under the 1056-B row stride; 16-B chunks of rows 8..15 and 24..31 are swapped pairwise (applied on
+//    the DMA source side) so the 16-lane ds_read_b128 groups of the QK operand are conflict-free too.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kT2 = kWideTile, kSlots = 4;
+constexpr int kSlotBytes = kT2 * kNopeStride + kT2 * kRopeStride;      // 37888
+constexpr int kRingBytes = 4 * kSlots * 64 * 4;                        // per-wave block-table rings
+constexpr int kFlagOff = kSlots * kSlotBytes + kRingBytes;            // restart flag (4 B)
+constexpr int kWideLds = kFlagOff + 16;                                // 155664
+
+// S^T chain in VGPRs (see the register plan above)
+template <bool BF16>
+__device__ __forceinline__ void mfma32_first(f32x16 &d, s16x8 a, s16x8 b)
+{
+    if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+template <bool BF16>
+__device__ __forceinline__ void mfma32_acc(f32x16 &d, s16x8 a, s16x8 b)
+{
+    if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_settle(f32x16 &d)      // XDL write -> VALU read of the 16-pass result
+{
+    asm volatile("s_nop 15\n\ts_nop 2" : "+v"(d));
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c)
+{
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+struct WideCtx {
+    const MlaParams *p;
+    int b, kvh, seq_len, wave, lane;
+    uint8_t *lds;
+    uint32_t *ring;        // this wave's [kSlots][64] block ids
+    uint32_t lds_base, ring_addr;      // LDS byte addresses of lds / ring (M0 values for the DMA)
+    int page_shift;                    // log2(page_size) when it is a power of two, else -1 (integer division)
+};
+
+// key of `tile` owned by this lane (lanes 32..63 mirror 0..31), clamped into the sequence
+__device__ __forceinline__ int wide_page(const WideCtx &c, int n)
+{
+    return c.page_shift >= 0 ? n >> c.page_shift : n / c.p->page_size;
+}
+
+__device__ __forceinline__ int wide_key(const WideCtx &c, int tile)
+{
+    int n = tile * kT2 + (c.lane & 31);
+    n = n < c.seq_len ? n : c.seq_len - 1;
+    return n < 0 ? 0 : n;
+}
+
+// LDS-DMA issued through inline asm: the compiler then sees no vector-memory operation in the tile loop and places no
+// vmcnt wait of its own (with the builtin it put an `s_waitcnt vmcnt(0)` in front of the first transpose read of every
+// tile, i.e. the whole fill latency sat between QK and PV).  Ordering is explicit instead: one `s_waitcnt vmcnt(19)` per
+// tile.  M0 carries the (wave-uniform) LDS destination; one wait state separates its write from the load.
+__device__ __forceinline__ uint32_t lds_addr(const void *generic)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)generic;
+}
+__device__ __forceinline__ void dma16_sbase(uint32_t dst, const void *sbase, uint32_t voff)      // lane l: 16 B from sbase + voff -> dst + 16 l
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_vaddr(uint32_t dst, const void *vaddr)                      // lane l: 16 B from its own address
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(vaddr) : "memory", "m0");
+}
+__device__ __forceinline__ void dma4_vaddr(uint32_t dst, const void *vaddr)                       // lane l: 4 B -> dst + 4 l
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(vaddr) : "memory", "m0");
+}
+
+// block-table entry of this lane's key of `tile` -> ring
+__device__ __forceinline__ void wide_issue_rows(const WideCtx &c, int tile)
+{
+    const int page = wide_page(c, wide_key(c, tile));
+    const int32_t *src = c.p->block_table + (int64_t)c.b * c.p->bt_stride + page;
+    dma4_vaddr(c.ring_addr + (uint32_t)((tile & (kSlots - 1)) * 256), src);
+}
+
+__device__ __forceinline__ TileRows wide_rows(const WideCtx &c, int tile)
+{
+    const int n = wide_key(c, tile);
+    const int page = wide_page(c, n), row = n - page * c.p->page_size;
+    const int64_t blk = (int32_t)c.ring[(tile & (kSlots - 1)) * 64 + c.lane];
+    TileRows r;
+    r.nope = blk * c.p->kn_sblk + (int64_t)row * c.p->kn_srow + (int64_t)c.kvh * c.p->kn_sh;
+    r.rope = blk * c.p->kr_sblk + (int64_t)row * c.p->kr_srow + (int64_t)c.kvh * c.p->kr_sh;
+    return r;
+}
+
+// piece idx 0..7: nope row wave + 4 idx (1 KiB); idx 8: rope rows 8 wave .. +8 (8 x 128 B); `slot` = LDS byte address
+__device__ __forceinline__ void wide_issue_piece(const WideCtx &c, const TileRows &rows, uint32_t slot, int idx)
+{
+    if (idx < 8) {
+        const int i = c.wave + 4 * idx;
+        const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), i);
+        const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), i);
+        const uint16_t *src = c.p->k_nope + (((int64_t)hi << 32) | (uint32_t)lo);
+        const int sw = (i >> 3) & 1;                       // rows 8..15, 24..31: 16-B chunk pairs swapped
+        dma16_sbase(slot + (uint32_t)(i * kNopeStride), src, (uint32_t)((c.lane ^ sw) * 16));
+    } else {
+        const int key = c.wave * 8 + (c.lane >> 3);
+        const int chunk = (c.lane & 7) ^ (key & 7);
+        const uint16_t *src = c.p->k_rope + lane_i64(rows.rope, key) + chunk * 8;
+        dma16_vaddr(slot + (uint32_t)(kT2 * kNopeStride + c.wave * 8 * kRopeStride), src);
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mla_decode_wide_kernel(MlaParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c32 = lane & 31, kg = lane >> 5;
+    const int head_blocks = (p.group + 127) / 128;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int unit = (j / head_blocks) * 8 + xcd;
+    const int hblk = j % head_blocks;
+    if (unit >= p.batch * p.kv_heads * p.num_splits) return;
+    const int split = unit % p.num_splits;
+    const int kvh = (unit / p.num_splits) % p.kv_heads;
+    const int b = unit / (p.num_splits * p.kv_heads);
+    const int seq_len = p.seq_lens[b];
+    const int ntiles = (seq_len + kT2 - 1) / kT2;
+    const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
+    const int t_begin = split * tps;
+    const int t_end = min(ntiles, t_begin + tps);
+    const int hg = hblk * 128 + wave * 32 + c32;
+    const bool head_ok = hg < p.group;
+    const bool wave_active = hblk * 128 + wave * 32 < p.group;       // wave-uniform; idle waves still feed the DMA
+    const int head = kvh * p.group + hg;
+    WideCtx cx{&p, b, kvh, seq_len, wave, lane, lds, (uint32_t *)(lds + kSlots * kSlotBytes) + wave * kSlots * 64, 0, 0,
+               (p.page_size & (p.page_size - 1)) == 0 ? __builtin_ctz(p.page_size) : -1};
+    cx.lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    cx.ring_addr = cx.lds_base + (uint32_t)(kSlots * kSlotBytes + wave * kSlots * 256);
+
+    // Q^T fragments: lane (c32, kg) holds q[head][16 ks + 8 kg .. +8]
+    s16x8 qf[36];
+    {
+        const uint16_t *qrow = p.q + (int64_t)b * p.q_sb + (int64_t)(head_ok ? head : 0) * p.q_sh;
+#pragma unroll
+        for (int ks = 0; ks < 36; ++ks) {
+            if (head_ok) qf[ks] = *(const s16x8 *)(qrow + ks * 16 + kg * 8);
+            else qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    volatile uint32_t *flag = (volatile uint32_t *)(lds + kFlagOff);
+    if (threadIdx.x == 0) *flag = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): Q^T is resident; no compiler-visible vector load
+                                                               // is pending when the tile loop starts (see dma16_sbase)
+    const float cs = p.sm_scale * 1.4426950408889634f;
+    // top of a tile: own pieces of tile t and the block ids of tile t+3 have landed (D(t+1), R(t+4), D(t+2) may still
+    // fly); after the barrier tile t is complete in LDS and the slot of tile t-1 is free for tile t+3
+    auto tile_top = [&](int t) -> TileRows {
+        asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+        __syncthreads();
+        wide_issue_rows(cx, t + 5);
+        return wide_rows(cx, t + 3);
+    };
+    // prologue in steady-state issue order: ... D(t) | R(t+3) D(t+1) | R(t+4) D(t+2)
+    auto prologue = [&]() {
+        wide_issue_rows(cx, t_begin);
+        wide_issue_rows(cx, t_begin + 1);
+        wide_issue_rows(cx, t_begin + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const TileRows r = wide_rows(cx, t_begin + d);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wide_issue_piece(cx, r, cx.lds_base + (uint32_t)(((t_begin + d) & (kSlots - 1)) * kSlotBytes), i);
+            if (d < 2) wide_issue_rows(cx, t_begin + 3 + d);
+        }
+    };
+    if (t_begin < t_end) prologue();
+    if (!wave_active) {                                        // idle waves only feed the DMA (same barriers as the others)
+        for (int t = t_begin; t < t_end; ++t) {
+            const TileRows rows3 = tile_top(t);
+            const uint32_t nslot = cx.lds_base + (uint32_t)(((t + 3) & (kSlots - 1)) * kSlotBytes);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wide_issue_piece(cx, rows3, nslot, i);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // pairs with the flag barrier of the active waves
+        return;
+    }
+
+    // ---- S^T[key, head] = K . Q^T : 36 k-steps of 16 dims, operand ring kAhead deep, one DMA piece per 4 k-steps;
+    // returns the tile maximum per head in the scaled log2 domain
+    auto qk = [&](int t, const TileRows &rows3, f32x16 &s) -> float {
+        const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
+        const uint32_t nslot = cx.lds_base + (uint32_t)(((t + 3) & (kSlots - 1)) * kSlotBytes);
+        // (2 ks + kg) ^ sw == 2 ks + (kg ^ sw): the swizzle folds into the lane base, k-steps are immediate offsets
+        const uint8_t *abase = buf + c32 * kNopeStride + ((kg ^ ((c32 >> 3) & 1)) << 4);
+        const uint8_t *rbase = buf + kT2 * kNopeStride + c32 * kRopeStride;
+        auto lda = [&](int ks) -> s16x8 {
+            if (ks < 32) return *(const s16x8 *)(abase + ks * 32);
+            return *(const s16x8 *)(rbase + ((((ks - 32) * 2 + kg) ^ (c32 & 7)) << 4));
+        };
+        constexpr int kAhead = MLAW_QK_AHEAD;
+        s16x8 af[kAhead + 1];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pre = 0; pre < kAhead; ++pre) af[pre] = lda(pre);
+#pragma unroll
+        for (int ks = 0; ks < 36; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + kAhead < 36) af[(ks + kAhead) % (kAhead + 1)] = lda(ks + kAhead);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) mfma32_first<BF16>(s, af[0], qf[0]);
+            else mfma32_acc<BF16>(s, af[ks % (kAhead + 1)], qf[ks]);
+            if ((ks & 3) == 0) wide_issue_piece(cx, rows3, nslot, ks >> 2);
+        }
+        mfma32_settle(s);
+        __builtin_amdgcn_sched_barrier(0);
+        // lane owns head c32 and keys 8 (r>>2) + 4 kg + (r&3); only the tile that crosses seq_len needs the mask
+        if ((t + 1) * kT2 > seq_len) {
+            const int kbase = t * kT2 + 4 * kg;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kbase + 8 * (r >> 2) + (r & 3) >= seq_len) s[r] = -INFINITY;
+        }
+        float tmax = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        return tmax * cs;                                      // sm_scale > 0: max commutes with the scaling
+    };
+
+    // ---- P = exp2(S c - m) against the current reference, l += sum P, O^T[d, head] += V^T . P^T
+    auto softmax_pv = [&](int t, const f32x16 &s) {
+        const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
+        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
+        float psum = 0.f;
+        uint32_t pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cs, nm));
+            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], cs, nm));
+            psum += e0 + e1;
+            pk[r >> 1] = pack2<BF16>(e0, e1);
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run += psum;
+        // k-step kk covers keys 16 kk + {4 kg + r, 8 + 4 kg + r}
+        s16x8 pf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            pf[kk] = __builtin_bit_cast(s16x8, u32x4{pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]});
+        const int c16 = lane & 15, q16 = (lane >> 4) & 1;
+        // rows 8..15 / 24..31 (the `hi` halves) have their 16-B chunk pairs swapped: XOR 16 on the lane's byte offset
+        const uint8_t *vlo = buf + (4 * kg + (c16 >> 2)) * kNopeStride + q16 * 128 + (c16 & 3) * 8;
+        const uint8_t *vhi = buf + (4 * kg + (c16 >> 2) + 8) * kNopeStride + q16 * 128 + (((c16 & 3) * 8) ^ 16);
+        auto ldv = [&](int i, int half) -> s16x4 {              // i = kk * 16 + db
+            const int kk = i >> 4, db = i & 15;
+            const int off = kk * 16 * kNopeStride + (db >> 2) * 256 + (db & 3) * 32;
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)((half ? vhi : vlo) + off));
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const s16x4 lo = ldv(i, 0), hi = ldv(i, 1);
+            const s16x8 a = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc[i & 15] = mfma32<BF16>(a, pf[i >> 4], acc[i & 15]);
+        }
+        constexpr int kPvAhead = MLAW_PV_AHEAD;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kPvAhead, 0);
+#pragma unroll
+        for (int i = 0; i < 32 - kPvAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kPvAhead, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // One softmax reference per head for the WHOLE key range of this workgroup: the first tile's maximum.  No accumulator
+    // is ever rescaled, so the tile loop contains no VALU access to the 256 accumulator registers (with a conditional
+    // rescale in it the register allocator moved them to VGPRs and spilled Q^T).  bf16 P spans the fp32 exponent range: a
+    // later tile may exceed the reference by 2^64 before anything is at risk; fp16 P must stay below 2^15.  If a tile
+    // maximum exceeds the reference by more than kGuard (log2 domain) the sequence is flagged and recomputed by the slow path of
+    // the merge kernel that follows this launch (mla_decode.hip: mla_recompute_head; data-dependent and rare).  out = acc / l is
+    // invariant to the reference.
+    constexpr float kGuard = BF16 ? 64.0f : 11.0f;
+#ifdef MLAW_TIMING
+    uint64_t tm[4] = {0, 0, 0, 0}, c0, c1;
+#define MLAW_TICK(i) c1 = __builtin_amdgcn_s_memtime(); tm[i] += c1 - c0; c0 = c1;
+#else
+#define MLAW_TICK(i)
+#endif
+    for (int t = t_begin; t < t_end; ++t) {
+#ifdef MLAW_TIMING
+        c0 = __builtin_amdgcn_s_memtime();
+#endif
+        const TileRows rows3 = tile_top(t);
+        MLAW_TICK(0)
+        f32x16 s;
+        const float tmax = qk(t, rows3, s);
+        MLAW_TICK(1)
+        if (t == t_begin) m_run = tmax;
+        if (__any(tmax > m_run + kGuard)) *flag = 1;
+        softmax_pv(t, s);
+        MLAW_TICK(2)
+    }
+#ifdef MLAW_TIMING
+    if (lane == 0 && blockIdx.x < 64) {
+        float *dbg = (float *)p.fix_flags + 1024 + (blockIdx.x * 4 + wave) * 4;
+        for (int i = 0; i < 3; ++i) dbg[i] = (float)tm[i] / (float)(t_end - t_begin);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // fills issued past the last tile
+    __syncthreads();
+    if (threadIdx.x == 0 && *flag != 0) p.fix_flags[b * p.kv_heads + kvh] = p.fix_epoch;
+
+    // ---- epilogue: acc[db][4 rg + i] = O^T[d][head c32], d = 128 (db>>2) + 64 (rg>>1) + 16 (db&3) + 8 (rg&1) + 4 kg + i
+    if (!head_ok) return;
+    if (p.num_splits == 1) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + 4 * kg;
+#pragma unroll
+        for (int db = 0; db < 16; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = (db >> 2) * 128 + (rg >> 1) * 64 + (db & 3) * 16 + (rg & 1) * 8;
+                const uint32_t w0 = (uint32_t)cvt_out<BF16>(acc[db][4 * rg + 0] * inv) | ((uint32_t)cvt_out<BF16>(acc[db][4 * rg + 1] * inv) << 16);
+                const uint32_t w1 = (uint32_t)cvt_out<BF16>(acc[db][4 * rg + 2] * inv) | ((uint32_t)cvt_out<BF16>(acc[db][4 * rg + 3] * inv) << 16);
+                *(uint2 *)(orow + d) = uint2{w0, w1};
+            }
+    } else {
+        const int64_t idx = ((int64_t)b * p.q_heads + head) * p.num_splits + split;
+        float *po = p.ws_o + idx * kDN + 4 * kg;
+#pragma unroll
+        for (int db = 0; db < 16; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = (db >> 2) * 128 + (rg >> 1) * 64 + (db & 3) * 16 + (rg & 1) * 8;
+                *(f32x4 *)(po + d) = f32x4{acc[db][4 * rg + 0], acc[db][4 * rg + 1], acc[db][4 * rg + 2], acc[db][4 * rg + 3]};
+            }
+        if (kg == 0) {
+            p.ws_ml[idx * 2 + 0] = m_run;
+            p.ws_ml[idx * 2 + 1] = l_run;
+        }
+    }
+}
+
+
+void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)mla_decode_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+        (void)hipFuncSetAttribute((const void *)mla_decode_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+        attr_set = true;
+    }
+    const int head_blocks = (p.group + 127) / 128;
+    dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
+    if (dtype == MI_DTYPE_BF16) mla_decode_wide_kernel<true><<<grid, 256, kWideLds, st>>>(p);
+    else mla_decode_wide_kernel<false><<<grid, 256, kWideLds, st>>>(p);
+}
+
+}  // namespace mi_sgl

@@ -129,3 +129,27 @@ def test_full_size_c4_vs_fp32():
             p = torch.softmax(s, dim=-1)
             ref = p @ K[:, :512]
             assert torch.allclose(got[b].float(), ref, atol=1e-3, rtol=2 ** -7), (got[b].float() - ref).abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("splits", [1, 2])
+def test_growing_scores_take_the_rescaling_path(dtype, splits):
+    """128-head groups run a kernel that fixes the softmax reference at the first tile; sequences whose later scores
+    outgrow it (here by ~90 nats) are flagged and recomputed by the rescaling kernel.  Mixed batch: one such sequence,
+    one ordinary."""
+    torch.manual_seed(4)
+    B, Hq, S, page = 2, 128, 512, 64
+    maxp = S // page
+    nb = B * maxp
+    q = torch.randn((B, Hq, 576)).to(dtype)
+    kn = torch.randn((nb, page, 1, 512)).to(dtype)
+    kr = torch.randn((nb, page, 1, 64)).to(dtype)
+    bt = torch.arange(nb, dtype=torch.int32).reshape(B, maxp)
+    # sequence 0: keys 300.. point along q[0, 5] (score ~ |q|^2 * sm * 4), earlier keys are ordinary
+    kn[bt[0, 5:].long()] = (4.0 * q[0, 5, :512]).to(dtype)[None, None, None, :] + 0.05 * kn[bt[0, 5:].long()]
+    lens = torch.tensor([S, S - 100], dtype=torch.int32)
+    sm = 1.0 / 576 ** 0.5
+    want = OK.decode_mla(q, kn, kr, lens, bt, sm)
+    got = run_mla(q.cuda(), kn.cuda(), kr.cuda(), lens.cuda(), bt.cuda(), sm, splits).cpu()
+    assert torch.isfinite(got.float()).all()
+    assert torch.allclose(got.float(), want.float(), rtol=2e-2, atol=2e-2), (got.float() - want.float()).abs().max()
