@@ -163,7 +163,7 @@ def mla_section(args):
     except Exception:
         return None
     try:
-        return bench_mla_decode()
+        return bench_mla_decode(steps=50, warmup=30)
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
 
@@ -264,14 +264,19 @@ def main():
             for k in ("dispatch_GBps", "combine_GBps"):
                 if result["xgmi"][k]:
                     result["xgmi"][k.replace("GBps", "frac")] = result["xgmi"][k] / peak
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(T)
-    if world == 1 and not args.no_mla:
+    if world == 1 and not args.no_mla:          # before the CPU leg: the GPU clocks sag while the host works alone
         mla = mla_section(args)
         if mla is not None:
             result["mla_decode"] = mla
-    print(json.dumps(result), flush=True)
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(T)
+    # The JSON line must be the LAST thing on stdout: RCCL prints its version banner to stdout when the communicator
+    # is torn down, so tear down first, print, and leave without running further exit hooks.
+    torch.cuda.synchronize()
     dist.destroy_process_group()
+    sys.stderr.flush()
+    print(json.dumps(result), flush=True)
+    os._exit(0)
 
 
 if __name__ == "__main__":
