@@ -270,13 +270,12 @@ def main():
             result["mla_decode"] = mla
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(T)
-    # The JSON line must be the LAST thing on stdout: RCCL prints its version banner to stdout when the communicator
-    # is torn down, so tear down first, print, and leave without running further exit hooks.
+    # The JSON line should be the last thing on stdout: RCCL prints its version banner to stdout when the communicator
+    # is torn down, so tear down first, then print (normal interpreter exit, so profilers can finalise).
     torch.cuda.synchronize()
     dist.destroy_process_group()
     sys.stderr.flush()
     print(json.dumps(result), flush=True)
-    os._exit(0)
 
 
 if __name__ == "__main__":

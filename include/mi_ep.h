@@ -84,6 +84,9 @@ int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int num_tokens, 
 int mi_ep_signal(uint64_t *const *peer_flags_host, int num_ranks, int my_rank, uint64_t epoch, void *stream);
 int mi_ep_wait(const uint64_t *my_flags, int num_ranks, uint64_t epoch, int32_t *status, int timeout_ms,
                void *stream);
+/* signal then wait in ONE launch (one rank per process: the peers' signals come from their own streams). */
+int mi_ep_signal_wait(uint64_t *const *peer_flags_host, const uint64_t *my_flags, int num_ranks, int my_rank, uint64_t epoch,
+                      int32_t *status, int timeout_ms, void *stream);
 
 /* ---- A2 notify ------------------------------------------------------------------------------
  * Counts all-gather through windows.  Every rank owns `uint64_t notify[W][E+1]` granules
@@ -93,6 +96,19 @@ int mi_ep_notify_post(uint64_t *const *peer_notify_host, int num_ranks, int my_r
                       const int32_t *num_tokens_per_expert, int num_tokens, uint32_t epoch, void *stream);
 int mi_ep_notify_wait(const uint64_t *my_notify, int num_ranks, int num_experts, uint32_t epoch,
                       int32_t *cnt_matrix, int32_t *status, int timeout_ms, void *stream);
+/* Fused forms used by the one-process-per-GPU runtime (fewer launches on the critical path):
+ * notify_post_signal = mi_ep_notify_post + mi_ep_signal(peer_flags, signal_epoch);
+ * notify_wait_tables = mi_ep_notify_wait + mi_ep_wait(my_flags, flag_epoch; skipped when my_flags is NULL) +
+ *                      mi_ep_notify_tables, one workgroup. */
+int mi_ep_notify_post_signal(uint64_t *const *peer_notify_host, uint64_t *const *peer_flags_host, int num_ranks, int my_rank,
+                             int num_experts, const int32_t *num_tokens_per_expert, int num_tokens, uint32_t notify_epoch,
+                             uint64_t signal_epoch, void *stream);
+int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t notify_epoch, const uint64_t *my_flags, uint64_t flag_epoch,
+                             int32_t *cnt_matrix, int num_ranks, int num_experts, int my_rank, int relative_pull,
+                             int32_t *recv_count, int32_t *recv_offset, int32_t *recv_tokens_per_expert,
+                             int32_t *expert_global_offset, int32_t *srcrank_in_expert_offset, int32_t *r_in_srcrank_offset,
+                             int32_t *total_recv_token, int32_t *max_bs, int32_t *pull_offset, int32_t *summary_host,
+                             int32_t *status, int timeout_ms, void *stream);
 /* Derived tables of rank `my_rank` from cnt_matrix [W, E+1] (last column = that rank's token count).
  * All int32: recv_count [L*W] (inclusive cumsum over i = le*W+src), recv_offset [L*W] (sender's
  * exclusive prefix), recv_tokens_per_expert [L], expert_global_offset [L], srcrank_in_expert_offset [L*W],

@@ -307,28 +307,28 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
                                      lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
                                      H, E, (int)rank, qm, my_rows, st)); }
     auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
-    MI_EP_CHECK(mi_ep_notify_post((uint64_t *const *)notify_peers.data(), W, (int)rank, E,
-                                  lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, st));
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
+    MI_EP_CHECK(mi_ep_notify_post_signal((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(), W, (int)rank,
+                                         E, lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, ep, st));
 
-    // receiver side: counts -> tables (+ pinned summary for the host)
-    auto cnt = at::empty({W, E + 1}, i32);
-    MI_EP_CHECK(mi_ep_notify_wait((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), W, E, (uint32_t)ep,
-                                  cnt.data_ptr<int>(), status_dev, timeout_ms, st));
-    auto recv_count = at::empty({E}, i32), recv_offset = at::empty({E}, i32);
-    auto recv_tokens_per_expert = at::empty({L}, i32), expert_global_offset = at::empty({L}, i32);
-    auto srcrank_in_expert_offset = at::empty({E}, i32), r_in_srcrank_offset = at::empty({E}, i32);
-    auto total_recv_token = at::empty({1}, i32), max_bs = at::empty({1}, i32), pull_offset = at::empty({E}, i32);
+    // receiver side: counts + "staged" flags -> tables (+ pinned summary for the host), one launch
+    NotifyTables nt = alloc_notify_tables(W, E, L, i32);
     const bool host_sync = num_worst_tokens <= 0;
     if (host_sync) __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
-    MI_EP_CHECK(mi_ep_notify_tables(cnt.data_ptr<int>(), W, E, (int)rank, 0, recv_count.data_ptr<int>(),
-                                    recv_offset.data_ptr<int>(), recv_tokens_per_expert.data_ptr<int>(),
-                                    expert_global_offset.data_ptr<int>(), srcrank_in_expert_offset.data_ptr<int>(),
-                                    r_in_srcrank_offset.data_ptr<int>(), total_recv_token.data_ptr<int>(),
-                                    max_bs.data_ptr<int>(), pull_offset.data_ptr<int>(), host_sync ? summary_dev : nullptr, st));
-    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), W, ep, status_dev,
-                           timeout_ms, st));
+    MI_EP_CHECK(mi_ep_notify_wait_tables((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
+                                         (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
+                                         nt.cnt.data_ptr<int>(), W, E, (int)rank, 0, nt.recv_count.data_ptr<int>(),
+                                         nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
+                                         nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
+                                         nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
+                                         nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(),
+                                         host_sync ? summary_dev : nullptr, status_dev, timeout_ms, st));
+    at::Tensor &cnt = nt.cnt, &recv_count = nt.recv_count, &recv_offset = nt.recv_offset;
+    at::Tensor &recv_tokens_per_expert = nt.recv_tokens_per_expert, &expert_global_offset = nt.expert_global_offset;
+    at::Tensor &srcrank_in_expert_offset = nt.srcrank_in_expert_offset, &r_in_srcrank_offset = nt.r_in_srcrank_offset;
+    at::Tensor &total_recv_token = nt.total_recv_token, &max_bs = nt.max_bs, &pull_offset = nt.pull_offset;
+    (void)cnt; (void)recv_offset; (void)recv_tokens_per_expert; (void)expert_global_offset; (void)srcrank_in_expert_offset;
+    (void)r_in_srcrank_offset; (void)total_recv_token; (void)max_bs; (void)pull_offset; (void)recv_count;
 
     int64_t trt;
     std::vector<int> num_recv_tokens_per_expert_list;
@@ -392,24 +392,22 @@ Buffer::notify_verify(const at::Tensor &x, const std::optional<at::Tensor> &, co
     const uint64_t ep = ++dispatch_epoch;
     const int par = (int)(ep & 1);
     auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
-    MI_EP_CHECK(mi_ep_notify_post((uint64_t *const *)notify_peers.data(), W, (int)rank, E,
-                                  lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, st));
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
-    auto cnt = at::empty({W, E + 1}, i32);
-    MI_EP_CHECK(mi_ep_notify_wait((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), W, E, (uint32_t)ep,
-                                  cnt.data_ptr<int>(), status_dev, timeout_ms, st));
-    auto recv_count = at::empty({E}, i32), recv_offset = at::empty({E}, i32);
-    auto recv_tokens_per_expert = at::empty({L}, i32), expert_global_offset = at::empty({L}, i32);
-    auto srcrank_in_expert_offset = at::empty({E}, i32), r_in_srcrank_offset = at::empty({E}, i32);
-    auto total_recv_token = at::empty({1}, i32), max_bs = at::empty({1}, i32), pull_offset = at::empty({E}, i32);
-    MI_EP_CHECK(mi_ep_notify_tables(cnt.data_ptr<int>(), W, E, (int)rank, 0, recv_count.data_ptr<int>(),
-                                    recv_offset.data_ptr<int>(), recv_tokens_per_expert.data_ptr<int>(),
-                                    expert_global_offset.data_ptr<int>(), srcrank_in_expert_offset.data_ptr<int>(),
-                                    r_in_srcrank_offset.data_ptr<int>(), total_recv_token.data_ptr<int>(),
-                                    max_bs.data_ptr<int>(), pull_offset.data_ptr<int>(), nullptr, st));
-    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), W, ep, status_dev,
-                           timeout_ms, st));
+    MI_EP_CHECK(mi_ep_notify_post_signal((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(), W, (int)rank,
+                                         E, lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, ep, st));
+    NotifyTables nt = alloc_notify_tables(W, E, L, i32);
+    MI_EP_CHECK(mi_ep_notify_wait_tables((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
+                                         (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
+                                         nt.cnt.data_ptr<int>(), W, E, (int)rank, 0, nt.recv_count.data_ptr<int>(),
+                                         nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
+                                         nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
+                                         nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
+                                         nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(), nullptr, status_dev,
+                                         timeout_ms, st));
+    at::Tensor &cnt = nt.cnt, &recv_count = nt.recv_count, &recv_offset = nt.recv_offset;
+    at::Tensor &recv_tokens_per_expert = nt.recv_tokens_per_expert, &expert_global_offset = nt.expert_global_offset;
+    at::Tensor &srcrank_in_expert_offset = nt.srcrank_in_expert_offset, &r_in_srcrank_offset = nt.r_in_srcrank_offset;
+    at::Tensor &total_recv_token = nt.total_recv_token, &max_bs = nt.max_bs;
     return {cnt, recv_count, recv_offset, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset,
             total_recv_token, max_bs, recv_tokens_per_expert};
 }
@@ -450,9 +448,9 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
     { ProfScope ps_(this, "combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1),
                                    (int)x.size(0), H, K, dst_peers.data(), W, st)); }
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
-    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, ep, status_dev,
-                           timeout_ms, st));
+    MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
+                                  (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, ep,
+                                  status_dev, timeout_ms, st));
     auto combined_x = at::empty({T, H}, x.options());
     { ProfScope ps_(this, "combine_reduce", st); MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                      topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, nullptr, nullptr,
@@ -558,14 +556,32 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     { ProfScope ps_(this, "ll_combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
                                    (int)x.size(0), H, K, dst_peers.data(), W, st)); }
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_signal((uint64_t *const *)flag_peers.data(), W, (int)rank, ep, st));
-    MI_EP_CHECK(mi_ep_wait((const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, ep, status_dev,
-                           timeout_ms, st));
+    MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
+                                  (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, ep,
+                                  status_dev, timeout_ms, st));
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
     auto combined_x = at::empty({T, H}, x.options());
     { ProfScope ps_(this, "ll_combine_reduce", st); MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                      topk_weights.data_ptr<float>(), nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), st)); }
     return {combined_x, std::nullopt, std::function<void()>([] {})};
+}
+
+// the nine int32 tables of one notify exchange carved out of ONE allocation (each at::empty costs ~1-2 us of host time)
+Buffer::NotifyTables Buffer::alloc_notify_tables(int W, int E, int L, const at::TensorOptions &i32)
+{
+    const int64_t n_cnt = (int64_t)W * (E + 1);
+    auto pad = [](int64_t n) { return (n + 3) / 4 * 4; };          // keep every table 16-byte aligned
+    const int64_t total = pad(n_cnt) + 5 * pad(E) + 2 * pad(L) + 2 * 4;
+    at::Tensor buf = at::empty({total}, i32);
+    int64_t off = 0;
+    auto take = [&](int64_t n) { at::Tensor t = buf.narrow(0, off, n); off += pad(n); return t; };
+    NotifyTables nt;
+    nt.cnt = take(n_cnt).view({W, E + 1});
+    nt.recv_count = take(E), nt.recv_offset = take(E), nt.srcrank_in_expert_offset = take(E);
+    nt.r_in_srcrank_offset = take(E), nt.pull_offset = take(E);
+    nt.recv_tokens_per_expert = take(L), nt.expert_global_offset = take(L);
+    nt.total_recv_token = take(1), nt.max_bs = take(1);
+    return nt;
 }
 
 void Buffer::internode_unsupported() const

@@ -173,6 +173,11 @@ private:
     int64_t profile_skip = 0, profile_active = 0, profile_calls = 0;
     bool profiling = false;
     std::string profile_dir;
+    struct NotifyTables {
+        at::Tensor cnt, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset,
+            r_in_srcrank_offset, total_recv_token, max_bs, pull_offset;
+    };
+    NotifyTables alloc_notify_tables(int W, int E, int L, const at::TensorOptions &i32);
     // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
     std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
                                        const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,

@@ -10,6 +10,8 @@
 // separate v_mul_f32 / v_add_f32 (file is built with -ffp-contract=off) to reproduce the reference's
 // Muls + Add ordering bit for bit.  Per-rank HBM traffic: push R*2H read + R*2H write, reduce
 // T*K*2H read + T*2H write.
+#include <stdlib.h>
+
 #include "ep_common.h"
 
 namespace mi_ep {
@@ -231,7 +233,8 @@ extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int
     const int max_segs = (nchunks + kWave - 1) / kWave;
     // enough waves to fill 256 CUs x 8 waves even for decode-size T
     int segs = 1;
-    while (segs < max_segs && (long long)T * segs < 2048) segs <<= 1;
+    static const long long target = getenv("MI_EP_REDUCE_WAVES") ? atoll(getenv("MI_EP_REDUCE_WAVES")) : 2048;
+    while (segs < max_segs && (long long)T * segs < target) segs <<= 1;
     if (segs > max_segs) segs = max_segs;
     const long long waves = (long long)T * segs;
     const int wpb = 4;

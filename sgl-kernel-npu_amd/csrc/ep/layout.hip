@@ -90,10 +90,15 @@ __global__ __launch_bounds__(1024) void layout_scan_kernel(int U, int E, int W, 
         const int e = base + tid;
         int32_t run = 0;
         if (e < E) {
-            for (int u = 0; u < U; ++u) {            // loads are independent of the stores (distinct buffers): they pipeline
-                const int32_t v = unit_hist[(long long)u * E + e];
-                unit_base[(long long)u * E + e] = run;   // the unit's first slot for expert e
-                run += v;
+            for (int u0 = 0; u0 < U; u0 += 16) {      // 16 independent loads in flight, then the short dependent scan
+                int32_t v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = (u0 + j < U) ? unit_hist[(long long)(u0 + j) * E + e] : 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (u0 + j < U) unit_base[(long long)(u0 + j) * E + e] = run;   // the unit's first slot for expert e
+                    run += v[j];
+                }
             }
             num_tokens_per_expert[e] = run;
         }
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(1024) void layout_scan_kernel(int U, int E, int W, 
     }
     for (int r = tid; r < W; r += blockDim.x) {
         int32_t s = 0;
+#pragma unroll 16
         for (int u = 0; u < U; ++u) s += unit_rank[(long long)u * W + r];
         num_tokens_per_rank[r] = s;
     }

@@ -32,14 +32,33 @@ __global__ void wait_kernel(const uint64_t *__restrict__ flags, int W, uint64_t 
 }
 
 __global__ void notify_post_kernel(PeerPtrs peers, int W, int my_rank, int E, const int32_t *__restrict__ cnt,
-                                   int num_tokens, uint32_t epoch)
+                                   int num_tokens, uint32_t epoch, PeerPtrs sig_peers, uint64_t sig_epoch)
 {
-    // grid.x = W destinations, threads sweep the E+1 values
+    // grid.x = W destinations, threads sweep the E+1 values; sig_epoch != 0 also raises this rank's "rows staged" flag
+    // at the destination (the fused form of notify_post + signal: both only need the preceding kernel boundary)
     const int d = blockIdx.x;
     uint64_t *row = (uint64_t *)peers.p[d] + (size_t)my_rank * (E + 1);
     for (int e = threadIdx.x; e <= E; e += blockDim.x) {
         const uint32_t v = (e < E) ? (uint32_t)cnt[e] : (uint32_t)num_tokens;
         sys_store_u64(row + e, ((uint64_t)epoch << 32) | v);
+    }
+    if (sig_epoch && threadIdx.x == 0) sys_store_u64((uint64_t *)sig_peers.p[d] + my_rank, sig_epoch);
+}
+
+// signal + wait in one launch (combine: rows pushed -> tell every owner, then wait for every expert rank)
+__global__ void signal_wait_kernel(PeerPtrs peers, const uint64_t *__restrict__ flags, int W, int my_rank, uint64_t epoch,
+                                   int32_t *status, uint64_t timeout_ticks)
+{
+    const int s = threadIdx.x;
+    if (s >= W) return;
+    sys_store_u64((uint64_t *)peers.p[s] + my_rank, epoch);
+    const uint64_t t0 = ticks_100mhz();
+    while (sys_load_u64(flags + s) < epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        if (ticks_100mhz() - t0 > timeout_ticks) {
+            report_status(status, 1 + s);
+            return;
+        }
     }
 }
 
@@ -65,14 +84,23 @@ __global__ void notify_wait_kernel(const uint64_t *__restrict__ notify, int n, u
 // (reference notify_dispatch.h:386-407,434-450,473-482,553-577,606-615,665-669,715-721,759-780).
 // Everything the serial reference core loops over is staged in LDS first (one coalesced pass over the counts), the
 // per-source sender prefixes are wave reductions, the short dependent scans run out of LDS: ~3 us instead of ~28 us.
-__global__ __launch_bounds__(256) void notify_tables_kernel(
+__device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+__device__ void notify_tables_body(
     const int32_t *__restrict__ cnt /*[W][E+1]*/, int W, int E, int me, int relative_pull,
     int32_t *__restrict__ recv_count, int32_t *__restrict__ recv_offset, int32_t *__restrict__ recv_tokens_per_expert,
     int32_t *__restrict__ expert_global_offset, int32_t *__restrict__ srcrank_in_expert_offset,
     int32_t *__restrict__ r_in_srcrank_offset, int32_t *__restrict__ total_recv_token, int32_t *__restrict__ max_bs,
-    int32_t *__restrict__ pull_offset, int32_t *summary_host)
+    int32_t *__restrict__ pull_offset, int32_t *summary_host, int32_t *sm)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
     const int L = E / W;
     const int LW = L * W;
     int32_t *c = sm;                 // [L*W] counts in idx-i order
@@ -80,14 +108,14 @@ __global__ __launch_bounds__(256) void notify_tables_kernel(
     int32_t *ego = pre + W;          // [L+1]
     int32_t *sie = ego + L + 1;      // [L*W] exclusive scan over src inside one local expert
     int32_t *mbs = sie + LW;         // [1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     // counts of my experts, idx-i order (coalesced over le for a fixed src)
     for (int i = tid; i < LW; i += blockDim.x) {
         const int le = i / W, src = i % W;
         c[i] = cnt[(size_t)src * (E + 1) + me * L + le];
     }
     // sender-side exclusive prefix up to my first expert: one wave per source rank
-    for (int src = wave; src < W; src += 4) {
+    for (int src = wave; src < W; src += nwaves) {
         const int32_t *row = cnt + (size_t)src * (E + 1);
         int32_t s = 0;
         for (int e = lane; e < me * L; e += 64) s += row[e];
@@ -95,23 +123,30 @@ __global__ __launch_bounds__(256) void notify_tables_kernel(
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
         if (lane == 0) pre[src] = s;
     }
-    if (tid == 0) {
+    if (wave == 0) {
         int32_t mb = 0;
-        for (int src = 0; src < W; ++src) mb = max(mb, cnt[(size_t)src * (E + 1) + E]);
-        mbs[0] = mb;
+        for (int src = lane; src < W; src += 64) mb = max(mb, cnt[(size_t)src * (E + 1) + E]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mb = max(mb, __shfl_xor(mb, off, 64));
+        if (lane == 0) mbs[0] = mb;
     }
     __syncthreads();
-    // per source: running sender offset over my experts
-    for (int src = tid; src < W; src += blockDim.x) {
-        int32_t run = pre[src];
-        for (int le = 0; le < L; ++le) {
-            const int i = le * W + src;
-            recv_offset[i] = run;
-            pull_offset[i] = relative_pull ? run - pre[src] : run;
-            run += c[i];
+    // per source: running sender offset over my experts -- one wave per source, 64 experts per step
+    for (int src = wave; src < W; src += nwaves) {
+        int32_t carry = pre[src];
+        for (int le0 = 0; le0 < L; le0 += 64) {
+            const int le = le0 + lane;
+            const int32_t v = le < L ? c[le * W + src] : 0;
+            const int32_t inc = wave_incl_scan(v, lane);
+            if (le < L) {
+                const int32_t run = carry + inc - v;
+                recv_offset[le * W + src] = run;
+                pull_offset[le * W + src] = relative_pull ? run - pre[src] : run;
+            }
+            carry += __shfl(inc, 63, 64);
         }
     }
-    // per local expert: scan over sources
+    // per local expert: scan over sources (W <= 64 values: serial per thread, experts in parallel)
     for (int le = tid; le < L; le += blockDim.x) {
         int32_t s = 0;
         for (int src = 0; src < W; ++src) {
@@ -122,14 +157,16 @@ __global__ __launch_bounds__(256) void notify_tables_kernel(
         recv_tokens_per_expert[le] = s;
     }
     __syncthreads();
-    if (tid == 0) {
-        int32_t run = 0;
-        for (int le = 0; le < L; ++le) {
-            const int32_t v = ego[le];
-            ego[le] = run;
-            run += v;
+    if (wave == 0) {                 // exclusive scan of the per-expert totals, 64 per step
+        int32_t carry = 0;
+        for (int le0 = 0; le0 < L; le0 += 64) {
+            const int le = le0 + lane;
+            const int32_t v = le < L ? ego[le] : 0;
+            const int32_t inc = wave_incl_scan(v, lane);
+            if (le < L) ego[le] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
         }
-        ego[L] = run;
+        if (lane == 0) ego[L] = carry;
     }
     __syncthreads();
     for (int i = tid; i < LW; i += blockDim.x) {
@@ -146,7 +183,7 @@ __global__ __launch_bounds__(256) void notify_tables_kernel(
     if (summary_host) {
         // per-expert counts first, the total last so a polling host sees a complete record
         for (int le = tid; le < L; le += blockDim.x)
-            __hip_atomic_store(summary_host + 2 + le, recv_tokens_per_expert[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(summary_host + 2 + le, ego[le + 1] - ego[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_store(summary_host + 1, mbs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -154,6 +191,58 @@ __global__ __launch_bounds__(256) void notify_tables_kernel(
             __hip_atomic_store(summary_host + 0, ego[L], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void notify_tables_kernel(
+    const int32_t *__restrict__ cnt /*[W][E+1]*/, int W, int E, int me, int relative_pull,
+    int32_t *__restrict__ recv_count, int32_t *__restrict__ recv_offset, int32_t *__restrict__ recv_tokens_per_expert,
+    int32_t *__restrict__ expert_global_offset, int32_t *__restrict__ srcrank_in_expert_offset,
+    int32_t *__restrict__ r_in_srcrank_offset, int32_t *__restrict__ total_recv_token, int32_t *__restrict__ max_bs,
+    int32_t *__restrict__ pull_offset, int32_t *summary_host)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
+    notify_tables_body(cnt, W, E, me, relative_pull, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset,
+                       srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs, pull_offset, summary_host, sm);
+}
+
+// notify_wait + wait + notify_tables in one launch: the workgroup first collects the W*(E+1) count granules and the W
+// "rows staged" flags of this call (bounded spins), then derives the tables from the counts it just wrote.
+__global__ __launch_bounds__(1024) void notify_wait_tables_kernel(
+    const uint64_t *__restrict__ notify, uint32_t notify_epoch, const uint64_t *__restrict__ flags, uint64_t flag_epoch,
+    int32_t *__restrict__ cnt, int W, int E, int me, int relative_pull, int32_t *__restrict__ recv_count,
+    int32_t *__restrict__ recv_offset, int32_t *__restrict__ recv_tokens_per_expert, int32_t *__restrict__ expert_global_offset,
+    int32_t *__restrict__ srcrank_in_expert_offset, int32_t *__restrict__ r_in_srcrank_offset,
+    int32_t *__restrict__ total_recv_token, int32_t *__restrict__ max_bs, int32_t *__restrict__ pull_offset,
+    int32_t *summary_host, int32_t *status, uint64_t timeout_ticks)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
+    const uint64_t t0 = ticks_100mhz();
+    const int n = W * (E + 1);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        uint64_t g;
+        while (((g = sys_load_u64(notify + i)) >> 32) != notify_epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                report_status(status, 1000 + i);
+                g = 0;
+                break;
+            }
+        }
+        cnt[i] = (int32_t)(uint32_t)g;
+    }
+    if (flags && threadIdx.x < W) {
+        while (sys_load_u64(flags + threadIdx.x) < flag_epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                report_status(status, 1 + threadIdx.x);
+                break;
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    notify_tables_body(cnt, W, E, me, relative_pull, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset,
+                       srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs, pull_offset, summary_host, sm);
 }
 
 }  // namespace mi_ep
@@ -197,7 +286,30 @@ extern "C" int mi_ep_notify_post(uint64_t *const *peer_notify_host, int W, int m
     if (fill_peers(pp, (const void *const *)peer_notify_host, W) || my_rank < 0 || my_rank >= W || E <= 0 ||
         !num_tokens_per_expert || epoch == 0)
         return MI_EP_EINVAL;
-    notify_post_kernel<<<W, 256, 0, (hipStream_t)stream>>>(pp, W, my_rank, E, num_tokens_per_expert, num_tokens, epoch);
+    notify_post_kernel<<<W, 256, 0, (hipStream_t)stream>>>(pp, W, my_rank, E, num_tokens_per_expert, num_tokens, epoch, pp, 0);
+    return launch_status();
+}
+
+extern "C" int mi_ep_notify_post_signal(uint64_t *const *peer_notify_host, uint64_t *const *peer_flags_host, int W, int my_rank,
+                                        int E, const int32_t *num_tokens_per_expert, int num_tokens, uint32_t notify_epoch,
+                                        uint64_t signal_epoch, void *stream)
+{
+    PeerPtrs pp, sp;
+    if (fill_peers(pp, (const void *const *)peer_notify_host, W) || fill_peers(sp, (const void *const *)peer_flags_host, W) ||
+        my_rank < 0 || my_rank >= W || E <= 0 || !num_tokens_per_expert || notify_epoch == 0 || signal_epoch == 0)
+        return MI_EP_EINVAL;
+    notify_post_kernel<<<W, 256, 0, (hipStream_t)stream>>>(pp, W, my_rank, E, num_tokens_per_expert, num_tokens, notify_epoch, sp,
+                                                           signal_epoch);
+    return launch_status();
+}
+
+extern "C" int mi_ep_signal_wait(uint64_t *const *peer_flags_host, const uint64_t *my_flags, int W, int my_rank, uint64_t epoch,
+                                 int32_t *status, int timeout_ms, void *stream)
+{
+    PeerPtrs pp;
+    if (fill_peers(pp, (const void *const *)peer_flags_host, W) || !my_flags || !status || my_rank < 0 || my_rank >= W)
+        return MI_EP_EINVAL;
+    signal_wait_kernel<<<1, kWave, 0, (hipStream_t)stream>>>(pp, my_flags, W, my_rank, epoch, status, ms_to_ticks(timeout_ms));
     return launch_status();
 }
 
@@ -226,5 +338,24 @@ extern "C" int mi_ep_notify_tables(const int32_t *cnt_matrix, int W, int E, int 
                                                               recv_offset, recv_tokens_per_expert, expert_global_offset,
                                                               srcrank_in_expert_offset, r_in_srcrank_offset,
                                                               total_recv_token, max_bs, pull_offset, summary_host);
+    return launch_status();
+}
+
+extern "C" int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t notify_epoch, const uint64_t *my_flags,
+                                        uint64_t flag_epoch, int32_t *cnt_matrix, int W, int E, int my_rank, int relative_pull,
+                                        int32_t *recv_count, int32_t *recv_offset, int32_t *recv_tokens_per_expert,
+                                        int32_t *expert_global_offset, int32_t *srcrank_in_expert_offset,
+                                        int32_t *r_in_srcrank_offset, int32_t *total_recv_token, int32_t *max_bs,
+                                        int32_t *pull_offset, int32_t *summary_host, int32_t *status, int timeout_ms, void *stream)
+{
+    if (!my_notify || !cnt_matrix || !status || notify_epoch == 0 || W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048 ||
+        my_rank < 0 || my_rank >= W)
+        return MI_EP_EINVAL;
+    const int L = E / W;
+    const size_t lds = (size_t)(2 * L * W + W + L + 2) * sizeof(int32_t);
+    notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
+        my_notify, notify_epoch, my_flags, flag_epoch, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
+        recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,
+        pull_offset, summary_host, status, ms_to_ticks(timeout_ms));
     return launch_status();
 }

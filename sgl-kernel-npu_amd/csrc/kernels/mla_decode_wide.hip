@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // top of a tile: own pieces of tile t and the block ids of tile t+3 have landed (D(t+1), R(t+4), D(t+2) may still
     // fly); after the barrier tile t is complete in LDS and the slot of tile t-1 is free for tile t+3
     auto tile_top = [&](int t) -> TileRows {
+#ifndef MLAW_NO_PIECES
         asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+#endif
         __syncthreads();
         wide_issue_rows(cx, t + 5);
         return wide_rows(cx, t + 3);
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0) mfma32_first<BF16>(s, af[0], qf[0]);
             else mfma32_acc<BF16>(s, af[ks % (kAhead + 1)], qf[ks]);
+#ifndef MLAW_NO_PIECES
             if ((ks & 3) == 0) wide_issue_piece(cx, rows3, nslot, ks >> 2);
+#endif
         }
         mfma32_settle(s);
         __builtin_amdgcn_sched_barrier(0);
