@@ -130,7 +130,8 @@ int mi_ep_notify_tables(const int32_t *cnt_matrix, int num_ranks, int num_expert
  *   row = payload | {scale, t, k, my_rank}.  x [T,H] bf16, topk_idx [T,K] int64/int32.
  * pull: for every output row r < total (= recv_count[L*W-1], read on device): find segment i,
  *   copy row pull_offset[i] + j of src_base[src] into recv_x[r] / recv_x_scales[r] / recv_src_idx[3r..].
- *   `rows_hint` only sizes the grid (>= total).  recv_x_scales may be NULL for bf16. */
+ *   `rows_hint` sizes the grid and bounds the rows written (the capacity of the output buffers; normally >= total).
+ *   recv_x_scales may be NULL for bf16. */
 int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                          const int32_t *send_data_offset, int num_tokens, int num_topk, int hidden,
                          int num_experts, int my_rank, int quant_mode, void *rows, void *stream);

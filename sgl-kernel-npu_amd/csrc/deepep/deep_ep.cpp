@@ -330,6 +330,27 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     (void)cnt; (void)recv_offset; (void)recv_tokens_per_expert; (void)expert_global_offset; (void)srcrank_in_expert_offset;
     (void)r_in_srcrank_offset; (void)total_recv_token; (void)max_bs; (void)pull_offset; (void)recv_count;
 
+    // Receive buffers + the pull launch.  The exact row count reaches the host only through the pinned summary word;
+    // to keep the GPU busy across that round trip the pull is launched FIRST into buffers sized from the previous call
+    // (+25 %), and the results are returned as exact-size prefixes once the host knows the count.  A call that receives
+    // more than the guess simply pulls again into exact-size buffers (the kernel never writes past `rows_hint`).
+    at::Tensor expandx_out, dynamic_scales_out, expand_idx_out;
+    auto src_peers = peer_ptrs((size_t)(region(kDispatch, ep) - window));
+    auto launch_pull = [&](int64_t rows_alloc) {
+        expandx_out = use_quant ? at::empty({rows_alloc, H}, at::dtype(at::kChar).device(dev)) : at::empty({rows_alloc, H}, x.options());
+        dynamic_scales_out = at::empty({rows_alloc}, at::dtype(at::kFloat).device(dev));
+        expand_idx_out = at::empty({rows_alloc * 3}, i32);
+        ProfScope ps_(this, "dispatch_pull", st);
+        MI_EP_CHECK(mi_ep_dispatch_pull((const void *const *)src_peers.data(), recv_count.data_ptr<int>(), pull_offset.data_ptr<int>(), W,
+                                        L, H, qm, (int)rows_alloc, expandx_out.data_ptr(),
+                                        use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr, expand_idx_out.data_ptr<int>(), st));
+    };
+    static const bool speculate = get_value_from_env("DEEPEP_SPECULATIVE_RECV", 1) != 0;
+    int64_t guess = 0;
+    if (host_sync && speculate && last_recv_rows > 0) {
+        guess = last_recv_rows + last_recv_rows / 4 + 256;
+        launch_pull(guess);
+    }
     int64_t trt;
     std::vector<int> num_recv_tokens_per_expert_list;
     if (host_sync) {
@@ -344,22 +365,22 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
             run = (type == 0) ? run + c : c;
             num_recv_tokens_per_expert_list.push_back(run);
         }
+        last_recv_rows = trt;
     } else {
         // DeepEP's graph-friendly mode: worst-case sized outputs, no host sync, empty list (buffer.py:337-338,356-358)
         trt = num_worst_tokens;
         real_max_bs = std::max<int64_t>(real_max_bs, num_worst_tokens);
     }
     const int64_t rows = trt == 0 ? 1 : trt;      // deep_ep.cpp:327-328
-    at::Tensor expandx_out = use_quant ? at::empty({rows, H}, at::dtype(at::kChar).device(dev)) : at::empty({rows, H}, x.options());
-    at::Tensor dynamic_scales_out = at::empty({rows}, at::dtype(at::kFloat).device(dev));
-    at::Tensor expand_idx_out = at::empty({rows * 3}, i32);
+    if (guess >= rows) {
+        expandx_out = expandx_out.narrow(0, 0, rows);
+        dynamic_scales_out = dynamic_scales_out.narrow(0, 0, rows);
+        expand_idx_out = expand_idx_out.narrow(0, 0, rows * 3);
+    } else {
+        launch_pull(rows);
+    }
     std::optional<at::Tensor> recv_topk_idx = at::empty({trt, K}, topk_idx->options());       // allocated, never written
     std::optional<at::Tensor> recv_topk_weights = at::empty({trt, K}, topk_weights->options());  // (deep_ep.cpp:371-374)
-    auto src_peers = peer_ptrs((size_t)(region(kDispatch, ep) - window));
-    { ProfScope ps_(this, "dispatch_pull", st); MI_EP_CHECK(mi_ep_dispatch_pull((const void *const *)src_peers.data(), recv_count.data_ptr<int>(),
-                                    pull_offset.data_ptr<int>(), W, L, H, qm, (int)trt, expandx_out.data_ptr(),
-                                    use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr,
-                                    expand_idx_out.data_ptr<int>(), st)); }
     if (dispatch_wait_recv_cost_stats.has_value()) {
         EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->scalar_type() == at::kInt);
         EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->dim() == 1 and dispatch_wait_recv_cost_stats->size(0) == num_ranks);

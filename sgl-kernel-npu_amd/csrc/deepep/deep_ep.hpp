@@ -173,6 +173,7 @@ private:
     int64_t profile_skip = 0, profile_active = 0, profile_calls = 0;
     bool profiling = false;
     std::string profile_dir;
+    int64_t last_recv_rows = 0;        // rows received by the previous host-synchronised dispatch (sizes the speculative pull)
     struct NotifyTables {
         at::Tensor cnt, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset,
             r_in_srcrank_offset, total_recv_token, max_bs, pull_offset;

@@ -189,12 +189,12 @@ constexpr int kPullRowsPerBlock = kPullWaves * kPullRowsPerWave;
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int seg_capacity,
     int W, int LW, int payload_bytes /*H or 2H*/, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
-    int32_t *__restrict__ recv_src_idx)
+    int32_t *__restrict__ recv_src_idx, int row_capacity)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
     for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
     __syncthreads();
-    const int total = cum[LW - 1];
+    const int total = min(cum[LW - 1], row_capacity);      // never write past the caller's buffers
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
     const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
@@ -303,7 +303,7 @@ extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32
     if (blocks > 256 * 16) blocks = 256 * 16;
     const size_t lds = (size_t)L * W * sizeof(int32_t);
     pull_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
-        pp, recv_count, pull_offset, 0, W, L * W, payload, (uint8_t *)recv_x, recv_x_scales, recv_src_idx);
+        pp, recv_count, pull_offset, 0, W, L * W, payload, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint);
     return launch_status();
 }
 
@@ -442,6 +442,6 @@ extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_co
     if (blocks < 1) blocks = 1;
     pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, s>>>(pp, layout_range, nullptr, max_tokens, W, L * W,
                                                                          payload, (uint8_t *)packed_recv_x,
-                                                                         packed_recv_x_scales, src_info);
+                                                                         packed_recv_x_scales, src_info, L * W * max_tokens);
     return launch_status();
 }

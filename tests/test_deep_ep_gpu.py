@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
     (4, 33, 7168, 8, 256, 0.0, True, "default", 3),
     (4, 40, 1024, 8, 64, 0.3, False, "default", 2),
     (8, 16, 2048, 8, 256, 0.1, True, "default", 3),
+    (2, 1200, 512, 4, 16, 0.0, True, "default", 3),       # 300 tokens, then 1200 twice: speculative receive miss, then hit
     (1, 64, 1024, 4, 16, 0.1, True, "alltoall", 1),
 ])
 def test_buffer_multi_process_one_gpu(cfg):
