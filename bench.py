@@ -108,7 +108,7 @@ def kernel_bytes(name, T, K, H, n_pairs, n_recv):
 
 
 PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatch_pull": "pull_kernel",
-                    "combine_push": "combine_push_kernel", "combine_reduce": "combine_reduce_kernel<false>"}
+                    "combine_push": "combine_push_kernel", "combine_reduce": "combine_reduce_kernel<false, 8>"}
 
 
 def pmc_traffic(kernel):
@@ -163,7 +163,11 @@ def mla_section(args):
     except Exception:
         return None
     try:
-        return bench_mla_decode(steps=50, warmup=30)
+        r = bench_mla_decode(steps=50, warmup=30)
+        parts = [pmc_traffic(k) for k in ("mla_decode_wide_kernel<true>", "mla_merge_kernel<true>")]
+        if all(v is not None for v in parts):
+            r["roofline"]["traffic"] = sum(parts)      # both launches of one decode step (split partials included)
+        return r
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
 
