@@ -187,14 +187,16 @@ int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint3
  *   w_scale f32 [L, two_i] permuted alike.  out f32 [rows, two_i/2]: up * silu(gate), gate/up = (i32 * w_scale[col]) * a_scale[row].
  * rowquant: q = int8 rint((v * 127) * (1 / rowmax)), scale = rowmax / 127 for rows < *total_rows_dev.
  * gemm2: a int8 [rows, inter] with scales, w int8 [L, hidden, inter], w_scale f32 [L, hidden]; out bf16 [rows, hidden].
- * hidden, inter multiples of 128; two_i multiple of 128. */
+ * hidden, inter multiples of 128; two_i multiple of 128.  rows_per_expert_hint: expected rows per local expert (0 = unknown);
+ * it only selects the tile shape (<= 96: 64-row tiles for decode-size groups, else 256-row tiles). */
 int mi_ep_moe_gemm1_swiglu(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale,
                            const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap, int hidden,
-                           int two_i, float *out, void *stream);
+                           int two_i, float *out, int rows_per_expert_hint, void *stream);
 int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_cap, int inter, int8_t *q, float *scale,
                        void *stream);
 int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,
-                    int cum_stride, int num_local_experts, int rows_cap, int inter, int hidden, void *out_bf16, void *stream);
+                    int cum_stride, int num_local_experts, int rows_cap, int inter, int hidden, void *out_bf16,
+                    int rows_per_expert_hint, void *stream);
 
 #ifdef __cplusplus
 }

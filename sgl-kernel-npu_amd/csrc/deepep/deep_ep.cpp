@@ -661,14 +661,16 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     at::Tensor sc2 = at::empty({M}, at::dtype(at::kFloat).device(dev));
     at::Tensor y = at::empty({M, H}, at::dtype(at::kBFloat16).device(dev));
     const int32_t *cum = layout_range.data_ptr<int>();
+    // expected rows per local expert under balanced routing (all ranks send about T tokens x K): picks the GEMM tile shape
+    const int rows_hint = (int)std::max<int64_t>(1, (int64_t)T * K * W / std::max(1, E));
     { ProfScope ps_(this, "moe_gemm1_swiglu", st);
       MI_EP_CHECK(mi_ep_moe_gemm1_swiglu((const int8_t *)rx.data_ptr(), rs.data_ptr<float>(), (const int8_t *)w1.data_ptr(),
-                                         s1.data_ptr<float>(), cum, W, L, M, H, N1, v.data_ptr<float>(), st)); }
+                                         s1.data_ptr<float>(), cum, W, L, M, H, N1, v.data_ptr<float>(), rows_hint, st)); }
     { ProfScope ps_(this, "moe_rowquant", st);
       MI_EP_CHECK(mi_ep_moe_rowquant(v.data_ptr<float>(), cum + (L * W - 1), M, I, (int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), st)); }
     { ProfScope ps_(this, "moe_gemm2", st);
       MI_EP_CHECK(mi_ep_moe_gemm2((const int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), (const int8_t *)w2.data_ptr(),
-                                  s2.data_ptr<float>(), cum, W, L, M, I, H, y.data_ptr(), st)); }
+                                  s2.data_ptr<float>(), cum, W, L, M, I, H, y.data_ptr(), rows_hint, st)); }
     auto comb = low_latency_combine(y, expert_ids, topk_weights, src_info, layout_range, num_max_dispatch_tokens_per_rank,
                                     num_experts, std::get<2>(disp), false, false, false, none);
     return {std::get<0>(comb), layout_range};

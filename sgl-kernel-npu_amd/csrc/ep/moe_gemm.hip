@@ -6,17 +6,28 @@
 // and GEMM2 int8[R,I] x int8[I,H] with per-token x per-channel dequant to bf16.
 //
 // MI355X design: weights are consumed as [expert][N][K] (K contiguous), activations as [row][K]: both MFMA operands are
-// 16-byte K-slices, so tiles go global -> registers -> LDS with 16-B accesses only, XOR-swizzled (chunk ^ (row & 7)) so the
-// ds_read_b128 of 16 rows x 128-B stride is conflict-free.  Workgroup tile 128(M) x 128(N) x 128(K bytes), 4 waves stacked in M
-// (32 x 128 each: 2 x 8 MFMA tiles = 64 accumulator registers) so a wave owns BOTH the gate (columns 0-63) and up (64-127)
-// halves of a fusion tile and the SwiGLU epilogue needs no exchange.  Expert row ranges come from the device-side
-// cumulative counts, so the same launch serves low-latency (no host sync) and normal mode; idle tile slots exit at once.
-// Bound: MFMA int8 for prefill-size groups (2*M*N*K ops), HBM (weights once: L*N*K bytes) for decode-size groups.
+// 16-byte K-slices.  What limits a grouped GEMM of this shape on this part is the operand stream into the CUs (L2 -> LDS
+// saturated near 47 GB/s per CU / 12 TB/s per chip in every variant tried), so the workgroup tile is as large as the LDS
+// allows: 256(M) x 256(N) x 64(K bytes) = 3.9 KB of operands per int8 MOP, 16 waves in a 4 x 4 grid of 64 x 64 wave tiles
+// (4 x 4 MFMA tiles = 64 accumulator registers, ~110 VGPRs -> 4 waves per SIMD, which is what hides the LDS latency).
+// Tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 rows x 64 B per wave-instruction, no staging registers),
+// XOR swizzle chunk ^ ((row >> 2) & 3) applied on the source side so the 16-row ds_read_b128 footprints are
+// conflict-free, into a ring of 4 stages (4 x 32 KB), three k-tiles in flight, one barrier per k-tile.
+// History: 128x128x128 tiles staged through VGPRs with one tile of look-ahead ran at 1.22 POPS (every k-tile waited out a
+// global-load latency); 128x256 with a 3-stage DMA ring 1.44; + dedicated loader waves 1.73 (MFMA waves then waited on the
+// loaders: bandwidth, not issue); this version trades the loaders for a third less traffic.
+// A SwiGLU fusion tile is 128 columns = 64 gate | 64 up (weights pre-permuted, reference test_fused_deep_moe.py:75-86); a wave
+// takes 32 gate columns and the matching 32 up columns, so the dequant + SwiGLU epilogue needs no exchange.
+// Expert row ranges come from the device-side cumulative counts, so the same launch serves low-latency (no host sync) and
+// normal mode; idle tile slots exit at once.
+// Bound: operand stream / MFMA int8 for prefill-size groups (2*M*N*K ops), HBM (weights once: L*N*K bytes) for decode.
 #include "ep_common.h"
 
 namespace mi_ep {
 
-constexpr int BM = 128, BN = 128, BK = 128;
+constexpr int BN = 256, BK = 64;
+constexpr int kStages = 4;
+constexpr int kGemmThreads = 1024;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
@@ -29,13 +40,32 @@ struct GemmArgs {
     void *out;                // mode 0: float [M_cap, N/2]; mode 1: bf16 [M_cap, N]
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 4); }
+// byte offset of 16-B chunk `chunk` (0..3) of row `row` inside a [rows][64 B] tile
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void grouped_gemm_i8_kernel(GemmArgs p)
+// LDS-DMA through inline asm (the compiler then places no vmcnt wait of its own; ordering is the explicit vmcnt below).
+// Lane l moves 16 B from its own address to dst + 16 l; M0 carries the wave-uniform LDS destination.
+__device__ __forceinline__ void dma16(uint32_t dst, const void *vaddr)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // 2 x (A 16 KB + B 16 KB)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(vaddr) : "memory");
+}
+
+#ifdef GEMM_TIMING
+__device__ float g_gemm_dbg[256];
+#endif
+
+// MT = MFMA row tiles per wave: 4 -> 256-row workgroup tile (prefill-size groups), 1 -> 64-row tile (decode-size groups:
+// the weights stream once either way, the small tile just stops multiplying padding).
+template <int MODE, int MT>
+__global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs p)
+{
+    constexpr int BM = 64 * MT;
+    constexpr int kStageBytes = (BM + BN) * BK;
+    constexpr int kAPieces = BM / 16;                 // DMA instructions (16 rows x 64 B) for the A tile of a stage
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x 64 B + B 16 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    const int wm = wave & 3, wn = wave >> 2;
     // which (expert, m-tile) is tile slot blockIdx.y?
     int e = -1, row0 = 0, rows = 0;
     {
@@ -56,82 +86,114 @@ __global__ __launch_bounds__(256) void grouped_gemm_i8_kernel(GemmArgs p)
     }
     if (e < 0) return;
     const int n0 = blockIdx.x * BN;
-    const int8_t *wbase = p.w + ((size_t)e * p.N + n0) * p.K;
+    const int8_t *wbase = p.w + (size_t)e * p.N * p.K;
     const int8_t *abase = p.a + (size_t)row0 * p.K;
 
-    i32x4 acc[2][8];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
-
-    // staging: thread t moves chunks c = t + 256*i (i < 4) of each tile: row = c / 8, 16-B chunk = c % 8
-    u32x4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, ch = c & 7;
-            ra[i] = (r < rows) ? *(const u32x4 *)(abase + (size_t)r * p.K + k0 + ch * 16) : u32x4{0, 0, 0, 0};
-            rb[i] = *(const u32x4 *)(wbase + (size_t)r * p.K + k0 + ch * 16);
-        }
-    };
-    auto lstore = [&](uint8_t *buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, ch = c & 7;
-            *(u32x4 *)(buf + swz(r, ch)) = ra[i];
-            *(u32x4 *)(buf + BM * BK + swz(r, ch)) = rb[i];
-        }
-    };
+    // ---- DMA plan: 32 instructions per stage (A: 16 x 16 rows, B: 16 x 16 rows); wave w issues A piece w and B piece w
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
+    const int8_t *srcA, *srcB;
+    {
+        const int row = 16 * wave + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);  // swizzle on the source side
+        srcA = abase + (size_t)min(row, rows - 1) * p.K + chunk * 16;             // rows past the group: any valid row
+        srcB = wbase + (size_t)min(n0 + row, p.N - 1) * p.K + chunk * 16;
+    }
     const int nk = p.K / BK;
-    gload(0);
-    lstore(lds);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        uint8_t *buf = lds + (kt & 1) * (BM * BK + BN * BK);
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+    auto issue_stage = [&](int kt) {
+        const int kc = min(kt, nk - 1) * BK;              // past the end: a harmless refill keeps the vmcnt arithmetic uniform
+        const uint32_t sbase = lds_base + (uint32_t)((kt % kStages) * kStageBytes + wave * 1024);
+        if (wave < kAPieces) dma16(sbase, srcA + kc);     // wave-uniform
+        dma16(sbase + (uint32_t)(BM * BK), srcB + kc);
+    };
+
+    i32x4 acc[MT][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            i32x4 af[2], bf[8];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                af[mt] = *(const i32x4 *)(buf + swz(wave * 32 + mt * 16 + c16, ks * 4 + g));
+        for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+
+    // LDS byte offsets of this lane's operand fragments inside a stage (k-step = the whole 64-B row: chunk g)
+    int aoff[MT], boff[4];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) bf[nt] = *(const i32x4 *)(buf + BM * BK + swz(nt * 16 + c16, ks * 4 + g));
+    for (int mt = 0; mt < MT; ++mt) aoff[mt] = swz(wm * 16 * MT + mt * 16 + c16, g);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-        }
-        if (kt + 1 < nk) lstore(lds + ((kt + 1) & 1) * (BM * BK + BN * BK));
-        __syncthreads();
+    for (int nt = 0; nt < 4; ++nt) {
+        int brow;
+        if (MODE == 0) brow = (wn >> 1) * 128 + (nt >> 1) * 64 + (wn & 1) * 32 + (nt & 1) * 16 + c16;   // nt 0,1 gate; 2,3 up
+        else brow = wn * 64 + nt * 16 + c16;
+        boff[nt] = BM * BK + swz(brow, g);
     }
 
-    // ---- epilogue: lane holds C[row = wave*32 + mt*16 + 4g + r][col = nt*16 + c16]
+#ifdef GEMM_TIMING
+    uint64_t tw = 0, tc = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+#endif
+    issue_stage(0);
+    issue_stage(1);
+    issue_stage(2);
+    for (int kt = 0; kt < nk; ++kt) {
+#ifdef GEMM_TIMING
+        c0 = __builtin_amdgcn_s_memtime();
+#endif
+        // own pieces of stage kt landed; those of stages kt+1, kt+2 may still fly (2 per stage, 1 for waves without an A piece)
+        if (wave < kAPieces) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __syncthreads();                                    // stage kt complete; the slot of stage kt-1 is free
+#ifdef GEMM_TIMING
+        c1 = __builtin_amdgcn_s_memtime(); tw += c1 - c0; c0 = c1;
+#endif
+        issue_stage(kt + 3);
+        const uint8_t *buf = lds + (kt % kStages) * kStageBytes;
+        i32x4 af[MT], bf[4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const i32x4 *)(buf + aoff[mt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = *(const i32x4 *)(buf + boff[nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+#ifdef GEMM_TIMING
+        c1 = __builtin_amdgcn_s_memtime(); tc += c1 - c0;
+#endif
+    }
+#ifdef GEMM_TIMING
+    if (lane == 0 && blockIdx.x == 3 && blockIdx.y < 4) {
+        g_gemm_dbg[(blockIdx.y * 16 + wave) * 2 + 0] = (float)tw / nk;
+        g_gemm_dbg[(blockIdx.y * 16 + wave) * 2 + 1] = (float)tc / nk;
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills issued past the last k-tile
+
+    // ---- epilogue: lane holds C[row = wm*16*MT + mt*16 + 4g + r][n-tile nt, col c16]
     const float *ws = p.w_scale + (size_t)e * p.N + n0;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int lr = wave * 32 + mt * 16 + 4 * g + r;
+            const int lr = wm * 16 * MT + mt * 16 + 4 * g + r;
             if (lr >= rows) continue;
             const size_t grow = (size_t)row0 + lr;
             const float as = p.a_scale[grow];
             if (MODE == 0) {
-                // fusion tile: columns 0-63 gate, 64-127 up (weights pre-permuted, reference test_fused_deep_moe.py:75-86)
-                float *orow = (float *)p.out + grow * (size_t)(p.N / 2) + blockIdx.x * (BN / 2);
+                // wave = fusion tile f (128 columns: 64 gate | 64 up), half h: gate columns 32 h .. +32 and their up columns
+                const int f = wn >> 1, h = wn & 1;
+                if (n0 + f * 128 >= p.N) continue;
+                float *orow = (float *)p.out + grow * (size_t)(p.N / 2) + (size_t)(blockIdx.x * 2 + f) * 64 + h * 32;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const float gate = ((float)acc[mt][nt][r] * ws[nt * 16 + c16]) * as;
-                    const float up = ((float)acc[mt][nt + 4][r] * ws[64 + nt * 16 + c16]) * as;
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int gc = f * 128 + h * 32 + nt * 16 + c16;
+                    const float gate = ((float)acc[mt][nt][r] * ws[gc]) * as;
+                    const float up = ((float)acc[mt][nt + 2][r] * ws[gc + 64]) * as;
                     orow[nt * 16 + c16] = up * (gate / (1.0f + __expf(-gate)));
                 }
             } else {
-                uint16_t *orow = (uint16_t *)p.out + grow * (size_t)p.N + n0;
+                uint16_t *orow = (uint16_t *)p.out + grow * (size_t)p.N + n0 + wn * 64;
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt)
-                    orow[nt * 16 + c16] = (uint16_t)f32_to_bf16_rne(((float)acc[mt][nt][r] * ws[nt * 16 + c16]) * as);
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int col = wn * 64 + nt * 16 + c16;
+                    if (n0 + col < p.N) orow[nt * 16 + c16] = (uint16_t)f32_to_bf16_rne(((float)acc[mt][nt][r] * ws[col]) * as);
+                }
             }
         }
 }
@@ -167,25 +229,39 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const float *__restrict__
 
 using namespace mi_ep;
 
+template <int MODE, int MT>
+static void gemm_launch_one(const GemmArgs &p, void *stream)
+{
+    constexpr int BM = 64 * MT;
+    constexpr int lds = kStages * (BM + BN) * BK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)grouped_gemm_i8_kernel<MODE, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M_cap + BM - 1) / BM + p.L);
+    grouped_gemm_i8_kernel<MODE, MT><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(p);
+}
+
 static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *cum,
-                       int cum_stride, int L, int M_cap, int K, int N, void *out, void *stream)
+                       int cum_stride, int L, int M_cap, int K, int N, void *out, int rows_per_expert_hint, void *stream)
 {
     if (!a || !a_scale || !w || !w_scale || !cum || !out || L <= 0 || L > 1024 || M_cap <= 0 || K <= 0 || K % BK || N <= 0 ||
-        N % BN || cum_stride <= 0)
+        N % 128 || cum_stride <= 0)
         return MI_EP_EINVAL;
     GemmArgs p{a, a_scale, w, w_scale, cum, cum_stride, L, M_cap, K, N, out};
-    dim3 grid(N / BN, (M_cap + BM - 1) / BM + L);
-    const size_t lds = 2 * (size_t)(BM * BK + BN * BK);
-    if (mode == 0) grouped_gemm_i8_kernel<0><<<grid, 256, lds, (hipStream_t)stream>>>(p);
-    else grouped_gemm_i8_kernel<1><<<grid, 256, lds, (hipStream_t)stream>>>(p);
+    const bool small = rows_per_expert_hint > 0 && rows_per_expert_hint <= 96;      // decode-size groups
+    if (mode == 0) { if (small) gemm_launch_one<0, 1>(p, stream); else gemm_launch_one<0, 4>(p, stream); }
+    else { if (small) gemm_launch_one<1, 1>(p, stream); else gemm_launch_one<1, 4>(p, stream); }
     return launch_status();
 }
 
 extern "C" int mi_ep_moe_gemm1_swiglu(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale,
                                       const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap, int hidden,
-                                      int two_i, float *out, void *stream)
+                                      int two_i, float *out, int rows_per_expert_hint, void *stream)
 {
-    return gemm_launch(0, a, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, hidden, two_i, out, stream);
+    return gemm_launch(0, a, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, hidden, two_i, out,
+                       rows_per_expert_hint, stream);
 }
 
 extern "C" int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_cap, int inter, int8_t *q, float *scale,
@@ -198,7 +274,15 @@ extern "C" int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev,
 
 extern "C" int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale,
                                const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap, int inter,
-                               int hidden, void *out_bf16, void *stream)
+                               int hidden, void *out_bf16, int rows_per_expert_hint, void *stream)
 {
-    return gemm_launch(1, a, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, inter, hidden, out_bf16, stream);
+    return gemm_launch(1, a, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, inter, hidden, out_bf16,
+                       rows_per_expert_hint, stream);
 }
+
+#ifdef GEMM_TIMING
+extern "C" int mi_ep_gemm_dbg(float *host128)
+{
+    return (int)hipMemcpyFromSymbol(host128, HIP_SYMBOL(mi_ep::g_gemm_dbg), 128 * sizeof(float));
+}
+#endif
