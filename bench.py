@@ -163,7 +163,7 @@ def mla_section(args):
     except Exception:
         return None
     try:
-        r = bench_mla_decode(steps=50, warmup=30)
+        r = bench_mla_decode(steps=100, warmup=300)      # MFMA-heavy: let the clocks settle (tens of ms)
         parts = [pmc_traffic(k) for k in ("mla_decode_wide_kernel<true>", "mla_merge_kernel<true>")]
         if all(v is not None for v in parts):
             r["roofline"]["traffic"] = sum(parts)      # both launches of one decode step (split partials included)
