@@ -177,6 +177,13 @@ int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint3
                            void *packed_recv_x, float *packed_recv_x_scales, int64_t *packed_recv_count,
                            int32_t *src_info, int32_t *layout_range, int32_t *status, int timeout_ms,
                            void *stream);
+/* ll_post_counts fused into the receive (one rank per process): the counts workgroup posts this rank's counts, collects
+ * everybody's, scans them; the packing kernel follows.  Two launches instead of three. */
+int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int my_rank, const void *my_rows,
+                       const uint64_t *my_counts, uint32_t epoch, int num_ranks, int num_local_experts, int max_tokens, int hidden,
+                       int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales,
+                       int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int32_t *status, int timeout_ms,
+                       void *stream);
 
 /* ---- A8 fused_deep_moe building blocks (reference: aclnnFusedDeepMoe, csrc/deepep/deep_ep.cpp:1223;
  * kernel csrc/deepep/ops/op_kernel/fused_deep_moe.h:336-427) -------------------------------------------------------

@@ -537,9 +537,8 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
                                        lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm,
                                        row_peers.data(), st)); }
     auto cnt_peers = peer_ptrs((size_t)(kOffLLCounts + par * kLLCountsParityBytes));
-    MI_EP_CHECK(mi_ep_ll_post_counts((uint64_t *const *)cnt_peers.data(), lay.num_tokens_per_expert.data_ptr<int>(), E, W,
-                                     (int)rank, (uint32_t)ep, st));
-    { ProfScope ps_(this, "ll_dispatch_recv", st); MI_EP_CHECK(mi_ep_ll_dispatch_recv(region(kLLDispatch, ep), (const uint64_t *)(window + kOffLLCounts + par * kLLCountsParityBytes),
+    { ProfScope ps_(this, "ll_dispatch_recv", st); MI_EP_CHECK(mi_ep_ll_post_recv((uint64_t *const *)cnt_peers.data(), lay.num_tokens_per_expert.data_ptr<int>(), (int)rank,
+                                       region(kLLDispatch, ep), (const uint64_t *)(window + kOffLLCounts + par * kLLCountsParityBytes),
                                        (uint32_t)ep, W, L, MT, H, qm, count_type, packed_recv_x.data_ptr(),
                                        qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(),
                                        (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(),

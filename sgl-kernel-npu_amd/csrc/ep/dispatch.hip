@@ -186,14 +186,12 @@ constexpr int kPullWaves = 4;
 constexpr int kPullRowsPerWave = 4;
 constexpr int kPullRowsPerBlock = kPullWaves * kPullRowsPerWave;
 
-__global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
-    PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int seg_capacity,
-    int W, int LW, int payload_bytes /*H or 2H*/, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
-    int32_t *__restrict__ recv_src_idx, int row_capacity)
+// rows [0, total) of the receive buffers from the (local expert, source) segments described by the inclusive cumsum in LDS
+__device__ __forceinline__ void pull_body(
+    const PeerPtrs &srcs, const int32_t *cum /*LDS [LW]*/, const int32_t *__restrict__ pull_offset, int seg_capacity, int W, int LW,
+    int payload_bytes /*H or 2H*/, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales, int32_t *__restrict__ recv_src_idx,
+    int row_capacity)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
-    for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
-    __syncthreads();
     const int total = min(cum[LW - 1], row_capacity);      // never write past the caller's buffers
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
@@ -240,6 +238,18 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
             }
         }
     }
+}
+
+
+__global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
+    PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int seg_capacity,
+    int W, int LW, int payload_bytes, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
+    int32_t *__restrict__ recv_src_idx, int row_capacity)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
+    for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
+    __syncthreads();
+    pull_body(srcs, cum, pull_offset, seg_capacity, W, LW, payload_bytes, recv_x, recv_scales, recv_src_idx, row_capacity);
 }
 
 }  // namespace mi_ep
@@ -322,16 +332,24 @@ __global__ void ll_post_counts_kernel(PeerPtrs peers, const int32_t *__restrict_
 }
 
 // one workgroup: wait for the L*W count granules, inclusive cumsum in idx-i order, per-expert counts
-__global__ __launch_bounds__(256) void ll_counts_kernel(const uint64_t *__restrict__ granules, uint32_t epoch, int L, int W,
+__global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, const int32_t *__restrict__ my_counts_out /*[E] or null*/,
+                                                        int my_rank, const uint64_t *__restrict__ granules, uint32_t epoch, int L, int W,
                                                         int count_type, int32_t *__restrict__ layout_range,
                                                         int64_t *__restrict__ packed_recv_count, int32_t *status,
                                                         uint64_t timeout_ticks)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t c[];   // [L*W] then per-expert sums [L]
-    const int LW = L * W;
-    int32_t *per_e = c + LW;
+    extern __shared__ __attribute__((aligned(16))) int32_t c[];   // [L*W] counts -> inclusive cumsum, then [4] wave totals
+    const int LW = L * W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t *wave_tot = c + LW;
+    // optional fused post (one rank per process): this rank's per-expert counts to every peer, then collect everybody's
+    if (my_counts_out) {
+        for (int i = tid; i < LW; i += blockDim.x) {
+            const int d = i / L, le = i % L;
+            sys_store_u64((uint64_t *)count_peers.p[d] + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)my_counts_out[d * L + le]);
+        }
+    }
     const uint64_t t0 = ticks_100mhz();
-    for (int i = threadIdx.x; i < LW; i += blockDim.x) {
+    for (int i = tid; i < LW; i += blockDim.x) {
         uint64_t g;
         while (((g = sys_load_u64(granules + i)) >> 32) != epoch) {
             __builtin_amdgcn_s_sleep(4);
@@ -344,23 +362,30 @@ __global__ __launch_bounds__(256) void ll_counts_kernel(const uint64_t *__restri
         c[i] = (int32_t)(uint32_t)g;
     }
     __syncthreads();
-    for (int le = threadIdx.x; le < L; le += blockDim.x) {
-        int32_t s = 0;
-        for (int src = 0; src < W; ++src) s += c[le * W + src];
-        per_e[le] = s;
+    // inclusive scan of c[0..LW): each thread owns a contiguous chunk, wave scan of the chunk sums, then wave offsets
+    const int per = (LW + blockDim.x - 1) / blockDim.x;
+    const int b0 = tid * per, b1 = min(LW, b0 + per);
+    int32_t sum = 0;
+    for (int i = b0; i < b1; ++i) sum += c[i];
+    int32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t n = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += n;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int32_t run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    for (int i = b0; i < b1; ++i) {
+        run += c[i];
+        c[i] = run;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t run = 0;
-        int64_t cum = 0;
-        for (int le = 0; le < L; ++le) {
-            for (int src = 0; src < W; ++src) {
-                run += c[le * W + src];
-                layout_range[le * W + src] = run;
-            }
-            cum = (count_type == 0) ? cum + per_e[le] : (int64_t)per_e[le];
-            packed_recv_count[le] = cum;
-        }
+    for (int i = tid; i < LW; i += blockDim.x) layout_range[i] = c[i];
+    for (int le = tid; le < L; le += blockDim.x) {
+        const int32_t end = c[(le + 1) * W - 1], beg = le ? c[le * W - 1] : 0;
+        packed_recv_count[le] = (count_type == 0) ? (int64_t)end : (int64_t)(end - beg);
     }
 }
 
@@ -428,7 +453,8 @@ extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_co
         return MI_EP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const uint64_t ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
-    ll_counts_kernel<<<1, 256, (size_t)(L * W + L) * 4, s>>>(my_counts, epoch, L, W, count_type, layout_range,
+    PeerPtrs none{};
+    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(none, nullptr, 0, my_counts, epoch, L, W, count_type, layout_range,
                                                             packed_recv_count, status, ticks);
     PeerPtrs pp;
     for (int i = 0; i < W; ++i) pp.p[i] = const_cast<void *>(my_rows);
@@ -443,5 +469,37 @@ extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_co
     pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, s>>>(pp, layout_range, nullptr, max_tokens, W, L * W,
                                                                          payload, (uint8_t *)packed_recv_x,
                                                                          packed_recv_x_scales, src_info, L * W * max_tokens);
+    return launch_status();
+}
+
+extern "C" int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int my_rank,
+                                  const void *my_rows, const uint64_t *my_counts, uint32_t epoch, int W, int L, int max_tokens, int H,
+                                  int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales,
+                                  int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int32_t *status,
+                                  int timeout_ms, void *stream)
+{
+    if (!peer_counts_host || !num_tokens_per_expert || !my_rows || !my_counts || !packed_recv_x || !packed_recv_count || !src_info ||
+        !layout_range || !status || W <= 0 || W > MI_EP_MAX_RANKS || my_rank < 0 || my_rank >= W || L <= 0 || L * W > 2048 || H <= 0 ||
+        H % 16 || max_tokens <= 0 || epoch == 0)
+        return MI_EP_EINVAL;
+    PeerPtrs cp, pp;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_counts_host[i]) return MI_EP_EINVAL;
+        cp.p[i] = peer_counts_host[i];
+        pp.p[i] = const_cast<void *>(my_rows);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
+    // only ONE workgroup ever spins on the peers (a chip full of spinning workgroups would starve whatever else has to run
+    // for the posts to happen when several processes share the GPU); the packing kernel follows on the stream
+    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(cp, num_tokens_per_expert, my_rank, my_counts, epoch, L, W, count_type,
+                                                            layout_range, packed_recv_count, status, ticks);
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    long long blocks = ((long long)L * W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, s>>>(pp, layout_range, nullptr, max_tokens, W, L * W, payload,
+                                                                         (uint8_t *)packed_recv_x, packed_recv_x_scales, src_info,
+                                                                         L * W * max_tokens);
     return launch_status();
 }
