@@ -108,7 +108,12 @@ int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t notify_epoch, c
                              int32_t *recv_count, int32_t *recv_offset, int32_t *recv_tokens_per_expert,
                              int32_t *expert_global_offset, int32_t *srcrank_in_expert_offset, int32_t *r_in_srcrank_offset,
                              int32_t *total_recv_token, int32_t *max_bs, int32_t *pull_offset, int32_t *summary_host,
-                             int32_t *status, int timeout_ms, void *stream);
+                             int32_t *status, int timeout_ms, int32_t *wait_cost_stats /*[W] or NULL: += us waited per source*/,
+                             void *stream);
+/* Diagnose helpers (reference dispatch_wait_recv_cost_stats / combine_send_cost_stats, buffer.py:343-345,500-501): a device
+ * timestamp (100 MHz ticks) and `stats[i] += microseconds since *t_start` for i < n.  Launched only when stats are requested. */
+int mi_ep_timestamp(uint64_t *dst, void *stream);
+int mi_ep_elapsed_add(int32_t *stats, int n, const uint64_t *t_start, void *stream);
 /* Derived tables of rank `my_rank` from cnt_matrix [W, E+1] (last column = that rank's token count).
  * All int32: recv_count [L*W] (inclusive cumsum over i = le*W+src), recv_offset [L*W] (sender's
  * exclusive prefix), recv_tokens_per_expert [L], expert_global_offset [L], srcrank_in_expert_offset [L*W],

@@ -312,6 +312,12 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
                                          E, lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, ep, st));
 
     // receiver side: counts + "staged" flags -> tables (+ pinned summary for the host), one launch
+    int32_t *wait_stats = nullptr;
+    if (dispatch_wait_recv_cost_stats.has_value()) {
+        EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->scalar_type() == at::kInt and dispatch_wait_recv_cost_stats->is_contiguous());
+        EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->dim() == 1 and dispatch_wait_recv_cost_stats->size(0) == num_ranks);
+        wait_stats = dispatch_wait_recv_cost_stats->data_ptr<int>();
+    }
     NotifyTables nt = alloc_notify_tables(W, E, L, i32);
     const bool host_sync = num_worst_tokens <= 0;
     if (host_sync) __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
@@ -322,7 +328,7 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
                                          nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
                                          nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
                                          nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(),
-                                         host_sync ? summary_dev : nullptr, status_dev, timeout_ms, st));
+                                         host_sync ? summary_dev : nullptr, status_dev, timeout_ms, wait_stats, st));
     at::Tensor &cnt = nt.cnt, &recv_count = nt.recv_count, &recv_offset = nt.recv_offset;
     at::Tensor &recv_tokens_per_expert = nt.recv_tokens_per_expert, &expert_global_offset = nt.expert_global_offset;
     at::Tensor &srcrank_in_expert_offset = nt.srcrank_in_expert_offset, &r_in_srcrank_offset = nt.r_in_srcrank_offset;
@@ -424,7 +430,7 @@ Buffer::notify_verify(const at::Tensor &x, const std::optional<at::Tensor> &, co
                                          nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
                                          nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
                                          nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(), nullptr, status_dev,
-                                         timeout_ms, st));
+                                         timeout_ms, nullptr, st));
     at::Tensor &cnt = nt.cnt, &recv_count = nt.recv_count, &recv_offset = nt.recv_offset;
     at::Tensor &recv_tokens_per_expert = nt.recv_tokens_per_expert, &expert_global_offset = nt.expert_global_offset;
     at::Tensor &srcrank_in_expert_offset = nt.srcrank_in_expert_offset, &r_in_srcrank_offset = nt.r_in_srcrank_offset;
@@ -465,9 +471,19 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
     hipStream_t st = cur_stream();
     const uint64_t ep = ++combine_epoch;
     auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
+    // diagnose (opt-in): every send of this rank is complete when the push kernel ends, so each destination is charged the
+    // push duration (device timestamps before / after; only launched when the caller passes the stats tensor)
+    at::Tensor t_start;
+    if (combine_send_cost_stats.has_value()) {
+        EP_HOST_ASSERT(combine_send_cost_stats->is_contiguous());
+        t_start = at::empty({1}, at::dtype(at::kLong).device(x.device()));
+        MI_EP_CHECK(mi_ep_timestamp((uint64_t *)t_start.data_ptr(), st));
+    }
     // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
     { ProfScope ps_(this, "combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1),
                                    (int)x.size(0), H, K, dst_peers.data(), W, st)); }
+    if (combine_send_cost_stats.has_value())
+        MI_EP_CHECK(mi_ep_elapsed_add(combine_send_cost_stats->data_ptr<int>(), W, (const uint64_t *)t_start.data_ptr(), st));
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
     MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
                                   (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, ep,

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(
     int32_t *__restrict__ recv_offset, int32_t *__restrict__ recv_tokens_per_expert, int32_t *__restrict__ expert_global_offset,
     int32_t *__restrict__ srcrank_in_expert_offset, int32_t *__restrict__ r_in_srcrank_offset,
     int32_t *__restrict__ total_recv_token, int32_t *__restrict__ max_bs, int32_t *__restrict__ pull_offset,
-    int32_t *summary_host, int32_t *status, uint64_t timeout_ticks)
+    int32_t *summary_host, int32_t *status, uint64_t timeout_ticks, int32_t *__restrict__ wait_cost_stats)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t sm[];
     const uint64_t t0 = ticks_100mhz();
@@ -238,6 +238,9 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(
                 break;
             }
         }
+        // diagnose: microseconds this rank waited for source rank `threadIdx.x`'s rows, accumulated across calls
+        // (reference cam_moe_dispatch_normal.h:580-602)
+        if (wait_cost_stats) atomicAdd(wait_cost_stats + threadIdx.x, (int32_t)((ticks_100mhz() - t0) / 100));
     }
     __threadfence();
     __syncthreads();
@@ -346,7 +349,8 @@ extern "C" int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t noti
                                         int32_t *recv_count, int32_t *recv_offset, int32_t *recv_tokens_per_expert,
                                         int32_t *expert_global_offset, int32_t *srcrank_in_expert_offset,
                                         int32_t *r_in_srcrank_offset, int32_t *total_recv_token, int32_t *max_bs,
-                                        int32_t *pull_offset, int32_t *summary_host, int32_t *status, int timeout_ms, void *stream)
+                                        int32_t *pull_offset, int32_t *summary_host, int32_t *status, int timeout_ms,
+                                        int32_t *wait_cost_stats, void *stream)
 {
     if (!my_notify || !cnt_matrix || !status || notify_epoch == 0 || W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048 ||
         my_rank < 0 || my_rank >= W)
@@ -356,6 +360,30 @@ extern "C" int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t noti
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
         my_notify, notify_epoch, my_flags, flag_epoch, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
         recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,
-        pull_offset, summary_host, status, ms_to_ticks(timeout_ms));
+        pull_offset, summary_host, status, ms_to_ticks(timeout_ms), wait_cost_stats);
+    return launch_status();
+}
+
+// ---- diagnose helpers (only launched when the caller passes a stats tensor) -------------------------------------------
+namespace mi_ep {
+__global__ void timestamp_kernel(uint64_t *dst) { *dst = ticks_100mhz(); }
+__global__ void elapsed_add_kernel(int32_t *stats, int n, const uint64_t *t_start)
+{
+    const int32_t us = (int32_t)((ticks_100mhz() - *t_start) / 100);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(stats + i, us);
+}
+}  // namespace mi_ep
+
+extern "C" int mi_ep_timestamp(uint64_t *dst, void *stream)
+{
+    if (!dst) return MI_EP_EINVAL;
+    mi_ep::timestamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(dst);
+    return launch_status();
+}
+
+extern "C" int mi_ep_elapsed_add(int32_t *stats, int n, const uint64_t *t_start, void *stream)
+{
+    if (!stats || !t_start || n <= 0) return MI_EP_EINVAL;
+    mi_ep::elapsed_add_kernel<<<1, 64, 0, (hipStream_t)stream>>>(stats, n, t_start);
     return launch_status();
 }

@@ -136,9 +136,13 @@ def _gpu_buffer(rank, world, port, cfg):
         tw = torch.from_numpy(ws[rank]).cuda()
         want = O.normal_dispatch(xs, idxs, E, quant)
         per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+        # diagnose tensors (reference buffer.py:343-345,500-501): accumulated microseconds per rank, filled when passed
+        wait_stats = torch.zeros(W, dtype=torch.int32, device="cuda") if it == iters - 1 else None
+        send_stats = torch.zeros(W, dtype=torch.int32, device="cuda") if it == iters - 1 else None
         recv_x, _, _, lst, handle, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
                                                     num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
-                                                    quant_mode="int8" if quant else None)
+                                                    quant_mode="int8" if quant else None,
+                                                    dispatch_wait_recv_cost_stats=wait_stats)
         n = want[rank].total_recv
         assert lst == want[rank].num_recv_tokens_per_expert_list, (lst, want[rank].num_recv_tokens_per_expert_list)
         assert np.array_equal(handle[3].cpu().numpy()[:3 * n], want[rank].recv_src_idx[:3 * n])
@@ -152,8 +156,12 @@ def _gpu_buffer(rank, world, port, cfg):
             y = recv_x
         ys = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) if quant else w.recv_x for w in want]
         comb_want = O.combine(ys, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)
-        out, _, _ = buf.combine(y, handle)
+        out, _, _ = buf.combine(y, handle, combine_send_cost_stats=send_stats)
         assert np.array_equal(torch_to_bits(out), comb_want[rank]), "combine mismatch"
+        if wait_stats is not None and strategy == "default":
+            ws_, ss_ = wait_stats.cpu(), send_stats.cpu()
+            assert (ws_ >= 0).all() and (ws_ < 60_000_000).all() and (ss_ >= 0).all() and (ss_ < 60_000_000).all()
+            assert int(ss_.min()) == int(ss_.max())             # every destination is charged the push duration
         # low latency
         MT = T + W
         llw = O.low_latency_dispatch(xs, idxs, MT, E, quant)
