@@ -75,9 +75,11 @@ __device__ __forceinline__ int sat_i8(float v)
 // q = clamp(floor(out / scale + 0.5), -128, 127)      (swiglu_quant.py:49-72; note floor(x+0.5), not rint)
 // bytes per row: 2I*2 read + I (+4) written.  One wave per row, I <= 4096.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSwigluItems = 8;   // 8 x (64 lanes x 8 elements) = 4096 columns
+constexpr int kSwigluItems = 8;   // at most 8 x (64 lanes x 8 elements) = 4096 output columns per row
 
-template <bool BF16, bool I64>
+// ITEMS = 16-byte items per lane (1, 2, 4 or 8): the row's SwiGLU values stay in registers between the max and the
+// quantisation pass, so the instantiation is picked by row width to keep the footprint (and occupancy) tight.
+template <bool BF16, bool I64, int ITEMS>
 __global__ __launch_bounds__(256) void swiglu_quant_kernel(const uint16_t *__restrict__ x, const void *__restrict__ group_list,
                                                           int num_groups, int group_list_type, int rows, int I,
                                                           int need_quant, int do_limit, float limit, void *__restrict__ out,
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const uint16_t *__res
     if (row >= rows || row >= total) return;
     const u32x4 *xr = (const u32x4 *)(x + row * 2 * (long long)I);
     const int nitems = I / 8;
-    float v[kSwigluItems][8];
+    float v[ITEMS][8];
     float amax = 0.f;
 #pragma unroll
-    for (int it = 0; it < kSwigluItems; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         const int item = it * 64 + lane;
         if (item < nitems) {
             float a[8], b[8];
@@ -111,7 +113,9 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const uint16_t *__res
             unpack8<BF16>(xr[nitems + item], b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float gate = a[j] * (1.0f / (1.0f + __expf(-a[j])));
+                // v_exp + v_rcp (1 ulp each) instead of an IEEE division: the reference test allows |dq| <= 1 on < 2 % of the
+                // elements (test_swiglu_quant.py:45-54), and the two divisions per element made this kernel VALU-bound
+                float gate = a[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-a[j]));
                 float up = b[j];
                 if (do_limit) {
                     gate = fminf(gate, limit);
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const uint16_t *__res
     if (!need_quant) {
         u32x4 *orow = (u32x4 *)((uint16_t *)out + row * (long long)I);
 #pragma unroll
-        for (int it = 0; it < kSwigluItems; ++it) {
+        for (int it = 0; it < ITEMS; ++it) {
             const int item = it * 64 + lane;
             if (item < nitems) orow[item] = pack8<BF16>(v[it]);
         }
@@ -133,16 +137,17 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const uint16_t *__res
     }
     amax = wave_max(amax);
     const float s = amax / 127.0f;
+    const float inv_s = s > 0.f ? 127.0f / amax : 0.f;
     if (lane == 0) scale[row] = s;
     u32x2 *orow = (u32x2 *)((int8_t *)out + row * (long long)I);
 #pragma unroll
-    for (int it = 0; it < kSwigluItems; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         const int item = it * 64 + lane;
         if (item < nitems) {
             uint32_t w[2] = {0, 0};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float q = (s > 0.f) ? floorf(v[it][j] / s + 0.5f) : 0.f;
+                float q = floorf(v[it][j] * inv_s + 0.5f);
                 q = fminf(fmaxf(q, -128.f), 127.f);
                 w[j >> 2] |= ((uint32_t)((int)q & 0xFF)) << (8 * (j & 3));
             }
@@ -296,6 +301,11 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_kernel(
 // so a wave handles 64*8/head_dim heads.  The RoPE partner (p +- rope_dim/2) lives rope_dim/16 lanes away and is fetched
 // with one shuffle per element; the RMS reduction is an xor-shuffle tree inside the head's lane group.
 // Needs rope_dim % 16 == 0 (neox) or % 8 == 0 (interleaved); otherwise the scalar kernel above runs.
+// Each wave handles kVecUnroll groups of 64*8/head_dim heads; ALL loads of all groups (x, norm weight / bias, sin, cos) are
+// issued before any arithmetic, so a lane has up to 5 x kVecUnroll independent 16-byte loads in flight instead of a chain of
+// three dependent round trips per kilobyte (the first version ran at 37 % of HBM).
+constexpr int kVecUnroll = 4;
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ sin, const uint16_t *__restrict__ cos, int rows, int q_hidden,
@@ -309,80 +319,101 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     const int q_heads = q_hidden / head_dim, kv_heads = kv_hidden / head_dim;
     const int heads_total = q_heads + 2 * kv_heads;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long hglobal = wid * heads_per_wave + lane / gl;
-    const long long row = hglobal / heads_total;
-    const int h = (int)(hglobal % heads_total);
     const int j = lane % gl;                           // chunk of 8 elements inside the head
-    const bool active = row < rows;
     const long long total_hidden = (long long)q_hidden + 2ll * kv_hidden;
-    float x[8];
-    if (active) unpack8<BF16>(*(const u32x4 *)(qkv + row * total_hidden + (long long)h * head_dim + j * 8), x);
-    else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = 0.f;
-    }
-    const bool is_v = h >= q_heads + kv_heads, is_q = h < q_heads;
-    if (has_norm) {
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-        for (int off = gl >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-        if (active && !is_v) {
-            const float rstd = 1.0f / sqrtf(ss / (float)head_dim + eps);
-            float wv[8];
-            unpack8<BF16>(*(const u32x4 *)((is_q ? qw : kw) + j * 8), wv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = (x[e] * rstd) * wv[e];
-            if (qb) {
-                float bv[8];
-                unpack8<BF16>(*(const u32x4 *)((is_q ? qb : kb) + j * 8), bv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = x[e] + bv[e];
-            }
-        }
-    }
     const int half = rope_dim >> 1;
-    float o[8];
-    if (neox) {
-        const int dl = half >> 3;                      // partner distance in lanes
-        const bool lower = (j * 8) < half;
-        const int partner = lower ? lane + dl : lane - dl;
-        float px[8];
+    const bool roped = j * 8 < rope_dim;
+    const u32x4 zero4 = u32x4{0, 0, 0, 0};
+
+    long long row[kVecUnroll];
+    int h[kVecUnroll];
+    bool active[kVecUnroll];
+    u32x4 xr[kVecUnroll], wr[kVecUnroll], br[kVecUnroll], sr[kVecUnroll], cr[kVecUnroll];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) px[e] = __shfl(x[e], partner & 63, 64);
-        if (active && !is_v && j * 8 < rope_dim) {
-            float sv[8], cv[8];
-            unpack8<BF16>(*(const u32x4 *)(sin + row * (long long)rope_dim + j * 8), sv);
-            unpack8<BF16>(*(const u32x4 *)(cos + row * (long long)rope_dim + j * 8), cv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (lower ? -px[e] : px[e]) * sv[e] + x[e] * cv[e];
+    for (int u = 0; u < kVecUnroll; ++u) {
+        const long long hglobal = (wid * kVecUnroll + u) * heads_per_wave + lane / gl;
+        row[u] = hglobal / heads_total;
+        h[u] = (int)(hglobal % heads_total);
+        active[u] = row[u] < rows;
+        const bool is_v = h[u] >= q_heads + kv_heads, is_q = h[u] < q_heads;
+        const bool normed = active[u] && !is_v;
+        xr[u] = active[u] ? *(const u32x4 *)(qkv + row[u] * total_hidden + (long long)h[u] * head_dim + j * 8) : zero4;
+        wr[u] = (has_norm && normed) ? *(const u32x4 *)((is_q ? qw : kw) + j * 8) : zero4;
+        br[u] = (has_norm && normed && qb) ? *(const u32x4 *)((is_q ? qb : kb) + j * 8) : zero4;
+        if (neox) {
+            sr[u] = (normed && roped) ? *(const u32x4 *)(sin + row[u] * (long long)rope_dim + j * 8) : zero4;
+            cr[u] = (normed && roped) ? *(const u32x4 *)(cos + row[u] * (long long)rope_dim + j * 8) : zero4;
         } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = x[e];
-        }
-    } else {
-        if (active && !is_v && j * 8 < rope_dim) {
             // pairs (2i, 2i+1) use sin/cos[i]; this lane's 4 pairs are i = 4j .. 4j+3
-            const u32x2 sraw = *(const u32x2 *)(sin + row * (long long)rope_dim + j * 4);
-            const u32x2 craw = *(const u32x2 *)(cos + row * (long long)rope_dim + j * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float sv = ld16<BF16>((sraw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
-                const float cv = ld16<BF16>((craw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
-                const float x1 = x[2 * i], x2 = x[2 * i + 1];
-                o[2 * i] = (-x2) * sv + x1 * cv;
-                o[2 * i + 1] = x1 * sv + x2 * cv;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = x[e];
+            const u32x2 s2 = (normed && roped) ? *(const u32x2 *)(sin + row[u] * (long long)rope_dim + j * 4) : u32x2{0, 0};
+            const u32x2 c2 = (normed && roped) ? *(const u32x2 *)(cos + row[u] * (long long)rope_dim + j * 4) : u32x2{0, 0};
+            sr[u] = u32x4{s2[0], s2[1], 0, 0};
+            cr[u] = u32x4{c2[0], c2[1], 0, 0};
         }
     }
-    if (!active) return;
-    uint16_t *dst = is_q ? q + row * (long long)q_hidden + (long long)h * head_dim
-                  : (!is_v ? k + row * (long long)kv_hidden + (long long)(h - q_heads) * head_dim
-                           : v + row * (long long)kv_hidden + (long long)(h - q_heads - kv_heads) * head_dim);
-    *(u32x4 *)(dst + j * 8) = is_v ? *(const u32x4 *)(qkv + row * total_hidden + (long long)h * head_dim + j * 8) : pack8<BF16>(o);
+#pragma unroll
+    for (int u = 0; u < kVecUnroll; ++u) {
+        const bool is_v = h[u] >= q_heads + kv_heads, is_q = h[u] < q_heads;
+        float x[8];
+        unpack8<BF16>(xr[u], x);
+        if (has_norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+            for (int off = gl >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            if (active[u] && !is_v) {
+                const float rstd = 1.0f / sqrtf(ss / (float)head_dim + eps);
+                float wv[8];
+                unpack8<BF16>(wr[u], wv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = (x[e] * rstd) * wv[e];
+                if (qb) {
+                    float bv[8];
+                    unpack8<BF16>(br[u], bv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = x[e] + bv[e];
+                }
+            }
+        }
+        float o[8];
+        if (neox) {
+            const int dl = half >> 3;                      // partner distance in lanes
+            const bool lower = (j * 8) < half;
+            const int partner = lower ? lane + dl : lane - dl;
+            float px[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) px[e] = __shfl(x[e], partner & 63, 64);
+            if (active[u] && !is_v && roped) {
+                float sv[8], cv[8];
+                unpack8<BF16>(sr[u], sv);
+                unpack8<BF16>(cr[u], cv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (lower ? -px[e] : px[e]) * sv[e] + x[e] * cv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = x[e];
+            }
+        } else {
+            if (active[u] && !is_v && roped) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sv = ld16<BF16>((sr[u][i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+                    const float cv = ld16<BF16>((cr[u][i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+                    const float x1 = x[2 * i], x2 = x[2 * i + 1];
+                    o[2 * i] = (-x2) * sv + x1 * cv;
+                    o[2 * i + 1] = x1 * sv + x2 * cv;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = x[e];
+            }
+        }
+        if (!active[u]) continue;
+        uint16_t *dst = is_q ? q + row[u] * (long long)q_hidden + (long long)h[u] * head_dim
+                      : (!is_v ? k + row[u] * (long long)kv_hidden + (long long)(h[u] - q_heads) * head_dim
+                               : v + row[u] * (long long)kv_hidden + (long long)(h[u] - q_heads - kv_heads) * head_dim);
+        *(u32x4 *)(dst + j * 8) = is_v ? xr[u] : pack8<BF16>(o);
+    }
 }
 
 }  // namespace mi_sgl
@@ -402,12 +433,21 @@ extern "C" int mi_swiglu_quant(const void *x, const void *group_list, int group_
     if (!x || !group_list || !out || (need_quant && !scale)) return MI_SGL_EINVAL;
     const int blocks = (rows + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
+    const int per_lane = (cols / 2 / 8 + 63) / 64;       // 16-byte items per lane
+#define MI_LAUNCH_N(B, L, N)                                                                                                     \
+    swiglu_quant_kernel<B, L, N><<<blocks, 256, 0, st>>>((const uint16_t *)x, group_list, num_groups, group_list_type, rows,       \
+                                                         cols / 2, need_quant, do_limit, limit, out, scale)
 #define MI_LAUNCH(B, L)                                                                                                          \
-    swiglu_quant_kernel<B, L><<<blocks, 256, 0, st>>>((const uint16_t *)x, group_list, num_groups, group_list_type, rows, cols / 2, \
-                                                      need_quant, do_limit, limit, out, scale)
+    do {                                                                                                                         \
+        if (per_lane <= 1) MI_LAUNCH_N(B, L, 1);                                                                                 \
+        else if (per_lane <= 2) MI_LAUNCH_N(B, L, 2);                                                                            \
+        else if (per_lane <= 4) MI_LAUNCH_N(B, L, 4);                                                                            \
+        else MI_LAUNCH_N(B, L, 8);                                                                                               \
+    } while (0)
     if (dtype == MI_DTYPE_BF16) { if (group_list_is_i64) MI_LAUNCH(true, true); else MI_LAUNCH(true, false); }
     else { if (group_list_is_i64) MI_LAUNCH(false, true); else MI_LAUNCH(false, false); }
 #undef MI_LAUNCH
+#undef MI_LAUNCH_N
     return launch_ok();
 }
 
@@ -452,7 +492,8 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
     if (vec_ok) {
         const long long heads = (long long)rows * heads_total;
         const int hpw = 64 / (head_dim / 8);
-        const int blocks = (int)(((heads + hpw - 1) / hpw + 3) / 4);
+        const long long waves = ((heads + hpw - 1) / hpw + kVecUnroll - 1) / kVecUnroll;
+        const int blocks = (int)((waves + 3) / 4);
 #define MI_VEC(B)                                                                                                                   \
     split_qkv_rmsnorm_rope_vec_kernel<B><<<blocks, 256, 0, st>>>(                                                                   \
         (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
