@@ -11,6 +11,9 @@
 #ifndef MLAW_QK_AHEAD
 #define MLAW_QK_AHEAD 8
 #endif
+#ifndef MLAW_PIPE
+#define MLAW_PIPE 0          // 1: softmax of tile t runs under the QK^T MFMAs of tile t+1 (2 tiles of DMA in flight instead of 3); measured: no gain
+#endif
 #ifndef MLAW_PV_AHEAD
 #define MLAW_PV_AHEAD 6
 #endif
@@ -199,33 +202,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float cs = p.sm_scale * 1.4426950408889634f;
     // top of a tile: own pieces of tile t and the block ids of tile t+3 have landed (D(t+1), R(t+4), D(t+2) may still
     // fly); after the barrier tile t is complete in LDS and the slot of tile t-1 is free for tile t+3
+    // kLead = how many tiles ahead of the one entering QK^T the fill is issued (slot ring of 4: the pipelined loop still reads
+    // tile t-1 for P.V while tile t is in QK^T, so it can only run 2 ahead).  Issue order per tile x: R(x + kLead + 2), D(x + kLead);
+    // the wait at the top of tile x leaves the (kLead - 1) youngest fills and their row loads in flight.
+    constexpr int kLead = MLAW_PIPE ? 2 : 3;
     auto tile_top = [&](int t) -> TileRows {
 #ifndef MLAW_NO_PIECES
-        asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * (kLead - 1) - 1 + (kLead == 3 ? 0 : 1)) : "memory");
 #endif
         __syncthreads();
-        wide_issue_rows(cx, t + 5);
-        return wide_rows(cx, t + 3);
+        wide_issue_rows(cx, t + kLead + 2);
+        return wide_rows(cx, t + kLead);
     };
-    // prologue in steady-state issue order: ... D(t) | R(t+3) D(t+1) | R(t+4) D(t+2)
+    // prologue in steady-state issue order: ... D(t) | R(t + kLead) D(t+1) | ...
     auto prologue = [&]() {
-        wide_issue_rows(cx, t_begin);
-        wide_issue_rows(cx, t_begin + 1);
-        wide_issue_rows(cx, t_begin + 2);
+#pragma unroll
+        for (int d = 0; d < kLead; ++d) wide_issue_rows(cx, t_begin + d);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < kLead; ++d) {
+            if (d + 2 >= kLead) wide_issue_rows(cx, t_begin + d + 2);      // R(x + kLead + 2) of the virtual iteration x = t_begin + d - kLead
             const TileRows r = wide_rows(cx, t_begin + d);
 #pragma unroll
             for (int i = 0; i < 9; ++i) wide_issue_piece(cx, r, cx.lds_base + (uint32_t)(((t_begin + d) & (kSlots - 1)) * kSlotBytes), i);
-            if (d < 2) wide_issue_rows(cx, t_begin + 3 + d);
         }
     };
     if (t_begin < t_end) prologue();
     if (!wave_active) {                                        // idle waves only feed the DMA (same barriers as the others)
         for (int t = t_begin; t < t_end; ++t) {
             const TileRows rows3 = tile_top(t);
-            const uint32_t nslot = cx.lds_base + (uint32_t)(((t + 3) & (kSlots - 1)) * kSlotBytes);
+            const uint32_t nslot = cx.lds_base + (uint32_t)(((t + kLead) & (kSlots - 1)) * kSlotBytes);
 #pragma unroll
             for (int i = 0; i < 9; ++i) wide_issue_piece(cx, rows3, nslot, i);
         }
@@ -236,9 +242,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- S^T[key, head] = K . Q^T : 36 k-steps of 16 dims, operand ring kAhead deep, one DMA piece per 4 k-steps;
     // returns the tile maximum per head in the scaled log2 domain
-    auto qk = [&](int t, const TileRows &rows3, f32x16 &s) -> float {
+    auto qk = [&](int t, const TileRows &rows3, f32x16 &s, auto &&between) -> float {
         const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
-        const uint32_t nslot = cx.lds_base + (uint32_t)(((t + 3) & (kSlots - 1)) * kSlotBytes);
+        const uint32_t nslot = cx.lds_base + (uint32_t)(((t + kLead) & (kSlots - 1)) * kSlotBytes);
         // (2 ks + kg) ^ sw == 2 ks + (kg ^ sw): the swizzle folds into the lane base, k-steps are immediate offsets
         const uint8_t *abase = buf + c32 * kNopeStride + ((kg ^ ((c32 >> 3) & 1)) << 4);
         const uint8_t *rbase = buf + kT2 * kNopeStride + c32 * kRopeStride;
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef MLAW_NO_PIECES
             if ((ks & 3) == 0) wide_issue_piece(cx, rows3, nslot, ks >> 2);
 #endif
+            between(ks);                                       // VALU work of the previous tile, hidden under this MFMA
         }
         mfma32_settle(s);
         __builtin_amdgcn_sched_barrier(0);
@@ -279,18 +286,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- P = exp2(S c - m) against the current reference, l += sum P, O^T[d, head] += V^T . P^T
-    auto softmax_pv = [&](int t, const f32x16 &s) {
+    // softmax in 8 pieces of two scores each, so that the pipelined loop can slot them between the next tile's MFMAs
+    auto softmax_piece = [&](int i, const f32x16 &s, float nm, float &psum, uint32_t (&pk)[8]) {
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * i], cs, nm));
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * i + 1], cs, nm));
+        psum += e0 + e1;
+        pk[i] = pack2<BF16>(e0, e1);
+    };
+    auto pv = [&](int t, float psum, const uint32_t (&pk)[8]) {
         const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
-        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
-        float psum = 0.f;
-        uint32_t pk[8];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cs, nm));
-            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], cs, nm));
-            psum += e0 + e1;
-            pk[r >> 1] = pack2<BF16>(e0, e1);
-        }
         psum += __shfl_xor(psum, 32, 64);
         l_run += psum;
         // k-step kk covers keys 16 kk + {4 kg + r, 8 + 4 kg + r}
@@ -324,6 +328,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_sched_group_barrier(0x008, kPvAhead, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto softmax_pv = [&](int t, const f32x16 &s) {
+        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
+        float psum = 0.f;
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) softmax_piece(i, s, nm, psum, pk);
+        pv(t, psum, pk);
+    };
 
     // One softmax reference per head for the WHOLE key range of this workgroup: the first tile's maximum.  No accumulator
     // is ever rescaled, so the tile loop contains no VALU access to the 256 accumulator registers (with a conditional
@@ -339,6 +351,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define MLAW_TICK(i)
 #endif
+    auto noop = [](int) {};
+#if MLAW_PIPE
+    // software pipeline over tiles: QK^T of tile t+1 (MFMA) carries the softmax of tile t (VALU) in its issue gaps
+    if (t_begin < t_end) {
+        f32x16 s_cur;
+        {
+            const TileRows rows = tile_top(t_begin);
+            const float tmax = qk(t_begin, rows, s_cur, noop);
+            m_run = tmax;
+        }
+        for (int t = t_begin; t + 1 < t_end; ++t) {
+#ifdef MLAW_TIMING
+            c0 = __builtin_amdgcn_s_memtime();
+#endif
+            const TileRows rows = tile_top(t + 1);
+            MLAW_TICK(0)
+            const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
+            float psum = 0.f;
+            uint32_t pk[8];
+            f32x16 s_next;
+            const float tmax = qk(t + 1, rows, s_next, [&](int ks) {
+                if ((ks & 3) == 1) softmax_piece(ks >> 2, s_cur, nm, psum, pk);      // ks = 1, 5, ..., 29 -> pieces 0..7
+            });
+            MLAW_TICK(1)
+            if (__any(tmax > m_run + kGuard)) *flag = 1;
+            pv(t, psum, pk);
+            MLAW_TICK(2)
+            s_cur = s_next;
+        }
+        softmax_pv(t_end - 1, s_cur);
+    }
+#else
     for (int t = t_begin; t < t_end; ++t) {
 #ifdef MLAW_TIMING
         c0 = __builtin_amdgcn_s_memtime();
@@ -346,13 +390,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const TileRows rows3 = tile_top(t);
         MLAW_TICK(0)
         f32x16 s;
-        const float tmax = qk(t, rows3, s);
+        const float tmax = qk(t, rows3, s, noop);
         MLAW_TICK(1)
         if (t == t_begin) m_run = tmax;
         if (__any(tmax > m_run + kGuard)) *flag = 1;
         softmax_pv(t, s);
         MLAW_TICK(2)
     }
+#endif
 #ifdef MLAW_TIMING
     if (lane == 0 && blockIdx.x < 64) {
         float *dbg = (float *)p.fix_flags + 1024 + (blockIdx.x * 4 + wave) * 4;
