@@ -10,6 +10,7 @@
  *   mi_add_rmsnorm_bias      <- norm/add_rmsnorm_bias.py:8-147        (add_rmsnorm_bias_kernel / add_rmsnorm_bias)
  *                               norm/add_rmsnorm_bias.py:150-232      (add_gemma_rms_norm)
  *   mi_split_qkv_rmsnorm_rope<- norm/split_qkv_rmsnorm_rope.py:8-438  (split_qkv_rmsnorm_rope)
+ *   mi_rope_qk_mqa           <- norm/fused_rope_qk_mqa.py:6-160       (fused_rope_qk_mqa)
  * and are what `torch.ops.npu.*` (csrc/pytorch_extensions.cpp) and the `sgl_kernel_npu` Python functions bind.
  *
  * Conventions: plain DEVICE pointers and sizes; every call only enqueues work on `stream` (hipStream_t as void*),
@@ -96,6 +97,15 @@ int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const void *cos,
                               int head_dim, int rope_dim, int has_norm, float eps, const void *q_weight,
                               const void *k_weight, const void *q_bias, const void *k_bias, int neox, int dtype, void *q,
                               void *k, void *v, void *stream);
+
+/* ---- RoPE on q and the shared key heads (norm/fused_rope_qk_mqa.py:113-160) -----------------------------------------
+ * q [tokens, q_heads, head_dim], k [tokens, k_heads, head_dim] (strides in elements, last dim contiguous); cos_sin
+ * [tokens, rope_dim] = cos | sin halves, one row per token; first rope_dim dims rotated (neox != 0: pairs (i, i+rope/2),
+ * else (2i, 2i+1)), the rest copied; every product and sum rounded to the I/O dtype like the reference kernel.
+ * out_q / out_k contiguous. */
+int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin, int tokens, int q_heads, int k_heads, int head_dim,
+                   int rope_dim, int neox, int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
+                   int64_t cs_stride_t, int dtype, void *out_q, void *out_k, void *stream);
 
 /* ---- mla_preprocess glue (everything that is not a plain GEMM; reference csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704,
  * arithmetic per tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483) -------------------------------------------

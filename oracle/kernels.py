@@ -239,6 +239,26 @@ def split_qkv_rmsnorm_rope(qkv, sin, cos, q_hidden, kv_hidden, head_dim, eps=Non
 # --------------------------------------------------------------------------------------
 # A14  mla_preprocess
 # --------------------------------------------------------------------------------------
+def fused_rope_qk_mqa(query, key, cos_sin, rotary_dim, is_neox_style):
+    """Transcription of the reference test golden forward_native / apply_rotary_emb
+    (tests/python/sgl_kernel_npu/test_fused_rope_qk_mqa.py:5-60): torch ops in the I/O dtype (every product and sum rounded),
+    cos = cos_sin[:, :R/2], sin = cos_sin[:, R/2:]; the first rotary_dim dims rotated, the rest passed through."""
+    cos, sin = cos_sin[:, :rotary_dim].chunk(2, dim=-1)
+
+    def rot(x):
+        xr, xp = x[..., :rotary_dim], x[..., rotary_dim:]
+        c, s_ = cos.unsqueeze(-2).to(x.dtype), sin.unsqueeze(-2).to(x.dtype)
+        if is_neox_style:
+            x1, x2 = torch.chunk(xr, 2, dim=-1)
+        else:
+            x1, x2 = xr[..., ::2], xr[..., 1::2]
+        o1, o2 = x1 * c - x2 * s_, x2 * c + x1 * s_
+        o = torch.cat((o1, o2), dim=-1) if is_neox_style else torch.stack((o1, o2), dim=-1).flatten(-2)
+        return torch.cat((o, xp), dim=-1)
+
+    return rot(query), rot(key)
+
+
 def _rotate_half(x):
     a, b = torch.chunk(x, 2, dim=-1)
     return torch.cat([-b, a], dim=-1)

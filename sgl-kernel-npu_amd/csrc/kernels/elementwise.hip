@@ -474,6 +474,65 @@ extern "C" int mi_add_rmsnorm_bias(const void *input, const void *residual, cons
     return launch_ok();
 }
 
+// ------------------------------------------------------------------------------------------------
+// RoPE on q [T, Hq, D] and the (few) key heads k [T, Hk, D] with one cos|sin row per token
+// (reference norm/fused_rope_qk_mqa.py:6-160: cos = cos_sin[t, :R/2], sin = cos_sin[t, R/2:R]).  One wave per (token, head).
+// Arithmetic follows the reference kernel / its test golden op by op in the I/O dtype: o1 = r(r(x1*c) - r(x2*s)),
+// o2 = r(r(x1*s) + r(x2*c)) with r = round to the I/O dtype (products of two 16-bit floats are exact in fp32).
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <bool BF16>
+__global__ __launch_bounds__(256) void rope_qk_mqa_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
+                                                         const uint16_t *__restrict__ cos_sin, int T, int Hq, int Hk, int D, int R,
+                                                         int neox, long long q_st, long long q_sh, long long k_st, long long k_sh,
+                                                         long long cs_st, uint16_t *__restrict__ oq, uint16_t *__restrict__ ok)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int H = Hq + Hk;
+    const long long t = wid / H;
+    const int h = (int)(wid % H);
+    if (t >= T) return;
+    const bool is_q = h < Hq;
+    const uint16_t *src = is_q ? q + t * q_st + (long long)h * q_sh : k + t * k_st + (long long)(h - Hq) * k_sh;
+    uint16_t *dst = is_q ? oq + (t * Hq + h) * (long long)D : ok + (t * Hk + (h - Hq)) * (long long)D;
+    const uint16_t *cs = cos_sin + t * cs_st;
+    const int half = R >> 1;
+    auto r = [](float f) -> float { return ld16<BF16>(st16<BF16>(f)); };
+    for (int i = lane; i < half; i += 64) {
+        const int ie = neox ? i : 2 * i, io = neox ? i + half : 2 * i + 1;
+        const float x1 = ld16<BF16>(src[ie]), x2 = ld16<BF16>(src[io]);
+        const float c = ld16<BF16>(cs[i]), sn = ld16<BF16>(cs[half + i]);
+        dst[ie] = (uint16_t)st16<BF16>(r(x1 * c) - r(x2 * sn));
+        dst[io] = (uint16_t)st16<BF16>(r(x1 * sn) + r(x2 * c));
+    }
+    for (int i = R + lane; i < D; i += 64) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin, int tokens, int q_heads, int k_heads, int head_dim,
+                              int rope_dim, int neox, int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
+                              int64_t cs_stride_t, int dtype, void *out_q, void *out_k, void *stream)
+{
+    if (tokens < 0 || q_heads <= 0 || k_heads <= 0 || head_dim <= 0 || rope_dim <= 0 || rope_dim > head_dim || rope_dim % 2 ||
+        (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16))
+        return MI_SGL_EINVAL;
+    if (tokens == 0) return MI_SGL_OK;
+    if (!q || !k || !cos_sin || !out_q || !out_k) return MI_SGL_EINVAL;
+    const long long waves = (long long)tokens * (q_heads + k_heads);
+    const int blocks = (int)((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI_DTYPE_BF16)
+        rope_qk_mqa_kernel<true><<<blocks, 256, 0, st>>>((const uint16_t *)q, (const uint16_t *)k, (const uint16_t *)cos_sin, tokens,
+                                                        q_heads, k_heads, head_dim, rope_dim, neox, q_stride_t, q_stride_h,
+                                                        k_stride_t, k_stride_h, cs_stride_t, (uint16_t *)out_q, (uint16_t *)out_k);
+    else
+        rope_qk_mqa_kernel<false><<<blocks, 256, 0, st>>>((const uint16_t *)q, (const uint16_t *)k, (const uint16_t *)cos_sin, tokens,
+                                                         q_heads, k_heads, head_dim, rope_dim, neox, q_stride_t, q_stride_h,
+                                                         k_stride_t, k_stride_h, cs_stride_t, (uint16_t *)out_q, (uint16_t *)out_k);
+    return launch_ok();
+}
+
 extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const void *cos, int rows, int q_hidden, int kv_hidden,
                                          int head_dim, int rope_dim, int has_norm, float eps, const void *q_weight,
                                          const void *k_weight, const void *q_bias, const void *k_bias, int neox, int dtype,

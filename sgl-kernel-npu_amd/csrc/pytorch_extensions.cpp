@@ -165,6 +165,24 @@ std::tuple<at::Tensor, at::Tensor> add_rmsnorm_bias(const at::Tensor &input, con
     return {out, out2};
 }
 
+// RoPE on q and the shared key heads; arguments / returns of fused_rope_qk_mqa (norm/fused_rope_qk_mqa.py:113-160).
+std::tuple<at::Tensor, at::Tensor> fused_rope_qk_mqa(const at::Tensor &query, const at::Tensor &key, const at::Tensor &cos_sin,
+                                                     int64_t rotary_dim, bool is_neox_style)
+{
+    TORCH_CHECK(query.dim() == 3 && key.dim() == 3 && cos_sin.dim() == 2, "fused_rope_qk_mqa: query [T,Hq,D], key [T,Hk,D], cos_sin [T,R]");
+    TORCH_CHECK(query.size(0) == key.size(0) && query.size(2) == key.size(2) && cos_sin.size(0) >= query.size(0) &&
+                    cos_sin.size(1) >= rotary_dim, "fused_rope_qk_mqa: shape mismatch");
+    TORCH_CHECK(query.stride(2) == 1 && key.stride(2) == 1 && cos_sin.stride(1) == 1, "fused_rope_qk_mqa: innermost dims must be contiguous");
+    TORCH_CHECK(query.scalar_type() == key.scalar_type() && query.scalar_type() == cos_sin.scalar_type(), "fused_rope_qk_mqa: dtype mismatch");
+    at::Tensor out_q = at::empty(query.sizes(), query.options()), out_k = at::empty(key.sizes(), key.options());
+    const int rc = mi_rope_qk_mqa(query.data_ptr(), key.data_ptr(), cos_sin.data_ptr(), (int)query.size(0), (int)query.size(1),
+                                  (int)key.size(1), (int)query.size(2), (int)rotary_dim, is_neox_style, query.stride(0), query.stride(1),
+                                  key.stride(0), key.stride(1), cos_sin.stride(0), dtype_code(query), out_q.data_ptr(), out_k.data_ptr(),
+                                  cur_stream());
+    TORCH_CHECK(rc == 0, "mi_rope_qk_mqa failed with code ", rc);
+    return {out_q, out_k};
+}
+
 // split QKV + per-head RMSNorm + RoPE; arguments as split_qkv_rmsnorm_rope (norm/split_qkv_rmsnorm_rope.py:374-438).
 std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
     const at::Tensor &input, const at::Tensor &sin, const at::Tensor &cos, int64_t q_hidden_size, int64_t kv_hidden_size,
@@ -287,6 +305,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
           "float limit=7.0) -> (Tensor, Tensor)");
     m.def("add_rmsnorm_bias(Tensor input, Tensor? residual, Tensor norm_weight, Tensor? norm_bias, float eps, "
           "Tensor? quant_scale=None, Tensor? quant_offset=None, bool gemma=False) -> (Tensor, Tensor)");
+    m.def("fused_rope_qk_mqa(Tensor query, Tensor key, Tensor cos_sin, int rotary_dim, bool is_neox_style) -> (Tensor, Tensor)");
     m.def("split_qkv_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "float? eps=None, Tensor? q_weight=None, Tensor? k_weight=None, Tensor? q_bias=None, Tensor? k_bias=None, "
           "bool is_neox_style=True) -> (Tensor, Tensor, Tensor)");
@@ -299,5 +318,6 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("mla_preprocess", TORCH_FN(sglang::npu_kernel::mla_preprocess));
     m.impl("swiglu_quant", TORCH_FN(sglang::npu_kernel::swiglu_quant));
     m.impl("add_rmsnorm_bias", TORCH_FN(sglang::npu_kernel::add_rmsnorm_bias));
+    m.impl("fused_rope_qk_mqa", TORCH_FN(sglang::npu_kernel::fused_rope_qk_mqa));
     m.impl("split_qkv_rmsnorm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope));
 }

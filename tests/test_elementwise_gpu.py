@@ -139,3 +139,22 @@ def test_mla_preprocess(N, Hq, hidden):
     mask = torch.ones(nblocks * block_size, dtype=torch.bool)
     mask[slots.long()] = False
     assert not kv.view(-1, 512).cpu()[mask].any()
+
+
+@pytest.mark.parametrize("T,Hq,Hk,D,R", [(32, 8, 1, 64, 32), (32, 8, 1, 32, 32), (17, 16, 1, 128, 64), (64, 32, 1, 128, 64),
+                                         (5, 128, 1, 192, 64)])       # reference cases (test_fused_rope_qk_mqa.py:64-71) + MLA-sized
+@pytest.mark.parametrize("neox", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_rope_qk_mqa(T, Hq, Hk, D, R, neox, dtype):
+    from sgl_kernel_npu.norm.fused_rope_qk_mqa import fused_rope_qk_mqa
+    torch.manual_seed(3)
+    q, k = torch.randn(T, Hq, D).to(dtype), torch.randn(T, Hk, D).to(dtype)
+    cs = torch.randn(T, R).to(dtype)
+    wq, wk = OK.fused_rope_qk_mqa(q, k, cs, R, neox)
+    oq, ok = fused_rope_qk_mqa(q.cuda(), k.cuda(), cs.cuda(), R, neox)
+    # op-by-op rounding in the I/O dtype is reproduced, so the result is bit-identical (reference: assert_close defaults)
+    assert torch.equal(oq.cpu(), wq) and torch.equal(ok.cpu(), wk)
+    # strided query (a slice of a wider tensor), as SGLang passes views
+    wide = torch.randn(T, Hq, D + 16).to(dtype).cuda()
+    oq2, _ = fused_rope_qk_mqa(wide[..., :D], k.cuda(), cs.cuda(), R, neox)
+    assert torch.equal(oq2.cpu(), OK.fused_rope_qk_mqa(wide[..., :D].cpu(), k, cs, R, neox)[0])
