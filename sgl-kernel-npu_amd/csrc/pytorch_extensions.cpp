@@ -260,10 +260,13 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
                 "quant_scale0/1 must be [1] in the input dtype, quant_offset0/1 int8 [1]");
     // hipBLASLt's INT8 GEMM (at::_int_mm) wants more than 16 rows: pad the token dimension to a multiple of 32
     const int64_t Np = (N + 31) / 32 * 32;
-    at::Tensor a8 = at::zeros({Np, hidden}, at::dtype(at::kChar).device(dev));
+    auto i8buf = [&](int64_t cols) {           // pad rows (if any) must be defined: they flow through the GEMM
+        return Np == N ? at::empty({Np, cols}, at::dtype(at::kChar).device(dev)) : at::zeros({Np, cols}, at::dtype(at::kChar).device(dev));
+    };
+    at::Tensor a8 = i8buf(hidden);
     TORCH_CHECK(0 == mi_mla_pre_quant(hiddenState.data_ptr(), quant_scale0.data_ptr(), (const int8_t *)quant_offset0.data_ptr(), N * hidden, dt, (int8_t *)a8.data_ptr(), st), "mi_mla_pre_quant failed");
     at::Tensor c1 = at::_int_mm(a8, wdqkv.t());                                   // [Np, 2112] int32
-    at::Tensor q8 = at::zeros({Np, 1536}, at::dtype(at::kChar).device(dev));
+    at::Tensor q8 = i8buf(1536);
     auto iptr = [](const at::Tensor &t) -> const int32_t * { return t.numel() ? t.data_ptr<int32_t>() : nullptr; };
     TORCH_CHECK(0 == mi_mla_pre_mid(c1.data_ptr<int32_t>(), iptr(bias0), descale0.data_ptr<float>(), gamma1.data_ptr(), beta1.data_ptr(),
                                     gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(), quant_scale1.data_ptr(),
@@ -274,8 +277,10 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     at::Tensor q_nope = at::empty({N, Hq, 128}, hiddenState.options());
     TORCH_CHECK(0 == mi_mla_pre_qsplit(c2.data_ptr<int32_t>(), iptr(bias1), descale1.data_ptr<float>(), cos.data_ptr(), sin.data_ptr(),
                                        (int)N, (int)Hq, dt, q_nope.data_ptr(), q_out1.data_ptr(), st), "mi_mla_pre_qsplit failed");
-    at::Tensor o = at::bmm(q_nope.transpose(0, 1), wuk);                          // [q_heads, N, 512]
-    q_out0.view({N, Hq, 512}).copy_(o.transpose(0, 1));
+    // per-head [N,128] x [128,512] straight into q_out0 viewed as [q_heads, N, 512] (row stride Hq*512, batch stride 512:
+    // a layout strided-batched GEMM writes natively, so no transpose copy afterwards)
+    at::Tensor o_view = q_out0.view({N, Hq, 512}).transpose(0, 1);
+    at::bmm_out(o_view, q_nope.transpose(0, 1), wuk);
     if (kv_cache_out0.data_ptr() != kv_cache.data_ptr()) kv_cache_out0.copy_(kv_cache);
     if (kv_cache_out1.data_ptr() != kv_cache_rope.data_ptr()) kv_cache_out1.copy_(kv_cache_rope);
     return {q_out0, kv_cache_out0, q_out1, kv_cache_out1};
