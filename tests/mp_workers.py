@@ -162,6 +162,22 @@ def _gpu_buffer(rank, world, port, cfg):
             ws_, ss_ = wait_stats.cpu(), send_stats.cpu()
             assert (ws_ >= 0).all() and (ws_ < 60_000_000).all() and (ss_ >= 0).all() and (ss_ < 60_000_000).all()
             assert int(ss_.min()) == int(ss_.max())             # every destination is charged the push duration
+        if strategy == "default" and it == iters - 1:
+            # DeepEP graph mode (buffer.py:337-338,356-358): worst-case sized outputs, no host sync, empty count list
+            worst = Tt * K * W
+            rw, _, _, lst_w, handle_w, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                        num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
+                                                        quant_mode="int8" if quant else None, num_worst_tokens=worst)
+            assert lst_w == []
+            rxw = rw[0] if quant else rw
+            assert rxw.shape[0] == worst
+            if quant:
+                assert np.array_equal(rxw.cpu().numpy()[:n], want[rank].recv_x[:n])
+            else:
+                assert np.array_equal(torch_to_bits(rxw)[:n], want[rank].recv_x[:n])
+            assert np.array_equal(handle_w[3].cpu().numpy()[:3 * n], want[rank].recv_src_idx[:3 * n])
+            out_w, _, _ = buf.combine(y, handle_w)
+            assert np.array_equal(torch_to_bits(out_w), comb_want[rank]), "combine after worst-token dispatch mismatch"
         # low latency
         MT = T + W
         llw = O.low_latency_dispatch(xs, idxs, MT, E, quant)
@@ -250,5 +266,43 @@ def _gpu_fused_moe(rank, world, port, cfg):
     assert diff < 1e-5, diff
     assert np.mean(np.abs(got - ref) / denom) < 4e-4, np.mean(np.abs(got - ref) / denom)   # reference: avg_diff < 4e-4 (:470)
     torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: a peer that never shows up must surface as a RuntimeError (bounded spins), not a hang
+# ----------------------------------------------------------------------------------------------
+def gpu_timeout_worker(rank, world, port, cfg):
+    run_guarded(_gpu_timeout, rank, world, port, cfg)
+
+
+def _gpu_timeout(rank, world, port, cfg):
+    import time
+    import deep_ep
+    torch.cuda.set_device(0)
+    os.environ["DEEPEP_TIMEOUT_MS"] = "300"
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(256 << 20))
+    group = _init(rank, world, port, "gloo")
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    T, H, K, E = 16, 512, 2, 8
+    x = torch.randn((T, H), device="cuda").to(torch.bfloat16)
+    ti = torch.randint(0, E, (T, K), device="cuda")
+    tw = torch.rand((T, K), device="cuda")
+    if rank == 0:
+        t0 = time.time()
+        try:
+            per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+            buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in, num_tokens_per_expert=per_expert, topk_idx=ti,
+                         topk_weights=tw)
+            torch.cuda.synchronize()
+            raised = False
+        except RuntimeError as e:
+            raised = True
+            assert "imeout" in str(e) or "status" in str(e) or "never arrived" in str(e), str(e)
+        assert raised, "dispatch without its peer must raise"
+        assert time.time() - t0 < 30
+    else:
+        time.sleep(3.0)          # never joins the exchange
     dist.barrier()
     dist.destroy_process_group()

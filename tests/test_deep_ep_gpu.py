@@ -34,3 +34,7 @@ def test_buffer_multi_process_one_gpu(cfg):
 ])
 def test_fused_deep_moe(cfg):
     _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)
+
+
+def test_missing_peer_raises_instead_of_hanging():
+    _spawn(mp_workers.gpu_timeout_worker, 2, None)
