@@ -45,6 +45,20 @@ def _event(e):
     return getattr(e, "event", None)
 
 
+def long_seq_rounds():
+    """(rounds, tokens per round) of the reference's long-sequence mode (csrc/deepep/deep_ep.cpp:63-90, README.md:224-226):
+    DEEPEP_NORMAL_LONG_SEQ_ROUND in [1, 256], DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS in [32, 8192], product <= 131072."""
+    rounds = int(os.getenv("DEEPEP_NORMAL_LONG_SEQ_ROUND", "1"))
+    per = int(os.getenv("DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS", "8192"))
+    if not (1 <= rounds <= 256):
+        raise ValueError(f"DEEPEP_NORMAL_LONG_SEQ_ROUND ({rounds}) must be in [1, 256]")
+    if not (32 <= per <= 8192):
+        raise ValueError(f"DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS ({per}) must be in [32, 8192]")
+    if rounds * per > 131072:
+        raise ValueError(f"DEEPEP_NORMAL_LONG_SEQ_ROUND ({rounds}) * DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS ({per}) must not exceed 131072")
+    return rounds, per
+
+
 @register_normal_strategy("default")
 class DefaultNormalCommStrategy(NormalEPCommStrategy):
     def __init__(self, runtime, group: dist.ProcessGroup):
@@ -71,6 +85,11 @@ class DefaultNormalCommStrategy(NormalEPCommStrategy):
         if handle is not None:
             raise NotImplementedError("Optional communication handle is not supported yet.")
         assert num_tokens_per_rank is not None and is_token_in_rank is not None and num_tokens_per_expert is not None
+        rounds, per_round = long_seq_rounds()
+        if rounds > 1:
+            assert num_worst_tokens == 0, "num_worst_tokens is not supported together with DEEPEP_NORMAL_LONG_SEQ_ROUND > 1"
+            return self._dispatch_rounds(data, quant_type, use_quant, is_token_in_rank, num_tokens_per_expert, topk_idx,
+                                         topk_weights, expert_alignment, config, dispatch_wait_recv_cost_stats, rounds, per_round)
         (recv_x, recv_x_scales, recv_topk_idx, recv_topk_weights, num_recv_tokens_per_expert_list, rank_prefix_matrix,
          channel_prefix_matrix, recv_channel_prefix_matrix, recv_src_idx, send_head, event) = self.runtime.intranode_dispatch(
             data, None, topk_idx, topk_weights, num_tokens_per_rank, is_token_in_rank, num_tokens_per_expert, 0, None, None,
@@ -81,11 +100,79 @@ class DefaultNormalCommStrategy(NormalEPCommStrategy):
         return ((recv_x, recv_x_scales) if use_quant else recv_x, recv_topk_idx, recv_topk_weights,
                 num_recv_tokens_per_expert_list, handle, EventOverlap(event))
 
+    # ---- long-sequence mode (reference "ant moving home": deep_ep.cpp:63-90, round loop
+    # cam_moe_dispatch_normal.h:767-781).  The reference re-uses a fixed-size window by sending `rounds` slices of
+    # `per_round` tokens through ONE kernel; here every slice is a complete exchange through the tested single-shot path
+    # (so the window only ever holds one slice) and the receive side is re-assembled into the single-shot order -- rows
+    # sorted by (local expert, source rank, token) -- with index copies.  Every rank must set the same two env values.
+    def _dispatch_rounds(self, data, quant_type, use_quant, is_token_in_rank, num_tokens_per_expert, topk_idx, topk_weights,
+                         expert_alignment, config, stats, rounds, per_round):
+        T, E = topk_idx.size(0), num_tokens_per_expert.numel()
+        if T > rounds * per_round:
+            raise ValueError(f"{T} tokens exceed DEEPEP_NORMAL_LONG_SEQ_ROUND * PER_ROUND_TOKENS = {rounds * per_round}")
+        dev = data.device
+        chunks, lists = [], []
+        for r in range(rounds):
+            t0, t1 = min(T, r * per_round), min(T, (r + 1) * per_round)
+            ti, wi = topk_idx[t0:t1].contiguous(), topk_weights[t0:t1].contiguous()
+            per_rank, _, per_expert, is_in, _ = self.runtime.get_dispatch_layout(ti, E, None, False, False)
+            (rx, rs, _, _, lst, rpm, cpm, rcpm, src_idx, send_head, _) = self.runtime.intranode_dispatch(
+                data[t0:t1].contiguous(), None, ti, wi, per_rank, is_in, per_expert, 0, None, None, stats, expert_alignment, 0,
+                config, None, False, False, use_quant, quant_type)
+            cum = send_head.to(torch.int64)
+            cnt = cum - torch.cat([cum.new_zeros(1), cum[:-1]])
+            # rows received in this slice, from the host-side per-expert list (counts, or inclusive sums when
+            # MOE_EXPERT_TOKEN_NUMS_TYPE=0)
+            cumulative = int(os.getenv("MOE_EXPERT_TOKEN_NUMS_TYPE", "1")) == 0
+            n = (int(lst[-1]) if cumulative else int(sum(lst))) if lst else 0
+            chunks.append(dict(t0=t0, n=n, rx=rx[:n], rs=rs[:n], src=src_idx[:3 * n].view(n, 3), cnt=cnt, src_idx=src_idx,
+                               send_head=send_head, topk_idx=ti, topk_weights=wi))
+            lists.append(lst)
+        total_cnt = sum(c["cnt"] for c in chunks)
+        final_cum = torch.cumsum(total_cnt, 0)
+        final_excl = final_cum - total_cnt
+        N = sum(c["n"] for c in chunks)
+        rows = max(N, 1)
+        recv_x = torch.empty((rows,) + tuple(chunks[0]["rx"].shape[1:]), dtype=chunks[0]["rx"].dtype, device=dev)
+        recv_scales = torch.empty((rows,), dtype=torch.float32, device=dev)
+        recv_src = torch.empty((rows, 3), dtype=torch.int32, device=dev)
+        running = torch.zeros_like(total_cnt)
+        seg_ids = torch.arange(E, device=dev)
+        for c in chunks:
+            n = c["n"]
+            seg = torch.repeat_interleave(seg_ids, c["cnt"], output_size=n)
+            excl = torch.cumsum(c["cnt"], 0) - c["cnt"]
+            dest = final_excl[seg] + running[seg] + (torch.arange(n, device=dev) - excl[seg])
+            running = running + c["cnt"]
+            recv_x.index_copy_(0, dest, c["rx"])
+            recv_scales.index_copy_(0, dest, c["rs"])
+            src = c["src"].clone()
+            src[:, 1] += c["t0"]                               # token index inside the whole batch
+            recv_src.index_copy_(0, dest, src)
+            c["dest"] = dest
+            del c["rx"], c["rs"], c["src"], c["cnt"]
+        counts = [sum(v) for v in zip(*lists)] if lists and lists[0] else []
+        final_src_idx = recv_src.reshape(-1)
+        final_src_idx._mi_long_seq = chunks                      # per-slice handles for combine()
+        handle = (rpm, cpm, rcpm, final_src_idx, is_token_in_rank, final_cum.to(torch.int32), topk_idx, topk_weights)
+        recv_topk_idx = torch.empty((N, topk_idx.size(1)), dtype=topk_idx.dtype, device=dev)
+        recv_topk_weights = torch.empty((N, topk_idx.size(1)), dtype=topk_weights.dtype, device=dev)
+        return ((recv_x, recv_scales) if use_quant else recv_x, recv_topk_idx, recv_topk_weights, counts, handle,
+                EventOverlap(None))
+
     def combine(self, x, handle, topk_weights=None, bias=None, config=None, previous_event=None, async_finish=False,
                 allocate_on_comm_stream=False, combine_send_cost_stats=None):
         # weights come from the handle (dispatch-time topk_weights); the `topk_weights` argument is ignored, exactly
         # like the reference (normal_strategy.py:407-420)
         _, _, _, src_idx, _, send_head, topk_idx, topk_weights_ori = handle
+        chunks = getattr(src_idx, "_mi_long_seq", None)
+        if chunks is not None:                                   # long-sequence mode: slice by slice, same order as dispatch
+            outs = []
+            for c in chunks:
+                out_r, _, _ = self.runtime.intranode_combine(x.index_select(0, c["dest"]), c["topk_idx"], c["topk_weights"],
+                                                             c["src_idx"], c["send_head"], combine_send_cost_stats)
+                outs.append(out_r)
+            return torch.cat(outs, dim=0), None, EventOverlap(None)
         recv_x, recv_topk_weights, event = self.runtime.intranode_combine(x, topk_idx, topk_weights_ori, src_idx, send_head,
                                                                          combine_send_cost_stats)
         return recv_x, recv_topk_weights, EventOverlap(event)

@@ -306,3 +306,51 @@ def _gpu_timeout(rank, world, port, cfg):
         time.sleep(3.0)          # never joins the exchange
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: long-sequence mode (DEEPEP_NORMAL_LONG_SEQ_*): several slices must give exactly the single-shot result
+# ----------------------------------------------------------------------------------------------
+def gpu_long_seq_worker(rank, world, port, cfg):
+    run_guarded(_gpu_long_seq, rank, world, port, cfg)
+
+
+def _gpu_long_seq(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits
+    torch.cuda.set_device(0)
+    W, T, H, K, E, drop, quant, rounds, per_round = cfg
+    os.environ["DEEPEP_NORMAL_LONG_SEQ_ROUND"] = str(rounds)
+    os.environ["DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS"] = str(per_round)
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(768 << 20))
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "20000")
+    group = _init(rank, world, port, "gloo")
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    xs, idxs, ws = make_inputs(W, T, H, K, E, drop, seed=321)
+    x = bits_to_torch(xs[rank]).cuda()
+    ti = torch.from_numpy(idxs[rank]).cuda()
+    tw = torch.from_numpy(ws[rank]).cuda()
+    want = O.normal_dispatch(xs, idxs, E, quant)           # the single-shot oracle is the contract
+    per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+    recv_x, _, _, lst, handle, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
+                                                quant_mode="int8" if quant else None)
+    n = want[rank].total_recv
+    assert lst == want[rank].num_recv_tokens_per_expert_list, (lst, want[rank].num_recv_tokens_per_expert_list)
+    assert np.array_equal(handle[3].cpu().numpy()[:3 * n], want[rank].recv_src_idx[:3 * n])
+    assert np.array_equal(handle[5].cpu().numpy(), want[rank].send_head)
+    if quant:
+        assert np.array_equal(recv_x[0].cpu().numpy()[:n], want[rank].recv_x[:n])
+        assert np.array_equal(recv_x[1].cpu().numpy()[:n], want[rank].recv_x_scales[:n])
+        y = bits_to_torch(O.per_token_cast_back(want[rank].recv_x, want[rank].recv_x_scales)).cuda()
+    else:
+        assert np.array_equal(torch_to_bits(recv_x)[:n], want[rank].recv_x[:n])
+        y = recv_x
+    ys = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) if quant else w.recv_x for w in want]
+    comb_want = O.combine(ys, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)
+    out, _, _ = buf.combine(y, handle)
+    assert np.array_equal(torch_to_bits(out), comb_want[rank]), "long-sequence combine mismatch"
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()

@@ -38,3 +38,13 @@ def test_fused_deep_moe(cfg):
 
 def test_missing_peer_raises_instead_of_hanging():
     _spawn(mp_workers.gpu_timeout_worker, 2, None)
+
+
+@pytest.mark.parametrize("cfg", [
+    # W, T, H, K, E, drop, quant, rounds, tokens per round
+    (2, 80, 512, 4, 16, 0.1, True, 3, 32),        # 32 + 32 + 16 tokens
+    (4, 70, 1024, 8, 32, 0.0, False, 4, 32),      # last slice empty on every rank
+    (1, 200, 512, 2, 8, 0.2, True, 2, 128),
+])
+def test_long_sequence_rounds_match_single_shot(cfg):
+    _spawn(mp_workers.gpu_long_seq_worker, cfg[0], cfg)

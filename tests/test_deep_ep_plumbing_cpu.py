@@ -60,3 +60,16 @@ def test_strategy_registry_and_errors():
     with pytest.raises(AssertionError):
         deep_ep.Buffer.set_num_sms(3)
     assert deep_ep.Buffer.get_low_latency_rdma_size_hint(128, 7168, 8, 256) == 128
+    # long-sequence env knobs: same ranges as the reference (csrc/deepep/deep_ep.cpp:63-90)
+    from deep_ep.strategies.normal_strategy import long_seq_rounds
+    for k in ("DEEPEP_NORMAL_LONG_SEQ_ROUND", "DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS"):
+        os.environ.pop(k, None)
+    assert long_seq_rounds() == (1, 8192)
+    os.environ["DEEPEP_NORMAL_LONG_SEQ_ROUND"], os.environ["DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS"] = "16", "8192"
+    assert long_seq_rounds() == (16, 8192)
+    for r, t in (("0", "8192"), ("257", "32"), ("2", "16"), ("2", "9000"), ("32", "8192")):
+        os.environ["DEEPEP_NORMAL_LONG_SEQ_ROUND"], os.environ["DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS"] = r, t
+        with pytest.raises(ValueError):
+            long_seq_rounds()
+    for k in ("DEEPEP_NORMAL_LONG_SEQ_ROUND", "DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS"):
+        os.environ.pop(k, None)
