@@ -49,6 +49,8 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int item = base + u * kWave + lane;
+                    // (nontemporal stores here were measured: the push slows 159 -> 183 us, the reduce that follows speeds
+                    //  up 137 -> 122 us because fewer dirty lines are left behind -- a wash for the step)
                     if (item < n16) d16[item] = v[u];
                 }
             }
