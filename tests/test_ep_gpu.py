@@ -259,3 +259,44 @@ def test_alltoall_transport_kernels_bit_exact(W, T, H, K, E, drop, active, quant
                            [torch.from_numpy(w_).cuda() for w_ in ws])
     for r in range(W):
         assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r]), r
+
+
+# ---- committed fixtures: HIP kernels (through the C-ABI) vs tests/golden/ep_case_*.npz ------------------------------------
+import glob as _glob
+import os as _os
+
+_GOLD = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(_glob.glob(_os.path.join(_GOLD, "ep_case_*.npz"))))
+def test_kernels_reproduce_committed_fixtures(path):
+    import ep_harness as Hh
+    z = np.load(path)
+    W, H, K, E, quant, MT = int(z["W"]), int(z["H"]), int(z["K"]), int(z["E"]), bool(z["quant"]), int(z["max_tokens"])
+    xs, idxs, ws = [z[f"x{r}"] for r in range(W)], [z[f"idx{r}"] for r in range(W)], [z[f"w{r}"] for r in range(W)]
+    h = Hh.InProcEP(W, E, MT, K, H)
+    got = h.dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).cuda() for i in idxs], Hh.QUANT_INT8 if quant else Hh.QUANT_NONE)
+    ys = []
+    for r in range(W):
+        n = len(z[f"recv_src_idx{r}"]) // 3
+        assert got[r]["total"] == n
+        assert np.array_equal(got[r]["recv_src_idx"].cpu().numpy()[:3 * n], z[f"recv_src_idx{r}"])
+        assert np.array_equal(got[r]["tables"]["recv_count"].cpu().numpy().reshape(-1), z[f"send_head{r}"])
+        if quant:
+            assert np.array_equal(got[r]["recv_x"].cpu().numpy()[:n], z[f"recv_x{r}"][:n])
+            assert np.array_equal(got[r]["recv_x_scales"].cpu().numpy()[:n].view(np.uint32), z[f"recv_scales{r}"][:n].view(np.uint32))
+            ys.append(O.per_token_cast_back(z[f"recv_x{r}"], z[f"recv_scales{r}"]))
+        else:
+            assert np.array_equal(torch_to_bits(got[r]["recv_x"])[:n], z[f"recv_x{r}"][:n])
+            ys.append(z[f"recv_x{r}"])
+    comb = h.combine([dev_bf16(y) for y in ys], [g["recv_src_idx"] for g in got], [g["total"] for g in got],
+                     [torch.from_numpy(i).cuda() for i in idxs], [torch.from_numpy(w_).cuda() for w_ in ws])
+    for r in range(W):
+        assert np.array_equal(torch_to_bits(comb[r]), z[f"combined{r}"]), r
+    qm = Hh.QUANT_INT8_NOEPS if quant else Hh.QUANT_NONE
+    ll = h.ll_dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).int().cuda() for i in idxs], qm, 1)
+    for r in range(W):
+        assert np.array_equal(ll[r]["layout_range"].cpu().numpy(), z[f"ll_layout_range{r}"])
+        assert np.array_equal(ll[r]["packed_recv_count"].cpu().numpy(), z[f"ll_recv_count{r}"])
+        n = len(z[f"ll_src_info{r}"]) // 3
+        assert np.array_equal(ll[r]["src_info"].cpu().numpy()[:3 * n], z[f"ll_src_info{r}"])

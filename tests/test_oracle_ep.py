@@ -185,3 +185,35 @@ def test_low_latency_dispatch_contract(W, T, K, E, quant, drop):
     # determinism (test_low_latency.py:448-484): identical inputs -> identical bytes
     res2 = ep.low_latency_dispatch(xs, idxs, T, E, quant)
     assert all(np.array_equal(a.packed_recv_x, b.packed_recv_x) for a, b in zip(res, res2))
+
+
+# ---- committed fixtures (tests/golden/ep_case_*.npz, generated by tests/golden/gen_ep_golden.py) freeze the oracle ---------
+import glob as _glob
+import os as _os
+
+_GOLD = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(_glob.glob(_os.path.join(_GOLD, "ep_case_*.npz"))))
+def test_oracle_reproduces_committed_fixtures(path):
+    z = np.load(path)
+    W, K, E, quant, MT = int(z["W"]), int(z["K"]), int(z["E"]), bool(z["quant"]), int(z["max_tokens"])
+    xs, idxs, ws = [z[f"x{r}"] for r in range(W)], [z[f"idx{r}"] for r in range(W)], [z[f"w{r}"] for r in range(W)]
+    disp = ep.normal_dispatch(xs, idxs, E, quant)
+    ys = [ep.per_token_cast_back(d.recv_x, d.recv_x_scales) if quant else d.recv_x for d in disp]
+    comb = ep.combine(ys, [d.recv_src_idx for d in disp], [d.total_recv for d in disp], idxs, ws, E)
+    ll = ep.low_latency_dispatch(xs, idxs, MT, E, quant)
+    for r in range(W):
+        lay = ep.dispatch_layout(idxs[r], E, W)
+        for k in ("num_tokens_per_rank", "num_tokens_per_expert", "is_token_in_rank", "send_token_idx_small"):
+            assert np.array_equal(np.asarray(lay[k]), z[f"lay_{k}{r}"]), (r, k)
+        n = disp[r].total_recv
+        assert np.array_equal(disp[r].recv_x[:max(n, 1)], z[f"recv_x{r}"])
+        if quant:
+            assert np.array_equal(disp[r].recv_x_scales[:max(n, 1)].view(np.uint32), z[f"recv_scales{r}"].view(np.uint32))
+        assert np.array_equal(disp[r].recv_src_idx[:3 * n], z[f"recv_src_idx{r}"])
+        assert np.array_equal(disp[r].send_head, z[f"send_head{r}"])
+        assert list(z[f"per_expert_list{r}"]) == list(disp[r].num_recv_tokens_per_expert_list)
+        assert np.array_equal(comb[r], z[f"combined{r}"])
+        assert np.array_equal(ll[r].packed_recv_count, z[f"ll_recv_count{r}"]) and np.array_equal(ll[r].layout_range, z[f"ll_layout_range{r}"])
+        assert np.array_equal(ll[r].src_info, z[f"ll_src_info{r}"])
