@@ -65,6 +65,10 @@ def test_against_reference_kernel_outputs(path, splits):
 CASES = [  # B, Hq, Hkv, S, page, ragged
     (2, 16, 1, 200, 64, True), (4, 128, 1, 700, 64, True), (3, 32, 1, 129, 16, True), (2, 8, 1, 64, 128, False),
     (1, 64, 1, 1, 64, False), (2, 128, 1, 1314, 128, True), (2, 64, 8, 333, 32, True), (1, 256, 1, 150, 64, False),
+    # wide (128-heads-per-workgroup) kernel edges: partially filled last wave, odd page size (integer-division path),
+    # sequences shorter than one 32-key tile, two kv heads of 128, page_size 1
+    (2, 96, 1, 200, 48, True), (3, 128, 1, 33, 64, True), (2, 128, 1, 1, 16, False), (1, 256, 2, 130, 64, True),
+    (1, 128, 1, 70, 1, False), (1, 200, 1, 95, 32, False),
 ]
 
 
