@@ -1,5 +1,6 @@
-// pybind11 module `deep_ep_cpp` for MI355X.  Same classes / methods / argument orders as the reference module
-// (csrc/deepep/pybind_extension.cpp:17-55) plus the window bootstrap and the alltoall-strategy kernel entry points.
+// pybind11 module `deep_ep_cpp` for MI355X.  It exposes the classes / method names / positional argument orders that
+// python/deep_ep (and SGLang behind it) call on the reference module (csrc/deepep/pybind_extension.cpp:17-55), plus the
+// hipIpc window bootstrap and the pack / unpack entry points of the RCCL `alltoall` strategies.
 #include <pybind11/functional.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -12,61 +13,75 @@
 #endif
 
 namespace py = pybind11;
+using deep_ep::Buffer;
+
+// one member function under its own name
+#define MI_METHOD(cls, name) cls.def(#name, &Buffer::name)
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "MI355X (gfx950) DeepEP host runtime";
     py::register_exception<deep_ep::EPException>(m, "EPException", PyExc_RuntimeError);
-
-    py::class_<deep_ep::Config>(m, "Config")
-        .def(py::init<int, int, int, int, int>(), py::arg("num_sms") = 20, py::arg("num_max_nvl_chunked_send_tokens") = 6,
-             py::arg("num_max_nvl_chunked_recv_tokens") = 256, py::arg("num_max_rdma_chunked_send_tokens") = 6,
-             py::arg("num_max_rdma_chunked_recv_tokens") = 256)
-        .def_readonly("num_sms", &deep_ep::Config::num_sms)
-        .def("get_nvl_buffer_size_hint", &deep_ep::Config::get_nvl_buffer_size_hint)
-        .def("get_rdma_buffer_size_hint", &deep_ep::Config::get_rdma_buffer_size_hint);
     m.def("get_low_latency_rdma_size_hint", &deep_ep::get_low_latency_rdma_size_hint);
 
-    py::class_<deep_ep::EventHandle>(m, "EventHandle")
-        .def(py::init<>())
-        .def("current_stream_wait", &deep_ep::EventHandle::current_stream_wait);
+    // ---- API-compat value types (reference config.hpp:10-35, event.hpp:6-15)
+    py::class_<deep_ep::Config> config(m, "Config");
+    config.def(py::init<int, int, int, int, int>(), py::arg("num_sms") = 20, py::arg("num_max_nvl_chunked_send_tokens") = 6,
+               py::arg("num_max_nvl_chunked_recv_tokens") = 256, py::arg("num_max_rdma_chunked_send_tokens") = 6,
+               py::arg("num_max_rdma_chunked_recv_tokens") = 256);
+    config.def_readonly("num_sms", &deep_ep::Config::num_sms);
+    config.def("get_nvl_buffer_size_hint", &deep_ep::Config::get_nvl_buffer_size_hint);
+    config.def("get_rdma_buffer_size_hint", &deep_ep::Config::get_rdma_buffer_size_hint);
 
-    py::class_<deep_ep::Buffer>(m, "Buffer")
-        .def(py::init<int, int, int64_t, int64_t, bool, std::string>())
-        // MI355X window bootstrap
-        .def("get_local_device_id", &deep_ep::Buffer::get_local_device_id)
-        .def("get_local_ipc_handle", [](const deep_ep::Buffer &b) { return py::bytes(b.get_local_ipc_handle()); })
-        .def("get_local_window_ptr", &deep_ep::Buffer::get_local_window_ptr)
-        .def("get_window_bytes", &deep_ep::Buffer::get_window_bytes)
-        .def("sync", &deep_ep::Buffer::sync, py::arg("handles"), py::arg("local_ptrs"))
-        // reference surface
-        .def("is_available", &deep_ep::Buffer::is_available)
-        .def("get_num_rdma_ranks", &deep_ep::Buffer::get_num_rdma_ranks)
-        .def("get_rdma_rank", &deep_ep::Buffer::get_rdma_rank)
-        .def("get_dispatch_layout", &deep_ep::Buffer::get_dispatch_layout)
-        .def("get_notify_send_data", &deep_ep::Buffer::get_notify_send_data)
-        .def("clean_low_latency_buffer", &deep_ep::Buffer::clean_low_latency_buffer)
-        .def("intranode_dispatch", &deep_ep::Buffer::intranode_dispatch)
-        .def("notify_verify", &deep_ep::Buffer::notify_verify)
-        .def("intranode_combine", &deep_ep::Buffer::intranode_combine)
-        .def("internode_dispatch", [](deep_ep::Buffer &b, py::args, py::kwargs) { b.internode_unsupported(); })
-        .def("internode_combine", [](deep_ep::Buffer &b, py::args, py::kwargs) { b.internode_unsupported(); })
-        .def("low_latency_dispatch", &deep_ep::Buffer::low_latency_dispatch)
-        .def("low_latency_combine", &deep_ep::Buffer::low_latency_combine)
-        .def("fused_deep_moe", &deep_ep::Buffer::fused_deep_moe, py::arg("x"), py::arg("expert_ids"),
-             py::arg("gmm1_permuted_weight"), py::arg("gmm1_permuted_weight_scale"), py::arg("gmm2_weight"),
-             py::arg("gmm2_weight_scale"), py::arg("expert_scales_optional"), py::arg("num_max_dispatch_tokens_per_rank"),
-             py::arg("num_experts"), py::arg("quant_mode"), py::arg("profile_enable") = false)
-        .def("begin_profile", &deep_ep::Buffer::begin_profile, py::arg("num_profile_skip_launches"),
-             py::arg("num_profile_active_launches"), py::arg("profile_trace_dir") = "")
-        .def("end_profile", &deep_ep::Buffer::end_profile)
-        .def("get_profile_summary", &deep_ep::Buffer::get_profile_summary)
-        .def("dispatch_ffn_combine", &deep_ep::Buffer::dispatch_ffn_combine)
-        // alltoall-strategy kernel entry points
-        .def("a2a_dispatch_stage", &deep_ep::Buffer::a2a_dispatch_stage)
-        .def("a2a_dispatch_tables", &deep_ep::Buffer::a2a_dispatch_tables)
-        .def("a2a_dispatch_unpack", &deep_ep::Buffer::a2a_dispatch_unpack)
-        .def("a2a_combine_pack", &deep_ep::Buffer::a2a_combine_pack)
-        .def("a2a_combine_prepare", &deep_ep::Buffer::a2a_combine_prepare)
-        .def("a2a_combine_reduce", &deep_ep::Buffer::a2a_combine_reduce);
+    py::class_<deep_ep::EventHandle> event(m, "EventHandle");
+    event.def(py::init<>());
+    event.def("current_stream_wait", &deep_ep::EventHandle::current_stream_wait);
+
+    py::class_<Buffer> buf(m, "Buffer");
+    buf.def(py::init<int, int, int64_t, int64_t, bool, std::string>());
+
+    // ---- MI355X only: symmetric-window bootstrap over hipIpc (replaces the HCCL window lookup by communicator name)
+    MI_METHOD(buf, get_local_device_id);
+    MI_METHOD(buf, get_local_window_ptr);
+    MI_METHOD(buf, get_window_bytes);
+    buf.def("get_local_ipc_handle", [](const Buffer &b) { return py::bytes(b.get_local_ipc_handle()); });
+    buf.def("sync", &Buffer::sync, py::arg("handles"), py::arg("local_ptrs"));
+
+    // ---- queries
+    MI_METHOD(buf, is_available);
+    MI_METHOD(buf, get_num_rdma_ranks);
+    MI_METHOD(buf, get_rdma_rank);
+    MI_METHOD(buf, get_notify_send_data);
+
+    // ---- normal (high-throughput) mode
+    MI_METHOD(buf, get_dispatch_layout);
+    MI_METHOD(buf, intranode_dispatch);
+    MI_METHOD(buf, intranode_combine);
+    MI_METHOD(buf, notify_verify);
+    for (const char *name : {"internode_dispatch", "internode_combine"})      // one xGMI node is a single rdma rank
+        buf.def(name, [](Buffer &b, py::args, py::kwargs) { b.internode_unsupported(); });
+
+    // ---- low-latency mode and the fused MoE paths
+    MI_METHOD(buf, clean_low_latency_buffer);
+    MI_METHOD(buf, low_latency_dispatch);
+    MI_METHOD(buf, low_latency_combine);
+    MI_METHOD(buf, dispatch_ffn_combine);
+    buf.def("fused_deep_moe", &Buffer::fused_deep_moe, py::arg("x"), py::arg("expert_ids"), py::arg("gmm1_permuted_weight"),
+            py::arg("gmm1_permuted_weight_scale"), py::arg("gmm2_weight"), py::arg("gmm2_weight_scale"),
+            py::arg("expert_scales_optional"), py::arg("num_max_dispatch_tokens_per_rank"), py::arg("num_experts"),
+            py::arg("quant_mode"), py::arg("profile_enable") = false);
+
+    // ---- per-kernel profiler (HIP events on the caller's stream)
+    buf.def("begin_profile", &Buffer::begin_profile, py::arg("num_profile_skip_launches"), py::arg("num_profile_active_launches"),
+            py::arg("profile_trace_dir") = "");
+    MI_METHOD(buf, end_profile);
+    MI_METHOD(buf, get_profile_summary);
+
+    // ---- MI355X only: pack / unpack kernels behind the RCCL `alltoall` strategies
+    MI_METHOD(buf, a2a_dispatch_stage);
+    MI_METHOD(buf, a2a_dispatch_tables);
+    MI_METHOD(buf, a2a_dispatch_unpack);
+    MI_METHOD(buf, a2a_combine_pack);
+    MI_METHOD(buf, a2a_combine_prepare);
+    MI_METHOD(buf, a2a_combine_reduce);
 }

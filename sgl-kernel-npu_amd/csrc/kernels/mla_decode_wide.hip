@@ -273,6 +273,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_sched_barrier(0);
         // lane owns head c32 and keys 8 (r>>2) + 4 kg + (r&3); only the tile that crosses seq_len needs the mask
         if ((t + 1) * kT2 > seq_len) {
+            asm volatile("" ::: "memory");                     // keep this a real (wave-uniform) branch: if-converted it costs
+                                                               // ~40 VALU ops on every tile instead of only the last one
             const int kbase = t * kT2 + 4 * kg;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
