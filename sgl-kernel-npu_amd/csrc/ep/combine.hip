@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < K && ((vmask >> k) & 1ull))
-                v[k] = *(const u32x4 *)(slots + (size_t)slot[k] * slot_stride + (size_t)c * 16);
+                // read-once stream: nontemporal loads keep the 0.47 GB of slots out of L2/MALL (measured 141 -> 102 us at C2)
+                v[k] = __builtin_nontemporal_load((const u32x4 *)(slots + (size_t)slot[k] * slot_stride + (size_t)c * 16));
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;

@@ -18,6 +18,10 @@
 #define MLAW_PV_AHEAD 6
 #endif
 
+#ifndef MLAW_CP
+#define MLAW_CP ""          // cache-policy suffix of the KV LDS-DMA; " nt" / " sc1" / " sc0 sc1" measured: no effect at C4
+#endif
+
 namespace mi_sgl {
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -103,11 +107,11 @@ __device__ __forceinline__ uint32_t lds_addr(const void *generic)
 }
 __device__ __forceinline__ void dma16_sbase(uint32_t dst, const void *sbase, uint32_t voff)      // lane l: 16 B from sbase + voff -> dst + 16 l
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MLAW_CP ::"s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16_vaddr(uint32_t dst, const void *vaddr)                      // lane l: 16 B from its own address
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(vaddr) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MLAW_CP ::"s"(dst), "v"(vaddr) : "memory", "m0");
 }
 __device__ __forceinline__ void dma4_vaddr(uint32_t dst, const void *vaddr)                       // lane l: 4 B -> dst + 4 l
 {
