@@ -8,9 +8,6 @@
 #include "mi_sgl_kernels.h"
 #include "mla_common.h"
 
-#ifndef MLAW_QK_AHEAD
-#define MLAW_QK_AHEAD 8
-#endif
 #ifndef MLAW_PIPE
 #define MLAW_PIPE 0          // 1: softmax of tile t runs under the QK^T MFMAs of tile t+1 (2 tiles of DMA in flight instead of 3); measured: no gain
 #endif
@@ -26,9 +23,18 @@ namespace mi_sgl {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Wide variant: kv groups of more than 64 heads (DeepSeek DP-attention decode: 128 heads on one latent head, BASELINE C4).
-// One workgroup = ALL 128 heads of a (sequence, KV split): 4 waves x 32 heads on v_mfma_f32_32x32x16 -- twice the FLOPs per
+// One workgroup = ALL 128 heads of a (sequence, KV split): 4 waves on v_mfma_f32_32x32x16 -- twice the FLOPs per
 // LDS operand byte and per issue slot of the 16x16x32 form, and each KV tile enters a CU's LDS once for 128 heads instead
 // of once per 64 (the 64-head kernel above relies on L2 for its second reader; here L2->LDS traffic = HBM traffic).
+// The two contractions split the work differently (MLAW_X, default): QK^T and the softmax by HEAD (wave w: heads 32 w ..+32,
+// all 576 dims, Q^T in registers), P.V by OUTPUT DIMENSION (wave w: dims 128 w ..+128 of all 128 heads).  P^T (bf16, 8 KB
+// per tile) crosses between the two through an LDS exchange buffer; in return a V tile is read from LDS once per workgroup
+// instead of once per wave (24 LDS reads per wave and tile instead of 64 -- with one wave per SIMD a 64-bit LDS read costs
+// ~25 issue cycles, and the head-split P.V ran at 52 cycles per MFMA because of it).  Tile pipeline per wave:
+//   barrier A | publish P^T(t) | QK^T(t+1) (+ DMA of tile t+3) | barrier B | P(t).V(t) with the softmax of tile t+1 in the
+//   shadow of its 32 independent MFMAs                                                    (2 tiles of DMA in flight).
+// Measured per tile and wave (shader clocks, C4): barrier A + wait 455, QK^T 2250, barrier B + P.V 1390 -- 4.1k against 4.3k
+// for the head-split P.V (MLAW_X=0, kept for comparison: 3 tiles in flight, no exchange).
 //  * registers: 16 accumulator blocks x 16 = 256 AGPRs, Q^T resident in 144 VGPRs; nothing is staged through registers:
 //    tiles of 32 keys arrive by LDS-DMA, one 1-KiB piece per 4 QK k-steps, into a ring of 4 LDS slots (3 tiles = 111 KB in
 //    flight per CU).  Block-table entries travel the same way (4-byte LDS-DMA into a small per-wave ring), so no vector
@@ -36,7 +42,7 @@ namespace mi_sgl {
 //    youngest tiles in flight;
 //  * layouts (lane = (c32 = lane & 31, kg = lane >> 5)): S^T[key, head] = K.Q^T with A = K rows (lane: key c32, dims
 //    16 ks + 8 kg ..+8), B = Q^T (lane: head c32, same dims), C regs r -> key 8 (r>>2) + 4 kg + (r&3); O^T[d, head] += V^T.P^T
-//    with B = P^T straight from the packed C registers and A = V^T via ds_read_b64_tr_b16.  MFMA row m of output block db
+//    with B = P^T = the packed C registers (through the exchange buffer, same lane index) and A = V^T via ds_read_b64_tr_b16.  MFMA row m of output block db
 //    is d = 128 (db>>2) + 64 (m>>4) + 16 (db&3) + (m&15), which makes the 32-lane tr-read footprint (4 keys x 2 x 32 B)
 //    tile the 64 banks under the 1056-B row stride; 16-B chunks of rows 8..15 and 24..31 are swapped pairwise (applied on
 //    the DMA source side) so the 16-lane ds_read_b128 groups of the QK operand are conflict-free too.
@@ -44,9 +50,19 @@ namespace mi_sgl {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kT2 = kWideTile, kSlots = 4;
 constexpr int kSlotBytes = kT2 * kNopeStride + kT2 * kRopeStride;      // 37888
-constexpr int kRingBytes = 4 * kSlots * 64 * 4;                        // per-wave block-table rings
-constexpr int kFlagOff = kSlots * kSlotBytes + kRingBytes;            // restart flag (4 B)
-constexpr int kWideLds = kFlagOff + 16;                                // 155664
+#ifndef MLAW_X
+#define MLAW_X 1            // P.V by output-dimension slices with P exchanged through LDS (see pv_x)
+#endif
+#ifndef MLAW_QK_AHEAD
+#define MLAW_QK_AHEAD (MLAW_X ? 6 : 8)      // K operand fragments in flight; 7+ with the exchange spills Q^T inside the tile loop
+#endif
+constexpr int kRingEntries = MLAW_X ? 32 : 64;                         // block ids per (wave, slot): lanes 32..63 mirror 0..31
+constexpr int kRingBytes = 4 * kSlots * kRingEntries * 4;              // per-wave block-table rings
+constexpr int kPOff = kSlots * kSlotBytes + kRingBytes;                // P^T exchange buffer [head block 4][k-step 2][lane 64] x 16 B
+constexpr int kPBytes = MLAW_X ? 8192 : 0;
+constexpr int kFlagOff = kPOff + kPBytes;                              // restart flag (4 B)
+constexpr int kWideLds = kFlagOff + 16;                                // 161808 (155664 without the exchange)
+static_assert(kWideLds <= 160 * 1024, "LDS budget");
 
 // S^T chain in VGPRs (see the register plan above)
 template <bool BF16>
@@ -123,14 +139,14 @@ __device__ __forceinline__ void wide_issue_rows(const WideCtx &c, int tile)
 {
     const int page = wide_page(c, wide_key(c, tile));
     const int32_t *src = c.p->block_table + (int64_t)c.b * c.p->bt_stride + page;
-    dma4_vaddr(c.ring_addr + (uint32_t)((tile & (kSlots - 1)) * 256), src);
+    if (kRingEntries == 64 || c.lane < kRingEntries) dma4_vaddr(c.ring_addr + (uint32_t)((tile & (kSlots - 1)) * kRingEntries * 4), src);
 }
 
 __device__ __forceinline__ TileRows wide_rows(const WideCtx &c, int tile)
 {
     const int n = wide_key(c, tile);
     const int page = wide_page(c, n), row = n - page * c.p->page_size;
-    const int64_t blk = (int32_t)c.ring[(tile & (kSlots - 1)) * 64 + c.lane];
+    const int64_t blk = (int32_t)c.ring[(tile & (kSlots - 1)) * kRingEntries + (c.lane & (kRingEntries - 1))];
     TileRows r;
     r.nope = blk * c.p->kn_sblk + (int64_t)row * c.p->kn_srow + (int64_t)c.kvh * c.p->kn_sh;
     r.rope = blk * c.p->kr_sblk + (int64_t)row * c.p->kr_srow + (int64_t)c.kvh * c.p->kr_sh;
@@ -178,10 +194,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool head_ok = hg < p.group;
     const bool wave_active = hblk * 128 + wave * 32 < p.group;       // wave-uniform; idle waves still feed the DMA
     const int head = kvh * p.group + hg;
-    WideCtx cx{&p, b, kvh, seq_len, wave, lane, lds, (uint32_t *)(lds + kSlots * kSlotBytes) + wave * kSlots * 64, 0, 0,
+    WideCtx cx{&p, b, kvh, seq_len, wave, lane, lds, (uint32_t *)(lds + kSlots * kSlotBytes) + wave * kSlots * kRingEntries, 0, 0,
                (p.page_size & (p.page_size - 1)) == 0 ? __builtin_ctz(p.page_size) : -1};
     cx.lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));
-    cx.ring_addr = cx.lds_base + (uint32_t)(kSlots * kSlotBytes + wave * kSlots * 256);
+    cx.ring_addr = cx.lds_base + (uint32_t)(kSlots * kSlotBytes + wave * kSlots * kRingEntries * 4);
 
     // Q^T fragments: lane (c32, kg) holds q[head][16 ks + 8 kg .. +8]
     s16x8 qf[36];
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // kLead = how many tiles ahead of the one entering QK^T the fill is issued (slot ring of 4: the pipelined loop still reads
     // tile t-1 for P.V while tile t is in QK^T, so it can only run 2 ahead).  Issue order per tile x: R(x + kLead + 2), D(x + kLead);
     // the wait at the top of tile x leaves the (kLead - 1) youngest fills and their row loads in flight.
-    constexpr int kLead = MLAW_PIPE ? 2 : 3;
+    constexpr int kLead = (MLAW_PIPE || MLAW_X) ? 2 : 3;
     auto tile_top = [&](int t) -> TileRows {
 #ifndef MLAW_NO_PIECES
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * (kLead - 1) - 1 + (kLead == 3 ? 0 : 1)) : "memory");
@@ -232,6 +248,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     if (t_begin < t_end) prologue();
+#if MLAW_X
+    // ---- O^T[d, head] += V^T . P^T, split by OUTPUT DIMENSION: wave w owns d in [128 w, 128 w + 128) for all 128 heads of the
+    // workgroup (accumulator block dbl*4 + hb = 32 dims x 32 heads), so a V tile is read from LDS once per workgroup instead
+    // of once per wave: 16 ds_read_b64_tr_b16 + 8 ds_read_b128 per wave and tile instead of 64 transpose reads.  With one
+    // wave per SIMD a 64-bit LDS read costs ~25 issue cycles, which made the head-split P.V LDS-issue-bound (52 cycles per
+    // MFMA).  P^T of the other head blocks comes through the exchange buffer: lane l of wave hb stores its two packed
+    // B-operand fragments at [hb][kk][l]; after a barrier every wave reads all eight.
+    uint8_t *const pbuf = lds + kPOff;
+    auto pv_x = [&](int t, auto &&embed) {                     // starts with barrier B
+        const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
+        const uint8_t *pb = pbuf + lane * 16;
+        const int c16 = lane & 15, q16 = (lane >> 4) & 1;
+        // rows 8..15 / 24..31 (the `hi` halves) have their 16-B chunk pairs swapped: XOR 16 on the lane's byte offset
+        const uint8_t *vlo = buf + (4 * kg + (c16 >> 2)) * kNopeStride + wave * 256 + q16 * 128 + (c16 & 3) * 8;
+        const uint8_t *vhi = buf + (4 * kg + (c16 >> 2) + 8) * kNopeStride + wave * 256 + q16 * 128 + (((c16 & 3) * 8) ^ 16);
+        auto lda = [&](int step) -> s16x8 {                    // step = kk * 4 + dbl
+            const int off = (step >> 2) * 16 * kNopeStride + (step & 3) * 32;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vhi + off));
+            return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto ldp = [&](int hb, int kk) -> s16x8 { return *(const s16x8 *)(pb + (hb * 2 + kk) * 1024); };
+        s16x8 pfr[4], af[3];
+        __builtin_amdgcn_sched_barrier(0);
+        af[0] = lda(0);                                        // V(t) has been resident since barrier A: its first fragments
+        af[1] = lda(1);                                        // are requested BEFORE barrier B and land while the wave waits there
+        __builtin_amdgcn_sched_barrier(0);
+        // barrier B.  LDS operations of a wave complete in order, so "all but the 4 youngest" covers this wave's P^T stores.
+        asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) pfr[hb] = ldp(hb, 0);
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < 8) af[(step + 2) % 3] = lda(step + 2);
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) {
+                const int a = (step & 3) * 4 + hb;
+                acc[a] = mfma32<BF16>(af[step % 3], pfr[hb], acc[a]);
+                if (step == 3) pfr[hb] = ldp(hb, 1);           // k-step 1 fragments, four MFMAs ahead of their first use
+            }
+            embed(step);                                       // softmax of the NEXT tile: VALU in the shadow of these independent MFMAs
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto no_embed = [](int) {};
+    auto fill_only = [&](int t) {
+        const TileRows rows3 = tile_top(t);
+        const uint32_t nslot = cx.lds_base + (uint32_t)(((t + kLead) & (kSlots - 1)) * kSlotBytes);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wide_issue_piece(cx, rows3, nslot, i);
+    };
+    if (!wave_active) {                                        // no heads of its own: P = 0 for its block, DMA share and P.V slice as usual
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) *(u32x4 *)(pbuf + ((wave * 2 + kk) * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t_begin < t_end) {
+            fill_only(t_begin);
+            for (int t = t_begin; t + 1 < t_end; ++t) {
+                fill_only(t + 1);
+                pv_x(t, no_embed);
+            }
+            __syncthreads();
+            pv_x(t_end - 1, no_embed);
+        }
+    }
+#else
     if (!wave_active) {                                        // idle waves only feed the DMA (same barriers as the others)
         for (int t = t_begin; t < t_end; ++t) {
             const TileRows rows3 = tile_top(t);
@@ -243,6 +326,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();                                       // pairs with the flag barrier of the active waves
         return;
     }
+
+#endif
 
     // ---- S^T[key, head] = K . Q^T : 36 k-steps of 16 dims, operand ring kAhead deep, one DMA piece per 4 k-steps;
     // returns the tile maximum per head in the scaled log2 domain
@@ -256,18 +341,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (ks < 32) return *(const s16x8 *)(abase + ks * 32);
             return *(const s16x8 *)(rbase + ((((ks - 32) * 2 + kg) ^ (c32 & 7)) << 4));
         };
-        constexpr int kAhead = MLAW_QK_AHEAD;
-        s16x8 af[kAhead + 1];
+        constexpr int kAhead = MLAW_QK_AHEAD, kRing = kAhead + 1;
+        s16x8 af[kRing];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pre = 0; pre < kAhead; ++pre) af[pre] = lda(pre);
 #pragma unroll
         for (int ks = 0; ks < 36; ++ks) {
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + kAhead < 36) af[(ks + kAhead) % (kAhead + 1)] = lda(ks + kAhead);
+            if (ks + kAhead < 36) af[(ks + kAhead) % kRing] = lda(ks + kAhead);
             __builtin_amdgcn_sched_barrier(0);
             if (ks == 0) mfma32_first<BF16>(s, af[0], qf[0]);
-            else mfma32_acc<BF16>(s, af[ks % (kAhead + 1)], qf[ks]);
+            else mfma32_acc<BF16>(s, af[ks % kRing], qf[ks]);
 #ifndef MLAW_NO_PIECES
             if ((ks & 3) == 0) wide_issue_piece(cx, rows3, nslot, ks >> 2);
 #endif
@@ -358,7 +443,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define MLAW_TICK(i)
 #endif
     auto noop = [](int) {};
-#if MLAW_PIPE
+#if MLAW_X
+    // software pipeline over tiles.  Interval i (between two tile_top barriers): publish P^T(i) (computed in the previous
+    // interval, still in registers) to the exchange buffer, QK^T of tile i+1, barrier B, then this wave's dimension slice of
+    // P(i).V(i) with the softmax of tile i+1 in the shadow of its 32 independent MFMAs.  (Under the QK^T chain the same VALU
+    // work is NOT free: every instruction between two MFMAs on one accumulator breaks their back-to-back issue.)
+    // Barrier A (tile_top): tile i+1 landed, everybody is done with V(i-1) and with the exchange buffer; barrier B: P^T(i) complete.
+    auto publish = [&](float psum, const uint32_t (&pk)[8]) {
+        psum += __shfl_xor(psum, 32, 64);
+        l_run += psum;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            *(u32x4 *)(pbuf + ((wave * 2 + kk) * 64 + lane) * 16) = u32x4{pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // stores done here, whatever gets scheduled before barrier B
+    };
+    if (wave_active && t_begin < t_end) {
+        f32x16 s;
+        float psum = 0.f, nm = 0.f;
+        uint32_t pk[8];
+        // the two empty asm statements pin a piece between the MFMA groups it is written next to (the compiler otherwise
+        // gathers all sixteen exponentials after the last MFMA)
+        auto piece = [&](int i) {
+            float a0 = s[2 * i], a1 = s[2 * i + 1];
+            asm volatile("" : "+v"(a0), "+v"(a1));
+            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(a0, cs, nm));
+            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(a1, cs, nm));
+            psum += e0 + e1;
+            pk[i] = pack2<BF16>(e0, e1);
+            asm volatile("" : "+v"(pk[i]), "+v"(psum));
+        };
+        {
+            const TileRows rows = tile_top(t_begin);
+            const float tmax = qk(t_begin, rows, s, noop);
+            m_run = tmax;
+            nm = (m_run == -INFINITY) ? 0.f : -m_run;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) piece(i);
+        }
+        for (int t = t_begin; t + 1 < t_end; ++t) {
+#ifdef MLAW_TIMING
+            c0 = __builtin_amdgcn_s_memtime();
+#endif
+            const TileRows rows = tile_top(t + 1);
+            MLAW_TICK(0)
+            publish(psum, pk);
+            psum = 0.f;
+            const float tmax = qk(t + 1, rows, s, noop);
+            if (__any(tmax > m_run + kGuard)) *flag = 1;
+            MLAW_TICK(1)
+            pv_x(t, piece);
+            MLAW_TICK(2)
+        }
+        __syncthreads();
+        publish(psum, pk);
+        pv_x(t_end - 1, no_embed);
+    }
+#elif MLAW_PIPE
     // software pipeline over tiles: QK^T of tile t+1 (MFMA) carries the softmax of tile t (VALU) in its issue gaps
     if (t_begin < t_end) {
         f32x16 s_cur;
@@ -414,6 +554,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     if (threadIdx.x == 0 && *flag != 0) p.fix_flags[b * p.kv_heads + kvh] = p.fix_epoch;
 
+#if MLAW_X
+    // ---- epilogue: wave w holds acc[dbl*4 + hb][4 rg + i] = O^T[d][head 32 hb + c32], d = 128 w + 64 (rg>>1) + 16 dbl + 8 (rg&1) + 4 kg + i;
+    // the softmax statistics of a head live in the wave that owns it and reach the others through LDS
+    float *lmb = (float *)pbuf;                                // [0..127] l, [128..255] m (all P.V reads are behind the barrier above)
+    if (kg == 0) {
+        lmb[wave * 32 + c32] = wave_active ? l_run : 0.f;
+        lmb[128 + wave * 32 + c32] = wave_active ? m_run : -INFINITY;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+        const int hgx = hblk * 128 + hb * 32 + c32;
+        if (hgx >= p.group) continue;
+        const int headx = kvh * p.group + hgx;
+        const float l_h = lmb[hb * 32 + c32];
+        if (p.num_splits == 1) {
+            const float inv = l_h > 0.f ? 1.f / l_h : 0.f;
+            uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + wave * 128 + 4 * kg;
+#pragma unroll
+            for (int dbl = 0; dbl < 4; ++dbl)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = (rg >> 1) * 64 + dbl * 16 + (rg & 1) * 8;
+                    const f32x16 &a = acc[dbl * 4 + hb];
+                    const uint32_t w0 = (uint32_t)cvt_out<BF16>(a[4 * rg + 0] * inv) | ((uint32_t)cvt_out<BF16>(a[4 * rg + 1] * inv) << 16);
+                    const uint32_t w1 = (uint32_t)cvt_out<BF16>(a[4 * rg + 2] * inv) | ((uint32_t)cvt_out<BF16>(a[4 * rg + 3] * inv) << 16);
+                    *(uint2 *)(orow + d) = uint2{w0, w1};
+                }
+        } else {
+            const int64_t idx = ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
+            float *po = p.ws_o + idx * kDN + wave * 128 + 4 * kg;
+#pragma unroll
+            for (int dbl = 0; dbl < 4; ++dbl)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = (rg >> 1) * 64 + dbl * 16 + (rg & 1) * 8;
+                    const f32x16 &a = acc[dbl * 4 + hb];
+                    *(f32x4 *)(po + d) = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
+                }
+            if (wave == 0 && kg == 0) {
+                p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + c32];
+                p.ws_ml[idx * 2 + 1] = l_h;
+            }
+        }
+    }
+}
+#else
     // ---- epilogue: acc[db][4 rg + i] = O^T[d][head c32], d = 128 (db>>2) + 64 (rg>>1) + 16 (db&3) + 8 (rg&1) + 4 kg + i
     if (!head_ok) return;
     if (p.num_splits == 1) {
@@ -444,6 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
 }
+#endif
 
 
 void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t st)
