@@ -8,12 +8,6 @@
 #include "mi_sgl_kernels.h"
 #include "mla_common.h"
 
-#ifndef MLAW_PIPE
-#define MLAW_PIPE 0          // 1: softmax of tile t runs under the QK^T MFMAs of tile t+1 (2 tiles of DMA in flight instead of 3); measured: no gain
-#endif
-#ifndef MLAW_PV_AHEAD
-#define MLAW_PV_AHEAD 6
-#endif
 
 #ifndef MLAW_CP
 #define MLAW_CP ""          // cache-policy suffix of the KV LDS-DMA; " nt" / " sc1" / " sc0 sc1" measured: no effect at C4
@@ -26,7 +20,7 @@ namespace mi_sgl {
 // One workgroup = ALL 128 heads of a (sequence, KV split): 4 waves on v_mfma_f32_32x32x16 -- twice the FLOPs per
 // LDS operand byte and per issue slot of the 16x16x32 form, and each KV tile enters a CU's LDS once for 128 heads instead
 // of once per 64 (the 64-head kernel above relies on L2 for its second reader; here L2->LDS traffic = HBM traffic).
-// The two contractions split the work differently (MLAW_X, default): QK^T and the softmax by HEAD (wave w: heads 32 w ..+32,
+// The two contractions split the work differently: QK^T and the softmax by HEAD (wave w: heads 32 w ..+32,
 // all 576 dims, Q^T in registers), P.V by OUTPUT DIMENSION (wave w: dims 128 w ..+128 of all 128 heads).  P^T (bf16, 8 KB
 // per tile) crosses between the two through an LDS exchange buffer; in return a V tile is read from LDS once per workgroup
 // instead of once per wave (24 LDS reads per wave and tile instead of 64 -- with one wave per SIMD a 64-bit LDS read costs
@@ -34,7 +28,7 @@ namespace mi_sgl {
 //   barrier A | publish P^T(t) | QK^T(t+1) (+ DMA of tile t+3) | barrier B | P(t).V(t) with the softmax of tile t+1 in the
 //   shadow of its 32 independent MFMAs                                                    (2 tiles of DMA in flight).
 // Measured per tile and wave (shader clocks, C4): barrier A + wait 455, QK^T 2250, barrier B + P.V 1390 -- 4.1k against 4.3k
-// for the head-split P.V (MLAW_X=0, kept for comparison: 3 tiles in flight, no exchange).
+// for the earlier head-split P.V (3 tiles in flight, no exchange, softmax exposed between QK^T and P.V).
 //  * registers: 16 accumulator blocks x 16 = 256 AGPRs, Q^T resident in 144 VGPRs; nothing is staged through registers:
 //    tiles of 32 keys arrive by LDS-DMA, one 1-KiB piece per 4 QK k-steps, into a ring of 4 LDS slots (3 tiles = 111 KB in
 //    flight per CU).  Block-table entries travel the same way (4-byte LDS-DMA into a small per-wave ring), so no vector
@@ -50,18 +44,15 @@ namespace mi_sgl {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kT2 = kWideTile, kSlots = 4;
 constexpr int kSlotBytes = kT2 * kNopeStride + kT2 * kRopeStride;      // 37888
-#ifndef MLAW_X
-#define MLAW_X 1            // P.V by output-dimension slices with P exchanged through LDS (see pv_x)
-#endif
 #ifndef MLAW_QK_AHEAD
-#define MLAW_QK_AHEAD (MLAW_X ? 6 : 8)      // K operand fragments in flight; 7+ with the exchange spills Q^T inside the tile loop
+#define MLAW_QK_AHEAD 6      // K operand fragments in flight (more does not pay: the chain is not waiting on them)
 #endif
-constexpr int kRingEntries = MLAW_X ? 32 : 64;                         // block ids per (wave, slot): lanes 32..63 mirror 0..31
+constexpr int kRingEntries = 32;                         // block ids per (wave, slot): lanes 32..63 mirror 0..31
 constexpr int kRingBytes = 4 * kSlots * kRingEntries * 4;              // per-wave block-table rings
 constexpr int kPOff = kSlots * kSlotBytes + kRingBytes;                // P^T exchange buffer [head block 4][k-step 2][lane 64] x 16 B
-constexpr int kPBytes = MLAW_X ? 8192 : 0;
+constexpr int kPBytes = 8192;
 constexpr int kFlagOff = kPOff + kPBytes;                              // restart flag (4 B)
-constexpr int kWideLds = kFlagOff + 16;                                // 161808 (155664 without the exchange)
+constexpr int kWideLds = kFlagOff + 16;                                // 161808
 static_assert(kWideLds <= 160 * 1024, "LDS budget");
 
 // S^T chain in VGPRs (see the register plan above)
@@ -115,7 +106,7 @@ __device__ __forceinline__ int wide_key(const WideCtx &c, int tile)
 
 // LDS-DMA issued through inline asm: the compiler then sees no vector-memory operation in the tile loop and places no
 // vmcnt wait of its own (with the builtin it put an `s_waitcnt vmcnt(0)` in front of the first transpose read of every
-// tile, i.e. the whole fill latency sat between QK and PV).  Ordering is explicit instead: one `s_waitcnt vmcnt(19)` per
+// tile, i.e. the whole fill latency sat between QK and PV).  Ordering is explicit instead: one `s_waitcnt vmcnt(10)` per
 // tile.  M0 carries the (wave-uniform) LDS destination; one wait state separates its write from the load.
 __device__ __forceinline__ uint32_t lds_addr(const void *generic)
 {
@@ -139,7 +130,7 @@ __device__ __forceinline__ void wide_issue_rows(const WideCtx &c, int tile)
 {
     const int page = wide_page(c, wide_key(c, tile));
     const int32_t *src = c.p->block_table + (int64_t)c.b * c.p->bt_stride + page;
-    if (kRingEntries == 64 || c.lane < kRingEntries) dma4_vaddr(c.ring_addr + (uint32_t)((tile & (kSlots - 1)) * kRingEntries * 4), src);
+    if (c.lane < kRingEntries) dma4_vaddr(c.ring_addr + (uint32_t)((tile & (kSlots - 1)) * kRingEntries * 4), src);
 }
 
 __device__ __forceinline__ TileRows wide_rows(const WideCtx &c, int tile)
@@ -220,15 +211,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): Q^T is resident; no compiler-visible vector load
                                                                // is pending when the tile loop starts (see dma16_sbase)
     const float cs = p.sm_scale * 1.4426950408889634f;
-    // top of a tile: own pieces of tile t and the block ids of tile t+3 have landed (D(t+1), R(t+4), D(t+2) may still
-    // fly); after the barrier tile t is complete in LDS and the slot of tile t-1 is free for tile t+3
-    // kLead = how many tiles ahead of the one entering QK^T the fill is issued (slot ring of 4: the pipelined loop still reads
-    // tile t-1 for P.V while tile t is in QK^T, so it can only run 2 ahead).  Issue order per tile x: R(x + kLead + 2), D(x + kLead);
-    // the wait at the top of tile x leaves the (kLead - 1) youngest fills and their row loads in flight.
-    constexpr int kLead = (MLAW_PIPE || MLAW_X) ? 2 : 3;
+    // kLead = how many tiles ahead of the one entering QK^T the fill is issued.  The slot ring has 4 entries and the loop still
+    // reads tile t-1 for P.V while tile t is in QK^T, so the fill runs 2 ahead.  Issue order per tile x: R(x + kLead + 2) (block
+    // ids), D(x + kLead) (9 pieces) = 10 vector-memory operations; the wait at the top of tile x leaves the youngest 10 in
+    // flight, i.e. this wave's pieces of tile x and the block ids of tile x + kLead have landed.  After the barrier tile x
+    // is complete in LDS and the slot of tile x-2 is free for tile x+2.
+    constexpr int kLead = 2;
     auto tile_top = [&](int t) -> TileRows {
 #ifndef MLAW_NO_PIECES
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * (kLead - 1) - 1 + (kLead == 3 ? 0 : 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 #endif
         __syncthreads();
         wide_issue_rows(cx, t + kLead + 2);
@@ -248,7 +239,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     if (t_begin < t_end) prologue();
-#if MLAW_X
     // ---- O^T[d, head] += V^T . P^T, split by OUTPUT DIMENSION: wave w owns d in [128 w, 128 w + 128) for all 128 heads of the
     // workgroup (accumulator block dbl*4 + hb = 32 dims x 32 heads), so a V tile is read from LDS once per workgroup instead
     // of once per wave: 16 ds_read_b64_tr_b16 + 8 ds_read_b128 per wave and tile instead of 64 transpose reads.  With one
@@ -314,24 +304,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             pv_x(t_end - 1, no_embed);
         }
     }
-#else
-    if (!wave_active) {                                        // idle waves only feed the DMA (same barriers as the others)
-        for (int t = t_begin; t < t_end; ++t) {
-            const TileRows rows3 = tile_top(t);
-            const uint32_t nslot = cx.lds_base + (uint32_t)(((t + kLead) & (kSlots - 1)) * kSlotBytes);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wide_issue_piece(cx, rows3, nslot, i);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                       // pairs with the flag barrier of the active waves
-        return;
-    }
-
-#endif
 
     // ---- S^T[key, head] = K . Q^T : 36 k-steps of 16 dims, operand ring kAhead deep, one DMA piece per 4 k-steps;
     // returns the tile maximum per head in the scaled log2 domain
-    auto qk = [&](int t, const TileRows &rows3, f32x16 &s, auto &&between) -> float {
+    auto qk = [&](int t, const TileRows &rows3, f32x16 &s) -> float {
         const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
         const uint32_t nslot = cx.lds_base + (uint32_t)(((t + kLead) & (kSlots - 1)) * kSlotBytes);
         // (2 ks + kg) ^ sw == 2 ks + (kg ^ sw): the swizzle folds into the lane base, k-steps are immediate offsets
@@ -356,7 +332,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef MLAW_NO_PIECES
             if ((ks & 3) == 0) wide_issue_piece(cx, rows3, nslot, ks >> 2);
 #endif
-            between(ks);                                       // VALU work of the previous tile, hidden under this MFMA
         }
         mfma32_settle(s);
         __builtin_amdgcn_sched_barrier(0);
@@ -376,58 +351,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return tmax * cs;                                      // sm_scale > 0: max commutes with the scaling
     };
 
-    // ---- P = exp2(S c - m) against the current reference, l += sum P, O^T[d, head] += V^T . P^T
-    // softmax in 8 pieces of two scores each, so that the pipelined loop can slot them between the next tile's MFMAs
-    auto softmax_piece = [&](int i, const f32x16 &s, float nm, float &psum, uint32_t (&pk)[8]) {
-        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * i], cs, nm));
-        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * i + 1], cs, nm));
-        psum += e0 + e1;
-        pk[i] = pack2<BF16>(e0, e1);
-    };
-    auto pv = [&](int t, float psum, const uint32_t (&pk)[8]) {
-        const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
-        psum += __shfl_xor(psum, 32, 64);
-        l_run += psum;
-        // k-step kk covers keys 16 kk + {4 kg + r, 8 + 4 kg + r}
-        s16x8 pf[2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            pf[kk] = __builtin_bit_cast(s16x8, u32x4{pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]});
-        const int c16 = lane & 15, q16 = (lane >> 4) & 1;
-        // rows 8..15 / 24..31 (the `hi` halves) have their 16-B chunk pairs swapped: XOR 16 on the lane's byte offset
-        const uint8_t *vlo = buf + (4 * kg + (c16 >> 2)) * kNopeStride + q16 * 128 + (c16 & 3) * 8;
-        const uint8_t *vhi = buf + (4 * kg + (c16 >> 2) + 8) * kNopeStride + q16 * 128 + (((c16 & 3) * 8) ^ 16);
-        auto ldv = [&](int i, int half) -> s16x4 {              // i = kk * 16 + db
-            const int kk = i >> 4, db = i & 15;
-            const int off = kk * 16 * kNopeStride + (db >> 2) * 256 + (db & 3) * 32;
-            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)((half ? vhi : vlo) + off));
-        };
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const s16x4 lo = ldv(i, 0), hi = ldv(i, 1);
-            const s16x8 a = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            acc[i & 15] = mfma32<BF16>(a, pf[i >> 4], acc[i & 15]);
-        }
-        constexpr int kPvAhead = MLAW_PV_AHEAD;
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kPvAhead, 0);
-#pragma unroll
-        for (int i = 0; i < 32 - kPvAhead; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, kPvAhead, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto softmax_pv = [&](int t, const f32x16 &s) {
-        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
-        float psum = 0.f;
-        uint32_t pk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) softmax_piece(i, s, nm, psum, pk);
-        pv(t, psum, pk);
-    };
-
     // One softmax reference per head for the WHOLE key range of this workgroup: the first tile's maximum.  No accumulator
     // is ever rescaled, so the tile loop contains no VALU access to the 256 accumulator registers (with a conditional
     // rescale in it the register allocator moved them to VGPRs and spilled Q^T).  bf16 P spans the fp32 exponent range: a
@@ -442,8 +365,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define MLAW_TICK(i)
 #endif
-    auto noop = [](int) {};
-#if MLAW_X
     // software pipeline over tiles.  Interval i (between two tile_top barriers): publish P^T(i) (computed in the previous
     // interval, still in registers) to the exchange buffer, QK^T of tile i+1, barrier B, then this wave's dimension slice of
     // P(i).V(i) with the softmax of tile i+1 in the shadow of its 32 independent MFMAs.  (Under the QK^T chain the same VALU
@@ -474,7 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         {
             const TileRows rows = tile_top(t_begin);
-            const float tmax = qk(t_begin, rows, s, noop);
+            const float tmax = qk(t_begin, rows, s);
             m_run = tmax;
             nm = (m_run == -INFINITY) ? 0.f : -m_run;
 #pragma unroll
@@ -488,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             MLAW_TICK(0)
             publish(psum, pk);
             psum = 0.f;
-            const float tmax = qk(t + 1, rows, s, noop);
+            const float tmax = qk(t + 1, rows, s);
             if (__any(tmax > m_run + kGuard)) *flag = 1;
             MLAW_TICK(1)
             pv_x(t, piece);
@@ -498,52 +419,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         publish(psum, pk);
         pv_x(t_end - 1, no_embed);
     }
-#elif MLAW_PIPE
-    // software pipeline over tiles: QK^T of tile t+1 (MFMA) carries the softmax of tile t (VALU) in its issue gaps
-    if (t_begin < t_end) {
-        f32x16 s_cur;
-        {
-            const TileRows rows = tile_top(t_begin);
-            const float tmax = qk(t_begin, rows, s_cur, noop);
-            m_run = tmax;
-        }
-        for (int t = t_begin; t + 1 < t_end; ++t) {
-#ifdef MLAW_TIMING
-            c0 = __builtin_amdgcn_s_memtime();
-#endif
-            const TileRows rows = tile_top(t + 1);
-            MLAW_TICK(0)
-            const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
-            float psum = 0.f;
-            uint32_t pk[8];
-            f32x16 s_next;
-            const float tmax = qk(t + 1, rows, s_next, [&](int ks) {
-                if ((ks & 3) == 1) softmax_piece(ks >> 2, s_cur, nm, psum, pk);      // ks = 1, 5, ..., 29 -> pieces 0..7
-            });
-            MLAW_TICK(1)
-            if (__any(tmax > m_run + kGuard)) *flag = 1;
-            pv(t, psum, pk);
-            MLAW_TICK(2)
-            s_cur = s_next;
-        }
-        softmax_pv(t_end - 1, s_cur);
-    }
-#else
-    for (int t = t_begin; t < t_end; ++t) {
-#ifdef MLAW_TIMING
-        c0 = __builtin_amdgcn_s_memtime();
-#endif
-        const TileRows rows3 = tile_top(t);
-        MLAW_TICK(0)
-        f32x16 s;
-        const float tmax = qk(t, rows3, s, noop);
-        MLAW_TICK(1)
-        if (t == t_begin) m_run = tmax;
-        if (__any(tmax > m_run + kGuard)) *flag = 1;
-        softmax_pv(t, s);
-        MLAW_TICK(2)
-    }
-#endif
 #ifdef MLAW_TIMING
     if (lane == 0 && blockIdx.x < 64) {
         float *dbg = (float *)p.fix_flags + 1024 + (blockIdx.x * 4 + wave) * 4;
@@ -554,7 +429,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     if (threadIdx.x == 0 && *flag != 0) p.fix_flags[b * p.kv_heads + kvh] = p.fix_epoch;
 
-#if MLAW_X
     // ---- epilogue: wave w holds acc[dbl*4 + hb][4 rg + i] = O^T[d][head 32 hb + c32], d = 128 w + 64 (rg>>1) + 16 dbl + 8 (rg&1) + 4 kg + i;
     // the softmax statistics of a head live in the wave that owns it and reach the others through LDS
     float *lmb = (float *)pbuf;                                // [0..127] l, [128..255] m (all P.V reads are behind the barrier above)
@@ -600,38 +474,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
 }
-#else
-    // ---- epilogue: acc[db][4 rg + i] = O^T[d][head c32], d = 128 (db>>2) + 64 (rg>>1) + 16 (db&3) + 8 (rg&1) + 4 kg + i
-    if (!head_ok) return;
-    if (p.num_splits == 1) {
-        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + 4 * kg;
-#pragma unroll
-        for (int db = 0; db < 16; ++db)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int d = (db >> 2) * 128 + (rg >> 1) * 64 + (db & 3) * 16 + (rg & 1) * 8;
-                const uint32_t w0 = (uint32_t)cvt_out<BF16>(acc[db][4 * rg + 0] * inv) | ((uint32_t)cvt_out<BF16>(acc[db][4 * rg + 1] * inv) << 16);
-                const uint32_t w1 = (uint32_t)cvt_out<BF16>(acc[db][4 * rg + 2] * inv) | ((uint32_t)cvt_out<BF16>(acc[db][4 * rg + 3] * inv) << 16);
-                *(uint2 *)(orow + d) = uint2{w0, w1};
-            }
-    } else {
-        const int64_t idx = ((int64_t)b * p.q_heads + head) * p.num_splits + split;
-        float *po = p.ws_o + idx * kDN + 4 * kg;
-#pragma unroll
-        for (int db = 0; db < 16; ++db)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int d = (db >> 2) * 128 + (rg >> 1) * 64 + (db & 3) * 16 + (rg & 1) * 8;
-                *(f32x4 *)(po + d) = f32x4{acc[db][4 * rg + 0], acc[db][4 * rg + 1], acc[db][4 * rg + 2], acc[db][4 * rg + 3]};
-            }
-        if (kg == 0) {
-            p.ws_ml[idx * 2 + 0] = m_run;
-            p.ws_ml[idx * 2 + 1] = l_run;
-        }
-    }
-}
-#endif
 
 
 void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t st)
