@@ -110,6 +110,18 @@ int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t notify_epoch, c
                              int32_t *total_recv_token, int32_t *max_bs, int32_t *pull_offset, int32_t *summary_host,
                              int32_t *status, int timeout_ms, int32_t *wait_cost_stats /*[W] or NULL: += us waited per source*/,
                              void *stream);
+/* Both halves of the exchange in ONE launch of one workgroup: post this rank's counts and its "rows staged" flag
+ * (= mi_ep_notify_post_signal with signal_epoch = flag_epoch), then mi_ep_notify_wait_tables.  Used by the host runtime
+ * when each rank is its own process; a harness that plays several ranks on one stream must keep the two halves apart
+ * (every rank has to post before any rank can finish waiting). */
+int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, uint64_t *const *peer_flags_host,
+                                 const int32_t *num_tokens_per_expert, int num_tokens, const uint64_t *my_notify,
+                                 uint32_t notify_epoch, const uint64_t *my_flags, uint64_t flag_epoch, int32_t *cnt_matrix,
+                                 int num_ranks, int num_experts, int my_rank, int relative_pull, int32_t *recv_count,
+                                 int32_t *recv_offset, int32_t *recv_tokens_per_expert, int32_t *expert_global_offset,
+                                 int32_t *srcrank_in_expert_offset, int32_t *r_in_srcrank_offset, int32_t *total_recv_token,
+                                 int32_t *max_bs, int32_t *pull_offset, int32_t *summary_host, int32_t *status, int timeout_ms,
+                                 int32_t *wait_cost_stats, void *stream);
 /* Diagnose helpers (reference dispatch_wait_recv_cost_stats / combine_send_cost_stats, buffer.py:343-345,500-501): a device
  * timestamp (100 MHz ticks) and `stats[i] += microseconds since *t_start` for i < n.  Launched only when stats are requested. */
 int mi_ep_timestamp(uint64_t *dst, void *stream);

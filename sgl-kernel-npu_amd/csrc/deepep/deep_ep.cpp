@@ -308,10 +308,9 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
                                      H, E, (int)rank, qm, my_rows, st)); }
     auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_notify_post_signal((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(), W, (int)rank,
-                                         E, lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, ep, st));
 
-    // receiver side: counts + "staged" flags -> tables (+ pinned summary for the host), one launch
+    // counts + "staged" flag to every peer, then (same launch, one workgroup) everybody's counts + flags -> tables
+    // (+ pinned summary for the host)
     int32_t *wait_stats = nullptr;
     if (dispatch_wait_recv_cost_stats.has_value()) {
         EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->scalar_type() == at::kInt and dispatch_wait_recv_cost_stats->is_contiguous());
@@ -321,14 +320,16 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     NotifyTables nt = alloc_notify_tables(W, E, L, i32);
     const bool host_sync = num_worst_tokens <= 0;
     if (host_sync) __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
-    MI_EP_CHECK(mi_ep_notify_wait_tables((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
-                                         (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
-                                         nt.cnt.data_ptr<int>(), W, E, (int)rank, 0, nt.recv_count.data_ptr<int>(),
-                                         nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
-                                         nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
-                                         nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
-                                         nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(),
-                                         host_sync ? summary_dev : nullptr, status_dev, timeout_ms, wait_stats, st));
+    MI_EP_CHECK(mi_ep_notify_exchange_tables((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(),
+                                             lay.num_tokens_per_expert.data_ptr<int>(), T,
+                                             (const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
+                                             (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
+                                             nt.cnt.data_ptr<int>(), W, E, (int)rank, 0, nt.recv_count.data_ptr<int>(),
+                                             nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
+                                             nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
+                                             nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
+                                             nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(),
+                                             host_sync ? summary_dev : nullptr, status_dev, timeout_ms, wait_stats, st));
     at::Tensor &cnt = nt.cnt, &recv_count = nt.recv_count, &recv_offset = nt.recv_offset;
     at::Tensor &recv_tokens_per_expert = nt.recv_tokens_per_expert, &expert_global_offset = nt.expert_global_offset;
     at::Tensor &srcrank_in_expert_offset = nt.srcrank_in_expert_offset, &r_in_srcrank_offset = nt.r_in_srcrank_offset;
@@ -420,10 +421,10 @@ Buffer::notify_verify(const at::Tensor &x, const std::optional<at::Tensor> &, co
     const int par = (int)(ep & 1);
     auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_notify_post_signal((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(), W, (int)rank,
-                                         E, lay.num_tokens_per_expert.data_ptr<int>(), T, (uint32_t)ep, ep, st));
     NotifyTables nt = alloc_notify_tables(W, E, L, i32);
-    MI_EP_CHECK(mi_ep_notify_wait_tables((const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
+    MI_EP_CHECK(mi_ep_notify_exchange_tables((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(),
+                                         lay.num_tokens_per_expert.data_ptr<int>(), T,
+                                         (const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
                                          (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
                                          nt.cnt.data_ptr<int>(), W, E, (int)rank, 0, nt.recv_count.data_ptr<int>(),
                                          nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),

@@ -205,9 +205,18 @@ __global__ __launch_bounds__(256) void notify_tables_kernel(
                        srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs, pull_offset, summary_host, sm);
 }
 
+// Optional sender half of the exchange, run by the same workgroup before it starts to wait (mi_ep_notify_exchange_tables):
+// this rank's E+1 count granules and its "rows staged" flag to every peer.
+struct NotifyPost {
+    PeerPtrs notify, flags;
+    const int32_t *cnt;
+    int num_tokens;
+    uint64_t sig_epoch;      // 0 = nothing to post
+};
+
 // notify_wait + wait + notify_tables in one launch: the workgroup first collects the W*(E+1) count granules and the W
 // "rows staged" flags of this call (bounded spins), then derives the tables from the counts it just wrote.
-__global__ __launch_bounds__(1024) void notify_wait_tables_kernel(
+__global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost post,
     const uint64_t *__restrict__ notify, uint32_t notify_epoch, const uint64_t *__restrict__ flags, uint64_t flag_epoch,
     int32_t *__restrict__ cnt, int W, int E, int me, int relative_pull, int32_t *__restrict__ recv_count,
     int32_t *__restrict__ recv_offset, int32_t *__restrict__ recv_tokens_per_expert, int32_t *__restrict__ expert_global_offset,
@@ -216,8 +225,16 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(
     int32_t *summary_host, int32_t *status, uint64_t timeout_ticks, int32_t *__restrict__ wait_cost_stats)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t sm[];
-    const uint64_t t0 = ticks_100mhz();
     const int n = W * (E + 1);
+    if (post.sig_epoch) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int d = i / (E + 1), e = i - d * (E + 1);
+            const uint32_t v = (e < E) ? (uint32_t)post.cnt[e] : (uint32_t)post.num_tokens;
+            sys_store_u64((uint64_t *)post.notify.p[d] + (size_t)me * (E + 1) + e, ((uint64_t)notify_epoch << 32) | v);
+        }
+        if (threadIdx.x < W) sys_store_u64((uint64_t *)post.flags.p[threadIdx.x] + me, post.sig_epoch);
+    }
+    const uint64_t t0 = ticks_100mhz();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         uint64_t g;
         while (((g = sys_load_u64(notify + i)) >> 32) != notify_epoch) {
@@ -357,8 +374,37 @@ extern "C" int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t noti
         return MI_EP_EINVAL;
     const int L = E / W;
     const size_t lds = (size_t)(2 * L * W + W + L + 2) * sizeof(int32_t);
+    NotifyPost none{};
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
-        my_notify, notify_epoch, my_flags, flag_epoch, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
+        none, my_notify, notify_epoch, my_flags, flag_epoch, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
+        recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,
+        pull_offset, summary_host, status, ms_to_ticks(timeout_ms), wait_cost_stats);
+    return launch_status();
+}
+
+extern "C" int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, uint64_t *const *peer_flags_host,
+                                            const int32_t *num_tokens_per_expert, int num_tokens, const uint64_t *my_notify,
+                                            uint32_t notify_epoch, const uint64_t *my_flags, uint64_t flag_epoch,
+                                            int32_t *cnt_matrix, int W, int E, int my_rank, int relative_pull, int32_t *recv_count,
+                                            int32_t *recv_offset, int32_t *recv_tokens_per_expert, int32_t *expert_global_offset,
+                                            int32_t *srcrank_in_expert_offset, int32_t *r_in_srcrank_offset,
+                                            int32_t *total_recv_token, int32_t *max_bs, int32_t *pull_offset,
+                                            int32_t *summary_host, int32_t *status, int timeout_ms, int32_t *wait_cost_stats,
+                                            void *stream)
+{
+    if (!my_notify || !my_flags || !cnt_matrix || !status || !num_tokens_per_expert || notify_epoch == 0 || flag_epoch == 0 ||
+        W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048 || my_rank < 0 || my_rank >= W)
+        return MI_EP_EINVAL;
+    NotifyPost post{};
+    if (fill_peers(post.notify, (const void *const *)peer_notify_host, W) || fill_peers(post.flags, (const void *const *)peer_flags_host, W))
+        return MI_EP_EINVAL;
+    post.cnt = num_tokens_per_expert;
+    post.num_tokens = num_tokens;
+    post.sig_epoch = flag_epoch;
+    const int L = E / W;
+    const size_t lds = (size_t)(2 * L * W + W + L + 2) * sizeof(int32_t);
+    notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
+        post, my_notify, notify_epoch, my_flags, flag_epoch, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
         recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,
         pull_offset, summary_host, status, ms_to_ticks(timeout_ms), wait_cost_stats);
     return launch_status();
