@@ -221,6 +221,13 @@ int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_c
 int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,
                     int cum_stride, int num_local_experts, int rows_cap, int inter, int hidden, void *out_bf16,
                     int rows_per_expert_hint, void *stream);
+/* GEMM2 with the combine push fused into its epilogue: the bf16 row r is not written to a dense [rows, hidden] tensor but
+ * straight into slot t*topk+k of rank src's combine window, (src, t, k) = src_idx[3 r ..] -- the same destination and the
+ * same bytes as mi_ep_moe_gemm2 followed by mi_ep_combine_push (the reference's fused op also sends from its GEMM2
+ * epilogue: fused_deep_moe.h:336-427).  dst_base_host[W] = every rank's combine region for this call (host array). */
+int mi_ep_moe_gemm2_push(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,
+                         int cum_stride, int num_local_experts, int rows_cap, int inter, int hidden, const int32_t *src_idx,
+                         int topk, void *const *dst_base_host, int num_ranks, int rows_per_expert_hint, void *stream);
 
 #ifdef __cplusplus
 }

@@ -592,15 +592,23 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     // valid packed rows = layout_range[L*W-1], read on device
     { ProfScope ps_(this, "ll_combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
                                    (int)x.size(0), H, K, dst_peers.data(), W, st)); }
+    // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
+    return {ll_combine_finish(topk_idx, topk_weights, H, E, ep, x.options(), st), std::nullopt, std::function<void()>([] {})};
+}
+
+// second half of a low-latency combine: "my rows are pushed" to every owner, wait for every expert rank, weighted sum
+at::Tensor Buffer::ll_combine_finish(const at::Tensor &topk_idx, const at::Tensor &topk_weights, int H, int E, uint64_t ep,
+                                     const at::TensorOptions &opts, hipStream_t st)
+{
+    const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), W = (int)num_ranks;
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
     MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
                                   (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, ep,
                                   status_dev, timeout_ms, st));
-    // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
-    auto combined_x = at::empty({T, H}, x.options());
+    auto combined_x = at::empty({T, H}, opts);
     { ProfScope ps_(this, "ll_combine_reduce", st); MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                      topk_weights.data_ptr<float>(), nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), st)); }
-    return {combined_x, std::nullopt, std::function<void()>([] {})};
+    return combined_x;
 }
 
 // the nine int32 tables of one notify exchange carved out of ONE allocation (each at::empty costs ~1-2 us of host time)
@@ -675,7 +683,6 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     at::Tensor v = at::empty({M, I}, at::dtype(at::kFloat).device(dev));
     at::Tensor q2 = at::empty({M, I}, at::dtype(at::kChar).device(dev));
     at::Tensor sc2 = at::empty({M}, at::dtype(at::kFloat).device(dev));
-    at::Tensor y = at::empty({M, H}, at::dtype(at::kBFloat16).device(dev));
     const int32_t *cum = layout_range.data_ptr<int>();
     // expected rows per local expert under balanced routing (all ranks send about T tokens x K): picks the GEMM tile shape
     const int rows_hint = (int)std::max<int64_t>(1, (int64_t)T * K * W / std::max(1, E));
@@ -684,12 +691,18 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
                                          s1.data_ptr<float>(), cum, W, L, M, H, N1, v.data_ptr<float>(), rows_hint, st)); }
     { ProfScope ps_(this, "moe_rowquant", st);
       MI_EP_CHECK(mi_ep_moe_rowquant(v.data_ptr<float>(), cum + (L * W - 1), M, I, (int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), st)); }
-    { ProfScope ps_(this, "moe_gemm2", st);
-      MI_EP_CHECK(mi_ep_moe_gemm2((const int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), (const int8_t *)w2.data_ptr(),
-                                  s2.data_ptr<float>(), cum, W, L, M, I, H, y.data_ptr(), rows_hint, st)); }
-    auto comb = low_latency_combine(y, expert_ids, topk_weights, src_info, layout_range, num_max_dispatch_tokens_per_rank,
-                                    num_experts, std::get<2>(disp), false, false, false, none);
-    return {std::get<0>(comb), layout_range};
+    // GEMM2 writes every bf16 row straight into its owner's combine slot (the push of low_latency_combine fused into the GEMM
+    // epilogue: no dense [M, H] intermediate, one pass over 2*M*H bytes less), then the usual signal / wait / weighted sum
+    const size_t cb = mi_ep_combine_row_bytes(H);
+    EP_HOST_ASSERT_S((size_t)num_max_dispatch_tokens_per_rank * K * cb <= region_bytes, "combine window too small; raise DEEPEP_WINDOW_BYTES");
+    const uint64_t ep = ++combine_epoch;
+    auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
+    { ProfScope ps_(this, "moe_gemm2_push", st);
+      MI_EP_CHECK(mi_ep_moe_gemm2_push((const int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), (const int8_t *)w2.data_ptr(),
+                                       s2.data_ptr<float>(), cum, W, L, M, I, H, src_info.data_ptr<int>(), K, dst_peers.data(), W,
+                                       rows_hint, st)); }
+    at::Tensor combined = ll_combine_finish(expert_ids, topk_weights, H, E, ep, x.options(), st);
+    return {combined, layout_range};
 }
 
 static void fused_common_checks(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1, const at::Tensor &w2,

@@ -179,6 +179,8 @@ private:
             r_in_srcrank_offset, total_recv_token, max_bs, pull_offset;
     };
     NotifyTables alloc_notify_tables(int W, int E, int L, const at::TensorOptions &i32);
+    at::Tensor ll_combine_finish(const at::Tensor &topk_idx, const at::Tensor &topk_weights, int H, int E, uint64_t ep,
+                                 const at::TensorOptions &opts, hipStream_t st);
     // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
     std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
                                        const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,

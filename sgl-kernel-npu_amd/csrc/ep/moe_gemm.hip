@@ -28,6 +28,7 @@ namespace mi_ep {
 constexpr int BN = 256, BK = 64;
 constexpr int kStages = 4;
 constexpr int kGemmThreads = 1024;
+constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
@@ -37,7 +38,12 @@ struct GemmArgs {
     const float *w_scale;     // [L, N]
     const int32_t *cum;       // inclusive cumulative row counts; expert e ends at cum[(e + 1) * cum_stride - 1]
     int cum_stride, L, M_cap, K, N;
-    void *out;                // mode 0: float [M_cap, N/2]; mode 1: bf16 [M_cap, N]
+    void *out;                // mode 0: float [M_cap, N/2]; mode 1: bf16 [M_cap, N]; mode 2: unused
+    // mode 2 (GEMM2 fused with the combine push): row r goes to slot t*K+k of rank src, (src, t, k) = src_idx[3 r ..]
+    const int32_t *src_idx;
+    PeerPtrs dsts;
+    size_t slot_stride;
+    int topk, W;
 };
 
 // byte offset of 16-B chunk `chunk` (0..3) of row `row` inside a [rows][64 B] tile
@@ -63,26 +69,48 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
     constexpr int kStageBytes = (BM + BN) * BK;
     constexpr int kAPieces = BM / 16;                 // DMA instructions (16 rows x 64 B) for the A tile of a stage
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x 64 B + B 16 KB)
+#ifdef GEMM_TIMING
+    const uint64_t t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c16 = lane & 15;
     const int wm = wave & 3, wn = wave >> 2;
-    // which (expert, m-tile) is tile slot blockIdx.y?
+    // which (expert, m-tile) is tile slot blockIdx.y?  64 experts per step: lane i reads the end of expert i, a wave scan of
+    // the per-expert tile counts locates the slot.  (A serial walk over the experts -- one dependent scalar load each -- cost
+    // up to ~15 us per workgroup for the last experts, a third of a GEMM2 tile.)
     int e = -1, row0 = 0, rows = 0;
     {
-        int slot = blockIdx.y, start = 0;
-        for (int i = 0; i < p.L; ++i) {
-            const int end = p.cum[(i + 1) * p.cum_stride - 1];
-            const int cnt = end - start;
+        int slot = blockIdx.y, start = 0;                   // wave-uniform
+        for (int base = 0; base < p.L && e < 0; base += 64) {
+            const int i = base + lane;
+            const int end = i < p.L ? p.cum[(i + 1) * p.cum_stride - 1] : 0;
+            int prev = __shfl_up(end, 1, 64);
+            if (lane == 0) prev = start;
+            const int cnt = i < p.L ? end - prev : 0;
             const int tiles = (cnt + BM - 1) / BM;
-            if (slot < tiles) {
-                e = i;
-                row0 = start + slot * BM;
-                rows = min(BM, cnt - slot * BM);
-                break;
+            int incl = tiles;                               // inclusive scan of the tile counts
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int n = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += n;
             }
-            slot -= tiles;
-            start = end;
+            const unsigned long long hit = __ballot(i < p.L && incl > slot);
+            if (hit) {
+                const int l = __builtin_ctzll(hit);
+                const int before = __shfl(incl - tiles, l, 64);
+                const int s0 = __shfl(prev, l, 64), c = __shfl(cnt, l, 64);
+                e = base + l;
+                row0 = s0 + (slot - before) * BM;
+                rows = min(BM, c - (slot - before) * BM);
+            } else {
+                const int last = min(63, p.L - 1 - base);
+                slot -= __shfl(incl, last, 64);
+                start = __shfl(end, last, 64);
+            }
         }
+        e = __builtin_amdgcn_readfirstlane(e);
+        row0 = __builtin_amdgcn_readfirstlane(row0);
+        rows = __builtin_amdgcn_readfirstlane(rows);
     }
     if (e < 0) return;
     const int n0 = blockIdx.x * BN;
@@ -126,6 +154,7 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
 
 #ifdef GEMM_TIMING
     uint64_t tw = 0, tc = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+    const uint64_t t_loop = c0;
 #endif
     issue_stage(0);
     issue_stage(1);
@@ -159,43 +188,83 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
     }
 #ifdef GEMM_TIMING
     if (lane == 0 && blockIdx.x == 3 && blockIdx.y < 4) {
-        g_gemm_dbg[(blockIdx.y * 16 + wave) * 2 + 0] = (float)tw / nk;
-        g_gemm_dbg[(blockIdx.y * 16 + wave) * 2 + 1] = (float)tc / nk;
+        g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 0] = (float)tw / nk;
+        g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 1] = (float)tc / nk;
+        g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 2] = (float)(t_loop - t_entry);
     }
+    const uint64_t t_epi = __builtin_amdgcn_s_memtime();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills issued past the last k-tile
 
-    // ---- epilogue: lane holds C[row = wm*16*MT + mt*16 + 4g + r][n-tile nt, col c16]
+    // ---- epilogue: lane holds C[row = wm*16*MT + mt*16 + 4g + r][n-tile nt, col c16].  Written straight from this layout a
+    // wave-store covers 4 rows x 32 (64) bytes and the 470 MB of GEMM2 output took a third of the kernel (store-issue-bound);
+    // instead every wave transposes its tile through LDS (the operand ring is free now) and stores whole 128-byte rows,
+    // 16 B per lane.  Row stride 144 B: the four 4-row groups of a wave-store land 16 banks apart.
     const float *ws = p.w_scale + (size_t)e * p.N + n0;
+    constexpr int kRowBytes = kEpiRowBytes, kWaveRows = 16 * MT;
+    __syncthreads();                                        // every wave is done reading the ring (and nothing is in flight)
+    uint8_t *tile = lds + wave * (kWaveRows * kRowBytes);
+    const int f = wn >> 1, h = wn & 1;                      // MODE 0: fusion tile f (128 columns: 64 gate | 64 up), half h
+    const bool wave_cols_ok = MODE == 0 ? (n0 + f * 128 < p.N) : (n0 + wn * 64 < p.N);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int lr = wm * 16 * MT + mt * 16 + 4 * g + r;
-            if (lr >= rows) continue;
-            const size_t grow = (size_t)row0 + lr;
-            const float as = p.a_scale[grow];
+            const int rl = mt * 16 + 4 * g + r;
+            const int lr = wm * kWaveRows + rl;
+            const float as = p.a_scale[(size_t)row0 + min(lr, rows - 1)];
             if (MODE == 0) {
-                // wave = fusion tile f (128 columns: 64 gate | 64 up), half h: gate columns 32 h .. +32 and their up columns
-                const int f = wn >> 1, h = wn & 1;
-                if (n0 + f * 128 >= p.N) continue;
-                float *orow = (float *)p.out + grow * (size_t)(p.N / 2) + (size_t)(blockIdx.x * 2 + f) * 64 + h * 32;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int gc = f * 128 + h * 32 + nt * 16 + c16;
                     const float gate = ((float)acc[mt][nt][r] * ws[gc]) * as;
                     const float up = ((float)acc[mt][nt + 2][r] * ws[gc + 64]) * as;
-                    orow[nt * 16 + c16] = up * (gate / (1.0f + __expf(-gate)));
+                    *(float *)(tile + rl * kRowBytes + (nt * 16 + c16) * 4) = up * (gate / (1.0f + __expf(-gate)));
                 }
             } else {
-                uint16_t *orow = (uint16_t *)p.out + grow * (size_t)p.N + n0 + wn * 64;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int col = wn * 64 + nt * 16 + c16;
-                    if (n0 + col < p.N) orow[nt * 16 + c16] = (uint16_t)f32_to_bf16_rne(((float)acc[mt][nt][r] * ws[col]) * as);
+                    const float wsc = n0 + col < p.N ? ws[col] : 0.f;
+                    *(uint16_t *)(tile + rl * kRowBytes + (nt * 16 + c16) * 2) = (uint16_t)f32_to_bf16_rne(((float)acc[mt][nt][r] * wsc) * as);
                 }
             }
         }
+    // a wave only reads back what it wrote itself: LDS operations of one wave complete in order, no barrier needed
+    if (!wave_cols_ok) return;
+#pragma unroll
+    for (int it = 0; it < kWaveRows / 8; ++it) {
+        const int rl = it * 8 + (lane >> 3), chunk = lane & 7;
+        const int lr = wm * kWaveRows + rl;
+        if (lr >= rows) continue;
+        const size_t grow = (size_t)row0 + lr;
+        const u32x4 v = *(const u32x4 *)(tile + rl * kRowBytes + chunk * 16);
+        if (MODE == 0) {
+            float *orow = (float *)p.out + grow * (size_t)(p.N / 2) + (size_t)(blockIdx.x * 2 + f) * 64 + h * 32;
+            *(u32x4 *)(orow + chunk * 4) = v;
+        } else {
+            const int col = n0 + wn * 64 + chunk * 8;
+            uint16_t *orow;
+            if (MODE == 2) {
+                // the 8 lanes of a row read the same triple (one 12-byte broadcast per row, L1-resident)
+                const int src = p.src_idx[grow * 3 + 0], t = p.src_idx[grow * 3 + 1], k = p.src_idx[grow * 3 + 2];
+                if (src < 0 || src >= p.W) continue;        // corrupted handle: drop instead of a wild store
+                orow = (uint16_t *)((uint8_t *)p.dsts.p[src] + ((size_t)t * p.topk + k) * p.slot_stride) + col;
+            } else {
+                orow = (uint16_t *)p.out + grow * (size_t)p.N + col;
+            }
+            if (col + 8 <= p.N) {
+                *(u32x4 *)orow = v;
+            } else {
+                for (int j = 0; j < 8 && col + j < p.N; ++j) orow[j] = (uint16_t)(v[j >> 1] >> (16 * (j & 1)));
+            }
+        }
+    }
+#ifdef GEMM_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && blockIdx.x == 3 && blockIdx.y < 4)
+        g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 3] = (float)(__builtin_amdgcn_s_memtime() - t_epi);
+#endif
 }
 
 // per-row symmetric requantisation of the SwiGLU output: q = rint((v * 127) * (1 / rowmax)), scale = rowmax / 127
@@ -233,7 +302,8 @@ template <int MODE, int MT>
 static void gemm_launch_one(const GemmArgs &p, void *stream)
 {
     constexpr int BM = 64 * MT;
-    constexpr int lds = kStages * (BM + BN) * BK;
+    constexpr int ring = kStages * (BM + BN) * BK, epi = 16 * 16 * MT * kEpiRowBytes;      // operand ring | epilogue tiles of 16 waves
+    constexpr int lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)grouped_gemm_i8_kernel<MODE, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -243,16 +313,31 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
     grouped_gemm_i8_kernel<MODE, MT><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(p);
 }
 
+struct PushArgs {
+    const int32_t *src_idx;
+    PeerPtrs dsts;
+    size_t slot_stride;
+    int topk, W;
+};
+
 static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *cum,
-                       int cum_stride, int L, int M_cap, int K, int N, void *out, int rows_per_expert_hint, void *stream)
+                       int cum_stride, int L, int M_cap, int K, int N, void *out, int rows_per_expert_hint, void *stream,
+                       const PushArgs *push = nullptr)
 {
-    if (!a || !a_scale || !w || !w_scale || !cum || !out || L <= 0 || L > 1024 || M_cap <= 0 || K <= 0 || K % BK || N <= 0 ||
+    if (!a || !a_scale || !w || !w_scale || !cum || (!out && !push) || L <= 0 || L > 1024 || M_cap <= 0 || K <= 0 || K % BK || N <= 0 ||
         N % 128 || cum_stride <= 0)
         return MI_EP_EINVAL;
-    GemmArgs p{a, a_scale, w, w_scale, cum, cum_stride, L, M_cap, K, N, out};
+    GemmArgs p{};
+    p.a = a, p.a_scale = a_scale, p.w = w, p.w_scale = w_scale, p.cum = cum, p.cum_stride = cum_stride, p.L = L, p.M_cap = M_cap;
+    p.K = K, p.N = N, p.out = out;
     const bool small = rows_per_expert_hint > 0 && rows_per_expert_hint <= 96;      // decode-size groups
+    if (push) {
+        p.src_idx = push->src_idx, p.dsts = push->dsts, p.slot_stride = push->slot_stride, p.topk = push->topk, p.W = push->W;
+        mode = 2;
+    }
     if (mode == 0) { if (small) gemm_launch_one<0, 1>(p, stream); else gemm_launch_one<0, 4>(p, stream); }
-    else { if (small) gemm_launch_one<1, 1>(p, stream); else gemm_launch_one<1, 4>(p, stream); }
+    else if (mode == 1) { if (small) gemm_launch_one<1, 1>(p, stream); else gemm_launch_one<1, 4>(p, stream); }
+    else { if (small) gemm_launch_one<2, 1>(p, stream); else gemm_launch_one<2, 4>(p, stream); }
     return launch_status();
 }
 
@@ -280,9 +365,26 @@ extern "C" int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8
                        rows_per_expert_hint, stream);
 }
 
+extern "C" int mi_ep_moe_gemm2_push(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale,
+                                    const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap, int inter,
+                                    int hidden, const int32_t *src_idx, int topk, void *const *dst_base_host, int num_ranks,
+                                    int rows_per_expert_hint, void *stream)
+{
+    if (!src_idx || !dst_base_host || topk <= 0 || topk > MI_EP_MAX_TOPK || num_ranks <= 0 || num_ranks > MI_EP_MAX_RANKS)
+        return MI_EP_EINVAL;
+    PushArgs push{};
+    push.src_idx = src_idx, push.slot_stride = mi_ep_combine_row_bytes(hidden), push.topk = topk, push.W = num_ranks;
+    for (int i = 0; i < num_ranks; ++i) {
+        if (!dst_base_host[i]) return MI_EP_EINVAL;
+        push.dsts.p[i] = dst_base_host[i];
+    }
+    return gemm_launch(1, a, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, inter, hidden, nullptr,
+                       rows_per_expert_hint, stream, &push);
+}
+
 #ifdef GEMM_TIMING
 extern "C" int mi_ep_gemm_dbg(float *host128)
 {
-    return (int)hipMemcpyFromSymbol(host128, HIP_SYMBOL(mi_ep::g_gemm_dbg), 128 * sizeof(float));
+    return (int)hipMemcpyFromSymbol(host128, HIP_SYMBOL(mi_ep::g_gemm_dbg), 256 * sizeof(float));
 }
 #endif

@@ -1,4 +1,4 @@
-"""Scratch: per-k-tile wait / compute cycles of the grouped GEMM (libmi_ep built with -DGEMM_TIMING)."""
+"""Scratch: grouped INT8 GEMM timing at the C5 shapes (and, in a -DGEMM_TIMING build, per-k-tile wait / compute cycles)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -6,26 +6,35 @@ import torch
 from capi import ptr, stream_ptr
 L = ctypes.CDLL(os.path.join(ROOT, "sgl-kernel-npu_amd", "lib", sys.argv[1]))
 E, H, I2, M = 32, 7168, 4096, 32768
-a = torch.randint(-8, 8, (M, H), dtype=torch.int8, device="cuda")
-asc = torch.rand(M, device="cuda")
-w = torch.randint(-8, 8, (E, I2, H), dtype=torch.int8, device="cuda")
-ws = torch.rand((E, I2), device="cuda")
-cum = (torch.arange(1, E + 1, device="cuda", dtype=torch.int32) * (M // E)).contiguous()
-out = torch.zeros((M, I2 // 2), dtype=torch.float32, device="cuda")
 c_vp = ctypes.c_void_p
-L.mi_ep_moe_gemm1_swiglu.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp]
-f = lambda: L.mi_ep_moe_gemm1_swiglu(ptr(a), ptr(asc), ptr(w), ptr(ws), ptr(cum), 1, E, M, H, I2, ptr(out), 0, stream_ptr())
-for _ in range(3): assert f() == 0
-torch.cuda.synchronize()
-for rep in range(8):
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(40): f()
-    e.record(); torch.cuda.synchronize()
-    us = s.elapsed_time(e) / 40 * 1e3
-    print(f"rep {rep}: gemm1 {us:.1f} us  {2 * M * H * I2 / us / 1e6:.0f} TOPS", flush=True)
-import numpy as np
-buf = np.zeros(128, dtype=np.float32)
-L.mi_ep_gemm_dbg(buf.ctypes.data_as(c_vp))
-dbg = torch.from_numpy(buf).reshape(-1, 2)[:32]
-print("per k-tile cycles [wait, compute] mean:", dbg.mean(dim=0).tolist())
+sig = [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp]
+L.mi_ep_moe_gemm1_swiglu.argtypes = sig
+L.mi_ep_moe_gemm2.argtypes = sig
+asc = torch.rand(M, device="cuda")
+cum = (torch.arange(1, E + 1, device="cuda", dtype=torch.int32) * (M // E)).contiguous()
+for name, K, N in (("gemm1", H, I2), ("gemm2", I2 // 2, H)):
+    a = torch.randint(-8, 8, (M, K), dtype=torch.int8, device="cuda")
+    w = torch.randint(-8, 8, (E, N, K), dtype=torch.int8, device="cuda")
+    ws = torch.rand((E, N), device="cuda")
+    if name == "gemm1":
+        out = torch.zeros((M, N // 2), dtype=torch.float32, device="cuda")
+        f = lambda: L.mi_ep_moe_gemm1_swiglu(ptr(a), ptr(asc), ptr(w), ptr(ws), ptr(cum), 1, E, M, K, N, ptr(out), 0, stream_ptr())
+    else:
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        f = lambda: L.mi_ep_moe_gemm2(ptr(a), ptr(asc), ptr(w), ptr(ws), ptr(cum), 1, E, M, K, N, ptr(out), 0, stream_ptr())
+    for _ in range(20): assert f() == 0
+    torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(5):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20): f()
+        e.record(); torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / 20 * 1e3)
+    print(f"{name}: {best:.1f} us  {2 * M * K * N / best / 1e6:.0f} TOPS", flush=True)
+    if hasattr(L, "mi_ep_gemm_dbg"):          # only in -DGEMM_TIMING builds
+        import numpy as np
+        buf = np.zeros(256, dtype=np.float32)
+        L.mi_ep_gemm_dbg(buf.ctypes.data_as(c_vp))
+        dbg = torch.from_numpy(buf).reshape(-1, 4)[:64]
+        print("   cycles: per k-tile [wait, compute], per tile [setup->first data, epilogue]:", dbg.mean(dim=0).tolist())
