@@ -31,6 +31,10 @@ struct MlaParams {
     uint32_t *fix_flags;      // [batch * kv_heads], entry == fix_epoch means "recompute"
     uint32_t fix_epoch;
     int fix_only;             // merge kernel: check the hand-off words and recompute flagged sequences
+    // wide kernel with in-kernel merge (num_splits <= 2): the two workgroups of a (sequence, kv head, head block) meet at
+    // arrive[...]; the second one merges and, if the sequence is flagged, recomputes -- no merge launch
+    uint32_t *arrive;         // [batch * kv_heads * head_blocks], values are tagged with fix_epoch (no clearing needed)
+    int inline_merge;
 };
 
 template <bool BF16>
@@ -108,5 +112,71 @@ __device__ __forceinline__ int64_t lane_i64(int64_t v, int src_lane)
 // wide kernel (mla_decode_wide.hip): launch for kv groups of more than 64 heads
 constexpr int kWideTile = 32;
 void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t st);
+
+// Slow path behind the wide kernel (mla_decode_wide.hip): a sequence whose scores outgrew the fixed softmax reference is
+// recomputed here, one wave per (b, head), with plain loads and fp32 VALU math -- exact two-pass softmax (max first), P
+// rounded to the KV dtype before P.V like the MFMA kernels.  Lane l owns output dims 8 l .. 8 l + 7.  Rare by construction
+// (bf16: a later tile must beat the first by 2^64), so it is written for clarity, not speed.
+template <bool BF16>
+__device__ __forceinline__ float ld_elem(const uint16_t *ptr)
+{
+    if constexpr (BF16) return __uint_as_float((uint32_t)*ptr << 16);
+    else return (float)__builtin_bit_cast(_Float16, *ptr);
+}
+
+template <bool BF16>
+__device__ inline void mla_recompute_head(const MlaParams &p, int b, int h, int lane)
+{
+    const int kvh = h / p.group, seq_len = p.seq_lens[b];
+    const uint16_t *qrow = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    float qv[9];                                               // lane holds q dims lane + 64 j
+#pragma unroll
+    for (int j = 0; j < 9; ++j) qv[j] = ld_elem<BF16>(qrow + lane + 64 * j);
+    auto key_ptrs = [&](int n, const uint16_t *&kn, const uint16_t *&kr) {
+        const int page = n / p.page_size, row = n - page * p.page_size;
+        const int64_t blk = p.block_table[(int64_t)b * p.bt_stride + page];
+        kn = p.k_nope + blk * p.kn_sblk + (int64_t)row * p.kn_srow + (int64_t)kvh * p.kn_sh;
+        kr = p.k_rope + blk * p.kr_sblk + (int64_t)row * p.kr_srow + (int64_t)kvh * p.kr_sh;
+    };
+    auto score = [&](int n) -> float {
+        const uint16_t *kn, *kr;
+        key_ptrs(n, kn, kr);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += qv[j] * ld_elem<BF16>(kn + lane + 64 * j);
+        d += qv[8] * ld_elem<BF16>(kr + lane);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        return d * p.sm_scale;
+    };
+    float m = -INFINITY;
+    for (int n = 0; n < seq_len; ++n) m = fmaxf(m, score(n));
+    float l = 0.f, o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int n = 0; n < seq_len; ++n) {
+        const float pr = __expf(score(n) - m);
+        l += pr;
+        float prq;                                             // P in the KV dtype
+        if constexpr (BF16) prq = __uint_as_float((uint32_t)cvt_out<true>(pr) << 16);
+        else prq = (float)(_Float16)pr;
+        const uint16_t *kn, *kr;
+        key_ptrs(n, kn, kr);
+        const u32x4 v = *(const u32x4 *)(kn + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint16_t lo = (uint16_t)(v[j] & 0xFFFFu), hi = (uint16_t)(v[j] >> 16);
+            o[2 * j] += prq * ld_elem<BF16>(&lo);
+            o[2 * j + 1] += prq * ld_elem<BF16>(&hi);
+        }
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh + lane * 8;
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        w[j] = (uint32_t)cvt_out<BF16>(o[2 * j] * inv) | ((uint32_t)cvt_out<BF16>(o[2 * j + 1] * inv) << 16);
+    *(u32x4 *)orow = w;
+}
 
 }  // namespace mi_sgl

@@ -27,6 +27,8 @@
 #include <stdint.h>
 
 #include "mi_sgl_kernels.h"
+#include <stdlib.h>
+
 #include "mla_common.h"
 
 // Tile fill: 0 = LDS-DMA (global_load_lds) with one 1-KiB piece issued per QK k-step (default, fastest);
@@ -362,72 +364,6 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-// Slow path behind the wide kernel (mla_decode_wide.hip): a sequence whose scores outgrew the fixed softmax reference is
-// recomputed here, one wave per (b, head), with plain loads and fp32 VALU math -- exact two-pass softmax (max first), P
-// rounded to the KV dtype before P.V like the MFMA kernels.  Lane l owns output dims 8 l .. 8 l + 7.  Rare by construction
-// (bf16: a later tile must beat the first by 2^64), so it is written for clarity, not speed.
-template <bool BF16>
-__device__ __forceinline__ float ld_elem(const uint16_t *ptr)
-{
-    if constexpr (BF16) return __uint_as_float((uint32_t)*ptr << 16);
-    else return (float)__builtin_bit_cast(_Float16, *ptr);
-}
-
-template <bool BF16>
-__device__ void mla_recompute_head(const MlaParams &p, int b, int h, int lane)
-{
-    const int kvh = h / p.group, seq_len = p.seq_lens[b];
-    const uint16_t *qrow = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
-    float qv[9];                                               // lane holds q dims lane + 64 j
-#pragma unroll
-    for (int j = 0; j < 9; ++j) qv[j] = ld_elem<BF16>(qrow + lane + 64 * j);
-    auto key_ptrs = [&](int n, const uint16_t *&kn, const uint16_t *&kr) {
-        const int page = n / p.page_size, row = n - page * p.page_size;
-        const int64_t blk = p.block_table[(int64_t)b * p.bt_stride + page];
-        kn = p.k_nope + blk * p.kn_sblk + (int64_t)row * p.kn_srow + (int64_t)kvh * p.kn_sh;
-        kr = p.k_rope + blk * p.kr_sblk + (int64_t)row * p.kr_srow + (int64_t)kvh * p.kr_sh;
-    };
-    auto score = [&](int n) -> float {
-        const uint16_t *kn, *kr;
-        key_ptrs(n, kn, kr);
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d += qv[j] * ld_elem<BF16>(kn + lane + 64 * j);
-        d += qv[8] * ld_elem<BF16>(kr + lane);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-        return d * p.sm_scale;
-    };
-    float m = -INFINITY;
-    for (int n = 0; n < seq_len; ++n) m = fmaxf(m, score(n));
-    float l = 0.f, o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int n = 0; n < seq_len; ++n) {
-        const float pr = __expf(score(n) - m);
-        l += pr;
-        float prq;                                             // P in the KV dtype
-        if constexpr (BF16) prq = __uint_as_float((uint32_t)cvt_out<true>(pr) << 16);
-        else prq = (float)(_Float16)pr;
-        const uint16_t *kn, *kr;
-        key_ptrs(n, kn, kr);
-        const u32x4 v = *(const u32x4 *)(kn + lane * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint16_t lo = (uint16_t)(v[j] & 0xFFFFu), hi = (uint16_t)(v[j] >> 16);
-            o[2 * j] += prq * ld_elem<BF16>(&lo);
-            o[2 * j + 1] += prq * ld_elem<BF16>(&hi);
-        }
-    }
-    const float inv = l > 0.f ? 1.f / l : 0.f;
-    uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh + lane * 8;
-    u32x4 w;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        w[j] = (uint32_t)cvt_out<BF16>(o[2 * j] * inv) | ((uint32_t)cvt_out<BF16>(o[2 * j + 1] * inv) << 16);
-    *(u32x4 *)orow = w;
-}
-
 // merge the flash-decoding partials: one wave per (b, head); lane handles 8 of the 512 dims.  With fix_only set (wide
 // kernel launches) it first checks the sequence's hand-off word and takes the slow path above instead.
 template <bool BF16>
@@ -478,7 +414,8 @@ using namespace mi_sgl;
 
 extern "C" const char *mi_sgl_kernels_version(void) { return "mi_sgl_kernels 0.1 gfx950"; }
 
-// workspace = [flash-decoding partials (num_splits > 1)] [one flag word per (sequence, kv head) for the wide kernel's hand-off]
+// workspace = [flash-decoding partials (num_splits > 1)] [batch * q_heads words: one "recompute" flag per (sequence, kv head) for the
+// wide kernel's hand-off, then one meeting word per (sequence, kv head, 128-head block) for its in-kernel merge]
 static size_t partial_bytes(int batch, int q_heads, int num_splits)
 {
     return num_splits <= 1 ? 0 : (size_t)batch * q_heads * num_splits * (kDN + 2) * sizeof(float);
@@ -534,6 +471,12 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     p.fix_flags = workspace ? (uint32_t *)((char *)workspace + partial_bytes(batch, q_heads, num_splits)) : nullptr;
     p.fix_epoch = ++epoch ? epoch : ++epoch;          // a stale word equal to the epoch only causes a redundant recompute
     p.fix_only = 0;
+    p.arrive = p.fix_flags ? p.fix_flags + (size_t)batch * kv_heads : nullptr;       // inside the batch * q_heads flag words (wide: group > 64)
+    // The wide kernel finishes a one-split launch itself (slow path included): no second launch.  With two splits its
+    // in-kernel merge is correct (MI_MLA_INLINE_MERGE=2 enables it) but measured 202 us against 195 us for the separate
+    // merge launch at C4: the agent-scope release / acquire each pair needs costs an L2 write-back and an L2 invalidate.
+    static const int inline_splits = getenv("MI_MLA_INLINE_MERGE") ? atoi(getenv("MI_MLA_INLINE_MERGE")) : 1;
+    p.inline_merge = wide && num_splits <= inline_splits && num_splits <= 2;
     p.batch = batch, p.q_heads = q_heads, p.kv_heads = kv_heads, p.group = q_heads / kv_heads, p.page_size = page_size;
     p.bt_stride = bt_stride, p.num_splits = num_splits;
     p.q_sb = q_stride_b, p.q_sh = q_stride_h, p.kn_sblk = kn_stride_blk, p.kn_srow = kn_stride_row, p.kn_sh = kn_stride_h;
@@ -559,7 +502,7 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
         if (dtype == MI_DTYPE_BF16) mla_decode_kernel<true><<<grid, 64 * nwaves, lds, st>>>(p);
         else mla_decode_kernel<false><<<grid, 64 * nwaves, lds, st>>>(p);
     }
-    if (num_splits > 1 || wide) {
+    if ((num_splits > 1 || wide) && !p.inline_merge) {
         const long long bh = (long long)batch * q_heads;
         const int blocks = (int)((bh + 3) / 4);
         if (dtype == MI_DTYPE_BF16) mla_merge_kernel<true><<<blocks, 256, 0, st>>>(p);

@@ -169,13 +169,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c32 = lane & 31, kg = lane >> 5;
     const int head_blocks = (p.group + 127) / 128;
+    // workgroups b % 8 run on XCD b % 8: the num_splits workgroups of a (sequence, kv head) share an XCD, so the partials they
+    // hand each other (in-kernel merge) or to the merge kernel are still in that XCD's L2
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int unit = (j / head_blocks) * 8 + xcd;
-    const int hblk = j % head_blocks;
-    if (unit >= p.batch * p.kv_heads * p.num_splits) return;
-    const int split = unit % p.num_splits;
-    const int kvh = (unit / p.num_splits) % p.kv_heads;
-    const int b = unit / (p.num_splits * p.kv_heads);
+    const int u = j / head_blocks, hblk = j % head_blocks;
+    const int split = u % p.num_splits;
+    const int seq = (u / p.num_splits) * 8 + xcd;              // (b, kvh) pair
+    if (seq >= p.batch * p.kv_heads) return;
+    const int kvh = seq % p.kv_heads;
+    const int b = seq / p.kv_heads;
     const int seq_len = p.seq_lens[b];
     const int ntiles = (seq_len + kT2 - 1) / kT2;
     const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
@@ -436,15 +438,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         lmb[wave * 32 + c32] = wave_active ? l_run : 0.f;
         lmb[128 + wave * 32 + c32] = wave_active ? m_run : -INFINITY;
     }
+    // In-kernel merge (num_splits <= 2): the two workgroups of a (sequence, kv head, head block) meet at one word tagged with
+    // this call's epoch.  The first to arrive writes its partial, then marks it complete; the second waits for that mark,
+    // adds the partner's partial to its own accumulators in registers and writes the final rows -- no merge launch, and half
+    // of the partial traffic.  Role 0 = alone (one split).
+    enum { kAlone = 0, kFirst = 1, kSecond = 2 };
+    uint32_t *const role_lds = (uint32_t *)(lds + kFlagOff + 4);
+    uint32_t *const word = p.arrive + ((size_t)b * p.kv_heads + kvh) * head_blocks + hblk;
+    const uint32_t tag = p.fix_epoch << 2;
+    if (threadIdx.x == 0) {
+        uint32_t role = kAlone;
+        if (p.inline_merge && p.num_splits == 2) {
+            uint32_t old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (true) {
+                if ((old >> 2) == p.fix_epoch) { role = kSecond; break; }
+                if (__hip_atomic_compare_exchange_strong(word, &old, tag | 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)) { role = kFirst; break; }
+            }
+        }
+        *role_lds = role;
+    }
     __syncthreads();
+    const uint32_t role = p.inline_merge ? *role_lds : (p.num_splits == 1 ? (uint32_t)kAlone : (uint32_t)kFirst);
+    const bool finals = role != kFirst;                       // this workgroup writes output rows
+    bool flagged = false;
+    if (role == kSecond) {
+        // ONE lane polls (relaxed) and then acquires: an agent-scope acquire invalidates the XCD's L2, a release writes it
+        // back, and those operations serialise at the L2 -- issued by every wave of every workgroup they cost > 100 us here
+        if (threadIdx.x == 0) {
+            while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (tag | 2u)) __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();                                       // the other waves read the partner's partial with plain loads
+    }
+    if (p.inline_merge && finals)                              // own tiles (LDS flag) or the partner's (hand-off word)
+        flagged = *flag != 0 || (role == kSecond && __hip_atomic_load(p.fix_flags + b * p.kv_heads + kvh, __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT) == p.fix_epoch);
+    if (flagged) {                                            // outgrown softmax reference: exact slow path, one head per wave at a time
+        for (int i = 0; i < 32; ++i) {
+            const int hg2 = hblk * 128 + wave * 32 + i;
+            if (hg2 < p.group) mla_recompute_head<BF16>(p, b, kvh * p.group + hg2, lane);
+        }
+        return;
+    }
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
         const int hgx = hblk * 128 + hb * 32 + c32;
         if (hgx >= p.group) continue;
         const int headx = kvh * p.group + hgx;
-        const float l_h = lmb[hb * 32 + c32];
-        if (p.num_splits == 1) {
-            const float inv = l_h > 0.f ? 1.f / l_h : 0.f;
+        const float l_h = lmb[hb * 32 + c32], m_h = lmb[128 + hb * 32 + c32];
+        const int64_t idx = ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
+        if (finals) {
+            // out = (w_s O_s + w_p O_p) / (w_s l_s + w_p l_p), w = exp2(m - max m) (the merge kernel's arithmetic, mla_decode.hip)
+            float w_s = 1.f, w_p = 0.f, l_tot = l_h;
+            const float *pp = nullptr;
+            if (role == kSecond) {
+                const int64_t idp = idx - split + (1 - split);
+                const float m_p = p.ws_ml[idp * 2 + 0], l_p = p.ws_ml[idp * 2 + 1];
+                const float mx = fmaxf(m_h, m_p);
+                w_s = m_h == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_h - mx);
+                w_p = m_p == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_p - mx);
+                l_tot = w_s * l_h + w_p * l_p;
+                pp = p.ws_o + idp * kDN + wave * 128 + 4 * kg;
+            }
+            const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
             uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + wave * 128 + 4 * kg;
 #pragma unroll
             for (int dbl = 0; dbl < 4; ++dbl)
@@ -452,12 +509,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int rg = 0; rg < 4; ++rg) {
                     const int d = (rg >> 1) * 64 + dbl * 16 + (rg & 1) * 8;
                     const f32x16 &a = acc[dbl * 4 + hb];
-                    const uint32_t w0 = (uint32_t)cvt_out<BF16>(a[4 * rg + 0] * inv) | ((uint32_t)cvt_out<BF16>(a[4 * rg + 1] * inv) << 16);
-                    const uint32_t w1 = (uint32_t)cvt_out<BF16>(a[4 * rg + 2] * inv) | ((uint32_t)cvt_out<BF16>(a[4 * rg + 3] * inv) << 16);
+                    f32x4 o = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
+                    if (role == kSecond) {
+                        const f32x4 q = *(const f32x4 *)(pp + d);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = w_s * o[e] + w_p * q[e];
+                    }
+                    const uint32_t w0 = (uint32_t)cvt_out<BF16>(o[0] * inv) | ((uint32_t)cvt_out<BF16>(o[1] * inv) << 16);
+                    const uint32_t w1 = (uint32_t)cvt_out<BF16>(o[2] * inv) | ((uint32_t)cvt_out<BF16>(o[3] * inv) << 16);
                     *(uint2 *)(orow + d) = uint2{w0, w1};
                 }
         } else {
-            const int64_t idx = ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
             float *po = p.ws_o + idx * kDN + wave * 128 + 4 * kg;
 #pragma unroll
             for (int dbl = 0; dbl < 4; ++dbl)
@@ -468,10 +530,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     *(f32x4 *)(po + d) = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
                 }
             if (wave == 0 && kg == 0) {
-                p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + c32];
+                p.ws_ml[idx * 2 + 0] = m_h;
                 p.ws_ml[idx * 2 + 1] = l_h;
             }
         }
+    }
+    if (p.inline_merge && role == kFirst) {                    // partial (and the hand-off word, written above) complete -> mark
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores have left the CU
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(word, tag | 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // one L2 write-back
     }
 }
 
@@ -485,7 +552,8 @@ void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t
         attr_set = true;
     }
     const int head_blocks = (p.group + 127) / 128;
-    dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
+    const long long seqs = units / p.num_splits;               // (sequence, kv head) pairs, 8 per grid row of XCDs
+    dim3 grid((unsigned)(((seqs + 7) / 8) * 8 * p.num_splits * head_blocks));
     if (dtype == MI_DTYPE_BF16) mla_decode_wide_kernel<true><<<grid, 256, kWideLds, st>>>(p);
     else mla_decode_wide_kernel<false><<<grid, 256, kWideLds, st>>>(p);
 }
