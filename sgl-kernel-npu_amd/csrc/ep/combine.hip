@@ -17,7 +17,6 @@
 namespace mi_ep {
 
 constexpr int kPushWaves = 4;
-constexpr int kPushRowsPerWave = 2;
 
 __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     const uint8_t *__restrict__ x, const int32_t *__restrict__ src_idx, const int32_t *__restrict__ total_dev,
@@ -27,12 +26,9 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
     const int n16 = row_bytes / 16;
-    const long long rows_per_block = kPushWaves * kPushRowsPerWave;
-    for (long long r0 = (long long)blockIdx.x * rows_per_block; r0 < total; r0 += (long long)gridDim.x * rows_per_block) {
+    {   // rows dealt to waves round-robin over the whole grid (see pull_body)
 #pragma unroll 1
-        for (int rr = 0; rr < kPushRowsPerWave; ++rr) {
-            const long long r = r0 + wave * kPushRowsPerWave + rr;
-            if (r >= total) break;
+        for (long long r = (long long)blockIdx.x * kPushWaves + wave; r < total; r += (long long)gridDim.x * kPushWaves) {
             const int src = src_idx[r * 3 + 0];
             const int t = src_idx[r * 3 + 1];
             const int k = src_idx[r * 3 + 2];
@@ -216,9 +212,8 @@ extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const i
         if (!dst_base_host[i]) return MI_EP_EINVAL;
         pp.p[i] = dst_base_host[i];
     }
-    const int rpb = kPushWaves * kPushRowsPerWave;
-    long long blocks = ((long long)rows_hint + rpb - 1) / rpb;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    long long blocks = ((long long)rows_hint + kPushWaves - 1) / kPushWaves;        // one row per wave until the chip is full
+    if (blocks > 256 * 8) blocks = 256 * 8;
     combine_push_kernel<<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
         (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp);
     return launch_status();

@@ -183,8 +183,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
 // pull
 // ---------------------------------------------------------------------------------------------
 constexpr int kPullWaves = 4;
-constexpr int kPullRowsPerWave = 4;
-constexpr int kPullRowsPerBlock = kPullWaves * kPullRowsPerWave;
+constexpr int kPullRowsPerBlock = kPullWaves;              // grid sizing: one row per wave until the chip is full (2048 workgroups)
 
 // rows [0, total) of the receive buffers from the (local expert, source) segments described by the inclusive cumsum in LDS
 __device__ __forceinline__ void pull_body(
@@ -197,12 +196,11 @@ __device__ __forceinline__ void pull_body(
     const int wave = threadIdx.x / kWave;
     const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
     const int n16 = payload_bytes / 16;
-    for (long long r0 = (long long)blockIdx.x * kPullRowsPerBlock; r0 < total;
-         r0 += (long long)gridDim.x * kPullRowsPerBlock) {
+    // rows are dealt to waves round-robin over the whole grid: a decode-size exchange (1 K rows) still spreads over every CU,
+    // a prefill-size one gives each wave a few rows a grid-width apart
+    {
 #pragma unroll 1
-        for (int rr = 0; rr < kPullRowsPerWave; ++rr) {
-            const long long r = r0 + wave * kPullRowsPerWave + rr;
-            if (r >= total) break;
+        for (long long r = (long long)blockIdx.x * kPullWaves + wave; r < total; r += (long long)gridDim.x * kPullWaves) {
             // first i with cum[i] > r
             int lo = 0, hi = LW - 1;
             while (lo < hi) {
@@ -310,7 +308,7 @@ extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32
     }
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
     long long blocks = ((long long)rows_hint + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 8) blocks = 256 * 8;
     const size_t lds = (size_t)L * W * sizeof(int32_t);
     pull_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
         pp, recv_count, pull_offset, 0, W, L * W, payload, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint);
