@@ -53,10 +53,12 @@ __device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const 
 template <bool I32, bool EPS>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
-    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll)
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit)
 {
     const int lane = lane_id();
-    const int t = blockIdx.x * kStageWaves + threadIdx.x / kWave;
+    // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
+    const int wid = blockIdx.x * kStageWaves + threadIdx.x / kWave;
+    const int t = wid / ksplit, kpart = wid - t * ksplit;
     if (t >= T) return;
     const int nitems = H / 16;
     const size_t stride = (size_t)H + MI_EP_ROW_META_BYTES;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
                 q[it][h * 2 + jj] = packed;
             }
     }
-    for (int k = 0; k < K; ++k) {
+    for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;          // wave-uniform
         const int slot = __shfl(slot_l, k, kWave);
         const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
@@ -140,10 +142,12 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
 template <bool I32>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
-    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll)
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit)
 {
     const int lane = lane_id();
-    const int t = blockIdx.x * kStageWaves + threadIdx.x / kWave;
+    // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
+    const int wid = blockIdx.x * kStageWaves + threadIdx.x / kWave;
+    const int t = wid / ksplit, kpart = wid - t * ksplit;
     if (t >= T) return;
     const int nitems = H / 8;
     const size_t stride = (size_t)H * 2 + MI_EP_ROW_META_BYTES;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
         const int item = it * kWave + lane;
         if (item < nitems) raw[it] = src[item];
     }
-    for (int k = 0; k < K; ++k) {
+    for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;
         const int slot = __shfl(slot_l, k, kWave);
         const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
@@ -267,7 +271,8 @@ extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx
     if (T == 0) return MI_EP_OK;
     if (!x || !topk_idx || !send_token_idx_small || !send_data_offset || !rows) return MI_EP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (T + kStageWaves - 1) / kStageWaves;
+    const int ksplit = T <= 512 ? K : 1;            // decode-size batches: one wave per (token, k) instead of per token
+    const int blocks = (int)(((long long)T * ksplit + kStageWaves - 1) / kStageWaves);
     const int threads = kWave * kStageWaves;
     const uint16_t *xp = (const uint16_t *)x;
     uint8_t *rp = (uint8_t *)rows;
@@ -275,7 +280,7 @@ extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx
     pp.p[0] = rp;
     const LLGeom ll{0, 0, 0};
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll)
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll, ksplit)
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
@@ -405,11 +410,12 @@ extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int i
     }
     const LLGeom ll{E / W, W, max_tokens};
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (T + kStageWaves - 1) / kStageWaves;
+    const int ksplit = T <= 512 ? K : 1;            // decode-size batches: one wave per (token, k) instead of per token
+    const int blocks = (int)(((long long)T * ksplit + kStageWaves - 1) / kStageWaves);
     const int threads = kWave * kStageWaves;
     const uint16_t *xp = (const uint16_t *)x;
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll)
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll, ksplit)
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
