@@ -100,14 +100,14 @@ def kernel_bytes(name, T, K, H, n_pairs, n_recv):
     """Algorithmic HBM bytes of one launch."""
     row = H + 16
     return {
-        "dispatch_stage": T * H * 2 + n_pairs * row,            # read bf16 tokens once, write one int8 row per (t,k)
-        "dispatch_pull": 2 * n_recv * row,                      # read staged rows, write recv_x / scales / triples
+        "dispatch_stage": T * H * 2 + T * row + n_pairs * 8,    # read bf16 tokens once, write one int8 row per token + the index
+        "dispatch_pull": 2 * n_recv * row + n_recv * 8,         # read a token row + index entry per received row, write recv_x / scales / triples
         "combine_push": 2 * n_recv * H * 2,                     # read bf16 rows, write them into the owners' slots
         "combine_reduce": n_pairs * H * 2 + T * H * 2,          # read K slots per token, write one bf16 row
     }[name]
 
 
-PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatch_pull": "pull_kernel",
+PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatch_pull": "pull_indexed_kernel",
                     "combine_push": "combine_push_kernel", "combine_reduce": "combine_reduce_kernel<false, 8>"}
 
 

@@ -155,6 +155,21 @@ int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx_is_i32, co
 int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset,
                         int num_ranks, int num_local_experts, int hidden, int quant_mode, int rows_hint,
                         void *recv_x, float *recv_x_scales, int32_t *recv_src_idx, void *stream);
+/* Compact staging for the pull transport (what the host runtime uses in normal mode).  A token selected by K experts is
+ * quantised and written ONCE -- row t of `region` = payload | {scale, t, 0, my_rank} -- instead of once per (t, k); the
+ * expert-sorted order travels as an index of K * 8 bytes per token: entry send_data_offset[e] + send_token_idx_small[t,k]
+ * = {t, k} (u32 pairs) at byte mi_ep_dispatch_index_offset(...) of the region.  Staging writes T*(H+16) + T*K*8 bytes
+ * instead of T*K*(H+16); the received rows, scales and (src, t, k) triples are identical to stage + pull
+ * (reference contract: cam_moe_dispatch_normal.h:717-760).  `region_bytes` (the same on every rank) fixes the index offset
+ * and the token capacity, index_offset / row_bytes; stage_compact returns MI_EP_EINVAL when T exceeds it.
+ * pull_indexed: row r of segment i = (le, src), position j, is token row index[pull_offset[i] + j].t of src_base[src]. */
+size_t mi_ep_dispatch_index_offset(int hidden, int quant_mode, int num_topk, size_t region_bytes);
+int mi_ep_dispatch_stage_compact(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                                 const int32_t *send_data_offset, int num_tokens, int num_topk, int hidden, int num_experts,
+                                 int my_rank, int quant_mode, void *region, size_t region_bytes, void *stream);
+int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset,
+                                int num_ranks, int num_local_experts, int hidden, int num_topk, int quant_mode, int rows_hint,
+                                size_t region_bytes, void *recv_x, float *recv_x_scales, int32_t *recv_src_idx, void *stream);
 
 /* ---- A4/A6 combine ---------------------------------------------------------------------------
  * push: row r < total (= *total_rows_dev if non-NULL else rows_hint) of x [R,H] bf16 with triple

@@ -290,8 +290,9 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     EP_HOST_ASSERT_S(E <= 2048, "num_experts (", E, ") must be <= 2048");
     const int qm = quant_mode_of(use_quant, quant_type);
     const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
-    EP_HOST_ASSERT_S((size_t)T * K * rb <= region_bytes, "dispatch window too small: need ", (size_t)T * K * rb,
-                     " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
+    // compact staging: one row per TOKEN plus K index entries (mi_ep_dispatch_stage_compact), not one row per (t, k)
+    EP_HOST_ASSERT_S((size_t)T <= mi_ep_dispatch_index_offset(H, qm, K, region_bytes) / rb, "dispatch window too small: need ",
+                     (size_t)T * (rb + (size_t)K * 8), " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
     check_status("intranode_dispatch");
     ++profile_calls;
     const Layout &lay = layout_for(*topk_idx, E);
@@ -303,9 +304,9 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
 
     // sender side: stage into the own window, publish counts, raise the "staged" flag on every peer
     uint8_t *my_rows = region(kDispatch, ep);
-    { ProfScope ps_(this, "dispatch_stage", st); MI_EP_CHECK(mi_ep_dispatch_stage(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
+    { ProfScope ps_(this, "dispatch_stage", st); MI_EP_CHECK(mi_ep_dispatch_stage_compact(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
                                      lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
-                                     H, E, (int)rank, qm, my_rows, st)); }
+                                     H, E, (int)rank, qm, my_rows, region_bytes, st)); }
     auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
 
@@ -348,9 +349,9 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
         dynamic_scales_out = at::empty({rows_alloc}, at::dtype(at::kFloat).device(dev));
         expand_idx_out = at::empty({rows_alloc * 3}, i32);
         ProfScope ps_(this, "dispatch_pull", st);
-        MI_EP_CHECK(mi_ep_dispatch_pull((const void *const *)src_peers.data(), recv_count.data_ptr<int>(), pull_offset.data_ptr<int>(), W,
-                                        L, H, qm, (int)rows_alloc, expandx_out.data_ptr(),
-                                        use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr, expand_idx_out.data_ptr<int>(), st));
+        MI_EP_CHECK(mi_ep_dispatch_pull_indexed((const void *const *)src_peers.data(), recv_count.data_ptr<int>(), pull_offset.data_ptr<int>(), W,
+                                                L, H, K, qm, (int)rows_alloc, region_bytes, expandx_out.data_ptr(),
+                                                use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr, expand_idx_out.data_ptr<int>(), st));
     };
     static const bool speculate = get_value_from_env("DEEPEP_SPECULATIVE_RECV", 1) != 0;
     int64_t guess = 0;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const 
 template <bool I32, bool EPS>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
-    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit)
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off)
 {
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
@@ -122,6 +122,21 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
                 q[it][h * 2 + jj] = packed;
             }
     }
+    if (idx_off) {
+        // compact staging (normal-mode pull transport): the row is written ONCE at slot t; the expert-sorted index tells the
+        // receivers which token row each of their rows is (K-fold less staging traffic than one copy per (t, k))
+        uint8_t *base = (uint8_t *)dsts.p[0];
+        uint8_t *row = base + (size_t)t * stride;
+        u32x4 *dst = (u32x4 *)row;
+#pragma unroll
+        for (int it = 0; it < kMaxItems; ++it) {
+            const int item = it * kWave + lane;
+            if (item < nitems) dst[item] = q[it];
+        }
+        if (lane == 0) *(u32x4 *)(row + H) = u32x4{__float_as_uint(scale_out), (uint32_t)t, 0u, (uint32_t)my_rank};
+        if (lane < K && e_l >= 0) ((uint2 *)(base + idx_off))[slot_l] = uint2{(uint32_t)t, (uint32_t)lane};
+        return;
+    }
     for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;          // wave-uniform
         const int slot = __shfl(slot_l, k, kWave);
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
 template <bool I32>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
-    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit)
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off)
 {
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
@@ -167,6 +182,19 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     for (int it = 0; it < kIt; ++it) {
         const int item = it * kWave + lane;
         if (item < nitems) raw[it] = src[item];
+    }
+    if (idx_off) {                                  // compact staging, see stage_int8_kernel
+        uint8_t *base = (uint8_t *)dsts.p[0];
+        uint8_t *row = base + (size_t)t * stride;
+        u32x4 *dst = (u32x4 *)row;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int item = it * kWave + lane;
+            if (item < nitems) dst[item] = raw[it];
+        }
+        if (lane == 0) *(u32x4 *)(row + (size_t)H * 2) = u32x4{0u, (uint32_t)t, 0u, (uint32_t)my_rank};
+        if (lane < K && e_l >= 0) ((uint2 *)(base + idx_off))[slot_l] = uint2{(uint32_t)t, (uint32_t)lane};
+        return;
     }
     for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;
@@ -254,6 +282,70 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
     pull_body(srcs, cum, pull_offset, seg_capacity, W, LW, payload_bytes, recv_x, recv_scales, recv_src_idx, row_capacity);
 }
 
+// pull for compact staging (mi_ep_dispatch_stage_compact): output row r of segment (le, src), position j, is token row
+// index[pull_offset + j].t of rank src.  The index entry of a wave's next row is requested before the current row is copied,
+// so the extra dependent (possibly remote) read is off the critical path.  Token rows are read up to K times (once per
+// selected expert): plain loads, so the local ones come from L2 / MALL after the first touch.
+__global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
+    PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int W, int LW,
+    int payload_bytes, size_t idx_off, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
+    int32_t *__restrict__ recv_src_idx, int row_capacity)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
+    for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
+    __syncthreads();
+    const int total = min(cum[LW - 1], row_capacity);
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
+    const int n16 = payload_bytes / 16;
+    const long long nw = (long long)gridDim.x * kPullWaves;
+    auto entry = [&](long long r, int &src) -> uint2 {          // wave-uniform
+        int lo = 0, hi = LW - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] > r) hi = mid; else lo = mid + 1;
+        }
+        const int j = (int)(r - (lo ? cum[lo - 1] : 0));
+        src = lo % W;
+        return ((const uint2 *)((const uint8_t *)srcs.p[src] + idx_off))[(size_t)pull_offset[lo] + j];
+    };
+    long long r = (long long)blockIdx.x * kPullWaves + wave;
+    int src_n = 0;
+    uint2 e_n = uint2{0u, 0u};
+    if (r < total) e_n = entry(r, src_n);
+#pragma unroll 1
+    while (r < total) {
+        const int src = src_n;
+        const uint2 e = e_n;
+        const long long rn = r + nw;
+        if (rn < total) e_n = entry(rn, src_n);                  // in flight while this row is copied
+        const uint8_t *srow = (const uint8_t *)srcs.p[src] + (size_t)e.x * stride;
+        const u32x4 *s16 = (const u32x4 *)srow;
+        u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
+        for (int base = 0; base < n16; base += kWave * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = base + u * kWave + lane;
+                if (item < n16) v[u] = s16[item];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = base + u * kWave + lane;
+                if (item < n16) d16[item] = v[u];
+            }
+        }
+        if (lane == 0) {
+            if (recv_scales) recv_scales[r] = *(const float *)(srow + payload_bytes);
+            recv_src_idx[r * 3 + 0] = src;
+            recv_src_idx[r * 3 + 1] = (int32_t)e.x;
+            recv_src_idx[r * 3 + 2] = (int32_t)e.y;
+        }
+        r = rn;
+    }
+}
+
 }  // namespace mi_ep
 
 using namespace mi_ep;
@@ -263,15 +355,22 @@ extern "C" size_t mi_ep_dispatch_row_bytes(int hidden, int quant_mode)
     return (size_t)hidden * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1) + MI_EP_ROW_META_BYTES;
 }
 
-extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx_is_i32,
-                                    const int32_t *send_token_idx_small, const int32_t *send_data_offset, int T, int K,
-                                    int H, int E, int my_rank, int quant_mode, void *rows, void *stream)
+extern "C" size_t mi_ep_dispatch_index_offset(int hidden, int quant_mode, int topk, size_t region_bytes)
+{
+    const size_t rb = mi_ep_dispatch_row_bytes(hidden, quant_mode);
+    const size_t cap = region_bytes / (rb + (size_t)topk * 8);      // tokens the region holds with their topk index entries
+    return cap * rb;
+}
+
+static int stage_launch(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                        const int32_t *send_data_offset, int T, int K, int H, int E, int my_rank, int quant_mode, void *rows,
+                        size_t idx_off, void *stream)
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0) return MI_EP_EINVAL;
     if (T == 0) return MI_EP_OK;
     if (!x || !topk_idx || !send_token_idx_small || !send_data_offset || !rows) return MI_EP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int ksplit = T <= 512 ? K : 1;            // decode-size batches: one wave per (token, k) instead of per token
+    const int ksplit = (T <= 512 && !idx_off) ? K : 1;   // decode-size batches: one wave per (token, k) instead of per token
     const int blocks = (int)(((long long)T * ksplit + kStageWaves - 1) / kStageWaves);
     const int threads = kWave * kStageWaves;
     const uint16_t *xp = (const uint16_t *)x;
@@ -280,7 +379,7 @@ extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx
     pp.p[0] = rp;
     const LLGeom ll{0, 0, 0};
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll, ksplit)
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll, ksplit, idx_off)
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
@@ -296,6 +395,27 @@ extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx
     }
 #undef MI_EP_STAGE
     return launch_status();
+}
+
+extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx_is_i32,
+                                    const int32_t *send_token_idx_small, const int32_t *send_data_offset, int T, int K,
+                                    int H, int E, int my_rank, int quant_mode, void *rows, void *stream)
+{
+    return stage_launch(x, topk_idx, idx_is_i32, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, quant_mode, rows, 0,
+                        stream);
+}
+
+extern "C" int mi_ep_dispatch_stage_compact(const void *x, const void *topk_idx, int idx_is_i32,
+                                            const int32_t *send_token_idx_small, const int32_t *send_data_offset, int T, int K,
+                                            int H, int E, int my_rank, int quant_mode, void *region, size_t region_bytes,
+                                            void *stream)
+{
+    if (H <= 0 || K <= 0) return MI_EP_EINVAL;
+    const size_t rb = mi_ep_dispatch_row_bytes(H, quant_mode);
+    const size_t idx_off = mi_ep_dispatch_index_offset(H, quant_mode, K, region_bytes);
+    if (idx_off == 0 || (size_t)T > idx_off / rb) return MI_EP_EINVAL;          // region too small for T tokens
+    return stage_launch(x, topk_idx, idx_is_i32, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, quant_mode, region,
+                        idx_off, stream);
 }
 
 extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_count,
@@ -317,6 +437,31 @@ extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32
     const size_t lds = (size_t)L * W * sizeof(int32_t);
     pull_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
         pp, recv_count, pull_offset, 0, W, L * W, payload, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint);
+    return launch_status();
+}
+
+extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t *recv_count,
+                                           const int32_t *pull_offset, int W, int L, int H, int K, int quant_mode,
+                                           int rows_hint, size_t region_bytes, void *recv_x, float *recv_x_scales,
+                                           int32_t *recv_src_idx, void *stream)
+{
+    if (!src_base_host || !recv_count || !pull_offset || W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || H <= 0 || H % 16 || K <= 0 ||
+        K > MI_EP_MAX_TOPK || !recv_x || !recv_src_idx)
+        return MI_EP_EINVAL;
+    if (rows_hint <= 0) return MI_EP_OK;
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) {
+        if (!src_base_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = const_cast<void *>(src_base_host[i]);
+    }
+    const size_t idx_off = mi_ep_dispatch_index_offset(H, quant_mode, K, region_bytes);
+    if (idx_off == 0) return MI_EP_EINVAL;
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    long long blocks = ((long long)rows_hint + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const size_t lds = (size_t)L * W * sizeof(int32_t);
+    pull_indexed_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
+        pp, recv_count, pull_offset, W, L * W, payload, idx_off, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint);
     return launch_status();
 }
 
@@ -415,7 +560,7 @@ extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int i
     const int threads = kWave * kStageWaves;
     const uint16_t *xp = (const uint16_t *)x;
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll, ksplit)
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll, ksplit, (size_t)0)
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);

@@ -31,6 +31,10 @@ def _lib():
     lib.mi_ep_notify_tables.argtypes = [V, I, I, I, I] + [V] * 10 + [V]
     lib.mi_ep_dispatch_stage.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, V]
     lib.mi_ep_dispatch_pull.argtypes = [V, V, V, I, I, I, I, I, V, V, V, V]
+    lib.mi_ep_dispatch_index_offset.restype = c_size_t
+    lib.mi_ep_dispatch_index_offset.argtypes = [I, I, I, c_size_t]
+    lib.mi_ep_dispatch_stage_compact.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, c_size_t, V]
+    lib.mi_ep_dispatch_pull_indexed.argtypes = [V, V, V, I, I, I, I, I, I, c_size_t, V, V, V, V]
     lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, V]
     lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, V, V, I, I, I, I, V, V]
     lib.mi_ep_combine_pack.argtypes = [V, V, I, I, I, I, V, V, V]
@@ -39,7 +43,7 @@ def _lib():
     lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
     lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, V, I, V]
     for n in ("mi_ep_dispatch_layout mi_ep_signal mi_ep_wait mi_ep_notify_post mi_ep_notify_wait mi_ep_notify_tables "
-              "mi_ep_dispatch_stage mi_ep_dispatch_pull mi_ep_combine_push mi_ep_combine_reduce mi_ep_ll_dispatch_send "
+              "mi_ep_dispatch_stage mi_ep_dispatch_pull mi_ep_dispatch_stage_compact mi_ep_dispatch_pull_indexed mi_ep_combine_push mi_ep_combine_reduce mi_ep_ll_dispatch_send "
               "mi_ep_ll_post_counts mi_ep_ll_dispatch_recv").split():
         getattr(lib, n).restype = c_int
     return lib
@@ -80,9 +84,10 @@ def layout(topk_idx, E, W):
 class InProcEP:
     """Normal + low-latency dispatch/combine for W simulated ranks."""
 
-    def __init__(self, W, E, max_tokens, K, H, device="cuda"):
+    def __init__(self, W, E, max_tokens, K, H, device="cuda", compact=False):
         self.W, self.E, self.L, self.K, self.H = W, E, E // W, K, H
         self.max_tokens = max_tokens
+        self.compact = compact          # normal dispatch through stage_compact + pull_indexed (what the host runtime uses)
         self.dev = torch.device(device)
         u8 = dict(dtype=torch.uint8, device=self.dev)
         rb = max(lib().mi_ep_dispatch_row_bytes(H, QUANT_NONE), lib().mi_ep_dispatch_row_bytes(H, QUANT_INT8))
@@ -109,9 +114,14 @@ class InProcEP:
         flag_ptrs = ptr_array([t.data_ptr() for t in self.flags])
         for r in range(W):
             T = xs[r].shape[0]
-            ck(L_.mi_ep_dispatch_stage(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
-                                       ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K, H, E,
-                                       r, quant_mode, ptr(self.send_win[r]), st))
+            if self.compact:
+                ck(L_.mi_ep_dispatch_stage_compact(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                                   ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K,
+                                                   H, E, r, quant_mode, ptr(self.send_win[r]), self.send_win[r].numel(), st))
+            else:
+                ck(L_.mi_ep_dispatch_stage(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                           ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K, H, E,
+                                           r, quant_mode, ptr(self.send_win[r]), st))
             ck(L_.mi_ep_notify_post(notify_ptrs, W, r, E, ptr(lay[r]["num_tokens_per_expert"]), T, ep, st))
             ck(L_.mi_ep_signal(flag_ptrs, W, r, ep, st))
         outs = []
@@ -139,8 +149,12 @@ class InProcEP:
                 recv_x = torch.zeros((rows, H), dtype=torch.int8, device=self.dev)
                 recv_s = torch.zeros(rows, dtype=torch.float32, device=self.dev)
             src_idx = torch.zeros(rows * 3, **i32)
-            ck(L_.mi_ep_dispatch_pull(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, quant_mode, R,
-                                      ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
+            if self.compact:
+                ck(L_.mi_ep_dispatch_pull_indexed(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
+                                                  R, self.send_win[r].numel(), ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
+            else:
+                ck(L_.mi_ep_dispatch_pull(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, quant_mode, R,
+                                          ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
             outs.append(dict(recv_x=recv_x, recv_x_scales=recv_s, recv_src_idx=src_idx, total=R, layout=lay[r], tables=tb,
                              cnt=cnt))
         torch.cuda.synchronize()

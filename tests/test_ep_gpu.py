@@ -68,7 +68,7 @@ DISPATCH_CASES = [
 ]
 
 
-def _run_dispatch(W, T, H, K, E, drop, active, quant_mode, ragged=True):
+def _run_dispatch(W, T, H, K, E, drop, active, quant_mode, ragged=True, compact=False):
     import ep_harness as Hh
     rng = np.random.default_rng(W * 1000 + T)
     Ts = [T + (r if ragged else 0) for r in range(W)]
@@ -80,17 +80,20 @@ def _run_dispatch(W, T, H, K, E, drop, active, quant_mode, ragged=True):
             x[1, :] = 0                               # an all-zero row (amax = 0)
     idxs = [make_topk(rng, t, K, E, drop, active) if t else np.zeros((0, K), np.int64) for t in Ts]
     ws = [rng.standard_normal((t, K)).astype(np.float32) for t in Ts]
-    h = Hh.InProcEP(W, E, max(Ts) + 1, K, H)
+    h = Hh.InProcEP(W, E, max(Ts) + 1, K, H, compact=compact)
     got = h.dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).cuda() for i in idxs], quant_mode)
     return h, xs, idxs, ws, got
 
 
 @pytest.mark.parametrize("W,T,H,K,E,drop,active", DISPATCH_CASES)
 @pytest.mark.parametrize("quant", [False, True])
-def test_normal_dispatch_combine_bit_exact(W, T, H, K, E, drop, active, quant):
+@pytest.mark.parametrize("compact", [False, True], ids=["replicated", "compact"])
+def test_normal_dispatch_combine_bit_exact(W, T, H, K, E, drop, active, quant, compact):
+    """stage + pull (one staged row per (t, k): the all-to-all transport's format) and stage_compact + pull_indexed (one row
+    per token + index: what the host runtime uses) must both reproduce the oracle bit for bit."""
     import ep_harness as Hh
     qm = Hh.QUANT_INT8 if quant else Hh.QUANT_NONE
-    h, xs, idxs, ws, got = _run_dispatch(W, T, H, K, E, drop, active, qm)
+    h, xs, idxs, ws, got = _run_dispatch(W, T, H, K, E, drop, active, qm, compact=compact)
     want = O.normal_dispatch(xs, idxs, E, quant)
     for r in range(W):
         g, w = got[r], want[r]
