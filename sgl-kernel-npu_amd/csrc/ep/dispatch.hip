@@ -476,7 +476,7 @@ __global__ void ll_post_counts_kernel(PeerPtrs peers, const int32_t *__restrict_
     const int d = blockIdx.x;
     uint64_t *g = (uint64_t *)peers.p[d];
     for (int le = threadIdx.x; le < L; le += blockDim.x)
-        sys_store_u64(g + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)cnt[d * L + le]);
+        sys_store_u64_relaxed(g + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)cnt[d * L + le]);
 }
 
 // one workgroup: wait for the L*W count granules, inclusive cumsum in idx-i order, per-expert counts
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, co
     if (my_counts_out) {
         for (int i = tid; i < LW; i += blockDim.x) {
             const int d = i / L, le = i % L;
-            sys_store_u64((uint64_t *)count_peers.p[d] + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)my_counts_out[d * L + le]);
+            sys_store_u64_relaxed((uint64_t *)count_peers.p[d] + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)my_counts_out[d * L + le]);
         }
     }
     const uint64_t t0 = ticks_100mhz();

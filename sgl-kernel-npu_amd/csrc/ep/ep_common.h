@@ -40,6 +40,12 @@ __device__ __forceinline__ void sys_store_u64(uint64_t *p, uint64_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// {epoch, value} granules are their own flag (nothing else has to be published with them): relaxed.  A release per
+// store would have every posting thread write the L2 back, and those write-backs serialise.
+__device__ __forceinline__ void sys_store_u64_relaxed(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ uint64_t sys_load_u64(const uint64_t *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -40,7 +40,7 @@ __global__ void notify_post_kernel(PeerPtrs peers, int W, int my_rank, int E, co
     uint64_t *row = (uint64_t *)peers.p[d] + (size_t)my_rank * (E + 1);
     for (int e = threadIdx.x; e <= E; e += blockDim.x) {
         const uint32_t v = (e < E) ? (uint32_t)cnt[e] : (uint32_t)num_tokens;
-        sys_store_u64(row + e, ((uint64_t)epoch << 32) | v);
+        sys_store_u64_relaxed(row + e, ((uint64_t)epoch << 32) | v);
     }
     if (sig_epoch && threadIdx.x == 0) sys_store_u64((uint64_t *)sig_peers.p[d] + my_rank, sig_epoch);
 }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int d = i / (E + 1), e = i - d * (E + 1);
             const uint32_t v = (e < E) ? (uint32_t)post.cnt[e] : (uint32_t)post.num_tokens;
-            sys_store_u64((uint64_t *)post.notify.p[d] + (size_t)me * (E + 1) + e, ((uint64_t)notify_epoch << 32) | v);
+            sys_store_u64_relaxed((uint64_t *)post.notify.p[d] + (size_t)me * (E + 1) + e, ((uint64_t)notify_epoch << 32) | v);
         }
         if (threadIdx.x < W) sys_store_u64((uint64_t *)post.flags.p[threadIdx.x] + me, post.sig_epoch);
     }
