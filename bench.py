@@ -274,11 +274,16 @@ def main():
             result["mla_decode"] = mla
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(T)
-    # The JSON line should be the last thing on stdout: RCCL prints its version banner to stdout when the communicator
-    # is torn down, so tear down first, then print (normal interpreter exit, so profilers can finalise).
+    # The JSON line must be the last thing on stdout.  RCCL printf()s its version banner at communicator creation; with stdout
+    # a pipe that text waits in libc's buffer until exit -- i.e. after anything Python prints -- unless it is flushed first.
     torch.cuda.synchronize()
     dist.destroy_process_group()
     sys.stderr.flush()
+    try:                                   # the banner sits in libc's stdout buffer (a pipe is fully buffered): push it out first
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     print(json.dumps(result), flush=True)
 
 
