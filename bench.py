@@ -51,10 +51,16 @@ def init_dist(n):
         rank = int(os.environ.get("RANK", 0))
         world = int(os.environ.get("WORLD_SIZE", n))
         local = int(os.environ.get("LOCAL_RANK", rank))
+        backend = "nccl"
+        if os.environ.get("BENCH_SINGLE_DEVICE") == "1":      # test hook: every rank on cuda:0 over gloo (the launch / JSON / fallback
+            local, backend = 0, "gloo"                         # plumbing of the N > 1 path on a one-GPU box; not a measurement)
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -83,6 +89,16 @@ def one_step(buf, x, topk_idx, topk_w, y):
         y = (recv[0].float() * recv[1][:, None]).to(torch.bfloat16)
     out, _, _ = buf.combine(y, handle)
     return out, n, y, recv, handle
+
+
+def flush_c_stdout():
+    """RCCL printf()s its version banner at communicator creation; with stdout a pipe that text waits in libc's buffer until
+    exit -- i.e. after the JSON line -- unless it is pushed out first (every rank, right after the first collective)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def barrier_sync():
@@ -195,6 +211,7 @@ def main():
         validated = False
     flag = torch.tensor([1 if validated else 0], device="cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    flush_c_stdout()
     if int(flag.item()) == 0 and strategy != "alltoall":
         strategy = "alltoall"
         buf = deep_ep.Buffer(group, normal_strategy="alltoall", low_latency_strategy="alltoall")
@@ -230,6 +247,7 @@ def main():
 
     if rank != 0:
         dist.destroy_process_group()
+        flush_c_stdout()
         return
     n_pairs = int((topk_idx >= 0).sum().item())
     result = {
@@ -279,11 +297,7 @@ def main():
     torch.cuda.synchronize()
     dist.destroy_process_group()
     sys.stderr.flush()
-    try:                                   # the banner sits in libc's stdout buffer (a pipe is fully buffered): push it out first
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:  # noqa: BLE001
-        pass
+    flush_c_stdout()
     print(json.dumps(result), flush=True)
 
 

@@ -1,0 +1,48 @@
+"""bench.py contract: the launch line the driver uses for N > 1, exercised on ONE GPU (every rank on cuda:0, gloo bootstrap --
+BENCH_SINGLE_DEVICE=1), and the default N = 1 run.  The JSON object must be the LAST line of stdout."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.strip().splitlines() if l.strip()]
+    assert lines, "bench.py printed nothing"
+    return json.loads(lines[-1])          # must parse: nothing may follow the JSON line
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_one_gpu():
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["strategy"] == "default" and d["validated_round_trip"] is True
+    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-mla"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in REQUIRED + ("roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "u8" and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
