@@ -261,9 +261,12 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
         }
     }
 #ifdef GEMM_TIMING
+    const uint64_t t_issued = __builtin_amdgcn_s_memtime();    // all stores issued (not yet drained)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0 && blockIdx.x == 3 && blockIdx.y < 4)
+    if (lane == 0 && blockIdx.x == 3 && blockIdx.y < 4) {
+        g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 2] = (float)(t_issued - t_epi);
         g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 3] = (float)(__builtin_amdgcn_s_memtime() - t_epi);
+    }
 #endif
 }
 

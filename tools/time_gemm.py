@@ -37,4 +37,4 @@ for name, K, N in (("gemm1", H, I2), ("gemm2", I2 // 2, H)):
         buf = np.zeros(256, dtype=np.float32)
         L.mi_ep_gemm_dbg(buf.ctypes.data_as(c_vp))
         dbg = torch.from_numpy(buf).reshape(-1, 4)[:64]
-        print("   cycles: per k-tile [wait, compute], per tile [setup->first data, epilogue]:", dbg.mean(dim=0).tolist())
+        print("   cycles: per k-tile [wait, compute], per tile epilogue [until all stores issued, until drained]:", dbg.mean(dim=0).tolist())
