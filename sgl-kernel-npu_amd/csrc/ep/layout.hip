@@ -165,35 +165,36 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void layout_assign_kernel(
 
 // Small batches (T <= 1024 tokens: decode / low-latency mode): the three passes in ONE workgroup of 16 waves, wave w owns
 // units w, w+16, ...; the per-unit histograms never leave LDS.  Same arithmetic and the same deterministic slot order as the three
-// kernels above; it only removes two launches (~10 us of a ~60 us low-latency dispatch).
-template <bool I32>
+// kernels above; it only removes two launches (~10 us of a ~60 us low-latency dispatch).  UT = tokens per unit: 64 like the
+// kernels above, or 16 for <= 256 tokens so that a 128-token decode batch occupies 8 waves instead of 2.
+template <bool I32, int UT>
 __global__ __launch_bounds__(1024) void layout_small_kernel(
     const void *__restrict__ topk_idx, int T, int K, int E, int W, int nbits, int32_t *__restrict__ num_tokens_per_rank,
     int32_t *__restrict__ num_tokens_per_expert, int32_t *__restrict__ is_token_in_rank,
     int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
-    const int U = (T + kUnitTokens - 1) / kUnitTokens;
+    const int U = (T + UT - 1) / UT;
     int32_t *hist = smem;                                                   // [U][E], becomes the running base in pass 2
     unsigned long long *rmask = (unsigned long long *)(smem + U * E);       // [U][64]
-    int32_t *rank_cnt = (int32_t *)(rmask + U * kUnitTokens);               // [W]
+    int32_t *rank_cnt = (int32_t *)(rmask + U * UT);               // [W]
     int32_t *wave_tot = rank_cnt + W;                                       // [16]
     int32_t *carry = wave_tot + 16;                                         // [1]
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / kWave;
     const int L = E / W;
     for (int i = tid; i < U * E; i += blockDim.x) hist[i] = 0;
-    for (int i = tid; i < U * kUnitTokens; i += blockDim.x) rmask[i] = 0ull;
+    for (int i = tid; i < U * UT; i += blockDim.x) rmask[i] = 0ull;
     for (int i = tid; i < W; i += blockDim.x) rank_cnt[i] = 0;
     if (tid == 0) carry[0] = 0;
     __syncthreads();
     // ---- pass 1: histogram + token -> rank masks; wave w takes units w, w + 16, ...
     for (int unit = wave; unit < U; unit += 16) {
-        const int t0 = unit * kUnitTokens;
-        const int ntok = min(kUnitTokens, T - t0);
+        const int t0 = unit * UT;
+        const int ntok = min(UT, T - t0);
         const long long p0 = (long long)t0 * K;
         const int npairs = ntok * K;
         int32_t *h = hist + unit * E;
-        unsigned long long *rm = rmask + unit * kUnitTokens;
+        unsigned long long *rm = rmask + unit * UT;
         for (int c = 0; c < npairs; c += kWave) {
             const int p = c + lane;
             if (p < npairs) {
@@ -247,9 +248,9 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
     // ---- pass 3: slot of every (t, k) inside its expert's segment
     __syncthreads();
     for (int unit = wave; unit < U; unit += 16) {
-        const int t0 = unit * kUnitTokens;
+        const int t0 = unit * UT;
         const long long p0 = (long long)t0 * K;
-        const int npairs = min(kUnitTokens, T - t0) * K;
+        const int npairs = min(UT, T - t0) * K;
         int32_t *cnt = hist + unit * E;
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int c = 0; c < npairs; c += kWave) {
@@ -302,20 +303,24 @@ extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T
     while ((1 << nbits) < E) ++nbits;
     // one launch instead of three for decode-size batches; at 4096 tokens the single workgroup (one CU walking 64 units)
     // measured ~30 us slower than the three parallel kernels, so larger batches keep those
-    if (U >= 1 && U <= 16 && (size_t)U * E <= 16384 && ((U * E) & 1) == 0) {
-        const size_t ldsf = (size_t)U * E * 4 + (size_t)U * kUnitTokens * 8 + (size_t)(W + 16 + 4) * 4;
+    const int ut = T <= 256 ? 16 : kUnitTokens;            // unit size of the single-launch path
+    const int Us = (T + ut - 1) / ut;
+    if (Us >= 1 && Us <= 16 && (size_t)Us * E <= 16384 && ((Us * E) & 1) == 0) {
+        const size_t ldsf = (size_t)Us * E * 4 + (size_t)Us * ut * 8 + (size_t)(W + 16 + 4) * 4;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)layout_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)layout_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)layout_small_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)layout_small_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)layout_small_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)layout_small_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        if (idx_is_i32)
-            layout_small_kernel<true><<<1, 1024, ldsf, s>>>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert,
-                                                            is_token_in_rank, send_token_idx_small, send_data_offset);
-        else
-            layout_small_kernel<false><<<1, 1024, ldsf, s>>>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert,
-                                                             is_token_in_rank, send_token_idx_small, send_data_offset);
+#define MI_EP_LAYOUT_SMALL(I32, UT)                                                                                            \
+    layout_small_kernel<I32, UT><<<1, 1024, ldsf, s>>>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, \
+                                                       is_token_in_rank, send_token_idx_small, send_data_offset)
+        if (ut == 16) { if (idx_is_i32) MI_EP_LAYOUT_SMALL(true, 16); else MI_EP_LAYOUT_SMALL(false, 16); }
+        else { if (idx_is_i32) MI_EP_LAYOUT_SMALL(true, 64); else MI_EP_LAYOUT_SMALL(false, 64); }
+#undef MI_EP_LAYOUT_SMALL
         return launch_status();
     }
     if (U > 0) {
