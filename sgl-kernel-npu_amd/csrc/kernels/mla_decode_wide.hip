@@ -166,6 +166,9 @@ template <bool BF16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mla_decode_wide_kernel(MlaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+#ifdef MLAW_TIMING
+    const uint64_t t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c32 = lane & 31, kg = lane >> 5;
     const int head_blocks = (p.group + 127) / 128;
@@ -192,6 +195,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     cx.lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     cx.ring_addr = cx.lds_base + (uint32_t)(kSlots * kSlotBytes + wave * kSlots * kRingEntries * 4);
 
+    // Block ids of the first kLead tiles are requested BEFORE the 36 Q^T loads: the prologue below then only has to wait for
+    // these (older) operations before it can start the KV fill, which runs while Q^T is still in flight.  (All 256 workgroups
+    // are in their prologue at once and HBM serves that burst slowly: Q^T, then block ids, then KV one after the other cost
+    // 35k cycles per workgroup, 11 % of the kernel at C4.)
+    constexpr int kLead = 2;
+#pragma unroll
+    for (int d = 0; d < kLead; ++d) wide_issue_rows(cx, t_begin + d);
     // Q^T fragments: lane (c32, kg) holds q[head][16 ks + 8 kg .. +8]
     s16x8 qf[36];
     {
@@ -209,16 +219,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     volatile uint32_t *flag = (volatile uint32_t *)(lds + kFlagOff);
-    if (threadIdx.x == 0) *flag = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): Q^T is resident; no compiler-visible vector load
-                                                               // is pending when the tile loop starts (see dma16_sbase)
+    if (threadIdx.x == 0) *(uint32_t *)(lds + kFlagOff) = 0;      // plain LDS store (the volatile one is a flat store + vmcnt(0))
     const float cs = p.sm_scale * 1.4426950408889634f;
     // kLead = how many tiles ahead of the one entering QK^T the fill is issued.  The slot ring has 4 entries and the loop still
     // reads tile t-1 for P.V while tile t is in QK^T, so the fill runs 2 ahead.  Issue order per tile x: R(x + kLead + 2) (block
     // ids), D(x + kLead) (9 pieces) = 10 vector-memory operations; the wait at the top of tile x leaves the youngest 10 in
     // flight, i.e. this wave's pieces of tile x and the block ids of tile x + kLead have landed.  After the barrier tile x
     // is complete in LDS and the slot of tile x-2 is free for tile x+2.
-    constexpr int kLead = 2;
     auto tile_top = [&](int t) -> TileRows {
 #ifndef MLAW_NO_PIECES
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -229,9 +236,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // prologue in steady-state issue order: ... D(t) | R(t + kLead) D(t+1) | ...
     auto prologue = [&]() {
-#pragma unroll
-        for (int d = 0; d < kLead; ++d) wide_issue_rows(cx, t_begin + d);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the block ids (issued first) have landed once at most the 36 Q^T loads of this wave are outstanding; a wave without
+        // heads issued none
+        if (__any(head_ok)) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int d = 0; d < kLead; ++d) {
             if (d + 2 >= kLead) wide_issue_rows(cx, t_begin + d + 2);      // R(x + kLead + 2) of the virtual iteration x = t_begin + d - kLead
@@ -241,6 +249,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     if (t_begin < t_end) prologue();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): Q^T is resident (and the first fills have landed): no
+                                                               // compiler-visible vector load is pending when the tile loop starts
     // ---- O^T[d, head] += V^T . P^T, split by OUTPUT DIMENSION: wave w owns d in [128 w, 128 w + 128) for all 128 heads of the
     // workgroup (accumulator block dbl*4 + hb = 32 dims x 32 heads), so a V tile is read from LDS once per workgroup instead
     // of once per wave: 16 ds_read_b64_tr_b16 + 8 ds_read_b128 per wave and tile instead of 64 transpose reads.  With one
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             publish(psum, pk);
             psum = 0.f;
             const float tmax = qk(t + 1, rows, s);
-            if (__any(tmax > m_run + kGuard)) *flag = 1;
+            if (__any(tmax > m_run + kGuard)) *(uint32_t *)(lds + kFlagOff) = 1;
             MLAW_TICK(1)
             pv_x(t, piece);
             MLAW_TICK(2)
@@ -422,9 +432,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         pv_x(t_end - 1, no_embed);
     }
 #ifdef MLAW_TIMING
+    const uint64_t t_loop_end = __builtin_amdgcn_s_memtime();
     if (lane == 0 && blockIdx.x < 64) {
         float *dbg = (float *)p.fix_flags + 1024 + (blockIdx.x * 4 + wave) * 4;
         for (int i = 0; i < 3; ++i) dbg[i] = (float)tm[i] / (float)(t_end - t_begin);
+        float *dbg2 = (float *)p.fix_flags + 1024 + 1024 + (blockIdx.x * 4 + wave) * 4;      // whole-kernel phases
+        dbg2[0] = (float)(t_loop_end - t_entry);               // entry -> end of the tile loop (prologue + all tiles)
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // fills issued past the last tile
@@ -481,57 +494,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         return;
     }
+    // Rows leave through LDS: written straight from the accumulator layout a wave-store is 64 pieces of 16 bytes in 64
+    // different rows; transposed in a wave-private LDS tile, one head block at a time, every half-wave writes 512 (fp32
+    // partial) or 256 (output) contiguous bytes of one head.  (The epilogue costs ~21k cycles per workgroup at C4 either way:
+    // 256 workgroups x 256 KB of partials is a write burst the memory system takes at ~12 B/clk per CU.)
+    constexpr int kEpiRow = 128 * 4 + 16;                      // one head: this wave's 128 dims in fp32, padded
+    uint8_t *const tile = lds + wave * (32 * kEpiRow);          // the KV ring is free now
 #pragma unroll
-    for (int hb = 0; hb < 4; ++hb) {
-        const int hgx = hblk * 128 + hb * 32 + c32;
-        if (hgx >= p.group) continue;
-        const int headx = kvh * p.group + hgx;
-        const float l_h = lmb[hb * 32 + c32], m_h = lmb[128 + hb * 32 + c32];
-        const int64_t idx = ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
-        if (finals) {
-            // out = (w_s O_s + w_p O_p) / (w_s l_s + w_p l_p), w = exp2(m - max m) (the merge kernel's arithmetic, mla_decode.hip)
-            float w_s = 1.f, w_p = 0.f, l_tot = l_h;
-            const float *pp = nullptr;
-            if (role == kSecond) {
-                const int64_t idp = idx - split + (1 - split);
-                const float m_p = p.ws_ml[idp * 2 + 0], l_p = p.ws_ml[idp * 2 + 1];
-                const float mx = fmaxf(m_h, m_p);
-                w_s = m_h == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_h - mx);
-                w_p = m_p == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_p - mx);
-                l_tot = w_s * l_h + w_p * l_p;
-                pp = p.ws_o + idp * kDN + wave * 128 + 4 * kg;
+    for (int hb = 0; hb < 4; ++hb) {                           // static accumulator indices: keep this loop unrolled
+        if (hblk * 128 + hb * 32 >= p.group) continue;
+#pragma unroll
+        for (int dbl = 0; dbl < 4; ++dbl)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = (rg >> 1) * 64 + dbl * 16 + (rg & 1) * 8 + 4 * kg;
+                const f32x16 &a = acc[dbl * 4 + hb];
+                *(f32x4 *)(tile + c32 * kEpiRow + d * 4) = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
             }
-            const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-            uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + wave * 128 + 4 * kg;
+        // wave-private tile: LDS operations of one wave complete in order, no barrier
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int hl = it * 2 + (lane >> 5), ch = lane & 31;
+            const int hgx = hblk * 128 + hb * 32 + hl;
+            if (hgx >= p.group) continue;
+            const int headx = kvh * p.group + hgx;
+            const int64_t idx = ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
+            f32x4 o = *(const f32x4 *)(tile + hl * kEpiRow + ch * 16);
+            const float l_h = lmb[hb * 32 + hl], m_h = lmb[128 + hb * 32 + hl];
+            if (finals) {
+                // out = (w_s O_s + w_p O_p) / (w_s l_s + w_p l_p), w = exp2(m - max m) (the merge kernel's arithmetic, mla_decode.hip)
+                float l_tot = l_h;
+                if (role == kSecond) {
+                    const int64_t idp = idx - split + (1 - split);
+                    const float m_p = p.ws_ml[idp * 2 + 0], l_p = p.ws_ml[idp * 2 + 1];
+                    const float mx = fmaxf(m_h, m_p);
+                    const float w_s = m_h == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_h - mx);
+                    const float w_p = m_p == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_p - mx);
+                    l_tot = w_s * l_h + w_p * l_p;
+                    const f32x4 q = *(const f32x4 *)(p.ws_o + idp * kDN + wave * 128 + ch * 4);
 #pragma unroll
-            for (int dbl = 0; dbl < 4; ++dbl)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int d = (rg >> 1) * 64 + dbl * 16 + (rg & 1) * 8;
-                    const f32x16 &a = acc[dbl * 4 + hb];
-                    f32x4 o = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
-                    if (role == kSecond) {
-                        const f32x4 q = *(const f32x4 *)(pp + d);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = w_s * o[e] + w_p * q[e];
-                    }
-                    const uint32_t w0 = (uint32_t)cvt_out<BF16>(o[0] * inv) | ((uint32_t)cvt_out<BF16>(o[1] * inv) << 16);
-                    const uint32_t w1 = (uint32_t)cvt_out<BF16>(o[2] * inv) | ((uint32_t)cvt_out<BF16>(o[3] * inv) << 16);
-                    *(uint2 *)(orow + d) = uint2{w0, w1};
+                    for (int e = 0; e < 4; ++e) o[e] = w_s * o[e] + w_p * q[e];
                 }
-        } else {
-            float *po = p.ws_o + idx * kDN + wave * 128 + 4 * kg;
-#pragma unroll
-            for (int dbl = 0; dbl < 4; ++dbl)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int d = (rg >> 1) * 64 + dbl * 16 + (rg & 1) * 8;
-                    const f32x16 &a = acc[dbl * 4 + hb];
-                    *(f32x4 *)(po + d) = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
+                const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+                const uint32_t w0 = (uint32_t)cvt_out<BF16>(o[0] * inv) | ((uint32_t)cvt_out<BF16>(o[1] * inv) << 16);
+                const uint32_t w1 = (uint32_t)cvt_out<BF16>(o[2] * inv) | ((uint32_t)cvt_out<BF16>(o[3] * inv) << 16);
+                *(uint2 *)(p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + wave * 128 + ch * 4) = uint2{w0, w1};
+            } else {
+                *(f32x4 *)(p.ws_o + idx * kDN + wave * 128 + ch * 4) = o;
+                if (wave == 0 && ch == 0) {
+                    p.ws_ml[idx * 2 + 0] = m_h;
+                    p.ws_ml[idx * 2 + 1] = l_h;
                 }
-            if (wave == 0 && kg == 0) {
-                p.ws_ml[idx * 2 + 0] = m_h;
-                p.ws_ml[idx * 2 + 1] = l_h;
             }
         }
     }
@@ -540,6 +553,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(word, tag | 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // one L2 write-back
     }
+#ifdef MLAW_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && blockIdx.x < 64) {
+        float *dbg2 = (float *)p.fix_flags + 1024 + 1024 + (blockIdx.x * 4 + wave) * 4;
+        dbg2[1] = (float)(__builtin_amdgcn_s_memtime() - t_loop_end);     // epilogue including the store drain
+    }
+#endif
 }
 
 

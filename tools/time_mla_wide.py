@@ -25,3 +25,5 @@ dbg = ws[part + 4096: part + 4096 + 64 * 4 * 4 * 4].view(torch.float32).reshape(
 print("per-tile s_memtime ticks (100 MHz => x10 ns) [top-wait, qk, softmax+pv]:")
 print("mean over 64 WGs x 4 waves:", dbg[:, :, :3].mean(dim=(0, 1)).tolist())
 print("wave0..3 of WG0:", dbg[0, :, :3].tolist())
+dbg2 = ws[part + 4096 + 4096: part + 4096 + 4096 + 64 * 4 * 4 * 4].view(torch.float32).reshape(64, 4, 4).cpu()
+print("whole kernel, cycles [entry -> end of tile loop, epilogue incl. drain]:", dbg2[:, :, :2].mean(dim=(0, 1)).tolist())
