@@ -320,7 +320,9 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         const uint2 e = e_n;
         const long long rn = r + nw;
         if (rn < total) e_n = entry(rn, src_n);                  // in flight while this row is copied
-        const uint8_t *srow = (const uint8_t *)srcs.p[src] + (size_t)e.x * stride;
+        // a stale index entry must not turn into a wild read: token rows live below the index
+        const size_t trow = min((size_t)e.x, idx_off / stride - 1);
+        const uint8_t *srow = (const uint8_t *)srcs.p[src] + trow * stride;
         const u32x4 *s16 = (const u32x4 *)srow;
         u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
         for (int base = 0; base < n16; base += kWave * 8) {
