@@ -19,3 +19,6 @@ grep "^{" "$OUT/bench_under_rocprof.out" | tail -1 > profiles/r${RND}_bench_n1_u
 cp profiles/r${RND}_* gpurun_out/ 2>/dev/null
 python bench.py 2>/dev/null | grep "^{" | tail -1 > gpurun_out/r${RND}_bench_n1.json
 head -12 profiles/r${RND}_kernel_stats.csv
+# secondary configs (LL latency, fused_deep_moe, primitives, GQA, mla_preprocess)
+python tools/bench_extra.py 2>/dev/null | grep "^{" | tail -1 > gpurun_out/r${RND}_extra_bench_n1.json
+# (MLA wide-kernel PMC counters: bash tools/pmc_mla.sh, medians go into profiles/r${RND}_pmc_mla_decode.json)
