@@ -438,6 +438,43 @@ def permute_fusion_cols(n: int, tile: int = 128) -> np.ndarray:
     return (h * (n // 2) + j * half + i).reshape(-1)
 
 
+def _int_matmul_exact(a_i8: np.ndarray, w_i8: np.ndarray) -> np.ndarray:
+    """a [M, K] int8 x w [N, K] int8 -> int32 [M, N], exact.  Done in float64 through BLAS (|sum| <= K * 128 * 128 < 2^53 for any
+    K this path allows, so every partial sum is an exactly representable integer); NumPy's integer matmul is a scalar loop."""
+    assert a_i8.shape[1] * 128 * 128 < 2 ** 53
+    return np.rint(a_i8.astype(np.float64) @ w_i8.astype(np.float64).T).astype(np.int32)
+
+
+def moe_gemm1_swiglu(a_i8: np.ndarray, a_scale: np.ndarray, w_i8: np.ndarray, w_scale: np.ndarray) -> np.ndarray:
+    """One expert's GEMM1 + per-token dequant + SwiGLU.  a [rows, H] int8 with per-token scales, w [2I, H] int8 / w_scale [2I]
+    in ORIGINAL column order (first I gate, last I up).  d = (float(c) * w_scale[col]) * tok_scale[row]
+    (block_epilogue_per_token_dequant_swiglu.h:250-269); v = up * gate / (1 + exp(-gate)).  -> f32 [rows, I]."""
+    c = _int_matmul_exact(a_i8, w_i8)                                                     # [rows, 2I] exact
+    dd = (c.astype(np.float32) * np.asarray(w_scale, np.float32)[None, :]) * np.asarray(a_scale, np.float32)[:, None]
+    I = dd.shape[1] // 2
+    gate, up = dd[:, :I], dd[:, I:]
+    with np.errstate(over="ignore"):
+        return (up * (gate / (np.float32(1.0) + np.exp(-gate).astype(np.float32)))).astype(np.float32)
+
+
+def moe_rowquant(v: np.ndarray):
+    """Per-row symmetric requantisation of the SwiGLU output: q = rint((v * 127) * (1 / rowmax)), scale = rowmax / 127
+    (...grouped_matmul_slice_m_per_token_dequant_swiglu_quant_multistage_workspace.h:199-265).  -> (int8 [rows, I], f32 [rows])."""
+    v = np.asarray(v, np.float32)
+    rowmax = np.abs(v).max(axis=1).astype(np.float32)
+    inv = np.where(rowmax > 0, np.float32(1.0) / np.where(rowmax > 0, rowmax, 1), 0).astype(np.float32)
+    q = np.rint((v * np.float32(127.0)) * inv[:, None]).astype(np.int32)
+    return q.astype(np.int8), (rowmax / np.float32(127.0)).astype(np.float32)
+
+
+def moe_gemm2(q_i8: np.ndarray, q_scale: np.ndarray, w_i8: np.ndarray, w_scale: np.ndarray) -> np.ndarray:
+    """One expert's GEMM2 + per-token x per-channel dequant: bf16((float(c2) * w_scale[col]) * scale[row]).  w [H, I] int8.
+    -> bf16 bits [rows, H]."""
+    c2 = _int_matmul_exact(q_i8, w_i8)
+    out = (c2.astype(np.float32) * np.asarray(w_scale, np.float32)[None, :]) * np.asarray(q_scale, np.float32)[:, None]
+    return f32_to_bf16_bits_rne(out)
+
+
 def fused_deep_moe(xs_bits, topk_idxs, topk_weights, w13, w13_scale, w2, w2_scale, num_max_dispatch_tokens_per_rank,
                    num_experts) -> List[np.ndarray]:
     """All ranks' fused_deep_moe.  w13[r] int8 [L, 2I, H] / w13_scale[r] f32 [L, 2I] in ORIGINAL column order (first half gate,
@@ -453,28 +490,15 @@ def fused_deep_moe(xs_bits, topk_idxs, topk_weights, w13, w13_scale, w2, w2_scal
     ys = []
     for r in range(W):
         d = disp[r]
-        n = d.total
         H = d.packed_recv_x.shape[1]
         y = np.zeros((d.packed_recv_x.shape[0], H), np.uint16)
         start = 0
         for le in range(L):
             end = int(d.layout_range[(le + 1) * W - 1])
             if end > start:
-                a = d.packed_recv_x[start:end].astype(np.int32)
-                asc = d.packed_recv_x_scales[start:end].astype(np.float32)
-                c = a @ w13[r][le].astype(np.int32).T                                   # [rows, 2I] exact
-                dd = (c.astype(np.float32) * w13_scale[r][le].astype(np.float32)[None, :]) * asc[:, None]
-                I = dd.shape[1] // 2
-                gate, up = dd[:, :I], dd[:, I:]
-                with np.errstate(over="ignore"):
-                    v = (up * (gate / (np.float32(1.0) + np.exp(-gate).astype(np.float32)))).astype(np.float32)
-                rowmax = np.abs(v).max(axis=1).astype(np.float32)
-                inv = np.where(rowmax > 0, np.float32(1.0) / np.where(rowmax > 0, rowmax, 1), 0).astype(np.float32)
-                q = np.rint((v * np.float32(127.0)) * inv[:, None]).astype(np.int32)
-                sc = (rowmax / np.float32(127.0)).astype(np.float32)
-                c2 = q @ w2[r][le].astype(np.int32).T                                    # [rows, H]
-                out = (c2.astype(np.float32) * w2_scale[r][le].astype(np.float32)[None, :]) * sc[:, None]
-                y[start:end] = f32_to_bf16_bits_rne(out)
+                v = moe_gemm1_swiglu(d.packed_recv_x[start:end], d.packed_recv_x_scales[start:end], w13[r][le], w13_scale[r][le])
+                q, sc = moe_rowquant(v)
+                y[start:end] = moe_gemm2(q, sc, w2[r][le], w2_scale[r][le])
             start = end
         ys.append(y)
     return combine(ys, [d.src_info for d in disp], [d.total for d in disp], topk_idxs, topk_weights, E)

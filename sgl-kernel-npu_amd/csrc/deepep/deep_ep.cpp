@@ -69,6 +69,18 @@ Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t n
                           "no HIP device visible: deep_ep_cpp needs an AMD GPU (there is no CPU fallback)");
     HIP_CHECK(hipGetDevice(&device_id));
     timeout_ms = get_value_from_env("DEEPEP_TIMEOUT_MS", 30000);
+    // Host-runtime env knobs of the reference that change the data layout (deep_ep.cpp:62,866-874,939,1076-1079):
+    //  * MOE_SHARED_EXPERT_RANK_NUM > 0 turns the first ranks into shared-expert ranks (num_local_experts becomes
+    //    num_experts / (W - S), one slab per shared rank).  That layout is not built here: refuse it loudly instead of
+    //    silently computing a different expert-to-rank map than the caller's model expects.
+    //  * MOE_ENABLE_TOPK_NEG_ONE=1 makes the reference pass x_active_mask = (topk_idx >= 0) so that -1 selections are
+    //    skipped; without it -1 is outside the reference's contract.  Here ids < 0 (and >= num_experts) are ALWAYS skipped by
+    //    every kernel (layout, stage, reduce), i.e. both settings of the knob behave like "1"; the value is validated only.
+    const int shared_expert_rank_num = get_value_from_env("MOE_SHARED_EXPERT_RANK_NUM", 0);
+    EP_HOST_ASSERT_S(shared_expert_rank_num == 0, "MOE_SHARED_EXPERT_RANK_NUM=", shared_expert_rank_num,
+                     " is not supported on MI355X: shared-expert ranks are not part of this build, run the shared expert outside deep_ep");
+    const int enable_neg_one = get_value_from_env("MOE_ENABLE_TOPK_NEG_ONE", 0);
+    EP_HOST_ASSERT_S(enable_neg_one == 0 || enable_neg_one == 1, "MOE_ENABLE_TOPK_NEG_ONE must be 0 or 1, got ", enable_neg_one);
 
     // Window budget.  The reference sizes its HCCL window with HCCL_BUFFSIZE (MB); DEEPEP_WINDOW_BYTES plays that
     // role here.  Default 6 GiB = six 1-GiB regions: dispatch x2, combine x2, low-latency dispatch x2 (ping-pong),
@@ -80,10 +92,20 @@ Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t n
     window_bytes = kCtrlBytes + 6 * (int64_t)region_bytes;
     void *p = nullptr;
     const bool want_fine = get_value_from_env("DEEPEP_WINDOW_FINEGRAINED", 1) != 0;
-    if (want_fine && hipExtMallocWithFlags(&p, (size_t)window_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+    // The protocol has running kernels poll flag / granule words that peer GPUs write and read rows peers wrote: that needs
+    // fine-grained (system-coherent) memory.  A failed fine-grained allocation is an error, not a silent downgrade; a
+    // coarse-grained window exists only on explicit request (DEEPEP_WINDOW_FINEGRAINED=0) and is reported through
+    // is_window_fine_grained() so that deep_ep.Buffer keeps W > 1 traffic on the alltoall (RCCL) strategies.
+    if (want_fine) {
+        const hipError_t e = hipExtMallocWithFlags(&p, (size_t)window_bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            throw EPException("HIP Assertion", __FILE__, __LINE__,
+                              ep_concat("cannot allocate a fine-grained window of ", window_bytes, " bytes (", hipGetErrorString(e),
+                                        "); lower DEEPEP_WINDOW_BYTES, or set DEEPEP_WINDOW_FINEGRAINED=0 to run on the alltoall strategies"));
+        }
         window_fine_grained = true;
     } else {
-        (void)hipGetLastError();
         HIP_CHECK(hipMalloc(&p, (size_t)window_bytes));
     }
     window = (uint8_t *)p;
@@ -202,7 +224,7 @@ Buffer::Layout Buffer::run_layout(const at::Tensor &topk_idx, int num_experts)
     EP_HOST_ASSERT_S(K >= 1 && K <= MI_EP_MAX_TOPK, "num_topk (", K, ") must be in [1, ", MI_EP_MAX_TOPK, "]");
     auto i32 = at::dtype(at::kInt).device(topk_idx.device());
     Layout l;
-    l.T = T, l.K = K, l.E = num_experts, l.idx_ptr = topk_idx.data_ptr();
+    l.T = T, l.K = K, l.E = num_experts, l.idx = topk_idx, l.idx_version = (int64_t)topk_idx._version();
     l.num_tokens_per_expert = at::empty({num_experts}, i32);
     l.num_tokens_per_rank = at::empty({num_ranks}, i32);
     l.is_token_in_rank = at::empty({T, num_ranks}, i32);
@@ -223,9 +245,9 @@ const Buffer::Layout &Buffer::layout_for(const at::Tensor &topk_idx, int num_exp
     // The reference silently reuses whatever get_dispatch_layout stashed last (deep_ep.cpp:170-172,321).  We reuse the
     // stash only when it was computed for this very tensor; otherwise the layout is recomputed (one extra ~30 us
     // kernel chain), which removes the hidden ordering requirement without changing results.
-    if (stash.idx_ptr != topk_idx.data_ptr() || stash.T != topk_idx.size(0) || stash.K != topk_idx.size(1) ||
-        stash.E != num_experts)
-        stash = run_layout(topk_idx, num_experts);
+    // "This very tensor" = same storage address AND the stash still holds that storage (so the address cannot have been
+    // recycled for another tensor by the caching allocator) AND the same version counter (no in-place rewrite since).
+    if (!stash.matches(topk_idx, num_experts)) stash = run_layout(topk_idx, num_experts);
     return stash;
 }
 
@@ -363,6 +385,7 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     std::vector<int> num_recv_tokens_per_expert_list;
     if (host_sync) {
         trt = wait_summary("intranode_dispatch");
+        check_status("intranode_dispatch");     // a peer that timed out inside THIS call's notify surfaces now, not one call later
         real_max_bs = __atomic_load_n(summary_host + 1, __ATOMIC_RELAXED);
         // counts, or inclusive cumsum when MOE_EXPERT_TOKEN_NUMS_TYPE=0 (deep_ep.cpp:311-312,384-401)
         const int type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
@@ -654,7 +677,7 @@ at::Tensor Buffer::prepared_weight(const at::Tensor &w, int kind, const std::fun
     if (it != weight_cache_.end() && it->second.version == (int64_t)w._version() && it->second.numel == w.numel()) return it->second.t;
     if (weight_cache_.size() >= 512) weight_cache_.clear();
     at::Tensor t = make();
-    weight_cache_[key] = WeightEntry{(int64_t)w._version(), w.numel(), t};
+    weight_cache_[key] = WeightEntry{(int64_t)w._version(), w.numel(), w, t};
     return t;
 }
 

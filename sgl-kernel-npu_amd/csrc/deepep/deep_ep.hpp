@@ -37,6 +37,9 @@ public:
     void sync(const std::vector<std::string> &handles, const std::vector<int64_t> &local_ptrs);
 
     bool is_available() const { return available; }
+    // false only when DEEPEP_WINDOW_FINEGRAINED=0 forced a coarse-grained window: peers' stores are then not guaranteed to
+    // become visible inside a running kernel, so deep_ep.Buffer selects the alltoall (RCCL) strategies for W > 1.
+    bool is_window_fine_grained() const { return window_fine_grained; }
     int get_num_rdma_ranks() const { return 1; }
     int get_rdma_rank() const { return 0; }
 
@@ -137,7 +140,15 @@ private:
         at::Tensor num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank, send_token_idx_small, send_data_offset,
             workspace;
         int64_t T = -1, K = -1, E = -1;
-        const void *idx_ptr = nullptr;
+        // The tensor the layout was computed for is HELD (its storage cannot be freed and recycled for another tensor while
+        // the stash is alive) together with its version counter (in-place rewrites invalidate the stash).
+        at::Tensor idx;
+        int64_t idx_version = -1;
+        bool matches(const at::Tensor &t, int64_t num_experts) const
+        {
+            return idx.defined() && idx.data_ptr() == t.data_ptr() && idx.scalar_type() == t.scalar_type() &&
+                   idx_version == (int64_t)t._version() && T == t.size(0) && K == t.size(1) && E == num_experts;
+        }
     };
     Layout run_layout(const at::Tensor &topk_idx, int num_experts);
     const Layout &layout_for(const at::Tensor &topk_idx, int num_experts);
@@ -194,6 +205,7 @@ private:
     };
     struct WeightEntry {
         int64_t version, numel;
+        at::Tensor src;        // the caller's tensor is held: its address cannot be recycled for a different weight
         at::Tensor t;
     };
     std::map<WeightKey, WeightEntry> weight_cache_;

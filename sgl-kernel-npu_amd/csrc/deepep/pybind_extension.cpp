@@ -49,6 +49,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 
     // ---- queries
     MI_METHOD(buf, is_available);
+    MI_METHOD(buf, is_window_fine_grained);
     MI_METHOD(buf, get_num_rdma_ranks);
     MI_METHOD(buf, get_rdma_rank);
     MI_METHOD(buf, get_notify_send_data);

@@ -75,6 +75,11 @@ class Buffer:
             return True
         if os.getenv("DEEPEP_DISABLE_P2P", "0") == "1":
             return False
+        fine = [None] * self.group_size
+        dist.all_gather_object(fine, bool(getattr(rt, "is_window_fine_grained", lambda: True)()), group=self.group)
+        if not all(fine):        # coarse-grained window (DEEPEP_WINDOW_FINEGRAINED=0): peers' stores are not kernel-visible
+            warnings.warn(f"[deep_ep rank {self.rank}] window is not fine-grained; using the alltoall strategies")
+            return False
         me = (socket.gethostname(), os.getpid(), rt.get_local_device_id(), bytes(rt.get_local_ipc_handle()),
               rt.get_local_window_ptr())
         everyone = [None] * self.group_size

@@ -31,6 +31,10 @@ def test_buffer_multi_process_one_gpu(cfg):
     (1, 64, 7168, 2048, 8, 8, "native"),          # DeepSeek-V3 hidden / intermediate, 8 local experts
     (2, 24, 512, 256, 4, 8, "ffn"),               # FuseMode.DISPATCH_FFN_COMBINE: plain weights, int64 scale bits
     (1, 32, 1024, 384, 8, 16, "ffn"),
+    # BASELINE C5 shapes (DeepSeek-V3 hidden 7168 / 2I = 4096) with 1024 rows per local expert: rows_hint > 96, i.e. the
+    # 256 x 256 x 64 workgroup tile, the LDS-transposed epilogue and the multi-tile lookup run end to end behind deep_ep.Buffer
+    (1, 1024, 7168, 2048, 8, 8, "native"),
+    (2, 512, 7168, 2048, 8, 8, "native"),         # same through two processes (windows mapped with hipIpc)
 ])
 def test_fused_deep_moe(cfg):
     _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)

@@ -178,8 +178,10 @@ def test_low_latency_dispatch_combine_bit_exact(W, T, H, K, E, drop, quant, coun
 
 
 @pytest.mark.parametrize("quant", [True, False])
-def test_full_size_c2_properties(quant):
-    """BASELINE C2 sizes (W=8, 4096 tok/rank, H=7168, top-8, E=256): size-independent properties --
+@pytest.mark.parametrize("compact", [False, True], ids=["replicated", "compact"])
+def test_full_size_c2_properties(quant, compact):
+    """BASELINE C2 sizes (W=8, 4096 tok/rank, H=7168, top-8, E=256), for both staging formats (compact = stage_compact +
+    pull_indexed, the path the host runtime and bench.py use): size-independent properties --
     counts == global histogram, ordering contract, int8 payload == quantised source row, round trip
     closed form (reference tests' golden) and run-to-run determinism."""
     import ep_harness as Hh
@@ -189,7 +191,7 @@ def test_full_size_c2_properties(quant):
     xs = [torch.randn((T, H), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16) for _ in range(W)]
     idxs = [torch.topk(torch.randn((T, E), generator=g, device="cuda").abs() + 1, K, dim=-1, sorted=False)[1] for _ in range(W)]
     ws = [torch.randn((T, K), generator=g, device="cuda") for _ in range(W)]
-    h = Hh.InProcEP(W, E, T, K, H)
+    h = Hh.InProcEP(W, E, T, K, H, compact=compact)
     qm = Hh.QUANT_INT8 if quant else Hh.QUANT_NONE
     got = h.dispatch(xs, idxs, qm)
     hist = sum(torch.bincount(i.reshape(-1), minlength=E) for i in idxs)

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import ep
+from oracle import ep as O
 from oracle.bf16 import bf16_bits_to_f32, f32_to_bf16_bits_rne, torch_to_bits, bits_to_torch
 
 
@@ -217,3 +218,56 @@ def test_oracle_reproduces_committed_fixtures(path):
         assert np.array_equal(comb[r], z[f"combined{r}"])
         assert np.array_equal(ll[r].packed_recv_count, z[f"ll_recv_count{r}"]) and np.array_equal(ll[r].layout_range, z[f"ll_layout_range{r}"])
         assert np.array_equal(ll[r].src_info, z[f"ll_src_info{r}"])
+
+
+# ---- A8 fused_deep_moe oracle: internal consistency pins (no reference-held vector exists for this row: the reference test
+# compares its fused op with torch_npu ops, tests/python/deepep/test_fused_deep_moe.py:155-235, neither runs off-NPU) ---------
+def test_int_matmul_exact_matches_integer_arithmetic():
+    rng = np.random.default_rng(3)
+    a = rng.integers(-128, 128, (37, 7168)).astype(np.int8)
+    w = rng.integers(-128, 128, (19, 7168)).astype(np.int8)
+    a[0, :], w[0, :] = -128, -128                       # the largest magnitude a row pair can reach
+    want = a.astype(np.int64) @ w.astype(np.int64).T
+    assert np.array_equal(O._int_matmul_exact(a, w).astype(np.int64), want)
+
+
+def test_fused_deep_moe_oracle_against_independent_float64_pipeline():
+    """The staged oracle (dispatch -> GEMM1+SwiGLU -> requant -> GEMM2 -> combine) against a from-scratch float64 evaluation of
+    the same network per token: y[t] = sum_k w[t,k] * FFN_{e(t,k)}(x[t]) with the two quantisation points mirrored.  Different
+    code path (per-token loops, float64 everywhere, no dispatch tables), so ordering / indexing mistakes cannot cancel."""
+    from oracle.bf16 import bf16_bits_to_f32, f32_to_bf16_bits_rne
+    W, T, H, I, K, E = 2, 9, 64, 32, 3, 4
+    L = E // W
+    rng = np.random.default_rng(5)
+    xs = [f32_to_bf16_bits_rne(rng.standard_normal((T, H)).astype(np.float32)) for _ in range(W)]
+    idxs = [np.argsort(-rng.random((T, E)), axis=1)[:, :K].astype(np.int64) for _ in range(W)]
+    idxs[0][2, 1] = -1
+    ws = [np.abs(rng.standard_normal((T, K))).astype(np.float32) for _ in range(W)]
+    w13 = [rng.integers(-16, 16, (L, 2 * I, H)).astype(np.int8) for _ in range(W)]
+    w2 = [rng.integers(-16, 16, (L, H, I)).astype(np.int8) for _ in range(W)]
+    s13 = [(rng.random((L, 2 * I)) * 4e-4 + 1.5e-3).astype(np.float32) for _ in range(W)]
+    s2 = [(rng.random((L, H)) * 4e-4 + 1.5e-3).astype(np.float32) for _ in range(W)]
+    got = O.fused_deep_moe(xs, idxs, ws, w13, s13, w2, s2, T, E)
+    for r in range(W):
+        x = bf16_bits_to_f32(xs[r]).astype(np.float64)
+        want = np.zeros((T, H))
+        for t in range(T):
+            amax = np.abs(x[t]).max()
+            q = np.rint(x[t] * (127.0 / amax))
+            sc = amax / 127.0
+            for k in range(K):
+                e = idxs[r][t, k]
+                if e < 0:
+                    continue
+                er, le = e // L, e % L
+                d = (w13[er][le].astype(np.float64) @ q) * s13[er][le] * sc
+                gate, up = d[:I], d[I:]
+                v = up * gate / (1 + np.exp(-gate))
+                vmax = np.abs(v).max()
+                q2 = np.rint(v * 127.0 / vmax)
+                y = (w2[er][le].astype(np.float64) @ q2) * s2[er][le] * (vmax / 127.0)
+                want[t] += ws[r][t, k] * y
+        g = bf16_bits_to_f32(got[r]).astype(np.float64)
+        # bf16 outputs of each expert + fp32 accumulation vs float64: relative error well below one bf16 ulp of the sum of terms
+        assert np.abs(g - want).max() <= 2.0 ** -7 * np.abs(want).max()
+        assert O.calc_diff(g, want) < 1e-5
