@@ -88,6 +88,15 @@ int mi_ep_wait(const uint64_t *my_flags, int num_ranks, uint64_t epoch, int32_t 
 int mi_ep_signal_wait(uint64_t *const *peer_flags_host, const uint64_t *my_flags, int num_ranks, int my_rank, uint64_t epoch,
                       int32_t *status, int timeout_ms, void *stream);
 
+/* Start-up self-test of mapped windows (the reference trusts HCCL for this; here the mapping is ours: hipIpc over xGMI).
+ * Every rank writes a 4 KiB pattern row into slot `my_rank` of every rank's `peer_rows_host[d]` area (mi_ep_selftest_bytes(W)
+ * bytes each), raises flag `epoch`, waits for all peers (bounded), then verifies the W rows it received (remote-write path) and
+ * reads its own row back from every peer (remote-read path).  Two launches on `stream`.  status[0] afterwards: 0 = pass,
+ * 1 + s = rank s never signalled, 3000 + s = corrupt row from s, 4000 + d = corrupt read-back from d. */
+size_t mi_ep_selftest_bytes(int num_ranks);
+int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host, const uint64_t *my_flags, int num_ranks,
+                   int my_rank, uint64_t epoch, uint32_t tag, int32_t *status, int timeout_ms, void *stream);
+
 /* ---- A2 notify ------------------------------------------------------------------------------
  * Counts all-gather through windows.  Every rank owns `uint64_t notify[W][E+1]` granules
  * {epoch << 32 | value}; post writes row `my_rank` of every peer (E counts + its token count T),
@@ -170,6 +179,23 @@ int mi_ep_dispatch_stage_compact(const void *x, const void *topk_idx, int idx_is
 int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset,
                                 int num_ranks, int num_local_experts, int hidden, int num_topk, int quant_mode, int rows_hint,
                                 size_t region_bytes, void *recv_x, float *recv_x_scales, int32_t *recv_src_idx, void *stream);
+
+/* Push transport of normal dispatch (selectable next to the pull above; the same received bytes).  The sender writes the
+ * quantised row of token t ONCE into the window of every rank that owns at least one of the token's experts (the reference
+ * also writes into the receiver's window, cam_moe_dispatch_normal.h:440-473, but one row per (t, k)): the dispatch region of a
+ * rank is cut into W source slabs of mi_ep_dispatch_push_slab_bytes() and rank s writes only slab s -- token row t at row t
+ * of the slab (sparse: only the tokens routed there), and for every pair (t, k) routed there the index entry {t, k} at
+ * position send_data_offset[e] - send_data_offset[first expert of that rank] + send_token_idx_small[t,k], i.e. in the
+ * sender's expert-sorted order.  Nothing depends on the other ranks' counts, so the push runs before the notify exchange;
+ * cross-GPU traffic is distinct (token, destination rank) pairs * (H + 16) bytes + 8 bytes per pair.
+ * Receiver: after the notify exchange computed with relative_pull = 1, mi_ep_dispatch_pull_indexed with
+ * src_base_host[s] = own region + s * slab and region_bytes = the slab size gathers recv_x / scales / triples locally.
+ * peer_region_host[W]: every rank's dispatch region for this call.  MI_EP_EINVAL when T exceeds a slab's token capacity. */
+size_t mi_ep_dispatch_push_slab_bytes(size_t region_bytes, int num_ranks);
+int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                              const int32_t *send_data_offset, int num_tokens, int num_topk, int hidden, int num_experts,
+                              int num_ranks, int my_rank, int quant_mode, void *const *peer_region_host, size_t region_bytes,
+                              void *stream);
 
 /* ---- A4/A6 combine ---------------------------------------------------------------------------
  * push: row r < total (= *total_rows_dev if non-NULL else rows_hint) of x [R,H] bf16 with triple

@@ -27,7 +27,7 @@ constexpr int64_t kNotifyParityBytes = 1100 << 10;
 constexpr int64_t kOffLLCounts = kOffNotify + 2 * kNotifyParityBytes;   // 2 parities x 2048 u64
 constexpr int64_t kLLCountsParityBytes = 2048 * 8;
 enum Family { kDispatch = 0, kCombine = 1, kLLDispatch = 2 };
-enum FlagGroup { kFlagDispatch = 0, kFlagCombine = 1 };
+enum FlagGroup { kFlagDispatch = 0, kFlagCombine = 1, kFlagSelfTest = 7 };
 constexpr int kMaxTotalTokens = 131072;            // reference MAX_TOTAL_TOKENS (deep_ep.cpp:37)
 
 hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
@@ -83,32 +83,48 @@ Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t n
     EP_HOST_ASSERT_S(enable_neg_one == 0 || enable_neg_one == 1, "MOE_ENABLE_TOPK_NEG_ONE must be 0 or 1, got ", enable_neg_one);
 
     // Window budget.  The reference sizes its HCCL window with HCCL_BUFFSIZE (MB); DEEPEP_WINDOW_BYTES plays that
-    // role here.  Default 6 GiB = six 1-GiB regions: dispatch x2, combine x2, low-latency dispatch x2 (ping-pong),
+    // role here.  Default 6 GiB = six ~1-GiB regions: dispatch x2, combine x2, low-latency dispatch x2 (ping-pong),
     // enough for 8192 tok x top-8 x 7168 BF16 per region; MI355X has 288 GB.
+    // The window is FOUR allocations (segments): the 4 MiB control area and one allocation per family holding both
+    // ping-pong regions.  Measured on ROCm 7.2 / MI355X (tools/probes/ipc_open_time.py): hipIpcOpenMemHandle of an
+    // allocation of 2 GiB or more never returns (2040 MiB maps in 0.1 s, 2056 MiB hangs), so a segment stays below that.
     long long want = get_ll_from_env("DEEPEP_WINDOW_BYTES", 0);
+    const bool explicit_size = want > 0;
     if (want <= 0) want = std::max<long long>(6ll << 30, std::max(num_nvl_bytes, num_rdma_bytes));
     region_bytes = (size_t)((want - kCtrlBytes) / 6) & ~(size_t)4095;
     EP_HOST_ASSERT_S(region_bytes >= (1u << 20), "DEEPEP_WINDOW_BYTES too small: ", want);
+    constexpr size_t kMaxRegionBytes = (size_t)1016 << 20;       // 2 regions per segment < 2040 MiB
+    if (region_bytes > kMaxRegionBytes) {
+        if (explicit_size && rank == 0)
+            std::fprintf(stderr, "[deep_ep] DEEPEP_WINDOW_BYTES=%lld asks for %zu-byte regions; clamped to %zu (an ipc-mapped allocation "
+                         "must stay below 2 GiB): use DEEPEP_NORMAL_LONG_SEQ_ROUND for larger batches\n", want, region_bytes, kMaxRegionBytes);
+        region_bytes = kMaxRegionBytes;
+    }
+    seg_bytes[kSegCtrl] = (size_t)kCtrlBytes;
+    for (int f = 0; f < 3; ++f) seg_bytes[1 + f] = 2 * region_bytes;
     window_bytes = kCtrlBytes + 6 * (int64_t)region_bytes;
-    void *p = nullptr;
     const bool want_fine = get_value_from_env("DEEPEP_WINDOW_FINEGRAINED", 1) != 0;
     // The protocol has running kernels poll flag / granule words that peer GPUs write and read rows peers wrote: that needs
     // fine-grained (system-coherent) memory.  A failed fine-grained allocation is an error, not a silent downgrade; a
     // coarse-grained window exists only on explicit request (DEEPEP_WINDOW_FINEGRAINED=0) and is reported through
     // is_window_fine_grained() so that deep_ep.Buffer keeps W > 1 traffic on the alltoall (RCCL) strategies.
-    if (want_fine) {
-        const hipError_t e = hipExtMallocWithFlags(&p, (size_t)window_bytes, hipDeviceMallocFinegrained);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            throw EPException("HIP Assertion", __FILE__, __LINE__,
-                              ep_concat("cannot allocate a fine-grained window of ", window_bytes, " bytes (", hipGetErrorString(e),
-                                        "); lower DEEPEP_WINDOW_BYTES, or set DEEPEP_WINDOW_FINEGRAINED=0 to run on the alltoall strategies"));
+    for (int sg = 0; sg < kNumSegs; ++sg) {
+        void *p = nullptr;
+        if (want_fine) {
+            const hipError_t e = hipExtMallocWithFlags(&p, seg_bytes[sg], hipDeviceMallocFinegrained);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                throw EPException("HIP Assertion", __FILE__, __LINE__,
+                                  ep_concat("cannot allocate a fine-grained window segment of ", seg_bytes[sg], " bytes (", hipGetErrorString(e),
+                                            "); lower DEEPEP_WINDOW_BYTES, or set DEEPEP_WINDOW_FINEGRAINED=0 to run on the alltoall strategies"));
+            }
+        } else {
+            HIP_CHECK(hipMalloc(&p, seg_bytes[sg]));
         }
-        window_fine_grained = true;
-    } else {
-        HIP_CHECK(hipMalloc(&p, (size_t)window_bytes));
+        seg_base[sg] = (uint8_t *)p;
     }
-    window = (uint8_t *)p;
+    window_fine_grained = want_fine;
+    window = seg_base[kSegCtrl];
     HIP_CHECK(hipMemset(window, 0, (size_t)kCtrlBytes));
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipHostMalloc((void **)&summary_host, sizeof(int32_t) * (4 + 2048), hipHostMallocMapped));
@@ -117,47 +133,99 @@ Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t n
     std::memset(status_host, 0, sizeof(int32_t) * 4);
     HIP_CHECK(hipHostGetDevicePointer((void **)&summary_dev, summary_host, 0));
     HIP_CHECK(hipHostGetDevicePointer((void **)&status_dev, status_host, 0));
-    peer_base.assign((size_t)num_ranks, nullptr);
+    peer_seg.assign((size_t)num_ranks, std::array<uint8_t *, kNumSegs>{});
     peer_opened.assign((size_t)num_ranks, false);
-    peer_base[(size_t)rank] = window;
+    for (int sg = 0; sg < kNumSegs; ++sg) peer_seg[(size_t)rank][(size_t)sg] = seg_base[sg];
     if (num_ranks == 1) available = true;      // nothing to exchange
+    // normal-dispatch transport: remote writes ("push", default for W > 1: posted stores need no round trip over xGMI) or
+    // remote reads ("pull"); both produce identical results, DEEPEP_DISPATCH_TRANSPORT / set_dispatch_transport() selects
+    const char *tr = std::getenv("DEEPEP_DISPATCH_TRANSPORT");
+    set_dispatch_transport(tr && *tr ? std::string(tr) : std::string(num_ranks > 1 ? "push" : "pull"));
+}
+
+void Buffer::set_dispatch_transport(const std::string &name)
+{
+    EP_HOST_ASSERT_S(name == "push" || name == "pull", "DEEPEP_DISPATCH_TRANSPORT must be push or pull, got ", name);
+    dispatch_transport = name == "push" ? kTransportPush : kTransportPull;
 }
 
 Buffer::~Buffer() noexcept(false)
 {
     hipDeviceSynchronize();
-    for (size_t r = 0; r < peer_base.size(); ++r)
-        if (peer_opened[r] && peer_base[r]) hipIpcCloseMemHandle(peer_base[r]);
-    if (window) hipFree(window);
+    for (size_t r = 0; r < peer_seg.size(); ++r)
+        if (peer_opened[r])
+            for (uint8_t *p : peer_seg[r])
+                if (p) hipIpcCloseMemHandle(p);
+    for (uint8_t *p : seg_base)
+        if (p) hipFree(p);
     if (summary_host) hipHostFree(summary_host);
     if (status_host) hipHostFree(status_host);
 }
 
 std::string Buffer::get_local_ipc_handle() const
 {
-    hipIpcMemHandle_t h;
-    HIP_CHECK(hipIpcGetMemHandle(&h, window));
-    return std::string((const char *)&h, sizeof(h));
+    std::string all;
+    for (int sg = 0; sg < kNumSegs; ++sg) {
+        hipIpcMemHandle_t h;
+        HIP_CHECK(hipIpcGetMemHandle(&h, seg_base[sg]));
+        all.append((const char *)&h, sizeof(h));
+    }
+    return all;
 }
 
-void Buffer::sync(const std::vector<std::string> &handles, const std::vector<int64_t> &local_ptrs)
+std::vector<int64_t> Buffer::get_local_window_ptrs() const
+{
+    std::vector<int64_t> v;
+    for (uint8_t *p : seg_base) v.push_back((int64_t)p);
+    return v;
+}
+
+void Buffer::sync(const std::vector<std::string> &handles, const std::vector<std::vector<int64_t>> &local_ptrs)
 {
     EP_HOST_ASSERT((int64_t)handles.size() == num_ranks and (int64_t)local_ptrs.size() == num_ranks);
     for (int64_t r = 0; r < num_ranks; ++r) {
         if (r == rank) continue;
-        if (local_ptrs[(size_t)r] != 0) {
-            peer_base[(size_t)r] = (uint8_t *)local_ptrs[(size_t)r];
+        if (!local_ptrs[(size_t)r].empty()) {                // the peer lives in this process: plain pointers
+            EP_HOST_ASSERT((int)local_ptrs[(size_t)r].size() == kNumSegs);
+            for (int sg = 0; sg < kNumSegs; ++sg) peer_seg[(size_t)r][(size_t)sg] = (uint8_t *)local_ptrs[(size_t)r][(size_t)sg];
             continue;
         }
-        EP_HOST_ASSERT_S(handles[(size_t)r].size() == sizeof(hipIpcMemHandle_t), "bad ipc handle from rank ", r);
-        hipIpcMemHandle_t h;
-        std::memcpy(&h, handles[(size_t)r].data(), sizeof(h));
-        void *p = nullptr;
-        HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
-        peer_base[(size_t)r] = (uint8_t *)p;
+        EP_HOST_ASSERT_S(handles[(size_t)r].size() == kNumSegs * sizeof(hipIpcMemHandle_t), "bad ipc handle from rank ", r);
+        for (int sg = 0; sg < kNumSegs; ++sg) {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, handles[(size_t)r].data() + (size_t)sg * sizeof(h), sizeof(h));
+            void *p = nullptr;
+            HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+            peer_seg[(size_t)r][(size_t)sg] = (uint8_t *)p;
+        }
         peer_opened[(size_t)r] = true;
     }
     available = true;
+}
+
+// One flag + one 4 KiB row round trip with every peer through the mapped windows (write path and read-back path), with a
+// checksum.  Called by deep_ep.Buffer on every rank right after sync(); a failure (no peer access, stale mapping, stores
+// that never become visible) makes the Python side fall back to the alltoall (RCCL) strategies instead of corrupting data.
+bool Buffer::self_test(int64_t test_timeout_ms)
+{
+    require_available();
+    if (num_ranks == 1) return true;
+    hipStream_t st = cur_stream();
+    const uint64_t ep = ++selftest_epoch;
+    auto rows = peer_regions(kLLDispatch, 1);          // scratch: the second low-latency region, unused before the first call
+    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagSelfTest * kFlagGroupSlots * 8));
+    EP_HOST_ASSERT(mi_ep_selftest_bytes((int)num_ranks) <= region_bytes);
+    MI_EP_CHECK(mi_ep_selftest(rows.data(), (uint64_t *const *)flag_peers.data(),
+                               (const uint64_t *)(window + kOffFlags + kFlagSelfTest * kFlagGroupSlots * 8), (int)num_ranks, (int)rank, ep,
+                               (uint32_t)(0x5E1F0000u + ep), status_dev, (int)test_timeout_ms, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const int32_t code = __atomic_load_n(status_host, __ATOMIC_ACQUIRE);
+    if (code != 0) {
+        __atomic_store_n(status_host, 0, __ATOMIC_RELEASE);
+        std::fprintf(stderr, "[deep_ep rank %lld] window self-test failed with code %d\n", (long long)rank, code);
+        return false;
+    }
+    return true;
 }
 
 void Buffer::require_available() const
@@ -169,13 +237,22 @@ void Buffer::require_available() const
 
 uint8_t *Buffer::region(int family, uint64_t epoch) const
 {
-    return window + kCtrlBytes + (size_t)(family * 2 + (int)(epoch & 1)) * region_bytes;
+    return seg_base[1 + family] + (size_t)(epoch & 1) * region_bytes;
 }
 
+// every rank's pointer to byte `offset` of the control segment
 std::vector<void *> Buffer::peer_ptrs(size_t offset) const
 {
     std::vector<void *> v((size_t)num_ranks);
-    for (size_t r = 0; r < (size_t)num_ranks; ++r) v[r] = peer_base[r] + offset;
+    for (size_t r = 0; r < (size_t)num_ranks; ++r) v[r] = peer_seg[r][kSegCtrl] + offset;
+    return v;
+}
+
+// every rank's region of `family` for the call with this epoch (ping-pong by parity)
+std::vector<void *> Buffer::peer_regions(int family, uint64_t epoch) const
+{
+    std::vector<void *> v((size_t)num_ranks);
+    for (size_t r = 0; r < (size_t)num_ranks; ++r) v[r] = peer_seg[r][(size_t)(1 + family)] + (size_t)(epoch & 1) * region_bytes;
     return v;
 }
 
@@ -312,9 +389,14 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     EP_HOST_ASSERT_S(E <= 2048, "num_experts (", E, ") must be <= 2048");
     const int qm = quant_mode_of(use_quant, quant_type);
     const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
-    // compact staging: one row per TOKEN plus K index entries (mi_ep_dispatch_stage_compact), not one row per (t, k)
-    EP_HOST_ASSERT_S((size_t)T <= mi_ep_dispatch_index_offset(H, qm, K, region_bytes) / rb, "dispatch window too small: need ",
-                     (size_t)T * (rb + (size_t)K * 8), " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
+    // compact staging: one row per TOKEN plus K index entries, not one row per (t, k).  Transport "pull": rows staged in the own
+    // window, receivers read them over xGMI (mi_ep_dispatch_stage_compact); "push": rows written once into every destination
+    // rank's window, slab `rank` of its region (mi_ep_dispatch_stage_push), receivers gather locally.
+    const bool push = dispatch_transport == kTransportPush;
+    const size_t slab_bytes = push ? mi_ep_dispatch_push_slab_bytes(region_bytes, (int)num_ranks) : region_bytes;
+    EP_HOST_ASSERT_S((size_t)T <= mi_ep_dispatch_index_offset(H, qm, K, slab_bytes) / rb, "dispatch window too small: need ",
+                     (size_t)T * (rb + (size_t)K * 8) * (push ? (size_t)num_ranks : 1), " bytes per region, have ", region_bytes,
+                     "; raise DEEPEP_WINDOW_BYTES");
     check_status("intranode_dispatch");
     ++profile_calls;
     const Layout &lay = layout_for(*topk_idx, E);
@@ -326,9 +408,16 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
 
     // sender side: stage into the own window, publish counts, raise the "staged" flag on every peer
     uint8_t *my_rows = region(kDispatch, ep);
-    { ProfScope ps_(this, "dispatch_stage", st); MI_EP_CHECK(mi_ep_dispatch_stage_compact(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
-                                     lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
-                                     H, E, (int)rank, qm, my_rows, region_bytes, st)); }
+    auto region_peers = peer_regions(kDispatch, ep);
+    { ProfScope ps_(this, push ? "dispatch_stage_push" : "dispatch_stage", st);
+      if (push)
+          MI_EP_CHECK(mi_ep_dispatch_stage_push(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
+                                                lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
+                                                H, E, W, (int)rank, qm, region_peers.data(), region_bytes, st));
+      else
+          MI_EP_CHECK(mi_ep_dispatch_stage_compact(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
+                                                   lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
+                                                   H, E, (int)rank, qm, my_rows, region_bytes, st)); }
     auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
 
@@ -347,7 +436,7 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
                                              lay.num_tokens_per_expert.data_ptr<int>(), T,
                                              (const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
                                              (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
-                                             nt.cnt.data_ptr<int>(), W, E, (int)rank, 0, nt.recv_count.data_ptr<int>(),
+                                             nt.cnt.data_ptr<int>(), W, E, (int)rank, push ? 1 : 0, nt.recv_count.data_ptr<int>(),
                                              nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
                                              nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
                                              nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
@@ -365,14 +454,17 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     // (+25 %), and the results are returned as exact-size prefixes once the host knows the count.  A call that receives
     // more than the guess simply pulls again into exact-size buffers (the kernel never writes past `rows_hint`).
     at::Tensor expandx_out, dynamic_scales_out, expand_idx_out;
-    auto src_peers = peer_ptrs((size_t)(region(kDispatch, ep) - window));
+    // pull: token rows + index live in every SOURCE rank's window; push: in the source slabs of the own window
+    std::vector<void *> src_peers = region_peers;
+    if (push)
+        for (int s = 0; s < W; ++s) src_peers[(size_t)s] = my_rows + (size_t)s * slab_bytes;
     auto launch_pull = [&](int64_t rows_alloc) {
         expandx_out = use_quant ? at::empty({rows_alloc, H}, at::dtype(at::kChar).device(dev)) : at::empty({rows_alloc, H}, x.options());
         dynamic_scales_out = at::empty({rows_alloc}, at::dtype(at::kFloat).device(dev));
         expand_idx_out = at::empty({rows_alloc * 3}, i32);
         ProfScope ps_(this, "dispatch_pull", st);
         MI_EP_CHECK(mi_ep_dispatch_pull_indexed((const void *const *)src_peers.data(), recv_count.data_ptr<int>(), pull_offset.data_ptr<int>(), W,
-                                                L, H, K, qm, (int)rows_alloc, region_bytes, expandx_out.data_ptr(),
+                                                L, H, K, qm, (int)rows_alloc, slab_bytes, expandx_out.data_ptr(),
                                                 use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr, expand_idx_out.data_ptr<int>(), st));
     };
     static const bool speculate = get_value_from_env("DEEPEP_SPECULATIVE_RECV", 1) != 0;
@@ -495,7 +587,7 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
     check_status("intranode_combine");
     hipStream_t st = cur_stream();
     const uint64_t ep = ++combine_epoch;
-    auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
+    auto dst_peers = peer_regions(kCombine, ep);
     // diagnose (opt-in): every send of this rank is complete when the push kernel ends, so each destination is charged the
     // push duration (device timestamps before / after; only launched when the caller passes the stats tensor)
     at::Tensor t_start;
@@ -573,7 +665,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     const Layout lay = run_layout(topk_idx, E);
     const uint64_t ep = ++ll_epoch;
     const int par = (int)(ep & 1);
-    auto row_peers = peer_ptrs((size_t)(region(kLLDispatch, ep) - window));
+    auto row_peers = peer_regions(kLLDispatch, ep);
     { ProfScope ps_(this, "ll_dispatch_send", st); MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                        lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm,
                                        row_peers.data(), st)); }
@@ -612,7 +704,7 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     check_status("low_latency_combine");
     hipStream_t st = cur_stream();
     const uint64_t ep = ++combine_epoch;
-    auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
+    auto dst_peers = peer_regions(kCombine, ep);
     // valid packed rows = layout_range[L*W-1], read on device
     { ProfScope ps_(this, "ll_combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
                                    (int)x.size(0), H, K, dst_peers.data(), W, st)); }
@@ -720,7 +812,7 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     const size_t cb = mi_ep_combine_row_bytes(H);
     EP_HOST_ASSERT_S((size_t)num_max_dispatch_tokens_per_rank * K * cb <= region_bytes, "combine window too small; raise DEEPEP_WINDOW_BYTES");
     const uint64_t ep = ++combine_epoch;
-    auto dst_peers = peer_ptrs((size_t)(region(kCombine, ep) - window));
+    auto dst_peers = peer_regions(kCombine, ep);
     { ProfScope ps_(this, "moe_gemm2_push", st);
       MI_EP_CHECK(mi_ep_moe_gemm2_push((const int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), (const int8_t *)w2.data_ptr(),
                                        s2.data_ptr<float>(), cum, W, L, M, I, H, src_info.data_ptr<int>(), K, dst_peers.data(), W,

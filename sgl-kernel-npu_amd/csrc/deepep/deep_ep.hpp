@@ -29,13 +29,19 @@ public:
     // buffer.py:67-83; here Python all-gathers these handles over the ProcessGroup, like upstream DeepEP's
     // get_local_ipc_handle()/sync()).
     int get_local_device_id() const { return device_id; }
-    std::string get_local_ipc_handle() const;         // hipIpcMemHandle_t bytes
-    int64_t get_local_window_ptr() const { return (int64_t)window; }
+    // The window is kNumSegs allocations (control area + one per family, each below the 2 GiB that hipIpcOpenMemHandle can map).
+    std::string get_local_ipc_handle() const;         // kNumSegs x hipIpcMemHandle_t bytes
+    std::vector<int64_t> get_local_window_ptrs() const;      // the kNumSegs segment bases
     int64_t get_window_bytes() const { return window_bytes; }
-    // handles[r]: ipc handle bytes of rank r (ignored for r == rank or when local_ptrs[r] != 0);
-    // local_ptrs[r]: window base of rank r when it lives in this process, else 0.
-    void sync(const std::vector<std::string> &handles, const std::vector<int64_t> &local_ptrs);
+    // handles[r]: ipc handle bytes of rank r (ignored for r == rank or when local_ptrs[r] is not empty);
+    // local_ptrs[r]: segment bases of rank r when it lives in this process, else empty.
+    void sync(const std::vector<std::string> &handles, const std::vector<std::vector<int64_t>> &local_ptrs);
 
+    // MI355X: transport of normal-mode dispatch, "push" (remote writes into the receivers' windows) or "pull" (receivers read
+    // the senders' windows).  Every rank of the group must select the same one before its next dispatch.
+    void set_dispatch_transport(const std::string &name);
+    std::string get_dispatch_transport() const { return dispatch_transport == kTransportPush ? "push" : "pull"; }
+    bool self_test(int64_t test_timeout_ms);     // collective: every rank calls it after sync()
     bool is_available() const { return available; }
     // false only when DEEPEP_WINDOW_FINEGRAINED=0 forced a coarse-grained window: peers' stores are then not guaranteed to
     // become visible inside a running kernel, so deep_ep.Buffer selects the alltoall (RCCL) strategies for W > 1.
@@ -156,7 +162,8 @@ private:
     void check_status(const char *where);
     int64_t wait_summary(const char *where);     // host spin on the pinned summary word written by notify_tables
     uint8_t *region(int family, uint64_t epoch) const;
-    std::vector<void *> peer_ptrs(size_t offset) const;
+    std::vector<void *> peer_ptrs(size_t offset) const;                 // into the control segment
+    std::vector<void *> peer_regions(int family, uint64_t epoch) const;
     void require_available() const;
 
     int64_t rank, num_ranks, num_nvl_bytes, num_rdma_bytes;
@@ -170,7 +177,10 @@ private:
     uint8_t *window = nullptr;
     int64_t window_bytes = 0;
     bool window_fine_grained = false;
-    std::vector<uint8_t *> peer_base;      // [W] mapped base of every rank's window (own = window)
+    enum { kSegCtrl = 0, kNumSegs = 4 };   // control area, then one segment per family (dispatch, combine, low-latency dispatch)
+    std::array<uint8_t *, kNumSegs> seg_base{};        // own segments (window == seg_base[kSegCtrl])
+    std::array<size_t, kNumSegs> seg_bytes{};
+    std::vector<std::array<uint8_t *, kNumSegs>> peer_seg;   // [W] mapped segment bases of every rank (own = seg_base)
     std::vector<bool> peer_opened;         // true when mapped through hipIpcOpenMemHandle
     size_t region_bytes = 0;               // each of the 6 data regions
     // pinned host words the kernels write with system scope
@@ -178,7 +188,9 @@ private:
     int32_t *status_host = nullptr;        // [4]
     int32_t *summary_dev = nullptr, *status_dev = nullptr;
 
-    uint64_t dispatch_epoch = 0, combine_epoch = 0, ll_epoch = 0;
+    enum { kTransportPull = 0, kTransportPush = 1 };
+    int dispatch_transport = kTransportPull;
+    uint64_t dispatch_epoch = 0, combine_epoch = 0, ll_epoch = 0, selftest_epoch = 0;
     Layout stash;                          // hidden state coupling of the reference (deep_ep.cpp:170-172,321)
     int64_t real_max_bs = 0;
     int64_t profile_skip = 0, profile_active = 0, profile_calls = 0;

@@ -42,7 +42,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 
     // ---- MI355X only: symmetric-window bootstrap over hipIpc (replaces the HCCL window lookup by communicator name)
     MI_METHOD(buf, get_local_device_id);
-    MI_METHOD(buf, get_local_window_ptr);
+    MI_METHOD(buf, get_local_window_ptrs);
     MI_METHOD(buf, get_window_bytes);
     buf.def("get_local_ipc_handle", [](const Buffer &b) { return py::bytes(b.get_local_ipc_handle()); });
     buf.def("sync", &Buffer::sync, py::arg("handles"), py::arg("local_ptrs"));
@@ -50,6 +50,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     // ---- queries
     MI_METHOD(buf, is_available);
     MI_METHOD(buf, is_window_fine_grained);
+    MI_METHOD(buf, self_test);
+    MI_METHOD(buf, set_dispatch_transport);
+    MI_METHOD(buf, get_dispatch_transport);
     MI_METHOD(buf, get_num_rdma_ranks);
     MI_METHOD(buf, get_rdma_rank);
     MI_METHOD(buf, get_notify_send_data);

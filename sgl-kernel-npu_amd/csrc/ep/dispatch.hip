@@ -35,6 +35,41 @@ __device__ __forceinline__ long long ld_idx(const void *p, long long i)
 struct LLGeom {
     int L, W, max_tokens;
 };
+// Push transport of normal dispatch (mi_ep_dispatch_stage_push): the quantised token row is written ONCE into the window of
+// every rank that owns at least one of its experts -- slab `my_rank` of that rank's dispatch region, row t -- and the
+// expert-sorted index entries {t, k} follow it into the same slab.  L == 0: not a push (compact staging in the own window).
+struct PushGeom {
+    int L;             // local experts per rank
+    size_t slab;       // bytes of one source slab = region_bytes / W (rounded down to 256)
+};
+// compact / push staging of one token: `write_row(base)` stores the payload + meta at row t of the slab at `base`
+template <class WriteRow>
+__device__ __forceinline__ void stage_token_rows(const PushGeom &pg, const PeerPtrs &dsts, size_t idx_off, int my_rank, int t, int K,
+                                                 long long e_l, int slot_l, const int32_t *send_off, WriteRow write_row)
+{
+    const int lane = lane_id();
+    if (pg.L == 0) {
+        uint8_t *base = (uint8_t *)dsts.p[0];
+        write_row(base);
+        if (lane < K && e_l >= 0) ((uint2 *)(base + idx_off))[slot_l] = uint2{(uint32_t)t, (uint32_t)lane};
+        return;
+    }
+    // distinct destination ranks of this token (K <= 16 selections, W <= 64 ranks): one row per rank, one index entry per pair
+    const int d_l = e_l >= 0 ? (int)(e_l / pg.L) : -1;
+    unsigned long long rmask = 0ull;
+    for (int k = 0; k < K; ++k) {
+        const int dk = __shfl(d_l, k, kWave);
+        if (dk >= 0) rmask |= 1ull << dk;
+    }
+    while (rmask) {                                   // wave-uniform
+        const int d = __builtin_ctzll(rmask);
+        rmask &= rmask - 1;
+        uint8_t *base = (uint8_t *)dsts.p[d] + (size_t)my_rank * pg.slab;
+        write_row(base);
+        // position among the rows this rank sends to d, in its expert-sorted order (= the receiver's relative pull offset)
+        if (d_l == d) ((uint2 *)(base + idx_off))[slot_l - send_off[d * pg.L]] = uint2{(uint32_t)t, (uint32_t)lane};
+    }
+}
 __device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const int32_t *send_off, int my_rank,
                                       int &slot, int &dst)
 {
@@ -53,7 +88,8 @@ __device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const 
 template <bool I32, bool EPS>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
-    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off)
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
+    PushGeom pg)
 {
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
@@ -124,17 +160,18 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     }
     if (idx_off) {
         // compact staging (normal-mode pull transport): the row is written ONCE at slot t; the expert-sorted index tells the
-        // receivers which token row each of their rows is (K-fold less staging traffic than one copy per (t, k))
-        uint8_t *base = (uint8_t *)dsts.p[0];
-        uint8_t *row = base + (size_t)t * stride;
-        u32x4 *dst = (u32x4 *)row;
+        // receivers which token row each of their rows is (K-fold less staging traffic than one copy per (t, k)).
+        // Push transport: the same row + index entries, written into every destination rank's window instead of the own one.
+        stage_token_rows(pg, dsts, idx_off, my_rank, t, K, e_l, slot_l, send_off, [&](uint8_t *base) {
+            uint8_t *row = base + (size_t)t * stride;
+            u32x4 *dst = (u32x4 *)row;
 #pragma unroll
-        for (int it = 0; it < kMaxItems; ++it) {
-            const int item = it * kWave + lane;
-            if (item < nitems) dst[item] = q[it];
-        }
-        if (lane == 0) *(u32x4 *)(row + H) = u32x4{__float_as_uint(scale_out), (uint32_t)t, 0u, (uint32_t)my_rank};
-        if (lane < K && e_l >= 0) ((uint2 *)(base + idx_off))[slot_l] = uint2{(uint32_t)t, (uint32_t)lane};
+            for (int it = 0; it < kMaxItems; ++it) {
+                const int item = it * kWave + lane;
+                if (item < nitems) dst[item] = q[it];
+            }
+            if (lane == 0) *(u32x4 *)(row + H) = u32x4{__float_as_uint(scale_out), (uint32_t)t, 0u, (uint32_t)my_rank};
+        });
         return;
     }
     for (int k = kpart; k < K; k += ksplit) {
@@ -157,7 +194,8 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
 template <bool I32>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
-    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off)
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
+    PushGeom pg)
 {
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
@@ -183,17 +221,17 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
         const int item = it * kWave + lane;
         if (item < nitems) raw[it] = src[item];
     }
-    if (idx_off) {                                  // compact staging, see stage_int8_kernel
-        uint8_t *base = (uint8_t *)dsts.p[0];
-        uint8_t *row = base + (size_t)t * stride;
-        u32x4 *dst = (u32x4 *)row;
+    if (idx_off) {                                  // compact / push staging, see stage_int8_kernel
+        stage_token_rows(pg, dsts, idx_off, my_rank, t, K, e_l, slot_l, send_off, [&](uint8_t *base) {
+            uint8_t *row = base + (size_t)t * stride;
+            u32x4 *dst = (u32x4 *)row;
 #pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            const int item = it * kWave + lane;
-            if (item < nitems) dst[item] = raw[it];
-        }
-        if (lane == 0) *(u32x4 *)(row + (size_t)H * 2) = u32x4{0u, (uint32_t)t, 0u, (uint32_t)my_rank};
-        if (lane < K && e_l >= 0) ((uint2 *)(base + idx_off))[slot_l] = uint2{(uint32_t)t, (uint32_t)lane};
+            for (int it = 0; it < kIt; ++it) {
+                const int item = it * kWave + lane;
+                if (item < nitems) dst[item] = raw[it];
+            }
+            if (lane == 0) *(u32x4 *)(row + (size_t)H * 2) = u32x4{0u, (uint32_t)t, 0u, (uint32_t)my_rank};
+        });
         return;
     }
     for (int k = kpart; k < K; k += ksplit) {
@@ -366,11 +404,11 @@ extern "C" size_t mi_ep_dispatch_index_offset(int hidden, int quant_mode, int to
 
 static int stage_launch(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                         const int32_t *send_data_offset, int T, int K, int H, int E, int my_rank, int quant_mode, void *rows,
-                        size_t idx_off, void *stream)
+                        size_t idx_off, void *stream, const PeerPtrs *push_peers = nullptr, PushGeom pg = PushGeom{0, 0})
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0) return MI_EP_EINVAL;
     if (T == 0) return MI_EP_OK;
-    if (!x || !topk_idx || !send_token_idx_small || !send_data_offset || !rows) return MI_EP_EINVAL;
+    if (!x || !topk_idx || !send_token_idx_small || !send_data_offset || (!rows && !push_peers)) return MI_EP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int ksplit = (T <= 512 && !idx_off) ? K : 1;   // decode-size batches: one wave per (token, k) instead of per token
     const int blocks = (int)(((long long)T * ksplit + kStageWaves - 1) / kStageWaves);
@@ -378,10 +416,11 @@ static int stage_launch(const void *x, const void *topk_idx, int idx_is_i32, con
     const uint16_t *xp = (const uint16_t *)x;
     uint8_t *rp = (uint8_t *)rows;
     PeerPtrs pp;
-    pp.p[0] = rp;
+    if (push_peers) pp = *push_peers;
+    else pp.p[0] = rp;
     const LLGeom ll{0, 0, 0};
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll, ksplit, idx_off)
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll, ksplit, idx_off, pg)
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
@@ -418,6 +457,31 @@ extern "C" int mi_ep_dispatch_stage_compact(const void *x, const void *topk_idx,
     if (idx_off == 0 || (size_t)T > idx_off / rb) return MI_EP_EINVAL;          // region too small for T tokens
     return stage_launch(x, topk_idx, idx_is_i32, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, quant_mode, region,
                         idx_off, stream);
+}
+
+extern "C" size_t mi_ep_dispatch_push_slab_bytes(size_t region_bytes, int num_ranks)
+{
+    if (num_ranks <= 0) return 0;
+    return (region_bytes / (size_t)num_ranks) & ~(size_t)255;
+}
+
+extern "C" int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                                         const int32_t *send_data_offset, int T, int K, int H, int E, int W, int my_rank,
+                                         int quant_mode, void *const *peer_region_host, size_t region_bytes, void *stream)
+{
+    if (H <= 0 || K <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || my_rank < 0 || my_rank >= W || !peer_region_host)
+        return MI_EP_EINVAL;
+    const size_t rb = mi_ep_dispatch_row_bytes(H, quant_mode);
+    const size_t slab = mi_ep_dispatch_push_slab_bytes(region_bytes, W);
+    const size_t idx_off = mi_ep_dispatch_index_offset(H, quant_mode, K, slab);
+    if (idx_off == 0 || (size_t)T > idx_off / rb) return MI_EP_EINVAL;          // a slab cannot hold T tokens
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_region_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = peer_region_host[i];
+    }
+    return stage_launch(x, topk_idx, idx_is_i32, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, quant_mode, nullptr,
+                        idx_off, stream, &pp, PushGeom{E / W, slab});
 }
 
 extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_count,
@@ -562,7 +626,7 @@ extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int i
     const int threads = kWave * kStageWaves;
     const uint16_t *xp = (const uint16_t *)x;
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll, ksplit, (size_t)0)
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll, ksplit, (size_t)0, PushGeom{0, 0})
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);

@@ -410,6 +410,74 @@ extern "C" int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, u
     return launch_status();
 }
 
+// ---- start-up self-test of the mapped windows -----------------------------------------------------------------------
+namespace mi_ep {
+constexpr int kSelfTestWords = 1024;      // one 4 KiB row per (source, destination) pair
+__device__ __forceinline__ uint32_t selftest_word(uint32_t tag, int src, int dst, int i)
+{
+    uint32_t h = tag * 0x9E3779B1u ^ (uint32_t)(src * 977 + dst * 131 + 7) * 0x85EBCA6Bu ^ (uint32_t)i * 0xC2B2AE35u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+// block d: write this rank's pattern row into rank d's window (slot my_rank) with ordinary 16-byte stores
+__global__ void selftest_post_kernel(PeerPtrs rows, int my_rank, uint32_t tag)
+{
+    const int d = blockIdx.x;
+    uint32_t *dst = (uint32_t *)((uint8_t *)rows.p[d] + (size_t)my_rank * kSelfTestWords * 4);
+    for (int i = threadIdx.x * 4; i < kSelfTestWords; i += blockDim.x * 4)
+        *(u32x4 *)(dst + i) = u32x4{selftest_word(tag, my_rank, d, i), selftest_word(tag, my_rank, d, i + 1),
+                                    selftest_word(tag, my_rank, d, i + 2), selftest_word(tag, my_rank, d, i + 3)};
+}
+// one workgroup: raise "my rows are written" on every peer, wait for every peer, then check (a) the rows the peers wrote into
+// MY window (remote-write path: push transports) and (b) the row I wrote into every PEER's window read back over the fabric
+// (remote-read path: pull transport).  status[0]: 0 ok, 1 + s timeout on rank s, 3000 + s bad row from s, 4000 + d bad read-back.
+__global__ __launch_bounds__(256) void selftest_check_kernel(PeerPtrs rows, PeerPtrs flags, const uint64_t *__restrict__ my_flags, int W,
+                                                            int my_rank, uint64_t epoch, uint32_t tag, int32_t *status,
+                                                            uint64_t timeout_ticks)
+{
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    if (threadIdx.x < W) {
+        sys_store_u64((uint64_t *)flags.p[threadIdx.x] + my_rank, epoch);
+        const uint64_t t0 = ticks_100mhz();
+        while (sys_load_u64(my_flags + threadIdx.x) < epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                report_status(status, 1 + threadIdx.x);
+                bad = 1;
+                break;
+            }
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (bad) return;
+    for (int s = 0; s < W; ++s) {
+        const uint32_t *mine = (const uint32_t *)((const uint8_t *)rows.p[my_rank] + (size_t)s * kSelfTestWords * 4);
+        const uint32_t *theirs = (const uint32_t *)((const uint8_t *)rows.p[s] + (size_t)my_rank * kSelfTestWords * 4);
+        for (int i = threadIdx.x; i < kSelfTestWords; i += blockDim.x) {
+            if (__builtin_nontemporal_load(mine + i) != selftest_word(tag, s, my_rank, i)) report_status(status, 3000 + s);
+            if (__builtin_nontemporal_load(theirs + i) != selftest_word(tag, my_rank, s, i)) report_status(status, 4000 + s);
+        }
+    }
+}
+}  // namespace mi_ep
+
+extern "C" size_t mi_ep_selftest_bytes(int num_ranks) { return (size_t)num_ranks * mi_ep::kSelfTestWords * 4; }
+
+extern "C" int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host, const uint64_t *my_flags, int W, int my_rank,
+                              uint64_t epoch, uint32_t tag, int32_t *status, int timeout_ms, void *stream)
+{
+    PeerPtrs rp, fp;
+    if (fill_peers(rp, (const void *const *)peer_rows_host, W) || fill_peers(fp, (const void *const *)peer_flags_host, W) || !my_flags ||
+        !status || my_rank < 0 || my_rank >= W || epoch == 0)
+        return MI_EP_EINVAL;
+    mi_ep::selftest_post_kernel<<<W, 256, 0, (hipStream_t)stream>>>(rp, my_rank, tag);
+    mi_ep::selftest_check_kernel<<<1, 256, 0, (hipStream_t)stream>>>(rp, fp, my_flags, W, my_rank, epoch, tag, status,
+                                                                    ms_to_ticks(timeout_ms));
+    return launch_status();
+}
+
 // ---- diagnose helpers (only launched when the caller passes a stats tensor) -------------------------------------------
 namespace mi_ep {
 __global__ void timestamp_kernel(uint64_t *dst) { *dst = ticks_100mhz(); }

@@ -81,7 +81,7 @@ class Buffer:
             warnings.warn(f"[deep_ep rank {self.rank}] window is not fine-grained; using the alltoall strategies")
             return False
         me = (socket.gethostname(), os.getpid(), rt.get_local_device_id(), bytes(rt.get_local_ipc_handle()),
-              rt.get_local_window_ptr())
+              list(rt.get_local_window_ptrs()))
         everyone = [None] * self.group_size
         dist.all_gather_object(everyone, me, group=self.group)
         ok = True
@@ -89,8 +89,14 @@ class Buffer:
             if any(h[0] != me[0] for h in everyone):
                 raise RuntimeError("ranks span several hosts; windows are single-node (xGMI) only")
             handles = [h[3] for h in everyone]
-            local_ptrs = [h[4] if (h[1] == me[1]) else 0 for h in everyone]
+            local_ptrs = [h[4] if (h[1] == me[1]) else [] for h in everyone]
             rt.sync(handles, local_ptrs)
+            # one flag + one 4 KiB row round trip with every peer (write path and read-back path, checksummed): a mapping
+            # that does not behave degrades to the alltoall strategies instead of corrupting tokens later
+            if hasattr(rt, "self_test") and os.getenv("DEEPEP_SKIP_SELF_TEST", "0") != "1":
+                dist.barrier(group=self.group)          # every rank has mapped everybody before anyone writes
+                if not rt.self_test(int(os.getenv("DEEPEP_SELF_TEST_TIMEOUT_MS", "10000"))):
+                    raise RuntimeError("window self-test failed")
         except Exception as e:  # noqa: BLE001
             warnings.warn(f"[deep_ep rank {self.rank}] cannot map peer windows ({e}); using the alltoall strategies")
             ok = False

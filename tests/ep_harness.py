@@ -35,6 +35,10 @@ def _lib():
     lib.mi_ep_dispatch_index_offset.argtypes = [I, I, I, c_size_t]
     lib.mi_ep_dispatch_stage_compact.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, c_size_t, V]
     lib.mi_ep_dispatch_pull_indexed.argtypes = [V, V, V, I, I, I, I, I, I, c_size_t, V, V, V, V]
+    lib.mi_ep_dispatch_push_slab_bytes.restype = c_size_t
+    lib.mi_ep_dispatch_push_slab_bytes.argtypes = [c_size_t, I]
+    lib.mi_ep_dispatch_stage_push.argtypes = [V, V, I, V, V, I, I, I, I, I, I, I, V, c_size_t, V]
+    lib.mi_ep_dispatch_stage_push.restype = c_int
     lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, V]
     lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, V, V, I, I, I, I, V, V]
     lib.mi_ep_combine_pack.argtypes = [V, V, I, I, I, I, V, V, V]
@@ -84,14 +88,20 @@ def layout(topk_idx, E, W):
 class InProcEP:
     """Normal + low-latency dispatch/combine for W simulated ranks."""
 
-    def __init__(self, W, E, max_tokens, K, H, device="cuda", compact=False):
+    def __init__(self, W, E, max_tokens, K, H, device="cuda", compact=False, transport="pull"):
         self.W, self.E, self.L, self.K, self.H = W, E, E // W, K, H
         self.max_tokens = max_tokens
         self.compact = compact          # normal dispatch through stage_compact + pull_indexed (what the host runtime uses)
+        # "push": mi_ep_dispatch_stage_push writes token rows + index entries into the DESTINATION ranks' regions (source slabs),
+        # the receiver gathers locally with pull_indexed -- the host runtime's default at W > 1
+        self.transport = transport
         self.dev = torch.device(device)
         u8 = dict(dtype=torch.uint8, device=self.dev)
         rb = max(lib().mi_ep_dispatch_row_bytes(H, QUANT_NONE), lib().mi_ep_dispatch_row_bytes(H, QUANT_INT8))
-        self.send_win = [torch.zeros(max(max_tokens * K, 1) * rb, **u8) for _ in range(W)]
+        win_bytes = max(max_tokens * K, 1) * rb
+        if transport == "push":         # W source slabs, each holding max_tokens rows + their K index entries (+ rounding slack)
+            win_bytes = W * ((max_tokens + 1) * (rb + 8 * K) + 512)
+        self.send_win = [torch.zeros(win_bytes, **u8) for _ in range(W)]
         self.comb_win = [torch.zeros(max(max_tokens * K, 1) * lib().mi_ep_combine_row_bytes(H), **u8) for _ in range(W)]
         self.ll_win = [torch.zeros(self.L * W * max_tokens * rb, **u8) for _ in range(W)]
         u64 = dict(dtype=torch.int64, device=self.dev)
@@ -114,7 +124,12 @@ class InProcEP:
         flag_ptrs = ptr_array([t.data_ptr() for t in self.flags])
         for r in range(W):
             T = xs[r].shape[0]
-            if self.compact:
+            if self.transport == "push":
+                ck(L_.mi_ep_dispatch_stage_push(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                                ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K, H, E,
+                                                W, r, quant_mode, ptr_array([t.data_ptr() for t in self.send_win]),
+                                                self.send_win[r].numel(), st))
+            elif self.compact:
                 ck(L_.mi_ep_dispatch_stage_compact(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
                                                    ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K,
                                                    H, E, r, quant_mode, ptr(self.send_win[r]), self.send_win[r].numel(), st))
@@ -135,7 +150,7 @@ class InProcEP:
                       srcrank_in_expert_offset=torch.empty(L * W, **i32), r_in_srcrank_offset=torch.empty(L * W, **i32),
                       total_recv_token=torch.empty(1, **i32), max_bs=torch.empty(1, **i32),
                       pull_offset=torch.empty(L * W, **i32))
-            ck(L_.mi_ep_notify_tables(ptr(cnt), W, E, r, 0, ptr(tb["recv_count"]), ptr(tb["recv_offset"]),
+            ck(L_.mi_ep_notify_tables(ptr(cnt), W, E, r, int(self.transport == "push"), ptr(tb["recv_count"]), ptr(tb["recv_offset"]),
                                       ptr(tb["recv_tokens_per_expert"]), ptr(tb["expert_global_offset"]),
                                       ptr(tb["srcrank_in_expert_offset"]), ptr(tb["r_in_srcrank_offset"]),
                                       ptr(tb["total_recv_token"]), ptr(tb["max_bs"]), ptr(tb["pull_offset"]), None, st))
@@ -149,7 +164,12 @@ class InProcEP:
                 recv_x = torch.zeros((rows, H), dtype=torch.int8, device=self.dev)
                 recv_s = torch.zeros(rows, dtype=torch.float32, device=self.dev)
             src_idx = torch.zeros(rows * 3, **i32)
-            if self.compact:
+            if self.transport == "push":
+                slab = L_.mi_ep_dispatch_push_slab_bytes(self.send_win[r].numel(), W)
+                own = ptr_array([self.send_win[r].data_ptr() + s_ * slab for s_ in range(W)])
+                ck(L_.mi_ep_dispatch_pull_indexed(own, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
+                                                  R, slab, ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
+            elif self.compact:
                 ck(L_.mi_ep_dispatch_pull_indexed(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
                                                   R, self.send_win[r].numel(), ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
             else:

@@ -130,6 +130,10 @@ def _gpu_buffer(rank, world, port, cfg):
         # the first of several iterations is small, so the next one receives far more rows than the runtime's speculative
         # receive buffers (sized from the previous call) hold: exercises both the hit and the re-pull path
         Tt = max(8, T // 4) if (iters > 1 and it == 0) else T
+        if strategy == "default":
+            # both normal-dispatch transports, alternating (every rank switches at the same call): identical results required
+            buf.runtime.set_dispatch_transport(("push", "pull")[it % 2])
+            assert buf.runtime.get_dispatch_transport() == ("push", "pull")[it % 2]
         xs, idxs, ws = make_inputs(W, Tt, H, K, E, drop, seed=100 + it)
         x = bits_to_torch(xs[rank]).cuda()
         ti = torch.from_numpy(idxs[rank]).cuda()
@@ -201,6 +205,96 @@ def _gpu_buffer(rank, world, port, cfg):
         hook()
         assert np.array_equal(torch_to_bits(outl), llc_want[rank]), "LL combine mismatch"
     torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: BASELINE C2 at full size through deep_ep.Buffer: 8 processes (one GPU here, 8 GPUs in production), 4096 tokens per rank
+# ----------------------------------------------------------------------------------------------
+def gpu_c2_size_worker(rank, world, port, cfg):
+    run_guarded(_gpu_c2_size, rank, world, port, cfg)
+
+
+def _c2_inputs(s, T, H, K, E):
+    g = torch.Generator(device="cuda").manual_seed(4321 + s)
+    x = torch.randn((T, H), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    idx = torch.topk(torch.randn((T, E), generator=g, device="cuda").abs() + 1, K, dim=-1, sorted=False)[1]
+    w = torch.rand((T, K), generator=g, device="cuda") + 0.5
+    return x, idx, w
+
+
+def _gpu_c2_size(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import torch_to_bits
+    torch.cuda.set_device(0)
+    import faulthandler
+    import time
+    W, T, H, K, E = cfg
+    L = E // W
+    faulthandler.dump_traceback_later(240, exit=True)      # a stuck rank prints where it is and ends the test instead of hanging it
+    t_start = time.time()
+    trace = (lambda *a: print(f"[c2 rank {rank} +{time.time() - t_start:6.1f}s]", *a, file=sys.stderr, flush=True)) \
+        if os.getenv("MI_TEST_TRACE") else (lambda *a: None)
+    group = _init(rank, world, port)
+    os.environ["DEEPEP_WINDOW_BYTES"] = str(6 * (T * K * H * 2 + (8 << 20)) + (4 << 20))     # combine slots are the largest region
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "60000")
+    buf = deep_ep.Buffer(group)
+    trace("buffer ready")
+    x, ti, tw = _c2_inputs(rank, T, H, K, E)
+    hist = torch.zeros(E, dtype=torch.long, device="cuda")
+    idx_all = []
+    for s in range(W):
+        i_s = _c2_inputs(s, T, H, K, E)[1]
+        idx_all.append(i_s)
+        hist += torch.bincount(i_s.reshape(-1), minlength=E)
+    first = None
+    for transport in ("push", "pull", "push"):
+        buf.runtime.set_dispatch_transport(transport)
+        trace("dispatch", transport)
+        per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+        (rx, rs), _, _, lst, handle, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                      num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
+                                                      quant_mode="int8")
+        trace("dispatched", sum(lst))
+        assert lst == hist[rank * L:(rank + 1) * L].tolist()                 # counts == global histogram (test_intranode.py:401-411)
+        n = sum(lst)
+        assert rx.shape[0] == max(n, 1)
+        tri = handle[3][:3 * n].view(-1, 3).long()
+        e_row = torch.empty(n, dtype=torch.long, device="cuda")
+        for s in range(W):
+            m = tri[:, 0] == s
+            e_row[m] = idx_all[s][tri[m, 1], tri[m, 2]]
+        key = ((e_row - rank * L) * W + tri[:, 0]) * (T * K) + tri[:, 1] * K + tri[:, 2]
+        assert bool((key[1:] > key[:-1]).all()), "receive order is not (local expert, source rank, row-major (t, k))"
+        assert bool(((e_row >= rank * L) & (e_row < (rank + 1) * L)).all())
+        # sampled rows: INT8 payload + scale == the oracle's quantisation of the source row
+        sel = torch.randperm(n, device="cuda")[:1024]
+        src_rows = torch.empty((sel.numel(), H), dtype=torch.bfloat16, device="cuda")
+        for s in range(W):
+            m = tri[sel, 0] == s
+            if bool(m.any()):
+                src_rows[m] = _c2_inputs(s, T, H, K, E)[0][tri[sel][m, 1]]
+        q_want, s_want = O.quant_int8_rows(torch_to_bits(src_rows), 1e-12)
+        assert np.array_equal(rx[sel].cpu().numpy(), q_want), transport
+        assert np.array_equal(rs[sel].cpu().numpy().view(np.uint32), s_want.view(np.uint32)), transport
+        if first is None:
+            first = (rx.clone(), rs.clone(), handle[3].clone())
+        else:                                                                # transports and repeated calls: identical bytes
+            assert torch.equal(first[0], rx) and torch.equal(first[1], rs) and torch.equal(first[2][:3 * n], handle[3][:3 * n])
+        # round trip (test_intranode.py:431-444): combine(dequantised rows) == x * sum_k w
+        y = (rx.float() * rs[:, None]).to(torch.bfloat16)
+        trace("combine")
+        out, _, _ = buf.combine(y, handle)
+        torch.cuda.synchronize()
+        trace("combined")
+        golden = x.float() * tw.sum(dim=1, keepdim=True)
+        a, b = out.double() + 1, golden.double() + 1
+        diff = 1 - 2 * (a * b).sum() / (a * a + b * b).sum()
+        assert diff.item() < 3e-3, diff.item()
+    torch.cuda.synchronize()
+    faulthandler.cancel_dump_traceback_later()
     dist.barrier()
     dist.destroy_process_group()
 

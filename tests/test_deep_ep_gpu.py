@@ -23,6 +23,12 @@ def test_buffer_multi_process_one_gpu(cfg):
     _spawn(mp_workers.gpu_buffer_worker, cfg[0], cfg)
 
 
+def test_c2_size_eight_processes():
+    """BASELINE C2 (EP = 8, 4096 tok/rank, H = 7168, top-8 of 256, INT8 dispatch / BF16 combine) through deep_ep.Buffer, eight
+    processes with hipIpc-mapped windows, both dispatch transports: counts, receive order, sampled payload bits, round trip."""
+    _spawn(mp_workers.gpu_c2_size_worker, 8, (8, 4096, 7168, 8, 256))
+
+
 @pytest.mark.parametrize("cfg", [
     # W, T, H, I, K, E, weight layout
     (1, 24, 512, 128, 4, 8, "native"),

@@ -68,7 +68,7 @@ DISPATCH_CASES = [
 ]
 
 
-def _run_dispatch(W, T, H, K, E, drop, active, quant_mode, ragged=True, compact=False):
+def _run_dispatch(W, T, H, K, E, drop, active, quant_mode, ragged=True, compact=False, transport="pull"):
     import ep_harness as Hh
     rng = np.random.default_rng(W * 1000 + T)
     Ts = [T + (r if ragged else 0) for r in range(W)]
@@ -80,20 +80,22 @@ def _run_dispatch(W, T, H, K, E, drop, active, quant_mode, ragged=True, compact=
             x[1, :] = 0                               # an all-zero row (amax = 0)
     idxs = [make_topk(rng, t, K, E, drop, active) if t else np.zeros((0, K), np.int64) for t in Ts]
     ws = [rng.standard_normal((t, K)).astype(np.float32) for t in Ts]
-    h = Hh.InProcEP(W, E, max(Ts) + 1, K, H, compact=compact)
+    h = Hh.InProcEP(W, E, max(Ts) + 1, K, H, compact=compact, transport=transport)
     got = h.dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).cuda() for i in idxs], quant_mode)
     return h, xs, idxs, ws, got
 
 
 @pytest.mark.parametrize("W,T,H,K,E,drop,active", DISPATCH_CASES)
 @pytest.mark.parametrize("quant", [False, True])
-@pytest.mark.parametrize("compact", [False, True], ids=["replicated", "compact"])
-def test_normal_dispatch_combine_bit_exact(W, T, H, K, E, drop, active, quant, compact):
-    """stage + pull (one staged row per (t, k): the all-to-all transport's format) and stage_compact + pull_indexed (one row
-    per token + index: what the host runtime uses) must both reproduce the oracle bit for bit."""
+@pytest.mark.parametrize("mode", ["replicated", "compact", "push"])
+def test_normal_dispatch_combine_bit_exact(W, T, H, K, E, drop, active, quant, mode):
+    """stage + pull (one staged row per (t, k): the all-to-all transport's format), stage_compact + pull_indexed (one row per
+    token + index in the sender's window, pulled by the receivers) and stage_push + local pull_indexed (the same row + index
+    written into the receivers' windows) must all reproduce the oracle bit for bit."""
     import ep_harness as Hh
     qm = Hh.QUANT_INT8 if quant else Hh.QUANT_NONE
-    h, xs, idxs, ws, got = _run_dispatch(W, T, H, K, E, drop, active, qm, compact=compact)
+    h, xs, idxs, ws, got = _run_dispatch(W, T, H, K, E, drop, active, qm, compact=mode == "compact",
+                                         transport="push" if mode == "push" else "pull")
     want = O.normal_dispatch(xs, idxs, E, quant)
     for r in range(W):
         g, w = got[r], want[r]
@@ -101,6 +103,14 @@ def test_normal_dispatch_combine_bit_exact(W, T, H, K, E, drop, active, quant, c
         for k in ("recv_count", "recv_offset", "recv_tokens_per_expert", "expert_global_offset",
                   "srcrank_in_expert_offset", "r_in_srcrank_offset", "total_recv_token", "max_bs"):
             assert np.array_equal(g["tables"][k].cpu().numpy().reshape(-1), np.asarray(w.notify[k]).reshape(-1)), (r, k)
+        if mode == "push":
+            # relative pull offsets: position of segment (le, src) among the rows `src` sends to this rank
+            L_ = E // W
+            cnt_m = g["cnt"].cpu().numpy()
+            rel = np.zeros(L_ * W, np.int32)
+            for src in range(W):
+                rel[src::W] = np.concatenate([[0], np.cumsum(cnt_m[src, r * L_:(r + 1) * L_])[:-1]])
+            assert np.array_equal(g["tables"]["pull_offset"].cpu().numpy(), rel)
         n = w.total_recv
         assert np.array_equal(g["recv_src_idx"].cpu().numpy()[:3 * n], w.recv_src_idx[:3 * n])
         if quant:
@@ -178,7 +188,7 @@ def test_low_latency_dispatch_combine_bit_exact(W, T, H, K, E, drop, quant, coun
 
 
 @pytest.mark.parametrize("quant", [True, False])
-@pytest.mark.parametrize("compact", [False, True], ids=["replicated", "compact"])
+@pytest.mark.parametrize("compact", ["replicated", "compact", "push"])
 def test_full_size_c2_properties(quant, compact):
     """BASELINE C2 sizes (W=8, 4096 tok/rank, H=7168, top-8, E=256), for both staging formats (compact = stage_compact +
     pull_indexed, the path the host runtime and bench.py use): size-independent properties --
@@ -191,7 +201,7 @@ def test_full_size_c2_properties(quant, compact):
     xs = [torch.randn((T, H), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16) for _ in range(W)]
     idxs = [torch.topk(torch.randn((T, E), generator=g, device="cuda").abs() + 1, K, dim=-1, sorted=False)[1] for _ in range(W)]
     ws = [torch.randn((T, K), generator=g, device="cuda") for _ in range(W)]
-    h = Hh.InProcEP(W, E, T, K, H, compact=compact)
+    h = Hh.InProcEP(W, E, T, K, H, compact=compact == "compact", transport="push" if compact == "push" else "pull")
     qm = Hh.QUANT_INT8 if quant else Hh.QUANT_NONE
     got = h.dispatch(xs, idxs, qm)
     hist = sum(torch.bincount(i.reshape(-1), minlength=E) for i in idxs)

@@ -155,7 +155,8 @@ def torch_rowquant(v):
     rowmax = v.abs().amax(dim=1)
     inv = torch.where(rowmax > 0, 1.0 / rowmax, torch.zeros_like(rowmax))
     q = torch.round((v * 127.0) * inv[:, None]).to(torch.int8)
-    return q, rowmax / 127.0
+    # tensor / tensor: a scalar divisor would be turned into a multiplication by its reciprocal by the elementwise kernel
+    return q, rowmax / torch.full_like(rowmax, 127.0)
 
 
 def torch_gemm2(q, sc, w2, s2):
