@@ -12,8 +12,16 @@ Weak scaling: per-GPU work is fixed as N grows.
 `value` follows the reference's own bandwidth convention (tests/python/deepep/test_intranode.py:447-448,530-534):
 bytes = BF16-equivalent size of every received row (local rows included) for dispatch plus the same for combine,
 summed over all ranks, divided by the max-over-ranks step time.  At N = 1 everything is a local permutation and the
-kernels are HBM-bound; the `roofline` object prices the dominant kernel against HBM.  A second object `mla_decode`
-reports BASELINE config C4 (single-GPU MLA paged decode) when that kernel is built.
+kernels are HBM-bound; the `roofline` object prices the dominant kernel against HBM.  At N > 1 both dispatch transports
+(push = remote writes, pull = remote reads) are timed with the same K steps; the faster one is the headline, the other is
+reported beside it under `transports`, and `xgmi` prices the cross-GPU legs against 153 GB/s per link.
+
+Further objects on the same JSON line (the other BASELINE configs, measured by the same process):
+  low_latency     C3: low-latency dispatch / combine at 128 tokens per rank, p50 / p99 per call (HIP events)
+  fused_deep_moe  C5: dispatch -> INT8 grouped GEMM1 + SwiGLU -> requant -> GEMM2 -> combine, 4096 tokens per rank, 32 local experts
+  mla_decode      C4: MLA paged decode (N = 1 only) with its own roofline and cpu_baseline
+  cpu_baseline    N = 1 only: the reference's alltoall algorithm restated on the host (oracle/cpu_alltoall.py, 8 gloo ranks
+                  sharing all host cores) on the same C2 workload, plus the single-core NumPy oracle.
 """
 import argparse
 import json
@@ -31,7 +39,9 @@ import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 XGMI_LINK_GBPS = 153.0          # per link, 7 links per GPU
+INT8_PEAK_TOPS = 3900.0         # dense int8 MFMA peak used in DESIGN.md (half the fp8 figure is quoted for bf16)
 T_TOKENS, HIDDEN, TOPK, EXPERTS = 4096, 7168, 8, 256
+INTER = 2048                    # DeepSeek-V3 MoE intermediate size (2I = 4096)
 
 
 def parse():
@@ -43,6 +53,7 @@ def parse():
     ap.add_argument("--strategy", default=os.getenv("DEEP_BENCH_STRATEGY", "default"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mla", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 (low-latency) and C5 (fused_deep_moe) sections")
     return ap.parse_args()
 
 
@@ -69,10 +80,10 @@ def init_dist(n):
     return dist.get_rank(), dist.get_world_size()
 
 
-def make_inputs(rank, T):
+def make_inputs(rank, T, experts=EXPERTS):
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)      # seed = 1234 + rank
     x = torch.randn((T, HIDDEN), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
-    scores = torch.randn((T, EXPERTS), generator=g, device="cuda").abs() + 1
+    scores = torch.randn((T, experts), generator=g, device="cuda").abs() + 1
     topk_idx = torch.topk(scores, TOPK, dim=-1, largest=True, sorted=False)[1]
     topk_w = torch.randn((T, TOPK), generator=g, device="cuda", dtype=torch.float32)
     return x, topk_idx, topk_w
@@ -106,17 +117,68 @@ def barrier_sync():
     torch.cuda.synchronize()
 
 
+_FLUSH = None
+
+
+def flush_cache():
+    """The reference's timer writes a 256 MB buffer before the timed region so nothing is served from a warm cache
+    (tests/python/deepep/utils.py:58-93); 256 MB also covers the MI355X's 256 MB MALL."""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    _FLUSH.zero_()
+
+
 def check_round_trip(out, x, topk_w):
     golden = x.float() * topk_w.sum(dim=1, keepdim=True)
     a, b = out.double() + 1, golden.double() + 1
     return float(1 - 2 * (a * b).sum() / (a * a + b * b).sum())
 
 
-def kernel_bytes(name, T, K, H, n_pairs, n_recv):
-    """Algorithmic HBM bytes of one launch."""
+def ev_stats(fn, n=50, warm=10):
+    """Per-call device time of fn() from HIP events on the current stream -> dict(p50_us, p99_us, min_us)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    return {"p50_us": ts[len(ts) // 2], "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "min_us": ts[0]}
+
+
+def max_over_ranks(d):
+    """Element-wise max over ranks of a flat {name: float} dict (every rank calls it with the same keys)."""
+    keys = sorted(d)
+    t = torch.tensor([float(d[k]) for k in keys], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+
+def routing_stats(topk_idx, world, rank):
+    """Per-destination counts of this rank's routing (all device-side, one sync): pairs[d] = (t, k) selections owned by rank d,
+    tokens[d] = distinct tokens with at least one expert on rank d."""
+    L = EXPERTS // world
+    dest = topk_idx // L
+    valid = topk_idx >= 0
+    pairs = torch.bincount(dest[valid].reshape(-1), minlength=world)
+    onehot = torch.zeros((topk_idx.shape[0], world), dtype=torch.bool, device=topk_idx.device)
+    onehot.scatter_(1, dest.clamp(min=0), valid)
+    tokens = onehot.sum(dim=0)
+    return pairs.tolist(), tokens.tolist()
+
+
+def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank):
+    """Algorithmic HBM bytes of one launch.  n_tok_rank = distinct (token, destination rank) pairs."""
     row = H + 16
     return {
         "dispatch_stage": T * H * 2 + T * row + n_pairs * 8,    # read bf16 tokens once, write one int8 row per token + the index
+        "dispatch_stage_push": T * H * 2 + n_tok_rank * row + n_pairs * 8,   # one row per (token, destination rank) + the index
         "dispatch_pull": 2 * n_recv * row + n_recv * 8,         # read a token row + index entry per received row, write recv_x / scales / triples
         "combine_push": 2 * n_recv * H * 2,                     # read bf16 rows, write them into the owners' slots
         "combine_reduce": n_pairs * H * 2 + T * H * 2,          # read K slots per token, write one bf16 row
@@ -128,9 +190,10 @@ PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatc
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r*_pmc_traffic.json, produced by tools/summarize_prof.py with the gfx950 FETCH_SIZE x2 correction);
-    None when no PMC summary is committed."""
+    """HBM bytes per launch of `kernel` measured by `tools/collect_profiles.sh` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this same command, summarised into profiles/r*_pmc_traffic.json with the gfx950 FETCH_SIZE x2 correction).  The collection
+    script fails when a kernel named here is missing from the counters, so the file cannot silently go stale; None when no PMC
+    summary is committed."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
@@ -143,34 +206,80 @@ def pmc_traffic(kernel):
         return None
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): bounded samples of the same workload on the host cores
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(sample_tokens):
-    """The oracle (a port of the reference arithmetic, NumPy, 1 thread of compute) on a bounded sample of the same
-    workload: W = 1, `sample_tokens` tokens, same hidden / top-k / experts; dispatch(int8) + cast-back + combine."""
+    """(1) `kind: port`, all host cores: the reference's alltoall strategy (normal_strategy.py:481-790) restated with torch CPU
+    ops, 8 gloo ranks x (cores / 8) threads, whole passes of the C2 workload (oracle/cpu_alltoall.py);
+    (2) `single_core`: the NumPy oracle (oracle/ep.py) on one core, W = 1."""
     import numpy as np
 
+    from oracle import cpu_alltoall as CA
     from oracle import ep as O
     from oracle.bf16 import f32_to_bf16_bits_rne
 
+    cores = os.cpu_count() or 8
+    out = {}
+    try:
+        r = CA.timed_run(W=8, T=sample_tokens, H=HIDDEN, K=TOPK, E=EXPERTS, cores=cores, min_seconds=10.0, max_passes=8)
+        bytes_ = 2 * r["rows_all_ranks"] * HIDDEN * 2 * r["passes"]
+        out = {"value": bytes_ / r["seconds"] / 1e9, "unit": "GB/s", "cores": r["cores"], "kind": "port",
+               "sample": f"{r['passes']} passes of EP=8 x {sample_tokens} tok/rank x hidden {HIDDEN} x top-{TOPK} of {EXPERTS}: layout + "
+                         f"int8 dispatch + cast-back + bf16 combine, reference alltoall strategy restated with torch CPU ops over "
+                         f"8 gloo ranks x {r['threads_per_rank']} threads (oracle/cpu_alltoall.py), {r['seconds']:.2f} s",
+               "seconds": r["seconds"]}
+    except Exception as e:  # noqa: BLE001
+        out = {"error": f"gloo alltoall baseline failed: {e}"}
     rng = np.random.default_rng(0)
-    x = f32_to_bf16_bits_rne(rng.standard_normal((sample_tokens, HIDDEN)).astype(np.float32))
-    scores = np.abs(rng.standard_normal((sample_tokens, EXPERTS))) + 1
+    T1 = min(sample_tokens, 1024)
+    x = f32_to_bf16_bits_rne(rng.standard_normal((T1, HIDDEN)).astype(np.float32))
+    scores = np.abs(rng.standard_normal((T1, EXPERTS))) + 1
     idx = np.argpartition(-scores, TOPK, axis=1)[:, :TOPK].astype(np.int64)
-    w = rng.standard_normal((sample_tokens, TOPK)).astype(np.float32)
+    w = rng.standard_normal((T1, TOPK)).astype(np.float32)
     t0 = time.perf_counter()
     reps = 0
-    while True:                       # ~10 s of CPU work, whole passes only
+    while True:
         res = O.normal_dispatch([x], [idx], EXPERTS, quant=True)[0]
         y = O.per_token_cast_back(res.recv_x, res.recv_x_scales)
         O.combine([y], [res.recv_src_idx], [res.total_recv], [idx], [w], EXPERTS)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 64:
+        if dt > 5.0 or reps >= 64:
             break
-    bytes_ = 2 * res.total_recv * HIDDEN * 2 * reps
-    return {"value": bytes_ / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} passes of W=1, {sample_tokens} tokens x hidden {HIDDEN} x top-{TOPK} of {EXPERTS} experts: "
-                      f"layout + int8 dispatch + cast-back + bf16 combine through oracle/ep.py (NumPy), {dt:.2f} s",
-            "seconds": dt}
+    out["single_core"] = {"value": 2 * res.total_recv * HIDDEN * 2 * reps / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                          "sample": f"{reps} passes of W=1, {T1} tokens through oracle/ep.py (NumPy), {dt:.2f} s"}
+    if "value" not in out:          # the multi-process leg failed: fall back to the single-core number as the baseline
+        out.update({k: v for k, v in out["single_core"].items()})
+    return out
+
+
+def mla_cpu_baseline(n_seq=2):
+    """The CPU golden of the reference test (decode_mla_golden, tests/python/sgl_kernel_npu/test_decode_attention.py:131-187) as
+    restated in oracle/kernels.py, torch CPU with all cores, on `n_seq` sequences of the C4 shape."""
+    from oracle import kernels as OK
+
+    B, Hq, S, page = n_seq, 128, 4096, 64
+    g = torch.Generator().manual_seed(0)
+    maxp = S // page
+    q = torch.randn((B, Hq, 576), generator=g).to(torch.bfloat16)
+    kn = torch.randn((B * maxp, page, 1, 512), generator=g).to(torch.bfloat16)
+    kr = torch.randn((B * maxp, page, 1, 64), generator=g).to(torch.bfloat16)
+    bt = torch.randperm(B * maxp, generator=g).to(torch.int32).reshape(B, maxp)
+    lens = torch.full((B,), S, dtype=torch.int32)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    OK.decode_mla(q[:1], kn, kr, lens[:1], bt[:1], 576 ** -0.5)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        OK.decode_mla(q, kn, kr, lens, bt, 576 ** -0.5)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 8.0 or reps >= 50:
+            break
+    return {"value": B * reps / dt, "unit": "tok/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {B} sequences of 4096 keys x 128 heads x 576/512 through oracle/kernels.py decode_mla (torch CPU), {dt:.2f} s"}
 
 
 def mla_section(args):
@@ -180,12 +289,99 @@ def mla_section(args):
         return None
     try:
         r = bench_mla_decode(steps=100, warmup=300)      # MFMA-heavy: let the clocks settle (tens of ms)
-        parts = [pmc_traffic(k) for k in ("mla_decode_wide_kernel<true>", "mla_merge_kernel<true>")]
-        if all(v is not None for v in parts):
-            r["roofline"]["traffic"] = sum(parts)      # both launches of one decode step (split partials included)
+        parts = [pmc_traffic(k) for k in r.pop("pmc_kernels", [])]
+        if parts and all(v is not None for v in parts):
+            r["roofline"]["traffic"] = sum(parts)      # all launches of one decode step
+        if not args.no_cpu_baseline:
+            r["cpu_baseline"] = mla_cpu_baseline()
         return r
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C3 / C5 sections (every rank runs them; rank 0 reports max-over-ranks numbers)
+# ---------------------------------------------------------------------------------------------------------------------
+def low_latency_section(buf, rank, world):
+    """BASELINE C3: low-latency dispatch + combine, 128 tokens per rank, hidden 7168, top-8, 32 local experts per rank."""
+    T, E = 128, 32 * world
+    g = torch.Generator(device="cuda").manual_seed(77 + rank)
+    x = torch.randn((T, HIDDEN), generator=g, device="cuda").to(torch.bfloat16)
+    idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), TOPK, dim=-1)[1]
+    w = torch.rand((T, TOPK), generator=g, device="cuda")
+    (rx, rs), cnt, handle, _, _ = buf.low_latency_dispatch(x, idx, T, E, use_fp8=True)
+    y = (rx.float() * rs[:, None]).to(torch.bfloat16)
+    out, _, _ = buf.low_latency_combine(y, idx, w, handle)
+    ok = check_round_trip(out, x, w) < 3e-3
+    barrier_sync()
+    d = ev_stats(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
+    barrier_sync()
+    c = ev_stats(lambda: buf.low_latency_combine(y, idx, w, handle))
+    barrier_sync()
+    m = max_over_ranks({"d50": d["p50_us"], "d99": d["p99_us"], "c50": c["p50_us"], "c99": c["p99_us"], "bad": 0.0 if ok else 1.0})
+    n_sel = T * TOPK
+    return {"config": f"low-latency dispatch(int8)+combine(bf16), EP={world}, 128 tok/rank, hidden {HIDDEN}, top-{TOPK} of {E} (BASELINE C3)",
+            "dispatch_us_p50": m["d50"], "dispatch_us_p99": m["d99"], "combine_us_p50": m["c50"], "combine_us_p99": m["c99"],
+            # reference byte convention (tests/python/deepep/test_low_latency.py:310-322)
+            "dispatch_GBps": n_sel * (HIDDEN + HIDDEN // 128 * 4 + 16) / m["d50"] / 1e3, "combine_GBps": n_sel * HIDDEN * 2 / m["c50"] / 1e3,
+            "validated_round_trip": m["bad"] == 0.0, "reference_A3_us": {"dispatch": 132, "combine": 126}}
+
+
+def fused_moe_section(buf, rank, world, T=4096):
+    """BASELINE C5: fused_deep_moe, DeepSeek-V3 expert shapes (hidden 7168, 2I = 4096), 32 local experts per rank, T tokens per rank."""
+    L = 32
+    E = L * world
+    g = torch.Generator(device="cuda").manual_seed(99 + rank)
+    w13 = torch.randint(-16, 16, (L, 2 * INTER, HIDDEN), generator=g, device="cuda", dtype=torch.int32).to(torch.int8)
+    w2 = torch.randint(-16, 16, (L, HIDDEN, INTER), generator=g, device="cuda", dtype=torch.int32).to(torch.int8)
+    s13 = torch.rand((L, 2 * INTER), generator=g, device="cuda") * 4e-4 + 1.5e-3
+    s2 = torch.rand((L, HIDDEN), generator=g, device="cuda") * 4e-4 + 1.5e-3
+    x = torch.randn((T, HIDDEN), generator=g, device="cuda").to(torch.bfloat16)
+    idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), TOPK, dim=-1)[1]
+    w = torch.rand((T, TOPK), generator=g, device="cuda")
+    f = lambda: buf.fused_deep_moe(x, idx, w, w13, s13, w2, s2, T, E)
+    out, _ = f()
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(out.float()).all())
+    barrier_sync()
+    buf.begin_profile(0, 10, "")
+    for _ in range(10):
+        f()
+    buf.end_profile()
+    prof = {k: ms / n * 1e3 for k, (n, ms) in buf.get_profile_summary().items() if n}
+    barrier_sync()
+    r = ev_stats(f, n=20, warm=20)
+    barrier_sync()
+    m = max_over_ranks({"p50": r["p50_us"], "p99": r["p99_us"]})
+    ops = T * TOPK * (HIDDEN * 2 * INTER + INTER * HIDDEN) * 2          # per rank under balanced routing
+    tops = ops / (m["p50"] * 1e-6) / 1e12
+    return {"config": f"fused_deep_moe, EP={world}, {T} tok/rank, hidden {HIDDEN}, 2I={2 * INTER}, top-{TOPK}, {L} local experts per rank (BASELINE C5)",
+            "ms_p50": m["p50"] / 1e3, "ms_p99": m["p99"] / 1e3, "int8_TOPs_per_gpu": tops,
+            "roofline": {"bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
+                         "traffic": None},
+            "kernels_avg_us": prof, "finite": finite}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def timed_steps(buf, x, topk_idx, topk_w, y, steps, warmup, profiled):
+    for _ in range(warmup):
+        one_step(buf, x, topk_idx, topk_w, y)
+    if profiled:
+        buf.begin_profile(0, steps, "")
+    flush_cache()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(buf, x, topk_idx, topk_w, y)
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if profiled:
+        buf.end_profile()
+        prof = buf.get_profile_summary()
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), prof
 
 
 def main():
@@ -199,7 +395,7 @@ def main():
     x, topk_idx, topk_w = make_inputs(rank, T)
     group = dist.group.WORLD
     strategy = args.strategy
-    buf = deep_ep.Buffer(group, normal_strategy=strategy, low_latency_strategy=strategy)
+    buf = deep_ep.Buffer(group, low_latency_mode=True, normal_strategy=strategy, low_latency_strategy=strategy)
     validated = None
     try:
         out, n_recv, y, recv, handle = one_step(buf, x, topk_idx, topk_w, None)
@@ -214,78 +410,110 @@ def main():
     flush_c_stdout()
     if int(flag.item()) == 0 and strategy != "alltoall":
         strategy = "alltoall"
-        buf = deep_ep.Buffer(group, normal_strategy="alltoall", low_latency_strategy="alltoall")
+        buf = deep_ep.Buffer(group, low_latency_mode=True, normal_strategy="alltoall", low_latency_strategy="alltoall")
         out, n_recv, y, recv, handle = one_step(buf, x, topk_idx, topk_w, None)
         torch.cuda.synchronize()
         validated = check_round_trip(out, x, topk_w) < 3e-3
     strategy = buf.normal_strategy.get_name()
+    windowed = strategy == "default" and hasattr(buf.runtime, "get_profile_summary")
 
-    for _ in range(args.warmup):
-        one_step(buf, x, topk_idx, topk_w, y)
-    profiled = hasattr(buf.runtime, "get_profile_summary") and strategy == "default"
-    if profiled:
-        buf.begin_profile(0, args.steps, "")
-    barrier_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(buf, x, topk_idx, topk_w, y)
-    barrier_sync()
-    dt = time.perf_counter() - t0
-    prof = {}
-    if profiled:
-        buf.end_profile()
-        prof = buf.get_profile_summary()
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    # ---- the timed region(s): exactly K steps per transport, barrier + synchronize on both sides, max over ranks
+    transports = [None]
+    if windowed and hasattr(buf.runtime, "set_dispatch_transport"):
+        transports = ["push", "pull"] if world > 1 else [buf.runtime.get_dispatch_transport()]
+    runs = {}
+    for tr in transports:
+        if tr is not None:
+            buf.runtime.set_dispatch_transport(tr)
+        try:
+            dt, prof = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, args.warmup, windowed)
+            runs[tr] = (dt, prof)
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] transport {tr} failed: {e}", file=sys.stderr)
+    assert runs, "no dispatch transport completed"
+    best = min(runs, key=lambda k: runs[k][0])
+    dt, prof = runs[best]
+    if best is not None:
+        buf.runtime.set_dispatch_transport(best)
     rows = torch.tensor([n_recv], device="cuda", dtype=torch.float64)
     dist.all_reduce(rows, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
     total_rows = float(rows.item())
     ms_per_step = dt / args.steps * 1e3
     bytes_per_step = 2 * total_rows * HIDDEN * 2          # dispatch recv + combine send, BF16-equivalent (reference convention)
     value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
 
+    # ---- the other BASELINE configs, same process group (every rank takes part)
+    extra = {}
+    if windowed and not args.no_extra:
+        for name, fn in (("low_latency", low_latency_section), ("fused_deep_moe", fused_moe_section)):
+            try:
+                extra[name] = fn(buf, rank, world)
+            except Exception as e:  # noqa: BLE001
+                extra[name] = {"error": str(e)[:300]}
+                torch.cuda.synchronize()
+
+    pairs_to, tokens_to = routing_stats(topk_idx, world, rank)
+    rows_from = torch.bincount(handle[3][:3 * n_recv].view(-1, 3)[:, 0].long(), minlength=world).tolist() if windowed else [0] * world
     if rank != 0:
         dist.destroy_process_group()
         flush_c_stdout()
         return
-    n_pairs = int((topk_idx >= 0).sum().item())
+    n_pairs = int(sum(pairs_to))
+    n_tok_rank = int(sum(tokens_to))
     result = {
         "metric": "dispatch+combine GB/s (EP=N, 4096 tok/rank, h=7168, top-8, INT8 dispatch / BF16 combine; "
                   "reference convention: BF16-equivalent received rows / time)",
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
+        "dtype": "int8/bf16", "data": "synthetic",
         "config": {"workload": f"deep_ep normal dispatch(int8)+combine(bf16), EP={world}, {T} tok/rank, hidden {HIDDEN}, "
                                f"top-{TOPK} of {EXPERTS} experts (BASELINE C2 shapes at EP={world})",
-                   "strategy": strategy, "tokens_per_rank": T, "hidden": HIDDEN, "topk": TOPK, "experts": EXPERTS},
+                   "strategy": strategy, "dispatch_transport": best, "tokens_per_rank": T, "hidden": HIDDEN, "topk": TOPK,
+                   "experts": EXPERTS, "cache_flush": "256 MB write before the timed region"},
         "per_gpu_GBps": value / world, "validated_round_trip": bool(validated),
     }
+    if len(runs) > 1:
+        result["transports"] = {k: {"ms_per_step": v[0] / args.steps * 1e3, "value": bytes_per_step / (v[0] / args.steps) / 1e9}
+                                for k, v in runs.items()}
     if prof:
         per = {k: {"launches": n, "avg_us": ms / n * 1e3} for k, (n, ms) in prof.items() if n}
-        dom = max(per, key=lambda k: per[k]["avg_us"])
-        alg = kernel_bytes(dom, T, TOPK, HIDDEN, n_pairs, n_recv)
+        bulk = [k for k in per if k in ("dispatch_stage", "dispatch_stage_push", "dispatch_pull", "combine_push", "combine_reduce")]
+        dom = max(bulk, key=lambda k: per[k]["avg_us"])
+        kb = lambda k: kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv, n_tok_rank)
+        alg = kb(dom)
         achieved = alg / (per[dom]["avg_us"] * 1e-6) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom) if world == 1 else None,
-                              "algorithmic_bytes": alg,
-                              "avg_launch_us": per[dom]["avg_us"]}
-        result["kernels"] = {k: dict(v, GBps=kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv) / (v["avg_us"] * 1e-6) / 1e9)
-                             for k, v in per.items() if k in ("dispatch_stage", "dispatch_pull", "combine_push", "combine_reduce")}
+                              "algorithmic_bytes": alg, "avg_launch_us": per[dom]["avg_us"]}
+        result["kernels"] = {k: dict(per[k], GBps=kb(k) / (per[k]["avg_us"] * 1e-6) / 1e9) for k in bulk}
+        result["kernels"].update({k: per[k] for k in per if k not in bulk})
         if world > 1:
-            # egress over xGMI per GPU: rows whose expert lives on another rank
-            remote = n_recv * (world - 1) / world
-            t_pull = per.get("dispatch_pull", {}).get("avg_us", 0) * 1e-6
-            t_push = per.get("combine_push", {}).get("avg_us", 0) * 1e-6
+            # cross-GPU bytes of this rank per step, per leg and per link (= per peer: one xGMI link each)
+            row = HIDDEN + 16
+            peers = [d for d in range(world) if d != rank]
+            if best == "push":        # sender writes one row per (token, destination rank) + 8 B per pair
+                disp_link = [tokens_to[d] * row + pairs_to[d] * 8 for d in peers]
+                t_disp = per.get("dispatch_stage_push", {}).get("avg_us", 0) * 1e-6
+            else:                     # receiver reads one row + one index entry per received row
+                disp_link = [rows_from[s] * (row + 8) for s in peers]
+                t_disp = per.get("dispatch_pull", {}).get("avg_us", 0) * 1e-6
+            comb_link = [rows_from[s] * HIDDEN * 2 for s in peers]      # rows pushed back to their source rank
+            t_comb = per.get("combine_push", {}).get("avg_us", 0) * 1e-6
             peak = XGMI_LINK_GBPS * (world - 1)
-            result["xgmi"] = {
-                "peak_GBps": peak,
-                "dispatch_GBps": remote * (HIDDEN + 4) / t_pull / 1e9 if t_pull else None,
-                "combine_GBps": remote * HIDDEN * 2 / t_push / 1e9 if t_push else None,
-            }
-            for k in ("dispatch_GBps", "combine_GBps"):
-                if result["xgmi"][k]:
-                    result["xgmi"][k.replace("GBps", "frac")] = result["xgmi"][k] / peak
+            xg = {"peak_GBps": peak, "link_GBps": XGMI_LINK_GBPS, "dispatch_transport": best,
+                  "dispatch_bytes": sum(disp_link), "combine_bytes": sum(comb_link),
+                  "dispatch_max_link_bytes": max(disp_link), "combine_max_link_bytes": max(comb_link)}
+            if t_disp:
+                xg["dispatch_GBps"] = sum(disp_link) / t_disp / 1e9
+                xg["dispatch_frac"] = xg["dispatch_GBps"] / peak
+                xg["dispatch_max_link_frac"] = max(disp_link) / t_disp / 1e9 / XGMI_LINK_GBPS
+            if t_comb:
+                xg["combine_GBps"] = sum(comb_link) / t_comb / 1e9
+                xg["combine_frac"] = xg["combine_GBps"] / peak
+                xg["combine_max_link_frac"] = max(comb_link) / t_comb / 1e9 / XGMI_LINK_GBPS
+            result["xgmi"] = xg
+    result.update(extra)
     if world == 1 and not args.no_mla:          # before the CPU leg: the GPU clocks sag while the host works alone
         mla = mla_section(args)
         if mla is not None:

@@ -26,6 +26,16 @@
  * as void*), never allocates, never synchronises and never throws.  Return value: 0 = enqueued,
  * negative = MI_EP_E* argument / launch error (nothing enqueued).
  *
+ * Device-resident epochs (graph replay).  Entry points that take `epoch_ctr` (+ a parity stride) can run without any host-side
+ * call counter: `epoch_ctr` points at a device word of the rank's own control area that holds the number of COMPLETED calls of
+ * the kernel family (normal dispatch / combine / low-latency dispatch).  The call's epoch is *epoch_ctr + 1; every window pointer
+ * argument is then the base of ping-pong half 0 and the kernel adds (epoch & 1) * stride itself; the family's single-workgroup
+ * exchange kernel (notify_exchange_tables / ll_post_recv / signal_wait) stores the new count when it is done, and the consume
+ * side launched after it (pull_indexed / the pull inside ll_post_recv / combine_reduce) reads the counter as is.  Nothing the
+ * host passes depends on how many calls ran before, so a captured HIP graph replays (the reference keeps its ping-pong word in the
+ * window for the same reason: cam_moe_dispatch_normal.h:273-286, notify_dispatch.h:924-938).  epoch_ctr == NULL: the explicit
+ * epoch / pointers are used as given and the stride is ignored.
+ *
  * Cross-rank data movement is one-sided through "windows": every rank owns a buffer that all
  * peers can address (hipIpc-mapped over xGMI, or plain pointers when several ranks live in one
  * process).  A kernel never spins on a peer inside a data-moving launch: hand-offs are
@@ -86,6 +96,7 @@ int mi_ep_wait(const uint64_t *my_flags, int num_ranks, uint64_t epoch, int32_t 
                void *stream);
 /* signal then wait in ONE launch (one rank per process: the peers' signals come from their own streams). */
 int mi_ep_signal_wait(uint64_t *const *peer_flags_host, const uint64_t *my_flags, int num_ranks, int my_rank, uint64_t epoch,
+                      uint64_t *epoch_ctr /* NULL, or: epoch = *epoch_ctr + 1, stored back when the wait is over */,
                       int32_t *status, int timeout_ms, void *stream);
 
 /* Start-up self-test of mapped windows (the reference trusts HCCL for this; here the mapping is ours: hipIpc over xGMI).
@@ -129,8 +140,10 @@ int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, uint64_t *co
                                  int num_ranks, int num_experts, int my_rank, int relative_pull, int32_t *recv_count,
                                  int32_t *recv_offset, int32_t *recv_tokens_per_expert, int32_t *expert_global_offset,
                                  int32_t *srcrank_in_expert_offset, int32_t *r_in_srcrank_offset, int32_t *total_recv_token,
-                                 int32_t *max_bs, int32_t *pull_offset, int32_t *summary_host, int32_t *status, int timeout_ms,
-                                 int32_t *wait_cost_stats, void *stream);
+                                 int32_t *max_bs, int32_t *pull_offset, int32_t *summary_host,
+                                 uint64_t *epoch_ctr /* NULL, or: both epochs = *epoch_ctr + 1, stored back at the end */,
+                                 size_t notify_parity_stride /* bytes between the two halves of the notify granules (peers and own) */,
+                                 int32_t *status, int timeout_ms, int32_t *wait_cost_stats, void *stream);
 /* Diagnose helpers (reference dispatch_wait_recv_cost_stats / combine_send_cost_stats, buffer.py:343-345,500-501): a device
  * timestamp (100 MHz ticks) and `stats[i] += microseconds since *t_start` for i < n.  Launched only when stats are requested. */
 int mi_ep_timestamp(uint64_t *dst, void *stream);
@@ -175,10 +188,12 @@ int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_co
 size_t mi_ep_dispatch_index_offset(int hidden, int quant_mode, int num_topk, size_t region_bytes);
 int mi_ep_dispatch_stage_compact(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                                  const int32_t *send_data_offset, int num_tokens, int num_topk, int hidden, int num_experts,
-                                 int my_rank, int quant_mode, void *region, size_t region_bytes, void *stream);
+                                 int my_rank, int quant_mode, void *region, size_t region_bytes,
+                                 const uint64_t *epoch_ctr, size_t parity_stride /* stage side: half (*epoch_ctr + 1) & 1 */, void *stream);
 int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset,
                                 int num_ranks, int num_local_experts, int hidden, int num_topk, int quant_mode, int rows_hint,
-                                size_t region_bytes, void *recv_x, float *recv_x_scales, int32_t *recv_src_idx, void *stream);
+                                size_t region_bytes, void *recv_x, float *recv_x_scales, int32_t *recv_src_idx,
+                                const uint64_t *epoch_ctr, size_t parity_stride /* consume side: half *epoch_ctr & 1 */, void *stream);
 
 /* Push transport of normal dispatch (selectable next to the pull above; the same received bytes).  The sender writes the
  * quantised row of token t ONCE into the window of every rank that owns at least one of the token's experts (the reference
@@ -195,7 +210,7 @@ size_t mi_ep_dispatch_push_slab_bytes(size_t region_bytes, int num_ranks);
 int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                               const int32_t *send_data_offset, int num_tokens, int num_topk, int hidden, int num_experts,
                               int num_ranks, int my_rank, int quant_mode, void *const *peer_region_host, size_t region_bytes,
-                              void *stream);
+                              const uint64_t *epoch_ctr, size_t parity_stride, void *stream);
 
 /* ---- A4/A6 combine ---------------------------------------------------------------------------
  * push: row r < total (= *total_rows_dev if non-NULL else rows_hint) of x [R,H] bf16 with triple
@@ -203,11 +218,15 @@ int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, int idx_is_i3
  * reduce: out[t] = bf16_rne( sum_{k asc, 0 <= idx[t,k] < E} float(slot[t*K+k]) * w[t,k] ) with separate fp32
  *   multiply and add (cam_moe_combine_normal.h:372-396).  topk_weights NULL -> ones.
  *   send_data_offset / send_token_idx_small: both NULL for the window layout above. */
+/* push: rows >= min(*total_rows_dev, rows_hint) are not touched; a triple outside [0,W) x slots of `slot_region_bytes`
+ * (0 = unchecked) x [0,K) is dropped instead of becoming a wild cross-GPU store. */
 int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
-                       int hidden, int num_topk, void *const *dst_base_host, int num_ranks, void *stream);
+                       int hidden, int num_topk, void *const *dst_base_host, int num_ranks, size_t slot_region_bytes,
+                       const uint64_t *epoch_ctr, size_t parity_stride, void *stream);
 int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                          const int32_t *send_data_offset, const int32_t *send_token_idx_small, int num_tokens,
-                         int num_topk, int hidden, int num_experts, void *out, void *stream);
+                         int num_topk, int hidden, int num_experts, void *out, const uint64_t *epoch_ctr, size_t parity_stride,
+                         void *stream);
 /* All-to-all (RCCL) transport helper: reorder x [R,H] bf16 from dispatch order (local expert, src, j) into
  * per-source blocks (src, local expert, j) -- each block is what that source staged for this rank, in its
  * send-slot order, so it can be returned as one contiguous message.  send_head [L*W] = recv_count of the
@@ -227,20 +246,22 @@ int mi_ep_combine_pack(const void *x, const int32_t *send_head, int num_ranks, i
  *   packed_recv_x_scales / src_info triples in idx-i order. */
 int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                            int num_tokens, int num_topk, int hidden, int num_experts, int num_ranks, int my_rank,
-                           int max_tokens, int quant_mode, void *const *peer_rows_host, void *stream);
+                           int max_tokens, int quant_mode, void *const *peer_rows_host, const uint64_t *epoch_ctr,
+                           size_t parity_stride, void *stream);
 int mi_ep_ll_post_counts(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int num_experts,
                          int num_ranks, int my_rank, uint32_t epoch, void *stream);
 int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint32_t epoch, int num_ranks,
                            int num_local_experts, int max_tokens, int hidden, int quant_mode, int count_type,
                            void *packed_recv_x, float *packed_recv_x_scales, int64_t *packed_recv_count,
-                           int32_t *src_info, int32_t *layout_range, int32_t *status, int timeout_ms,
-                           void *stream);
+                           int32_t *src_info, int32_t *layout_range, int rows_capacity /* rows packed_recv_x holds; 0 = L*W*max_tokens */,
+                           int32_t *status, int timeout_ms, void *stream);
 /* ll_post_counts fused into the receive (one rank per process): the counts workgroup posts this rank's counts, collects
  * everybody's, scans them; the packing kernel follows.  Two launches instead of three. */
 int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int my_rank, const void *my_rows,
                        const uint64_t *my_counts, uint32_t epoch, int num_ranks, int num_local_experts, int max_tokens, int hidden,
                        int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales,
-                       int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int32_t *status, int timeout_ms,
+                       int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int rows_capacity,
+                       uint64_t *epoch_ctr, size_t rows_parity_stride, size_t counts_parity_stride, int32_t *status, int timeout_ms,
                        void *stream);
 
 /* ---- A8 fused_deep_moe building blocks (reference: aclnnFusedDeepMoe, csrc/deepep/deep_ep.cpp:1223;
@@ -268,7 +289,8 @@ int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, cons
  * epilogue: fused_deep_moe.h:336-427).  dst_base_host[W] = every rank's combine region for this call (host array). */
 int mi_ep_moe_gemm2_push(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,
                          int cum_stride, int num_local_experts, int rows_cap, int inter, int hidden, const int32_t *src_idx,
-                         int topk, void *const *dst_base_host, int num_ranks, int rows_per_expert_hint, void *stream);
+                         int topk, void *const *dst_base_host, int num_ranks, size_t slot_region_bytes, const uint64_t *epoch_ctr,
+                         size_t parity_stride, int rows_per_expert_hint, void *stream);
 
 #ifdef __cplusplus
 }

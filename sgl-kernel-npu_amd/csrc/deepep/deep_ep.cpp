@@ -22,6 +22,7 @@ namespace {
 constexpr int64_t kCtrlBytes = 4ll << 20;          // flags + notify granules + LL count granules
 constexpr int kFlagGroupSlots = 64;                // MI_EP_MAX_RANKS
 constexpr int64_t kOffFlags = 0;                   // 8 groups x 64 x u64
+constexpr int64_t kOffEpochs = 8 << 10;                  // u64 completed-call counters, one per family (device-resident epochs)
 constexpr int64_t kOffNotify = 64 << 10;           // 2 parities x W x (E+1) u64  (<= 2 x 64 x 2049 x 8 = 2.1 MB)
 constexpr int64_t kNotifyParityBytes = 1100 << 10;
 constexpr int64_t kOffLLCounts = kOffNotify + 2 * kNotifyParityBytes;   // 2 parities x 2048 u64
@@ -212,7 +213,7 @@ bool Buffer::self_test(int64_t test_timeout_ms)
     if (num_ranks == 1) return true;
     hipStream_t st = cur_stream();
     const uint64_t ep = ++selftest_epoch;
-    auto rows = peer_regions(kLLDispatch, 1);          // scratch: the second low-latency region, unused before the first call
+    auto rows = peer_family_bases(kLLDispatch);        // scratch: the low-latency segment, unused before the first call
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagSelfTest * kFlagGroupSlots * 8));
     EP_HOST_ASSERT(mi_ep_selftest_bytes((int)num_ranks) <= region_bytes);
     MI_EP_CHECK(mi_ep_selftest(rows.data(), (uint64_t *const *)flag_peers.data(),
@@ -235,10 +236,11 @@ void Buffer::require_available() const
                           "deep_ep_cpp.Buffer used before sync(): peers' windows are not mapped");
 }
 
-uint8_t *Buffer::region(int family, uint64_t epoch) const
-{
-    return seg_base[1 + family] + (size_t)(epoch & 1) * region_bytes;
-}
+// base (ping-pong half 0) of this rank's segment of `family`; the kernels add (epoch & 1) * region_bytes themselves
+uint8_t *Buffer::family_base(int family) const { return seg_base[(size_t)(1 + family)]; }
+
+// device-resident count of completed calls of `family` (own control segment; see include/mi_ep.h "Device-resident epochs")
+uint64_t *Buffer::epoch_ctr(int family) const { return (uint64_t *)(window + kOffEpochs) + family; }
 
 // every rank's pointer to byte `offset` of the control segment
 std::vector<void *> Buffer::peer_ptrs(size_t offset) const
@@ -248,11 +250,11 @@ std::vector<void *> Buffer::peer_ptrs(size_t offset) const
     return v;
 }
 
-// every rank's region of `family` for the call with this epoch (ping-pong by parity)
-std::vector<void *> Buffer::peer_regions(int family, uint64_t epoch) const
+// every rank's segment base of `family`
+std::vector<void *> Buffer::peer_family_bases(int family) const
 {
     std::vector<void *> v((size_t)num_ranks);
-    for (size_t r = 0; r < (size_t)num_ranks; ++r) v[r] = peer_seg[r][(size_t)(1 + family)] + (size_t)(epoch & 1) * region_bytes;
+    for (size_t r = 0; r < (size_t)num_ranks; ++r) v[r] = peer_seg[r][(size_t)(1 + family)];
     return v;
 }
 
@@ -348,6 +350,76 @@ void Buffer::clean_low_latency_buffer(int, int, int) {}   // no-op, as in the re
 // ------------------------------------------------------------------------------------------------
 // A2 + A3  intranode_dispatch  (reference deep_ep.cpp:197-416)
 // ------------------------------------------------------------------------------------------------
+// Device half of a normal-mode dispatch, shared by intranode_dispatch and the prefill-size leg of fused_deep_moe:
+// stage (push: into the destination ranks' windows; pull: into the own window) -> ONE single-workgroup launch that posts
+// this rank's counts + "rows staged" flag, collects everybody's and derives the tables.  The call's epoch and ping-pong
+// half come from the device-resident counter of the family (see include/mi_ep.h), so nothing here depends on how many
+// calls ran before.
+Buffer::DispatchExchange Buffer::dispatch_exchange(const at::Tensor &x, const at::Tensor &topk_idx, const Layout &lay, int E, int qm,
+                                                   bool want_summary, int32_t *wait_stats, hipStream_t st)
+{
+    const int T = (int)x.size(0), H = (int)x.size(1), K = (int)topk_idx.size(1), W = (int)num_ranks, L = E / W;
+    const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
+    DispatchExchange ex;
+    ex.push = dispatch_transport == kTransportPush;
+    ex.slab_bytes = ex.push ? mi_ep_dispatch_push_slab_bytes(region_bytes, W) : region_bytes;
+    // compact staging: one row per TOKEN plus K index entries, not one row per (t, k).  Transport "pull": rows staged in the own
+    // window, receivers read them over xGMI (mi_ep_dispatch_stage_compact); "push": rows written once into every destination
+    // rank's window, slab `rank` of its region (mi_ep_dispatch_stage_push), receivers gather locally.
+    EP_HOST_ASSERT_S((size_t)T <= mi_ep_dispatch_index_offset(H, qm, K, ex.slab_bytes) / rb, "dispatch window too small: need ",
+                     (size_t)T * (rb + (size_t)K * 8) * (ex.push ? (size_t)W : 1), " bytes per region, have ", region_bytes,
+                     "; raise DEEPEP_WINDOW_BYTES (or use DEEPEP_NORMAL_LONG_SEQ_ROUND)");
+    uint64_t *ctr = epoch_ctr(kDispatch);
+    auto region_peers = peer_family_bases(kDispatch);
+    const bool i32idx = topk_idx.scalar_type() == at::kInt;
+    { ProfScope ps_(this, ex.push ? "dispatch_stage_push" : "dispatch_stage", st);
+      if (ex.push)
+          MI_EP_CHECK(mi_ep_dispatch_stage_push(x.data_ptr(), topk_idx.data_ptr(), i32idx, lay.send_token_idx_small.data_ptr<int>(),
+                                                lay.send_data_offset.data_ptr<int>(), T, K, H, E, W, (int)rank, qm,
+                                                region_peers.data(), region_bytes, ctr, region_bytes, st));
+      else
+          MI_EP_CHECK(mi_ep_dispatch_stage_compact(x.data_ptr(), topk_idx.data_ptr(), i32idx, lay.send_token_idx_small.data_ptr<int>(),
+                                                   lay.send_data_offset.data_ptr<int>(), T, K, H, E, (int)rank, qm,
+                                                   family_base(kDispatch), region_bytes, ctr, region_bytes, st)); }
+    auto notify_peers = peer_ptrs((size_t)kOffNotify);
+    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
+    ex.nt = alloc_notify_tables(W, E, L, at::dtype(at::kInt).device(x.device()));
+    NotifyTables &nt = ex.nt;
+    if (want_summary) __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
+    { ProfScope ps_(this, "dispatch_notify", st);
+      MI_EP_CHECK(mi_ep_notify_exchange_tables((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(),
+                                               lay.num_tokens_per_expert.data_ptr<int>(), T, (const uint64_t *)(window + kOffNotify), 0,
+                                               (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), 0,
+                                               nt.cnt.data_ptr<int>(), W, E, (int)rank, ex.push ? 1 : 0, nt.recv_count.data_ptr<int>(),
+                                               nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
+                                               nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
+                                               nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
+                                               nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(),
+                                               want_summary ? summary_dev : nullptr, ctr, (size_t)kNotifyParityBytes, status_dev,
+                                               timeout_ms, wait_stats, st)); }
+    // pull: token rows + index live in every SOURCE rank's window; push: in the source slabs of the own window
+    ex.src_bases = region_peers;
+    if (ex.push)
+        for (int s = 0; s < W; ++s) ex.src_bases[(size_t)s] = family_base(kDispatch) + (size_t)s * ex.slab_bytes;
+    return ex;
+}
+
+// receiver half: gather `rows_alloc` rows (at most; the device-side total bounds it too) into freshly allocated outputs
+void Buffer::dispatch_pull(const DispatchExchange &ex, int H, int K, int L, int qm, int64_t rows_alloc, const at::TensorOptions &x_opts,
+                           at::Tensor &rx, at::Tensor &rs, at::Tensor &src_idx, hipStream_t st)
+{
+    auto dev = x_opts.device();
+    const bool quant = qm != MI_EP_QUANT_NONE;
+    rx = quant ? at::empty({rows_alloc, H}, at::dtype(at::kChar).device(dev)) : at::empty({rows_alloc, H}, x_opts);
+    rs = at::empty({rows_alloc}, at::dtype(at::kFloat).device(dev));
+    src_idx = at::empty({rows_alloc * 3}, at::dtype(at::kInt).device(dev));
+    ProfScope ps_(this, "dispatch_pull", st);
+    MI_EP_CHECK(mi_ep_dispatch_pull_indexed((const void *const *)ex.src_bases.data(), ex.nt.recv_count.data_ptr<int>(),
+                                            ex.nt.pull_offset.data_ptr<int>(), (int)num_ranks, L, H, K, qm, (int)rows_alloc, ex.slab_bytes,
+                                            rx.data_ptr(), quant ? rs.data_ptr<float>() : nullptr, src_idx.data_ptr<int>(),
+                                            epoch_ctr(kDispatch), region_bytes, st));
+}
+
 std::tuple<at::Tensor, std::optional<at::Tensor>, std::optional<at::Tensor>, std::optional<at::Tensor>, std::vector<int>,
            at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, std::optional<EventHandle>>
 Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> &x_scales,
@@ -388,38 +460,11 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     EP_HOST_ASSERT_S(H % 16 == 0 && H <= MI_EP_MAX_HIDDEN, "hidden (", H, ") must be a multiple of 16 and <= ", MI_EP_MAX_HIDDEN);
     EP_HOST_ASSERT_S(E <= 2048, "num_experts (", E, ") must be <= 2048");
     const int qm = quant_mode_of(use_quant, quant_type);
-    const size_t rb = mi_ep_dispatch_row_bytes(H, qm);
-    // compact staging: one row per TOKEN plus K index entries, not one row per (t, k).  Transport "pull": rows staged in the own
-    // window, receivers read them over xGMI (mi_ep_dispatch_stage_compact); "push": rows written once into every destination
-    // rank's window, slab `rank` of its region (mi_ep_dispatch_stage_push), receivers gather locally.
-    const bool push = dispatch_transport == kTransportPush;
-    const size_t slab_bytes = push ? mi_ep_dispatch_push_slab_bytes(region_bytes, (int)num_ranks) : region_bytes;
-    EP_HOST_ASSERT_S((size_t)T <= mi_ep_dispatch_index_offset(H, qm, K, slab_bytes) / rb, "dispatch window too small: need ",
-                     (size_t)T * (rb + (size_t)K * 8) * (push ? (size_t)num_ranks : 1), " bytes per region, have ", region_bytes,
-                     "; raise DEEPEP_WINDOW_BYTES");
     check_status("intranode_dispatch");
     ++profile_calls;
     const Layout &lay = layout_for(*topk_idx, E);
     hipStream_t st = cur_stream();
-    auto dev = x.device();
-    auto i32 = at::dtype(at::kInt).device(dev);
-    const uint64_t ep = ++dispatch_epoch;
-    const int par = (int)(ep & 1);
-
-    // sender side: stage into the own window, publish counts, raise the "staged" flag on every peer
-    uint8_t *my_rows = region(kDispatch, ep);
-    auto region_peers = peer_regions(kDispatch, ep);
-    { ProfScope ps_(this, push ? "dispatch_stage_push" : "dispatch_stage", st);
-      if (push)
-          MI_EP_CHECK(mi_ep_dispatch_stage_push(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
-                                                lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
-                                                H, E, W, (int)rank, qm, region_peers.data(), region_bytes, st));
-      else
-          MI_EP_CHECK(mi_ep_dispatch_stage_compact(x.data_ptr(), topk_idx->data_ptr(), topk_idx->scalar_type() == at::kInt,
-                                                   lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), T, K,
-                                                   H, E, (int)rank, qm, my_rows, region_bytes, st)); }
-    auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
-    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
+    auto i32 = at::dtype(at::kInt).device(x.device());
 
     // counts + "staged" flag to every peer, then (same launch, one workgroup) everybody's counts + flags -> tables
     // (+ pinned summary for the host)
@@ -429,49 +474,19 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
         EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->dim() == 1 and dispatch_wait_recv_cost_stats->size(0) == num_ranks);
         wait_stats = dispatch_wait_recv_cost_stats->data_ptr<int>();
     }
-    NotifyTables nt = alloc_notify_tables(W, E, L, i32);
     const bool host_sync = num_worst_tokens <= 0;
-    if (host_sync) __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
-    MI_EP_CHECK(mi_ep_notify_exchange_tables((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(),
-                                             lay.num_tokens_per_expert.data_ptr<int>(), T,
-                                             (const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
-                                             (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
-                                             nt.cnt.data_ptr<int>(), W, E, (int)rank, push ? 1 : 0, nt.recv_count.data_ptr<int>(),
-                                             nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
-                                             nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
-                                             nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
-                                             nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(),
-                                             host_sync ? summary_dev : nullptr, status_dev, timeout_ms, wait_stats, st));
-    at::Tensor &cnt = nt.cnt, &recv_count = nt.recv_count, &recv_offset = nt.recv_offset;
-    at::Tensor &recv_tokens_per_expert = nt.recv_tokens_per_expert, &expert_global_offset = nt.expert_global_offset;
-    at::Tensor &srcrank_in_expert_offset = nt.srcrank_in_expert_offset, &r_in_srcrank_offset = nt.r_in_srcrank_offset;
-    at::Tensor &total_recv_token = nt.total_recv_token, &max_bs = nt.max_bs, &pull_offset = nt.pull_offset;
-    (void)cnt; (void)recv_offset; (void)recv_tokens_per_expert; (void)expert_global_offset; (void)srcrank_in_expert_offset;
-    (void)r_in_srcrank_offset; (void)total_recv_token; (void)max_bs; (void)pull_offset; (void)recv_count;
+    DispatchExchange ex = dispatch_exchange(x, *topk_idx, lay, E, qm, host_sync, wait_stats, st);
 
     // Receive buffers + the pull launch.  The exact row count reaches the host only through the pinned summary word;
     // to keep the GPU busy across that round trip the pull is launched FIRST into buffers sized from the previous call
     // (+25 %), and the results are returned as exact-size prefixes once the host knows the count.  A call that receives
     // more than the guess simply pulls again into exact-size buffers (the kernel never writes past `rows_hint`).
     at::Tensor expandx_out, dynamic_scales_out, expand_idx_out;
-    // pull: token rows + index live in every SOURCE rank's window; push: in the source slabs of the own window
-    std::vector<void *> src_peers = region_peers;
-    if (push)
-        for (int s = 0; s < W; ++s) src_peers[(size_t)s] = my_rows + (size_t)s * slab_bytes;
-    auto launch_pull = [&](int64_t rows_alloc) {
-        expandx_out = use_quant ? at::empty({rows_alloc, H}, at::dtype(at::kChar).device(dev)) : at::empty({rows_alloc, H}, x.options());
-        dynamic_scales_out = at::empty({rows_alloc}, at::dtype(at::kFloat).device(dev));
-        expand_idx_out = at::empty({rows_alloc * 3}, i32);
-        ProfScope ps_(this, "dispatch_pull", st);
-        MI_EP_CHECK(mi_ep_dispatch_pull_indexed((const void *const *)src_peers.data(), recv_count.data_ptr<int>(), pull_offset.data_ptr<int>(), W,
-                                                L, H, K, qm, (int)rows_alloc, slab_bytes, expandx_out.data_ptr(),
-                                                use_quant ? dynamic_scales_out.data_ptr<float>() : nullptr, expand_idx_out.data_ptr<int>(), st));
-    };
     static const bool speculate = get_value_from_env("DEEPEP_SPECULATIVE_RECV", 1) != 0;
     int64_t guess = 0;
     if (host_sync && speculate && last_recv_rows > 0) {
         guess = last_recv_rows + last_recv_rows / 4 + 256;
-        launch_pull(guess);
+        dispatch_pull(ex, H, K, L, qm, guess, x.options(), expandx_out, dynamic_scales_out, expand_idx_out, st);
     }
     int64_t trt;
     std::vector<int> num_recv_tokens_per_expert_list;
@@ -500,20 +515,16 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
         dynamic_scales_out = dynamic_scales_out.narrow(0, 0, rows);
         expand_idx_out = expand_idx_out.narrow(0, 0, rows * 3);
     } else {
-        launch_pull(rows);
+        dispatch_pull(ex, H, K, L, qm, rows, x.options(), expandx_out, dynamic_scales_out, expand_idx_out, st);
     }
     std::optional<at::Tensor> recv_topk_idx = at::empty({trt, K}, topk_idx->options());       // allocated, never written
     std::optional<at::Tensor> recv_topk_weights = at::empty({trt, K}, topk_weights->options());  // (deep_ep.cpp:371-374)
-    if (dispatch_wait_recv_cost_stats.has_value()) {
-        EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->scalar_type() == at::kInt);
-        EP_HOST_ASSERT(dispatch_wait_recv_cost_stats->dim() == 1 and dispatch_wait_recv_cost_stats->size(0) == num_ranks);
-    }
     // placeholders kept for handle-shape compatibility (uninitialised in the reference, deep_ep.cpp:220-222)
     auto rank_prefix_matrix = at::empty({W, W}, i32);
     auto channel_prefix_matrix = at::empty({W, num_channels}, i32);
     auto recv_channel_prefix_matrix = at::empty({W, num_channels}, i32);
     return {expandx_out, dynamic_scales_out, recv_topk_idx, recv_topk_weights, num_recv_tokens_per_expert_list,
-            rank_prefix_matrix, channel_prefix_matrix, recv_channel_prefix_matrix, expand_idx_out, recv_count, std::nullopt};
+            rank_prefix_matrix, channel_prefix_matrix, recv_channel_prefix_matrix, expand_idx_out, ex.nt.recv_count, std::nullopt};
 }
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>
@@ -521,39 +532,22 @@ Buffer::notify_verify(const at::Tensor &x, const std::optional<at::Tensor> &, co
                       const std::optional<at::Tensor> &, const std::optional<at::Tensor> &, const at::Tensor &,
                       const std::optional<at::Tensor> &num_tokens_per_expert, int, const std::optional<at::Tensor> &,
                       const std::optional<at::Tensor> &, const std::optional<at::Tensor> &, int, int, const Config &,
-                      std::optional<EventHandle> &, bool, bool, bool)
+                      std::optional<EventHandle> &, bool, bool, bool use_quant)
 {
-    // Test-only entry of the reference (deep_ep.cpp:418-550): run the notify exchange alone and return its tables
+    // Test-only entry of the reference (deep_ep.cpp:418-550): run the notify exchange and return its tables
     // (recv_data, recv_count, recv_offset, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset,
-    //  total_recv_token, max_bs, recv_tokens_per_expert).
+    //  total_recv_token, max_bs, recv_tokens_per_expert).  Here it is a complete dispatch exchange without the receive side (the
+    // staged rows are simply never gathered), so the call counters of all ranks stay in step.
     require_available();
     EP_HOST_ASSERT(topk_idx.has_value() and num_tokens_per_expert.has_value());
-    const int T = (int)x.size(0);
-    const int E = (int)num_tokens_per_expert->size(0), W = (int)num_ranks, L = E / W;
+    EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
+    const int E = (int)num_tokens_per_expert->size(0);
     const Layout &lay = layout_for(*topk_idx, E);
-    hipStream_t st = cur_stream();
-    auto i32 = at::dtype(at::kInt).device(x.device());
-    const uint64_t ep = ++dispatch_epoch;
-    const int par = (int)(ep & 1);
-    auto notify_peers = peer_ptrs((size_t)(kOffNotify + par * kNotifyParityBytes));
-    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
-    NotifyTables nt = alloc_notify_tables(W, E, L, i32);
-    MI_EP_CHECK(mi_ep_notify_exchange_tables((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(),
-                                         lay.num_tokens_per_expert.data_ptr<int>(), T,
-                                         (const uint64_t *)(window + kOffNotify + par * kNotifyParityBytes), (uint32_t)ep,
-                                         (const uint64_t *)(window + kOffFlags + kFlagDispatch * kFlagGroupSlots * 8), ep,
-                                         nt.cnt.data_ptr<int>(), W, E, (int)rank, 0, nt.recv_count.data_ptr<int>(),
-                                         nt.recv_offset.data_ptr<int>(), nt.recv_tokens_per_expert.data_ptr<int>(),
-                                         nt.expert_global_offset.data_ptr<int>(), nt.srcrank_in_expert_offset.data_ptr<int>(),
-                                         nt.r_in_srcrank_offset.data_ptr<int>(), nt.total_recv_token.data_ptr<int>(),
-                                         nt.max_bs.data_ptr<int>(), nt.pull_offset.data_ptr<int>(), nullptr, status_dev,
-                                         timeout_ms, nullptr, st));
-    at::Tensor &cnt = nt.cnt, &recv_count = nt.recv_count, &recv_offset = nt.recv_offset;
-    at::Tensor &recv_tokens_per_expert = nt.recv_tokens_per_expert, &expert_global_offset = nt.expert_global_offset;
-    at::Tensor &srcrank_in_expert_offset = nt.srcrank_in_expert_offset, &r_in_srcrank_offset = nt.r_in_srcrank_offset;
-    at::Tensor &total_recv_token = nt.total_recv_token, &max_bs = nt.max_bs;
-    return {cnt, recv_count, recv_offset, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset,
-            total_recv_token, max_bs, recv_tokens_per_expert};
+    DispatchExchange ex = dispatch_exchange(x, *topk_idx, lay, E, use_quant ? MI_EP_QUANT_INT8 : MI_EP_QUANT_NONE, false, nullptr,
+                                            cur_stream());
+    NotifyTables &nt = ex.nt;
+    return {nt.cnt, nt.recv_count, nt.recv_offset, nt.expert_global_offset, nt.srcrank_in_expert_offset, nt.r_in_srcrank_offset,
+            nt.total_recv_token, nt.max_bs, nt.recv_tokens_per_expert};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -586,8 +580,7 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
                      " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
     check_status("intranode_combine");
     hipStream_t st = cur_stream();
-    const uint64_t ep = ++combine_epoch;
-    auto dst_peers = peer_regions(kCombine, ep);
+    auto dst_peers = peer_family_bases(kCombine);
     // diagnose (opt-in): every send of this rank is complete when the push kernel ends, so each destination is charged the
     // push duration (device timestamps before / after; only launched when the caller passes the stats tensor)
     at::Tensor t_start;
@@ -597,19 +590,14 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
         MI_EP_CHECK(mi_ep_timestamp((uint64_t *)t_start.data_ptr(), st));
     }
     // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
-    { ProfScope ps_(this, "combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1),
-                                   (int)x.size(0), H, K, dst_peers.data(), W, st)); }
+    { ProfScope ps_(this, "combine_push", st);
+      MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1), (int)x.size(0), H, K,
+                                     dst_peers.data(), W, region_bytes, epoch_ctr(kCombine), region_bytes, st)); }
     if (combine_send_cost_stats.has_value())
         MI_EP_CHECK(mi_ep_elapsed_add(combine_send_cost_stats->data_ptr<int>(), W, (const uint64_t *)t_start.data_ptr(), st));
-    auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
-                                  (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, ep,
-                                  status_dev, timeout_ms, st));
-    auto combined_x = at::empty({T, H}, x.options());
-    { ProfScope ps_(this, "combine_reduce", st); MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
-                                     topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, nullptr, nullptr,
-                                     T, K, H, E, combined_x.data_ptr(), st)); }
-    return {combined_x, std::nullopt, std::nullopt};
+    return {combine_finish(topk_idx, topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, H, E, x.options(),
+                           "combine_reduce", st),
+            std::nullopt, std::nullopt};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -663,19 +651,21 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     const int count_type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
     hipStream_t st = cur_stream();
     const Layout lay = run_layout(topk_idx, E);
-    const uint64_t ep = ++ll_epoch;
-    const int par = (int)(ep & 1);
-    auto row_peers = peer_regions(kLLDispatch, ep);
-    { ProfScope ps_(this, "ll_dispatch_send", st); MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
-                                       lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm,
-                                       row_peers.data(), st)); }
-    auto cnt_peers = peer_ptrs((size_t)(kOffLLCounts + par * kLLCountsParityBytes));
-    { ProfScope ps_(this, "ll_dispatch_recv", st); MI_EP_CHECK(mi_ep_ll_post_recv((uint64_t *const *)cnt_peers.data(), lay.num_tokens_per_expert.data_ptr<int>(), (int)rank,
-                                       region(kLLDispatch, ep), (const uint64_t *)(window + kOffLLCounts + par * kLLCountsParityBytes),
-                                       (uint32_t)ep, W, L, MT, H, qm, count_type, packed_recv_x.data_ptr(),
-                                       qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(),
-                                       (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(),
-                                       ep_recv_count.data_ptr<int>(), status_dev, timeout_ms, st)); }
+    uint64_t *ctr = epoch_ctr(kLLDispatch);
+    auto row_peers = peer_family_bases(kLLDispatch);
+    { ProfScope ps_(this, "ll_dispatch_send", st);
+      MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                         lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm, row_peers.data(), ctr,
+                                         region_bytes, st)); }
+    auto cnt_peers = peer_ptrs((size_t)kOffLLCounts);
+    // rows the output tensors hold (and src_info / 3): the packing kernel never writes past them, whatever the counts say
+    const int rows_capacity = (int)std::min<int64_t>(num_max_tokens, max_size / 3);
+    { ProfScope ps_(this, "ll_dispatch_recv", st);
+      MI_EP_CHECK(mi_ep_ll_post_recv((uint64_t *const *)cnt_peers.data(), lay.num_tokens_per_expert.data_ptr<int>(), (int)rank,
+                                     family_base(kLLDispatch), (const uint64_t *)(window + kOffLLCounts), 0, W, L, MT, H, qm, count_type,
+                                     packed_recv_x.data_ptr(), qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(),
+                                     (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(), ep_recv_count.data_ptr<int>(),
+                                     rows_capacity, ctr, region_bytes, (size_t)kLLCountsParityBytes, status_dev, timeout_ms, st)); }
     real_max_bs = std::max<int64_t>(real_max_bs, MT);
     return {packed_recv_x, packed_recv_x_scales, packed_recv_count, expand_idx, ep_recv_count, std::nullopt,
             std::function<void()>([] {})};
@@ -697,33 +687,38 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     EP_HOST_ASSERT(topk_weights.dim() == 2 and topk_weights.is_contiguous() and topk_weights.scalar_type() == at::kFloat);
     EP_HOST_ASSERT(topk_weights.size(0) == topk_idx.size(0) and topk_weights.size(1) == topk_idx.size(1));
     EP_HOST_ASSERT(src_info.scalar_type() == at::kInt and layout_range.scalar_type() == at::kInt);
-    const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), H = (int)x.size(1);
+    const int K = (int)topk_idx.size(1), H = (int)x.size(1);
     const int W = (int)num_ranks, E = (int)num_experts;
     const size_t cb = mi_ep_combine_row_bytes(H);
     EP_HOST_ASSERT_S((size_t)num_max_dispatch_tokens_per_rank * K * cb <= region_bytes, "combine window too small; raise DEEPEP_WINDOW_BYTES");
     check_status("low_latency_combine");
     hipStream_t st = cur_stream();
-    const uint64_t ep = ++combine_epoch;
-    auto dst_peers = peer_regions(kCombine, ep);
+    auto dst_peers = peer_family_bases(kCombine);
     // valid packed rows = layout_range[L*W-1], read on device
-    { ProfScope ps_(this, "ll_combine_push", st); MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
-                                   (int)x.size(0), H, K, dst_peers.data(), W, st)); }
+    { ProfScope ps_(this, "ll_combine_push", st);
+      MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
+                                     (int)std::min<int64_t>(x.size(0), src_info.numel() / 3), H, K, dst_peers.data(), W, region_bytes,
+                                     epoch_ctr(kCombine), region_bytes, st)); }
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
-    return {ll_combine_finish(topk_idx, topk_weights, H, E, ep, x.options(), st), std::nullopt, std::function<void()>([] {})};
+    return {combine_finish(topk_idx, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st), std::nullopt,
+            std::function<void()>([] {})};
 }
 
-// second half of a low-latency combine: "my rows are pushed" to every owner, wait for every expert rank, weighted sum
-at::Tensor Buffer::ll_combine_finish(const at::Tensor &topk_idx, const at::Tensor &topk_weights, int H, int E, uint64_t ep,
-                                     const at::TensorOptions &opts, hipStream_t st)
+// second half of a combine: "my rows are pushed" to every owner, wait for every expert rank (ONE single-wave launch, which also
+// completes the family's device-resident call counter), then the weighted sum over the K slots of every token
+at::Tensor Buffer::combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
+                                  const char *reduce_name, hipStream_t st)
 {
     const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), W = (int)num_ranks;
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
-    MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
-                                  (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, ep,
-                                  status_dev, timeout_ms, st));
+    { ProfScope ps_(this, "combine_signal_wait", st);
+      MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
+                                    (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, 0,
+                                    epoch_ctr(kCombine), status_dev, timeout_ms, st)); }
     auto combined_x = at::empty({T, H}, opts);
-    { ProfScope ps_(this, "ll_combine_reduce", st); MI_EP_CHECK(mi_ep_combine_reduce(region(kCombine, ep), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
-                                     topk_weights.data_ptr<float>(), nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), st)); }
+    { ProfScope ps_(this, reduce_name, st);
+      MI_EP_CHECK(mi_ep_combine_reduce(family_base(kCombine), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, topk_weights,
+                                       nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), epoch_ctr(kCombine), region_bytes, st)); }
     return combined_x;
 }
 
@@ -785,17 +780,32 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     EP_HOST_ASSERT(s1.numel() == (int64_t)L * N1 and s2.numel() == (int64_t)L * H);
     EP_HOST_ASSERT_S(H % 128 == 0 && I % 128 == 0, "hidden (", H, ") and intermediate (", I, ") must be multiples of 128");
     EP_HOST_ASSERT(topk_weights.size(0) == T and topk_weights.size(1) == K);
-
-    std::optional<at::Tensor> none;
-    auto disp = low_latency_dispatch(x, expert_ids, none, num_max_dispatch_tokens_per_rank, num_experts, true, false, false,
-                                     false, false, false, "int8");
-    const at::Tensor &rx = std::get<0>(disp);
-    const at::Tensor &rs = *std::get<1>(disp);
-    const at::Tensor &src_info = std::get<3>(disp);
-    const at::Tensor &layout_range = std::get<4>(disp);
-    const int M = (int)rx.size(0);
+    const int64_t MT = num_max_dispatch_tokens_per_rank;
     hipStream_t st = cur_stream();
     auto dev = x.device();
+
+    // Dispatch leg.  Decode-size batches take the low-latency slabs (rows straight into the destination's (expert, source)
+    // slab, 4 launches).  Prefill-size batches take the normal-mode exchange without its host sync: one staged row per TOKEN
+    // instead of one per (token, k) -- 31 MB instead of 235 MB of staging at 4096 tokens -- and a window of T rows per source
+    // instead of L x W x max_tokens slabs (7.5 GB at EP = 8 x 4096 tokens, which no window holds).  Both produce the same packed
+    // rows in (local expert, source rank) order, the same triples and the same inclusive counts.
+    at::Tensor rx, rs, src_info, layout_range;
+    const size_t ll_bytes = (size_t)L * W * MT * mi_ep_dispatch_row_bytes(H, MI_EP_QUANT_INT8_NOEPS);
+    if (MT <= 512 && ll_bytes <= region_bytes) {
+        std::optional<at::Tensor> none;
+        auto disp = low_latency_dispatch(x, expert_ids, none, MT, num_experts, true, false, false, false, false, false, "int8");
+        rx = std::get<0>(disp), rs = *std::get<1>(disp), src_info = std::get<3>(disp), layout_range = std::get<4>(disp);
+    } else {
+        check_status("fused_deep_moe");
+        ++profile_calls;
+        const Layout lay = run_layout(expert_ids, E);
+        DispatchExchange ex = dispatch_exchange(x, expert_ids, lay, E, MI_EP_QUANT_INT8_NOEPS, false, nullptr, st);
+        const int64_t rows_cap = std::max<int64_t>(1, MT * W * std::min(K, L));         // worst case (deep_ep.cpp:867-873)
+        dispatch_pull(ex, H, K, L, MI_EP_QUANT_INT8_NOEPS, rows_cap, x.options(), rx, rs, src_info, st);
+        layout_range = ex.nt.recv_count;
+        real_max_bs = std::max<int64_t>(real_max_bs, MT);
+    }
+    const int M = (int)rx.size(0);
     at::Tensor v = at::empty({M, I}, at::dtype(at::kFloat).device(dev));
     at::Tensor q2 = at::empty({M, I}, at::dtype(at::kChar).device(dev));
     at::Tensor sc2 = at::empty({M}, at::dtype(at::kFloat).device(dev));
@@ -810,14 +820,13 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     // GEMM2 writes every bf16 row straight into its owner's combine slot (the push of low_latency_combine fused into the GEMM
     // epilogue: no dense [M, H] intermediate, one pass over 2*M*H bytes less), then the usual signal / wait / weighted sum
     const size_t cb = mi_ep_combine_row_bytes(H);
-    EP_HOST_ASSERT_S((size_t)num_max_dispatch_tokens_per_rank * K * cb <= region_bytes, "combine window too small; raise DEEPEP_WINDOW_BYTES");
-    const uint64_t ep = ++combine_epoch;
-    auto dst_peers = peer_regions(kCombine, ep);
+    EP_HOST_ASSERT_S((size_t)MT * K * cb <= region_bytes, "combine window too small; raise DEEPEP_WINDOW_BYTES");
+    auto dst_peers = peer_family_bases(kCombine);
     { ProfScope ps_(this, "moe_gemm2_push", st);
       MI_EP_CHECK(mi_ep_moe_gemm2_push((const int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), (const int8_t *)w2.data_ptr(),
                                        s2.data_ptr<float>(), cum, W, L, M, I, H, src_info.data_ptr<int>(), K, dst_peers.data(), W,
-                                       rows_hint, st)); }
-    at::Tensor combined = ll_combine_finish(expert_ids, topk_weights, H, E, ep, x.options(), st);
+                                       region_bytes, epoch_ctr(kCombine), region_bytes, rows_hint, st)); }
+    at::Tensor combined = combine_finish(expert_ids, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st);
     return {combined, layout_range};
 }
 
@@ -1087,7 +1096,7 @@ at::Tensor Buffer::a2a_combine_reduce(const at::Tensor &returned_rows, const at:
     MI_EP_CHECK(mi_ep_combine_reduce(returned_rows.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                      topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr,
                                      send_data_offset.data_ptr<int>(), send_token_idx_small.data_ptr<int>(), T, K, H,
-                                     (int)num_experts, out.data_ptr(), cur_stream()));
+                                     (int)num_experts, out.data_ptr(), nullptr, 0, cur_stream()));
     return out;
 }
 

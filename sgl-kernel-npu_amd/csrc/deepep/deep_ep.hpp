@@ -161,9 +161,10 @@ private:
 
     void check_status(const char *where);
     int64_t wait_summary(const char *where);     // host spin on the pinned summary word written by notify_tables
-    uint8_t *region(int family, uint64_t epoch) const;
+    uint8_t *family_base(int family) const;
+    uint64_t *epoch_ctr(int family) const;
     std::vector<void *> peer_ptrs(size_t offset) const;                 // into the control segment
-    std::vector<void *> peer_regions(int family, uint64_t epoch) const;
+    std::vector<void *> peer_family_bases(int family) const;
     void require_available() const;
 
     int64_t rank, num_ranks, num_nvl_bytes, num_rdma_bytes;
@@ -190,7 +191,7 @@ private:
 
     enum { kTransportPull = 0, kTransportPush = 1 };
     int dispatch_transport = kTransportPull;
-    uint64_t dispatch_epoch = 0, combine_epoch = 0, ll_epoch = 0, selftest_epoch = 0;
+    uint64_t selftest_epoch = 0;           // (dispatch / combine / low-latency call counters live on the device: epoch_ctr())
     Layout stash;                          // hidden state coupling of the reference (deep_ep.cpp:170-172,321)
     int64_t real_max_bs = 0;
     int64_t profile_skip = 0, profile_active = 0, profile_calls = 0;
@@ -202,8 +203,18 @@ private:
             r_in_srcrank_offset, total_recv_token, max_bs, pull_offset;
     };
     NotifyTables alloc_notify_tables(int W, int E, int L, const at::TensorOptions &i32);
-    at::Tensor ll_combine_finish(const at::Tensor &topk_idx, const at::Tensor &topk_weights, int H, int E, uint64_t ep,
-                                 const at::TensorOptions &opts, hipStream_t st);
+    struct DispatchExchange {              // device half of one normal-mode dispatch (stage + notify exchange)
+        NotifyTables nt;
+        std::vector<void *> src_bases;     // where the receive side finds source s's token rows + index (half 0 of the ping-pong)
+        size_t slab_bytes = 0;
+        bool push = false;
+    };
+    DispatchExchange dispatch_exchange(const at::Tensor &x, const at::Tensor &topk_idx, const Layout &lay, int E, int qm,
+                                       bool want_summary, int32_t *wait_stats, hipStream_t st);
+    void dispatch_pull(const DispatchExchange &ex, int H, int K, int L, int qm, int64_t rows_alloc, const at::TensorOptions &x_opts,
+                       at::Tensor &rx, at::Tensor &rs, at::Tensor &src_idx, hipStream_t st);
+    at::Tensor combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
+                              const char *reduce_name, hipStream_t st);
     // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
     std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
                                        const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,

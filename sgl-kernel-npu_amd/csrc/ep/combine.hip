@@ -12,6 +12,8 @@
 // T*K*2H read + T*2H write.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ep_common.h"
 
 namespace mi_ep {
@@ -20,9 +22,11 @@ constexpr int kPushWaves = 4;
 
 __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     const uint8_t *__restrict__ x, const int32_t *__restrict__ src_idx, const int32_t *__restrict__ total_dev,
-    int rows_hint, int row_bytes /*2H*/, size_t slot_stride, int K, int W, PeerPtrs dsts)
+    int rows_hint, int row_bytes /*2H*/, size_t slot_stride, int K, int W, PeerPtrs dsts, Parity par, int slot_rows)
 {
-    const int total = total_dev ? *total_dev : rows_hint;
+    // never trust the device-side count beyond the rows the caller's tensor holds
+    const int total = total_dev ? min(*total_dev, rows_hint) : rows_hint;
+    const size_t poff = parity_off(par);
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
     const int n16 = row_bytes / 16;
@@ -32,9 +36,10 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
             const int src = src_idx[r * 3 + 0];
             const int t = src_idx[r * 3 + 1];
             const int k = src_idx[r * 3 + 2];
-            if (src < 0 || src >= W) continue;        // corrupted handle: drop instead of a wild store
+            // corrupted / mismatched handle: drop the row instead of a wild (cross-GPU) store
+            if (src < 0 || src >= W || k < 0 || k >= K || t < 0 || (long long)t * K + k >= slot_rows) continue;
             const u32x4 *s16 = (const u32x4 *)(x + (size_t)r * row_bytes);
-            u32x4 *d16 = (u32x4 *)((uint8_t *)dsts.p[src] + ((size_t)t * K + k) * slot_stride);
+            u32x4 *d16 = (u32x4 *)((uint8_t *)dsts.p[src] + poff + ((size_t)t * K + k) * slot_stride);
             for (int base = 0; base < n16; base += kWave * 8) {
                 u32x4 v[8];
 #pragma unroll
@@ -58,8 +63,9 @@ template <bool I32, int KMAX>
 __global__ __launch_bounds__(256) void combine_reduce_kernel(
     const uint8_t *__restrict__ slots, size_t slot_stride, const void *__restrict__ topk_idx,
     const float *__restrict__ topk_w, const int32_t *__restrict__ send_off, const int32_t *__restrict__ idx_small,
-    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out)
+    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out, Parity par)
 {
+    slots += parity_off(par);
     const int lane = lane_id();
     const long long wid = (long long)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     const long long t = wid / segs_per_token;
@@ -201,7 +207,8 @@ extern "C" int mi_ep_combine_pack(const void *x, const int32_t *send_head, int W
 extern "C" size_t mi_ep_combine_row_bytes(int hidden) { return ((size_t)hidden * 2 + 15) / 16 * 16; }
 
 extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
-                                  int H, int K, void *const *dst_base_host, int W, void *stream)
+                                  int H, int K, void *const *dst_base_host, int W, size_t slot_region_bytes,
+                                  const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
 {
     if (H <= 0 || H % 8 || K <= 0 || K > MI_EP_MAX_TOPK || W <= 0 || W > MI_EP_MAX_RANKS || !dst_base_host)
         return MI_EP_EINVAL;
@@ -215,13 +222,15 @@ extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const i
     long long blocks = ((long long)rows_hint + kPushWaves - 1) / kPushWaves;        // one row per wave until the chip is full
     if (blocks > 256 * 8) blocks = 256 * 8;
     combine_push_kernel<<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
-        (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp);
+        (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp,
+        make_parity(epoch_ctr, 1, parity_stride),
+        slot_region_bytes ? (int)std::min<size_t>(slot_region_bytes / mi_ep_combine_row_bytes(H), 0x7FFFFFFF) : 0x7FFFFFFF);
     return launch_status();
 }
 
 extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                                     const int32_t *send_data_offset, const int32_t *send_token_idx_small, int T, int K,
-                                    int H, int E, void *out, void *stream)
+                                    int H, int E, void *out, const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
 {
     if ((send_data_offset == nullptr) != (send_token_idx_small == nullptr)) return MI_EP_EINVAL;
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 8 || E <= 0) return MI_EP_EINVAL;
@@ -238,11 +247,12 @@ extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int
     const int wpb = 4;
     const long long blocks = (waves + wpb - 1) / wpb;
     hipStream_t s = (hipStream_t)stream;
+    const Parity par = make_parity(epoch_ctr, 0, parity_stride);
     // top-k <= 8 (DeepSeek-V3) gets its own instantiation: half the row registers, twice the waves per SIMD
 #define MI_EP_REDUCE(I32, KMAX)                                                                                                    \
     combine_reduce_kernel<I32, KMAX><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H), topk_idx, \
                                                                          topk_weights, send_data_offset, send_token_idx_small, T, K, H,  \
-                                                                         E, segs, (uint16_t *)out)
+                                                                         E, segs, (uint16_t *)out, par)
     if (K <= 8) { if (idx_is_i32) MI_EP_REDUCE(true, 8); else MI_EP_REDUCE(false, 8); }
     else { if (idx_is_i32) MI_EP_REDUCE(true, MI_EP_MAX_TOPK); else MI_EP_REDUCE(false, MI_EP_MAX_TOPK); }
 #undef MI_EP_REDUCE

@@ -44,12 +44,12 @@ struct PushGeom {
 };
 // compact / push staging of one token: `write_row(base)` stores the payload + meta at row t of the slab at `base`
 template <class WriteRow>
-__device__ __forceinline__ void stage_token_rows(const PushGeom &pg, const PeerPtrs &dsts, size_t idx_off, int my_rank, int t, int K,
-                                                 long long e_l, int slot_l, const int32_t *send_off, WriteRow write_row)
+__device__ __forceinline__ void stage_token_rows(const PushGeom &pg, const PeerPtrs &dsts, size_t poff, size_t idx_off, int my_rank,
+                                                 int t, int K, long long e_l, int slot_l, const int32_t *send_off, WriteRow write_row)
 {
     const int lane = lane_id();
     if (pg.L == 0) {
-        uint8_t *base = (uint8_t *)dsts.p[0];
+        uint8_t *base = (uint8_t *)dsts.p[0] + poff;
         write_row(base);
         if (lane < K && e_l >= 0) ((uint2 *)(base + idx_off))[slot_l] = uint2{(uint32_t)t, (uint32_t)lane};
         return;
@@ -64,7 +64,7 @@ __device__ __forceinline__ void stage_token_rows(const PushGeom &pg, const PeerP
     while (rmask) {                                   // wave-uniform
         const int d = __builtin_ctzll(rmask);
         rmask &= rmask - 1;
-        uint8_t *base = (uint8_t *)dsts.p[d] + (size_t)my_rank * pg.slab;
+        uint8_t *base = (uint8_t *)dsts.p[d] + poff + (size_t)my_rank * pg.slab;
         write_row(base);
         // position among the rows this rank sends to d, in its expert-sorted order (= the receiver's relative pull offset)
         if (d_l == d) ((uint2 *)(base + idx_off))[slot_l - send_off[d * pg.L]] = uint2{(uint32_t)t, (uint32_t)lane};
@@ -89,7 +89,7 @@ template <bool I32, bool EPS>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
     const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
-    PushGeom pg)
+    PushGeom pg, Parity par)
 {
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
         // compact staging (normal-mode pull transport): the row is written ONCE at slot t; the expert-sorted index tells the
         // receivers which token row each of their rows is (K-fold less staging traffic than one copy per (t, k)).
         // Push transport: the same row + index entries, written into every destination rank's window instead of the own one.
-        stage_token_rows(pg, dsts, idx_off, my_rank, t, K, e_l, slot_l, send_off, [&](uint8_t *base) {
+        stage_token_rows(pg, dsts, parity_off(par), idx_off, my_rank, t, K, e_l, slot_l, send_off, [&](uint8_t *base) {
             uint8_t *row = base + (size_t)t * stride;
             u32x4 *dst = (u32x4 *)row;
 #pragma unroll
@@ -174,11 +174,12 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
         });
         return;
     }
+    const size_t poff = parity_off(par);
     for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;          // wave-uniform
         const int slot = __shfl(slot_l, k, kWave);
         const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
-        uint8_t *row = (uint8_t *)dsts.p[drank] + (size_t)slot * stride;
+        uint8_t *row = (uint8_t *)dsts.p[drank] + poff + (size_t)slot * stride;
         u32x4 *dst = (u32x4 *)row;
 #pragma unroll
         for (int it = 0; it < kMaxItems; ++it) {
@@ -195,7 +196,7 @@ template <bool I32>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
     const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
-    PushGeom pg)
+    PushGeom pg, Parity par)
 {
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
         if (item < nitems) raw[it] = src[item];
     }
     if (idx_off) {                                  // compact / push staging, see stage_int8_kernel
-        stage_token_rows(pg, dsts, idx_off, my_rank, t, K, e_l, slot_l, send_off, [&](uint8_t *base) {
+        stage_token_rows(pg, dsts, parity_off(par), idx_off, my_rank, t, K, e_l, slot_l, send_off, [&](uint8_t *base) {
             uint8_t *row = base + (size_t)t * stride;
             u32x4 *dst = (u32x4 *)row;
 #pragma unroll
@@ -234,11 +235,12 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
         });
         return;
     }
+    const size_t poff = parity_off(par);
     for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;
         const int slot = __shfl(slot_l, k, kWave);
         const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
-        uint8_t *row = (uint8_t *)dsts.p[drank] + (size_t)slot * stride;
+        uint8_t *row = (uint8_t *)dsts.p[drank] + poff + (size_t)slot * stride;
         u32x4 *dst = (u32x4 *)row;
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
@@ -259,7 +261,7 @@ constexpr int kPullRowsPerBlock = kPullWaves;              // grid sizing: one r
 __device__ __forceinline__ void pull_body(
     const PeerPtrs &srcs, const int32_t *cum /*LDS [LW]*/, const int32_t *__restrict__ pull_offset, int seg_capacity, int W, int LW,
     int payload_bytes /*H or 2H*/, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales, int32_t *__restrict__ recv_src_idx,
-    int row_capacity)
+    int row_capacity, size_t poff)
 {
     const int total = min(cum[LW - 1], row_capacity);      // never write past the caller's buffers
     const int lane = lane_id();
@@ -281,7 +283,7 @@ __device__ __forceinline__ void pull_body(
             const int j = (int)(r - (i ? cum[i - 1] : 0));
             const int src = i % W;
             const size_t off = pull_offset ? (size_t)pull_offset[i] : (size_t)i * seg_capacity;
-            const uint8_t *srow = (const uint8_t *)srcs.p[src] + (off + j) * stride;
+            const uint8_t *srow = (const uint8_t *)srcs.p[src] + poff + (off + j) * stride;
             const u32x4 *s16 = (const u32x4 *)srow;
             u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
             for (int base = 0; base < n16; base += kWave * 8) {
@@ -312,12 +314,13 @@ __device__ __forceinline__ void pull_body(
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int seg_capacity,
     int W, int LW, int payload_bytes, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
-    int32_t *__restrict__ recv_src_idx, int row_capacity)
+    int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
     for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
     __syncthreads();
-    pull_body(srcs, cum, pull_offset, seg_capacity, W, LW, payload_bytes, recv_x, recv_scales, recv_src_idx, row_capacity);
+    pull_body(srcs, cum, pull_offset, seg_capacity, W, LW, payload_bytes, recv_x, recv_scales, recv_src_idx, row_capacity,
+              parity_off(par));
 }
 
 // pull for compact staging (mi_ep_dispatch_stage_compact): output row r of segment (le, src), position j, is token row
@@ -327,11 +330,12 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int W, int LW,
     int payload_bytes, size_t idx_off, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
-    int32_t *__restrict__ recv_src_idx, int row_capacity)
+    int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
     for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
     __syncthreads();
+    const size_t poff = parity_off(par);
     const int total = min(cum[LW - 1], row_capacity);
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         }
         const int j = (int)(r - (lo ? cum[lo - 1] : 0));
         src = lo % W;
-        return ((const uint2 *)((const uint8_t *)srcs.p[src] + idx_off))[(size_t)pull_offset[lo] + j];
+        return ((const uint2 *)((const uint8_t *)srcs.p[src] + poff + idx_off))[(size_t)pull_offset[lo] + j];
     };
     long long r = (long long)blockIdx.x * kPullWaves + wave;
     int src_n = 0;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         if (rn < total) e_n = entry(rn, src_n);                  // in flight while this row is copied
         // a stale index entry must not turn into a wild read: token rows live below the index
         const size_t trow = min((size_t)e.x, idx_off / stride - 1);
-        const uint8_t *srow = (const uint8_t *)srcs.p[src] + trow * stride;
+        const uint8_t *srow = (const uint8_t *)srcs.p[src] + poff + trow * stride;
         const u32x4 *s16 = (const u32x4 *)srow;
         u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
         for (int base = 0; base < n16; base += kWave * 8) {
@@ -404,7 +408,8 @@ extern "C" size_t mi_ep_dispatch_index_offset(int hidden, int quant_mode, int to
 
 static int stage_launch(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                         const int32_t *send_data_offset, int T, int K, int H, int E, int my_rank, int quant_mode, void *rows,
-                        size_t idx_off, void *stream, const PeerPtrs *push_peers = nullptr, PushGeom pg = PushGeom{0, 0})
+                        size_t idx_off, void *stream, const PeerPtrs *push_peers = nullptr, PushGeom pg = PushGeom{0, 0},
+                        Parity par = Parity{EpochRef{nullptr, 0}, 0})
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0) return MI_EP_EINVAL;
     if (T == 0) return MI_EP_OK;
@@ -420,7 +425,7 @@ static int stage_launch(const void *x, const void *topk_idx, int idx_is_i32, con
     else pp.p[0] = rp;
     const LLGeom ll{0, 0, 0};
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll, ksplit, idx_off, pg)
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, pp, ll, ksplit, idx_off, pg, par)
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
@@ -449,14 +454,14 @@ extern "C" int mi_ep_dispatch_stage(const void *x, const void *topk_idx, int idx
 extern "C" int mi_ep_dispatch_stage_compact(const void *x, const void *topk_idx, int idx_is_i32,
                                             const int32_t *send_token_idx_small, const int32_t *send_data_offset, int T, int K,
                                             int H, int E, int my_rank, int quant_mode, void *region, size_t region_bytes,
-                                            void *stream)
+                                            const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
 {
     if (H <= 0 || K <= 0) return MI_EP_EINVAL;
     const size_t rb = mi_ep_dispatch_row_bytes(H, quant_mode);
     const size_t idx_off = mi_ep_dispatch_index_offset(H, quant_mode, K, region_bytes);
     if (idx_off == 0 || (size_t)T > idx_off / rb) return MI_EP_EINVAL;          // region too small for T tokens
     return stage_launch(x, topk_idx, idx_is_i32, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, quant_mode, region,
-                        idx_off, stream);
+                        idx_off, stream, nullptr, PushGeom{0, 0}, make_parity(epoch_ctr, 1, parity_stride));
 }
 
 extern "C" size_t mi_ep_dispatch_push_slab_bytes(size_t region_bytes, int num_ranks)
@@ -467,7 +472,8 @@ extern "C" size_t mi_ep_dispatch_push_slab_bytes(size_t region_bytes, int num_ra
 
 extern "C" int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                                          const int32_t *send_data_offset, int T, int K, int H, int E, int W, int my_rank,
-                                         int quant_mode, void *const *peer_region_host, size_t region_bytes, void *stream)
+                                         int quant_mode, void *const *peer_region_host, size_t region_bytes,
+                                         const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
 {
     if (H <= 0 || K <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || my_rank < 0 || my_rank >= W || !peer_region_host)
         return MI_EP_EINVAL;
@@ -481,7 +487,7 @@ extern "C" int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, in
         pp.p[i] = peer_region_host[i];
     }
     return stage_launch(x, topk_idx, idx_is_i32, send_token_idx_small, send_data_offset, T, K, H, E, my_rank, quant_mode, nullptr,
-                        idx_off, stream, &pp, PushGeom{E / W, slab});
+                        idx_off, stream, &pp, PushGeom{E / W, slab}, make_parity(epoch_ctr, 1, parity_stride));
 }
 
 extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_count,
@@ -502,14 +508,15 @@ extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32
     if (blocks > 256 * 8) blocks = 256 * 8;
     const size_t lds = (size_t)L * W * sizeof(int32_t);
     pull_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
-        pp, recv_count, pull_offset, 0, W, L * W, payload, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint);
+        pp, recv_count, pull_offset, 0, W, L * W, payload, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint,
+        Parity{EpochRef{nullptr, 0}, 0});
     return launch_status();
 }
 
 extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t *recv_count,
                                            const int32_t *pull_offset, int W, int L, int H, int K, int quant_mode,
                                            int rows_hint, size_t region_bytes, void *recv_x, float *recv_x_scales,
-                                           int32_t *recv_src_idx, void *stream)
+                                           int32_t *recv_src_idx, const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
 {
     if (!src_base_host || !recv_count || !pull_offset || W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || H <= 0 || H % 16 || K <= 0 ||
         K > MI_EP_MAX_TOPK || !recv_x || !recv_src_idx)
@@ -527,7 +534,8 @@ extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, con
     if (blocks > 256 * 8) blocks = 256 * 8;
     const size_t lds = (size_t)L * W * sizeof(int32_t);
     pull_indexed_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
-        pp, recv_count, pull_offset, W, L * W, payload, idx_off, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint);
+        pp, recv_count, pull_offset, W, L * W, payload, idx_off, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint,
+        make_parity(epoch_ctr, 0, parity_stride));
     return launch_status();
 }
 
@@ -547,7 +555,8 @@ __global__ void ll_post_counts_kernel(PeerPtrs peers, const int32_t *__restrict_
 
 // one workgroup: wait for the L*W count granules, inclusive cumsum in idx-i order, per-expert counts
 __global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, const int32_t *__restrict__ my_counts_out /*[E] or null*/,
-                                                        int my_rank, const uint64_t *__restrict__ granules, uint32_t epoch, int L, int W,
+                                                        int my_rank, const uint64_t *__restrict__ granules_base, EpochRef er,
+                                                        size_t counts_parity_stride, uint64_t *epoch_bump, int L, int W,
                                                         int count_type, int32_t *__restrict__ layout_range,
                                                         int64_t *__restrict__ packed_recv_count, int32_t *status,
                                                         uint64_t timeout_ticks)
@@ -555,11 +564,16 @@ __global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, co
     extern __shared__ __attribute__((aligned(16))) int32_t c[];   // [L*W] counts -> inclusive cumsum, then [4] wave totals
     const int LW = L * W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t *wave_tot = c + LW;
+    // this call's epoch (device-resident counter + 1, or the explicit value) and the ping-pong half of the count granules
+    const uint64_t ep64 = epoch_of(er);
+    const uint32_t epoch = (uint32_t)ep64;
+    const size_t cpoff = (size_t)(ep64 & 1ull) * counts_parity_stride;
+    const uint64_t *granules = (const uint64_t *)((const uint8_t *)granules_base + cpoff);
     // optional fused post (one rank per process): this rank's per-expert counts to every peer, then collect everybody's
     if (my_counts_out) {
         for (int i = tid; i < LW; i += blockDim.x) {
             const int d = i / L, le = i % L;
-            sys_store_u64_relaxed((uint64_t *)count_peers.p[d] + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)my_counts_out[d * L + le]);
+            sys_store_u64_relaxed((uint64_t *)((uint8_t *)count_peers.p[d] + cpoff) + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)my_counts_out[d * L + le]);
         }
     }
     const uint64_t t0 = ticks_100mhz();
@@ -601,13 +615,16 @@ __global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, co
         const int32_t end = c[(le + 1) * W - 1], beg = le ? c[le * W - 1] : 0;
         packed_recv_count[le] = (count_type == 0) ? (int64_t)end : (int64_t)(end - beg);
     }
+    // the call is now "complete" as far as later kernels of the family are concerned: they read the counter with add = 0
+    if (epoch_bump && tid == 0) *epoch_bump = ep64;
 }
 
 }  // namespace mi_ep
 
 extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int idx_is_i32,
                                       const int32_t *send_token_idx_small, int T, int K, int H, int E, int W, int my_rank,
-                                      int max_tokens, int quant_mode, void *const *peer_rows_host, void *stream)
+                                      int max_tokens, int quant_mode, void *const *peer_rows_host, const uint64_t *epoch_ctr,
+                                      size_t parity_stride, void *stream)
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0 || W <= 0 ||
         W > MI_EP_MAX_RANKS || E % W || T > max_tokens || !peer_rows_host)
@@ -620,13 +637,14 @@ extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int i
         pp.p[i] = peer_rows_host[i];
     }
     const LLGeom ll{E / W, W, max_tokens};
+    const Parity par = make_parity(epoch_ctr, 1, parity_stride);
     hipStream_t s = (hipStream_t)stream;
     const int ksplit = T <= 512 ? K : 1;            // decode-size batches: one wave per (token, k) instead of per token
     const int blocks = (int)(((long long)T * ksplit + kStageWaves - 1) / kStageWaves);
     const int threads = kWave * kStageWaves;
     const uint16_t *xp = (const uint16_t *)x;
 #define MI_EP_STAGE(KERNEL) \
-    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll, ksplit, (size_t)0, PushGeom{0, 0})
+    KERNEL<<<blocks, threads, 0, s>>>(xp, topk_idx, send_token_idx_small, nullptr, T, K, H, E, my_rank, pp, ll, ksplit, (size_t)0, PushGeom{0, 0}, par)
     switch (quant_mode) {
         case MI_EP_QUANT_NONE:
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
@@ -661,7 +679,7 @@ extern "C" int mi_ep_ll_post_counts(uint64_t *const *peer_counts_host, const int
 extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint32_t epoch, int W, int L,
                                       int max_tokens, int H, int quant_mode, int count_type, void *packed_recv_x,
                                       float *packed_recv_x_scales, int64_t *packed_recv_count, int32_t *src_info,
-                                      int32_t *layout_range, int32_t *status, int timeout_ms, void *stream)
+                                      int32_t *layout_range, int rows_capacity, int32_t *status, int timeout_ms, void *stream)
 {
     if (!my_rows || !my_counts || !packed_recv_x || !packed_recv_count || !src_info || !layout_range || !status ||
         W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || L * W > 2048 || H <= 0 || H % 16 || max_tokens <= 0 || epoch == 0)
@@ -669,8 +687,9 @@ extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_co
     hipStream_t s = (hipStream_t)stream;
     const uint64_t ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
     PeerPtrs none{};
-    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(none, nullptr, 0, my_counts, epoch, L, W, count_type, layout_range,
-                                                            packed_recv_count, status, ticks);
+    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(none, nullptr, 0, my_counts, EpochRef{nullptr, epoch}, 0, nullptr, L, W,
+                                                            count_type, layout_range, packed_recv_count, status, ticks);
+    const int cap = rows_capacity > 0 ? rows_capacity : L * W * max_tokens;      // rows the caller's output buffers hold
     PeerPtrs pp;
     for (int i = 0; i < W; ++i) pp.p[i] = const_cast<void *>(my_rows);
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
@@ -683,19 +702,21 @@ extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_co
     if (blocks < 1) blocks = 1;
     pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, s>>>(pp, layout_range, nullptr, max_tokens, W, L * W,
                                                                          payload, (uint8_t *)packed_recv_x,
-                                                                         packed_recv_x_scales, src_info, L * W * max_tokens);
+                                                                         packed_recv_x_scales, src_info, cap,
+                                                                         Parity{EpochRef{nullptr, 0}, 0});
     return launch_status();
 }
 
 extern "C" int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int my_rank,
                                   const void *my_rows, const uint64_t *my_counts, uint32_t epoch, int W, int L, int max_tokens, int H,
                                   int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales,
-                                  int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int32_t *status,
+                                  int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int rows_capacity,
+                                  uint64_t *epoch_ctr, size_t rows_parity_stride, size_t counts_parity_stride, int32_t *status,
                                   int timeout_ms, void *stream)
 {
     if (!peer_counts_host || !num_tokens_per_expert || !my_rows || !my_counts || !packed_recv_x || !packed_recv_count || !src_info ||
         !layout_range || !status || W <= 0 || W > MI_EP_MAX_RANKS || my_rank < 0 || my_rank >= W || L <= 0 || L * W > 2048 || H <= 0 ||
-        H % 16 || max_tokens <= 0 || epoch == 0)
+        H % 16 || max_tokens <= 0 || (epoch == 0 && !epoch_ctr))
         return MI_EP_EINVAL;
     PeerPtrs cp, pp;
     for (int i = 0; i < W; ++i) {
@@ -707,14 +728,17 @@ extern "C" int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32
     const uint64_t ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
     // only ONE workgroup ever spins on the peers (a chip full of spinning workgroups would starve whatever else has to run
     // for the posts to happen when several processes share the GPU); the packing kernel follows on the stream
-    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(cp, num_tokens_per_expert, my_rank, my_counts, epoch, L, W, count_type,
+    const EpochRef er = epoch_ctr ? EpochRef{epoch_ctr, 1} : EpochRef{nullptr, epoch};
+    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(cp, num_tokens_per_expert, my_rank, my_counts, er,
+                                                            epoch_ctr ? counts_parity_stride : 0, epoch_ctr, L, W, count_type,
                                                             layout_range, packed_recv_count, status, ticks);
+    const int cap = rows_capacity > 0 ? rows_capacity : L * W * max_tokens;      // rows the caller's output buffers hold
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
     long long blocks = ((long long)L * W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, s>>>(pp, layout_range, nullptr, max_tokens, W, L * W, payload,
-                                                                         (uint8_t *)packed_recv_x, packed_recv_x_scales, src_info,
-                                                                         L * W * max_tokens);
+                                                                         (uint8_t *)packed_recv_x, packed_recv_x_scales, src_info, cap,
+                                                                         make_parity(epoch_ctr, 0, rows_parity_stride));
     return launch_status();
 }

@@ -13,6 +13,25 @@ struct PeerPtrs {          // W <= MI_EP_MAX_RANKS base pointers, passed by valu
     void *p[MI_EP_MAX_RANKS];
 };
 
+// Device-resident call counter of a kernel family (normal dispatch, combine, low-latency dispatch).  The reference keeps its
+// ping-pong / magic word in the window (cam_moe_dispatch_normal.h:273-286, notify_dispatch.h:924-938) so that a captured
+// graph replays; here `ctr` points at a word of the rank's own control area holding the number of COMPLETED calls of the
+// family.  Kernels launched before the call's single-workgroup exchange kernel use add = 1, that kernel stores the new value
+// when it is done, kernels after it use add = 0 -- so nothing the host computes at launch (or capture) time depends on how
+// many calls ran before.  ctr == nullptr: `add` is the epoch itself (explicit-epoch entry points, in-process test harness).
+struct EpochRef {
+    const uint64_t *ctr;
+    uint64_t add;
+};
+__device__ __forceinline__ uint64_t epoch_of(const EpochRef &e) { return (e.ctr ? *e.ctr : 0ull) + e.add; }
+// byte offset of this call's ping-pong half inside an allocation holding both halves `stride` bytes apart
+struct Parity {
+    EpochRef ep;
+    size_t stride;
+};
+__device__ __forceinline__ size_t parity_off(const Parity &p) { return p.stride ? (size_t)(epoch_of(p.ep) & 1ull) * p.stride : 0; }
+inline Parity make_parity(const uint64_t *ctr, uint64_t add, size_t stride) { return Parity{EpochRef{ctr, ctr ? add : 0ull}, ctr ? stride : 0}; }
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 

@@ -44,6 +44,8 @@ struct GemmArgs {
     PeerPtrs dsts;
     size_t slot_stride;
     int topk, W;
+    Parity par;               // ping-pong half of the combine window (device-resident epoch, see ep_common.h)
+    int slot_rows;            // rows one combine region holds: (t, k) outside it are dropped
 };
 
 // byte offset of 16-B chunk `chunk` (0..3) of row `row` inside a [rows][64 B] tile
@@ -248,8 +250,9 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
             if (MODE == 2) {
                 // the 8 lanes of a row read the same triple (one 12-byte broadcast per row, L1-resident)
                 const int src = p.src_idx[grow * 3 + 0], t = p.src_idx[grow * 3 + 1], k = p.src_idx[grow * 3 + 2];
-                if (src < 0 || src >= p.W) continue;        // corrupted handle: drop instead of a wild store
-                orow = (uint16_t *)((uint8_t *)p.dsts.p[src] + ((size_t)t * p.topk + k) * p.slot_stride) + col;
+                // corrupted handle: drop instead of a wild (cross-GPU) store
+                if (src < 0 || src >= p.W || k < 0 || k >= p.topk || t < 0 || (long long)t * p.topk + k >= p.slot_rows) continue;
+                orow = (uint16_t *)((uint8_t *)p.dsts.p[src] + parity_off(p.par) + ((size_t)t * p.topk + k) * p.slot_stride) + col;
             } else {
                 orow = (uint16_t *)p.out + grow * (size_t)p.N + col;
             }
@@ -321,6 +324,8 @@ struct PushArgs {
     PeerPtrs dsts;
     size_t slot_stride;
     int topk, W;
+    Parity par;
+    int slot_rows;
 };
 
 static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *cum,
@@ -336,6 +341,7 @@ static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const in
     const bool small = rows_per_expert_hint > 0 && rows_per_expert_hint <= 96;      // decode-size groups
     if (push) {
         p.src_idx = push->src_idx, p.dsts = push->dsts, p.slot_stride = push->slot_stride, p.topk = push->topk, p.W = push->W;
+        p.par = push->par, p.slot_rows = push->slot_rows;
         mode = 2;
     }
     if (mode == 0) { if (small) gemm_launch_one<0, 1>(p, stream); else gemm_launch_one<0, 4>(p, stream); }
@@ -371,12 +377,16 @@ extern "C" int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8
 extern "C" int mi_ep_moe_gemm2_push(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale,
                                     const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap, int inter,
                                     int hidden, const int32_t *src_idx, int topk, void *const *dst_base_host, int num_ranks,
+                                    size_t slot_region_bytes, const uint64_t *epoch_ctr, size_t parity_stride,
                                     int rows_per_expert_hint, void *stream)
 {
     if (!src_idx || !dst_base_host || topk <= 0 || topk > MI_EP_MAX_TOPK || num_ranks <= 0 || num_ranks > MI_EP_MAX_RANKS)
         return MI_EP_EINVAL;
     PushArgs push{};
     push.src_idx = src_idx, push.slot_stride = mi_ep_combine_row_bytes(hidden), push.topk = topk, push.W = num_ranks;
+    push.par = make_parity(epoch_ctr, 1, parity_stride);
+    push.slot_rows = slot_region_bytes ? (int)(slot_region_bytes / push.slot_stride < 0x7FFFFFFF ? slot_region_bytes / push.slot_stride : 0x7FFFFFFF)
+                                       : 0x7FFFFFFF;
     for (int i = 0; i < num_ranks; ++i) {
         if (!dst_base_host[i]) return MI_EP_EINVAL;
         push.dsts.p[i] = dst_base_host[i];

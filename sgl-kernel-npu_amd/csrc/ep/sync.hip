@@ -46,20 +46,24 @@ __global__ void notify_post_kernel(PeerPtrs peers, int W, int my_rank, int E, co
 }
 
 // signal + wait in one launch (combine: rows pushed -> tell every owner, then wait for every expert rank)
-__global__ void signal_wait_kernel(PeerPtrs peers, const uint64_t *__restrict__ flags, int W, int my_rank, uint64_t epoch,
-                                   int32_t *status, uint64_t timeout_ticks)
+__global__ void signal_wait_kernel(PeerPtrs peers, const uint64_t *__restrict__ flags, int W, int my_rank, EpochRef er,
+                                   uint64_t *epoch_bump, int32_t *status, uint64_t timeout_ticks)
 {
     const int s = threadIdx.x;
-    if (s >= W) return;
-    sys_store_u64((uint64_t *)peers.p[s] + my_rank, epoch);
-    const uint64_t t0 = ticks_100mhz();
-    while (sys_load_u64(flags + s) < epoch) {
-        __builtin_amdgcn_s_sleep(8);
-        if (ticks_100mhz() - t0 > timeout_ticks) {
-            report_status(status, 1 + s);
-            return;
+    const uint64_t epoch = epoch_of(er);
+    if (s < W) {
+        sys_store_u64((uint64_t *)peers.p[s] + my_rank, epoch);
+        const uint64_t t0 = ticks_100mhz();
+        while (sys_load_u64(flags + s) < epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                report_status(status, 1 + s);
+                break;
+            }
         }
     }
+    // one wave: every lane has read the counter before lane 0 moves it (wave-level program order)
+    if (epoch_bump && s == 0) *epoch_bump = epoch;
 }
 
 __global__ void notify_wait_kernel(const uint64_t *__restrict__ notify, int n, uint32_t epoch,
@@ -217,7 +221,8 @@ struct NotifyPost {
 // notify_wait + wait + notify_tables in one launch: the workgroup first collects the W*(E+1) count granules and the W
 // "rows staged" flags of this call (bounded spins), then derives the tables from the counts it just wrote.
 __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost post,
-    const uint64_t *__restrict__ notify, uint32_t notify_epoch, const uint64_t *__restrict__ flags, uint64_t flag_epoch,
+    const uint64_t *__restrict__ notify_base, uint32_t notify_epoch_in, const uint64_t *__restrict__ flags, uint64_t flag_epoch_in,
+    const uint64_t *epoch_ctr, uint64_t *epoch_bump, size_t notify_parity_stride,
     int32_t *__restrict__ cnt, int W, int E, int me, int relative_pull, int32_t *__restrict__ recv_count,
     int32_t *__restrict__ recv_offset, int32_t *__restrict__ recv_tokens_per_expert, int32_t *__restrict__ expert_global_offset,
     int32_t *__restrict__ srcrank_in_expert_offset, int32_t *__restrict__ r_in_srcrank_offset,
@@ -226,13 +231,19 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
 {
     extern __shared__ __attribute__((aligned(16))) int32_t sm[];
     const int n = W * (E + 1);
+    // device-resident epoch (graph-replayable calls): this call = counter + 1, and the notify granules ping-pong by its parity
+    const uint64_t ep64 = epoch_ctr ? *epoch_ctr + 1 : 0;
+    const uint32_t notify_epoch = epoch_ctr ? (uint32_t)ep64 : notify_epoch_in;
+    const uint64_t flag_epoch = epoch_ctr ? ep64 : flag_epoch_in;
+    const size_t npoff = epoch_ctr ? (size_t)(ep64 & 1ull) * notify_parity_stride : 0;
+    const uint64_t *notify = (const uint64_t *)((const uint8_t *)notify_base + npoff);
     if (post.sig_epoch) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int d = i / (E + 1), e = i - d * (E + 1);
             const uint32_t v = (e < E) ? (uint32_t)post.cnt[e] : (uint32_t)post.num_tokens;
-            sys_store_u64_relaxed((uint64_t *)post.notify.p[d] + (size_t)me * (E + 1) + e, ((uint64_t)notify_epoch << 32) | v);
+            sys_store_u64_relaxed((uint64_t *)((uint8_t *)post.notify.p[d] + npoff) + (size_t)me * (E + 1) + e, ((uint64_t)notify_epoch << 32) | v);
         }
-        if (threadIdx.x < W) sys_store_u64((uint64_t *)post.flags.p[threadIdx.x] + me, post.sig_epoch);
+        if (threadIdx.x < W) sys_store_u64((uint64_t *)post.flags.p[threadIdx.x] + me, flag_epoch);
     }
     const uint64_t t0 = ticks_100mhz();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -261,6 +272,8 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
     }
     __threadfence();
     __syncthreads();
+    // every thread has read the counter (before the barrier above); later kernels of this call read it with add = 0
+    if (epoch_bump && threadIdx.x == 0) *epoch_bump = ep64;
     notify_tables_body(cnt, W, E, me, relative_pull, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset,
                        srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs, pull_offset, summary_host, sm);
 }
@@ -324,12 +337,13 @@ extern "C" int mi_ep_notify_post_signal(uint64_t *const *peer_notify_host, uint6
 }
 
 extern "C" int mi_ep_signal_wait(uint64_t *const *peer_flags_host, const uint64_t *my_flags, int W, int my_rank, uint64_t epoch,
-                                 int32_t *status, int timeout_ms, void *stream)
+                                 uint64_t *epoch_ctr, int32_t *status, int timeout_ms, void *stream)
 {
     PeerPtrs pp;
     if (fill_peers(pp, (const void *const *)peer_flags_host, W) || !my_flags || !status || my_rank < 0 || my_rank >= W)
         return MI_EP_EINVAL;
-    signal_wait_kernel<<<1, kWave, 0, (hipStream_t)stream>>>(pp, my_flags, W, my_rank, epoch, status, ms_to_ticks(timeout_ms));
+    const EpochRef er = epoch_ctr ? EpochRef{epoch_ctr, 1} : EpochRef{nullptr, epoch};
+    signal_wait_kernel<<<1, kWave, 0, (hipStream_t)stream>>>(pp, my_flags, W, my_rank, er, epoch_ctr, status, ms_to_ticks(timeout_ms));
     return launch_status();
 }
 
@@ -376,7 +390,7 @@ extern "C" int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t noti
     const size_t lds = (size_t)(2 * L * W + W + L + 2) * sizeof(int32_t);
     NotifyPost none{};
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
-        none, my_notify, notify_epoch, my_flags, flag_epoch, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
+        none, my_notify, notify_epoch, my_flags, flag_epoch, nullptr, nullptr, 0, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
         recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,
         pull_offset, summary_host, status, ms_to_ticks(timeout_ms), wait_cost_stats);
     return launch_status();
@@ -389,10 +403,10 @@ extern "C" int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, u
                                             int32_t *recv_offset, int32_t *recv_tokens_per_expert, int32_t *expert_global_offset,
                                             int32_t *srcrank_in_expert_offset, int32_t *r_in_srcrank_offset,
                                             int32_t *total_recv_token, int32_t *max_bs, int32_t *pull_offset,
-                                            int32_t *summary_host, int32_t *status, int timeout_ms, int32_t *wait_cost_stats,
-                                            void *stream)
+                                            int32_t *summary_host, uint64_t *epoch_ctr, size_t notify_parity_stride, int32_t *status,
+                                            int timeout_ms, int32_t *wait_cost_stats, void *stream)
 {
-    if (!my_notify || !my_flags || !cnt_matrix || !status || !num_tokens_per_expert || notify_epoch == 0 || flag_epoch == 0 ||
+    if (!my_notify || !my_flags || !cnt_matrix || !status || !num_tokens_per_expert || ((notify_epoch == 0 || flag_epoch == 0) && !epoch_ctr) ||
         W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048 || my_rank < 0 || my_rank >= W)
         return MI_EP_EINVAL;
     NotifyPost post{};
@@ -400,11 +414,11 @@ extern "C" int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, u
         return MI_EP_EINVAL;
     post.cnt = num_tokens_per_expert;
     post.num_tokens = num_tokens;
-    post.sig_epoch = flag_epoch;
+    post.sig_epoch = epoch_ctr ? 1 : flag_epoch;      // non-zero = post; the value comes from the counter when it is device-resident
     const int L = E / W;
     const size_t lds = (size_t)(2 * L * W + W + L + 2) * sizeof(int32_t);
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
-        post, my_notify, notify_epoch, my_flags, flag_epoch, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
+        post, my_notify, notify_epoch, my_flags, flag_epoch, epoch_ctr, epoch_ctr, notify_parity_stride, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
         recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,
         pull_offset, summary_host, status, ms_to_ticks(timeout_ms), wait_cost_stats);
     return launch_status();

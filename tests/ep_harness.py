@@ -33,19 +33,19 @@ def _lib():
     lib.mi_ep_dispatch_pull.argtypes = [V, V, V, I, I, I, I, I, V, V, V, V]
     lib.mi_ep_dispatch_index_offset.restype = c_size_t
     lib.mi_ep_dispatch_index_offset.argtypes = [I, I, I, c_size_t]
-    lib.mi_ep_dispatch_stage_compact.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, c_size_t, V]
-    lib.mi_ep_dispatch_pull_indexed.argtypes = [V, V, V, I, I, I, I, I, I, c_size_t, V, V, V, V]
+    lib.mi_ep_dispatch_stage_compact.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, c_size_t, V, c_size_t, V]
+    lib.mi_ep_dispatch_pull_indexed.argtypes = [V, V, V, I, I, I, I, I, I, c_size_t, V, V, V, V, c_size_t, V]
     lib.mi_ep_dispatch_push_slab_bytes.restype = c_size_t
     lib.mi_ep_dispatch_push_slab_bytes.argtypes = [c_size_t, I]
-    lib.mi_ep_dispatch_stage_push.argtypes = [V, V, I, V, V, I, I, I, I, I, I, I, V, c_size_t, V]
+    lib.mi_ep_dispatch_stage_push.argtypes = [V, V, I, V, V, I, I, I, I, I, I, I, V, c_size_t, V, c_size_t, V]
     lib.mi_ep_dispatch_stage_push.restype = c_int
-    lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, V]
-    lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, V, V, I, I, I, I, V, V]
+    lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, c_size_t, V, c_size_t, V]
+    lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, V, V, I, I, I, I, V, V, c_size_t, V]
     lib.mi_ep_combine_pack.argtypes = [V, V, I, I, I, I, V, V, V]
     lib.mi_ep_combine_pack.restype = c_int
-    lib.mi_ep_ll_dispatch_send.argtypes = [V, V, I, V, I, I, I, I, I, I, I, I, V, V]
+    lib.mi_ep_ll_dispatch_send.argtypes = [V, V, I, V, I, I, I, I, I, I, I, I, V, V, c_size_t, V]
     lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
-    lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, V, I, V]
+    lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, I, V, I, V]
     for n in ("mi_ep_dispatch_layout mi_ep_signal mi_ep_wait mi_ep_notify_post mi_ep_notify_wait mi_ep_notify_tables "
               "mi_ep_dispatch_stage mi_ep_dispatch_pull mi_ep_dispatch_stage_compact mi_ep_dispatch_pull_indexed mi_ep_combine_push mi_ep_combine_reduce mi_ep_ll_dispatch_send "
               "mi_ep_ll_post_counts mi_ep_ll_dispatch_recv").split():
@@ -128,11 +128,11 @@ class InProcEP:
                 ck(L_.mi_ep_dispatch_stage_push(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
                                                 ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K, H, E,
                                                 W, r, quant_mode, ptr_array([t.data_ptr() for t in self.send_win]),
-                                                self.send_win[r].numel(), st))
+                                                self.send_win[r].numel(), None, 0, st))
             elif self.compact:
                 ck(L_.mi_ep_dispatch_stage_compact(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
                                                    ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K,
-                                                   H, E, r, quant_mode, ptr(self.send_win[r]), self.send_win[r].numel(), st))
+                                                   H, E, r, quant_mode, ptr(self.send_win[r]), self.send_win[r].numel(), None, 0, st))
             else:
                 ck(L_.mi_ep_dispatch_stage(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
                                            ptr(lay[r]["send_token_idx_small"]), ptr(lay[r]["send_data_offset"]), T, K, H, E,
@@ -168,10 +168,10 @@ class InProcEP:
                 slab = L_.mi_ep_dispatch_push_slab_bytes(self.send_win[r].numel(), W)
                 own = ptr_array([self.send_win[r].data_ptr() + s_ * slab for s_ in range(W)])
                 ck(L_.mi_ep_dispatch_pull_indexed(own, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
-                                                  R, slab, ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
+                                                  R, slab, ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, st))
             elif self.compact:
                 ck(L_.mi_ep_dispatch_pull_indexed(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
-                                                  R, self.send_win[r].numel(), ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
+                                                  R, self.send_win[r].numel(), ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, st))
             else:
                 ck(L_.mi_ep_dispatch_pull(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, quant_mode, R,
                                           ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
@@ -192,7 +192,8 @@ class InProcEP:
         dst_ptrs = ptr_array([t.data_ptr() for t in self.comb_win])
         flag_ptrs = ptr_array([t.data_ptr() + 64 * 8 for t in self.flags])
         for r in range(W):
-            ck(L_.mi_ep_combine_push(ptr(ys[r]), ptr(src_idxs[r]), None, int(totals[r]), H, K, dst_ptrs, W, st))
+            ck(L_.mi_ep_combine_push(ptr(ys[r]), ptr(src_idxs[r]), None, int(totals[r]), H, K, dst_ptrs, W, self.comb_win[r].numel(),
+                                     None, 0, st))
             ck(L_.mi_ep_signal(flag_ptrs, W, r, ep, st))
         outs = []
         for r in range(W):
@@ -200,7 +201,7 @@ class InProcEP:
             ck(L_.mi_ep_wait(c_void_p(self.flags[r].data_ptr() + 64 * 8), W, ep, ptr(self.status[r]), 2000, st))
             out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
             ck(L_.mi_ep_combine_reduce(ptr(self.comb_win[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
-                                       ptr(topk_weights[r]), None, None, T, K, H, E, ptr(out), st))
+                                       ptr(topk_weights[r]), None, None, T, K, H, E, ptr(out), None, 0, st))
             outs.append(out)
         torch.cuda.synchronize()
         return outs
@@ -219,7 +220,7 @@ class InProcEP:
             T = xs[r].shape[0]
             lay.append(layout(topk_idxs[r], E, W))
             ck(L_.mi_ep_ll_dispatch_send(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
-                                         ptr(lay[r]["send_token_idx_small"]), T, K, H, E, W, r, MT, quant_mode, row_ptrs, st))
+                                         ptr(lay[r]["send_token_idx_small"]), T, K, H, E, W, r, MT, quant_mode, row_ptrs, None, 0, st))
             ck(L_.mi_ep_ll_post_counts(cnt_ptrs, ptr(lay[r]["num_tokens_per_expert"]), E, W, r, ep, st))
         outs = []
         M = W * MT * min(K, L)
@@ -235,7 +236,7 @@ class InProcEP:
             src_info = torch.zeros(max(xs[r].shape[0] * K, M * 128), **i32)
             rng = torch.zeros(L * W, **i32)
             ck(L_.mi_ep_ll_dispatch_recv(ptr(self.ll_win[r]), ptr(self.ll_counts[r]), ep, W, L, MT, H, quant_mode,
-                                         count_type, ptr(px), ptr(ps), ptr(prc), ptr(src_info), ptr(rng),
+                                         count_type, ptr(px), ptr(ps), ptr(prc), ptr(src_info), ptr(rng), M,
                                          ptr(self.status[r]), 2000, st))
             outs.append(dict(packed_recv_x=px, packed_recv_x_scales=ps, packed_recv_count=prc, src_info=src_info,
                              layout_range=rng))
@@ -331,7 +332,7 @@ class InProcA2A:
             out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
             lay = disp[me]["layout"]
             ck(L_.mi_ep_combine_reduce(ptr(ret), ptr(topk_idxs[me]), int(topk_idxs[me].dtype == torch.int32), ptr(topk_weights[me]),
-                                       ptr(lay["send_data_offset"]), ptr(lay["send_token_idx_small"]), T, K, H, E, ptr(out), st))
+                                       ptr(lay["send_data_offset"]), ptr(lay["send_token_idx_small"]), T, K, H, E, ptr(out), None, 0, st))
             outs.append(out)
         torch.cuda.synchronize()
         return outs

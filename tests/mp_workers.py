@@ -448,3 +448,133 @@ def _gpu_long_seq(rank, world, port, cfg):
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU / gloo: the comm-shaped CPU baseline (oracle/cpu_alltoall.py) against the oracle
+# ----------------------------------------------------------------------------------------------
+def cpu_baseline_worker(rank, world, port, cfg):
+    run_guarded(_cpu_baseline, rank, world, port, cfg)
+
+
+def _cpu_baseline(rank, world, port, cfg):
+    from oracle import cpu_alltoall as CA
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits, bf16_bits_to_f32
+    W, T, H, K, E, drop, quant = cfg
+    group = _init(rank, world, port)
+    xs, idxs, ws = make_inputs(W, T, H, K, E, drop, seed=77)
+    x, ti, tw = bits_to_torch(xs[rank]), torch.from_numpy(idxs[rank]), torch.from_numpy(ws[rank])
+    out, recv, scale, lay = CA.one_pass(x, ti, tw, E, group, quant)
+    want = O.normal_dispatch(xs, idxs, E, quant)
+    n = want[rank].total_recv
+    assert recv.shape[0] == n and lay["per_expert"].tolist() == want[rank].num_recv_tokens_per_expert_list
+    if quant:      # same receive order (local expert, source rank, row-major (t, k)) and the same INT8 bits as the oracle
+        assert np.array_equal(recv.numpy(), want[rank].recv_x[:n])
+        assert np.array_equal(scale.numpy().view(np.uint32), want[rank].recv_x_scales[:n].view(np.uint32))
+    else:
+        assert np.array_equal(torch_to_bits(recv), want[rank].recv_x[:n])
+    ys = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) if quant else w.recv_x for w in want]
+    comb = O.combine(ys, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)[rank]
+    a, b = bf16_bits_to_f32(torch_to_bits(out)), bf16_bits_to_f32(comb)
+    # the baseline accumulates in expert order, the reference kernel in k order: same terms, different fp32 rounding
+    assert O.calc_diff(a, b) < 1e-6
+    assert np.abs(a - b).max() <= 2.0 ** -6 * max(np.abs(b).max(), 1e-6)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: low-latency dispatch / combine / fused_deep_moe captured ONCE in a HIP graph and replayed with fresh inputs
+# (the call epoch and ping-pong half live on the device: reference cam_moe_dispatch_normal.h:273-286)
+# ----------------------------------------------------------------------------------------------
+def gpu_graph_worker(rank, world, port, cfg):
+    run_guarded(_gpu_graph, rank, world, port, cfg)
+
+
+def _gpu_graph(rank, world, port, cfg):
+    import faulthandler
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits, bf16_bits_to_f32
+    faulthandler.dump_traceback_later(200, exit=True)
+    torch.cuda.set_device(0)
+    W, T, H, I, K, E, replays = cfg
+    L = E // W
+    group = _init(rank, world, port)
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(512 << 20))
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "20000")
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    rng = np.random.default_rng(11)
+    w13 = [rng.integers(-16, 16, (L, 2 * I, H)).astype(np.int8) for _ in range(W)]
+    w2 = [rng.integers(-16, 16, (L, H, I)).astype(np.int8) for _ in range(W)]
+    s13 = [(rng.random((L, 2 * I)) * 4e-4 + 1.5e-3).astype(np.float32) for _ in range(W)]
+    s2 = [(rng.random((L, H)) * 4e-4 + 1.5e-3).astype(np.float32) for _ in range(W)]
+    perm = O.permute_fusion_cols(2 * I)
+    w13_d = torch.from_numpy(np.ascontiguousarray(w13[rank][:, perm, :])).cuda()
+    s13_d = torch.from_numpy(np.ascontiguousarray(s13[rank][:, perm])).cuda()
+    w2_d, s2_d = torch.from_numpy(w2[rank]).cuda(), torch.from_numpy(s2[rank]).cuda()
+
+    def inputs(seed):
+        xs, idxs, _ = make_inputs(W, T, H, K, E, 0.1, seed=seed)
+        xs, idxs = [x[:T] for x in xs], [i[:T] for i in idxs]
+        ws = [np.abs(np.random.default_rng(seed + r).standard_normal((T, K))).astype(np.float32) for r in range(W)]
+        return xs, idxs, ws
+
+    x_s = torch.zeros((T, H), dtype=torch.bfloat16, device="cuda")
+    ti_s = torch.zeros((T, K), dtype=torch.int64, device="cuda")
+    tw_s = torch.zeros((T, K), dtype=torch.float32, device="cuda")
+
+    def load(seed):
+        xs, idxs, ws = inputs(seed)
+        x_s.copy_(bits_to_torch(xs[rank]).cuda())
+        ti_s.copy_(torch.from_numpy(idxs[rank]).cuda())
+        tw_s.copy_(torch.from_numpy(ws[rank]).cuda())
+        return xs, idxs, ws
+
+    def step():
+        (rx, rs), cnt, handle, _, _ = buf.low_latency_dispatch(x_s, ti_s, T, E, use_fp8=True)
+        y = (rx.float() * rs[:, None]).to(torch.bfloat16)
+        out, _, _ = buf.low_latency_combine(y, ti_s, tw_s, handle)
+        fused, rc = buf.fused_deep_moe(x_s, ti_s, tw_s, w13_d, s13_d, w2_d, s2_d, T, E)
+        return rx, rs, cnt, handle, out, fused, rc
+
+    # warm-up on a side stream (allocator pools, one-off function attributes), an ODD number of calls so that the captured
+    # graph is first replayed on the other ping-pong half than the one it would have been captured "for" by a host-side counter
+    load(1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rx, rs, cnt, handle, out, fused, rc = step()
+    for rep in range(replays):
+        xs, idxs, ws = load(100 + rep)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g.replay()
+        torch.cuda.synchronize()
+        llw = O.low_latency_dispatch(xs, idxs, T, E, True)
+        nn = llw[rank].total
+        assert np.array_equal(cnt.cpu().numpy(), llw[rank].packed_recv_count), rep
+        assert np.array_equal(handle[1].cpu().numpy(), llw[rank].layout_range), rep
+        assert np.array_equal(handle[0].cpu().numpy()[:3 * nn], llw[rank].src_info), rep
+        assert np.array_equal(rx.cpu().numpy()[:nn], llw[rank].packed_recv_x[:nn]), rep
+        assert np.array_equal(rs.cpu().numpy()[:nn].view(np.uint32), llw[rank].packed_recv_x_scales[:nn].view(np.uint32)), rep
+        yls = [O.per_token_cast_back(w.packed_recv_x, w.packed_recv_x_scales) for w in llw]
+        want = O.combine(yls, [w.src_info for w in llw], [w.total for w in llw], idxs, ws, E)
+        assert np.array_equal(torch_to_bits(out), want[rank]), f"replay {rep}: LL combine mismatch"
+        fw = O.fused_deep_moe(xs, idxs, ws, w13, s13, w2, s2, T, E)[rank]
+        got, ref = bf16_bits_to_f32(torch_to_bits(fused)), bf16_bits_to_f32(fw)
+        assert np.array_equal(rc.cpu().numpy(), llw[rank].layout_range), rep
+        assert O.calc_diff(got, ref) < 1e-5, (rep, O.calc_diff(got, ref))
+        assert np.mean(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-2)) < 4e-4, rep
+    faulthandler.cancel_dump_traceback_later()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()

@@ -46,6 +46,17 @@ def test_fused_deep_moe(cfg):
     _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)
 
 
+@pytest.mark.parametrize("cfg", [
+    # W, T, H, I, K, E, replays
+    (2, 24, 512, 128, 4, 8, 3),
+    (1, 16, 1024, 128, 8, 16, 3),
+])
+def test_low_latency_calls_replay_in_a_captured_graph(cfg):
+    """low_latency_dispatch + low_latency_combine + fused_deep_moe captured once in torch.cuda.graph, replayed with fresh inputs,
+    bit-exact (fused: reference tolerance) against the oracle every time: the call epoch / ping-pong half are device-resident."""
+    _spawn(mp_workers.gpu_graph_worker, cfg[0], cfg)
+
+
 def test_missing_peer_raises_instead_of_hanging():
     _spawn(mp_workers.gpu_timeout_worker, 2, None)
 

@@ -73,3 +73,13 @@ def test_strategy_registry_and_errors():
             long_seq_rounds()
     for k in ("DEEPEP_NORMAL_LONG_SEQ_ROUND", "DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS"):
         os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 40, 128, 4, 8, 0.2, True),
+    (4, 24, 64, 2, 8, 0.0, False),
+    (1, 16, 64, 2, 4, 0.1, True),
+])
+def test_cpu_alltoall_baseline_matches_oracle(cfg):
+    """bench.py's comm-shaped CPU baseline (W gloo ranks, reference alltoall strategy restated with torch ops)."""
+    _spawn(mp_workers.cpu_baseline_worker, cfg[0], cfg)

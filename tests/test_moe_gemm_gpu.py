@@ -34,7 +34,7 @@ def lib():
         L.mi_ep_moe_gemm1_swiglu.argtypes = [V, V, V, V, V, I, I, I, I, I, V, I, V]
         L.mi_ep_moe_rowquant.argtypes = [V, V, I, I, V, V, V]
         L.mi_ep_moe_gemm2.argtypes = [V, V, V, V, V, I, I, I, I, I, V, I, V]
-        L.mi_ep_moe_gemm2_push.argtypes = [V, V, V, V, V, I, I, I, I, I, V, I, V, I, I, V]
+        L.mi_ep_moe_gemm2_push.argtypes = [V, V, V, V, V, I, I, I, I, I, V, I, V, I, ctypes.c_size_t, V, ctypes.c_size_t, I, V]
         L.mi_ep_combine_row_bytes.restype = ctypes.c_size_t
         L.mi_ep_combine_row_bytes.argtypes = [I]
         for n in ("mi_ep_moe_gemm1_swiglu", "mi_ep_moe_rowquant", "mi_ep_moe_gemm2", "mi_ep_moe_gemm2_push"):
@@ -243,7 +243,7 @@ def test_moe_gemm2_push_lands_in_combine_slots(hint):
     cb = lib().mi_ep_combine_row_bytes(H)
     wins = [torch.zeros(T * K * cb, dtype=torch.uint8, device=dev) for _ in range(W)]
     ck(lib().mi_ep_moe_gemm2_push(ptr(q), ptr(sc), ptr(w2), ptr(s2), ptr(cum), 1, L, rows_cap, I, H, ptr(src_idx), K,
-                                  ptr_array([w.data_ptr() for w in wins]), W, hint, stream_ptr()))
+                                  ptr_array([w.data_ptr() for w in wins]), W, wins[0].numel(), None, 0, hint, stream_ptr()))
     dense = run_gemm2(q, sc, w2, s2, cum, 1, L, rows_cap, I, H, hint)
     torch.cuda.synchronize()
     want = [torch.zeros((T * K, cb // 2), dtype=torch.int16, device=dev) for _ in range(W)]
