@@ -254,9 +254,10 @@ def cpu_baseline(sample_tokens):
     return out
 
 
-def mla_cpu_baseline(n_seq=2):
-    """The CPU golden of the reference test (decode_mla_golden, tests/python/sgl_kernel_npu/test_decode_attention.py:131-187) as
-    restated in oracle/kernels.py, torch CPU with all cores, on `n_seq` sequences of the C4 shape."""
+def mla_cpu_baseline(n_seq=8):
+    """The CPU restatement of the reference kernel (oracle/kernels.py decode_mla: per-page online softmax, the arithmetic the
+    parity tests check against) on `n_seq` sequences of the C4 shape, torch CPU.  The per-page operands are small (128 x 576 by
+    576 x 64), so more than ~16 threads only add synchronisation cost: cores = the threads actually used."""
     from oracle import kernels as OK
 
     B, Hq, S, page = n_seq, 128, 4096, 64
@@ -267,7 +268,7 @@ def mla_cpu_baseline(n_seq=2):
     kr = torch.randn((B * maxp, page, 1, 64), generator=g).to(torch.bfloat16)
     bt = torch.randperm(B * maxp, generator=g).to(torch.int32).reshape(B, maxp)
     lens = torch.full((B,), S, dtype=torch.int32)
-    cores = os.cpu_count() or 1
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     OK.decode_mla(q[:1], kn, kr, lens[:1], bt[:1], 576 ** -0.5)
     t0 = time.perf_counter()

@@ -107,22 +107,32 @@ int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin, int tokens
                    int rope_dim, int neox, int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
                    int64_t cs_stride_t, int dtype, void *out_q, void *out_k, void *stream);
 
-/* ---- mla_preprocess glue (everything that is not a plain GEMM; reference csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704,
- * arithmetic per tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483) -------------------------------------------
- * pre_quant:  out int8 = round(clamp(fp16(x / scale + zero_point), -128, 127)), numel % 8 == 0.
- * pre_mid:    gemm1_i32 [tokens, 2112] (+bias0) * descale0 -> I/O dtype -> [512 k_nope | 64 k_pe | 1536 q];
- *             kv_cache[slot, :512] = rms_norm(k_nope) * gamma2, kv_cache_rope[slot, :64] = rope_half(k_pe, cos, sin),
- *             q_int8 [tokens, 1536] = per-tensor quant of rms_norm(q) * gamma1 + beta1.  cos / sin [tokens, 64].
- * pre_qsplit: gemm2_i32 [tokens, q_heads*192] (+bias1) * descale1 -> per head [128 | 64]: q_nope [tokens, q_heads, 128],
- *             q_pe [tokens, q_heads, 64] = rope_half.  bias pointers may be NULL. */
+/* ---- mla_preprocess (reference: one AscendC MIX kernel, csrc/mla_preprocess/op_kernel/mla_preprocess_mix_bf16.hpp:285,2762,2814;
+ * host csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704; arithmetic per the test golden golden2_pytorch,
+ * tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483).  Five launches on one stream, every GEMM hand-written:
+ *   pre_quant -> pre_gemm_i8(mode 0) -> pre_mid -> pre_gemm_i8(mode 1) -> pre_bmm_rope
+ * pre_quant:   out int8 = round(clamp(fp16(x / scale + zero_point), -128, 127)), numel % 8 == 0.
+ * pre_gemm_i8: C[tokens, n] = A[tokens, k] int8 x W[n, k]^T int8 (W row-major: output channel major, K contiguous; k % 64 == 0).
+ *              mode 0: split-K, one workgroup per 512-byte K-chunk: c_i32 [ceil(k/512)][tokens][n] partial products whose sum
+ *                      (exact, order-independent) is the GEMM -- mi_mla_pre_gemm_i8_partials(k) of them;
+ *              mode 1: y[tokens, n] (I/O dtype) = (float(c + bias[n])) * descale[n], one rounding (golden :95-107); bias may be NULL.
+ * pre_mid:     sum of the num_partials slices of gemm1_i32 [num_partials][tokens, 2112] (+bias0) * descale0 -> I/O dtype -> [512 k_nope | 64 k_pe | 1536 q];
+ *              kv_cache[slot, :512] = rms_norm(k_nope) * gamma2, kv_cache_rope[slot, :64] = rope_half(k_pe, cos, sin),
+ *              q_int8 [tokens, 1536] = per-tensor quant of rms_norm(q) * gamma1 + beta1.  cos / sin [tokens, 64].
+ * pre_bmm_rope: y [tokens, q_heads*192] per head [128 nope | 64 pe]: q_out0[t, h, :512] = y_nope[t, h, :] x wuk_t[h]^T with
+ *              wuk_t [q_heads, 512, 128] (the caller's wuk [q_heads, 128, 512] transposed once: K contiguous), fp32 accumulate;
+ *              q_out1[t, h, :64] = rope_half(y_pe[t, h, :], cos, sin). */
 int mi_mla_pre_quant(const void *x, const void *scale /*[1], I/O dtype*/, const int8_t *zero_point /*[1]*/, int64_t numel, int dtype,
                      int8_t *out, void *stream);
-int mi_mla_pre_mid(const int32_t *gemm1_i32, const int32_t *bias0, const float *descale0, const void *gamma1, const void *beta1,
+int mi_mla_pre_gemm_i8_partials(int k);
+int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8_t *w, int n, int mode, int32_t *c_i32, const int32_t *bias,
+                       const float *descale, void *y, int dtype, void *stream);
+int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bias0, const float *descale0, const void *gamma1, const void *beta1,
                    const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping, const void *quant_scale1,
                    const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8, void *kv_cache, void *kv_cache_rope,
                    void *stream);
-int mi_mla_pre_qsplit(const int32_t *gemm2_i32, const int32_t *bias1, const float *descale1, const void *cos, const void *sin,
-                      int tokens, int q_heads, int dtype, void *q_nope, void *q_pe, void *stream);
+int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const void *wuk_t, const void *cos, const void *sin, int dtype,
+                        void *q_out0, void *q_out1, void *stream);
 
 #ifdef __cplusplus
 }

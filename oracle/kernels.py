@@ -273,7 +273,8 @@ def _quant_per_tensor(x, scale, zp):
 
 def _int8_gemm_dequant(a, w, descale, bias, dtype):
     """:95-107 (bf16 branch): exact int32 GEMM + bias, * float descale, to dtype."""
-    y = a.to(torch.int32) @ w.to(torch.int32).t()
+    # exact: |sum| <= K * 128 * 128 < 2^53, so the float64 BLAS product is the integer product (torch's int32 matmul is a scalar loop)
+    y = torch.round(a.double() @ w.double().t()).to(torch.int32)
     if bias is not None and bias.numel():
         y = y + bias
     return (y.to(torch.float32) * descale.float()).to(dtype)

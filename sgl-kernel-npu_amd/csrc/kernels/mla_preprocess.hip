@@ -1,13 +1,12 @@
-// mla_preprocess glue kernels for gfx950: everything of torch.ops.npu.mla_preprocess that is NOT a plain GEMM.
+// mla_preprocess elementwise / normalisation stages for gfx950 (the GEMMs are in mla_gemm.hip).
 // Reference: csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704 + op_kernel/mla_preprocess_mix_bf16.hpp (AscendC MIX kernel);
 // arithmetic pinned by the test golden golden2_pytorch (tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483):
 //   q8  = int8(round(clamp(fp16(h / qscale0 + qoff0))))                                   -> mi_mla_pre_quant
 //   f   = bf16((i32 GEMM1 + bias0) * descale0), split [512 k_nope | 64 k_pe | 1536 q]
 //   k_nope = bf16(rms_norm(k_nope) * gamma2) -> kv_cache[slot];  k_pe = rope_half(k_pe) -> kv_cache_rope[slot]
 //   q8' = int8(round(clamp(fp16((rms_norm(q) * gamma1 + beta1) / qscale1 + qoff1))))        -> mi_mla_pre_mid
-//   qo  = bf16((i32 GEMM2 + bias1) * descale1) per head [128 nope | 64 pe]; q_pe = rope_half -> q_out1 -> mi_mla_pre_qsplit
-// The three GEMMs (INT8 x2 through hipBLASLt, the per-head bf16 BMM with wuk) are plain library GEMMs issued by the host op
-// (csrc/pytorch_extensions.cpp); at decode sizes the op is weight-bandwidth bound (15 MB + 1536*Hq*192 B of INT8 weights).
+//   qo  = bf16((i32 GEMM2 + bias1) * descale1) per head [128 nope | 64 pe]; q_pe = rope_half -> q_out1 -> mla_gemm.hip
+// At decode sizes the op is weight-bandwidth bound (15 MB + 1536*Hq*192 B of INT8 weights + the bf16 wuk).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -30,6 +29,9 @@ __device__ __forceinline__ uint16_t sth(float f)
         if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
         return (uint16_t)((x + 0x7FFFu + ((x >> 16) & 1u)) >> 16);
     } else {
+        // the fp32 value is rounded to fp16 as a SEPARATE step (the golden materialises the fp32 product first): keep the
+        // compiler from folding the producing multiply into a mixed-precision v_fma_mixlo_f16, which rounds only once
+        asm volatile("" : "+v"(f));
         return __builtin_bit_cast(uint16_t, (_Float16)f);
     }
 }
@@ -40,6 +42,7 @@ __device__ __forceinline__ int8_t quant_pt(float x, float scale, float zp)
     v = fminf(fmaxf(v, -128.f), 127.f);
     return (int8_t)(int)rintf(v);
 }
+constexpr int kMidThreads = 1024;      // one workgroup per token: 16 waves keep enough loads in flight to sum the split-K partials
 __device__ __forceinline__ float block_sum(float v, float *red)
 {
 #pragma unroll
@@ -47,7 +50,10 @@ __device__ __forceinline__ float block_sum(float v, float *red)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kMidThreads / 64; ++w) s += red[w];      // same order in every thread
+    return s;
 }
 
 template <bool BF16>
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void pre_quant_kernel(const uint16_t *__restri
 constexpr int kKN = 512, kKR = 64, kQ = 1536, kMid = kKN + kKR + kQ;     // 2112
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void pre_mid_kernel(const int32_t *__restrict__ c1, const int32_t *__restrict__ bias0,
+__global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__restrict__ c1, int nparts, int ntok, const int32_t *__restrict__ bias0,
                                                      const float *__restrict__ descale0, const uint16_t *__restrict__ gamma1,
                                                      const uint16_t *__restrict__ beta1, const uint16_t *__restrict__ gamma2,
                                                      const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
@@ -80,21 +86,32 @@ __global__ __launch_bounds__(256) void pre_mid_kernel(const int32_t *__restrict_
                                                      uint16_t *__restrict__ kv_cache_rope)
 {
     __shared__ float f[kMid];
-    __shared__ float red[4];
+    __shared__ float red[kMidThreads / 64];
     const int n = blockIdx.x, tid = threadIdx.x;
     const float qscale1 = ldh<BF16>(qscale1_p[0]), qoff1 = (float)qoff1_p[0];
     const int32_t *row = c1 + (long long)n * kMid;
-    for (int j = tid; j < kMid; j += 256) {
-        const float y = (float)(row[j] + (bias0 ? bias0[j] : 0)) * descale0[j];
+    const long long part_stride = (long long)ntok * kMid;       // split-K partial products of GEMM1: exact int32 sum
+    for (int j = tid; j < kMid; j += kMidThreads) {
+        int32_t acc = bias0 ? bias0[j] : 0;
+        int p = 0;
+        for (; p + 8 <= nparts; p += 8) {               // eight independent loads in flight per step
+            int32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[(p + u) * part_stride + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; p < nparts; ++p) acc += row[p * part_stride + j];
+        const float y = (float)acc * descale0[j];
         f[j] = ldh<BF16>(sth<BF16>(y));                      // the GEMM output is materialised in the I/O dtype (golden :95-107)
     }
     __syncthreads();
     // k_nope: RMSNorm * gamma2 -> cache
     float ss = 0.f;
-    for (int j = tid; j < kKN; j += 256) ss += f[j] * f[j];
+    for (int j = tid; j < kKN; j += kMidThreads) ss += f[j] * f[j];
     const float rk = rsqrtf(block_sum(ss, red) / (float)kKN + eps);
     const long long slot = slotmapping[n];
-    for (int j = tid; j < kKN; j += 256) kv_cache[slot * kKN + j] = sth<BF16>((f[j] * rk) * ldh<BF16>(gamma2[j]));
+    for (int j = tid; j < kKN; j += kMidThreads) kv_cache[slot * kKN + j] = sth<BF16>((f[j] * rk) * ldh<BF16>(gamma2[j]));
     // k_pe: rotate-half RoPE -> rope cache
     if (tid < kKR) {
         const float x = f[kKN + tid];
@@ -104,37 +121,12 @@ __global__ __launch_bounds__(256) void pre_mid_kernel(const int32_t *__restrict_
     }
     // q: RMSNorm * gamma1 + beta1 -> per-tensor INT8
     ss = 0.f;
-    for (int j = tid; j < kQ; j += 256) ss += f[kKN + kKR + j] * f[kKN + kKR + j];
+    for (int j = tid; j < kQ; j += kMidThreads) ss += f[kKN + kKR + j] * f[kKN + kKR + j];
     const float rq = rsqrtf(block_sum(ss, red) / (float)kQ + eps);
-    for (int j = tid; j < kQ; j += 256) {
+    for (int j = tid; j < kQ; j += kMidThreads) {
         const float y = (f[kKN + kKR + j] * rq) * ldh<BF16>(gamma1[j]) + ldh<BF16>(beta1[j]);
         q8[(long long)n * kQ + j] = quant_pt(y, qscale1, qoff1);
     }
-}
-
-// one wave per (token, head): 192 = 128 nope + 64 pe
-template <bool BF16>
-__global__ __launch_bounds__(256) void pre_qsplit_kernel(const int32_t *__restrict__ c2, const int32_t *__restrict__ bias1,
-                                                        const float *__restrict__ descale1, const uint16_t *__restrict__ cosv,
-                                                        const uint16_t *__restrict__ sinv, int N, int Hq,
-                                                        uint16_t *__restrict__ q_nope, uint16_t *__restrict__ q_pe)
-{
-    const int lane = threadIdx.x & 63;
-    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= (long long)N * Hq) return;
-    const int n = (int)(wid / Hq), h = (int)(wid % Hq);
-    const long long base = (long long)n * Hq * 192 + (long long)h * 192;
-    auto val = [&](int j) -> float {
-        const int col = h * 192 + j;
-        const float y = (float)(c2[base + j] + (bias1 ? bias1[col] : 0)) * descale1[col];
-        return ldh<BF16>(sth<BF16>(y));
-    };
-    q_nope[wid * 128 + lane] = sth<BF16>(val(lane));
-    q_nope[wid * 128 + 64 + lane] = sth<BF16>(val(64 + lane));
-    const float x = val(128 + lane);
-    const float rot = lane < 32 ? -val(128 + lane + 32) : val(128 + lane - 32);
-    const float c = ldh<BF16>(cosv[(long long)n * 64 + lane]), s = ldh<BF16>(sinv[(long long)n * 64 + lane]);
-    q_pe[wid * 64 + lane] = sth<BF16>(x * c + rot * s);
 }
 
 }  // namespace mi_sgl
@@ -148,44 +140,29 @@ extern "C" int mi_mla_pre_quant(const void *x, const void *scale, const int8_t *
     if (numel == 0) return MI_SGL_OK;
     if (!x || !out || !scale || !zero_point) return MI_SGL_EINVAL;
     const int blocks = (int)((numel / 8 + 255) / 256);
-    if (dtype == MI_DTYPE_BF16) pre_quant_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, (const uint16_t *)scale, zero_point, numel, out);
-    else pre_quant_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, (const uint16_t *)scale, zero_point, numel, out);
+    if (dtype == MI_DTYPE_BF16)
+        pre_quant_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, (const uint16_t *)scale, zero_point, numel, out);
+    else
+        pre_quant_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, (const uint16_t *)scale, zero_point, numel, out);
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 
-extern "C" int mi_mla_pre_mid(const int32_t *gemm1_i32, const int32_t *bias0, const float *descale0, const void *gamma1,
+extern "C" int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bias0, const float *descale0, const void *gamma1,
                               const void *beta1, const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping,
                               const void *quant_scale1, const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8,
                               void *kv_cache, void *kv_cache_rope, void *stream)
 {
-    if (tokens < 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || !quant_scale1 || !quant_offset1) return MI_SGL_EINVAL;
+    if (tokens < 0 || num_partials < 1 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || !quant_scale1 || !quant_offset1)
+        return MI_SGL_EINVAL;
     if (tokens == 0) return MI_SGL_OK;
     if (!gemm1_i32 || !descale0 || !gamma1 || !beta1 || !gamma2 || !cos || !sin || !slotmapping || !q_int8 || !kv_cache || !kv_cache_rope)
         return MI_SGL_EINVAL;
 #define MI_MID(B)                                                                                                                  \
-    pre_mid_kernel<B><<<tokens, 256, 0, (hipStream_t)stream>>>(gemm1_i32, bias0, descale0, (const uint16_t *)gamma1,                 \
+    pre_mid_kernel<B><<<tokens, kMidThreads, 0, (hipStream_t)stream>>>(gemm1_i32, num_partials, tokens, bias0, descale0, (const uint16_t *)gamma1,                 \
                                                                (const uint16_t *)beta1, (const uint16_t *)gamma2, (const uint16_t *)cos, \
                                                                (const uint16_t *)sin, slotmapping, (const uint16_t *)quant_scale1, quant_offset1, eps,  \
                                                                q_int8, (uint16_t *)kv_cache, (uint16_t *)kv_cache_rope)
     if (dtype == MI_DTYPE_BF16) MI_MID(true); else MI_MID(false);
 #undef MI_MID
-    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
-}
-
-extern "C" int mi_mla_pre_qsplit(const int32_t *gemm2_i32, const int32_t *bias1, const float *descale1, const void *cos,
-                                 const void *sin, int tokens, int q_heads, int dtype, void *q_nope, void *q_pe, void *stream)
-{
-    if (tokens < 0 || q_heads <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16)) return MI_SGL_EINVAL;
-    if (tokens == 0) return MI_SGL_OK;
-    if (!gemm2_i32 || !descale1 || !cos || !sin || !q_nope || !q_pe) return MI_SGL_EINVAL;
-    const int blocks = (int)(((long long)tokens * q_heads + 3) / 4);
-    if (dtype == MI_DTYPE_BF16)
-        pre_qsplit_kernel<true><<<blocks, 256, 0, (hipStream_t)stream>>>(gemm2_i32, bias1, descale1, (const uint16_t *)cos,
-                                                                        (const uint16_t *)sin, tokens, q_heads, (uint16_t *)q_nope,
-                                                                        (uint16_t *)q_pe);
-    else
-        pre_qsplit_kernel<false><<<blocks, 256, 0, (hipStream_t)stream>>>(gemm2_i32, bias1, descale1, (const uint16_t *)cos,
-                                                                         (const uint16_t *)sin, tokens, q_heads, (uint16_t *)q_nope,
-                                                                         (uint16_t *)q_pe);
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }

@@ -4,6 +4,9 @@
 // (`torch.ops.npu.<op>`) are unchanged; the dispatch key is CUDA (= HIP on ROCm) instead of PrivateUse1.
 // The implementations are thin host functions (namespace sglang::npu_kernel, like include/sgl_kenel_npu_ops.h:14-239)
 // that validate arguments, allocate outputs and call the C-ABI of include/mi_sgl_kernels.h on the current stream.
+#include <map>
+#include <mutex>
+
 #include <ATen/ATen.h>
 #include <c10/util/string_view.h>
 #include <c10/hip/HIPStream.h>
@@ -217,8 +220,29 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
 // [q_heads*192, 1536] are plain row-major (output channel major, K contiguous) instead of the Ascend NZ fractal format;
 // wuk [q_heads, 128, 512]; kv_cache [blocks, block_size, 1, 512] + kv_cache_rope [blocks, block_size, 1, 64]
 // (cache_mode "krope_ctkv").  gamma0 / beta0 are accepted and unused, as in the reference's bf16 kernel (stage 1 is
-// quant-only).  The INT8 GEMMs and the per-head BMM are plain library GEMMs (hipBLASLt via at::_int_mm / at::bmm); the
-// quantisation, dequant + split + RMSNorm + RoPE + cache write stages are the HIP kernels of csrc/kernels/mla_preprocess.hip.
+// quant-only).  Every stage is a HIP kernel of csrc/kernels/mla_gemm.hip (the two INT8 GEMMs and the per-head BMM, hand-written
+// skinny split-K / weight-streaming kernels) or csrc/kernels/mla_preprocess.hip (quant, dequant + split + RMSNorm + RoPE + cache).
+// wuk is consumed K-contiguous: its [q_heads, 512, 128] transpose is made once per weight tensor and kept (the reference casts
+// its weights to the NZ format once as well).
+static at::Tensor prepared_wuk(const at::Tensor &wuk)
+{
+    struct Entry {
+        at::Tensor src, t;      // the source is held: its storage cannot be recycled for another weight while the entry lives
+        int64_t version;
+    };
+    static std::mutex mu;
+    static std::map<const void *, Entry> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(wuk.data_ptr());
+    if (it != cache.end() && it->second.version == (int64_t)wuk._version() && it->second.src.sizes() == wuk.sizes() &&
+        it->second.src.scalar_type() == wuk.scalar_type())
+        return it->second.t;
+    if (cache.size() >= 256) cache.clear();
+    at::Tensor t = wuk.transpose(1, 2).contiguous();
+    cache[wuk.data_ptr()] = Entry{wuk, t, (int64_t)wuk._version()};
+    return t;
+}
+
 std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preprocess(
     const at::Tensor &hiddenState, const at::Tensor &gamma0, const at::Tensor &beta0, const at::Tensor &wdqkv,
     const at::Tensor &descale0, const at::Tensor &gamma1, const at::Tensor &beta1, const at::Tensor &wuq,
@@ -258,29 +282,30 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
                     quant_scale1.scalar_type() == hiddenState.scalar_type() && quant_offset0.numel() == 1 && quant_offset1.numel() == 1 &&
                     quant_offset0.scalar_type() == at::kChar && quant_offset1.scalar_type() == at::kChar,
                 "quant_scale0/1 must be [1] in the input dtype, quant_offset0/1 int8 [1]");
-    // hipBLASLt's INT8 GEMM (at::_int_mm) wants more than 16 rows: pad the token dimension to a multiple of 32
-    const int64_t Np = (N + 31) / 32 * 32;
-    auto i8buf = [&](int64_t cols) {           // pad rows (if any) must be defined: they flow through the GEMM
-        return Np == N ? at::empty({Np, cols}, at::dtype(at::kChar).device(dev)) : at::zeros({Np, cols}, at::dtype(at::kChar).device(dev));
-    };
-    at::Tensor a8 = i8buf(hidden);
-    TORCH_CHECK(0 == mi_mla_pre_quant(hiddenState.data_ptr(), quant_scale0.data_ptr(), (const int8_t *)quant_offset0.data_ptr(), N * hidden, dt, (int8_t *)a8.data_ptr(), st), "mi_mla_pre_quant failed");
-    at::Tensor c1 = at::_int_mm(a8, wdqkv.t());                                   // [Np, 2112] int32
-    at::Tensor q8 = i8buf(1536);
+    // five launches on the caller's stream, no library GEMM (stage order of mla_preprocess_mix_bf16.hpp):
+    //   quant -> INT8 GEMM1 split-K (partial products) -> sum + dequant / RMSNorm / RoPE / cache write / requant
+    //   -> INT8 GEMM2 with the dequant epilogue -> per-head BMM + RoPE of the positional columns
+    auto i8 = at::dtype(at::kChar).device(dev);
+    at::Tensor a8 = at::empty({N, hidden}, i8);
+    const int parts = mi_mla_pre_gemm_i8_partials((int)hidden);                 // split-K partial products, summed by pre_mid
+    at::Tensor c1 = at::empty({parts, N, 2112}, at::dtype(at::kInt).device(dev));
+    TORCH_CHECK(0 == mi_mla_pre_quant(hiddenState.data_ptr(), quant_scale0.data_ptr(), (const int8_t *)quant_offset0.data_ptr(), N * hidden, dt,
+                                      (int8_t *)a8.data_ptr(), st), "mi_mla_pre_quant failed");
+    TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)a8.data_ptr(), (int)N, (int)hidden, (const int8_t *)wdqkv.data_ptr(), 2112, 0,
+                                        c1.data_ptr<int32_t>(), nullptr, nullptr, nullptr, dt, st), "mi_mla_pre_gemm_i8 (GEMM1) failed");
+    at::Tensor q8 = at::empty({N, 1536}, i8);
     auto iptr = [](const at::Tensor &t) -> const int32_t * { return t.numel() ? t.data_ptr<int32_t>() : nullptr; };
-    TORCH_CHECK(0 == mi_mla_pre_mid(c1.data_ptr<int32_t>(), iptr(bias0), descale0.data_ptr<float>(), gamma1.data_ptr(), beta1.data_ptr(),
+    TORCH_CHECK(0 == mi_mla_pre_mid(c1.data_ptr<int32_t>(), parts, iptr(bias0), descale0.data_ptr<float>(), gamma1.data_ptr(), beta1.data_ptr(),
                                     gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(), quant_scale1.data_ptr(),
                                     (const int8_t *)quant_offset1.data_ptr(), 1e-6f,
                                     (int)N, dt, (int8_t *)q8.data_ptr(), kv_cache.data_ptr(), kv_cache_rope.data_ptr(), st),
                 "mi_mla_pre_mid failed");
-    at::Tensor c2 = at::_int_mm(q8, wuq.t());                                     // [Np, q_heads*192] int32
-    at::Tensor q_nope = at::empty({N, Hq, 128}, hiddenState.options());
-    TORCH_CHECK(0 == mi_mla_pre_qsplit(c2.data_ptr<int32_t>(), iptr(bias1), descale1.data_ptr<float>(), cos.data_ptr(), sin.data_ptr(),
-                                       (int)N, (int)Hq, dt, q_nope.data_ptr(), q_out1.data_ptr(), st), "mi_mla_pre_qsplit failed");
-    // per-head [N,128] x [128,512] straight into q_out0 viewed as [q_heads, N, 512] (row stride Hq*512, batch stride 512:
-    // a layout strided-batched GEMM writes natively, so no transpose copy afterwards)
-    at::Tensor o_view = q_out0.view({N, Hq, 512}).transpose(0, 1);
-    at::bmm_out(o_view, q_nope.transpose(0, 1), wuk);
+    at::Tensor y2 = at::empty({N, Hq * 192}, hiddenState.options());              // GEMM2 output materialised in the I/O dtype (golden :95-107)
+    TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)q8.data_ptr(), (int)N, 1536, (const int8_t *)wuq.data_ptr(), (int)(Hq * 192), 1, nullptr,
+                                        iptr(bias1), descale1.data_ptr<float>(), y2.data_ptr(), dt, st), "mi_mla_pre_gemm_i8 (GEMM2) failed");
+    at::Tensor wuk_t = prepared_wuk(wuk.to(hiddenState.scalar_type()));
+    TORCH_CHECK(0 == mi_mla_pre_bmm_rope(y2.data_ptr(), (int)N, (int)Hq, wuk_t.data_ptr(), cos.data_ptr(), sin.data_ptr(), dt, q_out0.data_ptr(),
+                                         q_out1.data_ptr(), st), "mi_mla_pre_bmm_rope failed");
     if (kv_cache_out0.data_ptr() != kv_cache.data_ptr()) kv_cache_out0.copy_(kv_cache);
     if (kv_cache_out1.data_ptr() != kv_cache_rope.data_ptr()) kv_cache_out1.copy_(kv_cache_rope);
     return {q_out0, kv_cache_out0, q_out1, kv_cache_out1};

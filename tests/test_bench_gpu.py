@@ -32,6 +32,11 @@ def test_bench_two_ranks_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["strategy"] == "default" and d["validated_round_trip"] is True
     assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+    # N > 1: both dispatch transports timed with the same K steps, the cross-GPU legs priced per leg and per link, C3 / C5 emitted
+    assert set(d["transports"]) == {"push", "pull"} and d["config"]["dispatch_transport"] in ("push", "pull")
+    assert {"dispatch_frac", "combine_frac", "dispatch_max_link_bytes", "combine_max_link_bytes"} <= set(d["xgmi"])
+    assert d["low_latency"]["validated_round_trip"] is True and d["low_latency"]["dispatch_us_p50"] > 0
+    assert d["fused_deep_moe"].get("finite") is True, d["fused_deep_moe"]
 
 
 @pytest.mark.gpu
@@ -41,8 +46,10 @@ def test_bench_single_gpu_line():
                        capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    for k in REQUIRED + ("roofline", "cpu_baseline"):
+    for k in REQUIRED + ("roofline", "cpu_baseline", "low_latency", "fused_deep_moe"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["dtype"] == "u8" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["dtype"] == "int8/bf16" and d["vs_baseline"] is None
+    assert d["cpu_baseline"]["cores"] >= 1 and "single_core" in d["cpu_baseline"]
+    assert d["fused_deep_moe"]["roofline"]["bound"] == "mfma" and d["fused_deep_moe"]["finite"] is True
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])

@@ -95,50 +95,150 @@ def test_split_qkv_rmsnorm_rope(rope_dim, neox, norm, bias, hd, qh, kvh, B):
     assert torch.allclose(k.cpu().float(), wk.float(), rtol=2 ** -7, atol=1e-3)
 
 
-@pytest.mark.parametrize("N,Hq,hidden", [(1, 32, 7168), (16, 64, 7168), (31, 128, 7168), (31, 128, 6144), (70, 16, 2048)])
+def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
+    torch.manual_seed(42)
+    d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),
+             wuq=torch.randint(-8, 8, (Hq * 192, 1536), dtype=torch.int8), descale0=(torch.rand(2112) * 1e-3 + 5e-4).float(),
+             descale1=(torch.rand(Hq * 192) * 1e-3 + 5e-4).float(), bias0=torch.randint(-50, 50, (2112,), dtype=torch.int32),
+             bias1=torch.randint(-50, 50, (Hq * 192,), dtype=torch.int32), gamma0=torch.randn(hidden).to(dt), beta0=torch.randn(hidden).to(dt),
+             gamma1=torch.randn(1536).to(dt), beta1=(torch.randn(1536) * 0.1).to(dt), gamma2=torch.randn(512).to(dt),
+             wuk=(torch.randn(Hq, 128, 512) * 0.1).to(dt), cos=torch.rand(N, 64).to(dt), sin=torch.rand(N, 64).to(dt),
+             qs0=torch.tensor([0.02]).to(dt), qo0=torch.tensor([3], dtype=torch.int8), qs1=torch.tensor([0.03]).to(dt),
+             qo1=torch.tensor([-2], dtype=torch.int8))
+    return d
+
+
+def _mla_pre_exact(z, eps=1e-6):
+    """The same network in float64 with the golden's rounding / quantisation points kept (what both the kernel and the fp32
+    oracle approximate): exact statistics for the two RMSNorms, exact BMM accumulation."""
+    dt = z["hid"].dtype
+    q8 = OK._quant_per_tensor(z["hid"], z["qs0"], z["qo0"])
+    f = OK._int8_gemm_dequant(q8, z["wdqkv"], z["descale0"], z["bias0"], dt).double()
+    k_nope, k_pe, q = f[:, :512], f[:, 512:576], f[:, 576:]
+    rms = lambda x, g: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * g.double()
+    qn = (rms(q, z["gamma1"]) + z["beta1"].double()).float()
+    y = OK._int8_gemm_dequant(OK._quant_per_tensor(qn, z["qs1"], z["qo1"]), z["wuq"], z["descale1"], z["bias1"], dt)
+    y = y.view(y.shape[0], -1, 192).double()
+    c, s_ = z["cos"].double().unsqueeze(1), z["sin"].double().unsqueeze(1)
+    rot = lambda t: torch.cat([-t[..., 32:], t[..., :32]], -1)
+    q0 = torch.einsum("nhk,hkd->nhd", y[..., :128], z["wuk"].double())
+    q1 = y[..., 128:] * c + rot(y[..., 128:]) * s_
+    kp = k_pe.unsqueeze(1)
+    return q0, q1, rms(k_nope, z["gamma2"]), (kp * c + rot(kp) * s_).squeeze(1)
+
+
+@pytest.mark.parametrize("N,Hq,hidden", [(1, 32, 7168), (16, 64, 7168), (31, 128, 7168), (31, 128, 6144), (70, 16, 2048),
+                                         (128, 128, 7168), (1024, 16, 7168), (200, 128, 7168)])
 def test_mla_preprocess(N, Hq, hidden):
     """torch.ops.npu.mla_preprocess vs the transcription of the reference golden (seed 42, shapes of
-    tests/python/sgl_kernel_npu/test_mla_preprocess.py:487-498)."""
-    torch.manual_seed(42)
+    tests/python/sgl_kernel_npu/test_mla_preprocess.py:487-498, plus the decode batch 128, the maximum 1024 tokens and a token
+    count that is not a multiple of the 128-row block).
+
+    Bar.  The reference asserts atol = rtol = 1e-3 against golden2_pytorch (:700-745).  Kernel and golden run the same chain of
+    exact stages (int8 GEMMs, element-wise fp32 arithmetic with identical rounding points) except for the ORDER of the fp32
+    sums inside the two RMSNorms and the BMM; a last-bit difference there moves a bf16 rounding (or, before GEMM2, an int8
+    rounding) in a handful of elements.  So: (1) all but a vanishing fraction of the elements meet the reference's 1e-3,
+    (2) the rest are bounded by what one flipped int8 step can do, (3) measured against the float64 evaluation of the same
+    network, the kernel is as accurate as the golden (mean absolute error, which a few flips do not dominate)."""
     dt = torch.bfloat16
-    block_size, nblocks = 128, 4
-    hid = (torch.randn(N, hidden) * 0.5).to(dt)
-    wdqkv = torch.randint(-8, 8, (2112, hidden), dtype=torch.int8)
-    wuq = torch.randint(-8, 8, (Hq * 192, 1536), dtype=torch.int8)
-    descale0 = (torch.rand(2112) * 1e-3 + 5e-4).float()
-    descale1 = (torch.rand(Hq * 192) * 1e-3 + 5e-4).float()
-    bias0 = torch.randint(-50, 50, (2112,), dtype=torch.int32)
-    bias1 = torch.randint(-50, 50, (Hq * 192,), dtype=torch.int32)
-    gamma0, beta0 = torch.randn(hidden).to(dt), torch.randn(hidden).to(dt)
-    gamma1, beta1 = torch.randn(1536).to(dt), (torch.randn(1536) * 0.1).to(dt)
-    gamma2 = torch.randn(512).to(dt)
-    wuk = (torch.randn(Hq, 128, 512) * 0.1).to(dt)
-    cos, sin = torch.rand(N, 64).to(dt), torch.rand(N, 64).to(dt)
-    qs0, qo0 = torch.tensor([0.02]).to(dt), torch.tensor([3], dtype=torch.int8)
-    qs1, qo1 = torch.tensor([0.03]).to(dt), torch.tensor([-2], dtype=torch.int8)
+    block_size, nblocks = 128, max(4, (N + 127) // 128 + 1)
+    z = _mla_pre_inputs(N, Hq, hidden, dt)
     slots = torch.randperm(nblocks * block_size)[:N].to(torch.int32)
-    want = OK.mla_preprocess(hid, wdqkv, descale0, bias0, gamma1, beta1, gamma2, wuq, descale1, bias1, wuk, cos, sin, qs0, qo0, qs1, qo1)
+    want = OK.mla_preprocess(z["hid"], z["wdqkv"], z["descale0"], z["bias0"], z["gamma1"], z["beta1"], z["gamma2"], z["wuq"], z["descale1"],
+                             z["bias1"], z["wuk"], z["cos"], z["sin"], z["qs0"], z["qo0"], z["qs1"], z["qo1"])
     d = lambda t: t.cuda()
     kv = torch.zeros((nblocks, block_size, 1, 512), dtype=dt, device="cuda")
     kr = torch.zeros((nblocks, block_size, 1, 64), dtype=dt, device="cuda")
     q0 = torch.empty((N, Hq, 512), dtype=dt, device="cuda")
     q1 = torch.empty((N, Hq, 64), dtype=dt, device="cuda")
-    out = torch.ops.npu.mla_preprocess(d(hid), d(gamma0), d(beta0), d(wdqkv), d(descale0), d(gamma1), d(beta1), d(wuq), d(descale1),
-                                       d(gamma2), d(cos), d(sin), d(wuk), kv, kr, d(slots), d(qs0), d(qo0), d(bias0), d(qs1), d(qo1),
-                                       d(bias1), cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", q_out0=q0,
-                                       kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr)
+    for _ in range(2):
+        out = torch.ops.npu.mla_preprocess(d(z["hid"]), d(z["gamma0"]), d(z["beta0"]), d(z["wdqkv"]), d(z["descale0"]), d(z["gamma1"]),
+                                           d(z["beta1"]), d(z["wuq"]), d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), d(z["wuk"]),
+                                           kv, kr, d(slots), d(z["qs0"]), d(z["qo0"]), d(z["bias0"]), d(z["qs1"]), d(z["qo1"]), d(z["bias1"]),
+                                           cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", q_out0=q0, kv_cache_out0=kv,
+                                           q_out1=q1, kv_cache_out1=kr)
     assert out[0].data_ptr() == q0.data_ptr() and out[1].data_ptr() == kv.data_ptr()
     k_nope = kv.view(-1, 512)[slots.long().cuda()].cpu()
     k_pe = kr.view(-1, 64)[slots.long().cuda()].cpu()
-    tol = dict(rtol=2 ** -6, atol=2e-2)      # bf16 outputs: one ulp on either side of the golden
-    assert torch.allclose(k_nope.float(), want[2].float(), **tol)
-    assert torch.allclose(k_pe.float(), want[3].float(), **tol)
-    assert torch.allclose(q1.cpu().float(), want[1].float(), **tol)
-    assert torch.allclose(q0.cpu().float(), want[0].float(), rtol=2 ** -5, atol=5e-2)      # through a K=128 bf16 BMM
+    exact = _mla_pre_exact(z)
+    got = (q0.cpu(), q1.cpu(), k_nope, k_pe)
+    for name, g, w, ex in zip(("q_out0", "q_out1", "k_nope", "k_pe"), got, want, exact):
+        g64, w64 = g.double(), w.double()
+        bad = ~torch.isclose(g64, w64, rtol=1e-3, atol=1e-3)
+        assert bad.double().mean().item() <= 2e-3, (name, bad.double().mean().item())                 # (1)
+        assert torch.allclose(g64, w64, rtol=2 ** -5, atol=5e-2), (name, (g64 - w64).abs().max().item())  # (2)
+        err_k, err_o = (g64 - ex).abs().mean().item(), (w64 - ex).abs().mean().item()
+        assert err_k <= 1.05 * err_o + 1e-7, (name, err_k, err_o)                                       # (3)
+    assert torch.equal(k_pe, want[3]), "k_pe has no reduction in it: it must match the golden bit for bit"
     # untouched cache rows stay zero
     mask = torch.ones(nblocks * block_size, dtype=torch.bool)
     mask[slots.long()] = False
     assert not kv.view(-1, 512).cpu()[mask].any()
+
+
+def _sgl_lib():
+    import ctypes
+    from capi import load
+    L = load("libmi_sgl_kernels.so")
+    V, I = ctypes.c_void_p, ctypes.c_int
+    L.mi_mla_pre_gemm_i8.argtypes = [V, I, I, V, I, I, V, V, V, V, I, V]
+    L.mi_mla_pre_bmm_rope.argtypes = [V, I, I, V, V, V, I, V, V, V]
+    L.mi_mla_pre_gemm_i8_partials.argtypes = [I]
+    L.mi_mla_pre_gemm_i8.restype = L.mi_mla_pre_bmm_rope.restype = L.mi_mla_pre_gemm_i8_partials.restype = I
+    return L
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 7168, 2112), (128, 7168, 2112), (130, 6144, 2112), (77, 2048, 2112), (128, 1536, 24576),
+                                   (1024, 1536, 3072), (5, 192, 100), (128, 1536, 16384), (40, 1536, 8192 + 48), (3, 1536, 50)])
+def test_mla_pre_skinny_int8_gemm_exact(M, K, N):
+    """mi_mla_pre_gemm_i8 through the C-ABI: split-K atomics (mode 0) give the exact int32 product; mode 1 = the golden's
+    dequant (int32 + bias) * descale -> bf16 with one rounding.  Includes K that is not a multiple of the 512-byte chunk and
+    column / row counts that are not multiples of the tiles."""
+    from capi import ptr, stream_ptr
+    L = _sgl_lib()
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    a = torch.randint(-128, 128, (M, K), generator=g, device="cuda", dtype=torch.int32).to(torch.int8)
+    w = torch.randint(-128, 128, (N, K), generator=g, device="cuda", dtype=torch.int32).to(torch.int8)
+    want = torch.round(a.double() @ w.double().T)                    # exact in float64
+    parts = L.mi_mla_pre_gemm_i8_partials(K)
+    assert parts == (K + 511) // 512
+    c = torch.full((parts, M, N), 12345, dtype=torch.int32, device="cuda")      # no zero-fill needed: every slice is overwritten
+    assert L.mi_mla_pre_gemm_i8(ptr(a), M, K, ptr(w), N, 0, ptr(c), None, None, None, 0, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(c.double().sum(0), want)
+    bias = torch.randint(-50, 50, (N,), generator=g, device="cuda", dtype=torch.int32)
+    descale = torch.rand(N, generator=g, device="cuda") * 1e-3 + 5e-4
+    for dtype, code in ((torch.bfloat16, 0), (torch.float16, 1)):
+        y = torch.zeros((M, N), dtype=dtype, device="cuda")
+        assert L.mi_mla_pre_gemm_i8(ptr(a), M, K, ptr(w), N, 1, None, ptr(bias), ptr(descale), ptr(y), code, stream_ptr()) == 0
+        torch.cuda.synchronize()
+        y_want = ((want.to(torch.int32) + bias).float() * descale).to(dtype)
+        assert torch.equal(y.view(torch.int16), y_want.view(torch.int16)), dtype
+
+
+@pytest.mark.parametrize("M,Hq", [(1, 8), (128, 128), (33, 16), (300, 4)])
+@pytest.mark.parametrize("dtype,code", [(torch.bfloat16, 0), (torch.float16, 1)])
+def test_mla_pre_bmm_rope(M, Hq, dtype, code):
+    from capi import ptr, stream_ptr
+    L = _sgl_lib()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + Hq)
+    y = torch.randn((M, Hq * 192), generator=g, device="cuda").to(dtype)
+    wuk = (torch.randn((Hq, 128, 512), generator=g, device="cuda") * 0.1).to(dtype)
+    cos, sin = torch.rand((M, 64), generator=g, device="cuda").to(dtype), torch.rand((M, 64), generator=g, device="cuda").to(dtype)
+    q0 = torch.zeros((M, Hq, 512), dtype=dtype, device="cuda")
+    q1 = torch.zeros((M, Hq, 64), dtype=dtype, device="cuda")
+    wuk_t = wuk.transpose(1, 2).contiguous()
+    assert L.mi_mla_pre_bmm_rope(ptr(y), M, Hq, ptr(wuk_t), ptr(cos), ptr(sin), code, ptr(q0), ptr(q1), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    yv = y.view(M, Hq, 192)
+    exact = torch.einsum("nhk,hkd->nhd", yv[..., :128].double(), wuk.double())
+    # fp32 accumulation of exact products, one rounding: within one output ulp of the float64 result
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    assert bool(((q0.double() - exact).abs() <= ulp * exact.abs() + 1e-6).all())
+    pe = yv[..., 128:].float()
+    rot = torch.cat([-pe[..., 32:], pe[..., :32]], -1)
+    want1 = (pe * cos.float().unsqueeze(1) + rot * sin.float().unsqueeze(1)).to(dtype)
+    assert torch.equal(q1.view(torch.int16), want1.view(torch.int16))
 
 
 @pytest.mark.parametrize("T,Hq,Hk,D,R", [(32, 8, 1, 64, 32), (32, 8, 1, 32, 32), (17, 16, 1, 128, 64), (64, 32, 1, 128, 64),
