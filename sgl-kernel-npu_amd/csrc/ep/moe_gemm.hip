@@ -64,13 +64,14 @@ __device__ float g_gemm_dbg[256];
 
 // MT = MFMA row tiles per wave: 4 -> 256-row workgroup tile (prefill-size groups), 1 -> 64-row tile (decode-size groups:
 // the weights stream once either way, the small tile just stops multiplying padding).
+// one (expert, m-tile) x 256-column tile; `slot` = index of the tile in (expert, row block) order.  Returns false when the slot lies
+// past the last tile (workgroup-uniform).
 template <int MODE, int MT>
-__global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs p)
+__device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint8_t *lds)
 {
     constexpr int BM = 64 * MT;
     constexpr int kStageBytes = (BM + BN) * BK;
     constexpr int kAPieces = BM / 16;                 // DMA instructions (16 rows x 64 B) for the A tile of a stage
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x 64 B + B 16 KB)
 #ifdef GEMM_TIMING
     const uint64_t t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
     // up to ~15 us per workgroup for the last experts, a third of a GEMM2 tile.)
     int e = -1, row0 = 0, rows = 0;
     {
-        int slot = blockIdx.y, start = 0;                   // wave-uniform
+        int slot = tile_slot, start = 0;                    // wave-uniform
         for (int base = 0; base < p.L && e < 0; base += 64) {
             const int i = base + lane;
             const int end = i < p.L ? p.cum[(i + 1) * p.cum_stride - 1] : 0;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
         row0 = __builtin_amdgcn_readfirstlane(row0);
         rows = __builtin_amdgcn_readfirstlane(rows);
     }
-    if (e < 0) return;
+    if (e < 0) return false;
     const int n0 = blockIdx.x * BN;
     const int8_t *wbase = p.w + (size_t)e * p.N * p.K;
     const int8_t *abase = p.a + (size_t)row0 * p.K;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
             }
         }
     // a wave only reads back what it wrote itself: LDS operations of one wave complete in order, no barrier needed
-    if (!wave_cols_ok) return;
+    if (!wave_cols_ok) return true;
 #pragma unroll
     for (int it = 0; it < kWaveRows / 8; ++it) {
         const int rl = it * 8 + (lane >> 3), chunk = lane & 7;
@@ -271,6 +272,22 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
         g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 3] = (float)(__builtin_amdgcn_s_memtime() - t_epi);
     }
 #endif
+    return true;
+}
+
+// The grid's y dimension is a POOL of tile workers, not one workgroup per possible tile: with worst-case sized buffers (fused_deep_moe
+// at EP = 8 allocates W x max_tokens x K rows, 8x what arrives under balanced routing) one workgroup per possible tile would
+// launch thousands that only look up "no such tile" and exit.  Worker y takes tile slots y, y + gridDim.y, ... until the
+// cumulative counts say there are no more.
+template <int MODE, int MT>
+__global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x 64 B + B 16 KB)
+    for (int slot = blockIdx.y;; slot += gridDim.y) {
+        if (!gemm_tile<MODE, MT>(p, slot, lds)) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
+        __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
+    }
 }
 
 // per-row symmetric requantisation of the SwiGLU output: q = rint((v * 127) * (1 / rowmax)), scale = rowmax / 127
@@ -315,7 +332,10 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
         (void)hipFuncSetAttribute((const void *)grouped_gemm_i8_kernel<MODE, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    dim3 grid((p.N + BN - 1) / BN, (p.M_cap + BM - 1) / BM + p.L);
+    const int tiles_max = (p.M_cap + BM - 1) / BM + p.L;        // every expert may end in a partial tile
+    const int gx = (p.N + BN - 1) / BN;
+    const int pool = 2048 / gx > 8 ? 2048 / gx : 8;             // ~8 workgroups per CU in flight over the launch; the rest is looped
+    dim3 grid(gx, tiles_max < pool ? tiles_max : pool);
     grouped_gemm_i8_kernel<MODE, MT><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(p);
 }
 
