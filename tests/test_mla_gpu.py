@@ -125,14 +125,24 @@ def test_full_size_c4_vs_fp32():
         if ragged:
             lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
         got = run_mla(q, kn, kr, lens, bt, 576 ** -0.5)
-        for b in (0, 17, 127):
+        # the WHOLE batch against an fp32 evaluation on the GPU (one-shot softmax): BASELINE's bar is 1e-3, and since the outputs
+        # at this size are ~0.016 in magnitude an absolute 1e-3 would be a 6 % check -- so it is asserted per element RELATIVE to
+        # the output scale of its row, plus the reference tests' cosine metric (tests/python/deepep/utils.py:191-195 form)
+        worst_rel, worst_cos = 0.0, 0.0
+        for b in range(B):
             L = int(lens[b])
             idx = bt[b, :(L + page - 1) // page].long()
             K = torch.cat([kn[idx].reshape(-1, 512), kr[idx].reshape(-1, 64)], dim=1)[:L].float()
             s = (q[b].float() @ K.T) * 576 ** -0.5
-            p = torch.softmax(s, dim=-1)
-            ref = p @ K[:, :512]
-            assert torch.allclose(got[b].float(), ref, atol=1e-3, rtol=2 ** -7), (got[b].float() - ref).abs().max()
+            ref = torch.softmax(s, dim=-1) @ K[:, :512]
+            gb = got[b].float()
+            scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-6)              # per head
+            rel = ((gb - ref).abs() / scale).max().item()
+            cos = 1.0 - (2 * (gb.double() * ref.double()).sum() / (gb.double().pow(2).sum() + ref.double().pow(2).sum())).item()
+            worst_rel, worst_cos = max(worst_rel, rel), max(worst_cos, cos)
+        # bf16 outputs: half an ulp of the row scale is 2^-9 = 2e-3 at most; P is rounded to bf16 before P.V on top of that
+        assert worst_rel < 8e-3, worst_rel
+        assert worst_cos < 1e-5, worst_cos
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
