@@ -68,10 +68,12 @@ def init_dist(n):
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)      # a desynchronised rank ends the run in minutes, not after the default half hour
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=tmo)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
     else:
         torch.cuda.set_device(0)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -303,6 +305,29 @@ def mla_section(args):
 # ---------------------------------------------------------------------------------------------------------------------
 # C3 / C5 sections (every rank runs them; rank 0 reports max-over-ranks numbers)
 # ---------------------------------------------------------------------------------------------------------------------
+def _phases(phases):
+    """Run the section's phases in order.  Every rank executes the SAME sequence of host collectives (a barrier after each phase,
+    one all-reduce at the end) whether or not its own phase raised: a rank that failed alone must not leave the others waiting
+    inside a collective it never enters.  -> (results dict, error string or None)."""
+    res, err = {}, None
+    for ph in phases:
+        if err is None:
+            try:
+                res.update(ph() or {})
+            except Exception as e:  # noqa: BLE001
+                err = str(e)[:300]
+        try:
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = err or str(e)[:300]
+        dist.barrier()
+    bad = torch.tensor([0.0 if err is None else 1.0], device="cuda")
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if bad.item() > 0 and err is None:
+        err = "another rank failed in this section"
+    return res, err
+
+
 def low_latency_section(buf, rank, world):
     """BASELINE C3: low-latency dispatch + combine, 128 tokens per rank, hidden 7168, top-8, 32 local experts per rank."""
     T, E = 128, 32 * world
@@ -310,16 +335,26 @@ def low_latency_section(buf, rank, world):
     x = torch.randn((T, HIDDEN), generator=g, device="cuda").to(torch.bfloat16)
     idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), TOPK, dim=-1)[1]
     w = torch.rand((T, TOPK), generator=g, device="cuda")
-    (rx, rs), cnt, handle, _, _ = buf.low_latency_dispatch(x, idx, T, E, use_fp8=True)
-    y = (rx.float() * rs[:, None]).to(torch.bfloat16)
-    out, _, _ = buf.low_latency_combine(y, idx, w, handle)
-    ok = check_round_trip(out, x, w) < 3e-3
-    barrier_sync()
-    d = ev_stats(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
-    barrier_sync()
-    c = ev_stats(lambda: buf.low_latency_combine(y, idx, w, handle))
-    barrier_sync()
-    m = max_over_ranks({"d50": d["p50_us"], "d99": d["p99_us"], "c50": c["p50_us"], "c99": c["p99_us"], "bad": 0.0 if ok else 1.0})
+    st = {}
+
+    def first():
+        (rx, rs), cnt, handle, _, _ = buf.low_latency_dispatch(x, idx, T, E, use_fp8=True)
+        st["y"], st["handle"] = (rx.float() * rs[:, None]).to(torch.bfloat16), handle
+        out, _, _ = buf.low_latency_combine(st["y"], idx, w, handle)
+        return {"bad": 0.0 if check_round_trip(out, x, w) < 3e-3 else 1.0}
+
+    def time_dispatch():
+        d = ev_stats(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
+        return {"d50": d["p50_us"], "d99": d["p99_us"]}
+
+    def time_combine():
+        c = ev_stats(lambda: buf.low_latency_combine(st["y"], idx, w, st["handle"]))
+        return {"c50": c["p50_us"], "c99": c["p99_us"]}
+
+    res, err = _phases([first, time_dispatch, time_combine])
+    if err is not None:
+        return {"error": err}
+    m = max_over_ranks(res)
     n_sel = T * TOPK
     return {"config": f"low-latency dispatch(int8)+combine(bf16), EP={world}, 128 tok/rank, hidden {HIDDEN}, top-{TOPK} of {E} (BASELINE C3)",
             "dispatch_us_p50": m["d50"], "dispatch_us_p99": m["d99"], "combine_us_p50": m["c50"], "combine_us_p99": m["c99"],
@@ -341,48 +376,78 @@ def fused_moe_section(buf, rank, world, T=4096):
     idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), TOPK, dim=-1)[1]
     w = torch.rand((T, TOPK), generator=g, device="cuda")
     f = lambda: buf.fused_deep_moe(x, idx, w, w13, s13, w2, s2, T, E)
-    out, _ = f()
-    torch.cuda.synchronize()
-    finite = bool(torch.isfinite(out.float()).all())
-    barrier_sync()
-    buf.begin_profile(0, 10, "")
-    for _ in range(10):
-        f()
-    buf.end_profile()
-    prof = {k: ms / n * 1e3 for k, (n, ms) in buf.get_profile_summary().items() if n}
-    barrier_sync()
-    r = ev_stats(f, n=20, warm=20)
-    barrier_sync()
-    m = max_over_ranks({"p50": r["p50_us"], "p99": r["p99_us"]})
+    st = {}
+
+    def first():
+        out, _ = f()
+        torch.cuda.synchronize()
+        return {"finite": 1.0 if bool(torch.isfinite(out.float()).all()) else 0.0}
+
+    def profile():
+        buf.begin_profile(0, 10, "")
+        for _ in range(10):
+            f()
+        buf.end_profile()
+        st["prof"] = {k: ms / n * 1e3 for k, (n, ms) in buf.get_profile_summary().items() if n}
+
+    def timed():
+        r = ev_stats(f, n=20, warm=20)
+        return {"p50": r["p50_us"], "p99": r["p99_us"]}
+
+    res, err = _phases([first, profile, timed])
+    if err is not None:
+        return {"error": err}
+    finite = res.pop("finite")
+    m = max_over_ranks(res)
+    fin = torch.tensor([finite], device="cuda")
+    dist.all_reduce(fin, op=dist.ReduceOp.MIN)
     ops = T * TOPK * (HIDDEN * 2 * INTER + INTER * HIDDEN) * 2          # per rank under balanced routing
     tops = ops / (m["p50"] * 1e-6) / 1e12
     return {"config": f"fused_deep_moe, EP={world}, {T} tok/rank, hidden {HIDDEN}, 2I={2 * INTER}, top-{TOPK}, {L} local experts per rank (BASELINE C5)",
             "ms_p50": m["p50"] / 1e3, "ms_p99": m["p99"] / 1e3, "int8_TOPs_per_gpu": tops,
             "roofline": {"bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
                          "traffic": None},
-            "kernels_avg_us": prof, "finite": finite}
+            "kernels_avg_us": st.get("prof", {}), "finite": bool(fin.item() > 0)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 def timed_steps(buf, x, topk_idx, topk_w, y, steps, warmup, profiled):
-    for _ in range(warmup):
-        one_step(buf, x, topk_idx, topk_w, y)
-    if profiled:
-        buf.begin_profile(0, steps, "")
-    flush_cache()
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize pairs; max over ranks.  The host collectives are
+    executed by every rank whether or not its own steps raised (see _phases); -> (seconds, profile dict, error or None)."""
+    err = None
+    try:
+        for _ in range(warmup):
+            one_step(buf, x, topk_idx, topk_w, y)
+        if profiled:
+            buf.begin_profile(0, steps, "")
+        flush_cache()
+    except Exception as e:  # noqa: BLE001
+        err = str(e)[:300]
     barrier_sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        one_step(buf, x, topk_idx, topk_w, y)
-    barrier_sync()
+    if err is None:
+        try:
+            for _ in range(steps):
+                one_step(buf, x, topk_idx, topk_w, y)
+        except Exception as e:  # noqa: BLE001
+            err = str(e)[:300]
+    try:
+        barrier_sync()
+    except Exception as e:  # noqa: BLE001
+        err = err or str(e)[:300]
     dt = time.perf_counter() - t0
     prof = {}
     if profiled:
-        buf.end_profile()
-        prof = buf.get_profile_summary()
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        try:
+            buf.end_profile()
+            prof = buf.get_profile_summary()
+        except Exception as e:  # noqa: BLE001
+            err = err or str(e)[:300]
+    tmax = torch.tensor([dt, 0.0 if err is None else 1.0], device="cuda", dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    return float(tmax.item()), prof
+    if tmax[1].item() > 0 and err is None:
+        err = "another rank failed"
+    return float(tmax[0].item()), prof, err
 
 
 def main():
@@ -426,12 +491,11 @@ def main():
     for tr in transports:
         if tr is not None:
             buf.runtime.set_dispatch_transport(tr)
-        try:
-            dt, prof = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, args.warmup, windowed)
+        dt, prof, err = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, args.warmup, windowed)
+        if err is None:
             runs[tr] = (dt, prof)
-        except Exception as e:  # noqa: BLE001
-            if rank == 0:
-                print(f"[bench] transport {tr} failed: {e}", file=sys.stderr)
+        elif rank == 0:
+            print(f"[bench] transport {tr} failed: {err}", file=sys.stderr)
     assert runs, "no dispatch transport completed"
     best = min(runs, key=lambda k: runs[k][0])
     dt, prof = runs[best]
@@ -448,11 +512,7 @@ def main():
     extra = {}
     if windowed and not args.no_extra:
         for name, fn in (("low_latency", low_latency_section), ("fused_deep_moe", fused_moe_section)):
-            try:
-                extra[name] = fn(buf, rank, world)
-            except Exception as e:  # noqa: BLE001
-                extra[name] = {"error": str(e)[:300]}
-                torch.cuda.synchronize()
+            extra[name] = fn(buf, rank, world)
 
     pairs_to, tokens_to = routing_stats(topk_idx, world, rank)
     rows_from = torch.bincount(handle[3][:3 * n_recv].view(-1, 3)[:, 0].long(), minlength=world).tolist() if windowed else [0] * world
