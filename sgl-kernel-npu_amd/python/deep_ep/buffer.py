@@ -84,6 +84,14 @@ class Buffer:
               list(rt.get_local_window_ptrs()))
         everyone = [None] * self.group_size
         dist.all_gather_object(everyone, me, group=self.group)
+
+        def agree(ok: bool) -> bool:
+            """Every rank reports; the step counts only if it worked everywhere.  (Also the barrier between the steps: a rank
+            that failed locally still takes part in every collective, so nobody is left waiting for it.)"""
+            flags = [None] * self.group_size
+            dist.all_gather_object(flags, bool(ok), group=self.group)
+            return all(flags)
+
         ok = True
         try:
             if any(h[0] != me[0] for h in everyone):
@@ -91,18 +99,23 @@ class Buffer:
             handles = [h[3] for h in everyone]
             local_ptrs = [h[4] if (h[1] == me[1]) else [] for h in everyone]
             rt.sync(handles, local_ptrs)
-            # one flag + one 4 KiB row round trip with every peer (write path and read-back path, checksummed): a mapping
-            # that does not behave degrades to the alltoall strategies instead of corrupting tokens later
-            if hasattr(rt, "self_test") and os.getenv("DEEPEP_SKIP_SELF_TEST", "0") != "1":
-                dist.barrier(group=self.group)          # every rank has mapped everybody before anyone writes
-                if not rt.self_test(int(os.getenv("DEEPEP_SELF_TEST_TIMEOUT_MS", "10000"))):
-                    raise RuntimeError("window self-test failed")
         except Exception as e:  # noqa: BLE001
             warnings.warn(f"[deep_ep rank {self.rank}] cannot map peer windows ({e}); using the alltoall strategies")
             ok = False
-        flags = [None] * self.group_size
-        dist.all_gather_object(flags, ok, group=self.group)
-        return all(flags)
+        if not agree(ok):           # every rank has mapped everybody before anyone writes into a peer's window
+            return False
+        # one flag + one 4 KiB row round trip with every peer (write path and read-back path, checksummed): a mapping that does
+        # not behave degrades to the alltoall strategies instead of corrupting tokens later
+        if hasattr(rt, "self_test") and os.getenv("DEEPEP_SKIP_SELF_TEST", "0") != "1":
+            try:
+                ok = bool(rt.self_test(int(os.getenv("DEEPEP_SELF_TEST_TIMEOUT_MS", "10000"))))
+            except Exception as e:  # noqa: BLE001
+                warnings.warn(f"[deep_ep rank {self.rank}] window self-test raised ({e})")
+                ok = False
+            if not ok:
+                warnings.warn(f"[deep_ep rank {self.rank}] window self-test failed; using the alltoall strategies")
+            return agree(ok)
+        return True
 
     def _init_normal_strategy(self, strategy):
         if isinstance(strategy, NormalStrategy):
