@@ -256,8 +256,11 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     (void)gamma0, (void)beta0, (void)ctkv_scale, (void)q_nope_scale;
     TORCH_CHECK(!cache_mode.has_value() || *cache_mode == "krope_ctkv", "mla_preprocess: only cache_mode='krope_ctkv' is implemented "
                 "(the int8 / NZ cache modes are Ascend layouts), got ", cache_mode.value_or(""));
-    TORCH_CHECK(!quant_mode.has_value() || *quant_mode == "per_tensor_quant_asymm", "mla_preprocess: only quant_mode="
-                "'per_tensor_quant_asymm' is implemented, got ", quant_mode.value_or(""));
+    // the reference defaults quant_mode to per_token_quant_symm (csrc/mla_preprocess/op_host/mla_preprocess.cpp:635): a caller that
+    // omits it must not silently get different arithmetic, so the default is rejected like the explicit name
+    TORCH_CHECK(quant_mode.has_value() && *quant_mode == "per_tensor_quant_asymm", "mla_preprocess: only quant_mode="
+                "'per_tensor_quant_asymm' is implemented (the reference's default, 'per_token_quant_symm', is not: pass the mode "
+                "explicitly), got ", quant_mode.has_value() ? *quant_mode : c10::string_view("None"));
     TORCH_CHECK(hiddenState.dim() == 2 && hiddenState.is_contiguous(), "hiddenState must be contiguous [tokens, hidden]");
     const int64_t N = hiddenState.size(0), hidden = hiddenState.size(1);
     TORCH_CHECK(N <= 1024, "mla_preprocess: tokenNum <= 1024 (csrc/mla_preprocess/README.md)");

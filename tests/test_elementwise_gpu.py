@@ -176,6 +176,28 @@ def test_mla_preprocess(N, Hq, hidden):
     assert not kv.view(-1, 512).cpu()[mask].any()
 
 
+def test_mla_preprocess_rejects_modes_it_does_not_implement():
+    """cache modes 2 / 3 are Ascend NZ cache layouts; quant_mode=None means per_token_quant_symm in the reference
+    (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-612,634-635): both must fail loudly, never run other arithmetic."""
+    dt = torch.bfloat16
+    z = _mla_pre_inputs(2, 16, 2048, dt)
+    d = lambda t: t.cuda()
+    kv = torch.zeros((2, 128, 1, 512), dtype=dt, device="cuda")
+    kr = torch.zeros((2, 128, 1, 64), dtype=dt, device="cuda")
+    q0, q1 = torch.empty((2, 16, 512), dtype=dt, device="cuda"), torch.empty((2, 16, 64), dtype=dt, device="cuda")
+    slots = torch.tensor([0, 5], dtype=torch.int32, device="cuda")
+    args = (d(z["hid"]), d(z["gamma0"]), d(z["beta0"]), d(z["wdqkv"]), d(z["descale0"]), d(z["gamma1"]), d(z["beta1"]), d(z["wuq"]),
+            d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), d(z["wuk"]), kv, kr, slots, d(z["qs0"]), d(z["qo0"]), d(z["bias0"]),
+            d(z["qs1"]), d(z["qo1"]), d(z["bias1"]))
+    outs = dict(q_out0=q0, kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr)
+    for bad in (dict(cache_mode="krope_ctkv"), dict(cache_mode="krope_ctkv", quant_mode="per_token_quant_symm"),
+                dict(cache_mode="int8_nzcache", quant_mode="per_tensor_quant_asymm"),
+                dict(cache_mode="nzcache", quant_mode="per_tensor_quant_asymm")):
+        with pytest.raises(RuntimeError):
+            torch.ops.npu.mla_preprocess(*args, **bad, **outs)
+    torch.ops.npu.mla_preprocess(*args, cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", **outs)      # the built mode runs
+
+
 def _sgl_lib():
     import ctypes
     from capi import load
