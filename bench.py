@@ -394,7 +394,15 @@ def fused_moe_section(buf, rank, world, T=4096):
         r = ev_stats(f, n=20, warm=20)
         return {"p50": r["p50_us"], "p99": r["p99_us"]}
 
-    res, err = _phases([first, profile, timed])
+    def vendor_gemm():
+        # calibration, not a target: what the vendor library's DENSE int8 GEMM (hipBLASLt through torch._int_mm, int32 output, no
+        # epilogue, no grouping) reaches on this chip for GEMM1's shape -- the 3.9 POPS datasheet peak is not attainable in practice
+        a = torch.randint(-8, 8, (T * TOPK, HIDDEN), device="cuda", dtype=torch.int32).to(torch.int8)
+        wd = w13[0].t()
+        r = ev_stats(lambda: torch._int_mm(a, wd), n=5, warm=3)
+        return {"vendor": 2.0 * T * TOPK * HIDDEN * 2 * INTER / (r["p50_us"] * 1e-6) / 1e12}
+
+    res, err = _phases([first, profile, timed, vendor_gemm])
     if err is not None:
         return {"error": err}
     finite = res.pop("finite")
@@ -407,6 +415,7 @@ def fused_moe_section(buf, rank, world, T=4096):
             "ms_p50": m["p50"] / 1e3, "ms_p99": m["p99"] / 1e3, "int8_TOPs_per_gpu": tops,
             "roofline": {"bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
                          "traffic": None},
+            "vendor_dense_int8_gemm_TOPs": m.get("vendor"),      # hipBLASLt dense GEMM of GEMM1's shape on the same GPU (calibration)
             "kernels_avg_us": st.get("prof", {}), "finite": bool(fin.item() > 0)}
 
 

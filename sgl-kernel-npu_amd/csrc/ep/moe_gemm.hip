@@ -235,6 +235,29 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
         }
     // a wave only reads back what it wrote itself: LDS operations of one wave complete in order, no barrier needed
     if (!wave_cols_ok) return true;
+    // MODE 2: where do this lane's rows go?  The (src, t, k) triples and, from them, the slot addresses are requested in ONE batch for all 8
+    // row groups (after the transposition, when the accumulators are dead and the registers are free), two dependent round trips in all.
+    // (Loaded inside the store loop, each of the 8 row groups paid both round trips in front of its store: GEMM2's epilogue cost
+    // 18k cycles per tile against 11k for GEMM1, which writes as many bytes.)
+    uint16_t *push_row[kWaveRows / 8];
+    if (MODE == 2) {
+        const int32_t *__restrict__ sidx = p.src_idx;
+        int ts[kWaveRows / 8], tt[kWaveRows / 8], tk[kWaveRows / 8];
+#pragma unroll
+        for (int it = 0; it < kWaveRows / 8; ++it) {
+            const int lr = wm * kWaveRows + it * 8 + (lane >> 3);
+            const size_t grow = (size_t)row0 + min(lr, rows - 1);
+            ts[it] = sidx[grow * 3 + 0], tt[it] = sidx[grow * 3 + 1], tk[it] = sidx[grow * 3 + 2];
+        }
+        const size_t poff = parity_off(p.par);
+#pragma unroll
+        for (int it = 0; it < kWaveRows / 8; ++it) {
+            const int src = ts[it], t = tt[it], k = tk[it];
+            // corrupted handle: drop instead of a wild (cross-GPU) store
+            const bool ok = src >= 0 && src < p.W && k >= 0 && k < p.topk && t >= 0 && (long long)t * p.topk + k < p.slot_rows;
+            push_row[it] = ok ? (uint16_t *)((uint8_t *)p.dsts.p[ok ? src : 0] + poff + ((size_t)t * p.topk + k) * p.slot_stride) : nullptr;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < kWaveRows / 8; ++it) {
         const int rl = it * 8 + (lane >> 3), chunk = lane & 7;
@@ -249,11 +272,8 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
             const int col = n0 + wn * 64 + chunk * 8;
             uint16_t *orow;
             if (MODE == 2) {
-                // the 8 lanes of a row read the same triple (one 12-byte broadcast per row, L1-resident)
-                const int src = p.src_idx[grow * 3 + 0], t = p.src_idx[grow * 3 + 1], k = p.src_idx[grow * 3 + 2];
-                // corrupted handle: drop instead of a wild (cross-GPU) store
-                if (src < 0 || src >= p.W || k < 0 || k >= p.topk || t < 0 || (long long)t * p.topk + k >= p.slot_rows) continue;
-                orow = (uint16_t *)((uint8_t *)p.dsts.p[src] + parity_off(p.par) + ((size_t)t * p.topk + k) * p.slot_stride) + col;
+                if (!push_row[it]) continue;
+                orow = push_row[it] + col;
             } else {
                 orow = (uint16_t *)p.out + grow * (size_t)p.N + col;
             }
