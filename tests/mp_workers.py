@@ -537,7 +537,15 @@ def _gpu_graph(rank, world, port, cfg):
         y = (rx.float() * rs[:, None]).to(torch.bfloat16)
         out, _, _ = buf.low_latency_combine(y, ti_s, tw_s, handle)
         fused, rc = buf.fused_deep_moe(x_s, ti_s, tw_s, w13_d, s13_d, w2_d, s2_d, T, E)
-        return rx, rs, cnt, handle, out, fused, rc
+        # normal mode in DeepEP's graph-friendly form (num_worst_tokens: worst-case sized outputs, no host sync) + combine
+        per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti_s, E)
+        (nrx, nrs), _, _, lst, nh, _ = buf.dispatch(x_s, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                    num_tokens_per_expert=per_expert, topk_idx=ti_s, topk_weights=tw_s,
+                                                    quant_mode="int8", num_worst_tokens=T * K * W)
+        assert lst == []
+        ny = (nrx.float() * nrs[:, None]).to(torch.bfloat16)      # rows past the received total are garbage and never pushed
+        nout, _, _ = buf.combine(ny, nh)
+        return rx, rs, cnt, handle, out, fused, rc, nrx, nrs, nh, nout
 
     # warm-up on a side stream (allocator pools, one-off function attributes), an ODD number of calls so that the captured
     # graph is first replayed on the other ping-pong half than the one it would have been captured "for" by a host-side counter
@@ -552,7 +560,7 @@ def _gpu_graph(rank, world, port, cfg):
     dist.barrier()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        rx, rs, cnt, handle, out, fused, rc = step()
+        rx, rs, cnt, handle, out, fused, rc, nrx, nrs, nh, nout = step()
     for rep in range(replays):
         xs, idxs, ws = load(100 + rep)
         torch.cuda.synchronize()
@@ -574,6 +582,14 @@ def _gpu_graph(rank, world, port, cfg):
         assert np.array_equal(rc.cpu().numpy(), llw[rank].layout_range), rep
         assert O.calc_diff(got, ref) < 1e-5, (rep, O.calc_diff(got, ref))
         assert np.mean(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-2)) < 4e-4, rep
+        nw = O.normal_dispatch(xs, idxs, E, True)
+        n = nw[rank].total_recv
+        assert np.array_equal(nrx.cpu().numpy()[:n], nw[rank].recv_x[:n]), rep
+        assert np.array_equal(nrs.cpu().numpy()[:n].view(np.uint32), nw[rank].recv_x_scales[:n].view(np.uint32)), rep
+        assert np.array_equal(nh[3].cpu().numpy()[:3 * n], nw[rank].recv_src_idx[:3 * n]), rep
+        nys = [O.per_token_cast_back(w_.recv_x, w_.recv_x_scales) for w_ in nw]
+        ncomb = O.combine(nys, [w_.recv_src_idx for w_ in nw], [w_.total_recv for w_ in nw], idxs, ws, E)
+        assert np.array_equal(torch_to_bits(nout), ncomb[rank]), f"replay {rep}: normal combine mismatch"
     faulthandler.cancel_dump_traceback_later()
     torch.cuda.synchronize()
     dist.barrier()
