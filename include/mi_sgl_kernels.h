@@ -116,6 +116,11 @@ int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin, int tokens
  *              mode 0: split-K, one workgroup per 512-byte K-chunk: c_i32 [ceil(k/512)][tokens][n] partial products whose sum
  *                      (exact, order-independent) is the GEMM -- mi_mla_pre_gemm_i8_partials(k) of them;
  *              mode 1: y[tokens, n] (I/O dtype) = (float(c + bias[n])) * descale[n], one rounding (golden :95-107); bias may be NULL.
+ * quant_mode "per_token_quant_symm" (the reference's default; mla_preprocess_mix_bf16.hpp:389-483,2262-2279): pre_quant_token writes
+ *              int8 rows quantised against their own maximum (scale = max|x| / 127, q = rint(clamp(fp16(x * (1 / scale))))) and the
+ *              per-token scales; pre_mid with tok_scale_in / tok_scale_out dequantises GEMM1 with (float(c) * descale0[j]) *
+ *              tok_scale_in[t] (no bias) and requantises the normalised q against its own row maximum; pre_gemm_i8 mode 1 with
+ *              row_scale multiplies by the token scale after the channel scale (pass bias = NULL).
  * pre_mid:     sum of the num_partials slices of gemm1_i32 [num_partials][tokens, 2112] (+bias0) * descale0 -> I/O dtype -> [512 k_nope | 64 k_pe | 1536 q];
  *              kv_cache[slot, :512] = rms_norm(k_nope) * gamma2, kv_cache_rope[slot, :64] = rope_half(k_pe, cos, sin),
  *              q_int8 [tokens, 1536] = per-tensor quant of rms_norm(q) * gamma1 + beta1.  cos / sin [tokens, 64].
@@ -125,11 +130,14 @@ int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin, int tokens
 int mi_mla_pre_quant(const void *x, const void *scale /*[1], I/O dtype*/, const int8_t *zero_point /*[1]*/, int64_t numel, int dtype,
                      int8_t *out, void *stream);
 int mi_mla_pre_gemm_i8_partials(int k);
+int mi_mla_pre_quant_token(const void *x, int tokens, int hidden, int dtype, int8_t *out, float *tok_scale, void *stream);
 int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8_t *w, int n, int mode, int32_t *c_i32, const int32_t *bias,
-                       const float *descale, void *y, int dtype, void *stream);
+                       const float *descale, const float *row_scale /* NULL, or [tokens]: per-token dequant scale */, void *y,
+                       int dtype, void *stream);
 int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bias0, const float *descale0, const void *gamma1, const void *beta1,
                    const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping, const void *quant_scale1,
                    const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8, void *kv_cache, void *kv_cache_rope,
+                   const float *tok_scale_in /* NULL = per-tensor mode */, float *tok_scale_out /* [tokens], with tok_scale_in */,
                    void *stream);
 int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const void *wuk_t, const void *cos, const void *sin, int dtype,
                         void *q_out0, void *q_out1, void *stream);

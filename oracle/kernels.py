@@ -280,6 +280,52 @@ def _int8_gemm_dequant(a, w, descale, bias, dtype):
     return (y.to(torch.float32) * descale.float()).to(dtype)
 
 
+def _quant_per_token(x):
+    """quant_mode 'per_token_quant_symm' (csrc/mla_preprocess/op_kernel/mla_preprocess_mix_bf16.hpp:437-483): scale = max|x| / 127 per
+    row (fp32), y = x * (1 / scale), fp16, clamp, round half to even, int8.  -> (int8, float32 scales).  An all-zero row gives zeros
+    with scale 0 (the reference would divide by zero)."""
+    xf = x.float()
+    scale = xf.abs().amax(dim=-1) / torch.full((), 127.0)
+    inv = torch.where(scale > 0, torch.ones_like(scale) / scale, torch.zeros_like(scale))
+    y = torch.clamp((xf * inv[..., None]).to(torch.float16), -128, 127)
+    return torch.round(y).to(torch.int8), scale
+
+
+def _int8_gemm_dequant_token(a, w, descale, tok_scale, dtype):
+    """:389-421 / :2262-2279: (float(int32) * per-channel descale) * per-token scale, no bias, one rounding to dtype."""
+    y = torch.round(a.double() @ w.double().t()).to(torch.int32)
+    return ((y.to(torch.float32) * descale.float()) * tok_scale.float()[:, None]).to(dtype)
+
+
+def mla_preprocess_per_token(hidden, wdqkv, descale0, gamma1, beta1, gamma2, wuq, descale1, wuk, cos, sin, eps=1e-6):
+    """mla_preprocess with quant_mode='per_token_quant_symm' (the reference's default; no golden exists for it in the reference
+    tests -- tests/python/sgl_kernel_npu/test_mla_preprocess.py only runs per_tensor_quant_asymm -- so this restates the kernel:
+    mla_preprocess_mix_bf16.hpp Quant :284-490, the GEMM2 epilogue :2196-2290; PARITY UNPINNED for this mode).  Same network as
+    mla_preprocess() below with the two quantisations per token and the two dequants by (channel scale) * (token scale), no bias."""
+    dtype = hidden.dtype
+    N = hidden.shape[0]
+    Hq = wuq.shape[0] // 192
+
+    def rms(x, g):
+        xf = x.float()
+        return xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * g.float()
+
+    a8, t0 = _quant_per_token(hidden)
+    fused = _int8_gemm_dequant_token(a8, wdqkv, descale0, t0, dtype)
+    latent, q = fused.split([576, 1536], dim=-1)
+    k_nope, k_pe = latent[..., :512], latent[..., 512:].unsqueeze(1)
+    q = rms(q, gamma1) + beta1
+    k_nope = rms(k_nope, gamma2)
+    q8, t1 = _quant_per_token(q)
+    q_out = _int8_gemm_dequant_token(q8, wuq, descale1, t1, dtype).view(N, Hq, 192)
+    q_nope, q_pe = q_out.split([128, 64], dim=-1)
+    q_nope_out = torch.bmm(q_nope.transpose(0, 1), wuk).transpose(0, 1)
+    c, s = cos.unsqueeze(1).float(), sin.unsqueeze(1).float()
+    q_pe_r = (q_pe.float() * c + _rotate_half(q_pe.float()) * s).to(dtype)
+    k_pe_r = (k_pe.float() * c + _rotate_half(k_pe.float()) * s).to(dtype)
+    return q_nope_out.to(dtype), q_pe_r, k_nope.to(dtype), k_pe_r.squeeze(1)
+
+
 def mla_preprocess(hidden, wdqkv, descale0, bias0, gamma1, beta1, gamma2, wuq, descale1, bias1, wuk, cos, sin, qscale0, qoff0,
                    qscale1, qoff1, eps=1e-6):
     """Transcription of golden2_pytorch, cache_mode 'krope_ctkv' (tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483):

@@ -73,7 +73,8 @@ __device__ __forceinline__ void dma16(uint32_t dst, const void *vaddr)
 template <int MODE, int BN, bool BF16>
 __global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict__ A, int M, int K, const int8_t *__restrict__ W, int N,
                                                        int32_t *__restrict__ C, const int32_t *__restrict__ bias,
-                                                       const float *__restrict__ descale, uint16_t *__restrict__ Y)
+                                                       const float *__restrict__ descale, const float *__restrict__ row_scale,
+                                                       uint16_t *__restrict__ Y)
 {
     constexpr int NT = BN / 16;                       // MFMA column tiles, all of them handled by every wave
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // [BN][kRowStride]
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict
                     // would have to leave the XCD-local L2 and ran 3x slower than the whole GEMM)
                     C[((size_t)blockIdx.y * M + row) * N + col] = acc[mt][nt][r];
                 } else {
-                    const float y = (float)(acc[mt][nt][r] + (bias ? bias[col] : 0)) * descale[col];
+                    float y = (float)(acc[mt][nt][r] + (bias ? bias[col] : 0)) * descale[col];
+                    if (row_scale) y = y * row_scale[row];      // per_token_quant_symm: the token's own scale (hpp:2273-2279)
                     Y[(size_t)row * N + col] = sth16<BF16>(y);
                 }
             }
@@ -168,7 +170,7 @@ constexpr int kK2 = 1536, kRow2 = kK2 + 16;
 template <int NT, bool BF16>
 __global__ __launch_bounds__(256) void skinny_i8_k1536_kernel(const int8_t *__restrict__ A, int M, const int8_t *__restrict__ W, int N,
                                                              const int32_t *__restrict__ bias, const float *__restrict__ descale,
-                                                             uint16_t *__restrict__ Y)
+                                                             const float *__restrict__ row_scale, uint16_t *__restrict__ Y)
 {
     constexpr int BN = NT * 16, KS = kKC / 64;       // 8 k-steps per chunk, 3 chunks
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // [BN][kRow2]; reused for the output tile
@@ -235,8 +237,11 @@ __global__ __launch_bounds__(256) void skinny_i8_k1536_kernel(const int8_t *__re
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *(uint16_t *)(tile + (mt * 16 + 4 * g + r) * kTileRow + (nt * 16 + c16) * 2) = sth16<BF16>((float)(acc[mt][nt][r] + bs) * ds);
+            for (int r = 0; r < 4; ++r) {
+                float y = (float)(acc[mt][nt][r] + bs) * ds;
+                if (row_scale) y = y * row_scale[min(m0 + mt * 16 + 4 * g + r, M - 1)];      // per_token_quant_symm
+                *(uint16_t *)(tile + (mt * 16 + 4 * g + r) * kTileRow + (nt * 16 + c16) * 2) = sth16<BF16>(y);
+            }
     }
     // a wave reads back only what it wrote itself (its LDS operations complete in order)
     constexpr int kChunks = BN / 8;                   // 16-byte chunks per row
@@ -335,7 +340,7 @@ using namespace mi_sgl;
 extern "C" int mi_mla_pre_gemm_i8_partials(int k) { return k > 0 ? (k + kKC - 1) / kKC : 0; }
 
 extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8_t *w, int n, int mode, int32_t *c_i32,
-                                  const int32_t *bias, const float *descale, void *y, int dtype, void *stream)
+                                  const int32_t *bias, const float *descale, const float *row_scale, void *y, int dtype, void *stream)
 {
     if (tokens < 0 || k <= 0 || k % 64 || n <= 0 || (mode != 0 && mode != 1) || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16))
         return MI_SGL_EINVAL;
@@ -352,7 +357,7 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
             attr_set = true;
         }
         dim3 grid((n + BN - 1) / BN, chunks, mblocks);
-        skinny_i8_kernel<0, BN, true><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, c_i32, nullptr, nullptr, nullptr);
+        skinny_i8_kernel<0, BN, true><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, c_i32, nullptr, nullptr, nullptr, nullptr);
     } else if (k == kK2) {
         // the op's GEMM2: pick the widest column tile that still gives the chip a full round of workgroups
         const int nt = n >= 256 * 96 ? 6 : n >= 256 * 64 ? 4 : n >= 256 * 32 ? 2 : 1;
@@ -365,7 +370,7 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
                 (void)hipFuncSetAttribute((const void *)skinny_i8_k1536_kernel<NT, B>, hipFuncAttributeMaxDynamicSharedMemorySize, NT * 16 * kRow2); \
                 attr_set = true;                                                                                                         \
             }                                                                                                                            \
-            skinny_i8_k1536_kernel<NT, B><<<grid, 256, lds, s>>>(a, tokens, w, n, bias, descale, (uint16_t *)y);                          \
+            skinny_i8_k1536_kernel<NT, B><<<grid, 256, lds, s>>>(a, tokens, w, n, bias, descale, row_scale, (uint16_t *)y);                          \
         } while (0)
         const bool bf = dtype == MI_DTYPE_BF16;
         if (nt == 6) { if (bf) MI_K1536(6, true); else MI_K1536(6, false); }
@@ -377,9 +382,9 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
         constexpr int BN = 64;
         dim3 grid((n + BN - 1) / BN, 1, mblocks);
         if (dtype == MI_DTYPE_BF16)
-            skinny_i8_kernel<1, BN, true><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, nullptr, bias, descale, (uint16_t *)y);
+            skinny_i8_kernel<1, BN, true><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, nullptr, bias, descale, row_scale, (uint16_t *)y);
         else
-            skinny_i8_kernel<1, BN, false><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, nullptr, bias, descale, (uint16_t *)y);
+            skinny_i8_kernel<1, BN, false><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, nullptr, bias, descale, row_scale, (uint16_t *)y);
     }
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }

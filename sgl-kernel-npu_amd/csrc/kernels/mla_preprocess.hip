@@ -74,6 +74,58 @@ __global__ __launch_bounds__(256) void pre_quant_kernel(const uint16_t *__restri
     *(uint2 *)(out + i) = uint2{o[0], o[1]};
 }
 
+// quant_mode "per_token_quant_symm" (the reference's default, mla_preprocess_mix_bf16.hpp:437-483): scale = max|y| / 127 per row,
+// q = int8(rint(clamp(fp16(y * (1 / scale))))), the row's scale is kept for the dequant of the following GEMM
+__device__ __forceinline__ int8_t quant_tok(float y, float inv_scale)
+{
+    float v = y * inv_scale;
+    asm volatile("" : "+v"(v));                          // fp32 product first, then a separate rounding to fp16 (no v_fma_mixlo)
+    v = (float)(_Float16)v;
+    v = fminf(fmaxf(v, -128.f), 127.f);
+    return (int8_t)(int)rintf(v);
+}
+__device__ __forceinline__ float block_max(float v, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+    return m;
+}
+
+// one workgroup per token: row maximum, then the quantisation (the row is re-read from L2)
+template <bool BF16>
+__global__ __launch_bounds__(256) void pre_quant_token_kernel(const uint16_t *__restrict__ x, int H, int8_t *__restrict__ out,
+                                                             float *__restrict__ tok_scale)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const uint16_t *row = x + (long long)n * H;
+    float amax = 0.f;
+    for (int i = tid * 8; i < H; i += 256 * 8) {
+        const uint4 v = *(const uint4 *)(row + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(ldh<BF16>((uint16_t)(w[j >> 1] >> (16 * (j & 1))))));
+    }
+    amax = block_max(amax, red);
+    const float scale = amax / 127.0f;
+    const float inv = scale > 0.f ? 1.0f / scale : 0.f;       // an all-zero row quantises to zeros with scale 0
+    if (tid == 0) tok_scale[n] = scale;
+    for (int i = tid * 8; i < H; i += 256 * 8) {
+        const uint4 v = *(const uint4 *)(row + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j >> 2] |= ((uint32_t)(uint8_t)quant_tok(ldh<BF16>((uint16_t)(w[j >> 1] >> (16 * (j & 1)))), inv)) << (8 * (j & 3));
+        *(uint2 *)(out + (long long)n * H + i) = uint2{o[0], o[1]};
+    }
+}
+
 constexpr int kKN = 512, kKR = 64, kQ = 1536, kMid = kKN + kKR + kQ;     // 2112
 
 template <bool BF16>
@@ -83,16 +135,21 @@ __global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__r
                                                      const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
                                                      const int32_t *__restrict__ slotmapping, const uint16_t *__restrict__ qscale1_p,
                                                      const int8_t *__restrict__ qoff1_p, float eps, int8_t *__restrict__ q8, uint16_t *__restrict__ kv_cache,
-                                                     uint16_t *__restrict__ kv_cache_rope)
+                                                     uint16_t *__restrict__ kv_cache_rope, const float *__restrict__ tok_scale_in,
+                                                     float *__restrict__ tok_scale_out)
 {
     __shared__ float f[kMid];
     __shared__ float red[kMidThreads / 64];
     const int n = blockIdx.x, tid = threadIdx.x;
-    const float qscale1 = ldh<BF16>(qscale1_p[0]), qoff1 = (float)qoff1_p[0];
+    // per_token_quant_symm (tok_scale_in / tok_scale_out non-null): GEMM1 is dequantised with the token's own scale and no bias
+    // (mla_preprocess_mix_bf16.hpp:389-421), the normalised q is requantised against its own row maximum (:437-483)
+    const bool per_token = tok_scale_in != nullptr;
+    const float qscale1 = per_token ? 1.f : ldh<BF16>(qscale1_p[0]), qoff1 = per_token ? 0.f : (float)qoff1_p[0];
+    const float ts_in = per_token ? tok_scale_in[n] : 1.f;
     const int32_t *row = c1 + (long long)n * kMid;
     const long long part_stride = (long long)ntok * kMid;       // split-K partial products of GEMM1: exact int32 sum
     for (int j = tid; j < kMid; j += kMidThreads) {
-        int32_t acc = bias0 ? bias0[j] : 0;
+        int32_t acc = (bias0 && !per_token) ? bias0[j] : 0;
         int p = 0;
         for (; p + 8 <= nparts; p += 8) {               // eight independent loads in flight per step
             int32_t v[8];
@@ -102,7 +159,8 @@ __global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__r
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
         for (; p < nparts; ++p) acc += row[p * part_stride + j];
-        const float y = (float)acc * descale0[j];
+        float y = (float)acc * descale0[j];
+        if (per_token) y = y * ts_in;
         f[j] = ldh<BF16>(sth<BF16>(y));                      // the GEMM output is materialised in the I/O dtype (golden :95-107)
     }
     __syncthreads();
@@ -123,9 +181,23 @@ __global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__r
     ss = 0.f;
     for (int j = tid; j < kQ; j += kMidThreads) ss += f[kKN + kKR + j] * f[kKN + kKR + j];
     const float rq = rsqrtf(block_sum(ss, red) / (float)kQ + eps);
+    if (!per_token) {
+        for (int j = tid; j < kQ; j += kMidThreads) {
+            const float y = (f[kKN + kKR + j] * rq) * ldh<BF16>(gamma1[j]) + ldh<BF16>(beta1[j]);
+            q8[(long long)n * kQ + j] = quant_pt(y, qscale1, qoff1);
+        }
+        return;
+    }
+    float amax = 0.f;
+    for (int j = tid; j < kQ; j += kMidThreads)
+        amax = fmaxf(amax, fabsf((f[kKN + kKR + j] * rq) * ldh<BF16>(gamma1[j]) + ldh<BF16>(beta1[j])));
+    amax = block_max(amax, red);
+    const float scale = amax / 127.0f;
+    const float inv = scale > 0.f ? 1.0f / scale : 0.f;
+    if (tid == 0) tok_scale_out[n] = scale;
     for (int j = tid; j < kQ; j += kMidThreads) {
         const float y = (f[kKN + kKR + j] * rq) * ldh<BF16>(gamma1[j]) + ldh<BF16>(beta1[j]);
-        q8[(long long)n * kQ + j] = quant_pt(y, qscale1, qoff1);
+        q8[(long long)n * kQ + j] = quant_tok(y, inv);
     }
 }
 
@@ -147,12 +219,24 @@ extern "C" int mi_mla_pre_quant(const void *x, const void *scale, const int8_t *
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 
+extern "C" int mi_mla_pre_quant_token(const void *x, int tokens, int hidden, int dtype, int8_t *out, float *tok_scale, void *stream)
+{
+    if (tokens < 0 || hidden <= 0 || hidden % 8 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16)) return MI_SGL_EINVAL;
+    if (tokens == 0) return MI_SGL_OK;
+    if (!x || !out || !tok_scale) return MI_SGL_EINVAL;
+    if (dtype == MI_DTYPE_BF16) pre_quant_token_kernel<true><<<tokens, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, hidden, out, tok_scale);
+    else pre_quant_token_kernel<false><<<tokens, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x, hidden, out, tok_scale);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
 extern "C" int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bias0, const float *descale0, const void *gamma1,
                               const void *beta1, const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping,
                               const void *quant_scale1, const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8,
-                              void *kv_cache, void *kv_cache_rope, void *stream)
+                              void *kv_cache, void *kv_cache_rope, const float *tok_scale_in, float *tok_scale_out, void *stream)
 {
-    if (tokens < 0 || num_partials < 1 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || !quant_scale1 || !quant_offset1)
+    if ((tok_scale_in == nullptr) != (tok_scale_out == nullptr)) return MI_SGL_EINVAL;
+    if (tokens < 0 || num_partials < 1 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) ||
+        (!tok_scale_in && (!quant_scale1 || !quant_offset1)))
         return MI_SGL_EINVAL;
     if (tokens == 0) return MI_SGL_OK;
     if (!gemm1_i32 || !descale0 || !gamma1 || !beta1 || !gamma2 || !cos || !sin || !slotmapping || !q_int8 || !kv_cache || !kv_cache_rope)
@@ -161,7 +245,7 @@ extern "C" int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const 
     pre_mid_kernel<B><<<tokens, kMidThreads, 0, (hipStream_t)stream>>>(gemm1_i32, num_partials, tokens, bias0, descale0, (const uint16_t *)gamma1,                 \
                                                                (const uint16_t *)beta1, (const uint16_t *)gamma2, (const uint16_t *)cos, \
                                                                (const uint16_t *)sin, slotmapping, (const uint16_t *)quant_scale1, quant_offset1, eps,  \
-                                                               q_int8, (uint16_t *)kv_cache, (uint16_t *)kv_cache_rope)
+                                                               q_int8, (uint16_t *)kv_cache, (uint16_t *)kv_cache_rope, tok_scale_in, tok_scale_out)
     if (dtype == MI_DTYPE_BF16) MI_MID(true); else MI_MID(false);
 #undef MI_MID
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;

@@ -256,11 +256,11 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     (void)gamma0, (void)beta0, (void)ctkv_scale, (void)q_nope_scale;
     TORCH_CHECK(!cache_mode.has_value() || *cache_mode == "krope_ctkv", "mla_preprocess: only cache_mode='krope_ctkv' is implemented "
                 "(the int8 / NZ cache modes are Ascend layouts), got ", cache_mode.value_or(""));
-    // the reference defaults quant_mode to per_token_quant_symm (csrc/mla_preprocess/op_host/mla_preprocess.cpp:635): a caller that
-    // omits it must not silently get different arithmetic, so the default is rejected like the explicit name
-    TORCH_CHECK(quant_mode.has_value() && *quant_mode == "per_tensor_quant_asymm", "mla_preprocess: only quant_mode="
-                "'per_tensor_quant_asymm' is implemented (the reference's default, 'per_token_quant_symm', is not: pass the mode "
-                "explicitly), got ", quant_mode.has_value() ? *quant_mode : c10::string_view("None"));
+    // quant_mode: "per_tensor_quant_asymm" (the mode the reference tests cover) or "per_token_quant_symm" -- the reference's DEFAULT
+    // when the argument is omitted (csrc/mla_preprocess/op_host/mla_preprocess.cpp:634-635), so it is the default here too
+    const c10::string_view qmode = quant_mode.value_or("per_token_quant_symm");
+    TORCH_CHECK(qmode == "per_tensor_quant_asymm" || qmode == "per_token_quant_symm", "Unsupported quant_mode value: '", qmode, "'");
+    const bool per_token = qmode == "per_token_quant_symm";
     TORCH_CHECK(hiddenState.dim() == 2 && hiddenState.is_contiguous(), "hiddenState must be contiguous [tokens, hidden]");
     const int64_t N = hiddenState.size(0), hidden = hiddenState.size(1);
     TORCH_CHECK(N <= 1024, "mla_preprocess: tokenNum <= 1024 (csrc/mla_preprocess/README.md)");
@@ -281,9 +281,10 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     const int dt = dtype_code(hiddenState);
     auto dev = hiddenState.device();
     void *st = cur_stream();
-    TORCH_CHECK(quant_scale0.numel() == 1 && quant_scale1.numel() == 1 && quant_scale0.scalar_type() == hiddenState.scalar_type() &&
-                    quant_scale1.scalar_type() == hiddenState.scalar_type() && quant_offset0.numel() == 1 && quant_offset1.numel() == 1 &&
-                    quant_offset0.scalar_type() == at::kChar && quant_offset1.scalar_type() == at::kChar,
+    TORCH_CHECK(per_token ||
+                    (quant_scale0.numel() == 1 && quant_scale1.numel() == 1 && quant_scale0.scalar_type() == hiddenState.scalar_type() &&
+                     quant_scale1.scalar_type() == hiddenState.scalar_type() && quant_offset0.numel() == 1 && quant_offset1.numel() == 1 &&
+                     quant_offset0.scalar_type() == at::kChar && quant_offset1.scalar_type() == at::kChar),
                 "quant_scale0/1 must be [1] in the input dtype, quant_offset0/1 int8 [1]");
     // five launches on the caller's stream, no library GEMM (stage order of mla_preprocess_mix_bf16.hpp):
     //   quant -> INT8 GEMM1 split-K (partial products) -> sum + dequant / RMSNorm / RoPE / cache write / requant
@@ -292,20 +293,30 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     at::Tensor a8 = at::empty({N, hidden}, i8);
     const int parts = mi_mla_pre_gemm_i8_partials((int)hidden);                 // split-K partial products, summed by pre_mid
     at::Tensor c1 = at::empty({parts, N, 2112}, at::dtype(at::kInt).device(dev));
-    TORCH_CHECK(0 == mi_mla_pre_quant(hiddenState.data_ptr(), quant_scale0.data_ptr(), (const int8_t *)quant_offset0.data_ptr(), N * hidden, dt,
-                                      (int8_t *)a8.data_ptr(), st), "mi_mla_pre_quant failed");
+    // per-token mode: every row is quantised against its own maximum and carries its scale to the dequant of the following GEMM
+    at::Tensor tok0, tok1;
+    if (per_token) {
+        tok0 = at::empty({N}, at::dtype(at::kFloat).device(dev)), tok1 = at::empty({N}, at::dtype(at::kFloat).device(dev));
+        TORCH_CHECK(0 == mi_mla_pre_quant_token(hiddenState.data_ptr(), (int)N, (int)hidden, dt, (int8_t *)a8.data_ptr(), tok0.data_ptr<float>(), st),
+                    "mi_mla_pre_quant_token failed");
+    } else {
+        TORCH_CHECK(0 == mi_mla_pre_quant(hiddenState.data_ptr(), quant_scale0.data_ptr(), (const int8_t *)quant_offset0.data_ptr(), N * hidden, dt,
+                                          (int8_t *)a8.data_ptr(), st), "mi_mla_pre_quant failed");
+    }
     TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)a8.data_ptr(), (int)N, (int)hidden, (const int8_t *)wdqkv.data_ptr(), 2112, 0,
-                                        c1.data_ptr<int32_t>(), nullptr, nullptr, nullptr, dt, st), "mi_mla_pre_gemm_i8 (GEMM1) failed");
+                                        c1.data_ptr<int32_t>(), nullptr, nullptr, nullptr, nullptr, dt, st), "mi_mla_pre_gemm_i8 (GEMM1) failed");
     at::Tensor q8 = at::empty({N, 1536}, i8);
     auto iptr = [](const at::Tensor &t) -> const int32_t * { return t.numel() ? t.data_ptr<int32_t>() : nullptr; };
     TORCH_CHECK(0 == mi_mla_pre_mid(c1.data_ptr<int32_t>(), parts, iptr(bias0), descale0.data_ptr<float>(), gamma1.data_ptr(), beta1.data_ptr(),
-                                    gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(), quant_scale1.data_ptr(),
-                                    (const int8_t *)quant_offset1.data_ptr(), 1e-6f,
-                                    (int)N, dt, (int8_t *)q8.data_ptr(), kv_cache.data_ptr(), kv_cache_rope.data_ptr(), st),
+                                    gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(),
+                                    per_token ? nullptr : quant_scale1.data_ptr(), per_token ? nullptr : (const int8_t *)quant_offset1.data_ptr(),
+                                    1e-6f, (int)N, dt, (int8_t *)q8.data_ptr(), kv_cache.data_ptr(), kv_cache_rope.data_ptr(),
+                                    per_token ? tok0.data_ptr<float>() : nullptr, per_token ? tok1.data_ptr<float>() : nullptr, st),
                 "mi_mla_pre_mid failed");
     at::Tensor y2 = at::empty({N, Hq * 192}, hiddenState.options());              // GEMM2 output materialised in the I/O dtype (golden :95-107)
     TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)q8.data_ptr(), (int)N, 1536, (const int8_t *)wuq.data_ptr(), (int)(Hq * 192), 1, nullptr,
-                                        iptr(bias1), descale1.data_ptr<float>(), y2.data_ptr(), dt, st), "mi_mla_pre_gemm_i8 (GEMM2) failed");
+                                        per_token ? nullptr : iptr(bias1), descale1.data_ptr<float>(), per_token ? tok1.data_ptr<float>() : nullptr,
+                                        y2.data_ptr(), dt, st), "mi_mla_pre_gemm_i8 (GEMM2) failed");
     at::Tensor wuk_t = prepared_wuk(wuk.to(hiddenState.scalar_type()));
     TORCH_CHECK(0 == mi_mla_pre_bmm_rope(y2.data_ptr(), (int)N, (int)Hq, wuk_t.data_ptr(), cos.data_ptr(), sin.data_ptr(), dt, q_out0.data_ptr(),
                                          q_out1.data_ptr(), st), "mi_mla_pre_bmm_rope failed");

@@ -176,9 +176,63 @@ def test_mla_preprocess(N, Hq, hidden):
     assert not kv.view(-1, 512).cpu()[mask].any()
 
 
+def _mla_pre_exact_token(z, eps=1e-6):
+    """float64 evaluation of the per-token network with the kernel's rounding / quantisation points kept."""
+    dt = z["hid"].dtype
+    a8, t0 = OK._quant_per_token(z["hid"])
+    f = OK._int8_gemm_dequant_token(a8, z["wdqkv"], z["descale0"], t0, dt).double()
+    k_nope, k_pe, q = f[:, :512], f[:, 512:576], f[:, 576:]
+    rms = lambda x, g: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * g.double()
+    qn = (rms(q, z["gamma1"]) + z["beta1"].double()).float()
+    q8, t1 = OK._quant_per_token(qn)
+    y = OK._int8_gemm_dequant_token(q8, z["wuq"], z["descale1"], t1, dt)
+    y = y.view(y.shape[0], -1, 192).double()
+    c, s_ = z["cos"].double().unsqueeze(1), z["sin"].double().unsqueeze(1)
+    rot = lambda t: torch.cat([-t[..., 32:], t[..., :32]], -1)
+    kp = k_pe.unsqueeze(1)
+    return (torch.einsum("nhk,hkd->nhd", y[..., :128], z["wuk"].double()), y[..., 128:] * c + rot(y[..., 128:]) * s_,
+            rms(k_nope, z["gamma2"]), (kp * c + rot(kp) * s_).squeeze(1))
+
+
+@pytest.mark.parametrize("N,Hq,hidden", [(1, 32, 7168), (31, 128, 7168), (70, 16, 2048), (128, 128, 7168), (300, 16, 6144)])
+def test_mla_preprocess_per_token_quant(N, Hq, hidden):
+    """quant_mode='per_token_quant_symm', the reference's default.  The reference tests hold no golden for this mode, so the
+    oracle restates the kernel (oracle/kernels.py mla_preprocess_per_token: PARITY UNPINNED); same three-part bar as
+    test_mla_preprocess, plus the sanity that per-token quantisation is at least as accurate as per-tensor against the
+    unquantised float64 network would be out of scope here."""
+    dt = torch.bfloat16
+    block_size, nblocks = 128, max(4, (N + 127) // 128 + 1)
+    z = _mla_pre_inputs(N, Hq, hidden, dt)
+    z["hid"][0, :] = 0 if N > 2 else z["hid"][0, :]               # an all-zero token: scale 0, zeros out
+    slots = torch.randperm(nblocks * block_size)[:N].to(torch.int32)
+    want = OK.mla_preprocess_per_token(z["hid"], z["wdqkv"], z["descale0"], z["gamma1"], z["beta1"], z["gamma2"], z["wuq"], z["descale1"],
+                                       z["wuk"], z["cos"], z["sin"])
+    d = lambda t: t.cuda()
+    kv = torch.zeros((nblocks, block_size, 1, 512), dtype=dt, device="cuda")
+    kr = torch.zeros((nblocks, block_size, 1, 64), dtype=dt, device="cuda")
+    q0 = torch.empty((N, Hq, 512), dtype=dt, device="cuda")
+    q1 = torch.empty((N, Hq, 64), dtype=dt, device="cuda")
+    torch.ops.npu.mla_preprocess(d(z["hid"]), d(z["gamma0"]), d(z["beta0"]), d(z["wdqkv"]), d(z["descale0"]), d(z["gamma1"]), d(z["beta1"]),
+                                 d(z["wuq"]), d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), d(z["wuk"]), kv, kr, d(slots),
+                                 d(z["qs0"]), d(z["qo0"]), d(z["bias0"]), d(z["qs1"]), d(z["qo1"]), d(z["bias1"]), cache_mode="krope_ctkv",
+                                 quant_mode="per_token_quant_symm", q_out0=q0, kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr)
+    k_nope = kv.view(-1, 512)[slots.long().cuda()].cpu()
+    k_pe = kr.view(-1, 64)[slots.long().cuda()].cpu()
+    exact = _mla_pre_exact_token(z)
+    for name, g, w, ex in zip(("q_out0", "q_out1", "k_nope", "k_pe"), (q0.cpu(), q1.cpu(), k_nope, k_pe), want, exact):
+        assert torch.isfinite(g.float()).all(), name
+        g64, w64 = g.double(), w.double()
+        bad = ~torch.isclose(g64, w64, rtol=1e-3, atol=1e-3)
+        assert bad.double().mean().item() <= 2e-3, (name, bad.double().mean().item())
+        assert torch.allclose(g64, w64, rtol=2 ** -5, atol=5e-2), (name, (g64 - w64).abs().max().item())
+        err_k, err_o = (g64 - ex).abs().mean().item(), (w64 - ex).abs().mean().item()
+        assert err_k <= 1.05 * err_o + 1e-7, (name, err_k, err_o)
+    assert torch.equal(k_pe, want[3])
+
+
 def test_mla_preprocess_rejects_modes_it_does_not_implement():
-    """cache modes 2 / 3 are Ascend NZ cache layouts; quant_mode=None means per_token_quant_symm in the reference
-    (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-612,634-635): both must fail loudly, never run other arithmetic."""
+    """cache modes 2 / 3 are Ascend NZ cache layouts (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-612): they and unknown
+    quant modes must fail loudly; an omitted quant_mode selects per_token_quant_symm, as in the reference (:634-635)."""
     dt = torch.bfloat16
     z = _mla_pre_inputs(2, 16, 2048, dt)
     d = lambda t: t.cuda()
@@ -190,12 +244,14 @@ def test_mla_preprocess_rejects_modes_it_does_not_implement():
             d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), d(z["wuk"]), kv, kr, slots, d(z["qs0"]), d(z["qo0"]), d(z["bias0"]),
             d(z["qs1"]), d(z["qo1"]), d(z["bias1"]))
     outs = dict(q_out0=q0, kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr)
-    for bad in (dict(cache_mode="krope_ctkv"), dict(cache_mode="krope_ctkv", quant_mode="per_token_quant_symm"),
-                dict(cache_mode="int8_nzcache", quant_mode="per_tensor_quant_asymm"),
+    for bad in (dict(cache_mode="krope_ctkv", quant_mode="per_channel"), dict(cache_mode="int8_nzcache", quant_mode="per_tensor_quant_asymm"),
                 dict(cache_mode="nzcache", quant_mode="per_tensor_quant_asymm")):
         with pytest.raises(RuntimeError):
             torch.ops.npu.mla_preprocess(*args, **bad, **outs)
-    torch.ops.npu.mla_preprocess(*args, cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", **outs)      # the built mode runs
+    torch.ops.npu.mla_preprocess(*args, cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", **outs)      # the built modes run
+    a = torch.ops.npu.mla_preprocess(*args, quant_mode="per_token_quant_symm", **outs)[0].clone()
+    b = torch.ops.npu.mla_preprocess(*args, **outs)[0]              # omitted quant_mode == the reference's default, per-token
+    assert torch.equal(a, b)
 
 
 def _sgl_lib():
@@ -203,7 +259,7 @@ def _sgl_lib():
     from capi import load
     L = load("libmi_sgl_kernels.so")
     V, I = ctypes.c_void_p, ctypes.c_int
-    L.mi_mla_pre_gemm_i8.argtypes = [V, I, I, V, I, I, V, V, V, V, I, V]
+    L.mi_mla_pre_gemm_i8.argtypes = [V, I, I, V, I, I, V, V, V, V, V, I, V]
     L.mi_mla_pre_bmm_rope.argtypes = [V, I, I, V, V, V, I, V, V, V]
     L.mi_mla_pre_gemm_i8_partials.argtypes = [I]
     L.mi_mla_pre_gemm_i8.restype = L.mi_mla_pre_bmm_rope.restype = L.mi_mla_pre_gemm_i8_partials.restype = I
@@ -225,16 +281,22 @@ def test_mla_pre_skinny_int8_gemm_exact(M, K, N):
     parts = L.mi_mla_pre_gemm_i8_partials(K)
     assert parts == (K + 511) // 512
     c = torch.full((parts, M, N), 12345, dtype=torch.int32, device="cuda")      # no zero-fill needed: every slice is overwritten
-    assert L.mi_mla_pre_gemm_i8(ptr(a), M, K, ptr(w), N, 0, ptr(c), None, None, None, 0, stream_ptr()) == 0
+    assert L.mi_mla_pre_gemm_i8(ptr(a), M, K, ptr(w), N, 0, ptr(c), None, None, None, None, 0, stream_ptr()) == 0
     torch.cuda.synchronize()
     assert torch.equal(c.double().sum(0), want)
     bias = torch.randint(-50, 50, (N,), generator=g, device="cuda", dtype=torch.int32)
     descale = torch.rand(N, generator=g, device="cuda") * 1e-3 + 5e-4
     for dtype, code in ((torch.bfloat16, 0), (torch.float16, 1)):
         y = torch.zeros((M, N), dtype=dtype, device="cuda")
-        assert L.mi_mla_pre_gemm_i8(ptr(a), M, K, ptr(w), N, 1, None, ptr(bias), ptr(descale), ptr(y), code, stream_ptr()) == 0
+        assert L.mi_mla_pre_gemm_i8(ptr(a), M, K, ptr(w), N, 1, None, ptr(bias), ptr(descale), None, ptr(y), code, stream_ptr()) == 0
         torch.cuda.synchronize()
         y_want = ((want.to(torch.int32) + bias).float() * descale).to(dtype)
+        assert torch.equal(y.view(torch.int16), y_want.view(torch.int16)), dtype
+        # per-token form: no bias, (channel scale) then (token scale), one rounding
+        rs = torch.rand(M, generator=g, device="cuda") * 0.05 + 0.01
+        assert L.mi_mla_pre_gemm_i8(ptr(a), M, K, ptr(w), N, 1, None, None, ptr(descale), ptr(rs), ptr(y), code, stream_ptr()) == 0
+        torch.cuda.synchronize()
+        y_want = ((want.float() * descale) * rs[:, None]).to(dtype)
         assert torch.equal(y.view(torch.int16), y_want.view(torch.int16)), dtype
 
 
