@@ -500,14 +500,20 @@ def main():
     for tr in transports:
         if tr is not None:
             buf.runtime.set_dispatch_transport(tr)
-        dt, prof, err = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, args.warmup, windowed)
+        # the timed region: exactly K steps, no instrumentation.  Kernel durations (roofline) come from a SECOND pass of the same
+        # K steps with a HIP event pair around every kernel: each pair costs ~10 us of bubble at a kernel boundary (0.396 -> 0.448 ms
+        # per step measured), which must not be charged to the hot path; that pass's own time is reported as profiled_ms_per_step.
+        dt, _, err = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, args.warmup, False)
+        prof, dt_prof = {}, None
+        if err is None and windowed:
+            dt_prof, prof, err = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, 0, True)
         if err is None:
-            runs[tr] = (dt, prof)
+            runs[tr] = (dt, prof, dt_prof)
         elif rank == 0:
             print(f"[bench] transport {tr} failed: {err}", file=sys.stderr)
     assert runs, "no dispatch transport completed"
     best = min(runs, key=lambda k: runs[k][0])
-    dt, prof = runs[best]
+    dt, prof, dt_prof = runs[best]
     if best is not None:
         buf.runtime.set_dispatch_transport(best)
     rows = torch.tensor([n_recv], device="cuda", dtype=torch.float64)
@@ -542,6 +548,7 @@ def main():
                    "strategy": strategy, "dispatch_transport": best, "tokens_per_rank": T, "hidden": HIDDEN, "topk": TOPK,
                    "experts": EXPERTS, "cache_flush": "256 MB write before the timed region"},
         "per_gpu_GBps": value / world, "validated_round_trip": bool(validated),
+        "profiled_ms_per_step": dt_prof / args.steps * 1e3 if dt_prof else None,     # second pass of K steps with HIP events (roofline)
     }
     if len(runs) > 1:
         result["transports"] = {k: {"ms_per_step": v[0] / args.steps * 1e3, "value": bytes_per_step / (v[0] / args.steps) / 1e9}
@@ -554,6 +561,7 @@ def main():
         alg = kb(dom)
         achieved = alg / (per[dom]["avg_us"] * 1e-6) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "timing": f"HIP event pairs on the kernels' stream, {args.steps} launches, pass right after the timed region",
                               "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom) if world == 1 else None,
                               "algorithmic_bytes": alg, "avg_launch_us": per[dom]["avg_us"]}
         result["kernels"] = {k: dict(per[k], GBps=kb(k) / (per[k]["avg_us"] * 1e-6) / 1e9) for k in bulk}
