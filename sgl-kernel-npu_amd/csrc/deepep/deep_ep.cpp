@@ -900,8 +900,9 @@ std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &x, const 
         if (s.scalar_type() == at::kLong) return s.to(at::kInt).contiguous().view(at::kFloat);   // fp32 bits carried in int64
         return s.to(at::kFloat).contiguous();
     };
-    at::Tensor s1 = as_f32(scale1).reshape({L, N1}).index_select(1, fusion_perm()).contiguous();
-    at::Tensor s2 = as_f32(scale2).reshape({L, H}).contiguous();
+    // the re-laid-out scales are layer constants like the weights: prepared once and kept
+    at::Tensor s1 = prepared_weight(scale1, 3, [&] { return as_f32(scale1).reshape({L, N1}).index_select(1, fusion_perm()).contiguous(); });
+    at::Tensor s2 = prepared_weight(scale2, 4, [&] { return as_f32(scale2).reshape({L, H}).contiguous(); });
     at::Tensor topk_weights = expert_scales->to(at::kFloat).contiguous();
     // every rank may send at most max(T over ranks) tokens; the caller's bound is rows received = max_bs * W * K
     int64_t per_rank = (max_output_size + (int64_t)W * K - 1) / ((int64_t)W * K);

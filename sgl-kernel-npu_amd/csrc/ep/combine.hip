@@ -220,7 +220,8 @@ extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const i
         pp.p[i] = dst_base_host[i];
     }
     long long blocks = ((long long)rows_hint + kPushWaves - 1) / kPushWaves;        // one row per wave until the chip is full
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    static const long long cap = getenv("MI_EP_PUSH_BLOCKS") ? atoll(getenv("MI_EP_PUSH_BLOCKS")) : 256 * 8;
+    if (blocks > cap) blocks = cap;
     combine_push_kernel<<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
         (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp,
         make_parity(epoch_ctr, 1, parity_stride),

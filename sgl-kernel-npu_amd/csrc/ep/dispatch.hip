@@ -15,6 +15,8 @@
 //    at the same time; 8 x 16 B per lane in flight.
 // HBM roofline (per rank, algorithmic): stage reads T*H*2 and writes n_pairs*(H+16); pull reads and
 // writes n_recv*(H+16).
+#include <stdlib.h>
+
 #include "ep_common.h"
 
 namespace mi_ep {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
 // selected expert): plain loads, so the local ones come from L2 / MALL after the first touch.
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int W, int LW,
-    int payload_bytes, size_t idx_off, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
+    int payload_bytes, size_t idx_off, size_t idx_entries, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
     int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
@@ -350,7 +352,9 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         }
         const int j = (int)(r - (lo ? cum[lo - 1] : 0));
         src = lo % W;
-        return ((const uint2 *)((const uint8_t *)srcs.p[src] + poff + idx_off))[(size_t)pull_offset[lo] + j];
+        // a corrupt count / offset must not turn into a wild (possibly cross-GPU) read: the index holds idx_entries entries
+        const size_t pos = min((size_t)max(pull_offset[lo] + j, 0), idx_entries - 1);
+        return ((const uint2 *)((const uint8_t *)srcs.p[src] + poff + idx_off))[pos];
     };
     long long r = (long long)blockIdx.x * kPullWaves + wave;
     int src_n = 0;
@@ -531,11 +535,12 @@ extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, con
     if (idx_off == 0) return MI_EP_EINVAL;
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
     long long blocks = ((long long)rows_hint + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    static const long long cap = getenv("MI_EP_PULL_BLOCKS") ? atoll(getenv("MI_EP_PULL_BLOCKS")) : 256 * 8;
+    if (blocks > cap) blocks = cap;
     const size_t lds = (size_t)L * W * sizeof(int32_t);
     pull_indexed_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
-        pp, recv_count, pull_offset, W, L * W, payload, idx_off, (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint,
-        make_parity(epoch_ctr, 0, parity_stride));
+        pp, recv_count, pull_offset, W, L * W, payload, idx_off, (idx_off / mi_ep_dispatch_row_bytes(H, quant_mode)) * (size_t)K,
+        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, make_parity(epoch_ctr, 0, parity_stride));
     return launch_status();
 }
 
