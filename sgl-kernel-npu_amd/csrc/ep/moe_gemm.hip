@@ -26,7 +26,9 @@
 namespace mi_ep {
 
 constexpr int BN = 256, BK = 64;
-constexpr int kStages = 4;
+// ring depth of the operand stages: 4 x 64-byte k-tiles (4 x 32 KB for the 256-row tile, 4 x 20 KB for the 64-row tile), 3 x 128-byte
+// k-tiles (3 x 40 KB) for the decode tile when K allows it
+template <int BKT> struct RingDepth { static constexpr int value = BKT == 128 ? 3 : 4; };
 constexpr int kGemmThreads = 1024;
 constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -48,8 +50,14 @@ struct GemmArgs {
     int slot_rows;            // rows one combine region holds: (t, k) outside it are dropped
 };
 
-// byte offset of 16-B chunk `chunk` (0..3) of row `row` inside a [rows][64 B] tile
-__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// position (16-B units) of k-chunk `chunk` inside row `row` of a [rows][BKT B] tile.  A ds_read_b128 of 16 consecutive rows at one chunk
+// then covers all 64 banks: 64-B rows -- 4 rows span the banks, the position rotates every 4 rows; 128-B rows -- 2 rows span the banks, the
+// position rotates every 2 rows.
+template <int BKT> __device__ __forceinline__ int swz_pos(int row, int chunk)
+{
+    return BKT == 64 ? (chunk ^ ((row >> 2) & 3)) : (chunk ^ ((row >> 1) & 7));
+}
+template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) { return row * BKT + (swz_pos<BKT>(row, chunk) << 4); }
 
 // LDS-DMA through inline asm (the compiler then places no vmcnt wait of its own; ordering is the explicit vmcnt below).
 // Lane l moves 16 B from its own address to dst + 16 l; M0 carries the wave-uniform LDS destination.
@@ -64,14 +72,23 @@ __device__ float g_gemm_dbg[256];
 
 // MT = MFMA row tiles per wave: 4 -> 256-row workgroup tile (prefill-size groups), 1 -> 64-row tile (decode-size groups:
 // the weights stream once either way, the small tile just stops multiplying padding).
+// BKT = bytes of K per stage: 64, or 128 for the decode tile -- a decode-size group is a pure weight stream, and with 64-byte k-tiles
+// every request touches half a 128-byte line of a weight row (the other half comes a stage later): 3.8-5.1 TB/s.  A deeper ring did not
+// move that (7 x 20 KB measured the same as 4 x 20 KB), whole lines per request did (GEMM1 184 -> 169 us, GEMM2 124 -> 114 us at 128
+// tokens x 32 experts; a 2-deep ring of 128-byte k-tiles, two workgroups per CU, gave 185 / 121 us).
 // one (expert, m-tile) x 256-column tile; `slot` = index of the tile in (expert, row block) order.  Returns false when the slot lies
 // past the last tile (workgroup-uniform).
-template <int MODE, int MT>
+template <int MODE, int MT, int BKT>
 __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint8_t *lds)
 {
     constexpr int BM = 64 * MT;
-    constexpr int kStageBytes = (BM + BN) * BK;
-    constexpr int kAPieces = BM / 16;                 // DMA instructions (16 rows x 64 B) for the A tile of a stage
+    constexpr int kStages = RingDepth<BKT>::value;
+    constexpr int kStageBytes = (BM + BN) * BKT;
+    constexpr int kPieceRows = 1024 / BKT;            // rows one DMA instruction (64 lanes x 16 B) covers
+    constexpr int kChunks = BKT / 16;                 // 16-B chunks per row
+    constexpr int kAPieces = BM / kPieceRows;         // DMA instructions for the A tile of a stage (<= 16: at most one per wave)
+    constexpr int kBPerWave = BN / kPieceRows / 16;   // B pieces every wave issues per stage
+    static_assert(kAPieces <= 16 && kBPerWave >= 1, "DMA plan");
 #ifdef GEMM_TIMING
     const uint64_t t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -120,21 +137,27 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
     const int8_t *wbase = p.w + (size_t)e * p.N * p.K;
     const int8_t *abase = p.a + (size_t)row0 * p.K;
 
-    // ---- DMA plan: 32 instructions per stage (A: 16 x 16 rows, B: 16 x 16 rows); wave w issues A piece w and B piece w
+    // ---- DMA plan: one instruction moves kPieceRows rows x BKT bytes (1 KB); wave w issues A piece w (if there is one) and B pieces
+    // w, w + 16, ...
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
-    const int8_t *srcA, *srcB;
+    const int8_t *srcA, *srcB[kBPerWave];
     {
-        const int row = 16 * wave + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);  // swizzle on the source side
+        const int row = kPieceRows * wave + lane / kChunks;
+        const int chunk = swz_pos<BKT>(row, lane % kChunks);                      // swizzle on the source side (an involution)
         srcA = abase + (size_t)min(row, rows - 1) * p.K + chunk * 16;             // rows past the group: any valid row
-        srcB = wbase + (size_t)min(n0 + row, p.N - 1) * p.K + chunk * 16;
+#pragma unroll
+        for (int j = 0; j < kBPerWave; ++j) {
+            const int brow = row + j * 16 * kPieceRows;                           // 128 rows further: the same swizzle term
+            srcB[j] = wbase + (size_t)min(n0 + brow, p.N - 1) * p.K + chunk * 16;
+        }
     }
-    const int nk = p.K / BK;
+    const int nk = p.K / BKT;
     auto issue_stage = [&](int kt) {
-        const int kc = min(kt, nk - 1) * BK;              // past the end: a harmless refill keeps the vmcnt arithmetic uniform
+        const int kc = min(kt, nk - 1) * BKT;             // past the end: a harmless refill keeps the vmcnt arithmetic uniform
         const uint32_t sbase = lds_base + (uint32_t)((kt % kStages) * kStageBytes + wave * 1024);
         if (wave < kAPieces) dma16(sbase, srcA + kc);     // wave-uniform
-        dma16(sbase + (uint32_t)(BM * BK), srcB + kc);
+#pragma unroll
+        for (int j = 0; j < kBPerWave; ++j) dma16(sbase + (uint32_t)(BM * BKT + j * 16 * 1024), srcB[j] + kc);
     };
 
     i32x4 acc[MT][4];
@@ -143,48 +166,55 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
 
-    // LDS byte offsets of this lane's operand fragments inside a stage (k-step = the whole 64-B row: chunk g)
-    int aoff[MT], boff[4];
+    // LDS byte offsets of this lane's operand fragments inside a stage (k-step ks = 64 bytes of the row: chunk 4 ks + g)
+    constexpr int kSteps = BKT / 64;
+    int aoff[kSteps][MT], boff[kSteps][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) aoff[mt] = swz(wm * 16 * MT + mt * 16 + c16, g);
+    for (int ks = 0; ks < kSteps; ++ks) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        int brow;
-        if (MODE == 0) brow = (wn >> 1) * 128 + (nt >> 1) * 64 + (wn & 1) * 32 + (nt & 1) * 16 + c16;   // nt 0,1 gate; 2,3 up
-        else brow = wn * 64 + nt * 16 + c16;
-        boff[nt] = BM * BK + swz(brow, g);
+        for (int mt = 0; mt < MT; ++mt) aoff[ks][mt] = swz<BKT>(wm * 16 * MT + mt * 16 + c16, 4 * ks + g);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int brow;
+            if (MODE == 0) brow = (wn >> 1) * 128 + (nt >> 1) * 64 + (wn & 1) * 32 + (nt & 1) * 16 + c16;   // nt 0,1 gate; 2,3 up
+            else brow = wn * 64 + nt * 16 + c16;
+            boff[ks][nt] = BM * BKT + swz<BKT>(brow, 4 * ks + g);
+        }
     }
 
 #ifdef GEMM_TIMING
     uint64_t tw = 0, tc = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
     const uint64_t t_loop = c0;
 #endif
-    issue_stage(0);
-    issue_stage(1);
-    issue_stage(2);
+#pragma unroll
+    for (int st = 0; st < kStages - 1; ++st) issue_stage(st);
     for (int kt = 0; kt < nk; ++kt) {
 #ifdef GEMM_TIMING
         c0 = __builtin_amdgcn_s_memtime();
 #endif
-        // own pieces of stage kt landed; those of stages kt+1, kt+2 may still fly (2 per stage, 1 for waves without an A piece)
-        if (wave < kAPieces) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // own pieces of stage kt landed; those of the kStages - 2 younger stages may still fly (kBPerWave per stage, one more for
+        // the waves with an A piece)
+        if (wave < kAPieces) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kBPerWave + 1) * (kStages - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kBPerWave * (kStages - 2)) : "memory");
         __syncthreads();                                    // stage kt complete; the slot of stage kt-1 is free
 #ifdef GEMM_TIMING
         c1 = __builtin_amdgcn_s_memtime(); tw += c1 - c0; c0 = c1;
 #endif
-        issue_stage(kt + 3);
+        issue_stage(kt + kStages - 1);
         const uint8_t *buf = lds + (kt % kStages) * kStageBytes;
-        i32x4 af[MT], bf[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const i32x4 *)(buf + aoff[mt]);
+        for (int ks = 0; ks < kSteps; ++ks) {
+            i32x4 af[MT], bf[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bf[nt] = *(const i32x4 *)(buf + boff[nt]);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const i32x4 *)(buf + aoff[ks][mt]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int nt = 0; nt < 4; ++nt) bf[nt] = *(const i32x4 *)(buf + boff[ks][nt]);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
 #ifdef GEMM_TIMING
         c1 = __builtin_amdgcn_s_memtime(); tc += c1 - c0;
 #endif
@@ -299,12 +329,12 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
 // at EP = 8 allocates W x max_tokens x K rows, 8x what arrives under balanced routing) one workgroup per possible tile would
 // launch thousands that only look up "no such tile" and exit.  Worker y takes tile slots y, y + gridDim.y, ... until the
 // cumulative counts say there are no more.
-template <int MODE, int MT>
+template <int MODE, int MT, int BKT>
 __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x 64 B + B 16 KB)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x BKT + B 256 x BKT)
     for (int slot = blockIdx.y;; slot += gridDim.y) {
-        if (!gemm_tile<MODE, MT>(p, slot, lds)) break;
+        if (!gemm_tile<MODE, MT, BKT>(p, slot, lds)) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
         __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
     }
@@ -365,22 +395,22 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const float *__restrict__
 
 using namespace mi_ep;
 
-template <int MODE, int MT>
+template <int MODE, int MT, int BKT>
 static void gemm_launch_one(const GemmArgs &p, void *stream)
 {
     constexpr int BM = 64 * MT;
-    constexpr int ring = kStages * (BM + BN) * BK, epi = 16 * 16 * MT * kEpiRowBytes;      // operand ring | epilogue tiles of 16 waves
+    constexpr int ring = RingDepth<BKT>::value * (BM + BN) * BKT, epi = 16 * 16 * MT * kEpiRowBytes;      // operand ring | epilogue tiles of 16 waves
     constexpr int lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)grouped_gemm_i8_kernel<MODE, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)grouped_gemm_i8_kernel<MODE, MT, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles_max = (p.M_cap + BM - 1) / BM + p.L;        // every expert may end in a partial tile
     const int gx = (p.N + BN - 1) / BN;
     const int pool = 2048 / gx > 8 ? 2048 / gx : 8;             // ~8 workgroups per CU in flight over the launch; the rest is looped
     dim3 grid(gx, tiles_max < pool ? tiles_max : pool);
-    grouped_gemm_i8_kernel<MODE, MT><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(p);
+    grouped_gemm_i8_kernel<MODE, MT, BKT><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(p);
 }
 
 struct PushArgs {
@@ -408,9 +438,17 @@ static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const in
         p.par = push->par, p.slot_rows = push->slot_rows;
         mode = 2;
     }
-    if (mode == 0) { if (small) gemm_launch_one<0, 1>(p, stream); else gemm_launch_one<0, 4>(p, stream); }
-    else if (mode == 1) { if (small) gemm_launch_one<1, 1>(p, stream); else gemm_launch_one<1, 4>(p, stream); }
-    else { if (small) gemm_launch_one<2, 1>(p, stream); else gemm_launch_one<2, 4>(p, stream); }
+    const bool wide_k = small && K % 128 == 0;             // decode tile with whole 128-byte lines per request
+#define MI_GEMM_DISPATCH(M)                                                          \
+    do {                                                                             \
+        if (wide_k) gemm_launch_one<M, 1, 128>(p, stream);                           \
+        else if (small) gemm_launch_one<M, 1, 64>(p, stream);                        \
+        else gemm_launch_one<M, 4, 64>(p, stream);                                   \
+    } while (0)
+    if (mode == 0) MI_GEMM_DISPATCH(0);
+    else if (mode == 1) MI_GEMM_DISPATCH(1);
+    else MI_GEMM_DISPATCH(2);
+#undef MI_GEMM_DISPATCH
     return launch_status();
 }
 

@@ -97,6 +97,7 @@ ORACLE_CASES = [
     ([300, 1, 0, 257, 256, 511], 512, 256, 4, 64),    # same on the 64-row tile
     ([130] * 3 + [0] * 70 + [3, 260], 128, 128, 1, 200),   # > 64 experts: the tile lookup needs its second 64-expert step
     ([97, 33], 1024, 384, 1, 97),                 # 2I = 768 = 3 x 256-column tiles, I not a multiple of 256
+    ([5, 0, 1, 70, 33], 256, 192, 1, 16),         # GEMM2's K = 192 is no multiple of 128: 64-row tile with 64-byte k-tiles
 ]
 
 
