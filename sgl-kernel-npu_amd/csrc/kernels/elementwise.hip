@@ -28,9 +28,7 @@ template <bool BF16>
 __device__ __forceinline__ uint32_t st16(float f)
 {
     if constexpr (BF16) {
-        uint32_t x = __float_as_uint(f);
-        if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
-        return (x + 0x7FFFu + ((x >> 16) & 1u)) >> 16;
+        return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);      // v_cvt_pk_bf16_f32: round to nearest even in one instruction
     } else {
         return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
     }
@@ -49,8 +47,21 @@ __device__ __forceinline__ u32x4 pack8(const float *f)
 {
     u32x4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = st16<BF16>(f[2 * j]) | (st16<BF16>(f[2 * j + 1]) << 16);
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (BF16) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            v[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f[2 * j], f[2 * j + 1]}, bf16x2));   // one v_cvt_pk_bf16_f32
+        } else {
+            v[j] = st16<BF16>(f[2 * j]) | (st16<BF16>(f[2 * j + 1]) << 16);
+        }
+    }
     return v;
+}
+// v of the lane selected by DPP control CTRL (quad_perm / row_ror / row_mirror ...), all rows and banks enabled
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -304,7 +315,11 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_kernel(
 // Each wave handles kVecUnroll groups of 64*8/head_dim heads; ALL loads of all groups (x, norm weight / bias, sin, cos) are
 // issued before any arithmetic, so a lane has up to 5 x kVecUnroll independent 16-byte loads in flight instead of a chain of
 // three dependent round trips per kilobyte (the first version ran at 37 % of HBM).
-constexpr int kVecUnroll = 4;
+// Round 2 (4096 x 8192, kernel time from rocprofv3): 38 -> 29 us = 4.6 TB/s: 32-bit index arithmetic instead of four 64-bit divisions
+// per lane, v_cvt_pk_bf16_f32, DPP for the head reduction and the RoPE partner, two groups per wave (58 VGPRs, 8 waves per SIMD).
+// Measured and dropped: a grid-stride loop over 2048 workgroups (31.8), NEOX / NORM as template parameters plus a copy path for
+// all-V groups (31.5), sharing one sin / cos load between the groups of a wave (31.4; with the selection deferred to the use: 36).
+constexpr int kVecUnroll = 2;
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
@@ -314,12 +329,13 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v)
 {
     const int lane = threadIdx.x & 63;
-    const int gl = head_dim >> 3;                      // lanes per head (8 .. 32)
-    const int heads_per_wave = 64 / gl;
+    const int gl = head_dim >> 3;                      // lanes per head (8 .. 32), a power of two
+    const int gl_shift = 31 - __builtin_clz(gl);
+    const int heads_per_wave = 64 >> gl_shift;
     const int q_heads = q_hidden / head_dim, kv_heads = kv_hidden / head_dim;
     const int heads_total = q_heads + 2 * kv_heads;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int j = lane % gl;                           // chunk of 8 elements inside the head
+    const int j = lane & (gl - 1);                     // chunk of 8 elements inside the head
     const long long total_hidden = (long long)q_hidden + 2ll * kv_hidden;
     const int half = rope_dim >> 1;
     const bool roped = j * 8 < rope_dim;
@@ -331,9 +347,12 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     u32x4 xr[kVecUnroll], wr[kVecUnroll], br[kVecUnroll], sr[kVecUnroll], cr[kVecUnroll];
 #pragma unroll
     for (int u = 0; u < kVecUnroll; ++u) {
-        const long long hglobal = (wid * kVecUnroll + u) * heads_per_wave + lane / gl;
-        row[u] = hglobal / heads_total;
-        h[u] = (int)(hglobal % heads_total);
+        // 32-bit index arithmetic (the launcher checks rows x heads < 2^31): four 64-bit divisions per lane were a large part of
+        // this kernel's instruction stream
+        const uint32_t hglobal = ((uint32_t)wid * kVecUnroll + u) * heads_per_wave + (lane >> gl_shift);
+        const uint32_t r32 = hglobal / (uint32_t)heads_total;
+        row[u] = r32;
+        h[u] = (int)(hglobal - r32 * (uint32_t)heads_total);
         active[u] = row[u] < rows;
         const bool is_v = h[u] >= q_heads + kv_heads, is_q = h[u] < q_heads;
         const bool normed = active[u] && !is_v;
@@ -360,7 +379,14 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             float ss = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-            for (int off = gl >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            // sum over the head's gl lanes with DPP moves (one VALU instruction per step instead of a ds_bpermute round trip).  The
+            // operand pairs are those of the xor tree (each step adds the two partial sums of sibling lane groups), so the result
+            // is bit-identical to it.
+            ss += dpp_f32<0xB1>(ss);                        // quad_perm [1,0,3,2]: lane ^ 1
+            ss += dpp_f32<0x4E>(ss);                        // quad_perm [2,3,0,1]: lane ^ 2
+            ss += dpp_f32<0x141>(ss);                       // row_half_mirror: the other quad of the 8-lane group
+            if (gl >= 16) ss += dpp_f32<0x140>(ss);         // row_mirror: the other half of the 16-lane row
+            if (gl == 32) ss += __shfl_xor(ss, 16, 64);
             if (active[u] && !is_v) {
                 const float rstd = 1.0f / sqrtf(ss / (float)head_dim + eps);
                 float wv[8];
@@ -381,8 +407,13 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             const bool lower = (j * 8) < half;
             const int partner = lower ? lane + dl : lane - dl;
             float px[8];
+            if (dl == 8) {                                 // rope_dim 128: the partner is lane ^ 8 = a rotation by 8 inside the 16-lane row
 #pragma unroll
-            for (int e = 0; e < 8; ++e) px[e] = __shfl(x[e], partner & 63, 64);
+                for (int e = 0; e < 8; ++e) px[e] = dpp_f32<0x128>(x[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) px[e] = __shfl(x[e], partner & 63, 64);
+            }
             if (active[u] && !is_v && roped) {
                 float sv[8], cv[8];
                 unpack8<BF16>(sr[u], sv);
@@ -547,7 +578,8 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
         return MI_SGL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int heads_total = (q_hidden + 2 * kv_hidden) / head_dim;
-    const bool vec_ok = head_dim >= 64 && head_dim <= 256 && (neox ? rope_dim % 16 == 0 : rope_dim % 8 == 0);
+    const bool vec_ok = head_dim >= 64 && head_dim <= 256 && (neox ? rope_dim % 16 == 0 : rope_dim % 8 == 0) &&
+                        (long long)rows * heads_total < (1ll << 31) - 4096;
     if (vec_ok) {
         const long long heads = (long long)rows * heads_total;
         const int hpw = 64 / (head_dim / 8);
