@@ -220,13 +220,19 @@ int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, int idx_is_i3
  *   send_data_offset / send_token_idx_small: both NULL for the window layout above. */
 /* push: rows >= min(*total_rows_dev, rows_hint) are not touched; a triple outside [0,W) x slots of `slot_region_bytes`
  * (0 = unchecked) x [0,K) is dropped instead of becoming a wild cross-GPU store. */
+/* Rows that do not travel (local_row != NULL on the push, x_local != NULL on the reduce): a row whose token lives on this rank
+ * (src == my_rank) is not copied into the window; the push stores its row number r at local_row[t*K + k] and the reduce reads
+ * selection (t, k) -- expert idx[t,k] / (num_experts / num_ranks) == my_rank -- from x_local [local_rows, H] row local_row[t*K + k]
+ * (clamped into x_local).  Same values, same k-ascending order: bit-identical to the all-through-the-window path; saves the read
+ * + write of the push and reads the same bytes in the reduce (all of the combine traffic at EP = 1, 1/W of it at EP = W).
+ * Not available with the all-to-all slot layout (send_data_offset != NULL). */
 int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
                        int hidden, int num_topk, void *const *dst_base_host, int num_ranks, size_t slot_region_bytes,
-                       const uint64_t *epoch_ctr, size_t parity_stride, void *stream);
+                       const uint64_t *epoch_ctr, size_t parity_stride, int my_rank, int32_t *local_row, void *stream);
 int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                          const int32_t *send_data_offset, const int32_t *send_token_idx_small, int num_tokens,
                          int num_topk, int hidden, int num_experts, void *out, const uint64_t *epoch_ctr, size_t parity_stride,
-                         void *stream);
+                         const void *x_local, const int32_t *local_row, int local_rows, int my_rank, int num_ranks, void *stream);
 /* All-to-all (RCCL) transport helper: reorder x [R,H] bf16 from dispatch order (local expert, src, j) into
  * per-source blocks (src, local expert, j) -- each block is what that source staged for this rank, in its
  * send-slot order, so it can be returned as one contiguous message.  send_head [L*W] = recv_count of the

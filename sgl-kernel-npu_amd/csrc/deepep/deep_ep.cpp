@@ -590,13 +590,16 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
         MI_EP_CHECK(mi_ep_timestamp((uint64_t *)t_start.data_ptr(), st));
     }
     // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
+    // rows whose token lives on this rank stay where they are: the push only records their row number, the reduce reads x
+    auto local_row = combine_local_rows(topk_idx);
     { ProfScope ps_(this, "combine_push", st);
       MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1), (int)x.size(0), H, K,
-                                     dst_peers.data(), W, region_bytes, epoch_ctr(kCombine), region_bytes, st)); }
+                                     dst_peers.data(), W, region_bytes, epoch_ctr(kCombine), region_bytes, (int)rank,
+                                     local_row.defined() ? local_row.data_ptr<int>() : nullptr, st)); }
     if (combine_send_cost_stats.has_value())
         MI_EP_CHECK(mi_ep_elapsed_add(combine_send_cost_stats->data_ptr<int>(), W, (const uint64_t *)t_start.data_ptr(), st));
     return {combine_finish(topk_idx, topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, H, E, x.options(),
-                           "combine_reduce", st),
+                           "combine_reduce", st, x, local_row),
             std::nullopt, std::nullopt};
 }
 
@@ -695,19 +698,31 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     hipStream_t st = cur_stream();
     auto dst_peers = peer_family_bases(kCombine);
     // valid packed rows = layout_range[L*W-1], read on device
+    auto local_row = combine_local_rows(topk_idx);
     { ProfScope ps_(this, "ll_combine_push", st);
       MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
                                      (int)std::min<int64_t>(x.size(0), src_info.numel() / 3), H, K, dst_peers.data(), W, region_bytes,
-                                     epoch_ctr(kCombine), region_bytes, st)); }
+                                     epoch_ctr(kCombine), region_bytes, (int)rank,
+                                     local_row.defined() ? local_row.data_ptr<int>() : nullptr, st)); }
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
-    return {combine_finish(topk_idx, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st), std::nullopt,
-            std::function<void()>([] {})};
+    return {combine_finish(topk_idx, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st, x, local_row),
+            std::nullopt, std::function<void()>([] {})};
 }
 
 // second half of a combine: "my rows are pushed" to every owner, wait for every expert rank (ONE single-wave launch, which also
 // completes the family's device-resident call counter), then the weighted sum over the K slots of every token
+// One int32 per (token, selection) of this rank: the row of the expert output that holds it, for the selections this rank's own
+// experts served (written by the combine push, read by the reduce).  MI_EP_COMBINE_LOCAL=0 sends those rows through the window
+// like everyone else's.
+at::Tensor Buffer::combine_local_rows(const at::Tensor &topk_idx) const
+{
+    static const bool enabled = !(getenv("MI_EP_COMBINE_LOCAL") && atoi(getenv("MI_EP_COMBINE_LOCAL")) == 0);
+    if (!enabled || topk_idx.numel() == 0) return at::Tensor();
+    return at::empty({topk_idx.numel()}, at::dtype(at::kInt).device(topk_idx.device()));
+}
+
 at::Tensor Buffer::combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
-                                  const char *reduce_name, hipStream_t st)
+                                  const char *reduce_name, hipStream_t st, const at::Tensor &x_local, const at::Tensor &local_row)
 {
     const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), W = (int)num_ranks;
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
@@ -716,9 +731,12 @@ at::Tensor Buffer::combine_finish(const at::Tensor &topk_idx, const float *topk_
                                     (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, 0,
                                     epoch_ctr(kCombine), status_dev, timeout_ms, st)); }
     auto combined_x = at::empty({T, H}, opts);
+    const bool use_local = local_row.defined() && x_local.defined() && x_local.size(0) > 0;
     { ProfScope ps_(this, reduce_name, st);
       MI_EP_CHECK(mi_ep_combine_reduce(family_base(kCombine), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, topk_weights,
-                                       nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), epoch_ctr(kCombine), region_bytes, st)); }
+                                       nullptr, nullptr, T, K, H, E, combined_x.data_ptr(), epoch_ctr(kCombine), region_bytes,
+                                       use_local ? x_local.data_ptr() : nullptr, use_local ? local_row.data_ptr<int>() : nullptr,
+                                       use_local ? (int)x_local.size(0) : 0, (int)rank, W, st)); }
     return combined_x;
 }
 
@@ -1097,7 +1115,7 @@ at::Tensor Buffer::a2a_combine_reduce(const at::Tensor &returned_rows, const at:
     MI_EP_CHECK(mi_ep_combine_reduce(returned_rows.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
                                      topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr,
                                      send_data_offset.data_ptr<int>(), send_token_idx_small.data_ptr<int>(), T, K, H,
-                                     (int)num_experts, out.data_ptr(), nullptr, 0, cur_stream()));
+                                     (int)num_experts, out.data_ptr(), nullptr, 0, nullptr, nullptr, 0, 0, 1, cur_stream()));
     return out;
 }
 

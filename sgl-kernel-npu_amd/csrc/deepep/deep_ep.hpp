@@ -214,7 +214,9 @@ private:
     void dispatch_pull(const DispatchExchange &ex, int H, int K, int L, int qm, int64_t rows_alloc, const at::TensorOptions &x_opts,
                        at::Tensor &rx, at::Tensor &rs, at::Tensor &src_idx, hipStream_t st);
     at::Tensor combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
-                              const char *reduce_name, hipStream_t st);
+                              const char *reduce_name, hipStream_t st, const at::Tensor &x_local = at::Tensor(),
+                              const at::Tensor &local_row = at::Tensor());
+    at::Tensor combine_local_rows(const at::Tensor &topk_idx) const;
     // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
     std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
                                        const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,

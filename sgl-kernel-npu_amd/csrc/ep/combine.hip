@@ -22,7 +22,8 @@ constexpr int kPushWaves = 4;
 
 __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     const uint8_t *__restrict__ x, const int32_t *__restrict__ src_idx, const int32_t *__restrict__ total_dev,
-    int rows_hint, int row_bytes /*2H*/, size_t slot_stride, int K, int W, PeerPtrs dsts, Parity par, int slot_rows)
+    int rows_hint, int row_bytes /*2H*/, size_t slot_stride, int K, int W, PeerPtrs dsts, Parity par, int slot_rows, int my_rank,
+    int32_t *__restrict__ local_row)
 {
     // never trust the device-side count beyond the rows the caller's tensor holds
     const int total = total_dev ? min(*total_dev, rows_hint) : rows_hint;
@@ -38,6 +39,11 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
             const int k = src_idx[r * 3 + 2];
             // corrupted / mismatched handle: drop the row instead of a wild (cross-GPU) store
             if (src < 0 || src >= W || k < 0 || k >= K || t < 0 || (long long)t * K + k >= slot_rows) continue;
+            // a row whose token lives on this rank does not travel: the reduce reads it where it is (x), all it needs is the row number
+            if (local_row && src == my_rank) {
+                if (lane == 0) local_row[(long long)t * K + k] = (int32_t)r;
+                continue;
+            }
             const u32x4 *s16 = (const u32x4 *)(x + (size_t)r * row_bytes);
             u32x4 *d16 = (u32x4 *)((uint8_t *)dsts.p[src] + poff + ((size_t)t * K + k) * slot_stride);
             for (int base = 0; base < n16; base += kWave * 8) {
@@ -63,7 +69,8 @@ template <bool I32, int KMAX>
 __global__ __launch_bounds__(256) void combine_reduce_kernel(
     const uint8_t *__restrict__ slots, size_t slot_stride, const void *__restrict__ topk_idx,
     const float *__restrict__ topk_w, const int32_t *__restrict__ send_off, const int32_t *__restrict__ idx_small,
-    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out, Parity par)
+    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out, Parity par, const uint8_t *__restrict__ x_local,
+    const int32_t *__restrict__ local_row, int local_rows, int my_rank, int experts_per_rank)
 {
     slots += parity_off(par);
     const int lane = lane_id();
@@ -73,15 +80,21 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
     if (t >= T) return;
     // routing + weights of this token (lane k < K)
     float w_l = 0.f;
-    bool valid_l = false;
+    bool valid_l = false, local_l = false;
     long long slot_l = t * K + lane;      // slot mode: t*K+k (window push) or the dispatch send slot (all-to-all return)
     if (lane < K) {
         long long e = I32 ? (long long)((const int32_t *)topk_idx)[t * K + lane] : ((const long long *)topk_idx)[t * K + lane];
         valid_l = (e >= 0 && e < E);
         w_l = topk_w ? topk_w[t * K + lane] : 1.0f;
         if (send_off && valid_l) slot_l = (long long)send_off[e] + idx_small[t * K + lane];
+        // selections served by this rank's own experts were not pushed: their rows are read from the expert output itself
+        if (x_local && valid_l && (int)(e / experts_per_rank) == my_rank) {
+            local_l = true;
+            slot_l = min(max(local_row[t * K + lane], 0), local_rows - 1);       // never read outside x, whatever the handle says
+        }
     }
     const unsigned long long vmask = __ballot(valid_l);
+    const unsigned long long lmask = __ballot(local_l);
     float w[KMAX];
     long long slot[KMAX];
 #pragma unroll
@@ -96,7 +109,9 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
         for (int k = 0; k < KMAX; ++k)
             if (k < K && ((vmask >> k) & 1ull))
                 // read-once stream: nontemporal loads keep the 0.47 GB of slots out of L2/MALL (measured 141 -> 102 us at C2)
-                v[k] = __builtin_nontemporal_load((const u32x4 *)(slots + (size_t)slot[k] * slot_stride + (size_t)c * 16));
+                v[k] = __builtin_nontemporal_load((const u32x4 *)(((lmask >> k) & 1ull ? x_local + (size_t)slot[k] * ((size_t)H * 2)
+                                                                                             : slots + (size_t)slot[k] * slot_stride) +
+                                                                   (size_t)c * 16));
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -208,9 +223,10 @@ extern "C" size_t mi_ep_combine_row_bytes(int hidden) { return ((size_t)hidden *
 
 extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
                                   int H, int K, void *const *dst_base_host, int W, size_t slot_region_bytes,
-                                  const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
+                                  const uint64_t *epoch_ctr, size_t parity_stride, int my_rank, int32_t *local_row, void *stream)
 {
-    if (H <= 0 || H % 8 || K <= 0 || K > MI_EP_MAX_TOPK || W <= 0 || W > MI_EP_MAX_RANKS || !dst_base_host)
+    if (H <= 0 || H % 8 || K <= 0 || K > MI_EP_MAX_TOPK || W <= 0 || W > MI_EP_MAX_RANKS || !dst_base_host ||
+        (local_row && (my_rank < 0 || my_rank >= W)))
         return MI_EP_EINVAL;
     if (rows_hint <= 0) return MI_EP_OK;
     if (!x || !src_idx) return MI_EP_EINVAL;
@@ -225,15 +241,20 @@ extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const i
     combine_push_kernel<<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
         (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp,
         make_parity(epoch_ctr, 1, parity_stride),
-        slot_region_bytes ? (int)std::min<size_t>(slot_region_bytes / mi_ep_combine_row_bytes(H), 0x7FFFFFFF) : 0x7FFFFFFF);
+        slot_region_bytes ? (int)std::min<size_t>(slot_region_bytes / mi_ep_combine_row_bytes(H), 0x7FFFFFFF) : 0x7FFFFFFF, my_rank,
+        local_row);
     return launch_status();
 }
 
 extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                                     const int32_t *send_data_offset, const int32_t *send_token_idx_small, int T, int K,
-                                    int H, int E, void *out, const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
+                                    int H, int E, void *out, const uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
+                                    const int32_t *local_row, int local_rows, int my_rank, int num_ranks, void *stream)
 {
     if ((send_data_offset == nullptr) != (send_token_idx_small == nullptr)) return MI_EP_EINVAL;
+    if (x_local && (!local_row || local_rows <= 0 || num_ranks <= 0 || E % num_ranks || my_rank < 0 || my_rank >= num_ranks ||
+                    send_data_offset))
+        return MI_EP_EINVAL;
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 8 || E <= 0) return MI_EP_EINVAL;
     if (T == 0) return MI_EP_OK;
     if (!slots || !topk_idx || !out) return MI_EP_EINVAL;
@@ -254,7 +275,8 @@ extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int
 #define MI_EP_REDUCE(I32, KMAX)                                                                                                    \
     combine_reduce_kernel<I32, KMAX><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H), topk_idx, \
                                                                          topk_weights, send_data_offset, send_token_idx_small, T, K, H,  \
-                                                                         E, segs, (uint16_t *)out, par)
+                                                                         E, segs, (uint16_t *)out, par, (const uint8_t *)x_local,   \
+                                                                         local_row, local_rows, my_rank, x_local ? E / num_ranks : 1)
     if (K <= 8) { if (idx_is_i32) MI_EP_REDUCE(true, 8); else MI_EP_REDUCE(false, 8); }
     else { if (idx_is_i32) MI_EP_REDUCE(true, MI_EP_MAX_TOPK); else MI_EP_REDUCE(false, MI_EP_MAX_TOPK); }
 #undef MI_EP_REDUCE

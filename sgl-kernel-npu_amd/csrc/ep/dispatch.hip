@@ -100,16 +100,8 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     if (t >= T) return;
     const int nitems = H / 16;
     const size_t stride = (size_t)H + MI_EP_ROW_META_BYTES;
-    // routing of this token: lane k < K owns pair (t,k)
-    long long e_l = -1;
-    int slot_l = 0, dst_l = 0;
-    if (lane < K) {
-        e_l = ld_idx<I32>(topk_idx, (long long)t * K + lane);
-        if (e_l >= 0 && e_l < E) route(ll, (int)e_l, idx_small[(long long)t * K + lane], send_off, my_rank, slot_l, dst_l);
-        else e_l = -1;
-    }
-    const unsigned long long vmask = __ballot(e_l >= 0);
-    if (vmask == 0ull) return;      // token selects nothing: no row is produced
+    // the row is requested before the routing is known (a token that selects nothing is the rare case): behind the routing's two
+    // dependent loads (expert id, then slot and segment offset) the 14 KB of the row started one to two round trips late
     const u32x4 *src = (const u32x4 *)(x + (size_t)t * H);
     u32x4 raw[kMaxItems][2];
     float amax = 0.f;
@@ -123,6 +115,16 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
             raw[it][0] = raw[it][1] = u32x4{0, 0, 0, 0};
         }
     }
+    // routing of this token: lane k < K owns pair (t,k)
+    long long e_l = -1;
+    int slot_l = 0, dst_l = 0;
+    if (lane < K) {
+        e_l = ld_idx<I32>(topk_idx, (long long)t * K + lane);
+        if (e_l >= 0 && e_l < E) route(ll, (int)e_l, idx_small[(long long)t * K + lane], send_off, my_rank, slot_l, dst_l);
+        else e_l = -1;
+    }
+    const unsigned long long vmask = __ballot(e_l >= 0);
+    if (vmask == 0ull) return;      // token selects nothing: no row is produced
 #pragma unroll
     for (int it = 0; it < kMaxItems; ++it)
 #pragma unroll

@@ -39,8 +39,8 @@ def _lib():
     lib.mi_ep_dispatch_push_slab_bytes.argtypes = [c_size_t, I]
     lib.mi_ep_dispatch_stage_push.argtypes = [V, V, I, V, V, I, I, I, I, I, I, I, V, c_size_t, V, c_size_t, V]
     lib.mi_ep_dispatch_stage_push.restype = c_int
-    lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, c_size_t, V, c_size_t, V]
-    lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, V, V, I, I, I, I, V, V, c_size_t, V]
+    lib.mi_ep_combine_push.argtypes = [V, V, V, I, I, I, V, I, c_size_t, V, c_size_t, I, V, V]
+    lib.mi_ep_combine_reduce.argtypes = [V, V, I, V, V, V, I, I, I, I, V, V, c_size_t, V, V, I, I, I, V]
     lib.mi_ep_combine_pack.argtypes = [V, V, I, I, I, I, V, V, V]
     lib.mi_ep_combine_pack.restype = c_int
     lib.mi_ep_ll_dispatch_send.argtypes = [V, V, I, V, I, I, I, I, I, I, I, I, V, V, c_size_t, V]
@@ -95,6 +95,9 @@ class InProcEP:
         # "push": mi_ep_dispatch_stage_push writes token rows + index entries into the DESTINATION ranks' regions (source slabs),
         # the receiver gathers locally with pull_indexed -- the host runtime's default at W > 1
         self.transport = transport
+        # rows whose token lives on the expert rank itself do not go through the combine window (the host runtime's default);
+        # exercised together with the push transport, the other modes send every row through the window
+        self.combine_local = transport == "push"
         self.dev = torch.device(device)
         u8 = dict(dtype=torch.uint8, device=self.dev)
         rb = max(lib().mi_ep_dispatch_row_bytes(H, QUANT_NONE), lib().mi_ep_dispatch_row_bytes(H, QUANT_INT8))
@@ -191,17 +194,22 @@ class InProcEP:
         st = stream_ptr()
         dst_ptrs = ptr_array([t.data_ptr() for t in self.comb_win])
         flag_ptrs = ptr_array([t.data_ptr() + 64 * 8 for t in self.flags])
+        local_rows = [torch.full((max(topk_idxs[r].numel(), 1),), -1, dtype=torch.int32, device=self.dev) if self.combine_local else None
+                      for r in range(W)]
         for r in range(W):
             ck(L_.mi_ep_combine_push(ptr(ys[r]), ptr(src_idxs[r]), None, int(totals[r]), H, K, dst_ptrs, W, self.comb_win[r].numel(),
-                                     None, 0, st))
+                                     None, 0, r, ptr(local_rows[r]) if self.combine_local else None, st))
             ck(L_.mi_ep_signal(flag_ptrs, W, r, ep, st))
         outs = []
         for r in range(W):
             T = topk_idxs[r].shape[0]
             ck(L_.mi_ep_wait(c_void_p(self.flags[r].data_ptr() + 64 * 8), W, ep, ptr(self.status[r]), 2000, st))
             out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
+            loc = self.combine_local and int(totals[r]) > 0
             ck(L_.mi_ep_combine_reduce(ptr(self.comb_win[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
-                                       ptr(topk_weights[r]), None, None, T, K, H, E, ptr(out), None, 0, st))
+                                       ptr(topk_weights[r]), None, None, T, K, H, E, ptr(out), None, 0,
+                                       ptr(ys[r]) if loc else None, ptr(local_rows[r]) if loc else None, int(ys[r].shape[0]) if loc else 0,
+                                       r, W, st))
             outs.append(out)
         torch.cuda.synchronize()
         return outs
@@ -332,7 +340,8 @@ class InProcA2A:
             out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
             lay = disp[me]["layout"]
             ck(L_.mi_ep_combine_reduce(ptr(ret), ptr(topk_idxs[me]), int(topk_idxs[me].dtype == torch.int32), ptr(topk_weights[me]),
-                                       ptr(lay["send_data_offset"]), ptr(lay["send_token_idx_small"]), T, K, H, E, ptr(out), None, 0, st))
+                                       ptr(lay["send_data_offset"]), ptr(lay["send_token_idx_small"]), T, K, H, E, ptr(out), None, 0,
+                                       None, None, 0, 0, 1, st))
             outs.append(out)
         torch.cuda.synchronize()
         return outs
