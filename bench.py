@@ -175,14 +175,16 @@ def routing_stats(topk_idx, world, rank):
     return pairs.tolist(), tokens.tolist()
 
 
-def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank):
-    """Algorithmic HBM bytes of one launch.  n_tok_rank = distinct (token, destination rank) pairs."""
+def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank, n_local=0):
+    """Algorithmic HBM bytes of one launch (DESIGN.md section 4).  n_tok_rank = distinct (token, destination rank) pairs;
+    n_local = received rows whose token lives on this rank (the combine does not move those: the push stores their row number, the
+    reduce reads them from the expert output)."""
     row = H + 16
     return {
         "dispatch_stage": T * H * 2 + T * row + n_pairs * 8,    # read bf16 tokens once, write one int8 row per token + the index
         "dispatch_stage_push": T * H * 2 + n_tok_rank * row + n_pairs * 8,   # one row per (token, destination rank) + the index
         "dispatch_pull": 2 * n_recv * row + n_recv * 8,         # read a token row + index entry per received row, write recv_x / scales / triples
-        "combine_push": 2 * n_recv * H * 2,                     # read bf16 rows, write them into the owners' slots
+        "combine_push": 2 * (n_recv - n_local) * H * 2 + n_recv * 12 + n_local * 4,   # rows read and written into the owners' slots
         "combine_reduce": n_pairs * H * 2 + T * H * 2,          # read K slots per token, write one bf16 row
     }[name]
 
@@ -557,7 +559,8 @@ def main():
         per = {k: {"launches": n, "avg_us": ms / n * 1e3} for k, (n, ms) in prof.items() if n}
         bulk = [k for k in per if k in ("dispatch_stage", "dispatch_stage_push", "dispatch_pull", "combine_push", "combine_reduce")]
         dom = max(bulk, key=lambda k: per[k]["avg_us"])
-        kb = lambda k: kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv, n_tok_rank)
+        n_local = rows_from[rank] if windowed and os.environ.get("MI_EP_COMBINE_LOCAL", "1") != "0" else 0
+        kb = lambda k: kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv, n_tok_rank, n_local)
         alg = kb(dom)
         achieved = alg / (per[dom]["avg_us"] * 1e-6) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -61,9 +61,10 @@ template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) { retu
 
 // LDS-DMA through inline asm (the compiler then places no vmcnt wait of its own; ordering is the explicit vmcnt below).
 // Lane l moves 16 B from its own address to dst + 16 l; M0 carries the wave-uniform LDS destination.
-__device__ __forceinline__ void dma16(uint32_t dst, const void *vaddr)
+// Address = wave-uniform base (SGPR pair) + 32-bit lane offset: one VGPR per operand stream instead of a 64-bit pointer per lane.
+__device__ __forceinline__ void dma16(uint32_t dst, const void *sbase, uint32_t voff)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(vaddr) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory");
 }
 
 #ifdef GEMM_TIMING
@@ -140,24 +141,24 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
     // ---- DMA plan: one instruction moves kPieceRows rows x BKT bytes (1 KB); wave w issues A piece w (if there is one) and B pieces
     // w, w + 16, ...
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
-    const int8_t *srcA, *srcB[kBPerWave];
+    uint32_t offA, offB[kBPerWave];               // lane offsets from the wave-uniform bases abase / wbase
     {
         const int row = kPieceRows * wave + lane / kChunks;
         const int chunk = swz_pos<BKT>(row, lane % kChunks);                      // swizzle on the source side (an involution)
-        srcA = abase + (size_t)min(row, rows - 1) * p.K + chunk * 16;             // rows past the group: any valid row
+        offA = (uint32_t)min(row, rows - 1) * (uint32_t)p.K + chunk * 16;         // rows past the group: any valid row
 #pragma unroll
         for (int j = 0; j < kBPerWave; ++j) {
             const int brow = row + j * 16 * kPieceRows;                           // 128 rows further: the same swizzle term
-            srcB[j] = wbase + (size_t)min(n0 + brow, p.N - 1) * p.K + chunk * 16;
+            offB[j] = (uint32_t)min(n0 + brow, p.N - 1) * (uint32_t)p.K + chunk * 16;
         }
     }
     const int nk = p.K / BKT;
     auto issue_stage = [&](int kt) {
         const int kc = min(kt, nk - 1) * BKT;             // past the end: a harmless refill keeps the vmcnt arithmetic uniform
         const uint32_t sbase = lds_base + (uint32_t)((kt % kStages) * kStageBytes + wave * 1024);
-        if (wave < kAPieces) dma16(sbase, srcA + kc);     // wave-uniform
+        if (wave < kAPieces) dma16(sbase, abase + kc, offA);     // wave-uniform
 #pragma unroll
-        for (int j = 0; j < kBPerWave; ++j) dma16(sbase + (uint32_t)(BM * BKT + j * 16 * 1024), srcB[j] + kc);
+        for (int j = 0; j < kBPerWave; ++j) dma16(sbase + (uint32_t)(BM * BKT + j * 16 * 1024), wbase + kc, offB[j]);
     };
 
     i32x4 acc[MT][4];
@@ -263,7 +264,10 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
                 }
             }
         }
-    // a wave only reads back what it wrote itself: LDS operations of one wave complete in order, no barrier needed
+    // a wave only reads back what it wrote itself: LDS operations of one wave complete in order, no barrier needed -- but the compiler
+    // must not move the 16-byte loads below above the float / uint16_t stores above (different types: type-based alias analysis would
+    // allow it; an 8-rows-at-a-time variant of this epilogue produced wrong rows exactly that way)
+    asm volatile("" ::: "memory");
     if (!wave_cols_ok) return true;
     // MODE 2: where do this lane's rows go?  The (src, t, k) triples and, from them, the slot addresses are requested in ONE batch for all 8
     // row groups (after the transposition, when the accumulators are dead and the registers are free), two dependent round trips in all.
@@ -329,6 +333,12 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
 // at EP = 8 allocates W x max_tokens x K rows, 8x what arrives under balanced routing) one workgroup per possible tile would
 // launch thousands that only look up "no such tile" and exit.  Worker y takes tile slots y, y + gridDim.y, ... until the
 // cumulative counts say there are no more.
+// Measured and dropped (round 2): running a worker's tiles as ONE operand stream -- the last refills of a tile fetch the first stages
+// of the next one, the epilogue moves to its own 18 KB LDS area (8 rows per pass) so the ring keeps filling under it, the expert ends
+// sit in LDS so the next lookup needs no vector load.  Bit-exact, but GEMM1 1.05 -> 1.10 ms and GEMM2 0.74 -> 0.76 ms at C5: only the
+// kStages - 1 stages already requested overlap the epilogue (the accumulators occupy the registers a second tile would need, so the
+// MFMA stream still stops for the ~11k-cycle epilogue), which buys back the pipeline fill (~5 % of a GEMM2 tile) and loses it again
+// to the ring bookkeeping inside the k-loop.
 template <int MODE, int MT, int BKT>
 __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs p)
 {
