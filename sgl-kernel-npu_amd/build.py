@@ -51,7 +51,7 @@ def build_hip_lib(name, subdir, extra=()):
     srcs = sorted(glob.glob(os.path.join(HERE, "csrc", subdir, "*.hip")))
     hdrs = glob.glob(os.path.join(HERE, "csrc", subdir, "*.h")) + glob.glob(os.path.join(INC, "*.h"))
     out = os.path.join(LIB, name)
-    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{INC}",
+    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", f"-I{INC}",
               f"-I{os.path.join(HERE, 'csrc', subdir)}", *extra]
     objs, procs = [], []
     for src in srcs:
