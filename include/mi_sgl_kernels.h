@@ -138,9 +138,15 @@ int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bi
                    const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping, const void *quant_scale1,
                    const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8, void *kv_cache, void *kv_cache_rope,
                    const float *tok_scale_in /* NULL = per-tensor mode */, float *tok_scale_out /* [tokens], with tok_scale_in */,
+                   int cache_mode /* 1 krope_ctkv, 2 int8_nzcache, 3 nzcache (op_host/mla_preprocess.cpp:605-606) */,
+                   int block_size /* slots per cache block (modes 2, 3) */, const void *ctkv_scale /* [1], I/O dtype (mode 2) */,
                    void *stream);
+/* Cache layouts: mode 1 [slot][dim]; mode 3 per block of block_size slots [dim / 16][slot in block][16]; mode 2 k_nope as int8
+ * = round(clamp(fp16(k_nope / ctkv_scale))) in [dim / 32][slot in block][32], k_pe as in mode 3 (element positions as read back by
+ * the reference test's extract_from_nzcache, tests/python/sgl_kernel_npu/test_mla_preprocess.py:122-136).
+ * q_nope_scale != NULL ([q_heads], I/O dtype; mode 2): q_out0 is int8 [tokens, q_heads, 512] = round(clamp(fp16(q * scale[h]))). */
 int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const void *wuk_t, const void *cos, const void *sin, int dtype,
-                        void *q_out0, void *q_out1, void *stream);
+                        void *q_out0, void *q_out1, const void *q_nope_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -271,6 +271,29 @@ def _quant_per_tensor(x, scale, zp):
     return torch.round(x).to(torch.int8)
 
 
+def _quant_per_tensor_muls(x, scale, zp):
+    """tests/python/sgl_kernel_npu/test_mla_preprocess.py:83-90 (multiply instead of divide: the q_nope quantisation of int8_nzcache)."""
+    x = x * scale.float() + zp.float()
+    x = torch.clamp(x.to(torch.float16), -128, 127)
+    return torch.round(x).to(torch.int8)
+
+
+def nz_cache_offsets(slot, block_size, dim, c0):
+    """Flat element offsets (into a cache [blocks, block_size, 1, dim]) of the `dim` values of cache slot `slot` in the NZ layouts:
+    inside the slot's block, element d sits at ((d // c0) * block_size + slot % block_size) * c0 + d % c0 -- the positions the
+    reference test reads back (extract_from_nzcache, tests/python/sgl_kernel_npu/test_mla_preprocess.py:122-136, which hard-codes
+    block_size = 128; c0 = 16 for bf16 / fp16, 32 for int8)."""
+    blk, inner = slot // block_size, slot % block_size
+    d = torch.arange(dim)
+    return blk * block_size * dim + ((d // c0) * block_size + inner) * c0 + d % c0
+
+
+def extract_from_nzcache(cache, slot, c0):
+    """Read one slot's row back out of an NZ cache [blocks, block_size, 1, dim] (the reference test's read-back, :122-136)."""
+    block_size, dim = cache.shape[1], cache.shape[-1]
+    return cache.reshape(-1)[nz_cache_offsets(int(slot), block_size, dim, c0)]
+
+
 def _int8_gemm_dequant(a, w, descale, bias, dtype):
     """:95-107 (bf16 branch): exact int32 GEMM + bias, * float descale, to dtype."""
     # exact: |sum| <= K * 128 * 128 < 2^53, so the float64 BLAS product is the integer product (torch's int32 matmul is a scalar loop)
@@ -327,8 +350,11 @@ def mla_preprocess_per_token(hidden, wdqkv, descale0, gamma1, beta1, gamma2, wuq
 
 
 def mla_preprocess(hidden, wdqkv, descale0, bias0, gamma1, beta1, gamma2, wuq, descale1, bias1, wuk, cos, sin, qscale0, qoff0,
-                   qscale1, qoff1, eps=1e-6):
-    """Transcription of golden2_pytorch, cache_mode 'krope_ctkv' (tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483):
+                   qscale1, qoff1, eps=1e-6, cache_mode="krope_ctkv", ctkv_scale=None, qnope_scale=None):
+    """Transcription of golden2_pytorch (tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483).  cache_mode 'krope_ctkv' and
+    'nzcache' produce the same VALUES (only the cache layout differs, see nz_cache_offsets); 'int8_nzcache' (:465-475) returns
+    q_nope_out and k_nope as int8: quant_per_tensor_muls(q_nope_out, qnope_scale[head]) and quant_per_tensor(k_nope, ctkv_scale).
+    The network:
     quant -> INT8 GEMM [N,H]x[H,2112] -> split [512 k_nope | 64 k_pe | 1536 q] -> rms_norm(q)*gamma1+beta1,
     rms_norm(k_nope)*gamma2 -> quant -> INT8 GEMM [N,1536]x[1536,Hq*192] -> per head [128|64] -> bmm(q_nope, wuk) ->
     rotate-half RoPE on q_pe / k_pe.  Weights are [out, in] row-major.  Returns (q_nope_out [N,Hq,512], q_pe [N,Hq,64],
@@ -352,4 +378,8 @@ def mla_preprocess(hidden, wdqkv, descale0, bias0, gamma1, beta1, gamma2, wuq, d
     c, s = cos.unsqueeze(1).float(), sin.unsqueeze(1).float()
     q_pe_r = (q_pe.float() * c + _rotate_half(q_pe.float()) * s).to(dtype)
     k_pe_r = (k_pe.float() * c + _rotate_half(k_pe.float()) * s).to(dtype)
+    if cache_mode == "int8_nzcache":
+        q8 = _quant_per_tensor_muls(q_nope_out, qnope_scale.reshape(1, Hq, 1), torch.zeros_like(q_nope_out))
+        k8 = _quant_per_tensor(k_nope, ctkv_scale, torch.zeros_like(k_nope))
+        return q8, q_pe_r, k8, k_pe_r.squeeze(1)
     return q_nope_out.to(dtype), q_pe_r, k_nope.to(dtype), k_pe_r.squeeze(1)

@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void skinny_i8_k1536_kernel(const int8_t *__re
 template <bool BF16>
 __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restrict__ Y, int M, int Hq, const uint16_t *__restrict__ wuk_t,
                                                       const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
-                                                      uint16_t *__restrict__ out0, uint16_t *__restrict__ out1)
+                                                      uint16_t *__restrict__ out0, uint16_t *__restrict__ out1,
+                                                      const uint16_t *__restrict__ q_nope_scale)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[4][32][128 + 8];      // per wave: 32 rows x 128 columns (+16 B: bank spread)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,8 +312,26 @@ __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restric
     for (int it = 0; it < 8; ++it) {
         const int rl = it * 4 + (lane >> 4), chunk = lane & 15;
         const int row = m0 + rl;
-        if (row < M)
-            *(uint4 *)(out0 + ((size_t)row * Hq + h) * 512 + quarter * 128 + chunk * 8) = *(const uint4 *)&tile[wave][rl][chunk * 8];
+        if (row >= M) continue;
+        const uint4 v = *(const uint4 *)&tile[wave][rl][chunk * 8];
+        if (!q_nope_scale) {
+            *(uint4 *)(out0 + ((size_t)row * Hq + h) * 512 + quarter * 128 + chunk * 8) = v;
+        } else {
+            // cache_mode int8_nzcache: q_out0 is int8 = round(clamp(fp16(q * q_nope_scale[h]))) of the value already rounded to the
+            // I/O dtype (quant_per_tensor_muls of the golden, tests/python/sgl_kernel_npu/test_mla_preprocess.py:83-90,466-471)
+            const float sc = ldh16<BF16>(q_nope_scale[h]);
+            const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+            uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float prod = ldh16<BF16>((uint16_t)(wds[j >> 1] >> (16 * (j & 1)))) * sc;
+                asm volatile("" : "+v"(prod));          // the fp32 product is rounded before the fp16 conversion (no v_fma_mixlo folding)
+                float hq = (float)(_Float16)prod;
+                hq = fminf(fmaxf(hq, -128.f), 127.f);
+                pk[j >> 2] |= ((uint32_t)(int)rintf(hq) & 0xFFu) << (8 * (j & 3));
+            }
+            *(uint2 *)((int8_t *)out0 + ((size_t)row * Hq + h) * 512 + quarter * 128 + chunk * 8) = uint2{pk[0], pk[1]};
+        }
     }
     // RoPE of the 64 positional columns (lane = column): column quarter q takes rows 8q .. 8q+7 of the wave's 32; the eight rows
     // are independent, so their loads are all in flight together (a serial row loop cost one memory round trip per row)
@@ -360,7 +379,8 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
         skinny_i8_kernel<0, BN, true><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, c_i32, nullptr, nullptr, nullptr, nullptr);
     } else if (k == kK2) {
         // the op's GEMM2: pick the widest column tile that still gives the chip a full round of workgroups
-        const int nt = n >= 256 * 96 ? 6 : n >= 256 * 64 ? 4 : n >= 256 * 32 ? 2 : 1;
+        static const int force_nt = getenv("MI_MLA_GEMM2_NT") ? atoi(getenv("MI_MLA_GEMM2_NT")) : 0;
+        const int nt = force_nt ? force_nt : n >= 256 * 96 ? 6 : n >= 256 * 64 ? 4 : n >= 256 * 32 ? 2 : 1;
         dim3 grid((n + nt * 16 - 1) / (nt * 16), 1, mblocks);
         const size_t lds = (size_t)nt * 16 * kRow2;
 #define MI_K1536(NT, B)                                                                                                                  \
@@ -374,6 +394,7 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
         } while (0)
         const bool bf = dtype == MI_DTYPE_BF16;
         if (nt == 6) { if (bf) MI_K1536(6, true); else MI_K1536(6, false); }
+        else if (nt == 3) { if (bf) MI_K1536(3, true); else MI_K1536(3, false); }
         else if (nt == 4) { if (bf) MI_K1536(4, true); else MI_K1536(4, false); }
         else if (nt == 2) { if (bf) MI_K1536(2, true); else MI_K1536(2, false); }
         else { if (bf) MI_K1536(1, true); else MI_K1536(1, false); }
@@ -390,7 +411,7 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
 }
 
 extern "C" int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const void *wuk_t, const void *cos, const void *sin, int dtype,
-                                   void *q_out0, void *q_out1, void *stream)
+                                   void *q_out0, void *q_out1, const void *q_nope_scale, void *stream)
 {
     if (tokens < 0 || q_heads <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16)) return MI_SGL_EINVAL;
     if (tokens == 0) return MI_SGL_OK;
@@ -399,10 +420,10 @@ extern "C" int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const
     if (dtype == MI_DTYPE_BF16)
         bmm_rope_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t *)y, tokens, q_heads, (const uint16_t *)wuk_t,
                                                                     (const uint16_t *)cos, (const uint16_t *)sin, (uint16_t *)q_out0,
-                                                                    (uint16_t *)q_out1);
+                                                                    (uint16_t *)q_out1, (const uint16_t *)q_nope_scale);
     else
         bmm_rope_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t *)y, tokens, q_heads, (const uint16_t *)wuk_t,
                                                                      (const uint16_t *)cos, (const uint16_t *)sin, (uint16_t *)q_out0,
-                                                                     (uint16_t *)q_out1);
+                                                                     (uint16_t *)q_out1, (const uint16_t *)q_nope_scale);
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__r
                                                      const int32_t *__restrict__ slotmapping, const uint16_t *__restrict__ qscale1_p,
                                                      const int8_t *__restrict__ qoff1_p, float eps, int8_t *__restrict__ q8, uint16_t *__restrict__ kv_cache,
                                                      uint16_t *__restrict__ kv_cache_rope, const float *__restrict__ tok_scale_in,
-                                                     float *__restrict__ tok_scale_out)
+                                                     float *__restrict__ tok_scale_out, int cache_mode, int block_size,
+                                                     const uint16_t *__restrict__ ctkv_scale)
 {
     __shared__ float f[kMid];
     __shared__ float red[kMidThreads / 64];
@@ -169,13 +170,35 @@ __global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__r
     for (int j = tid; j < kKN; j += kMidThreads) ss += f[j] * f[j];
     const float rk = rsqrtf(block_sum(ss, red) / (float)kKN + eps);
     const long long slot = slotmapping[n];
-    for (int j = tid; j < kKN; j += kMidThreads) kv_cache[slot * kKN + j] = sth<BF16>((f[j] * rk) * ldh<BF16>(gamma2[j]));
+    // Cache layouts (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-606; element positions per the reference test's
+    // extract_from_nzcache, tests/python/sgl_kernel_npu/test_mla_preprocess.py:122-136):
+    //   1 krope_ctkv    [slot][dim]
+    //   3 nzcache       per block of block_size slots: [dim / 16][slot in block][16]
+    //   2 int8_nzcache  k_nope as int8 = round(clamp(fp16(k_nope / ctkv_scale))) in [dim / 32][slot in block][32]; k_pe as mode 3
+    const long long blk = cache_mode == 1 ? 0 : slot / block_size, inner = cache_mode == 1 ? 0 : slot % block_size;
+    auto nz = [&](int dim, int j, int c0) { return blk * block_size * dim + ((long long)(j / c0) * block_size + inner) * c0 + j % c0; };
+    if (cache_mode == 2) {
+        const float cs = ldh<BF16>(ctkv_scale[0]);
+        int8_t *kv8 = (int8_t *)kv_cache;
+        for (int j = tid; j < kKN; j += kMidThreads) {
+            const float y = (f[j] * rk) * ldh<BF16>(gamma2[j]);
+            // quant_per_tensor of the golden (:74-80): fp32 divide, one rounding to fp16, clamp, round half to even
+            float qv = y / cs;
+            asm volatile("" : "+v"(qv));
+            float h = (float)(_Float16)qv;
+            h = fminf(fmaxf(h, -128.f), 127.f);
+            kv8[nz(kKN, j, 32)] = (int8_t)(int)rintf(h);
+        }
+    } else {
+        for (int j = tid; j < kKN; j += kMidThreads)
+            kv_cache[cache_mode == 1 ? slot * kKN + j : nz(kKN, j, 16)] = sth<BF16>((f[j] * rk) * ldh<BF16>(gamma2[j]));
+    }
     // k_pe: rotate-half RoPE -> rope cache
     if (tid < kKR) {
         const float x = f[kKN + tid];
         const float rot = tid < kKR / 2 ? -f[kKN + tid + kKR / 2] : f[kKN + tid - kKR / 2];
         const float c = ldh<BF16>(cosv[(long long)n * kKR + tid]), s = ldh<BF16>(sinv[(long long)n * kKR + tid]);
-        kv_cache_rope[slot * kKR + tid] = sth<BF16>(x * c + rot * s);
+        kv_cache_rope[cache_mode == 1 ? slot * kKR + tid : nz(kKR, tid, 16)] = sth<BF16>(x * c + rot * s);
     }
     // q: RMSNorm * gamma1 + beta1 -> per-tensor INT8
     ss = 0.f;
@@ -232,9 +255,11 @@ extern "C" int mi_mla_pre_quant_token(const void *x, int tokens, int hidden, int
 extern "C" int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bias0, const float *descale0, const void *gamma1,
                               const void *beta1, const void *gamma2, const void *cos, const void *sin, const int32_t *slotmapping,
                               const void *quant_scale1, const int8_t *quant_offset1, float eps, int tokens, int dtype, int8_t *q_int8,
-                              void *kv_cache, void *kv_cache_rope, const float *tok_scale_in, float *tok_scale_out, void *stream)
+                              void *kv_cache, void *kv_cache_rope, const float *tok_scale_in, float *tok_scale_out, int cache_mode,
+                              int block_size, const void *ctkv_scale, void *stream)
 {
     if ((tok_scale_in == nullptr) != (tok_scale_out == nullptr)) return MI_SGL_EINVAL;
+    if (cache_mode < 1 || cache_mode > 3 || (cache_mode != 1 && block_size <= 0) || (cache_mode == 2 && !ctkv_scale)) return MI_SGL_EINVAL;
     if (tokens < 0 || num_partials < 1 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) ||
         (!tok_scale_in && (!quant_scale1 || !quant_offset1)))
         return MI_SGL_EINVAL;
@@ -245,7 +270,8 @@ extern "C" int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const 
     pre_mid_kernel<B><<<tokens, kMidThreads, 0, (hipStream_t)stream>>>(gemm1_i32, num_partials, tokens, bias0, descale0, (const uint16_t *)gamma1,                 \
                                                                (const uint16_t *)beta1, (const uint16_t *)gamma2, (const uint16_t *)cos, \
                                                                (const uint16_t *)sin, slotmapping, (const uint16_t *)quant_scale1, quant_offset1, eps,  \
-                                                               q_int8, (uint16_t *)kv_cache, (uint16_t *)kv_cache_rope, tok_scale_in, tok_scale_out)
+                                                               q_int8, (uint16_t *)kv_cache, (uint16_t *)kv_cache_rope, tok_scale_in, tok_scale_out, \
+                                                               cache_mode, block_size, (const uint16_t *)ctkv_scale)
     if (dtype == MI_DTYPE_BF16) MI_MID(true); else MI_MID(false);
 #undef MI_MID
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;

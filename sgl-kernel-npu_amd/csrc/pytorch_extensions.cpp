@@ -219,7 +219,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
 // csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704).  MI355X layouts: wdqkv int8 [2112, hidden] and wuq int8
 // [q_heads*192, 1536] are plain row-major (output channel major, K contiguous) instead of the Ascend NZ fractal format;
 // wuk [q_heads, 128, 512]; kv_cache [blocks, block_size, 1, 512] + kv_cache_rope [blocks, block_size, 1, 64]
-// (cache_mode "krope_ctkv").  gamma0 / beta0 are accepted and unused, as in the reference's bf16 kernel (stage 1 is
+// (cache_mode "krope_ctkv": [slot][dim]; "nzcache": per block [dim/16][slot in block][16]; "int8_nzcache": k_nope quantised with
+// ctkv_scale into [dim/32][slot in block][32] and q_out0 as int8 quantised with q_nope_scale[head] -- the cache block is the
+// unit of the NZ layouts, weights stay row-major).  gamma0 / beta0 are accepted and unused, as in the reference's bf16 kernel (stage 1 is
 // quant-only).  Every stage is a HIP kernel of csrc/kernels/mla_gemm.hip (the two INT8 GEMMs and the per-head BMM, hand-written
 // skinny split-K / weight-streaming kernels) or csrc/kernels/mla_preprocess.hip (quant, dequant + split + RMSNorm + RoPE + cache).
 // wuk is consumed K-contiguous: its [q_heads, 512, 128] transpose is made once per weight tensor and kept (the reference casts
@@ -253,9 +255,11 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     std::optional<c10::string_view> cache_mode, std::optional<c10::string_view> quant_mode, at::Tensor &q_out0,
     at::Tensor &kv_cache_out0, at::Tensor &q_out1, at::Tensor &kv_cache_out1)
 {
-    (void)gamma0, (void)beta0, (void)ctkv_scale, (void)q_nope_scale;
-    TORCH_CHECK(!cache_mode.has_value() || *cache_mode == "krope_ctkv", "mla_preprocess: only cache_mode='krope_ctkv' is implemented "
-                "(the int8 / NZ cache modes are Ascend layouts), got ", cache_mode.value_or(""));
+    (void)gamma0, (void)beta0;
+    // cache_mode (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-606,634): krope_ctkv = 1 (default), int8_nzcache = 2, nzcache = 3
+    const c10::string_view cmode = cache_mode.value_or("krope_ctkv");
+    TORCH_CHECK(cmode == "krope_ctkv" || cmode == "int8_nzcache" || cmode == "nzcache", "Unsupported cache_mode value: '", cmode, "'");
+    const int cmode_i = cmode == "krope_ctkv" ? 1 : cmode == "int8_nzcache" ? 2 : 3;
     // quant_mode: "per_tensor_quant_asymm" (the mode the reference tests cover) or "per_token_quant_symm" -- the reference's DEFAULT
     // when the argument is omitted (csrc/mla_preprocess/op_host/mla_preprocess.cpp:634-635), so it is the default here too
     const c10::string_view qmode = quant_mode.value_or("per_token_quant_symm");
@@ -278,6 +282,25 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
                 "kv_cache [..., 512] and kv_cache_rope [..., 64] must be contiguous");
     TORCH_CHECK(q_out0.is_contiguous() && q_out0.numel() == N * Hq * 512 && q_out1.is_contiguous() && q_out1.numel() == N * Hq * 64,
                 "q_out0 [tokens, q_heads, 512] / q_out1 [tokens, q_heads, 64]");
+    int64_t block_size = 0;
+    if (cmode_i != 1) {        // the NZ layouts are defined per cache block: [blocks, block_size, 1, dim]
+        TORCH_CHECK(kv_cache.dim() >= 2 && kv_cache_rope.dim() == kv_cache.dim() && kv_cache_rope.size(1) == kv_cache.size(1),
+                    "nzcache modes need kv_cache [blocks, block_size, ..., 512] and kv_cache_rope with the same block_size");
+        block_size = kv_cache.size(1);
+    }
+    if (cmode_i == 2) {
+        TORCH_CHECK(kv_cache.scalar_type() == at::kChar && q_out0.scalar_type() == at::kChar,
+                    "cache_mode='int8_nzcache': kv_cache and q_out0 must be int8");
+        TORCH_CHECK(ctkv_scale.has_value() && ctkv_scale->numel() == 1 && ctkv_scale->scalar_type() == hiddenState.scalar_type() &&
+                        q_nope_scale.has_value() && q_nope_scale->numel() == Hq && q_nope_scale->is_contiguous() &&
+                        q_nope_scale->scalar_type() == hiddenState.scalar_type(),
+                    "cache_mode='int8_nzcache' needs ctkv_scale [1] and q_nope_scale [q_heads] in the input dtype");
+    } else {
+        TORCH_CHECK(kv_cache.scalar_type() == hiddenState.scalar_type() && q_out0.scalar_type() == hiddenState.scalar_type(),
+                    "kv_cache / q_out0 must have the input dtype");
+    }
+    TORCH_CHECK(kv_cache_rope.scalar_type() == hiddenState.scalar_type() && q_out1.scalar_type() == hiddenState.scalar_type(),
+                "kv_cache_rope / q_out1 must have the input dtype");
     const int dt = dtype_code(hiddenState);
     auto dev = hiddenState.device();
     void *st = cur_stream();
@@ -311,7 +334,8 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
                                     gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(),
                                     per_token ? nullptr : quant_scale1.data_ptr(), per_token ? nullptr : (const int8_t *)quant_offset1.data_ptr(),
                                     1e-6f, (int)N, dt, (int8_t *)q8.data_ptr(), kv_cache.data_ptr(), kv_cache_rope.data_ptr(),
-                                    per_token ? tok0.data_ptr<float>() : nullptr, per_token ? tok1.data_ptr<float>() : nullptr, st),
+                                    per_token ? tok0.data_ptr<float>() : nullptr, per_token ? tok1.data_ptr<float>() : nullptr, cmode_i,
+                                    (int)block_size, cmode_i == 2 ? ctkv_scale->data_ptr() : nullptr, st),
                 "mi_mla_pre_mid failed");
     at::Tensor y2 = at::empty({N, Hq * 192}, hiddenState.options());              // GEMM2 output materialised in the I/O dtype (golden :95-107)
     TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)q8.data_ptr(), (int)N, 1536, (const int8_t *)wuq.data_ptr(), (int)(Hq * 192), 1, nullptr,
@@ -319,7 +343,7 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
                                         y2.data_ptr(), dt, st), "mi_mla_pre_gemm_i8 (GEMM2) failed");
     at::Tensor wuk_t = prepared_wuk(wuk.to(hiddenState.scalar_type()));
     TORCH_CHECK(0 == mi_mla_pre_bmm_rope(y2.data_ptr(), (int)N, (int)Hq, wuk_t.data_ptr(), cos.data_ptr(), sin.data_ptr(), dt, q_out0.data_ptr(),
-                                         q_out1.data_ptr(), st), "mi_mla_pre_bmm_rope failed");
+                                         q_out1.data_ptr(), cmode_i == 2 ? q_nope_scale->data_ptr() : nullptr, st), "mi_mla_pre_bmm_rope failed");
     if (kv_cache_out0.data_ptr() != kv_cache.data_ptr()) kv_cache_out0.copy_(kv_cache);
     if (kv_cache_out1.data_ptr() != kv_cache_rope.data_ptr()) kv_cache_out1.copy_(kv_cache_rope);
     return {q_out0, kv_cache_out0, q_out1, kv_cache_out1};

@@ -230,9 +230,73 @@ def test_mla_preprocess_per_token_quant(N, Hq, hidden):
     assert torch.equal(k_pe, want[3])
 
 
+@pytest.mark.parametrize("cache_mode", ["nzcache", "int8_nzcache"])
+@pytest.mark.parametrize("N,Hq,hidden,block_size", [(1, 32, 7168, 128), (31, 128, 7168, 128), (128, 128, 7168, 128), (70, 16, 2048, 64)])
+def test_mla_preprocess_nz_cache_modes(cache_mode, N, Hq, hidden, block_size):
+    """cache_mode 'nzcache' / 'int8_nzcache' (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-606; the reference test runs all three
+    modes, tests/python/sgl_kernel_npu/test_mla_preprocess.py:504-600).  Caches are read back the way the reference test does
+    (extract_from_nzcache with C0 = 16, or 32 for the int8 k_nope), and nothing outside the written slots may change.
+    nzcache: the VALUES must be bit-identical to what krope_ctkv writes for the same inputs (only the layout differs).
+    int8_nzcache: against the golden's int8 outputs -- an int8 step is what one flipped rounding upstream can do, so: equal up to
+    +-1, and all but a vanishing fraction equal exactly."""
+    dt = torch.bfloat16
+    nblocks = max(3, (N + block_size - 1) // block_size + 1)
+    z = _mla_pre_inputs(N, Hq, hidden, dt)
+    torch.manual_seed(7)
+    slots = torch.randperm(nblocks * block_size)[:N].to(torch.int32)
+    ctkv_scale = torch.tensor([0.37]).to(dt)                      # reference test: uniform(-2, 2) / uniform(-1, 1); avoid ~0 here
+    qnope_scale = (torch.rand(Hq) * 1.5 + 0.25).to(dt) * torch.where(torch.rand(Hq) < 0.5, -1.0, 1.0).to(dt)
+    int8 = cache_mode == "int8_nzcache"
+    d = lambda t: t.cuda()
+
+    def run(mode, kv, kr, q0, q1):
+        kw = dict(ctkv_scale=d(ctkv_scale), q_nope_scale=d(qnope_scale)) if mode == "int8_nzcache" else {}
+        torch.ops.npu.mla_preprocess(d(z["hid"]), d(z["gamma0"]), d(z["beta0"]), d(z["wdqkv"]), d(z["descale0"]), d(z["gamma1"]),
+                                     d(z["beta1"]), d(z["wuq"]), d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), d(z["wuk"]),
+                                     kv, kr, d(slots), d(z["qs0"]), d(z["qo0"]), d(z["bias0"]), d(z["qs1"]), d(z["qo1"]), d(z["bias1"]),
+                                     cache_mode=mode, quant_mode="per_tensor_quant_asymm", q_out0=q0, kv_cache_out0=kv, q_out1=q1,
+                                     kv_cache_out1=kr, **kw)
+
+    mk = lambda dim, dtype: torch.zeros((nblocks, block_size, 1, dim), dtype=dtype, device="cuda")
+    kv, kr = mk(512, torch.int8 if int8 else dt), mk(64, dt)
+    q0 = torch.empty((N, Hq, 512), dtype=torch.int8 if int8 else dt, device="cuda")
+    q1 = torch.empty((N, Hq, 64), dtype=dt, device="cuda")
+    run(cache_mode, kv, kr, q0, q1)
+    kv_ref, kr_ref = mk(512, dt), mk(64, dt)
+    q0_ref, q1_ref = torch.empty((N, Hq, 512), dtype=dt, device="cuda"), torch.empty((N, Hq, 64), dtype=dt, device="cuda")
+    run("krope_ctkv", kv_ref, kr_ref, q0_ref, q1_ref)
+    kv_h, kr_h = kv.cpu(), kr.cpu()
+    k_nope = torch.stack([OK.extract_from_nzcache(kv_h, s_, 32 if int8 else 16) for s_ in slots.tolist()])
+    k_pe = torch.stack([OK.extract_from_nzcache(kr_h, s_, 16) for s_ in slots.tolist()])
+    # the rope cache and q_out1 do not depend on the int8 path: bit-identical to the krope_ctkv run, just laid out differently
+    assert torch.equal(k_pe, kr_ref.view(-1, 64)[slots.long().cuda()].cpu())
+    assert torch.equal(q1.cpu(), q1_ref.cpu())
+    if not int8:
+        assert torch.equal(k_nope, kv_ref.view(-1, 512)[slots.long().cuda()].cpu())
+        assert torch.equal(q0.cpu(), q0_ref.cpu())
+    else:
+        want = OK.mla_preprocess(z["hid"], z["wdqkv"], z["descale0"], z["bias0"], z["gamma1"], z["beta1"], z["gamma2"], z["wuq"],
+                                 z["descale1"], z["bias1"], z["wuk"], z["cos"], z["sin"], z["qs0"], z["qo0"], z["qs1"], z["qo1"],
+                                 cache_mode="int8_nzcache", ctkv_scale=ctkv_scale, qnope_scale=qnope_scale)
+        for name, g, w in (("q_out0", q0.cpu(), want[0]), ("k_nope", k_nope, want[2])):
+            diff = (g.int() - w.int()).abs()
+            assert diff.max().item() <= 1, (name, diff.max().item())
+            assert (diff != 0).double().mean().item() <= 5e-3, (name, (diff != 0).double().mean().item())
+        # the int8 q is exactly the golden's quantisation of the value the bf16 path writes (same kernel, one more rounding step)
+        q0_from_bf16 = OK._quant_per_tensor_muls(q0_ref.cpu(), qnope_scale.reshape(1, Hq, 1), torch.zeros(1))
+        assert torch.equal(q0.cpu(), q0_from_bf16)
+    # slots that were not written stay zero: count the non-zero elements per cache
+    written = set(slots.tolist())
+    for cache, dim, c0 in ((kv_h, 512, 32 if int8 else 16), (kr_h, 64, 16)):
+        keep = torch.ones(cache.numel(), dtype=torch.bool)
+        for s_ in written:
+            keep[OK.nz_cache_offsets(s_, block_size, dim, c0)] = False
+        assert not cache.reshape(-1)[keep].any()
+
+
 def test_mla_preprocess_rejects_modes_it_does_not_implement():
-    """cache modes 2 / 3 are Ascend NZ cache layouts (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-612): they and unknown
-    quant modes must fail loudly; an omitted quant_mode selects per_token_quant_symm, as in the reference (:634-635)."""
+    """Unknown cache / quant modes and inconsistent int8_nzcache arguments must fail loudly; an omitted quant_mode selects
+    per_token_quant_symm, as in the reference (csrc/mla_preprocess/op_host/mla_preprocess.cpp:634-635)."""
     dt = torch.bfloat16
     z = _mla_pre_inputs(2, 16, 2048, dt)
     d = lambda t: t.cuda()
@@ -244,8 +308,9 @@ def test_mla_preprocess_rejects_modes_it_does_not_implement():
             d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), d(z["wuk"]), kv, kr, slots, d(z["qs0"]), d(z["qo0"]), d(z["bias0"]),
             d(z["qs1"]), d(z["qo1"]), d(z["bias1"]))
     outs = dict(q_out0=q0, kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr)
+    # int8_nzcache without its scales / with bf16 outputs is inconsistent; "nz" is not a mode
     for bad in (dict(cache_mode="krope_ctkv", quant_mode="per_channel"), dict(cache_mode="int8_nzcache", quant_mode="per_tensor_quant_asymm"),
-                dict(cache_mode="nzcache", quant_mode="per_tensor_quant_asymm")):
+                dict(cache_mode="nz", quant_mode="per_tensor_quant_asymm")):
         with pytest.raises(RuntimeError):
             torch.ops.npu.mla_preprocess(*args, **bad, **outs)
     torch.ops.npu.mla_preprocess(*args, cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", **outs)      # the built modes run
@@ -260,7 +325,7 @@ def _sgl_lib():
     L = load("libmi_sgl_kernels.so")
     V, I = ctypes.c_void_p, ctypes.c_int
     L.mi_mla_pre_gemm_i8.argtypes = [V, I, I, V, I, I, V, V, V, V, V, I, V]
-    L.mi_mla_pre_bmm_rope.argtypes = [V, I, I, V, V, V, I, V, V, V]
+    L.mi_mla_pre_bmm_rope.argtypes = [V, I, I, V, V, V, I, V, V, V, V]
     L.mi_mla_pre_gemm_i8_partials.argtypes = [I]
     L.mi_mla_pre_gemm_i8.restype = L.mi_mla_pre_bmm_rope.restype = L.mi_mla_pre_gemm_i8_partials.restype = I
     return L
@@ -312,7 +377,7 @@ def test_mla_pre_bmm_rope(M, Hq, dtype, code):
     q0 = torch.zeros((M, Hq, 512), dtype=dtype, device="cuda")
     q1 = torch.zeros((M, Hq, 64), dtype=dtype, device="cuda")
     wuk_t = wuk.transpose(1, 2).contiguous()
-    assert L.mi_mla_pre_bmm_rope(ptr(y), M, Hq, ptr(wuk_t), ptr(cos), ptr(sin), code, ptr(q0), ptr(q1), stream_ptr()) == 0
+    assert L.mi_mla_pre_bmm_rope(ptr(y), M, Hq, ptr(wuk_t), ptr(cos), ptr(sin), code, ptr(q0), ptr(q1), None, stream_ptr()) == 0
     torch.cuda.synchronize()
     yv = y.view(M, Hq, 192)
     exact = torch.einsum("nhk,hkd->nhd", yv[..., :128].double(), wuk.double())
