@@ -28,7 +28,10 @@ namespace mi_ep {
 constexpr int BN = 256, BK = 64;
 // ring depth of the operand stages: 4 x 64-byte k-tiles (4 x 32 KB for the 256-row tile, 4 x 20 KB for the 64-row tile), 3 x 128-byte
 // k-tiles (3 x 40 KB) for the decode tile when K allows it.  (A 5-deep ring for the 256-row tile -- all 160 KB of LDS, four stages in
-// flight -- measured the same as 4: GEMM1 1.08 ms, GEMM2 0.74 ms at C5.  The wait at the k-tile barrier is not a ring-depth effect.)
+// flight -- measured the same as 4: GEMM1 1.08 ms, GEMM2 0.74 ms at C5.  The wait at the k-tile barrier is not a ring-depth effect.
+// Two k-tiles per barrier (the pair being multiplied + the pair in flight): GEMM1 1.085, GEMM2 0.705 -- within the box-to-box
+// noise; the same with a 5-deep ring and three stages in flight: 1.14 / 0.74, i.e. MORE requests in flight make it slower.  What
+// the barrier waits for is the operand stream itself (L2 misses on activation tiles that all 8 XCDs fetch), not latency.)
 template <int BKT> struct RingDepth { static constexpr int value = BKT == 128 ? 3 : 4; };
 constexpr int kGemmThreads = 1024;
 constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
