@@ -617,6 +617,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
     EP_HOST_ASSERT(num_max_dispatch_tokens_per_rank >= x.size(0));
     EP_HOST_ASSERT(topk_idx.dim() == 2 and topk_idx.is_contiguous() and topk_idx.size(0) == x.size(0));
+    EP_HOST_ASSERT(topk_idx.scalar_type() == at::kLong or topk_idx.scalar_type() == at::kInt);
     EP_HOST_ASSERT(num_experts % num_ranks == 0);
     const int T = (int)x.size(0), H = (int)x.size(1), K = (int)topk_idx.size(1);
     const int W = (int)num_ranks, E = (int)num_experts, L = E / W, MT = (int)num_max_dispatch_tokens_per_rank;
@@ -687,6 +688,7 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
     EP_HOST_ASSERT(num_max_dispatch_tokens_per_rank >= topk_idx.size(0));
     EP_HOST_ASSERT(topk_idx.dim() == 2 and topk_idx.is_contiguous());
+    EP_HOST_ASSERT(topk_idx.scalar_type() == at::kLong or topk_idx.scalar_type() == at::kInt);
     EP_HOST_ASSERT(topk_weights.dim() == 2 and topk_weights.is_contiguous() and topk_weights.scalar_type() == at::kFloat);
     EP_HOST_ASSERT(topk_weights.size(0) == topk_idx.size(0) and topk_weights.size(1) == topk_idx.size(1));
     EP_HOST_ASSERT(src_info.scalar_type() == at::kInt and layout_range.scalar_type() == at::kInt);
@@ -853,6 +855,7 @@ static void fused_common_checks(const at::Tensor &x, const at::Tensor &expert_id
 {
     EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
     EP_HOST_ASSERT(expert_ids.dim() == 2 and expert_ids.is_contiguous() and expert_ids.size(0) == x.size(0));
+    EP_HOST_ASSERT(expert_ids.scalar_type() == at::kLong or expert_ids.scalar_type() == at::kInt);
     EP_HOST_ASSERT_S(quant_mode == 1, what, ": only quant_mode=1 (INT8 weights) is implemented on this device");
     EP_HOST_ASSERT(expert_scales.has_value() and expert_scales->dim() == 2);
     EP_HOST_ASSERT(w1.dim() == 3 and w2.dim() == 3);

@@ -295,7 +295,7 @@ class Buffer:
                        num_experts: int, quant_mode: int = 1, fuse_mode: FuseMode = FuseMode.FUSED_DEEP_MOE,
                        profile_enable: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """dispatch -> INT8 grouped GEMM1 -> dequant+SwiGLU+requant -> grouped GEMM2 -> dequant -> combine."""
-        topk_ids = topk_idx.int()
+        topk_ids = topk_idx if topk_idx.dtype in (torch.int32, torch.int64) and topk_idx.is_contiguous() else topk_idx.int().contiguous()
         if fuse_mode == FuseMode.FUSED_DEEP_MOE:
             out, ep_recv_count = self.runtime.fused_deep_moe(x, topk_ids, gmm1_permuted_weight, gmm1_permuted_weight_scale,
                                                              gmm2_weight, gmm2_weight_scale, topk_weights,

@@ -15,6 +15,14 @@ from ..utils import EventOverlap
 _VALID_LL_QUANT = {None, "int8", "mx_fp8_e4m3", "mx_fp8_e5m2", "pertoken_fp8_e4m3", "mx_fp4_e2m1"}
 
 
+def _as_index(topk_idx: torch.Tensor) -> torch.Tensor:
+    """int32 / int64 contiguous indices go to the runtime as they are; anything else is narrowed to int32 like the reference does."""
+    if topk_idx.dtype in (torch.int32, torch.int64) and topk_idx.is_contiguous():
+        return topk_idx
+    return topk_idx.int().contiguous()
+
+
+
 @register_low_latency_strategy("default")
 class DefaultLowLatencyCommStrategy(LowLatencyEPCommStrategy):
     def __init__(self, runtime, group: dist.ProcessGroup, comm_alg: str = "hierarchy"):
@@ -32,7 +40,9 @@ class DefaultLowLatencyCommStrategy(LowLatencyEPCommStrategy):
                              use_mxfp4=False, async_finish=False, return_recv_hook=False, topk_weights=None, quant_mode=None):
         if quant_mode not in _VALID_LL_QUANT:
             raise ValueError(f"Unsupported quant_mode: {quant_mode}")
-        topk_ids = topk_idx.int()      # the reference also narrows to int32 here (:57)
+        # (the reference narrows to int32 here, :57; the kernels below read either width, and at decode sizes the conversion is a
+        # launch that costs as much as the layout kernel)
+        topk_ids = _as_index(topk_idx)
         (packed_recv_x, packed_recv_x_scales, packed_recv_count, packed_recv_src_info, packed_recv_layout_range, event,
          hook) = self.runtime.low_latency_dispatch(
             x, topk_ids, cumulative_local_expert_recv_stats, num_max_dispatch_tokens_per_rank, num_experts, use_fp8,
@@ -46,7 +56,7 @@ class DefaultLowLatencyCommStrategy(LowLatencyEPCommStrategy):
 
     def low_latency_combine(self, x, topk_idx, topk_weights, handle, zero_copy=False, async_finish=False,
                             return_recv_hook=False, out=None):
-        topk_ids = topk_idx.int()
+        topk_ids = _as_index(topk_idx)
         src_info, layout_range, num_max_dispatch_tokens_per_rank, _hidden, num_experts, packed_recv_count, _ = handle
         combined_x, event, hook = self.runtime.low_latency_combine(
             x, topk_ids, topk_weights, src_info, layout_range, num_max_dispatch_tokens_per_rank, num_experts,
