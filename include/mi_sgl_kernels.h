@@ -147,6 +147,11 @@ int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bi
  * q_nope_scale != NULL ([q_heads], I/O dtype; mode 2): q_out0 is int8 [tokens, q_heads, 512] = round(clamp(fp16(q * scale[h]))). */
 int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const void *wuk_t, const void *cos, const void *sin, int dtype,
                         void *q_out0, void *q_out1, const void *q_nope_scale, void *stream);
+/* GEMM2 + per-head BMM + RoPE in one launch (what the op runs): bit-identical to mi_mla_pre_gemm_i8(mode 1, k = 1536) followed by
+ * mi_mla_pre_bmm_rope; the GEMM2 output y never goes to global memory.  a [tokens, 1536] int8, wuq [q_heads*192, 1536] int8. */
+int mi_mla_pre_gemm2_bmm_rope(const int8_t *a, int tokens, const int8_t *wuq, int q_heads, const int32_t *bias, const float *descale,
+                              const float *row_scale, const void *wuk_t, const void *cos, const void *sin, int dtype, void *q_out0,
+                              void *q_out1, const void *q_nope_scale, void *stream);
 
 #ifdef __cplusplus
 }

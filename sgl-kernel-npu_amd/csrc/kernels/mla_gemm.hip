@@ -352,6 +352,272 @@ __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// GEMM2 + per-head BMM + RoPE in ONE launch: a workgroup owns one q head (192 GEMM2 columns = 128 nope | 64 rope) and 128 token rows.
+//   phase A  y[128, 192] = dequant(A8[128, 1536] x Wuq[h*192 .., :]^T): the weights stream through a 2-deep ring of 256-byte k-chunks
+//            (192 rows x 256 B = 48 KB per stage, THREE stages: a CU alone sustains only (bytes in flight) / (memory latency), and with
+//            one chunk in flight this kernel ran 34.7 us; whole-wave LDS-DMA instructions of 4 rows; chunk position XOR row & 15 instead of
+//            row padding), the activations sit in registers for the whole K, y goes to an LDS tile in the I/O dtype -- the rounding
+//            point of the golden (test_mla_preprocess.py:95-107) -- and never to global memory;
+//   phase B  q_out0[:, h, :] = y[:, 0:128] x wuk_t[h]^T with wuk_t[h] streamed through the same ring in four 128-column quarters,
+//            q_out1[:, h, :] = rope_half(y[:, 128:192]).
+// Same MFMA shapes and accumulation order as skinny_i8_k1536_kernel + bmm_rope_kernel, so the outputs are bit-identical to the
+// two-launch path.  128 heads = 128 workgroups: half the CUs, each pulling 426 KB, which is what a CU's DMA stream sustains when
+// the other half is idle; per launch the 6.3 MB y round trip and one launch latency go away.
+// Measured at 128 tokens x 128 heads: 28.8 us against 22.4 + 15.5 us for the two launches.  Shader-clock accounting (s_memtime, one
+// workgroup): phase A 28-31k cycles for 6 chunks = 4.7k per 48 KB chunk (1.5k of MFMA issue per SIMD), dequant + RoPE 8k, phase B 15k.
+// What phase A waits for is the arrival of the chunks at ~10 B/clk per CU, and none of the following moved it: two or three stages in
+// the ring, 48 KB chunks made contiguous in memory, one or two barriers per chunk, DMA issue staggered between the two waves of a
+// SIMD, a deeper ds_read pipeline.  4 waves x 32 rows (every weight fragment feeding two MFMAs, one wave per SIMD) ran 48 us.
+constexpr int kF_Chunk = 256, kF_NChunks = kK2 / kF_Chunk, kF_Rows = 192, kF_Stage = kF_Rows * kF_Chunk;      // 48 KB
+constexpr int kF_YRow = 192 * 2;                                       // y tile row (bytes); the 16 nope chunks of a row are XOR-swizzled
+constexpr int kF_OutRow = 128 * 2 + 16;
+constexpr int kF_Slots = 3;                                            // ring depth: two k-chunks (96 KB) in flight per CU
+constexpr int kF_Lds = kF_Slots * kF_Stage;                            // 147456; the y tile (128 x 384 B) takes over slot 0 after phase A
+static_assert(kBM * kF_YRow <= kF_Stage, "y tile fits a ring slot");
+// byte offset of element (row, col) of the y tile: 16-byte chunk col / 8 of the nope part sits at position chunk ^ ((row >> 1) & 7), so
+// the 16 rows x 16 B of an MFMA operand fetch cover all 64 banks with 384-byte rows (positional columns 128.. are not swizzled)
+__device__ __forceinline__ int ytile_off(int row, int col)
+{
+    const int chunk = col >> 3;
+    const int pos = chunk < 16 ? (chunk ^ ((row >> 1) & 7)) : chunk;
+    return row * kF_YRow + pos * 16 + (col & 7) * 2;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__restrict__ A, int M, const int8_t *__restrict__ W, int Hq,
+                                                            const int32_t *__restrict__ bias, const float *__restrict__ descale,
+                                                            const float *__restrict__ row_scale, const uint16_t *__restrict__ wuk_t,
+                                                            const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
+                                                            uint16_t *__restrict__ out0, uint16_t *__restrict__ out1,
+                                                            const uint16_t *__restrict__ q_nope_scale)
+{
+    // 8 waves, one 16-row MFMA tile each (two waves per SIMD): a wave alone on its SIMD waits out every ds_read_b128 in front of the
+    // two MFMAs it feeds -- the first version of this kernel, 4 waves x 32 rows with all 256 VGPRs taken by the activations, ran
+    // 48 us, slower than the two launches it replaces
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // ring [3][192][256]; slot 0 later: y tile, then output tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, m0 = blockIdx.z * kBM + wave * 16;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
+    uint8_t *ytile = lds + kF_Stage;                       // slot 1
+    const int8_t *wh = W + (size_t)h * kF_Rows * kK2;
+    const uint16_t *uk = wuk_t + (size_t)h * 512 * 128;
+
+    // ---- DMA plans.  One instruction = 4 rows x 256 B; lane l: row 4 i + l / 16, 16-byte position l % 16, which receives source chunk
+    // position ^ (row & 15): a ds_read_b128 of 16 consecutive rows at one k-chunk then touches 16 different bank quads.
+    const int drow = lane >> 4, dpos = lane & 15;
+    auto issue_w = [&](int c, int slot) {                                  // GEMM2 weights, k-chunk c: 48 instructions, 6 per wave
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int row = 4 * (wave * 6 + i) + drow;
+            dma16(lds_base + (uint32_t)(slot * kF_Stage + 4 * (wave * 6 + i) * kF_Chunk),
+                  wh + (size_t)row * kK2 + c * kF_Chunk + ((dpos ^ (row & 15)) << 4));
+        }
+    };
+    // wuk_t[h] travels in eighths: 64 output columns x 256 B = 16 KB = 16 instructions, two per wave; `dst` = LDS byte offset
+    auto issue_uk = [&](int e, int dst) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 4 * (wave * 2 + i) + drow;
+            dma16(lds_base + (uint32_t)(dst + 4 * (wave * 2 + i) * kF_Chunk), uk + ((size_t)(e * 64 + row) * 128) + ((dpos ^ (row & 15)) << 3));
+        }
+    };
+    constexpr int kEighth = 64 * kF_Chunk;                 // 16 KB
+    // where eighth e waits in LDS: 0..2 in slot 0, 3..5 in slot 2, 6 and 7 take the places of 0 and 1 once those have been multiplied
+    auto eighth_at = [&](int e) { return e < 3 ? e * kEighth : e < 6 ? 2 * kF_Stage + (e - 3) * kEighth : (e - 6) * kEighth; };
+    // dequant operands of this lane's 12 columns and 4 rows: requested before anything else (behind the DMA stream their loads would
+    // wait for every piece in flight)
+    float dsc[12], rsc[4];
+    int32_t bsv[12];
+#pragma unroll
+    for (int nt = 0; nt < 12; ++nt) {
+        dsc[nt] = descale[h * kF_Rows + nt * 16 + c16];
+        bsv[nt] = bias ? bias[h * kF_Rows + nt * 16 + c16] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rsc[r] = row_scale ? row_scale[min(m0 + 4 * g + r, M - 1)] : 1.f;
+    // RoPE operands of this lane (row = lane / 4 of the wave's 16, 16 of the 64 positional columns): requested first, used last
+    const int rrow = lane >> 2, rq = lane & 3;
+    const bool rvalid = m0 + rrow < M;
+    uint4 rc[2], rs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        rc[j] = rvalid ? *(const uint4 *)(cosv + (size_t)(m0 + rrow) * 64 + rq * 16 + j * 8) : uint4{0, 0, 0, 0};
+        rs[j] = rvalid ? *(const uint4 *)(sinv + (size_t)(m0 + rrow) * 64 + rq * 16 + j * 8) : uint4{0, 0, 0, 0};
+    }
+    // ---- phase A.  Activations travel WITH the weight chunks: the 4 fragments of chunk c are requested right behind chunk c's DMA
+    // pieces (inline asm, so that the explicit vmcnt below is the only wait they get) into a double buffer.  Holding all 24 fragments
+    // for the whole K left the compiler two registers' worth of ds_read look-ahead in front of every pair of MFMAs (phase A: 31k
+    // cycles against 1.5k of MFMA issue per chunk and SIMD).
+    const int8_t *arow = A + (size_t)min(m0 + c16, M - 1) * kK2 + g * 16;
+    i32x4 afb[2][4];
+    auto issue_a = [&](int c, i32x4 (&dst)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[ks]) : "v"(arow + c * kF_Chunk + ks * 64) : "memory");
+    };
+    issue_w(0, 0);
+    issue_a(0, afb[0]);
+    issue_w(1, 1);
+    issue_a(1, afb[1]);
+    // the compiler's own loads above (dequant operands, cos / sin) are consumed here in its eyes: its wait lands at the start of the
+    // kernel, where it costs nothing extra, instead of in front of the epilogue behind a ring full of requests
+#pragma unroll
+    for (int nt = 0; nt < 12; ++nt) asm volatile("" ::"v"(dsc[nt]), "v"(bsv[nt]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(rsc[r]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(rc[j].x), "v"(rc[j].y), "v"(rc[j].z), "v"(rc[j].w), "v"(rs[j].x), "v"(rs[j].y), "v"(rs[j].z), "v"(rs[j].w));
+    i32x4 acc[12];
+#pragma unroll
+    for (int nt = 0; nt < 12; ++nt) acc[nt] = i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < kF_NChunks; ++c) {
+        // chunk c and its activation fragments landed: requests complete in issue order, and the one request group younger than chunk
+        // c is chunk c + 1 (6 pieces + 4 fragments; behind the last chunk: the 6 pieces of wuk_t's first three eighths).  The
+        // fragment registers are operands of the wait so that no MFMA is scheduled above it.
+        i32x4(&af)[4] = afb[c & 1];
+        if (c + 1 < kF_NChunks) asm volatile("s_waitcnt vmcnt(10)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+        __syncthreads();                                  // chunk c complete for every wave; the slot of chunk c - 1 is free
+        // ONE barrier per chunk: the refill of the freed slot is requested here, by half of the waves before and by the other half
+        // after their MFMAs (waves w and w + 4 share a SIMD: one issues DMA while the other multiplies)
+        auto refill = [&]() {
+            if (c + 2 < kF_NChunks) issue_w(c + 2, (c + 2) % kF_Slots);
+            else if (c == 4) {                            // slot 0 (chunk 3) -> wuk_t[h] eighths 0..2; slot 1 (chunk 4) becomes the y tile
+                issue_uk(0, eighth_at(0));
+                issue_uk(1, eighth_at(1));
+                issue_uk(2, eighth_at(2));
+            }
+        };
+        if (wave < 4) refill();
+        const uint8_t *st = lds + (c % kF_Slots) * kF_Stage;
+        // (a fenced explicit pipeline -- the 12 fragments of k-step ks + 1 requested before the 12 MFMAs of ks -- measured the same
+        // wall time: phase A is not waiting for LDS reads)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 12; ++nt) {
+                const i32x4 bf = *(const i32x4 *)(st + (nt * 16 + c16) * kF_Chunk + (((4 * ks + g) ^ c16) << 4));
+                acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], bf, acc[nt], 0, 0, 0);
+            }
+        if (wave >= 4) refill();
+        if (c + 2 < kF_NChunks) issue_a(c + 2, afb[c & 1]);      // into the buffer this chunk's MFMAs have just read
+    }
+    __syncthreads();                                      // every wave is done with the last chunk (slot 2)
+    issue_uk(3, eighth_at(3));
+    issue_uk(4, eighth_at(4));
+    issue_uk(5, eighth_at(5));
+    // dequant into the I/O dtype -> y tile
+#pragma unroll
+    for (int nt = 0; nt < 12; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float y = (float)(acc[nt][r] + bsv[nt]) * dsc[nt];
+            if (row_scale) y = y * rsc[r];                  // per_token_quant_symm
+            *(uint16_t *)(ytile + ytile_off(wave * 16 + 4 * g + r, nt * 16 + c16)) = sth16<BF16>(y);
+        }
+    asm volatile("" ::: "memory");                       // 2-byte stores above, 16-byte loads below: keep their order (see moe_gemm.hip)
+    // ---- phase B operands: this wave's 16 rows of y_nope as MFMA A fragments; RoPE of its 16 x 64 positional values
+    s16x8 yf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) yf[ks] = *(const s16x8 *)(ytile + ytile_off(wave * 16 + c16, ks * 32 + g * 8));
+    {   // rotate-half RoPE: lane = (row, 16-column quarter); the partner columns (c ^ 32) are quarter ^ 2 of the same y tile row
+        const uint16_t *yrow = (const uint16_t *)(ytile + (wave * 16 + rrow) * kF_YRow) + 128;
+        uint4 xv[2], pv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            xv[j] = *(const uint4 *)(yrow + rq * 16 + j * 8);
+            pv[j] = *(const uint4 *)(yrow + (rq ^ 2) * 16 + j * 8);
+        }
+        if (rvalid) {
+            uint16_t *dst = out1 + ((size_t)(m0 + rrow) * Hq + h) * 64 + rq * 16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t xw[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, pw[4] = {pv[j].x, pv[j].y, pv[j].z, pv[j].w};
+                const uint32_t cw[4] = {rc[j].x, rc[j].y, rc[j].z, rc[j].w}, sw[4] = {rs[j].x, rs[j].y, rs[j].z, rs[j].w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t o2 = 0;
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const float x = ldh16<BF16>((uint16_t)(xw[e] >> (16 * b2)));
+                        const float pr = ldh16<BF16>((uint16_t)(pw[e] >> (16 * b2)));
+                        const float rot = rq < 2 ? -pr : pr;
+                        const float cc = ldh16<BF16>((uint16_t)(cw[e] >> (16 * b2))), ss = ldh16<BF16>((uint16_t)(sw[e] >> (16 * b2)));
+                        o2 |= (uint32_t)sth16<BF16>(x * cc + rot * ss) << (16 * b2);
+                    }
+                    ow[e] = o2;
+                }
+                *(uint4 *)(dst + j * 8) = uint4{ow[0], ow[1], ow[2], ow[3]};
+            }
+        }
+    }
+    const float qsc = q_nope_scale ? ldh16<BF16>(q_nope_scale[h]) : 0.f;
+    uint8_t *otile = ytile + wave * (16 * kF_OutRow);      // the y tile becomes the waves' output tiles after the barrier of quarter 0
+    auto multiply_eighth = [&](int e) {                    // 16 rows x 64 output columns of q_out0
+        const uint8_t *st = lds + eighth_at(e);
+        // four independent accumulation chains (k ascending inside each, as in bmm_rope_kernel): the MFMAs issue back to back
+        f32x4 oacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const s16x8 bf = *(const s16x8 *)(st + (nt * 16 + c16) * kF_Chunk + (((4 * ks + g) ^ c16) << 4));
+                if constexpr (BF16)
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yf[ks]), __builtin_bit_cast(bf16x8, bf), oacc[nt], 0, 0, 0);
+                else
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, yf[ks]), __builtin_bit_cast(f16x8, bf), oacc[nt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *(uint16_t *)(otile + (4 * g + r) * kF_OutRow + (nt * 16 + c16) * 2) = sth16<BF16>(oacc[nt][r]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rl = it * 8 + (lane >> 3), chunk = lane & 7;
+            const int row = m0 + rl;
+            const uint4 v = *(const uint4 *)(otile + rl * kF_OutRow + chunk * 16);
+            if (row >= M) continue;
+            if (!q_nope_scale) {
+                *(uint4 *)(out0 + ((size_t)row * Hq + h) * 512 + e * 64 + chunk * 8) = v;
+            } else {                                        // int8_nzcache: see bmm_rope_kernel
+                const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+                uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float prod = ldh16<BF16>((uint16_t)(wds[j >> 1] >> (16 * (j & 1)))) * qsc;
+                    asm volatile("" : "+v"(prod));
+                    float hq = (float)(_Float16)prod;
+                    hq = fminf(fmaxf(hq, -128.f), 127.f);
+                    pk[j >> 2] |= ((uint32_t)(int)rintf(hq) & 0xFFu) << (8 * (j & 3));
+                }
+                *(uint2 *)((int8_t *)out0 + ((size_t)row * Hq + h) * 512 + e * 64 + chunk * 8) = uint2{pk[0], pk[1]};
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // eighths 0..5 landed
+    __syncthreads();                                        // ... for every wave; the y tile reads are done, it becomes the output tiles
+    multiply_eighth(0);
+    multiply_eighth(1);
+    __syncthreads();                                        // the places of eighths 0 and 1 are free
+    issue_uk(6, eighth_at(6));
+    issue_uk(7, eighth_at(7));
+#pragma unroll 1
+    for (int e = 2; e < 6; ++e) multiply_eighth(e);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    multiply_eighth(6);
+    multiply_eighth(7);
+}
+
 }  // namespace mi_sgl
 
 using namespace mi_sgl;
@@ -425,5 +691,30 @@ extern "C" int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const
         bmm_rope_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t *)y, tokens, q_heads, (const uint16_t *)wuk_t,
                                                                      (const uint16_t *)cos, (const uint16_t *)sin, (uint16_t *)q_out0,
                                                                      (uint16_t *)q_out1, (const uint16_t *)q_nope_scale);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_mla_pre_gemm2_bmm_rope(const int8_t *a, int tokens, const int8_t *wuq, int q_heads, const int32_t *bias,
+                                         const float *descale, const float *row_scale, const void *wuk_t, const void *cos,
+                                         const void *sin, int dtype, void *q_out0, void *q_out1, const void *q_nope_scale, void *stream)
+{
+    if (tokens < 0 || q_heads <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16)) return MI_SGL_EINVAL;
+    if (tokens == 0) return MI_SGL_OK;
+    if (!a || !wuq || !descale || !wuk_t || !cos || !sin || !q_out0 || !q_out1) return MI_SGL_EINVAL;
+    dim3 grid(q_heads, 1, (tokens + kBM - 1) / kBM);
+#define MI_FUSED(B)                                                                                                                 \
+    do {                                                                                                                            \
+        static bool attr_set = false;                                                                                               \
+        if (!attr_set) {                                                                                                            \
+            (void)hipFuncSetAttribute((const void *)gemm2_bmm_rope_kernel<B>, hipFuncAttributeMaxDynamicSharedMemorySize, kF_Lds); \
+            attr_set = true;                                                                                                        \
+        }                                                                                                                           \
+        gemm2_bmm_rope_kernel<B><<<grid, 512, kF_Lds, (hipStream_t)stream>>>(a, tokens, wuq, q_heads, bias, descale, row_scale,     \
+                                                                             (const uint16_t *)wuk_t, (const uint16_t *)cos,        \
+                                                                             (const uint16_t *)sin, (uint16_t *)q_out0,             \
+                                                                             (uint16_t *)q_out1, (const uint16_t *)q_nope_scale);   \
+    } while (0)
+    if (dtype == MI_DTYPE_BF16) MI_FUSED(true); else MI_FUSED(false);
+#undef MI_FUSED
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }

@@ -4,6 +4,7 @@
 // (`torch.ops.npu.<op>`) are unchanged; the dispatch key is CUDA (= HIP on ROCm) instead of PrivateUse1.
 // The implementations are thin host functions (namespace sglang::npu_kernel, like include/sgl_kenel_npu_ops.h:14-239)
 // that validate arguments, allocate outputs and call the C-ABI of include/mi_sgl_kernels.h on the current stream.
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -337,13 +338,24 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
                                     per_token ? tok0.data_ptr<float>() : nullptr, per_token ? tok1.data_ptr<float>() : nullptr, cmode_i,
                                     (int)block_size, cmode_i == 2 ? ctkv_scale->data_ptr() : nullptr, st),
                 "mi_mla_pre_mid failed");
-    at::Tensor y2 = at::empty({N, Hq * 192}, hiddenState.options());              // GEMM2 output materialised in the I/O dtype (golden :95-107)
-    TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)q8.data_ptr(), (int)N, 1536, (const int8_t *)wuq.data_ptr(), (int)(Hq * 192), 1, nullptr,
-                                        per_token ? nullptr : iptr(bias1), descale1.data_ptr<float>(), per_token ? tok1.data_ptr<float>() : nullptr,
-                                        y2.data_ptr(), dt, st), "mi_mla_pre_gemm_i8 (GEMM2) failed");
     at::Tensor wuk_t = prepared_wuk(wuk.to(hiddenState.scalar_type()));
-    TORCH_CHECK(0 == mi_mla_pre_bmm_rope(y2.data_ptr(), (int)N, (int)Hq, wuk_t.data_ptr(), cos.data_ptr(), sin.data_ptr(), dt, q_out0.data_ptr(),
-                                         q_out1.data_ptr(), cmode_i == 2 ? q_nope_scale->data_ptr() : nullptr, st), "mi_mla_pre_bmm_rope failed");
+    const void *qns = cmode_i == 2 ? q_nope_scale->data_ptr() : nullptr;
+    // GEMM2 + per-head BMM + RoPE: one launch, a workgroup per head, the GEMM2 output stays in LDS (MI_MLA_PRE_FUSED=0: the two-launch
+    // form with the GEMM2 output materialised in global memory; bit-identical)
+    static const bool fused = !(getenv("MI_MLA_PRE_FUSED") && atoi(getenv("MI_MLA_PRE_FUSED")) == 0);
+    if (fused) {
+        TORCH_CHECK(0 == mi_mla_pre_gemm2_bmm_rope((const int8_t *)q8.data_ptr(), (int)N, (const int8_t *)wuq.data_ptr(), (int)Hq,
+                                                   per_token ? nullptr : iptr(bias1), descale1.data_ptr<float>(),
+                                                   per_token ? tok1.data_ptr<float>() : nullptr, wuk_t.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                   dt, q_out0.data_ptr(), q_out1.data_ptr(), qns, st), "mi_mla_pre_gemm2_bmm_rope failed");
+    } else {
+        at::Tensor y2 = at::empty({N, Hq * 192}, hiddenState.options());          // GEMM2 output in the I/O dtype (golden :95-107)
+        TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)q8.data_ptr(), (int)N, 1536, (const int8_t *)wuq.data_ptr(), (int)(Hq * 192), 1,
+                                            nullptr, per_token ? nullptr : iptr(bias1), descale1.data_ptr<float>(),
+                                            per_token ? tok1.data_ptr<float>() : nullptr, y2.data_ptr(), dt, st), "mi_mla_pre_gemm_i8 (GEMM2) failed");
+        TORCH_CHECK(0 == mi_mla_pre_bmm_rope(y2.data_ptr(), (int)N, (int)Hq, wuk_t.data_ptr(), cos.data_ptr(), sin.data_ptr(), dt,
+                                             q_out0.data_ptr(), q_out1.data_ptr(), qns, st), "mi_mla_pre_bmm_rope failed");
+    }
     if (kv_cache_out0.data_ptr() != kv_cache.data_ptr()) kv_cache_out0.copy_(kv_cache);
     if (kv_cache_out1.data_ptr() != kv_cache_rope.data_ptr()) kv_cache_out1.copy_(kv_cache_rope);
     return {q_out0, kv_cache_out0, q_out1, kv_cache_out1};

@@ -327,6 +327,8 @@ def _sgl_lib():
     L.mi_mla_pre_gemm_i8.argtypes = [V, I, I, V, I, I, V, V, V, V, V, I, V]
     L.mi_mla_pre_bmm_rope.argtypes = [V, I, I, V, V, V, I, V, V, V, V]
     L.mi_mla_pre_gemm_i8_partials.argtypes = [I]
+    L.mi_mla_pre_gemm2_bmm_rope.argtypes = [V, I, V, I, V, V, V, V, V, V, I, V, V, V, V]
+    L.mi_mla_pre_gemm2_bmm_rope.restype = I
     L.mi_mla_pre_gemm_i8.restype = L.mi_mla_pre_bmm_rope.restype = L.mi_mla_pre_gemm_i8_partials.restype = I
     return L
 
@@ -407,3 +409,33 @@ def test_fused_rope_qk_mqa(T, Hq, Hk, D, R, neox, dtype):
     wide = torch.randn(T, Hq, D + 16).to(dtype).cuda()
     oq2, _ = fused_rope_qk_mqa(wide[..., :D], k.cuda(), cs.cuda(), R, neox)
     assert torch.equal(oq2.cpu(), OK.fused_rope_qk_mqa(wide[..., :D].cpu(), k, cs, R, neox)[0])
+
+
+@pytest.mark.parametrize("M,Hq,per_token,dt", [(128, 128, False, torch.bfloat16), (1, 16, False, torch.bfloat16), (70, 32, True, torch.bfloat16),
+                                              (200, 16, False, torch.float16), (31, 128, True, torch.bfloat16)])
+def test_mla_pre_fused_gemm2_bmm_rope_equals_two_launches(M, Hq, per_token, dt):
+    """mi_mla_pre_gemm2_bmm_rope (one launch, the GEMM2 output stays in LDS) against mi_mla_pre_gemm_i8(mode 1) + mi_mla_pre_bmm_rope:
+    same MFMA shapes and accumulation order, so q_out0 and q_out1 must match BIT FOR BIT -- which carries every parity statement of
+    the two-launch kernels (exact int32 products, golden rounding points) over to the fused one."""
+    from capi import ptr, stream_ptr
+    L = _sgl_lib()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + Hq)
+    code = 0 if dt == torch.bfloat16 else 1                       # MI_DTYPE_BF16 / MI_DTYPE_F16
+    a8 = torch.randint(-127, 128, (M, 1536), generator=g, device="cuda", dtype=torch.int8)
+    wuq = torch.randint(-8, 8, (Hq * 192, 1536), generator=g, device="cuda", dtype=torch.int8)
+    descale = torch.rand(Hq * 192, generator=g, device="cuda") * 1e-3 + 5e-4
+    bias = None if per_token else torch.randint(-50, 50, (Hq * 192,), generator=g, device="cuda", dtype=torch.int32)
+    rscale = (torch.rand(M, generator=g, device="cuda") * 0.02 + 0.01) if per_token else None
+    wuk_t = (torch.randn((Hq, 512, 128), generator=g, device="cuda") * 0.1).to(dt)
+    cos, sin = torch.rand((M, 64), generator=g, device="cuda").to(dt), torch.rand((M, 64), generator=g, device="cuda").to(dt)
+    y = torch.empty((M, Hq * 192), dtype=dt, device="cuda")
+    q0a, q1a = torch.full((M, Hq, 512), 7.0, dtype=dt, device="cuda"), torch.full((M, Hq, 64), 7.0, dtype=dt, device="cuda")
+    q0b, q1b = torch.full_like(q0a, 9.0), torch.full_like(q1a, 9.0)
+    p = lambda t: None if t is None else ptr(t)
+    assert L.mi_mla_pre_gemm_i8(ptr(a8), M, 1536, ptr(wuq), Hq * 192, 1, None, p(bias), ptr(descale), p(rscale), ptr(y), code, stream_ptr()) == 0
+    assert L.mi_mla_pre_bmm_rope(ptr(y), M, Hq, ptr(wuk_t), ptr(cos), ptr(sin), code, ptr(q0a), ptr(q1a), None, stream_ptr()) == 0
+    assert L.mi_mla_pre_gemm2_bmm_rope(ptr(a8), M, ptr(wuq), Hq, p(bias), ptr(descale), p(rscale), ptr(wuk_t), ptr(cos), ptr(sin), code,
+                                       ptr(q0b), ptr(q1b), None, stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(q1a.view(torch.int16), q1b.view(torch.int16)), "rope columns"
+    assert torch.equal(q0a.view(torch.int16), q0b.view(torch.int16)), "BMM output"
