@@ -365,7 +365,8 @@ __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restric
 // Same MFMA shapes and accumulation order as skinny_i8_k1536_kernel + bmm_rope_kernel, so the outputs are bit-identical to the
 // two-launch path.  128 heads = 128 workgroups: half the CUs, each pulling 426 KB, which is what a CU's DMA stream sustains when
 // the other half is idle; per launch the 6.3 MB y round trip and one launch latency go away.
-// Measured at 128 tokens x 128 heads: 28.8 us against 22.4 + 15.5 us for the two launches.  Shader-clock accounting (s_memtime, one
+// Measured at 128 tokens x 128 heads: 26.6 us (28.8 before the per-head rotation of the piece order) against 22.4 + 15.5 us for
+// the two launches.  Shader-clock accounting (s_memtime, one
 // workgroup): phase A 28-31k cycles for 6 chunks = 4.7k per 48 KB chunk (1.5k of MFMA issue per SIMD), dequant + RoPE 8k, phase B 15k.
 // What phase A waits for is the arrival of the chunks at ~10 B/clk per CU, and none of the following moved it: two or three stages in
 // the ring, 48 KB chunks made contiguous in memory, one or two barriers per chunk, DMA issue staggered between the two waves of a
@@ -408,11 +409,17 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     // ---- DMA plans.  One instruction = 4 rows x 256 B; lane l: row 4 i + l / 16, 16-byte position l % 16, which receives source chunk
     // position ^ (row & 15): a ds_read_b128 of 16 consecutive rows at one k-chunk then touches 16 different bank quads.
     const int drow = lane >> 4, dpos = lane & 15;
+    const int rot48 = (h * 11) % 48;
+    // (walking the k-chunks in a per-head rotated order on top of that changed nothing: 26.6 us either way)
     auto issue_w = [&](int c, int slot) {                                  // GEMM2 weights, k-chunk c: 48 instructions, 6 per wave
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const int row = 4 * (wave * 6 + i) + drow;
-            dma16(lds_base + (uint32_t)(slot * kF_Stage + 4 * (wave * 6 + i) * kF_Chunk),
+            // the 48 pieces of a chunk are requested in an order rotated by head: every workgroup's weight block starts 288 KB
+            // after its neighbour's, so in lockstep they would all be asking the same few memory channels for the same rows
+            int piece = wave * 6 + i + rot48;
+            piece = piece >= 48 ? piece - 48 : piece;
+            const int row = 4 * piece + drow;
+            dma16(lds_base + (uint32_t)(slot * kF_Stage + 4 * piece * kF_Chunk),
                   wh + (size_t)row * kK2 + c * kF_Chunk + ((dpos ^ (row & 15)) << 4));
         }
     };
