@@ -31,7 +31,10 @@ constexpr int BN = 256, BK = 64;
 // flight -- measured the same as 4: GEMM1 1.08 ms, GEMM2 0.74 ms at C5.  The wait at the k-tile barrier is not a ring-depth effect.
 // Two k-tiles per barrier (the pair being multiplied + the pair in flight): GEMM1 1.085, GEMM2 0.705 -- within the box-to-box
 // noise; the same with a 5-deep ring and three stages in flight: 1.14 / 0.74, i.e. MORE requests in flight make it slower.  What
-// the barrier waits for is the operand stream itself (L2 misses on activation tiles that all 8 XCDs fetch), not latency.)
+// the barrier waits for is the operand stream itself (L2 misses on activation tiles that all 8 XCDs fetch), not latency.
+// Starting every tile's walk over K at a different k-tile (exact: integer accumulation) -- which spreads the memory channels a
+// lockstep launch hits and helped the per-head mla_preprocess kernel -- is WORSE here: GEMM1 1.07 -> 1.14 ms, GEMM2 0.73 -> 0.80 ms
+// (decode tile: 170 -> 175 us, 115 -> 110 us): the tiles that share an operand tile want to read the same k-tile at the same time.)
 template <int BKT> struct RingDepth { static constexpr int value = BKT == 128 ? 3 : 4; };
 constexpr int kGemmThreads = 1024;
 constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
