@@ -368,9 +368,11 @@ __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restric
 // Measured at 128 tokens x 128 heads: 26.6 us (28.8 before the per-head rotation of the piece order) against 22.4 + 15.5 us for
 // the two launches.  Shader-clock accounting (s_memtime, one
 // workgroup): phase A 28-31k cycles for 6 chunks = 4.7k per 48 KB chunk (1.5k of MFMA issue per SIMD), dequant + RoPE 8k, phase B 15k.
-// What phase A waits for is the arrival of the chunks at ~10 B/clk per CU, and none of the following moved it: two or three stages in
-// the ring, 48 KB chunks made contiguous in memory, one or two barriers per chunk, DMA issue staggered between the two waves of a
-// SIMD, a deeper ds_read pipeline.  4 waves x 32 rows (every weight fragment feeding two MFMAs, one wave per SIMD) ran 48 us.
+// None of the following moved phase A: two or three stages in the ring, 48 KB chunks made contiguous in memory, one or two barriers per
+// chunk, DMA issue staggered between the two waves of a SIMD, a deeper ds_read pipeline.  Ablations (whole kernel, 26.6 us): without
+// the weight DMA 28.3 us, without the LDS operand reads 24.4, without the activation loads 24.4 -- it is not waiting for memory (a
+// plain stream over 128 CUs reaches 5.6 TB/s, tools/probes/stream_probe.hip); what is left is eight waves meeting at a barrier every
+// 48 MFMAs.  4 waves x 32 rows (every weight fragment feeding two MFMAs, one wave per SIMD) ran 48 us.
 constexpr int kF_Chunk = 256, kF_NChunks = kK2 / kF_Chunk, kF_Rows = 192, kF_Stage = kF_Rows * kF_Chunk;      // 48 KB
 constexpr int kF_YRow = 192 * 2;                                       // y tile row (bytes); the 16 nope chunks of a row are XOR-swizzled
 constexpr int kF_OutRow = 128 * 2 + 16;
