@@ -37,6 +37,25 @@ __global__ __launch_bounds__(512) void stream_kernel(const uint8_t *src, size_t 
     if (acc[0] == 0x12345678u) sink[0] = acc[1];
 }
 
+// the access pattern of combine_reduce: a wave takes one 1 KB segment of 8 pseudo-random 14 KB rows (a token's K expert rows)
+__global__ __launch_bounds__(256) void gather_kernel(const uint8_t *src, size_t nrows, size_t tokens, uint32_t *sink)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t t = wid / 14, seg = wid % 14;
+    if (t >= tokens) return;
+    u32x4 acc = {0, 0, 0, 0};
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t row = ((t * 8 + k) * 2654435761ull + 12345) % nrows;
+        v[k] = __builtin_nontemporal_load((const u32x4 *)(src + row * 14336 + seg * 1024 + lane * 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc ^= v[k];
+    if (acc[0] == 0x12345678u) sink[0] = acc[1];
+}
+
 template <int MODE, int DEPTH>
 static void run(const uint8_t *src, size_t total, int wgs, int threads, uint32_t *sink)
 {
@@ -77,5 +96,22 @@ int main()
     }
     run<0, 8>(src, total, 2048, 256, sink);
     run<1, 8>(src, total, 2048, 256, sink);
+    {
+        const size_t nrows = total / 14336, tokens = 4096 * 2;      // 8192 tokens x 8 rows x 14 KB = 0.94 GB of reads
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0), hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+            hipEventRecord(e0);
+            gather_kernel<<<(unsigned)((tokens * 14 + 3) / 4), 256>>>(src, nrows, tokens, sink);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("gather of 8 random 14 KB rows per token, 1 KB per wave and row: %7.1f us  %6.2f TB/s\n", best * 1e3,
+               tokens * 8 * 14336.0 / (best * 1e-3) / 1e12);
+    }
     return 0;
 }
