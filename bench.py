@@ -175,7 +175,7 @@ def routing_stats(topk_idx, world, rank):
     return pairs.tolist(), tokens.tolist()
 
 
-def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank, n_local=0):
+def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank, n_local=0, n_local_tok=0):
     """Algorithmic HBM bytes of one launch (DESIGN.md section 4).  n_tok_rank = distinct (token, destination rank) pairs;
     n_local = received rows whose token lives on this rank (the combine does not move those: the push stores their row number, the
     reduce reads them from the expert output)."""
@@ -183,13 +183,16 @@ def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank, n_local=0):
     return {
         "dispatch_stage": T * H * 2 + T * row + n_pairs * 8,    # read bf16 tokens once, write one int8 row per token + the index
         "dispatch_stage_push": T * H * 2 + n_tok_rank * row + n_pairs * 8,   # one row per (token, destination rank) + the index
-        "dispatch_pull": 2 * n_recv * row + n_recv * 8,         # read a token row + index entry per received row, write recv_x / scales / triples
+        # read a token row + index entry per received row, write recv_x / scales / triples; this rank's own tokens (n_local rows of
+        # n_local_tok tokens) are read once per TOKEN
+        "dispatch_pull": 2 * (n_recv - n_local) * row + (n_recv - n_local) * 8 + (n_local_tok + n_local) * row,
         "combine_push": 2 * (n_recv - n_local) * H * 2 + n_recv * 12 + n_local * 4,   # rows read and written into the owners' slots
         "combine_reduce": n_pairs * H * 2 + T * H * 2,          # read K slots per token, write one bf16 row
     }[name]
 
 
-PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatch_pull": "pull_indexed_kernel",
+# (N = 1: every received row is one of this rank's own tokens, so the whole pull is the token-wise pull_local_kernel)
+PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatch_pull": "pull_local_kernel<false>",
                     "combine_push": "combine_push_kernel", "combine_reduce": "combine_reduce_kernel<false, 8>"}
 
 
@@ -560,7 +563,9 @@ def main():
         bulk = [k for k in per if k in ("dispatch_stage", "dispatch_stage_push", "dispatch_pull", "combine_push", "combine_reduce")]
         dom = max(bulk, key=lambda k: per[k]["avg_us"])
         n_local = rows_from[rank] if windowed and os.environ.get("MI_EP_COMBINE_LOCAL", "1") != "0" else 0
-        kb = lambda k: kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv, n_tok_rank, n_local)
+        n_local_d = rows_from[rank] if windowed and os.environ.get("MI_EP_DISPATCH_LOCAL", "1") != "0" else 0
+        kb = lambda k: kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv, n_tok_rank, n_local if k.startswith("combine") else n_local_d,
+                                    tokens_to[rank] if n_local_d else 0)
         alg = kb(dom)
         achieved = alg / (per[dom]["avg_us"] * 1e-6) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -193,7 +193,18 @@ int mi_ep_dispatch_stage_compact(const void *x, const void *topk_idx, int idx_is
 int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset,
                                 int num_ranks, int num_local_experts, int hidden, int num_topk, int quant_mode, int rows_hint,
                                 size_t region_bytes, void *recv_x, float *recv_x_scales, int32_t *recv_src_idx,
-                                const uint64_t *epoch_ctr, size_t parity_stride /* consume side: half *epoch_ctr & 1 */, void *stream);
+                                const uint64_t *epoch_ctr, size_t parity_stride /* consume side: half *epoch_ctr & 1 */,
+                                int skip_src /* -1, or a source rank whose rows mi_ep_dispatch_pull_local writes */, void *stream);
+/* The rows whose token lives on this rank, token by token: the staged row of token t (`my_rows` = the own region for the pull
+ * transport, the own source slab for push; half 0) is read once and stored to each selection (t, k) served by this rank's experts,
+ * at output row recv_count[le * W + me] - num_tokens_per_expert[me * L + le] + send_token_idx_small[t, k] -- the rows, scales and
+ * triples mi_ep_dispatch_pull_indexed writes for source `my_rank`, which is then called with skip_src = my_rank (not at all when
+ * num_ranks == 1).  K-fold fewer reads of the staged rows for the local share of the traffic. */
+int mi_ep_dispatch_pull_local(const void *my_rows, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                              const int32_t *recv_count, const int32_t *num_tokens_per_expert, int num_tokens, int num_topk,
+                              int hidden, int num_experts, int num_ranks, int my_rank, int quant_mode, int rows_hint, void *recv_x,
+                              float *recv_x_scales, int32_t *recv_src_idx, const uint64_t *epoch_ctr, size_t parity_stride,
+                              void *stream);
 
 /* Push transport of normal dispatch (selectable next to the pull above; the same received bytes).  The sender writes the
  * quantised row of token t ONCE into the window of every rank that owns at least one of the token's experts (the reference

@@ -401,6 +401,8 @@ Buffer::DispatchExchange Buffer::dispatch_exchange(const at::Tensor &x, const at
     ex.src_bases = region_peers;
     if (ex.push)
         for (int s = 0; s < W; ++s) ex.src_bases[(size_t)s] = family_base(kDispatch) + (size_t)s * ex.slab_bytes;
+    ex.topk_idx = topk_idx, ex.send_token_idx_small = lay.send_token_idx_small, ex.num_tokens_per_expert = lay.num_tokens_per_expert;
+    ex.num_tokens = T, ex.num_experts = E;
     return ex;
 }
 
@@ -414,10 +416,20 @@ void Buffer::dispatch_pull(const DispatchExchange &ex, int H, int K, int L, int 
     rs = at::empty({rows_alloc}, at::dtype(at::kFloat).device(dev));
     src_idx = at::empty({rows_alloc * 3}, at::dtype(at::kInt).device(dev));
     ProfScope ps_(this, "dispatch_pull", st);
-    MI_EP_CHECK(mi_ep_dispatch_pull_indexed((const void *const *)ex.src_bases.data(), ex.nt.recv_count.data_ptr<int>(),
-                                            ex.nt.pull_offset.data_ptr<int>(), (int)num_ranks, L, H, K, qm, (int)rows_alloc, ex.slab_bytes,
-                                            rx.data_ptr(), quant ? rs.data_ptr<float>() : nullptr, src_idx.data_ptr<int>(),
-                                            epoch_ctr(kDispatch), region_bytes, st));
+    // this rank's own tokens are gathered token by token (their staged row is read once, not once per selection); everybody else's
+    // rows row by row.  MI_EP_DISPATCH_LOCAL=0: every row through pull_indexed.
+    static const bool local = !(getenv("MI_EP_DISPATCH_LOCAL") && atoi(getenv("MI_EP_DISPATCH_LOCAL")) == 0);
+    if (local && ex.num_tokens > 0)
+        MI_EP_CHECK(mi_ep_dispatch_pull_local(ex.src_bases[(size_t)rank], ex.topk_idx.data_ptr(), ex.topk_idx.scalar_type() == at::kInt,
+                                              ex.send_token_idx_small.data_ptr<int>(), ex.nt.recv_count.data_ptr<int>(),
+                                              ex.num_tokens_per_expert.data_ptr<int>(), ex.num_tokens, K, H, ex.num_experts, (int)num_ranks,
+                                              (int)rank, qm, (int)rows_alloc, rx.data_ptr(), quant ? rs.data_ptr<float>() : nullptr,
+                                              src_idx.data_ptr<int>(), epoch_ctr(kDispatch), region_bytes, st));
+    if (!(local && num_ranks == 1))
+        MI_EP_CHECK(mi_ep_dispatch_pull_indexed((const void *const *)ex.src_bases.data(), ex.nt.recv_count.data_ptr<int>(),
+                                                ex.nt.pull_offset.data_ptr<int>(), (int)num_ranks, L, H, K, qm, (int)rows_alloc,
+                                                ex.slab_bytes, rx.data_ptr(), quant ? rs.data_ptr<float>() : nullptr,
+                                                src_idx.data_ptr<int>(), epoch_ctr(kDispatch), region_bytes, local ? (int)rank : -1, st));
 }
 
 std::tuple<at::Tensor, std::optional<at::Tensor>, std::optional<at::Tensor>, std::optional<at::Tensor>, std::vector<int>,

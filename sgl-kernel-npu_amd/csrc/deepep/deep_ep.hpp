@@ -208,6 +208,9 @@ private:
         std::vector<void *> src_bases;     // where the receive side finds source s's token rows + index (half 0 of the ping-pong)
         size_t slab_bytes = 0;
         bool push = false;
+        // what the token-wise gather of this rank's own rows needs (mi_ep_dispatch_pull_local)
+        at::Tensor topk_idx, send_token_idx_small, num_tokens_per_expert;
+        int num_tokens = 0, num_experts = 0;
     };
     DispatchExchange dispatch_exchange(const at::Tensor &x, const at::Tensor &topk_idx, const Layout &lay, int E, int qm,
                                        bool want_summary, int32_t *wait_stats, hipStream_t st);

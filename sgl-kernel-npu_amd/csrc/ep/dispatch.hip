@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int W, int LW,
     int payload_bytes, size_t idx_off, size_t idx_entries, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
-    int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par)
+    int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par, int skip_src)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
     for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
@@ -354,6 +354,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         }
         const int j = (int)(r - (lo ? cum[lo - 1] : 0));
         src = lo % W;
+        if (src == skip_src) return uint2{0u, 0u};                // rows of this rank's own tokens: written by pull_local_kernel
         // a corrupt count / offset must not turn into a wild (possibly cross-GPU) read: the index holds idx_entries entries
         const size_t pos = min((size_t)max(pull_offset[lo] + j, 0), idx_entries - 1);
         return ((const uint2 *)((const uint8_t *)srcs.p[src] + poff + idx_off))[pos];
@@ -368,6 +369,10 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         const uint2 e = e_n;
         const long long rn = r + nw;
         if (rn < total) e_n = entry(rn, src_n);                  // in flight while this row is copied
+        if (src == skip_src) {
+            r = rn;
+            continue;
+        }
         // a stale index entry must not turn into a wild read: token rows live below the index
         const size_t trow = min((size_t)e.x, idx_off / stride - 1);
         const uint8_t *srow = (const uint8_t *)srcs.p[src] + poff + trow * stride;
@@ -393,6 +398,63 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
             recv_src_idx[r * 3 + 2] = (int32_t)e.y;
         }
         r = rn;
+    }
+}
+
+// Receive rows whose token lives on THIS rank, written token by token instead of row by row: the staged row of token t (own region
+// or own source slab) is read ONCE and stored to each of its selections served by this rank's experts -- output row
+// start(le, me) + send_token_idx_small[t, k], start = recv_count[le * W + me] - num_tokens_per_expert[me * L + le] -- with the same
+// bytes, scale and (me, t, k) triple pull_indexed_kernel produces for it (which then skips source `me`).  At EP = 1 that is the whole
+// pull: T staged rows read instead of T * K.
+template <bool I32>
+__global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
+    const uint8_t *__restrict__ my_rows, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
+    const int32_t *__restrict__ recv_count, const int32_t *__restrict__ tokens_per_expert, int T, int K, int E, int W, int my_rank,
+    int payload_bytes, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales, int32_t *__restrict__ recv_src_idx,
+    int row_capacity, Parity par)
+{
+    const int lane = lane_id();
+    const int t = blockIdx.x * kPullWaves + threadIdx.x / kWave;
+    if (t >= T) return;
+    const int L = E / W;
+    int r_l = -1;
+    if (lane < K) {
+        const long long e = ld_idx<I32>(topk_idx, (long long)t * K + lane);
+        if (e >= 0 && e < E && (int)(e / L) == my_rank) {
+            const int le = (int)(e % L);
+            const int r = recv_count[le * W + my_rank] - tokens_per_expert[e] + idx_small[(long long)t * K + lane];
+            if (r >= 0 && r < row_capacity) r_l = r;
+        }
+    }
+    unsigned long long lmask = __ballot(r_l >= 0);
+    if (lmask == 0ull) return;
+    const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
+    const uint8_t *srow = my_rows + parity_off(par) + (size_t)t * stride;
+    const u32x4 *s16 = (const u32x4 *)srow;
+    const int n16 = payload_bytes / 16;
+    const float scale = *(const float *)(srow + payload_bytes);
+    for (int base = 0; base < n16; base += kWave * 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int item = base + u * kWave + lane;
+            if (item < n16) v[u] = s16[item];
+        }
+        for (unsigned long long m = lmask; m; m &= m - 1) {       // wave-uniform walk over this rank's selections of the token
+            const int k = __builtin_ctzll(m);
+            u32x4 *d16 = (u32x4 *)(recv_x + (size_t)__shfl(r_l, k, kWave) * payload_bytes);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = base + u * kWave + lane;
+                if (item < n16) d16[item] = v[u];
+            }
+        }
+    }
+    if (r_l >= 0) {                                               // lane k writes the meta of selection k
+        if (recv_scales) recv_scales[r_l] = scale;
+        recv_src_idx[(size_t)r_l * 3 + 0] = my_rank;
+        recv_src_idx[(size_t)r_l * 3 + 1] = t;
+        recv_src_idx[(size_t)r_l * 3 + 2] = lane;
     }
 }
 
@@ -522,10 +584,11 @@ extern "C" int mi_ep_dispatch_pull(const void *const *src_base_host, const int32
 extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t *recv_count,
                                            const int32_t *pull_offset, int W, int L, int H, int K, int quant_mode,
                                            int rows_hint, size_t region_bytes, void *recv_x, float *recv_x_scales,
-                                           int32_t *recv_src_idx, const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
+                                           int32_t *recv_src_idx, const uint64_t *epoch_ctr, size_t parity_stride, int skip_src,
+                                           void *stream)
 {
     if (!src_base_host || !recv_count || !pull_offset || W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || H <= 0 || H % 16 || K <= 0 ||
-        K > MI_EP_MAX_TOPK || !recv_x || !recv_src_idx)
+        K > MI_EP_MAX_TOPK || !recv_x || !recv_src_idx || skip_src >= W)
         return MI_EP_EINVAL;
     if (rows_hint <= 0) return MI_EP_OK;
     PeerPtrs pp;
@@ -542,7 +605,30 @@ extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, con
     const size_t lds = (size_t)L * W * sizeof(int32_t);
     pull_indexed_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
         pp, recv_count, pull_offset, W, L * W, payload, idx_off, (idx_off / mi_ep_dispatch_row_bytes(H, quant_mode)) * (size_t)K,
-        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, make_parity(epoch_ctr, 0, parity_stride));
+        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, make_parity(epoch_ctr, 0, parity_stride), skip_src < 0 ? -1 : skip_src);
+    return launch_status();
+}
+
+extern "C" int mi_ep_dispatch_pull_local(const void *my_rows, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
+                                         const int32_t *recv_count, const int32_t *num_tokens_per_expert, int T, int K, int H, int E,
+                                         int W, int my_rank, int quant_mode, int rows_hint, void *recv_x, float *recv_x_scales,
+                                         int32_t *recv_src_idx, const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
+{
+    if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || E <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E % W || my_rank < 0 ||
+        my_rank >= W)
+        return MI_EP_EINVAL;
+    if (T == 0 || rows_hint <= 0) return MI_EP_OK;               // a rank without tokens has nothing of its own to gather
+    if (!my_rows || !topk_idx || !send_token_idx_small || !recv_count || !num_tokens_per_expert || !recv_x || !recv_src_idx)
+        return MI_EP_EINVAL;
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    const int blocks = (T + kPullWaves - 1) / kPullWaves;
+    const Parity par = make_parity(epoch_ctr, 0, parity_stride);
+#define MI_EP_PULL_LOCAL(I32)                                                                                                       \
+    pull_local_kernel<I32><<<blocks, kWave * kPullWaves, 0, (hipStream_t)stream>>>(                                                \
+        (const uint8_t *)my_rows, topk_idx, send_token_idx_small, recv_count, num_tokens_per_expert, T, K, E, W, my_rank, payload, \
+        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, par)
+    if (idx_is_i32) MI_EP_PULL_LOCAL(true); else MI_EP_PULL_LOCAL(false);
+#undef MI_EP_PULL_LOCAL
     return launch_status();
 }
 

@@ -34,7 +34,8 @@ def _lib():
     lib.mi_ep_dispatch_index_offset.restype = c_size_t
     lib.mi_ep_dispatch_index_offset.argtypes = [I, I, I, c_size_t]
     lib.mi_ep_dispatch_stage_compact.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, c_size_t, V, c_size_t, V]
-    lib.mi_ep_dispatch_pull_indexed.argtypes = [V, V, V, I, I, I, I, I, I, c_size_t, V, V, V, V, c_size_t, V]
+    lib.mi_ep_dispatch_pull_indexed.argtypes = [V, V, V, I, I, I, I, I, I, c_size_t, V, V, V, V, c_size_t, I, V]
+    lib.mi_ep_dispatch_pull_local.argtypes = [V, V, I, V, V, V, I, I, I, I, I, I, I, I, V, V, V, V, c_size_t, V]
     lib.mi_ep_dispatch_push_slab_bytes.restype = c_size_t
     lib.mi_ep_dispatch_push_slab_bytes.argtypes = [c_size_t, I]
     lib.mi_ep_dispatch_stage_push.argtypes = [V, V, I, V, V, I, I, I, I, I, I, I, V, c_size_t, V, c_size_t, V]
@@ -47,7 +48,7 @@ def _lib():
     lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
     lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, I, V, I, V]
     for n in ("mi_ep_dispatch_layout mi_ep_signal mi_ep_wait mi_ep_notify_post mi_ep_notify_wait mi_ep_notify_tables "
-              "mi_ep_dispatch_stage mi_ep_dispatch_pull mi_ep_dispatch_stage_compact mi_ep_dispatch_pull_indexed mi_ep_combine_push mi_ep_combine_reduce mi_ep_ll_dispatch_send "
+              "mi_ep_dispatch_stage mi_ep_dispatch_pull mi_ep_dispatch_stage_compact mi_ep_dispatch_pull_indexed mi_ep_dispatch_pull_local mi_ep_combine_push mi_ep_combine_reduce mi_ep_ll_dispatch_send "
               "mi_ep_ll_post_counts mi_ep_ll_dispatch_recv").split():
         getattr(lib, n).restype = c_int
     return lib
@@ -170,11 +171,18 @@ class InProcEP:
             if self.transport == "push":
                 slab = L_.mi_ep_dispatch_push_slab_bytes(self.send_win[r].numel(), W)
                 own = ptr_array([self.send_win[r].data_ptr() + s_ * slab for s_ in range(W)])
-                ck(L_.mi_ep_dispatch_pull_indexed(own, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
-                                                  R, slab, ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, st))
+                # the host runtime's form: own tokens token by token (pull_local), the other sources row by row
+                T_r = int(topk_idxs[r].shape[0])
+                ck(L_.mi_ep_dispatch_pull_local(c_void_p(self.send_win[r].data_ptr() + r * slab), ptr(topk_idxs[r]),
+                                                int(topk_idxs[r].dtype == torch.int32), ptr(lay[r]["send_token_idx_small"]),
+                                                ptr(tb["recv_count"]), ptr(lay[r]["num_tokens_per_expert"]), T_r, K, H, E, W, r, quant_mode,
+                                                R, ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, st))
+                if W > 1:
+                    ck(L_.mi_ep_dispatch_pull_indexed(own, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
+                                                      R, slab, ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, r, st))
             elif self.compact:
                 ck(L_.mi_ep_dispatch_pull_indexed(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
-                                                  R, self.send_win[r].numel(), ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, st))
+                                                  R, self.send_win[r].numel(), ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, -1, st))
             else:
                 ck(L_.mi_ep_dispatch_pull(src_ptrs, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, quant_mode, R,
                                           ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
