@@ -145,6 +145,11 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
         scale_out = (amax == 0.f) ? 0.f : 1.0f / s;
     }
     u32x4 q[kMaxItems];
+    // the raw row is made opaque between the two passes: otherwise the compiler keeps the 128 floats it unpacked for the maximum alive
+    // for the quantisation (161 VGPRs, 3 waves per SIMD -- the 4096 token waves of a C2 batch then need two rounds); unpacking again
+    // costs one shift / mask per element
+#pragma unroll
+    for (int it = 0; it < kMaxItems; ++it) asm volatile("" : "+v"(raw[it][0]), "+v"(raw[it][1]));
 #pragma unroll
     for (int it = 0; it < kMaxItems; ++it) {
 #pragma unroll
@@ -315,6 +320,25 @@ __device__ __forceinline__ void pull_body(
 }
 
 
+// Store of a received row.  A receive buffer larger than the last-level cache (kPullWriteAround) is written around it
+// (nontemporal): left to write-back, its dirty lines are evicted under the NEXT kernels' loads -- measured at C2 (235 MB received):
+// the pull itself 44 -> 52 us, but the stage kernel of the following call 30 -> 19 us and the combine reduce 110 -> 102 us, the
+// step 0.222 -> 0.208 ms.  Decode-size receives stay cached for the grouped GEMM that reads them next.
+constexpr size_t kPullWriteAround = 64u << 20;
+template <bool NT>
+__device__ __forceinline__ void st_row(u32x4 *p, const u32x4 &v)
+{
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+static bool pull_write_around(long long rows, int payload)
+{
+    static const char *env = getenv("MI_EP_PULL_NT");             // 0 / 1 force the choice (measurement only)
+    if (env && *env) return atoi(env) != 0;
+    return (size_t)rows * (size_t)payload >= kPullWriteAround;
+}
+
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int seg_capacity,
     int W, int LW, int payload_bytes, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
@@ -331,6 +355,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
 // index[pull_offset + j].t of rank src.  The index entry of a wave's next row is requested before the current row is copied,
 // so the extra dependent (possibly remote) read is off the critical path.  Token rows are read up to K times (once per
 // selected expert): plain loads, so the local ones come from L2 / MALL after the first touch.
+template <bool NT>
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int W, int LW,
     int payload_bytes, size_t idx_off, size_t idx_entries, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
@@ -388,7 +413,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int item = base + u * kWave + lane;
-                if (item < n16) d16[item] = v[u];
+                if (item < n16) st_row<NT>(d16 + item, v[u]);
             }
         }
         if (lane == 0) {
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
 // start(le, me) + send_token_idx_small[t, k], start = recv_count[le * W + me] - num_tokens_per_expert[me * L + le] -- with the same
 // bytes, scale and (me, t, k) triple pull_indexed_kernel produces for it (which then skips source `me`).  At EP = 1 that is the whole
 // pull: T staged rows read instead of T * K.
-template <bool I32>
+template <bool I32, bool NT>
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
     const uint8_t *__restrict__ my_rows, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
     const int32_t *__restrict__ recv_count, const int32_t *__restrict__ tokens_per_expert, int T, int K, int E, int W, int my_rank,
@@ -446,7 +471,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int item = base + u * kWave + lane;
-                if (item < n16) d16[item] = v[u];
+                if (item < n16) st_row<NT>(d16 + item, v[u]);
             }
         }
     }
@@ -603,9 +628,12 @@ extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, con
     static const long long cap = getenv("MI_EP_PULL_BLOCKS") ? atoll(getenv("MI_EP_PULL_BLOCKS")) : 256 * 8;
     if (blocks > cap) blocks = cap;
     const size_t lds = (size_t)L * W * sizeof(int32_t);
-    pull_indexed_kernel<<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(
-        pp, recv_count, pull_offset, W, L * W, payload, idx_off, (idx_off / mi_ep_dispatch_row_bytes(H, quant_mode)) * (size_t)K,
-        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, make_parity(epoch_ctr, 0, parity_stride), skip_src < 0 ? -1 : skip_src);
+#define MI_EP_PULL_INDEXED(NT)                                                                                                      \
+    pull_indexed_kernel<NT><<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(                                         \
+        pp, recv_count, pull_offset, W, L * W, payload, idx_off, (idx_off / mi_ep_dispatch_row_bytes(H, quant_mode)) * (size_t)K,  \
+        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, make_parity(epoch_ctr, 0, parity_stride), skip_src < 0 ? -1 : skip_src)
+    if (pull_write_around(rows_hint, payload)) MI_EP_PULL_INDEXED(true); else MI_EP_PULL_INDEXED(false);
+#undef MI_EP_PULL_INDEXED
     return launch_status();
 }
 
@@ -623,12 +651,16 @@ extern "C" int mi_ep_dispatch_pull_local(const void *my_rows, const void *topk_i
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
     const int blocks = (T + kPullWaves - 1) / kPullWaves;
     const Parity par = make_parity(epoch_ctr, 0, parity_stride);
+    const bool nt = pull_write_around(rows_hint, payload);
 #define MI_EP_PULL_LOCAL(I32)                                                                                                       \
-    pull_local_kernel<I32><<<blocks, kWave * kPullWaves, 0, (hipStream_t)stream>>>(                                                \
+    if (nt) MI_EP_PULL_LOCAL2(I32, true); else MI_EP_PULL_LOCAL2(I32, false)
+#define MI_EP_PULL_LOCAL2(I32, NT)                                                                                                  \
+    pull_local_kernel<I32, NT><<<blocks, kWave * kPullWaves, 0, (hipStream_t)stream>>>(                                                \
         (const uint8_t *)my_rows, topk_idx, send_token_idx_small, recv_count, num_tokens_per_expert, T, K, E, W, my_rank, payload, \
         (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, par)
-    if (idx_is_i32) MI_EP_PULL_LOCAL(true); else MI_EP_PULL_LOCAL(false);
+    if (idx_is_i32) { MI_EP_PULL_LOCAL(true); } else { MI_EP_PULL_LOCAL(false); }
 #undef MI_EP_PULL_LOCAL
+#undef MI_EP_PULL_LOCAL2
     return launch_status();
 }
 
