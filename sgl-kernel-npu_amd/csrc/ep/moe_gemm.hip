@@ -35,7 +35,7 @@ constexpr int BN = 256, BK = 64;
 // Starting every tile's walk over K at a different k-tile (exact: integer accumulation) -- which spreads the memory channels a
 // lockstep launch hits and helped the per-head mla_preprocess kernel -- is WORSE here: GEMM1 1.07 -> 1.14 ms, GEMM2 0.73 -> 0.80 ms
 // (decode tile: 170 -> 175 us, 115 -> 110 us): the tiles that share an operand tile want to read the same k-tile at the same time.)
-template <int BKT> struct RingDepth { static constexpr int value = BKT == 128 ? 3 : 4; };
+template <int BKT, int MT> struct RingDepth { static constexpr int value = BKT == 128 ? (MT == 4 ? 2 : 3) : 4; };
 constexpr int kGemmThreads = 1024;
 constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -90,13 +90,14 @@ template <int MODE, int MT, int BKT>
 __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint8_t *lds)
 {
     constexpr int BM = 64 * MT;
-    constexpr int kStages = RingDepth<BKT>::value;
+    constexpr int kStages = RingDepth<BKT, MT>::value;
     constexpr int kStageBytes = (BM + BN) * BKT;
     constexpr int kPieceRows = 1024 / BKT;            // rows one DMA instruction (64 lanes x 16 B) covers
     constexpr int kChunks = BKT / 16;                 // 16-B chunks per row
-    constexpr int kAPieces = BM / kPieceRows;         // DMA instructions for the A tile of a stage (<= 16: at most one per wave)
+    constexpr int kAPieces = BM / kPieceRows;         // DMA instructions for the A tile of a stage
+    constexpr int kAPerWave = (kAPieces + 15) / 16;   // A pieces per wave: wave w issues pieces w, w + 16, ... below kAPieces
     constexpr int kBPerWave = BN / kPieceRows / 16;   // B pieces every wave issues per stage
-    static_assert(kAPieces <= 16 && kBPerWave >= 1, "DMA plan");
+    static_assert((kAPieces <= 16 || kAPieces % 16 == 0) && kBPerWave >= 1, "DMA plan");
 #ifdef GEMM_TIMING
     const uint64_t t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -148,11 +149,13 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
     // ---- DMA plan: one instruction moves kPieceRows rows x BKT bytes (1 KB); wave w issues A piece w (if there is one) and B pieces
     // w, w + 16, ...
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
-    uint32_t offA, offB[kBPerWave];               // lane offsets from the wave-uniform bases abase / wbase
+    uint32_t offA[kAPerWave], offB[kBPerWave];    // lane offsets from the wave-uniform bases abase / wbase
     {
         const int row = kPieceRows * wave + lane / kChunks;
         const int chunk = swz_pos<BKT>(row, lane % kChunks);                      // swizzle on the source side (an involution)
-        offA = (uint32_t)min(row, rows - 1) * (uint32_t)p.K + chunk * 16;         // rows past the group: any valid row
+#pragma unroll
+        for (int j = 0; j < kAPerWave; ++j)                                       // rows past the group: any valid row
+            offA[j] = (uint32_t)min(row + j * 16 * kPieceRows, rows - 1) * (uint32_t)p.K + chunk * 16;
 #pragma unroll
         for (int j = 0; j < kBPerWave; ++j) {
             const int brow = row + j * 16 * kPieceRows;                           // 128 rows further: the same swizzle term
@@ -163,7 +166,9 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
     auto issue_stage = [&](int kt) {
         const int kc = min(kt, nk - 1) * BKT;             // past the end: a harmless refill keeps the vmcnt arithmetic uniform
         const uint32_t sbase = lds_base + (uint32_t)((kt % kStages) * kStageBytes + wave * 1024);
-        if (wave < kAPieces) dma16(sbase, abase + kc, offA);     // wave-uniform
+#pragma unroll
+        for (int j = 0; j < kAPerWave; ++j)
+            if (wave + 16 * j < kAPieces) dma16(sbase + (uint32_t)(j * 16 * 1024), abase + kc, offA[j]);     // wave-uniform
 #pragma unroll
         for (int j = 0; j < kBPerWave; ++j) dma16(sbase + (uint32_t)(BM * BKT + j * 16 * 1024), wbase + kc, offB[j]);
     };
@@ -202,7 +207,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
 #endif
         // own pieces of stage kt landed; those of the kStages - 2 younger stages may still fly (kBPerWave per stage, one more for
         // the waves with an A piece)
-        if (wave < kAPieces) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kBPerWave + 1) * (kStages - 2)) : "memory");
+        if (kAPieces >= 16 || wave < kAPieces) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kBPerWave + kAPerWave) * (kStages - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kBPerWave * (kStages - 2)) : "memory");
         __syncthreads();                                    // stage kt complete; the slot of stage kt-1 is free
 #ifdef GEMM_TIMING
@@ -416,7 +421,7 @@ template <int MODE, int MT, int BKT>
 static void gemm_launch_one(const GemmArgs &p, void *stream)
 {
     constexpr int BM = 64 * MT;
-    constexpr int ring = RingDepth<BKT>::value * (BM + BN) * BKT, epi = 16 * 16 * MT * kEpiRowBytes;      // operand ring | epilogue tiles of 16 waves
+    constexpr int ring = RingDepth<BKT, MT>::value * (BM + BN) * BKT, epi = 16 * 16 * MT * kEpiRowBytes;      // operand ring | epilogue tiles of 16 waves
     constexpr int lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
@@ -456,10 +461,13 @@ static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const in
         mode = 2;
     }
     const bool wide_k = small && K % 128 == 0;             // decode tile with whole 128-byte lines per request
+    static const bool wide_big_env = !(getenv("MI_GEMM_WIDE_K") && atoi(getenv("MI_GEMM_WIDE_K")) == 0);      // 0: 64-byte k-tiles (A/B runs)
+    const bool wide_big = !small && wide_big_env && K % 128 == 0;
 #define MI_GEMM_DISPATCH(M)                                                          \
     do {                                                                             \
         if (wide_k) gemm_launch_one<M, 1, 128>(p, stream);                           \
         else if (small) gemm_launch_one<M, 1, 64>(p, stream);                        \
+        else if (wide_big) gemm_launch_one<M, 4, 128>(p, stream);                    \
         else gemm_launch_one<M, 4, 64>(p, stream);                                   \
     } while (0)
     if (mode == 0) MI_GEMM_DISPATCH(0);

@@ -98,6 +98,7 @@ ORACLE_CASES = [
     ([130] * 3 + [0] * 70 + [3, 260], 128, 128, 1, 200),   # > 64 experts: the tile lookup needs its second 64-expert step
     ([97, 33], 1024, 384, 1, 97),                 # 2I = 768 = 3 x 256-column tiles, I not a multiple of 256
     ([5, 0, 1, 70, 33], 256, 192, 1, 16),         # GEMM2's K = 192 is no multiple of 128: 64-row tile with 64-byte k-tiles
+    ([300, 1, 257], 256, 192, 1, 512),            # the same K on the 256-row tile (GEMM1: 128-byte k-tiles, GEMM2: 64-byte k-tiles)
 ]
 
 
