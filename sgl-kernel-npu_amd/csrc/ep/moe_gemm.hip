@@ -35,6 +35,16 @@ constexpr int BN = 256, BK = 64;
 // Starting every tile's walk over K at a different k-tile (exact: integer accumulation) -- which spreads the memory channels a
 // lockstep launch hits and helped the per-head mla_preprocess kernel -- is WORSE here: GEMM1 1.07 -> 1.14 ms, GEMM2 0.73 -> 0.80 ms
 // (decode tile: 170 -> 175 us, 115 -> 110 us): the tiles that share an operand tile want to read the same k-tile at the same time.)
+// 256-row tile with 128-byte k-tiles (round 2c): a stage is 64 KB, the ring two stages deep -- one k-tile in flight.  With 64-byte k-tiles
+// every LDS-DMA request used half of a 128-byte line and the other half was fetched again a stage later (the 32 KB L1 does not
+// hold a stage): GEMM1 1.14 -> 1.02 ms, GEMM2 0.786 -> 0.726 ms at C5, same box.  A ring of five HALF stages (A or B of a k-tile,
+// 32 KB each: A(kt+1), B(kt+1), A(kt+2) in flight) was built on top of it, bit-exact, and is slower again: 1.08 / 0.77 ms.
+// Ablations of that kernel at C5 (timing only, wrong products): without the refills inside the k-loop GEMM1 takes 0.79 ms and GEMM2
+// 0.56 ms (the operand stream costs 23 % although it is asynchronous); with 5 instead of 8 operand fragments read from LDS per
+// k-step 0.97 / 0.74 ms (the LDS read volume is NOT the limiter: larger wave tiles would buy <= 5 %).  Per k-tile a wave spends
+// ~40 % of its time at the barrier even without refills: four waves share a SIMD's MFMA pipe, and after the barrier every wave first
+// waits out its operand reads.  Carrying the next k-step's fragments across the barrier needs a second fragment set (32 VGPRs) next
+// to 64 accumulators inside the 128-register budget of 16 waves per CU.
 template <int BKT, int MT> struct RingDepth { static constexpr int value = BKT == 128 ? (MT == 4 ? 2 : 3) : 4; };
 constexpr int kGemmThreads = 1024;
 constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
