@@ -236,7 +236,9 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+                    // operands swapped: the MFMA produces the TRANSPOSED block, i.e. lane (g, c16) holds C[row mt*16 + c16][columns
+                    // nt*16 + 4g .. +3] -- four consecutive columns of one row, which the epilogue packs and writes as one piece
+                    acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);
         }
 #ifdef GEMM_TIMING
         c1 = __builtin_amdgcn_s_memtime(); tc += c1 - c0;
@@ -252,43 +254,64 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills issued past the last k-tile
 
-    // ---- epilogue: lane holds C[row = wm*16*MT + mt*16 + 4g + r][n-tile nt, col c16].  Written straight from this layout a
-    // wave-store covers 4 rows x 32 (64) bytes and the 470 MB of GEMM2 output took a third of the kernel (store-issue-bound);
-    // instead every wave transposes its tile through LDS (the operand ring is free now) and stores whole 128-byte rows,
-    // 16 B per lane.  Row stride 144 B: the four 4-row groups of a wave-store land 16 banks apart.
+    // ---- epilogue: lane holds C[row = wm*16*MT + mt*16 + c16][n-tile nt, columns 4g .. 4g+3] (transposed MFMA blocks, see the k-loop).
+    // Written straight from the accumulators a wave-store would cover 16 rows x 32 B; instead every wave passes its tile through LDS (the
+    // operand ring is free now) and stores whole 128-byte rows, 16 B per lane.  Row stride 144 B.  A lane dequantises four consecutive
+    // columns of a row: one 16-byte load of their weight scales per n-tile, one activation scale per row tile, hardware bf16 packing
+    // (v_cvt_pk_bf16_f32), and ONE LDS write per (row tile, n-tile).  (Round 2b held the untransposed block -- 4 rows x 1 column per
+    // lane: 2-byte LDS writes, a software bf16 rounding of ~7 VALU operations per element and 16 activation scales per lane; on the
+    // 16-lane SIMDs that VALU work, 4 cycles per wave instruction and four waves per SIMD, was most of the epilogue's 17.5k cycles.)
     const float *ws = p.w_scale + (size_t)e * p.N + n0;
     constexpr int kRowBytes = kEpiRowBytes, kWaveRows = 16 * MT;
     __syncthreads();                                        // every wave is done reading the ring (and nothing is in flight)
     uint8_t *tile = lds + wave * (kWaveRows * kRowBytes);
     const int f = wn >> 1, h = wn & 1;                      // MODE 0: fusion tile f (128 columns: 64 gate | 64 up), half h
     const bool wave_cols_ok = MODE == 0 ? (n0 + f * 128 < p.N) : (n0 + wn * 64 < p.N);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 wsv[4];                                           // weight scales of this lane's columns: n-tile nt, columns 4g .. 4g+3
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < 4; ++nt) {
+        int col;                                            // first of the four columns, relative to n0
+        if (MODE == 0) col = f * 128 + (nt >> 1) * 64 + h * 32 + (nt & 1) * 16 + 4 * g;      // nt 0,1 gate; 2,3 up
+        else col = wn * 64 + nt * 16 + 4 * g;
+        wsv[nt] = wave_cols_ok ? *(const f32x4 *)(ws + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rl = mt * 16 + 4 * g + r;
-            const int lr = wm * kWaveRows + rl;
-            const float as = p.a_scale[(size_t)row0 + min(lr, rows - 1)];
-            if (MODE == 0) {
+    for (int mt = 0; mt < MT; ++mt) {
+        const int rl = mt * 16 + c16;
+        const float as = p.a_scale[(size_t)row0 + min(wm * kWaveRows + rl, rows - 1)];
+        if (MODE == 0) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int gc = f * 128 + h * 32 + nt * 16 + c16;
-                    const float gate = ((float)acc[mt][nt][r] * ws[gc]) * as;
-                    const float up = ((float)acc[mt][nt + 2][r] * ws[gc + 64]) * as;
-                    *(float *)(tile + rl * kRowBytes + (nt * 16 + c16) * 4) = up * (gate / (1.0f + __expf(-gate)));
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gate = ((float)acc[mt][nt][r] * wsv[nt][r]) * as;
+                    const float up = ((float)acc[mt][nt + 2][r] * wsv[nt + 2][r]) * as;
+                    // sigmoid through v_rcp_f32 (1 ulp) instead of an IEEE division (~10 VALU operations per element): the fast exponential
+                    // next to it is a few ulp off libm already, and the parity bar of this stage is rtol 3e-5 (tests/test_moe_gemm_gpu.py)
+                    o[r] = up * (gate * __builtin_amdgcn_rcpf(1.0f + __expf(-gate)));
                 }
-            } else {
+                *(f32x4 *)(tile + rl * kRowBytes + (nt * 16 + 4 * g) * 4) = o;
+            }
+        } else {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int col = wn * 64 + nt * 16 + c16;
-                    const float wsc = n0 + col < p.N ? ws[col] : 0.f;
-                    *(uint16_t *)(tile + rl * kRowBytes + (nt * 16 + c16) * 2) = (uint16_t)f32_to_bf16_rne(((float)acc[mt][nt][r] * wsc) * as);
-                }
+            for (int nt = 0; nt < 4; ++nt) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                float d[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = ((float)acc[mt][nt][r] * wsv[nt][r]) * as;
+                uint2 o;                                    // round to nearest even, as f32_to_bf16_rne (the products are finite)
+                o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{d[0], d[1]}, bf16x2));
+                o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{d[2], d[3]}, bf16x2));
+                *(uint2 *)(tile + rl * kRowBytes + (nt * 16 + 4 * g) * 2) = o;
             }
         }
+    }
     // a wave only reads back what it wrote itself: LDS operations of one wave complete in order, no barrier needed -- but the compiler
-    // must not move the 16-byte loads below above the float / uint16_t stores above (different types: type-based alias analysis would
-    // allow it; an 8-rows-at-a-time variant of this epilogue produced wrong rows exactly that way)
+    // must not move the 16-byte loads below above the stores above (different types: type-based alias analysis would allow it; an
+    // 8-rows-at-a-time variant of this epilogue produced wrong rows exactly that way)
     asm volatile("" ::: "memory");
     if (!wave_cols_ok) return true;
     // MODE 2: where do this lane's rows go?  The (src, t, k) triples and, from them, the slot addresses are requested in ONE batch for all 8

@@ -37,6 +37,41 @@ __global__ __launch_bounds__(512) void stream_kernel(const uint8_t *src, size_t 
     if (acc[0] == 0x12345678u) sink[0] = acc[1];
 }
 
+// write side: each workgroup stores `bytes_per_wg` contiguous bytes, 16 B per lane; NT = nontemporal stores
+template <bool NT>
+__global__ __launch_bounds__(512) void store_kernel(uint8_t *dst, size_t bytes_per_wg)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint8_t *base = dst + (size_t)blockIdx.x * bytes_per_wg;
+    const size_t step = (size_t)nw * 1024, iters = bytes_per_wg / step;
+    const u32x4 v = {(uint32_t)lane, 1u, 2u, 3u};
+    for (size_t i = 0; i < iters; ++i) {
+        u32x4 *p = (u32x4 *)(base + i * step + wave * 1024 + lane * 16);
+        if (NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    }
+}
+
+template <bool NT>
+static void run_store(uint8_t *dst, size_t total, int wgs, int threads)
+{
+    const size_t per = (total / wgs) / (threads / 64 * 1024) * (threads / 64 * 1024);
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        hipEventRecord(a);
+        store_kernel<NT><<<wgs, threads>>>(dst, per);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    printf("store nt %d wgs %4d threads %4d (%6.1f MB): %7.1f us  %6.2f TB/s  %6.1f GB/s per WG\n", (int)NT, wgs, threads, per * wgs / 1e6,
+           best * 1e3, per * wgs / (best * 1e-3) / 1e12, per / (best * 1e-3) / 1e9);
+}
+
 // the access pattern of combine_reduce: a wave takes one 1 KB segment of 8 pseudo-random 14 KB rows (a token's K expert rows)
 __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *src, size_t nrows, size_t tokens, uint32_t *sink)
 {
@@ -94,6 +129,14 @@ int main()
         run<2, 8>(src, total, wgs, 512, sink);
         run<2, 16>(src, total, wgs, 512, sink);
     }
+    // per-CU store rate: few workgroups (one per CU at most), 4 MB each, then the whole chip
+    for (int wgs : {8, 32, 128, 256, 1024}) {
+        const size_t bytes = (size_t)wgs * (4u << 20) < total ? (size_t)wgs * (4u << 20) : total;      // never past the allocation
+        run_store<false>(src, bytes, wgs, 512);
+        run_store<true>(src, bytes, wgs, 512);
+    }
+    run_store<false>(src, total, 2048, 256);
+    run_store<true>(src, total, 2048, 256);
     run<0, 8>(src, total, 2048, 256, sink);
     run<1, 8>(src, total, 2048, 256, sink);
     {
