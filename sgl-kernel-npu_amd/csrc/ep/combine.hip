@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "ep_common.h"
+#include <type_traits>
 
 namespace mi_ep {
 
@@ -74,63 +75,77 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
 {
     slots += parity_off(par);
     const int lane = lane_id();
-    const long long wid = (long long)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    const long long t = wid / segs_per_token;
-    const int seg0 = (int)(wid % segs_per_token);
-    if (t >= T) return;
-    // routing + weights of this token (lane k < K)
+    // wave-uniform 32-bit index arithmetic (the launcher bounds T * segs_per_token): a 64-bit division per lane was ~150 VALU operations
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+    const uint32_t t = wid / (uint32_t)segs_per_token;
+    const int seg0 = (int)(wid - t * (uint32_t)segs_per_token);
+    if (t >= (uint32_t)T) return;
+    // routing + weights of this token (lane k < K); lane k also forms the address of ITS row, so that the K row bases reach the loads
+    // below as wave-uniform values (v_readlane -> SGPR pair + one lane offset) instead of K 64-bit multiplications and selects per lane
     float w_l = 0.f;
-    bool valid_l = false, local_l = false;
-    long long slot_l = t * K + lane;      // slot mode: t*K+k (window push) or the dispatch send slot (all-to-all return)
+    bool valid_l = false;
+    const uint8_t *base_l = slots + (size_t)t * K * slot_stride;      // absent / invalid selections: a row that is always there, never summed
     if (lane < K) {
-        long long e = I32 ? (long long)((const int32_t *)topk_idx)[t * K + lane] : ((const long long *)topk_idx)[t * K + lane];
+        const size_t tk = (size_t)t * K + lane;
+        long long e = I32 ? (long long)((const int32_t *)topk_idx)[tk] : ((const long long *)topk_idx)[tk];
         valid_l = (e >= 0 && e < E);
-        w_l = topk_w ? topk_w[t * K + lane] : 1.0f;
-        if (send_off && valid_l) slot_l = (long long)send_off[e] + idx_small[t * K + lane];
+        w_l = topk_w ? topk_w[tk] : 1.0f;
+        long long slot_l = (long long)tk;      // slot mode: t*K+k (window push) or the dispatch send slot (all-to-all return)
+        if (send_off && valid_l) slot_l = (long long)send_off[e] + idx_small[tk];
+        if (valid_l) base_l = slots + (size_t)(int)slot_l * slot_stride;
         // selections served by this rank's own experts were not pushed: their rows are read from the expert output itself
-        if (x_local && valid_l && (int)(e / experts_per_rank) == my_rank) {
-            local_l = true;
-            slot_l = min(max(local_row[t * K + lane], 0), local_rows - 1);       // never read outside x, whatever the handle says
-        }
+        if (x_local && valid_l && (int)(e / experts_per_rank) == my_rank)
+            base_l = x_local + (size_t)min(max(local_row[tk], 0), local_rows - 1) * ((size_t)H * 2);       // never read outside x, whatever the handle says
     }
     const unsigned long long vmask = __ballot(valid_l);
-    const unsigned long long lmask = __ballot(local_l);
+    const uint64_t base_bits = (uint64_t)(uintptr_t)base_l;
+    const int base_lo = (int)(uint32_t)base_bits, base_hi = (int)(uint32_t)(base_bits >> 32);
     float w[KMAX];
-    long long slot[KMAX];
+    const uint8_t *rowp[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        w[k] = __shfl(w_l, k, kWave);
-        slot[k] = __shfl((int)slot_l, k, kWave);
+        w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_l), k));
+        rowp[k] = (const uint8_t *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(base_hi, k) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readlane(base_lo, k));
     }
     const int nchunks = H / 8;          // 16-B chunks of 8 bf16
-    for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) u32x4 *gptr;       // global, not generic: the bases went through v_readlane as integers
+    // Two elements per VALU instruction (v_pk_mul_f32, v_pk_add_f32: separately rounded, as the scalar pair was) and the hardware bf16
+    // rounding: a wave instruction takes 4 cycles on the 16-lane SIMDs, and the scalar form kept them ~40 % busy (104 -> 93 us at C2).
+    // read-once stream: nontemporal loads keep the 0.47 GB of slots out of L2/MALL (measured 141 -> 102 us at C2)
+    auto chunk = [&](int c, auto all_tag) {
+        constexpr bool ALL = decltype(all_tag)::value;
         u32x4 v[KMAX];
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k < K && ((vmask >> k) & 1ull))
-                // read-once stream: nontemporal loads keep the 0.47 GB of slots out of L2/MALL (measured 141 -> 102 us at C2)
-                v[k] = __builtin_nontemporal_load((const u32x4 *)(((lmask >> k) & 1ull ? x_local + (size_t)slot[k] * ((size_t)H * 2)
-                                                                                             : slots + (size_t)slot[k] * slot_stride) +
-                                                                   (size_t)c * 16));
-        float acc[8];
+            if (ALL || (k < K && ((vmask >> k) & 1ull))) v[k] = __builtin_nontemporal_load((gptr)(uintptr_t)(rowp[k] + (uint32_t)c * 16u));
+        f32x2 acc[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[j] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-            if (k < K && ((vmask >> k) & 1ull)) {
+            if (ALL || (k < K && ((vmask >> k) & 1ull))) {
+                const f32x2 wk = f32x2{w[k], w[k]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float lo = bf16_to_f32(v[k][j] & 0xFFFFu) * w[k];
-                    const float hi = __uint_as_float(v[k][j] & 0xFFFF0000u) * w[k];
-                    acc[2 * j] = acc[2 * j] + lo;
-                    acc[2 * j + 1] = acc[2 * j + 1] + hi;
+                    const f32x2 val = f32x2{bf16_to_f32(v[k][j] & 0xFFFFu), __uint_as_float(v[k][j] & 0xFFFF0000u)};
+                    acc[j] = acc[j] + val * wk;
                 }
             }
         }
         u32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16_rne(acc[2 * j]) | (f32_to_bf16_rne(acc[2 * j + 1]) << 16);
+        for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(acc[j], bf16x2));
         *(u32x4 *)(out + (size_t)t * H + (size_t)c * 8) = o;
+    };
+    // Every selection of the token present (the usual case): straight-line code, all KMAX row reads issued back to back.  With -1 entries
+    // or K < KMAX the conditions are wave-uniform, the compiler turns them into branches and gives each read its own block (and wait).
+    if (K == KMAX && vmask == (KMAX == 64 ? ~0ull : (1ull << KMAX) - 1ull)) {
+        for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) chunk(c, std::true_type{});
+    } else {
+        for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) chunk(c, std::false_type{});
     }
 }
 
@@ -267,6 +282,7 @@ extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int
     while (segs < max_segs && (long long)T * segs < target) segs <<= 1;
     if (segs > max_segs) segs = max_segs;
     const long long waves = (long long)T * segs;
+    if (waves > 0x7fffffffll) return MI_EP_EINVAL;          // the kernel's wave index is 32 bits wide
     const int wpb = 4;
     const long long blocks = (waves + wpb - 1) / wpb;
     hipStream_t s = (hipStream_t)stream;
