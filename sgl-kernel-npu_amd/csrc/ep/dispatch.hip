@@ -125,16 +125,23 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     }
     const unsigned long long vmask = __ballot(e_l >= 0);
     if (vmask == 0ull) return;      // token selects nothing: no row is produced
+    // |x| of a bf16 orders like its bit pattern as an unsigned 16-bit integer, so the row maximum is taken on the packed words
+    // (v_pk_max_u16, two elements per instruction, no unpacking): the SIMDs are 16 lanes wide, every wave instruction costs 4 cycles,
+    // and this kernel spent as long in its ~1260 VALU instructions per token as in its memory phases
+    {
+        typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+        u16x2 m2 = u16x2{0, 0};
 #pragma unroll
-    for (int it = 0; it < kMaxItems; ++it)
+        for (int it = 0; it < kMaxItems; ++it)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t w = raw[it][h][j];
-                amax = fmaxf(amax, fabsf(bf16_to_f32(w & 0xFFFFu)));
-                amax = fmaxf(amax, fabsf(__uint_as_float(w & 0xFFFF0000u)));
-            }
+                for (int j = 0; j < 4; ++j)
+                    m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, raw[it][h][j] & 0x7FFF7FFFu));
+        const uint32_t m = m2[0] > m2[1] ? m2[0] : m2[1];
+        // a NaN element (pattern above 0x7F80) wins the integer maximum: such a row gets amax = inf (its bytes are meaningless either way)
+        amax = __uint_as_float((m > 0x7F80u ? 0x7F80u : m) << 16);
+    }
     amax = wave_max(amax);
     float s, scale_out;
     if (EPS) {
@@ -156,15 +163,17 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                uint32_t packed = 0;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const uint32_t w = raw[it][h][jj * 2 + b];
-                    const int lo = (int)rintf(bf16_to_f32(w & 0xFFFFu) * s);
-                    const int hi = (int)rintf(__uint_as_float(w & 0xFFFF0000u) * s);
-                    packed |= ((uint32_t)(lo & 0xFF) | ((uint32_t)(hi & 0xFF) << 8)) << (16 * b);
-                }
-                q[it][h * 2 + jj] = packed;
+                // round(x * s) through the 1.5 * 2^23 trick: the float sum's low mantissa bits are the nearest-even integer in two's
+                // complement (|x * s| <= 127), i.e. rintf + cvt in one addition, on two elements per instruction (v_pk_mul_f32 /
+                // v_pk_add_f32); the four low bytes are gathered with v_perm_b32
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 s2 = f32x2{s, s}, magic = f32x2{12582912.0f, 12582912.0f};
+                const uint32_t w0 = raw[it][h][jj * 2], w1 = raw[it][h][jj * 2 + 1];
+                const f32x2 r0 = f32x2{bf16_to_f32(w0 & 0xFFFFu), __uint_as_float(w0 & 0xFFFF0000u)} * s2 + magic;
+                const f32x2 r1 = f32x2{bf16_to_f32(w1 & 0xFFFFu), __uint_as_float(w1 & 0xFFFF0000u)} * s2 + magic;
+                const uint32_t p0 = __builtin_amdgcn_perm(__float_as_uint(r0[1]), __float_as_uint(r0[0]), 0x0c0c0400u);   // bytes: lo, hi, 0, 0
+                const uint32_t p1 = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x04000c0cu);   // bytes: 0, 0, lo, hi
+                q[it][h * 2 + jj] = p0 | p1;
             }
     }
     if (idx_off) {
