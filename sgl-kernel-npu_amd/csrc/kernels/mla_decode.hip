@@ -459,7 +459,12 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
         (kr_stride_row % 8) || (kr_stride_blk % 8) || (kr_stride_h % 8) || (o_stride_h % 8) || (o_stride_b % 8))
         return MI_SGL_EINVAL;      // 16-byte vector accesses
     if (num_splits <= 0) num_splits = mi_mla_decode_num_splits(batch, q_heads, kv_heads, max_seq_len);
-    const bool wide = use_wide(q_heads / kv_heads);
+    // the wide kernel addresses the cache with 32-bit block strides and 24-bit row strides (elements); anything else (blocks of 4 GB,
+    // rows of 32 MB) goes to the 64-head kernel, which keeps the general int64 form
+    auto fits = [](int64_t v, int bits) { return v >= 0 && v < (1ll << bits); };
+    const bool narrow = fits(kn_stride_blk, 31) && fits(kr_stride_blk, 31) && fits(kn_stride_row, 24) && fits(kr_stride_row, 24) &&
+                        page_size < (1 << 24);
+    const bool wide = use_wide(q_heads / kv_heads) && narrow;
     if ((num_splits > 1 || wide) && (!workspace || workspace_bytes < mi_mla_decode_workspace(batch, q_heads, num_splits)))
         return MI_SGL_EINVAL;
     MlaParams p;

@@ -89,6 +89,10 @@ struct WideCtx {
     uint32_t *ring;        // this wave's [kSlots][64] block ids
     uint32_t lds_base, ring_addr;      // LDS byte addresses of lds / ring (M0 values for the DMA)
     int page_shift;                    // log2(page_size) when it is a power of two, else -1 (integer division)
+    // cache addressing in 32-bit pieces (the launcher sends caches whose strides do not fit to the 64-head kernel): the general
+    // int64 form cost 14 quarter-rate multiplications per tile, in front of the first MFMA of the tile
+    const uint16_t *kn_base, *kr_base; // k_nope / k_rope + kv head offset
+    uint32_t kn_sblk, kn_srow, kr_sblk, kr_srow;
 };
 
 // key of `tile` owned by this lane (lanes 32..63 mirror 0..31), clamped into the sequence
@@ -136,11 +140,12 @@ __device__ __forceinline__ void wide_issue_rows(const WideCtx &c, int tile)
 __device__ __forceinline__ TileRows wide_rows(const WideCtx &c, int tile)
 {
     const int n = wide_key(c, tile);
-    const int page = wide_page(c, n), row = n - page * c.p->page_size;
-    const int64_t blk = (int32_t)c.ring[(tile & (kSlots - 1)) * kRingEntries + (c.lane & (kRingEntries - 1))];
-    TileRows r;
-    r.nope = blk * c.p->kn_sblk + (int64_t)row * c.p->kn_srow + (int64_t)c.kvh * c.p->kn_sh;
-    r.rope = blk * c.p->kr_sblk + (int64_t)row * c.p->kr_srow + (int64_t)c.kvh * c.p->kr_sh;
+    const int page = wide_page(c, n);
+    const uint32_t row = c.page_shift >= 0 ? (uint32_t)n & (uint32_t)(c.p->page_size - 1) : (uint32_t)(n - page * c.p->page_size);
+    const uint32_t blk = c.ring[(tile & (kSlots - 1)) * kRingEntries + (c.lane & (kRingEntries - 1))];
+    TileRows r;                        // one v_mad_u64_u32 + one 24-bit multiplication each (row < page_size, strides < 2^24: launcher)
+    r.nope = (int64_t)((uint64_t)blk * c.kn_sblk + __umul24(row, c.kn_srow));
+    r.rope = (int64_t)((uint64_t)blk * c.kr_sblk + __umul24(row, c.kr_srow));
     return r;
 }
 
@@ -151,13 +156,13 @@ __device__ __forceinline__ void wide_issue_piece(const WideCtx &c, const TileRow
         const int i = c.wave + 4 * idx;
         const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), i);
         const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), i);
-        const uint16_t *src = c.p->k_nope + (((int64_t)hi << 32) | (uint32_t)lo);
+        const uint16_t *src = c.kn_base + (((int64_t)hi << 32) | (uint32_t)lo);
         const int sw = (i >> 3) & 1;                       // rows 8..15, 24..31: 16-B chunk pairs swapped
         dma16_sbase(slot + (uint32_t)(i * kNopeStride), src, (uint32_t)((c.lane ^ sw) * 16));
     } else {
         const int key = c.wave * 8 + (c.lane >> 3);
         const int chunk = (c.lane & 7) ^ (key & 7);
-        const uint16_t *src = c.p->k_rope + lane_i64(rows.rope, key) + chunk * 8;
+        const uint16_t *src = c.kr_base + lane_i64(rows.rope, key) + chunk * 8;
         dma16_vaddr(slot + (uint32_t)(kT2 * kNopeStride + c.wave * 8 * kRopeStride), src);
     }
 }
@@ -191,7 +196,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool wave_active = hblk * 128 + wave * 32 < p.group;       // wave-uniform; idle waves still feed the DMA
     const int head = kvh * p.group + hg;
     WideCtx cx{&p, b, kvh, seq_len, wave, lane, lds, (uint32_t *)(lds + kSlots * kSlotBytes) + wave * kSlots * kRingEntries, 0, 0,
-               (p.page_size & (p.page_size - 1)) == 0 ? __builtin_ctz(p.page_size) : -1};
+               (p.page_size & (p.page_size - 1)) == 0 ? __builtin_ctz(p.page_size) : -1,
+               p.k_nope + (int64_t)kvh * p.kn_sh, p.k_rope + (int64_t)kvh * p.kr_sh,
+               (uint32_t)p.kn_sblk, (uint32_t)p.kn_srow, (uint32_t)p.kr_sblk, (uint32_t)p.kr_srow};
     cx.lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     cx.ring_addr = cx.lds_base + (uint32_t)(kSlots * kSlotBytes + wave * kSlots * kRingEntries * 4);
 
