@@ -448,31 +448,43 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
     int row_capacity, Parity par)
 {
     const int lane = lane_id();
-    const int t = blockIdx.x * kPullWaves + threadIdx.x / kWave;
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * kPullWaves + threadIdx.x / kWave);
     if (t >= T) return;
-    const int L = E / W;
-    int r_l = -1;
-    if (lane < K) {
-        const long long e = ld_idx<I32>(topk_idx, (long long)t * K + lane);
-        if (e >= 0 && e < E && (int)(e / L) == my_rank) {
-            const int le = (int)(e % L);
-            const int r = recv_count[le * W + my_rank] - tokens_per_expert[e] + idx_small[(long long)t * K + lane];
-            if (r >= 0 && r < row_capacity) r_l = r;
-        }
-    }
-    unsigned long long lmask = __ballot(r_l >= 0);
-    if (lmask == 0ull) return;
+    // the first part of the row is requested before the routing is known (a token without a selection on this rank is the rare case at
+    // the sizes where this kernel matters): the routing costs three dependent loads
     const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
     const uint8_t *srow = my_rows + parity_off(par) + (size_t)t * stride;
     const u32x4 *s16 = (const u32x4 *)srow;
     const int n16 = payload_bytes / 16;
-    const float scale = *(const float *)(srow + payload_bytes);
-    for (int base = 0; base < n16; base += kWave * 8) {
-        u32x4 v[8];
+    u32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int item = base + u * kWave + lane;
-            if (item < n16) v[u] = s16[item];
+    for (int u = 0; u < 8; ++u) {
+        const int item = u * kWave + lane;
+        if (item < n16) v[u] = s16[item];
+    }
+    const float scale = *(const float *)(srow + payload_bytes);
+    const uint32_t L = (uint32_t)(E / W);
+    int r_l = -1;
+    if (lane < K) {
+        const long long e64 = ld_idx<I32>(topk_idx, (long long)t * K + lane);
+        if (e64 >= 0 && e64 < E) {
+            const uint32_t e = (uint32_t)e64, rank_e = e / L;     // 32-bit: the 64-bit division is ~150 VALU operations
+            if ((int)rank_e == my_rank) {
+                const int le = (int)(e - rank_e * L);
+                const int r = recv_count[le * W + my_rank] - tokens_per_expert[e] + idx_small[(long long)t * K + lane];
+                if (r >= 0 && r < row_capacity) r_l = r;
+            }
+        }
+    }
+    unsigned long long lmask = __ballot(r_l >= 0);
+    if (lmask == 0ull) return;
+    for (int base = 0; base < n16; base += kWave * 8) {
+        if (base) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = base + u * kWave + lane;
+                if (item < n16) v[u] = s16[item];
+            }
         }
         for (unsigned long long m = lmask; m; m &= m - 1) {       // wave-uniform walk over this rank's selections of the token
             const int k = __builtin_ctzll(m);
