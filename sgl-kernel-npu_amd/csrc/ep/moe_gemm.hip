@@ -97,7 +97,7 @@ __device__ float g_gemm_dbg[256];
 // one (expert, m-tile) x 256-column tile; `slot` = index of the tile in (expert, row block) order.  Returns false when the slot lies
 // past the last tile (workgroup-uniform).
 template <int MODE, int MT, int BKT>
-__device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint8_t *lds)
+__device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint8_t *lds, int end_first)
 {
     constexpr int BM = 64 * MT;
     constexpr int kStages = RingDepth<BKT, MT>::value;
@@ -122,7 +122,9 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
         int slot = tile_slot, start = 0;                    // wave-uniform
         for (int base = 0; base < p.L && e < 0; base += 64) {
             const int i = base + lane;
-            const int end = i < p.L ? p.cum[(i + 1) * p.cum_stride - 1] : 0;
+            // the ends of the first 64 experts were loaded once per workgroup (grouped_gemm_i8_kernel): one dependent global load
+            // less in front of every tile
+            const int end = base == 0 ? end_first : (i < p.L ? p.cum[(i + 1) * p.cum_stride - 1] : 0);
             int prev = __shfl_up(end, 1, 64);
             if (lane == 0) prev = start;
             const int cnt = i < p.L ? end - prev : 0;
@@ -388,8 +390,10 @@ template <int MODE, int MT, int BKT>
 __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x BKT + B 256 x BKT)
+    const int lane0 = threadIdx.x & 63;
+    const int end_first = lane0 < p.L ? p.cum[(lane0 + 1) * p.cum_stride - 1] : 0;     // end of expert `lane` (cumulative row count)
     for (int slot = blockIdx.y;; slot += gridDim.y) {
-        if (!gemm_tile<MODE, MT, BKT>(p, slot, lds)) break;
+        if (!gemm_tile<MODE, MT, BKT>(p, slot, lds, end_first)) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
         __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
     }
