@@ -227,6 +227,39 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
 #endif
         issue_stage(kt + kStages - 1);
         const uint8_t *buf = lds + (kt % kStages) * kStageBytes;
+        if constexpr (MT == 4) {
+            // Operand fragments two MFMA groups ahead of their use.  Left to itself the compiler emitted `ds_read -> s_waitcnt lgkmcnt(0) ->
+            // 4 MFMAs` eight times per k-tile: every group of four MFMAs (64 cycles) waited out a full LDS read, and only the other three
+            // waves of the SIMD covered for it.  Order per k-tile: the four column fragments of k-step 0 and the first two row
+            // fragments; then per row fragment i: request fragment i + 2, multiply fragment i.  sched_barrier pins the order, the waits
+            // are the compiler's (LDS returns in order).
+            constexpr int NA = kSteps * MT;
+            i32x4 bfr[4], ar[3];          // ONE set of column fragments: the set of k-step 1 replaces that of k-step 0 register by register,
+                                          // each right behind the last MFMA that read it (two sets spilled 22 registers in the epilogue)
+            auto load_a = [&](int idx) { return *(const i32x4 *)(buf + aoff[idx / MT][idx % MT]); };
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bfr[nt] = *(const i32x4 *)(buf + boff[0][nt]);
+            ar[0] = load_a(0);
+            ar[1] = load_a(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int idx = 0; idx < NA; ++idx) {
+                const int mt = idx % MT;
+                const bool last_of_step = kSteps == 2 && idx == MT - 1;
+                if (idx + 2 < NA) ar[(idx + 2) % 3] = load_a(idx + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bfr[nt], ar[idx % 3], acc[mt][nt], 0, 0, 0);      // operands swapped, see below
+                    if (last_of_step) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        bfr[nt] = *(const i32x4 *)(buf + boff[kSteps - 1][nt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < kSteps; ++ks) {
             i32x4 af[MT], bf[4];
