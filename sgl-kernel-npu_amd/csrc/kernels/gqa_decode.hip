@@ -120,27 +120,48 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
     // ---- tile staging: thread owns rows (tid >> 3) [+32] and chunks (tid & 7) + 8 j
     u32x4 kreg[RP][KJ], vreg[RP][VJ];
     const int srow = tid >> 3, sch = tid & 7;
-    auto stage_load = [&](int tile) {
+    // block ids of the tile that stage_load fetches next: requested one tile ahead (bt_load), so that the row loads of a tile do not sit
+    // behind a block-table round trip -- and never behind each other: left in one loop the compiler emitted `block id -> vmcnt(0) ->
+    // rows of group 0 -> block id -> vmcnt(0) -> rows of group 1`, four serial memory round trips per tile
+    const int page_shift = (p.page_size & (p.page_size - 1)) == 0 ? __builtin_ctz(p.page_size) : -1;
+    auto key_of = [&](int tile, int rp) {
+        int n = tile * TILE + rp * 32 + srow;
+        n = n < seq_len ? n : seq_len - 1;                        // rows past the end are masked later; keep the address valid
+        return n < 0 ? 0 : n;
+    };
+    auto page_of = [&](int n) { return page_shift >= 0 ? n >> page_shift : n / p.page_size; };
+    int32_t nblk[RP];
+    auto bt_load = [&](int tile) {
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) nblk[rp] = p.block_table[(int64_t)b * p.bt_stride + page_of(key_of(tile, rp))];
+    };
+    auto stage_load = [&](int tile) {                             // nblk holds this tile's block ids
+        const uint16_t *kr[RP], *vr[RP];
+        // both ids are consumed HERE (requested a tile ago: no wait in practice); otherwise the wait for the second one lands behind the
+        // first group's row loads as a vmcnt(0)
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) asm volatile("" : "+v"(nblk[rp]));
 #pragma unroll
         for (int rp = 0; rp < RP; ++rp) {
-            int n = tile * TILE + rp * 32 + srow;
-            n = n < seq_len ? n : seq_len - 1;                    // rows past the end are masked later; keep the address valid
-            n = n < 0 ? 0 : n;
-            const int page = n / p.page_size;
-            const int64_t blk = p.block_table[(int64_t)b * p.bt_stride + page], r = n - page * p.page_size;
-            const uint16_t *kr = p.k + blk * p.k_sblk + r * p.k_srow + (int64_t)kvh * p.k_sh;
-            const uint16_t *vr = p.v + blk * p.v_sblk + r * p.v_srow + (int64_t)kvh * p.v_sh;
+            const int n = key_of(tile, rp);
+            const int64_t blk = nblk[rp], r = n - page_of(n) * p.page_size;
+            kr[rp] = p.k + blk * p.k_sblk + r * p.k_srow + (int64_t)kvh * p.k_sh;
+            vr[rp] = p.v + blk * p.v_sblk + r * p.v_srow + (int64_t)kvh * p.v_sh;
+        }
+#pragma unroll
+        for (int rp = 0; rp < RP; ++rp) {
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 const int c = sch + 8 * j;
-                kreg[rp][j] = (c * 8 < p.lk) ? *(const u32x4 *)(kr + c * 8) : u32x4{0, 0, 0, 0};
+                kreg[rp][j] = (c * 8 < p.lk) ? *(const u32x4 *)(kr[rp] + c * 8) : u32x4{0, 0, 0, 0};
             }
 #pragma unroll
             for (int j = 0; j < VJ; ++j) {
                 const int c = sch + 8 * j;
-                vreg[rp][j] = (c * 8 < p.lv) ? *(const u32x4 *)(vr + c * 8) : u32x4{0, 0, 0, 0};
+                vreg[rp][j] = (c * 8 < p.lv) ? *(const u32x4 *)(vr[rp] + c * 8) : u32x4{0, 0, 0, 0};
             }
         }
+        bt_load(tile + 1);                                        // clamped into the sequence: always a valid entry
     };
     auto stage_store = [&](uint8_t *buf) {
 #pragma unroll
@@ -160,9 +181,13 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
     };
 
     if (t_begin < t_end) {
+        bt_load(t_begin);
         stage_load(t_begin);
         stage_store(lds);
     }
+    // nothing the compiler knows of is in flight when the tile loop starts (Q^T above all): otherwise its wait for those registers lands
+    // inside the loop as a vmcnt(0) in front of every tile's first MFMA, i.e. behind the NEXT tile's row loads
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     const float cs = p.sm_scale * 1.4426950408889634f;
     for (int t = t_begin; t < t_end; ++t) {
         uint8_t *buf = lds + ((t - t_begin) & 1) * kBuf;
