@@ -57,6 +57,16 @@ constexpr bool kDmaInterleaved = !MLA_STAGE && MLA_WAVES == 4;   // 18 DMA piece
 constexpr int kHeadsPerBlock = kHeadWaves * 16;
 constexpr int kAccTiles = 32 / kDSplit;
 
+// LDS-DMA through inline asm: lane l moves 16 B from its own address to dst + 16 l (M0 = wave-uniform LDS destination).  With the
+// builtin the compiler put an `s_waitcnt vmcnt(0)` behind EVERY piece (it cannot tell which later ds_read the DMA might feed), i.e. one
+// memory round trip per QK k-step; the only wait these requests need is the explicit one at the top of the tile loop.  The compiler's
+// own waits (block-table loads, Q^T) stay correct: requests complete in order, so extra ones in flight only make them conservative.
+__device__ __forceinline__ void dma16_row(const uint8_t *dst_lds, const void *vaddr)
+{
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)dst_lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(vaddr) : "memory");
+}
+
 // issue the LDS-DMA of one KV tile into `buf`; the 72 wave-instructions are dealt round-robin to the waves
 __device__ __forceinline__ void issue_tile(const MlaParams &p, const TileRows &rows, uint8_t *buf, int wave, int nwaves, int lane)
 {
@@ -64,16 +74,13 @@ __device__ __forceinline__ void issue_tile(const MlaParams &p, const TileRows &r
         const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), i);
         const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), i);
         const uint16_t *src = p.k_nope + (((int64_t)hi << 32) | (uint32_t)lo);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane * 8),
-                                         (void __attribute__((address_space(3))) *)(buf + i * kNopeStride), 16, 0, 0);
+        dma16_row(buf + i * kNopeStride, src + lane * 8);
     }
     for (int j = wave; j < kTile / 8; j += nwaves) {   // 8 keys x 128 B of rope per instruction
         const int key = j * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (key & 7);       // XOR swizzle on the source side
         const uint16_t *src = p.k_rope + lane_i64(rows.rope, key);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + chunk * 8),
-                                         (void __attribute__((address_space(3))) *)(buf + kTile * kNopeStride + j * 8 * kRopeStride),
-                                         16, 0, 0);
+        dma16_row(buf + kTile * kNopeStride + j * 8 * kRopeStride, src + chunk * 8);
     }
 }
 
@@ -86,16 +93,13 @@ __device__ __forceinline__ void issue_piece(const MlaParams &p, const TileRows &
         const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), i);
         const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), i);
         const uint16_t *src = p.k_nope + (((int64_t)hi << 32) | (uint32_t)lo);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + lane * 8),
-                                         (void __attribute__((address_space(3))) *)(buf + i * kNopeStride), 16, 0, 0);
+        dma16_row(buf + i * kNopeStride, src + lane * 8);
     } else {
         const int j = wave + 4 * (idx - 16);
         const int key = j * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (key & 7);
         const uint16_t *src = p.k_rope + lane_i64(rows.rope, key);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + chunk * 8),
-                                         (void __attribute__((address_space(3))) *)(buf + kTile * kNopeStride + j * 8 * kRopeStride),
-                                         16, 0, 0);
+        dma16_row(buf + kTile * kNopeStride + j * 8 * kRopeStride, src + chunk * 8);
     }
 }
 
