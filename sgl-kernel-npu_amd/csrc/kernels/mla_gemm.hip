@@ -505,13 +505,27 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
         const uint8_t *st = lds + (c % kF_Slots) * kF_Stage;
         // (a fenced explicit pipeline -- the 12 fragments of k-step ks + 1 requested before the 12 MFMAs of ks -- measured the same
         // wall time: phase A is not waiting for LDS reads)
+        {
+            // weight fragments kF_Ahead MFMAs ahead of their use (ring of kF_Ahead + 2 registers sets): the compiler's own order was
+            // `2 ds_read -> wait -> MFMA -> wait -> MFMA`, one exposed LDS round trip per pair with only two waves on the SIMD
+            constexpr int kF_Ahead = 6, kRingF = 8, NF = 4 * 12;
+            auto ldf = [&](int i) {
+                const int ks = i / 12, nt = i % 12;
+                return *(const i32x4 *)(st + (nt * 16 + c16) * kF_Chunk + (((4 * ks + g) ^ c16) << 4));
+            };
+            i32x4 fr[kRingF];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int i = 0; i < kF_Ahead; ++i) fr[i] = ldf(i);
 #pragma unroll
-            for (int nt = 0; nt < 12; ++nt) {
-                const i32x4 bf = *(const i32x4 *)(st + (nt * 16 + c16) * kF_Chunk + (((4 * ks + g) ^ c16) << 4));
-                acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ks], bf, acc[nt], 0, 0, 0);
+            for (int i = 0; i < NF; ++i) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + kF_Ahead < NF) fr[(i + kF_Ahead) % kRingF] = ldf(i + kF_Ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i % 12] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i / 12], fr[i % kRingF], acc[i % 12], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (wave >= 4) refill();
         if (c + 2 < kF_NChunks) issue_a(c + 2, afb[c & 1]);      // into the buffer this chunk's MFMAs have just read
     }
