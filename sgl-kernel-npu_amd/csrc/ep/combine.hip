@@ -47,21 +47,10 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
             }
             const u32x4 *s16 = (const u32x4 *)(x + (size_t)r * row_bytes);
             u32x4 *d16 = (u32x4 *)((uint8_t *)dsts.p[src] + poff + ((size_t)t * K + k) * slot_stride);
-            for (int base = 0; base < n16; base += kWave * 8) {
-                u32x4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int item = base + u * kWave + lane;
-                    if (item < n16) v[u] = __builtin_nontemporal_load(s16 + item);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int item = base + u * kWave + lane;
-                    // (nontemporal stores here were measured: the push slows 159 -> 183 us, the reduce that follows speeds
-                    //  up 137 -> 122 us because fewer dirty lines are left behind -- a wash for the step)
-                    if (item < n16) d16[item] = v[u];
-                }
-            }
+            // straight-line groups of whole 1 KB pieces (copy_row, ep_common.h): loads back to back, then the (possibly remote) stores.
+            // (nontemporal stores were measured: the push slows 159 -> 183 us, the reduce that follows speeds up 137 -> 122 us because
+            //  fewer dirty lines are left behind -- a wash for the step)
+            copy_row<true, false>(s16, d16, n16, lane);
         }
     }
 }

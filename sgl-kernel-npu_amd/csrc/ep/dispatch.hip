@@ -304,19 +304,7 @@ __device__ __forceinline__ void pull_body(
             const uint8_t *srow = (const uint8_t *)srcs.p[src] + poff + (off + j) * stride;
             const u32x4 *s16 = (const u32x4 *)srow;
             u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
-            for (int base = 0; base < n16; base += kWave * 8) {
-                u32x4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int item = base + u * kWave + lane;
-                    if (item < n16) v[u] = __builtin_nontemporal_load(s16 + item);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int item = base + u * kWave + lane;
-                    if (item < n16) d16[item] = v[u];
-                }
-            }
+            copy_row<true, false>(s16, d16, n16, lane);           // straight-line groups of 1 KB pieces (ep_common.h)
             if (lane == 0) {
                 const u32x4 m = *(const u32x4 *)(srow + payload_bytes);
                 if (recv_scales) recv_scales[r] = __uint_as_float(m[0]);
@@ -412,19 +400,8 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         const uint8_t *srow = (const uint8_t *)srcs.p[src] + poff + trow * stride;
         const u32x4 *s16 = (const u32x4 *)srow;
         u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
-        for (int base = 0; base < n16; base += kWave * 8) {
-            u32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int item = base + u * kWave + lane;
-                if (item < n16) v[u] = s16[item];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int item = base + u * kWave + lane;
-                if (item < n16) st_row<NT>(d16 + item, v[u]);
-            }
-        }
+        copy_row<false, NT>(s16, d16, n16, lane);                 // straight-line groups of 1 KB pieces (ep_common.h); plain loads: a token
+                                                                  // row is read up to K times
         if (lane == 0) {
             if (recv_scales) recv_scales[r] = *(const float *)(srow + payload_bytes);
             recv_src_idx[r * 3 + 0] = src;

@@ -54,6 +54,51 @@ __device__ __forceinline__ float wave_max(float v)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
+// ---- row copy by one wave.  N pieces of 1 KB (lane l moves 16 B at s[64 u], u < N): all loads back to back, then all stores, in
+// straight-line code.  Written as `for u < 8: if (item < n16) v[u] = load(...)` the compiler gave every load and every store its own
+// block with an s_waitcnt vmcnt(0) in front of it: sixteen serial round trips per 8 KB, each store waiting for the (possibly remote)
+// acknowledgement of the one before (combine_push, pull_indexed and the low-latency pull were all compiled that way).
+// NTL / NTS: nontemporal loads / stores.
+template <int N, bool NTL, bool NTS>
+__device__ __forceinline__ void copy_pieces(const u32x4 *s, u32x4 *d)
+{
+    u32x4 v[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = NTL ? __builtin_nontemporal_load(s + u * kWave) : s[u * kWave];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        if (NTS) __builtin_nontemporal_store(v[u], d + u * kWave);
+        else d[u * kWave] = v[u];
+    }
+}
+// a row of n16 16-byte items: whole pieces in groups of up to eight (the group size is wave-uniform), then the items past the last
+// whole piece
+template <bool NTL, bool NTS>
+__device__ __forceinline__ void copy_row(const u32x4 *s16, u32x4 *d16, int n16, int lane)
+{
+    const int nfull = n16 / kWave;
+    const u32x4 *s = s16 + lane;
+    u32x4 *d = d16 + lane;
+    int c = 0;
+    for (; c + 8 <= nfull; c += 8) copy_pieces<8, NTL, NTS>(s + c * kWave, d + c * kWave);
+    switch (nfull - c) {
+        case 7: copy_pieces<7, NTL, NTS>(s + c * kWave, d + c * kWave); break;
+        case 6: copy_pieces<6, NTL, NTS>(s + c * kWave, d + c * kWave); break;
+        case 5: copy_pieces<5, NTL, NTS>(s + c * kWave, d + c * kWave); break;
+        case 4: copy_pieces<4, NTL, NTS>(s + c * kWave, d + c * kWave); break;
+        case 3: copy_pieces<3, NTL, NTS>(s + c * kWave, d + c * kWave); break;
+        case 2: copy_pieces<2, NTL, NTS>(s + c * kWave, d + c * kWave); break;
+        case 1: copy_pieces<1, NTL, NTS>(s + c * kWave, d + c * kWave); break;
+        default: break;
+    }
+    const int tail = nfull * kWave + lane;
+    if (tail < n16) {
+        const u32x4 v = NTL ? __builtin_nontemporal_load(s16 + tail) : s16[tail];
+        if (NTS) __builtin_nontemporal_store(v, d16 + tail);
+        else d16[tail] = v;
+    }
+}
+
 // 8-byte words other GPUs write/poll: always system-scope atomics, never plain accesses.
 __device__ __forceinline__ void sys_store_u64(uint64_t *p, uint64_t v)
 {
