@@ -115,13 +115,22 @@ __global__ __launch_bounds__(256) void swiglu_quant_kernel(const uint16_t *__res
     const int nitems = I / 8;
     float v[ITEMS][8];
     float amax = 0.f;
+    // all loads of the row first, unconditional (index clamped into the row): under `if (item < nitems)` every item's pair of loads sat
+    // in its own block behind an s_waitcnt vmcnt(0), i.e. up to eight serial memory round trips per row and wave
+    u32x4 ra[ITEMS], rb[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int item = min(it * 64 + lane, nitems - 1);
+        ra[it] = xr[item];
+        rb[it] = xr[nitems + item];
+    }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = it * 64 + lane;
         if (item < nitems) {
             float a[8], b[8];
-            unpack8<BF16>(xr[item], a);
-            unpack8<BF16>(xr[nitems + item], b);
+            unpack8<BF16>(ra[it], a);
+            unpack8<BF16>(rb[it], b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // v_exp + v_rcp (1 ulp each) instead of an IEEE division: the reference test allows |dq| <= 1 on < 2 % of the
@@ -190,15 +199,25 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const uint16_t *__rest
     const u32x4 *rr = res ? (const u32x4 *)(res + row * in_stride) : nullptr;
     float y[kNormItems][8];
     float ss = 0.f;
+    // every load of the row first, unconditional (index clamped into the row), the weights with them: under `if (item < nitems)` each
+    // item's loads sat in their own block behind an s_waitcnt vmcnt(0), and the weight loads waited behind the reduction barrier
+    u32x4 ra[kNormItems], rb[kNormItems], rw[kNormItems];
+#pragma unroll
+    for (int it = 0; it < kNormItems; ++it) {
+        const int item = min(it * 256 + tid, nitems - 1);
+        ra[it] = ir[item];
+        if (rr) rb[it] = rr[item];
+        rw[it] = ((const u32x4 *)w)[item];
+    }
 #pragma unroll
     for (int it = 0; it < kNormItems; ++it) {
         const int item = it * 256 + tid;
         if (item < nitems) {
             float a[8];
-            unpack8<BF16>(ir[item], a);
+            unpack8<BF16>(ra[it], a);
             if (rr) {
                 float b[8];
-                unpack8<BF16>(rr[item], b);
+                unpack8<BF16>(rb[it], b);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[j] = ld16<BF16>(st16<BF16>(a[j] + b[j]));   // the sum lives in the I/O dtype
                 if (out2) ((u32x4 *)(out2 + row * (long long)H))[item] = pack8<BF16>(a);
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(const uint16_t *__rest
         const int item = it * 256 + tid;
         if (item < nitems) {
             float wv[8], o[8];
-            unpack8<BF16>(((const u32x4 *)w)[item], wv);
+            unpack8<BF16>(rw[it], wv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (y[it][j] * rstd) * (gemma ? wv[j] + 1.0f : wv[j]);
             if (bias) {
