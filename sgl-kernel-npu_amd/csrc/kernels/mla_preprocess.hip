@@ -151,15 +151,15 @@ __global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__r
     const long long part_stride = (long long)ntok * kMid;       // split-K partial products of GEMM1: exact int32 sum
     for (int j = tid; j < kMid; j += kMidThreads) {
         int32_t acc = (bias0 && !per_token) ? bias0[j] : 0;
-        int p = 0;
-        for (; p + 8 <= nparts; p += 8) {               // eight independent loads in flight per step
+        // eight independent loads in flight per step, the last step included: its loads are unconditional (index clamped to the last
+        // partial, surplus values dropped) -- a scalar tail loop was one memory round trip per partial (14 partials = 1 + 6 round trips)
+        for (int p = 0; p < nparts; p += 8) {
             int32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = row[(p + u) * part_stride + j];
+            for (int u = 0; u < 8; ++u) v[u] = row[(long long)min(p + u, nparts - 1) * part_stride + j];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < 8; ++u) acc += (p + u < nparts) ? v[u] : 0;
         }
-        for (; p < nparts; ++p) acc += row[p * part_stride + j];
         float y = (float)acc * descale0[j];
         if (per_token) y = y * ts_in;
         f[j] = ldh<BF16>(sth<BF16>(y));                      // the GEMM output is materialised in the I/O dtype (golden :95-107)
