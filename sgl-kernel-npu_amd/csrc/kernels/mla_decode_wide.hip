@@ -519,6 +519,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 *(f32x4 *)(tile + c32 * kEpiRow + d * 4) = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
             }
         // wave-private tile: LDS operations of one wave complete in order, no barrier
+        if (!finals) {
+            // partial rows (the C4 case): eight rows read from the tile back to back, then their eight stores.  In the general loop
+            // below every row is an LDS round trip followed by its store, one after the other, with the wave-uniform `finals` branch
+            // splitting each iteration into blocks: 64 serial round trips per wave were most of the epilogue's 21k cycles.
+#pragma unroll
+            for (int it0 = 0; it0 < 16; it0 += 8) {
+                f32x4 o8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] = *(const f32x4 *)(tile + ((it0 + j) * 2 + (lane >> 5)) * kEpiRow + (lane & 31) * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int hgx = hblk * 128 + hb * 32 + (it0 + j) * 2 + (lane >> 5);
+                    const int64_t idx = ((int64_t)b * p.q_heads + kvh * p.group + min(hgx, p.group - 1)) * p.num_splits + split;
+                    if (hgx < p.group) *(f32x4 *)(p.ws_o + idx * kDN + wave * 128 + (lane & 31) * 4) = o8[j];
+                }
+            }
+            if (wave == 0 && lane < 32) {                      // softmax statistics of the block's 32 heads: lane = head
+                const int hgx = hblk * 128 + hb * 32 + lane;
+                if (hgx < p.group) {
+                    const int64_t idx = ((int64_t)b * p.q_heads + kvh * p.group + hgx) * p.num_splits + split;
+                    p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + lane];
+                    p.ws_ml[idx * 2 + 1] = lmb[hb * 32 + lane];
+                }
+            }
+            continue;
+        }
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int hl = it * 2 + (lane >> 5), ch = lane & 31;
