@@ -372,13 +372,18 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
             push_row[it] = ok ? (uint16_t *)((uint8_t *)p.dsts.p[ok ? src : 0] + poff + ((size_t)t * p.topk + k) * p.slot_stride) : nullptr;
         }
     }
+    // the rows are read back from the tile in one batch (always valid LDS reads), then stored: inside the conditional store loop every row
+    // was an LDS round trip in front of its store
+    u32x4 vrow[kWaveRows / 8];
+#pragma unroll
+    for (int it = 0; it < kWaveRows / 8; ++it) vrow[it] = *(const u32x4 *)(tile + (it * 8 + (lane >> 3)) * kRowBytes + (lane & 7) * 16);
 #pragma unroll
     for (int it = 0; it < kWaveRows / 8; ++it) {
         const int rl = it * 8 + (lane >> 3), chunk = lane & 7;
         const int lr = wm * kWaveRows + rl;
         if (lr >= rows) continue;
         const size_t grow = (size_t)row0 + lr;
-        const u32x4 v = *(const u32x4 *)(tile + rl * kRowBytes + chunk * 16);
+        const u32x4 v = vrow[it];
         if (MODE == 0) {
             float *orow = (float *)p.out + grow * (size_t)(p.N / 2) + (size_t)(blockIdx.x * 2 + f) * 64 + h * 32;
             *(u32x4 *)(orow + chunk * 4) = v;
