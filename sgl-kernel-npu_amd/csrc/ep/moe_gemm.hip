@@ -452,10 +452,12 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const float *__restrict__
         // the row stays in registers between the max pass and the quantisation (8 x 16 B per lane): v is read ONCE -- the PMC
         // counters showed 600 MB per launch against 336 MB algorithmic when the second pass re-read it
         float4 x[8];
+        // unconditional loads (index clamped into the row; I % 4 == 0): conditional ones get a block and a vmcnt(0) each
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *(const float4 *)(vr + min(lane * 4 + u * 256, I - 4));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = lane * 4 + u * 256;
-            x[u] = i < I ? *(const float4 *)(vr + i) : float4{0.f, 0.f, 0.f, 0.f};
+            if (lane * 4 + u * 256 >= I) x[u] = float4{0.f, 0.f, 0.f, 0.f};
             amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[u].x), fabsf(x[u].y)), fmaxf(fabsf(x[u].z), fabsf(x[u].w))));
         }
         amax = wave_max(amax);
