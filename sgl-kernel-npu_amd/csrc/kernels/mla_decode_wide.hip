@@ -82,6 +82,19 @@ __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// value of the lower half-wave's lane (l & 31) and of the upper half-wave's, in every lane: one v_permlane32_swap
+struct HalfPair {
+    float lo, hi;
+};
+__device__ __forceinline__ HalfPair halves(float x)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(x);
+    // vdst' = {lower lanes of vdst | lower lanes of vsrc}, vsrc' = {upper lanes of vdst | upper lanes of vsrc}
+    const u32x2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return HalfPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+
 struct WideCtx {
     const MlaParams *p;
     int b, kvh, seq_len, wave, lane;
@@ -366,7 +379,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float tmax = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        {   // the two half-waves meet through v_permlane32_swap (VALU) instead of ds_bpermute: an LDS round trip at the end of the chain
+            const auto sw = halves(tmax);
+            tmax = fmaxf(sw.lo, sw.hi);
+        }
         return tmax * cs;                                      // sm_scale > 0: max commutes with the scaling
     };
 
@@ -390,7 +406,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // work is NOT free: every instruction between two MFMAs on one accumulator breaks their back-to-back issue.)
     // Barrier A (tile_top): tile i+1 landed, everybody is done with V(i-1) and with the exchange buffer; barrier B: P^T(i) complete.
     auto publish = [&](float psum, const uint32_t (&pk)[8]) {
-        psum += __shfl_xor(psum, 32, 64);
+        {
+            const auto sw = halves(psum);
+            psum = sw.lo + sw.hi;
+        }
         l_run += psum;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
