@@ -21,6 +21,39 @@
 
 namespace mi_gqa {
 
+// Reductions across the four 16-lane rows of a wave through v_permlane16_swap / v_permlane32_swap (VALU) instead of ds_bpermute (an LDS
+// round trip each).  swap16(x): {rows 0,0,2,2 | rows 1,1,3,3} of x; swap32(x): {lower half twice | upper half twice}.  Sums and maxima of
+// the two parts are the xor-16 / xor-32 butterfly steps (same two operands in every lane: bit-identical to the shuffle form).
+struct RowPair {
+    float a, b;
+};
+__device__ __forceinline__ RowPair swap16(float x)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(x);
+    const u32x2v r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return RowPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ RowPair swap32(float x)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(x);
+    const u32x2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return RowPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ float max_over_rows(float x)
+{
+    const RowPair p = swap16(x);
+    const RowPair q = swap32(fmaxf(p.a, p.b));
+    return fmaxf(q.a, q.b);
+}
+__device__ __forceinline__ float sum_over_rows(float x)
+{
+    const RowPair p = swap16(x);
+    const RowPair q = swap32(p.a + p.b);
+    return q.a + q.b;
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -222,8 +255,7 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
             float tmax = -INFINITY;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) tmax = fmaxf(fmaxf(tmax, fmaxf(s[mt][0], s[mt][1])), fmaxf(s[mt][2], s[mt][3]));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = max_over_rows(tmax);
             tmax *= cs;                                           // sm_scale > 0: max commutes with the scaling
             if (__any(tmax > m_run[hb])) {
                 const float m_new = fmaxf(m_run[hb], tmax);
@@ -247,8 +279,7 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
                 pk[mt * 2 + 0] = pack2<BF16>(e[0], e[1]);
                 pk[mt * 2 + 1] = pack2<BF16>(e[2], e[3]);
             }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
+            psum = sum_over_rows(psum);
             l_run[hb] += psum;
             // ---- O^T[d, head] += V^T . P^T ; k-step kk covers key tiles (2kk, 2kk+1): slots 0..3 / 4..7 of lane group g
             const uint8_t *vrow = buf + TILE * KS + (4 * g + (c16 >> 2)) * VS + (c16 & 3) * 8;

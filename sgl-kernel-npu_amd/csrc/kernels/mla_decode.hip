@@ -39,6 +39,39 @@
 
 namespace mi_sgl {
 
+// Reductions across the four 16-lane rows of a wave through v_permlane16_swap / v_permlane32_swap (VALU) instead of ds_bpermute (an LDS
+// round trip each).  swap16(x): {rows 0,0,2,2 | rows 1,1,3,3} of x; swap32(x): {lower half twice | upper half twice}.  Sums and maxima of
+// the two parts are the xor-16 / xor-32 butterfly steps (same two operands in every lane: bit-identical to the shuffle form).
+struct RowPair {
+    float a, b;
+};
+__device__ __forceinline__ RowPair swap16(float x)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(x);
+    const u32x2v r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return RowPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ RowPair swap32(float x)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(x);
+    const u32x2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return RowPair{__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ float max_over_rows(float x)
+{
+    const RowPair p = swap16(x);
+    const RowPair q = swap32(fmaxf(p.a, p.b));
+    return fmaxf(q.a, q.b);
+}
+__device__ __forceinline__ float sum_over_rows(float x)
+{
+    const RowPair p = swap16(x);
+    const RowPair q = swap32(p.a + p.b);
+    return q.a + q.b;
+}
+
 constexpr int kBufBytes = kTile * kNopeStride + kTile * kRopeStride;   // 74752
 #ifndef MLA_QK_AHEAD
 #define MLA_QK_AHEAD 3
@@ -270,8 +303,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         float tmax = -INFINITY;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) tmax = fmaxf(fmaxf(tmax, fmaxf(s[mt][0], s[mt][1])), fmaxf(s[mt][2], s[mt][3]));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = max_over_rows(tmax);
         tmax *= cs;                                     // sm_scale > 0: max commutes with the scaling
         // Deferred rescale: the running reference m_run only moves when some head's tile maximum exceeds it by more
         // than kDefer (then every head of the wave re-bases to its true maximum); otherwise P = exp2(.) <= 2^kDefer
@@ -303,8 +335,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
             pk[mt * 2 + 0] = pack2<BF16>(e[0], e[1]);
             pk[mt * 2 + 1] = pack2<BF16>(e[2], e[3]);
         }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
+        psum = sum_over_rows(psum);
         l_run += psum;
         if (MLA_STAGE && more) {
             __builtin_amdgcn_sched_barrier(0);
