@@ -71,9 +71,20 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    // maximum over the wave without LDS: four DPP steps inside each row of 16 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+    // row_mirror), then v_permlane16_swap / v_permlane32_swap across the rows.  The shuffle form was six ds_bpermute round trips
+    // (~120 cycles each), on the critical path of every token wave of the stage kernels.
+#define MI_DPP_MAX(CTRL) v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false)))
+    MI_DPP_MAX(0xB1);
+    MI_DPP_MAX(0x4E);
+    MI_DPP_MAX(0x141);
+    MI_DPP_MAX(0x140);
+#undef MI_DPP_MAX
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    u32x2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ int sat_i8(float v)
 {
