@@ -57,10 +57,10 @@ __device__ __forceinline__ void stage_token_rows(const PushGeom &pg, const PeerP
         return;
     }
     // distinct destination ranks of this token (K <= 16 selections, W <= 64 ranks): one row per rank, one index entry per pair
-    const int d_l = e_l >= 0 ? (int)(e_l / pg.L) : -1;
+    const int d_l = e_l >= 0 ? (int)((uint32_t)e_l / (uint32_t)pg.L) : -1;      // 0 <= e_l < E: 32-bit division (the 64-bit one is ~150 VALU operations)
     unsigned long long rmask = 0ull;
     for (int k = 0; k < K; ++k) {
-        const int dk = __shfl(d_l, k, kWave);
+        const int dk = __builtin_amdgcn_readlane(d_l, k);                   // k is wave-uniform: v_readlane, not ds_bpermute
         if (dk >= 0) rmask |= 1ull << dk;
     }
     while (rmask) {                                   // wave-uniform
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     const size_t poff = parity_off(par);
     for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;          // wave-uniform
-        const int slot = __shfl(slot_l, k, kWave);
-        const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
+        const int slot = __builtin_amdgcn_readlane(slot_l, k);      // k is wave-uniform: v_readlane instead of an LDS round trip
+        const int drank = __builtin_amdgcn_readlane(dst_l, k);
         uint8_t *row = (uint8_t *)dsts.p[drank] + poff + (size_t)slot * stride;
         u32x4 *dst = (u32x4 *)row;
 #pragma unroll
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     const size_t poff = parity_off(par);
     for (int k = kpart; k < K; k += ksplit) {
         if (!((vmask >> k) & 1ull)) continue;
-        const int slot = __shfl(slot_l, k, kWave);
-        const int drank = __builtin_amdgcn_readfirstlane(__shfl(dst_l, k, kWave));
+        const int slot = __builtin_amdgcn_readlane(slot_l, k);      // k is wave-uniform: v_readlane instead of an LDS round trip
+        const int drank = __builtin_amdgcn_readlane(dst_l, k);
         uint8_t *row = (uint8_t *)dsts.p[drank] + poff + (size_t)slot * stride;
         u32x4 *dst = (u32x4 *)row;
 #pragma unroll
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
         }
         for (unsigned long long m = lmask; m; m &= m - 1) {       // wave-uniform walk over this rank's selections of the token
             const int k = __builtin_ctzll(m);
-            u32x4 *d16 = (u32x4 *)(recv_x + (size_t)__shfl(r_l, k, kWave) * payload_bytes);
+            u32x4 *d16 = (u32x4 *)(recv_x + (size_t)__builtin_amdgcn_readlane(r_l, k) * payload_bytes);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int item = base + u * kWave + lane;
