@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
         u32x4 v[KMAX];
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (ALL || (k < K && ((vmask >> k) & 1ull))) v[k] = __builtin_nontemporal_load((gptr)(uintptr_t)(rowp[k] + (uint32_t)c * 16u));
+            // unconditional in both paths: an absent / invalid selection re-reads a row that is always there (base_l above) and is skipped in
+            // the sum -- under the wave-uniform condition each load got its own block and its own vmcnt(0)
+            v[k] = __builtin_nontemporal_load((gptr)(uintptr_t)(rowp[k] + (uint32_t)c * 16u));
         f32x2 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = f32x2{0.f, 0.f};
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
         for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(acc[j], bf16x2));
         *(u32x4 *)(out + (size_t)t * H + (size_t)c * 8) = o;
     };
-    // Every selection of the token present (the usual case): straight-line code, all KMAX row reads issued back to back.  With -1 entries
-    // or K < KMAX the conditions are wave-uniform, the compiler turns them into branches and gives each read its own block (and wait).
+    // Every selection of the token present (the usual case): straight-line code.  With -1 entries or K < KMAX (top-6 models on the
+    // top-8 build) the sum skips the absent rows under wave-uniform branches; the KMAX row reads are issued back to back either way.
     if (K == KMAX && vmask == (KMAX == 64 ? ~0ull : (1ull << KMAX) - 1ull)) {
         for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) chunk(c, std::true_type{});
     } else {
