@@ -254,18 +254,29 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
     for (int i = tid; i < W; i += blockDim.x) rank_cnt[i] = 0;
     if (tid == 0) carry[0] = 0;
     __syncthreads();
-    // ---- pass 1: histogram + token -> rank masks; wave w takes units w, w + 16, ...
+    // ---- pass 1: histogram + token -> rank masks; wave w takes unit w (T <= 1024 with 64-token units, <= 256 with 16-token units:
+    // never more than 16 units).  The unit's expert ids are requested in ONE batch and stay in registers for pass 3: read batch by batch
+    // in both passes they were four to eight dependent global round trips of a ~6 us kernel.
+    constexpr int kB = UT * MI_EP_MAX_TOPK / kWave;               // batches of 64 (token, k) pairs in a unit
+    long long ev[kB];
+    {
+        const int unit0 = wave < U ? wave : 0;
+        const long long q0 = (long long)unit0 * UT * K;
+        const int np0 = min(UT, T - unit0 * UT) * K;
+#pragma unroll
+        for (int i = 0; i < kB; ++i) ev[i] = (U > 0 && np0 > 0) ? load_idx<I32>(topk_idx, q0 + min(i * kWave + lane, np0 - 1)) : -1;
+    }
     for (int unit = wave; unit < U; unit += 16) {
         const int t0 = unit * UT;
         const int ntok = min(UT, T - t0);
-        const long long p0 = (long long)t0 * K;
         const int npairs = ntok * K;
         int32_t *h = hist + unit * E;
         unsigned long long *rm = rmask + unit * UT;
-        for (int c = 0; c < npairs; c += kWave) {
-            const int p = c + lane;
-            if (p < npairs) {
-                const long long e = load_idx<I32>(topk_idx, p0 + p);
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+            const int p = i * kWave + lane;
+            if (i * kWave < npairs && p < npairs) {
+                const long long e = ev[i];
                 if (e >= 0 && e < E) {
                     atomicAdd(&h[(int)e], 1);
                     atomicOr(&rm[p / K], 1ull << ((int)e / L));
@@ -320,10 +331,12 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
         const int npairs = min(UT, T - t0) * K;
         int32_t *cnt = hist + unit * E;
         const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int c = 0; c < npairs; c += kWave) {
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+            const int c = i * kWave;
+            if (c >= npairs) break;                                // wave-uniform
             const int p = c + lane;
-            long long e = -1;
-            if (p < npairs) e = load_idx<I32>(topk_idx, p0 + p);
+            const long long e = p < npairs ? ev[i] : -1;           // the ids of pass 1
             const bool valid = (e >= 0 && e < E);
             const unsigned long long same = match_any_bits(valid ? (unsigned)e : 0u, valid, nbits);
             int32_t out = 0;
