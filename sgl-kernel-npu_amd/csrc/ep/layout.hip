@@ -22,6 +22,12 @@ __device__ __forceinline__ long long load_idx(const void *p, long long i)
     return ((const long long *)p)[i];
 }
 
+// n / d for 0 <= n < 2048 * 64 and 1 <= d <= 2048 through a float reciprocal (inv = 1.0f / d): (n + 0.5) / d is at least 0.5 / d away
+// from an integer, three orders of magnitude more than the rounding of the two float operations, so the truncation is exact.  An
+// integer division is ~25 instructions, five of them quarter-rate; the histogram kernel had two per batch of 64 pairs and was
+// VALU-bound after its loads were batched.
+__device__ __forceinline__ int div_small(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
 // lanes holding the same key as this lane (key < 2^nbits), via nbits ballots
 __device__ __forceinline__ unsigned long long match_any_bits(unsigned key, bool active, int nbits)
 {
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void layout_hist_kernel(
     const int t0 = unit * kUnitTokens;
     const int ntok = min(kUnitTokens, T - t0);
     const int L = E / W;
+    const float inv_k = 1.0f / (float)K, inv_l = 1.0f / (float)L;
     const long long p0 = (long long)t0 * K;
     const int npairs = ntok * K;
     // all of the unit's expert ids first (at most 64 tokens x 16 selections = 16 per lane; index clamped, so unconditional): read inside
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void layout_hist_kernel(
             const long long e = ev[i];
             if (e >= 0 && e < E) {
                 atomicAdd(&hist[(int)e], 1);
-                atomicOr(&rmask[p / K], 1ull << ((int)e / L));
+                atomicOr(&rmask[div_small(p, inv_k)], 1ull << div_small((int)e, inv_l));
             }
         }
     }
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
     int32_t *carry = wave_tot + 16;                                         // [1]
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / kWave;
     const int L = E / W;
+    const float inv_k = 1.0f / (float)K, inv_l = 1.0f / (float)L;
     for (int i = tid; i < U * E; i += blockDim.x) hist[i] = 0;
     for (int i = tid; i < U * UT; i += blockDim.x) rmask[i] = 0ull;
     for (int i = tid; i < W; i += blockDim.x) rank_cnt[i] = 0;
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
                 const long long e = ev[i];
                 if (e >= 0 && e < E) {
                     atomicAdd(&h[(int)e], 1);
-                    atomicOr(&rm[p / K], 1ull << ((int)e / L));
+                    atomicOr(&rm[div_small(p, inv_k)], 1ull << div_small((int)e, inv_l));
                 }
             }
         }
