@@ -320,8 +320,9 @@ __device__ __forceinline__ void pull_body(
 // Store of a received row.  A receive buffer larger than the last-level cache (kPullWriteAround) is written around it
 // (nontemporal): left to write-back, its dirty lines are evicted under the NEXT kernels' loads -- measured at C2 (235 MB received):
 // the pull itself 44 -> 52 us, but the stage kernel of the following call 30 -> 19 us and the combine reduce 110 -> 102 us, the
-// step 0.222 -> 0.208 ms.  Decode-size receives stay cached for the grouped GEMM that reads them next.
-constexpr size_t kPullWriteAround = 64u << 20;
+// step 0.222 -> 0.208 ms.  At 2048 tokens (117 MB, inside the 256 MB MALL) the same switch LOSES 3 us (pull 24.0 -> 27.5 us, nothing
+// gained downstream): the threshold sits between the two.  Decode-size receives stay cached for the grouped GEMM that reads them next.
+constexpr size_t kPullWriteAround = 160u << 20;
 template <bool NT>
 __device__ __forceinline__ void st_row(u32x4 *p, const u32x4 &v)
 {
