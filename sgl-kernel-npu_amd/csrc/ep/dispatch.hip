@@ -317,12 +317,14 @@ __device__ __forceinline__ void pull_body(
 }
 
 
-// Store of a received row.  A receive buffer larger than the last-level cache (kPullWriteAround) is written around it
-// (nontemporal): left to write-back, its dirty lines are evicted under the NEXT kernels' loads -- measured at C2 (235 MB received):
-// the pull itself 44 -> 52 us, but the stage kernel of the following call 30 -> 19 us and the combine reduce 110 -> 102 us, the
-// step 0.222 -> 0.208 ms.  At 2048 tokens (117 MB, inside the 256 MB MALL) the same switch LOSES 3 us (pull 24.0 -> 27.5 us, nothing
-// gained downstream): the threshold sits between the two.  Decode-size receives stay cached for the grouped GEMM that reads them next.
-constexpr size_t kPullWriteAround = 160u << 20;
+// Store of a received row.  The first kPullWriteBack bytes of a receive buffer are written normally (write-back: the MALL absorbs them),
+// everything behind them around the cache (nontemporal).  Left to write-back entirely, the 235 MB of a C2 receive sit dirty in L2 / MALL
+// when the pull ends and are evicted under the NEXT kernels' loads (pull 44 us, but the following stage kernel 30 instead of 18 us and
+// the combine reduce 110 instead of 102 us); written around entirely, the pull pays for all of its writes itself (52 us).  Share
+// written back, C2, one box (tools/probes/nt_from_sweep.sh): 0 MB pull 52.6 / stage 17.7 us, 32 MB 46.8 / 17.6, 64 MB 43.0 / 17.7,
+// 96 MB 42.5 / 18.1, 112 MB 42.5 / 19.8, 160 MB 44.8 / 28.9 -- step 0.197 -> 0.182 ms at 64-96 MB.  Smaller buffers (2048 tokens: 117 MB)
+// behave the same way: all write-back 24.0 us, all written around 27.5 us.
+constexpr size_t kPullWriteBack = 80u << 20;
 template <bool NT>
 __device__ __forceinline__ void st_row(u32x4 *p, const u32x4 &v)
 {
@@ -330,11 +332,16 @@ __device__ __forceinline__ void st_row(u32x4 *p, const u32x4 &v)
     else *p = v;
 }
 
-static bool pull_write_around(long long rows, int payload)
+// first row that is written around the cache (rows are `payload` bytes); INT_MAX = none.  MI_EP_PULL_NT=0 / 1 force none / all,
+// MI_EP_PULL_NT_FROM_MB sets the write-back share (measurement only)
+static int pull_nt_from_row(long long rows, int payload)
 {
-    static const char *env = getenv("MI_EP_PULL_NT");             // 0 / 1 force the choice (measurement only)
-    if (env && *env) return atoi(env) != 0;
-    return (size_t)rows * (size_t)payload >= kPullWriteAround;
+    static const char *env = getenv("MI_EP_PULL_NT");
+    static const char *env_mb = getenv("MI_EP_PULL_NT_FROM_MB");
+    if (env && *env) return atoi(env) != 0 ? 0 : 0x7fffffff;
+    const size_t share = env_mb && *env_mb ? (size_t)atoll(env_mb) << 20 : kPullWriteBack;
+    const long long from = (long long)(share / (size_t)payload);
+    return from >= rows ? 0x7fffffff : (int)from;
 }
 
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
@@ -357,7 +364,7 @@ template <bool NT>
 __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
     PeerPtrs srcs, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int W, int LW,
     int payload_bytes, size_t idx_off, size_t idx_entries, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales,
-    int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par, int skip_src)
+    int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par, int skip_src, int nt_from_row)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
     for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
@@ -401,8 +408,9 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
         const uint8_t *srow = (const uint8_t *)srcs.p[src] + poff + trow * stride;
         const u32x4 *s16 = (const u32x4 *)srow;
         u32x4 *d16 = (u32x4 *)(recv_x + (size_t)r * payload_bytes);
-        copy_row<false, NT>(s16, d16, n16, lane);                 // straight-line groups of 1 KB pieces (ep_common.h); plain loads: a token
-                                                                  // row is read up to K times
+        // straight-line groups of 1 KB pieces (ep_common.h); plain loads: a token row is read up to K times
+        if (NT && r >= nt_from_row) copy_row<false, true>(s16, d16, n16, lane);
+        else copy_row<false, false>(s16, d16, n16, lane);
         if (lane == 0) {
             if (recv_scales) recv_scales[r] = *(const float *)(srow + payload_bytes);
             recv_src_idx[r * 3 + 0] = src;
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
     const uint8_t *__restrict__ my_rows, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
     const int32_t *__restrict__ recv_count, const int32_t *__restrict__ tokens_per_expert, int T, int K, int E, int W, int my_rank,
     int payload_bytes, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales, int32_t *__restrict__ recv_src_idx,
-    int row_capacity, Parity par)
+    int row_capacity, Parity par, int nt_from_row)
 {
     const int lane = lane_id();
     const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * kPullWaves + threadIdx.x / kWave);
@@ -466,11 +474,20 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
         }
         for (unsigned long long m = lmask; m; m &= m - 1) {       // wave-uniform walk over this rank's selections of the token
             const int k = __builtin_ctzll(m);
-            u32x4 *d16 = (u32x4 *)(recv_x + (size_t)__builtin_amdgcn_readlane(r_l, k) * payload_bytes);
+            const int rk = __builtin_amdgcn_readlane(r_l, k);
+            u32x4 *d16 = (u32x4 *)(recv_x + (size_t)rk * payload_bytes);
+            if (NT && rk >= nt_from_row) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int item = base + u * kWave + lane;
-                if (item < n16) st_row<NT>(d16 + item, v[u]);
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * kWave + lane;
+                    if (item < n16) st_row<true>(d16 + item, v[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int item = base + u * kWave + lane;
+                    if (item < n16) st_row<false>(d16 + item, v[u]);
+                }
             }
         }
     }
@@ -630,8 +647,10 @@ extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, con
 #define MI_EP_PULL_INDEXED(NT)                                                                                                      \
     pull_indexed_kernel<NT><<<(int)blocks, kWave * kPullWaves, lds, (hipStream_t)stream>>>(                                         \
         pp, recv_count, pull_offset, W, L * W, payload, idx_off, (idx_off / mi_ep_dispatch_row_bytes(H, quant_mode)) * (size_t)K,  \
-        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, make_parity(epoch_ctr, 0, parity_stride), skip_src < 0 ? -1 : skip_src)
-    if (pull_write_around(rows_hint, payload)) MI_EP_PULL_INDEXED(true); else MI_EP_PULL_INDEXED(false);
+        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, make_parity(epoch_ctr, 0, parity_stride), skip_src < 0 ? -1 : skip_src, \
+        nt_from)
+    const int nt_from = pull_nt_from_row(rows_hint, payload);
+    if (nt_from != 0x7fffffff) MI_EP_PULL_INDEXED(true); else MI_EP_PULL_INDEXED(false);
 #undef MI_EP_PULL_INDEXED
     return launch_status();
 }
@@ -650,13 +669,14 @@ extern "C" int mi_ep_dispatch_pull_local(const void *my_rows, const void *topk_i
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
     const int blocks = (T + kPullWaves - 1) / kPullWaves;
     const Parity par = make_parity(epoch_ctr, 0, parity_stride);
-    const bool nt = pull_write_around(rows_hint, payload);
+    const int nt_from = pull_nt_from_row(rows_hint, payload);
+    const bool nt = nt_from != 0x7fffffff;
 #define MI_EP_PULL_LOCAL(I32)                                                                                                       \
     if (nt) MI_EP_PULL_LOCAL2(I32, true); else MI_EP_PULL_LOCAL2(I32, false)
 #define MI_EP_PULL_LOCAL2(I32, NT)                                                                                                  \
     pull_local_kernel<I32, NT><<<blocks, kWave * kPullWaves, 0, (hipStream_t)stream>>>(                                                \
         (const uint8_t *)my_rows, topk_idx, send_token_idx_small, recv_count, num_tokens_per_expert, T, K, E, W, my_rank, payload, \
-        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, par)
+        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, par, nt_from)
     if (idx_is_i32) { MI_EP_PULL_LOCAL(true); } else { MI_EP_PULL_LOCAL(false); }
 #undef MI_EP_PULL_LOCAL
 #undef MI_EP_PULL_LOCAL2
