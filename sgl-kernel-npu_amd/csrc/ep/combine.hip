@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
         if (send_off && valid_l) slot_l = (long long)send_off[e] + idx_small[tk];
         if (valid_l) base_l = slots + (size_t)(int)slot_l * slot_stride;
         // selections served by this rank's own experts were not pushed: their rows are read from the expert output itself
-        if (x_local && valid_l && (int)(e / experts_per_rank) == my_rank)
+        if (x_local && valid_l && (int)((uint32_t)e / (uint32_t)experts_per_rank) == my_rank)      // 0 <= e < E: 32-bit division
             base_l = x_local + (size_t)min(max(local_row[tk], 0), local_rows - 1) * ((size_t)H * 2);       // never read outside x, whatever the handle says
     }
     const unsigned long long vmask = __ballot(valid_l);
