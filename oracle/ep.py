@@ -165,17 +165,24 @@ def quant_int8_rows(x_bits: np.ndarray, eps: Optional[float]) -> tuple:
         s = 127.0f / max_j |x_j| with no epsilon.  An all-zero row gives s = inf and
         0 * inf = NaN in the reference (result unspecified); here (and in the HIP kernel)
         such a row quantises to q = 0, scale = 0.
+    Non-finite input (the reference's ReduceMax over a row holding a NaN is unspecified): a row that holds a
+    NaN or an infinity has max |x| = +inf here and in the HIP kernel (which takes the maximum on the bf16 bit
+    patterns, where a NaN orders above infinity and is clamped to it) -> s = 0, scale_out = +inf, q = 0 at
+    every finite element; the bytes at the non-finite positions themselves are unspecified.
     Returns (q int8 [N,H], scale f32 [N]).
     """
     xf = bf16_bits_to_f32(x_bits)
-    amax = np.max(np.abs(xf), axis=1).astype(np.float32) if xf.shape[1] else np.zeros(xf.shape[0], np.float32)
+    with np.errstate(invalid="ignore"):
+        ax = np.abs(xf)
+        ax = np.where(np.isnan(ax), np.float32(np.inf), ax)
+    amax = np.max(ax, axis=1).astype(np.float32) if xf.shape[1] else np.zeros(xf.shape[0], np.float32)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         if eps is None:
             s = np.float32(127.0) / amax
         else:
             s = np.float32(127.0) / (amax + np.float32(eps))
         y = xf * s[:, None]
-        q = np.rint(y)                       # round half to even
+        q = np.nan_to_num(np.rint(y), nan=0.0)   # round half to even (non-finite positions: unspecified, 0 here)
         scale = (np.float32(1.0) / s).astype(np.float32)
     if eps is None:
         zero = amax == 0

@@ -303,7 +303,7 @@ Buffer::Layout Buffer::run_layout(const at::Tensor &topk_idx, int num_experts)
     EP_HOST_ASSERT_S(K >= 1 && K <= MI_EP_MAX_TOPK, "num_topk (", K, ") must be in [1, ", MI_EP_MAX_TOPK, "]");
     auto i32 = at::dtype(at::kInt).device(topk_idx.device());
     Layout l;
-    l.T = T, l.K = K, l.E = num_experts, l.idx = topk_idx, l.idx_version = (int64_t)topk_idx._version();
+    l.T = T, l.K = K, l.E = num_experts, l.idx = topk_idx, l.idx_version = Layout::version_of(topk_idx);
     l.num_tokens_per_expert = at::empty({num_experts}, i32);
     l.num_tokens_per_rank = at::empty({num_ranks}, i32);
     l.is_token_in_rank = at::empty({T, num_ranks}, i32);
@@ -793,10 +793,13 @@ at::Tensor Buffer::prepared_weight(const at::Tensor &w, int kind, const std::fun
 {
     const WeightKey key{w.data_ptr(), kind};
     auto it = weight_cache_.find(key);
-    if (it != weight_cache_.end() && it->second.version == (int64_t)w._version() && it->second.numel == w.numel()) return it->second.t;
+    // Inference tensors have no version counter (version -1): the entry then hangs on (address, held storage, numel) alone;
+    // weights are layer constants, a caller that rewrites an inference-mode weight in place calls clear_weight_cache().
+    const int64_t ver = Layout::version_of(w);
+    if (it != weight_cache_.end() && it->second.version == ver && it->second.numel == w.numel()) return it->second.t;
     if (weight_cache_.size() >= 512) weight_cache_.clear();
     at::Tensor t = make();
-    weight_cache_[key] = WeightEntry{(int64_t)w._version(), w.numel(), w, t};
+    weight_cache_[key] = WeightEntry{ver, w.numel(), w, t};
     return t;
 }
 

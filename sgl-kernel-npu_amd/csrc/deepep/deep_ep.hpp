@@ -150,10 +150,15 @@ private:
         // the stash is alive) together with its version counter (in-place rewrites invalidate the stash).
         at::Tensor idx;
         int64_t idx_version = -1;
+        // Inference tensors (torch.inference_mode(), the reference's own test harness runs every rank under it,
+        // tests/python/deepep/test_fused_deep_moe_a5.py:723) carry no version counter: at::Tensor::_version() throws for
+        // them.  Their version is recorded as -1 and a stash with version -1 never matches (an in-place rewrite could
+        // not be seen), so such callers always get a freshly computed layout.
+        static int64_t version_of(const at::Tensor &t) { return t.is_inference() ? -1 : (int64_t)t._version(); }
         bool matches(const at::Tensor &t, int64_t num_experts) const
         {
-            return idx.defined() && idx.data_ptr() == t.data_ptr() && idx.scalar_type() == t.scalar_type() &&
-                   idx_version == (int64_t)t._version() && T == t.size(0) && K == t.size(1) && E == num_experts;
+            return idx.defined() && idx_version >= 0 && idx.data_ptr() == t.data_ptr() && idx.scalar_type() == t.scalar_type() &&
+                   idx_version == version_of(t) && T == t.size(0) && K == t.size(1) && E == num_experts;
         }
     };
     Layout run_layout(const at::Tensor &topk_idx, int num_experts);
@@ -237,6 +242,9 @@ private:
         at::Tensor t;
     };
     std::map<WeightKey, WeightEntry> weight_cache_;
+  public:
+    void clear_weight_cache() { weight_cache_.clear(); }   // MI355X only: after an in-place weight update of inference tensors
+  private:
 
     struct ProfRec {
         const char *name;

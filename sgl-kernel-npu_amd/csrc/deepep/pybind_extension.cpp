@@ -70,6 +70,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     MI_METHOD(buf, low_latency_dispatch);
     MI_METHOD(buf, low_latency_combine);
     MI_METHOD(buf, dispatch_ffn_combine);
+    MI_METHOD(buf, clear_weight_cache);
     buf.def("fused_deep_moe", &Buffer::fused_deep_moe, py::arg("x"), py::arg("expert_ids"), py::arg("gmm1_permuted_weight"),
             py::arg("gmm1_permuted_weight_scale"), py::arg("gmm2_weight"), py::arg("gmm2_weight_scale"),
             py::arg("expert_scales_optional"), py::arg("num_max_dispatch_tokens_per_rank"), py::arg("num_experts"),

@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
     // below as wave-uniform values (v_readlane -> SGPR pair + one lane offset) instead of K 64-bit multiplications and selects per lane
     float w_l = 0.f;
     bool valid_l = false;
-    const uint8_t *base_l = slots + (size_t)t * K * slot_stride;      // absent / invalid selections: a row that is always there, never summed
+    // absent / invalid selections re-read a row that is always there and is never summed: slot t*K of the window layout (T*K slots), row 0
+    // of the all-to-all return buffer (send_off != NULL: it holds exactly the valid pairs, at least one row -- row t*K may lie past its end)
+    const uint8_t *base_l = send_off ? slots : slots + (size_t)t * K * slot_stride;
     if (lane < K) {
         const size_t tk = (size_t)t * K + lane;
         long long e = I32 ? (long long)((const int32_t *)topk_idx)[tk] : ((const long long *)topk_idx)[tk];

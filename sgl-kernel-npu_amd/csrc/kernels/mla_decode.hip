@@ -498,7 +498,9 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     // rows of 32 MB) goes to the 64-head kernel, which keeps the general int64 form
     auto fits = [](int64_t v, int bits) { return v >= 0 && v < (1ll << bits); };
     const bool narrow = fits(kn_stride_blk, 31) && fits(kr_stride_blk, 31) && fits(kn_stride_row, 24) && fits(kr_stride_row, 24) &&
-                        page_size < (1 << 24);
+                        page_size < (1 << 24) &&
+                        // row-in-block * row stride is formed with a 24 x 24 -> 32-bit multiply: the product must fit 32 bits too
+                        fits((int64_t)(page_size - 1) * kn_stride_row, 32) && fits((int64_t)(page_size - 1) * kr_stride_row, 32);
     const bool wide = use_wide(q_heads / kv_heads) && narrow;
     if ((num_splits > 1 || wide) && (!workspace || workspace_bytes < mi_mla_decode_workspace(batch, q_heads, num_splits)))
         return MI_SGL_EINVAL;

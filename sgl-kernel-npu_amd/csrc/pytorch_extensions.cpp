@@ -227,22 +227,27 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
 // skinny split-K / weight-streaming kernels) or csrc/kernels/mla_preprocess.hip (quant, dequant + split + RMSNorm + RoPE + cache).
 // wuk is consumed K-contiguous: its [q_heads, 512, 128] transpose is made once per weight tensor and kept (the reference casts
 // its weights to the NZ format once as well).
-static at::Tensor prepared_wuk(const at::Tensor &wuk)
+static at::Tensor prepared_wuk(const at::Tensor &wuk, at::ScalarType dtype)
 {
+    // Keyed on the CALLER's tensor (address, version, target dtype): a dtype conversion happens inside the make step, so a wuk
+    // stored in another dtype than the activations still hits.  Inference tensors carry no version counter (_version() throws):
+    // they are recorded as version -1 and matched on (address, held storage, shape, dtype) alone.
     struct Entry {
         at::Tensor src, t;      // the source is held: its storage cannot be recycled for another weight while the entry lives
         int64_t version;
     };
     static std::mutex mu;
-    static std::map<const void *, Entry> cache;
+    static std::map<std::pair<const void *, int>, Entry> cache;
+    const int64_t ver = wuk.is_inference() ? -1 : (int64_t)wuk._version();
+    const auto key = std::make_pair((const void *)wuk.data_ptr(), (int)dtype);
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(wuk.data_ptr());
-    if (it != cache.end() && it->second.version == (int64_t)wuk._version() && it->second.src.sizes() == wuk.sizes() &&
+    auto it = cache.find(key);
+    if (it != cache.end() && it->second.version == ver && it->second.src.sizes() == wuk.sizes() &&
         it->second.src.scalar_type() == wuk.scalar_type())
         return it->second.t;
     if (cache.size() >= 256) cache.clear();
-    at::Tensor t = wuk.transpose(1, 2).contiguous();
-    cache[wuk.data_ptr()] = Entry{wuk, t, (int64_t)wuk._version()};
+    at::Tensor t = wuk.to(dtype).transpose(1, 2).contiguous();
+    cache[key] = Entry{wuk, t, ver};
     return t;
 }
 
@@ -338,7 +343,7 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
                                     per_token ? tok0.data_ptr<float>() : nullptr, per_token ? tok1.data_ptr<float>() : nullptr, cmode_i,
                                     (int)block_size, cmode_i == 2 ? ctkv_scale->data_ptr() : nullptr, st),
                 "mi_mla_pre_mid failed");
-    at::Tensor wuk_t = prepared_wuk(wuk.to(hiddenState.scalar_type()));
+    at::Tensor wuk_t = prepared_wuk(wuk, hiddenState.scalar_type());
     const void *qns = cmode_i == 2 ? q_nope_scale->data_ptr() : nullptr;
     // GEMM2 + per-head BMM + RoPE: one launch, a workgroup per head, the GEMM2 output stays in LDS (MI_MLA_PRE_FUSED=0: the two-launch
     // form with the GEMM2 output materialised in global memory; bit-identical)

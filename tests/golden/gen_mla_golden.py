@@ -22,8 +22,13 @@ def main():
     spec = importlib.util.spec_from_file_location("ref_decode_attention", REF)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    cases = [("a", 2, 16, 1, 200, 64, 7), ("b", 3, 32, 1, 131, 16, 11), ("c", 1, 8, 1, 64, 64, 3)]
+    # a-c: kv groups of <= 64 heads (mla_decode_kernel); d-f: groups of 128 heads -- the kernel BASELINE C4 runs
+    # (mla_decode_wide_kernel): C4's own head layout (128 q heads on one latent head), two kv heads of 128, a short ragged batch
+    cases = [("a", 2, 16, 1, 200, 64, 7), ("b", 3, 32, 1, 131, 16, 11), ("c", 1, 8, 1, 64, 64, 3),
+             ("d", 2, 128, 1, 300, 64, 13), ("e", 1, 256, 2, 130, 64, 17), ("f", 3, 128, 1, 77, 16, 19)]
     for name, B, Hq, Hkv, S, page, seed in cases:
+        if os.path.exists(os.path.join(OUT, f"mla_ref_fp16_{name}.npz")) and "--all" not in sys.argv:
+            continue
         torch.manual_seed(seed)
         max_pages = (S + page - 1) // page
         nblocks = B * max_pages + 2

@@ -365,6 +365,125 @@ def _gpu_fused_moe(rank, world, port, cfg):
 
 
 # ----------------------------------------------------------------------------------------------
+# GPU: BASELINE C5 at full size (EP = 8, 4096 tok/rank, hidden 7168, 2I = 4096, 32 local experts per rank) through
+# deep_ep.Buffer.fused_deep_moe: the prefill-size exchange branch with peers; a sample of every rank's tokens against the
+# per-token float64 evaluation (tests/fused_f64.py) at the reference bar (test_fused_deep_moe.py:470)
+# ----------------------------------------------------------------------------------------------
+def gpu_fused_c5_worker(rank, world, port, cfg):
+    run_guarded(_gpu_fused_c5, rank, world, port, cfg)
+
+
+def _gpu_fused_c5(rank, world, port, cfg):
+    import faulthandler
+    import deep_ep
+    import fused_f64 as F
+    torch.cuda.set_device(0)
+    W, T, H, I, K, L, samples = cfg
+    E = L * W
+    faulthandler.dump_traceback_later(420, exit=True)
+    group = _init(rank, world, port)
+    cb = T * K * H * 2
+    os.environ["DEEPEP_WINDOW_BYTES"] = str(min(6 << 30, 6 * (cb + (8 << 20)) + (4 << 20)))
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "120000")
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    w13, w2, s13, s2 = F.fused_weights(900 + rank, L, H, I)
+    perm = F.fusion_perm(2 * I)
+    w13_p, s13_p = w13[:, perm, :].contiguous(), s13[:, perm].contiguous()
+    del w13
+    g = torch.Generator(device="cuda").manual_seed(1900 + rank)
+    x = torch.randn((T, H), generator=g, device="cuda").to(torch.bfloat16)
+    idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), K, dim=-1)[1]
+    idx[5, 1] = -1
+    w = torch.rand((T, K), generator=g, device="cuda")
+    with torch.inference_mode():                      # the reference harness runs its ranks under inference_mode (no version counters)
+        for _ in range(2):
+            out, counts = buf.fused_deep_moe(x, idx, w, w13_p, s13_p, w2, s2, T, E)
+    torch.cuda.synchronize()
+    assert out.shape == (T, H) and out.dtype == torch.bfloat16 and bool(torch.isfinite(out.float()).all())
+    # received rows per (local expert, source rank): inclusive cumulative counts == the global histogram
+    hist = torch.zeros((W, E), dtype=torch.long, device="cuda")
+    for s in range(W):
+        gs = torch.Generator(device="cuda").manual_seed(1900 + s)
+        torch.randn((T, H), generator=gs, device="cuda")
+        i_s = torch.topk(torch.rand((T, E), generator=gs, device="cuda"), K, dim=-1)[1]
+        i_s[5, 1] = -1
+        hist[s] = torch.bincount(i_s[i_s >= 0].reshape(-1), minlength=E)
+    mine = hist[:, rank * L:(rank + 1) * L].t().reshape(-1)                    # [L, W] -> (le, src)
+    assert torch.equal(counts.long().reshape(-1), torch.cumsum(mine, 0)), "recv counts differ from the global histogram"
+    dist.barrier()                                    # every rank done with the fused calls before the memory-hungry check
+    del w13_p, s13_p, w2, s2
+    torch.cuda.empty_cache()
+    r = F.sampled_check(out, x, idx, w, lambda rr: F.fused_weights(900 + rr, L, H, I), L, n_samples=samples, seed=rank)
+    assert r["ok"], r
+    faulthandler.cancel_dump_traceback_later()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: the whole API under torch.inference_mode() (the reference harness decorates its rank function with it,
+# tests/python/deepep/test_fused_deep_moe_a5.py:723): inference tensors carry no version counter, every call must still work
+# and give the bytes the same call gives outside inference mode
+# ----------------------------------------------------------------------------------------------
+def gpu_inference_mode_worker(rank, world, port, cfg):
+    run_guarded(_gpu_inference_mode, rank, world, port, cfg)
+
+
+def _gpu_inference_mode(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch
+    torch.cuda.set_device(0)
+    W, T, H, I, K, E = cfg
+    L = E // W
+    group = _init(rank, world, port)
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(512 << 20))
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    xs, idxs, ws = make_inputs(W, T, H, K, E, 0.1, seed=11)
+    rng = np.random.default_rng(3)
+    w13 = rng.integers(-16, 16, (L, 2 * I, H)).astype(np.int8)
+    w2 = rng.integers(-16, 16, (L, I, H)).astype(np.int8)          # reference logical shape [L, I, H]: goes through the weight cache
+    s13 = (rng.random((L, 2 * I)) * 4e-4 + 1.5e-3).astype(np.float32)
+    s2 = (rng.random((L, H)) * 4e-4 + 1.5e-3).astype(np.float32)
+
+    def run():
+        x = bits_to_torch(xs[rank]).cuda()
+        ti = torch.from_numpy(idxs[rank]).cuda()
+        tw = torch.from_numpy(np.abs(ws[rank])).cuda()
+        res = []
+        for _ in range(2):      # twice: the second call meets the layout stash / weight cache entries the first one left
+            per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+            (rx, rs), _, _, lst, handle, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                          num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
+                                                          quant_mode="int8")
+            y = (rx.float() * rs[:, None]).to(torch.bfloat16)
+            out, _, _ = buf.combine(y, handle)
+            (lx, ls), cnt, h, _, hook = buf.low_latency_dispatch(x, ti, x.size(0) + W, E, use_fp8=True)
+            hook()
+            n = int(h[1].reshape(-1)[-1])
+            yl = (lx.float() * ls[:, None]).to(torch.bfloat16)
+            outl, _, hook = buf.low_latency_combine(yl, ti, tw, h)
+            hook()
+            fo, _ = buf.fused_deep_moe(x, ti, tw, torch.from_numpy(w13).cuda(), torch.from_numpy(s13).cuda(),
+                                       torch.from_numpy(w2).cuda(), torch.from_numpy(s2).cuda(), x.size(0) + W, E)
+            # rewriting the routing in place between calls must be seen (inference tensors: the stash is never reused)
+            ti = ti.clone()
+            res.append([t.clone() for t in (rx[:sum(lst)], rs[:sum(lst)], out, lx[:n], outl, fo)])
+        return res
+
+    plain = run()
+    with torch.inference_mode():
+        inf = run()
+        assert inf[0][2].is_inference()
+    for a, b in zip(plain, inf):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
 # GPU: a peer that never shows up must surface as a RuntimeError (bounded spins), not a hang
 # ----------------------------------------------------------------------------------------------
 def gpu_timeout_worker(rank, world, port, cfg):

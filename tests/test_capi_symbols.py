@@ -36,12 +36,9 @@ def test_compact_staging_geometry_and_capacity_check():
     """mi_ep_dispatch_index_offset fixes where the expert-sorted index sits in a staging region (same value on every rank:
     it only depends on hidden, mode, top-k and the region size); stage_compact refuses a batch the region cannot hold
     before it launches anything (host-side check, callable without a GPU)."""
-    lib = load("libmi_ep.so")
-    lib.mi_ep_dispatch_index_offset.restype = ctypes.c_size_t
-    lib.mi_ep_dispatch_index_offset.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
-    V, I = ctypes.c_void_p, ctypes.c_int
-    lib.mi_ep_dispatch_stage_compact.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, ctypes.c_size_t, V]
-    lib.mi_ep_dispatch_stage_compact.restype = I
+    import ep_harness
+    lib = ep_harness.lib()          # ONE set of argtypes for the whole suite: the 16-argument form of include/mi_ep.h
+    assert len(lib.mi_ep_dispatch_stage_compact.argtypes) == 16
     H, K, rb = 7168, 8, 7168 + 16
     region = 1 << 30
     off = lib.mi_ep_dispatch_index_offset(H, 1, K, region)
@@ -50,6 +47,8 @@ def test_compact_staging_geometry_and_capacity_check():
     assert cap * (rb + K * 8) <= region < (cap + 1) * (rb + K * 8)          # rows + index entries fill the region
     assert cap > 7 * ((1 << 30) // (K * rb))                                 # almost K times the tokens of one-row-per-(t, k) staging
     dummy = ctypes.c_void_p(0x1000)                                          # never dereferenced: the call fails its checks first
-    MI_EP_EINVAL = lib.mi_ep_dispatch_stage_compact(dummy, dummy, 0, dummy, dummy, cap + 1, K, H, 256, 0, 1, dummy, region, None)
+    # (x, topk_idx, idx_is_i32, send_token_idx_small, send_data_offset, T, K, H, E, rank, quant_mode, region base, region bytes,
+    #  epoch counter, parity stride, stream)
+    MI_EP_EINVAL = lib.mi_ep_dispatch_stage_compact(dummy, dummy, 0, dummy, dummy, cap + 1, K, H, 256, 0, 1, dummy, region, None, region, None)
     assert MI_EP_EINVAL != 0
-    assert lib.mi_ep_dispatch_stage_compact(dummy, dummy, 0, dummy, dummy, 0, K, H, 256, 0, 1, dummy, region, None) == 0   # T = 0: nothing to do
+    assert lib.mi_ep_dispatch_stage_compact(dummy, dummy, 0, dummy, dummy, 0, K, H, 256, 0, 1, dummy, region, None, region, None) == 0   # T = 0

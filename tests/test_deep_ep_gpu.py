@@ -41,9 +41,21 @@ def test_c2_size_eight_processes():
     # 256 x 256 x 64 workgroup tile, the LDS-transposed epilogue and the multi-tile lookup run end to end behind deep_ep.Buffer
     (1, 1024, 7168, 2048, 8, 8, "native"),
     (2, 512, 7168, 2048, 8, 8, "native"),         # same through two processes (windows mapped with hipIpc)
+    # more than 512 tokens per rank: the prefill-size dispatch leg (normal-mode exchange without host sync, worst-case sized
+    # buffers, pooled GEMM tile workers) WITH peers -- the branch BASELINE C5 (4096 tok/rank) takes
+    (2, 640, 512, 128, 4, 8, "native"),
+    (4, 768, 512, 256, 8, 32, "native"),
+    (2, 1024, 1024, 256, 8, 16, "reference"),
+    (4, 600, 512, 128, 4, 16, "ffn"),
 ])
 def test_fused_deep_moe(cfg):
     _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)
+
+
+def test_fused_deep_moe_c5_size_eight_processes():
+    """BASELINE C5 through deep_ep.Buffer: eight processes with hipIpc-mapped windows, 4096 tokens per rank, DeepSeek-V3 expert
+    shapes, 32 local experts per rank; 256 sampled tokens per rank against the per-token float64 evaluation."""
+    _spawn(mp_workers.gpu_fused_c5_worker, 8, (8, 4096, 7168, 2048, 8, 32, 256))
 
 
 @pytest.mark.parametrize("cfg", [
@@ -55,6 +67,11 @@ def test_low_latency_calls_replay_in_a_captured_graph(cfg):
     """low_latency_dispatch + low_latency_combine + fused_deep_moe captured once in torch.cuda.graph, replayed with fresh inputs,
     bit-exact (fused: reference tolerance) against the oracle every time: the call epoch / ping-pong half are device-resident."""
     _spawn(mp_workers.gpu_graph_worker, cfg[0], cfg)
+
+
+@pytest.mark.parametrize("cfg", [(1, 40, 512, 128, 4, 8), (2, 33, 512, 128, 4, 8)])      # W, T, H, I, K, E
+def test_every_call_works_under_inference_mode(cfg):
+    _spawn(mp_workers.gpu_inference_mode_worker, cfg[0], cfg)
 
 
 def test_missing_peer_raises_instead_of_hanging():

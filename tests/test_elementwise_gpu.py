@@ -176,6 +176,41 @@ def test_mla_preprocess(N, Hq, hidden):
     assert not kv.view(-1, 512).cpu()[mask].any()
 
 
+def test_mla_preprocess_under_inference_mode_and_foreign_wuk_dtype():
+    """Inference tensors carry no version counter (at::Tensor::_version() throws): the wuk re-layout cache must not ask for one.
+    And a wuk stored in another dtype than the activations is converted inside the cache's make step, keyed on the caller's tensor:
+    same bytes as the plain call, twice (second call = cache hit)."""
+    dt = torch.bfloat16
+    N, Hq, hidden, block_size, nblocks = 17, 16, 2048, 128, 4
+    z = _mla_pre_inputs(N, Hq, hidden, dt)
+    slots = torch.randperm(nblocks * block_size)[:N].to(torch.int32)
+
+    def run(wuk_dtype):
+        d = lambda t: t.cuda()
+        kv = torch.zeros((nblocks, block_size, 1, 512), dtype=dt, device="cuda")
+        kr = torch.zeros((nblocks, block_size, 1, 64), dtype=dt, device="cuda")
+        q0 = torch.empty((N, Hq, 512), dtype=dt, device="cuda")
+        q1 = torch.empty((N, Hq, 64), dtype=dt, device="cuda")
+        wuk = d(z["wuk"]).to(wuk_dtype)
+        outs = []
+        for _ in range(2):
+            torch.ops.npu.mla_preprocess(d(z["hid"]), d(z["gamma0"]), d(z["beta0"]), d(z["wdqkv"]), d(z["descale0"]), d(z["gamma1"]),
+                                         d(z["beta1"]), d(z["wuq"]), d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), wuk,
+                                         kv, kr, d(slots), d(z["qs0"]), d(z["qo0"]), d(z["bias0"]), d(z["qs1"]), d(z["qo1"]), d(z["bias1"]),
+                                         cache_mode="krope_ctkv", quant_mode="per_tensor_quant_asymm", q_out0=q0, kv_cache_out0=kv,
+                                         q_out1=q1, kv_cache_out1=kr)
+            outs.append([t.clone() for t in (q0, q1, kv, kr)])
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
+        return outs[0]
+
+    plain = run(dt)
+    with torch.inference_mode():
+        inf = run(dt)
+        inf32 = run(torch.float32)              # bf16 values held in fp32: converts back exactly
+    for a, b, c in zip(plain, inf, inf32):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def _mla_pre_exact_token(z, eps=1e-6):
     """float64 evaluation of the per-token network with the kernel's rounding / quantisation points kept."""
     dt = z["hid"].dtype

@@ -90,10 +90,10 @@ def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits):
     if dtype == torch.float16:
         assert torch.allclose(got.float(), want.float(), **tol(dtype)), (got.float() - want.float()).abs().max()
         return
-    # bf16: P is rounded to 8 bits before P.V (reference decode_attention.py:152), which for these SHORT sequences puts
-    # ~2.5e-3 of rounding noise on the oracle itself; kernel and oracle round P against different (equally valid)
-    # softmax references, so they are compared through the exact fp64 result: the kernel must be as accurate as the
-    # oracle, and within the reference test's own tolerance (rtol = atol = 1e-2, test_decode_attention.py:233) of it.
+    # bf16: P is rounded to 8 bits before P.V (reference decode_attention.py:152); kernel and oracle round P against different
+    # (equally valid) softmax references, so neither is the other's bit pattern.  Both are measured against the exact fp64 result,
+    # in the form the full-C4 test uses: every element within 8e-3 of its head's output scale (half a bf16 ulp of the row scale is
+    # 2^-9 = 2e-3, the P rounding comes on top), cosine distance < 1e-5 -- and the kernel must be as accurate as the oracle.
     exact = torch.zeros_like(want, dtype=torch.float64)
     group = Hq // Hkv
     for b in range(B):
@@ -103,10 +103,14 @@ def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits):
             K = torch.cat([kn[idx, :, kvh].reshape(-1, 512), kr[idx, :, kvh].reshape(-1, 64)], 1)[:L].double()
             hs = slice(kvh * group, (kvh + 1) * group)
             exact[b, hs] = torch.softmax((q[b, hs].double() @ K.T) * sm, -1) @ K[:, :512]
-    err_k = (got.double() - exact).abs().max().item()
-    err_o = (want.double() - exact).abs().max().item()
-    assert err_k <= 1.5 * err_o + 1e-3, (err_k, err_o)
-    assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-2)
+    scale = exact.abs().amax(dim=-1, keepdim=True).clamp_min(1e-6)                   # per (sequence, head)
+    rel_k = ((got.double() - exact).abs() / scale).max().item()
+    rel_o = ((want.double() - exact).abs() / scale).max().item()
+    g64 = got.double()
+    cos = 1.0 - (2 * (g64 * exact).sum() / (g64.pow(2).sum() + exact.pow(2).sum())).item()
+    assert rel_k < 8e-3, (rel_k, rel_o)
+    assert cos < 1e-5, cos
+    assert rel_k <= 1.5 * rel_o + 1e-3, (rel_k, rel_o)
 
 
 def test_full_size_c4_vs_fp32():

@@ -271,3 +271,37 @@ def test_fused_deep_moe_oracle_against_independent_float64_pipeline():
         # bf16 outputs of each expert + fp32 accumulation vs float64: relative error well below one bf16 ulp of the sum of terms
         assert np.abs(g - want).max() <= 2.0 ** -7 * np.abs(want).max()
         assert O.calc_diff(g, want) < 1e-5
+
+
+def test_sampled_float64_checker_agrees_with_the_staged_oracle():
+    """tests/fused_f64.py (the torch-float64 per-token evaluation the C5-size GPU test and bench.py validate against) on CPU against
+    the staged oracle on a case the oracle can run: every token, several owner ranks, a -1 selection; and its weight generator's
+    fusion-tile permutation == the oracle's."""
+    import torch
+    import fused_f64 as F
+    from oracle.bf16 import bf16_bits_to_f32, torch_to_bits
+    W, T, H, I, K, L = 3, 21, 256, 128, 4, 2
+    E = W * L
+    weights = [F.fused_weights(40 + r, L, H, I, device="cpu") for r in range(W)]
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn((T, H), generator=g).to(torch.bfloat16) for _ in range(W)]
+    idxs = [torch.topk(torch.rand((T, E), generator=g), K, dim=-1)[1] for _ in range(W)]
+    idxs[1][2, 3] = -1
+    ws = [torch.rand((T, K), generator=g) for _ in range(W)]
+    got = O.fused_deep_moe([torch_to_bits(x) for x in xs], [i.numpy() for i in idxs], [w.numpy() for w in ws],
+                           [w_[0].numpy() for w_ in weights], [w_[2].numpy() for w_ in weights],
+                           [w_[1].numpy() for w_ in weights], [w_[3].numpy() for w_ in weights], T, E)
+    for r in range(W):
+        want = F.sampled_reference(xs[r], idxs[r], ws[r], lambda rr: weights[rr], L, torch.arange(T))
+        g_ = torch.from_numpy(bf16_bits_to_f32(got[r]))
+        calc, avg = F.diffs(g_, want)
+        # same rounding points on both sides: most tokens agree bit for bit; the rest is one flipped int8 step of the requantisation
+        # (exp() of NumPy and torch differ in the last place), which at this tiny I = 128 and |y| < 1e-2 weighs far more than at C5 size
+        assert float((g_.double() == want).all(dim=1).float().mean()) >= 0.8
+        assert calc < 1e-5 and avg < 1e-3, (calc, avg)
+        # and it is sensitive: a wrong expert for one selection of every token is far outside the bar
+        wrong = idxs[r].clone()
+        wrong[:, 0] = (wrong[:, 0] + 1) % E
+        calc_w, avg_w = F.diffs(torch.from_numpy(bf16_bits_to_f32(got[r])), F.sampled_reference(xs[r], wrong, ws[r], lambda rr: weights[rr], L, torch.arange(T)))
+        assert avg_w > 10 * 4e-4
+    assert np.array_equal(F.fusion_perm(512, device="cpu").numpy(), O.permute_fusion_cols(512))
