@@ -372,11 +372,13 @@ def fused_moe_section(buf, rank, world, T=4096):
     """BASELINE C5: fused_deep_moe, DeepSeek-V3 expert shapes (hidden 7168, 2I = 4096), 32 local experts per rank, T tokens per rank."""
     L = 32
     E = L * world
-    g = torch.Generator(device="cuda").manual_seed(99 + rank)
-    w13 = torch.randint(-16, 16, (L, 2 * INTER, HIDDEN), generator=g, device="cuda", dtype=torch.int32).to(torch.int8)
-    w2 = torch.randint(-16, 16, (L, HIDDEN, INTER), generator=g, device="cuda", dtype=torch.int32).to(torch.int8)
-    s13 = torch.rand((L, 2 * INTER), generator=g, device="cuda") * 4e-4 + 1.5e-3
-    s2 = torch.rand((L, HIDDEN), generator=g, device="cuda") * 4e-4 + 1.5e-3
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fused_f64 as F                      # validation only: per-token evaluation of sampled tokens (tests/fused_f64.py)
+    w13_o, w2, s13_o, s2 = F.fused_weights(99 + rank, L, HIDDEN, INTER)          # original column order (gate rows, then up rows)
+    perm = F.fusion_perm(2 * INTER)
+    w13, s13 = w13_o[:, perm, :].contiguous(), s13_o[:, perm].contiguous()       # the fusion-tile order the op consumes
+    del w13_o, s13_o
+    g = torch.Generator(device="cuda").manual_seed(199 + rank)
     x = torch.randn((T, HIDDEN), generator=g, device="cuda").to(torch.bfloat16)
     idx = torch.topk(torch.rand((T, E), generator=g, device="cuda"), TOPK, dim=-1)[1]
     w = torch.rand((T, TOPK), generator=g, device="cuda")
@@ -386,7 +388,15 @@ def fused_moe_section(buf, rank, world, T=4096):
     def first():
         out, _ = f()
         torch.cuda.synchronize()
+        st["out"] = out.clone()
         return {"finite": 1.0 if bool(torch.isfinite(out.float()).all()) else 0.0}
+
+    def validate():
+        # 256 sampled tokens of this rank against the per-token evaluation with exact integer products, at the reference test's bar
+        # (tests/python/deepep/test_fused_deep_moe.py:470: avg relative diff < 4e-4).  Runs after the timed phases: it regenerates
+        # every owner rank's weights from their seeds (1.4 GB at a time).
+        r = F.sampled_check(st.pop("out"), x, idx, w, lambda rr: F.fused_weights(99 + rr, L, HIDDEN, INTER), L, n_samples=256, seed=rank)
+        return {"val_ok": 1.0 if r["ok"] else 0.0, "val_avg": r["avg_diff"], "val_calc": r["calc_diff"]}
 
     def profile():
         buf.begin_profile(0, 10, "")
@@ -407,11 +417,11 @@ def fused_moe_section(buf, rank, world, T=4096):
         r = ev_stats(lambda: torch._int_mm(a, wd), n=5, warm=3)
         return {"vendor": 2.0 * T * TOPK * HIDDEN * 2 * INTER / (r["p50_us"] * 1e-6) / 1e12}
 
-    res, err = _phases([first, profile, timed, vendor_gemm])
+    res, err = _phases([first, profile, timed, vendor_gemm, validate])
     if err is not None:
         return {"error": err}
-    finite = res.pop("finite")
-    m = max_over_ranks(res)
+    finite = min(res.pop("finite"), res.pop("val_ok"))
+    m = max_over_ranks(res)                      # val_avg / val_calc: the worst rank's
     fin = torch.tensor([finite], device="cuda")
     dist.all_reduce(fin, op=dist.ReduceOp.MIN)
     ops = T * TOPK * (HIDDEN * 2 * INTER + INTER * HIDDEN) * 2          # per rank under balanced routing
@@ -421,7 +431,10 @@ def fused_moe_section(buf, rank, world, T=4096):
             "roofline": {"bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
                          "traffic": None},
             "vendor_dense_int8_gemm_TOPs": m.get("vendor"),      # hipBLASLt dense GEMM of GEMM1's shape on the same GPU (calibration)
-            "kernels_avg_us": st.get("prof", {}), "finite": bool(fin.item() > 0)}
+            "kernels_avg_us": st.get("prof", {}),
+            # every rank: output finite AND 256 sampled tokens within the reference bar of the per-token evaluation (tests/fused_f64.py)
+            "validated": bool(fin.item() > 0), "validation": {"samples_per_rank": 256, "avg_diff_max": m["val_avg"], "calc_diff_max": m["val_calc"],
+                                                              "bar": {"avg_diff": 4e-4, "calc_diff": 1e-5}}}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -462,7 +462,13 @@ extern "C" size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits
     return partial_bytes(batch, q_heads, num_splits) + (size_t)batch * q_heads * sizeof(uint32_t);   // q_heads >= kv_heads
 }
 
-static bool use_wide(int group) { return group > kHeadsPerBlock && MLA_WAVES == 4; }
+static bool use_wide(int group)
+{
+    // MI_MLA_WIDE=0: groups of more than 64 heads also run the 64-head kernel, as ceil(group / 64) sibling workgroups per sequence that
+    // share an XCD (A/B switch; DESIGN section 4.1 has the measurement)
+    static const bool allow = !(getenv("MI_MLA_WIDE") && atoi(getenv("MI_MLA_WIDE")) == 0);
+    return allow && group > kHeadsPerBlock && MLA_WAVES == 4;
+}
 
 extern "C" int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
 {

@@ -34,6 +34,14 @@ def fusion_perm(n, tile=128, device="cuda"):
     return (h * (n // 2) + j * half + i).reshape(-1)
 
 
+def _div32(a, b):
+    """Correctly rounded fp32 quotient.  torch's fp32 division on the GPU is NOT (measured on MI355X: 127.0f / amax one ulp off in
+    ~10 % of the rows, which flips first-quantisation steps of bf16 inputs); the quotient is formed in float64 and rounded once."""
+    a = a.double() if torch.is_tensor(a) else a
+    b = b.double() if torch.is_tensor(b) else b
+    return (a / b).float()
+
+
 @torch.no_grad()
 def sampled_reference(x, idx, w, weights_of, L, sel):
     """Per-token evaluation (exact integer products, fp32 epilogues) of the tokens `sel` (1-D long tensor) of this rank.  weights_of(r) -> (w13, w2, s13, s2) of rank r
@@ -43,9 +51,9 @@ def sampled_reference(x, idx, w, weights_of, L, sel):
     E_sel = idx[sel].long()
     # first quantisation point, fp32 as the kernel has it (moe_distribute_dispatch_v2.h:1006-1033): s = 127 / max|x|, q = rint(x * s)
     amax = xs.abs().amax(dim=1, keepdim=True)
-    s = torch.where(amax > 0, 127.0 / amax, torch.zeros_like(amax))
+    s = torch.where(amax > 0, _div32(127.0, amax), torch.zeros_like(amax))
     q = torch.round(xs * s).double()                                                       # torch.round: half to even
-    sc = torch.where(amax > 0, 1.0 / s, torch.zeros_like(amax))                            # fp32 token scale
+    sc = torch.where(amax > 0, _div32(1.0, s), torch.zeros_like(amax))                     # fp32 token scale
     Y = torch.zeros((S, E_sel.shape[1], H), dtype=torch.float32, device=x.device)      # bf16-rounded expert outputs per selection
     owners = torch.div(E_sel, L, rounding_mode="floor")
     for r in sorted(set(owners[E_sel >= 0].tolist())):
@@ -60,12 +68,12 @@ def sampled_reference(x, idx, w, weights_of, L, sel):
             c = (q[rows] @ w13[le].double().t()).float()
             d = (c * s13[le].float()[None, :]) * sc[rows]
             gate, up = d[:, :I], d[:, I:]
-            v = up * (gate / (1 + torch.exp(-gate)))
+            v = up * _div32(gate, 1 + torch.exp(-gate))
             vmax = v.abs().amax(dim=1, keepdim=True)
-            inv = torch.where(vmax > 0, 1.0 / vmax, torch.zeros_like(vmax))
+            inv = torch.where(vmax > 0, _div32(1.0, vmax), torch.zeros_like(vmax))
             q2 = torch.round((v * 127.0) * inv).double()
             c2 = (q2 @ w2[le].double().t()).float()
-            y = (c2 * s2[le].float()[None, :]) * (vmax / 127.0)
+            y = (c2 * s2[le].float()[None, :]) * _div32(vmax, 127.0)
             Y[rows, ks] = y.to(torch.bfloat16).float()       # an expert's output row leaves its GEMM2 as bf16
         del w13, w2, s13, s2
     # the weighted sum as the combine kernel forms it (cam_moe_combine_normal.h:359-400): fp32, separate multiply and add, k ascending

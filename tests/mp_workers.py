@@ -458,14 +458,14 @@ def _gpu_inference_mode(rank, world, port, cfg):
                                                           quant_mode="int8")
             y = (rx.float() * rs[:, None]).to(torch.bfloat16)
             out, _, _ = buf.combine(y, handle)
-            (lx, ls), cnt, h, _, hook = buf.low_latency_dispatch(x, ti, x.size(0) + W, E, use_fp8=True)
+            (lx, ls), cnt, h, _, hook = buf.low_latency_dispatch(x, ti, T + W, E, use_fp8=True)      # the same bound on every rank
             hook()
             n = int(h[1].reshape(-1)[-1])
             yl = (lx.float() * ls[:, None]).to(torch.bfloat16)
             outl, _, hook = buf.low_latency_combine(yl, ti, tw, h)
             hook()
             fo, _ = buf.fused_deep_moe(x, ti, tw, torch.from_numpy(w13).cuda(), torch.from_numpy(s13).cuda(),
-                                       torch.from_numpy(w2).cuda(), torch.from_numpy(s2).cuda(), x.size(0) + W, E)
+                                       torch.from_numpy(w2).cuda(), torch.from_numpy(s2).cuda(), T + W, E)
             # rewriting the routing in place between calls must be seen (inference tensors: the stash is never reused)
             ti = ti.clone()
             res.append([t.clone() for t in (rx[:sum(lst)], rs[:sum(lst)], out, lx[:n], outl, fo)])
@@ -475,9 +475,19 @@ def _gpu_inference_mode(rank, world, port, cfg):
     with torch.inference_mode():
         inf = run()
         assert inf[0][2].is_inference()
-    for a, b in zip(plain, inf):
-        for u, v in zip(a, b):
-            assert torch.equal(u, v)
+    # and the low-latency combine of both against the oracle (same inputs every iteration)
+    from oracle.bf16 import torch_to_bits
+    MT = T + W
+    llw = O.low_latency_dispatch(xs, idxs, MT, E, True)
+    yls = [O.per_token_cast_back(w_.packed_recv_x, w_.packed_recv_x_scales) for w_ in llw]
+    llc = O.combine(yls, [w_.src_info for w_ in llw], [w_.total for w_ in llw], idxs, [np.abs(w_) for w_ in ws], E)[rank]
+    for tag, runs in (("plain", plain), ("inference", inf)):
+        for it, a in enumerate(runs):
+            assert np.array_equal(torch_to_bits(a[4]), llc), (tag, it, "low-latency combine differs from the oracle")
+    names = ("recv_x", "recv_x_scales", "combined", "ll_recv_x", "ll_combined", "fused")
+    for it, (a, b) in enumerate(zip(plain, inf)):
+        for name, u, v in zip(names, a, b):
+            assert u.shape == v.shape and torch.equal(u, v), (it, name, u.shape, v.shape, int((u != v).sum()) if u.shape == v.shape else -1)
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
