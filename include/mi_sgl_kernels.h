@@ -49,6 +49,10 @@ const char *mi_sgl_kernels_version(void);
  * num_splits > 1 or q_heads / kv_heads > 64.  Pass num_splits = 0 to let the library choose (mi_mla_decode_num_splits). */
 size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
 int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
+/* kv groups of more than 64 heads have two kernel forms: 4 waves per workgroup (one per SIMD, the default) and 8 (two per SIMD).
+ * waves = 4 / 8 forces one for the calls that follow, 0 returns to the default (or MI_MLA_WIDE8).  Process-wide, not thread-safe:
+ * a test / tuning knob, results do not depend on it beyond fp32 summation order. */
+int mi_mla_decode_select_wide(int waves);
 int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
                   const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
                   int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk, int64_t kn_stride_row,

@@ -485,6 +485,14 @@ extern "C" int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, in
     return s < 1 ? 1 : s;
 }
 
+static int g_wide_variant = 0;      // 0 = environment / default, 4 or 8 = forced (tests run both forms in one process)
+extern "C" int mi_mla_decode_select_wide(int waves)
+{
+    if (waves != 0 && waves != 4 && waves != 8) return MI_SGL_EINVAL;
+    g_wide_variant = waves;
+    return MI_SGL_OK;
+}
+
 extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
                              const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
                              int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk,
@@ -524,7 +532,12 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     // in-kernel merge is correct (MI_MLA_INLINE_MERGE=2 enables it) but measured 202 us against 195 us for the separate
     // merge launch at C4: the agent-scope release / acquire each pair needs costs an L2 write-back and an L2 invalidate.
     static const int inline_splits = getenv("MI_MLA_INLINE_MERGE") ? atoi(getenv("MI_MLA_INLINE_MERGE")) : 1;
-    p.inline_merge = wide && num_splits <= inline_splits && num_splits <= 2;
+    // kv groups of more than 64 heads: the four-wave wide kernel (one wave per SIMD; default) or the eight-wave one (two per SIMD;
+    // MI_MLA_WIDE8=1 or mi_mla_decode_select_wide(8)) -- same results to the bit pattern of the split partials' sum order, measured
+    // within 1-2 % of each other at BASELINE C4
+    static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) ? 8 : 4) : 4;
+    const bool wide8 = (g_wide_variant ? g_wide_variant : wide_env) == 8;
+    p.inline_merge = wide && (wide8 ? num_splits == 1 : (num_splits <= inline_splits && num_splits <= 2));
     p.batch = batch, p.q_heads = q_heads, p.kv_heads = kv_heads, p.group = q_heads / kv_heads, p.page_size = page_size;
     p.bt_stride = bt_stride, p.num_splits = num_splits;
     p.q_sb = q_stride_b, p.q_sh = q_stride_h, p.kn_sblk = kn_stride_blk, p.kn_srow = kn_stride_row, p.kn_sh = kn_stride_h;
@@ -540,7 +553,8 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
         attr_set = true;
     }
     if (wide) {
-        launch_mla_wide(p, dtype, units, st);
+        if (wide8) launch_mla_wide8(p, dtype, units, st);
+        else launch_mla_wide(p, dtype, units, st);
         p.fix_only = 1;                                // the merge kernel also serves as the slow path for flagged sequences
     } else {
         const int head_blocks = (p.group + kHeadsPerBlock - 1) / kHeadsPerBlock;

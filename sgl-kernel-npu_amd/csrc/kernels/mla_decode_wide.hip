@@ -162,21 +162,37 @@ __device__ __forceinline__ TileRows wide_rows(const WideCtx &c, int tile)
     return r;
 }
 
-// piece idx 0..7: nope row wave + 4 idx (1 KiB); idx 8: rope rows 8 wave .. +8 (8 x 128 B); `slot` = LDS byte address
-__device__ __forceinline__ void wide_issue_piece(const WideCtx &c, const TileRows &rows, uint32_t slot, int idx)
+// Source addresses of this wave's nine DMA pieces of a tile, formed once at the top of the tile (MI_MLAW_PIECES: the eight K-row
+// addresses are wave-uniform SGPR pairs, the rope piece keeps a per-lane pointer) instead of two v_readlane + a 64-bit add per piece --
+// and, for the rope piece, two ds_bpermute round trips -- in the middle of the QK^T MFMA chain.
+struct WidePieces {
+    const uint16_t *nope[8];
+    const uint16_t *rope;
+};
+__device__ __forceinline__ WidePieces wide_pieces(const WideCtx &c, const TileRows &rows)
 {
-    if (idx < 8) {
+    WidePieces q;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
         const int i = c.wave + 4 * idx;
         const int lo = __builtin_amdgcn_readlane((int)(rows.nope & 0xFFFFFFFFll), i);
         const int hi = __builtin_amdgcn_readlane((int)(rows.nope >> 32), i);
-        const uint16_t *src = c.kn_base + (((int64_t)hi << 32) | (uint32_t)lo);
+        q.nope[idx] = c.kn_base + (((int64_t)hi << 32) | (uint32_t)lo);
+    }
+    const int key = c.wave * 8 + (c.lane >> 3);
+    const int chunk = (c.lane & 7) ^ (key & 7);
+    q.rope = c.kr_base + lane_i64(rows.rope, key) + chunk * 8;
+    return q;
+}
+// piece idx 0..7: nope row wave + 4 idx (1 KiB); idx 8: rope rows 8 wave .. +8 (8 x 128 B); `slot` = LDS byte address
+__device__ __forceinline__ void wide_issue_piece(const WideCtx &c, const WidePieces &q, uint32_t slot, int idx)
+{
+    if (idx < 8) {
+        const int i = c.wave + 4 * idx;
         const int sw = (i >> 3) & 1;                       // rows 8..15, 24..31: 16-B chunk pairs swapped
-        dma16_sbase(slot + (uint32_t)(i * kNopeStride), src, (uint32_t)((c.lane ^ sw) * 16));
+        dma16_sbase(slot + (uint32_t)(i * kNopeStride), q.nope[idx], (uint32_t)((c.lane ^ sw) * 16));
     } else {
-        const int key = c.wave * 8 + (c.lane >> 3);
-        const int chunk = (c.lane & 7) ^ (key & 7);
-        const uint16_t *src = c.kr_base + lane_i64(rows.rope, key) + chunk * 8;
-        dma16_vaddr(slot + (uint32_t)(kT2 * kNopeStride + c.wave * 8 * kRopeStride), src);
+        dma16_vaddr(slot + (uint32_t)(kT2 * kNopeStride + c.wave * 8 * kRopeStride), q.rope);
     }
 }
 
@@ -246,13 +262,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ids), D(x + kLead) (9 pieces) = 10 vector-memory operations; the wait at the top of tile x leaves the youngest 10 in
     // flight, i.e. this wave's pieces of tile x and the block ids of tile x + kLead have landed.  After the barrier tile x
     // is complete in LDS and the slot of tile x-2 is free for tile x+2.
-    auto tile_top = [&](int t) -> TileRows {
+    auto tile_top = [&](int t) -> WidePieces {
 #ifndef MLAW_NO_PIECES
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 #endif
         __syncthreads();
         wide_issue_rows(cx, t + kLead + 2);
-        return wide_rows(cx, t + kLead);
+        return wide_pieces(cx, wide_rows(cx, t + kLead));
     };
     // prologue in steady-state issue order: ... D(t) | R(t + kLead) D(t+1) | ...
     auto prologue = [&]() {
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int d = 0; d < kLead; ++d) {
             if (d + 2 >= kLead) wide_issue_rows(cx, t_begin + d + 2);      // R(x + kLead + 2) of the virtual iteration x = t_begin + d - kLead
-            const TileRows r = wide_rows(cx, t_begin + d);
+            const WidePieces r = wide_pieces(cx, wide_rows(cx, t_begin + d));
 #pragma unroll
             for (int i = 0; i < 9; ++i) wide_issue_piece(cx, r, cx.lds_base + (uint32_t)(((t_begin + d) & (kSlots - 1)) * kSlotBytes), i);
         }
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto no_embed = [](int) {};
     auto fill_only = [&](int t) {
-        const TileRows rows3 = tile_top(t);
+        const WidePieces rows3 = tile_top(t);
         const uint32_t nslot = cx.lds_base + (uint32_t)(((t + kLead) & (kSlots - 1)) * kSlotBytes);
 #pragma unroll
         for (int i = 0; i < 9; ++i) wide_issue_piece(cx, rows3, nslot, i);
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- S^T[key, head] = K . Q^T : 36 k-steps of 16 dims, operand ring kAhead deep, one DMA piece per 4 k-steps;
     // returns the tile maximum per head in the scaled log2 domain
-    auto qk = [&](int t, const TileRows &rows3, f32x16 &s) -> float {
+    auto qk = [&](int t, const WidePieces &rows3, f32x16 &s) -> float {
         const uint8_t *buf = lds + (t & (kSlots - 1)) * kSlotBytes;
         const uint32_t nslot = cx.lds_base + (uint32_t)(((t + kLead) & (kSlots - 1)) * kSlotBytes);
         // (2 ks + kg) ^ sw == 2 ks + (kg ^ sw): the swizzle folds into the lane base, k-steps are immediate offsets
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile("" : "+v"(pk[i]), "+v"(psum));
         };
         {
-            const TileRows rows = tile_top(t_begin);
+            const WidePieces rows = tile_top(t_begin);
             const float tmax = qk(t_begin, rows, s);
             m_run = tmax;
             nm = (m_run == -INFINITY) ? 0.f : -m_run;
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef MLAW_TIMING
             c0 = __builtin_amdgcn_s_memtime();
 #endif
-            const TileRows rows = tile_top(t + 1);
+            const WidePieces rows = tile_top(t + 1);
             MLAW_TICK(0)
             publish(psum, pk);
             psum = 0.f;

@@ -48,14 +48,24 @@ def run_mla(q, kn, kr, lens, bt, sm_scale, num_splits=0):
     return out
 
 
+@pytest.fixture(params=[4, 8], ids=["wide4", "wide8"])
+def wide_variant(request):
+    """Both forms of the > 64-heads-per-group kernel (mla_decode_wide.hip, mla_decode_wide8.hip) for the cases that reach them."""
+    assert lib().mi_mla_decode_select_wide(request.param) == 0
+    yield request.param
+    lib().mi_mla_decode_select_wide(0)
+
+
 def tol(dtype):
     return dict(atol=1e-3, rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -10)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mla_ref_fp16_*.npz"))))
 @pytest.mark.parametrize("splits", [1, 3])
-def test_against_reference_kernel_outputs(path, splits):
+def test_against_reference_kernel_outputs(path, splits, wide_variant):
     z = np.load(path)
+    if wide_variant == 8 and z["q"].shape[1] // z["k_nope"].shape[2] <= 64:
+        pytest.skip("64-head kernel: one form")
     t = lambda k: torch.from_numpy(z[k]).cuda()
     got = run_mla(t("q"), t("k_nope"), t("k_rope"), t("kv_seq_lens"), t("block_table"), float(z["sm_scale"]), splits)
     want = torch.from_numpy(z["out"]).cuda()
@@ -75,7 +85,9 @@ CASES = [  # B, Hq, Hkv, S, page, ragged
 @pytest.mark.parametrize("B,Hq,Hkv,S,page,ragged", CASES)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("splits", [0, 1, 2])
-def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits):
+def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits, wide_variant):
+    if wide_variant == 8 and Hq // Hkv <= 64:
+        pytest.skip("64-head kernel: one form")
     torch.manual_seed(2)
     maxp = (S + page - 1) // page
     nb = B * maxp + 3
@@ -113,7 +125,7 @@ def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits):
     assert rel_k <= 1.5 * rel_o + 1e-3, (rel_k, rel_o)
 
 
-def test_full_size_c4_vs_fp32():
+def test_full_size_c4_vs_fp32(wide_variant):
     """BASELINE C4: B=128, 128 q-heads, one latent KV head, D=576, page 64, seqlen 4096 (+ a ragged copy)."""
     torch.manual_seed(0)
     B, Hq, S, page = 128, 128, 4096, 64
@@ -151,7 +163,7 @@ def test_full_size_c4_vs_fp32():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("splits", [1, 2])
-def test_growing_scores_take_the_rescaling_path(dtype, splits):
+def test_growing_scores_take_the_rescaling_path(dtype, splits, wide_variant):
     """128-head groups run a kernel that fixes the softmax reference at the first tile; sequences whose later scores
     outgrow it (here by ~90 nats) are flagged and recomputed by the rescaling kernel.  Mixed batch: one such sequence,
     one ordinary."""

@@ -28,6 +28,9 @@ byts = float(lens.sum().item()) * 576 * 2 + B * Hq * (576 + 512) * 2
 us = sorted(ts)[len(ts) // 2]
 print(f"MI_MLA_WIDE={os.getenv('MI_MLA_WIDE', '1')} splits={splits}: {us:.1f} us  {byts / us / 1e6:.2f} TB/s  frac {byts / us / 1e6 / 8:.3f}", flush=True)
 ''' % HERE
-for wide, splits in (("1", 0), ("0", 1), ("0", 2), ("1", 1), ("0", 4)):
-    env = dict(os.environ, MI_MLA_WIDE=wide)
+variants = [("1", "1", 0), ("1", "0", 0), ("1", "1", 1), ("1", "1", 3), ("1", "1", 4)] if "--wide8" in sys.argv else \
+    [("1", "1", 0), ("0", "1", 1), ("0", "1", 2), ("1", "0", 1), ("0", "1", 4)]
+for wide, wide8, splits in variants:
+    env = dict(os.environ, MI_MLA_WIDE=wide, MI_MLA_WIDE8=wide8)
+    print(f"MI_MLA_WIDE8={wide8}", end=" ", flush=True)
     subprocess.run([sys.executable, "-c", CHILD, str(splits)], env=env)
