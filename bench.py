@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mla", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 (low-latency) and C5 (fused_deep_moe) sections")
+    ap.add_argument("--dry-run-8", action="store_true",
+                    help="plumbing check of the 8-GPU launch on ONE GPU: re-executes itself as 8 ranks that all use cuda:0 (gloo bootstrap, "
+                         "hipIpc windows), full C2 size; the JSON line carries every N > 1 key and \"dry_run_single_device\": true -- NOT a measurement")
     return ap.parse_args()
 
 
@@ -213,6 +216,14 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_traffic_source():
+    """Which committed counter summary `traffic` values come from (they are read from the file, not collected in this run)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return os.path.relpath(files[-1], ROOT) if files else None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baselines (rank 0, N = 1 only): bounded samples of the same workload on the host cores
 # ---------------------------------------------------------------------------------------------------------------------
@@ -300,6 +311,7 @@ def mla_section(args):
         parts = [pmc_traffic(k) for k in r.pop("pmc_kernels", [])]
         if parts and all(v is not None for v in parts):
             r["roofline"]["traffic"] = sum(parts)      # all launches of one decode step
+            r["roofline"]["traffic_source"] = pmc_traffic_source()
         if not args.no_cpu_baseline:
             r["cpu_baseline"] = mla_cpu_baseline()
         return r
@@ -479,6 +491,12 @@ def timed_steps(buf, x, topk_idx, topk_w, y, steps, warmup, profiled):
 
 def main():
     args = parse()
+    if args.dry_run_8 and "RANK" not in os.environ:
+        env = dict(os.environ, BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(29600 + os.getpid() % 300), os.path.abspath(__file__), "--gpus", "8", "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--tokens", str(args.tokens), "--dry-run-8"] + (["--no-extra"] if args.no_extra else [])
+        os.execvpe(cmd[0], cmd, env)
     rank, world = init_dist(args.gpus)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import deep_ep
@@ -541,6 +559,20 @@ def main():
     bytes_per_step = 2 * total_rows * HIDDEN * 2          # dispatch recv + combine send, BF16-equivalent (reference convention)
     value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
 
+    # ---- EP = 8 proxy on whatever this run has: with the own-rank shortcuts off EVERY row takes the path a remote row takes (dispatch:
+    # pull_indexed / stage_push for all rows; combine: every row pushed through the window), which is what 7/8 of the rows of an EP = 8
+    # rank do.  Same results; the kernel times transfer to EP = 8 as HBM-side costs (the xGMI legs come on top).
+    proxy = None
+    if windowed and hasattr(buf.runtime, "set_local_row_paths"):
+        was = list(buf.runtime.get_local_row_paths())
+        buf.runtime.set_local_row_paths(False, False)
+        try:
+            dt_p, _, err_p = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, 2, False)
+            dt_pp, prof_p, err_pp = timed_steps(buf, x, topk_idx, topk_w, y, args.steps, 0, True) if err_p is None else (None, {}, err_p)
+            proxy = {"error": err_p or err_pp} if (err_p or err_pp) else {"ms_per_step": dt_p / args.steps * 1e3, "prof": prof_p}
+        finally:
+            buf.runtime.set_local_row_paths(*was)
+
     # ---- the other BASELINE configs, same process group (every rank takes part)
     extra = {}
     if windowed and not args.no_extra:
@@ -575,8 +607,9 @@ def main():
         per = {k: {"launches": n, "avg_us": ms / n * 1e3} for k, (n, ms) in prof.items() if n}
         bulk = [k for k in per if k in ("dispatch_stage", "dispatch_stage_push", "dispatch_pull", "combine_push", "combine_reduce")]
         dom = max(bulk, key=lambda k: per[k]["avg_us"])
-        n_local = rows_from[rank] if windowed and os.environ.get("MI_EP_COMBINE_LOCAL", "1") != "0" else 0
-        n_local_d = rows_from[rank] if windowed and os.environ.get("MI_EP_DISPATCH_LOCAL", "1") != "0" else 0
+        local_paths = list(buf.runtime.get_local_row_paths()) if hasattr(buf.runtime, "get_local_row_paths") else [True, True]
+        n_local = rows_from[rank] if windowed and local_paths[1] else 0
+        n_local_d = rows_from[rank] if windowed and local_paths[0] else 0
         kb = lambda k: kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv, n_tok_rank, n_local if k.startswith("combine") else n_local_d,
                                     tokens_to[rank] if n_local_d else 0)
         alg = kb(dom)
@@ -584,6 +617,7 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "timing": f"HIP event pairs on the kernels' stream, {args.steps} launches, pass right after the timed region",
                               "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom) if world == 1 else None,
+                              "traffic_source": pmc_traffic_source() if world == 1 else None,
                               "algorithmic_bytes": alg, "avg_launch_us": per[dom]["avg_us"]}
         result["kernels"] = {k: dict(per[k], GBps=kb(k) / (per[k]["avg_us"] * 1e-6) / 1e9) for k in bulk}
         result["kernels"].update({k: per[k] for k in per if k not in bulk})
@@ -612,6 +646,19 @@ def main():
                 xg["combine_frac"] = xg["combine_GBps"] / peak
                 xg["combine_max_link_frac"] = max(comb_link) / t_comb / 1e9 / XGMI_LINK_GBPS
             result["xgmi"] = xg
+    if proxy is not None:
+        if "prof" in proxy:
+            perp = {k: ms / n * 1e3 for k, (n, ms) in proxy.pop("prof").items() if n}
+            kbp = lambda k: kernel_bytes(k, T, TOPK, HIDDEN, n_pairs, n_recv, n_tok_rank, 0, 0)
+            proxy["kernels"] = {k: {"avg_us": perp[k], "GBps": kbp(k) / (perp[k] * 1e-6) / 1e9, "algorithmic_bytes": kbp(k)}
+                                for k in ("dispatch_stage", "dispatch_stage_push", "dispatch_pull", "combine_push", "combine_reduce") if k in perp}
+            proxy["small_launches_us"] = {k: v for k, v in perp.items() if k not in proxy["kernels"]}
+            proxy["value"] = bytes_per_step / (proxy["ms_per_step"] * 1e-3) / 1e9
+            proxy["what"] = ("own-rank shortcuts off (set_local_row_paths(False, False)): every row staged, pulled by index and pushed "
+                             "through the window like a remote row; HBM-side kernel times of an EP = 8 rank, xGMI legs not included")
+        result["ep8_proxy"] = proxy
+    if args.dry_run_8:
+        result["dry_run_single_device"] = True       # every rank ran on cuda:0: plumbing only, not a measurement
     result.update(extra)
     if world == 1 and not args.no_mla:          # before the CPU leg: the GPU clocks sag while the host works alone
         mla = mla_section(args)

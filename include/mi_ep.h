@@ -100,13 +100,19 @@ int mi_ep_signal_wait(uint64_t *const *peer_flags_host, const uint64_t *my_flags
                       int32_t *status, int timeout_ms, void *stream);
 
 /* Start-up self-test of mapped windows (the reference trusts HCCL for this; here the mapping is ours: hipIpc over xGMI).
- * Every rank writes a 4 KiB pattern row into slot `my_rank` of every rank's `peer_rows_host[d]` area (mi_ep_selftest_bytes(W)
- * bytes each), raises flag `epoch`, waits for all peers (bounded), then verifies the W rows it received (remote-write path) and
- * reads its own row back from every peer (remote-read path).  Two launches on `stream`.  status[0] afterwards: 0 = pass,
- * 1 + s = rank s never signalled, 3000 + s = corrupt row from s, 4000 + d = corrupt read-back from d. */
+ * `rounds` rounds on the SAME addresses, a fresh pattern each: every rank writes a 4 KiB pattern row into slot `my_rank` of every
+ * rank's `peer_rows_host[d]` area (mi_ep_selftest_bytes(W) bytes each) with ordinary stores plus one {epoch, value} granule with a
+ * relaxed system-scope store, raises flag `epoch`, waits for all peers (bounded), then -- with ORDINARY cached loads, in a launch of
+ * its own -- verifies the W rows it received (remote-write path), its own row read back from every peer (remote-read path) and the
+ * W granules, and acknowledges; round r + 1 starts writing only when every peer has acknowledged round r, so a cache line kept
+ * from round r that is served stale in round r + 1 fails the test (a single round on fresh addresses cannot show that).
+ * Epochs first_epoch .. first_epoch + rounds - 1 must continue where the previous call on these flag words stopped (start at 1).
+ * Three launches per round on `stream`.  status[0] afterwards: 0 = pass, 1 + s = rank s never signalled, 3000 + s = corrupt row
+ * from s, 4000 + d = corrupt read-back from d, 5000 + s = missing / corrupt granule from s. */
 size_t mi_ep_selftest_bytes(int num_ranks);
-int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host, const uint64_t *my_flags, int num_ranks,
-                   int my_rank, uint64_t epoch, uint32_t tag, int32_t *status, int timeout_ms, void *stream);
+int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host, const uint64_t *my_flags,
+                   uint64_t *const *peer_acks_host, const uint64_t *my_acks, int num_ranks, int my_rank, uint64_t first_epoch,
+                   int rounds, uint32_t tag, int32_t *status, int timeout_ms, void *stream);
 
 /* ---- A2 notify ------------------------------------------------------------------------------
  * Counts all-gather through windows.  Every rank owns `uint64_t notify[W][E+1]` granules

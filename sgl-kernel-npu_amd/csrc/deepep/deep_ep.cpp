@@ -28,7 +28,7 @@ constexpr int64_t kNotifyParityBytes = 1100 << 10;
 constexpr int64_t kOffLLCounts = kOffNotify + 2 * kNotifyParityBytes;   // 2 parities x 2048 u64
 constexpr int64_t kLLCountsParityBytes = 2048 * 8;
 enum Family { kDispatch = 0, kCombine = 1, kLLDispatch = 2 };
-enum FlagGroup { kFlagDispatch = 0, kFlagCombine = 1, kFlagSelfTest = 7 };
+enum FlagGroup { kFlagDispatch = 0, kFlagCombine = 1, kFlagSelfTestAck = 6, kFlagSelfTest = 7 };
 constexpr int kMaxTotalTokens = 131072;            // reference MAX_TOTAL_TOKENS (deep_ep.cpp:37)
 
 hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
@@ -144,6 +144,15 @@ Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t n
     set_dispatch_transport(tr && *tr ? std::string(tr) : std::string(num_ranks > 1 ? "push" : "pull"));
 }
 
+// MI355X only: whether the rows of a rank's OWN tokens bypass the window (dispatch: gathered token by token by pull_local; combine:
+// read in place by the reduce).  Switching both off makes every row take the path a REMOTE row takes -- on one GPU that is the
+// kernel mix of an EP = 8 rank (7/8 of whose rows are remote), which bench.py times as `ep8_proxy`.  Results are identical either way.
+void Buffer::set_local_row_paths(bool dispatch_local, bool combine_local)
+{
+    dispatch_local_rows = dispatch_local;
+    combine_local_rows_enabled = combine_local;
+}
+
 void Buffer::set_dispatch_transport(const std::string &name)
 {
     EP_HOST_ASSERT_S(name == "push" || name == "pull", "DEEPEP_DISPATCH_TRANSPORT must be push or pull, got ", name);
@@ -204,21 +213,27 @@ void Buffer::sync(const std::vector<std::string> &handles, const std::vector<std
     available = true;
 }
 
-// One flag + one 4 KiB row round trip with every peer through the mapped windows (write path and read-back path), with a
-// checksum.  Called by deep_ep.Buffer on every rank right after sync(); a failure (no peer access, stale mapping, stores
-// that never become visible) makes the Python side fall back to the alltoall (RCCL) strategies instead of corrupting data.
+// Two rounds of {flag, 4 KiB row, granule} with every peer through the mapped windows on the SAME addresses (write path, read-back
+// path, 8-byte granule path; checked with ordinary cached loads, so a line cached in round 1 and served stale in round 2 shows
+// up).  Called by deep_ep.Buffer on every rank right after sync(); a failure (no peer access, stale mapping, stores that never
+// become visible) makes the Python side fall back to the alltoall (RCCL) strategies instead of corrupting data.
 bool Buffer::self_test(int64_t test_timeout_ms)
 {
     require_available();
     if (num_ranks == 1) return true;
     hipStream_t st = cur_stream();
-    const uint64_t ep = ++selftest_epoch;
+    constexpr int kRounds = 2;
+    const uint64_t ep = selftest_epoch + 1;
+    selftest_epoch += kRounds;
     auto rows = peer_family_bases(kLLDispatch);        // scratch: the low-latency segment, unused before the first call
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagSelfTest * kFlagGroupSlots * 8));
+    auto ack_peers = peer_ptrs((size_t)(kOffFlags + kFlagSelfTestAck * kFlagGroupSlots * 8));
     EP_HOST_ASSERT(mi_ep_selftest_bytes((int)num_ranks) <= region_bytes);
     MI_EP_CHECK(mi_ep_selftest(rows.data(), (uint64_t *const *)flag_peers.data(),
-                               (const uint64_t *)(window + kOffFlags + kFlagSelfTest * kFlagGroupSlots * 8), (int)num_ranks, (int)rank, ep,
-                               (uint32_t)(0x5E1F0000u + ep), status_dev, (int)test_timeout_ms, st));
+                               (const uint64_t *)(window + kOffFlags + kFlagSelfTest * kFlagGroupSlots * 8),
+                               (uint64_t *const *)ack_peers.data(),
+                               (const uint64_t *)(window + kOffFlags + kFlagSelfTestAck * kFlagGroupSlots * 8), (int)num_ranks, (int)rank, ep,
+                               kRounds, (uint32_t)(0x5E1F0000u + ep), status_dev, (int)test_timeout_ms, st));
     HIP_CHECK(hipStreamSynchronize(st));
     const int32_t code = __atomic_load_n(status_host, __ATOMIC_ACQUIRE);
     if (code != 0) {
@@ -418,7 +433,7 @@ void Buffer::dispatch_pull(const DispatchExchange &ex, int H, int K, int L, int 
     ProfScope ps_(this, "dispatch_pull", st);
     // this rank's own tokens are gathered token by token (their staged row is read once, not once per selection); everybody else's
     // rows row by row.  MI_EP_DISPATCH_LOCAL=0: every row through pull_indexed.
-    static const bool local = !(getenv("MI_EP_DISPATCH_LOCAL") && atoi(getenv("MI_EP_DISPATCH_LOCAL")) == 0);
+    const bool local = dispatch_local_rows;
     if (local && ex.num_tokens > 0)
         MI_EP_CHECK(mi_ep_dispatch_pull_local(ex.src_bases[(size_t)rank], ex.topk_idx.data_ptr(), ex.topk_idx.scalar_type() == at::kInt,
                                               ex.send_token_idx_small.data_ptr<int>(), ex.nt.recv_count.data_ptr<int>(),
@@ -730,8 +745,7 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
 // like everyone else's.
 at::Tensor Buffer::combine_local_rows(const at::Tensor &topk_idx) const
 {
-    static const bool enabled = !(getenv("MI_EP_COMBINE_LOCAL") && atoi(getenv("MI_EP_COMBINE_LOCAL")) == 0);
-    if (!enabled || topk_idx.numel() == 0) return at::Tensor();
+    if (!combine_local_rows_enabled || topk_idx.numel() == 0) return at::Tensor();
     return at::empty({topk_idx.numel()}, at::dtype(at::kInt).device(topk_idx.device()));
 }
 

@@ -40,6 +40,8 @@ public:
     // MI355X: transport of normal-mode dispatch, "push" (remote writes into the receivers' windows) or "pull" (receivers read
     // the senders' windows).  Every rank of the group must select the same one before its next dispatch.
     void set_dispatch_transport(const std::string &name);
+    void set_local_row_paths(bool dispatch_local, bool combine_local);
+    std::vector<bool> get_local_row_paths() const { return {dispatch_local_rows, combine_local_rows_enabled}; }
     std::string get_dispatch_transport() const { return dispatch_transport == kTransportPush ? "push" : "pull"; }
     bool self_test(int64_t test_timeout_ms);     // collective: every rank calls it after sync()
     bool is_available() const { return available; }
@@ -225,6 +227,9 @@ private:
                               const char *reduce_name, hipStream_t st, const at::Tensor &x_local = at::Tensor(),
                               const at::Tensor &local_row = at::Tensor());
     at::Tensor combine_local_rows(const at::Tensor &topk_idx) const;
+    // defaults from MI_EP_DISPATCH_LOCAL / MI_EP_COMBINE_LOCAL (0 = off), see set_local_row_paths()
+    bool dispatch_local_rows = !(getenv("MI_EP_DISPATCH_LOCAL") && atoi(getenv("MI_EP_DISPATCH_LOCAL")) == 0);
+    bool combine_local_rows_enabled = !(getenv("MI_EP_COMBINE_LOCAL") && atoi(getenv("MI_EP_COMBINE_LOCAL")) == 0);
     // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
     std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
                                        const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,

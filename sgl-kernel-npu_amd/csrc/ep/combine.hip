@@ -24,7 +24,7 @@ constexpr int kPushWaves = 4;
 __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     const uint8_t *__restrict__ x, const int32_t *__restrict__ src_idx, const int32_t *__restrict__ total_dev,
     int rows_hint, int row_bytes /*2H*/, size_t slot_stride, int K, int W, PeerPtrs dsts, Parity par, int slot_rows, int my_rank,
-    int32_t *__restrict__ local_row)
+    int32_t *__restrict__ local_row, unsigned deal_stride)
 {
     // never trust the device-side count beyond the rows the caller's tensor holds
     const int total = total_dev ? min(*total_dev, rows_hint) : rows_hint;
@@ -32,9 +32,21 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
     const int n16 = row_bytes / 16;
-    {   // rows dealt to waves round-robin over the whole grid (see pull_body)
+    {   // rows dealt to waves round-robin over the whole grid (see pull_body).  Rows arrive in (local expert, source rank) order, so waves
+        // i, i + 1, ... of the plain deal write to the SAME peer for a whole segment (~R / (L W) rows: 128 at C2) -- four waves of a CU,
+        // and at small batches the whole chip, on one xGMI link at a time.  With W > 1 the deal is therefore scattered: wave step i takes
+        // row (i * deal_stride) mod 2^k (odd stride: a bijection on [0, 2^k), 2^k >= total; the indices >= total are skipped), so that
+        // neighbouring waves sit two segments apart.  Every row is still copied exactly once into its own slot: bit-neutral.
+        unsigned pow2m1 = 0;
+        if (deal_stride > 1) {
+            pow2m1 = (unsigned)max(total, 1) - 1u;
+            pow2m1 |= pow2m1 >> 1, pow2m1 |= pow2m1 >> 2, pow2m1 |= pow2m1 >> 4, pow2m1 |= pow2m1 >> 8, pow2m1 |= pow2m1 >> 16;
+        }
+        const long long limit = deal_stride > 1 ? (long long)pow2m1 + 1 : (long long)total;
 #pragma unroll 1
-        for (long long r = (long long)blockIdx.x * kPushWaves + wave; r < total; r += (long long)gridDim.x * kPushWaves) {
+        for (long long i = (long long)blockIdx.x * kPushWaves + wave; i < limit; i += (long long)gridDim.x * kPushWaves) {
+            const long long r = deal_stride > 1 ? (long long)(((unsigned)i * deal_stride) & pow2m1) : i;
+            if (r >= total) continue;
             const int src = src_idx[r * 3 + 0];
             const int t = src_idx[r * 3 + 1];
             const int k = src_idx[r * 3 + 2];
@@ -246,11 +258,14 @@ extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const i
     long long blocks = ((long long)rows_hint + kPushWaves - 1) / kPushWaves;        // one row per wave until the chip is full
     static const long long cap = getenv("MI_EP_PUSH_BLOCKS") ? atoll(getenv("MI_EP_PUSH_BLOCKS")) : 256 * 8;
     if (blocks > cap) blocks = cap;
+    // MI_EP_PUSH_STRIDE: 1 = rows in order (the W = 1 form), odd > 1 = scattered deal (default 257 at W > 1, see the kernel)
+    static const long long stride_env = getenv("MI_EP_PUSH_STRIDE") ? atoll(getenv("MI_EP_PUSH_STRIDE")) : 0;
+    unsigned deal_stride = stride_env > 0 ? (unsigned)stride_env | 1u : (W > 1 ? 257u : 1u);
     combine_push_kernel<<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
         (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp,
         make_parity(epoch_ctr, 1, parity_stride),
         slot_region_bytes ? (int)std::min<size_t>(slot_region_bytes / mi_ep_combine_row_bytes(H), 0x7FFFFFFF) : 0x7FFFFFFF, my_rank,
-        local_row);
+        local_row, deal_stride);
     return launch_status();
 }
 

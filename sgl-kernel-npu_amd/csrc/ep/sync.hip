@@ -433,25 +433,49 @@ __device__ __forceinline__ uint32_t selftest_word(uint32_t tag, int src, int dst
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
     return h;
 }
-// block d: write this rank's pattern row into rank d's window (slot my_rank) with ordinary 16-byte stores
-__global__ void selftest_post_kernel(PeerPtrs rows, int my_rank, uint32_t tag)
+// Round protocol (two or more rounds on the SAME addresses, a fresh tag each): a line that a rank cached while checking round r and
+// that a peer rewrote in round r + 1 must not be served stale -- the one failure a single round with fresh addresses and
+// cache-bypassing loads cannot show.  All checks therefore use ORDINARY loads (what the bulk kernels use), in a launch of their own.
+//   gate   (round > first): wait until every peer has finished CHECKING the previous round (ack flags), so nobody's rows are
+//          rewritten under a reader
+//   post   block d: this rank's pattern row -> rank d's window, slot my_rank (ordinary 16-byte stores), plus one {epoch, value}
+//          granule (relaxed system-scope store, the notify / low-latency count path)
+//   check  one workgroup: raise "written" on every peer, wait for every peer; verify the rows peers wrote into MY window
+//          (remote-write path: push transports), my row read back from every PEER (remote-read path: pull transport) and the granules;
+//          then raise "checked" on every peer.
+// status[0]: 0 ok, 1 + s timeout on rank s, 3000 + s bad row from s, 4000 + d bad read-back from d, 5000 + s bad granule from s.
+__global__ void selftest_gate_kernel(const uint64_t *__restrict__ my_acks, int W, uint64_t prev_epoch, int32_t *status, uint64_t timeout_ticks)
+{
+    if ((int)threadIdx.x >= W) return;
+    const uint64_t t0 = ticks_100mhz();
+    while (sys_load_u64(my_acks + threadIdx.x) < prev_epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        if (ticks_100mhz() - t0 > timeout_ticks) {
+            report_status(status, 1 + threadIdx.x);
+            break;
+        }
+    }
+}
+__global__ void selftest_post_kernel(PeerPtrs rows, int W, int my_rank, uint32_t tag, uint64_t epoch)
 {
     const int d = blockIdx.x;
     uint32_t *dst = (uint32_t *)((uint8_t *)rows.p[d] + (size_t)my_rank * kSelfTestWords * 4);
     for (int i = threadIdx.x * 4; i < kSelfTestWords; i += blockDim.x * 4)
         *(u32x4 *)(dst + i) = u32x4{selftest_word(tag, my_rank, d, i), selftest_word(tag, my_rank, d, i + 1),
                                     selftest_word(tag, my_rank, d, i + 2), selftest_word(tag, my_rank, d, i + 3)};
+    if (threadIdx.x == 0) {
+        uint64_t *gran = (uint64_t *)((uint8_t *)rows.p[d] + (size_t)W * kSelfTestWords * 4) + my_rank;
+        sys_store_u64_relaxed(gran, (epoch << 32) | selftest_word(tag, my_rank, d, kSelfTestWords));
+    }
 }
-// one workgroup: raise "my rows are written" on every peer, wait for every peer, then check (a) the rows the peers wrote into
-// MY window (remote-write path: push transports) and (b) the row I wrote into every PEER's window read back over the fabric
-// (remote-read path: pull transport).  status[0]: 0 ok, 1 + s timeout on rank s, 3000 + s bad row from s, 4000 + d bad read-back.
-__global__ __launch_bounds__(256) void selftest_check_kernel(PeerPtrs rows, PeerPtrs flags, const uint64_t *__restrict__ my_flags, int W,
-                                                            int my_rank, uint64_t epoch, uint32_t tag, int32_t *status,
+__global__ __launch_bounds__(256) void selftest_check_kernel(PeerPtrs rows, PeerPtrs flags, PeerPtrs acks, const uint64_t *__restrict__ my_flags,
+                                                            int W, int my_rank, uint64_t epoch, uint32_t tag, int32_t *status,
                                                             uint64_t timeout_ticks)
 {
     __shared__ int bad;
     if (threadIdx.x == 0) bad = 0;
-    if (threadIdx.x < W) {
+    __syncthreads();
+    if ((int)threadIdx.x < W) {
         sys_store_u64((uint64_t *)flags.p[threadIdx.x] + my_rank, epoch);
         const uint64_t t0 = ticks_100mhz();
         while (sys_load_u64(my_flags + threadIdx.x) < epoch) {
@@ -470,25 +494,43 @@ __global__ __launch_bounds__(256) void selftest_check_kernel(PeerPtrs rows, Peer
         const uint32_t *mine = (const uint32_t *)((const uint8_t *)rows.p[my_rank] + (size_t)s * kSelfTestWords * 4);
         const uint32_t *theirs = (const uint32_t *)((const uint8_t *)rows.p[s] + (size_t)my_rank * kSelfTestWords * 4);
         for (int i = threadIdx.x; i < kSelfTestWords; i += blockDim.x) {
-            if (__builtin_nontemporal_load(mine + i) != selftest_word(tag, s, my_rank, i)) report_status(status, 3000 + s);
-            if (__builtin_nontemporal_load(theirs + i) != selftest_word(tag, my_rank, s, i)) report_status(status, 4000 + s);
+            if (mine[i] != selftest_word(tag, s, my_rank, i)) report_status(status, 3000 + s);
+            if (theirs[i] != selftest_word(tag, my_rank, s, i)) report_status(status, 4000 + s);
         }
     }
+    if ((int)threadIdx.x < W) {
+        const int s = threadIdx.x;
+        const uint64_t *gran = (const uint64_t *)((const uint8_t *)rows.p[my_rank] + (size_t)W * kSelfTestWords * 4) + s;
+        // the granule travelled as a relaxed store posted BEFORE the peer's "written" flag (a release): it must be there by now
+        const uint64_t g = sys_load_u64(gran);
+        if ((g >> 32) != epoch || (uint32_t)g != selftest_word(tag, s, my_rank, kSelfTestWords)) report_status(status, 5000 + s);
+    }
+    __syncthreads();                                   // every thread's reads are done before anybody may rewrite these rows
+    if ((int)threadIdx.x < W) sys_store_u64((uint64_t *)acks.p[threadIdx.x] + my_rank, epoch);
 }
 }  // namespace mi_ep
 
-extern "C" size_t mi_ep_selftest_bytes(int num_ranks) { return (size_t)num_ranks * mi_ep::kSelfTestWords * 4; }
+extern "C" size_t mi_ep_selftest_bytes(int num_ranks) { return (size_t)num_ranks * (mi_ep::kSelfTestWords * 4 + 8); }
 
-extern "C" int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host, const uint64_t *my_flags, int W, int my_rank,
-                              uint64_t epoch, uint32_t tag, int32_t *status, int timeout_ms, void *stream)
+extern "C" int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host, const uint64_t *my_flags,
+                              uint64_t *const *peer_acks_host, const uint64_t *my_acks, int W, int my_rank, uint64_t first_epoch,
+                              int rounds, uint32_t tag, int32_t *status, int timeout_ms, void *stream)
 {
-    PeerPtrs rp, fp;
-    if (fill_peers(rp, (const void *const *)peer_rows_host, W) || fill_peers(fp, (const void *const *)peer_flags_host, W) || !my_flags ||
-        !status || my_rank < 0 || my_rank >= W || epoch == 0)
+    PeerPtrs rp, fp, ap;
+    if (fill_peers(rp, (const void *const *)peer_rows_host, W) || fill_peers(fp, (const void *const *)peer_flags_host, W) ||
+        fill_peers(ap, (const void *const *)peer_acks_host, W) || !my_flags || !my_acks || !status || my_rank < 0 || my_rank >= W ||
+        first_epoch == 0 || rounds < 1 || rounds > 16)
         return MI_EP_EINVAL;
-    mi_ep::selftest_post_kernel<<<W, 256, 0, (hipStream_t)stream>>>(rp, my_rank, tag);
-    mi_ep::selftest_check_kernel<<<1, 256, 0, (hipStream_t)stream>>>(rp, fp, my_flags, W, my_rank, epoch, tag, status,
-                                                                    ms_to_ticks(timeout_ms));
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t ticks = ms_to_ticks(timeout_ms);
+    for (int r = 0; r < rounds; ++r) {
+        const uint64_t epoch = first_epoch + (uint64_t)r;
+        const uint32_t rtag = tag + (uint32_t)r * 0x01000193u;
+        // the acks of the epoch BEFORE the first one of this call were raised by the previous call's last round (or are 0 = nothing to wait for)
+        if (epoch > 1) mi_ep::selftest_gate_kernel<<<1, 64, 0, st>>>(my_acks, W, epoch - 1, status, ticks);
+        mi_ep::selftest_post_kernel<<<W, 256, 0, st>>>(rp, W, my_rank, rtag, epoch);
+        mi_ep::selftest_check_kernel<<<1, 256, 0, st>>>(rp, fp, ap, my_flags, W, my_rank, epoch, rtag, status, ticks);
+    }
     return launch_status();
 }
 

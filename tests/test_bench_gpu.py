@@ -51,5 +51,32 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["dtype"] == "int8/bf16" and d["vs_baseline"] is None
     assert d["cpu_baseline"]["cores"] >= 1 and "single_core" in d["cpu_baseline"]
     assert d["fused_deep_moe"]["roofline"]["bound"] == "mfma" and d["fused_deep_moe"]["validated"] is True
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    # the number that transfers to EP = 8: every row through the window paths, kernel by kernel
+    px = d["ep8_proxy"]
+    assert px["ms_per_step"] > d["ms_per_step"] and {"dispatch_pull", "combine_push", "combine_reduce"} <= set(px["kernels"])
+    assert px["kernels"]["combine_push"]["algorithmic_bytes"] > 9e8
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_dry_run_eight_ranks_one_gpu():
+    """`bench.py --dry-run-8`: the 8-GPU launch line on ONE GPU at full C2 size (every rank on cuda:0, hipIpc windows): every key a real
+    8-GPU line carries must be there -- both transports, per-leg and per-link xGMI pricing, C3 and C5 sections validated."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-8", "--steps", "2", "--warmup", "1"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["dry_run_single_device"] is True and d["scaling"] == "weak" and d["validated_round_trip"] is True
+    assert d["config"]["strategy"] == "default" and d["config"]["tokens_per_rank"] == 4096
+    assert set(d["transports"]) == {"push", "pull"}
+    xg = d["xgmi"]
+    for k in ("peak_GBps", "link_GBps", "dispatch_bytes", "combine_bytes", "dispatch_max_link_bytes", "combine_max_link_bytes",
+              "dispatch_GBps", "dispatch_frac", "dispatch_max_link_frac", "combine_GBps", "combine_frac", "combine_max_link_frac"):
+        assert k in xg and xg[k] > 0, k
+    assert xg["peak_GBps"] == 7 * 153.0
+    assert d["low_latency"]["validated_round_trip"] is True and d["fused_deep_moe"]["validated"] is True
+    assert "ep8_proxy" in d and "kernels" in d["ep8_proxy"]

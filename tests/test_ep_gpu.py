@@ -315,3 +315,47 @@ def test_kernels_reproduce_committed_fixtures(path):
         assert np.array_equal(ll[r]["packed_recv_count"].cpu().numpy(), z[f"ll_recv_count{r}"])
         n = len(z[f"ll_src_info{r}"]) // 3
         assert np.array_equal(ll[r]["src_info"].cpu().numpy()[:3 * n], z[f"ll_src_info{r}"])
+
+
+# ---- start-up self-test of mapped windows (C-ABI): W simulated ranks, one stream each (a rank's check kernel waits for its peers') ------
+def _selftest_run(W, rounds, first_epoch, state, bad_rank=None, stale_rank=None):
+    import ep_harness as Hh
+    from ctypes import c_int, c_size_t, c_uint32, c_uint64, c_void_p
+    from capi import ptr, ptr_array
+    L_ = Hh.lib()
+    L_.mi_ep_selftest_bytes.restype = c_size_t
+    L_.mi_ep_selftest_bytes.argtypes = [c_int]
+    L_.mi_ep_selftest.restype = c_int
+    L_.mi_ep_selftest.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_uint64, c_int, c_uint32, c_void_p, c_int, c_void_p]
+    if not state:
+        nb = L_.mi_ep_selftest_bytes(W)
+        state.update(rows=[torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(W)],
+                     flags=[torch.zeros(64, dtype=torch.int64, device="cuda") for _ in range(W)],
+                     acks=[torch.zeros(64, dtype=torch.int64, device="cuda") for _ in range(W)],
+                     streams=[torch.cuda.Stream() for _ in range(W)])
+    status = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(W)]
+    torch.cuda.synchronize()
+    rows_p, flags_p, acks_p = ptr_array([t.data_ptr() for t in state["rows"]]), ptr_array([t.data_ptr() for t in state["flags"]]), \
+        ptr_array([t.data_ptr() for t in state["acks"]])
+    for r in range(W):
+        tag = 0x5E1F0000 + first_epoch + (77 if r == bad_rank else 0)
+        rc = L_.mi_ep_selftest(rows_p, flags_p, ptr(state["flags"][r]), acks_p, ptr(state["acks"][r]), W, r, first_epoch, rounds, tag,
+                               ptr(status[r]), 2000, c_void_p(state["streams"][r].cuda_stream))
+        assert rc == 0
+    torch.cuda.synchronize()
+    return [int(s[0]) for s in status]
+
+
+@pytest.mark.parametrize("W", [2])      # in ONE process two simulated ranks get their own hardware queues; more would share one (the runtime maps streams
+def test_window_selftest_rounds_and_failure_codes(W):      # onto 4 queues) and a spinning check kernel would block its peer's post behind it.
+                                                           # W = 4, 8: every multi-process deep_ep.Buffer test runs the self-test at start-up.
+    """mi_ep_selftest: two rounds on the same addresses pass; a second call continues the epochs; a rank that writes a different
+    pattern is reported by every other rank as a corrupt row (3000 + s) and sees corrupt read-backs itself; a rank that never
+    shows up is a bounded timeout (1 + s), not a hang."""
+    state = {}
+    assert _selftest_run(W, 2, 1, state) == [0] * W
+    assert _selftest_run(W, 2, 3, state) == [0] * W
+    codes = _selftest_run(W, 1, 5, state, bad_rank=1)
+    assert all(c != 0 for c in codes)
+    assert all(c in (3001, 5001) for i, c in enumerate(codes) if i != 1), codes
+    assert codes[1] // 1000 in (3, 4, 5), codes

@@ -20,6 +20,32 @@ def short(name):
     return (m.group(2) + (m.group(3) or "")) if m else name[:60]
 
 
+def by_grid(rnd, stats_dir, out_dir):
+    """profiles/r<round>_kernel_stats_by_grid.csv: one row per (kernel, grid size, workgroup size) from the per-dispatch kernel trace --
+    the same kernel runs at several problem sizes inside one bench (C2-size, decode-size, validation launches), and an average over
+    all of them prices nothing.  `frac` of a bench object can be recomputed from this file alone: algorithmic bytes
+    / avg_ns of the row with the largest grid of that kernel."""
+    files = glob.glob(os.path.join(stats_dir, "*kernel_trace.csv"))
+    if not files:
+        return
+    agg = defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        try:
+            grid = tuple(int(r.get(f"Grid_Size_{a}", r.get(f"Grid_Size{a}", 0)) or 0) for a in "XYZ")
+            wg = tuple(int(r.get(f"Workgroup_Size_{a}", r.get(f"Workgroup_Size{a}", 0)) or 0) for a in "XYZ")
+            agg[(short(r["Kernel_Name"]), grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        except (KeyError, ValueError):
+            continue
+    ours = ("stage", "pull", "combine", "layout", "notify", "signal", "mla", "swiglu", "rms", "rope", "ll_", "grouped_gemm", "rowquant",
+            "skinny", "bmm_rope", "pre_", "gqa", "gemm2", "selftest", "add_", "split_")
+    rows = sorted(((k, v) for k, v in agg.items() if k[0].startswith(ours)), key=lambda kv: (kv[0][0], -kv[0][1][0] * max(kv[0][1][1], 1)))
+    with open(os.path.join(out_dir, f"r{rnd}_kernel_stats_by_grid.csv"), "w") as o:
+        o.write("kernel,grid_threads_x,grid_y,grid_z,workgroup_x,calls,avg_ns,p50_ns,min_ns,max_ns\n")
+        for (name, grid, wg), v in rows:
+            v = sorted(v)
+            o.write(f"\"{name}\",{grid[0]},{grid[1]},{grid[2]},{wg[0]},{len(v)},{sum(v) / len(v):.0f},{v[len(v) // 2]},{v[0]},{v[-1]}\n")
+
+
 def main():
     rnd, stats_dir = sys.argv[1], sys.argv[2]
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
@@ -31,6 +57,7 @@ def main():
         for r in rows[:25]:
             o.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},{r['Percentage']},"
                     f"{r['MinNs']},{r['MaxNs']}\n")
+    by_grid(rnd, stats_dir, out_dir)
     if len(sys.argv) >= 5:
         agg = defaultdict(lambda: defaultdict(list))
         for d, cname in ((sys.argv[3], "FETCH_SIZE"), (sys.argv[4], "WRITE_SIZE")):
@@ -60,7 +87,9 @@ def main():
         spec = importlib.util.spec_from_file_location("bench_names", os.path.join(os.path.dirname(out_dir), "bench.py"))
         src = open(spec.origin).read()
         names = re.search(r"PMC_KERNEL_NAMES = (\{.*?\})", src, re.S)
-        wanted = list(eval(names.group(1)).values()) + ["mla_decode_wide_kernel<true>", "mla_merge_kernel<true>"]
+        wanted = list(eval(names.group(1)).values()) + ["mla_merge_kernel<true>"]
+        if not any(k.startswith("mla_decode_wide") for k in out):
+            wanted.append("mla_decode_wide_kernel<true>")
         missing = [k for k in wanted if k not in out]
         if missing:
             print("PMC counters are missing kernels that bench.py prices:", missing, "-- have:", sorted(out), file=sys.stderr)
