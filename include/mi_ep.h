@@ -79,12 +79,15 @@ size_t mi_ep_combine_row_bytes(int hidden);
  *   num_tokens_per_rank [W], num_tokens_per_expert [E], is_token_in_rank [T,W],
  *   send_token_idx_small [T,K]  (rank of the pair among earlier row-major pairs of the same expert; 0 at invalid ids),
  *   send_data_offset [E]        (exclusive prefix of num_tokens_per_expert; reference notify_dispatch.h:185-198).
- * workspace: mi_ep_dispatch_layout_workspace(T,K,E) bytes, contents irrelevant.  idx_is_i32 != 0: topk_idx is int32. */
+ * workspace: mi_ep_dispatch_layout_workspace(T,K,E) bytes, contents irrelevant.  idx_is_i32 != 0: topk_idx is int32.
+ * sync_words: NULL, or two uint32 words in device memory that the CALLER zero-initialises once and then only lends to this function
+ * (one call at a time per pair of words): batches of more than 1024 tokens then run as ONE cooperative launch (workgroups of 1024
+ * tokens meeting at a self-resetting grid barrier) instead of three; NULL keeps the three launches.  Results are identical. */
 size_t mi_ep_dispatch_layout_workspace(int num_tokens, int num_topk, int num_experts);
 int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int num_tokens, int num_topk, int num_experts,
                           int num_ranks, int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
                           int32_t *is_token_in_rank, int32_t *send_token_idx_small, int32_t *send_data_offset,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          void *workspace, size_t workspace_bytes, uint32_t *sync_words, void *stream);
 
 /* ---- flags ----------------------------------------------------------------------------------
  * Each rank owns `uint64_t flags[nslots]`; slot s of rank d is written only by rank s.

@@ -330,8 +330,15 @@ Buffer::Layout Buffer::run_layout(const at::Tensor &topk_idx, int num_experts)
                                       (int)num_ranks, l.num_tokens_per_rank.data_ptr<int>(),
                                       l.num_tokens_per_expert.data_ptr<int>(), l.is_token_in_rank.data_ptr<int>(),
                                       l.send_token_idx_small.data_ptr<int>(), l.send_data_offset.data_ptr<int>(),
-                                      l.workspace.data_ptr(), wsb, cur_stream()));
+                                      l.workspace.data_ptr(), wsb, layout_sync_words(topk_idx.device()), cur_stream()));
     return l;
+}
+
+// two persistent words for the cooperative layout launch (zeroed once; the kernel's grid barrier re-arms them itself)
+uint32_t *Buffer::layout_sync_words(const at::Device &dev)
+{
+    if (!layout_sync.defined()) layout_sync = at::zeros({2}, at::dtype(at::kInt).device(dev));
+    return (uint32_t *)layout_sync.data_ptr<int>();
 }
 
 const Buffer::Layout &Buffer::layout_for(const at::Tensor &topk_idx, int num_experts)

@@ -164,6 +164,8 @@ private:
         }
     };
     Layout run_layout(const at::Tensor &topk_idx, int num_experts);
+    at::Tensor layout_sync;
+    uint32_t *layout_sync_words(const at::Device &dev);
     const Layout &layout_for(const at::Tensor &topk_idx, int num_experts);
 
     void check_status(const char *where);

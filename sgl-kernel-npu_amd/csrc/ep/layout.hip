@@ -237,49 +237,85 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void layout_assign_kernel(
     }
 }
 
-// Small batches (T <= 1024 tokens: decode / low-latency mode): the three passes in ONE workgroup of 16 waves, wave w owns
-// units w, w+16, ...; the per-unit histograms never leave LDS.  Same arithmetic and the same deterministic slot order as the three
-// kernels above; it only removes two launches (~10 us of a ~60 us low-latency dispatch).  UT = tokens per unit: 64 like the
-// kernels above, or 16 for <= 256 tokens so that a 128-token decode batch occupies 8 waves instead of 2.
+// The three passes in ONE launch: workgroups of 16 waves, a wave per unit (16 units = 1024 tokens per workgroup with 64-token units;
+// 16-token units for <= 256 tokens so that a 128-token decode batch occupies 8 waves instead of 2); the per-unit histograms never
+// leave LDS.  Same arithmetic and the same deterministic slot order as the three kernels above.
+//   one workgroup  (T <= 1024: decode / low-latency mode): removes two launches (~10 us of a ~60 us low-latency dispatch);
+//   B workgroups   (larger batches, `sync` != NULL): every workgroup publishes the histogram of ITS 16 units (E + W words), all meet at
+//     a grid barrier (B <= 128 co-resident workgroups; two self-resetting words in caller-owned zero-initialised memory), and each
+//     derives the running base of its units from the totals of the workgroups in front of it: three launches (4.9 + 6.2 + 6.9 us
+//     back to back at 4096 tokens) become one, and the [U][E] histograms / bases never travel through global memory.
+__device__ __forceinline__ void layout_grid_barrier(uint32_t *sync, int B)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t0 = wall_clock64();
+        while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)B) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 200000000ull) break;            // 2 s: never hang (a lost launch leaves garbage tables, not a stuck GPU)
+        }
+        // the last workgroup to LEAVE the spin re-arms both words for the next launch on this stream
+        if (__hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)B - 1u) {
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+}
+
 template <bool I32, int UT>
 __global__ __launch_bounds__(1024) void layout_small_kernel(
     const void *__restrict__ topk_idx, int T, int K, int E, int W, int nbits, int32_t *__restrict__ num_tokens_per_rank,
     int32_t *__restrict__ num_tokens_per_expert, int32_t *__restrict__ is_token_in_rank,
-    int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset)
+    int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset,
+    int32_t *__restrict__ block_tot /*[B][E + W], B > 1 only*/, uint32_t *__restrict__ sync)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
-    const int U = (T + UT - 1) / UT;
-    int32_t *hist = smem;                                                   // [U][E], becomes the running base in pass 2
-    unsigned long long *rmask = (unsigned long long *)(smem + U * E);       // [U][64]
-    int32_t *rank_cnt = (int32_t *)(rmask + U * UT);               // [W]
+    const int B = gridDim.x, blk = blockIdx.x;
+    const int U_all = (T + UT - 1) / UT;
+    const int u_first = blk * 16;
+    const int U = min(16, U_all - u_first);                                 // units of this workgroup (wave w owns unit u_first + w)
+    int32_t *hist = smem;                                                   // [16][E], becomes the running base in pass 2
+    unsigned long long *rmask = (unsigned long long *)(smem + 16 * E);      // [16][UT]
+    int32_t *rank_cnt = (int32_t *)(rmask + 16 * UT);                       // [W]
     int32_t *wave_tot = rank_cnt + W;                                       // [16]
     int32_t *carry = wave_tot + 16;                                         // [1]
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / kWave;
+#ifdef LAYOUT_TIMING
+    uint64_t tk[8]; int ntk = 0;
+#define LT_TICK() tk[ntk++] = wall_clock64();
+#else
+#define LT_TICK()
+#endif
+    LT_TICK()
     const int L = E / W;
     const float inv_k = 1.0f / (float)K, inv_l = 1.0f / (float)L;
-    for (int i = tid; i < U * E; i += blockDim.x) hist[i] = 0;
-    for (int i = tid; i < U * UT; i += blockDim.x) rmask[i] = 0ull;
-    for (int i = tid; i < W; i += blockDim.x) rank_cnt[i] = 0;
-    if (tid == 0) carry[0] = 0;
-    __syncthreads();
-    // ---- pass 1: histogram + token -> rank masks; wave w takes unit w (T <= 1024 with 64-token units, <= 256 with 16-token units:
-    // never more than 16 units).  The unit's expert ids are requested in ONE batch and stay in registers for pass 3: read batch by batch
-    // in both passes they were four to eight dependent global round trips of a ~6 us kernel.
+    // ---- pass 1: histogram + token -> rank masks.  The unit's expert ids are requested in ONE batch and stay in registers for pass 3:
+    // read batch by batch in both passes they were four to eight dependent global round trips of a ~6 us kernel.  (Requested before the
+    // LDS tables are cleared: the clearing runs under the loads' latency.)
     constexpr int kB = UT * MI_EP_MAX_TOPK / kWave;               // batches of 64 (token, k) pairs in a unit
     long long ev[kB];
+    const int unit = u_first + wave;                              // global unit of this wave (valid when wave < U)
     {
-        const int unit0 = wave < U ? wave : 0;
+        const int unit0 = wave < U ? unit : u_first;
         const long long q0 = (long long)unit0 * UT * K;
         const int np0 = min(UT, T - unit0 * UT) * K;
 #pragma unroll
         for (int i = 0; i < kB; ++i) ev[i] = (U > 0 && np0 > 0) ? load_idx<I32>(topk_idx, q0 + min(i * kWave + lane, np0 - 1)) : -1;
     }
-    for (int unit = wave; unit < U; unit += 16) {
+    for (int i = tid; i < 16 * E; i += blockDim.x) hist[i] = 0;
+    for (int i = tid; i < 16 * UT; i += blockDim.x) rmask[i] = 0ull;
+    for (int i = tid; i < W; i += blockDim.x) rank_cnt[i] = 0;
+    if (tid == 0) carry[0] = 0;
+    __syncthreads();
+    if (wave < U) {
         const int t0 = unit * UT;
         const int ntok = min(UT, T - t0);
         const int npairs = ntok * K;
-        int32_t *h = hist + unit * E;
-        unsigned long long *rm = rmask + unit * UT;
+        int32_t *h = hist + wave * E;
+        unsigned long long *rm = rmask + wave * UT;
 #pragma unroll
         for (int i = 0; i < kB; ++i) {
             const int p = i * kWave + lane;
@@ -302,18 +338,42 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
         }
     }
     __syncthreads();
-    // ---- pass 2: per-expert exclusive scan over units (in place), totals, exclusive scan over experts
+    LT_TICK()
+    if (B > 1) {
+        // this workgroup's totals -> global, everybody meets, then the totals of the workgroups in front of this one
+        int32_t *mine = block_tot + (size_t)blk * (E + W);
+        for (int e = tid; e < E; e += blockDim.x) {
+            int32_t s = 0;
+#pragma unroll 16
+            for (int w = 0; w < 16; ++w) s += hist[w * E + e];
+            mine[e] = s;
+        }
+        for (int r = tid; r < W; r += blockDim.x) mine[E + r] = rank_cnt[r];
+        layout_grid_barrier(sync, B);
+    }
+    LT_TICK()
+    // ---- pass 2: per-expert exclusive scan over units (in place), totals, exclusive scan over experts.  With several workgroups a unit's
+    // base starts at the sum of the earlier workgroups' totals; the LAST workgroup then holds the grand totals and writes the outputs.
+    const bool writer = blk == B - 1;
     for (int base = 0; base < E; base += blockDim.x) {
         const int e = base + tid;
         int32_t run = 0;
         if (e < E) {
-            for (int u = 0; u < U; ++u) {
+            for (int b0 = 0; b0 < blk; b0 += 16) {                   // batches of independent loads
+                int32_t v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = (b0 + j < blk) ? block_tot[(size_t)(b0 + j) * (E + W) + e] : 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) run += v[j];
+            }
+            for (int u = 0; u < 16; ++u) {
                 const int32_t v = hist[u * E + e];
                 hist[u * E + e] = run;
                 run += v;
             }
-            num_tokens_per_expert[e] = run;
+            if (writer) num_tokens_per_expert[e] = run;
         }
+        if (!writer) continue;                                     // workgroup-uniform
         int32_t inc = run;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
@@ -330,14 +390,20 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
         if (tid == blockDim.x - 1) carry[0] = c + wbase + inc;
         __syncthreads();
     }
-    for (int r = tid; r < W; r += blockDim.x) num_tokens_per_rank[r] = rank_cnt[r];
+    if (writer)
+        for (int r = tid; r < W; r += blockDim.x) {
+            int32_t s = rank_cnt[r];
+            for (int b0 = 0; b0 < blk; ++b0) s += block_tot[(size_t)b0 * (E + W) + E + r];
+            num_tokens_per_rank[r] = s;
+        }
     // ---- pass 3: slot of every (t, k) inside its expert's segment
     __syncthreads();
-    for (int unit = wave; unit < U; unit += 16) {
+    LT_TICK()
+    if (wave < U) {
         const int t0 = unit * UT;
         const long long p0 = (long long)t0 * K;
         const int npairs = min(UT, T - t0) * K;
-        int32_t *cnt = hist + unit * E;
+        int32_t *cnt = hist + wave * E;
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int i = 0; i < kB; ++i) {
@@ -357,6 +423,10 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
             if (p < npairs) send_token_idx_small[p0 + p] = out;
         }
     }
+#ifdef LAYOUT_TIMING
+    LT_TICK()
+    if (tid == 0 && blk == 0) for (int i = 0; i < ntk; ++i) ((uint64_t *)((char *)block_tot + (512 << 10)))[i] = tk[i];
+#endif
 }
 
 }  // namespace mi_ep
@@ -374,7 +444,7 @@ extern "C" size_t mi_ep_dispatch_layout_workspace(int T, int K, int E)
 extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T, int K, int E, int W,
                                      int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
                                      int32_t *is_token_in_rank, int32_t *send_token_idx_small,
-                                     int32_t *send_data_offset, void *workspace, size_t workspace_bytes, void *stream)
+                                     int32_t *send_data_offset, void *workspace, size_t workspace_bytes, uint32_t *sync_words, void *stream)
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || E <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E % W != 0 || E > 2048)
         return MI_EP_EINVAL;
@@ -393,10 +463,21 @@ extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T
     // measured ~30 us slower than the three parallel kernels, so larger batches keep those.  (Folding the scan over the units into
     // the assign kernel -- every wave summing the histograms in front of its own unit -- was also built: bit-exact, two launches
     // instead of three, and 5.7 + 12.2 us instead of 5.7 + 5.9 + 7.4 us back to back: not worth its code.)
-    const int ut = T <= 256 ? 16 : kUnitTokens;            // unit size of the single-launch path
+    // one launch: a single workgroup for <= 16 units; for more, the cooperative form when the caller lends two persistent sync words
+    // (MI_EP_LAYOUT_COOP=0 keeps the three launches) and the grid is small enough to be co-resident whatever else runs.  Unit size:
+    // 16 tokens wherever the grid allows (<= 32768 tokens): a unit's serial chain -- LDS count read -> ballots -> count write, once per
+    // batch of 64 pairs -- is 2 batches long instead of 8 at top-8 (pass 1 + pass 3 of a 64-token unit: 6.5 + 4.4 us, of a 16-token
+    // unit 2.5 + 1.2 us, tools/probes/time_layout_phases.py); 64-token units beyond that.
+    static const bool coop_ok = !(getenv("MI_EP_LAYOUT_COOP") && atoi(getenv("MI_EP_LAYOUT_COOP")) == 0);
+    const bool lend = sync_words && coop_ok;
+    int ut = kUnitTokens;
+    if (T <= 256 || (lend && T <= 128 * 256)) ut = 16;
     const int Us = (T + ut - 1) / ut;
-    if (Us >= 1 && Us <= 16 && (size_t)Us * E <= 16384 && ((Us * E) & 1) == 0) {
-        const size_t ldsf = (size_t)Us * E * 4 + (size_t)Us * ut * 8 + (size_t)(W + 16 + 4) * 4;
+    const int Bc = (Us + 15) / 16;                         // workgroups of 16 units
+    const bool single = Us >= 1 && Us <= 16;
+    const bool coop = Us > 16 && lend && Bc <= 128 && workspace_bytes >= (size_t)Bc * (E + MI_EP_MAX_RANKS) * sizeof(int32_t);
+    if ((single || coop) && (size_t)16 * E <= 16384 && ((16 * E) & 1) == 0) {
+        const size_t ldsf = (size_t)16 * E * 4 + (size_t)16 * ut * 8 + (size_t)(W + 16 + 4) * 4;
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)layout_small_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -405,9 +486,10 @@ extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T
             (void)hipFuncSetAttribute((const void *)layout_small_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-#define MI_EP_LAYOUT_SMALL(I32, UT)                                                                                            \
-    layout_small_kernel<I32, UT><<<1, 1024, ldsf, s>>>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, \
-                                                       is_token_in_rank, send_token_idx_small, send_data_offset)
+#define MI_EP_LAYOUT_SMALL(I32, UT)                                                                                              \
+    layout_small_kernel<I32, UT><<<Bc, 1024, ldsf, s>>>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, \
+                                                        is_token_in_rank, send_token_idx_small, send_data_offset,                \
+                                                        (int32_t *)workspace, sync_words)
         if (ut == 16) { if (idx_is_i32) MI_EP_LAYOUT_SMALL(true, 16); else MI_EP_LAYOUT_SMALL(false, 16); }
         else { if (idx_is_i32) MI_EP_LAYOUT_SMALL(true, 64); else MI_EP_LAYOUT_SMALL(false, 64); }
 #undef MI_EP_LAYOUT_SMALL

@@ -32,12 +32,17 @@ def dev_bf16(bits):
 
 LAYOUT_CASES = [(0, 4, 16, 4, 0), (1, 1, 2, 2, 0), (4, 2, 8, 2, 0), (33, 8, 64, 8, 0.3), (256, 2, 8, 1, 0),
                 (257, 8, 256, 8, 0.1), (4096, 8, 256, 8, 0.0), (1000, 16, 1024, 16, 0.2), (8192, 8, 256, 8, 0.05),
-                (129, 3, 24, 4, 0.5)]
+                (129, 3, 24, 4, 0.5),
+                # the cooperative single launch at its edges: one token past a workgroup (1025), a ragged last workgroup, 1024 experts
+                # (the LDS limit of the 16-unit workgroup), 2048 experts (falls back to three launches), its 128-workgroup ceiling
+                (1025, 8, 256, 8, 0.1), (5000, 6, 384, 8, 0.2), (3000, 16, 1024, 64, 0.0), (2500, 8, 2048, 8, 0.1),
+                (131072, 2, 64, 8, 0.3)]
 
 
 @pytest.mark.parametrize("T,K,E,W,drop", LAYOUT_CASES)
 @pytest.mark.parametrize("i32", [False, True])
-def test_dispatch_layout_bit_exact(T, K, E, W, drop, i32):
+@pytest.mark.parametrize("coop", [False, True], ids=["three_launches", "one_launch"])
+def test_dispatch_layout_bit_exact(T, K, E, W, drop, i32, coop):
     import ep_harness as Hh
     rng = np.random.default_rng(T * 31 + K + E)
     idx = make_topk(rng, T, K, E, drop) if T else np.zeros((0, K), np.int64)
@@ -48,11 +53,13 @@ def test_dispatch_layout_bit_exact(T, K, E, W, drop, i32):
     t = torch.from_numpy(idx).cuda()
     if i32:
         t = t.int()
-    got = Hh.layout(t, E, W)
-    torch.cuda.synchronize()
-    for k in ("num_tokens_per_rank", "num_tokens_per_expert", "is_token_in_rank", "send_token_idx_small"):
-        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
-    assert np.array_equal(got["send_data_offset"].cpu().numpy(), O.send_data_offset(want["num_tokens_per_expert"]))
+    for rep in range(2):                   # twice on the same sync words: the grid barrier re-armed itself
+        got = Hh.layout(t, E, W, coop=coop)
+        torch.cuda.synchronize()
+        for k in ("num_tokens_per_rank", "num_tokens_per_expert", "is_token_in_rank", "send_token_idx_small"):
+            assert np.array_equal(got[k].cpu().numpy(), want[k]), (k, rep)
+        assert np.array_equal(got["send_data_offset"].cpu().numpy(), O.send_data_offset(want["num_tokens_per_expert"]))
+    assert not Hh._SYNC["words"].any()
 
 
 DISPATCH_CASES = [
