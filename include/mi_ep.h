@@ -65,6 +65,9 @@ extern "C" {
 #define MI_EP_QUANT_NONE 0      /* bf16 rows */
 #define MI_EP_QUANT_INT8 1      /* s = 127/(amax + 1e-12)   (normal mode, cam_moe_dispatch_normal.h:326-363) */
 #define MI_EP_QUANT_INT8_NOEPS 2 /* s = 127/amax             (low-latency, moe_distribute_dispatch_v2.h:1006-1033) */
+#define MI_EP_QUANT_FP8_E4M3 3  /* per-token OCP FP8 E4M3 (quant_mode "pertoken_fp8_e4m3"): s = amax > 0 ? 448/amax : 1, q = e4m3fn(x * s)
+                                 * round-to-nearest-even, scale_out = 1/s (moe_distribute_dispatch_v2_a5.h:1109-1157, the reference's
+                                 * Ascend950-only mode; gfx950 converts natively: v_cvt_pk_fp8_f32).  Row layout as INT8: H bytes + meta */
 
 /* library / build identification ("gfx950") */
 const char *mi_ep_version(void);

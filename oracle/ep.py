@@ -192,10 +192,81 @@ def quant_int8_rows(x_bits: np.ndarray, eps: Optional[float]) -> tuple:
     return q.astype(np.int8), scale
 
 
+# --------------------------------------------------------------------------------------
+# per-token FP8 E4M3 quantisation (quant_mode "pertoken_fp8_e4m3")  -- PARITY UNPINNED: the reference serves this mode on its
+# Ascend950 build only (deep_ep.cpp:338-343), holds no vector for it, and the kernel below is restated from source.
+# --------------------------------------------------------------------------------------
+def f32_to_e4m3fn_bits(y: np.ndarray) -> np.ndarray:
+    """float32 -> OCP FP8 E4M3 ("fn": no infinities, S.1111.111 = NaN, largest finite 448 = S.1111.110), round to nearest even,
+    as a uint8 bit pattern.  Written from the format definition (OCP 8-bit Floating Point Specification v1.0, section 5): bias 7,
+    3 mantissa bits, subnormals below 2^-6 in steps of 2^-9.  Magnitudes that round above 448 saturate to 448 here (they cannot
+    occur in quant_fp8_e4m3_rows: |x * s| <= 448 up to one fp32 rounding, far below the midpoint 464 to the next binade step)."""
+    y = np.asarray(y, np.float32)
+    sign = (y.view(np.uint32) >> 31).astype(np.uint8) << 7
+    a = np.abs(y).astype(np.float64)
+    out = np.zeros(y.shape, np.uint8)
+    nan = np.isnan(a)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))            # exponent of the binade (exact for floats: log2 of a power of two
+        e = np.where(np.ldexp(1.0, e.astype(np.int64)) > a, e - 1, e)      # is exact, the correction covers the neighbours)
+        e = np.where(np.ldexp(1.0, (e + 1).astype(np.int64)) <= a, e + 1, e)
+    e = np.clip(e, -6, 8)                                            # below 2^-6: the subnormal step 2^-9 applies
+    step = np.ldexp(1.0, (e - 3).astype(np.int64))                   # spacing of representable values in that binade
+    qn = np.rint(a / step)                                           # np.rint: half to even; a / step is exact (power of two)
+    val = qn * step
+    val = np.minimum(val, 448.0)
+    # value -> bits: normal numbers have qn in [8, 16) (16 = next binade), subnormals qn in [0, 8)
+    e2 = np.floor(np.log2(np.where(val > 0, val, 1.0)))
+    e2 = np.where(np.ldexp(1.0, e2.astype(np.int64)) > val, e2 - 1, e2)
+    e2 = np.where(np.ldexp(1.0, (e2 + 1).astype(np.int64)) <= val, e2 + 1, e2)
+    normal = val >= 2.0 ** -6
+    mant_n = np.rint(val / np.ldexp(1.0, (e2 - 3).astype(np.int64))) - 8
+    bits_n = ((e2 + 7).astype(np.int64) << 3) | mant_n.astype(np.int64)
+    bits_s = np.rint(val / 2.0 ** -9).astype(np.int64)
+    out = np.where(normal, bits_n, bits_s).astype(np.uint8)
+    out = np.where(val == 0, 0, out).astype(np.uint8)
+    out = np.where(nan, 0x7F, out).astype(np.uint8)
+    return out | sign
+
+
+def e4m3fn_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    b = np.asarray(b, np.uint8).astype(np.int64)
+    s = np.where(b & 0x80, -1.0, 1.0)
+    e, m = (b >> 3) & 0xF, b & 7
+    v = np.where(e == 0, m * 2.0 ** -9, (8 + m) * np.ldexp(1.0, e - 10))
+    v = np.where((e == 15) & (m == 7), np.nan, v)
+    return (s * v).astype(np.float32)
+
+
+def quant_fp8_e4m3_rows(x_bits: np.ndarray) -> tuple:
+    """Per-row FP8 E4M3 quantisation of bf16 rows (moe_distribute_dispatch_v2_a5.h:1109-1157, QuantDynamicPerToken with
+    ExpandXOutType = fp8_e4m3fn): tokenF32 = float(x); scale = max|x| > 0 ? 448.0f / max|x| : 1.0f (:1130-1131); tokenF32 *= scale
+    (:1133); out = cast<e4m3fn, CAST_RINT>(tokenF32) (:1150); the row's scale word = 1.0f / scale (:1154-1155).
+    Non-finite rows as in quant_int8_rows (max = +inf -> scale 0, scale word +inf).  Returns (uint8 e4m3 bits [N,H], f32 [N])."""
+    xf = bf16_bits_to_f32(x_bits)
+    with np.errstate(invalid="ignore"):
+        ax = np.abs(xf)
+        ax = np.where(np.isnan(ax), np.float32(np.inf), ax)
+    amax = np.max(ax, axis=1).astype(np.float32) if xf.shape[1] else np.zeros(xf.shape[0], np.float32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        s = np.where(amax > 0, np.float32(448.0) / np.where(amax > 0, amax, np.float32(1)), np.float32(1.0)).astype(np.float32)
+        y = (xf * s[:, None]).astype(np.float32)
+        scale = (np.float32(1.0) / s).astype(np.float32)
+    return f32_to_e4m3fn_bits(np.nan_to_num(y, nan=0.0)), scale
+
+
+def _quant_rows(x_bits, quant, eps):
+    """quant: False / True ("int8") / "fp8" (pertoken_fp8_e4m3) -> (payload [N,H] int8 | uint8 e4m3 bits, scales f32 [N])."""
+    if quant == "fp8":
+        return quant_fp8_e4m3_rows(x_bits)
+    return quant_int8_rows(x_bits, eps)
+
+
 def per_token_cast_back(q: np.ndarray, scale: np.ndarray) -> np.ndarray:
     """De-quantisation convention of the reference tests (float32-scale branch of
-    tests/python/deepep/utils.py:182-188): bf16(float(q) * scale).  Returns bf16 bits."""
-    return f32_to_bf16_bits_rne(q.astype(np.float32) * scale.astype(np.float32)[:, None])
+    tests/python/deepep/utils.py:182-188): bf16(float(q) * scale).  Returns bf16 bits.  uint8 payloads are E4M3 bit patterns."""
+    qf = e4m3fn_bits_to_f32(q) if q.dtype == np.uint8 else q.astype(np.float32)
+    return f32_to_bf16_bits_rne(qf * scale.astype(np.float32)[:, None])
 
 
 # --------------------------------------------------------------------------------------
@@ -250,7 +321,7 @@ def normal_dispatch(xs_bits: Sequence[np.ndarray], topk_idxs: Sequence[np.ndarra
         tok = (vidx // K).astype(np.int32)
         kk = (vidx % K).astype(np.int32)
         if quant:
-            q_all, s_all = quant_int8_rows(x, 1e-12)
+            q_all, s_all = _quant_rows(x, quant, 1e-12)
             payload = np.zeros((n, H), np.int8)
             payload[slot] = q_all[tok]
             scales = np.zeros(n, np.float32)
@@ -270,7 +341,7 @@ def normal_dispatch(xs_bits: Sequence[np.ndarray], topk_idxs: Sequence[np.ndarra
         nt = notify_dispatch(cnt, Ts, me)
         R = int(nt["total_recv_token"])
         rows = max(R, 1)
-        recv_x = np.zeros((rows, H), np.int8 if quant else np.uint16)
+        recv_x = np.zeros((rows, H), (np.uint8 if quant == "fp8" else np.int8) if quant else np.uint16)
         recv_s = np.zeros(rows, np.float32) if quant else None
         recv_t = np.zeros((rows, 3), np.int32)
         prev = 0
@@ -389,10 +460,10 @@ def low_latency_dispatch(xs_bits: Sequence[np.ndarray], topk_idxs: Sequence[np.n
     pre = []
     for r in range(W):
         x = np.ascontiguousarray(xs_bits[r]).view(np.uint16)
-        pre.append(quant_int8_rows(x, None) if quant else (x, None))
+        pre.append(_quant_rows(x, quant, None) if quant else (x, None))
     out = []
     for me in range(W):
-        rx = np.zeros((M, H), np.int8 if quant else np.uint16)
+        rx = np.zeros((M, H), (np.uint8 if quant == "fp8" else np.int8) if quant else np.uint16)
         rs = np.zeros(M, np.float32) if quant else None
         tri = []
         rng = np.zeros(L * W, np.int32)

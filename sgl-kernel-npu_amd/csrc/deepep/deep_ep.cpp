@@ -37,10 +37,15 @@ int quant_mode_of(bool use_quant, const std::string &quant_type)
 {
     if (!use_quant) return MI_EP_QUANT_NONE;
     if (quant_type == "int8_ll") return MI_EP_QUANT_INT8_NOEPS;     // low-latency rounding (no epsilon), a2a strategy only
-    // MXFP8 / MXFP4 / per-token FP8 are Ascend950-only in the reference too (deep_ep.cpp:338-343)
-    EP_HOST_ASSERT_S(quant_type == "int8", quant_type, " is not supported on this device, please use int8 or bf16 instead.");
+    // per-token FP8 E4M3 is Ascend950-only in the reference (deep_ep.cpp:338-343); gfx950 converts to OCP FP8 natively, so it is
+    // served here.  The block-scaled MXFP8 / MXFP4 modes are not built.
+    if (quant_type == "pertoken_fp8_e4m3") return MI_EP_QUANT_FP8_E4M3;
+    EP_HOST_ASSERT_S(quant_type == "int8", quant_type, " is not supported on this device, please use int8, pertoken_fp8_e4m3 or bf16 instead.");
     return MI_EP_QUANT_INT8;
 }
+
+// dtype of a one-byte-per-element payload tensor (reference deep_ep.cpp:344-365)
+at::ScalarType payload_dtype(int qm) { return qm == MI_EP_QUANT_FP8_E4M3 ? at::kFloat8_e4m3fn : at::kChar; }
 }  // namespace
 
 EventHandle::EventHandle()
@@ -434,7 +439,7 @@ void Buffer::dispatch_pull(const DispatchExchange &ex, int H, int K, int L, int 
 {
     auto dev = x_opts.device();
     const bool quant = qm != MI_EP_QUANT_NONE;
-    rx = quant ? at::empty({rows_alloc, H}, at::dtype(at::kChar).device(dev)) : at::empty({rows_alloc, H}, x_opts);
+    rx = quant ? at::empty({rows_alloc, H}, at::dtype(payload_dtype(qm)).device(dev)) : at::empty({rows_alloc, H}, x_opts);
     rs = at::empty({rows_alloc}, at::dtype(at::kFloat).device(dev));
     src_idx = at::empty({rows_alloc * 3}, at::dtype(at::kInt).device(dev));
     ProfScope ps_(this, "dispatch_pull", st);
@@ -657,10 +662,10 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     const int W = (int)num_ranks, E = (int)num_experts, L = E / W, MT = (int)num_max_dispatch_tokens_per_rank;
     int qm;
     if (quant_mode_name == "int8") qm = MI_EP_QUANT_INT8_NOEPS;
+    else if (quant_mode_name == "pertoken_fp8_e4m3") qm = MI_EP_QUANT_FP8_E4M3;
     else {
-        const bool a5_only = quant_mode_name == "mx_fp8_e4m3" || quant_mode_name == "mx_fp8_e5m2" ||
-                             quant_mode_name == "mx_fp4_e2m1" || quant_mode_name == "pertoken_fp8_e4m3";
-        EP_HOST_ASSERT_S(!a5_only, quant_mode_name, " is not supported on this device, please use int8 or bf16 instead.");
+        const bool not_built = quant_mode_name == "mx_fp8_e4m3" || quant_mode_name == "mx_fp8_e5m2" || quant_mode_name == "mx_fp4_e2m1";
+        EP_HOST_ASSERT_S(!not_built, quant_mode_name, " is not supported on this device, please use int8, pertoken_fp8_e4m3 or bf16 instead.");
         EP_HOST_ASSERT(quant_mode_name == "none");
         qm = MI_EP_QUANT_NONE;
     }
@@ -680,7 +685,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
         packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(at::kBFloat16).device(dev));
         packed_recv_x_scales = at::empty({1}, at::dtype(at::kFloat).device(dev));
     } else {
-        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(at::kChar).device(dev));
+        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(payload_dtype(qm)).device(dev));
         packed_recv_x_scales = at::empty({num_max_tokens}, at::dtype(at::kFloat).device(dev));
     }
     auto expand_idx = at::empty({max_size}, i32);
@@ -1109,7 +1114,7 @@ Buffer::a2a_dispatch_unpack(const at::Tensor &staging, const std::vector<int64_t
     EP_HOST_ASSERT(off == total_recv);
     const int64_t rows = std::max<int64_t>(total_recv == 0 ? 1 : total_recv, min_rows);
     auto dev = staging.device();
-    at::Tensor recv_x = use_quant ? at::empty({rows, H}, at::dtype(at::kChar).device(dev))
+    at::Tensor recv_x = use_quant ? at::empty({rows, H}, at::dtype(payload_dtype(qm)).device(dev))
                                   : at::empty({rows, H}, at::dtype(at::kBFloat16).device(dev));
     at::Tensor scales = at::empty({rows}, at::dtype(at::kFloat).device(dev));
     at::Tensor src_idx = at::empty({std::max<int64_t>(rows * 3, src_idx_len)}, at::dtype(at::kInt).device(dev));

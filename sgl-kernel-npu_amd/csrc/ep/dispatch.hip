@@ -87,7 +87,8 @@ __device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const 
 // ---------------------------------------------------------------------------------------------
 // stage, INT8: item = 16 consecutive elements = two 16-B loads -> one 16-B store
 // ---------------------------------------------------------------------------------------------
-template <bool I32, bool EPS>
+// QM = MI_EP_QUANT_INT8 / MI_EP_QUANT_INT8_NOEPS / MI_EP_QUANT_FP8_E4M3 (one byte per element each, same row layout)
+template <bool I32, int QM>
 __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
     const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
@@ -144,12 +145,15 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     }
     amax = wave_max(amax);
     float s, scale_out;
-    if (EPS) {
+    if (QM == MI_EP_QUANT_INT8) {
         s = 127.0f / (amax + 1e-12f);
         scale_out = 1.0f / s;
-    } else {
+    } else if (QM == MI_EP_QUANT_INT8_NOEPS) {
         s = (amax == 0.f) ? 0.f : 127.0f / amax;       // all-zero row: q = 0, scale = 0 (see oracle)
         scale_out = (amax == 0.f) ? 0.f : 1.0f / s;
+    } else {                                           // per-token FP8 E4M3 (moe_distribute_dispatch_v2_a5.h:1130-1131,1154-1155)
+        s = amax > 0.f ? 448.0f / amax : 1.0f;
+        scale_out = 1.0f / s;
     }
     u32x4 q[kMaxItems];
     // the raw row is made opaque between the two passes: otherwise the compiler keeps the 128 floats it unpacked for the maximum alive
@@ -163,16 +167,27 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 s2 = f32x2{s, s};
+                const uint32_t w0 = raw[it][h][jj * 2], w1 = raw[it][h][jj * 2 + 1];
+                uint32_t p0, p1 = 0u;
+                if (QM == MI_EP_QUANT_FP8_E4M3) {
+                    // fp32 product, then the hardware's round-to-nearest-even conversion to OCP E4M3 (two elements per instruction,
+                    // the 16-bit half of the destination selected by the last operand); |x * s| <= 448 by construction
+                    const f32x2 r0 = f32x2{bf16_to_f32(w0 & 0xFFFFu), __uint_as_float(w0 & 0xFFFF0000u)} * s2;
+                    const f32x2 r1 = f32x2{bf16_to_f32(w1 & 0xFFFFu), __uint_as_float(w1 & 0xFFFF0000u)} * s2;
+                    p0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(r0[0], r0[1], 0, false);
+                    p0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(r1[0], r1[1], (int)p0, true);
+                } else {
                 // round(x * s) through the 1.5 * 2^23 trick: the float sum's low mantissa bits are the nearest-even integer in two's
                 // complement (|x * s| <= 127), i.e. rintf + cvt in one addition, on two elements per instruction (v_pk_mul_f32 /
                 // v_pk_add_f32); the four low bytes are gathered with v_perm_b32
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 s2 = f32x2{s, s}, magic = f32x2{12582912.0f, 12582912.0f};
-                const uint32_t w0 = raw[it][h][jj * 2], w1 = raw[it][h][jj * 2 + 1];
+                const f32x2 magic = f32x2{12582912.0f, 12582912.0f};
                 const f32x2 r0 = f32x2{bf16_to_f32(w0 & 0xFFFFu), __uint_as_float(w0 & 0xFFFF0000u)} * s2 + magic;
                 const f32x2 r1 = f32x2{bf16_to_f32(w1 & 0xFFFFu), __uint_as_float(w1 & 0xFFFF0000u)} * s2 + magic;
-                const uint32_t p0 = __builtin_amdgcn_perm(__float_as_uint(r0[1]), __float_as_uint(r0[0]), 0x0c0c0400u);   // bytes: lo, hi, 0, 0
-                const uint32_t p1 = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x04000c0cu);   // bytes: 0, 0, lo, hi
+                p0 = __builtin_amdgcn_perm(__float_as_uint(r0[1]), __float_as_uint(r0[0]), 0x0c0c0400u);   // bytes: lo, hi, 0, 0
+                p1 = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x04000c0cu);   // bytes: 0, 0, lo, hi
+                }
                 q[it][h * 2 + jj] = p0 | p1;
             }
     }
@@ -540,10 +555,13 @@ static int stage_launch(const void *x, const void *topk_idx, int idx_is_i32, con
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
             break;
         case MI_EP_QUANT_INT8:
-            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, true>)); else MI_EP_STAGE((stage_int8_kernel<false, true>));
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, MI_EP_QUANT_INT8>)); else MI_EP_STAGE((stage_int8_kernel<false, MI_EP_QUANT_INT8>));
             break;
         case MI_EP_QUANT_INT8_NOEPS:
-            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, false>)); else MI_EP_STAGE((stage_int8_kernel<false, false>));
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, MI_EP_QUANT_INT8_NOEPS>)); else MI_EP_STAGE((stage_int8_kernel<false, MI_EP_QUANT_INT8_NOEPS>));
+            break;
+        case MI_EP_QUANT_FP8_E4M3:
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, MI_EP_QUANT_FP8_E4M3>)); else MI_EP_STAGE((stage_int8_kernel<false, MI_EP_QUANT_FP8_E4M3>));
             break;
         default:
             return MI_EP_EINVAL;
@@ -794,10 +812,13 @@ extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int i
             if (idx_is_i32) MI_EP_STAGE(stage_bf16_kernel<true>); else MI_EP_STAGE(stage_bf16_kernel<false>);
             break;
         case MI_EP_QUANT_INT8:
-            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, true>)); else MI_EP_STAGE((stage_int8_kernel<false, true>));
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, MI_EP_QUANT_INT8>)); else MI_EP_STAGE((stage_int8_kernel<false, MI_EP_QUANT_INT8>));
             break;
         case MI_EP_QUANT_INT8_NOEPS:
-            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, false>)); else MI_EP_STAGE((stage_int8_kernel<false, false>));
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, MI_EP_QUANT_INT8_NOEPS>)); else MI_EP_STAGE((stage_int8_kernel<false, MI_EP_QUANT_INT8_NOEPS>));
+            break;
+        case MI_EP_QUANT_FP8_E4M3:
+            if (idx_is_i32) MI_EP_STAGE((stage_int8_kernel<true, MI_EP_QUANT_FP8_E4M3>)); else MI_EP_STAGE((stage_int8_kernel<false, MI_EP_QUANT_FP8_E4M3>));
             break;
         default:
             return MI_EP_EINVAL;

@@ -97,8 +97,8 @@ class AllToAllLowLatencyCommStrategy(LowLatencyEPCommStrategy):
                              use_mxfp4=False, async_finish=False, return_recv_hook=False, topk_weights=None, quant_mode=None):
         if quant_mode not in _VALID_LL_QUANT:
             raise ValueError(f"Unsupported quant_mode: {quant_mode}")
-        if quant_mode not in (None, "int8"):
-            raise ValueError(f"{quant_mode} is not supported on this device, please use int8 or bf16 instead.")
+        if quant_mode not in (None, "int8", "pertoken_fp8_e4m3"):
+            raise ValueError(f"{quant_mode} is not supported on this device, please use int8, pertoken_fp8_e4m3 or bf16 instead.")
         import os
 
         topk_ids = topk_idx.int()
@@ -106,7 +106,7 @@ class AllToAllLowLatencyCommStrategy(LowLatencyEPCommStrategy):
         L = num_experts // W
         K = topk_ids.size(1)
         hidden = x.size(1)
-        qt = "int8_ll" if quant_mode == "int8" else "bf16"
+        qt = {"int8": "int8_ll", "pertoken_fp8_e4m3": "pertoken_fp8_e4m3"}.get(quant_mode, "bf16")
         rows, cnt_vec = self.runtime.a2a_dispatch_stage(x, topk_ids, num_experts, qt)
         cnt_matrix = torch.empty((W, cnt_vec.numel()), dtype=cnt_vec.dtype, device=cnt_vec.device)
         dist.all_gather_into_tensor(cnt_matrix.view(-1), cnt_vec, group=self.group)

@@ -218,7 +218,7 @@ class AlltoAllNormalCommStrategy(NormalEPCommStrategy):
                  topk_idx, topk_weights, expert_alignment=1, num_worst_tokens=0, config=None, previous_event=None,
                  async_finish=False, allocate_on_comm_stream=False, dispatch_wait_recv_cost_stats=None, quant_mode=None):
         data, quant_type, use_quant = resolve_quant(x, quant_mode)
-        if quant_type not in ("bf16", "int8"):
+        if quant_type not in ("bf16", "int8", "pertoken_fp8_e4m3"):
             raise ValueError(f"{quant_type} is not supported on this device, please use int8 or bf16 instead.")
         if handle is not None:
             raise NotImplementedError("Optional communication handle is not supported yet.")

@@ -10,7 +10,7 @@ import torch
 
 from capi import load, ptr, ptr_array, stream_ptr
 
-QUANT_NONE, QUANT_INT8, QUANT_INT8_NOEPS = 0, 1, 2
+QUANT_NONE, QUANT_INT8, QUANT_INT8_NOEPS, QUANT_FP8_E4M3 = 0, 1, 2, 3
 
 
 def _lib():

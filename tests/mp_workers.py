@@ -494,6 +494,67 @@ def _gpu_inference_mode(rank, world, port, cfg):
 
 
 # ----------------------------------------------------------------------------------------------
+# GPU: quant_mode="pertoken_fp8_e4m3" through deep_ep.Buffer (normal + low-latency dispatch): returned dtypes / shapes as the
+# reference's Ascend950 build returns them (deep_ep.cpp:352-355, buffer.py:652-662), payload bits and scales == oracle
+# ----------------------------------------------------------------------------------------------
+def gpu_fp8_worker(rank, world, port, cfg):
+    run_guarded(_gpu_fp8, rank, world, port, cfg)
+
+
+def _gpu_fp8(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits
+    torch.cuda.set_device(0)
+    W, T, H, K, E, drop = cfg
+    group = _init(rank, world, port)
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(512 << 20))
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    xs, idxs, ws = make_inputs(W, T, H, K, E, drop, seed=21)
+    x, ti = bits_to_torch(xs[rank]).cuda(), torch.from_numpy(idxs[rank]).cuda()
+    tw = torch.from_numpy(np.abs(ws[rank])).cuda()
+    for transport in (("push", "pull") if W > 1 else ("pull",)):
+        buf.runtime.set_dispatch_transport(transport)
+        want = O.normal_dispatch(xs, idxs, E, "fp8")[rank]
+        per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(ti, E)
+        (rx, rs), _, _, lst, handle, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in,
+                                                      num_tokens_per_expert=per_expert, topk_idx=ti, topk_weights=tw,
+                                                      quant_mode="pertoken_fp8_e4m3")
+        n = want.total_recv
+        assert rx.dtype == torch.float8_e4m3fn and rs.dtype == torch.float32 and rx.shape[1] == H and lst == want.num_recv_tokens_per_expert_list
+        assert np.array_equal(rx.view(torch.uint8).cpu().numpy()[:n], want.recv_x[:n])
+        assert np.array_equal(rs.cpu().numpy()[:n].view(np.uint32), want.recv_x_scales[:n].view(np.uint32))
+        assert np.array_equal(handle[3].cpu().numpy()[:3 * n], want.recv_src_idx[:3 * n])
+        # de-quantise the way a consumer would (torch's own float8 -> float conversion), combine, compare with the oracle's round trip
+        y = (rx.float() * rs[:, None]).to(torch.bfloat16)
+        assert np.array_equal(torch_to_bits(y)[:n], O.per_token_cast_back(want.recv_x, want.recv_x_scales)[:n])
+        out, _, _ = buf.combine(y, handle)
+        allw = O.normal_dispatch(xs, idxs, E, "fp8")
+        ys = [O.per_token_cast_back(w_.recv_x, w_.recv_x_scales) for w_ in allw]
+        comb = O.combine(ys, [w_.recv_src_idx for w_ in allw], [w_.total_recv for w_ in allw], idxs, [np.abs(w_) for w_ in ws], E)[rank]
+        assert np.array_equal(torch_to_bits(out), comb)
+    MT = T + W
+    llw = O.low_latency_dispatch(xs, idxs, MT, E, "fp8")[rank]
+    (lx, ls), cnt, h, _, hook = buf.low_latency_dispatch(x, ti, MT, E, quant_mode="pertoken_fp8_e4m3")
+    hook()
+    nn = llw.total
+    assert lx.dtype == torch.float8_e4m3fn and ls.shape == (lx.shape[0],) and np.array_equal(cnt.cpu().numpy(), llw.packed_recv_count)
+    assert np.array_equal(lx.view(torch.uint8).cpu().numpy()[:nn], llw.packed_recv_x[:nn])
+    assert np.array_equal(ls.cpu().numpy()[:nn].view(np.uint32), llw.packed_recv_x_scales[:nn].view(np.uint32))
+    assert np.array_equal(h[0].cpu().numpy()[:3 * nn], llw.src_info)
+    # the block-scaled modes are not built: a clear error, as the reference gives off its Ascend950 build (deep_ep.cpp:338-343)
+    for qmode in ("mx_fp8_e4m3", "mx_fp4_e2m1"):
+        try:
+            buf.low_latency_dispatch(x, ti, MT, E, quant_mode=qmode)
+            raise AssertionError(f"{qmode} must be rejected")
+        except (RuntimeError, ValueError) as e:
+            assert "not supported" in str(e)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
 # GPU: a peer that never shows up must surface as a RuntimeError (bounded spins), not a hang
 # ----------------------------------------------------------------------------------------------
 def gpu_timeout_worker(rank, world, port, cfg):

@@ -74,6 +74,11 @@ def test_every_call_works_under_inference_mode(cfg):
     _spawn(mp_workers.gpu_inference_mode_worker, cfg[0], cfg)
 
 
+@pytest.mark.parametrize("cfg", [(1, 64, 7168, 8, 64, 0.1), (2, 40, 1024, 4, 16, 0.2), (4, 33, 2048, 8, 64, 0.0)])   # W, T, H, K, E, drop
+def test_pertoken_fp8_e4m3_dispatch_through_buffer(cfg):
+    _spawn(mp_workers.gpu_fp8_worker, cfg[0], cfg)
+
+
 def test_missing_peer_raises_instead_of_hanging():
     _spawn(mp_workers.gpu_timeout_worker, 2, None)
 

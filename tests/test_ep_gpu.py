@@ -366,3 +366,45 @@ def test_window_selftest_rounds_and_failure_codes(W):      # onto 4 queues) and 
     assert all(c != 0 for c in codes)
     assert all(c in (3001, 5001) for i, c in enumerate(codes) if i != 1), codes
     assert codes[1] // 1000 in (3, 4, 5), codes
+
+
+# ---- quant_mode "pertoken_fp8_e4m3" (MI_EP_QUANT_FP8_E4M3): the reference's Ascend950-only per-token FP8 dispatch, served natively here ----
+@pytest.mark.parametrize("W,T,H,K,E,drop,active", DISPATCH_CASES[:6])
+@pytest.mark.parametrize("mode", ["replicated", "compact", "push", "low_latency"])
+def test_fp8_e4m3_dispatch_bit_exact(W, T, H, K, E, drop, active, mode):
+    """Payload bytes (OCP E4M3 bit patterns from v_cvt_pk_fp8_f32) and scale words against oracle.ep.quant_fp8_e4m3_rows through all
+    three normal-dispatch forms and the low-latency slabs; the routing tables must not depend on the payload type; combine of the
+    de-quantised rows round-trips like INT8 does."""
+    import ep_harness as Hh
+    rng = np.random.default_rng(W * 131 + T + H)
+    Ts = [T + r for r in range(W)]
+    xs = [rand_bits(rng, (t, H), float(rng.choice([0.01, 1.0, 300.0]))) for t in Ts]
+    for x in xs:
+        if x.shape[0] > 2:
+            x[1, :] = 0                                  # an all-zero token: scale 1, zeros
+            x[2, 5] = 0x7F7F                             # the largest finite bf16 in one element: everything else flushes towards zero
+    idxs = [make_topk(rng, t, K, E, drop, active) for t in Ts]
+    ws = [np.abs(rng.standard_normal((t, K))).astype(np.float32) for t in Ts]
+    dev_idx = [torch.from_numpy(i).int().cuda() if mode == "low_latency" else torch.from_numpy(i).cuda() for i in idxs]
+    if mode == "low_latency":
+        MT = max(Ts)
+        h = Hh.InProcEP(W, E, MT, K, H)
+        got = h.ll_dispatch([dev_bf16(x) for x in xs], dev_idx, Hh.QUANT_FP8_E4M3, 1)
+        want = O.low_latency_dispatch(xs, idxs, MT, E, "fp8")
+        view = lambda g, w: (g["packed_recv_x"], g["packed_recv_x_scales"], g["src_info"], w.packed_recv_x, w.packed_recv_x_scales, w.src_info, w.total)
+    else:
+        h = Hh.InProcEP(W, E, max(Ts) + 1, K, H, compact=mode == "compact", transport="push" if mode == "push" else "pull")
+        got = h.dispatch([dev_bf16(x) for x in xs], dev_idx, Hh.QUANT_FP8_E4M3)
+        want = O.normal_dispatch(xs, idxs, E, "fp8")
+        view = lambda g, w: (g["recv_x"], g["recv_x_scales"], g["recv_src_idx"], w.recv_x, w.recv_x_scales, w.recv_src_idx, w.total_recv)
+    ys, tris, totals = [], [], []
+    for r in range(W):
+        gx, gs, gi, wx, wsc, wi, n = view(got[r], want[r])
+        assert np.array_equal(gi.cpu().numpy()[:3 * n], wi[:3 * n])
+        assert np.array_equal(gx.cpu().numpy().view(np.uint8)[:n], wx[:n]), (mode, r)
+        assert np.array_equal(gs.cpu().numpy()[:n].view(np.uint32), wsc[:n].view(np.uint32))
+        ys.append(O.per_token_cast_back(wx, wsc)), tris.append(gi), totals.append(n)
+    comb_want = O.combine(ys, [view(got[r], want[r])[5] for r in range(W)], totals, idxs, ws, E)
+    comb_got = h.combine([dev_bf16(y) for y in ys], tris, totals, dev_idx, [torch.from_numpy(w_).cuda() for w_ in ws])
+    for r in range(W):
+        assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r]), r

@@ -305,3 +305,35 @@ def test_sampled_float64_checker_agrees_with_the_staged_oracle():
         calc_w, avg_w = F.diffs(torch.from_numpy(bf16_bits_to_f32(got[r])), F.sampled_reference(xs[r], wrong, ws[r], lambda rr: weights[rr], L, torch.arange(T)))
         assert avg_w > 10 * 4e-4
     assert np.array_equal(F.fusion_perm(512, device="cpu").numpy(), O.permute_fusion_cols(512))
+
+
+# ---- quant_mode "pertoken_fp8_e4m3": the oracle's E4M3 conversion is written from the format definition; pinned here against torch's
+# own CPU cast (an independent implementation) and hand-computed known answers.  No reference-held vector exists: PARITY UNPINNED.
+def test_fp8_e4m3_conversion_matches_torch_cast_and_known_answers():
+    import torch
+    b = np.arange(256, dtype=np.uint8)
+    dec = O.e4m3fn_bits_to_f32(b)
+    tdec = torch.from_numpy(b).view(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(np.isnan(dec), np.isnan(tdec)) and np.array_equal(dec[~np.isnan(dec)], tdec[~np.isnan(tdec)])
+    rng = np.random.default_rng(0)
+    y = np.concatenate([rng.standard_normal(100000).astype(np.float32) * s for s in (1e-3, 0.02, 1, 30, 200)])
+    y = np.clip(np.concatenate([y, dec[~np.isnan(dec)], np.float32([2 ** -10, 1.5 * 2 ** -9, 2.5 * 2 ** -9, 0.0146484375, 447.9, 17.0, 19.0])]), -448, 448)
+    assert np.array_equal(O.f32_to_e4m3fn_bits(y), torch.from_numpy(y).to(torch.float8_e4m3fn).view(torch.uint8).numpy())
+    # every representable value is a fixed point; ties go to the even mantissa: 17 = 16 + 1 (between 16 and 18) -> 16, 19 -> 20
+    rep = dec[~np.isnan(dec)]
+    assert np.array_equal(O.e4m3fn_bits_to_f32(O.f32_to_e4m3fn_bits(rep)), rep)
+    assert O.e4m3fn_bits_to_f32(O.f32_to_e4m3fn_bits(np.float32([17.0, 19.0, 2 ** -10]))).tolist() == [16.0, 20.0, 0.0]
+
+
+def test_fp8_e4m3_row_quantisation_known_answers():
+    from oracle.bf16 import f32_to_bf16_bits_rne
+    x = np.zeros((3, 32), np.float32)
+    x[0, :4] = [2.0, -1.0, 0.5, 2.0 / 448]          # max 2 -> scale 224: 448, -224, 112, 1
+    x[2, :2] = [3.0, 1.0]                            # max 3: s = fl32(448/3) = 149.33333; 1.0 * s = 149.33 -> 144 | 160 grid -> 144 (0x71)
+    q, sc = O.quant_fp8_e4m3_rows(f32_to_bf16_bits_rne(x))
+    assert q[0, :4].tolist() == [0x7E, 0xF6, 0x6E, 0x38] and sc[0] == np.float32(1.0) / np.float32(224.0)
+    assert not q[1].any() and sc[1] == 1.0           # all-zero row: scale 1 (moe_distribute_dispatch_v2_a5.h:1131)
+    assert q[2, 0] == 0x7E and q[2, 1] == 0x71 and sc[2] == np.float32(1.0) / (np.float32(448.0) / np.float32(3.0))
+    from oracle.bf16 import bf16_bits_to_f32
+    back = bf16_bits_to_f32(O.per_token_cast_back(q, sc))
+    assert back[0, :3].tolist() == [2.0, -1.0, 0.5] and abs(back[2, 1] - 144.0 * 3 / 448) < 2 ** -8
