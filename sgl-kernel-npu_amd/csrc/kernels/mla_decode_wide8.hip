@@ -15,6 +15,13 @@
 // waves per SIMD the partner's MFMAs cover a wave's DMA issue, operand waits and softmax.
 // Softmax reference: the first tile's maximum per head, never rescaled (see mla_decode_wide.hip); a sequence whose later scores
 // outgrow it is flagged and recomputed exactly by the merge kernel's slow path (mla_decode.hip: mla_recompute_head).
+// Measured at C4: per tile and wave 5980 cycles -- QK^T 2950 (its 8 x 36 KB of LDS operand reads per tile, one 1 KB
+// fragment per 16-cycle MFMA, are the LDS peak rate exactly), barrier A + piece addresses 1090, softmax + publish 490, barrier B 550,
+// P.V 900; the own DMA wait is 8 cycles (memory is never late).  The kernel ties with the four-wave one (181 vs 183 us).  A
+// K-SPLIT variant (pairs of waves share 32 heads and split the 576 dims on 32x32x16 -- half the LDS traffic -- and exchange half of
+// their partial S^T through LDS; three KV slots) was built and is correct, but 128 accumulators + 72 of Q^T + the 16-register S^T
+// chain leave no room in 256 registers: five Q^T fragments went to scratch, each reload waits vmcnt(0) = every DMA piece in
+// flight, 264 us.  Eight waves double the per-wave overhead registers over the same 512 KB register file; the 4-wave form fits.
 // LDS: ring of 4 KV slots (32 keys x (1056 + 128) B), per-wave block-table rings, exchange buffer = 160 KiB exactly; the two
 // control words live in the pad bytes of the last K row.  K rows are NOT chunk-swapped here (the 16-row operand fetch of the
 // 16x16x32 form is conflict-free under the plain 1056-byte stride, and so is the transposed V fetch).
