@@ -195,7 +195,7 @@ def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank, n_local=0, n_local_
 
 
 # (N = 1: every received row is one of this rank's own tokens, so the whole pull is the token-wise pull_local_kernel)
-PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, true>", "dispatch_pull": "pull_local_kernel<false, true>",
+PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, 1>", "dispatch_pull": "pull_local_kernel<false, true>",
                     "combine_push": "combine_push_kernel", "combine_reduce": "combine_reduce_kernel<false, 8>"}
 
 
