@@ -6,6 +6,8 @@
 //     notify kernel writes, instead of the reference's two .item() calls + a .to(CPU).
 #include "deep_ep.hpp"
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -339,12 +341,9 @@ Buffer::Layout Buffer::run_layout(const at::Tensor &topk_idx, int num_experts)
     return l;
 }
 
-// two persistent words for the cooperative layout launch (zeroed once; the kernel's grid barrier re-arms them itself)
-uint32_t *Buffer::layout_sync_words(const at::Device &dev)
-{
-    if (!layout_sync.defined()) layout_sync = at::zeros({2}, at::dtype(at::kInt).device(dev));
-    return (uint32_t *)layout_sync.data_ptr<int>();
-}
+// two persistent words for the cooperative layout launch: in the rank's control area (zeroed at construction, behind the per-family
+// call counters), so no allocation can happen under a graph capture; the kernel's grid barrier re-arms them itself
+uint32_t *Buffer::layout_sync_words(const at::Device &) { return (uint32_t *)(window + kOffEpochs + 512); }
 
 const Buffer::Layout &Buffer::layout_for(const at::Tensor &topk_idx, int num_experts)
 {
@@ -980,8 +979,37 @@ std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &x, const 
 // kernel of the dispatch/combine chains, on the caller's stream.  Calls = dispatch/combine API calls; the first
 // `skip` are ignored, the next `active` are recorded.  end_profile() drains the events, fills get_profile_summary()
 // and, if a directory was given, writes <dir>/trace_view_rank<r>.json (chrome://tracing "X" events).
+// DEEPEP_ROCTX=1: every kernel chain of dispatch / combine / fused_deep_moe is also a roctx range (host-side push / pop around
+// its launches; `rocprofv3 --marker-trace --kernel-trace` then groups the kernels by the same names get_profile_summary() uses).
+// libroctx64 is looked up at first use, so there is no link-time dependency and no cost when the switch is off.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *on = getenv("DEEPEP_ROCTX");
+        if (!on || !atoi(on)) return;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {      // rocprofv3 listens to the SDK library
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr, pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx()
+{
+    static const Roctx r;
+    return r;
+}
+}  // namespace
+
 ProfScope::ProfScope(Buffer *b, const char *name, hipStream_t st) : b(b), st(st)
 {
+    if (roctx().push) roctx().push(name), marked = true;
     if (!b->profile_now()) return;
     Buffer::ProfRec r{name, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -992,6 +1020,7 @@ ProfScope::ProfScope(Buffer *b, const char *name, hipStream_t st) : b(b), st(st)
 ProfScope::~ProfScope()
 {
     if (idx != (size_t)-1) hipEventRecord(b->profile_recs[idx].b, st);
+    if (marked) roctx().pop();
 }
 
 void Buffer::begin_profile(int64_t skip, int64_t active, const std::string &dir)

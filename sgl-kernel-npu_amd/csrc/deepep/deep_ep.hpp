@@ -164,7 +164,6 @@ private:
         }
     };
     Layout run_layout(const at::Tensor &topk_idx, int num_experts);
-    at::Tensor layout_sync;
     uint32_t *layout_sync_words(const at::Device &dev);
     const Layout &layout_for(const at::Tensor &topk_idx, int num_experts);
 
@@ -268,6 +267,7 @@ struct ProfScope {
     Buffer *b;
     size_t idx = (size_t)-1;
     hipStream_t st;
+    bool marked = false;
     ProfScope(Buffer *b, const char *name, hipStream_t st);
     ~ProfScope();
 };
