@@ -211,12 +211,15 @@ int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t 
  * transport, the own source slab for push; half 0) is read once and stored to each selection (t, k) served by this rank's experts,
  * at output row recv_count[le * W + me] - num_tokens_per_expert[me * L + le] + send_token_idx_small[t, k] -- the rows, scales and
  * triples mi_ep_dispatch_pull_indexed writes for source `my_rank`, which is then called with skip_src = my_rank (not at all when
- * num_ranks == 1).  K-fold fewer reads of the staged rows for the local share of the traffic. */
+ * num_ranks == 1).  K-fold fewer reads of the staged rows for the local share of the traffic.
+ * local_row_out (NULL or int32 [T * K]): entry t * K + k receives the output row of every selection written here -- exactly the
+ * `local_row` table mi_ep_combine_push builds for the rows of own-rank tokens, available a whole expert computation earlier; at
+ * num_ranks == 1 it covers every row, and the combine of that exchange is mi_ep_combine_reduce alone (no push, no signal / wait). */
 int mi_ep_dispatch_pull_local(const void *my_rows, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                               const int32_t *recv_count, const int32_t *num_tokens_per_expert, int num_tokens, int num_topk,
                               int hidden, int num_experts, int num_ranks, int my_rank, int quant_mode, int rows_hint, void *recv_x,
-                              float *recv_x_scales, int32_t *recv_src_idx, const uint64_t *epoch_ctr, size_t parity_stride,
-                              void *stream);
+                              float *recv_x_scales, int32_t *recv_src_idx, int32_t *local_row_out, const uint64_t *epoch_ctr,
+                              size_t parity_stride, void *stream);
 
 /* Push transport of normal dispatch (selectable next to the pull above; the same received bytes).  The sender writes the
  * quantised row of token t ONCE into the window of every rank that owns at least one of the token's experts (the reference

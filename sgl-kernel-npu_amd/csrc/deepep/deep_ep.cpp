@@ -445,12 +445,20 @@ void Buffer::dispatch_pull(const DispatchExchange &ex, int H, int K, int L, int 
     // this rank's own tokens are gathered token by token (their staged row is read once, not once per selection); everybody else's
     // rows row by row.  MI_EP_DISPATCH_LOCAL=0: every row through pull_indexed.
     const bool local = dispatch_local_rows;
+    // At EP = 1 every received row is one of this rank's own: pull_local also records, per (token, selection), the receive row it wrote.
+    // That is the table the combine push would build later, so the combine of this exchange needs no push and no signal / wait at all
+    // (remember_local_rows / intranode_combine).
+    at::Tensor local_row_out;
+    if (local && num_ranks == 1 && combine_local_rows_enabled && ex.num_tokens > 0)
+        local_row_out = at::empty({(int64_t)ex.num_tokens * K}, at::dtype(at::kInt).device(dev));
     if (local && ex.num_tokens > 0)
         MI_EP_CHECK(mi_ep_dispatch_pull_local(ex.src_bases[(size_t)rank], ex.topk_idx.data_ptr(), ex.topk_idx.scalar_type() == at::kInt,
                                               ex.send_token_idx_small.data_ptr<int>(), ex.nt.recv_count.data_ptr<int>(),
                                               ex.num_tokens_per_expert.data_ptr<int>(), ex.num_tokens, K, H, ex.num_experts, (int)num_ranks,
                                               (int)rank, qm, (int)rows_alloc, rx.data_ptr(), quant ? rs.data_ptr<float>() : nullptr,
-                                              src_idx.data_ptr<int>(), epoch_ctr(kDispatch), region_bytes, st));
+                                              src_idx.data_ptr<int>(), local_row_out.defined() ? local_row_out.data_ptr<int>() : nullptr,
+                                              epoch_ctr(kDispatch), region_bytes, st));
+    if (local_row_out.defined()) remember_local_rows(src_idx, local_row_out, ex.num_tokens, K);
     if (!(local && num_ranks == 1))
         MI_EP_CHECK(mi_ep_dispatch_pull_indexed((const void *const *)ex.src_bases.data(), ex.nt.recv_count.data_ptr<int>(),
                                                 ex.nt.pull_offset.data_ptr<int>(), (int)num_ranks, L, H, K, qm, (int)rows_alloc,
@@ -627,6 +635,19 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
         t_start = at::empty({1}, at::dtype(at::kLong).device(x.device()));
         MI_EP_CHECK(mi_ep_timestamp((uint64_t *)t_start.data_ptr(), st));
     }
+    // EP = 1 and the handle comes from a dispatch that recorded its receive rows: the weighted sum reads x in place, nothing to push, nobody
+    // to wait for (same values in the same order as the three-launch form: tests/ep_harness.py runs both against the oracle)
+    if (W == 1 && combine_local_rows_enabled && !combine_send_cost_stats.has_value() && T > 0) {
+        const at::Tensor known = recall_local_rows(src_idx, T, K);
+        if (known.defined()) {
+            at::Tensor out = at::empty({T, H}, x.options());
+            ProfScope ps_(this, "combine_reduce", st);
+            MI_EP_CHECK(mi_ep_combine_reduce(family_base(kCombine), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                             topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, nullptr, nullptr, T, K, H, E,
+                                             out.data_ptr(), nullptr, 0, x.data_ptr(), known.data_ptr<int>(), (int)x.size(0), 0, 1, st));
+            return {out, std::nullopt, std::nullopt};
+        }
+    }
     // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
     // rows whose token lives on this rank stay where they are: the push only records their row number, the reduce reads x
     auto local_row = combine_local_rows(topk_idx);
@@ -747,6 +768,22 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, con
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
     return {combine_finish(topk_idx, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st, x, local_row),
             std::nullopt, std::function<void()>([] {})};
+}
+
+// EP = 1: receive rows recorded by the dispatch, keyed by the handle's recv_src_idx tensor (held, so its address cannot be recycled while the
+// entry lives); a few exchanges may be in flight between their dispatch and their combine (two-batch overlap)
+void Buffer::remember_local_rows(const at::Tensor &src_idx, const at::Tensor &rows, int T, int K)
+{
+    if (local_row_stash.size() >= 8) local_row_stash.erase(local_row_stash.begin());
+    local_row_stash.push_back(LocalRowEntry{src_idx, rows, T, K});
+}
+
+at::Tensor Buffer::recall_local_rows(const at::Tensor &src_idx, int T, int K) const
+{
+    for (auto it = local_row_stash.rbegin(); it != local_row_stash.rend(); ++it)
+        if (it->src_idx.data_ptr() == src_idx.data_ptr() && it->src_idx.numel() >= src_idx.numel() && it->T == T && it->K == K)
+            return it->rows;
+    return at::Tensor();
 }
 
 // second half of a combine: "my rows are pushed" to every owner, wait for every expert rank (ONE single-wave launch, which also

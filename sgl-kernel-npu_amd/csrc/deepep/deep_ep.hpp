@@ -228,6 +228,13 @@ private:
                               const char *reduce_name, hipStream_t st, const at::Tensor &x_local = at::Tensor(),
                               const at::Tensor &local_row = at::Tensor());
     at::Tensor combine_local_rows(const at::Tensor &topk_idx) const;
+    struct LocalRowEntry {
+        at::Tensor src_idx, rows;
+        int T, K;
+    };
+    std::vector<LocalRowEntry> local_row_stash;
+    void remember_local_rows(const at::Tensor &src_idx, const at::Tensor &rows, int T, int K);
+    at::Tensor recall_local_rows(const at::Tensor &src_idx, int T, int K) const;
     // defaults from MI_EP_DISPATCH_LOCAL / MI_EP_COMBINE_LOCAL (0 = off), see set_local_row_paths()
     bool dispatch_local_rows = !(getenv("MI_EP_DISPATCH_LOCAL") && atoi(getenv("MI_EP_DISPATCH_LOCAL")) == 0);
     bool combine_local_rows_enabled = !(getenv("MI_EP_COMBINE_LOCAL") && atoi(getenv("MI_EP_COMBINE_LOCAL")) == 0);

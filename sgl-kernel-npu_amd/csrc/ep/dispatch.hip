@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
     const uint8_t *__restrict__ my_rows, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
     const int32_t *__restrict__ recv_count, const int32_t *__restrict__ tokens_per_expert, int T, int K, int E, int W, int my_rank,
     int payload_bytes, uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales, int32_t *__restrict__ recv_src_idx,
-    int row_capacity, Parity par, int nt_from_row)
+    int row_capacity, Parity par, int nt_from_row, int32_t *__restrict__ local_row_out)
 {
     const int lane = lane_id();
     const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * kPullWaves + threadIdx.x / kWave);
@@ -511,6 +511,8 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
         recv_src_idx[(size_t)r_l * 3 + 0] = my_rank;
         recv_src_idx[(size_t)r_l * 3 + 1] = t;
         recv_src_idx[(size_t)r_l * 3 + 2] = lane;
+        // the receive row of selection (t, k): what mi_ep_combine_push would record for it later (see mi_ep.h)
+        if (local_row_out) local_row_out[(size_t)t * K + lane] = r_l;
     }
 }
 
@@ -676,7 +678,8 @@ extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, con
 extern "C" int mi_ep_dispatch_pull_local(const void *my_rows, const void *topk_idx, int idx_is_i32, const int32_t *send_token_idx_small,
                                          const int32_t *recv_count, const int32_t *num_tokens_per_expert, int T, int K, int H, int E,
                                          int W, int my_rank, int quant_mode, int rows_hint, void *recv_x, float *recv_x_scales,
-                                         int32_t *recv_src_idx, const uint64_t *epoch_ctr, size_t parity_stride, void *stream)
+                                         int32_t *recv_src_idx, int32_t *local_row_out, const uint64_t *epoch_ctr, size_t parity_stride,
+                                         void *stream)
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || E <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E % W || my_rank < 0 ||
         my_rank >= W)
@@ -694,7 +697,7 @@ extern "C" int mi_ep_dispatch_pull_local(const void *my_rows, const void *topk_i
 #define MI_EP_PULL_LOCAL2(I32, NT)                                                                                                  \
     pull_local_kernel<I32, NT><<<blocks, kWave * kPullWaves, 0, (hipStream_t)stream>>>(                                                \
         (const uint8_t *)my_rows, topk_idx, send_token_idx_small, recv_count, num_tokens_per_expert, T, K, E, W, my_rank, payload, \
-        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, par, nt_from)
+        (uint8_t *)recv_x, recv_x_scales, recv_src_idx, rows_hint, par, nt_from, local_row_out)
     if (idx_is_i32) { MI_EP_PULL_LOCAL(true); } else { MI_EP_PULL_LOCAL(false); }
 #undef MI_EP_PULL_LOCAL
 #undef MI_EP_PULL_LOCAL2

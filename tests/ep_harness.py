@@ -35,7 +35,7 @@ def _lib():
     lib.mi_ep_dispatch_index_offset.argtypes = [I, I, I, c_size_t]
     lib.mi_ep_dispatch_stage_compact.argtypes = [V, V, I, V, V, I, I, I, I, I, I, V, c_size_t, V, c_size_t, V]
     lib.mi_ep_dispatch_pull_indexed.argtypes = [V, V, V, I, I, I, I, I, I, c_size_t, V, V, V, V, c_size_t, I, V]
-    lib.mi_ep_dispatch_pull_local.argtypes = [V, V, I, V, V, V, I, I, I, I, I, I, I, I, V, V, V, V, c_size_t, V]
+    lib.mi_ep_dispatch_pull_local.argtypes = [V, V, I, V, V, V, I, I, I, I, I, I, I, I, V, V, V, V, V, c_size_t, V]
     lib.mi_ep_dispatch_push_slab_bytes.restype = c_size_t
     lib.mi_ep_dispatch_push_slab_bytes.argtypes = [c_size_t, I]
     lib.mi_ep_dispatch_stage_push.argtypes = [V, V, I, V, V, I, I, I, I, I, I, I, V, c_size_t, V, c_size_t, V]
@@ -183,10 +183,12 @@ class InProcEP:
                 own = ptr_array([self.send_win[r].data_ptr() + s_ * slab for s_ in range(W)])
                 # the host runtime's form: own tokens token by token (pull_local), the other sources row by row
                 T_r = int(topk_idxs[r].shape[0])
+                # the receive rows of this rank's own selections, as the dispatch knows them (sentinel: untouched entries)
+                disp_local_row = torch.full((max(T_r * K, 1),), -7, dtype=torch.int32, device=self.dev)
                 ck(L_.mi_ep_dispatch_pull_local(c_void_p(self.send_win[r].data_ptr() + r * slab), ptr(topk_idxs[r]),
                                                 int(topk_idxs[r].dtype == torch.int32), ptr(lay[r]["send_token_idx_small"]),
                                                 ptr(tb["recv_count"]), ptr(lay[r]["num_tokens_per_expert"]), T_r, K, H, E, W, r, quant_mode,
-                                                R, ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, st))
+                                                R, ptr(recv_x), ptr(recv_s), ptr(src_idx), ptr(disp_local_row), None, 0, st))
                 if W > 1:
                     ck(L_.mi_ep_dispatch_pull_indexed(own, ptr(tb["recv_count"]), ptr(tb["pull_offset"]), W, L, H, K, quant_mode,
                                                       R, slab, ptr(recv_x), ptr(recv_s), ptr(src_idx), None, 0, r, st))
@@ -198,14 +200,27 @@ class InProcEP:
                                           ptr(recv_x), ptr(recv_s), ptr(src_idx), st))
             outs.append(dict(recv_x=recv_x, recv_x_scales=recv_s, recv_src_idx=src_idx, total=R, layout=lay[r], tables=tb,
                              cnt=cnt))
+            if self.transport == "push":
+                outs[-1]["local_row"] = disp_local_row
         torch.cuda.synchronize()
         for r in range(W):
             assert int(self.status[r][0].item()) == 0, f"rank {r} wait timed out: {self.status[r].tolist()}"
         return outs
 
     # ---- combine (A4 / A6)
-    def combine(self, ys, src_idxs, totals, topk_idxs, topk_weights):
+    def combine(self, ys, src_idxs, totals, topk_idxs, topk_weights, dispatch_local_rows=None):
+        """dispatch_local_rows: per rank, the `local_row` table mi_ep_dispatch_pull_local produced.  W == 1: the combine is then the
+        reduce alone (no push, no signal / wait).  W > 1: the push still runs, and the table it builds for the own-rank rows must equal it."""
         W, E, K, H = self.W, self.E, self.K, self.H
+        if dispatch_local_rows is not None and W == 1 and self.combine_local:
+            T = topk_idxs[0].shape[0]
+            out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
+            if T:
+                ck(lib().mi_ep_combine_reduce(ptr(self.comb_win[0]), ptr(topk_idxs[0]), int(topk_idxs[0].dtype == torch.int32),
+                                              ptr(topk_weights[0]), None, None, T, K, H, E, ptr(out), None, 0, ptr(ys[0]),
+                                              ptr(dispatch_local_rows[0]), int(ys[0].shape[0]), 0, 1, stream_ptr()))
+            torch.cuda.synchronize()
+            return [out]
         L_ = lib()
         self.epoch += 1
         ep = self.epoch
@@ -230,6 +245,12 @@ class InProcEP:
                                        r, W, st))
             outs.append(out)
         torch.cuda.synchronize()
+        if dispatch_local_rows is not None and self.combine_local:
+            for r in range(W):                                   # where the push recorded a row, the dispatch had recorded the same one
+                a, b = local_rows[r][:topk_idxs[r].numel()], dispatch_local_rows[r][:topk_idxs[r].numel()]
+                own = a >= 0
+                assert torch.equal(a[own], b[own]), r
+                assert bool((b[~own] == -7).all()), r            # and nothing else
         return outs
 
     # ---- low-latency dispatch (A5)

@@ -57,8 +57,11 @@ def test_random_normal_dispatch_combine(seed, mode):
             assert np.array_equal(torch_to_bits(g["recv_x"])[:n], w.recv_x[:n])
     ys = [O.per_token_cast_back(w.recv_x, w.recv_x_scales) if quant else w.recv_x for w in want]
     comb_want = O.combine(ys, [w.recv_src_idx for w in want], [w.total_recv for w in want], idxs, ws, E)
+    # push mode: the dispatch already knows the receive row of every own-rank selection (pull_local's local_row table): at W = 1 the combine
+    # is the reduce alone, at W > 1 the table must equal the one the combine push builds
     comb_got = h.combine([dev_bf16(y) for y in ys], [g["recv_src_idx"] for g in got], [g["total"] for g in got],
-                         [to_idx(i) for i in idxs], [torch.from_numpy(w_).cuda() for w_ in ws])
+                         [to_idx(i) for i in idxs], [torch.from_numpy(w_).cuda() for w_ in ws],
+                         dispatch_local_rows=[g["local_row"] for g in got] if mode == "push" else None)
     for r in range(W):
         assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r]), r
 
