@@ -49,7 +49,7 @@ const char *mi_sgl_kernels_version(void);
  * num_splits > 1 or q_heads / kv_heads > 64.  Pass num_splits = 0 to let the library choose (mi_mla_decode_num_splits). */
 size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
 int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
-/* kv groups of more than 64 heads have two kernel forms: 4 waves per workgroup (one per SIMD, the default) and 8 (two per SIMD).
+/* kv groups of more than 64 heads have two kernel forms: 8 waves per workgroup (two per SIMD, the default) and 4 (one per SIMD).
  * waves = 4 / 8 forces one for the calls that follow, 0 returns to the default (or MI_MLA_WIDE8).  Process-wide, not thread-safe:
  * a test / tuning knob, results do not depend on it beyond fp32 summation order. */
 int mi_mla_decode_select_wide(int waves);

@@ -231,6 +231,13 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
 {
     extern __shared__ __attribute__((aligned(16))) int32_t sm[];
     const int n = W * (E + 1);
+#ifdef NOTIFY_TIMING
+    uint64_t tk[8]; int ntk = 0;
+#define NT_TICK() tk[ntk++] = wall_clock64();
+#else
+#define NT_TICK()
+#endif
+    NT_TICK()
     // device-resident epoch (graph-replayable calls): this call = counter + 1, and the notify granules ping-pong by its parity
     const uint64_t ep64 = epoch_ctr ? *epoch_ctr + 1 : 0;
     const uint32_t notify_epoch = epoch_ctr ? (uint32_t)ep64 : notify_epoch_in;
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
         }
         if (threadIdx.x < W) sys_store_u64((uint64_t *)post.flags.p[threadIdx.x] + me, flag_epoch);
     }
+    NT_TICK()
     const uint64_t t0 = ticks_100mhz();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         uint64_t g;
@@ -270,12 +278,18 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
         // (reference cam_moe_dispatch_normal.h:580-602)
         if (wait_cost_stats) atomicAdd(wait_cost_stats + threadIdx.x, (int32_t)((ticks_100mhz() - t0) / 100));
     }
+    NT_TICK()
     __threadfence();
     __syncthreads();
+    NT_TICK()
     // every thread has read the counter (before the barrier above); later kernels of this call read it with add = 0
     if (epoch_bump && threadIdx.x == 0) *epoch_bump = ep64;
     notify_tables_body(cnt, W, E, me, relative_pull, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset,
                        srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs, pull_offset, summary_host, sm);
+#ifdef NOTIFY_TIMING
+    NT_TICK()
+    if (threadIdx.x == 0) for (int i = 0; i < ntk; ++i) ((uint64_t *)(cnt + ((n + 17) & ~1)))[i] = tk[i];
+#endif
 }
 
 }  // namespace mi_ep

@@ -532,10 +532,11 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     // in-kernel merge is correct (MI_MLA_INLINE_MERGE=2 enables it) but measured 202 us against 195 us for the separate
     // merge launch at C4: the agent-scope release / acquire each pair needs costs an L2 write-back and an L2 invalidate.
     static const int inline_splits = getenv("MI_MLA_INLINE_MERGE") ? atoi(getenv("MI_MLA_INLINE_MERGE")) : 1;
-    // kv groups of more than 64 heads: the four-wave wide kernel (one wave per SIMD; default) or the eight-wave one (two per SIMD;
-    // MI_MLA_WIDE8=1 or mi_mla_decode_select_wide(8)) -- same results to the bit pattern of the split partials' sum order, measured
-    // within 1-2 % of each other at BASELINE C4
-    static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) ? 8 : 4) : 4;
+    // kv groups of more than 64 heads: the eight-wave wide kernel (two waves per SIMD; default) or the four-wave one (one per SIMD;
+    // MI_MLA_WIDE8=0 or mi_mla_decode_select_wide(4)) -- same numerics contract, both under the whole test matrix; alternating in one
+    // process at BASELINE C4 the eight-wave form is 1 % faster on full sequences (178.5 vs 180.5 us with the merge) and 4 % on ragged ones
+    // (135.9 vs 141.4 us), DESIGN section 4.1
+    static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) ? 8 : 4) : 8;
     const bool wide8 = (g_wide_variant ? g_wide_variant : wide_env) == 8;
     p.inline_merge = wide && (wide8 ? num_splits == 1 : (num_splits <= inline_splits && num_splits <= 2));
     p.batch = batch, p.q_heads = q_heads, p.kv_heads = kv_heads, p.group = q_heads / kv_heads, p.page_size = page_size;

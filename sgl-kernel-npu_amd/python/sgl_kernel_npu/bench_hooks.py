@@ -50,10 +50,10 @@ def bench_mla_decode(steps=30, warmup=5):
         "host_ms_per_step": wall * 1e3, "dtype": "bf16",
         "config": {"workload": "MLA paged decode, bs=128, q_heads=128, kv_heads=1, head_dim=576 (512+64), page_size=64, "
                                "seqlen=4096 (BASELINE C4)"},
-        "roofline": {"bound": "hbm", "kernel": "mla_decode_wide_kernel + mla_merge_kernel (2 KV splits)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "mla_decode_wide8_kernel + mla_merge_kernel (2 KV splits)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes": kv_bytes + io_bytes, "avg_launch_us": dev_ms * 1e3},
-        "pmc_kernels": ["mla_decode_wide_kernel<true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
+        "pmc_kernels": ["mla_decode_wide8_kernel<true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
         "mfma": {"achieved_TFLOPs": flops / (dev_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                  "frac": flops / (dev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
     }
