@@ -280,6 +280,16 @@ int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int idx_is_i32, 
                            int num_tokens, int num_topk, int hidden, int num_experts, int num_ranks, int my_rank,
                            int max_tokens, int quant_mode, void *const *peer_rows_host, const uint64_t *epoch_ctr,
                            size_t parity_stride, void *stream);
+/* mi_ep_dispatch_layout + mi_ep_ll_dispatch_send in ONE launch (the form the host runtime uses for low-latency dispatch, <= 1024
+ * tokens, num_experts <= 1024): the first workgroup computes the layout tables of the batch (all five outputs are written, as by
+ * mi_ep_dispatch_layout: the count exchange needs num_tokens_per_expert); the other workgroups are the send waves, one per
+ * (token, selection), which find their slab position themselves -- the number of earlier (t, k) pairs with the same expert, counted in
+ * an LDS copy of the routing table -- so no workgroup waits for another one.  Same rows, tables and bytes as the two separate calls. */
+int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx, int idx_is_i32, int num_tokens, int num_topk, int hidden,
+                                  int num_experts, int num_ranks, int my_rank, int max_tokens, int quant_mode,
+                                  void *const *peer_rows_host, const uint64_t *epoch_ctr, size_t parity_stride,
+                                  int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert, int32_t *is_token_in_rank,
+                                  int32_t *send_token_idx_small, int32_t *send_data_offset, void *stream);
 int mi_ep_ll_post_counts(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int num_experts,
                          int num_ranks, int my_rank, uint32_t epoch, void *stream);
 int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint32_t epoch, int num_ranks,

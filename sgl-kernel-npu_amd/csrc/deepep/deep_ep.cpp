@@ -713,13 +713,31 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     auto packed_recv_count = at::empty({L}, at::dtype(at::kLong).device(dev));
     const int count_type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
     hipStream_t st = cur_stream();
-    const Layout lay = run_layout(topk_idx, E);
     uint64_t *ctr = epoch_ctr(kLLDispatch);
     auto row_peers = peer_family_bases(kLLDispatch);
-    { ProfScope ps_(this, "ll_dispatch_send", st);
-      MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
-                                         lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm, row_peers.data(), ctr,
-                                         region_bytes, st)); }
+    // Layout + send in ONE launch (MI_EP_LL_FUSED=0: the two launches): the layout workgroup and the send waves of the same kernel run
+    // side by side; a send wave counts its slab position itself in an LDS copy of the routing table (mi_ep_ll_dispatch_layout_send).
+    static const bool fused_send = get_value_from_env("MI_EP_LL_FUSED", 1) != 0;
+    Layout lay;
+    if (fused_send && T <= 1024 && (size_t)16 * E <= 16384 && E % 2 == 0) {
+        lay.T = T, lay.K = K, lay.E = E;
+        lay.num_tokens_per_expert = at::empty({E}, i32);
+        lay.num_tokens_per_rank = at::empty({W}, i32);
+        lay.is_token_in_rank = at::empty({T, W}, i32);
+        lay.send_token_idx_small = at::empty({T, K}, i32);
+        lay.send_data_offset = at::empty({E}, i32);
+        ProfScope ps_(this, "ll_dispatch_layout_send", st);
+        MI_EP_CHECK(mi_ep_ll_dispatch_layout_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, T, K, H, E, W, (int)rank,
+                                                  MT, qm, row_peers.data(), ctr, region_bytes, lay.num_tokens_per_rank.data_ptr<int>(),
+                                                  lay.num_tokens_per_expert.data_ptr<int>(), lay.is_token_in_rank.data_ptr<int>(),
+                                                  lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), st));
+    } else {
+        lay = run_layout(topk_idx, E);
+        ProfScope ps_(this, "ll_dispatch_send", st);
+        MI_EP_CHECK(mi_ep_ll_dispatch_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt,
+                                           lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm, row_peers.data(), ctr,
+                                           region_bytes, st));
+    }
     auto cnt_peers = peer_ptrs((size_t)kOffLLCounts);
     // rows the output tensors hold (and src_info / 3): the packing kernel never writes past them, whatever the counts say
     const int rows_capacity = (int)std::min<int64_t>(num_max_tokens, max_size / 3);

@@ -17,7 +17,10 @@
 // writes n_recv*(H+16).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ep_common.h"
+#include "layout_dev.h"
 
 namespace mi_ep {
 
@@ -84,19 +87,47 @@ __device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const 
     }
 }
 
+// Self-routing (low-latency dispatch in one launch, ll_layout_send_kernel): a send wave finds the slab position of ITS (token, selection)
+// itself -- the number of earlier pairs, in row-major (t, k) order, that selected the same expert, which is what the layout's
+// send_token_idx_small holds -- from a copy of the batch's routing table in LDS (<= 8192 ids; every workgroup loads it once, one id
+// per thread), 64 pairs per step: compare, ballot, popcount.  No wave waits for the layout workgroup; the row is loaded and quantised
+// first, so the count runs under the row's memory latency.
+struct LateIdx {
+    const int32_t *ids;        // LDS: expert id of pair p = t * K + k, -1 = no selection; NULL: the layout ran in an earlier launch
+    int kpart;                 // the selection this wave sends
+};
+template <bool I32, bool LATE>
+__device__ __forceinline__ void route_token(const LLGeom &ll, const void *topk_idx, const int32_t *idx_small, const int32_t *send_off, int t,
+                                            int K, int E, int my_rank, const LateIdx &late, long long &e_l, int &slot_l, int &dst_l)
+{
+    const int lane = lane_id();
+    if (LATE) {
+        const int p = t * K + late.kpart;                        // wave-uniform
+        const int e = late.ids[p];
+        if (e < 0) return;
+        int before = 0;
+        for (int c = 0; c < p; c += kWave) {
+            const int i = c + lane;
+            before += __popcll(__ballot(i < p && late.ids[i] == e));
+        }
+        if (lane == late.kpart) route(ll, e, before, send_off, my_rank, slot_l, dst_l);
+        return;
+    }
+    if (lane < K && e_l >= 0) route(ll, (int)e_l, idx_small[(long long)t * K + lane], send_off, my_rank, slot_l, dst_l);
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage, INT8: item = 16 consecutive elements = two 16-B loads -> one 16-B store
 // ---------------------------------------------------------------------------------------------
 // QM = MI_EP_QUANT_INT8 / MI_EP_QUANT_INT8_NOEPS / MI_EP_QUANT_FP8_E4M3 (one byte per element each, same row layout)
-template <bool I32, int QM>
-__global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
+template <bool I32, int QM, bool LATE>
+__device__ __forceinline__ void stage_int8_body(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
-    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
-    PushGeom pg, Parity par)
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, const PeerPtrs &dsts, const LLGeom &ll, int ksplit,
+    size_t idx_off, const PushGeom &pg, const Parity &par, const int wid, const LateIdx &late)
 {
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
-    const int wid = blockIdx.x * kStageWaves + threadIdx.x / kWave;
     const int t = wid / ksplit, kpart = wid - t * ksplit;
     if (t >= T) return;
     const int nitems = H / 16;
@@ -121,9 +152,9 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     int slot_l = 0, dst_l = 0;
     if (lane < K) {
         e_l = ld_idx<I32>(topk_idx, (long long)t * K + lane);
-        if (e_l >= 0 && e_l < E) route(ll, (int)e_l, idx_small[(long long)t * K + lane], send_off, my_rank, slot_l, dst_l);
-        else e_l = -1;
+        if (e_l < 0 || e_l >= E) e_l = -1;
     }
+    if (!LATE) route_token<I32, false>(ll, topk_idx, idx_small, send_off, t, K, E, my_rank, late, e_l, slot_l, dst_l);
     const unsigned long long vmask = __ballot(e_l >= 0);
     if (vmask == 0ull) return;      // token selects nothing: no row is produced
     // |x| of a bf16 orders like its bit pattern as an unsigned 16-bit integer, so the row maximum is taken on the packed words
@@ -191,6 +222,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
                 q[it][h * 2 + jj] = p0 | p1;
             }
     }
+    if (LATE) route_token<I32, true>(ll, topk_idx, idx_small, send_off, t, K, E, my_rank, late, e_l, slot_l, dst_l);
     if (idx_off) {
         // compact staging (normal-mode pull transport): the row is written ONCE at slot t; the expert-sorted index tells the
         // receivers which token row each of their rows is (K-fold less staging traffic than one copy per (t, k)).
@@ -224,16 +256,25 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     }
 }
 
-// stage, BF16 (no quantisation): item = one 16-B chunk
-template <bool I32>
-__global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
+template <bool I32, int QM>
+__global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
     const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
     PushGeom pg, Parity par)
 {
+    stage_int8_body<I32, QM, false>(x, topk_idx, idx_small, send_off, T, K, H, E, my_rank, dsts, ll, ksplit, idx_off, pg, par,
+                                    (int)(blockIdx.x * kStageWaves + threadIdx.x / kWave), LateIdx{nullptr, 0});
+}
+
+// stage, BF16 (no quantisation): item = one 16-B chunk
+template <bool I32, bool LATE>
+__device__ __forceinline__ void stage_bf16_body(
+    const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, const PeerPtrs &dsts, const LLGeom &ll, int ksplit,
+    size_t idx_off, const PushGeom &pg, const Parity &par, const int wid, const LateIdx &late)
+{
     const int lane = lane_id();
     // ksplit waves share a token (decode-size batches: every wave re-reads the row from L2 and writes K / ksplit copies)
-    const int wid = blockIdx.x * kStageWaves + threadIdx.x / kWave;
     const int t = wid / ksplit, kpart = wid - t * ksplit;
     if (t >= T) return;
     const int nitems = H / 8;
@@ -242,9 +283,9 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     int slot_l = 0, dst_l = 0;
     if (lane < K) {
         e_l = ld_idx<I32>(topk_idx, (long long)t * K + lane);
-        if (e_l >= 0 && e_l < E) route(ll, (int)e_l, idx_small[(long long)t * K + lane], send_off, my_rank, slot_l, dst_l);
-        else e_l = -1;
+        if (e_l < 0 || e_l >= E) e_l = -1;
     }
+    if (!LATE) route_token<I32, false>(ll, topk_idx, idx_small, send_off, t, K, E, my_rank, late, e_l, slot_l, dst_l);
     const unsigned long long vmask = __ballot(e_l >= 0);
     if (vmask == 0ull) return;
     const u32x4 *src = (const u32x4 *)(x + (size_t)t * H);
@@ -255,6 +296,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
         const int item = it * kWave + lane;
         if (item < nitems) raw[it] = src[item];
     }
+    if (LATE) route_token<I32, true>(ll, topk_idx, idx_small, send_off, t, K, E, my_rank, late, e_l, slot_l, dst_l);
     if (idx_off) {                                  // compact / push staging, see stage_int8_kernel
         stage_token_rows(pg, dsts, parity_off(par), idx_off, my_rank, t, K, e_l, slot_l, send_off, [&](uint8_t *base) {
             uint8_t *row = base + (size_t)t * stride;
@@ -282,6 +324,52 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
         }
         if (lane == 0) *(u32x4 *)(row + (size_t)H * 2) = u32x4{0u, (uint32_t)t, (uint32_t)k, (uint32_t)my_rank};
     }
+}
+template <bool I32>
+__global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
+    const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, const int32_t *__restrict__ idx_small,
+    const int32_t *__restrict__ send_off, int T, int K, int H, int E, int my_rank, PeerPtrs dsts, LLGeom ll, int ksplit, size_t idx_off,
+    PushGeom pg, Parity par)
+{
+    stage_bf16_body<I32, false>(x, topk_idx, idx_small, send_off, T, K, H, E, my_rank, dsts, ll, ksplit, idx_off, pg, par,
+                                (int)(blockIdx.x * kStageWaves + threadIdx.x / kWave), LateIdx{nullptr, 0});
+}
+
+// Low-latency dispatch, layout + send in ONE launch of 1024-thread workgroups: workgroup 0 computes the layout tables of the batch
+// (<= 1024 tokens: one workgroup of layout_small_body; the count exchange that follows needs num_tokens_per_expert, the handle the rest);
+// workgroups 1.. are the send waves, one per (token, selection), which route themselves from an LDS copy of the routing table (above).
+// No workgroup waits for any other.  Same rows, tables and bytes as mi_ep_dispatch_layout + mi_ep_ll_dispatch_send.
+constexpr int kLLSendWaves = 4;
+template <bool I32, int QM, int UT>
+__global__ __launch_bounds__(1024) void ll_layout_send_kernel(
+    const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, int T, int K, int H, int E, int W, int nbits, int my_rank, PeerPtrs dsts,
+    LLGeom ll, Parity par, int32_t *__restrict__ num_tokens_per_rank, int32_t *__restrict__ num_tokens_per_expert,
+    int32_t *__restrict__ is_token_in_rank, int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset, int send_waves)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    if (blockIdx.x == 0) {
+        layout_small_body<I32, UT>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank,
+                                   send_token_idx_small, send_data_offset, nullptr, nullptr, smem, 1, 0);
+        return;
+    }
+    const int npairs = T * K;
+    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+        const long long e = ld_idx<I32>(topk_idx, i);
+        smem[i] = (e >= 0 && e < E) ? (int32_t)e : -1;
+    }
+    __syncthreads();
+    // kLLSendWaves send waves per workgroup (the rest only helped to load the table): 1024 pairs on 64 workgroups of 16 sending waves left three
+    // quarters of the CUs idle and ran 12.4 us; spread over 256 workgroups the rows stream from all of them
+    const int wave = (int)(threadIdx.x / kWave);
+    if (wave >= send_waves) return;
+    const int wid = (int)(blockIdx.x - 1) * send_waves + wave;
+    if (wid >= npairs) return;
+    const LateIdx late{smem, wid % K};
+    if (QM == MI_EP_QUANT_NONE)
+        stage_bf16_body<I32, true>(x, topk_idx, nullptr, nullptr, T, K, H, E, my_rank, dsts, ll, K, (size_t)0, PushGeom{0, 0}, par, wid, late);
+    else
+        stage_int8_body<I32, QM == MI_EP_QUANT_NONE ? MI_EP_QUANT_INT8 : QM, true>(x, topk_idx, nullptr, nullptr, T, K, H, E, my_rank, dsts, ll, K,
+                                                                                    (size_t)0, PushGeom{0, 0}, par, wid, late);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -827,6 +915,67 @@ extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int i
             return MI_EP_EINVAL;
     }
 #undef MI_EP_STAGE
+    return launch_status();
+}
+
+extern "C" int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx, int idx_is_i32, int T, int K, int H, int E, int W, int my_rank,
+                                            int max_tokens, int quant_mode, void *const *peer_rows_host, const uint64_t *epoch_ctr,
+                                            size_t parity_stride, int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
+                                            int32_t *is_token_in_rank, int32_t *send_token_idx_small, int32_t *send_data_offset,
+                                            void *stream)
+{
+    if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0 || W <= 0 ||
+        W > MI_EP_MAX_RANKS || E % W || T > max_tokens || !peer_rows_host || !num_tokens_per_rank || !num_tokens_per_expert ||
+        !send_data_offset)
+        return MI_EP_EINVAL;
+    // one layout workgroup: at most 16 units of 16 tokens (<= 256 tokens) or of 64 tokens (<= 1024), and the histograms must fit its LDS
+    const int ut = T <= 256 ? 16 : kLayoutUnitTokens;
+    if ((T + ut - 1) / ut > 16 || (size_t)16 * E > 16384 || ((16 * E) & 1)) return MI_EP_EINVAL;
+    if (T > 0 && (!x || !topk_idx || !is_token_in_rank || !send_token_idx_small)) return MI_EP_EINVAL;
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_rows_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = peer_rows_host[i];
+    }
+    const LLGeom ll{E / W, W, max_tokens};
+    const Parity par = make_parity(epoch_ctr, 1, parity_stride);
+    hipStream_t s = (hipStream_t)stream;
+    int nbits = 1;
+    while ((1 << nbits) < E) ++nbits;
+    static const int send_waves_env = getenv("MI_EP_LL_SEND_WAVES") ? atoi(getenv("MI_EP_LL_SEND_WAVES")) : 0;
+    const int send_waves = send_waves_env >= 1 && send_waves_env <= 16 ? send_waves_env : kLLSendWaves;
+    const int blocks = 1 + (int)(((long long)T * K + send_waves - 1) / send_waves);       // the layout workgroup + the send workgroups
+    // dynamic LDS: the layout workgroup's tables, or the send workgroups' copy of the routing table (int32 per pair)
+    const size_t lds = std::max(layout_small_lds_bytes(E, W, ut), (size_t)T * K * sizeof(int32_t));
+    const uint16_t *xp = (const uint16_t *)x;
+    static bool attr_set = false;
+#define MI_EP_LLS_ATTR(I32, QM, UT) (void)hipFuncSetAttribute((const void *)ll_layout_send_kernel<I32, QM, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
+    if (!attr_set) {
+        MI_EP_LLS_ATTR(true, MI_EP_QUANT_NONE, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_NONE, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_NONE, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_NONE, 64);
+        MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8, 64);
+        MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8_NOEPS, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8_NOEPS, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8_NOEPS, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8_NOEPS, 64);
+        MI_EP_LLS_ATTR(true, MI_EP_QUANT_FP8_E4M3, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_FP8_E4M3, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_FP8_E4M3, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_FP8_E4M3, 64);
+        attr_set = true;
+    }
+#undef MI_EP_LLS_ATTR
+#define MI_EP_LLS(I32, QM, UT)                                                                                                         \
+    ll_layout_send_kernel<I32, QM, UT><<<blocks, 1024, lds, s>>>(xp, topk_idx, T, K, H, E, W, nbits, my_rank, pp, ll, par,              \
+                                                                  num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank,         \
+                                                                  send_token_idx_small, send_data_offset, send_waves)
+#define MI_EP_LLS_Q(QM)                                                                                       \
+    do {                                                                                                      \
+        if (ut == 16) { if (idx_is_i32) MI_EP_LLS(true, QM, 16); else MI_EP_LLS(false, QM, 16); }             \
+        else { if (idx_is_i32) MI_EP_LLS(true, QM, 64); else MI_EP_LLS(false, QM, 64); }                      \
+    } while (0)
+    switch (quant_mode) {
+        case MI_EP_QUANT_NONE: MI_EP_LLS_Q(MI_EP_QUANT_NONE); break;
+        case MI_EP_QUANT_INT8: MI_EP_LLS_Q(MI_EP_QUANT_INT8); break;
+        case MI_EP_QUANT_INT8_NOEPS: MI_EP_LLS_Q(MI_EP_QUANT_INT8_NOEPS); break;
+        case MI_EP_QUANT_FP8_E4M3: MI_EP_LLS_Q(MI_EP_QUANT_FP8_E4M3); break;
+        default: return MI_EP_EINVAL;
+    }
+#undef MI_EP_LLS_Q
+#undef MI_EP_LLS
     return launch_status();
 }
 

@@ -45,6 +45,8 @@ def _lib():
     lib.mi_ep_combine_pack.argtypes = [V, V, I, I, I, I, V, V, V]
     lib.mi_ep_combine_pack.restype = c_int
     lib.mi_ep_ll_dispatch_send.argtypes = [V, V, I, V, I, I, I, I, I, I, I, I, V, V, c_size_t, V]
+    lib.mi_ep_ll_dispatch_layout_send.argtypes = [V, V, I, I, I, I, I, I, I, I, I, V, V, c_size_t, V, V, V, V, V, V]
+    lib.mi_ep_ll_dispatch_layout_send.restype = c_int
     lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
     lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, I, V, I, V]
     for n in ("mi_ep_dispatch_layout mi_ep_signal mi_ep_wait mi_ep_notify_post mi_ep_notify_wait mi_ep_notify_tables "
@@ -263,11 +265,27 @@ class InProcEP:
         row_ptrs = ptr_array([t.data_ptr() for t in self.ll_win])
         cnt_ptrs = ptr_array([t.data_ptr() for t in self.ll_counts])
         lay = []
+        # every other call takes the one-launch form (layout workgroup + send waves, mi_ep_ll_dispatch_layout_send) when the batch fits it;
+        # its layout tables must equal the stand-alone layout's, its rows are checked by the caller like any other
+        _SYNC["ll"] = _SYNC.get("ll", 0) + 1                  # alternates over the whole test session, whatever harness object is used
+        fused = (_SYNC["ll"] & 1) == 0 and max(x.shape[0] for x in xs) <= 1024 and 16 * E <= 16384 and E % 2 == 0
         for r in range(W):
             T = xs[r].shape[0]
             lay.append(layout(topk_idxs[r], E, W))
-            ck(L_.mi_ep_ll_dispatch_send(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
-                                         ptr(lay[r]["send_token_idx_small"]), T, K, H, E, W, r, MT, quant_mode, row_ptrs, None, 0, st))
+            if fused:
+                i32 = dict(dtype=torch.int32, device=self.dev)
+                f = dict(num_tokens_per_rank=torch.empty(W, **i32), num_tokens_per_expert=torch.empty(E, **i32),
+                         is_token_in_rank=torch.empty((T, W), **i32), send_token_idx_small=torch.full((T, K), -9, **i32),
+                         send_data_offset=torch.empty(E, **i32))
+                ck(L_.mi_ep_ll_dispatch_layout_send(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32), T, K, H, E, W, r, MT,
+                                                    quant_mode, row_ptrs, None, 0, ptr(f["num_tokens_per_rank"]), ptr(f["num_tokens_per_expert"]),
+                                                    ptr(f["is_token_in_rank"]), ptr(f["send_token_idx_small"]), ptr(f["send_data_offset"]), st))
+                torch.cuda.synchronize()
+                for k_ in f:
+                    assert torch.equal(f[k_], lay[r][k_]), (k_, r)
+            else:
+                ck(L_.mi_ep_ll_dispatch_send(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32),
+                                             ptr(lay[r]["send_token_idx_small"]), T, K, H, E, W, r, MT, quant_mode, row_ptrs, None, 0, st))
             ck(L_.mi_ep_ll_post_counts(cnt_ptrs, ptr(lay[r]["num_tokens_per_expert"]), E, W, r, ep, st))
         outs = []
         M = W * MT * min(K, L)
