@@ -256,7 +256,7 @@ class InProcEP:
         return outs
 
     # ---- low-latency dispatch (A5)
-    def ll_dispatch(self, xs, topk_idxs, quant_mode, count_type=1):
+    def ll_dispatch(self, xs, topk_idxs, quant_mode, count_type=1, fused=None):
         W, E, L, K, H, MT = self.W, self.E, self.L, self.K, self.H, self.max_tokens
         L_ = lib()
         self.epoch += 1
@@ -265,10 +265,11 @@ class InProcEP:
         row_ptrs = ptr_array([t.data_ptr() for t in self.ll_win])
         cnt_ptrs = ptr_array([t.data_ptr() for t in self.ll_counts])
         lay = []
-        # every other call takes the one-launch form (layout workgroup + send waves, mi_ep_ll_dispatch_layout_send) when the batch fits it;
-        # its layout tables must equal the stand-alone layout's, its rows are checked by the caller like any other
+        # fused=True: the one-launch form (layout workgroup + send waves, mi_ep_ll_dispatch_layout_send) when the batch fits it -- its layout
+        # tables must equal the stand-alone layout's, its rows are checked by the caller like any other; fused=None: every other call
         _SYNC["ll"] = _SYNC.get("ll", 0) + 1                  # alternates over the whole test session, whatever harness object is used
-        fused = (_SYNC["ll"] & 1) == 0 and max(x.shape[0] for x in xs) <= 1024 and 16 * E <= 16384 and E % 2 == 0
+        fits = max(x.shape[0] for x in xs) <= 1024 and 16 * E <= 16384 and E % 2 == 0
+        fused = ((_SYNC["ll"] & 1) == 0 if fused is None else bool(fused)) and fits
         for r in range(W):
             T = xs[r].shape[0]
             lay.append(layout(topk_idxs[r], E, W))

@@ -154,25 +154,30 @@ def test_combine_without_weights_uses_ones():
 
 
 LL_CASES = [(2, 16, 128, 2, 8, 0.0), (8, 128, 7168, 8, 256, 0.0), (8, 128, 512, 8, 64, 0.3), (4, 1, 256, 4, 16, 0.0),
-            (8, 2, 1024, 8, 8, 0.0)]
+            (8, 2, 1024, 8, 8, 0.0),
+            # edges of the one-launch send: one selection per token, one local expert per rank, a rank without tokens (T = 3: rank 1 has none),
+            # the largest batch it takes (1024 tokens), more experts than a 1024-thread workgroup has lanes
+            (2, 33, 256, 1, 8, 0.0), (4, 20, 512, 4, 4, 0.2), (2, 3, 128, 2, 4, 0.0), (2, 1024, 128, 8, 64, 0.1), (2, 64, 256, 8, 1024, 0.0)]
 
 
 @pytest.mark.parametrize("W,T,H,K,E,drop", LL_CASES)
 @pytest.mark.parametrize("quant", [False, True])
-@pytest.mark.parametrize("count_type", [1, 0])
-def test_low_latency_dispatch_combine_bit_exact(W, T, H, K, E, drop, quant, count_type):
+@pytest.mark.parametrize("count_type,fused", [(1, True), (1, False), (0, True)])
+def test_low_latency_dispatch_combine_bit_exact(W, T, H, K, E, drop, quant, count_type, fused):
     import ep_harness as Hh
     rng = np.random.default_rng(W * 77 + T)
     Ts = [T] * W
     if T > 1:
         Ts[0] = T - 1                                   # fewer tokens than num_max_dispatch_tokens_per_rank
+    if T == 3:
+        Ts[1] = 0                                       # a rank that sends nothing
     xs = [rand_bits(rng, (t, H), 2.0) for t in Ts]
     idxs = [make_topk(rng, t, K, E, drop) for t in Ts]
     ws = [np.abs(rng.standard_normal((t, K))).astype(np.float32) for t in Ts]
     h = Hh.InProcEP(W, E, T, K, H)
     qm = Hh.QUANT_INT8_NOEPS if quant else Hh.QUANT_NONE
     # the reference casts topk_idx to int32 for LL (low_latency_strategy.py:57)
-    got = h.ll_dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).int().cuda() for i in idxs], qm, count_type)
+    got = h.ll_dispatch([dev_bf16(x) for x in xs], [torch.from_numpy(i).int().cuda() for i in idxs], qm, count_type, fused=fused)
     want = O.low_latency_dispatch(xs, idxs, T, E, quant, expert_token_nums_type=count_type)
     for r in range(W):
         g, w = got[r], want[r]
