@@ -373,6 +373,17 @@ __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restric
 // the weight DMA 28.3 us, without the LDS operand reads 24.4, without the activation loads 24.4 -- it is not waiting for memory (a
 // plain stream over 128 CUs reaches 5.6 TB/s, tools/probes/stream_probe.hip); what is left is eight waves meeting at a barrier every
 // 48 MFMAs.  4 waves x 32 rows (every weight fragment feeding two MFMAs, one wave per SIMD) ran 48 us.
+// Round 3: 64-row workgroups (HALF below: 256 workgroups at 128 tokens x 128 heads) 26.6 -> 22.9 us; stamps of one wave (-DF_TIMING,
+// tools/probes/time_mla_pre_tail.py; shader clocks, 64-row / 128-row form): first chunk landed for every wave 7.7k / 7.2k -- all CUs ask
+// for their first 96 KB at once, 24 MB at HBM rate --, the other five chunks 13.0k / 14.6k, dequant + y tile + RoPE 4.9k / 6.0k,
+// phase B 9.0k / 17.2k; total 36k / 46k cycles.  Phase A does not depend on the MFMA or LDS volume per workgroup (halved by HALF, same
+// 22k cycles): after the cold start it runs at one chunk per ~2.6k cycles against 0.4k / 0.8k of MFMA issue per SIMD.
+#ifdef F_TIMING
+__device__ unsigned long long g_f_dbg[4][64];
+#define F_STAMP(i) if (tid == 0 && blockIdx.x < 4 && blockIdx.z == 0) g_f_dbg[blockIdx.x][i] = __builtin_amdgcn_s_memtime();
+#else
+#define F_STAMP(i)
+#endif
 constexpr int kF_Chunk = 256, kF_NChunks = kK2 / kF_Chunk, kF_Rows = 192, kF_Stage = kF_Rows * kF_Chunk;      // 48 KB
 constexpr int kF_YRow = 192 * 2;                                       // y tile row (bytes); the 16 nope chunks of a row are XOR-swizzled
 constexpr int kF_OutRow = 128 * 2 + 16;
@@ -388,7 +399,11 @@ __device__ __forceinline__ int ytile_off(int row, int col)
     return row * kF_YRow + pos * 16 + (col & 7) * 2;
 }
 
-template <bool BF16>
+// HALF: the workgroup takes 64 token rows instead of 128 -- wave w = row tile w & 3, column half w >> 2 (6 of the 12 GEMM2 column tiles,
+// 2 of the 4 column tiles of every wuk_t eighth).  Same weight stream per workgroup, half the MFMAs and half the LDS operand reads:
+// 128 tokens x 128 heads become 256 workgroups (every CU) instead of 128, and batches of <= 64 tokens stop multiplying padding rows.
+// Accumulation order per output element is unchanged, so both forms are bit-identical.
+template <bool BF16, bool HALF>
 __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__restrict__ A, int M, const int8_t *__restrict__ W, int Hq,
                                                             const int32_t *__restrict__ bias, const float *__restrict__ descale,
                                                             const float *__restrict__ row_scale, const uint16_t *__restrict__ wuk_t,
@@ -402,7 +417,10 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // ring [3][192][256]; slot 0 later: y tile, then output tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x, m0 = blockIdx.z * kBM + wave * 16;
+    constexpr int NT = HALF ? 6 : 12;                       // GEMM2 column tiles of this wave
+    const int rt = HALF ? (wave & 3) : wave, ch = HALF ? (wave >> 2) : 0;      // row tile inside the workgroup, column half
+    const int nt0 = ch * NT;
+    const int h = blockIdx.x, m0 = blockIdx.z * (HALF ? 64 : kBM) + rt * 16;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
     uint8_t *ytile = lds + kF_Stage;                       // slot 1
     const int8_t *wh = W + (size_t)h * kF_Rows * kK2;
@@ -438,12 +456,12 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     auto eighth_at = [&](int e) { return e < 3 ? e * kEighth : e < 6 ? 2 * kF_Stage + (e - 3) * kEighth : (e - 6) * kEighth; };
     // dequant operands of this lane's 12 columns and 4 rows: requested before anything else (behind the DMA stream their loads would
     // wait for every piece in flight)
-    float dsc[12], rsc[4];
-    int32_t bsv[12];
+    float dsc[NT], rsc[4];
+    int32_t bsv[NT];
 #pragma unroll
-    for (int nt = 0; nt < 12; ++nt) {
-        dsc[nt] = descale[h * kF_Rows + nt * 16 + c16];
-        bsv[nt] = bias ? bias[h * kF_Rows + nt * 16 + c16] : 0;
+    for (int nt = 0; nt < NT; ++nt) {
+        dsc[nt] = descale[h * kF_Rows + (nt0 + nt) * 16 + c16];
+        bsv[nt] = bias ? bias[h * kF_Rows + (nt0 + nt) * 16 + c16] : 0;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) rsc[r] = row_scale ? row_scale[min(m0 + 4 * g + r, M - 1)] : 1.f;
@@ -467,6 +485,7 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
         for (int ks = 0; ks < 4; ++ks)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[ks]) : "v"(arow + c * kF_Chunk + ks * 64) : "memory");
     };
+    F_STAMP(0)
     issue_w(0, 0);
     issue_a(0, afb[0]);
     issue_w(1, 1);
@@ -474,14 +493,14 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     // the compiler's own loads above (dequant operands, cos / sin) are consumed here in its eyes: its wait lands at the start of the
     // kernel, where it costs nothing extra, instead of in front of the epilogue behind a ring full of requests
 #pragma unroll
-    for (int nt = 0; nt < 12; ++nt) asm volatile("" ::"v"(dsc[nt]), "v"(bsv[nt]));
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(dsc[nt]), "v"(bsv[nt]));
 #pragma unroll
     for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(rsc[r]));
 #pragma unroll
     for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(rc[j].x), "v"(rc[j].y), "v"(rc[j].z), "v"(rc[j].w), "v"(rs[j].x), "v"(rs[j].y), "v"(rs[j].z), "v"(rs[j].w));
-    i32x4 acc[12];
+    i32x4 acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < 12; ++nt) acc[nt] = i32x4{0, 0, 0, 0};
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = i32x4{0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < kF_NChunks; ++c) {
         // chunk c and its activation fragments landed: requests complete in issue order, and the one request group younger than chunk
@@ -490,7 +509,9 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
         i32x4(&af)[4] = afb[c & 1];
         if (c + 1 < kF_NChunks) asm volatile("s_waitcnt vmcnt(10)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
         else asm volatile("s_waitcnt vmcnt(6)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3])::"memory");
+        F_STAMP(1 + 3 * c)
         __syncthreads();                                  // chunk c complete for every wave; the slot of chunk c - 1 is free
+        F_STAMP(2 + 3 * c)
         // ONE barrier per chunk: the refill of the freed slot is requested here, by half of the waves before and by the other half
         // after their MFMAs (waves w and w + 4 share a SIMD: one issues DMA while the other multiplies)
         auto refill = [&]() {
@@ -508,9 +529,9 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
         {
             // weight fragments kF_Ahead MFMAs ahead of their use (ring of kF_Ahead + 2 registers sets): the compiler's own order was
             // `2 ds_read -> wait -> MFMA -> wait -> MFMA`, one exposed LDS round trip per pair with only two waves on the SIMD
-            constexpr int kF_Ahead = 6, kRingF = 8, NF = 4 * 12;
+            constexpr int kF_Ahead = 6, kRingF = 8, NF = 4 * NT;
             auto ldf = [&](int i) {
-                const int ks = i / 12, nt = i % 12;
+                const int ks = i / NT, nt = nt0 + i % NT;
                 return *(const i32x4 *)(st + (nt * 16 + c16) * kF_Chunk + (((4 * ks + g) ^ c16) << 4));
             };
             i32x4 fr[kRingF];
@@ -522,12 +543,13 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + kF_Ahead < NF) fr[(i + kF_Ahead) % kRingF] = ldf(i + kF_Ahead);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[i % 12] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i / 12], fr[i % kRingF], acc[i % 12], 0, 0, 0);
+                acc[i % NT] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i / NT], fr[i % kRingF], acc[i % NT], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (wave >= 4) refill();
         if (c + 2 < kF_NChunks) issue_a(c + 2, afb[c & 1]);      // into the buffer this chunk's MFMAs have just read
+        F_STAMP(3 + 3 * c)
     }
     __syncthreads();                                      // every wave is done with the last chunk (slot 2)
     issue_uk(3, eighth_at(3));
@@ -535,20 +557,21 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     issue_uk(5, eighth_at(5));
     // dequant into the I/O dtype -> y tile
 #pragma unroll
-    for (int nt = 0; nt < 12; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float y = (float)(acc[nt][r] + bsv[nt]) * dsc[nt];
             if (row_scale) y = y * rsc[r];                  // per_token_quant_symm
-            *(uint16_t *)(ytile + ytile_off(wave * 16 + 4 * g + r, nt * 16 + c16)) = sth16<BF16>(y);
+            *(uint16_t *)(ytile + ytile_off(rt * 16 + 4 * g + r, (nt0 + nt) * 16 + c16)) = sth16<BF16>(y);
         }
     asm volatile("" ::: "memory");                       // 2-byte stores above, 16-byte loads below: keep their order (see moe_gemm.hip)
+    if constexpr (HALF) __syncthreads();                  // a row tile of y is written by two waves
     // ---- phase B operands: this wave's 16 rows of y_nope as MFMA A fragments; RoPE of its 16 x 64 positional values
     s16x8 yf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) yf[ks] = *(const s16x8 *)(ytile + ytile_off(wave * 16 + c16, ks * 32 + g * 8));
-    {   // rotate-half RoPE: lane = (row, 16-column quarter); the partner columns (c ^ 32) are quarter ^ 2 of the same y tile row
-        const uint16_t *yrow = (const uint16_t *)(ytile + (wave * 16 + rrow) * kF_YRow) + 128;
+    for (int ks = 0; ks < 4; ++ks) yf[ks] = *(const s16x8 *)(ytile + ytile_off(rt * 16 + c16, ks * 32 + g * 8));
+    if (ch == 0) {   // rotate-half RoPE: lane = (row, 16-column quarter); the partner columns (c ^ 32) are quarter ^ 2 of the same y tile row
+        const uint16_t *yrow = (const uint16_t *)(ytile + (rt * 16 + rrow) * kF_YRow) + 128;
         uint4 xv[2], pv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -579,37 +602,42 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
             }
         }
     }
+    F_STAMP(20)
     const float qsc = q_nope_scale ? ldh16<BF16>(q_nope_scale[h]) : 0.f;
     uint8_t *otile = ytile + wave * (16 * kF_OutRow);      // the y tile becomes the waves' output tiles after the barrier of quarter 0
-    auto multiply_eighth = [&](int e) {                    // 16 rows x 64 output columns of q_out0
+    auto multiply_eighth = [&](int e) {                    // 16 rows x 64 output columns of q_out0 (HALF: this wave's 32 of them)
         const uint8_t *st = lds + eighth_at(e);
-        // four independent accumulation chains (k ascending inside each, as in bmm_rope_kernel): the MFMAs issue back to back
-        f32x4 oacc[4];
+        constexpr int NB = HALF ? 2 : 4;                   // column tiles of the eighth this wave multiplies
+        const int nb0 = ch * NB;
+        // independent accumulation chains (k ascending inside each, as in bmm_rope_kernel): the MFMAs issue back to back
+        f32x4 oacc[NB];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NB; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const s16x8 bf = *(const s16x8 *)(st + (nt * 16 + c16) * kF_Chunk + (((4 * ks + g) ^ c16) << 4));
+            for (int nt = 0; nt < NB; ++nt) {
+                const s16x8 bf = *(const s16x8 *)(st + ((nb0 + nt) * 16 + c16) * kF_Chunk + (((4 * ks + g) ^ c16) << 4));
                 if constexpr (BF16)
                     oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, yf[ks]), __builtin_bit_cast(bf16x8, bf), oacc[nt], 0, 0, 0);
                 else
                     oacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, yf[ks]), __builtin_bit_cast(f16x8, bf), oacc[nt], 0, 0, 0);
             }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NB; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) *(uint16_t *)(otile + (4 * g + r) * kF_OutRow + (nt * 16 + c16) * 2) = sth16<BF16>(oacc[nt][r]);
         asm volatile("" ::: "memory");
+        constexpr int kChunks = NB * 2;                    // 16-byte chunks per output tile row
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int rl = it * 8 + (lane >> 3), chunk = lane & 7;
+        for (int it = 0; it < NB / 2; ++it) {
+            const int rl = it * (64 / kChunks) + lane / kChunks, chunk = lane % kChunks;
             const int row = m0 + rl;
             const uint4 v = *(const uint4 *)(otile + rl * kF_OutRow + chunk * 16);
             if (row >= M) continue;
+            const int col = e * 64 + nb0 * 16 + chunk * 8;
             if (!q_nope_scale) {
-                *(uint4 *)(out0 + ((size_t)row * Hq + h) * 512 + e * 64 + chunk * 8) = v;
+                *(uint4 *)(out0 + ((size_t)row * Hq + h) * 512 + col) = v;
             } else {                                        // int8_nzcache: see bmm_rope_kernel
                 const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
                 uint32_t pk[2] = {0u, 0u};
@@ -621,7 +649,7 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
                     hq = fminf(fmaxf(hq, -128.f), 127.f);
                     pk[j >> 2] |= ((uint32_t)(int)rintf(hq) & 0xFFu) << (8 * (j & 3));
                 }
-                *(uint2 *)((int8_t *)out0 + ((size_t)row * Hq + h) * 512 + e * 64 + chunk * 8) = uint2{pk[0], pk[1]};
+                *(uint2 *)((int8_t *)out0 + ((size_t)row * Hq + h) * 512 + col) = uint2{pk[0], pk[1]};
             }
         }
         asm volatile("" ::: "memory");
@@ -639,6 +667,7 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     __syncthreads();
     multiply_eighth(6);
     multiply_eighth(7);
+    F_STAMP(21)
 }
 
 }  // namespace mi_sgl
@@ -699,6 +728,9 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 
+#ifdef F_TIMING
+extern "C" int mi_dbg_read_f(unsigned long long *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_sgl::g_f_dbg), sizeof(unsigned long long) * 4 * 64); }
+#endif
 extern "C" int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const void *wuk_t, const void *cos, const void *sin, int dtype,
                                    void *q_out0, void *q_out1, const void *q_nope_scale, void *stream)
 {
@@ -724,15 +756,25 @@ extern "C" int mi_mla_pre_gemm2_bmm_rope(const int8_t *a, int tokens, const int8
     if (tokens < 0 || q_heads <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16)) return MI_SGL_EINVAL;
     if (tokens == 0) return MI_SGL_OK;
     if (!a || !wuq || !descale || !wuk_t || !cos || !sin || !q_out0 || !q_out1) return MI_SGL_EINVAL;
-    dim3 grid(q_heads, 1, (tokens + kBM - 1) / kBM);
+    // 64-row workgroups while 128-row ones would leave CUs idle (and for batches of <= 64 tokens, whose second half would be padding)
+    static const int half_env = getenv("MI_MLA_PRE_HALF") ? atoi(getenv("MI_MLA_PRE_HALF")) : -1;
+    const bool half = half_env >= 0 ? half_env != 0 : (tokens <= 64 || (long long)q_heads * ((tokens + kBM - 1) / kBM) < 256);
+    dim3 grid(q_heads, 1, half ? (tokens + 63) / 64 : (tokens + kBM - 1) / kBM);
 #define MI_FUSED(B)                                                                                                                 \
     do {                                                                                                                            \
         static bool attr_set = false;                                                                                               \
         if (!attr_set) {                                                                                                            \
-            (void)hipFuncSetAttribute((const void *)gemm2_bmm_rope_kernel<B>, hipFuncAttributeMaxDynamicSharedMemorySize, kF_Lds); \
+            (void)hipFuncSetAttribute((const void *)gemm2_bmm_rope_kernel<B, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kF_Lds); \
+            (void)hipFuncSetAttribute((const void *)gemm2_bmm_rope_kernel<B, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kF_Lds); \
             attr_set = true;                                                                                                        \
         }                                                                                                                           \
-        gemm2_bmm_rope_kernel<B><<<grid, 512, kF_Lds, (hipStream_t)stream>>>(a, tokens, wuq, q_heads, bias, descale, row_scale,     \
+        if (half)                                                                                                                   \
+            gemm2_bmm_rope_kernel<B, true><<<grid, 512, kF_Lds, (hipStream_t)stream>>>(a, tokens, wuq, q_heads, bias, descale, row_scale, \
+                                                                             (const uint16_t *)wuk_t, (const uint16_t *)cos,        \
+                                                                             (const uint16_t *)sin, (uint16_t *)q_out0,             \
+                                                                             (uint16_t *)q_out1, (const uint16_t *)q_nope_scale);   \
+        else                                                                                                                        \
+            gemm2_bmm_rope_kernel<B, false><<<grid, 512, kF_Lds, (hipStream_t)stream>>>(a, tokens, wuq, q_heads, bias, descale, row_scale, \
                                                                              (const uint16_t *)wuk_t, (const uint16_t *)cos,        \
                                                                              (const uint16_t *)sin, (uint16_t *)q_out0,             \
                                                                              (uint16_t *)q_out1, (const uint16_t *)q_nope_scale);   \

@@ -447,7 +447,9 @@ def test_fused_rope_qk_mqa(T, Hq, Hk, D, R, neox, dtype):
 
 
 @pytest.mark.parametrize("M,Hq,per_token,dt", [(128, 128, False, torch.bfloat16), (1, 16, False, torch.bfloat16), (70, 32, True, torch.bfloat16),
-                                              (200, 16, False, torch.float16), (31, 128, True, torch.bfloat16)])
+                                              (200, 16, False, torch.float16), (31, 128, True, torch.bfloat16),
+                                              # 128-row workgroups (heads x row blocks >= 256); the cases above take the 64-row form
+                                              (300, 128, False, torch.bfloat16), (257, 128, True, torch.float16)])
 def test_mla_pre_fused_gemm2_bmm_rope_equals_two_launches(M, Hq, per_token, dt):
     """mi_mla_pre_gemm2_bmm_rope (one launch, the GEMM2 output stays in LDS) against mi_mla_pre_gemm_i8(mode 1) + mi_mla_pre_bmm_rope:
     same MFMA shapes and accumulation order, so q_out0 and q_out1 must match BIT FOR BIT -- which carries every parity statement of
