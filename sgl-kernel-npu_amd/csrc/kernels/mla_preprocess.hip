@@ -149,20 +149,39 @@ __global__ __launch_bounds__(kMidThreads) void pre_mid_kernel(const int32_t *__r
     const float ts_in = per_token ? tok_scale_in[n] : 1.f;
     const int32_t *row = c1 + (long long)n * kMid;
     const long long part_stride = (long long)ntok * kMid;       // split-K partial products of GEMM1: exact int32 sum
-    for (int j = tid; j < kMid; j += kMidThreads) {
-        int32_t acc = (bias0 && !per_token) ? bias0[j] : 0;
-        // eight independent loads in flight per step, the last step included: its loads are unconditional (index clamped to the last
-        // partial, surplus values dropped) -- a scalar tail loop was one memory round trip per partial (14 partials = 1 + 6 round trips)
+    // Column j = tid, tid + 1024 and (threads 0..63) 2048 + tid: all three are summed TOGETHER, eight partials per step -- the loads of a
+    // step are independent and unconditional (index clamped to the last partial, surplus values dropped), so the 14 partials cost two
+    // memory round trips per thread.  (Column after column it was six: three passes of two steps, the third for 64 columns.)
+    static_assert(kMid > 2 * kMidThreads && kMid <= 2 * kMidThreads + 64, "column plan of pre_mid");
+    {
+        const int j0 = tid, j1 = tid + kMidThreads, j2 = min(2 * kMidThreads + tid, kMid - 1);
+        const bool has2 = tid < kMid - 2 * kMidThreads;
+        const bool use_bias = bias0 && !per_token;
+        int32_t acc0 = use_bias ? bias0[j0] : 0, acc1 = use_bias ? bias0[j1] : 0, acc2 = use_bias ? bias0[j2] : 0;
+        const float d0 = descale0[j0], d1 = descale0[j1], d2 = descale0[j2];
         for (int p = 0; p < nparts; p += 8) {
-            int32_t v[8];
+            int32_t v0[8], v1[8], v2[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = row[(long long)min(p + u, nparts - 1) * part_stride + j];
+            for (int u = 0; u < 8; ++u) {
+                const int32_t *pr = row + (long long)min(p + u, nparts - 1) * part_stride;
+                v0[u] = pr[j0];
+                v1[u] = pr[j1];
+                v2[u] = has2 ? pr[j2] : 0;
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (p + u < nparts) ? v[u] : 0;
+            for (int u = 0; u < 8; ++u) {
+                const bool live = p + u < nparts;
+                acc0 += live ? v0[u] : 0;
+                acc1 += live ? v1[u] : 0;
+                acc2 += live ? v2[u] : 0;
+            }
         }
-        float y = (float)acc * descale0[j];
-        if (per_token) y = y * ts_in;
-        f[j] = ldh<BF16>(sth<BF16>(y));                      // the GEMM output is materialised in the I/O dtype (golden :95-107)
+        // the GEMM output is materialised in the I/O dtype (golden :95-107)
+        float y0 = (float)acc0 * d0, y1 = (float)acc1 * d1, y2 = (float)acc2 * d2;
+        if (per_token) y0 = y0 * ts_in, y1 = y1 * ts_in, y2 = y2 * ts_in;
+        f[j0] = ldh<BF16>(sth<BF16>(y0));
+        f[j1] = ldh<BF16>(sth<BF16>(y1));
+        if (has2) f[j2] = ldh<BF16>(sth<BF16>(y2));
     }
     __syncthreads();
     // k_nope: RMSNorm * gamma2 -> cache
