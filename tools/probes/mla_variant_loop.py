@@ -1,4 +1,4 @@
-"""Scratch: BASELINE C4 MLA decode in a loop with one kernel form (argv[1] = 4 | 8 | 64), for rocprofv3 passes."""
+"""Scratch: BASELINE C4 MLA decode in a loop with one kernel form (argv[1] = 4 | 8), for rocprofv3 passes."""
 import ctypes, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, os.path.join(ROOT, "sgl-kernel-npu_amd", "python"))
