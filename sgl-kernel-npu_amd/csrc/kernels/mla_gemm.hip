@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restric
 //   phase B  q_out0[:, h, :] = y[:, 0:128] x wuk_t[h]^T with wuk_t[h] streamed through the same ring in four 128-column quarters,
 //            q_out1[:, h, :] = rope_half(y[:, 128:192]).
 // Same MFMA shapes and accumulation order as skinny_i8_k1536_kernel + bmm_rope_kernel, so the outputs are bit-identical to the
-// two-launch path.  128 heads = 128 workgroups: half the CUs, each pulling 426 KB, which is what a CU's DMA stream sustains when
+// two-launch path.  (128-row form:) 128 heads = 128 workgroups: half the CUs, each pulling 426 KB, which is what a CU's DMA stream sustains when
 // the other half is idle; per launch the 6.3 MB y round trip and one launch latency go away.
 // Measured at 128 tokens x 128 heads: 26.6 us (28.8 before the per-head rotation of the piece order) against 22.4 + 15.5 us for
 // the two launches.  Shader-clock accounting (s_memtime, one
