@@ -10,6 +10,7 @@
  *   mi_add_rmsnorm_bias      <- norm/add_rmsnorm_bias.py:8-147        (add_rmsnorm_bias_kernel / add_rmsnorm_bias)
  *                               norm/add_rmsnorm_bias.py:150-232      (add_gemma_rms_norm)
  *   mi_split_qkv_rmsnorm_rope<- norm/split_qkv_rmsnorm_rope.py:8-438  (split_qkv_rmsnorm_rope)
+ *   mi_split_qkvgate_gemma_rmsnorm_rope <- norm/split_qkv_rmsnorm_rope.py:441-745  (split_qkvgate_gemma_rmsnorm_rope)
  *   mi_rope_qk_mqa           <- norm/fused_rope_qk_mqa.py:6-160       (fused_rope_qk_mqa)
  * and are what `torch.ops.npu.*` (csrc/pytorch_extensions.cpp) and the `sgl_kernel_npu` Python functions bind.
  *
@@ -101,6 +102,12 @@ int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const void *cos,
                               int head_dim, int rope_dim, int has_norm, float eps, const void *q_weight,
                               const void *k_weight, const void *q_bias, const void *k_bias, int neox, int dtype, void *q,
                               void *k, void *v, void *stream);
+/* ---- split [q | gate] + K + V, Gemma RMSNorm (weight + 1) + neox RoPE (split_qkv_rmsnorm_rope.py:441-745) ----------------------
+ * input [rows, 2 q_hidden + 2 kv_hidden]: q_hidden / head_dim pairs [q head | gate head], then K, then V; sin / cos [rows, rope_dim];
+ * q, gate [rows, q_hidden], k, v [rows, kv_hidden]; head_dim a power of two in [8, 2048], q_hidden % kv_hidden == 0 (:700-702). */
+int mi_split_qkvgate_gemma_rmsnorm_rope(const void *input, const void *sin, const void *cos, int rows, int q_hidden, int kv_hidden,
+                                        int head_dim, int rope_dim, float eps, const void *q_weight, const void *k_weight, int dtype,
+                                        void *q, void *k, void *v, void *gate, void *stream);
 
 /* ---- RoPE on q and the shared key heads (norm/fused_rope_qk_mqa.py:113-160) -----------------------------------------
  * q [tokens, q_heads, head_dim], k [tokens, k_heads, head_dim] (strides in elements, last dim contiguous); cos_sin

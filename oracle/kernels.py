@@ -236,6 +236,33 @@ def split_qkv_rmsnorm_rope(qkv, sin, cos, q_hidden, kv_hidden, head_dim, eps=Non
     return one(q, q_weight, q_bias), one(k, k_weight, k_bias), v.clone()
 
 
+def split_qkvgate_gemma_rmsnorm_rope(x, sin, cos, q_hidden, kv_hidden, head_dim, rope_dim, eps, q_weight, k_weight):
+    """Restates split_qkvgate_gemma_rmsnorm_rope_kernel (python/sgl_kernel_npu/sgl_kernel_npu/norm/split_qkv_rmsnorm_rope.py:441-745) in
+    fp32: the first 2*q_hidden columns are per-head pairs [q head | gate head] (:478-497); q and k heads: x * rsqrt(mean(x^2) + eps)
+    * (w + 1) (:468, :499-503, :586, :603-609), then cat(-x2, x1) * sin + x * cos on the first rope_dim dims, the rest passed through
+    (:505-558, :611-656); gate and V are copied (:567-571, :658-667).  PARITY UNPINNED: the reference holds no test or vector for this
+    function; tests/test_oracle_kernels.py ties it to split_qkv_rmsnorm_rope (pinned to the reference test's golden) on rearranged input."""
+    B = x.shape[0]
+    half = rope_dim // 2
+    qh = q_hidden // head_dim
+    qg = x[:, :2 * q_hidden].reshape(B, qh, 2, head_dim)
+    q, gate = qg[:, :, 0, :], qg[:, :, 1, :]
+    k = x[:, 2 * q_hidden:2 * q_hidden + kv_hidden].reshape(B, -1, head_dim)
+    v = x[:, 2 * q_hidden + kv_hidden:]
+    s = sin.reshape(B, 1, rope_dim).float()
+    c = cos.reshape(B, 1, rope_dim).float()
+
+    def one(t, w):
+        t = t.float()
+        rstd = torch.rsqrt((t * t).sum(dim=-1, keepdim=True) / head_dim + eps)
+        t = (t * rstd) * (w.float() + 1.0)
+        rot, rest = t[..., :rope_dim], t[..., rope_dim:]
+        cat = torch.cat([-rot[..., half:], rot[..., :half]], dim=-1)
+        return torch.cat([cat * s + rot * c, rest], dim=-1).reshape(B, -1).to(x.dtype)
+
+    return one(q, q_weight), one(k, k_weight), v.clone(), gate.reshape(B, -1).clone()
+
+
 # --------------------------------------------------------------------------------------
 # A14  mla_preprocess
 # --------------------------------------------------------------------------------------

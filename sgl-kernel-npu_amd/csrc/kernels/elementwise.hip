@@ -338,6 +338,103 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_kernel(
     for (int i = rope_dim + lane; i < head_dim; i += 64) dst[i] = (uint16_t)st16<BF16>(nrm(i));
 }
 
+// ------------------------------------------------------------------------------------------------
+// split [q | gate] pairs + K + V, Gemma RMSNorm (weight + 1) of every q and k head, neox RoPE on the first rope_dim dims
+// (split_qkv_rmsnorm_rope.py:441-745, split_qkvgate_gemma_rmsnorm_rope).  Input row = q_heads x [q head | gate head], then K, then V
+// (:478-497, :590-592, :660).  One wave per (row, item), items = q heads (q + its gate), k heads, v heads; a lane owns 8 consecutive
+// elements (16-byte loads / stores) of up to four chunks of the head.
+//   q, k:  y = (x * rsqrt(mean(x^2) + eps)) * (w + 1)   in fp32 (:499-503, :603-609)
+//          out[p] = (-y[p + h]) * sin[p] + y[p] * cos[p],  out[p + h] = y[p] * sin[p + h] + y[p + h] * cos[p + h],  h = rope_dim / 2 (:505-558)
+//   gate, v: copied (:567-571, :658-667)
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void split_qkvgate_gemma_kernel(
+    const uint16_t *__restrict__ in, const uint16_t *__restrict__ sin, const uint16_t *__restrict__ cos, int rows, int q_hidden,
+    int kv_hidden, int head_dim, int rope_dim, float eps, const uint16_t *__restrict__ qw, const uint16_t *__restrict__ kw,
+    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v, uint16_t *__restrict__ gate)
+{
+    const int lane = threadIdx.x & 63;
+    const int q_heads = q_hidden / head_dim, kv_heads = kv_hidden / head_dim;
+    const int items = q_heads + 2 * kv_heads;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long row = wid / items;
+    const int it = (int)(wid % items);
+    if (row >= rows) return;
+    const long long total = 2ll * q_hidden + 2ll * kv_hidden;
+    const uint16_t *rin = in + row * total;
+    if (it >= q_heads + kv_heads) {                          // V: plain copy
+        const int h = it - q_heads - kv_heads;
+        const uint16_t *src = rin + 2ll * q_hidden + kv_hidden + (long long)h * head_dim;
+        uint16_t *dst = v + row * (long long)kv_hidden + (long long)h * head_dim;
+        for (int i = lane * 8; i < head_dim; i += 512) *(u32x4 *)(dst + i) = *(const u32x4 *)(src + i);
+        return;
+    }
+    const bool is_q = it < q_heads;
+    const uint16_t *src = is_q ? rin + (long long)it * 2 * head_dim : rin + 2ll * q_hidden + (long long)(it - q_heads) * head_dim;
+    uint16_t *dst = is_q ? q + row * (long long)q_hidden + (long long)it * head_dim
+                         : k + row * (long long)kv_hidden + (long long)(it - q_heads) * head_dim;
+    const uint16_t *wt = is_q ? qw : kw;
+    if (is_q) {                                              // the head's gate: copied
+        const uint16_t *gs = src + head_dim;
+        uint16_t *gd = gate + row * (long long)q_hidden + (long long)it * head_dim;
+        for (int i = lane * 8; i < head_dim; i += 512) *(u32x4 *)(gd + i) = *(const u32x4 *)(gs + i);
+    }
+    // head_dim <= 2048: a lane holds up to 4 chunks of 8 elements
+    constexpr int kMaxChunks = 4;
+    float x[kMaxChunks][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < head_dim) {
+            unpack8<BF16>(*(const u32x4 *)(src + i), x[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)head_dim + eps);
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < head_dim) {
+            float w[8];
+            unpack8<BF16>(*(const u32x4 *)(wt + i), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] = (x[c][e] * rstd) * (w[e] + 1.0f);
+        }
+    }
+    // RoPE: the partner of element p is p +- rope_dim / 2, i.e. a register of another lane: the normalised head is staged in a wave-private
+    // LDS row (LDS operations of one wave complete in order: no workgroup barrier)
+    __shared__ float stage[4][2048];
+    float *sw = stage[threadIdx.x >> 6];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < head_dim) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sw[i + e] = x[c][e];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int half = rope_dim >> 1;
+    const uint16_t *sr = sin + row * (long long)rope_dim, *cr = cos + row * (long long)rope_dim;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < head_dim) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int pidx = i + e;
+                if (pidx < half) o[e] = (-sw[pidx + half]) * ld16<BF16>(sr[pidx]) + x[c][e] * ld16<BF16>(cr[pidx]);
+                else if (pidx < rope_dim) o[e] = sw[pidx - half] * ld16<BF16>(sr[pidx]) + x[c][e] * ld16<BF16>(cr[pidx]);
+                else o[e] = x[c][e];
+            }
+            *(u32x4 *)(dst + i) = pack8<BF16>(o);
+        }
+    }
+}
+
 // Vectorised variant: a head is spread over head_dim/8 lanes holding 8 consecutive elements each (16-B loads / stores),
 // so a wave handles 64*8/head_dim heads.  The RoPE partner (p +- rope_dim/2) lives rope_dim/16 lanes away and is fetched
 // with one shuffle per element; the RMS reduction is an xor-shuffle tree inside the head's lane group.
@@ -356,17 +453,22 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ sin, const uint16_t *__restrict__ cos, int rows, int q_hidden,
     int kv_hidden, int head_dim, int rope_dim, int has_norm, float eps, const uint16_t *__restrict__ qw,
     const uint16_t *__restrict__ kw, const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kb, int neox,
-    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v)
+    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v, uint16_t *__restrict__ gate)
 {
+    // gate != nullptr: the gated Gemma form (split_qkv_rmsnorm_rope.py:441-745) -- the row is q_heads pairs [q head | gate head], then K,
+    // then V, i.e. still one head-sized item every head_dim elements; odd items of the first 2 q_heads are gates (copied like V), the
+    // norm weight is w + 1 and the scale rsqrt(mean + eps) (:468, :499-503)
+    const bool gated = gate != nullptr;
     const int lane = threadIdx.x & 63;
     const int gl = head_dim >> 3;                      // lanes per head (8 .. 32), a power of two
     const int gl_shift = 31 - __builtin_clz(gl);
     const int heads_per_wave = 64 >> gl_shift;
     const int q_heads = q_hidden / head_dim, kv_heads = kv_hidden / head_dim;
-    const int heads_total = q_heads + 2 * kv_heads;
+    const int q_items = gated ? 2 * q_heads : q_heads;      // head-sized items in front of K
+    const int heads_total = q_items + 2 * kv_heads;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int j = lane & (gl - 1);                     // chunk of 8 elements inside the head
-    const long long total_hidden = (long long)q_hidden + 2ll * kv_hidden;
+    const long long total_hidden = (long long)q_items * head_dim + 2ll * kv_hidden;
     const int half = rope_dim >> 1;
     const bool roped = j * 8 < rope_dim;
     const u32x4 zero4 = u32x4{0, 0, 0, 0};
@@ -384,7 +486,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
         row[u] = r32;
         h[u] = (int)(hglobal - r32 * (uint32_t)heads_total);
         active[u] = row[u] < rows;
-        const bool is_v = h[u] >= q_heads + kv_heads, is_q = h[u] < q_heads;
+        const bool is_v = h[u] >= q_items + kv_heads || (gated && h[u] < q_items && (h[u] & 1)), is_q = h[u] < q_items;
         const bool normed = active[u] && !is_v;
         xr[u] = active[u] ? *(const u32x4 *)(qkv + row[u] * total_hidden + (long long)h[u] * head_dim + j * 8) : zero4;
         wr[u] = (has_norm && normed) ? *(const u32x4 *)((is_q ? qw : kw) + j * 8) : zero4;
@@ -402,7 +504,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     }
 #pragma unroll
     for (int u = 0; u < kVecUnroll; ++u) {
-        const bool is_v = h[u] >= q_heads + kv_heads, is_q = h[u] < q_heads;
+        const bool is_v = h[u] >= q_items + kv_heads || (gated && h[u] < q_items && (h[u] & 1)), is_q = h[u] < q_items;      // is_v: copied
         float x[8];
         unpack8<BF16>(xr[u], x);
         if (has_norm) {
@@ -418,9 +520,13 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             if (gl >= 16) ss += dpp_f32<0x140>(ss);         // row_mirror: the other half of the 16-lane row
             if (gl == 32) ss += __shfl_xor(ss, 16, 64);
             if (active[u] && !is_v) {
-                const float rstd = 1.0f / sqrtf(ss / (float)head_dim + eps);
+                const float rstd = gated ? rsqrtf(ss / (float)head_dim + eps) : 1.0f / sqrtf(ss / (float)head_dim + eps);
                 float wv[8];
                 unpack8<BF16>(wr[u], wv);
+                if (gated) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wv[e] = wv[e] + 1.0f;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = (x[e] * rstd) * wv[e];
                 if (qb) {
@@ -470,9 +576,10 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             }
         }
         if (!active[u]) continue;
-        uint16_t *dst = is_q ? q + row[u] * (long long)q_hidden + (long long)h[u] * head_dim
-                      : (!is_v ? k + row[u] * (long long)kv_hidden + (long long)(h[u] - q_heads) * head_dim
-                               : v + row[u] * (long long)kv_hidden + (long long)(h[u] - q_heads - kv_heads) * head_dim);
+        uint16_t *dst;
+        if (is_q) dst = ((gated && (h[u] & 1)) ? gate : q) + row[u] * (long long)q_hidden + (long long)(gated ? h[u] >> 1 : h[u]) * head_dim;
+        else if (h[u] < q_items + kv_heads) dst = k + row[u] * (long long)kv_hidden + (long long)(h[u] - q_items) * head_dim;
+        else dst = v + row[u] * (long long)kv_hidden + (long long)(h[u] - q_items - kv_heads) * head_dim;
         *(u32x4 *)(dst + j * 8) = is_v ? xr[u] : pack8<BF16>(o);
     }
 }
@@ -619,7 +726,7 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
     split_qkv_rmsnorm_rope_vec_kernel<B><<<blocks, 256, 0, st>>>(                                                                   \
         (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox, (uint16_t *)q,   \
-        (uint16_t *)k, (uint16_t *)v)
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr)
         if (dtype == MI_DTYPE_BF16) MI_VEC(true); else MI_VEC(false);
 #undef MI_VEC
         return launch_ok();
@@ -636,5 +743,49 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
             (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm,
             eps, (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox,
             (uint16_t *)q, (uint16_t *)k, (uint16_t *)v);
+    return launch_ok();
+}
+
+extern "C" int mi_split_qkvgate_gemma_rmsnorm_rope(const void *input, const void *sin, const void *cos, int rows, int q_hidden, int kv_hidden,
+                                                   int head_dim, int rope_dim, float eps, const void *q_weight, const void *k_weight,
+                                                   int dtype, void *q, void *k, void *v, void *gate, void *stream)
+{
+    if (rows < 0 || head_dim < 8 || head_dim > 2048 || (head_dim & (head_dim - 1)) || q_hidden <= 0 || q_hidden % head_dim ||
+        kv_hidden <= 0 || kv_hidden % head_dim || q_hidden % kv_hidden || rope_dim <= 0 || rope_dim > head_dim || rope_dim % 2 ||
+        (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!input || !sin || !cos || !q_weight || !k_weight || !q || !k || !v || !gate) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // the vectorised kernel of split_qkv_rmsnorm_rope serves the common shapes (a head spread over head_dim / 8 lanes); the wave-per-item
+    // kernel above is the general form
+    const int items_total = (2 * q_hidden + 2 * kv_hidden) / head_dim;
+    if (head_dim >= 64 && head_dim <= 256 && rope_dim % 16 == 0 && (long long)rows * items_total < (1ll << 31) - 4096) {
+        const long long heads = (long long)rows * items_total;
+        const int hpw = 64 / (head_dim / 8);
+        const long long vwaves = ((heads + hpw - 1) / hpw + kVecUnroll - 1) / kVecUnroll;
+        const int vblocks = (int)((vwaves + 3) / 4);
+#define MI_GVEC(B)                                                                                                                   \
+    split_qkv_rmsnorm_rope_vec_kernel<B><<<vblocks, 256, 0, st>>>(                                                                   \
+        (const uint16_t *)input, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, 1, eps,  \
+        (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)nullptr, (const uint16_t *)nullptr, 1, (uint16_t *)q,  \
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate)
+        if (dtype == MI_DTYPE_BF16) MI_GVEC(true); else MI_GVEC(false);
+#undef MI_GVEC
+        return launch_ok();
+    }
+    const long long waves = (long long)rows * ((q_hidden + 2 * kv_hidden) / head_dim);
+    if (waves > (1ll << 31) - 8) return MI_SGL_EINVAL;
+    const int blocks = (int)((waves + 3) / 4);
+    if (dtype == MI_DTYPE_BF16)
+        split_qkvgate_gemma_kernel<true><<<blocks, 256, 0, st>>>((const uint16_t *)input, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden,
+                                                                 kv_hidden, head_dim, rope_dim, eps, (const uint16_t *)q_weight,
+                                                                 (const uint16_t *)k_weight, (uint16_t *)q, (uint16_t *)k, (uint16_t *)v,
+                                                                 (uint16_t *)gate);
+    else
+        split_qkvgate_gemma_kernel<false><<<blocks, 256, 0, st>>>((const uint16_t *)input, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden,
+                                                                  kv_hidden, head_dim, rope_dim, eps, (const uint16_t *)q_weight,
+                                                                  (const uint16_t *)k_weight, (uint16_t *)q, (uint16_t *)k, (uint16_t *)v,
+                                                                  (uint16_t *)gate);
     return launch_ok();
 }

@@ -216,6 +216,32 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
     return {q, k, v};
 }
 
+// split [q | gate] + K + V, Gemma RMSNorm + neox RoPE; arguments as split_qkvgate_gemma_rmsnorm_rope (norm/split_qkv_rmsnorm_rope.py:686-745)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkvgate_gemma_rmsnorm_rope(
+    const at::Tensor &input, const at::Tensor &sin, const at::Tensor &cos, int64_t q_hidden_size, int64_t kv_hidden_size,
+    int64_t head_dim, int64_t rope_dim, double eps, const at::Tensor &q_weight, const at::Tensor &k_weight)
+{
+    TORCH_CHECK(input.dim() == 2 && input.is_contiguous(), "split_qkvgate_gemma_rmsnorm_rope: input must be contiguous [batch, 2q+2kv]");
+    TORCH_CHECK((head_dim & (head_dim - 1)) == 0, "head_dim must be a power of two");        // reference :700-701
+    TORCH_CHECK(q_hidden_size % kv_hidden_size == 0, "q_hidden_size % kv_hidden_size != 0");   // reference :702
+    TORCH_CHECK(input.size(1) == 2 * q_hidden_size + 2 * kv_hidden_size, "split_qkvgate_gemma_rmsnorm_rope: input width");
+    const int64_t B = input.size(0);
+    TORCH_CHECK(sin.numel() == B * rope_dim && cos.numel() == B * rope_dim && sin.is_contiguous() && cos.is_contiguous() &&
+                    sin.scalar_type() == input.scalar_type() && cos.scalar_type() == input.scalar_type(),
+                "split_qkvgate_gemma_rmsnorm_rope: sin/cos must be contiguous [batch, ..., rope_dim] in the input dtype");
+    TORCH_CHECK(q_weight.numel() == head_dim && k_weight.numel() == head_dim && q_weight.is_contiguous() && k_weight.is_contiguous() &&
+                    q_weight.scalar_type() == input.scalar_type() && k_weight.scalar_type() == input.scalar_type(),
+                "split_qkvgate_gemma_rmsnorm_rope: norm weights must be [head_dim] in the input dtype");
+    at::Tensor q = at::empty({B, q_hidden_size}, input.options()), k = at::empty({B, kv_hidden_size}, input.options()),
+               v = at::empty({B, kv_hidden_size}, input.options()), gate = at::empty({B, q_hidden_size}, input.options());
+    const int rc = mi_split_qkvgate_gemma_rmsnorm_rope(input.data_ptr(), sin.data_ptr(), cos.data_ptr(), (int)B, (int)q_hidden_size,
+                                                       (int)kv_hidden_size, (int)head_dim, (int)rope_dim, (float)eps, q_weight.data_ptr(),
+                                                       k_weight.data_ptr(), dtype_code(input), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                       gate.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_split_qkvgate_gemma_rmsnorm_rope failed with code ", rc);
+    return {q, k, v, gate};
+}
+
 // torch.ops.npu.mla_preprocess: same schema as the reference (csrc/pytorch_extensions.cpp:105-115; host
 // csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704).  MI355X layouts: wdqkv int8 [2112, hidden] and wuq int8
 // [q_heads*192, 1536] are plain row-major (output channel major, K contiguous) instead of the Ascend NZ fractal format;
@@ -394,6 +420,8 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("split_qkv_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "float? eps=None, Tensor? q_weight=None, Tensor? k_weight=None, Tensor? q_bias=None, Tensor? k_bias=None, "
           "bool is_neox_style=True) -> (Tensor, Tensor, Tensor)");
+    m.def("split_qkvgate_gemma_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
+          "int rope_dim, float eps, Tensor q_weight, Tensor k_weight) -> (Tensor, Tensor, Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(npu, CUDA, m)
@@ -405,4 +433,5 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("add_rmsnorm_bias", TORCH_FN(sglang::npu_kernel::add_rmsnorm_bias));
     m.impl("fused_rope_qk_mqa", TORCH_FN(sglang::npu_kernel::fused_rope_qk_mqa));
     m.impl("split_qkv_rmsnorm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope));
+    m.impl("split_qkvgate_gemma_rmsnorm_rope", TORCH_FN(sglang::npu_kernel::split_qkvgate_gemma_rmsnorm_rope));
 }

@@ -95,6 +95,37 @@ def test_split_qkv_rmsnorm_rope(rope_dim, neox, norm, bias, hd, qh, kvh, B):
     assert torch.allclose(k.cpu().float(), wk.float(), rtol=2 ** -7, atol=1e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hd,qh,kvh,B,rope_dim", [(128, 2048, 512, 7, 64), (128, 4096, 1024, 33, 128), (64, 256, 64, 3, 64), (256, 1024, 256, 4, 32),
+                                                  (8, 16, 8, 2, 4), (1024, 2048, 1024, 2, 512)])
+def test_split_qkvgate_gemma_rmsnorm_rope(hd, qh, kvh, B, rope_dim, dt):
+    """split_qkv_rmsnorm_rope.py:441-745 through torch.ops.npu: gate and V bit for bit, q and k within one ulp of the fp32 restatement."""
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope import split_qkvgate_gemma_rmsnorm_rope
+    torch.manual_seed(hd * 3 + B)
+    x = torch.randn(B, 2 * qh + 2 * kvh).to(dt)
+    qw, kw = torch.randn(hd).to(dt), torch.randn(hd).to(dt)
+    sin, cos = torch.rand(B, rope_dim).to(dt), torch.rand(B, rope_dim).to(dt)
+    wq, wk, wv, wg = OK.split_qkvgate_gemma_rmsnorm_rope(x, sin, cos, qh, kvh, hd, rope_dim, 1e-6, qw, kw)
+    q, k, v, g = split_qkvgate_gemma_rmsnorm_rope(x.cuda(), sin.cuda(), cos.cuda(), qh, kvh, hd, rope_dim, 1e-6, qw.cuda(), kw.cuda())
+    assert q.shape == (B, qh) and k.shape == (B, kvh) and v.shape == (B, kvh) and g.shape == (B, qh)
+    assert torch.equal(v.cpu(), wv) and torch.equal(g.cpu(), wg)
+    ulp = 2 ** -7 if dt == torch.bfloat16 else 2 ** -10
+    assert torch.allclose(q.cpu().float(), wq.float(), rtol=ulp, atol=1e-3)
+    assert torch.allclose(k.cpu().float(), wk.float(), rtol=ulp, atol=1e-3)
+    assert (q.cpu().view(torch.int16) != wq.view(torch.int16)).float().mean() < 0.02      # fp32 on both sides: rounding-boundary cases only
+
+
+def test_split_qkvgate_gemma_rmsnorm_rope_rejects_bad_shapes():
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope import split_qkvgate_gemma_rmsnorm_rope
+    x = torch.randn(2, 2 * 256 + 2 * 128, device="cuda").bfloat16()
+    w = torch.randn(128, device="cuda").bfloat16()
+    sc = torch.rand(2, 64, device="cuda").bfloat16()
+    with pytest.raises(RuntimeError):
+        split_qkvgate_gemma_rmsnorm_rope(x[:, :-8].contiguous(), sc, sc, 256, 128, 128, 64, 1e-6, w, w)       # input width
+    with pytest.raises(AssertionError):
+        split_qkvgate_gemma_rmsnorm_rope(x, sc, sc, 256, 96, 96, 64, 1e-6, w, w)                                # head_dim not a power of two
+
+
 def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
     torch.manual_seed(42)
     d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),

@@ -75,6 +75,11 @@ def main():
     hw = torch.randn(128, device="cuda").to(torch.bfloat16)
     t = ev_time(lambda: split_qkv_rmsnorm_rope(qkv, sn, cs, 6144, 1024, 128, 1e-6, hw, hw, hw, hw))
     out["split_qkv_rmsnorm_rope_4096x8192"] = dict(t, GBps=B * 8192 * 4 / t["p50_us"] / 1e3)
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope import split_qkvgate_gemma_rmsnorm_rope
+    xg = torch.randn((B, 2 * 4096 + 2 * 1024), generator=g, device="cuda").to(torch.bfloat16)
+    sg, cg = torch.rand((B, 64), device="cuda").to(torch.bfloat16), torch.rand((B, 64), device="cuda").to(torch.bfloat16)
+    t = ev_time(lambda: split_qkvgate_gemma_rmsnorm_rope(xg, sg, cg, 4096, 1024, 128, 64, 1e-6, hw, hw))
+    out["split_qkvgate_gemma_rmsnorm_rope_4096x10240"] = dict(t, GBps=B * 10240 * 4 / t["p50_us"] / 1e3)
     # ---- paged GQA decode (HBM-bound): Llama-70B-like (64 q / 8 kv heads, D=128) and the reference's 288/256 config
     from sgl_kernel_npu.attention.decode_attention import decode_gqa
     for name, Bq, Hq, Hkv, D, Dv, Sq in (("gqa_decode_b64_h64kv8_d128_s4096", 64, 64, 8, 128, 128, 4096),
