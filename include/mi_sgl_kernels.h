@@ -33,6 +33,7 @@ extern "C" {
 
 #define MI_DTYPE_BF16 0
 #define MI_DTYPE_F16 1
+#define MI_DTYPE_F32 2      /* the row statistics / scalings below only */
 
 const char *mi_sgl_kernels_version(void);
 
@@ -108,6 +109,18 @@ int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const void *cos,
 int mi_split_qkvgate_gemma_rmsnorm_rope(const void *input, const void *sin, const void *cos, int rows, int q_hidden, int kv_hidden,
                                         int head_dim, int rope_dim, float eps, const void *q_weight, const void *k_weight, int dtype,
                                         void *q, void *k, void *v, void *gate, void *stream);
+
+/* ---- row statistics and scalings (norm/l1_norm.py:7-38, norm/rmsnorm_without_weight.py:30-76, norm/rmsnorm_split.py:34-161) -------------
+ * x [rows, cols] contiguous, dtype MI_DTYPE_BF16 / F16 / F32 (the reference tests use fp32); arithmetic in fp32.
+ *   mi_l1_norm                 out fp32 [rows, cols] = x / sum(x) per row
+ *   mi_rmsnorm_without_weight  out (dtype of x)      = x * rsqrt(sum(x^2) * (1 / cols) + eps)
+ *   mi_row_variance            out (dtype of x) [rows] = sum(x^2) / cols
+ *   mi_rsqrt_mul               out (dtype of x)      = (x * rsqrt(variance[row] + eps)) * weight[col]; variance [rows], weight [cols] in x's dtype */
+int mi_l1_norm(const void *x, long long rows, int cols, int dtype, float *out, void *stream);
+int mi_rmsnorm_without_weight(const void *x, long long rows, int cols, float eps, int dtype, void *out, void *stream);
+int mi_row_variance(const void *x, long long rows, int cols, int dtype, void *out, void *stream);
+int mi_rsqrt_mul(const void *x, const void *variance, const void *weight, long long rows, int cols, float eps, int dtype, void *out,
+                 void *stream);
 
 /* ---- RoPE on q and the shared key heads (norm/fused_rope_qk_mqa.py:113-160) -----------------------------------------
  * q [tokens, q_heads, head_dim], k [tokens, k_heads, head_dim] (strides in elements, last dim contiguous); cos_sin

@@ -264,6 +264,33 @@ def split_qkvgate_gemma_rmsnorm_rope(x, sin, cos, q_hidden, kv_hidden, head_dim,
 
 
 # --------------------------------------------------------------------------------------
+# row statistics / scalings of norm/{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py: transcriptions of the reference tests' goldens
+# --------------------------------------------------------------------------------------
+def l1_norm(x):
+    """tests/python/sgl_kernel_npu/test_l1_norm.py:11-13: fp32 x / sum(x, -1) (kernel: norm/l1_norm.py:19-26)."""
+    xf = x.float()
+    return xf / xf.sum(dim=-1, keepdim=True)
+
+
+def rmsnorm_without_weight(x, eps):
+    """tests/python/sgl_kernel_npu/test_rmsnorm_without_weight.py:7-11: F.rms_norm without a weight = x * rsqrt(mean(x^2) + eps)
+    (kernel: norm/rmsnorm_without_weight.py:50-57), evaluated in fp32 and returned in x's dtype."""
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + eps)).to(x.dtype)
+
+
+def fused_variance(x):
+    """tests/python/sgl_kernel_npu/test_rmsnorm_split.py:15-16: x.pow(2).mean(-1, keepdim=True) (kernel: norm/rmsnorm_split.py:148-156)."""
+    return x.float().pow(2).mean(dim=-1, keepdim=True).to(x.dtype)
+
+
+def fused_rsqrt_mul(x, variance, weight, eps=1e-6):
+    """tests/python/sgl_kernel_npu/test_rmsnorm_split.py:6-12: x * rsqrt(variance + eps) * weight (kernel: norm/rmsnorm_split.py:64-74)."""
+    B, L, C = x.shape
+    return ((x.float() * torch.rsqrt(variance.float().reshape(B, L, 1) + eps)) * weight.float()).to(x.dtype)
+
+
+# --------------------------------------------------------------------------------------
 # A14  mla_preprocess
 # --------------------------------------------------------------------------------------
 def fused_rope_qk_mqa(query, key, cos_sin, rotary_dim, is_neox_style):

@@ -1,0 +1,250 @@
+// Row statistics and row scalings for gfx950, HBM-bound: L1 normalisation, RMSNorm without a weight, and the two halves of a split
+// RMSNorm (row variance; x * rsqrt(variance + eps) * weight).  Replace the reference's Triton-Ascend kernels:
+//   l1_norm                        python/sgl_kernel_npu/sgl_kernel_npu/norm/l1_norm.py:7-38
+//   fused_rmsnorm_without_weight   python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_without_weight.py:30-76
+//   fused_variance                 python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_split.py:124-161
+//   fused_rsqrt_mul                python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_split.py:34-97
+// The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
+// on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
+// MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
+// scaling (one pass over HBM), longer rows are read a second time (out of L2).  L1 rows of at most 32 elements (a router's 8 expert
+// scores per token: 2048 x 8 in the reference test) take one lane each.
+// Algorithmic bytes: rows x cols x (in + out element sizes) (+ 4 rows for the variance).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi_sgl_kernels.h"
+
+namespace mi_sgl {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// element access by dtype code (wave-uniform): 0 = bf16, 1 = fp16, 2 = fp32
+template <int DT> struct Elem;
+template <> struct Elem<MI_DTYPE_BF16> {
+    typedef uint16_t T;
+    static constexpr int kPer16 = 8;
+    static __device__ __forceinline__ float ld(T v) { return __uint_as_float((uint32_t)v << 16); }
+    static __device__ __forceinline__ T st(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+};
+template <> struct Elem<MI_DTYPE_F16> {
+    typedef uint16_t T;
+    static constexpr int kPer16 = 8;
+    static __device__ __forceinline__ float ld(T v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ T st(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+};
+template <> struct Elem<MI_DTYPE_F32> {
+    typedef float T;
+    static constexpr int kPer16 = 4;
+    static __device__ __forceinline__ float ld(T v) { return v; }
+    static __device__ __forceinline__ T st(float f) { return f; }
+};
+
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// what a row kernel computes
+enum { kOpL1 = 0, kOpRms = 1, kOpVariance = 2, kOpRsqrtMul = 3 };
+
+// 16 bytes of a row -> fp32 values (n = elements per 16 bytes)
+template <int DT>
+__device__ __forceinline__ void load16(const typename Elem<DT>::T *p, float *f)
+{
+    const u32x4 v = *(const u32x4 *)p;
+    if constexpr (DT == MI_DTYPE_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = __uint_as_float(v[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = Elem<DT>::ld((uint16_t)(v[j] & 0xFFFFu));
+            f[2 * j + 1] = Elem<DT>::ld((uint16_t)(v[j] >> 16));
+        }
+    }
+}
+template <int DT>
+__device__ __forceinline__ void store16(typename Elem<DT>::T *p, const float *f)
+{
+    u32x4 v;
+    if constexpr (DT == MI_DTYPE_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(f[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (uint32_t)Elem<DT>::st(f[2 * j]) | ((uint32_t)Elem<DT>::st(f[2 * j + 1]) << 16);
+    }
+    *(u32x4 *)p = v;
+}
+
+// One wave per row.  DT = element type of x (and of the output, except L1: fp32 out; variance: DT out).  kChunks 16-byte pieces per lane
+// are kept in registers when the row fits (cols <= 64 * kChunks * kPer16), otherwise the row is read twice.
+template <int OP, int DT>
+__global__ __launch_bounds__(256) void row_kernel(const typename Elem<DT>::T *__restrict__ x, long long rows, int cols, float eps,
+                                                  const typename Elem<DT>::T *__restrict__ variance, const typename Elem<DT>::T *__restrict__ weight,
+                                                  void *__restrict__ out_v)
+{
+    typedef typename Elem<DT>::T T;
+    constexpr int N = Elem<DT>::kPer16;
+    constexpr int kChunks = 16;                             // rows of up to 8192 (16-bit) / 4096 (fp32) elements stay in registers
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T *xr = x + row * (long long)cols;
+    const bool vec = (cols % N) == 0;                       // rows then start 16-byte aligned (the base pointer is)
+    const bool in_regs = vec && cols <= 64 * kChunks * N;
+    float keep[kChunks][N];
+    float acc = 0.f;
+    if (OP != kOpRsqrtMul) {
+        if (in_regs) {
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int i = (c * 64 + lane) * N;
+                if (i < cols) {
+                    load16<DT>(xr + i, keep[c]);
+#pragma unroll
+                    for (int e = 0; e < N; ++e) acc += (OP == kOpL1) ? keep[c][e] : keep[c][e] * keep[c][e];
+                }
+            }
+        } else if (vec) {
+            for (int i = lane * N; i < cols; i += 64 * N) {
+                float f[N];
+                load16<DT>(xr + i, f);
+#pragma unroll
+                for (int e = 0; e < N; ++e) acc += (OP == kOpL1) ? f[e] : f[e] * f[e];
+            }
+        } else {
+            for (int i = lane; i < cols; i += 64) {
+                const float f = Elem<DT>::ld(xr[i]);
+                acc += (OP == kOpL1) ? f : f * f;
+            }
+        }
+        acc = wave_sum_f(acc);
+    }
+    if (OP == kOpVariance) {                                // sum / hidden_size (rmsnorm_split.py:152-154)
+        if (lane == 0) ((T *)out_v)[row] = Elem<DT>::st(acc / (float)cols);
+        return;
+    }
+    // the row's factor: 1 / sum (l1_norm.py:23), rsqrt(sum * (1 / hidden) + eps) (rmsnorm_without_weight.py:52-54),
+    // rsqrt(variance + eps) (rmsnorm_split.py:72)
+    float factor;
+    if (OP == kOpL1) factor = acc;                          // divided below, as the reference does
+    else if (OP == kOpRms) factor = rsqrtf(acc * (1.0f / (float)cols) + eps);
+    else factor = rsqrtf(Elem<DT>::ld(variance[row]) + eps);
+    auto scale = [&](float v, int col) -> float {
+        if (OP == kOpL1) return v / factor;
+        if (OP == kOpRms) return v * factor;
+        return (v * factor) * Elem<DT>::ld(weight[col]);
+    };
+    if (OP == kOpL1) {                                      // fp32 output whatever the input type (l1_norm.py:24-26, :32-34)
+        float *o = (float *)out_v + row * (long long)cols;
+        if (in_regs) {
+#pragma unroll
+            for (int c = 0; c < kChunks; ++c) {
+                const int i = (c * 64 + lane) * N;
+                if (i < cols) {
+#pragma unroll
+                    for (int e = 0; e < N; ++e) o[i + e] = scale(keep[c][e], i + e);
+                }
+            }
+        } else {
+            for (int i = lane; i < cols; i += 64) o[i] = scale(Elem<DT>::ld(xr[i]), i);
+        }
+        return;
+    }
+    T *o = (T *)out_v + row * (long long)cols;
+    if (OP == kOpRms && in_regs) {
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int i = (c * 64 + lane) * N;
+            if (i < cols) {
+                float f[N];
+#pragma unroll
+                for (int e = 0; e < N; ++e) f[e] = scale(keep[c][e], i + e);
+                store16<DT>(o + i, f);
+            }
+        }
+    } else if (vec) {
+        for (int i = lane * N; i < cols; i += 64 * N) {
+            float f[N];
+            load16<DT>(xr + i, f);
+#pragma unroll
+            for (int e = 0; e < N; ++e) f[e] = scale(f[e], i + e);
+            store16<DT>(o + i, f);
+        }
+    } else {
+        for (int i = lane; i < cols; i += 64) o[i] = Elem<DT>::st(scale(Elem<DT>::ld(xr[i]), i));
+    }
+}
+
+// rows of at most 32 elements (a router's expert scores): one lane per row
+template <int DT>
+__global__ __launch_bounds__(256) void l1_small_kernel(const typename Elem<DT>::T *__restrict__ x, long long rows, int cols, float *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const typename Elem<DT>::T *xr = x + row * (long long)cols;
+    float v[32];
+    float s = 0.f;
+    for (int i = 0; i < cols; ++i) {
+        v[i] = Elem<DT>::ld(xr[i]);
+        s += v[i];
+    }
+    for (int i = 0; i < cols; ++i) out[row * (long long)cols + i] = v[i] / s;
+}
+
+template <int OP>
+int launch_rows(const void *x, long long rows, int cols, float eps, const void *variance, const void *weight, int dtype, void *out, void *stream)
+{
+    if (rows < 0 || cols <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16 && dtype != MI_DTYPE_F32)) return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!x || !out || (OP == kOpRsqrtMul && (!variance || !weight))) return MI_SGL_EINVAL;
+    if (rows > (1ll << 33)) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+#define MI_ROW(DT) row_kernel<OP, DT><<<blocks, 256, 0, st>>>((const typename Elem<DT>::T *)x, rows, cols, eps, (const typename Elem<DT>::T *)variance, \
+                                                             (const typename Elem<DT>::T *)weight, out)
+    if (dtype == MI_DTYPE_BF16) MI_ROW(MI_DTYPE_BF16);
+    else if (dtype == MI_DTYPE_F16) MI_ROW(MI_DTYPE_F16);
+    else MI_ROW(MI_DTYPE_F32);
+#undef MI_ROW
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+}  // namespace
+}  // namespace mi_sgl
+
+using namespace mi_sgl;
+
+extern "C" int mi_l1_norm(const void *x, long long rows, int cols, int dtype, float *out, void *stream)
+{
+    if (cols > 0 && cols <= 32 && rows > 0 && x && out && (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16 || dtype == MI_DTYPE_F32)) {
+        const unsigned blocks = (unsigned)((rows + 255) / 256);
+        hipStream_t st = (hipStream_t)stream;
+        if (dtype == MI_DTYPE_BF16) l1_small_kernel<MI_DTYPE_BF16><<<blocks, 256, 0, st>>>((const uint16_t *)x, rows, cols, out);
+        else if (dtype == MI_DTYPE_F16) l1_small_kernel<MI_DTYPE_F16><<<blocks, 256, 0, st>>>((const uint16_t *)x, rows, cols, out);
+        else l1_small_kernel<MI_DTYPE_F32><<<blocks, 256, 0, st>>>((const float *)x, rows, cols, out);
+        return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+    }
+    return launch_rows<kOpL1>(x, rows, cols, 0.f, nullptr, nullptr, dtype, out, stream);
+}
+
+extern "C" int mi_rmsnorm_without_weight(const void *x, long long rows, int cols, float eps, int dtype, void *out, void *stream)
+{
+    return launch_rows<kOpRms>(x, rows, cols, eps, nullptr, nullptr, dtype, out, stream);
+}
+
+extern "C" int mi_row_variance(const void *x, long long rows, int cols, int dtype, void *out, void *stream)
+{
+    return launch_rows<kOpVariance>(x, rows, cols, 0.f, nullptr, nullptr, dtype, out, stream);
+}
+
+extern "C" int mi_rsqrt_mul(const void *x, const void *variance, const void *weight, long long rows, int cols, float eps, int dtype, void *out,
+                            void *stream)
+{
+    return launch_rows<kOpRsqrtMul>(x, rows, cols, eps, variance, weight, dtype, out, stream);
+}

@@ -27,6 +27,12 @@ static int dtype_code(const at::Tensor &t)
     return t.scalar_type() == at::kBFloat16 ? MI_DTYPE_BF16 : MI_DTYPE_F16;
 }
 
+static int dtype_code3(const at::Tensor &t)        // the row statistics / scalings also take fp32 (the reference tests run them in fp32)
+{
+    if (t.scalar_type() == at::kFloat) return MI_DTYPE_F32;
+    return dtype_code(t);
+}
+
 std::string sgl_kernel_npu_version() { return std::string("sgl-kernel-npu_amd 0.1 (") + mi_sgl_kernels_version() + ")"; }
 
 // Paged MLA decode, same argument meaning as the reference Python entry point decode_mla
@@ -214,6 +220,53 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
                                              is_neox_style, dtype_code(input), q.data_ptr(), k.data_ptr(), v.data_ptr(), cur_stream());
     TORCH_CHECK(rc == 0, "mi_split_qkv_rmsnorm_rope failed with code ", rc);
     return {q, k, v};
+}
+
+// norm/l1_norm.py:29-38: fp32 [batch, hidden] = input / sum(input, -1)
+at::Tensor l1_norm(const at::Tensor &input)
+{
+    TORCH_CHECK(input.dim() == 2 && input.is_contiguous(), "l1_norm: input must be contiguous [batch, hidden]");
+    at::Tensor out = at::empty(input.sizes(), input.options().dtype(at::kFloat));
+    const int rc = mi_l1_norm(input.data_ptr(), input.size(0), (int)input.size(1), dtype_code3(input), out.data_ptr<float>(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_l1_norm failed with code ", rc);
+    return out;
+}
+
+// norm/rmsnorm_without_weight.py:59-76: x [B, L, C] -> x * rsqrt(mean(x^2, -1) + eps), same dtype
+at::Tensor rmsnorm_without_weight(const at::Tensor &x, double eps)
+{
+    TORCH_CHECK(x.dim() >= 1 && x.is_contiguous(), "fused_rmsnorm_without_weight: x must be contiguous");
+    at::Tensor out = at::empty_like(x);
+    const int64_t cols = x.size(-1);
+    const int rc = mi_rmsnorm_without_weight(x.data_ptr(), cols ? x.numel() / cols : 0, (int)cols, (float)eps, dtype_code3(x), out.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_rmsnorm_without_weight failed with code ", rc);
+    return out;
+}
+
+// norm/rmsnorm_split.py:150-161: x [B, L, C] -> mean(x^2, -1) as [B, L, 1] in x's dtype
+at::Tensor fused_variance(const at::Tensor &x)
+{
+    TORCH_CHECK(x.dim() == 3 && x.is_contiguous(), "fused_variance: x must be contiguous [B, L, C]");
+    at::Tensor out = at::empty({x.size(0), x.size(1), 1}, x.options());
+    const int rc = mi_row_variance(x.data_ptr(), x.size(0) * x.size(1), (int)x.size(2), dtype_code3(x), out.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_row_variance failed with code ", rc);
+    return out;
+}
+
+// norm/rmsnorm_split.py:76-97: x [B, L, C], variance [B * L], weight [C] -> x * rsqrt(variance + eps) * weight in x's dtype
+at::Tensor fused_rsqrt_mul(const at::Tensor &x, const at::Tensor &variance, const at::Tensor &weight, double eps)
+{
+    TORCH_CHECK(x.dim() == 3 && x.is_contiguous(), "fused_rsqrt_mul: x must be contiguous [B, L, C]");
+    const int64_t rows = x.size(0) * x.size(1), cols = x.size(2);
+    TORCH_CHECK(variance.numel() == rows && variance.is_contiguous() && variance.scalar_type() == x.scalar_type(),
+                "fused_rsqrt_mul: variance must hold B * L values in x's dtype");
+    TORCH_CHECK(weight.numel() == cols && weight.is_contiguous() && weight.scalar_type() == x.scalar_type(),
+                "fused_rsqrt_mul: weight must hold C values in x's dtype");
+    at::Tensor out = at::empty_like(x);
+    const int rc = mi_rsqrt_mul(x.data_ptr(), variance.data_ptr(), weight.data_ptr(), rows, (int)cols, (float)eps, dtype_code3(x), out.data_ptr(),
+                                cur_stream());
+    TORCH_CHECK(rc == 0, "mi_rsqrt_mul failed with code ", rc);
+    return out;
 }
 
 // split [q | gate] + K + V, Gemma RMSNorm + neox RoPE; arguments as split_qkvgate_gemma_rmsnorm_rope (norm/split_qkv_rmsnorm_rope.py:686-745)
@@ -420,6 +473,10 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("split_qkv_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "float? eps=None, Tensor? q_weight=None, Tensor? k_weight=None, Tensor? q_bias=None, Tensor? k_bias=None, "
           "bool is_neox_style=True) -> (Tensor, Tensor, Tensor)");
+    m.def("l1_norm(Tensor input) -> Tensor");
+    m.def("rmsnorm_without_weight(Tensor x, float eps) -> Tensor");
+    m.def("fused_variance(Tensor x) -> Tensor");
+    m.def("fused_rsqrt_mul(Tensor x, Tensor variance, Tensor weight, float eps=1e-6) -> Tensor");
     m.def("split_qkvgate_gemma_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "int rope_dim, float eps, Tensor q_weight, Tensor k_weight) -> (Tensor, Tensor, Tensor, Tensor)");
 }
@@ -434,4 +491,8 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("fused_rope_qk_mqa", TORCH_FN(sglang::npu_kernel::fused_rope_qk_mqa));
     m.impl("split_qkv_rmsnorm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope));
     m.impl("split_qkvgate_gemma_rmsnorm_rope", TORCH_FN(sglang::npu_kernel::split_qkvgate_gemma_rmsnorm_rope));
+    m.impl("l1_norm", TORCH_FN(sglang::npu_kernel::l1_norm));
+    m.impl("rmsnorm_without_weight", TORCH_FN(sglang::npu_kernel::rmsnorm_without_weight));
+    m.impl("fused_variance", TORCH_FN(sglang::npu_kernel::fused_variance));
+    m.impl("fused_rsqrt_mul", TORCH_FN(sglang::npu_kernel::fused_rsqrt_mul));
 }

@@ -126,6 +126,59 @@ def test_split_qkvgate_gemma_rmsnorm_rope_rejects_bad_shapes():
         split_qkvgate_gemma_rmsnorm_rope(x, sc, sc, 256, 96, 96, 64, 1e-6, w, w)                                # head_dim not a power of two
 
 
+_ROW_DT = [torch.float32, torch.bfloat16, torch.float16]
+_ROW_TOL = {torch.float32: 2e-6, torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10}
+
+
+@pytest.mark.parametrize("dt", _ROW_DT)
+@pytest.mark.parametrize("B,C", [(2048, 8), (5, 32), (33, 40), (7, 4096), (3, 20000), (1, 1)])
+def test_l1_norm(B, C, dt):
+    """norm/l1_norm.py against the reference test's golden (test_l1_norm.py: 2048 x 8 bf16, rtol 5e-3): fp32 out."""
+    from sgl_kernel_npu.norm.l1_norm import l1_norm
+    torch.manual_seed(B + C)
+    x = (torch.rand(B, C) + 0.1).to(dt)                  # positive rows: the sum is well away from zero
+    got = l1_norm(x.cuda())
+    want = OK.l1_norm(x)
+    assert got.dtype == torch.float32 and got.shape == (B, C)
+    assert torch.allclose(got.cpu(), want, rtol=2e-5, atol=0)       # fp32 on both sides: summation order only
+    assert torch.allclose(got.cpu().sum(-1), torch.ones(B), atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", _ROW_DT)
+@pytest.mark.parametrize("B,L,C", [(1, 130, 2048), (2, 5, 24), (1, 3, 6000), (1, 9, 20008), (4, 1, 4)])
+def test_rmsnorm_without_weight(B, L, C, dt):
+    """norm/rmsnorm_without_weight.py against F.rms_norm (the reference test's golden: 1 x 130 x 2048 fp32, rtol 1e-3)."""
+    from sgl_kernel_npu.norm.rmsnorm_without_weight import fused_rmsnorm_without_weight
+    torch.manual_seed(L + C)
+    x = torch.randn(B, L, C).to(dt)
+    got = fused_rmsnorm_without_weight(x.cuda(), 1e-6)
+    want = OK.rmsnorm_without_weight(x, 1e-6)
+    assert got.dtype == dt and got.shape == x.shape
+    assert torch.allclose(got.cpu().float(), want.float(), rtol=_ROW_TOL[dt], atol=1e-6)
+    if dt == torch.float32:
+        assert torch.allclose(got.cpu(), torch.nn.functional.rms_norm(x, (C,), eps=1e-6), rtol=1e-3)      # the reference's own assertion
+
+
+@pytest.mark.parametrize("dt", _ROW_DT)
+@pytest.mark.parametrize("B,L,C", [(1, 1024, 512), (1, 8190, 2560), (2, 7, 36), (1, 5, 20008)])
+def test_rmsnorm_split(B, L, C, dt):
+    """norm/rmsnorm_split.py: fused_variance and fused_rsqrt_mul against the reference test's goldens (fp32, rtol 1e-3)."""
+    from sgl_kernel_npu.norm.rmsnorm_split import fused_rsqrt_mul, fused_variance
+    torch.manual_seed(L)
+    x = torch.randn(B, L, C).to(dt)
+    w = torch.randn(C).to(dt)
+    var = (torch.randn(1, B * L, 1).abs() + 0.1).to(dt)
+    gv = fused_variance(x.cuda())
+    assert gv.shape == (B, L, 1) and gv.dtype == dt
+    assert torch.allclose(gv.cpu().float(), OK.fused_variance(x).float(), rtol=max(_ROW_TOL[dt], 1e-5), atol=1e-7)
+    go = fused_rsqrt_mul(x.cuda(), var.view(-1).cuda(), w.cuda(), 1e-6)
+    want = OK.fused_rsqrt_mul(x, var.view(-1), w, 1e-6)
+    assert go.shape == x.shape and go.dtype == dt
+    assert torch.allclose(go.cpu().float(), want.float(), rtol=_ROW_TOL[dt] * 2, atol=1e-6)
+    if dt == torch.float32:
+        assert torch.allclose(go.cpu(), x * torch.rsqrt(var.reshape(B, L, 1) + 1e-6) * w, rtol=1e-3)     # the reference's own assertion
+
+
 def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
     torch.manual_seed(42)
     d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),

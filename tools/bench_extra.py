@@ -80,6 +80,18 @@ def main():
     sg, cg = torch.rand((B, 64), device="cuda").to(torch.bfloat16), torch.rand((B, 64), device="cuda").to(torch.bfloat16)
     t = ev_time(lambda: split_qkvgate_gemma_rmsnorm_rope(xg, sg, cg, 4096, 1024, 128, 64, 1e-6, hw, hw))
     out["split_qkvgate_gemma_rmsnorm_rope_4096x10240"] = dict(t, GBps=B * 10240 * 4 / t["p50_us"] / 1e3)
+    # ---- row statistics / scalings at the reference tests' shapes (fp32) and a bf16 model shape
+    from sgl_kernel_npu.norm.rmsnorm_split import fused_rsqrt_mul, fused_variance
+    from sgl_kernel_npu.norm.rmsnorm_without_weight import fused_rmsnorm_without_weight
+    xr = torch.randn((1, 8190, 2560), generator=g, device="cuda")
+    wr, vr = torch.randn(2560, device="cuda"), torch.rand(8190, device="cuda") + 0.1
+    t = ev_time(lambda: fused_rsqrt_mul(xr, vr, wr, 1e-6))
+    out["fused_rsqrt_mul_8190x2560_f32"] = dict(t, GBps=8190 * 2560 * 8 / t["p50_us"] / 1e3)
+    t = ev_time(lambda: fused_variance(xr))
+    out["fused_variance_8190x2560_f32"] = dict(t, GBps=8190 * 2560 * 4 / t["p50_us"] / 1e3)
+    xb = torch.randn((1, 16384, 7168), generator=g, device="cuda").to(torch.bfloat16)
+    t = ev_time(lambda: fused_rmsnorm_without_weight(xb, 1e-6))
+    out["rmsnorm_without_weight_16384x7168_bf16"] = dict(t, GBps=16384 * 7168 * 4 / t["p50_us"] / 1e3)
     # ---- paged GQA decode (HBM-bound): Llama-70B-like (64 q / 8 kv heads, D=128) and the reference's 288/256 config
     from sgl_kernel_npu.attention.decode_attention import decode_gqa
     for name, Bq, Hq, Hkv, D, Dv, Sq in (("gqa_decode_b64_h64kv8_d128_s4096", 64, 64, 8, 128, 128, 4096),
