@@ -121,6 +121,11 @@ int mi_rmsnorm_without_weight(const void *x, long long rows, int cols, float eps
 int mi_row_variance(const void *x, long long rows, int cols, int dtype, void *out, void *stream);
 int mi_rsqrt_mul(const void *x, const void *variance, const void *weight, long long rows, int cols, float eps, int dtype, void *out,
                  void *stream);
+/* out = x * (c + scale) + shift (norm/scale_shift.py:122-183): x, out [rows, cols] in `dtype`; scale (1 or cols values) and shift (1, cols or
+ * rows * cols values) in ss_dtype = dtype or MI_DTYPE_F32.  c = scale_constant when shift has one value per element (then scale must have
+ * one per column), 1.0 otherwise -- the reference's two kernels (:60, :112). */
+int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel, long long shift_numel,
+                   float scale_constant, int dtype, int ss_dtype, void *out, void *stream);
 
 /* ---- RoPE on q and the shared key heads (norm/fused_rope_qk_mqa.py:113-160) -----------------------------------------
  * q [tokens, q_heads, head_dim], k [tokens, k_heads, head_dim] (strides in elements, last dim contiguous); cos_sin

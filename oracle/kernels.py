@@ -290,6 +290,17 @@ def fused_rsqrt_mul(x, variance, weight, eps=1e-6):
     return ((x.float() * torch.rsqrt(variance.float().reshape(B, L, 1) + eps)) * weight.float()).to(x.dtype)
 
 
+def fused_scale_shift(x, scale, shift, scale_constant=1.0):
+    """tests/python/sgl_kernel_npu/test_scale_shift.py:6-11: x * (1 + scale) + shift; with one shift value per element the kernel uses
+    scale_constant instead of 1 (norm/scale_shift.py:112 against :60).  fp32, returned in x's dtype."""
+    full = shift.numel() == x.numel()                    # tested first by the wrapper (:149)
+    c = scale_constant if full else 1.0
+    sc = scale.float().reshape(-1)
+    sh = shift.float().reshape(-1)
+    sh = sh.reshape(x.shape) if full else sh
+    return (x.float() * (c + sc) + sh).to(x.dtype)
+
+
 # --------------------------------------------------------------------------------------
 # A14  mla_preprocess
 # --------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 //   fused_rmsnorm_without_weight   python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_without_weight.py:30-76
 //   fused_variance                 python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_split.py:124-161
 //   fused_rsqrt_mul                python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_split.py:34-97
+//   fused_scale_shift              python/sgl_kernel_npu/sgl_kernel_npu/norm/scale_shift.py:9-183
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
 // on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
 // MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
@@ -215,10 +216,74 @@ int launch_rows(const void *x, long long rows, int cols, float eps, const void *
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 
+// out = x * (c + scale) + shift (norm/scale_shift.py:9-183): scale one value or one per column, shift one value, one per column or one per
+// element.  With a per-element shift c = scale_constant (fused_scale_shift_kernel_2, :112), otherwise c = 1.0 whatever scale_constant says
+// (fused_scale_shift_kernel, :60) -- as the reference.  DT = type of x and out, ST = type of scale and shift; fp32 arithmetic.
+template <int DT, int ST>
+__global__ __launch_bounds__(256) void scale_shift_kernel(const typename Elem<DT>::T *__restrict__ x, const typename Elem<ST>::T *__restrict__ scale,
+                                                          const typename Elem<ST>::T *__restrict__ shift, long long numel, int cols, int scale_numel,
+                                                          long long shift_numel, float c, typename Elem<DT>::T *__restrict__ out)
+{
+    constexpr int N = Elem<DT>::kPer16;
+    const bool vec = (cols % N) == 0;
+    const long long stride = (long long)gridDim.x * 256;
+    if (vec) {
+        const long long chunks = numel / N;
+        for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < chunks; ch += stride) {
+            const long long i0 = ch * N;
+            const int col0 = (int)(i0 % cols);
+            float f[N];
+            load16<DT>(x + i0, f);
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const float sc = Elem<ST>::ld(scale[scale_numel == 1 ? 0 : col0 + e]);
+                const float sh = Elem<ST>::ld(shift[shift_numel == numel ? i0 + e : (shift_numel == 1 ? 0 : (long long)(col0 + e))]);
+                f[e] = f[e] * (c + sc) + sh;
+            }
+            store16<DT>(out + i0, f);
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) {
+            const int col = (int)(i % cols);
+            const float sc = Elem<ST>::ld(scale[scale_numel == 1 ? 0 : col]);
+            const float sh = Elem<ST>::ld(shift[shift_numel == numel ? i : (shift_numel == 1 ? 0 : (long long)col)]);
+            out[i] = Elem<DT>::st(Elem<DT>::ld(x[i]) * (c + sc) + sh);
+        }
+    }
+}
+
 }  // namespace
 }  // namespace mi_sgl
 
 using namespace mi_sgl;
+
+extern "C" int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel,
+                              long long shift_numel, float scale_constant, int dtype, int ss_dtype, void *out, void *stream)
+{
+    auto ok_dt = [](int d) { return d == MI_DTYPE_BF16 || d == MI_DTYPE_F16 || d == MI_DTYPE_F32; };
+    if (rows < 0 || cols <= 0 || !ok_dt(dtype) || (ss_dtype != dtype && ss_dtype != MI_DTYPE_F32)) return MI_SGL_EINVAL;
+    const long long numel = rows * cols;
+    // the reference's asserts (scale_shift.py:136-141); a per-element shift goes with a per-column scale (kernel_2 reads scale by column)
+    if ((scale_numel != 1 && scale_numel != cols) || (shift_numel != 1 && shift_numel != cols && shift_numel != numel)) return MI_SGL_EINVAL;
+    const bool full_shift = shift_numel == numel;           // tested first, as the reference does (:149): a one-row x takes this form too
+    if (full_shift && scale_numel != cols) return MI_SGL_EINVAL;
+    if (numel == 0) return MI_SGL_OK;
+    if (!x || !scale || !shift || !out) return MI_SGL_EINVAL;
+    const float c = full_shift ? scale_constant : 1.0f;
+    long long blocks = (numel / 4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_SS(DT, ST)                                                                                                                     \
+    scale_shift_kernel<DT, ST><<<(unsigned)blocks, 256, 0, st>>>((const typename Elem<DT>::T *)x, (const typename Elem<ST>::T *)scale,    \
+                                                                 (const typename Elem<ST>::T *)shift, numel, cols, (int)scale_numel,      \
+                                                                 shift_numel, c, (typename Elem<DT>::T *)out)
+    if (dtype == MI_DTYPE_F32) MI_SS(MI_DTYPE_F32, MI_DTYPE_F32);
+    else if (dtype == MI_DTYPE_BF16) { if (ss_dtype == MI_DTYPE_F32) MI_SS(MI_DTYPE_BF16, MI_DTYPE_F32); else MI_SS(MI_DTYPE_BF16, MI_DTYPE_BF16); }
+    else { if (ss_dtype == MI_DTYPE_F32) MI_SS(MI_DTYPE_F16, MI_DTYPE_F32); else MI_SS(MI_DTYPE_F16, MI_DTYPE_F16); }
+#undef MI_SS
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
 
 extern "C" int mi_l1_norm(const void *x, long long rows, int cols, int dtype, float *out, void *stream)
 {

@@ -269,6 +269,23 @@ at::Tensor fused_rsqrt_mul(const at::Tensor &x, const at::Tensor &variance, cons
     return out;
 }
 
+// norm/scale_shift.py:122-183: x [B, L, C] * (c + scale) + shift
+at::Tensor fused_scale_shift(const at::Tensor &x, const at::Tensor &scale, const at::Tensor &shift, double scale_constant)
+{
+    TORCH_CHECK(x.dim() == 3 && x.is_contiguous(), "fused_scale_shift: x must be contiguous [B, L, C]");
+    TORCH_CHECK(scale.is_contiguous() && shift.is_contiguous() && scale.scalar_type() == shift.scalar_type() &&
+                    (scale.scalar_type() == x.scalar_type() || scale.scalar_type() == at::kFloat),
+                "fused_scale_shift: scale and shift must be contiguous, of one dtype: x's or float32");
+    const int64_t rows = x.size(0) * x.size(1), cols = x.size(2);
+    TORCH_CHECK(scale.numel() == 1 || scale.numel() == cols, "scale must be scalar or [hidden_size]");                               // reference :136-138
+    TORCH_CHECK(shift.numel() == 1 || shift.numel() == cols || shift.numel() == x.numel(), "shift must be scalar, [hidden_size] or x's size");      // :139-141
+    at::Tensor out = at::empty_like(x);
+    const int rc = mi_scale_shift(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), rows, (int)cols, scale.numel(), shift.numel(), (float)scale_constant,
+                                  dtype_code3(x), dtype_code3(scale), out.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_scale_shift failed with code ", rc);
+    return out;
+}
+
 // split [q | gate] + K + V, Gemma RMSNorm + neox RoPE; arguments as split_qkvgate_gemma_rmsnorm_rope (norm/split_qkv_rmsnorm_rope.py:686-745)
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkvgate_gemma_rmsnorm_rope(
     const at::Tensor &input, const at::Tensor &sin, const at::Tensor &cos, int64_t q_hidden_size, int64_t kv_hidden_size,
@@ -477,6 +494,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("rmsnorm_without_weight(Tensor x, float eps) -> Tensor");
     m.def("fused_variance(Tensor x) -> Tensor");
     m.def("fused_rsqrt_mul(Tensor x, Tensor variance, Tensor weight, float eps=1e-6) -> Tensor");
+    m.def("fused_scale_shift(Tensor x, Tensor scale, Tensor shift, float scale_constant=1.0) -> Tensor");
     m.def("split_qkvgate_gemma_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "int rope_dim, float eps, Tensor q_weight, Tensor k_weight) -> (Tensor, Tensor, Tensor, Tensor)");
 }
@@ -495,4 +513,5 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("rmsnorm_without_weight", TORCH_FN(sglang::npu_kernel::rmsnorm_without_weight));
     m.impl("fused_variance", TORCH_FN(sglang::npu_kernel::fused_variance));
     m.impl("fused_rsqrt_mul", TORCH_FN(sglang::npu_kernel::fused_rsqrt_mul));
+    m.impl("fused_scale_shift", TORCH_FN(sglang::npu_kernel::fused_scale_shift));
 }

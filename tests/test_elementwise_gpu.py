@@ -179,6 +179,34 @@ def test_rmsnorm_split(B, L, C, dt):
         assert torch.allclose(go.cpu(), x * torch.rsqrt(var.reshape(B, L, 1) + 1e-6) * w, rtol=1e-3)     # the reference's own assertion
 
 
+@pytest.mark.parametrize("dt,ss", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                   (torch.float16, torch.float16)])
+@pytest.mark.parametrize("B,L,C", [(3, 130, 5120), (2, 7, 36), (1, 5, 33), (1, 1, 64)])
+@pytest.mark.parametrize("form", ["per_column", "scalars", "per_element", "per_element_constant"])
+def test_fused_scale_shift(B, L, C, form, dt, ss):
+    """norm/scale_shift.py against the reference test's golden x * (1 + scale) + shift, its three scale / shift shapes (test_scale_shift.py:
+    19-32; 3 x 37440 x 5120 there) and the scale_constant of the per-element form."""
+    from sgl_kernel_npu.norm.scale_shift import fused_scale_shift
+    torch.manual_seed(C)
+    x = torch.randn(B, L, C).to(dt)
+    c = 1.0
+    if form == "per_column":
+        scale, shift = torch.randn(1, 1, C), torch.randn(1, 1, C)
+    elif form == "scalars":
+        scale, shift = torch.randn(1), torch.randn(1)
+    else:
+        scale, shift = torch.randn(1, 1, C), torch.randn(B, L, C)
+        c = 0.5 if form == "per_element_constant" else 1.0
+    scale, shift = scale.to(ss), shift.to(ss)
+    got = fused_scale_shift(x.cuda(), scale.cuda(), shift.cuda(), c)
+    want = OK.fused_scale_shift(x, scale, shift, c)
+    assert got.dtype == dt and got.shape == x.shape
+    tol = {torch.float32: 1e-6, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[dt]
+    assert torch.allclose(got.cpu().float(), want.float(), rtol=tol, atol=tol)
+    if dt == torch.float32 and c == 1.0:
+        assert torch.allclose(got.cpu(), x * (1 + scale) + shift, rtol=1e-3, atol=1e-6)      # the reference's own assertion
+
+
 def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
     torch.manual_seed(42)
     d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),
