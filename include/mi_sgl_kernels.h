@@ -124,6 +124,14 @@ int mi_rsqrt_mul(const void *x, const void *variance, const void *weight, long l
 /* out = x * (c + scale) + shift (norm/scale_shift.py:122-183): x, out [rows, cols] in `dtype`; scale (1 or cols values) and shift (1, cols or
  * rows * cols values) in ss_dtype = dtype or MI_DTYPE_F32.  c = scale_constant when shift has one value per element (then scale must have
  * one per column), 1.0 otherwise -- the reference's two kernels (:60, :112). */
+/* split QKV + tensor-parallel RMSNorm + RoPE (norm/split_qkv_tp_rmsnorm_rope.py:179-288) in two launches around the caller's all-reduce of
+ * qk_var: (1) V copied, qk_var [rows, 2] fp32 = mean(q^2), mean(k^2) over this rank's columns; (2) q, k = rope(dtype((x * rsqrt-like scale) *
+ * weight[col])) with scale = 1 / sqrt(qk_var * inv_tp_world + eps), neox rotation of the first rotary_dim dims of every head with the first
+ * half of the row's cos / sin [rows, rotary_dim].  input [rows, q_cols + 2 k_cols]; weights [q_cols], [k_cols] in the I/O dtype. */
+int mi_split_qkv_tp_var(const void *input, long long rows, int q_cols, int k_cols, int dtype, void *v, float *qk_var, void *stream);
+int mi_split_qkv_tp_norm_rope(const void *input, const void *cos, const void *sin, const float *qk_var, long long rows, int q_cols, int k_cols,
+                              int head_dim, int rotary_dim, float eps, float inv_tp_world, const void *q_weight, const void *k_weight, int dtype,
+                              void *q, void *k, void *stream);
 int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel, long long shift_numel,
                    float scale_constant, int dtype, int ss_dtype, void *out, void *stream);
 

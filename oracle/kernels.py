@@ -290,6 +290,30 @@ def fused_rsqrt_mul(x, variance, weight, eps=1e-6):
     return ((x.float() * torch.rsqrt(variance.float().reshape(B, L, 1) + eps)) * weight.float()).to(x.dtype)
 
 
+def split_qkv_tp_rmsnorm_rope(qkv, cos, sin, q_hidden, kv_hidden, head_dim, eps, q_weight, k_weight, rotary_dim, tp_world=1, other_var=None):
+    """Transcription of the reference test's golden (tests/python/sgl_kernel_npu/test_split_qkv_tp_rmsnorm_rope.py:7-44: rms_norm_tp over
+    the whole row, rounded to the I/O dtype, then custom_rope with the first half of cos / sin, rounded again), generalised the way the
+    kernel is (norm/split_qkv_tp_rmsnorm_rope.py:75-177): rotary_dim <= head_dim, and `other_var` [B, 2] = the sum of the OTHER ranks' local
+    means of squares (what the all-reduce adds) for tp_world > 1."""
+    B = qkv.shape[0]
+    q, k, v = qkv.split([q_hidden, kv_hidden, kv_hidden], dim=-1)
+    half = rotary_dim // 2
+    c = cos.reshape(B, 1, rotary_dim).float()[..., :half]
+    s_ = sin.reshape(B, 1, rotary_dim).float()[..., :half]
+
+    def one(x, w, col):
+        xf = x.float()
+        var = xf.pow(2).mean(dim=-1, keepdim=True)
+        if other_var is not None:
+            var = var + other_var[:, col:col + 1].float()
+        y = (xf * (1.0 / torch.sqrt(var * (1.0 / tp_world) + eps)) * w.float()).to(x.dtype).float().reshape(B, -1, head_dim)
+        x1, x2 = y[..., :half], y[..., half:2 * half]
+        out = torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_, y[..., 2 * half:]], dim=-1)
+        return out.reshape(B, -1).to(x.dtype)
+
+    return one(q, q_weight, 0), one(k, k_weight, 1), v.clone()
+
+
 def fused_scale_shift(x, scale, shift, scale_constant=1.0):
     """tests/python/sgl_kernel_npu/test_scale_shift.py:6-11: x * (1 + scale) + shift; with one shift value per element the kernel uses
     scale_constant instead of 1 (norm/scale_shift.py:112 against :60).  fp32, returned in x's dtype."""

@@ -5,6 +5,7 @@
 //   fused_variance                 python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_split.py:124-161
 //   fused_rsqrt_mul                python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_split.py:34-97
 //   fused_scale_shift              python/sgl_kernel_npu/sgl_kernel_npu/norm/scale_shift.py:9-183
+//   split_qkv_tp_rmsnorm_rope      python/sgl_kernel_npu/sgl_kernel_npu/norm/split_qkv_tp_rmsnorm_rope.py:7-288
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
 // on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
 // MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
@@ -252,10 +253,150 @@ __global__ __launch_bounds__(256) void scale_shift_kernel(const typename Elem<DT
     }
 }
 
+// ---- split QKV + tensor-parallel RMSNorm + RoPE (norm/split_qkv_tp_rmsnorm_rope.py:7-288) -------------------------------------------------
+// The norm runs over the WHOLE q row and the whole k row of this rank's shard (not per head), its mean of squares is summed over the
+// tensor-parallel ranks between the two kernels (the caller's all-reduce).
+//   kernel 1 (:7-73): V copied; qk_var[row] = {sum(q^2) / q_cols, sum(k^2) / k_cols} in fp32 (the reference also copies q and k here and
+//            normalises them in place later; here kernel 2 reads them from the input row, same result, one pass less)
+//   kernel 2 (:75-177): scale = 1 / sqrt(var * inv_tp_world + eps); y = dtype((x * scale) * w[col]) -- rounded to the I/O dtype before the
+//            rotation, as the reference stores it (:113-117) --; per head, p < rotary_dim / 2: out[p] = y[p] cos[p] - y[p + h] sin[p],
+//            out[p + h] = y[p + h] cos[p] + y[p] sin[p] with the FIRST half of the row's cos / sin (:131-152); other dims keep y.
+template <int DT>
+__global__ __launch_bounds__(256) void tp_var_kernel(const typename Elem<DT>::T *__restrict__ in, int q_cols, int k_cols, typename Elem<DT>::T *__restrict__ v,
+                                                     float *__restrict__ qk_var)
+{
+    typedef typename Elem<DT>::T T;
+    constexpr int N = Elem<DT>::kPer16;
+    __shared__ float red[2][4];
+    const long long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T *rin = in + row * (long long)(q_cols + 2 * k_cols);
+    float ssq = 0.f, ssk = 0.f;
+    for (int i = tid * N; i < q_cols; i += 256 * N) {
+        float f[N];
+        load16<DT>(rin + i, f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) ssq += f[e] * f[e];
+    }
+    for (int i = tid * N; i < k_cols; i += 256 * N) {
+        float f[N];
+        load16<DT>(rin + q_cols + i, f);
+#pragma unroll
+        for (int e = 0; e < N; ++e) ssk += f[e] * f[e];
+        *(u32x4 *)(v + row * (long long)k_cols + i) = *(const u32x4 *)(rin + q_cols + k_cols + i);
+    }
+    ssq = wave_sum_f(ssq), ssk = wave_sum_f(ssk);
+    if ((tid & 63) == 0) red[0][tid >> 6] = ssq, red[1][tid >> 6] = ssk;
+    __syncthreads();
+    if (tid == 0) {
+        qk_var[row * 2 + 0] = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) / (float)q_cols;
+        qk_var[row * 2 + 1] = (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) / (float)k_cols;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void tp_norm_rope_kernel(const typename Elem<DT>::T *__restrict__ in, const typename Elem<DT>::T *__restrict__ cos,
+                                                           const typename Elem<DT>::T *__restrict__ sin, const float *__restrict__ qk_var, int q_cols, int k_cols,
+                                                           int head_dim, int rotary_dim, float eps, float inv_tp, const typename Elem<DT>::T *__restrict__ qw,
+                                                           const typename Elem<DT>::T *__restrict__ kw, typename Elem<DT>::T *__restrict__ q,
+                                                           typename Elem<DT>::T *__restrict__ k)
+{
+    typedef typename Elem<DT>::T T;
+    constexpr int N = Elem<DT>::kPer16;
+    const long long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T *rin = in + row * (long long)(q_cols + 2 * k_cols);
+    const int half = rotary_dim >> 1;
+    const T *cr = cos + row * (long long)rotary_dim, *sr = sin + row * (long long)rotary_dim;
+    // units of N consecutive elements: a rotated unit carries its partner (half further on) with it
+    const int units_head = head_dim / N, rot_units = half / N;               // per head: [0, rot_units) lower halves, partners implied
+    const int work_head = units_head - rot_units;                           // lower-half units + the units behind rotary_dim
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+        const int cols = part ? k_cols : q_cols;
+        const T *src = part ? rin + q_cols : rin;
+        const T *w = part ? kw : qw;
+        T *dst = (part ? k + row * (long long)k_cols : q + row * (long long)q_cols);
+        const float scale = 1.0f / sqrtf(qk_var[row * 2 + part] * inv_tp + eps);
+        const int heads = cols / head_dim;
+        for (int u = tid; u < heads * work_head; u += 256) {
+            const int h = u / work_head, j = u - h * work_head;
+            const bool rot = j < rot_units;
+            const int c0 = h * head_dim + (rot ? j * N : rotary_dim + (j - rot_units) * N);
+            float a[N], wa[N];
+            load16<DT>(src + c0, a);
+            load16<DT>(w + c0, wa);
+#pragma unroll
+            for (int e = 0; e < N; ++e) a[e] = Elem<DT>::ld(Elem<DT>::st((a[e] * scale) * wa[e]));
+            if (rot) {
+                float b[N], wb[N], cv[N], sv[N];
+                load16<DT>(src + c0 + half, b);
+                load16<DT>(w + c0 + half, wb);
+                load16<DT>(cr + j * N, cv);
+                load16<DT>(sr + j * N, sv);
+                float o1[N], o2[N];
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    b[e] = Elem<DT>::ld(Elem<DT>::st((b[e] * scale) * wb[e]));
+                    o1[e] = a[e] * cv[e] - b[e] * sv[e];
+                    o2[e] = b[e] * cv[e] + a[e] * sv[e];
+                }
+                store16<DT>(dst + c0, o1);
+                store16<DT>(dst + c0 + half, o2);
+            } else {
+                store16<DT>(dst + c0, a);
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace mi_sgl
 
 using namespace mi_sgl;
+
+static bool tp_shape_ok(long long rows, int q_cols, int k_cols, int head_dim, int rotary_dim, int dtype)
+{
+    const int n = dtype == MI_DTYPE_F32 ? 4 : 8;
+    return rows >= 0 && rows < (1ll << 31) && head_dim > 0 && (head_dim & (head_dim - 1)) == 0 && q_cols > 0 && k_cols > 0 && q_cols % head_dim == 0 &&
+           k_cols % head_dim == 0 && q_cols % k_cols == 0 && rotary_dim > 0 && rotary_dim <= head_dim && rotary_dim % (2 * n) == 0 && head_dim % n == 0 &&
+           (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16 || dtype == MI_DTYPE_F32);
+}
+
+extern "C" int mi_split_qkv_tp_var(const void *input, long long rows, int q_cols, int k_cols, int dtype, void *v, float *qk_var, void *stream)
+{
+    const int n16 = dtype == MI_DTYPE_F32 ? 4 : 8;          // elements per 16-byte access
+    if (rows < 0 || rows >= (1ll << 31) || q_cols <= 0 || k_cols <= 0 || q_cols % n16 || k_cols % n16 ||
+        (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16 && dtype != MI_DTYPE_F32))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!input || !v || !qk_var) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI_DTYPE_BF16) tp_var_kernel<MI_DTYPE_BF16><<<(unsigned)rows, 256, 0, st>>>((const uint16_t *)input, q_cols, k_cols, (uint16_t *)v, qk_var);
+    else if (dtype == MI_DTYPE_F16) tp_var_kernel<MI_DTYPE_F16><<<(unsigned)rows, 256, 0, st>>>((const uint16_t *)input, q_cols, k_cols, (uint16_t *)v, qk_var);
+    else tp_var_kernel<MI_DTYPE_F32><<<(unsigned)rows, 256, 0, st>>>((const float *)input, q_cols, k_cols, (float *)v, qk_var);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_split_qkv_tp_norm_rope(const void *input, const void *cos, const void *sin, const float *qk_var, long long rows, int q_cols, int k_cols,
+                                         int head_dim, int rotary_dim, float eps, float inv_tp_world, const void *q_weight, const void *k_weight, int dtype,
+                                         void *q, void *k, void *stream)
+{
+    if (!tp_shape_ok(rows, q_cols, k_cols, head_dim, rotary_dim, dtype)) return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!input || !cos || !sin || !qk_var || !q_weight || !k_weight || !q || !k) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_TPN(DT)                                                                                                                              \
+    tp_norm_rope_kernel<DT><<<(unsigned)rows, 256, 0, st>>>((const typename Elem<DT>::T *)input, (const typename Elem<DT>::T *)cos,               \
+                                                            (const typename Elem<DT>::T *)sin, qk_var, q_cols, k_cols, head_dim, rotary_dim, eps,  \
+                                                            inv_tp_world, (const typename Elem<DT>::T *)q_weight, (const typename Elem<DT>::T *)k_weight, \
+                                                            (typename Elem<DT>::T *)q, (typename Elem<DT>::T *)k)
+    if (dtype == MI_DTYPE_BF16) MI_TPN(MI_DTYPE_BF16);
+    else if (dtype == MI_DTYPE_F16) MI_TPN(MI_DTYPE_F16);
+    else MI_TPN(MI_DTYPE_F32);
+#undef MI_TPN
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
 
 extern "C" int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel,
                               long long shift_numel, float scale_constant, int dtype, int ss_dtype, void *out, void *stream)

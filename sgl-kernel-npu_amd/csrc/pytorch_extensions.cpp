@@ -286,6 +286,45 @@ at::Tensor fused_scale_shift(const at::Tensor &x, const at::Tensor &scale, const
     return out;
 }
 
+// norm/split_qkv_tp_rmsnorm_rope.py:179-288, first launch: (v, qk_var [batch, 2] fp32 = mean(q^2), mean(k^2) of this rank's columns)
+std::tuple<at::Tensor, at::Tensor> split_qkv_tp_local_var(const at::Tensor &input, int64_t q_hidden_size, int64_t kv_hidden_size)
+{
+    TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && input.size(1) == q_hidden_size + 2 * kv_hidden_size,
+                "split_qkv_tp_rmsnorm_rope: input must be contiguous [batch, q + 2 kv]");
+    const int64_t B = input.size(0);
+    at::Tensor v = at::empty({B, kv_hidden_size}, input.options());
+    at::Tensor qk_var = at::empty({B, 2}, input.options().dtype(at::kFloat));
+    const int rc = mi_split_qkv_tp_var(input.data_ptr(), B, (int)q_hidden_size, (int)kv_hidden_size, dtype_code3(input), v.data_ptr(),
+                                       qk_var.data_ptr<float>(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_split_qkv_tp_var failed with code ", rc);
+    return {v, qk_var};
+}
+
+// second launch, behind the all-reduce of qk_var: (q, k)
+std::tuple<at::Tensor, at::Tensor> split_qkv_tp_norm_rope(const at::Tensor &input, const at::Tensor &cos, const at::Tensor &sin, const at::Tensor &qk_var,
+                                                          int64_t q_hidden_size, int64_t kv_hidden_size, int64_t head_dim, double eps,
+                                                          const at::Tensor &q_weight, const at::Tensor &k_weight, int64_t rotary_dim, double inv_tp_world)
+{
+    TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && input.size(1) == q_hidden_size + 2 * kv_hidden_size,
+                "split_qkv_tp_rmsnorm_rope: input must be contiguous [batch, q + 2 kv]");
+    const int64_t B = input.size(0);
+    TORCH_CHECK((head_dim & (head_dim - 1)) == 0, "head_dim must be a power of two");              // reference :229-230
+    TORCH_CHECK(q_hidden_size % kv_hidden_size == 0, "q_hidden_size % kv_hidden_size != 0");         // reference :231
+    TORCH_CHECK(cos.numel() == B * rotary_dim && sin.numel() == B * rotary_dim && cos.is_contiguous() && sin.is_contiguous() &&
+                    cos.scalar_type() == input.scalar_type() && sin.scalar_type() == input.scalar_type(),
+                "split_qkv_tp_rmsnorm_rope: cos / sin must be contiguous [batch, rotary_dim] in the input dtype");
+    TORCH_CHECK(q_weight.numel() == q_hidden_size && k_weight.numel() == kv_hidden_size && q_weight.is_contiguous() && k_weight.is_contiguous() &&
+                    q_weight.scalar_type() == input.scalar_type() && k_weight.scalar_type() == input.scalar_type(),
+                "split_qkv_tp_rmsnorm_rope: weights must be [q_hidden_size] / [kv_hidden_size] in the input dtype");
+    TORCH_CHECK(qk_var.numel() == 2 * B && qk_var.is_contiguous() && qk_var.scalar_type() == at::kFloat, "qk_var must be float32 [batch, 2]");
+    at::Tensor q = at::empty({B, q_hidden_size}, input.options()), k = at::empty({B, kv_hidden_size}, input.options());
+    const int rc = mi_split_qkv_tp_norm_rope(input.data_ptr(), cos.data_ptr(), sin.data_ptr(), qk_var.data_ptr<float>(), B, (int)q_hidden_size,
+                                             (int)kv_hidden_size, (int)head_dim, (int)rotary_dim, (float)eps, (float)inv_tp_world, q_weight.data_ptr(),
+                                             k_weight.data_ptr(), dtype_code3(input), q.data_ptr(), k.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_split_qkv_tp_norm_rope failed with code ", rc);
+    return {q, k};
+}
+
 // split [q | gate] + K + V, Gemma RMSNorm + neox RoPE; arguments as split_qkvgate_gemma_rmsnorm_rope (norm/split_qkv_rmsnorm_rope.py:686-745)
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkvgate_gemma_rmsnorm_rope(
     const at::Tensor &input, const at::Tensor &sin, const at::Tensor &cos, int64_t q_hidden_size, int64_t kv_hidden_size,
@@ -495,6 +534,9 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("fused_variance(Tensor x) -> Tensor");
     m.def("fused_rsqrt_mul(Tensor x, Tensor variance, Tensor weight, float eps=1e-6) -> Tensor");
     m.def("fused_scale_shift(Tensor x, Tensor scale, Tensor shift, float scale_constant=1.0) -> Tensor");
+    m.def("split_qkv_tp_local_var(Tensor input, int q_hidden_size, int kv_hidden_size) -> (Tensor, Tensor)");
+    m.def("split_qkv_tp_norm_rope(Tensor input, Tensor cos, Tensor sin, Tensor qk_var, int q_hidden_size, int kv_hidden_size, int head_dim, "
+          "float eps, Tensor q_weight, Tensor k_weight, int rotary_dim, float inv_tp_world) -> (Tensor, Tensor)");
     m.def("split_qkvgate_gemma_rmsnorm_rope(Tensor input, Tensor sin, Tensor cos, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "int rope_dim, float eps, Tensor q_weight, Tensor k_weight) -> (Tensor, Tensor, Tensor, Tensor)");
 }
@@ -514,4 +556,6 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("fused_variance", TORCH_FN(sglang::npu_kernel::fused_variance));
     m.impl("fused_rsqrt_mul", TORCH_FN(sglang::npu_kernel::fused_rsqrt_mul));
     m.impl("fused_scale_shift", TORCH_FN(sglang::npu_kernel::fused_scale_shift));
+    m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));
+    m.impl("split_qkv_tp_norm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_tp_norm_rope));
 }

@@ -207,6 +207,44 @@ def test_fused_scale_shift(B, L, C, form, dt, ss):
         assert torch.allclose(got.cpu(), x * (1 + scale) + shift, rtol=1e-3, atol=1e-6)      # the reference's own assertion
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("qh,kvh,hd,B,rot", [(6144, 1024, 128, 12, 128), (512, 128, 64, 3, 32), (256, 256, 256, 5, 64), (1024, 512, 128, 1, 128)])
+def test_split_qkv_tp_rmsnorm_rope(qh, kvh, hd, B, rot, dt):
+    """norm/split_qkv_tp_rmsnorm_rope.py at tp_world = 1 against the reference test's golden (6144 / 1024 / 128, 12 rows, bf16, atol 5e-2 there):
+    V bit for bit; q, k within one ulp of the golden's two roundings (the sum of squares is added up in another order)."""
+    from sgl_kernel_npu.norm.split_qkv_tp_rmsnorm_rope import split_qkv_tp_rmsnorm_rope
+    torch.manual_seed(qh + B)
+    qkv = torch.randn(B, qh + 2 * kvh).to(dt)
+    qw, kw = torch.randn(qh).to(dt), torch.randn(kvh).to(dt)
+    sin, cos = torch.rand(B, rot).to(dt), torch.rand(B, rot).to(dt)
+    q, k, v = split_qkv_tp_rmsnorm_rope(qkv.cuda(), cos.cuda(), sin.cuda(), qh, kvh, hd, 1e-6, qw.cuda(), kw.cuda(), rot, 1, None)
+    wq, wk, wv = OK.split_qkv_tp_rmsnorm_rope(qkv, cos, sin, qh, kvh, hd, 1e-6, qw, kw, rot)
+    assert torch.equal(v.cpu(), wv)
+    ulp = {torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10, torch.float32: 1e-5}[dt]
+    for got, want in ((q, wq), (k, wk)):
+        assert got.dtype == dt
+        assert torch.allclose(got.cpu().float(), want.float(), rtol=2 * ulp, atol=2 * ulp)       # two roundings: norm, then rotation
+        assert torch.allclose(got.cpu().float(), want.float(), atol=5e-2)                        # the reference's own bar
+
+
+def test_split_qkv_tp_rmsnorm_rope_two_launch_form_with_a_foreign_variance():
+    """tp_world = 2 without a second rank: the second launch is fed local + foreign variance, as the all-reduce would."""
+    torch.manual_seed(5)
+    B, qh, kvh, hd = 6, 512, 128, 64
+    dt = torch.bfloat16
+    qkv = torch.randn(B, qh + 2 * kvh).to(dt)
+    qw, kw = torch.randn(qh).to(dt), torch.randn(kvh).to(dt)
+    sin, cos = torch.rand(B, hd).to(dt), torch.rand(B, hd).to(dt)
+    other = torch.rand(B, 2) + 0.5
+    v, var = torch.ops.npu.split_qkv_tp_local_var(qkv.cuda(), qh, kvh)
+    want_var = torch.stack([qkv[:, :qh].float().pow(2).mean(-1), qkv[:, qh:qh + kvh].float().pow(2).mean(-1)], dim=-1)
+    assert torch.allclose(var.cpu(), want_var, rtol=1e-5)
+    q, k = torch.ops.npu.split_qkv_tp_norm_rope(qkv.cuda(), cos.cuda(), sin.cuda(), var + other.cuda(), qh, kvh, hd, 1e-6, qw.cuda(), kw.cuda(), hd, 0.5)
+    wq, wk, wv = OK.split_qkv_tp_rmsnorm_rope(qkv, cos, sin, qh, kvh, hd, 1e-6, qw, kw, hd, tp_world=2, other_var=other)
+    assert torch.equal(v.cpu(), wv)
+    assert torch.allclose(q.cpu().float(), wq.float(), rtol=2 ** -6, atol=2 ** -6) and torch.allclose(k.cpu().float(), wk.float(), rtol=2 ** -6, atol=2 ** -6)
+
+
 def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
     torch.manual_seed(42)
     d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),
