@@ -110,6 +110,15 @@ int mi_split_qkvgate_gemma_rmsnorm_rope(const void *input, const void *sin, cons
                                         int head_dim, int rope_dim, float eps, const void *q_weight, const void *k_weight, int dtype,
                                         void *q, void *k, void *v, void *gate, void *stream);
 
+/* split QKV (+ gate) + per-head RMSNorm (+ bias) + multimodal RoPE (norm/split_qkv_rmsnorm_mrope.py:335-420): cos_sin [3, rows, rope_dim],
+ * per section (t, h, w) the first half of a row = cos, the second = sin; rotation offset o < rope_dim / 2 reads section h when
+ * (sections_interleaved: o % 3 == 1 and o <= 3 sec_h; else sec_t <= o < sec_t + sec_h), w when (o % 3 == 2 and o <= 3 sec_w; else
+ * o >= sec_t + sec_h), otherwise t; rotate-half on the first rope_dim dims.  gate != NULL: the row starts with q_heads pairs
+ * [q head | gate head] and the gates are copied out.  head_dim a power of two in [64, 256], rope_dim % 16 == 0. */
+int mi_split_qkv_rmsnorm_mrope(const void *qkv, const void *cos_sin, int rows, int q_hidden, int kv_hidden, int head_dim, int rope_dim, float eps,
+                               const void *q_weight, const void *k_weight, const void *q_bias, const void *k_bias, int sec_t, int sec_h,
+                               int sec_w, int sections_interleaved, int dtype, void *q, void *k, void *v, void *gate, void *stream);
+
 /* ---- row statistics and scalings (norm/l1_norm.py:7-38, norm/rmsnorm_without_weight.py:30-76, norm/rmsnorm_split.py:34-161) -------------
  * x [rows, cols] contiguous, dtype MI_DTYPE_BF16 / F16 / F32 (the reference tests use fp32); arithmetic in fp32.
  *   mi_l1_norm                 out fp32 [rows, cols] = x / sum(x) per row

@@ -290,6 +290,53 @@ def fused_rsqrt_mul(x, variance, weight, eps=1e-6):
     return ((x.float() * torch.rsqrt(variance.float().reshape(B, L, 1) + eps)) * weight.float()).to(x.dtype)
 
 
+def split_qkv_rmsnorm_mrope(qkv, q_weight, k_weight, cos_sin, num_q_heads, num_kv_heads, head_size, eps, mrope_section, is_interleaved,
+                            rope_dim=None, q_bias=None, k_bias=None, has_gate=False):
+    """Transcription of the reference test's golden (tests/python/sgl_kernel_npu/test_split_qkv_rmsnorm_mrope.py:7-110: _select_mrope_cos_sin,
+    _rms_norm, _apply_mrope, _golden) for norm/split_qkv_rmsnorm_mrope.py:57-420; outputs in the I/O dtype."""
+    rope_dim = head_size if rope_dim is None else rope_dim
+    T = qkv.shape[0]
+    q_size, kv_size = num_q_heads * head_size, num_kv_heads * head_size
+    half = rope_dim // 2
+    off = torch.arange(half)
+    if is_interleaved:
+        h_mask = (off % 3 == 1) & (off <= 3 * mrope_section[1])
+        w_mask = (off % 3 == 2) & (off <= 3 * mrope_section[2])
+        t_mask = ~(h_mask | w_mask)
+    else:
+        t_end = mrope_section[0]
+        h_end = t_end + mrope_section[1]
+        t_mask = off < t_end
+        h_mask = (off >= t_end) & (off < h_end)
+    cs = cos_sin.float()
+    cos = torch.where(t_mask, cs[0, :, :half], torch.where(h_mask, cs[1, :, :half], cs[2, :, :half]))
+    sin = torch.where(t_mask, cs[0, :, half:], torch.where(h_mask, cs[1, :, half:], cs[2, :, half:]))
+    cos, sin = torch.cat((cos, cos), dim=-1), torch.cat((sin, sin), dim=-1)
+    if has_gate:
+        q_gate, k, v = qkv.split((q_size * 2, kv_size, kv_size), dim=-1)
+        q, gate = q_gate.reshape(T, num_q_heads, head_size * 2).chunk(2, dim=-1)
+        gate = gate.reshape(T, q_size).clone()
+    else:
+        q, k, v = qkv.split((q_size, kv_size, kv_size), dim=-1)
+        q = q.reshape(T, num_q_heads, head_size)
+        gate = qkv.new_empty((T, 0))
+    k = k.reshape(T, num_kv_heads, head_size)
+
+    def norm(x, w, b):
+        x = x.float()
+        x = x * torch.rsqrt(x.square().mean(dim=-1, keepdim=True) + eps)
+        x = x * w.float()
+        return x + b.float() if b is not None else x
+
+    def rope(x):
+        rot = x[..., :rope_dim]
+        x1, x2 = rot.chunk(2, dim=-1)
+        rot = rot * cos[:, None, :] + torch.cat((-x2, x1), dim=-1) * sin[:, None, :]
+        return torch.cat((rot, x[..., rope_dim:]), dim=-1)
+
+    return (rope(norm(q, q_weight, q_bias)).flatten(1).to(qkv.dtype), rope(norm(k, k_weight, k_bias)).flatten(1).to(qkv.dtype), v.clone(), gate)
+
+
 def split_qkv_tp_rmsnorm_rope(qkv, cos, sin, q_hidden, kv_hidden, head_dim, eps, q_weight, k_weight, rotary_dim, tp_world=1, other_var=None):
     """Transcription of the reference test's golden (tests/python/sgl_kernel_npu/test_split_qkv_tp_rmsnorm_rope.py:7-44: rms_norm_tp over
     the whole row, rounded to the I/O dtype, then custom_rope with the first half of cos / sin, rounded again), generalised the way the

@@ -448,16 +448,33 @@ __global__ __launch_bounds__(256) void split_qkvgate_gemma_kernel(
 // all-V groups (31.5), sharing one sin / cos load between the groups of a wave (31.4; with the selection deferred to the use: 36).
 constexpr int kVecUnroll = 2;
 
-template <bool BF16>
+// MROPE (norm/split_qkv_rmsnorm_mrope.py:57-333; golden tests/python/sgl_kernel_npu/test_split_qkv_rmsnorm_mrope.py:7-110): `sin` is
+// cos_sin [3, rows, rope_dim] -- per section (t, h, w) the first half of a row holds cos, the second sin --, `cos` unused; rotation
+// offset o = p mod rope_dim / 2 takes its cos / sin from section h when (sections interleaved: o % 3 == 1 and o <= 3 sec1; contiguous:
+// sec0 <= o < sec0 + sec1), from w when (o % 3 == 2 and o <= 3 sec2; contiguous: o >= sec0 + sec1), else from t.  Always rotate-half.
+struct MropeSections {
+    int sec0, sec1, sec2, interleaved;
+};
+__device__ __forceinline__ int mrope_section_of(const MropeSections &m, int o)
+{
+    if (m.interleaved) {
+        const int r = o % 3;
+        if (r == 1 && o <= 3 * m.sec1) return 1;
+        if (r == 2 && o <= 3 * m.sec2) return 2;
+        return 0;
+    }
+    return o < m.sec0 ? 0 : (o < m.sec0 + m.sec1 ? 1 : 2);
+}
+template <bool BF16, bool MROPE>
 __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ sin, const uint16_t *__restrict__ cos, int rows, int q_hidden,
     int kv_hidden, int head_dim, int rope_dim, int has_norm, float eps, const uint16_t *__restrict__ qw,
     const uint16_t *__restrict__ kw, const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kb, int neox,
-    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v, uint16_t *__restrict__ gate)
+    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v, uint16_t *__restrict__ gate, int gemma, MropeSections ms)
 {
     // gate != nullptr: the gated Gemma form (split_qkv_rmsnorm_rope.py:441-745) -- the row is q_heads pairs [q head | gate head], then K,
-    // then V, i.e. still one head-sized item every head_dim elements; odd items of the first 2 q_heads are gates (copied like V), the
-    // norm weight is w + 1 and the scale rsqrt(mean + eps) (:468, :499-503)
+    // then V, i.e. still one head-sized item every head_dim elements; odd items of the first 2 q_heads are gates (copied like V).
+    // gemma: the norm weight is w + 1 and the scale rsqrt(mean + eps) (:468, :499-503)
     const bool gated = gate != nullptr;
     const int lane = threadIdx.x & 63;
     const int gl = head_dim >> 3;                      // lanes per head (8 .. 32), a power of two
@@ -491,7 +508,29 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
         xr[u] = active[u] ? *(const u32x4 *)(qkv + row[u] * total_hidden + (long long)h[u] * head_dim + j * 8) : zero4;
         wr[u] = (has_norm && normed) ? *(const u32x4 *)((is_q ? qw : kw) + j * 8) : zero4;
         br[u] = (has_norm && normed && qb) ? *(const u32x4 *)((is_q ? qb : kb) + j * 8) : zero4;
-        if (neox) {
+        if (MROPE) {
+            sr[u] = zero4, cr[u] = zero4;
+            if (normed && roped) {
+                const int o0 = (j * 8) % half;            // this lane's eight rotation offsets: the chunk does not straddle rope_dim / 2
+                const long long sec_stride = (long long)rows * rope_dim;
+                const uint16_t *base = sin + row[u] * (long long)rope_dim + o0;
+                u32x4 c3[3], s3[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    c3[t] = *(const u32x4 *)(base + t * sec_stride);
+                    s3[t] = *(const u32x4 *)(base + t * sec_stride + half);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int sec = mrope_section_of(ms, o0 + e);
+                    const int wd = e >> 1, sh = (e & 1) * 16;
+                    const uint32_t cvv = sec == 0 ? c3[0][wd] : (sec == 1 ? c3[1][wd] : c3[2][wd]);
+                    const uint32_t svv = sec == 0 ? s3[0][wd] : (sec == 1 ? s3[1][wd] : s3[2][wd]);
+                    cr[u][wd] |= ((cvv >> sh) & 0xFFFFu) << sh;
+                    sr[u][wd] |= ((svv >> sh) & 0xFFFFu) << sh;
+                }
+            }
+        } else if (neox) {
             sr[u] = (normed && roped) ? *(const u32x4 *)(sin + row[u] * (long long)rope_dim + j * 8) : zero4;
             cr[u] = (normed && roped) ? *(const u32x4 *)(cos + row[u] * (long long)rope_dim + j * 8) : zero4;
         } else {
@@ -520,10 +559,10 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             if (gl >= 16) ss += dpp_f32<0x140>(ss);         // row_mirror: the other half of the 16-lane row
             if (gl == 32) ss += __shfl_xor(ss, 16, 64);
             if (active[u] && !is_v) {
-                const float rstd = gated ? rsqrtf(ss / (float)head_dim + eps) : 1.0f / sqrtf(ss / (float)head_dim + eps);
+                const float rstd = (gemma || MROPE) ? rsqrtf(ss / (float)head_dim + eps) : 1.0f / sqrtf(ss / (float)head_dim + eps);
                 float wv[8];
                 unpack8<BF16>(wr[u], wv);
-                if (gated) {
+                if (gemma) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) wv[e] = wv[e] + 1.0f;
                 }
@@ -723,10 +762,10 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
         const long long waves = ((heads + hpw - 1) / hpw + kVecUnroll - 1) / kVecUnroll;
         const int blocks = (int)((waves + 3) / 4);
 #define MI_VEC(B)                                                                                                                   \
-    split_qkv_rmsnorm_rope_vec_kernel<B><<<blocks, 256, 0, st>>>(                                                                   \
+    split_qkv_rmsnorm_rope_vec_kernel<B, false><<<blocks, 256, 0, st>>>(                                                            \
         (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox, (uint16_t *)q,   \
-        (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr)
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, MropeSections{0, 0, 0, 0})
         if (dtype == MI_DTYPE_BF16) MI_VEC(true); else MI_VEC(false);
 #undef MI_VEC
         return launch_ok();
@@ -766,10 +805,10 @@ extern "C" int mi_split_qkvgate_gemma_rmsnorm_rope(const void *input, const void
         const long long vwaves = ((heads + hpw - 1) / hpw + kVecUnroll - 1) / kVecUnroll;
         const int vblocks = (int)((vwaves + 3) / 4);
 #define MI_GVEC(B)                                                                                                                   \
-    split_qkv_rmsnorm_rope_vec_kernel<B><<<vblocks, 256, 0, st>>>(                                                                   \
+    split_qkv_rmsnorm_rope_vec_kernel<B, false><<<vblocks, 256, 0, st>>>(                                                            \
         (const uint16_t *)input, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, 1, eps,  \
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)nullptr, (const uint16_t *)nullptr, 1, (uint16_t *)q,  \
-        (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate)
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate, 1, MropeSections{0, 0, 0, 0})
         if (dtype == MI_DTYPE_BF16) MI_GVEC(true); else MI_GVEC(false);
 #undef MI_GVEC
         return launch_ok();
@@ -787,5 +826,34 @@ extern "C" int mi_split_qkvgate_gemma_rmsnorm_rope(const void *input, const void
                                                                   kv_hidden, head_dim, rope_dim, eps, (const uint16_t *)q_weight,
                                                                   (const uint16_t *)k_weight, (uint16_t *)q, (uint16_t *)k, (uint16_t *)v,
                                                                   (uint16_t *)gate);
+    return launch_ok();
+}
+
+extern "C" int mi_split_qkv_rmsnorm_mrope(const void *qkv, const void *cos_sin, int rows, int q_hidden, int kv_hidden, int head_dim, int rope_dim,
+                                          float eps, const void *q_weight, const void *k_weight, const void *q_bias, const void *k_bias, int sec_t,
+                                          int sec_h, int sec_w, int sections_interleaved, int dtype, void *q, void *k, void *v, void *gate,
+                                          void *stream)
+{
+    if (rows < 0 || head_dim < 64 || head_dim > 256 || (head_dim & (head_dim - 1)) || q_hidden <= 0 || q_hidden % head_dim || kv_hidden <= 0 ||
+        kv_hidden % head_dim || rope_dim <= 0 || rope_dim > head_dim || rope_dim % 16 || sec_t < 0 || sec_h < 0 || sec_w < 0 ||
+        (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!qkv || !cos_sin || !q_weight || !k_weight || !q || !k || !v || ((q_bias == nullptr) != (k_bias == nullptr))) return MI_SGL_EINVAL;
+    const int items_total = ((gate ? 2 : 1) * q_hidden + 2 * kv_hidden) / head_dim;
+    if ((long long)rows * items_total >= (1ll << 31) - 4096) return MI_SGL_EINVAL;
+    const long long heads = (long long)rows * items_total;
+    const int hpw = 64 / (head_dim / 8);
+    const long long vwaves = ((heads + hpw - 1) / hpw + kVecUnroll - 1) / kVecUnroll;
+    const int vblocks = (int)((vwaves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    const MropeSections ms{sec_t, sec_h, sec_w, sections_interleaved ? 1 : 0};
+#define MI_MVEC(B)                                                                                                                     \
+    split_qkv_rmsnorm_rope_vec_kernel<B, true><<<vblocks, 256, 0, st>>>(                                                               \
+        (const uint16_t *)qkv, (const uint16_t *)cos_sin, (const uint16_t *)nullptr, rows, q_hidden, kv_hidden, head_dim, rope_dim, 1, eps, \
+        (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, 1, (uint16_t *)q,    \
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate, 0, ms)
+    if (dtype == MI_DTYPE_BF16) MI_MVEC(true); else MI_MVEC(false);
+#undef MI_MVEC
     return launch_ok();
 }

@@ -286,6 +286,38 @@ at::Tensor fused_scale_shift(const at::Tensor &x, const at::Tensor &scale, const
     return out;
 }
 
+// norm/split_qkv_rmsnorm_mrope.py:335-420 (triton_split_qkv_rmsnorm_mrope)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_mrope(
+    const at::Tensor &qkv, const at::Tensor &q_weight, const at::Tensor &k_weight, const at::Tensor &cos_sin, int64_t num_q_heads,
+    int64_t num_kv_heads, int64_t head_size, double eps, at::IntArrayRef mrope_section, bool is_interleaved, std::optional<int64_t> rope_dim_opt,
+    const std::optional<at::Tensor> &q_bias, const std::optional<at::Tensor> &k_bias, bool has_gate)
+{
+    const int64_t q_size = num_q_heads * head_size, kv_size = num_kv_heads * head_size, gate_size = has_gate ? q_size : 0;
+    const int64_t rope_dim = rope_dim_opt.value_or(head_size);
+    TORCH_CHECK(qkv.dim() == 2 && qkv.is_contiguous() && qkv.size(1) == q_size + gate_size + 2 * kv_size,
+                "split_qkv_rmsnorm_mrope: qkv must be contiguous [tokens, q (+ gate) + 2 kv]");
+    const int64_t T = qkv.size(0);
+    TORCH_CHECK(mrope_section.size() == 3, "mrope_section must hold three section sizes");
+    TORCH_CHECK(cos_sin.dim() == 3 && cos_sin.size(0) == 3 && cos_sin.size(1) == T && cos_sin.size(2) == rope_dim && cos_sin.is_contiguous() &&
+                    cos_sin.scalar_type() == qkv.scalar_type(),
+                "split_qkv_rmsnorm_mrope: cos_sin must be contiguous [3, tokens, rope_dim] in the input dtype");
+    TORCH_CHECK(q_weight.numel() == head_size && k_weight.numel() == head_size && q_weight.scalar_type() == qkv.scalar_type() &&
+                    k_weight.scalar_type() == qkv.scalar_type() && q_weight.is_contiguous() && k_weight.is_contiguous(),
+                "split_qkv_rmsnorm_mrope: weights must be [head_size] in the input dtype");
+    TORCH_CHECK(q_bias.has_value() == k_bias.has_value(), "q_bias and k_bias go together");
+    TORCH_CHECK((head_size & (head_size - 1)) == 0 && head_size >= 64 && head_size <= 256 && rope_dim % 16 == 0 && rope_dim <= head_size,
+                "split_qkv_rmsnorm_mrope: head_size must be 64, 128 or 256 and rope_dim a multiple of 16 (this build)");
+    at::Tensor q = at::empty({T, q_size}, qkv.options()), k = at::empty({T, kv_size}, qkv.options()), v = at::empty({T, kv_size}, qkv.options()),
+               gate = at::empty({T, gate_size}, qkv.options());
+    auto p = [](const std::optional<at::Tensor> &t) -> const void * { return t.has_value() ? t->data_ptr() : nullptr; };
+    const int rc = mi_split_qkv_rmsnorm_mrope(qkv.data_ptr(), cos_sin.data_ptr(), (int)T, (int)q_size, (int)kv_size, (int)head_size, (int)rope_dim,
+                                              (float)eps, q_weight.data_ptr(), k_weight.data_ptr(), p(q_bias), p(k_bias), (int)mrope_section[0],
+                                              (int)mrope_section[1], (int)mrope_section[2], is_interleaved, dtype_code(qkv), q.data_ptr(),
+                                              k.data_ptr(), v.data_ptr(), has_gate ? gate.data_ptr() : nullptr, cur_stream());
+    TORCH_CHECK(rc == 0, "mi_split_qkv_rmsnorm_mrope failed with code ", rc);
+    return {q, k, v, gate};
+}
+
 // norm/split_qkv_tp_rmsnorm_rope.py:179-288, first launch: (v, qk_var [batch, 2] fp32 = mean(q^2), mean(k^2) of this rank's columns)
 std::tuple<at::Tensor, at::Tensor> split_qkv_tp_local_var(const at::Tensor &input, int64_t q_hidden_size, int64_t kv_hidden_size)
 {
@@ -534,6 +566,9 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("fused_variance(Tensor x) -> Tensor");
     m.def("fused_rsqrt_mul(Tensor x, Tensor variance, Tensor weight, float eps=1e-6) -> Tensor");
     m.def("fused_scale_shift(Tensor x, Tensor scale, Tensor shift, float scale_constant=1.0) -> Tensor");
+    m.def("split_qkv_rmsnorm_mrope(Tensor qkv, Tensor q_weight, Tensor k_weight, Tensor cos_sin, int num_q_heads, int num_kv_heads, int head_size, "
+          "float eps, int[] mrope_section, bool is_interleaved, int? rope_dim=None, Tensor? q_bias=None, Tensor? k_bias=None, "
+          "bool has_gate=False) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("split_qkv_tp_local_var(Tensor input, int q_hidden_size, int kv_hidden_size) -> (Tensor, Tensor)");
     m.def("split_qkv_tp_norm_rope(Tensor input, Tensor cos, Tensor sin, Tensor qk_var, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "float eps, Tensor q_weight, Tensor k_weight, int rotary_dim, float inv_tp_world) -> (Tensor, Tensor)");
@@ -556,6 +591,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("fused_variance", TORCH_FN(sglang::npu_kernel::fused_variance));
     m.impl("fused_rsqrt_mul", TORCH_FN(sglang::npu_kernel::fused_rsqrt_mul));
     m.impl("fused_scale_shift", TORCH_FN(sglang::npu_kernel::fused_scale_shift));
+    m.impl("split_qkv_rmsnorm_mrope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_mrope));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));
     m.impl("split_qkv_tp_norm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_tp_norm_rope));
 }

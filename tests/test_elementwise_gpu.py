@@ -245,6 +245,37 @@ def test_split_qkv_tp_rmsnorm_rope_two_launch_form_with_a_foreign_variance():
     assert torch.allclose(q.cpu().float(), wq.float(), rtol=2 ** -6, atol=2 ** -6) and torch.allclose(k.cpu().float(), wk.float(), rtol=2 ** -6, atol=2 ** -6)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,nq,nkv,hd,rope_dim,sections,inter,gate,bias", [
+    (7, 2, 1, 256, 256, [32, 48, 48], True, True, False),         # the reference test's two cases (test_split_qkv_rmsnorm_mrope.py:113-122)
+    (65, 2, 1, 256, 128, [48, 40, 40], False, False, True),
+    (33, 16, 2, 128, 128, [24, 20, 20], True, False, False),      # Qwen2.5-VL / Qwen3-VL head shapes
+    (33, 16, 2, 128, 128, [16, 24, 24], False, True, True),
+    (5, 4, 4, 64, 32, [8, 4, 4], False, False, False),
+])
+def test_split_qkv_rmsnorm_mrope(T, nq, nkv, hd, rope_dim, sections, inter, gate, bias, dt):
+    """norm/split_qkv_rmsnorm_mrope.py against the reference test's golden (its two cases and more): V and gate bit for bit, q and k within one
+    output ulp of the golden's fp32 evaluation (the reference's own bar: atol 5e-2, rtol 5e-3)."""
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_mrope import triton_split_qkv_rmsnorm_mrope, triton_split_qkv_rmsnorm_mrope_fake
+    torch.manual_seed(T + hd)
+    qs, kvs = nq * hd, nkv * hd
+    qkv = torch.randn(T, qs + (qs if gate else 0) + 2 * kvs).to(dt)
+    qw, kw = torch.randn(hd).to(dt), torch.randn(hd).to(dt)
+    qb, kb = (torch.randn(hd).to(dt), torch.randn(hd).to(dt)) if bias else (None, None)
+    cos_sin = torch.randn(3, T, rope_dim).to(dt)
+    want = OK.split_qkv_rmsnorm_mrope(qkv, qw, kw, cos_sin, nq, nkv, hd, 1e-6, sections, inter, rope_dim, qb, kb, gate)
+    c = lambda t: None if t is None else t.cuda()
+    got = triton_split_qkv_rmsnorm_mrope(qkv.cuda(), qw.cuda(), kw.cuda(), cos_sin.cuda(), nq, nkv, hd, 1e-6, sections, inter, rope_dim, c(qb), c(kb), gate)
+    fake = triton_split_qkv_rmsnorm_mrope_fake(qkv, qw, kw, cos_sin, nq, nkv, hd, 1e-6, sections, inter, rope_dim, qb, kb, gate)
+    for g_, w_, f_ in zip(got, want, fake):
+        assert g_.shape == w_.shape == f_.shape and g_.dtype == dt
+    assert torch.equal(got[2].cpu(), want[2]) and torch.equal(got[3].cpu(), want[3])
+    ulp = 2 ** -7 if dt == torch.bfloat16 else 2 ** -10
+    for i in (0, 1):
+        assert torch.allclose(got[i].cpu().float(), want[i].float(), rtol=ulp, atol=2e-3)
+        torch.testing.assert_close(got[i].cpu().float(), want[i].float(), atol=5e-2, rtol=5e-3)      # the reference's own assertion
+
+
 def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
     torch.manual_seed(42)
     d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),
