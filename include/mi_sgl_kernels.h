@@ -119,6 +119,15 @@ int mi_split_qkv_rmsnorm_mrope(const void *qkv, const void *cos_sin, int rows, i
                                const void *q_weight, const void *k_weight, const void *q_bias, const void *k_bias, int sec_t, int sec_h,
                                int sec_w, int sections_interleaved, int dtype, void *q, void *k, void *v, void *gate, void *stream);
 
+/* split QKV + optional per-head RMSNorm (+ bias) + rotate-half RoPE whose cos / sin come from a position-indexed cache
+ * (norm/split_qkv_rmsnorm_rope_pos_cache_half_npu.py:232-407): cos_sin_cache [max_seq, cache_stride0 >= rope_dim] of cache_dtype (BF16 / F16 /
+ * F32; the reference test passes fp32), row = [rope_dim / 2 cos | rope_dim / 2 sin]; positions [rows] int32 / int64, clamped to [0, max_seq).
+ * cast_norm: the normalised value is rounded to the I/O dtype before the rotation (the reference's default).  has_norm = 0: no norm. */
+int mi_split_qkv_rmsnorm_rope_pos_cache(const void *qkv, const void *positions, int pos_is_i64, const void *cos_sin_cache, int cache_dtype,
+                                        int max_seq, long long cache_stride0, int rows, int q_hidden, int kv_hidden, int head_dim, int rope_dim,
+                                        int has_norm, float eps, const void *q_weight, const void *k_weight, const void *q_bias, const void *k_bias,
+                                        int cast_norm, int dtype, void *q, void *k, void *v, void *stream);
+
 /* ---- row statistics and scalings (norm/l1_norm.py:7-38, norm/rmsnorm_without_weight.py:30-76, norm/rmsnorm_split.py:34-161) -------------
  * x [rows, cols] contiguous, dtype MI_DTYPE_BF16 / F16 / F32 (the reference tests use fp32); arithmetic in fp32.
  *   mi_l1_norm                 out fp32 [rows, cols] = x / sum(x) per row

@@ -337,6 +337,34 @@ def split_qkv_rmsnorm_mrope(qkv, q_weight, k_weight, cos_sin, num_q_heads, num_k
     return (rope(norm(q, q_weight, q_bias)).flatten(1).to(qkv.dtype), rope(norm(k, k_weight, k_bias)).flatten(1).to(qkv.dtype), v.clone(), gate)
 
 
+def split_qkv_rmsnorm_rope_pos_cache_half(qkv, positions, cos_sin_cache, q_hidden, kv_hidden, head_dim, eps=None, q_weight=None, k_weight=None,
+                                          q_bias=None, k_bias=None, rope_dim=None, cast_norm=True):
+    """Restates split_qkv_rmsnorm_rope_half_pos_cache_kernel (norm/split_qkv_rmsnorm_rope_pos_cache_half_npu.py:25-230): position clamped to
+    the cache (:76-79), cos / sin = the two halves of the cache row in fp32 (:80-91), fp32 x * rsqrt(mean + eps) * w (+ b) (:103-112), optional
+    rounding to the I/O dtype (:118-121), o1 = x1 cos - x2 sin, o2 = x2 cos + x1 sin in fp32 (:138-139), rounded on store; V copied.  Pinned:
+    tests/test_oracle_kernels.py holds it within the reference test's own tolerance of that test's torch golden (atol 5e-2, rtol 5e-3)."""
+    rope_dim = head_dim if rope_dim is None else rope_dim
+    B = qkv.shape[0]
+    half = rope_dim // 2
+    q, k, v = qkv.split([q_hidden, kv_hidden, kv_hidden], dim=-1)
+    p = positions.reshape(-1).long().clamp(0, cos_sin_cache.shape[0] - 1)
+    cs = cos_sin_cache.float()[p]
+    c, s_ = cs[:, None, :half], cs[:, None, half:rope_dim]
+
+    def one(x, w, b):
+        y = x.reshape(B, -1, head_dim).float()
+        if eps is not None:
+            y = y * torch.rsqrt((y * y).sum(dim=-1, keepdim=True) / (1.0 * head_dim) + eps)
+            y = y * w.float()[:head_dim] + b.float()[:head_dim] if b is not None else y * w.float()[:head_dim]
+        if cast_norm:
+            y = y.to(x.dtype).float()
+        x1, x2 = y[..., :half], y[..., half:rope_dim]
+        out = torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_, y[..., rope_dim:]], dim=-1)
+        return out.reshape(B, -1).to(x.dtype)
+
+    return one(q, q_weight, q_bias), one(k, k_weight, k_bias), v.clone()
+
+
 def split_qkv_tp_rmsnorm_rope(qkv, cos, sin, q_hidden, kv_hidden, head_dim, eps, q_weight, k_weight, rotary_dim, tp_world=1, other_var=None):
     """Transcription of the reference test's golden (tests/python/sgl_kernel_npu/test_split_qkv_tp_rmsnorm_rope.py:7-44: rms_norm_tp over
     the whole row, rounded to the I/O dtype, then custom_rope with the first half of cos / sin, rounded again), generalised the way the

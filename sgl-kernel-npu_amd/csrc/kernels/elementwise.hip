@@ -17,6 +17,7 @@ namespace mi_sgl {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <bool BF16>
 __device__ __forceinline__ float ld16(uint32_t bits)
@@ -454,6 +455,14 @@ constexpr int kVecUnroll = 2;
 // sec0 <= o < sec0 + sec1), from w when (o % 3 == 2 and o <= 3 sec2; contiguous: o >= sec0 + sec1), else from t.  Always rotate-half.
 struct MropeSections {
     int sec0, sec1, sec2, interleaved;
+    // mode 1 = position-indexed cache (norm/split_qkv_rmsnorm_rope_pos_cache_half_npu.py:25-230): `sin` is cos_sin_cache [max_seq, stride0]
+    // (row = [cos half | sin half], element type cache_dtype: MI_DTYPE_BF16 / F16 / F32), the row of batch item b is pos[b] clamped to
+    // [0, max_seq) (:76-79); cast_norm: the normalised value is rounded to the I/O dtype before the rotation (:118-121)
+    int mode;
+    const void *pos;
+    int pos_is_i64, max_seq;
+    long long stride0;
+    int cache_dtype, cast_norm;
 };
 __device__ __forceinline__ int mrope_section_of(const MropeSections &m, int o)
 {
@@ -494,6 +503,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     int h[kVecUnroll];
     bool active[kVecUnroll];
     u32x4 xr[kVecUnroll], wr[kVecUnroll], br[kVecUnroll], sr[kVecUnroll], cr[kVecUnroll];
+    float cvf[MROPE ? kVecUnroll : 1][8], svf[MROPE ? kVecUnroll : 1][8];      // MROPE: cos / sin of this lane's eight elements, selected at load time
 #pragma unroll
     for (int u = 0; u < kVecUnroll; ++u) {
         // 32-bit index arithmetic (the launcher checks rows x heads < 2^31): four 64-bit divisions per lane were a large part of
@@ -510,24 +520,41 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
         br[u] = (has_norm && normed && qb) ? *(const u32x4 *)((is_q ? qb : kb) + j * 8) : zero4;
         if (MROPE) {
             sr[u] = zero4, cr[u] = zero4;
-            if (normed && roped) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cvf[u][e] = 0.f, svf[u][e] = 0.f;
+            if (normed && roped && ms.mode == 1) {
+                const int o0 = (j * 8) % half;
+                long long pidx = ms.pos_is_i64 ? ((const long long *)ms.pos)[row[u]] : (long long)((const int *)ms.pos)[row[u]];
+                pidx = pidx < 0 ? 0 : (pidx > ms.max_seq - 1 ? ms.max_seq - 1 : pidx);
+                if (ms.cache_dtype == MI_DTYPE_F32) {
+                    const float *base = (const float *)sin + pidx * ms.stride0 + o0;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 4) {
+                        const f32x4_t c4 = *(const f32x4_t *)(base + e), s4 = *(const f32x4_t *)(base + half + e);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cvf[u][e + i] = c4[i], svf[u][e + i] = s4[i];
+                    }
+                } else {
+                    const uint16_t *base = sin + pidx * ms.stride0 + o0;
+                    const u32x4 c4 = *(const u32x4 *)base, s4 = *(const u32x4 *)(base + half);
+                    if (ms.cache_dtype == MI_DTYPE_BF16) unpack8<true>(c4, cvf[u]), unpack8<true>(s4, svf[u]);
+                    else unpack8<false>(c4, cvf[u]), unpack8<false>(s4, svf[u]);
+                }
+            } else if (normed && roped) {
                 const int o0 = (j * 8) % half;            // this lane's eight rotation offsets: the chunk does not straddle rope_dim / 2
                 const long long sec_stride = (long long)rows * rope_dim;
                 const uint16_t *base = sin + row[u] * (long long)rope_dim + o0;
-                u32x4 c3[3], s3[3];
+                float c3[3][8], s3[3][8];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    c3[t] = *(const u32x4 *)(base + t * sec_stride);
-                    s3[t] = *(const u32x4 *)(base + t * sec_stride + half);
+                    unpack8<BF16>(*(const u32x4 *)(base + t * sec_stride), c3[t]);
+                    unpack8<BF16>(*(const u32x4 *)(base + t * sec_stride + half), s3[t]);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int sec = mrope_section_of(ms, o0 + e);
-                    const int wd = e >> 1, sh = (e & 1) * 16;
-                    const uint32_t cvv = sec == 0 ? c3[0][wd] : (sec == 1 ? c3[1][wd] : c3[2][wd]);
-                    const uint32_t svv = sec == 0 ? s3[0][wd] : (sec == 1 ? s3[1][wd] : s3[2][wd]);
-                    cr[u][wd] |= ((cvv >> sh) & 0xFFFFu) << sh;
-                    sr[u][wd] |= ((svv >> sh) & 0xFFFFu) << sh;
+                    cvf[u][e] = sec == 0 ? c3[0][e] : (sec == 1 ? c3[1][e] : c3[2][e]);
+                    svf[u][e] = sec == 0 ? s3[0][e] : (sec == 1 ? s3[1][e] : s3[2][e]);
                 }
             }
         } else if (neox) {
@@ -574,6 +601,10 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = x[e] + bv[e];
                 }
+                if (MROPE && ms.cast_norm) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = ld16<BF16>(st16<BF16>(x[e]));
+                }
             }
         }
         float o[8];
@@ -591,8 +622,13 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             }
             if (active[u] && !is_v && roped) {
                 float sv[8], cv[8];
-                unpack8<BF16>(sr[u], sv);
-                unpack8<BF16>(cr[u], cv);
+                if (MROPE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sv[e] = svf[u][e], cv[e] = cvf[u][e];
+                } else {
+                    unpack8<BF16>(sr[u], sv);
+                    unpack8<BF16>(cr[u], cv);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (lower ? -px[e] : px[e]) * sv[e] + x[e] * cv[e];
             } else {
@@ -765,7 +801,7 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
     split_qkv_rmsnorm_rope_vec_kernel<B, false><<<blocks, 256, 0, st>>>(                                                            \
         (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox, (uint16_t *)q,   \
-        (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, MropeSections{0, 0, 0, 0})
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, MropeSections{0, 0, 0, 0, 0, nullptr, 0, 0, 0, 0, 0})
         if (dtype == MI_DTYPE_BF16) MI_VEC(true); else MI_VEC(false);
 #undef MI_VEC
         return launch_ok();
@@ -808,7 +844,7 @@ extern "C" int mi_split_qkvgate_gemma_rmsnorm_rope(const void *input, const void
     split_qkv_rmsnorm_rope_vec_kernel<B, false><<<vblocks, 256, 0, st>>>(                                                            \
         (const uint16_t *)input, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, 1, eps,  \
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)nullptr, (const uint16_t *)nullptr, 1, (uint16_t *)q,  \
-        (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate, 1, MropeSections{0, 0, 0, 0})
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate, 1, MropeSections{0, 0, 0, 0, 0, nullptr, 0, 0, 0, 0, 0})
         if (dtype == MI_DTYPE_BF16) MI_GVEC(true); else MI_GVEC(false);
 #undef MI_GVEC
         return launch_ok();
@@ -847,7 +883,7 @@ extern "C" int mi_split_qkv_rmsnorm_mrope(const void *qkv, const void *cos_sin, 
     const long long vwaves = ((heads + hpw - 1) / hpw + kVecUnroll - 1) / kVecUnroll;
     const int vblocks = (int)((vwaves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    const MropeSections ms{sec_t, sec_h, sec_w, sections_interleaved ? 1 : 0};
+    const MropeSections ms{sec_t, sec_h, sec_w, sections_interleaved ? 1 : 0, 0, nullptr, 0, 0, 0, 0, 0};
 #define MI_MVEC(B)                                                                                                                     \
     split_qkv_rmsnorm_rope_vec_kernel<B, true><<<vblocks, 256, 0, st>>>(                                                               \
         (const uint16_t *)qkv, (const uint16_t *)cos_sin, (const uint16_t *)nullptr, rows, q_hidden, kv_hidden, head_dim, rope_dim, 1, eps, \
@@ -855,5 +891,38 @@ extern "C" int mi_split_qkv_rmsnorm_mrope(const void *qkv, const void *cos_sin, 
         (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate, 0, ms)
     if (dtype == MI_DTYPE_BF16) MI_MVEC(true); else MI_MVEC(false);
 #undef MI_MVEC
+    return launch_ok();
+}
+
+extern "C" int mi_split_qkv_rmsnorm_rope_pos_cache(const void *qkv, const void *positions, int pos_is_i64, const void *cos_sin_cache, int cache_dtype,
+                                                   int max_seq, long long cache_stride0, int rows, int q_hidden, int kv_hidden, int head_dim, int rope_dim,
+                                                   int has_norm, float eps, const void *q_weight, const void *k_weight, const void *q_bias,
+                                                   const void *k_bias, int cast_norm, int dtype, void *q, void *k, void *v, void *stream)
+{
+    if (rows < 0 || head_dim < 64 || head_dim > 256 || (head_dim & (head_dim - 1)) || q_hidden <= 0 || q_hidden % head_dim || kv_hidden <= 0 ||
+        kv_hidden % head_dim || q_hidden % kv_hidden || rope_dim <= 0 || rope_dim > head_dim || rope_dim % 16 || max_seq < 1 ||
+        cache_stride0 < rope_dim || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) ||
+        (cache_dtype != MI_DTYPE_BF16 && cache_dtype != MI_DTYPE_F16 && cache_dtype != MI_DTYPE_F32) ||
+        (cache_stride0 % (cache_dtype == MI_DTYPE_F32 ? 4 : 8)))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!qkv || !positions || !cos_sin_cache || !q || !k || !v || (has_norm && (!q_weight || !k_weight)) || ((q_bias == nullptr) != (k_bias == nullptr)) ||
+        (!has_norm && q_bias))
+        return MI_SGL_EINVAL;
+    const int items_total = (q_hidden + 2 * kv_hidden) / head_dim;
+    if ((long long)rows * items_total >= (1ll << 31) - 4096) return MI_SGL_EINVAL;
+    const long long heads = (long long)rows * items_total;
+    const int hpw = 64 / (head_dim / 8);
+    const long long vwaves = ((heads + hpw - 1) / hpw + kVecUnroll - 1) / kVecUnroll;
+    const int vblocks = (int)((vwaves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    const MropeSections ms{0, 0, 0, 0, 1, positions, pos_is_i64 ? 1 : 0, max_seq, cache_stride0, cache_dtype, cast_norm ? 1 : 0};
+#define MI_PVEC(B)                                                                                                                     \
+    split_qkv_rmsnorm_rope_vec_kernel<B, true><<<vblocks, 256, 0, st>>>(                                                               \
+        (const uint16_t *)qkv, (const uint16_t *)cos_sin_cache, (const uint16_t *)nullptr, rows, q_hidden, kv_hidden, head_dim, rope_dim, \
+        has_norm, eps, (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, 1,   \
+        (uint16_t *)q, (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, ms)
+    if (dtype == MI_DTYPE_BF16) MI_PVEC(true); else MI_PVEC(false);
+#undef MI_PVEC
     return launch_ok();
 }

@@ -318,6 +318,41 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_mro
     return {q, k, v, gate};
 }
 
+// norm/split_qkv_rmsnorm_rope_pos_cache_half_npu.py:232-407
+std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope_pos_cache_half(
+    const at::Tensor &input, const at::Tensor &positions, const at::Tensor &cos_sin_cache, int64_t q_hidden_size, int64_t kv_hidden_size,
+    int64_t head_dim, std::optional<double> eps, const std::optional<at::Tensor> &q_weight, const std::optional<at::Tensor> &k_weight,
+    const std::optional<at::Tensor> &q_bias, const std::optional<at::Tensor> &k_bias, int64_t rope_dim, bool cast_norm_to_bf16)
+{
+    TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && input.size(1) == q_hidden_size + 2 * kv_hidden_size,
+                "split_qkv_rmsnorm_rope_pos_cache_half: input must be contiguous [B, q + 2 kv]");
+    const int64_t B = input.size(0);
+    TORCH_CHECK(positions.numel() == B && positions.is_contiguous() && (positions.scalar_type() == at::kInt || positions.scalar_type() == at::kLong),
+                "positions must be [B], int32 or int64");
+    TORCH_CHECK(cos_sin_cache.dim() == 2 && cos_sin_cache.is_contiguous() && cos_sin_cache.size(0) >= 1 && cos_sin_cache.size(1) >= rope_dim,
+                "cos_sin_cache must be contiguous [max_seq, rope_dim]");
+    TORCH_CHECK((head_dim & (head_dim - 1)) == 0 && head_dim >= 64 && head_dim <= 256 && rope_dim % 16 == 0 && rope_dim <= head_dim,
+                "split_qkv_rmsnorm_rope_pos_cache_half: head_dim must be 64, 128 or 256 and rope_dim a multiple of 16 (this build)");
+    TORCH_CHECK(q_hidden_size % kv_hidden_size == 0, "q_hidden_size % kv_hidden_size != 0");
+    const bool norms = eps.has_value();
+    if (norms)
+        TORCH_CHECK(q_weight.has_value() && k_weight.has_value() && q_weight->numel() >= head_dim && k_weight->numel() >= head_dim &&
+                        q_weight->scalar_type() == input.scalar_type() && k_weight->scalar_type() == input.scalar_type(),
+                    "When using RMSNorm (eps is not None), q_weight / k_weight must have at least head_dim elements in the input dtype");
+    TORCH_CHECK(q_bias.has_value() == k_bias.has_value(), "q_bias and k_bias go together");
+    if (q_bias.has_value()) TORCH_CHECK(norms && q_bias->numel() >= head_dim && k_bias->numel() >= head_dim, "bias needs the norm and head_dim elements");
+    at::Tensor q = at::empty({B, q_hidden_size}, input.options()), k = at::empty({B, kv_hidden_size}, input.options()),
+               v = at::empty({B, kv_hidden_size}, input.options());
+    auto p = [](const std::optional<at::Tensor> &t) -> const void * { return t.has_value() ? t->contiguous().data_ptr() : nullptr; };
+    const int rc = mi_split_qkv_rmsnorm_rope_pos_cache(input.data_ptr(), positions.data_ptr(), positions.scalar_type() == at::kLong, cos_sin_cache.data_ptr(),
+                                                       dtype_code3(cos_sin_cache), (int)cos_sin_cache.size(0), cos_sin_cache.stride(0), (int)B,
+                                                       (int)q_hidden_size, (int)kv_hidden_size, (int)head_dim, (int)rope_dim, norms, (float)eps.value_or(0.0),
+                                                       p(q_weight), p(k_weight), p(q_bias), p(k_bias), cast_norm_to_bf16, dtype_code(input), q.data_ptr(),
+                                                       k.data_ptr(), v.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_split_qkv_rmsnorm_rope_pos_cache failed with code ", rc);
+    return {q, k, v};
+}
+
 // norm/split_qkv_tp_rmsnorm_rope.py:179-288, first launch: (v, qk_var [batch, 2] fp32 = mean(q^2), mean(k^2) of this rank's columns)
 std::tuple<at::Tensor, at::Tensor> split_qkv_tp_local_var(const at::Tensor &input, int64_t q_hidden_size, int64_t kv_hidden_size)
 {
@@ -569,6 +604,9 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("split_qkv_rmsnorm_mrope(Tensor qkv, Tensor q_weight, Tensor k_weight, Tensor cos_sin, int num_q_heads, int num_kv_heads, int head_size, "
           "float eps, int[] mrope_section, bool is_interleaved, int? rope_dim=None, Tensor? q_bias=None, Tensor? k_bias=None, "
           "bool has_gate=False) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("split_qkv_rmsnorm_rope_pos_cache_half(Tensor input, Tensor positions, Tensor cos_sin_cache, int q_hidden_size, int kv_hidden_size, "
+          "int head_dim, float? eps, Tensor? q_weight, Tensor? k_weight, Tensor? q_bias, Tensor? k_bias, int rope_dim, "
+          "bool cast_norm_to_bf16) -> (Tensor, Tensor, Tensor)");
     m.def("split_qkv_tp_local_var(Tensor input, int q_hidden_size, int kv_hidden_size) -> (Tensor, Tensor)");
     m.def("split_qkv_tp_norm_rope(Tensor input, Tensor cos, Tensor sin, Tensor qk_var, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "float eps, Tensor q_weight, Tensor k_weight, int rotary_dim, float inv_tp_world) -> (Tensor, Tensor)");
@@ -592,6 +630,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("fused_rsqrt_mul", TORCH_FN(sglang::npu_kernel::fused_rsqrt_mul));
     m.impl("fused_scale_shift", TORCH_FN(sglang::npu_kernel::fused_scale_shift));
     m.impl("split_qkv_rmsnorm_mrope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_mrope));
+    m.impl("split_qkv_rmsnorm_rope_pos_cache_half", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope_pos_cache_half));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));
     m.impl("split_qkv_tp_norm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_tp_norm_rope));
 }

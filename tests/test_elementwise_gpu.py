@@ -276,6 +276,45 @@ def test_split_qkv_rmsnorm_mrope(T, nq, nkv, hd, rope_dim, sections, inter, gate
         torch.testing.assert_close(got[i].cpu().float(), want[i].float(), atol=5e-2, rtol=5e-3)      # the reference's own assertion
 
 
+@pytest.mark.parametrize("cache_dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,qh,kvh,hd,rope_dim,norm,bias,cast,pos_dt", [
+    (12, 2048, 512, 128, 128, True, False, True, torch.int64),      # the reference test's shapes (full and partial rotary, with and without qk norm)
+    (12, 2048, 512, 128, 64, True, False, True, torch.int64),
+    (12, 2048, 512, 128, 128, False, False, True, torch.int64),
+    (1500, 1024, 256, 128, 128, True, True, True, torch.int32),     # past the reference's wide-grid threshold; bias
+    (7, 512, 512, 256, 32, True, True, False, torch.int32),         # no rounding between norm and rotation
+    (3, 256, 64, 64, 64, True, False, True, torch.int64),
+])
+def test_split_qkv_rmsnorm_rope_pos_cache_half(B, qh, kvh, hd, rope_dim, norm, bias, cast, pos_dt, cache_dt):
+    """norm/split_qkv_rmsnorm_rope_pos_cache_half_npu.py: V bit for bit; q, k within one output ulp of the kernel's restatement and within the
+    reference test's bar (atol 5e-2, rtol 5e-3); out-of-range positions clamp."""
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope_pos_cache_half_npu import split_qkv_rmsnorm_rope_pos_cache_half_npu
+    torch.manual_seed(B + hd)
+    dt = torch.bfloat16
+    max_pos = 2048
+    qkv = torch.randn(B, qh + 2 * kvh).to(dt)
+    pos = torch.randint(0, max_pos, (B,), dtype=pos_dt)
+    pos[0] = -3
+    if B > 1:
+        pos[1] = max_pos + 7
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, rope_dim, 2, dtype=torch.float32) / rope_dim))
+    freqs = torch.einsum("i,j -> ij", torch.arange(max_pos, dtype=torch.float32), inv_freq)
+    cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(cache_dt)
+    qw, kw = torch.randn(hd + 3).to(dt), torch.randn(hd).to(dt)          # "at least head_dim elements"
+    qb, kb = (torch.randn(hd).to(dt), torch.randn(hd).to(dt)) if bias else (None, None)
+    c = lambda t: None if t is None else t.cuda()
+    kwargs = dict(eps=1e-6 if norm else None, q_weight=c(qw) if norm else None, k_weight=c(kw) if norm else None, q_bias=c(qb), k_bias=c(kb),
+                  rope_dim=rope_dim, cast_norm_to_bf16=cast)
+    q, k, v = split_qkv_rmsnorm_rope_pos_cache_half_npu(qkv.cuda(), pos.cuda(), cache.cuda(), qh, kvh, hd, **kwargs)
+    wq, wk, wv = OK.split_qkv_rmsnorm_rope_pos_cache_half(qkv, pos, cache, qh, kvh, hd, 1e-6 if norm else None, qw if norm else None,
+                                                          kw if norm else None, qb, kb, rope_dim, cast)
+    assert torch.equal(v.cpu(), wv)
+    for got, want in ((q, wq), (k, wk)):
+        assert torch.allclose(got.cpu().float(), want.float(), rtol=2 ** -7, atol=2e-3)
+        torch.testing.assert_close(got.cpu().float(), want.float(), atol=5e-2, rtol=5e-3)
+        assert (got.cpu().view(torch.int16) != want.view(torch.int16)).float().mean() < 0.02
+
+
 def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
     torch.manual_seed(42)
     d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),
