@@ -315,6 +315,39 @@ def test_split_qkv_rmsnorm_rope_pos_cache_half(B, qh, kvh, hd, rope_dim, norm, b
         assert (got.cpu().view(torch.int16) != want.view(torch.int16)).float().mean() < 0.02
 
 
+def test_split_qkv_rmsnorm_rope_pos_cache_half_replays_in_a_captured_graph():
+    """The reference test replays the op in a captured device graph with new inputs in the same buffers
+    (test_split_qkv_rmsnorm_rope_pos_cache_half_npu.py:213-260): positions are clamped inside the kernel, nothing synchronises."""
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope_pos_cache_half_npu import split_qkv_rmsnorm_rope_pos_cache_half_npu
+    torch.manual_seed(1)
+    B, qh, kvh, hd, max_pos = 12, 2048, 512, 128, 2048
+    dt = torch.bfloat16
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    freqs = torch.einsum("i,j -> ij", torch.arange(max_pos, dtype=torch.float32), inv_freq)
+    cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1).cuda()
+    qw, kw = torch.randn(hd).to(dt).cuda(), torch.randn(hd).to(dt).cuda()
+    qkv_s = torch.randn(B, qh + 2 * kvh).to(dt).cuda()
+    pos_s = torch.randint(0, max_pos, (B,), dtype=torch.int64).cuda()
+    run = lambda: split_qkv_rmsnorm_rope_pos_cache_half_npu(qkv_s, pos_s, cache, qh, kvh, hd, eps=1e-6, q_weight=qw, k_weight=kw, rope_dim=hd)
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        run()
+    torch.cuda.current_stream().wait_stream(s_)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = run()
+    for it in range(2):
+        qkv_s.copy_(torch.randn(B, qh + 2 * kvh).to(dt))
+        pos_s.copy_(torch.randint(0, max_pos, (B,), dtype=torch.int64))
+        g.replay()
+        torch.cuda.synchronize()
+        want = OK.split_qkv_rmsnorm_rope_pos_cache_half(qkv_s.cpu(), pos_s.cpu(), cache.cpu(), qh, kvh, hd, 1e-6, qw.cpu(), kw.cpu(), None, None, hd)
+        assert torch.equal(outs[2].cpu(), want[2])
+        assert torch.allclose(outs[0].cpu().float(), want[0].float(), rtol=2 ** -7, atol=2e-3)
+        assert torch.allclose(outs[1].cpu().float(), want[1].float(), rtol=2 ** -7, atol=2e-3)
+
+
 def _mla_pre_inputs(N, Hq, hidden, dt=torch.bfloat16):
     torch.manual_seed(42)
     d = dict(hid=(torch.randn(N, hidden) * 0.5).to(dt), wdqkv=torch.randint(-8, 8, (2112, hidden), dtype=torch.int8),
