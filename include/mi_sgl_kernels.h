@@ -150,6 +150,11 @@ int mi_split_qkv_tp_var(const void *input, long long rows, int q_cols, int k_col
 int mi_split_qkv_tp_norm_rope(const void *input, const void *cos, const void *sin, const float *qk_var, long long rows, int q_cols, int k_cols,
                               int head_dim, int rotary_dim, float eps, float inv_tp_world, const void *q_weight, const void *k_weight, int dtype,
                               void *q, void *k, void *stream);
+/* MLA down-projection row [q_lora_rank | kv_lora_rank | qk_rope_dim] -> RMSNorm(q part) * q_weight (+ q_bias), RMSNorm(kv part) * k_weight
+ * (+ k_bias), rope part copied (norm/fused_split_qk_norm.py:93-134); weights / biases (nullable) in the I/O dtype; fp32 arithmetic. */
+int mi_fused_split_qk_norm(const void *x, long long rows, int q_lora_rank, int kv_lora_rank, int qk_rope_dim, float eps, const void *q_weight,
+                           const void *q_bias, const void *k_weight, const void *k_bias, int dtype, void *q_lora, void *k_nope, void *k_pe,
+                           void *stream);
 int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel, long long shift_numel,
                    float scale_constant, int dtype, int ss_dtype, void *out, void *stream);
 

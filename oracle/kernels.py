@@ -389,6 +389,20 @@ def split_qkv_tp_rmsnorm_rope(qkv, cos, sin, q_hidden, kv_hidden, head_dim, eps,
     return one(q, q_weight, 0), one(k, k_weight, 1), v.clone()
 
 
+def fused_split_qk_norm(x, q_weight, q_bias, k_weight, k_bias, q_lora_rank, kv_lora_rank, qk_rope_dim, eps=1e-6):
+    """Restates fused_split_qk_norm_kernel (norm/fused_split_qk_norm.py:6-91) in fp32: per part x * rsqrt(sum(x^2) / n + eps) * w (+ b)
+    (:39-47, :62-70), the rope part copied (:75-90).  PARITY UNPINNED (the reference holds no test for it); tests/test_oracle_kernels.py ties
+    it to the pinned add_rmsnorm_bias oracle."""
+    q, kn, kp = x.split([q_lora_rank, kv_lora_rank, qk_rope_dim], dim=-1)
+
+    def one(t, w, b):
+        tf = t.float()
+        y = (tf * torch.rsqrt((tf * tf).sum(dim=-1, keepdim=True) / t.shape[-1] + eps)) * w.float()
+        return (y + b.float() if b is not None else y).to(x.dtype)
+
+    return one(q, q_weight, q_bias), one(kn, k_weight, k_bias).unsqueeze(1), kp.clone().unsqueeze(1)
+
+
 def fused_scale_shift(x, scale, shift, scale_constant=1.0):
     """tests/python/sgl_kernel_npu/test_scale_shift.py:6-11: x * (1 + scale) + shift; with one shift value per element the kernel uses
     scale_constant instead of 1 (norm/scale_shift.py:112 against :60).  fp32, returned in x's dtype."""

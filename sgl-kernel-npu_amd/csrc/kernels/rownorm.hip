@@ -6,6 +6,7 @@
 //   fused_rsqrt_mul                python/sgl_kernel_npu/sgl_kernel_npu/norm/rmsnorm_split.py:34-97
 //   fused_scale_shift              python/sgl_kernel_npu/sgl_kernel_npu/norm/scale_shift.py:9-183
 //   split_qkv_tp_rmsnorm_rope      python/sgl_kernel_npu/sgl_kernel_npu/norm/split_qkv_tp_rmsnorm_rope.py:7-288
+//   fused_split_qk_norm            python/sgl_kernel_npu/sgl_kernel_npu/norm/fused_split_qk_norm.py:6-134
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
 // on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
 // MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
@@ -217,6 +218,41 @@ int launch_rows(const void *x, long long rows, int cols, float eps, const void *
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 
+// [q_lora | kv_lora | rope] row of the MLA down-projection -> RMSNorm(q_lora) * w (+ b), RMSNorm(kv_lora) * w (+ b), rope part copied
+// (norm/fused_split_qk_norm.py:6-91): y = (x * rsqrt(sum(x^2) / n + eps)) * w (+ b) in fp32 (:39-47, :62-70).  Two waves per row: wave 0 the
+// q part, wave 1 the kv part and the copy.
+template <int DT>
+__global__ __launch_bounds__(128) void split_qk_norm_kernel(const typename Elem<DT>::T *__restrict__ x, int q_rank, int kv_rank, int rope_dim, float eps,
+                                                            const typename Elem<DT>::T *__restrict__ qw, const typename Elem<DT>::T *__restrict__ qb,
+                                                            const typename Elem<DT>::T *__restrict__ kw, const typename Elem<DT>::T *__restrict__ kb,
+                                                            typename Elem<DT>::T *__restrict__ q, typename Elem<DT>::T *__restrict__ k_nope,
+                                                            typename Elem<DT>::T *__restrict__ k_pe)
+{
+    typedef typename Elem<DT>::T T;
+    const long long row = blockIdx.x;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const T *xr = x + row * (long long)(q_rank + kv_rank + rope_dim);
+    const int n = part ? kv_rank : q_rank;
+    const T *src = part ? xr + q_rank : xr;
+    const T *w = part ? kw : qw, *b = part ? kb : qb;
+    T *dst = part ? k_nope + row * (long long)kv_rank : q + row * (long long)q_rank;
+    float ss = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const float f = Elem<DT>::ld(src[i]);
+        ss += f * f;
+    }
+    const float rstd = rsqrtf(wave_sum_f(ss) / (float)n + eps);
+    for (int i = lane; i < n; i += 64) {
+        float y = (Elem<DT>::ld(src[i]) * rstd) * Elem<DT>::ld(w[i]);
+        if (b) y = y + Elem<DT>::ld(b[i]);
+        dst[i] = Elem<DT>::st(y);
+    }
+    if (part) {
+        const T *pe = xr + q_rank + kv_rank;
+        for (int i = lane; i < rope_dim; i += 64) k_pe[row * (long long)rope_dim + i] = pe[i];
+    }
+}
+
 // out = x * (c + scale) + shift (norm/scale_shift.py:9-183): scale one value or one per column, shift one value, one per column or one per
 // element.  With a per-element shift c = scale_constant (fused_scale_shift_kernel_2, :112), otherwise c = 1.0 whatever scale_constant says
 // (fused_scale_shift_kernel, :60) -- as the reference.  DT = type of x and out, ST = type of scale and shift; fp32 arithmetic.
@@ -354,6 +390,28 @@ __global__ __launch_bounds__(256) void tp_norm_rope_kernel(const typename Elem<D
 }  // namespace mi_sgl
 
 using namespace mi_sgl;
+
+extern "C" int mi_fused_split_qk_norm(const void *x, long long rows, int q_lora_rank, int kv_lora_rank, int qk_rope_dim, float eps, const void *q_weight,
+                                      const void *q_bias, const void *k_weight, const void *k_bias, int dtype, void *q_lora, void *k_nope, void *k_pe,
+                                      void *stream)
+{
+    if (rows < 0 || rows >= (1ll << 31) || q_lora_rank <= 0 || kv_lora_rank <= 0 || qk_rope_dim <= 0 ||
+        (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16 && dtype != MI_DTYPE_F32))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!x || !q_weight || !k_weight || !q_lora || !k_nope || !k_pe) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_SQK(DT)                                                                                                                           \
+    split_qk_norm_kernel<DT><<<(unsigned)rows, 128, 0, st>>>((const typename Elem<DT>::T *)x, q_lora_rank, kv_lora_rank, qk_rope_dim, eps,      \
+                                                             (const typename Elem<DT>::T *)q_weight, (const typename Elem<DT>::T *)q_bias,     \
+                                                             (const typename Elem<DT>::T *)k_weight, (const typename Elem<DT>::T *)k_bias,     \
+                                                             (typename Elem<DT>::T *)q_lora, (typename Elem<DT>::T *)k_nope, (typename Elem<DT>::T *)k_pe)
+    if (dtype == MI_DTYPE_BF16) MI_SQK(MI_DTYPE_BF16);
+    else if (dtype == MI_DTYPE_F16) MI_SQK(MI_DTYPE_F16);
+    else MI_SQK(MI_DTYPE_F32);
+#undef MI_SQK
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
 
 static bool tp_shape_ok(long long rows, int q_cols, int k_cols, int head_dim, int rotary_dim, int dtype)
 {

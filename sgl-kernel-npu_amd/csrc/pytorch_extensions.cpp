@@ -318,6 +318,30 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_mro
     return {q, k, v, gate};
 }
 
+// norm/fused_split_qk_norm.py:93-134 (weights / biases of the two layer norms passed as tensors)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> fused_split_qk_norm(const at::Tensor &x, const at::Tensor &q_weight, const std::optional<at::Tensor> &q_bias,
+                                                                   const at::Tensor &k_weight, const std::optional<at::Tensor> &k_bias, int64_t q_lora_rank,
+                                                                   int64_t kv_lora_rank, int64_t qk_rope_dim, double eps)
+{
+    TORCH_CHECK(x.dim() == 2 && x.is_contiguous() && x.size(1) == q_lora_rank + kv_lora_rank + qk_rope_dim,
+                "fused_split_qk_norm: input must be contiguous [B, q_lora_rank + kv_lora_rank + qk_rope_dim]");
+    auto chk = [&](const at::Tensor &t, int64_t n, const char *what) {
+        TORCH_CHECK(t.numel() == n && t.is_contiguous() && t.scalar_type() == x.scalar_type(), "fused_split_qk_norm: ", what, " must hold ", n,
+                    " values in the input dtype");
+    };
+    chk(q_weight, q_lora_rank, "q weight"), chk(k_weight, kv_lora_rank, "k weight");
+    if (q_bias.has_value()) chk(*q_bias, q_lora_rank, "q bias");
+    if (k_bias.has_value()) chk(*k_bias, kv_lora_rank, "k bias");
+    const int64_t B = x.size(0);
+    at::Tensor q = at::empty({B, q_lora_rank}, x.options()), kn = at::empty({B, kv_lora_rank}, x.options()), kp = at::empty({B, qk_rope_dim}, x.options());
+    const int rc = mi_fused_split_qk_norm(x.data_ptr(), B, (int)q_lora_rank, (int)kv_lora_rank, (int)qk_rope_dim, (float)eps, q_weight.data_ptr(),
+                                          q_bias.has_value() ? q_bias->data_ptr() : nullptr, k_weight.data_ptr(),
+                                          k_bias.has_value() ? k_bias->data_ptr() : nullptr, dtype_code3(x), q.data_ptr(), kn.data_ptr(), kp.data_ptr(),
+                                          cur_stream());
+    TORCH_CHECK(rc == 0, "mi_fused_split_qk_norm failed with code ", rc);
+    return {q, kn, kp};
+}
+
 // norm/split_qkv_rmsnorm_rope_pos_cache_half_npu.py:232-407
 std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope_pos_cache_half(
     const at::Tensor &input, const at::Tensor &positions, const at::Tensor &cos_sin_cache, int64_t q_hidden_size, int64_t kv_hidden_size,
@@ -607,6 +631,8 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("split_qkv_rmsnorm_rope_pos_cache_half(Tensor input, Tensor positions, Tensor cos_sin_cache, int q_hidden_size, int kv_hidden_size, "
           "int head_dim, float? eps, Tensor? q_weight, Tensor? k_weight, Tensor? q_bias, Tensor? k_bias, int rope_dim, "
           "bool cast_norm_to_bf16) -> (Tensor, Tensor, Tensor)");
+    m.def("fused_split_qk_norm(Tensor x, Tensor q_weight, Tensor? q_bias, Tensor k_weight, Tensor? k_bias, int q_lora_rank, int kv_lora_rank, "
+          "int qk_rope_dim, float eps=1e-6) -> (Tensor, Tensor, Tensor)");
     m.def("split_qkv_tp_local_var(Tensor input, int q_hidden_size, int kv_hidden_size) -> (Tensor, Tensor)");
     m.def("split_qkv_tp_norm_rope(Tensor input, Tensor cos, Tensor sin, Tensor qk_var, int q_hidden_size, int kv_hidden_size, int head_dim, "
           "float eps, Tensor q_weight, Tensor k_weight, int rotary_dim, float inv_tp_world) -> (Tensor, Tensor)");
@@ -631,6 +657,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("fused_scale_shift", TORCH_FN(sglang::npu_kernel::fused_scale_shift));
     m.impl("split_qkv_rmsnorm_mrope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_mrope));
     m.impl("split_qkv_rmsnorm_rope_pos_cache_half", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope_pos_cache_half));
+    m.impl("fused_split_qk_norm", TORCH_FN(sglang::npu_kernel::fused_split_qk_norm));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));
     m.impl("split_qkv_tp_norm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_tp_norm_rope));
 }

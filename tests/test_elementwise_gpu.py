@@ -315,6 +315,32 @@ def test_split_qkv_rmsnorm_rope_pos_cache_half(B, qh, kvh, hd, rope_dim, norm, b
         assert (got.cpu().view(torch.int16) != want.view(torch.int16)).float().mean() < 0.02
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,ql,kl,rd,qbias,kbias", [(128, 1536, 512, 64, False, False), (5, 1536, 512, 64, True, True), (3, 100, 36, 10, True, False)])
+def test_fused_split_qk_norm(B, ql, kl, rd, qbias, kbias, dt):
+    """norm/fused_split_qk_norm.py (the MLA down-projection split, DeepSeek shapes 1536 / 512 / 64): rope part bit for bit, the two normed parts
+    within one output ulp of the fp32 restatement; layer-norm modules with and without a bias."""
+    from sgl_kernel_npu.norm.fused_split_qk_norm import fused_split_qk_norm
+    torch.manual_seed(B)
+    x = torch.randn(B, ql + kl + rd).to(dt)
+
+    class LN:                                       # stands in for the model's RMSNorm modules: .weight, optionally .bias
+        pass
+    qln, kln = LN(), LN()
+    qln.weight, kln.weight = torch.randn(ql).to(dt).cuda(), torch.randn(kl).to(dt).cuda()
+    if qbias:
+        qln.bias = torch.randn(ql).to(dt).cuda()
+    if kbias:
+        kln.bias = torch.randn(kl).to(dt).cuda()
+    q, kn, kp = fused_split_qk_norm(x.cuda(), qln, kln, ql, kl, rd, 1e-6)
+    cpu = lambda t: None if t is None else t.cpu()
+    wq, wkn, wkp = OK.fused_split_qk_norm(x, cpu(qln.weight), cpu(getattr(qln, "bias", None)), cpu(kln.weight), cpu(getattr(kln, "bias", None)), ql, kl, rd, 1e-6)
+    assert q.shape == wq.shape and kn.shape == wkn.shape == (B, 1, kl) and kp.shape == wkp.shape == (B, 1, rd)
+    assert torch.equal(kp.cpu(), wkp)
+    ulp = {torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10, torch.float32: 2e-6}[dt]
+    assert torch.allclose(q.cpu().float(), wq.float(), rtol=ulp, atol=1e-5) and torch.allclose(kn.cpu().float(), wkn.float(), rtol=ulp, atol=1e-5)
+
+
 def test_split_qkv_rmsnorm_rope_pos_cache_half_replays_in_a_captured_graph():
     """The reference test replays the op in a captured device graph with new inputs in the same buffers
     (test_split_qkv_rmsnorm_rope_pos_cache_half_npu.py:213-260): positions are clamped inside the kernel, nothing synchronises."""
