@@ -155,6 +155,9 @@ int mi_split_qkv_tp_norm_rope(const void *input, const void *cos, const void *si
 int mi_fused_split_qk_norm(const void *x, long long rows, int q_lora_rank, int kv_lora_rank, int qk_rope_dim, float eps, const void *q_weight,
                            const void *q_bias, const void *k_weight, const void *k_bias, int dtype, void *q_lora, void *k_nope, void *k_pe,
                            void *stream);
+/* GPT-OSS SwiGLU (activation/swiglu_oai.py:53-83): x [rows, dim] with gate / up interleaved (even / odd columns) -> out [rows, dim / 2] =
+ * (min(max(up, -limit), limit) + 1) * g * sigmoid(g * alpha), g = min(gate, limit); dim / 2 a multiple of 8 (4 for fp32). */
+int mi_swiglu_oai(const void *x, long long rows, int dim, float alpha, float limit, int dtype, void *out, void *stream);
 int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel, long long shift_numel,
                    float scale_constant, int dtype, int ss_dtype, void *out, void *stream);
 

@@ -403,6 +403,15 @@ def fused_split_qk_norm(x, q_weight, q_bias, k_weight, k_bias, q_lora_rank, kv_l
     return one(q, q_weight, q_bias), one(kn, k_weight, k_bias).unsqueeze(1), kp.clone().unsqueeze(1)
 
 
+def swiglu_oai(x, dim, alpha, limit):
+    """Restates swiglu_oai_kernel (activation/swiglu_oai.py:7-50) in fp32: gate = even columns clamped from above (:36), up = odd columns
+    clamped to +-limit (:37-38), (up + 1) * gate * 1 / (1 + exp(-gate * alpha)) (:39-41).  Pinned to the file's own torch formulation
+    swiglu_oai_native (:86-96), which computes in the tensors' dtype (tests/test_oracle_kernels.py: exact for fp32 inputs)."""
+    xf = x.reshape(-1, dim).float()
+    gate, up = xf[:, 0::2].clamp(max=limit), xf[:, 1::2].clamp(min=-limit, max=limit)
+    return ((up + 1.0) * (gate * (1.0 / (1.0 + torch.exp(-gate * alpha))))).to(x.dtype)
+
+
 def fused_scale_shift(x, scale, shift, scale_constant=1.0):
     """tests/python/sgl_kernel_npu/test_scale_shift.py:6-11: x * (1 + scale) + shift; with one shift value per element the kernel uses
     scale_constant instead of 1 (norm/scale_shift.py:112 against :60).  fp32, returned in x's dtype."""

@@ -7,6 +7,7 @@
 //   fused_scale_shift              python/sgl_kernel_npu/sgl_kernel_npu/norm/scale_shift.py:9-183
 //   split_qkv_tp_rmsnorm_rope      python/sgl_kernel_npu/sgl_kernel_npu/norm/split_qkv_tp_rmsnorm_rope.py:7-288
 //   fused_split_qk_norm            python/sgl_kernel_npu/sgl_kernel_npu/norm/fused_split_qk_norm.py:6-134
+//   swiglu_oai                     python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai.py:7-104
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
 // on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
 // MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
@@ -253,6 +254,32 @@ __global__ __launch_bounds__(128) void split_qk_norm_kernel(const typename Elem<
     }
 }
 
+// GPT-OSS SwiGLU on INTERLEAVED gate / up columns (activation/swiglu_oai.py:7-50): gate = x[2j] clamped from above at limit, up = x[2j + 1]
+// clamped to [-limit, limit], out[j] = (up + 1) * gate * (1 / (1 + exp(-gate * alpha))) (:36-41).  fp32 arithmetic, output in x's dtype.
+template <int DT>
+__global__ __launch_bounds__(256) void swiglu_oai_kernel(const typename Elem<DT>::T *__restrict__ x, long long n_out, float alpha, float limit,
+                                                         typename Elem<DT>::T *__restrict__ out)
+{
+    constexpr int N = Elem<DT>::kPer16;                     // outputs per thread and step: 2 N inputs
+    const long long stride = (long long)gridDim.x * 256 * N;
+    for (long long o0 = ((long long)blockIdx.x * 256 + threadIdx.x) * N; o0 < n_out; o0 += stride) {
+        float a[N], b[N], r[N];
+        load16<DT>(x + 2 * o0, a);
+        load16<DT>(x + 2 * o0 + N, b);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            float g = (e < N / 2) ? a[2 * e] : b[2 * e - N];
+            float u = (e < N / 2) ? a[2 * e + 1] : b[2 * e + 1 - N];
+            g = g > limit ? limit : g;
+            u = u > limit ? limit : u;
+            u = u < -limit ? -limit : u;
+            const float sig = 1.0f / (1.0f + __expf(-g * alpha));
+            r[e] = (u + 1.0f) * (g * sig);
+        }
+        store16<DT>(out + o0, r);
+    }
+}
+
 // out = x * (c + scale) + shift (norm/scale_shift.py:9-183): scale one value or one per column, shift one value, one per column or one per
 // element.  With a per-element shift c = scale_constant (fused_scale_shift_kernel_2, :112), otherwise c = 1.0 whatever scale_constant says
 // (fused_scale_shift_kernel, :60) -- as the reference.  DT = type of x and out, ST = type of scale and shift; fp32 arithmetic.
@@ -410,6 +437,23 @@ extern "C" int mi_fused_split_qk_norm(const void *x, long long rows, int q_lora_
     else if (dtype == MI_DTYPE_F16) MI_SQK(MI_DTYPE_F16);
     else MI_SQK(MI_DTYPE_F32);
 #undef MI_SQK
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_swiglu_oai(const void *x, long long rows, int dim, float alpha, float limit, int dtype, void *out, void *stream)
+{
+    if (rows < 0 || dim <= 0 || dim % 2 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16 && dtype != MI_DTYPE_F32)) return MI_SGL_EINVAL;
+    const int n16 = dtype == MI_DTYPE_F32 ? 4 : 8;
+    if ((dim / 2) % n16) return MI_SGL_EINVAL;              // 16-byte pieces of the output rows
+    const long long n_out = rows * (long long)(dim / 2);
+    if (n_out == 0) return MI_SGL_OK;
+    if (!x || !out) return MI_SGL_EINVAL;
+    long long blocks = (n_out / n16 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI_DTYPE_BF16) swiglu_oai_kernel<MI_DTYPE_BF16><<<(unsigned)blocks, 256, 0, st>>>((const uint16_t *)x, n_out, alpha, limit, (uint16_t *)out);
+    else if (dtype == MI_DTYPE_F16) swiglu_oai_kernel<MI_DTYPE_F16><<<(unsigned)blocks, 256, 0, st>>>((const uint16_t *)x, n_out, alpha, limit, (uint16_t *)out);
+    else swiglu_oai_kernel<MI_DTYPE_F32><<<(unsigned)blocks, 256, 0, st>>>((const float *)x, n_out, alpha, limit, (float *)out);
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 

@@ -318,6 +318,19 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_mro
     return {q, k, v, gate};
 }
 
+// activation/swiglu_oai.py:53-83 (swiglu_oai_triton)
+at::Tensor swiglu_oai(const at::Tensor &hidden_states, int64_t dim, double gemm1_alpha, double gemm1_clamp_limit)
+{
+    TORCH_CHECK(hidden_states.is_contiguous() && dim > 0 && dim % 2 == 0 && hidden_states.numel() % dim == 0,
+                "swiglu_oai: hidden_states must be contiguous with a multiple of dim elements");
+    const int64_t rows = hidden_states.numel() / dim;
+    at::Tensor out = at::empty({rows, dim / 2}, hidden_states.options());
+    const int rc = mi_swiglu_oai(hidden_states.data_ptr(), rows, (int)dim, (float)gemm1_alpha, (float)gemm1_clamp_limit, dtype_code3(hidden_states),
+                                 out.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_swiglu_oai failed with code ", rc, " (dim / 2 must be a multiple of 8)");
+    return out;
+}
+
 // norm/fused_split_qk_norm.py:93-134 (weights / biases of the two layer norms passed as tensors)
 std::tuple<at::Tensor, at::Tensor, at::Tensor> fused_split_qk_norm(const at::Tensor &x, const at::Tensor &q_weight, const std::optional<at::Tensor> &q_bias,
                                                                    const at::Tensor &k_weight, const std::optional<at::Tensor> &k_bias, int64_t q_lora_rank,
@@ -631,6 +644,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("split_qkv_rmsnorm_rope_pos_cache_half(Tensor input, Tensor positions, Tensor cos_sin_cache, int q_hidden_size, int kv_hidden_size, "
           "int head_dim, float? eps, Tensor? q_weight, Tensor? k_weight, Tensor? q_bias, Tensor? k_bias, int rope_dim, "
           "bool cast_norm_to_bf16) -> (Tensor, Tensor, Tensor)");
+    m.def("swiglu_oai(Tensor hidden_states, int dim, float gemm1_alpha, float gemm1_clamp_limit) -> Tensor");
     m.def("fused_split_qk_norm(Tensor x, Tensor q_weight, Tensor? q_bias, Tensor k_weight, Tensor? k_bias, int q_lora_rank, int kv_lora_rank, "
           "int qk_rope_dim, float eps=1e-6) -> (Tensor, Tensor, Tensor)");
     m.def("split_qkv_tp_local_var(Tensor input, int q_hidden_size, int kv_hidden_size) -> (Tensor, Tensor)");
@@ -657,6 +671,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("fused_scale_shift", TORCH_FN(sglang::npu_kernel::fused_scale_shift));
     m.impl("split_qkv_rmsnorm_mrope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_mrope));
     m.impl("split_qkv_rmsnorm_rope_pos_cache_half", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope_pos_cache_half));
+    m.impl("swiglu_oai", TORCH_FN(sglang::npu_kernel::swiglu_oai));
     m.impl("fused_split_qk_norm", TORCH_FN(sglang::npu_kernel::fused_split_qk_norm));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));
     m.impl("split_qkv_tp_norm_rope", TORCH_FN(sglang::npu_kernel::split_qkv_tp_norm_rope));

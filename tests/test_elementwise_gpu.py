@@ -341,6 +341,29 @@ def test_fused_split_qk_norm(B, ql, kl, rd, qbias, kbias, dt):
     assert torch.allclose(q.cpu().float(), wq.float(), rtol=ulp, atol=1e-5) and torch.allclose(kn.cpu().float(), wkn.float(), rtol=ulp, atol=1e-5)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,dim", [(1024, 5760), (7, 64), (1, 16), (300, 2880 * 2)])
+def test_swiglu_oai(rows, dim, dt):
+    """activation/swiglu_oai.py (GPT-OSS: 2880 intermediate columns) through the module-style entry point the reference exposes."""
+    from sgl_kernel_npu.activation.swiglu_oai import swiglu_oai, swiglu_oai_native
+    torch.manual_seed(rows)
+    x = (torch.randn(rows, dim) * 4).to(dt)
+
+    class Cfg:
+        gemm1_alpha, gemm1_clamp_limit = 1.702, 7.0
+
+    class Layer:
+        w13_weight = torch.empty(2, 1, dim)
+        moe_runner_config = Cfg()
+    got = swiglu_oai(Layer(), x.cuda())
+    want = OK.swiglu_oai(x, dim, 1.702, 7.0)
+    assert got.shape == (rows, dim // 2) and got.dtype == dt
+    ulp = {torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10, torch.float32: 1e-5}[dt]
+    assert torch.allclose(got.cpu().float(), want.float(), rtol=2 * ulp, atol=1e-5)
+    native = swiglu_oai_native(Layer(), x)                       # dtype arithmetic: several roundings
+    assert torch.allclose(got.cpu().float(), native.float(), rtol=6 * ulp + 1e-5, atol=6 * ulp)
+
+
 def test_split_qkv_rmsnorm_rope_pos_cache_half_replays_in_a_captured_graph():
     """The reference test replays the op in a captured device graph with new inputs in the same buffers
     (test_split_qkv_rmsnorm_rope_pos_cache_half_npu.py:213-260): positions are clamped inside the kernel, nothing synchronises."""
