@@ -344,7 +344,10 @@ def _selftest_run(W, rounds, first_epoch, state, bad_rank=None, stale_rank=None)
         state.update(rows=[torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(W)],
                      flags=[torch.zeros(64, dtype=torch.int64, device="cuda") for _ in range(W)],
                      acks=[torch.zeros(64, dtype=torch.int64, device="cuda") for _ in range(W)],
-                     streams=[torch.cuda.Stream() for _ in range(W)])
+                     # one stream per simulated rank, on DIFFERENT hardware queues: the runtime deals plain streams round-robin onto four
+                     # queues, so which two a test gets depends on how many streams the process made before it; streams of different
+                     # priorities never share a queue
+                     streams=[torch.cuda.Stream(priority=(0 if r % 2 == 0 else -1)) for r in range(W)])
     status = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(W)]
     torch.cuda.synchronize()
     rows_p, flags_p, acks_p = ptr_array([t.data_ptr() for t in state["rows"]]), ptr_array([t.data_ptr() for t in state["flags"]]), \
