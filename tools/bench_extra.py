@@ -92,6 +92,21 @@ def main():
     xb = torch.randn((1, 16384, 7168), generator=g, device="cuda").to(torch.bfloat16)
     t = ev_time(lambda: fused_rmsnorm_without_weight(xb, 1e-6))
     out["rmsnorm_without_weight_16384x7168_bf16"] = dict(t, GBps=16384 * 7168 * 4 / t["p50_us"] / 1e3)
+    from sgl_kernel_npu.norm.split_qkv_tp_rmsnorm_rope import split_qkv_tp_rmsnorm_rope
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_mrope import triton_split_qkv_rmsnorm_mrope
+    from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope_pos_cache_half_npu import split_qkv_rmsnorm_rope_pos_cache_half_npu
+    xt = torch.randn((B, 6144 + 2048), generator=g, device="cuda").to(torch.bfloat16)
+    wq_, wk_ = torch.randn(6144, device="cuda").to(torch.bfloat16), torch.randn(1024, device="cuda").to(torch.bfloat16)
+    s2, c2 = torch.rand((B, 128), device="cuda").to(torch.bfloat16), torch.rand((B, 128), device="cuda").to(torch.bfloat16)
+    t = ev_time(lambda: split_qkv_tp_rmsnorm_rope(xt, c2, s2, 6144, 1024, 128, 1e-6, wq_, wk_, 128, 1, None))
+    out["split_qkv_tp_rmsnorm_rope_4096x8192"] = dict(t, GBps=B * 8192 * 4 / t["p50_us"] / 1e3, launches=2)
+    cs3 = torch.randn((3, B, 128), device="cuda").to(torch.bfloat16)
+    t = ev_time(lambda: triton_split_qkv_rmsnorm_mrope(xt, hw, hw, cs3, 48, 8, 128, 1e-6, [24, 20, 20], True))
+    out["split_qkv_rmsnorm_mrope_4096x8192"] = dict(t, GBps=B * 8192 * 4 / t["p50_us"] / 1e3)
+    cache = torch.randn((8192, 128), device="cuda")
+    posb = torch.randint(0, 8192, (B,), device="cuda")
+    t = ev_time(lambda: split_qkv_rmsnorm_rope_pos_cache_half_npu(xt, posb, cache, 6144, 1024, 128, eps=1e-6, q_weight=hw, k_weight=hw))
+    out["split_qkv_rmsnorm_rope_pos_cache_4096x8192"] = dict(t, GBps=B * 8192 * 4 / t["p50_us"] / 1e3)
     # ---- paged GQA decode (HBM-bound): Llama-70B-like (64 q / 8 kv heads, D=128) and the reference's 288/256 config
     from sgl_kernel_npu.attention.decode_attention import decode_gqa
     for name, Bq, Hq, Hkv, D, Dv, Sq in (("gqa_decode_b64_h64kv8_d128_s4096", 64, 64, 8, 128, 128, 4096),
