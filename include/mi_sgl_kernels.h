@@ -6,6 +6,7 @@
  * These replace the reference's Triton-Ascend kernels (python/sgl_kernel_npu/sgl_kernel_npu/...):
  *   mi_mla_decode            <- attention/decode_attention.py:5-230   (_paged_mla_fwd_kernel / decode_mla)
  *   mi_gqa_decode            <- attention/decode_attention.py:233-450,646-760 (decode_gqa, decode_gqa_high_performance)
+ *   mi_gqa_decode_sinks      <- attention/sinks_attention.py:7-286 (attention_sinks_triton, attention_sinks_prefill_triton)
  *   mi_swiglu_quant          <- activation/swiglu_quant.py:8-127      (_swiglu_quant_kernel / swiglu_quant)
  *   mi_add_rmsnorm_bias      <- norm/add_rmsnorm_bias.py:8-147        (add_rmsnorm_bias_kernel / add_rmsnorm_bias)
  *                               norm/add_rmsnorm_bias.py:150-232      (add_gemma_rms_norm)
@@ -76,6 +77,16 @@ int mi_gqa_decode(const void *q, const void *k, const void *v, void *out, const 
                   int64_t k_stride_row, int64_t k_stride_h, int64_t v_stride_blk, int64_t v_stride_row, int64_t v_stride_h,
                   int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits, void *workspace,
                   size_t workspace_bytes, void *stream);
+/* The same kernel with attention sinks, a sliding window and one block-table row per query row (attention/sinks_attention.py:7-286):
+ * sinks [q_heads] (sinks_dtype MI_DTYPE_BF16 / F16 / F32; NULL = none) = a per-head logit, not scaled by sm_scale, that enters the softmax
+ * maximum and denominator but has no value row; sliding_window = keys [len - window, len) (-1 = all); block_table_rows [batch] = the
+ * block-table row of query row b (NULL = b) -- the extend form runs every new token as a row of its own with kv_seq_lens = its causal length. */
+int mi_gqa_decode_sinks(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens, const int32_t *block_table, int batch,
+                        int q_heads, int kv_heads, int k_dim, int v_dim, int page_size, int bt_stride, int max_seq_len, int64_t q_stride_b,
+                        int64_t q_stride_h, int64_t k_stride_blk, int64_t k_stride_row, int64_t k_stride_h, int64_t v_stride_blk,
+                        int64_t v_stride_row, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits,
+                        void *workspace, size_t workspace_bytes, const void *sinks, int sinks_dtype, int sliding_window,
+                        const int32_t *block_table_rows, void *stream);
 
 /* ---- SwiGLU + per-row INT8 quantisation (swiglu_quant.py:87-127) -------------------------------------------------
  * x [rows, cols] (cols = 2I; gate = x[:, :I], up = x[:, I:]); only the first `total` rows are processed, where total =

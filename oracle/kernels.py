@@ -403,6 +403,39 @@ def fused_split_qk_norm(x, q_weight, q_bias, k_weight, k_bias, q_lora_rank, kv_l
     return one(q, q_weight, q_bias), one(kn, k_weight, k_bias).unsqueeze(1), kp.clone().unsqueeze(1)
 
 
+def attention_sinks(query, k_cache, v_cache, sinks, block_tables, kv_lens, scale, window, q_head_num, k_head_num, bt_rows=None):
+    """Restates attention_sinks_kernel / attention_sinks_prefill_kernel (attention/sinks_attention.py:7-87, :139-238) in fp32, one query row at
+    a time: keys [max(len - window, 0), len) of the row's sequence (:35-39, :174-180), logits q . k * scale, softmax over the keys AND the
+    head's sink logit (running maximum starts at the sink, :45, the denominator gains exp(sink - max), :78-79), P rounded to the cache dtype
+    before P . V (:73).  kv_lens [rows]; bt_rows [rows] = block-table row of a query row (extend form).  PARITY UNPINNED (no reference test);
+    tests/test_oracle_kernels.py ties it to the pinned decode_gqa oracle (sink = -inf, no window)."""
+    rows = query.shape[0]
+    D = query.shape[1] // q_head_num
+    page = k_cache.shape[1]
+    Dv = v_cache.shape[-1]
+    group = q_head_num // k_head_num
+    out = torch.zeros(rows, q_head_num, Dv, dtype=torch.float32)
+    q = query.reshape(rows, q_head_num, D).float()
+    for r in range(rows):
+        n = int(kv_lens[r])
+        lo = max(n - window, 0) if window != -1 else 0
+        br = int(bt_rows[r]) if bt_rows is not None else r
+        pos = torch.arange(lo, n)
+        blk = block_tables[br][pos // page].long()
+        for h in range(q_head_num):
+            kvh = h // group
+            sk = float(sinks[h])
+            if n > lo:
+                k = k_cache[blk, pos % page, kvh].float()
+                v = v_cache[blk, pos % page, kvh]
+                s = (k @ q[r, h]) * scale
+                m = max(float(s.max()), sk)
+                pexp = torch.exp(s - m)
+                l = float(pexp.sum()) + float(torch.exp(torch.tensor(sk - m)))
+                out[r, h] = (pexp.to(v.dtype).float() @ v.float()) / l
+    return out.to(query.dtype).reshape(rows, q_head_num * Dv)
+
+
 def swiglu_oai(x, dim, alpha, limit):
     """Restates swiglu_oai_kernel (activation/swiglu_oai.py:7-50) in fp32: gate = even columns clamped from above (:36), up = odd columns
     clamped to +-limit (:37-38), (up + 1) * gate * 1 / (1 + exp(-gate * alpha)) (:39-41).  Pinned to the file's own torch formulation

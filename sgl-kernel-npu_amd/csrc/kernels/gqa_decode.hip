@@ -73,7 +73,21 @@ struct GqaParams {
     int batch, q_heads, kv_heads, group, page_size, bt_stride, num_splits, lk, lv;
     int64_t q_sb, q_sh, k_sblk, k_srow, k_sh, v_sblk, v_srow, v_sh, o_sb, o_sh;
     float sm_scale;
+    // attention with sinks (attention/sinks_attention.py:7-137, :139-286): a per-q-head logit that takes part in the softmax denominator only;
+    // a sliding window (keys [len - window, len)); and, for the extend ("prefill") form, a row of the block table per query row
+    const void *sinks;          // [q_heads], element type sinks_dtype (MI_DTYPE_*); null = none
+    int sinks_dtype;
+    int window;                 // -1 = all keys
+    const int32_t *bt_rows;     // [batch] block-table row of every query row; null = row b
 };
+__device__ __forceinline__ float gqa_sink_l2(const GqaParams &p, int head)      // the sink logit in the kernel's log2 domain (NOT scaled by sm_scale)
+{
+    float v;
+    if (p.sinks_dtype == MI_DTYPE_F32) v = ((const float *)p.sinks)[head];
+    else if (p.sinks_dtype == MI_DTYPE_BF16) v = __uint_as_float((uint32_t)((const uint16_t *)p.sinks)[head] << 16);
+    else v = (float)__builtin_bit_cast(_Float16, ((const uint16_t *)p.sinks)[head]);
+    return v * 1.4426950408889634f;
+}
 
 template <bool BF16>
 __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)
@@ -118,9 +132,13 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
     const int b = unit / (p.num_splits * p.kv_heads);
     const int seq_len = p.seq_lens[b];
     const int ntiles = (seq_len + TILE - 1) / TILE;
-    const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
-    const int t_begin = split * tps;
+    // sliding window: keys [start_kv, seq_len) (sinks_attention.py:35-39); the splits share the tiles from the window's first one on
+    const int start_kv = (p.window >= 0 && seq_len > p.window) ? seq_len - p.window : 0;
+    const int first_tile = start_kv / TILE;
+    const int tps = (ntiles - first_tile + p.num_splits - 1) / p.num_splits;
+    const int t_begin = first_tile + split * tps;
     const int t_end = min(ntiles, t_begin + tps);
+    const int64_t bt_row = p.bt_rows ? p.bt_rows[b] : b;
 
     // Q^T fragments: lane (g, c16) holds q[head][ks*32 + g*8 .. +8] of head block hb
     s16x8 qf[HB][QS];
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
     int32_t nblk[RP];
     auto bt_load = [&](int tile) {
 #pragma unroll
-        for (int rp = 0; rp < RP; ++rp) nblk[rp] = p.block_table[(int64_t)b * p.bt_stride + page_of(key_of(tile, rp))];
+        for (int rp = 0; rp < RP; ++rp) nblk[rp] = p.block_table[bt_row * p.bt_stride + page_of(key_of(tile, rp))];
     };
     auto stage_load = [&](int tile) {                             // nblk holds this tile's block ids
         const uint16_t *kr[RP], *vr[RP];
@@ -244,13 +262,13 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
                     s[mt] = mfma16<BF16>(a, qf[hb][ks], s[mt]);
                 }
             // ---- online softmax in the scaled log2 domain; lane owns head c16 and keys mt*16 + 4g + r
-            if ((t + 1) * TILE > seq_len) {
+            if ((t + 1) * TILE > seq_len || t * TILE < start_kv) {      // the tile that crosses the end, the tile the window starts in
                 const int kbase = t * TILE + 4 * g;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kbase + mt * 16 + r >= seq_len) s[mt][r] = -INFINITY;
+                        if (kbase + mt * 16 + r >= seq_len || kbase + mt * 16 + r < start_kv) s[mt][r] = -INFINITY;
             }
             float tmax = -INFINITY;
 #pragma unroll
@@ -306,7 +324,16 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
         if (hg[hb] >= p.group) continue;
         const int head = kvh * p.group + hg[hb];
         if (p.num_splits == 1) {
-            const float inv = l_run[hb] > 0.f ? 1.f / l_run[hb] : 0.f;
+            float inv;
+            if (p.sinks) {                                        // l += exp(sink - max) with the sink inside the max (:78-80)
+                const float sk = gqa_sink_l2(p, head);
+                const float M = fmaxf(m_run[hb], sk);
+                const float wa = (m_run[hb] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[hb] - M);
+                const float L = l_run[hb] * wa + __builtin_amdgcn_exp2f(sk - M);
+                inv = wa / L;
+            } else {
+                inv = l_run[hb] > 0.f ? 1.f / l_run[hb] : 0.f;
+            }
             uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -337,13 +364,15 @@ __global__ __launch_bounds__(256) void gqa_merge_kernel(GqaParams p, int dvp)
     if (bh >= (int64_t)p.batch * p.q_heads) return;
     const int S = p.num_splits;
     const float *ml = p.ws_ml + bh * S * 2;
+    const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
     float M = -INFINITY;
     for (int s = 0; s < S; ++s) M = fmaxf(M, ml[s * 2]);
-    float L = 0.f;
+    const float sk = p.sinks ? gqa_sink_l2(p, h) : -INFINITY;
+    M = fmaxf(M, sk);
+    float L = p.sinks ? __builtin_amdgcn_exp2f(sk - M) : 0.f;
     for (int s = 0; s < S; ++s)
         if (ml[s * 2] != -INFINITY) L += __builtin_amdgcn_exp2f(ml[s * 2] - M) * ml[s * 2 + 1];
     const float inv = L > 0.f ? 1.f / L : 0.f;
-    const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
     uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
     for (int d = lane * 4; d < p.lv; d += 256) {
         f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -423,12 +452,13 @@ extern "C" int mi_gqa_decode_num_splits(int batch, int q_heads, int kv_heads, in
     return s < 1 ? 1 : s;
 }
 
-extern "C" int mi_gqa_decode(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
+static int gqa_decode_impl(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
                              const int32_t *block_table, int batch, int q_heads, int kv_heads, int k_dim, int v_dim, int page_size,
                              int bt_stride, int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_blk,
                              int64_t k_stride_row, int64_t k_stride_h, int64_t v_stride_blk, int64_t v_stride_row,
                              int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits,
-                             void *workspace, size_t workspace_bytes, void *stream)
+                             void *workspace, size_t workspace_bytes, void *stream, const void *sinks, int sinks_dtype, int window,
+                             const int32_t *bt_rows)
 {
     if (batch < 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads || page_size <= 0 || bt_stride <= 0) return MI_SGL_EINVAL;
     if (k_dim <= 0 || v_dim <= 0 || (k_dim % 8) || (v_dim % 8)) return MI_SGL_EINVAL;
@@ -452,6 +482,7 @@ extern "C" int mi_gqa_decode(const void *q, const void *k, const void *v, void *
     p.q_sb = q_stride_b, p.q_sh = q_stride_h, p.k_sblk = k_stride_blk, p.k_srow = k_stride_row, p.k_sh = k_stride_h;
     p.v_sblk = v_stride_blk, p.v_srow = v_stride_row, p.v_sh = v_stride_h, p.o_sb = o_stride_b, p.o_sh = o_stride_h;
     p.sm_scale = sm_scale;
+    p.sinks = sinks, p.sinks_dtype = sinks_dtype, p.window = window, p.bt_rows = bt_rows;
     hipStream_t st = (hipStream_t)stream;
     const int hpw = heads_per_wg(*shape, p.group);
     const int head_blocks = (p.group + hpw - 1) / hpw;
@@ -468,4 +499,32 @@ extern "C" int mi_gqa_decode(const void *q, const void *k, const void *v, void *
         else gqa_merge_kernel<false><<<blocks, 256, 0, st>>>(p, shape->dvp);
     }
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_gqa_decode(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
+                             const int32_t *block_table, int batch, int q_heads, int kv_heads, int k_dim, int v_dim, int page_size,
+                             int bt_stride, int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_blk,
+                             int64_t k_stride_row, int64_t k_stride_h, int64_t v_stride_blk, int64_t v_stride_row,
+                             int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    return gqa_decode_impl(q, k, v, out, kv_seq_lens, block_table, batch, q_heads, kv_heads, k_dim, v_dim, page_size, bt_stride, max_seq_len,
+                           q_stride_b, q_stride_h, k_stride_blk, k_stride_row, k_stride_h, v_stride_blk, v_stride_row, v_stride_h, o_stride_b,
+                           o_stride_h, sm_scale, dtype, num_splits, workspace, workspace_bytes, stream, nullptr, 0, -1, nullptr);
+}
+
+extern "C" int mi_gqa_decode_sinks(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
+                                   const int32_t *block_table, int batch, int q_heads, int kv_heads, int k_dim, int v_dim, int page_size,
+                                   int bt_stride, int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_blk,
+                                   int64_t k_stride_row, int64_t k_stride_h, int64_t v_stride_blk, int64_t v_stride_row,
+                                   int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, int num_splits,
+                                   void *workspace, size_t workspace_bytes, const void *sinks, int sinks_dtype, int sliding_window,
+                                   const int32_t *block_table_rows, void *stream)
+{
+    if (sinks && sinks_dtype != MI_DTYPE_BF16 && sinks_dtype != MI_DTYPE_F16 && sinks_dtype != MI_DTYPE_F32) return MI_SGL_EINVAL;
+    if (sliding_window < -1) return MI_SGL_EINVAL;
+    return gqa_decode_impl(q, k, v, out, kv_seq_lens, block_table, batch, q_heads, kv_heads, k_dim, v_dim, page_size, bt_stride, max_seq_len,
+                           q_stride_b, q_stride_h, k_stride_blk, k_stride_row, k_stride_h, v_stride_blk, v_stride_row, v_stride_h, o_stride_b,
+                           o_stride_h, sm_scale, dtype, num_splits, workspace, workspace_bytes, stream, sinks, sinks_dtype, sliding_window,
+                           block_table_rows);
 }

@@ -121,6 +121,41 @@ void decode_gqa(const at::Tensor &q, const at::Tensor &k_buffer, const at::Tenso
                 " (head dims must be multiples of 8 with (k, v) <= (64,64) (128,128) (192,128) (256,256) (288,256) or (576,512))");
 }
 
+// attention/sinks_attention.py:90-137 (decode) and :241-286 (extend): query [rows, Hq * D]; kv_lens [rows] int32 = keys each query row sees;
+// bt_rows [rows] int32 = its block-table row (undefined tensor = row index).  Returns [rows, Hq * Dv].
+at::Tensor attention_sinks(const at::Tensor &query, const at::Tensor &k_cache, const at::Tensor &v_cache, const at::Tensor &sinks,
+                           const at::Tensor &block_tables, const at::Tensor &kv_lens, double scale, int64_t sliding_window_size, int64_t q_head_num,
+                           int64_t k_head_num, const std::optional<at::Tensor> &bt_rows)
+{
+    TORCH_CHECK(query.dim() == 2 && query.is_contiguous() && k_cache.dim() == 4 && v_cache.dim() == 4 && block_tables.dim() == 2,
+                "attention_sinks: query [rows, Hq * D], caches [blocks, page, Hkv, D], block_tables [seqs, max_blocks]");
+    TORCH_CHECK(k_cache.stride(3) == 1 && v_cache.stride(3) == 1 && block_tables.stride(1) == 1, "attention_sinks: innermost dimensions must be contiguous");
+    TORCH_CHECK(query.scalar_type() == k_cache.scalar_type() && query.scalar_type() == v_cache.scalar_type(), "attention_sinks: dtype mismatch");
+    TORCH_CHECK(kv_lens.scalar_type() == at::kInt && kv_lens.is_contiguous() && block_tables.scalar_type() == at::kInt,
+                "attention_sinks: kv lengths / block_tables must be int32");
+    const int rows = (int)query.size(0), Hq = (int)q_head_num, Hkv = (int)k_head_num;
+    TORCH_CHECK(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && query.size(1) % Hq == 0 && k_cache.size(2) == Hkv && v_cache.size(2) == Hkv, "attention_sinks: heads");
+    const int D = (int)(query.size(1) / Hq), Dv = (int)v_cache.size(3);
+    TORCH_CHECK(k_cache.size(3) == D && kv_lens.numel() == rows, "attention_sinks: shape mismatch");
+    TORCH_CHECK(sinks.numel() == Hq && sinks.is_contiguous(), "attention_sinks: sinks must hold one value per q head");
+    if (bt_rows.has_value()) TORCH_CHECK(bt_rows->scalar_type() == at::kInt && bt_rows->is_contiguous() && bt_rows->numel() == rows, "attention_sinks: bt_rows");
+    const int page = (int)k_cache.size(1);
+    at::Tensor out = at::empty({rows, (int64_t)Hq * Dv}, query.options());
+    int64_t max_len = std::min<int64_t>(block_tables.size(1) * (int64_t)page, INT32_MAX);
+    if (sliding_window_size >= 0) max_len = std::min<int64_t>(max_len, std::max<int64_t>(sliding_window_size, 1));
+    const int splits = mi_gqa_decode_num_splits(rows, Hq, Hkv, (int)max_len);
+    const size_t wsb = mi_gqa_decode_workspace(rows, Hq, Dv, splits);
+    at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(query.device()));
+    const int rc = mi_gqa_decode_sinks(query.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), kv_lens.data_ptr<int>(),
+                                       block_tables.data_ptr<int>(), rows, Hq, Hkv, D, Dv, page, (int)block_tables.stride(0), (int)max_len,
+                                       (int64_t)Hq * D, D, k_cache.stride(0), k_cache.stride(1), k_cache.stride(2), v_cache.stride(0),
+                                       v_cache.stride(1), v_cache.stride(2), (int64_t)Hq * Dv, Dv, (float)scale, dtype_code(query), splits,
+                                       ws.data_ptr(), wsb, sinks.data_ptr(), dtype_code3(sinks), (int)sliding_window_size,
+                                       bt_rows.has_value() ? bt_rows->data_ptr<int>() : nullptr, cur_stream());
+    TORCH_CHECK(rc == 0, "mi_gqa_decode_sinks failed with code ", rc);
+    return out;
+}
+
 // SwiGLU + per-row INT8 quantisation; same arguments / returns as swiglu_quant (activation/swiglu_quant.py:87-127).
 std::tuple<at::Tensor, at::Tensor> swiglu_quant(const at::Tensor &x, const at::Tensor &group_list, int64_t group_list_type,
                                                 bool need_quant, bool do_limit, double limit)
@@ -644,6 +679,8 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("split_qkv_rmsnorm_rope_pos_cache_half(Tensor input, Tensor positions, Tensor cos_sin_cache, int q_hidden_size, int kv_hidden_size, "
           "int head_dim, float? eps, Tensor? q_weight, Tensor? k_weight, Tensor? q_bias, Tensor? k_bias, int rope_dim, "
           "bool cast_norm_to_bf16) -> (Tensor, Tensor, Tensor)");
+    m.def("attention_sinks(Tensor query, Tensor k_cache, Tensor v_cache, Tensor sinks, Tensor block_tables, Tensor kv_lens, float scale, "
+          "int sliding_window_size, int q_head_num, int k_head_num, Tensor? bt_rows=None) -> Tensor");
     m.def("swiglu_oai(Tensor hidden_states, int dim, float gemm1_alpha, float gemm1_clamp_limit) -> Tensor");
     m.def("fused_split_qk_norm(Tensor x, Tensor q_weight, Tensor? q_bias, Tensor k_weight, Tensor? k_bias, int q_lora_rank, int kv_lora_rank, "
           "int qk_rope_dim, float eps=1e-6) -> (Tensor, Tensor, Tensor)");
@@ -671,6 +708,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("fused_scale_shift", TORCH_FN(sglang::npu_kernel::fused_scale_shift));
     m.impl("split_qkv_rmsnorm_mrope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_mrope));
     m.impl("split_qkv_rmsnorm_rope_pos_cache_half", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope_pos_cache_half));
+    m.impl("attention_sinks", TORCH_FN(sglang::npu_kernel::attention_sinks));
     m.impl("swiglu_oai", TORCH_FN(sglang::npu_kernel::swiglu_oai));
     m.impl("fused_split_qk_norm", TORCH_FN(sglang::npu_kernel::fused_split_qk_norm));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));

@@ -168,3 +168,76 @@ def test_full_size_vs_fp32():
             hs = slice(kvh * 8, kvh * 8 + 8)
             ref = torch.softmax((q[b, hs].float() @ K.T) * D ** -0.5, -1) @ V
             assert torch.allclose(got[b, hs].float(), ref, atol=1e-3, rtol=2 ** -7), (got[b, hs].float() - ref).abs().max()
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Hq,Hkv,D,page,S,window,sink_dt", [
+    (4, 64, 8, 64, 128, 700, -1, torch.bfloat16),          # GPT-OSS head shape (64 q / 8 kv heads of 64)
+    (4, 64, 8, 64, 128, 700, 128, torch.float32),
+    (3, 16, 2, 128, 16, 333, 100, torch.float32),           # window start inside a tile and inside a page
+    (2, 8, 8, 64, 64, 40, 64, torch.float16),               # sequences shorter than the window
+    (5, 32, 4, 128, 32, 2100, 1024, torch.bfloat16),        # several KV splits
+])
+def test_attention_sinks_decode(B, Hq, Hkv, D, page, S, window, sink_dt, dt):
+    """attention/sinks_attention.py:90-137 through its Python entry point against the fp32 restatement: sink in the denominator, sliding window."""
+    from sgl_kernel_npu.attention.sinks_attention import attention_sinks_triton
+    torch.manual_seed(B * 7 + S)
+    maxp = (S + page - 1) // page
+    nb = B * maxp + 2
+    q = torch.randn(B, Hq * D).to(dt)
+    kc, vc = torch.randn(nb, page, Hkv, D).to(dt), torch.randn(nb, page, Hkv, D).to(dt)
+    bt = torch.randperm(nb)[:B * maxp].reshape(B, maxp).to(torch.int32)
+    lens = torch.tensor([max(1, S - 97 * i) for i in range(B)], dtype=torch.int32)
+    sinks = (torch.randn(Hq) * 2).to(sink_dt)
+    scale = D ** -0.5
+    got = attention_sinks_triton(q.cuda(), kc.cuda(), vc.cuda(), sinks.cuda(), bt.cuda(), lens.cuda(), scale, window, Hq, Hkv)
+    want = OK.attention_sinks(q, kc, vc, sinks, bt, lens, scale, window, Hq, Hkv)
+    assert got.shape == (B, Hq * D) and got.dtype == dt
+    tol = dict(atol=2e-3, rtol=2 ** -6 if dt == torch.bfloat16 else 2 ** -9)
+    assert torch.allclose(got.cpu().float(), want.float(), **tol), (got.cpu().float() - want.float()).abs().max()
+
+
+def test_attention_sinks_without_a_sink_equals_decode_gqa():
+    """sinks = -inf, no window: the same kernel must give decode_gqa's bits."""
+    from sgl_kernel_npu.attention.decode_attention import decode_gqa
+    from sgl_kernel_npu.attention.sinks_attention import attention_sinks_triton
+    torch.manual_seed(3)
+    B, Hq, Hkv, D, page, S = 3, 32, 4, 128, 64, 900
+    dt = torch.bfloat16
+    maxp = (S + page - 1) // page
+    nb = B * maxp
+    q = torch.randn(B, Hq, D).to(dt).cuda()
+    kc, vc = torch.randn(nb, page, Hkv, D).to(dt).cuda(), torch.randn(nb, page, Hkv, D).to(dt).cuda()
+    bt = torch.randperm(nb)[:B * maxp].reshape(B, maxp).to(torch.int32).cuda()
+    lens = torch.tensor([900, 1, 517], dtype=torch.int32).cuda()
+    out = torch.empty(B, Hq, D, dtype=dt, device="cuda")
+    decode_gqa(q, kc, vc, out, lens, D ** -0.5, page, bt)
+    got = attention_sinks_triton(q.reshape(B, Hq * D), kc, vc, torch.full((Hq,), float("-inf"), device="cuda"), bt, lens, D ** -0.5, -1, Hq, Hkv)
+    assert torch.equal(got.reshape(B, Hq, D), out)
+
+
+@pytest.mark.parametrize("window", [-1, 48])
+def test_attention_sinks_extend(window):
+    """attention/sinks_attention.py:241-286: every new token of every sequence attends causally (its own length, its own window)."""
+    from sgl_kernel_npu.attention.sinks_attention import attention_sinks_prefill_triton
+    torch.manual_seed(11)
+    Hq, Hkv, D, page = 16, 4, 64, 16
+    dt = torch.bfloat16
+    seq_lens = torch.tensor([5, 1, 37], dtype=torch.int32)          # new tokens
+    ctx = torch.tensor([60, 1, 37], dtype=torch.int32)              # keys in the cache including them
+    Bn, S = 3, int(seq_lens.sum())
+    maxp = 8
+    nb = Bn * maxp
+    q = torch.randn(S, Hq * D).to(dt)
+    kc, vc = torch.randn(nb, page, Hkv, D).to(dt), torch.randn(nb, page, Hkv, D).to(dt)
+    bt = torch.randperm(nb).reshape(Bn, maxp).to(torch.int32)
+    sinks = torch.randn(Hq)
+    scale = D ** -0.5
+    got = attention_sinks_prefill_triton(q.cuda(), kc.cuda(), vc.cuda(), sinks.cuda(), seq_lens.cuda(), bt.cuda(), ctx.cuda(), scale, window, Hq, Hkv)
+    kv, rows = [], []
+    for b in range(Bn):
+        for t in range(int(seq_lens[b])):
+            kv.append(int(ctx[b]) - int(seq_lens[b]) + t + 1)
+            rows.append(b)
+    want = OK.attention_sinks(q, kc, vc, sinks, bt, torch.tensor(kv, dtype=torch.int32), scale, window, Hq, Hkv, torch.tensor(rows, dtype=torch.int32))
+    assert torch.allclose(got.cpu().float(), want.float(), atol=2e-3, rtol=2 ** -6), (got.cpu().float() - want.float()).abs().max()

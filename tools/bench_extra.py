@@ -80,6 +80,19 @@ def main():
     sg, cg = torch.rand((B, 64), device="cuda").to(torch.bfloat16), torch.rand((B, 64), device="cuda").to(torch.bfloat16)
     t = ev_time(lambda: split_qkvgate_gemma_rmsnorm_rope(xg, sg, cg, 4096, 1024, 128, 64, 1e-6, hw, hw))
     out["split_qkvgate_gemma_rmsnorm_rope_4096x10240"] = dict(t, GBps=B * 10240 * 4 / t["p50_us"] / 1e3)
+    # ---- attention with sinks, GPT-OSS decode shape: 64 q / 8 kv heads of 64, 4096 keys, window 128 and no window
+    from sgl_kernel_npu.attention.sinks_attention import attention_sinks_triton
+    Bs, Hqs, Hkvs, Ds, pg, Ss = 128, 64, 8, 64, 128, 4096
+    nbs = Bs * Ss // pg
+    qs_ = torch.randn((Bs, Hqs * Ds), generator=g, device="cuda").to(torch.bfloat16)
+    kcs, vcs = (torch.randn((nbs, pg, Hkvs, Ds), generator=g, device="cuda").to(torch.bfloat16) for _ in range(2))
+    bts = torch.randperm(nbs, device="cuda").to(torch.int32).reshape(Bs, Ss // pg)
+    lns = torch.full((Bs,), Ss, dtype=torch.int32, device="cuda")
+    snk = torch.randn(Hqs, device="cuda")
+    for wname, wsz in (("full", -1), ("window128", 128)):
+        t = ev_time(lambda: attention_sinks_triton(qs_, kcs, vcs, snk, bts, lns, Ds ** -0.5, wsz, Hqs, Hkvs), n=20, warm=3)
+        keys = Ss if wsz < 0 else wsz
+        out[f"attention_sinks_decode_b128_h64kv8_d64_s4096_{wname}"] = dict(t, GBps=Bs * keys * Hkvs * Ds * 2 * 2 / t["p50_us"] / 1e3)
     # ---- row statistics / scalings at the reference tests' shapes (fp32) and a bf16 model shape
     from sgl_kernel_npu.norm.rmsnorm_split import fused_rsqrt_mul, fused_variance
     from sgl_kernel_npu.norm.rmsnorm_without_weight import fused_rmsnorm_without_weight
