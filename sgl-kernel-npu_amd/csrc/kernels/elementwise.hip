@@ -550,9 +550,17 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
                     unpack8<BF16>(*(const u32x4 *)(base + t * sec_stride), c3[t]);
                     unpack8<BF16>(*(const u32x4 *)(base + t * sec_stride + half), s3[t]);
                 }
+                const int r0 = o0 % 3;                   // one division per lane: (o0 + e) % 3 follows from it
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int sec = mrope_section_of(ms, o0 + e);
+                    const int o = o0 + e;
+                    int sec;
+                    if (ms.interleaved) {
+                        const int r = (r0 + e) % 3;       // r0 + e < 10: folds to compares
+                        sec = (r == 1 && o <= 3 * ms.sec1) ? 1 : ((r == 2 && o <= 3 * ms.sec2) ? 2 : 0);
+                    } else {
+                        sec = o < ms.sec0 ? 0 : (o < ms.sec0 + ms.sec1 ? 1 : 2);
+                    }
                     cvf[u][e] = sec == 0 ? c3[0][e] : (sec == 1 ? c3[1][e] : c3[2][e]);
                     svf[u][e] = sec == 0 ? s3[0][e] : (sec == 1 ? s3[1][e] : s3[2][e]);
                 }
