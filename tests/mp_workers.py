@@ -784,3 +784,43 @@ def _gpu_graph(rank, world, port, cfg):
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# tensor-parallel RMSNorm + RoPE: the wrapper's all-reduce between its two launches, two column shards on one GPU (gloo carries the
+# device tensor through the host; RCCL would refuse two ranks on one device)
+# ----------------------------------------------------------------------------------------------
+def gpu_tp_rmsnorm_worker(rank, world, port, cfg):
+    run_guarded(_gpu_tp_rmsnorm, rank, world, port, cfg)
+
+
+def _gpu_tp_rmsnorm(rank, world, port, cfg):
+    import torch
+    import torch.distributed as dist
+    from oracle import kernels as OK
+    from sgl_kernel_npu.norm.split_qkv_tp_rmsnorm_rope import split_qkv_tp_rmsnorm_rope
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    B, qh, kvh, hd = cfg                                   # per-rank shard sizes
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(1234)                # the same full tensors on every rank
+    full_q, full_k, full_v = (torch.randn(B, n * world, generator=g).to(dt) for n in (qh, kvh, kvh))
+    fqw, fkw = torch.randn(qh * world, generator=g).to(dt), torch.randn(kvh * world, generator=g).to(dt)
+    cos, sin = torch.rand(B, hd, generator=g).to(dt), torch.rand(B, hd, generator=g).to(dt)
+    sl = lambda t, n: t[..., rank * n:(rank + 1) * n]
+    shard = torch.cat([sl(full_q, qh), sl(full_k, kvh), sl(full_v, kvh)], dim=-1).contiguous()
+    q, k, v = split_qkv_tp_rmsnorm_rope(shard.cuda(), cos.cuda(), sin.cuda(), qh, kvh, hd, 1e-6, sl(fqw, qh).contiguous().cuda(),
+                                        sl(fkw, kvh).contiguous().cuda(), hd, world, dist.group.WORLD)
+    # what the all-reduce must have supplied: the other shards' local means of squares
+    other = torch.zeros(B, 2)
+    for r in range(world):
+        if r != rank:
+            other[:, 0] += full_q[:, r * qh:(r + 1) * qh].float().pow(2).mean(-1)
+            other[:, 1] += full_k[:, r * kvh:(r + 1) * kvh].float().pow(2).mean(-1)
+    wq, wk, wv = OK.split_qkv_tp_rmsnorm_rope(shard, cos, sin, qh, kvh, hd, 1e-6, sl(fqw, qh), sl(fkw, kvh), hd, tp_world=world, other_var=other)
+    assert torch.equal(v.cpu(), wv)
+    assert torch.allclose(q.cpu().float(), wq.float(), rtol=2 ** -6, atol=2 ** -6), (q.cpu().float() - wq.float()).abs().max()
+    assert torch.allclose(k.cpu().float(), wk.float(), rtol=2 ** -6, atol=2 ** -6)
+    dist.barrier()
+    dist.destroy_process_group()

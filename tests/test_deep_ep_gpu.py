@@ -91,3 +91,10 @@ def test_missing_peer_raises_instead_of_hanging():
 ])
 def test_long_sequence_rounds_match_single_shot(cfg):
     _spawn(mp_workers.gpu_long_seq_worker, cfg[0], cfg)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_split_qkv_tp_rmsnorm_rope_all_reduces_the_variance_across_ranks(world):
+    """norm/split_qkv_tp_rmsnorm_rope.py with tp_world > 1: `world` processes hold the column shards of one row batch; the wrapper's
+    dist.all_reduce between its two launches must make every shard normalise with the GLOBAL mean of squares."""
+    _spawn(mp_workers.gpu_tp_rmsnorm_worker, world, (9, 512, 128, 64))
