@@ -169,6 +169,12 @@ int mi_fused_split_qk_norm(const void *x, long long rows, int q_lora_rank, int k
 /* GPT-OSS SwiGLU (activation/swiglu_oai.py:53-83): x [rows, dim] with gate / up interleaved (even / odd columns) -> out [rows, dim / 2] =
  * (min(max(up, -limit), limit) + 1) * g * sigmoid(g * alpha), g = min(gate, limit); dim / 2 a multiple of 8 (4 for fp32). */
 int mi_swiglu_oai(const void *x, long long rows, int dim, float alpha, float limit, int dtype, void *out, void *stream);
+/* GPT-OSS SwiGLU on [gate | up] halves with optional per-row INT8 (activation/swiglu_oai_quant.py:115-211): x [rows, cols]; group_list NULL
+ * (all rows) or num_groups counts / cumulative counts (type 1 / 0) bounding the rows that are computed; need_quant: out int8 [rows, cols / 2] +
+ * scale fp32 [rows] (= max|out| / 127; q = trunc(dtype(out / scale)) saturated -- see rownorm.hip for the rounding assumption), else out in
+ * x's dtype. */
+int mi_swiglu_oai_quant(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type, long long rows, int cols,
+                        float alpha, float limit, int need_quant, int dtype, void *out, float *scale, void *stream);
 int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel, long long shift_numel,
                    float scale_constant, int dtype, int ss_dtype, void *out, void *stream);
 

@@ -445,6 +445,29 @@ def swiglu_oai(x, dim, alpha, limit):
     return ((up + 1.0) * (gate * (1.0 / (1.0 + torch.exp(-gate * alpha))))).to(x.dtype)
 
 
+def swiglu_oai_quant(x, alpha, limit, need_quant=True, total_rows=None):
+    """Restates _swiglu_oai_quant_kernel (activation/swiglu_oai_quant.py:39-112) in fp32: gate = min(x1, limit), up = clamp(x2, +-limit),
+    out = gate * sigmoid(gate * alpha) * (up + 1) (:83-85); scale = max|out| / 127 (:89); q = saturate(trunc(dtype(out / scale))) (:96-97 --
+    the cast's rounding is the backend's in the reference; truncation = the Triton language's float -> int conversion: stated assumption,
+    PARITY UNPINNED, no reference test exists).  Rows >= total_rows are returned as zeros (uninitialised in the kernel)."""
+    x2 = x.reshape(-1, x.shape[-1]).float()
+    half = x2.shape[-1] // 2
+    gate, up = x2[:, :half].clamp(max=limit), x2[:, half:].clamp(min=-limit, max=limit)
+    out = (gate * (1.0 / (1.0 + torch.exp(-gate * alpha)))) * (up + 1.0)
+    n = x2.shape[0] if total_rows is None else total_rows
+    if not need_quant:
+        o = out.to(x.dtype)
+        o[n:] = 0
+        return o.reshape(*x.shape[:-1], half), None
+    scale = out.abs().amax(dim=-1) / 127.0
+    q = (out / scale[:, None]).to(x.dtype).float()
+    q = torch.nan_to_num(q, nan=0.0).trunc().clamp(-128, 127).to(torch.int8)
+    q[n:] = 0
+    scale = scale.clone()
+    scale[n:] = 0
+    return q.reshape(*x.shape[:-1], half), scale
+
+
 def fused_scale_shift(x, scale, shift, scale_constant=1.0):
     """tests/python/sgl_kernel_npu/test_scale_shift.py:6-11: x * (1 + scale) + shift; with one shift value per element the kernel uses
     scale_constant instead of 1 (norm/scale_shift.py:112 against :60).  fp32, returned in x's dtype."""

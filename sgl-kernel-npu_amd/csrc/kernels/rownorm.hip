@@ -8,6 +8,7 @@
 //   split_qkv_tp_rmsnorm_rope      python/sgl_kernel_npu/sgl_kernel_npu/norm/split_qkv_tp_rmsnorm_rope.py:7-288
 //   fused_split_qk_norm            python/sgl_kernel_npu/sgl_kernel_npu/norm/fused_split_qk_norm.py:6-134
 //   swiglu_oai                     python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai.py:7-104
+//   swiglu_oai_quant               python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai_quant.py:39-211
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
 // on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
 // MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
@@ -280,6 +281,59 @@ __global__ __launch_bounds__(256) void swiglu_oai_kernel(const typename Elem<DT>
     }
 }
 
+// GPT-OSS SwiGLU on CONCATENATED [gate | up] halves with optional per-row INT8 (activation/swiglu_oai_quant.py:39-112): gate = min(x1, limit),
+// up = clamp(x2, +-limit), out = gate * sigmoid(gate * alpha) * (up + 1) (:83-85); quantised: scale = max|out| / 127 (:89), q = int8 of
+// (out / scale) rounded to the I/O dtype first (:96) and then converted with saturation (:97).  The reference leaves that conversion to the
+// backend's cast; here it TRUNCATES toward zero, the float -> int conversion of the Triton language the reference kernel is written in
+// (stated assumption: the reference holds no test or vector for this function).  Rows beyond the group list's total are left untouched.
+// One wave per row; the row's outputs stay in registers (half_cols <= 8192) or are recomputed in the second pass.
+template <int DT, bool I64>
+__global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename Elem<DT>::T *__restrict__ x, const void *__restrict__ group_list, int num_groups,
+                                                               int group_list_type, long long rows, int half, float alpha, float limit, int need_quant,
+                                                               void *__restrict__ out, float *__restrict__ scale)
+{
+    typedef typename Elem<DT>::T T;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long total = rows;
+    if (group_list) {                                     // 0 = cumulative counts (last entry = total, :63-64), 1 = counts (:66-71)
+        if (group_list_type == 0) {
+            total = I64 ? ((const long long *)group_list)[num_groups - 1] : (long long)((const int *)group_list)[num_groups - 1];
+        } else {
+            long long sacc = 0;
+            for (int i = lane; i < num_groups; i += 64) sacc += I64 ? ((const long long *)group_list)[i] : (long long)((const int *)group_list)[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+            total = sacc;
+        }
+    }
+    if (row >= rows || row >= total) return;
+    const T *xr = x + row * 2 * (long long)half;
+    auto value = [&](int j) -> float {
+        float g = Elem<DT>::ld(xr[j]), u = Elem<DT>::ld(xr[half + j]);
+        g = fminf(g, limit);
+        u = fminf(fmaxf(u, -limit), limit);
+        return (g * (1.0f / (1.0f + __expf(-g * alpha)))) * (u + 1.0f);
+    };
+    if (!need_quant) {
+        T *o = (T *)out + row * (long long)half;
+        for (int j = lane; j < half; j += 64) o[j] = Elem<DT>::st(value(j));
+        return;
+    }
+    float amax = 0.f;
+    for (int j = lane; j < half; j += 64) amax = fmaxf(amax, fabsf(value(j)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    const float sc = amax / 127.0f;
+    if (lane == 0) scale[row] = sc;
+    int8_t *o = (int8_t *)out + row * (long long)half;
+    for (int j = lane; j < half; j += 64) {
+        float r = Elem<DT>::ld(Elem<DT>::st(value(j) / sc));     // rounded to the I/O dtype first (:96); 0 / 0 = NaN -> 0 below
+        r = r != r ? 0.f : truncf(r);
+        o[j] = (int8_t)(int)fminf(fmaxf(r, -128.f), 127.f);
+    }
+}
+
 // out = x * (c + scale) + shift (norm/scale_shift.py:9-183): scale one value or one per column, shift one value, one per column or one per
 // element.  With a per-element shift c = scale_constant (fused_scale_shift_kernel_2, :112), otherwise c = 1.0 whatever scale_constant says
 // (fused_scale_shift_kernel, :60) -- as the reference.  DT = type of x and out, ST = type of scale and shift; fp32 arithmetic.
@@ -454,6 +508,23 @@ extern "C" int mi_swiglu_oai(const void *x, long long rows, int dim, float alpha
     if (dtype == MI_DTYPE_BF16) swiglu_oai_kernel<MI_DTYPE_BF16><<<(unsigned)blocks, 256, 0, st>>>((const uint16_t *)x, n_out, alpha, limit, (uint16_t *)out);
     else if (dtype == MI_DTYPE_F16) swiglu_oai_kernel<MI_DTYPE_F16><<<(unsigned)blocks, 256, 0, st>>>((const uint16_t *)x, n_out, alpha, limit, (uint16_t *)out);
     else swiglu_oai_kernel<MI_DTYPE_F32><<<(unsigned)blocks, 256, 0, st>>>((const float *)x, n_out, alpha, limit, (float *)out);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_swiglu_oai_quant(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type, long long rows,
+                                   int cols, float alpha, float limit, int need_quant, int dtype, void *out, float *scale, void *stream)
+{
+    if (rows < 0 || cols <= 0 || cols % 2 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || (group_list && (num_groups <= 0 || (group_list_type != 0 && group_list_type != 1))))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!x || !out || (need_quant && !scale)) return MI_SGL_EINVAL;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+#define MI_SOQ(DT, I64) swiglu_oai_quant_kernel<DT, I64><<<blocks, 256, 0, st>>>((const uint16_t *)x, group_list, num_groups, group_list_type, rows, cols / 2, \
+                                                                             alpha, limit, need_quant, out, scale)
+    if (dtype == MI_DTYPE_BF16) { if (group_list_is_i64) MI_SOQ(MI_DTYPE_BF16, true); else MI_SOQ(MI_DTYPE_BF16, false); }
+    else { if (group_list_is_i64) MI_SOQ(MI_DTYPE_F16, true); else MI_SOQ(MI_DTYPE_F16, false); }
+#undef MI_SOQ
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 

@@ -366,6 +366,30 @@ at::Tensor swiglu_oai(const at::Tensor &hidden_states, int64_t dim, double gemm1
     return out;
 }
 
+// activation/swiglu_oai_quant.py:115-211
+std::tuple<at::Tensor, at::Tensor> swiglu_oai_quant(const at::Tensor &x, double alpha, double limit, bool need_quant, const std::optional<at::Tensor> &group_list,
+                                                    std::optional<int64_t> group_list_type)
+{
+    TORCH_CHECK(x.dim() >= 1 && x.is_contiguous() && x.size(-1) % 2 == 0, "swiglu_oai_quant: x must be contiguous [..., 2d]");
+    const int64_t h = x.size(-1), rows = h ? x.numel() / h : 0;
+    if (group_list.has_value()) {
+        TORCH_CHECK(group_list_type.has_value() && (*group_list_type == 0 || *group_list_type == 1), "group_list_type must be 0 or 1, got ",
+                    group_list_type.value_or(-1));                                              // reference :151-152
+        TORCH_CHECK(group_list->scalar_type() == at::kInt || group_list->scalar_type() == at::kLong, "group_list dtype must be torch.int32 or torch.int64");
+        TORCH_CHECK(group_list->is_contiguous() && group_list->dim() == 1, "group_list must be a contiguous vector");
+    }
+    std::vector<int64_t> oshape(x.sizes().begin(), x.sizes().end());
+    oshape.back() = h / 2;
+    at::Tensor out = at::empty(oshape, x.options().dtype(need_quant ? at::kChar : x.scalar_type()));
+    at::Tensor scale = at::empty({rows}, x.options().dtype(at::kFloat));
+    const int rc = mi_swiglu_oai_quant(x.data_ptr(), group_list.has_value() ? group_list->data_ptr() : nullptr,
+                                       group_list.has_value() && group_list->scalar_type() == at::kLong, group_list.has_value() ? (int)group_list->numel() : 0,
+                                       (int)group_list_type.value_or(0), rows, (int)h, (float)alpha, (float)limit, need_quant, dtype_code(x), out.data_ptr(),
+                                       scale.data_ptr<float>(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_swiglu_oai_quant failed with code ", rc);
+    return {out, scale};
+}
+
 // norm/fused_split_qk_norm.py:93-134 (weights / biases of the two layer norms passed as tensors)
 std::tuple<at::Tensor, at::Tensor, at::Tensor> fused_split_qk_norm(const at::Tensor &x, const at::Tensor &q_weight, const std::optional<at::Tensor> &q_bias,
                                                                    const at::Tensor &k_weight, const std::optional<at::Tensor> &k_bias, int64_t q_lora_rank,
@@ -681,6 +705,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
           "bool cast_norm_to_bf16) -> (Tensor, Tensor, Tensor)");
     m.def("attention_sinks(Tensor query, Tensor k_cache, Tensor v_cache, Tensor sinks, Tensor block_tables, Tensor kv_lens, float scale, "
           "int sliding_window_size, int q_head_num, int k_head_num, Tensor? bt_rows=None) -> Tensor");
+    m.def("swiglu_oai_quant(Tensor x, float alpha, float limit, bool need_quant=True, Tensor? group_list=None, int? group_list_type=None) -> (Tensor, Tensor)");
     m.def("swiglu_oai(Tensor hidden_states, int dim, float gemm1_alpha, float gemm1_clamp_limit) -> Tensor");
     m.def("fused_split_qk_norm(Tensor x, Tensor q_weight, Tensor? q_bias, Tensor k_weight, Tensor? k_bias, int q_lora_rank, int kv_lora_rank, "
           "int qk_rope_dim, float eps=1e-6) -> (Tensor, Tensor, Tensor)");
@@ -709,6 +734,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("split_qkv_rmsnorm_mrope", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_mrope));
     m.impl("split_qkv_rmsnorm_rope_pos_cache_half", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope_pos_cache_half));
     m.impl("attention_sinks", TORCH_FN(sglang::npu_kernel::attention_sinks));
+    m.impl("swiglu_oai_quant", TORCH_FN(sglang::npu_kernel::swiglu_oai_quant));
     m.impl("swiglu_oai", TORCH_FN(sglang::npu_kernel::swiglu_oai));
     m.impl("fused_split_qk_norm", TORCH_FN(sglang::npu_kernel::fused_split_qk_norm));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));

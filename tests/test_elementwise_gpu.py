@@ -364,6 +364,39 @@ def test_swiglu_oai(rows, dim, dt):
     assert torch.allclose(got.cpu().float(), native.float(), rtol=6 * ulp + 1e-5, atol=6 * ulp)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,cols,mode", [(300, 5760, "dense"), (64, 128, "dense"), (257, 2880 * 2, "counts"), (100, 512, "cumsum"), (9, 6, "noquant")])
+def test_swiglu_oai_quant(rows, cols, mode, dt):
+    """activation/swiglu_oai_quant.py: dense and grouped forms.  fp32 on both sides but exp / reciprocal differ in the last bit, and the value is
+    rounded to the I/O dtype before the truncating cast, so a step may move at a rounding boundary: |dq| <= 1 on < 2 % of the elements (the bar
+    the reference sets for its sibling swiglu_quant, test_swiglu_quant.py:45-54), scales to 1e-5, and the dequantised row within one step."""
+    from sgl_kernel_npu.activation.swiglu_oai_quant import swiglu_oai_quant
+    torch.manual_seed(rows + cols)
+    x = (torch.randn(rows, cols) * 3).to(dt)
+    alpha, limit = 1.702, 7.0
+    gl, glt, total = None, None, rows
+    if mode == "counts":
+        gl, glt = torch.tensor([100, 0, 57, 60], dtype=torch.int64), 1
+        total = 217
+    elif mode == "cumsum":
+        gl, glt = torch.tensor([10, 10, 64, 90], dtype=torch.int32), 0
+        total = 90
+    need_quant = mode != "noquant"
+    got, gs = swiglu_oai_quant(x.cuda(), alpha, limit, need_quant, None if gl is None else gl.cuda(), glt)
+    want, ws = OK.swiglu_oai_quant(x, alpha, limit, need_quant, total)
+    assert got.shape == (rows, cols // 2) and gs.shape == (rows,)
+    if not need_quant:
+        assert got.dtype == dt
+        assert torch.allclose(got.cpu().float(), want.float(), rtol=2 ** -7 if dt == torch.bfloat16 else 2 ** -10, atol=1e-5)
+        return
+    assert got.dtype == torch.int8
+    assert torch.allclose(gs.cpu()[:total], ws[:total], rtol=1e-5)
+    d = (got.cpu()[:total].int() - want[:total].int()).abs()
+    assert d.max() <= 1 and (d != 0).float().mean() < 2e-2
+    with pytest.raises(ValueError):
+        swiglu_oai_quant(x.cuda(), alpha, limit, True, torch.tensor([1, 2]).cuda(), 3)
+
+
 def test_split_qkv_rmsnorm_rope_pos_cache_half_replays_in_a_captured_graph():
     """The reference test replays the op in a captured device graph with new inputs in the same buffers
     (test_split_qkv_rmsnorm_rope_pos_cache_half_npu.py:213-260): positions are clamped inside the kernel, nothing synchronises."""

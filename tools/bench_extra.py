@@ -105,6 +105,10 @@ def main():
     xb = torch.randn((1, 16384, 7168), generator=g, device="cuda").to(torch.bfloat16)
     t = ev_time(lambda: fused_rmsnorm_without_weight(xb, 1e-6))
     out["rmsnorm_without_weight_16384x7168_bf16"] = dict(t, GBps=16384 * 7168 * 4 / t["p50_us"] / 1e3)
+    from sgl_kernel_npu.activation.swiglu_oai_quant import swiglu_oai_quant
+    xo = torch.randn((16384, 5760), generator=g, device="cuda").to(torch.bfloat16)      # GPT-OSS expert intermediate 2880
+    t = ev_time(lambda: swiglu_oai_quant(xo, 1.702, 7.0))
+    out["swiglu_oai_quant_16384x5760_bf16"] = dict(t, GBps=16384 * (5760 * 2 + 2880 + 4) / t["p50_us"] / 1e3)
     from sgl_kernel_npu.norm.split_qkv_tp_rmsnorm_rope import split_qkv_tp_rmsnorm_rope
     from sgl_kernel_npu.norm.split_qkv_rmsnorm_mrope import triton_split_qkv_rmsnorm_mrope
     from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope_pos_cache_half_npu import split_qkv_rmsnorm_rope_pos_cache_half_npu
