@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void swiglu_oai_kernel(const typename Elem<DT>
 // (out / scale) rounded to the I/O dtype first (:96) and then converted with saturation (:97).  The reference leaves that conversion to the
 // backend's cast; here it TRUNCATES toward zero, the float -> int conversion of the Triton language the reference kernel is written in
 // (stated assumption: the reference holds no test or vector for this function).  Rows beyond the group list's total are left untouched.
-// One wave per row; the row's outputs stay in registers (half_cols <= 8192) or are recomputed in the second pass.
+// One wave per row, 16-byte loads; rows of up to 4096 outputs stay in registers between the maximum and the conversion, longer ones are
+// recomputed from a second read.
 template <int DT, bool I64>
 __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename Elem<DT>::T *__restrict__ x, const void *__restrict__ group_list, int num_groups,
                                                                int group_list_type, long long rows, int half, float alpha, float limit, int need_quant,
@@ -309,28 +310,94 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     }
     if (row >= rows || row >= total) return;
     const T *xr = x + row * 2 * (long long)half;
-    auto value = [&](int j) -> float {
-        float g = Elem<DT>::ld(xr[j]), u = Elem<DT>::ld(xr[half + j]);
+    auto act = [&](float g, float u) -> float {
         g = fminf(g, limit);
         u = fminf(fmaxf(u, -limit), limit);
         return (g * (1.0f / (1.0f + __expf(-g * alpha)))) * (u + 1.0f);
     };
+    auto value = [&](int j) -> float { return act(Elem<DT>::ld(xr[j]), Elem<DT>::ld(xr[half + j])); };
+    // rounded to the I/O dtype first (:96), then truncated and saturated (:97); 0 / 0 (an all-zero row) -> 0
+    auto quant = [&](float v, float sc) -> int {
+        float r = Elem<DT>::ld(Elem<DT>::st(v / sc));
+        r = r != r ? 0.f : truncf(r);
+        return (int)fminf(fmaxf(r, -128.f), 127.f);
+    };
+    constexpr int N = Elem<DT>::kPer16;
+    const bool vec = (half % N) == 0;                      // both halves of every row then start 16-byte aligned
     if (!need_quant) {
         T *o = (T *)out + row * (long long)half;
-        for (int j = lane; j < half; j += 64) o[j] = Elem<DT>::st(value(j));
+        if (vec) {
+            for (int j = lane * N; j < half; j += 64 * N) {
+                float g[N], u[N];
+                load16<DT>(xr + j, g);
+                load16<DT>(xr + half + j, u);
+#pragma unroll
+                for (int e = 0; e < N; ++e) g[e] = act(g[e], u[e]);
+                store16<DT>(o + j, g);
+            }
+        } else {
+            for (int j = lane; j < half; j += 64) o[j] = Elem<DT>::st(value(j));
+        }
         return;
     }
     float amax = 0.f;
-    for (int j = lane; j < half; j += 64) amax = fmaxf(amax, fabsf(value(j)));
+    constexpr int kChunks = 8;                             // rows of up to 4096 outputs stay in registers between the maximum and the conversion
+    const bool in_regs = vec && half <= 64 * kChunks * N;
+    float keep[kChunks][N];
+    if (in_regs) {
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int j = (c * 64 + lane) * N;
+            if (j < half) {
+                float u[N];
+                load16<DT>(xr + j, keep[c]);
+                load16<DT>(xr + half + j, u);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    keep[c][e] = act(keep[c][e], u[e]);
+                    amax = fmaxf(amax, fabsf(keep[c][e]));
+                }
+            }
+        }
+    } else if (vec) {
+        for (int j = lane * N; j < half; j += 64 * N) {
+            float g[N], u[N];
+            load16<DT>(xr + j, g);
+            load16<DT>(xr + half + j, u);
+#pragma unroll
+            for (int e = 0; e < N; ++e) amax = fmaxf(amax, fabsf(act(g[e], u[e])));
+        }
+    } else {
+        for (int j = lane; j < half; j += 64) amax = fmaxf(amax, fabsf(value(j)));
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     const float sc = amax / 127.0f;
     if (lane == 0) scale[row] = sc;
     int8_t *o = (int8_t *)out + row * (long long)half;
-    for (int j = lane; j < half; j += 64) {
-        float r = Elem<DT>::ld(Elem<DT>::st(value(j) / sc));     // rounded to the I/O dtype first (:96); 0 / 0 = NaN -> 0 below
-        r = r != r ? 0.f : truncf(r);
-        o[j] = (int8_t)(int)fminf(fmaxf(r, -128.f), 127.f);
+    if (in_regs) {
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int j = (c * 64 + lane) * N;
+            if (j < half) {
+                uint32_t w[2] = {0u, 0u};
+#pragma unroll
+                for (int e = 0; e < N; ++e) w[e >> 2] |= (uint32_t)(quant(keep[c][e], sc) & 0xFF) << (8 * (e & 3));
+                *(uint2 *)(o + j) = uint2{w[0], w[1]};
+            }
+        }
+    } else if (vec) {                                      // second pass over the row (out of L2)
+        for (int j = lane * N; j < half; j += 64 * N) {
+            float g[N], u[N];
+            load16<DT>(xr + j, g);
+            load16<DT>(xr + half + j, u);
+            uint32_t w[2] = {0u, 0u};
+#pragma unroll
+            for (int e = 0; e < N; ++e) w[e >> 2] |= (uint32_t)(quant(act(g[e], u[e]), sc) & 0xFF) << (8 * (e & 3));
+            *(uint2 *)(o + j) = uint2{w[0], w[1]};
+        }
+    } else {
+        for (int j = lane; j < half; j += 64) o[j] = (int8_t)quant(value(j), sc);
     }
 }
 

@@ -365,7 +365,8 @@ def test_swiglu_oai(rows, dim, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("rows,cols,mode", [(300, 5760, "dense"), (64, 128, "dense"), (257, 2880 * 2, "counts"), (100, 512, "cumsum"), (9, 6, "noquant")])
+@pytest.mark.parametrize("rows,cols,mode", [(300, 5760, "dense"), (64, 128, "dense"), (257, 2880 * 2, "counts"), (100, 512, "cumsum"), (9, 6, "noquant"), (9, 6, "dense"), (12, 16384, "dense"),
+                                            (12, 16384, "noquant")])
 def test_swiglu_oai_quant(rows, cols, mode, dt):
     """activation/swiglu_oai_quant.py: dense and grouped forms.  fp32 on both sides but exp / reciprocal differ in the last bit, and the value is
     rounded to the I/O dtype before the truncating cast, so a step may move at a rounding boundary: |dq| <= 1 on < 2 % of the elements (the bar
