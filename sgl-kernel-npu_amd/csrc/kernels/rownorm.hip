@@ -208,7 +208,7 @@ int launch_rows(const void *x, long long rows, int cols, float eps, const void *
     if (rows < 0 || cols <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16 && dtype != MI_DTYPE_F32)) return MI_SGL_EINVAL;
     if (rows == 0) return MI_SGL_OK;
     if (!x || !out || (OP == kOpRsqrtMul && (!variance || !weight))) return MI_SGL_EINVAL;
-    if (rows > (1ll << 33)) return MI_SGL_EINVAL;
+    if (rows > (1ll << 32)) return MI_SGL_EINVAL;        // four rows per workgroup, grid.x < 2^31
     hipStream_t st = (hipStream_t)stream;
     const unsigned blocks = (unsigned)((rows + 3) / 4);
 #define MI_ROW(DT) row_kernel<OP, DT><<<blocks, 256, 0, st>>>((const typename Elem<DT>::T *)x, rows, cols, eps, (const typename Elem<DT>::T *)variance, \
@@ -584,7 +584,7 @@ extern "C" int mi_swiglu_oai_quant(const void *x, const void *group_list, int gr
     if (rows < 0 || cols <= 0 || cols % 2 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || (group_list && (num_groups <= 0 || (group_list_type != 0 && group_list_type != 1))))
         return MI_SGL_EINVAL;
     if (rows == 0) return MI_SGL_OK;
-    if (!x || !out || (need_quant && !scale)) return MI_SGL_EINVAL;
+    if (!x || !out || (need_quant && !scale) || rows > (1ll << 32)) return MI_SGL_EINVAL;
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
 #define MI_SOQ(DT, I64) swiglu_oai_quant_kernel<DT, I64><<<blocks, 256, 0, st>>>((const uint16_t *)x, group_list, num_groups, group_list_type, rows, cols / 2, \
@@ -668,7 +668,7 @@ extern "C" int mi_scale_shift(const void *x, const void *scale, const void *shif
 
 extern "C" int mi_l1_norm(const void *x, long long rows, int cols, int dtype, float *out, void *stream)
 {
-    if (cols > 0 && cols <= 32 && rows > 0 && x && out && (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16 || dtype == MI_DTYPE_F32)) {
+    if (cols > 0 && cols <= 32 && rows > 0 && rows <= (1ll << 32) && x && out && (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16 || dtype == MI_DTYPE_F32)) {
         const unsigned blocks = (unsigned)((rows + 255) / 256);
         hipStream_t st = (hipStream_t)stream;
         if (dtype == MI_DTYPE_BF16) l1_small_kernel<MI_DTYPE_BF16><<<blocks, 256, 0, st>>>((const uint16_t *)x, rows, cols, out);

@@ -10,6 +10,7 @@
 
 #include <ATen/ATen.h>
 #include <c10/util/string_view.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -41,6 +42,7 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
                 const at::Tensor &kv_seq_lens, double sm_scale, int64_t page_size, const at::Tensor &block_table,
                 int64_t num_splits)
 {
+    const c10::DeviceGuard device_guard(q.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(q.dim() == 3 && k_nope_buffer.dim() == 4 && k_rope_buffer.dim() == 4 && att_out.dim() == 3 && block_table.dim() == 2,
                 "decode_mla: bad ranks");
     TORCH_CHECK(k_nope_buffer.size(3) == 512 && k_rope_buffer.size(3) == 64 && q.size(2) == 576 && att_out.size(2) == 512,
@@ -76,6 +78,7 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
 void decode_gqa(const at::Tensor &q, const at::Tensor &k_buffer, const at::Tensor &v_buffer, at::Tensor &att_out,
                 const at::Tensor &kv_seq_lens, double sm_scale, int64_t page_size, const at::Tensor &block_table, int64_t num_splits)
 {
+    const c10::DeviceGuard device_guard(q.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(q.dim() == 3 && k_buffer.dim() == 4 && v_buffer.dim() == 4 && att_out.dim() == 3 && block_table.dim() == 2,
                 "decode_gqa: bad ranks");
     TORCH_CHECK(q.stride(2) == 1 && k_buffer.stride(3) == 1 && v_buffer.stride(3) == 1 && att_out.stride(2) == 1,
@@ -127,6 +130,7 @@ at::Tensor attention_sinks(const at::Tensor &query, const at::Tensor &k_cache, c
                            const at::Tensor &block_tables, const at::Tensor &kv_lens, double scale, int64_t sliding_window_size, int64_t q_head_num,
                            int64_t k_head_num, const std::optional<at::Tensor> &bt_rows)
 {
+    const c10::DeviceGuard device_guard(query.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(query.dim() == 2 && query.is_contiguous() && k_cache.dim() == 4 && v_cache.dim() == 4 && block_tables.dim() == 2,
                 "attention_sinks: query [rows, Hq * D], caches [blocks, page, Hkv, D], block_tables [seqs, max_blocks]");
     TORCH_CHECK(k_cache.stride(3) == 1 && v_cache.stride(3) == 1 && block_tables.stride(1) == 1, "attention_sinks: innermost dimensions must be contiguous");
@@ -160,6 +164,7 @@ at::Tensor attention_sinks(const at::Tensor &query, const at::Tensor &k_cache, c
 std::tuple<at::Tensor, at::Tensor> swiglu_quant(const at::Tensor &x, const at::Tensor &group_list, int64_t group_list_type,
                                                 bool need_quant, bool do_limit, double limit)
 {
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(group_list_type == 0 || group_list_type == 1, "group_list_type must be 0 or 1, but got ", group_list_type);
     TORCH_CHECK(x.dim() == 2 && x.is_contiguous(), "swiglu_quant: x must be a contiguous [s, h] tensor");
     TORCH_CHECK(group_list.scalar_type() == at::kInt || group_list.scalar_type() == at::kLong,
@@ -182,6 +187,7 @@ std::tuple<at::Tensor, at::Tensor> add_rmsnorm_bias(const at::Tensor &input, con
                                                     double eps, const std::optional<at::Tensor> &quant_scale,
                                                     const std::optional<at::Tensor> &quant_offset, bool gemma)
 {
+    const c10::DeviceGuard device_guard(input.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(input.dim() == 2 && input.stride(1) == 1, "add_rmsnorm_bias: input must be [batch, hidden] with contiguous rows");
     const int64_t B = input.size(0), H = input.size(1);
     TORCH_CHECK(norm_weight.numel() == H && norm_weight.is_contiguous() && norm_weight.scalar_type() == input.scalar_type(),
@@ -214,6 +220,7 @@ std::tuple<at::Tensor, at::Tensor> add_rmsnorm_bias(const at::Tensor &input, con
 std::tuple<at::Tensor, at::Tensor> fused_rope_qk_mqa(const at::Tensor &query, const at::Tensor &key, const at::Tensor &cos_sin,
                                                      int64_t rotary_dim, bool is_neox_style)
 {
+    const c10::DeviceGuard device_guard(query.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(query.dim() == 3 && key.dim() == 3 && cos_sin.dim() == 2, "fused_rope_qk_mqa: query [T,Hq,D], key [T,Hk,D], cos_sin [T,R]");
     TORCH_CHECK(query.size(0) == key.size(0) && query.size(2) == key.size(2) && cos_sin.size(0) >= query.size(0) &&
                     cos_sin.size(1) >= rotary_dim, "fused_rope_qk_mqa: shape mismatch");
@@ -235,6 +242,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
     const std::optional<at::Tensor> &k_weight, const std::optional<at::Tensor> &q_bias, const std::optional<at::Tensor> &k_bias,
     bool is_neox_style)
 {
+    const c10::DeviceGuard device_guard(input.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(input.dim() == 2 && input.is_contiguous(), "split_qkv_rmsnorm_rope: input must be contiguous [batch, q+2kv]");
     TORCH_CHECK((head_dim & (head_dim - 1)) == 0, "head_dim must be a power of two");        // reference :390-391
     TORCH_CHECK(q_hidden_size % kv_hidden_size == 0, "q_hidden_size % kv_hidden_size != 0");   // reference :392
@@ -260,6 +268,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope(
 // norm/l1_norm.py:29-38: fp32 [batch, hidden] = input / sum(input, -1)
 at::Tensor l1_norm(const at::Tensor &input)
 {
+    const c10::DeviceGuard device_guard(input.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(input.dim() == 2 && input.is_contiguous(), "l1_norm: input must be contiguous [batch, hidden]");
     at::Tensor out = at::empty(input.sizes(), input.options().dtype(at::kFloat));
     const int rc = mi_l1_norm(input.data_ptr(), input.size(0), (int)input.size(1), dtype_code3(input), out.data_ptr<float>(), cur_stream());
@@ -270,6 +279,7 @@ at::Tensor l1_norm(const at::Tensor &input)
 // norm/rmsnorm_without_weight.py:59-76: x [B, L, C] -> x * rsqrt(mean(x^2, -1) + eps), same dtype
 at::Tensor rmsnorm_without_weight(const at::Tensor &x, double eps)
 {
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(x.dim() >= 1 && x.is_contiguous(), "fused_rmsnorm_without_weight: x must be contiguous");
     at::Tensor out = at::empty_like(x);
     const int64_t cols = x.size(-1);
@@ -281,6 +291,7 @@ at::Tensor rmsnorm_without_weight(const at::Tensor &x, double eps)
 // norm/rmsnorm_split.py:150-161: x [B, L, C] -> mean(x^2, -1) as [B, L, 1] in x's dtype
 at::Tensor fused_variance(const at::Tensor &x)
 {
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(x.dim() == 3 && x.is_contiguous(), "fused_variance: x must be contiguous [B, L, C]");
     at::Tensor out = at::empty({x.size(0), x.size(1), 1}, x.options());
     const int rc = mi_row_variance(x.data_ptr(), x.size(0) * x.size(1), (int)x.size(2), dtype_code3(x), out.data_ptr(), cur_stream());
@@ -291,6 +302,7 @@ at::Tensor fused_variance(const at::Tensor &x)
 // norm/rmsnorm_split.py:76-97: x [B, L, C], variance [B * L], weight [C] -> x * rsqrt(variance + eps) * weight in x's dtype
 at::Tensor fused_rsqrt_mul(const at::Tensor &x, const at::Tensor &variance, const at::Tensor &weight, double eps)
 {
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(x.dim() == 3 && x.is_contiguous(), "fused_rsqrt_mul: x must be contiguous [B, L, C]");
     const int64_t rows = x.size(0) * x.size(1), cols = x.size(2);
     TORCH_CHECK(variance.numel() == rows && variance.is_contiguous() && variance.scalar_type() == x.scalar_type(),
@@ -307,6 +319,7 @@ at::Tensor fused_rsqrt_mul(const at::Tensor &x, const at::Tensor &variance, cons
 // norm/scale_shift.py:122-183: x [B, L, C] * (c + scale) + shift
 at::Tensor fused_scale_shift(const at::Tensor &x, const at::Tensor &scale, const at::Tensor &shift, double scale_constant)
 {
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(x.dim() == 3 && x.is_contiguous(), "fused_scale_shift: x must be contiguous [B, L, C]");
     TORCH_CHECK(scale.is_contiguous() && shift.is_contiguous() && scale.scalar_type() == shift.scalar_type() &&
                     (scale.scalar_type() == x.scalar_type() || scale.scalar_type() == at::kFloat),
@@ -327,6 +340,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_mro
     int64_t num_kv_heads, int64_t head_size, double eps, at::IntArrayRef mrope_section, bool is_interleaved, std::optional<int64_t> rope_dim_opt,
     const std::optional<at::Tensor> &q_bias, const std::optional<at::Tensor> &k_bias, bool has_gate)
 {
+    const c10::DeviceGuard device_guard(qkv.device());   // launches and the current stream follow the tensor's GPU
     const int64_t q_size = num_q_heads * head_size, kv_size = num_kv_heads * head_size, gate_size = has_gate ? q_size : 0;
     const int64_t rope_dim = rope_dim_opt.value_or(head_size);
     TORCH_CHECK(qkv.dim() == 2 && qkv.is_contiguous() && qkv.size(1) == q_size + gate_size + 2 * kv_size,
@@ -356,6 +370,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_mro
 // activation/swiglu_oai.py:53-83 (swiglu_oai_triton)
 at::Tensor swiglu_oai(const at::Tensor &hidden_states, int64_t dim, double gemm1_alpha, double gemm1_clamp_limit)
 {
+    const c10::DeviceGuard device_guard(hidden_states.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(hidden_states.is_contiguous() && dim > 0 && dim % 2 == 0 && hidden_states.numel() % dim == 0,
                 "swiglu_oai: hidden_states must be contiguous with a multiple of dim elements");
     const int64_t rows = hidden_states.numel() / dim;
@@ -370,6 +385,7 @@ at::Tensor swiglu_oai(const at::Tensor &hidden_states, int64_t dim, double gemm1
 std::tuple<at::Tensor, at::Tensor> swiglu_oai_quant(const at::Tensor &x, double alpha, double limit, bool need_quant, const std::optional<at::Tensor> &group_list,
                                                     std::optional<int64_t> group_list_type)
 {
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(x.dim() >= 1 && x.is_contiguous() && x.size(-1) % 2 == 0, "swiglu_oai_quant: x must be contiguous [..., 2d]");
     const int64_t h = x.size(-1), rows = h ? x.numel() / h : 0;
     if (group_list.has_value()) {
@@ -395,6 +411,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> fused_split_qk_norm(const at::Ten
                                                                    const at::Tensor &k_weight, const std::optional<at::Tensor> &k_bias, int64_t q_lora_rank,
                                                                    int64_t kv_lora_rank, int64_t qk_rope_dim, double eps)
 {
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(x.dim() == 2 && x.is_contiguous() && x.size(1) == q_lora_rank + kv_lora_rank + qk_rope_dim,
                 "fused_split_qk_norm: input must be contiguous [B, q_lora_rank + kv_lora_rank + qk_rope_dim]");
     auto chk = [&](const at::Tensor &t, int64_t n, const char *what) {
@@ -420,6 +437,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope_pos_cache_
     int64_t head_dim, std::optional<double> eps, const std::optional<at::Tensor> &q_weight, const std::optional<at::Tensor> &k_weight,
     const std::optional<at::Tensor> &q_bias, const std::optional<at::Tensor> &k_bias, int64_t rope_dim, bool cast_norm_to_bf16)
 {
+    const c10::DeviceGuard device_guard(input.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && input.size(1) == q_hidden_size + 2 * kv_hidden_size,
                 "split_qkv_rmsnorm_rope_pos_cache_half: input must be contiguous [B, q + 2 kv]");
     const int64_t B = input.size(0);
@@ -452,6 +470,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope_pos_cache_
 // norm/split_qkv_tp_rmsnorm_rope.py:179-288, first launch: (v, qk_var [batch, 2] fp32 = mean(q^2), mean(k^2) of this rank's columns)
 std::tuple<at::Tensor, at::Tensor> split_qkv_tp_local_var(const at::Tensor &input, int64_t q_hidden_size, int64_t kv_hidden_size)
 {
+    const c10::DeviceGuard device_guard(input.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && input.size(1) == q_hidden_size + 2 * kv_hidden_size,
                 "split_qkv_tp_rmsnorm_rope: input must be contiguous [batch, q + 2 kv]");
     const int64_t B = input.size(0);
@@ -468,6 +487,7 @@ std::tuple<at::Tensor, at::Tensor> split_qkv_tp_norm_rope(const at::Tensor &inpu
                                                           int64_t q_hidden_size, int64_t kv_hidden_size, int64_t head_dim, double eps,
                                                           const at::Tensor &q_weight, const at::Tensor &k_weight, int64_t rotary_dim, double inv_tp_world)
 {
+    const c10::DeviceGuard device_guard(input.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && input.size(1) == q_hidden_size + 2 * kv_hidden_size,
                 "split_qkv_tp_rmsnorm_rope: input must be contiguous [batch, q + 2 kv]");
     const int64_t B = input.size(0);
@@ -493,6 +513,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> split_qkvgate_gemma_r
     const at::Tensor &input, const at::Tensor &sin, const at::Tensor &cos, int64_t q_hidden_size, int64_t kv_hidden_size,
     int64_t head_dim, int64_t rope_dim, double eps, const at::Tensor &q_weight, const at::Tensor &k_weight)
 {
+    const c10::DeviceGuard device_guard(input.device());   // launches and the current stream follow the tensor's GPU
     TORCH_CHECK(input.dim() == 2 && input.is_contiguous(), "split_qkvgate_gemma_rmsnorm_rope: input must be contiguous [batch, 2q+2kv]");
     TORCH_CHECK((head_dim & (head_dim - 1)) == 0, "head_dim must be a power of two");        // reference :700-701
     TORCH_CHECK(q_hidden_size % kv_hidden_size == 0, "q_hidden_size % kv_hidden_size != 0");   // reference :702
@@ -559,6 +580,7 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     std::optional<c10::string_view> cache_mode, std::optional<c10::string_view> quant_mode, at::Tensor &q_out0,
     at::Tensor &kv_cache_out0, at::Tensor &q_out1, at::Tensor &kv_cache_out1)
 {
+    const c10::DeviceGuard device_guard(hiddenState.device());   // launches and the current stream follow the tensor's GPU
     (void)gamma0, (void)beta0;
     // cache_mode (csrc/mla_preprocess/op_host/mla_preprocess.cpp:605-606,634): krope_ctkv = 1 (default), int8_nzcache = 2, nzcache = 3
     const c10::string_view cmode = cache_mode.value_or("krope_ctkv");
