@@ -373,11 +373,19 @@ __global__ __launch_bounds__(256) void bmm_rope_kernel(const uint16_t *__restric
 // the weight DMA 28.3 us, without the LDS operand reads 24.4, without the activation loads 24.4 -- it is not waiting for memory (a
 // plain stream over 128 CUs reaches 5.6 TB/s, tools/probes/stream_probe.hip); what is left is eight waves meeting at a barrier every
 // 48 MFMAs.  4 waves x 32 rows (every weight fragment feeding two MFMAs, one wave per SIMD) ran 48 us.
+// Workgroup spans (-DF_SPAN, tools/probes/time_mla_pre_tail.py): the 256 workgroups start within 0.5-1.0 us of each other and run 15.2-16.0 us
+// each; the kernel takes 21.5 us between the command processor's timestamps -- ~5 us of every launch here is ramp and drain, not work.
 // Round 3: 64-row workgroups (HALF below: 256 workgroups at 128 tokens x 128 heads) 26.6 -> 22.9 us; stamps of one wave (-DF_TIMING,
 // tools/probes/time_mla_pre_tail.py; shader clocks, 64-row / 128-row form): first chunk landed for every wave 7.7k / 7.2k -- all CUs ask
 // for their first 96 KB at once, 24 MB at HBM rate --, the other five chunks 13.0k / 14.6k, dequant + y tile + RoPE 4.9k / 6.0k,
 // phase B 9.0k / 17.2k; total 36k / 46k cycles.  Phase A does not depend on the MFMA or LDS volume per workgroup (halved by HALF, same
 // 22k cycles): after the cold start it runs at one chunk per ~2.6k cycles against 0.4k / 0.8k of MFMA issue per SIMD.
+#ifdef F_SPAN        // start / end of every workgroup on the 100 MHz clock (launch skew and spread of the workgroup durations)
+__device__ unsigned long long g_f_span[1024][2];
+#define F_SPAN_AT(i) if (tid == 0 && blockIdx.z == 0 && blockIdx.x < 1024) g_f_span[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define F_SPAN_AT(i)
+#endif
 #ifdef F_TIMING
 __device__ unsigned long long g_f_dbg[4][64];
 #define F_STAMP(i) if (tid == 0 && blockIdx.x < 4 && blockIdx.z == 0) g_f_dbg[blockIdx.x][i] = __builtin_amdgcn_s_memtime();
@@ -486,6 +494,7 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[ks]) : "v"(arow + c * kF_Chunk + ks * 64) : "memory");
     };
     F_STAMP(0)
+    F_SPAN_AT(0)
     issue_w(0, 0);
     issue_a(0, afb[0]);
     issue_w(1, 1);
@@ -668,6 +677,7 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     multiply_eighth(6);
     multiply_eighth(7);
     F_STAMP(21)
+    F_SPAN_AT(1)
 }
 
 }  // namespace mi_sgl
@@ -728,6 +738,9 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 
+#ifdef F_SPAN
+extern "C" int mi_dbg_read_f_span(unsigned long long *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_sgl::g_f_span), sizeof(unsigned long long) * 1024 * 2); }
+#endif
 #ifdef F_TIMING
 extern "C" int mi_dbg_read_f(unsigned long long *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_sgl::g_f_dbg), sizeof(unsigned long long) * 4 * 64); }
 #endif

@@ -35,3 +35,17 @@ if hasattr(L, "mi_dbg_read_f"):
         print("block", blk, "prologue->first wait", t[1] - t[0], "| per chunk [vmcnt wait (prev end -> wait done), barrier, work]:",
               [(int(t[1 + 3 * c] - (t[3 * c] if c else t[0])), int(t[2 + 3 * c] - t[1 + 3 * c]), int(t[3 + 3 * c] - t[2 + 3 * c])) for c in range(6)],
               "| A end -> phase B start", t[20] - t[18], "| phase B", t[21] - t[20], "| total", t[21] - t[0])
+
+if hasattr(L, "mi_dbg_read_f_span"):      # built with -DF_SPAN: every workgroup's start / end on the 100 MHz clock
+    import numpy as np
+    torch.cuda.synchronize(); f(); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 2048)()
+    L.mi_dbg_read_f_span(buf)
+    d = np.array(buf, dtype=np.int64).reshape(1024, 2)
+    n = int((d[:, 1] > 0).sum())
+    d = d[:n]
+    t0 = d[:, 0].min()
+    st, en = (d[:, 0] - t0) / 100.0, (d[:, 1] - t0) / 100.0
+    du = en - st
+    q = lambda a: "min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f" % (a.min(), np.percentile(a, 10), np.percentile(a, 50), np.percentile(a, 90), a.max())
+    print("workgroups", n, "| start (us after the first):", q(st), "| duration:", q(du), "| end:", q(en))
