@@ -46,10 +46,13 @@ __device__ __forceinline__ void layout_grid_barrier(uint32_t *sync, int B)
         __threadfence();
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t t0 = wall_clock64();
-        while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)B) {
-            __builtin_amdgcn_s_sleep(2);
+        // relaxed polls, ONE acquire fence after the last arrival: an acquire load invalidates the XCD's L2 on every iteration, for every
+        // workgroup of the XCD (tools/probes/ubench/launch_floor.hip: a flag hop between XCDs costs 0.4-0.7 us polled this way)
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)B) {
+            __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ull) break;            // 2 s: never hang (a lost launch leaves garbage tables, not a stuck GPU)
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // the last workgroup to LEAVE the spin re-arms both words for the next launch on this stream
         if (__hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)B - 1u) {
             __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
