@@ -534,14 +534,30 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
         guess = last_recv_rows + last_recv_rows / 4 + 256;
         dispatch_pull(ex, H, K, L, qm, guess, x.options(), expandx_out, dynamic_scales_out, expand_idx_out, st);
     }
+    // Everything the host can prepare without the row count is prepared BEFORE it waits for it: the wait ends when the notify kernel
+    // does, and from then on the host has one pull kernel (~40 us at 4096 tokens) to return, get called again and queue the combine.
+    // (Measured: 3-4 us from the end of the wait to the return, 9-11 us of Python until the combine is entered, 4-5 us until its kernel
+    // is queued -- 18 us of the 40; a 20 us busy-wait injected after the wait did not change the step time.  The 6-8 us of idle GPU in
+    // front of the reduce that a rocprofv3 kernel trace shows is the tracer's own per-call cost.)
+    // placeholders kept for handle-shape compatibility (uninitialised in the reference, deep_ep.cpp:220-222)
+    auto rank_prefix_matrix = at::empty({W, W}, i32);
+    auto channel_prefix_matrix = at::empty({W, num_channels}, i32);
+    auto recv_channel_prefix_matrix = at::empty({W, num_channels}, i32);
+    at::Tensor recv_idx_guess, recv_w_guess;           // allocated, never written (deep_ep.cpp:371-374)
+    if (guess > 0) {
+        recv_idx_guess = at::empty({guess, K}, topk_idx->options());
+        recv_w_guess = at::empty({guess, K}, topk_weights->options());
+    }
     int64_t trt;
     std::vector<int> num_recv_tokens_per_expert_list;
+    num_recv_tokens_per_expert_list.reserve((size_t)L);
+    const int token_nums_type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);     // (read per call: callers switch it)
     if (host_sync) {
         trt = wait_summary("intranode_dispatch");
         check_status("intranode_dispatch");     // a peer that timed out inside THIS call's notify surfaces now, not one call later
         real_max_bs = __atomic_load_n(summary_host + 1, __ATOMIC_RELAXED);
         // counts, or inclusive cumsum when MOE_EXPERT_TOKEN_NUMS_TYPE=0 (deep_ep.cpp:311-312,384-401)
-        const int type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
+        const int type = token_nums_type;
         EP_HOST_ASSERT(type == 1 or type == 0);
         int run = 0;
         for (int le = 0; le < L; ++le) {
@@ -563,12 +579,14 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     } else {
         dispatch_pull(ex, H, K, L, qm, rows, x.options(), expandx_out, dynamic_scales_out, expand_idx_out, st);
     }
-    std::optional<at::Tensor> recv_topk_idx = at::empty({trt, K}, topk_idx->options());       // allocated, never written
-    std::optional<at::Tensor> recv_topk_weights = at::empty({trt, K}, topk_weights->options());  // (deep_ep.cpp:371-374)
-    // placeholders kept for handle-shape compatibility (uninitialised in the reference, deep_ep.cpp:220-222)
-    auto rank_prefix_matrix = at::empty({W, W}, i32);
-    auto channel_prefix_matrix = at::empty({W, num_channels}, i32);
-    auto recv_channel_prefix_matrix = at::empty({W, num_channels}, i32);
+    std::optional<at::Tensor> recv_topk_idx, recv_topk_weights;                                // allocated, never written
+    if (guess >= trt && guess > 0) {
+        recv_topk_idx = recv_idx_guess.narrow(0, 0, trt);
+        recv_topk_weights = recv_w_guess.narrow(0, 0, trt);
+    } else {
+        recv_topk_idx = at::empty({trt, K}, topk_idx->options());
+        recv_topk_weights = at::empty({trt, K}, topk_weights->options());
+    }
     return {expandx_out, dynamic_scales_out, recv_topk_idx, recv_topk_weights, num_recv_tokens_per_expert_list,
             rank_prefix_matrix, channel_prefix_matrix, recv_channel_prefix_matrix, expand_idx_out, ex.nt.recv_count, std::nullopt};
 }
