@@ -167,7 +167,8 @@ int mi_ep_elapsed_add(int32_t *stats, int n, const uint64_t *t_start, void *stre
  * pull_offset [L*W]: row offset the pull kernel adds to src_base[src]; == recv_offset when
  * relative_pull == 0, recv_offset - send_prefix_src[my_rank*L] when relative_pull != 0 (per-source
  * contiguous staging, RCCL transport).  summary_host (may be NULL): pinned host int32[2 + L] =
- * {total_recv, max_bs, recv_tokens_per_expert...}, written with system scope so the host can poll it. */
+ * {total_recv, max_bs, recv_tokens_per_expert...}: every word is written exactly once per call with a value >= 0, at system scope, in no
+ * particular order -- a host that polls pre-sets every word it will read to -1 and waits for each. */
 int mi_ep_notify_tables(const int32_t *cnt_matrix, int num_ranks, int num_experts, int my_rank,
                         int relative_pull, int32_t *recv_count, int32_t *recv_offset,
                         int32_t *recv_tokens_per_expert, int32_t *expert_global_offset,

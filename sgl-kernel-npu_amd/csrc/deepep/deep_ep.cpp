@@ -308,6 +308,21 @@ int64_t Buffer::wait_summary(const char *where)
     }
 }
 
+// one word of the pinned summary: normally there already when the total (word 0) is, but the kernel orders nothing
+int32_t Buffer::summary_word(int i, const char *where)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+        const int32_t v = __atomic_load_n(summary_host + i, __ATOMIC_ACQUIRE);
+        if (v >= 0) return v;
+        if ((spins & 0xFFF) == 0xFFF) {
+            check_status(where);
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > 2ll * timeout_ms) throw EPException("Timeout", __FILE__, __LINE__, ep_concat(where, ": notify summary word ", i, " never arrived"));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // A1  get_dispatch_layout  (reference deep_ep.cpp:111-180)
 // ------------------------------------------------------------------------------------------------
@@ -411,7 +426,10 @@ Buffer::DispatchExchange Buffer::dispatch_exchange(const at::Tensor &x, const at
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagDispatch * kFlagGroupSlots * 8));
     ex.nt = alloc_notify_tables(W, E, L, at::dtype(at::kInt).device(x.device()));
     NotifyTables &nt = ex.nt;
-    if (want_summary) __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
+    if (want_summary) {        // every word the host will read: the kernel writes them in no particular order (mi_ep.h)
+        for (int i = 2 + L - 1; i >= 1; --i) __atomic_store_n(summary_host + i, -1, __ATOMIC_RELAXED);
+        __atomic_store_n(summary_host, -1, __ATOMIC_RELEASE);
+    }
     { ProfScope ps_(this, "dispatch_notify", st);
       MI_EP_CHECK(mi_ep_notify_exchange_tables((uint64_t *const *)notify_peers.data(), (uint64_t *const *)flag_peers.data(),
                                                lay.num_tokens_per_expert.data_ptr<int>(), T, (const uint64_t *)(window + kOffNotify), 0,
@@ -555,13 +573,13 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     if (host_sync) {
         trt = wait_summary("intranode_dispatch");
         check_status("intranode_dispatch");     // a peer that timed out inside THIS call's notify surfaces now, not one call later
-        real_max_bs = __atomic_load_n(summary_host + 1, __ATOMIC_RELAXED);
+        real_max_bs = summary_word(1, "intranode_dispatch");
         // counts, or inclusive cumsum when MOE_EXPERT_TOKEN_NUMS_TYPE=0 (deep_ep.cpp:311-312,384-401)
         const int type = token_nums_type;
         EP_HOST_ASSERT(type == 1 or type == 0);
         int run = 0;
         for (int le = 0; le < L; ++le) {
-            const int c = __atomic_load_n(summary_host + 2 + le, __ATOMIC_RELAXED);
+            const int c = summary_word(2 + le, "intranode_dispatch");
             run = (type == 0) ? run + c : c;
             num_recv_tokens_per_expert_list.push_back(run);
         }

@@ -169,6 +169,7 @@ private:
 
     void check_status(const char *where);
     int64_t wait_summary(const char *where);     // host spin on the pinned summary word written by notify_tables
+    int32_t summary_word(int i, const char *where);  // one further word of it (the kernel orders nothing among them)
     uint8_t *family_base(int family) const;
     uint64_t *epoch_ctr(int family) const;
     std::vector<void *> peer_ptrs(size_t offset) const;                 // into the control segment

@@ -173,6 +173,18 @@ __device__ void notify_tables_body(
         if (lane == 0) ego[L] = carry;
     }
     __syncthreads();
+    if (summary_host) {
+        // The host's words go out first (they cross PCIe while the tables below are stored), every word exactly once, >= 0, in NO
+        // particular order and with no fence: the host pre-sets every word it reads to -1 and waits for each.  (Per-expert counts, a
+        // barrier, a system fence and a release store of the total -- the ordered form -- kept the workgroup waiting for two PCIe
+        // write round trips: ~3 us of the 4.8 us this phase took.)
+        for (int le = tid; le < L; le += blockDim.x)
+            __hip_atomic_store(summary_host + 2 + le, ego[le + 1] - ego[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {
+            __hip_atomic_store(summary_host + 1, mbs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(summary_host + 0, ego[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     for (int i = tid; i < LW; i += blockDim.x) {
         const int le = i / W;
         srcrank_in_expert_offset[i] = sie[i];
@@ -183,17 +195,6 @@ __device__ void notify_tables_body(
     if (tid == 0) {
         total_recv_token[0] = ego[L];
         max_bs[0] = mbs[0];
-    }
-    if (summary_host) {
-        // per-expert counts first, the total last so a polling host sees a complete record
-        for (int le = tid; le < L; le += blockDim.x)
-            __hip_atomic_store(summary_host + 2 + le, ego[le + 1] - ego[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_store(summary_host + 1, mbs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
-            __hip_atomic_store(summary_host + 0, ego[L], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 }
 
@@ -238,6 +239,15 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
 #define NT_TICK()
 #endif
     NT_TICK()
+    // this thread's first granule value is requested together with the call counter below: two independent loads of words the previous
+    // kernels wrote, one round trip instead of two (the post phase took 3.2-3.8 us of the kernel's 11)
+    int32_t *sc = sm;                                     // [n] the counts as they arrive: the tables are derived from LDS, not read back
+    int32_t *sm_tables = sm + ((n + 3) & ~3);
+    uint32_t pv0 = 0;
+    if (post.sig_epoch && (int)threadIdx.x < n) {
+        const int e0 = (int)threadIdx.x % (E + 1);
+        pv0 = (e0 < E) ? (uint32_t)post.cnt[e0] : (uint32_t)post.num_tokens;
+    }
     // device-resident epoch (graph-replayable calls): this call = counter + 1, and the notify granules ping-pong by its parity
     const uint64_t ep64 = epoch_ctr ? *epoch_ctr + 1 : 0;
     const uint32_t notify_epoch = epoch_ctr ? (uint32_t)ep64 : notify_epoch_in;
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
     if (post.sig_epoch) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int d = i / (E + 1), e = i - d * (E + 1);
-            const uint32_t v = (e < E) ? (uint32_t)post.cnt[e] : (uint32_t)post.num_tokens;
+            const uint32_t v = i < (int)blockDim.x ? pv0 : ((e < E) ? (uint32_t)post.cnt[e] : (uint32_t)post.num_tokens);
             sys_store_u64_relaxed((uint64_t *)((uint8_t *)post.notify.p[d] + npoff) + (size_t)me * (E + 1) + e, ((uint64_t)notify_epoch << 32) | v);
         }
         if (threadIdx.x < W) sys_store_u64((uint64_t *)post.flags.p[threadIdx.x] + me, flag_epoch);
@@ -264,7 +274,8 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
                 break;
             }
         }
-        cnt[i] = (int32_t)(uint32_t)g;
+        cnt[i] = (int32_t)(uint32_t)g;                    // (for the kernels that follow)
+        sc[i] = (int32_t)(uint32_t)g;
     }
     if (flags && threadIdx.x < W) {
         while (sys_load_u64(flags + threadIdx.x) < flag_epoch) {
@@ -279,13 +290,12 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
         if (wait_cost_stats) atomicAdd(wait_cost_stats + threadIdx.x, (int32_t)((ticks_100mhz() - t0) / 100));
     }
     NT_TICK()
-    __threadfence();
     __syncthreads();
     NT_TICK()
     // every thread has read the counter (before the barrier above); later kernels of this call read it with add = 0
     if (epoch_bump && threadIdx.x == 0) *epoch_bump = ep64;
-    notify_tables_body(cnt, W, E, me, relative_pull, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset,
-                       srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs, pull_offset, summary_host, sm);
+    notify_tables_body(sc, W, E, me, relative_pull, recv_count, recv_offset, recv_tokens_per_expert, expert_global_offset,
+                       srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs, pull_offset, summary_host, sm_tables);
 #ifdef NOTIFY_TIMING
     NT_TICK()
     if (threadIdx.x == 0) for (int i = 0; i < ntk; ++i) ((uint64_t *)(cnt + ((n + 17) & ~1)))[i] = tk[i];
@@ -295,6 +305,18 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
 }  // namespace mi_ep
 
 using namespace mi_ep;
+
+// dynamic LDS of notify_wait_tables_kernel: the tables' scratch + the W * (E + 1) counts (84 KB at E = 2048, W = 8: above the 64 KB default)
+static size_t notify_lds_bytes(int W, int E)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)notify_wait_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    const int L = E / W;
+    return (size_t)(2 * L * W + W + L + 2 + ((W * (E + 1) + 3) & ~3)) * sizeof(int32_t);
+}
 
 static uint64_t ms_to_ticks(int ms) { return (uint64_t)(ms > 0 ? ms : 10000) * 100000ull; }
 
@@ -401,7 +423,7 @@ extern "C" int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t noti
         my_rank < 0 || my_rank >= W)
         return MI_EP_EINVAL;
     const int L = E / W;
-    const size_t lds = (size_t)(2 * L * W + W + L + 2) * sizeof(int32_t);
+    const size_t lds = notify_lds_bytes(W, E);
     NotifyPost none{};
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
         none, my_notify, notify_epoch, my_flags, flag_epoch, nullptr, nullptr, 0, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
@@ -430,7 +452,7 @@ extern "C" int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, u
     post.num_tokens = num_tokens;
     post.sig_epoch = epoch_ctr ? 1 : flag_epoch;      // non-zero = post; the value comes from the counter when it is device-resident
     const int L = E / W;
-    const size_t lds = (size_t)(2 * L * W + W + L + 2) * sizeof(int32_t);
+    const size_t lds = notify_lds_bytes(W, E);
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
         post, my_notify, notify_epoch, my_flags, flag_epoch, epoch_ctr, epoch_ctr, notify_parity_stride, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
         recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,
