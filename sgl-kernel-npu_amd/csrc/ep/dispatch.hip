@@ -848,12 +848,7 @@ __global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, co
     const int b0 = tid * per, b1 = min(LW, b0 + per);
     int32_t sum = 0;
     for (int i = b0; i < b1; ++i) sum += c[i];
-    int32_t inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int32_t n = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += n;
-    }
+    const int32_t inc = wave_incl_scan_i32(sum);
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
     int32_t run = inc - sum;

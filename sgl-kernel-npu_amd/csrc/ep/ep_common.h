@@ -126,6 +126,31 @@ __device__ __forceinline__ uint64_t sys_load_u64(const uint64_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Inclusive scan / sum / max over the 64 lanes of a wave on DPP (VALU only: row_shr inside the rows of 16, row_bcast:15 / :31 across
+// them) instead of six ds_bpermute round trips: a scan costs ~50 cycles instead of ~600 -- the small single-workgroup kernels on the
+// dispatch path (layout, notify tables, low-latency counts) are chains of such scans.  Every lane must be active.
+__device__ __forceinline__ int32_t wave_incl_scan_i32(int32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int32_t wave_sum_i32(int32_t v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63); }
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)             // v >= 0
+{
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // error reporting word (device or pinned-host memory): first writer wins is not required, any code is enough
 __device__ __forceinline__ void report_status(int32_t *status, int32_t code)
 {

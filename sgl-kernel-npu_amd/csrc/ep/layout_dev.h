@@ -171,12 +171,7 @@ __device__ __forceinline__ void layout_small_body(
             if (writer) num_tokens_per_expert[e] = run;
         }
         if (!writer) continue;                                     // workgroup-uniform
-        int32_t inc = run;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const int32_t n = __shfl_up(inc, off, kWave);
-            if (lane >= off) inc += n;
-        }
+        const int32_t inc = wave_incl_scan_i32(run);
         if (lane == kWave - 1) wave_tot[wave] = inc;
         __syncthreads();
         int32_t wbase = 0;

@@ -88,15 +88,7 @@ __global__ void notify_wait_kernel(const uint64_t *__restrict__ notify, int n, u
 // (reference notify_dispatch.h:386-407,434-450,473-482,553-577,606-615,665-669,715-721,759-780).
 // Everything the serial reference core loops over is staged in LDS first (one coalesced pass over the counts), the
 // per-source sender prefixes are wave reductions, the short dependent scans run out of LDS: ~3 us instead of ~28 us.
-__device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int32_t n = __shfl_up(v, off, 64);
-        if (lane >= off) v += n;
-    }
-    return v;
-}
+__device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int) { return wave_incl_scan_i32(v); }
 
 __device__ void notify_tables_body(
     const int32_t *__restrict__ cnt /*[W][E+1]*/, int W, int E, int me, int relative_pull,
@@ -123,15 +115,13 @@ __device__ void notify_tables_body(
         const int32_t *row = cnt + (size_t)src * (E + 1);
         int32_t s = 0;
         for (int e = lane; e < me * L; e += 64) s += row[e];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        s = wave_sum_i32(s);
         if (lane == 0) pre[src] = s;
     }
     if (wave == 0) {
         int32_t mb = 0;
         for (int src = lane; src < W; src += 64) mb = max(mb, cnt[(size_t)src * (E + 1) + E]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mb = max(mb, __shfl_xor(mb, off, 64));
+        mb = wave_max_i32(mb);
         if (lane == 0) mbs[0] = mb;
     }
     __syncthreads();
@@ -147,7 +137,7 @@ __device__ void notify_tables_body(
                 recv_offset[le * W + src] = run;
                 pull_offset[le * W + src] = relative_pull ? run - pre[src] : run;
             }
-            carry += __shfl(inc, 63, 64);
+            carry += __builtin_amdgcn_readlane(inc, 63);
         }
     }
     // per local expert: scan over sources (W <= 64 values: serial per thread, experts in parallel)
@@ -168,7 +158,7 @@ __device__ void notify_tables_body(
             const int32_t v = le < L ? ego[le] : 0;
             const int32_t inc = wave_incl_scan(v, lane);
             if (le < L) ego[le] = carry + inc - v;
-            carry += __shfl(inc, 63, 64);
+            carry += __builtin_amdgcn_readlane(inc, 63);
         }
         if (lane == 0) ego[L] = carry;
     }
