@@ -736,17 +736,6 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     const int64_t max_size = std::max<int64_t>((int64_t)T * K, num_max_tokens * 128);   // deep_ep.cpp:875
     auto dev = x.device();
     auto i32 = at::dtype(at::kInt).device(dev);
-    at::Tensor packed_recv_x, packed_recv_x_scales;
-    if (qm == MI_EP_QUANT_NONE) {
-        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(at::kBFloat16).device(dev));
-        packed_recv_x_scales = at::empty({1}, at::dtype(at::kFloat).device(dev));
-    } else {
-        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(payload_dtype(qm)).device(dev));
-        packed_recv_x_scales = at::empty({num_max_tokens}, at::dtype(at::kFloat).device(dev));
-    }
-    auto expand_idx = at::empty({max_size}, i32);
-    auto ep_recv_count = at::empty({(int64_t)L * W}, i32);
-    auto packed_recv_count = at::empty({L}, at::dtype(at::kLong).device(dev));
     const int count_type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
     hipStream_t st = cur_stream();
     uint64_t *ctr = epoch_ctr(kLLDispatch);
@@ -757,11 +746,16 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     Layout lay;
     if (fused_send && T <= 1024 && (size_t)16 * E <= 16384 && E % 2 == 0) {
         lay.T = T, lay.K = K, lay.E = E;
-        lay.num_tokens_per_expert = at::empty({E}, i32);
-        lay.num_tokens_per_rank = at::empty({W}, i32);
-        lay.is_token_in_rank = at::empty({T, W}, i32);
-        lay.send_token_idx_small = at::empty({T, K}, i32);
-        lay.send_data_offset = at::empty({E}, i32);
+        // the five layout tables carved out of ONE allocation (each at::empty costs ~1-2 us of host time in front of the first launch)
+        auto pad = [](int64_t n) { return (n + 3) / 4 * 4; };      // every table 16-byte aligned
+        at::Tensor lbuf = at::empty({2 * pad(E) + pad(W) + pad((int64_t)T * W) + pad((int64_t)T * K)}, i32);
+        int64_t off = 0;
+        auto take = [&](int64_t n) { at::Tensor t = lbuf.narrow(0, off, n); off += pad(n); return t; };
+        lay.num_tokens_per_expert = take(E);
+        lay.num_tokens_per_rank = take(W);
+        lay.is_token_in_rank = take((int64_t)T * W).view({T, W});
+        lay.send_token_idx_small = take((int64_t)T * K).view({T, K});
+        lay.send_data_offset = take(E);
         ProfScope ps_(this, "ll_dispatch_layout_send", st);
         MI_EP_CHECK(mi_ep_ll_dispatch_layout_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, T, K, H, E, W, (int)rank,
                                                   MT, qm, row_peers.data(), ctr, region_bytes, lay.num_tokens_per_rank.data_ptr<int>(),
@@ -774,6 +768,19 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
                                            lay.send_token_idx_small.data_ptr<int>(), T, K, H, E, W, (int)rank, MT, qm, row_peers.data(), ctr,
                                            region_bytes, st));
     }
+    // The outputs are allocated AFTER the first launch, which does not touch them: a lone decode-step call is host-bound until its first
+    // kernel is queued (the GPU idles while the host prepares), and five allocations are ~6 us of that.
+    at::Tensor packed_recv_x, packed_recv_x_scales;
+    if (qm == MI_EP_QUANT_NONE) {
+        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(at::kBFloat16).device(dev));
+        packed_recv_x_scales = at::empty({1}, at::dtype(at::kFloat).device(dev));
+    } else {
+        packed_recv_x = at::empty({num_max_tokens, H}, at::dtype(payload_dtype(qm)).device(dev));
+        packed_recv_x_scales = at::empty({num_max_tokens}, at::dtype(at::kFloat).device(dev));
+    }
+    auto expand_idx = at::empty({max_size}, i32);
+    auto ep_recv_count = at::empty({(int64_t)L * W}, i32);
+    auto packed_recv_count = at::empty({L}, at::dtype(at::kLong).device(dev));
     auto cnt_peers = peer_ptrs((size_t)kOffLLCounts);
     // rows the output tensors hold (and src_info / 3): the packing kernel never writes past them, whatever the counts say
     const int rows_capacity = (int)std::min<int64_t>(num_max_tokens, max_size / 3);
