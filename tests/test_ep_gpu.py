@@ -72,6 +72,7 @@ DISPATCH_CASES = [
     (8, 64, 512, 8, 64, 0.0, [0, 1, 2, 3, 8, 9]),   # skewed routing (--active-ranks style)
     (3, 50, 2048, 6, 12, 0.1, None),        # non power-of-two world
     (2, 5, 8192, 16, 32, 0.0, None),        # max hidden, max top-k
+    (8, 20, 128, 8, 2048, 0.1, None),       # the most experts: the count exchange keeps W * (E + 1) counts in LDS (84 KB, above the 64 KB default)
 ]
 
 
