@@ -175,6 +175,11 @@ int mi_swiglu_oai(const void *x, long long rows, int dim, float alpha, float lim
  * x's dtype. */
 int mi_swiglu_oai_quant(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type, long long rows, int cols,
                         float alpha, float limit, int need_quant, int dtype, void *out, float *scale, void *stream);
+/* SiTU (activation/situ.py:11-480): x [rows, cols] = [gate | up]; out = beta * tanh(gate / beta) * sigmoid(gate) * up', up' = linear_beta *
+ * tanh(up / linear_beta) (linear_beta <= 0: up' = up); group_list as in mi_swiglu_oai_quant; need_quant: int8 out + scale = max(max|out| / 127,
+ * 1e-30), q = clamp(floor(out / scale + 0.5), -128, 127); else out in x's dtype. */
+int mi_situ_and_mul(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type, long long rows, int cols,
+                    float beta, float linear_beta, int need_quant, int dtype, void *out, float *scale, void *stream);
 int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel, long long shift_numel,
                    float scale_constant, int dtype, int ss_dtype, void *out, void *stream);
 

@@ -468,6 +468,31 @@ def swiglu_oai_quant(x, alpha, limit, need_quant=True, total_rows=None):
     return q.reshape(*x.shape[:-1], half), scale
 
 
+def situ_and_mul(x, beta=4.0, linear_beta=25.0, need_quant=False, total_rows=None):
+    """Restates the SiTU kernels (activation/situ.py:58-90, :101-162, :395-427) in fp32: gate' = beta * tanh(gate / beta) * sigmoid(gate) (:61),
+    up' = linear_beta * tanh(up / linear_beta) when linear_beta is given (:62-63), out = gate' * up' (:64); quantised: scale = max(max|out| / 127,
+    1e-30) (:67), q = clamp(floor(out / scale + 0.5), -128, 127) (:78-80).  PARITY UNPINNED: the reference holds no test or vector for this file.
+    Rows >= total_rows are returned as zeros (not written by the kernel)."""
+    x2 = x.reshape(-1, x.shape[-1]).float()
+    half = x2.shape[-1] // 2
+    gate, up = x2[:, :half], x2[:, half:]
+    ga = (beta * torch.tanh(gate * (1.0 / beta))) * (1.0 / (1.0 + torch.exp(-gate)))
+    if linear_beta is not None:
+        up = linear_beta * torch.tanh(up * (1.0 / linear_beta))
+    out = ga * up
+    n = x2.shape[0] if total_rows is None else total_rows
+    if not need_quant:
+        o = out.to(x.dtype)
+        o[n:] = 0
+        return o.reshape(*x.shape[:-1], half), None
+    scale = torch.clamp(out.abs().amax(dim=-1) / 127.0, min=1e-30)
+    q = torch.floor(out / scale[:, None] + 0.5).clamp(-128, 127).to(torch.int8)
+    q[n:] = 0
+    scale = scale.clone()
+    scale[n:] = 0
+    return q.reshape(*x.shape[:-1], half), scale
+
+
 def fused_scale_shift(x, scale, shift, scale_constant=1.0):
     """tests/python/sgl_kernel_npu/test_scale_shift.py:6-11: x * (1 + scale) + shift; with one shift value per element the kernel uses
     scale_constant instead of 1 (norm/scale_shift.py:112 against :60).  fp32, returned in x's dtype."""

@@ -9,6 +9,7 @@
 //   fused_split_qk_norm            python/sgl_kernel_npu/sgl_kernel_npu/norm/fused_split_qk_norm.py:6-134
 //   swiglu_oai                     python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai.py:7-104
 //   swiglu_oai_quant               python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai_quant.py:39-211
+//   situ / situ_and_mul(_quant)    python/sgl_kernel_npu/sgl_kernel_npu/activation/situ.py:11-480
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
 // on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
 // MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
@@ -288,7 +289,10 @@ __global__ __launch_bounds__(256) void swiglu_oai_kernel(const typename Elem<DT>
 // (stated assumption: the reference holds no test or vector for this function).  Rows beyond the group list's total are left untouched.
 // One wave per row, 16-byte loads; rows of up to 4096 outputs stay in registers between the maximum and the conversion, longer ones are
 // recomputed from a second read.
-template <int DT, bool I64>
+// ACT 1: SiTU (activation/situ.py:11-90, :361-427): gate' = beta * tanh(gate / beta) * sigmoid(gate), up' = linear_beta * tanh(up / linear_beta)
+// (optional), out = gate' * up' (:61-64); quantised: scale = max(max|out| / 127, 1e-30) (:67), q = clamp(floor(out / scale + 0.5), -128, 127)
+// (:78-80) -- the rounding is explicit here.  alpha = beta, limit = linear_beta (<= 0: the up path is left alone).
+template <int DT, bool I64, int ACT = 0>
 __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename Elem<DT>::T *__restrict__ x, const void *__restrict__ group_list, int num_groups,
                                                                int group_list_type, long long rows, int half, float alpha, float limit, int need_quant,
                                                                void *__restrict__ out, float *__restrict__ scale)
@@ -310,14 +314,22 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     }
     if (row >= rows || row >= total) return;
     const T *xr = x + row * 2 * (long long)half;
+    const float inv_alpha = 1.0f / alpha, inv_limit = limit > 0.f ? 1.0f / limit : 0.f;
     auto act = [&](float g, float u) -> float {
-        g = fminf(g, limit);
-        u = fminf(fmaxf(u, -limit), limit);
-        return (g * (1.0f / (1.0f + __expf(-g * alpha)))) * (u + 1.0f);
+        if constexpr (ACT == 1) {
+            const float ga = (alpha * tanhf(g * inv_alpha)) * (1.0f / (1.0f + __expf(-g)));
+            if (limit > 0.f) u = limit * tanhf(u * inv_limit);
+            return ga * u;
+        } else {
+            g = fminf(g, limit);
+            u = fminf(fmaxf(u, -limit), limit);
+            return (g * (1.0f / (1.0f + __expf(-g * alpha)))) * (u + 1.0f);
+        }
     };
     auto value = [&](int j) -> float { return act(Elem<DT>::ld(xr[j]), Elem<DT>::ld(xr[half + j])); };
     // rounded to the I/O dtype first (:96), then truncated and saturated (:97); 0 / 0 (an all-zero row) -> 0
     auto quant = [&](float v, float sc) -> int {
+        if constexpr (ACT == 1) return (int)fminf(fmaxf(floorf(v / sc + 0.5f), -128.f), 127.f);
         float r = Elem<DT>::ld(Elem<DT>::st(v / sc));
         r = r != r ? 0.f : truncf(r);
         return (int)fminf(fmaxf(r, -128.f), 127.f);
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-    const float sc = amax / 127.0f;
+    const float sc = ACT == 1 ? fmaxf(amax / 127.0f, 1e-30f) : amax / 127.0f;
     if (lane == 0) scale[row] = sc;
     int8_t *o = (int8_t *)out + row * (long long)half;
     if (in_regs) {
@@ -592,6 +604,25 @@ extern "C" int mi_swiglu_oai_quant(const void *x, const void *group_list, int gr
     if (dtype == MI_DTYPE_BF16) { if (group_list_is_i64) MI_SOQ(MI_DTYPE_BF16, true); else MI_SOQ(MI_DTYPE_BF16, false); }
     else { if (group_list_is_i64) MI_SOQ(MI_DTYPE_F16, true); else MI_SOQ(MI_DTYPE_F16, false); }
 #undef MI_SOQ
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+// SiTU + optional per-row INT8 (activation/situ.py): x [rows, cols] = [gate | up]; linear_beta <= 0: the up path is left alone
+extern "C" int mi_situ_and_mul(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type, long long rows,
+                               int cols, float beta, float linear_beta, int need_quant, int dtype, void *out, float *scale, void *stream)
+{
+    if (rows < 0 || cols <= 0 || cols % 2 || !(beta > 0.f) || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) ||
+        (group_list && (num_groups <= 0 || (group_list_type != 0 && group_list_type != 1))))
+        return MI_SGL_EINVAL;
+    if (rows == 0) return MI_SGL_OK;
+    if (!x || !out || (need_quant && !scale) || rows > (1ll << 32)) return MI_SGL_EINVAL;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+#define MI_SITU(DT, I64) swiglu_oai_quant_kernel<DT, I64, 1><<<blocks, 256, 0, st>>>((const uint16_t *)x, group_list, num_groups, group_list_type, rows, cols / 2, \
+                                                                                 beta, linear_beta, need_quant, out, scale)
+    if (dtype == MI_DTYPE_BF16) { if (group_list_is_i64) MI_SITU(MI_DTYPE_BF16, true); else MI_SITU(MI_DTYPE_BF16, false); }
+    else { if (group_list_is_i64) MI_SITU(MI_DTYPE_F16, true); else MI_SITU(MI_DTYPE_F16, false); }
+#undef MI_SITU
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 

@@ -406,6 +406,30 @@ std::tuple<at::Tensor, at::Tensor> swiglu_oai_quant(const at::Tensor &x, double 
     return {out, scale};
 }
 
+// activation/situ.py:165-480 (situ_and_mul, situ_and_mul_quant, situ share this op)
+std::tuple<at::Tensor, at::Tensor> situ_and_mul(const at::Tensor &x, const std::optional<at::Tensor> &group_list, std::optional<int64_t> group_list_type,
+                                                double beta, std::optional<double> linear_beta, bool need_quant)
+{
+    const c10::DeviceGuard device_guard(x.device());   // launches and the current stream follow the tensor's GPU
+    TORCH_CHECK(x.dim() >= 1 && x.is_contiguous() && x.size(-1) % 2 == 0, "situ: x must be contiguous [..., 2d]");
+    const int64_t h = x.size(-1), rows = h ? x.numel() / h : 0;
+    if (group_list.has_value()) {
+        TORCH_CHECK(group_list_type.has_value() && (*group_list_type == 0 || *group_list_type == 1), "group_list_type must be 0 or 1");
+        TORCH_CHECK(group_list->scalar_type() == at::kInt || group_list->scalar_type() == at::kLong, "group_list dtype must be torch.int32 or torch.int64");
+        TORCH_CHECK(group_list->is_contiguous() && group_list->dim() == 1, "group_list must be a contiguous vector");
+    }
+    std::vector<int64_t> oshape(x.sizes().begin(), x.sizes().end());
+    oshape.back() = h / 2;
+    at::Tensor out = at::empty(oshape, x.options().dtype(need_quant ? at::kChar : x.scalar_type()));
+    at::Tensor scale = at::empty({rows}, x.options().dtype(at::kFloat));
+    const int rc = mi_situ_and_mul(x.data_ptr(), group_list.has_value() ? group_list->data_ptr() : nullptr,
+                                   group_list.has_value() && group_list->scalar_type() == at::kLong, group_list.has_value() ? (int)group_list->numel() : 0,
+                                   (int)group_list_type.value_or(0), rows, (int)h, (float)beta, linear_beta.has_value() ? (float)*linear_beta : 0.f,
+                                   need_quant, dtype_code(x), out.data_ptr(), scale.data_ptr<float>(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_situ_and_mul failed with code ", rc);
+    return {out, scale};
+}
+
 // norm/fused_split_qk_norm.py:93-134 (weights / biases of the two layer norms passed as tensors)
 std::tuple<at::Tensor, at::Tensor, at::Tensor> fused_split_qk_norm(const at::Tensor &x, const at::Tensor &q_weight, const std::optional<at::Tensor> &q_bias,
                                                                    const at::Tensor &k_weight, const std::optional<at::Tensor> &k_bias, int64_t q_lora_rank,
@@ -728,6 +752,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("attention_sinks(Tensor query, Tensor k_cache, Tensor v_cache, Tensor sinks, Tensor block_tables, Tensor kv_lens, float scale, "
           "int sliding_window_size, int q_head_num, int k_head_num, Tensor? bt_rows=None) -> Tensor");
     m.def("swiglu_oai_quant(Tensor x, float alpha, float limit, bool need_quant=True, Tensor? group_list=None, int? group_list_type=None) -> (Tensor, Tensor)");
+    m.def("situ_and_mul(Tensor x, Tensor? group_list, int? group_list_type, float beta, float? linear_beta, bool need_quant) -> (Tensor, Tensor)");
     m.def("swiglu_oai(Tensor hidden_states, int dim, float gemm1_alpha, float gemm1_clamp_limit) -> Tensor");
     m.def("fused_split_qk_norm(Tensor x, Tensor q_weight, Tensor? q_bias, Tensor k_weight, Tensor? k_bias, int q_lora_rank, int kv_lora_rank, "
           "int qk_rope_dim, float eps=1e-6) -> (Tensor, Tensor, Tensor)");
@@ -757,6 +782,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("split_qkv_rmsnorm_rope_pos_cache_half", TORCH_FN(sglang::npu_kernel::split_qkv_rmsnorm_rope_pos_cache_half));
     m.impl("attention_sinks", TORCH_FN(sglang::npu_kernel::attention_sinks));
     m.impl("swiglu_oai_quant", TORCH_FN(sglang::npu_kernel::swiglu_oai_quant));
+    m.impl("situ_and_mul", TORCH_FN(sglang::npu_kernel::situ_and_mul));
     m.impl("swiglu_oai", TORCH_FN(sglang::npu_kernel::swiglu_oai));
     m.impl("fused_split_qk_norm", TORCH_FN(sglang::npu_kernel::fused_split_qk_norm));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));

@@ -398,6 +398,51 @@ def test_swiglu_oai_quant(rows, cols, mode, dt):
         swiglu_oai_quant(x.cuda(), alpha, limit, True, torch.tensor([1, 2]).cuda(), 3)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,cols,mode,linear_beta", [(300, 6144, "dense", 25.0), (64, 128, "dense", None), (257, 12288, "counts", 25.0),
+                                                        (100, 512, "cumsum", 3.0), (9, 6, "dense", 25.0), (40, 2 * 8448, "noquant", 25.0)])
+def test_situ(rows, cols, mode, linear_beta, dt):
+    """activation/situ.py: situ_and_mul, situ_and_mul_quant and situ against the fp32 restatement.  tanh / exp differ from torch's in the last
+    bits, so a quantised value may move by one step at a rounding boundary: |dq| <= 1 on < 2 % of the elements, scales to 1e-5; the
+    unquantised output to one rounding of the I/O dtype."""
+    from sgl_kernel_npu.activation.situ import situ, situ_and_mul, situ_and_mul_quant
+    torch.manual_seed(rows + cols)
+    x = (torch.randn(rows, cols) * 3).to(dt)
+    beta = 4.0
+    gl, glt, total = None, None, rows
+    if mode == "counts":
+        gl, glt, total = torch.tensor([100, 0, 57, 60], dtype=torch.int64), 1, 217
+    elif mode == "cumsum":
+        gl, glt, total = torch.tensor([10, 10, 64, 90], dtype=torch.int32), 0, 90
+    glc = None if gl is None else gl.cuda()
+    tol = dict(rtol=2 ** -7 if dt == torch.bfloat16 else 2 ** -10, atol=1e-4)
+    want_f, _ = OK.situ_and_mul(x, beta, linear_beta, False, total)
+    got_f = situ_and_mul(x.cuda(), glc, glt, beta, linear_beta)
+    assert got_f.dtype == dt and got_f.shape == (rows, cols // 2)
+    assert torch.allclose(got_f.cpu()[:total].float(), want_f[:total].float(), **tol)
+    if mode == "noquant":                      # d > 6144: the quantising entry point refuses, as the reference does
+        with pytest.raises(NotImplementedError):
+            situ_and_mul_quant(x.cuda(), glc, glt, beta, linear_beta)
+        return
+    with pytest.raises(NotImplementedError):
+        situ_and_mul_quant(x.cuda(), glc, glt, beta, linear_beta, need_quant=False)
+    with pytest.raises(NotImplementedError):
+        situ_and_mul_quant(x.cuda(), glc, glt, beta, linear_beta, quant_type=1)
+    want, ws = OK.situ_and_mul(x, beta, linear_beta, True, total)
+    got, gs = situ_and_mul_quant(x.cuda(), glc, glt, beta, linear_beta)
+    assert got.dtype == torch.int8 and gs.shape == (rows,)
+    assert torch.allclose(gs.cpu()[:total], ws[:total], rtol=1e-5)
+    d = (got.cpu()[:total].int() - want[:total].int()).abs()
+    assert d.max() <= 1 and (d != 0).float().mean() < 2e-2
+    if gl is not None:                         # the grouped entry point: same kernel, scale None without quantisation
+        g2, s2 = situ(x.cuda(), glc, glt, need_quant=True, beta=beta, linear_beta=linear_beta)
+        assert torch.equal(g2[:total], got[:total]) and torch.equal(s2[:total], gs[:total])
+        g3, s3 = situ(x.cuda(), glc, glt, need_quant=False, beta=beta, linear_beta=linear_beta)
+        assert s3 is None and torch.equal(g3[:total], got_f[:total])
+        with pytest.raises(ValueError):
+            situ(x.cuda(), glc, 2, need_quant=True)
+
+
 def test_split_qkv_rmsnorm_rope_pos_cache_half_replays_in_a_captured_graph():
     """The reference test replays the op in a captured device graph with new inputs in the same buffers
     (test_split_qkv_rmsnorm_rope_pos_cache_half_npu.py:213-260): positions are clamped inside the kernel, nothing synchronises."""

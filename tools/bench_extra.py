@@ -109,6 +109,12 @@ def main():
     xo = torch.randn((16384, 5760), generator=g, device="cuda").to(torch.bfloat16)      # GPT-OSS expert intermediate 2880
     t = ev_time(lambda: swiglu_oai_quant(xo, 1.702, 7.0))
     out["swiglu_oai_quant_16384x5760_bf16"] = dict(t, GBps=16384 * (5760 * 2 + 2880 + 4) / t["p50_us"] / 1e3)
+    from sgl_kernel_npu.activation.situ import situ_and_mul, situ_and_mul_quant
+    xs = torch.randn((16384, 12288), generator=g, device="cuda").to(torch.bfloat16)      # d = 6144: the largest the quantising form takes
+    t = ev_time(lambda: situ_and_mul_quant(xs))
+    out["situ_and_mul_quant_16384x12288_bf16"] = dict(t, GBps=16384 * (12288 * 2 + 6144 + 4) / t["p50_us"] / 1e3)
+    t = ev_time(lambda: situ_and_mul(xs))
+    out["situ_and_mul_16384x12288_bf16"] = dict(t, GBps=16384 * (12288 * 2 + 6144 * 2) / t["p50_us"] / 1e3)
     from sgl_kernel_npu.norm.split_qkv_tp_rmsnorm_rope import split_qkv_tp_rmsnorm_rope
     from sgl_kernel_npu.norm.split_qkv_rmsnorm_mrope import triton_split_qkv_rmsnorm_mrope
     from sgl_kernel_npu.norm.split_qkv_rmsnorm_rope_pos_cache_half_npu import split_qkv_rmsnorm_rope_pos_cache_half_npu
