@@ -73,6 +73,21 @@ __device__ __forceinline__ void load16(const typename Elem<DT>::T *p, float *f)
         }
     }
 }
+// 16 bytes already in registers -> fp32 values
+template <int DT>
+__device__ __forceinline__ void unpack16(const u32x4 v, float *f)
+{
+    if constexpr (DT == MI_DTYPE_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = __uint_as_float(v[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = Elem<DT>::ld((uint16_t)(v[j] & 0xFFFFu));
+            f[2 * j + 1] = Elem<DT>::ld((uint16_t)(v[j] >> 16));
+        }
+    }
+}
 template <int DT>
 __device__ __forceinline__ void store16(typename Elem<DT>::T *p, const float *f)
 {
@@ -287,8 +302,19 @@ __global__ __launch_bounds__(256) void swiglu_oai_kernel(const typename Elem<DT>
 // (out / scale) rounded to the I/O dtype first (:96) and then converted with saturation (:97).  The reference leaves that conversion to the
 // backend's cast; here it TRUNCATES toward zero, the float -> int conversion of the Triton language the reference kernel is written in
 // (stated assumption: the reference holds no test or vector for this function).  Rows beyond the group list's total are left untouched.
-// One wave per row, 16-byte loads; rows of up to 4096 outputs stay in registers between the maximum and the conversion, longer ones are
+// One wave per row, 16-byte loads; rows of up to 6144 outputs stay in registers between the maximum and the conversion, longer ones are
 // recomputed from a second read.
+// tanh to ~1e-6 relative in ~12 VALU operations (libm's tanhf costs ~40 and made SiTU VALU-bound at 2.3 TB/s): the odd polynomial
+// x - x^3/3 + 2x^5/15 - 17x^7/315 below |x| = 0.25 (next term 8e-8 relative there), 1 - 2 / (exp(2|x|) + 1) above (no cancellation: the
+// result is >= 0.24)
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float ax = fabsf(x), x2 = x * x;
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * ax) + 1.0f);
+    const float p = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - x2 * 0.05396825f)));
+    return ax < 0.25f ? p : copysignf(t, x);
+}
+
 // ACT 1: SiTU (activation/situ.py:11-90, :361-427): gate' = beta * tanh(gate / beta) * sigmoid(gate), up' = linear_beta * tanh(up / linear_beta)
 // (optional), out = gate' * up' (:61-64); quantised: scale = max(max|out| / 127, 1e-30) (:67), q = clamp(floor(out / scale + 0.5), -128, 127)
 // (:78-80) -- the rounding is explicit here.  alpha = beta, limit = linear_beta (<= 0: the up path is left alone).
@@ -317,8 +343,8 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     const float inv_alpha = 1.0f / alpha, inv_limit = limit > 0.f ? 1.0f / limit : 0.f;
     auto act = [&](float g, float u) -> float {
         if constexpr (ACT == 1) {
-            const float ga = (alpha * tanhf(g * inv_alpha)) * (1.0f / (1.0f + __expf(-g)));
-            if (limit > 0.f) u = limit * tanhf(u * inv_limit);
+            const float ga = (alpha * tanh_fast(g * inv_alpha)) * (1.0f / (1.0f + __expf(-g)));
+            if (limit > 0.f) u = limit * tanh_fast(u * inv_limit);
             return ga * u;
         } else {
             g = fminf(g, limit);
@@ -328,9 +354,17 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     };
     auto value = [&](int j) -> float { return act(Elem<DT>::ld(xr[j]), Elem<DT>::ld(xr[half + j])); };
     // rounded to the I/O dtype first (:96), then truncated and saturated (:97); 0 / 0 (an all-zero row) -> 0
+    // v / sc for a row's one sc: through the correctly rounded reciprocal and one residual correction (q0 = v r, q = q0 + (v - sc q0) r --
+    // the IEEE quotient whenever nothing under- or overflows, three operations instead of the ~12 of a division; sc == 0 keeps 0 / 0 = NaN)
+    float rsc = 0.f;
+    auto div_sc = [&](float v, float sc) -> float {
+        const float q0 = v * rsc;
+        const float q = __builtin_fmaf(__builtin_fmaf(-sc, q0, v), rsc, q0);
+        return (sc > 1e-30f && sc < 1e30f) ? q : v / sc;
+    };
     auto quant = [&](float v, float sc) -> int {
-        if constexpr (ACT == 1) return (int)fminf(fmaxf(floorf(v / sc + 0.5f), -128.f), 127.f);
-        float r = Elem<DT>::ld(Elem<DT>::st(v / sc));
+        if constexpr (ACT == 1) return (int)fminf(fmaxf(floorf(div_sc(v, sc) + 0.5f), -128.f), 127.f);
+        float r = Elem<DT>::ld(Elem<DT>::st(div_sc(v, sc)));
         r = r != r ? 0.f : truncf(r);
         return (int)fminf(fmaxf(r, -128.f), 127.f);
     };
@@ -339,13 +373,27 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     if (!need_quant) {
         T *o = (T *)out + row * (long long)half;
         if (vec) {
-            for (int j = lane * N; j < half; j += 64 * N) {
-                float g[N], u[N];
-                load16<DT>(xr + j, g);
-                load16<DT>(xr + half + j, u);
+            // four 16-byte pieces of each half per lane and step, requested TOGETHER and unconditionally (index clamped into the row: a
+            // conditional load gets a block and a wait of its own, which left one or two loads in flight per wave: 3.2 TB/s)
+            for (int j0 = lane * N; j0 < half; j0 += 4 * 64 * N) {
+                u32x4 rg[4], ru[4];
 #pragma unroll
-                for (int e = 0; e < N; ++e) g[e] = act(g[e], u[e]);
-                store16<DT>(o + j, g);
+                for (int b = 0; b < 4; ++b) {
+                    const int j = min(j0 + b * 64 * N, half - N);
+                    rg[b] = *(const u32x4 *)(xr + j);
+                    ru[b] = *(const u32x4 *)(xr + half + j);
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int j = j0 + b * 64 * N;
+                    if (j >= half) break;
+                    float g[N], u[N];
+                    unpack16<DT>(rg[b], g);
+                    unpack16<DT>(ru[b], u);
+#pragma unroll
+                    for (int e = 0; e < N; ++e) g[e] = act(g[e], u[e]);
+                    store16<DT>(o + j, g);
+                }
             }
         } else {
             for (int j = lane; j < half; j += 64) o[j] = Elem<DT>::st(value(j));
@@ -353,21 +401,31 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
         return;
     }
     float amax = 0.f;
-    constexpr int kChunks = 8;                             // rows of up to 4096 outputs stay in registers between the maximum and the conversion
+    constexpr int kChunks = 12;                            // rows of up to 6144 outputs (the most SiTU quantises) stay in registers between the maximum and the conversion
     const bool in_regs = vec && half <= 64 * kChunks * N;
-    float keep[kChunks][N];
+    float keep[kChunks][N];                                // the row's activations (the quantising forms are VALU-bound: computed once)
     if (in_regs) {
+        // all of the row's loads are requested together and unconditionally (index clamped into the row; see the unquantised path)
+        u32x4 kg[kChunks], ku[kChunks];
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
-            const int j = (c * 64 + lane) * N;
-            if (j < half) {
+            const int j = min((c * 64 + lane) * N, half - N);
+            if (c * 64 * N < half) {                          // (wave-uniform)
+                kg[c] = *(const u32x4 *)(xr + j);
+                ku[c] = *(const u32x4 *)(xr + half + j);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            if (c * 64 * N < half) {                          // (wave-uniform; lanes past the row compute on the clamped piece and store nothing)
                 float u[N];
-                load16<DT>(xr + j, keep[c]);
-                load16<DT>(xr + half + j, u);
+                unpack16<DT>(kg[c], keep[c]);
+                unpack16<DT>(ku[c], u);
+                const bool live = (c * 64 + lane) * N < half;
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
                     keep[c][e] = act(keep[c][e], u[e]);
-                    amax = fmaxf(amax, fabsf(keep[c][e]));
+                    amax = fmaxf(amax, live ? fabsf(keep[c][e]) : 0.f);
                 }
             }
         }
@@ -386,6 +444,7 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     const float sc = ACT == 1 ? fmaxf(amax / 127.0f, 1e-30f) : amax / 127.0f;
     if (lane == 0) scale[row] = sc;
+    rsc = 1.0f / sc;
     int8_t *o = (int8_t *)out + row * (long long)half;
     if (in_regs) {
 #pragma unroll
