@@ -192,6 +192,14 @@ int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin, int tokens
                    int rope_dim, int neox, int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
                    int64_t cs_stride_t, int dtype, void *out_q, void *out_k, void *stream);
 
+/* Per-query block tables of the sparse + causal prefill path (attention/fia_blockq_attention.py:11-88): topk_idx [total_q, topk1] int32,
+ * -1-padded logical blocks; seq_lens [total_q] = position + 1; per_query_req [total_q] int32 / int64; req_to_token [requests, max_cols]
+ * slot table (strides in elements).  Out: block_table [total_q, topk1] physical pages, the query's own block last, pads 0;
+ * actual_kvlen [total_q].  The attention is mi_gqa_decode with one query row per "sequence" on these tables. */
+int mi_fia_prep(const int32_t *topk_idx, long long stride_ti_t, long long stride_ti_k, const int32_t *seq_lens, const void *per_query_req,
+                int req_is_i64, const int32_t *req_to_token, long long stride_rtt_r, long long stride_rtt_t, int max_cols, int total_q, int topk1,
+                int block_size, int32_t *block_table, long long stride_bt_t, int32_t *actual_kvlen, void *stream);
+
 /* ---- mla_preprocess (reference: one AscendC MIX kernel, csrc/mla_preprocess/op_kernel/mla_preprocess_mix_bf16.hpp:285,2762,2814;
  * host csrc/mla_preprocess/op_host/mla_preprocess.cpp:623-704; arithmetic per the test golden golden2_pytorch,
  * tests/python/sgl_kernel_npu/test_mla_preprocess.py:407-483).  Five launches on one stream, every GEMM hand-written:

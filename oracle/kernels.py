@@ -436,6 +436,49 @@ def attention_sinks(query, k_cache, v_cache, sinks, block_tables, kv_lens, scale
     return out.to(query.dtype).reshape(rows, q_head_num * Dv)
 
 
+def fia_prep(topk_idx, seq_lens, per_query_req, req_to_token, block_size):
+    """Restates _fia_prep_kernel (attention/fia_blockq_attention.py:35-88) query by query: the own logical block (position // block_size) goes
+    last, the other real blocks keep their order, logical -> physical page through req_to_token[req, block * block_size] // block_size (:58-72),
+    pads 0; actual_kvlen = real non-own blocks * block_size (+ offset + 1 when the own block is selected) (:84-87).  PARITY UNPINNED (no
+    reference test).  -> (block_table [T, topk1] int32, actual_kvlen [T] int32)."""
+    T, topk1 = topk_idx.shape
+    max_cols = req_to_token.shape[1]
+    bt = torch.zeros((T, topk1), dtype=torch.int32)
+    kvl = torch.zeros(T, dtype=torch.int32)
+    for t in range(T):
+        abs_pos = max(int(seq_lens[t]) - 1, 0)
+        own, own_offset = abs_pos // block_size, abs_pos % block_size
+        req = int(per_query_req[t])
+        blocks = [int(b) for b in topk_idx[t]]
+        real = [b for b in blocks if b >= 0 and b != own]
+        own_present = any(b == own for b in blocks if b >= 0)
+        page = lambda b: int(req_to_token[req, min(b * block_size, max_cols - 1)]) // block_size
+        for i, b in enumerate(real):
+            bt[t, i] = page(b)
+        if len(real) < topk1:
+            bt[t, len(real)] = page(own)
+        kvl[t] = len(real) * block_size + (own_offset + 1 if own_present else 0)
+    return bt, kvl
+
+
+def fia_blockq_sparse(q, k_cache, v_cache, topk_idx, seq_lens, per_query_req, req_to_token, block_size, sm_scale):
+    """fp32 softmax attention of every query over the first actual_kvlen keys of its own block table (what the reference asks of its
+    fused-infer-attention op, fia_blockq_attention.py:167-180)."""
+    bt, kvl = fia_prep(topk_idx, seq_lens, per_query_req, req_to_token, block_size)
+    T, Hq, D = q.shape
+    out = torch.zeros((T, Hq, v_cache.shape[-1]), dtype=torch.float32)
+    for t in range(T):
+        n = int(kvl[t])
+        if n == 0:
+            continue
+        pages = bt[t, :(n + block_size - 1) // block_size].long()
+        k = k_cache[pages, :, 0, :].reshape(-1, D)[:n].float()
+        v = v_cache[pages, :, 0, :].reshape(-1, v_cache.shape[-1])[:n].float()
+        p = torch.softmax((q[t].float() @ k.T) * sm_scale, dim=-1)
+        out[t] = p @ v
+    return out.to(q.dtype)
+
+
 def swiglu_oai(x, dim, alpha, limit):
     """Restates swiglu_oai_kernel (activation/swiglu_oai.py:7-50) in fp32: gate = even columns clamped from above (:36), up = odd columns
     clamped to +-limit (:37-38), (up + 1) * gate * 1 / (1 + exp(-gate * alpha)) (:39-41).  Pinned to the file's own torch formulation

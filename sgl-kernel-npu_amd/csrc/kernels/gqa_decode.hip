@@ -528,3 +528,61 @@ extern "C" int mi_gqa_decode_sinks(const void *q, const void *k, const void *v, 
                            o_stride_h, sm_scale, dtype, num_splits, workspace, workspace_bytes, stream, sinks, sinks_dtype, sliding_window,
                            block_table_rows);
 }
+
+
+// ---- per-query block tables of the sparse + causal prefill path (attention/fia_blockq_attention.py:11-88) ------------------------------------
+// One wave per query (topk + 1 <= 64 slots, a lane each): the query's own logical block (the one holding its position) goes LAST, the other
+// real blocks keep their order in front of it, every logical block becomes the physical page req_to_token[req, block * block_size] /
+// block_size, pads are 0; actual_kvlen = real non-own blocks * block_size (+ offset in the own block + 1 when the own block is selected)
+// (:35-88).  The attention itself is then a paged decode with one query row per "sequence" (mi_gqa_decode): the reference hands the same
+// tables to its fused-infer-attention op (:167-180), after a host round trip for the lengths that this path does not need.
+namespace mi_sgl {
+__global__ __launch_bounds__(256) void fia_prep_kernel(const int32_t *__restrict__ topk_idx, long long stride_ti_t, long long stride_ti_k,
+                                                       const int32_t *__restrict__ seq_lens, const void *__restrict__ req_pool, int req_is_i64,
+                                                       const int32_t *__restrict__ req_to_token, long long stride_rtt_r, long long stride_rtt_t,
+                                                       int max_cols, int total_q, int topk1, int block_size, int32_t *__restrict__ block_table,
+                                                       long long stride_bt_t, int32_t *__restrict__ actual_kvlen)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= total_q) return;
+    const int seq_len = seq_lens[q];
+    const int abs_pos = max(seq_len - 1, 0);
+    const int own = abs_pos / block_size, own_offset = abs_pos % block_size;
+    const long long req = req_is_i64 ? ((const long long *)req_pool)[q] : (long long)((const int *)req_pool)[q];
+    const bool slot = lane < topk1;
+    const int log_blk = slot ? topk_idx[q * stride_ti_t + lane * stride_ti_k] : -1;
+    const bool is_own = slot && log_blk >= 0 && log_blk == own;
+    const bool real_nonown = slot && log_blk >= 0 && log_blk != own;
+    const unsigned long long m = __ballot(real_nonown);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));         // exclusive scan: this slot's place among the real non-own blocks
+    const int count_real = __popcll(m);
+    const bool own_present = __ballot(is_own) != 0ull;
+    int phys = 0;
+    if (slot && log_blk >= 0) {
+        const int col = min(log_blk * block_size, max_cols - 1);
+        phys = req_to_token[req * stride_rtt_r + col * stride_rtt_t] / block_size;
+    }
+    const int own_col = min(own * block_size, max_cols - 1);
+    const int own_phys = req_to_token[req * stride_rtt_r + own_col * stride_rtt_t] / block_size;
+    int32_t *bt = block_table + q * stride_bt_t;
+    if (slot) bt[lane] = 0;                                           // the wave's stores to one address keep program order
+    if (real_nonown) bt[rank] = phys;
+    // (the reference stores the own page unconditionally, also at slot topk1 -- behind the row -- when every slot is a real non-own block)
+    if (lane == 0 && count_real < topk1) bt[count_real] = own_phys;
+    if (lane == 0) actual_kvlen[q] = own_present ? count_real * block_size + own_offset + 1 : count_real * block_size;
+}
+}  // namespace mi_sgl
+
+extern "C" int mi_fia_prep(const int32_t *topk_idx, long long stride_ti_t, long long stride_ti_k, const int32_t *seq_lens, const void *per_query_req,
+                           int req_is_i64, const int32_t *req_to_token, long long stride_rtt_r, long long stride_rtt_t, int max_cols, int total_q,
+                           int topk1, int block_size, int32_t *block_table, long long stride_bt_t, int32_t *actual_kvlen, void *stream)
+{
+    if (total_q < 0 || topk1 <= 0 || topk1 > 64 || block_size <= 0 || max_cols <= 0) return MI_SGL_EINVAL;
+    if (total_q == 0) return MI_SGL_OK;
+    if (!topk_idx || !seq_lens || !per_query_req || !req_to_token || !block_table || !actual_kvlen) return MI_SGL_EINVAL;
+    mi_sgl::fia_prep_kernel<<<(total_q + 3) / 4, 256, 0, (hipStream_t)stream>>>(topk_idx, stride_ti_t, stride_ti_k, seq_lens, per_query_req, req_is_i64,
+                                                                                req_to_token, stride_rtt_r, stride_rtt_t, max_cols, total_q, topk1,
+                                                                                block_size, block_table, stride_bt_t, actual_kvlen);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}

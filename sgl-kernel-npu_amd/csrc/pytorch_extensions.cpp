@@ -160,6 +160,35 @@ at::Tensor attention_sinks(const at::Tensor &query, const at::Tensor &k_cache, c
     return out;
 }
 
+// attention/fia_blockq_attention.py:89-181: per-query block tables (mi_fia_prep), then a paged decode with one query row per "sequence"
+at::Tensor fia_blockq_sparse_prefill(const at::Tensor &q, const at::Tensor &k_cache, const at::Tensor &v_cache, const at::Tensor &topk_idx,
+                                     const at::Tensor &seq_lens, const at::Tensor &per_query_req, const at::Tensor &req_to_token,
+                                     int64_t block_size, double sm_scale, const std::optional<at::Tensor> &block_table_out,
+                                     const std::optional<at::Tensor> &actual_kvlen_out)
+{
+    const c10::DeviceGuard device_guard(q.device());
+    TORCH_CHECK(q.dim() == 3 && k_cache.dim() == 4 && topk_idx.dim() == 2 && req_to_token.dim() == 2, "fia_blockq_sparse_prefill: bad ranks");
+    TORCH_CHECK(topk_idx.scalar_type() == at::kInt && seq_lens.scalar_type() == at::kInt && req_to_token.scalar_type() == at::kInt,
+                "fia_blockq_sparse_prefill: topk_idx / seq_lens / req_to_token must be int32");
+    TORCH_CHECK(per_query_req.scalar_type() == at::kInt || per_query_req.scalar_type() == at::kLong, "per_query_req must be int32 or int64");
+    const int64_t total_q = q.size(0), topk1 = topk_idx.size(1);
+    TORCH_CHECK(topk_idx.size(0) == total_q && seq_lens.numel() == total_q && per_query_req.numel() == total_q && seq_lens.is_contiguous() &&
+                    per_query_req.is_contiguous() && topk1 <= 64 && k_cache.size(1) == block_size,
+                "fia_blockq_sparse_prefill: shape mismatch (topk + 1 <= 64)");
+    at::Tensor bt = block_table_out.has_value() ? *block_table_out : at::empty({total_q, topk1}, topk_idx.options());
+    at::Tensor kvl = actual_kvlen_out.has_value() ? *actual_kvlen_out : at::empty({total_q}, topk_idx.options());
+    TORCH_CHECK(bt.scalar_type() == at::kInt && bt.dim() == 2 && bt.size(0) == total_q && bt.size(1) == topk1 && bt.stride(1) == 1 &&
+                    kvl.scalar_type() == at::kInt && kvl.numel() == total_q && kvl.is_contiguous(), "block_table_out / actual_kvlen_out");
+    const int rc = mi_fia_prep(topk_idx.data_ptr<int>(), topk_idx.stride(0), topk_idx.stride(1), seq_lens.data_ptr<int>(), per_query_req.data_ptr(),
+                               per_query_req.scalar_type() == at::kLong, req_to_token.data_ptr<int>(), req_to_token.stride(0),
+                               req_to_token.stride(1), (int)req_to_token.size(1), (int)total_q, (int)topk1, (int)block_size, bt.data_ptr<int>(),
+                               bt.stride(0), kvl.data_ptr<int>(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_fia_prep failed with code ", rc);
+    at::Tensor out = at::empty({total_q, q.size(1), v_cache.size(3)}, q.options());
+    if (total_q > 0) decode_gqa(q, k_cache, v_cache, out, kvl, sm_scale, block_size, bt, 0);
+    return out;
+}
+
 // SwiGLU + per-row INT8 quantisation; same arguments / returns as swiglu_quant (activation/swiglu_quant.py:87-127).
 std::tuple<at::Tensor, at::Tensor> swiglu_quant(const at::Tensor &x, const at::Tensor &group_list, int64_t group_list_type,
                                                 bool need_quant, bool do_limit, double limit)
@@ -753,6 +782,8 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
           "int sliding_window_size, int q_head_num, int k_head_num, Tensor? bt_rows=None) -> Tensor");
     m.def("swiglu_oai_quant(Tensor x, float alpha, float limit, bool need_quant=True, Tensor? group_list=None, int? group_list_type=None) -> (Tensor, Tensor)");
     m.def("situ_and_mul(Tensor x, Tensor? group_list, int? group_list_type, float beta, float? linear_beta, bool need_quant) -> (Tensor, Tensor)");
+    m.def("fia_blockq_sparse_prefill(Tensor q, Tensor k_cache, Tensor v_cache, Tensor topk_idx, Tensor seq_lens, Tensor per_query_req, "
+          "Tensor req_to_token, int block_size, float sm_scale, Tensor? block_table_out=None, Tensor? actual_kvlen_out=None) -> Tensor");
     m.def("swiglu_oai(Tensor hidden_states, int dim, float gemm1_alpha, float gemm1_clamp_limit) -> Tensor");
     m.def("fused_split_qk_norm(Tensor x, Tensor q_weight, Tensor? q_bias, Tensor k_weight, Tensor? k_bias, int q_lora_rank, int kv_lora_rank, "
           "int qk_rope_dim, float eps=1e-6) -> (Tensor, Tensor, Tensor)");
@@ -783,6 +814,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("attention_sinks", TORCH_FN(sglang::npu_kernel::attention_sinks));
     m.impl("swiglu_oai_quant", TORCH_FN(sglang::npu_kernel::swiglu_oai_quant));
     m.impl("situ_and_mul", TORCH_FN(sglang::npu_kernel::situ_and_mul));
+    m.impl("fia_blockq_sparse_prefill", TORCH_FN(sglang::npu_kernel::fia_blockq_sparse_prefill));
     m.impl("swiglu_oai", TORCH_FN(sglang::npu_kernel::swiglu_oai));
     m.impl("fused_split_qk_norm", TORCH_FN(sglang::npu_kernel::fused_split_qk_norm));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));

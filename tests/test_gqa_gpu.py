@@ -241,3 +241,52 @@ def test_attention_sinks_extend(window):
             rows.append(b)
     want = OK.attention_sinks(q, kc, vc, sinks, bt, torch.tensor(kv, dtype=torch.int32), scale, window, Hq, Hkv, torch.tensor(rows, dtype=torch.int32))
     assert torch.allclose(got.cpu().float(), want.float(), atol=2e-3, rtol=2 ** -6), (got.cpu().float() - want.float()).abs().max()
+
+
+def _fia_case(total_q, topk1, block_size, Hq, D, dtype, seed):
+    """A prefill batch of two requests with scattered pages: every query selects up to topk1 - 1 past blocks (random, -1-padded) and, most of
+    the time, its own block somewhere in the list."""
+    g = torch.Generator().manual_seed(seed)
+    n_req, max_ctx = 2, 6 * block_size
+    num_pages = 2 * (max_ctx // block_size) + 3
+    perm = torch.randperm(num_pages - 1, generator=g) + 1
+    req_to_token = torch.zeros((n_req, max_ctx), dtype=torch.int32)
+    for r in range(n_req):
+        for b in range(max_ctx // block_size):
+            page = int(perm[r * (max_ctx // block_size) + b])
+            req_to_token[r, b * block_size:(b + 1) * block_size] = page * block_size + torch.arange(block_size, dtype=torch.int32)
+    req = torch.randint(0, n_req, (total_q,), generator=g)
+    seq_lens = torch.randint(1, max_ctx + 1, (total_q,), generator=g, dtype=torch.int32)
+    seq_lens[0] = 1                                        # the very first position: own block only, one key
+    topk = torch.full((total_q, topk1), -1, dtype=torch.int32)
+    for t in range(total_q):
+        own = (int(seq_lens[t]) - 1) // block_size
+        past = torch.randperm(own, generator=g)[:topk1 - 1].tolist() if own > 0 else []
+        blocks = past + ([own] if t % 5 != 4 else [])      # every fifth query does not select its own block
+        order = torch.randperm(len(blocks), generator=g).tolist()
+        for i, j in enumerate(order):
+            topk[t, i] = blocks[j]
+    k = (torch.randn((num_pages, block_size, 1, D), generator=g)).to(dtype)
+    v = (torch.randn((num_pages, block_size, 1, D), generator=g)).to(dtype)
+    q = torch.randn((total_q, Hq, D), generator=g).to(dtype)
+    return q, k, v, topk, seq_lens, req, req_to_token, num_pages
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("total_q,topk1,block_size,Hq,D", [(37, 4, 16, 16, 128), (64, 16, 64, 16, 128), (9, 3, 128, 8, 64)])
+def test_fia_blockq_sparse_prefill(total_q, topk1, block_size, Hq, D, dtype):
+    """attention/fia_blockq_attention.py: the per-query block tables and lengths bit for bit against the restated prep kernel (own block last,
+    logical -> physical pages, pads 0), the attention against an fp32 softmax over exactly those keys; caller-lent table buffers are used."""
+    from sgl_kernel_npu.attention.fia_blockq_attention import flash_prefill_bnsd_blockq_sparse_fia
+    q, k, v, topk, seq_lens, req, rtt, num_pages = _fia_case(total_q, topk1, block_size, Hq, D, dtype, total_q * 7 + topk1)
+    bt_want, kvl_want = OK.fia_prep(topk, seq_lens, req, rtt, block_size)
+    want = OK.fia_blockq_sparse(q, k, v, topk, seq_lens, req, rtt, block_size, D ** -0.5)
+    bt = torch.full((total_q, topk1), -7, dtype=torch.int32, device="cuda")
+    kvl = torch.full((total_q,), -7, dtype=torch.int32, device="cuda")
+    for req_dtype in (torch.int32, torch.int64):
+        got = flash_prefill_bnsd_blockq_sparse_fia(q.cuda(), k.cuda(), v.cuda(), topk[None].cuda(), seq_lens.cuda(), req.to(req_dtype).cuda(),
+                                                   rtt.cuda(), block_size, None, num_pages, topk1, block_table_out=bt, actual_kvlen_out=kvl)
+        assert torch.equal(bt.cpu(), bt_want) and torch.equal(kvl.cpu(), kvl_want)
+        tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+        err = (got.cpu().float() - want.float()).abs()
+        assert bool((err <= tol * want.float().abs().amax(dim=-1, keepdim=True) + 1e-5).all()), float(err.max())

@@ -109,6 +109,24 @@ def main():
     xo = torch.randn((16384, 5760), generator=g, device="cuda").to(torch.bfloat16)      # GPT-OSS expert intermediate 2880
     t = ev_time(lambda: swiglu_oai_quant(xo, 1.702, 7.0))
     out["swiglu_oai_quant_16384x5760_bf16"] = dict(t, GBps=16384 * (5760 * 2 + 2880 + 4) / t["p50_us"] / 1e3)
+    # ---- sparse + causal prefill on per-query block tables (MiniMax-M3 shape: 16 q heads on 1 kv head, d = 128, top-16 + own block of 128 keys)
+    from sgl_kernel_npu.attention.fia_blockq_attention import flash_prefill_bnsd_blockq_sparse_fia
+    Tq, bsz, tk1 = 4096, 128, 17
+    n_ctx = 8192
+    pages_f = n_ctx // bsz + 1
+    rtt = (torch.arange(n_ctx, device="cuda", dtype=torch.int32) + bsz)[None].contiguous()        # request 0: pages 1 ..
+    kf = torch.randn((pages_f, bsz, 1, 128), generator=g, device="cuda").to(torch.bfloat16)
+    vf = torch.randn((pages_f, bsz, 1, 128), generator=g, device="cuda").to(torch.bfloat16)
+    qf = torch.randn((Tq, 16, 128), generator=g, device="cuda").to(torch.bfloat16)
+    sl = torch.arange(n_ctx - Tq + 1, n_ctx + 1, device="cuda", dtype=torch.int32)                 # the last 4096 positions of the context
+    own_b = (sl - 1) // bsz
+    tki = torch.stack([torch.randperm(int(n_ctx // bsz) - 2, device="cuda")[:tk1 - 1].to(torch.int32) for _ in range(64)]).repeat(Tq // 64, 1)
+    tki = torch.minimum(tki, (own_b - 1).clamp(min=0)[:, None])
+    tki = torch.cat([tki, own_b[:, None]], dim=1).contiguous()
+    reqs = torch.zeros(Tq, dtype=torch.int32, device="cuda")
+    t = ev_time(lambda: flash_prefill_bnsd_blockq_sparse_fia(qf, kf, vf, tki[None], sl, reqs, rtt, bsz, None, pages_f, tk1), n=20, warm=3)
+    out["fia_blockq_sparse_prefill_4096q_h16_d128_top16x128"] = dict(t, keys_per_query=(tk1 - 1) * bsz + bsz // 2,
+                                                                       note="duplicate block ids allowed in this synthetic selection; KV read per query from L2 / MALL")
     from sgl_kernel_npu.activation.situ import situ_and_mul, situ_and_mul_quant
     xs = torch.randn((16384, 12288), generator=g, device="cuda").to(torch.bfloat16)      # d = 6144: the largest the quantising form takes
     t = ev_time(lambda: situ_and_mul_quant(xs))
