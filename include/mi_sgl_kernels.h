@@ -180,6 +180,13 @@ int mi_swiglu_oai_quant(const void *x, const void *group_list, int group_list_is
  * 1e-30), q = clamp(floor(out / scale + 0.5), -128, 127); else out in x's dtype. */
 int mi_situ_and_mul(const void *x, const void *group_list, int group_list_is_i64, int num_groups, int group_list_type, long long rows, int cols,
                     float beta, float linear_beta, int need_quant, int dtype, void *out, float *scale, void *stream);
+/* out = routed * factor + shared (moe/mul_add.py:9-60), the product rounded to the I/O dtype before the sum. */
+int mi_mul_add(const void *routed, const void *shared, float factor, long long numel, int dtype, void *out, void *stream);
+/* "Zero experts" of type identity (moe/zero_experts_compute_identity.py:6-81): result [tokens, D] = hidden * sum of the scales of the
+ * selections with index >= num_experts; IN PLACE those scales become 0 and those indices identity_mask_value (the first one 0 when all K
+ * selections of the token were zero experts).  expert_indices [tokens, K] int32 / int64, expert_scales [tokens, K] fp32 or the I/O dtype. */
+int mi_zero_experts_identity(void *expert_indices, int idx_is_i64, void *expert_scales, int scales_dtype, int num_experts, const void *hidden,
+                             long long tokens, int K, int D, int identity_mask_value, int dtype, void *result, void *stream);
 int mi_scale_shift(const void *x, const void *scale, const void *shift, long long rows, int cols, long long scale_numel, long long shift_numel,
                    float scale_constant, int dtype, int ss_dtype, void *out, void *stream);
 

@@ -536,6 +536,27 @@ def situ_and_mul(x, beta=4.0, linear_beta=25.0, need_quant=False, total_rows=Non
     return q.reshape(*x.shape[:-1], half), scale
 
 
+def mul_add(routed, shared, factor):
+    """moe/mul_add.py:24-26: routed * factor + shared evaluated in the tensors' dtype (the product is rounded before the sum).  PARITY
+    UNPINNED (no reference test)."""
+    return (routed.float() * factor).to(routed.dtype).float().add(shared.float()).to(routed.dtype)
+
+
+def zero_experts_compute_identity(expert_indices, expert_scales, num_experts, hidden, identity_mask_value=0):
+    """Restates experts_compute_identity_kernel (moe/zero_experts_compute_identity.py:20-47): -> (result, indices, scales) with the in-place
+    effects applied to copies.  PARITY UNPINNED (no reference test)."""
+    idx, sc = expert_indices.clone(), expert_scales.clone()
+    mask = idx >= num_experts                                           # :24
+    sum_scales = torch.where(mask, sc.float(), torch.zeros_like(sc, dtype=torch.float32)).sum(dim=-1)      # :25-26
+    result = (hidden.float() * sum_scales[:, None]).to(hidden.dtype)    # :35-39
+    ident = torch.full_like(idx, identity_mask_value)
+    all_zero = mask.all(dim=-1)                                         # :29-31: no real expert left: the first selection becomes expert 0
+    ident[all_zero, 0] = 0
+    sc[mask] = 0                                                        # :40
+    idx[mask] = ident[mask]                                             # :41
+    return result, idx, sc
+
+
 def fused_scale_shift(x, scale, shift, scale_constant=1.0):
     """tests/python/sgl_kernel_npu/test_scale_shift.py:6-11: x * (1 + scale) + shift; with one shift value per element the kernel uses
     scale_constant instead of 1 (norm/scale_shift.py:112 against :60).  fp32, returned in x's dtype."""

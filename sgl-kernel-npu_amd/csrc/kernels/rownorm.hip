@@ -10,6 +10,8 @@
 //   swiglu_oai                     python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai.py:7-104
 //   swiglu_oai_quant               python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai_quant.py:39-211
 //   situ / situ_and_mul(_quant)    python/sgl_kernel_npu/sgl_kernel_npu/activation/situ.py:11-480
+//   mul_add                        python/sgl_kernel_npu/sgl_kernel_npu/moe/mul_add.py:9-60
+//   zero_experts_compute_identity  python/sgl_kernel_npu/sgl_kernel_npu/moe/zero_experts_compute_identity.py:6-81
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
 // on bf16 / fp16: all three element types, arithmetic in fp32 throughout.
 // MI355X design: one wave64 per row, 16-byte loads; a row of up to 8192 16-bit / 4096 fp32 elements stays in registers between the reduction and the
@@ -472,6 +474,67 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     }
 }
 
+// out = routed * factor + shared (moe/mul_add.py:9-36), the shared-expert add behind the MoE combine.  The product is rounded to the I/O
+// dtype before the sum, as the tensor expression `routed * factor + shared` evaluates in that dtype (two roundings).
+template <int DT>
+__global__ __launch_bounds__(256) void mul_add_kernel(const typename Elem<DT>::T *__restrict__ a, const typename Elem<DT>::T *__restrict__ b, float factor,
+                                                      long long numel, typename Elem<DT>::T *__restrict__ out)
+{
+    constexpr int N = Elem<DT>::kPer16;
+    const long long stride = (long long)gridDim.x * 256 * N;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * N; i < numel; i += stride) {
+        if (i + N <= numel) {
+            float x[N], y[N];
+            load16<DT>(a + i, x);
+            load16<DT>(b + i, y);
+#pragma unroll
+            for (int e = 0; e < N; ++e) x[e] = Elem<DT>::ld(Elem<DT>::st(x[e] * factor)) + y[e];
+            store16<DT>(out + i, x);
+        } else {
+            for (long long j = i; j < numel; ++j) out[j] = Elem<DT>::st(Elem<DT>::ld(Elem<DT>::st(Elem<DT>::ld(a[j]) * factor)) + Elem<DT>::ld(b[j]));
+        }
+    }
+}
+
+// "Zero experts" of type identity (moe/zero_experts_compute_identity.py:6-47): the selections of a token that point past the real experts
+// (idx >= num_experts) contribute hidden * (sum of their scales) (:24-25, :35-39); their scales are then cleared and their indices replaced
+// by identity_mask_value -- the first by 0 when ALL K selections were zero experts (:28-31, :40-41).  One wave per token; K <= 64.
+template <int DT, bool I64, int ST>
+__global__ __launch_bounds__(256) void zero_experts_identity_kernel(void *__restrict__ idx, typename Elem<ST>::T *__restrict__ scales, int num_experts,
+                                                                    const typename Elem<DT>::T *__restrict__ hidden, long long tokens, int K, int D,
+                                                                    int identity_mask_value, typename Elem<DT>::T *__restrict__ result)
+{
+    constexpr int N = Elem<DT>::kPer16;
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= tokens) return;
+    long long e = 0;
+    if (lane < K) e = I64 ? ((const long long *)idx)[t * K + lane] : (long long)((const int *)idx)[t * K + lane];
+    const bool zero_expert = lane < K && e >= num_experts;
+    float sc = zero_expert ? Elem<ST>::ld(scales[t * K + lane]) : 0.f;
+    const float sum_scales = wave_sum_f(sc);
+    const bool all_zero = __popcll(__ballot(zero_expert)) == K;
+    const typename Elem<DT>::T *h = hidden + t * (long long)D;
+    typename Elem<DT>::T *r = result + t * (long long)D;
+    if (D % N == 0) {
+        for (int j = lane * N; j < D; j += 64 * N) {
+            float x[N];
+            load16<DT>(h + j, x);
+#pragma unroll
+            for (int q = 0; q < N; ++q) x[q] = x[q] * sum_scales;
+            store16<DT>(r + j, x);
+        }
+    } else {
+        for (int j = lane; j < D; j += 64) r[j] = Elem<DT>::st(Elem<DT>::ld(h[j]) * sum_scales);
+    }
+    if (zero_expert) {
+        scales[t * K + lane] = Elem<ST>::st(0.f);
+        const long long v = (all_zero && lane == 0) ? 0 : (long long)identity_mask_value;
+        if (I64) ((long long *)idx)[t * K + lane] = v;
+        else ((int *)idx)[t * K + lane] = (int)v;
+    }
+}
+
 // out = x * (c + scale) + shift (norm/scale_shift.py:9-183): scale one value or one per column, shift one value, one per column or one per
 // element.  With a per-element shift c = scale_constant (fused_scale_shift_kernel_2, :112), otherwise c = 1.0 whatever scale_constant says
 // (fused_scale_shift_kernel, :60) -- as the reference.  DT = type of x and out, ST = type of scale and shift; fp32 arithmetic.
@@ -682,6 +745,45 @@ extern "C" int mi_situ_and_mul(const void *x, const void *group_list, int group_
     if (dtype == MI_DTYPE_BF16) { if (group_list_is_i64) MI_SITU(MI_DTYPE_BF16, true); else MI_SITU(MI_DTYPE_BF16, false); }
     else { if (group_list_is_i64) MI_SITU(MI_DTYPE_F16, true); else MI_SITU(MI_DTYPE_F16, false); }
 #undef MI_SITU
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_mul_add(const void *routed, const void *shared, float factor, long long numel, int dtype, void *out, void *stream)
+{
+    if (numel < 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16 && dtype != MI_DTYPE_F32)) return MI_SGL_EINVAL;
+    if (numel == 0) return MI_SGL_OK;
+    if (!routed || !shared || !out) return MI_SGL_EINVAL;
+    long long blocks = (numel / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 256 * 32 ? 256 * 32 : blocks);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MI_DTYPE_BF16) mul_add_kernel<MI_DTYPE_BF16><<<(unsigned)blocks, 256, 0, st>>>((const uint16_t *)routed, (const uint16_t *)shared, factor, numel, (uint16_t *)out);
+    else if (dtype == MI_DTYPE_F16) mul_add_kernel<MI_DTYPE_F16><<<(unsigned)blocks, 256, 0, st>>>((const uint16_t *)routed, (const uint16_t *)shared, factor, numel, (uint16_t *)out);
+    else mul_add_kernel<MI_DTYPE_F32><<<(unsigned)blocks, 256, 0, st>>>((const float *)routed, (const float *)shared, factor, numel, (float *)out);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_zero_experts_identity(void *expert_indices, int idx_is_i64, void *expert_scales, int scales_dtype, int num_experts,
+                                        const void *hidden, long long tokens, int K, int D, int identity_mask_value, int dtype, void *result,
+                                        void *stream)
+{
+    if (tokens < 0 || K <= 0 || K > 64 || D <= 0 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) ||
+        (scales_dtype != MI_DTYPE_F32 && scales_dtype != dtype) || tokens > (1ll << 32))
+        return MI_SGL_EINVAL;
+    if (tokens == 0) return MI_SGL_OK;
+    if (!expert_indices || !expert_scales || !hidden || !result) return MI_SGL_EINVAL;
+    const unsigned blocks = (unsigned)((tokens + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+#define MI_ZE(DT, I64, ST)                                                                                                                            \
+    zero_experts_identity_kernel<DT, I64, ST><<<blocks, 256, 0, st>>>(expert_indices, (typename Elem<ST>::T *)expert_scales, num_experts,             \
+                                                                      (const uint16_t *)hidden, tokens, K, D, identity_mask_value, (uint16_t *)result)
+#define MI_ZE2(DT)                                                                                                                \
+    do {                                                                                                                          \
+        if (scales_dtype == MI_DTYPE_F32) { if (idx_is_i64) MI_ZE(DT, true, MI_DTYPE_F32); else MI_ZE(DT, false, MI_DTYPE_F32); } \
+        else { if (idx_is_i64) MI_ZE(DT, true, DT); else MI_ZE(DT, false, DT); }                                                  \
+    } while (0)
+    if (dtype == MI_DTYPE_BF16) MI_ZE2(MI_DTYPE_BF16); else MI_ZE2(MI_DTYPE_F16);
+#undef MI_ZE2
+#undef MI_ZE
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 

@@ -459,6 +459,38 @@ std::tuple<at::Tensor, at::Tensor> situ_and_mul(const at::Tensor &x, const std::
     return {out, scale};
 }
 
+// moe/mul_add.py:38-60
+at::Tensor mul_add(const at::Tensor &routed_input, const at::Tensor &shared_input, double scaling_factor)
+{
+    const c10::DeviceGuard device_guard(routed_input.device());
+    TORCH_CHECK(routed_input.dim() == 2 && routed_input.is_contiguous() && shared_input.is_contiguous() && shared_input.sizes() == routed_input.sizes() &&
+                    shared_input.scalar_type() == routed_input.scalar_type(), "mul_add: two contiguous [batch, hidden] tensors of one dtype");
+    at::Tensor out = at::empty_like(routed_input);
+    const int rc = mi_mul_add(routed_input.data_ptr(), shared_input.data_ptr(), (float)scaling_factor, routed_input.numel(), dtype_code3(routed_input),
+                              out.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_mul_add failed with code ", rc);
+    return out;
+}
+
+// moe/zero_experts_compute_identity.py:50-81 (expert_indices and expert_scales are modified in place)
+at::Tensor zero_experts_compute_identity(at::Tensor &expert_indices, at::Tensor &expert_scales, int64_t num_experts, const at::Tensor &hidden_states,
+                                         int64_t identity_mask_value)
+{
+    const c10::DeviceGuard device_guard(hidden_states.device());
+    TORCH_CHECK(hidden_states.dim() == 2 && hidden_states.is_contiguous() && expert_indices.dim() == 2 && expert_indices.is_contiguous() &&
+                    expert_scales.is_contiguous() && expert_scales.sizes() == expert_indices.sizes() && expert_indices.size(0) == hidden_states.size(0),
+                "zero_experts_compute_identity: hidden [S, D], indices / scales [S, K], all contiguous");
+    TORCH_CHECK(expert_indices.scalar_type() == at::kInt || expert_indices.scalar_type() == at::kLong, "expert_indices must be int32 or int64");
+    TORCH_CHECK(expert_indices.size(1) <= 64, "zero_experts_compute_identity: K <= 64");
+    at::Tensor out = at::empty_like(hidden_states);
+    const int rc = mi_zero_experts_identity(expert_indices.data_ptr(), expert_indices.scalar_type() == at::kLong, expert_scales.data_ptr(),
+                                            dtype_code3(expert_scales), (int)num_experts, hidden_states.data_ptr(), hidden_states.size(0),
+                                            (int)expert_indices.size(1), (int)hidden_states.size(1), (int)identity_mask_value, dtype_code(hidden_states),
+                                            out.data_ptr(), cur_stream());
+    TORCH_CHECK(rc == 0, "mi_zero_experts_identity failed with code ", rc);
+    return out;
+}
+
 // norm/fused_split_qk_norm.py:93-134 (weights / biases of the two layer norms passed as tensors)
 std::tuple<at::Tensor, at::Tensor, at::Tensor> fused_split_qk_norm(const at::Tensor &x, const at::Tensor &q_weight, const std::optional<at::Tensor> &q_bias,
                                                                    const at::Tensor &k_weight, const std::optional<at::Tensor> &k_bias, int64_t q_lora_rank,
@@ -784,6 +816,9 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("situ_and_mul(Tensor x, Tensor? group_list, int? group_list_type, float beta, float? linear_beta, bool need_quant) -> (Tensor, Tensor)");
     m.def("fia_blockq_sparse_prefill(Tensor q, Tensor k_cache, Tensor v_cache, Tensor topk_idx, Tensor seq_lens, Tensor per_query_req, "
           "Tensor req_to_token, int block_size, float sm_scale, Tensor? block_table_out=None, Tensor? actual_kvlen_out=None) -> Tensor");
+    m.def("mul_add(Tensor routed_input, Tensor shared_input, float scaling_factor) -> Tensor");
+    m.def("zero_experts_compute_identity(Tensor(a!) expert_indices, Tensor(b!) expert_scales, int num_experts, Tensor hidden_states, "
+          "int identity_mask_value=0) -> Tensor");
     m.def("swiglu_oai(Tensor hidden_states, int dim, float gemm1_alpha, float gemm1_clamp_limit) -> Tensor");
     m.def("fused_split_qk_norm(Tensor x, Tensor q_weight, Tensor? q_bias, Tensor k_weight, Tensor? k_bias, int q_lora_rank, int kv_lora_rank, "
           "int qk_rope_dim, float eps=1e-6) -> (Tensor, Tensor, Tensor)");
@@ -815,6 +850,8 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("swiglu_oai_quant", TORCH_FN(sglang::npu_kernel::swiglu_oai_quant));
     m.impl("situ_and_mul", TORCH_FN(sglang::npu_kernel::situ_and_mul));
     m.impl("fia_blockq_sparse_prefill", TORCH_FN(sglang::npu_kernel::fia_blockq_sparse_prefill));
+    m.impl("mul_add", TORCH_FN(sglang::npu_kernel::mul_add));
+    m.impl("zero_experts_compute_identity", TORCH_FN(sglang::npu_kernel::zero_experts_compute_identity));
     m.impl("swiglu_oai", TORCH_FN(sglang::npu_kernel::swiglu_oai));
     m.impl("fused_split_qk_norm", TORCH_FN(sglang::npu_kernel::fused_split_qk_norm));
     m.impl("split_qkv_tp_local_var", TORCH_FN(sglang::npu_kernel::split_qkv_tp_local_var));

@@ -443,6 +443,45 @@ def test_situ(rows, cols, mode, linear_beta, dt):
             situ(x.cuda(), glc, 2, need_quant=True)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(4096, 7168), (3, 7), (129, 2880)])
+def test_mul_add(rows, cols, dt):
+    """moe/mul_add.py: routed * factor + shared in the tensors' dtype, bit for bit against the same expression restated in fp32 with the
+    product's rounding made explicit."""
+    from sgl_kernel_npu.moe.mul_add import mul_add
+    torch.manual_seed(rows + cols)
+    a, b = (torch.randn(rows, cols) * 2).to(dt), torch.randn(rows, cols).to(dt)
+    got = mul_add(a.cuda(), b.cuda(), 2.5)
+    assert got.dtype == dt and torch.equal(got.cpu(), OK.mul_add(a, b, 2.5))
+    assert torch.equal(got.cpu(), a * 2.5 + b)                 # ... which is what torch's own evaluation of the expression gives
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("idx_dt", [torch.int32, torch.int64])
+@pytest.mark.parametrize("S,K,D,E,Z", [(257, 8, 7168, 256, 64), (5, 12, 100, 16, 16), (64, 2, 512, 4, 1)])
+def test_zero_experts_compute_identity(S, K, D, E, Z, idx_dt, dt):
+    """moe/zero_experts_compute_identity.py: E real experts + Z zero experts; the result, the cleared scales and the rewritten indices (first
+    one 0 when every selection of a token was a zero expert) against the restated kernel.  Integer effects exactly, the result within one
+    rounding of the I/O dtype (the K scales are summed in another order)."""
+    from sgl_kernel_npu.moe.zero_experts_compute_identity import zero_experts_compute_identity_triton
+    torch.manual_seed(S + K + D)
+    idx = torch.randint(0, E + Z, (S, K)).to(idx_dt)
+    idx[0] = torch.arange(E, E + K) % (E + Z) if Z >= K else E          # a token whose selections are all zero experts
+    idx[0] = torch.clamp(idx[0], min=E)
+    if S > 1:
+        idx[1] = torch.arange(K) % E                                    # ... and one with none
+    scales = torch.rand(S, K)
+    hidden = torch.randn(S, D).to(dt)
+    want, widx, wsc = OK.zero_experts_compute_identity(idx, scales, E, hidden, identity_mask_value=7)
+    gidx, gsc = idx.cuda(), scales.cuda()
+    got = zero_experts_compute_identity_triton(gidx, gsc, E, "identity", hidden.cuda(), identity_mask_value=7)
+    assert torch.equal(gidx.cpu(), widx) and torch.equal(gsc.cpu(), wsc)
+    assert int(widx[0, 0]) == 0 and (widx[0, 1:] == 7).all()
+    tol = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    assert torch.allclose(got.cpu().float(), want.float(), rtol=tol, atol=1e-6)
+    assert (got.cpu()[1] == 0).all() if S > 1 else True
+
+
 def test_split_qkv_rmsnorm_rope_pos_cache_half_replays_in_a_captured_graph():
     """The reference test replays the op in a captured device graph with new inputs in the same buffers
     (test_split_qkv_rmsnorm_rope_pos_cache_half_npu.py:213-260): positions are clamped inside the kernel, nothing synchronises."""
