@@ -536,6 +536,17 @@ def situ_and_mul(x, beta=4.0, linear_beta=25.0, need_quant=False, total_rows=Non
     return q.reshape(*x.shape[:-1], half), scale
 
 
+def attn_residual_mix(prefix_sum, bank, num_valid_blocks, combined_weight, eps):
+    """Restates _mix_fused_kernel (kimi_k3/attn_residual.py:27-63) in fp32: rows = bank[:, :B] then the prefix row; score = sum(row *
+    rsqrt(mean(row^2) + eps) * combined_weight) (:40-41), softmax over the B + 1 scores (:43-45), out = sum_r p_r row_r (:47-59).  PARITY
+    UNPINNED (no reference test)."""
+    rows = torch.cat([bank[:, :num_valid_blocks].float(), prefix_sum[:, None].float()], dim=1)          # [T, B + 1, H]
+    inv = torch.rsqrt((rows * rows).sum(dim=-1) / rows.shape[-1] + eps)
+    scores = ((rows * inv[..., None]) * combined_weight.float()).sum(dim=-1)
+    p = torch.softmax(scores, dim=-1)
+    return (p[..., None] * rows).sum(dim=1).to(prefix_sum.dtype)
+
+
 def mul_add(routed, shared, factor):
     """moe/mul_add.py:24-26: routed * factor + shared evaluated in the tensors' dtype (the product is rounded before the sum).  PARITY
     UNPINNED (no reference test)."""

@@ -10,6 +10,7 @@
 //   swiglu_oai                     python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai.py:7-104
 //   swiglu_oai_quant               python/sgl_kernel_npu/sgl_kernel_npu/activation/swiglu_oai_quant.py:39-211
 //   situ / situ_and_mul(_quant)    python/sgl_kernel_npu/sgl_kernel_npu/activation/situ.py:11-480
+//   mix_fused (attn residual)      python/sgl_kernel_npu/sgl_kernel_npu/kimi_k3/attn_residual.py:7-111
 //   mul_add                        python/sgl_kernel_npu/sgl_kernel_npu/moe/mul_add.py:9-60
 //   zero_experts_compute_identity  python/sgl_kernel_npu/sgl_kernel_npu/moe/zero_experts_compute_identity.py:6-81
 // The reference tests run them on fp32 tensors (tests/python/sgl_kernel_npu/test_{l1_norm,rmsnorm_without_weight,rmsnorm_split}.py), models
@@ -474,6 +475,83 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
     }
 }
 
+// Kimi-K3 attention residual (kimi_k3/attn_residual.py:7-63): per token, B bank rows and the prefix row are scored -- score = sum(row *
+// rsqrt(mean(row^2) + eps) * combined_weight) (:40-41) --, the scores go through a softmax (:43-45) and the output is the probability-
+// weighted sum of the same rows (:47-59).  One wave per token; a row stays in registers between its two reductions (H <= 8192), the rows
+// are read a second time (out of L2) for the mix.  WT = type of combined_weight.
+template <int DT, int WT>
+__global__ __launch_bounds__(64) void attn_residual_mix_kernel(const typename Elem<DT>::T *__restrict__ prefix, long long stride_pm,
+                                                               const typename Elem<DT>::T *__restrict__ bank, long long stride_bm, long long stride_bb,
+                                                               const typename Elem<WT>::T *__restrict__ cw, int B, int H, float eps,
+                                                               typename Elem<DT>::T *__restrict__ out, long long stride_om)
+{
+    typedef typename Elem<DT>::T T;
+    constexpr int N = Elem<DT>::kPer16, kChunks = 16;
+    const int lane = threadIdx.x;
+    const long long t = blockIdx.x;
+    auto row_ptr = [&](int r) -> const T * { return r < B ? bank + t * stride_bm + r * stride_bb : prefix + t * stride_pm; };
+    float my_score = -INFINITY;                              // lane r keeps the score of row r
+    for (int r = 0; r <= B; ++r) {
+        const T *rp = row_ptr(r);
+        float v[kChunks][N];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int j = (c * 64 + lane) * N;
+            if (c * 64 * N < H) {                            // (wave-uniform)
+                load16<DT>(rp + min(j, H - N), v[c]);
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    if (j >= H) v[c][e] = 0.f;
+                    ss += v[c][e] * v[c][e];
+                }
+            }
+        }
+        const float inv = rsqrtf(wave_sum_f(ss) / (float)H + eps);
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int j = (c * 64 + lane) * N;
+            if (c * 64 * N < H && j < H) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) dot += (v[c][e] * inv) * Elem<WT>::ld(cw[j + e]);
+            }
+        }
+        dot = wave_sum_f(dot);
+        if (lane == r) my_score = dot;
+    }
+    float mx = my_score;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float ex = lane <= B ? __expf(my_score - mx) : 0.f;
+    const float prob = ex / wave_sum_f(ex);
+    float acc[kChunks][N];
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c)
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[c][e] = 0.f;
+    for (int r = 0; r <= B; ++r) {
+        const T *rp = row_ptr(r);
+        const float p = __shfl(prob, r, 64);
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int j = (c * 64 + lane) * N;
+            if (c * 64 * N < H) {
+                float v[N];
+                load16<DT>(rp + min(j, H - N), v);
+#pragma unroll
+                for (int e = 0; e < N; ++e) acc[c][e] += p * v[e];
+            }
+        }
+    }
+    T *o = out + t * stride_om;
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        const int j = (c * 64 + lane) * N;
+        if (c * 64 * N < H && j < H) store16<DT>(o + j, acc[c]);
+    }
+}
+
 // out = routed * factor + shared (moe/mul_add.py:9-36), the shared-expert add behind the MoE combine.  The product is rounded to the I/O
 // dtype before the sum, as the tensor expression `routed * factor + shared` evaluates in that dtype (two roundings).
 template <int DT>
@@ -745,6 +823,26 @@ extern "C" int mi_situ_and_mul(const void *x, const void *group_list, int group_
     if (dtype == MI_DTYPE_BF16) { if (group_list_is_i64) MI_SITU(MI_DTYPE_BF16, true); else MI_SITU(MI_DTYPE_BF16, false); }
     else { if (group_list_is_i64) MI_SITU(MI_DTYPE_F16, true); else MI_SITU(MI_DTYPE_F16, false); }
 #undef MI_SITU
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+extern "C" int mi_attn_residual_mix(const void *prefix_sum, long long stride_pm, const void *bank, long long stride_bm, long long stride_bb,
+                                    const void *combined_weight, int weight_dtype, long long tokens, int num_valid_blocks, int hidden, float eps,
+                                    int dtype, void *out, long long stride_om, void *stream)
+{
+    if (tokens < 0 || tokens >= (1ll << 31) || num_valid_blocks < 0 || num_valid_blocks > 63 || hidden <= 0 || hidden % 8 || hidden > 8192 ||
+        (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || (weight_dtype != dtype && weight_dtype != MI_DTYPE_F32))
+        return MI_SGL_EINVAL;
+    if (tokens == 0) return MI_SGL_OK;
+    if (!prefix_sum || (!bank && num_valid_blocks > 0) || !combined_weight || !out) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_AR(DT, WT)                                                                                                                         \
+    attn_residual_mix_kernel<DT, WT><<<(unsigned)tokens, 64, 0, st>>>((const uint16_t *)prefix_sum, stride_pm, (const uint16_t *)bank, stride_bm, \
+                                                                      stride_bb, (const typename Elem<WT>::T *)combined_weight, num_valid_blocks,  \
+                                                                      hidden, eps, (uint16_t *)out, stride_om)
+    if (dtype == MI_DTYPE_BF16) { if (weight_dtype == MI_DTYPE_F32) MI_AR(MI_DTYPE_BF16, MI_DTYPE_F32); else MI_AR(MI_DTYPE_BF16, MI_DTYPE_BF16); }
+    else { if (weight_dtype == MI_DTYPE_F32) MI_AR(MI_DTYPE_F16, MI_DTYPE_F32); else MI_AR(MI_DTYPE_F16, MI_DTYPE_F16); }
+#undef MI_AR
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 

@@ -459,6 +459,24 @@ std::tuple<at::Tensor, at::Tensor> situ_and_mul(const at::Tensor &x, const std::
     return {out, scale};
 }
 
+// kimi_k3/attn_residual.py:66-111
+at::Tensor attn_residual_mix(const at::Tensor &prefix_sum, const at::Tensor &bank, int64_t num_valid_blocks, const at::Tensor &combined_weight,
+                             double variance_epsilon)
+{
+    const c10::DeviceGuard device_guard(prefix_sum.device());
+    TORCH_CHECK(prefix_sum.dim() == 2 && bank.dim() == 3 && prefix_sum.stride(1) == 1 && bank.stride(2) == 1 && bank.size(0) == prefix_sum.size(0) &&
+                    bank.size(2) == prefix_sum.size(1) && bank.scalar_type() == prefix_sum.scalar_type(),
+                "mix_fused: prefix_sum [tokens, hidden], bank [tokens, blocks, hidden], hidden contiguous, one dtype");
+    TORCH_CHECK(combined_weight.numel() == prefix_sum.size(1) && combined_weight.is_contiguous(), "mix_fused: combined_weight [hidden]");
+    at::Tensor out = at::empty_like(prefix_sum, at::MemoryFormat::Contiguous);
+    const int rc = mi_attn_residual_mix(prefix_sum.data_ptr(), prefix_sum.stride(0), bank.data_ptr(), bank.stride(0), bank.stride(1),
+                                        combined_weight.data_ptr(), dtype_code3(combined_weight), prefix_sum.size(0), (int)num_valid_blocks,
+                                        (int)prefix_sum.size(1), (float)variance_epsilon, dtype_code(prefix_sum), out.data_ptr(), out.stride(0),
+                                        cur_stream());
+    TORCH_CHECK(rc == 0, "mi_attn_residual_mix failed with code ", rc, " (hidden % 8 == 0, <= 8192; at most 63 blocks)");
+    return out;
+}
+
 // moe/mul_add.py:38-60
 at::Tensor mul_add(const at::Tensor &routed_input, const at::Tensor &shared_input, double scaling_factor)
 {
@@ -816,6 +834,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("situ_and_mul(Tensor x, Tensor? group_list, int? group_list_type, float beta, float? linear_beta, bool need_quant) -> (Tensor, Tensor)");
     m.def("fia_blockq_sparse_prefill(Tensor q, Tensor k_cache, Tensor v_cache, Tensor topk_idx, Tensor seq_lens, Tensor per_query_req, "
           "Tensor req_to_token, int block_size, float sm_scale, Tensor? block_table_out=None, Tensor? actual_kvlen_out=None) -> Tensor");
+    m.def("attn_residual_mix(Tensor prefix_sum, Tensor bank, int num_valid_blocks, Tensor combined_weight, float variance_epsilon) -> Tensor");
     m.def("mul_add(Tensor routed_input, Tensor shared_input, float scaling_factor) -> Tensor");
     m.def("zero_experts_compute_identity(Tensor(a!) expert_indices, Tensor(b!) expert_scales, int num_experts, Tensor hidden_states, "
           "int identity_mask_value=0) -> Tensor");
@@ -850,6 +869,7 @@ TORCH_LIBRARY_IMPL(npu, CUDA, m)
     m.impl("swiglu_oai_quant", TORCH_FN(sglang::npu_kernel::swiglu_oai_quant));
     m.impl("situ_and_mul", TORCH_FN(sglang::npu_kernel::situ_and_mul));
     m.impl("fia_blockq_sparse_prefill", TORCH_FN(sglang::npu_kernel::fia_blockq_sparse_prefill));
+    m.impl("attn_residual_mix", TORCH_FN(sglang::npu_kernel::attn_residual_mix));
     m.impl("mul_add", TORCH_FN(sglang::npu_kernel::mul_add));
     m.impl("zero_experts_compute_identity", TORCH_FN(sglang::npu_kernel::zero_experts_compute_identity));
     m.impl("swiglu_oai", TORCH_FN(sglang::npu_kernel::swiglu_oai));

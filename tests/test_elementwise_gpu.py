@@ -443,6 +443,28 @@ def test_situ(rows, cols, mode, linear_beta, dt):
             situ(x.cuda(), glc, 2, need_quant=True)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,blocks,B,H,wdt", [(130, 8, 8, 7168, torch.float32), (17, 6, 3, 2048, None), (5, 4, 0, 64, None), (3, 70, 63, 8192, torch.float32)])
+def test_attn_residual_mix(T, blocks, B, H, wdt, dt):
+    """kimi_k3/attn_residual.py::mix_fused against the fp32 restatement: scores, softmax and mix in fp32, one rounding at the end -- within one
+    step of the I/O dtype relative to the row's largest value.  Includes no bank rows at all (the output is the prefix row) and a strided bank."""
+    from sgl_kernel_npu.kimi_k3.attn_residual import mix_fused
+    torch.manual_seed(T + H)
+    prefix = torch.randn(T, H).to(dt)
+    bank_full = torch.randn(T, blocks + 1, H).to(dt)
+    bank = bank_full[:, 1:]                                               # token stride (blocks + 1) * H: not the dense layout
+    cw = (torch.randn(H) * 0.05).to(wdt or dt)
+    want = OK.attn_residual_mix(prefix, bank, B, cw, 1e-6)
+    got = mix_fused(prefix.cuda(), bank_full.cuda()[:, 1:], B, cw.cuda(), 1e-6)
+    tol = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    err = (got.cpu().float() - want.float()).abs()
+    assert bool((err <= tol * want.float().abs().amax(dim=-1, keepdim=True) + 1e-6).all()), float(err.max())
+    if B == 0:
+        assert torch.equal(got.cpu(), prefix)
+    with pytest.raises(ValueError):
+        mix_fused(prefix.cuda(), bank.cuda(), blocks + 1, cw.cuda(), 1e-6)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("rows,cols", [(4096, 7168), (3, 7), (129, 2880)])
 def test_mul_add(rows, cols, dt):
