@@ -182,7 +182,7 @@ int mi_situ_and_mul(const void *x, const void *group_list, int group_list_is_i64
                     float beta, float linear_beta, int need_quant, int dtype, void *out, float *scale, void *stream);
 /* Kimi-K3 attention residual (kimi_k3/attn_residual.py:7-111): per token the num_valid_blocks bank rows and the prefix row are scored
  * (sum(rmsnorm(row) * combined_weight)), soft-maxed and mixed: out = sum_r p_r row_r.  prefix_sum [tokens, hidden], bank [tokens, blocks,
- * hidden], out [tokens, hidden] (row strides in elements, hidden contiguous; hidden % 8 == 0, <= 8192; num_valid_blocks <= 63);
+ * hidden], out [tokens, hidden] (row strides in elements, hidden contiguous; hidden % 8 == 0; num_valid_blocks <= 63);
  * combined_weight [hidden] in the I/O dtype or fp32. */
 int mi_attn_residual_mix(const void *prefix_sum, long long stride_pm, const void *bank, long long stride_bm, long long stride_bb,
                          const void *combined_weight, int weight_dtype, long long tokens, int num_valid_blocks, int hidden, float eps, int dtype,

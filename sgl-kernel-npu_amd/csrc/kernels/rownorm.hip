@@ -477,78 +477,91 @@ __global__ __launch_bounds__(256) void swiglu_oai_quant_kernel(const typename El
 
 // Kimi-K3 attention residual (kimi_k3/attn_residual.py:7-63): per token, B bank rows and the prefix row are scored -- score = sum(row *
 // rsqrt(mean(row^2) + eps) * combined_weight) (:40-41) --, the scores go through a softmax (:43-45) and the output is the probability-
-// weighted sum of the same rows (:47-59).  One wave per token; a row stays in registers between its two reductions (H <= 8192), the rows
-// are read a second time (out of L2) for the mix.  WT = type of combined_weight.
+// weighted sum of the same rows (:47-59).  One wave per token, four tokens per workgroup; the rows are read a second time (out of L2) for the
+// mix.  WT = type of combined_weight.
+// sum over the 64 lanes on DPP (row_shr inside the rows of 16, row_bcast:15 / :31 across them; total in lane 63) instead of six
+// ds_bpermute round trips: two reductions per bank row sit on this kernel's critical path
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+#define MI_DPP_ADD(CTRL, ROWS) v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, ROWS, 0xf, false))
+    MI_DPP_ADD(0x111, 0xf);
+    MI_DPP_ADD(0x112, 0xf);
+    MI_DPP_ADD(0x114, 0xf);
+    MI_DPP_ADD(0x118, 0xf);
+    MI_DPP_ADD(0x142, 0xa);
+    MI_DPP_ADD(0x143, 0xc);
+#undef MI_DPP_ADD
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+
 template <int DT, int WT>
-__global__ __launch_bounds__(64) void attn_residual_mix_kernel(const typename Elem<DT>::T *__restrict__ prefix, long long stride_pm,
-                                                               const typename Elem<DT>::T *__restrict__ bank, long long stride_bm, long long stride_bb,
-                                                               const typename Elem<WT>::T *__restrict__ cw, int B, int H, float eps,
-                                                               typename Elem<DT>::T *__restrict__ out, long long stride_om)
+__global__ __launch_bounds__(256) void attn_residual_mix_kernel(const typename Elem<DT>::T *__restrict__ prefix, long long stride_pm,
+                                                                const typename Elem<DT>::T *__restrict__ bank, long long stride_bm, long long stride_bb,
+                                                                const typename Elem<WT>::T *__restrict__ cw, long long tokens, int B, int H, float eps,
+                                                                typename Elem<DT>::T *__restrict__ out, long long stride_om)
 {
     typedef typename Elem<DT>::T T;
-    constexpr int N = Elem<DT>::kPer16, kChunks = 16;
-    const int lane = threadIdx.x;
-    const long long t = blockIdx.x;
+    constexpr int N = Elem<DT>::kPer16, kBatch = 4;          // 16-byte pieces requested together
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= tokens) return;
     auto row_ptr = [&](int r) -> const T * { return r < B ? bank + t * stride_bm + r * stride_bb : prefix + t * stride_pm; };
+    const int nchunks = (H + 64 * N - 1) / (64 * N);
+    // pass 1: per row, sum of squares and sum(row * weight) in one sweep (score = rsqrt(mean + eps) * sum(row * weight): the row-wide factor
+    // taken out of the sum, so that no row has to be held); loads in batches of four pieces, index clamped, contributions masked
     float my_score = -INFINITY;                              // lane r keeps the score of row r
     for (int r = 0; r <= B; ++r) {
         const T *rp = row_ptr(r);
-        float v[kChunks][N];
-        float ss = 0.f;
+        float ss = 0.f, dot = 0.f;
+        for (int c0 = 0; c0 < nchunks; c0 += kBatch) {
+            u32x4 raw[kBatch];
 #pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const int j = (c * 64 + lane) * N;
-            if (c * 64 * N < H) {                            // (wave-uniform)
-                load16<DT>(rp + min(j, H - N), v[c]);
+            for (int b = 0; b < kBatch; ++b) raw[b] = *(const u32x4 *)(rp + min(((c0 + b) * 64 + lane) * N, H - N));
 #pragma unroll
-                for (int e = 0; e < N; ++e) {
-                    if (j >= H) v[c][e] = 0.f;
-                    ss += v[c][e] * v[c][e];
+            for (int b = 0; b < kBatch; ++b) {
+                const int j = ((c0 + b) * 64 + lane) * N;
+                if (j < H) {
+                    float v[N];
+                    unpack16<DT>(raw[b], v);
+#pragma unroll
+                    for (int e = 0; e < N; ++e) {
+                        ss += v[e] * v[e];
+                        dot += v[e] * Elem<WT>::ld(cw[j + e]);
+                    }
                 }
             }
         }
-        const float inv = rsqrtf(wave_sum_f(ss) / (float)H + eps);
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const int j = (c * 64 + lane) * N;
-            if (c * 64 * N < H && j < H) {
-#pragma unroll
-                for (int e = 0; e < N; ++e) dot += (v[c][e] * inv) * Elem<WT>::ld(cw[j + e]);
-            }
-        }
-        dot = wave_sum_f(dot);
-        if (lane == r) my_score = dot;
+        const float score = wave_sum_dpp(dot) * rsqrtf(wave_sum_dpp(ss) / (float)H + eps);
+        if (lane == r) my_score = score;
     }
     float mx = my_score;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     const float ex = lane <= B ? __expf(my_score - mx) : 0.f;
-    const float prob = ex / wave_sum_f(ex);
-    float acc[kChunks][N];
+    const float prob = ex / wave_sum_dpp(ex);
+    // pass 2: piece by piece, the B + 1 rows of a piece mixed into eight accumulators (the rows come out of L2 this time)
+    T *o = out + t * stride_om;
+    for (int c = 0; c < nchunks; ++c) {
+        const int j = (c * 64 + lane) * N, jc = min(j, H - N);
+        float acc[N];
 #pragma unroll
-    for (int c = 0; c < kChunks; ++c)
+        for (int e = 0; e < N; ++e) acc[e] = 0.f;
+        for (int r0 = 0; r0 <= B; r0 += kBatch) {
+            u32x4 raw[kBatch];
 #pragma unroll
-        for (int e = 0; e < N; ++e) acc[c][e] = 0.f;
-    for (int r = 0; r <= B; ++r) {
-        const T *rp = row_ptr(r);
-        const float p = __shfl(prob, r, 64);
+            for (int b = 0; b < kBatch; ++b) raw[b] = *(const u32x4 *)(row_ptr(min(r0 + b, B)) + jc);
 #pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const int j = (c * 64 + lane) * N;
-            if (c * 64 * N < H) {
-                float v[N];
-                load16<DT>(rp + min(j, H - N), v);
+            for (int b = 0; b < kBatch; ++b) {
+                if (r0 + b <= B) {                           // (wave-uniform)
+                    const float p = __shfl(prob, r0 + b, 64);
+                    float v[N];
+                    unpack16<DT>(raw[b], v);
 #pragma unroll
-                for (int e = 0; e < N; ++e) acc[c][e] += p * v[e];
+                    for (int e = 0; e < N; ++e) acc[e] += p * v[e];
+                }
             }
         }
-    }
-    T *o = out + t * stride_om;
-#pragma unroll
-    for (int c = 0; c < kChunks; ++c) {
-        const int j = (c * 64 + lane) * N;
-        if (c * 64 * N < H && j < H) store16<DT>(o + j, acc[c]);
+        if (j < H) store16<DT>(o + j, acc);
     }
 }
 
@@ -830,16 +843,16 @@ extern "C" int mi_attn_residual_mix(const void *prefix_sum, long long stride_pm,
                                     const void *combined_weight, int weight_dtype, long long tokens, int num_valid_blocks, int hidden, float eps,
                                     int dtype, void *out, long long stride_om, void *stream)
 {
-    if (tokens < 0 || tokens >= (1ll << 31) || num_valid_blocks < 0 || num_valid_blocks > 63 || hidden <= 0 || hidden % 8 || hidden > 8192 ||
+    if (tokens < 0 || tokens >= (1ll << 31) || num_valid_blocks < 0 || num_valid_blocks > 63 || hidden <= 0 || hidden % 8 ||
         (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || (weight_dtype != dtype && weight_dtype != MI_DTYPE_F32))
         return MI_SGL_EINVAL;
     if (tokens == 0) return MI_SGL_OK;
     if (!prefix_sum || (!bank && num_valid_blocks > 0) || !combined_weight || !out) return MI_SGL_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define MI_AR(DT, WT)                                                                                                                         \
-    attn_residual_mix_kernel<DT, WT><<<(unsigned)tokens, 64, 0, st>>>((const uint16_t *)prefix_sum, stride_pm, (const uint16_t *)bank, stride_bm, \
-                                                                      stride_bb, (const typename Elem<WT>::T *)combined_weight, num_valid_blocks,  \
-                                                                      hidden, eps, (uint16_t *)out, stride_om)
+    attn_residual_mix_kernel<DT, WT><<<(unsigned)((tokens + 3) / 4), 256, 0, st>>>((const uint16_t *)prefix_sum, stride_pm, (const uint16_t *)bank,  \
+                                                                                   stride_bm, stride_bb, (const typename Elem<WT>::T *)combined_weight, \
+                                                                                   tokens, num_valid_blocks, hidden, eps, (uint16_t *)out, stride_om)
     if (dtype == MI_DTYPE_BF16) { if (weight_dtype == MI_DTYPE_F32) MI_AR(MI_DTYPE_BF16, MI_DTYPE_F32); else MI_AR(MI_DTYPE_BF16, MI_DTYPE_BF16); }
     else { if (weight_dtype == MI_DTYPE_F32) MI_AR(MI_DTYPE_F16, MI_DTYPE_F32); else MI_AR(MI_DTYPE_F16, MI_DTYPE_F16); }
 #undef MI_AR

@@ -473,7 +473,7 @@ at::Tensor attn_residual_mix(const at::Tensor &prefix_sum, const at::Tensor &ban
                                         combined_weight.data_ptr(), dtype_code3(combined_weight), prefix_sum.size(0), (int)num_valid_blocks,
                                         (int)prefix_sum.size(1), (float)variance_epsilon, dtype_code(prefix_sum), out.data_ptr(), out.stride(0),
                                         cur_stream());
-    TORCH_CHECK(rc == 0, "mi_attn_residual_mix failed with code ", rc, " (hidden % 8 == 0, <= 8192; at most 63 blocks)");
+    TORCH_CHECK(rc == 0, "mi_attn_residual_mix failed with code ", rc, " (hidden % 8 == 0; at most 63 blocks)");
     return out;
 }
 

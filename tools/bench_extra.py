@@ -127,6 +127,16 @@ def main():
     t = ev_time(lambda: flash_prefill_bnsd_blockq_sparse_fia(qf, kf, vf, tki[None], sl, reqs, rtt, bsz, None, pages_f, tk1), n=20, warm=3)
     out["fia_blockq_sparse_prefill_4096q_h16_d128_top16x128"] = dict(t, keys_per_query=(tk1 - 1) * bsz + bsz // 2,
                                                                        note="duplicate block ids allowed in this synthetic selection; KV read per query from L2 / MALL")
+    from sgl_kernel_npu.moe.mul_add import mul_add
+    from sgl_kernel_npu.kimi_k3.attn_residual import mix_fused
+    ra, rb = torch.randn((16384, 7168), generator=g, device="cuda").to(torch.bfloat16), torch.randn((16384, 7168), generator=g, device="cuda").to(torch.bfloat16)
+    t = ev_time(lambda: mul_add(ra, rb, 2.5))
+    out["mul_add_16384x7168_bf16"] = dict(t, GBps=16384 * 7168 * 6 / t["p50_us"] / 1e3)
+    pf, bk = torch.randn((4096, 7168), generator=g, device="cuda").to(torch.bfloat16), torch.randn((4096, 8, 7168), generator=g, device="cuda").to(torch.bfloat16)
+    cwv = torch.randn(7168, generator=g, device="cuda") * 0.05
+    t = ev_time(lambda: mix_fused(pf, bk, 8, cwv, 1e-6))
+    out["attn_residual_mix_4096tok_8blocks_h7168_bf16"] = dict(t, GBps=4096 * 7168 * 2 * (9 + 1) / t["p50_us"] / 1e3,
+                                                              note="algorithmic bytes: nine rows read once + the output; the rows are read a second time out of L2")
     from sgl_kernel_npu.activation.situ import situ_and_mul, situ_and_mul_quant
     xs = torch.randn((16384, 12288), generator=g, device="cuda").to(torch.bfloat16)      # d = 6144: the largest the quantising form takes
     t = ev_time(lambda: situ_and_mul_quant(xs))
