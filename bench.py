@@ -60,6 +60,29 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch_command(args, environ):
+    """The driver starts N > 1 through `python -m torch.distributed.run ... bench.py --gpus N ...` (RANK / WORLD_SIZE set), but a plain
+    `python bench.py --gpus N` must produce the same line instead of waiting in a rendezvous nobody else joins: when --gpus N > 1 and
+    the environment carries no RANK, this process re-executes itself through torch.distributed.run, one rank per GPU.  `--dry-run-8` is
+    the same re-execution with every rank on cuda:0 (BENCH_SINGLE_DEVICE=1).  -> (argv, env) to exec, or None to run in this process."""
+    if "RANK" in environ:
+        return None                                   # already a rank of a launcher (the driver's, or our own re-execution)
+    n = 8 if args.dry_run_8 else args.gpus
+    if n <= 1:
+        return None
+    env = dict(environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if args.dry_run_8:
+        env["BENCH_SINGLE_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--tokens", str(args.tokens), "--strategy", args.strategy]
+    for flag, on in (("--dry-run-8", args.dry_run_8), ("--no-extra", args.no_extra), ("--no-mla", args.no_mla),
+                     ("--no-cpu-baseline", args.no_cpu_baseline)):
+        if on:
+            cmd.append(flag)
+    return cmd, env
+
+
 def init_dist(n):
     if n > 1 or "RANK" in os.environ:
         rank = int(os.environ.get("RANK", 0))
@@ -236,6 +259,45 @@ def kernel_bytes(name, T, K, H, n_pairs, n_recv, n_tok_rank, n_local=0, n_local_
         "combine_push": 2 * (n_recv - n_local) * H * 2 + n_recv * 12 + n_local * 4,   # rows read and written into the owners' slots
         "combine_reduce": n_pairs * H * 2 + T * H * 2,          # read K slots per token, write one bf16 row
     }[name]
+
+
+def xgmi_projection(pairs_to, tokens_to, kernels_us, small_us, hidden, ep=8, me=0):
+    """What an EP = `ep` rank should reach on xGMI, stated BEFORE the first multi-GPU run (N = 1 line): this rank's routing as if its
+    256 experts were spread over `ep` ranks (pairs_to / tokens_to from routing_stats(topk_idx, ep, me); by symmetry the rows it
+    receives from peer s ~ the pairs it sends to s), the cross-GPU bytes of each leg (push dispatch = one
+    (H+16)-byte row per (token, destination rank) + 8 B per pair; combine = one 2H-byte row per remote selection), the time those
+    bytes need on (ep-1) links of 153 GB/s -- and on the busiest single link --, and the HBM-side kernel times of `ep8_proxy`
+    (every row taking the remote-row code path on this GPU).  Per leg the projection is max(HBM-side kernel, busiest link);
+    the step is the sum of the legs + the kernels that stay local + the small launches.  Pure arithmetic on host integers."""
+    row = hidden + 16
+    peers = [d for d in range(ep) if d != me]
+    disp_link = [tokens_to[d] * row + pairs_to[d] * 8 for d in peers]
+    comb_link = [pairs_to[d] * hidden * 2 for d in peers]
+    peak = XGMI_LINK_GBPS * (ep - 1)
+    us = lambda b, gbps: b / gbps / 1e3
+    legs = {}
+    for name, link, kern in (("dispatch_push", disp_link, "dispatch_stage"), ("combine_push", comb_link, "combine_push")):
+        k_us = kernels_us.get(kern) or kernels_us.get(kern + "_push") or 0.0
+        all_links_us, max_link_us = us(sum(link), peak), us(max(link), XGMI_LINK_GBPS)
+        legs[name] = {"cross_gpu_bytes": int(sum(link)), "max_link_bytes": int(max(link)), "all_links_us": all_links_us,
+                      "busiest_link_us": max_link_us, "hbm_side_kernel_us": k_us, "projected_us": max(k_us, max_link_us),
+                      "bound": "xgmi" if max_link_us > k_us else "hbm"}
+    local_us = sum(kernels_us.get(k, 0.0) for k in ("dispatch_pull", "combine_reduce"))
+    small = sum(small_us.values())
+    step_us = sum(l["projected_us"] for l in legs.values()) + local_us + small
+    cross = sum(l["cross_gpu_bytes"] for l in legs.values())
+    link_us = sum(l["busiest_link_us"] for l in legs.values())
+    n_rows = sum(pairs_to)
+    return {"ep": ep, "link_GBps": XGMI_LINK_GBPS, "links": ep - 1, "peak_GBps": peak, "legs": legs,
+            "local_kernels_us": local_us, "small_launches_us": small, "projected_step_ms": step_us / 1e3,
+            # reference convention (BF16-equivalent received rows, dispatch + combine) per GPU at the projected step
+            "projected_value_GBps_per_gpu": 2 * n_rows * hidden * 2 / (step_us * 1e-6) / 1e9,
+            # cross-GPU bytes over the time the two link-facing legs are projected to take: the figure north_star's ">= 70 % of per-GPU
+            # xGMI peak" is read against; 1.0 would mean both legs run at the busiest link's rate with nothing else in the way
+            "projected_xgmi_frac_during_legs": cross / (sum(l["projected_us"] for l in legs.values()) * 1e-6) / 1e9 / peak,
+            "link_bound_floor_ms": link_us / 1e3, "target_frac": 0.70,
+            "assumes": "push dispatch transport; remote stores keep all 7 links busy concurrently (rows dealt to peers by the "
+                       "MI_EP_PUSH_STRIDE deal); HBM-side kernel times from ep8_proxy on this GPU; unmeasured on xGMI"}
 
 
 # (N = 1: every received row is one of this rank's own tokens, so the whole pull is the token-wise pull_local_kernel)
@@ -567,12 +629,9 @@ def timed_steps(buf, x, topk_idx, topk_w, y, steps, warmup, profiled):
 
 def main():
     args = parse()
-    if args.dry_run_8 and "RANK" not in os.environ:
-        env = dict(os.environ, BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-               "--master-port", str(29600 + os.getpid() % 300), os.path.abspath(__file__), "--gpus", "8", "--steps", str(args.steps),
-               "--warmup", str(args.warmup), "--tokens", str(args.tokens), "--dry-run-8"] + (["--no-extra"] if args.no_extra else [])
-        os.execvpe(cmd[0], cmd, env)
+    relaunch = self_launch_command(args, os.environ)
+    if relaunch is not None:
+        os.execvpe(relaunch[0][0], relaunch[0], relaunch[1])
     rank, world = init_dist(args.gpus)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import deep_ep
@@ -733,6 +792,10 @@ def main():
             proxy["what"] = ("own-rank shortcuts off (set_local_row_paths(False, False)): every row staged, pulled by index and pushed "
                              "through the window like a remote row; HBM-side kernel times of an EP = 8 rank, xGMI legs not included")
         result["ep8_proxy"] = proxy
+    if world == 1 and proxy is not None and "kernels" in proxy:
+        p8, t8 = routing_stats(topk_idx, 8, 0)
+        result["xgmi_projection"] = xgmi_projection(p8, t8, {k: v["avg_us"] for k, v in proxy["kernels"].items()},
+                                                    proxy.get("small_launches_us", {}), HIDDEN)
     if args.dry_run_8:
         result["dry_run_single_device"] = True       # every rank ran on cuda:0: plumbing only, not a measurement
     result.update(extra)

@@ -22,8 +22,10 @@ def _last_json(stdout):
 @pytest.mark.timeout(600)
 def test_bench_two_ranks_one_gpu():
     env = dict(os.environ, BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    # plain `python bench.py --gpus 2`, no RANK in the environment: bench.py re-executes itself through torch.distributed.run (the
+    # launch line the driver uses for N > 1), so this one call covers the self-launch AND the launcher form
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -57,6 +59,10 @@ def test_bench_single_gpu_line():
     px = d["ep8_proxy"]
     assert px["ms_per_step"] > d["ms_per_step"] and {"dispatch_pull", "combine_push", "combine_reduce"} <= set(px["kernels"])
     assert px["kernels"]["combine_push"]["algorithmic_bytes"] > 9e8
+    # the stated expectation for the first EP = 8 run: per-leg cross-GPU bytes, link-bound time, projected step
+    xp = d["xgmi_projection"]
+    assert xp["ep"] == 8 and xp["peak_GBps"] == 7 * 153.0 and set(xp["legs"]) == {"dispatch_push", "combine_push"}
+    assert xp["legs"]["combine_push"]["cross_gpu_bytes"] > 3.5e8 and xp["projected_step_ms"] > xp["link_bound_floor_ms"] > 0.3
 
 
 @pytest.mark.gpu
