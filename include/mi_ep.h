@@ -84,13 +84,19 @@ size_t mi_ep_combine_row_bytes(int hidden);
  *   send_data_offset [E]        (exclusive prefix of num_tokens_per_expert; reference notify_dispatch.h:185-198).
  * workspace: mi_ep_dispatch_layout_workspace(T,K,E) bytes, contents irrelevant.  idx_is_i32 != 0: topk_idx is int32.
  * sync_words: NULL, or two uint32 words in device memory that the CALLER zero-initialises once and then only lends to this function
- * (one call at a time per pair of words): batches of more than 1024 tokens then run as ONE cooperative launch (workgroups of 1024
- * tokens meeting at a self-resetting grid barrier) instead of three; NULL keeps the three launches.  Results are identical. */
+ * -- ONE LAUNCH IN FLIGHT PER PAIR: calls that may overlap (different streams) must be lent different pairs; the host runtime deals
+ * them from a ring.  Batches of more than 1024 tokens then run as ONE launch (workgroups of 1024 tokens meeting at a self-resetting
+ * grid barrier; at most 128 workgroups, which this 256-CU part keeps co-resident) instead of three; NULL keeps the three launches.
+ * Results are identical.
+ * status: NULL, or a device-visible word: if the grid barrier is not passed within 2 s (a workgroup that never became resident, or a
+ * pair of sync words lent twice) the kernel stores MI_EP_STATUS_LAYOUT_BARRIER there, sets the three count tables to -1 and returns;
+ * it never hangs and never returns plausible-looking garbage silently. */
+#define MI_EP_STATUS_LAYOUT_BARRIER 6000
 size_t mi_ep_dispatch_layout_workspace(int num_tokens, int num_topk, int num_experts);
 int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int num_tokens, int num_topk, int num_experts,
                           int num_ranks, int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
                           int32_t *is_token_in_rank, int32_t *send_token_idx_small, int32_t *send_data_offset,
-                          void *workspace, size_t workspace_bytes, uint32_t *sync_words, void *stream);
+                          void *workspace, size_t workspace_bytes, uint32_t *sync_words, int32_t *status, void *stream);
 
 /* ---- flags ----------------------------------------------------------------------------------
  * Each rank owns `uint64_t flags[nslots]`; slot s of rank d is written only by rank s.
@@ -142,6 +148,10 @@ int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t notify_epoch, c
                              int32_t *total_recv_token, int32_t *max_bs, int32_t *pull_offset, int32_t *summary_host,
                              int32_t *status, int timeout_ms, int32_t *wait_cost_stats /*[W] or NULL: += us waited per source*/,
                              void *stream);
+/* Dynamic LDS of the notify_wait_tables / notify_exchange_tables workgroup for (num_ranks, num_experts): it keeps the W * (E + 1)
+ * counts next to the tables' scratch.  Shapes needing more than a CU's 160 KB (0 = invalid W / E) make those two entry points
+ * return MI_EP_EINVAL -- e.g. W = 64 with E = 2048; every shape with W <= 16 fits up to E = 2048, W = 64 up to E = 512. */
+size_t mi_ep_notify_lds_bytes(int num_ranks, int num_experts);
 /* Both halves of the exchange in ONE launch of one workgroup: post this rank's counts and its "rows staged" flag
  * (= mi_ep_notify_post_signal with signal_epoch = flag_epoch), then mi_ep_notify_wait_tables.  Used by the host runtime
  * when each rank is its own process; a harness that plays several ranks on one stream must keep the two halves apart

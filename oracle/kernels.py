@@ -302,15 +302,21 @@ def split_qkv_rmsnorm_mrope(qkv, q_weight, k_weight, cos_sin, num_q_heads, num_k
     if is_interleaved:
         h_mask = (off % 3 == 1) & (off <= 3 * mrope_section[1])
         w_mask = (off % 3 == 2) & (off <= 3 * mrope_section[2])
-        t_mask = ~(h_mask | w_mask)
+        t_mask = ~(h_mask | w_mask)                     # interleaved: t is the complement, nothing is left over
     else:
         t_end = mrope_section[0]
         h_end = t_end + mrope_section[1]
         t_mask = off < t_end
         h_mask = (off >= t_end) & (off < h_end)
+        w_mask = (off >= h_end) & (off < h_end + mrope_section[2])
     cs = cos_sin.float()
-    cos = torch.where(t_mask, cs[0, :, :half], torch.where(h_mask, cs[1, :, :half], cs[2, :, :half]))
-    sin = torch.where(t_mask, cs[0, :, half:], torch.where(h_mask, cs[1, :, half:], cs[2, :, half:]))
+    # The test's golden sends everything that is neither t nor h to w; the KERNEL masks w as well (contiguous sections: w covers
+    # [t + h, t + h + w) only, split_qkv_rmsnorm_mrope.py:157-163, masked loads with other = 0), so rotation offsets behind the three
+    # sections get cos = sin = 0.  The two agree whenever the sections fill rope_dim / 2 (every case of the reference test); where they
+    # do not, this follows the kernel.
+    zero = torch.zeros_like(cs[2, :, :half])
+    cos = torch.where(t_mask, cs[0, :, :half], torch.where(h_mask, cs[1, :, :half], torch.where(w_mask, cs[2, :, :half], zero)))
+    sin = torch.where(t_mask, cs[0, :, half:], torch.where(h_mask, cs[1, :, half:], torch.where(w_mask, cs[2, :, half:], zero)))
     cos, sin = torch.cat((cos, cos), dim=-1), torch.cat((sin, sin), dim=-1)
     if has_gate:
         q_gate, k, v = qkv.split((q_size * 2, kv_size, kv_size), dim=-1)

@@ -49,10 +49,10 @@ def build_hip_lib(name, subdir, extra=()):
     objdir = os.path.join(LIB, "obj", subdir)
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(HERE, "csrc", subdir, "*.hip")))
-    hdrs = glob.glob(os.path.join(HERE, "csrc", subdir, "*.h")) + glob.glob(os.path.join(INC, "*.h"))
+    hdrs = glob.glob(os.path.join(HERE, "csrc", subdir, "*.h")) + glob.glob(os.path.join(INC, "*.h")) + glob.glob(os.path.join(HERE, "csrc", "*.h"))
     out = os.path.join(LIB, name)
     common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", f"-I{INC}",
-              f"-I{os.path.join(HERE, 'csrc', subdir)}", *extra]
+              f"-I{os.path.join(HERE, 'csrc', subdir)}", f"-I{os.path.join(HERE, 'csrc')}", *extra]
     objs, procs = [], []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")

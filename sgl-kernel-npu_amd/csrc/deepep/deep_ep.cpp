@@ -352,13 +352,22 @@ Buffer::Layout Buffer::run_layout(const at::Tensor &topk_idx, int num_experts)
                                       (int)num_ranks, l.num_tokens_per_rank.data_ptr<int>(),
                                       l.num_tokens_per_expert.data_ptr<int>(), l.is_token_in_rank.data_ptr<int>(),
                                       l.send_token_idx_small.data_ptr<int>(), l.send_data_offset.data_ptr<int>(),
-                                      l.workspace.data_ptr(), wsb, layout_sync_words(topk_idx.device()), cur_stream()));
+                                      l.workspace.data_ptr(), wsb, layout_sync_words(topk_idx.device()), status_dev, cur_stream()));
     return l;
 }
 
 // two persistent words for the cooperative layout launch: in the rank's control area (zeroed at construction, behind the per-family
-// call counters), so no allocation can happen under a graph capture; the kernel's grid barrier re-arms them itself
-uint32_t *Buffer::layout_sync_words(const at::Device &) { return (uint32_t *)(window + kOffEpochs + 512); }
+// call counters), so no allocation can happen under a graph capture; the kernel's grid barrier re-arms them itself.  A pair serves
+// ONE launch in flight: calls that overlap on different streams of one Buffer (two-batch overlap) must not share it, so the pairs are
+// dealt from a ring of kLayoutSyncPairs -- a pair comes round again only after that many later layout calls were issued.  (Under a
+// graph capture the pair is baked into the graph: replays of ONE graph serialise on its stream, and eager calls keep moving through
+// the ring.)  A barrier that does not close within 2 s reports MI_EP_STATUS_LAYOUT_BARRIER: check_status raises.
+uint32_t *Buffer::layout_sync_words(const at::Device &)
+{
+    constexpr uint64_t kLayoutSyncPairs = 32;         // 32 x 8 B at control offset kOffEpochs + 512 .. + 768
+    const uint64_t i = layout_calls++ % kLayoutSyncPairs;
+    return (uint32_t *)(window + kOffEpochs + 512) + 2 * i;
+}
 
 const Buffer::Layout &Buffer::layout_for(const at::Tensor &topk_idx, int num_experts)
 {
@@ -410,6 +419,9 @@ Buffer::DispatchExchange Buffer::dispatch_exchange(const at::Tensor &x, const at
     EP_HOST_ASSERT_S((size_t)T <= mi_ep_dispatch_index_offset(H, qm, K, ex.slab_bytes) / rb, "dispatch window too small: need ",
                      (size_t)T * (rb + (size_t)K * 8) * (ex.push ? (size_t)W : 1), " bytes per region, have ", region_bytes,
                      "; raise DEEPEP_WINDOW_BYTES (or use DEEPEP_NORMAL_LONG_SEQ_ROUND)");
+    EP_HOST_ASSERT_S(mi_ep_notify_lds_bytes(W, E) <= 160u * 1024u, "num_experts (", E, ") x num_ranks (", W,
+                     "): the count exchange keeps W * (E + 1) counts in one workgroup's LDS (", mi_ep_notify_lds_bytes(W, E),
+                     " bytes needed, 163840 available); use fewer experts per exchange");
     uint64_t *ctr = epoch_ctr(kDispatch);
     auto region_peers = peer_family_bases(kDispatch);
     const bool i32idx = topk_idx.scalar_type() == at::kInt;

@@ -165,6 +165,7 @@ private:
     };
     Layout run_layout(const at::Tensor &topk_idx, int num_experts);
     uint32_t *layout_sync_words(const at::Device &dev);
+    uint64_t layout_calls = 0;
     const Layout &layout_for(const at::Tensor &topk_idx, int num_experts);
 
     void check_status(const char *where);

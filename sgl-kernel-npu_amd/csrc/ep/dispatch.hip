@@ -15,6 +15,7 @@
 //    at the same time; 8 x 16 B per lane in flight.
 // HBM roofline (per rank, algorithmic): stage reads T*H*2 and writes n_pairs*(H+16); pull reads and
 // writes n_recv*(H+16).
+#include "device_once.h"
 #include <stdlib.h>
 
 #include <algorithm>
@@ -943,14 +944,13 @@ extern "C" int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx
     // dynamic LDS: the layout workgroup's tables, or the send workgroups' copy of the routing table (int32 per pair)
     const size_t lds = std::max(layout_small_lds_bytes(E, W, ut), (size_t)T * K * sizeof(int32_t));
     const uint16_t *xp = (const uint16_t *)x;
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
 #define MI_EP_LLS_ATTR(I32, QM, UT) (void)hipFuncSetAttribute((const void *)ll_layout_send_kernel<I32, QM, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
-    if (!attr_set) {
+    if (attr_once.need()) {
         MI_EP_LLS_ATTR(true, MI_EP_QUANT_NONE, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_NONE, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_NONE, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_NONE, 64);
         MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8, 64);
         MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8_NOEPS, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8_NOEPS, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_INT8_NOEPS, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_INT8_NOEPS, 64);
         MI_EP_LLS_ATTR(true, MI_EP_QUANT_FP8_E4M3, 16); MI_EP_LLS_ATTR(false, MI_EP_QUANT_FP8_E4M3, 16); MI_EP_LLS_ATTR(true, MI_EP_QUANT_FP8_E4M3, 64); MI_EP_LLS_ATTR(false, MI_EP_QUANT_FP8_E4M3, 64);
-        attr_set = true;
     }
 #undef MI_EP_LLS_ATTR
 #define MI_EP_LLS(I32, QM, UT)                                                                                                         \

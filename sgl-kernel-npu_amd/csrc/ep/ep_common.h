@@ -151,6 +151,8 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)             // v >= 0
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+constexpr int32_t kStatusLayoutBarrier = MI_EP_STATUS_LAYOUT_BARRIER;   // the cooperative layout launch's grid barrier timed out
+
 // error reporting word (device or pinned-host memory): first writer wins is not required, any code is enough
 __device__ __forceinline__ void report_status(int32_t *status, int32_t code)
 {

@@ -8,6 +8,7 @@
 //   pass 3  per unit, pairs are walked in row-major order 64 at a time; the rank of a pair among
 //           equal experts inside the 64-wide step comes from ballots (no serial loop), the running
 //           base lives in LDS.  Results are order-deterministic (no global atomics).
+#include "device_once.h"
 #include "ep_common.h"
 #include "layout_dev.h"
 
@@ -229,7 +230,8 @@ extern "C" size_t mi_ep_dispatch_layout_workspace(int T, int K, int E)
 extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T, int K, int E, int W,
                                      int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
                                      int32_t *is_token_in_rank, int32_t *send_token_idx_small,
-                                     int32_t *send_data_offset, void *workspace, size_t workspace_bytes, uint32_t *sync_words, void *stream)
+                                     int32_t *send_data_offset, void *workspace, size_t workspace_bytes, uint32_t *sync_words, int32_t *status,
+                                     void *stream)
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || E <= 0 || W <= 0 || W > MI_EP_MAX_RANKS || E % W != 0 || E > 2048)
         return MI_EP_EINVAL;
@@ -263,18 +265,17 @@ extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T
     const bool coop = Us > 16 && lend && Bc <= 128 && workspace_bytes >= (size_t)Bc * (E + MI_EP_MAX_RANKS) * sizeof(int32_t);
     if ((single || coop) && (size_t)16 * E <= 16384 && ((16 * E) & 1) == 0) {
         const size_t ldsf = layout_small_lds_bytes(E, W, ut);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_once;
+        if (attr_once.need()) {
             (void)hipFuncSetAttribute((const void *)layout_small_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)layout_small_kernel<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)layout_small_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)layout_small_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
         }
 #define MI_EP_LAYOUT_SMALL(I32, UT)                                                                                              \
     layout_small_kernel<I32, UT><<<Bc, 1024, ldsf, s>>>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, \
                                                         is_token_in_rank, send_token_idx_small, send_data_offset,                \
-                                                        (int32_t *)workspace, sync_words)
+                                                        (int32_t *)workspace, sync_words, status)
         if (ut == 16) { if (idx_is_i32) MI_EP_LAYOUT_SMALL(true, 16); else MI_EP_LAYOUT_SMALL(false, 16); }
         else { if (idx_is_i32) MI_EP_LAYOUT_SMALL(true, 64); else MI_EP_LAYOUT_SMALL(false, 64); }
 #undef MI_EP_LAYOUT_SMALL

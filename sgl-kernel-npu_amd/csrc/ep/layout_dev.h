@@ -39,27 +39,35 @@ __device__ __forceinline__ unsigned long long match_any_bits(unsigned key, bool 
 //     a grid barrier (B <= 128 co-resident workgroups; two self-resetting words in caller-owned zero-initialised memory), and each
 //     derives the running base of its units from the totals of the workgroups in front of it: three launches (4.9 + 6.2 + 6.9 us
 //     back to back at 4096 tokens) become one, and the [U][E] histograms / bases never travel through global memory.
-__device__ __forceinline__ void layout_grid_barrier(uint32_t *sync, int B)
+// -> true when every workgroup arrived; false after a 2 s spin (a workgroup that never became resident, or sync words shared with
+// another launch in flight): the caller must then NOT trust the other workgroups' totals -- it reports MI_EP_STATUS_LAYOUT_BARRIER
+// through `status` (the host's check_status raises) and poisons its outputs instead of writing plausible garbage.
+__device__ __forceinline__ bool layout_grid_barrier(uint32_t *sync, int B, int32_t *status)
 {
+    __shared__ int ok_s;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t t0 = wall_clock64();
+        bool ok = true;
         // relaxed polls, ONE acquire fence after the last arrival: an acquire load invalidates the XCD's L2 on every iteration, for every
         // workgroup of the XCD (tools/probes/ubench/launch_floor.hip: a flag hop between XCDs costs 0.4-0.7 us polled this way)
         while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)B) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 200000000ull) break;            // 2 s: never hang (a lost launch leaves garbage tables, not a stuck GPU)
+            if (wall_clock64() - t0 > 200000000ull) { ok = false; break; }      // 2 s: never hang
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        // the last workgroup to LEAVE the spin re-arms both words for the next launch on this stream
+        if (!ok && status) report_status(status, kStatusLayoutBarrier);
+        // the last workgroup to LEAVE the spin re-arms both words for the next launch that borrows this pair
         if (__hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)B - 1u) {
             __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        ok_s = ok ? 1 : 0;
     }
     __syncthreads();
+    return ok_s != 0;
 }
 
 // (a device function: the low-latency send kernel of dispatch.hip runs it in its first workgroup, B = 1, while the other workgroups
@@ -69,7 +77,8 @@ __device__ __forceinline__ void layout_small_body(
     const void *__restrict__ topk_idx, int T, int K, int E, int W, int nbits, int32_t *__restrict__ num_tokens_per_rank,
     int32_t *__restrict__ num_tokens_per_expert, int32_t *__restrict__ is_token_in_rank,
     int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset,
-    int32_t *__restrict__ block_tot /*[B][E + W], B > 1 only*/, uint32_t *__restrict__ sync, int32_t *smem, const int B, const int blk)
+    int32_t *__restrict__ block_tot /*[B][E + W], B > 1 only*/, uint32_t *__restrict__ sync, int32_t *smem, const int B, const int blk,
+    int32_t *__restrict__ status = nullptr)
 {
     const int U_all = (T + UT - 1) / UT;
     const int u_first = blk * 16;
@@ -146,7 +155,15 @@ __device__ __forceinline__ void layout_small_body(
             mine[e] = s;
         }
         for (int r = tid; r < W; r += blockDim.x) mine[E + r] = rank_cnt[r];
-        layout_grid_barrier(sync, B);
+        if (!layout_grid_barrier(sync, B, status)) {
+            // barrier timed out: the tables of this launch cannot be formed.  The host learns through `status` (that is the contract);
+            // the count tables are additionally set to -1 so that a caller who ignores it does not read plausible numbers.
+            if (blk == B - 1) {
+                for (int e = tid; e < E; e += blockDim.x) { num_tokens_per_expert[e] = -1; send_data_offset[e] = -1; }
+                for (int r = tid; r < W; r += blockDim.x) num_tokens_per_rank[r] = -1;
+            }
+            return;
+        }
     }
     LT_TICK()
     // ---- pass 2: per-expert exclusive scan over units (in place), totals, exclusive scan over experts.  With several workgroups a unit's
@@ -227,11 +244,11 @@ __global__ __launch_bounds__(1024) void layout_small_kernel(
     const void *__restrict__ topk_idx, int T, int K, int E, int W, int nbits, int32_t *__restrict__ num_tokens_per_rank,
     int32_t *__restrict__ num_tokens_per_expert, int32_t *__restrict__ is_token_in_rank,
     int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset,
-    int32_t *__restrict__ block_tot /*[B][E + W], B > 1 only*/, uint32_t *__restrict__ sync)
+    int32_t *__restrict__ block_tot /*[B][E + W], B > 1 only*/, uint32_t *__restrict__ sync, int32_t *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     layout_small_body<I32, UT>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank,
-                               send_token_idx_small, send_data_offset, block_tot, sync, smem, (int)gridDim.x, (int)blockIdx.x);
+                               send_token_idx_small, send_data_offset, block_tot, sync, smem, (int)gridDim.x, (int)blockIdx.x, status);
 }
 
 // bytes of dynamic LDS layout_small_body needs (16 units per workgroup)

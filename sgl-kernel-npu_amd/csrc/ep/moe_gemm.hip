@@ -21,6 +21,7 @@
 // Expert row ranges come from the device-side cumulative counts, so the same launch serves low-latency (no host sync) and
 // normal mode; idle tile slots exit at once.
 // Bound: operand stream / MFMA int8 for prefill-size groups (2*M*N*K ops), HBM (weights once: L*N*K bytes) for decode.
+#include "device_once.h"
 #include "ep_common.h"
 
 namespace mi_ep {
@@ -500,10 +501,9 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
     constexpr int BM = 64 * MT;
     constexpr int ring = RingDepth<BKT, MT>::value * (BM + BN) * BKT, epi = 16 * 16 * MT * kEpiRowBytes;      // operand ring | epilogue tiles of 16 waves
     constexpr int lds = ring > epi ? ring : epi;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute((const void *)grouped_gemm_i8_kernel<MODE, MT, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     const int tiles_max = (p.M_cap + BM - 1) / BM + p.L;        // every expert may end in a partial tile
     const int gx = (p.N + BN - 1) / BN;

@@ -6,6 +6,7 @@
 // flag words); notify values travel as 8-byte {epoch, value} granules so the data is its own flag.
 // Only these 8-byte words are touched with system-scope atomics; bulk payload hand-off is ordered by
 // kernel boundaries (post kernel -> signal kernel | wait kernel -> consume kernel).
+#include "device_once.h"
 #include "ep_common.h"
 
 namespace mi_ep {
@@ -296,16 +297,25 @@ __global__ __launch_bounds__(1024) void notify_wait_tables_kernel(NotifyPost pos
 
 using namespace mi_ep;
 
+// The count exchange keeps all W * (E + 1) counts in LDS next to the tables' scratch; a CU has 160 KB.  Shapes beyond that (W = 64 with
+// E = 2048, say) are refused with MI_EP_EINVAL by the entry points -- they are far outside one xGMI node (W <= 8) -- instead of failing
+// at launch; mi_ep_notify_lds_bytes lets a host check up front.
+static constexpr size_t kNotifyLdsMax = 160 * 1024;
+extern "C" size_t mi_ep_notify_lds_bytes(int W, int E)
+{
+    if (W <= 0 || E <= 0 || E % W) return 0;
+    const int L = E / W;
+    return (size_t)(2 * L * W + W + L + 2 + ((W * (E + 1) + 3) & ~3)) * sizeof(int32_t);
+}
+
 // dynamic LDS of notify_wait_tables_kernel: the tables' scratch + the W * (E + 1) counts (84 KB at E = 2048, W = 8: above the 64 KB default)
 static size_t notify_lds_bytes(int W, int E)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)notify_wait_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_set = true;
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        (void)hipFuncSetAttribute((const void *)notify_wait_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNotifyLdsMax);
     }
-    const int L = E / W;
-    return (size_t)(2 * L * W + W + L + 2 + ((W * (E + 1) + 3) & ~3)) * sizeof(int32_t);
+    return mi_ep_notify_lds_bytes(W, E);
 }
 
 static uint64_t ms_to_ticks(int ms) { return (uint64_t)(ms > 0 ? ms : 10000) * 100000ull; }
@@ -412,8 +422,8 @@ extern "C" int mi_ep_notify_wait_tables(const uint64_t *my_notify, uint32_t noti
     if (!my_notify || !cnt_matrix || !status || notify_epoch == 0 || W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048 ||
         my_rank < 0 || my_rank >= W)
         return MI_EP_EINVAL;
-    const int L = E / W;
     const size_t lds = notify_lds_bytes(W, E);
+    if (lds > kNotifyLdsMax) return MI_EP_EINVAL;
     NotifyPost none{};
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
         none, my_notify, notify_epoch, my_flags, flag_epoch, nullptr, nullptr, 0, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
@@ -441,8 +451,8 @@ extern "C" int mi_ep_notify_exchange_tables(uint64_t *const *peer_notify_host, u
     post.cnt = num_tokens_per_expert;
     post.num_tokens = num_tokens;
     post.sig_epoch = epoch_ctr ? 1 : flag_epoch;      // non-zero = post; the value comes from the counter when it is device-resident
-    const int L = E / W;
     const size_t lds = notify_lds_bytes(W, E);
+    if (lds > kNotifyLdsMax) return MI_EP_EINVAL;
     notify_wait_tables_kernel<<<1, 1024, lds, (hipStream_t)stream>>>(
         post, my_notify, notify_epoch, my_flags, flag_epoch, epoch_ctr, epoch_ctr, notify_parity_stride, cnt_matrix, W, E, my_rank, relative_pull, recv_count, recv_offset,
         recv_tokens_per_expert, expert_global_offset, srcrank_in_expert_offset, r_in_srcrank_offset, total_recv_token, max_bs,

@@ -472,7 +472,8 @@ __device__ __forceinline__ int mrope_section_of(const MropeSections &m, int o)
         if (r == 2 && o <= 3 * m.sec2) return 2;
         return 0;
     }
-    return o < m.sec0 ? 0 : (o < m.sec0 + m.sec1 ? 1 : 2);
+    // offsets behind the three sections take cos = sin = 0 (the reference masks w to [t + h, t + h + w), :157-163)
+    return o < m.sec0 ? 0 : (o < m.sec0 + m.sec1 ? 1 : (o < m.sec0 + m.sec1 + m.sec2 ? 2 : 3));
 }
 template <bool BF16, bool MROPE>
 __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
@@ -559,10 +560,10 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
                         const int r = (r0 + e) % 3;       // r0 + e < 10: folds to compares
                         sec = (r == 1 && o <= 3 * ms.sec1) ? 1 : ((r == 2 && o <= 3 * ms.sec2) ? 2 : 0);
                     } else {
-                        sec = o < ms.sec0 ? 0 : (o < ms.sec0 + ms.sec1 ? 1 : 2);
+                        sec = o < ms.sec0 ? 0 : (o < ms.sec0 + ms.sec1 ? 1 : (o < ms.sec0 + ms.sec1 + ms.sec2 ? 2 : 3));   // 3: behind the sections, cos = sin = 0
                     }
-                    cvf[u][e] = sec == 0 ? c3[0][e] : (sec == 1 ? c3[1][e] : c3[2][e]);
-                    svf[u][e] = sec == 0 ? s3[0][e] : (sec == 1 ? s3[1][e] : s3[2][e]);
+                    cvf[u][e] = sec == 0 ? c3[0][e] : (sec == 1 ? c3[1][e] : (sec == 2 ? c3[2][e] : 0.0f));
+                    svf[u][e] = sec == 0 ? s3[0][e] : (sec == 1 ? s3[1][e] : (sec == 2 ? s3[2][e] : 0.0f));
                 }
             }
         } else if (neox) {
@@ -594,7 +595,8 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             if (gl >= 16) ss += dpp_f32<0x140>(ss);         // row_mirror: the other half of the 16-lane row
             if (gl == 32) ss += __shfl_xor(ss, 16, 64);
             if (active[u] && !is_v) {
-                const float rstd = (gemma || MROPE) ? rsqrtf(ss / (float)head_dim + eps) : 1.0f / sqrtf(ss / (float)head_dim + eps);
+                // rsqrt where the reference kernel says tl.rsqrt (gemma :500, position cache :101), 1 / sqrt where it says so (mrope :202)
+                const float rstd = (gemma || (MROPE && ms.mode == 1)) ? rsqrtf(ss / (float)head_dim + eps) : 1.0f / sqrtf(ss / (float)head_dim + eps);
                 float wv[8];
                 unpack8<BF16>(wr[u], wv);
                 if (gemma) {

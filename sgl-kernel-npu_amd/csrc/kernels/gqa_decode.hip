@@ -13,6 +13,7 @@
 // ds_read_b64_tr_b16, B = P^T = the S^T accumulator layout packed in place) -- no cross-lane traffic between the GEMMs.
 // LDS rows are padded to an odd number of 32-byte units, which makes both read patterns conflict-free.
 // Flash-decoding split over the KV range + a merge kernel fill the 256 CUs for small batch x kv_heads.
+#include "device_once.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -403,11 +404,10 @@ template <bool BF16, int DKP, int DVP, int TILE, int HB>
 static void launch_one(const GqaParams &p, dim3 grid, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)TILE * (row_stride(DKP) + row_stride(DVP));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute((const void *)gqa_decode_kernel<BF16, DKP, DVP, TILE, HB>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     gqa_decode_kernel<BF16, DKP, DVP, TILE, HB><<<grid, 256, lds, st>>>(p);
 }

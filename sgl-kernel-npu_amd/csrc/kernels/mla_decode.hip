@@ -23,6 +23,7 @@
 //    kernel merges the (m, l, O) partials.
 // Algorithmic HBM bytes per launch: sum_b len_b * 576 * 2 (KV once) + B*Hq*(576+512)*2 (Q, out); FLOPs
 // sum_b Hq * len_b * (576+512) * 2.
+#include "device_once.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -546,12 +547,11 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     p.sm_scale = sm_scale;
     hipStream_t st = (hipStream_t)stream;
     const long long units = (long long)batch * kv_heads * num_splits;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         const int lds1 = 2 * kBufBytes;
         (void)hipFuncSetAttribute((const void *)mla_decode_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
         (void)hipFuncSetAttribute((const void *)mla_decode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-        attr_set = true;
     }
     if (wide) {
         if (wide8) launch_mla_wide8(p, dtype, units, st);

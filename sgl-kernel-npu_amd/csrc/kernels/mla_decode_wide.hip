@@ -5,6 +5,7 @@
 // inline asm with a VGPR destination (16 registers), next to the 144 VGPRs of resident Q^T.  The hazards the compiler
 // cannot see for them are covered by hand: dependent MFMAs on one accumulator issue back to back (hardware interlock),
 // and 18 wait states separate the last one from the first VALU read of S^T.
+#include "device_once.h"
 #include "mi_sgl_kernels.h"
 #include "mla_common.h"
 
@@ -633,11 +634,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute((const void *)mla_decode_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
         (void)hipFuncSetAttribute((const void *)mla_decode_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
-        attr_set = true;
     }
     const int head_blocks = (p.group + 127) / 128;
     const long long seqs = units / p.num_splits;               // (sequence, kv head) pairs, 8 per grid row of XCDs

@@ -25,6 +25,7 @@
 // LDS: ring of 4 KV slots (32 keys x (1056 + 128) B), per-wave block-table rings, exchange buffer = 160 KiB exactly; the two
 // control words live in the pad bytes of the last K row.  K rows are NOT chunk-swapped here (the 16-row operand fetch of the
 // 16x16x32 form is conflict-free under the plain 1056-byte stride, and so is the transposed V fetch).
+#include "device_once.h"
 #include "mi_sgl_kernels.h"
 #include "mla_common.h"
 
@@ -460,11 +461,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 void launch_mla_wide8(const MlaParams &p, int dtype, long long units, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute((const void *)mla_decode_wide8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k8Lds);
         (void)hipFuncSetAttribute((const void *)mla_decode_wide8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k8Lds);
-        attr_set = true;
     }
     const int head_blocks = (p.group + 127) / 128;
     const long long seqs = units / p.num_splits;               // (sequence, kv head) pairs, 8 per grid row of XCDs

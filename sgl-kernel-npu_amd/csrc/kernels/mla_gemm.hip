@@ -24,6 +24,7 @@
 //    512 (head x column quarter): every launch fills the 256 CUs once.
 // Bound: HBM (weights once: 15.1 + 37.7 + 16.8 MB at 128 heads); algorithmic bytes per launch = N*K (+ M*K per column tile
 // from L2).
+#include "device_once.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -698,10 +699,9 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
     const int chunks = (k + kKC - 1) / kKC;
     if (mode == 0) {
         constexpr int BN = 128;
-        static bool attr_set = false;                  // 66 KB of dynamic LDS: above the 64 KB default limit
-        if (!attr_set) {
+        static PerDeviceOnce attr_once;                  // 66 KB of dynamic LDS: above the 64 KB default limit
+        if (attr_once.need()) {
             (void)hipFuncSetAttribute((const void *)skinny_i8_kernel<0, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BN * kRowStride);
-            attr_set = true;
         }
         dim3 grid((n + BN - 1) / BN, chunks, mblocks);
         skinny_i8_kernel<0, BN, true><<<grid, 256, BN * kRowStride, s>>>(a, tokens, k, w, n, c_i32, nullptr, nullptr, nullptr, nullptr);
@@ -713,10 +713,9 @@ extern "C" int mi_mla_pre_gemm_i8(const int8_t *a, int tokens, int k, const int8
         const size_t lds = (size_t)nt * 16 * kRow2;
 #define MI_K1536(NT, B)                                                                                                                  \
         do {                                                                                                                             \
-            static bool attr_set = false;                                                                                                \
-            if (!attr_set) {                                                                                                             \
+            static PerDeviceOnce attr_once;                                                                                                \
+            if (attr_once.need()) {                                                                                                             \
                 (void)hipFuncSetAttribute((const void *)skinny_i8_k1536_kernel<NT, B>, hipFuncAttributeMaxDynamicSharedMemorySize, NT * 16 * kRow2); \
-                attr_set = true;                                                                                                         \
             }                                                                                                                            \
             skinny_i8_k1536_kernel<NT, B><<<grid, 256, lds, s>>>(a, tokens, w, n, bias, descale, row_scale, (uint16_t *)y);                          \
         } while (0)
@@ -775,11 +774,10 @@ extern "C" int mi_mla_pre_gemm2_bmm_rope(const int8_t *a, int tokens, const int8
     dim3 grid(q_heads, 1, half ? (tokens + 63) / 64 : (tokens + kBM - 1) / kBM);
 #define MI_FUSED(B)                                                                                                                 \
     do {                                                                                                                            \
-        static bool attr_set = false;                                                                                               \
-        if (!attr_set) {                                                                                                            \
+        static PerDeviceOnce attr_once;                                                                                               \
+        if (attr_once.need()) {                                                                                                            \
             (void)hipFuncSetAttribute((const void *)gemm2_bmm_rope_kernel<B, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kF_Lds); \
             (void)hipFuncSetAttribute((const void *)gemm2_bmm_rope_kernel<B, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kF_Lds); \
-            attr_set = true;                                                                                                        \
         }                                                                                                                           \
         if (half)                                                                                                                   \
             gemm2_bmm_rope_kernel<B, true><<<grid, 512, kF_Lds, (hipStream_t)stream>>>(a, tokens, wuq, q_heads, bias, descale, row_scale, \

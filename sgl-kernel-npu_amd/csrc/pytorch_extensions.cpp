@@ -468,8 +468,18 @@ at::Tensor attn_residual_mix(const at::Tensor &prefix_sum, const at::Tensor &ban
                     bank.size(2) == prefix_sum.size(1) && bank.scalar_type() == prefix_sum.scalar_type(),
                 "mix_fused: prefix_sum [tokens, hidden], bank [tokens, blocks, hidden], hidden contiguous, one dtype");
     TORCH_CHECK(combined_weight.numel() == prefix_sum.size(1) && combined_weight.is_contiguous(), "mix_fused: combined_weight [hidden]");
+    TORCH_CHECK(num_valid_blocks >= 0 && num_valid_blocks <= 63, "mix_fused: num_valid_blocks must be in [0, 63] in this build (got ", num_valid_blocks, ")");
+    // the kernel moves 16-byte vectors: sliced views whose rows do not start on 16 bytes (bank[:, :, 4:], odd row strides) are copied first
+    auto vec_ok = [](const at::Tensor &t, std::initializer_list<int64_t> strides) {
+        if (reinterpret_cast<uintptr_t>(t.data_ptr()) % 16) return false;
+        for (int64_t st : strides) if ((st * (int64_t)t.element_size()) % 16) return false;
+        return true;
+    };
+    const at::Tensor prefix_sum_c = vec_ok(prefix_sum, {prefix_sum.stride(0)}) ? prefix_sum : prefix_sum.contiguous();
+    const at::Tensor bank_c = vec_ok(bank, {bank.stride(0), bank.stride(1)}) ? bank : bank.contiguous();
+    const at::Tensor &prefix_sum_ = prefix_sum_c, &bank_ = bank_c;
     at::Tensor out = at::empty_like(prefix_sum, at::MemoryFormat::Contiguous);
-    const int rc = mi_attn_residual_mix(prefix_sum.data_ptr(), prefix_sum.stride(0), bank.data_ptr(), bank.stride(0), bank.stride(1),
+    const int rc = mi_attn_residual_mix(prefix_sum_.data_ptr(), prefix_sum_.stride(0), bank_.data_ptr(), bank_.stride(0), bank_.stride(1),
                                         combined_weight.data_ptr(), dtype_code3(combined_weight), prefix_sum.size(0), (int)num_valid_blocks,
                                         (int)prefix_sum.size(1), (float)variance_epsilon, dtype_code(prefix_sum), out.data_ptr(), out.stride(0),
                                         cur_stream());
@@ -557,14 +567,20 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> split_qkv_rmsnorm_rope_pos_cache_
                         q_weight->scalar_type() == input.scalar_type() && k_weight->scalar_type() == input.scalar_type(),
                     "When using RMSNorm (eps is not None), q_weight / k_weight must have at least head_dim elements in the input dtype");
     TORCH_CHECK(q_bias.has_value() == k_bias.has_value(), "q_bias and k_bias go together");
-    if (q_bias.has_value()) TORCH_CHECK(norms && q_bias->numel() >= head_dim && k_bias->numel() >= head_dim, "bias needs the norm and head_dim elements");
+    if (q_bias.has_value())
+        TORCH_CHECK(norms && q_bias->numel() >= head_dim && k_bias->numel() >= head_dim && q_bias->scalar_type() == input.scalar_type() &&
+                        k_bias->scalar_type() == input.scalar_type(),
+                    "bias needs the norm, head_dim elements and the input dtype");
     at::Tensor q = at::empty({B, q_hidden_size}, input.options()), k = at::empty({B, kv_hidden_size}, input.options()),
                v = at::empty({B, kv_hidden_size}, input.options());
-    auto p = [](const std::optional<at::Tensor> &t) -> const void * { return t.has_value() ? t->contiguous().data_ptr() : nullptr; };
+    // contiguous copies (no-ops for contiguous arguments) held in locals that outlive the launch
+    const at::Tensor qw_c = q_weight.has_value() ? q_weight->contiguous() : at::Tensor(), kw_c = k_weight.has_value() ? k_weight->contiguous() : at::Tensor(),
+                     qb_c = q_bias.has_value() ? q_bias->contiguous() : at::Tensor(), kb_c = k_bias.has_value() ? k_bias->contiguous() : at::Tensor();
+    auto p = [](const at::Tensor &t) -> const void * { return t.defined() ? t.data_ptr() : nullptr; };
     const int rc = mi_split_qkv_rmsnorm_rope_pos_cache(input.data_ptr(), positions.data_ptr(), positions.scalar_type() == at::kLong, cos_sin_cache.data_ptr(),
                                                        dtype_code3(cos_sin_cache), (int)cos_sin_cache.size(0), cos_sin_cache.stride(0), (int)B,
                                                        (int)q_hidden_size, (int)kv_hidden_size, (int)head_dim, (int)rope_dim, norms, (float)eps.value_or(0.0),
-                                                       p(q_weight), p(k_weight), p(q_bias), p(k_bias), cast_norm_to_bf16, dtype_code(input), q.data_ptr(),
+                                                       p(qw_c), p(kw_c), p(qb_c), p(kb_c), cast_norm_to_bf16, dtype_code(input), q.data_ptr(),
                                                        k.data_ptr(), v.data_ptr(), cur_stream());
     TORCH_CHECK(rc == 0, "mi_split_qkv_rmsnorm_rope_pos_cache failed with code ", rc);
     return {q, k, v};

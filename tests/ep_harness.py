@@ -23,7 +23,7 @@ def _lib():
     lib.mi_ep_combine_row_bytes.argtypes = [I]
     lib.mi_ep_dispatch_layout_workspace.restype = c_size_t
     lib.mi_ep_dispatch_layout_workspace.argtypes = [I, I, I]
-    lib.mi_ep_dispatch_layout.argtypes = [V, I, I, I, I, I, V, V, V, V, V, V, c_size_t, V, V]
+    lib.mi_ep_dispatch_layout.argtypes = [V, I, I, I, I, I, V, V, V, V, V, V, c_size_t, V, V, V]
     lib.mi_ep_signal.argtypes = [V, I, I, c_uint64, V]
     lib.mi_ep_wait.argtypes = [V, I, c_uint64, V, I, V]
     lib.mi_ep_notify_post.argtypes = [V, I, I, I, V, I, c_uint32, V]
@@ -73,7 +73,7 @@ def ck(rc):
 _SYNC = {}
 
 
-def layout(topk_idx, E, W, coop=None):
+def layout(topk_idx, E, W, coop=None, status=None, words=None):
     """-> dict of device tensors (A1).  coop: True = lend the two persistent sync words (one cooperative launch for > 1024 tokens),
     False = NULL (three launches); default alternates per call so that every test exercises both forms of the same function."""
     T, K = topk_idx.shape
@@ -93,7 +93,7 @@ def layout(topk_idx, E, W, coop=None):
     ck(lib().mi_ep_dispatch_layout(ptr(topk_idx), int(topk_idx.dtype == torch.int32), T, K, E, W,
                                    ptr(out["num_tokens_per_rank"]), ptr(out["num_tokens_per_expert"]), ptr(out["is_token_in_rank"]),
                                    ptr(out["send_token_idx_small"]), ptr(out["send_data_offset"]), ptr(ws), wsb,
-                                   ptr(_SYNC["words"]) if coop else None, stream_ptr()))
+                                   (ptr(words) if words is not None else ptr(_SYNC["words"])) if coop else None, ptr(status) if status is not None else None, stream_ptr()))
     out["_ws"] = ws
     return out
 

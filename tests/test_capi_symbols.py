@@ -32,6 +32,19 @@ def test_row_geometry_helpers_are_host_callable():
     assert b"gfx950" in lib.mi_ep_version()
 
 
+def test_notify_lds_budget_is_host_checkable():
+    """The count exchange keeps W * (E + 1) counts in one workgroup's LDS; shapes beyond a CU's 160 KB are refused with MI_EP_EINVAL
+    instead of failing at launch.  The helper is host-callable so a runtime can say so up front."""
+    lib = load("libmi_ep.so")
+    lib.mi_ep_notify_lds_bytes.restype = ctypes.c_size_t
+    lib.mi_ep_notify_lds_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    f = lib.mi_ep_notify_lds_bytes
+    assert f(8, 256) == (2 * 256 + 8 + 32 + 2 + 8 * 257) * 4
+    assert f(8, 2048) <= 160 * 1024 and f(16, 2048) <= 160 * 1024 and f(64, 512) <= 160 * 1024      # every shape of one xGMI node, and more
+    assert f(64, 2048) > 160 * 1024 and f(32, 2048) > 160 * 1024
+    assert f(3, 8) == 0 and f(0, 8) == 0
+
+
 def test_compact_staging_geometry_and_capacity_check():
     """mi_ep_dispatch_index_offset fixes where the expert-sorted index sits in a staging region (same value on every rank:
     it only depends on hidden, mode, top-k and the region size); stage_compact refuses a batch the region cannot hold

@@ -62,6 +62,31 @@ def test_dispatch_layout_bit_exact(T, K, E, W, drop, i32, coop):
     assert not Hh._SYNC["words"].any()
 
 
+def test_dispatch_layout_barrier_timeout_is_reported():
+    """A grid barrier that cannot close (here: an arrival word preset so that the workgroups' arrivals wrap it to 0) must not return
+    plausible tables silently: after its 2 s bound the kernel stores MI_EP_STATUS_LAYOUT_BARRIER in the caller's status word and sets
+    the count tables to -1; the pair of words re-arms itself, and the next launch that borrows it is correct again."""
+    import ep_harness as Hh
+    T, K, E, W = 4096, 8, 256, 8
+    rng = np.random.default_rng(5)
+    idx = make_topk(rng, T, K, E, 0.0)
+    t = torch.from_numpy(idx).cuda()
+    B = (T + 16 * 16 - 1) // (16 * 16)                     # workgroups of 16 units of 16 tokens
+    words = torch.tensor([-B, 0], dtype=torch.int32, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    got = Hh.layout(t, E, W, coop=True, status=status, words=words)
+    torch.cuda.synchronize()
+    assert int(status[0]) == 6000                           # MI_EP_STATUS_LAYOUT_BARRIER
+    assert (got["num_tokens_per_expert"] == -1).all() and (got["num_tokens_per_rank"] == -1).all()
+    assert not words.any()                                  # re-armed by the last workgroup to leave
+    status.zero_()
+    got = Hh.layout(t, E, W, coop=True, status=status, words=words)
+    torch.cuda.synchronize()
+    want = O.dispatch_layout(idx, E, W)
+    assert int(status[0]) == 0 and np.array_equal(got["num_tokens_per_expert"].cpu().numpy(), want["num_tokens_per_expert"])
+    assert np.array_equal(got["send_token_idx_small"].cpu().numpy(), want["send_token_idx_small"])
+
+
 DISPATCH_CASES = [
     # W, T, H, K, E, drop, active
     (1, 256, 1024, 2, 8, 0.0, None),        # BASELINE C1 shape
