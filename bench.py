@@ -130,6 +130,18 @@ def one_step(buf, x, topk_idx, topk_w, y):
     return out, n, y, recv, handle
 
 
+def one_step_nosync(buf, x, topk_idx, topk_w, y, worst):
+    """The same step in DeepEP's graph-friendly form: dispatch(num_worst_tokens = worst) returns worst-case sized outputs and the host
+    never learns the row count (no pinned-word spin, no allocation after the exchange); combine consumes the handle as is."""
+    per_rank, _, per_expert, is_in, _ = buf.get_dispatch_layout(topk_idx, EXPERTS)
+    recv, _, _, _, handle, _ = buf.dispatch(x, num_tokens_per_rank=per_rank, is_token_in_rank=is_in, num_tokens_per_expert=per_expert,
+                                            topk_idx=topk_idx, topk_weights=topk_w, quant_mode="int8", num_worst_tokens=worst)
+    if y is None:
+        y = (recv[0].float() * recv[1][:, None]).to(torch.bfloat16)      # expert stand-in, made once, untimed
+    out, _, _ = buf.combine(y, handle)
+    return out, y
+
+
 def flush_c_stdout():
     """RCCL printf()s its version banner at communicator creation; with stdout a pipe that text waits in libc's buffer until
     exit -- i.e. after the JSON line -- unless it is pushed out first (every rank, right after the first collective)."""
@@ -186,13 +198,24 @@ def queued_stats(fn, n=200, warm=10):
     for _ in range(warm):
         fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    host = []
     for a, b in evs:
         a.record()
+        h0 = time.perf_counter()
         fn()
+        host.append((time.perf_counter() - h0) * 1e6)
         b.record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-    return {"p50_us": ts[len(ts) // 2], "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "min_us": ts[0]}
+    dev = [a.elapsed_time(b) * 1e3 for a, b in evs]
+    ts = sorted(dev)
+    # The slowest device samples are not slow kernels: the event pair brackets "start event executed ... end event executed" on the GPU,
+    # so whenever the HOST takes longer to enqueue a call than the GPU takes to run it (allocator growth, a Python GC pause) the GPU sits
+    # between the two events waiting for work.  Reported so that the tail can be read: the host's own enqueue time of the slowest sample.
+    worst = max(range(n), key=lambda i: dev[i])
+    hs = sorted(host)
+    return {"p50_us": ts[len(ts) // 2], "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "min_us": ts[0],
+            "host_enqueue_us_p50": hs[len(hs) // 2], "host_enqueue_us_max": hs[-1], "host_enqueue_us_of_slowest_sample": host[worst],
+            "slowest_sample_index": worst}
 
 
 def graph_stats(fn, n=200, warm=3):
@@ -477,7 +500,9 @@ def low_latency_section(buf, rank, world):
     def queued():               # the same calls queued back to back (no host synchronisation between calls)
         d = queued_stats(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
         c = queued_stats(lambda: buf.low_latency_combine(st["y"], idx, w, st["handle"]))
-        return {"qd50": d["p50_us"], "qd99": d["p99_us"], "qc50": c["p50_us"], "qc99": c["p99_us"]}
+        return {"qd50": d["p50_us"], "qd99": d["p99_us"], "qc50": c["p50_us"], "qc99": c["p99_us"],
+                "qdh50": d["host_enqueue_us_p50"], "qdhmax": d["host_enqueue_us_max"], "qdhslow": d["host_enqueue_us_of_slowest_sample"],
+                "qdslowi": d["slowest_sample_index"]}
 
     def graph_dispatch():       # the same calls replayed from a captured HIP graph (device-resident epochs make them capturable)
         d = graph_stats(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
@@ -509,7 +534,11 @@ def low_latency_section(buf, rank, world):
             # each call captured once in a HIP graph and replayed (200 replays): no host work between its kernels
             # 200 calls queued back to back, one synchronisation at the end (the p50 / p99 above synchronise after every call: the GPU idles
             # in between and its clocks sag, which is what a lone decode step sees, not a streaming one)
-            "queued": {"dispatch_us_p50": m["qd50"], "dispatch_us_p99": m["qd99"], "combine_us_p50": m["qc50"], "combine_us_p99": m["qc99"]},
+            "queued": {"dispatch_us_p50": m["qd50"], "dispatch_us_p99": m["qd99"], "combine_us_p50": m["qc50"], "combine_us_p99": m["qc99"],
+                       # reading the tail: host time to enqueue one dispatch call (p50 / max) and of the slowest device sample -- when that is
+                       # of the order of the p99, the GPU was waiting for the host between the two events, not running a slow kernel
+                       "dispatch_host_enqueue_us_p50": m["qdh50"], "dispatch_host_enqueue_us_max": m["qdhmax"],
+                       "dispatch_host_enqueue_us_of_slowest_sample": m["qdhslow"], "dispatch_slowest_sample_index": m["qdslowi"]},
             "graph_replay": {"dispatch_us_p50": m["gd50"], "dispatch_us_p99": m["gd99"], "combine_us_p50": m["gc50"], "combine_us_p99": m["gc99"],
                              # per dispatch + combine PAIR inside a graph of ten pairs (submission amortised)
                              "pair_us_p50_in_graph_of_10": m["gp50"], "pair_us_p99_in_graph_of_10": m["gp99"]},
@@ -694,6 +723,40 @@ def main():
     bytes_per_step = 2 * total_rows * HIDDEN * 2          # dispatch recv + combine send, BF16-equivalent (reference convention)
     value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
 
+    # ---- the same K steps without the host on the critical path (dispatch(num_worst_tokens = T * K * W): worst-case sized outputs, the
+    # host never reads the receive count): what a serving stack that captures the step in a graph pays
+    nosync = None
+    if windowed:
+        try:
+            worst = T * TOPK * world
+            out_ns, y_ns = one_step_nosync(buf, x, topk_idx, topk_w, None, worst)
+            torch.cuda.synchronize()
+            ok_ns = check_round_trip(out_ns, x, topk_w) < 3e-3
+            err_ns = None
+        except Exception as e:  # noqa: BLE001
+            ok_ns, err_ns, y_ns, worst = False, str(e)[:300], None, 0
+        for _ in range(2):
+            if err_ns is None:
+                try:
+                    one_step_nosync(buf, x, topk_idx, topk_w, y_ns, worst)
+                except Exception as e:  # noqa: BLE001
+                    err_ns = str(e)[:300]
+        flush_cache()
+        barrier_sync()
+        t0 = time.perf_counter()
+        if err_ns is None:
+            try:
+                for _ in range(args.steps):
+                    one_step_nosync(buf, x, topk_idx, topk_w, y_ns, worst)
+            except Exception as e:  # noqa: BLE001
+                err_ns = str(e)[:300]
+        barrier_sync()
+        tns = torch.tensor([time.perf_counter() - t0, 0.0 if (err_ns is None and ok_ns) else 1.0], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tns, op=dist.ReduceOp.MAX)
+        nosync = {"error": err_ns or "round trip check failed on some rank"} if tns[1].item() > 0 else \
+            {"ms_per_step": float(tns[0].item()) / args.steps * 1e3, "num_worst_tokens": worst}
+        del y_ns
+
     # ---- EP = 8 proxy on whatever this run has: with the own-rank shortcuts off EVERY row takes the path a remote row takes (dispatch:
     # pull_indexed / stage_push for all rows; combine: every row pushed through the window), which is what 7/8 of the rows of an EP = 8
     # rank do.  Same results; the kernel times transfer to EP = 8 as HBM-side costs (the xGMI legs come on top).
@@ -792,6 +855,12 @@ def main():
             proxy["what"] = ("own-rank shortcuts off (set_local_row_paths(False, False)): every row staged, pulled by index and pushed "
                              "through the window like a remote row; HBM-side kernel times of an EP = 8 rank, xGMI legs not included")
         result["ep8_proxy"] = proxy
+    if nosync is not None:
+        if "ms_per_step" in nosync:
+            nosync["value"] = bytes_per_step / (nosync["ms_per_step"] * 1e-3) / 1e9
+            nosync["what"] = ("same K steps through dispatch(num_worst_tokens=T*K*W): worst-case sized outputs, no host read of the "
+                              "receive count between dispatch and combine (the headline's dispatch reads it: one pinned-word spin per step)")
+        result["no_host_sync"] = nosync
     if world == 1 and proxy is not None and "kernels" in proxy:
         p8, t8 = routing_stats(topk_idx, 8, 0)
         result["xgmi_projection"] = xgmi_projection(p8, t8, {k: v["avg_us"] for k, v in proxy["kernels"].items()},

@@ -88,8 +88,8 @@ size_t mi_ep_combine_row_bytes(int hidden);
  * them from a ring.  Batches of more than 1024 tokens then run as ONE launch (workgroups of 1024 tokens meeting at a self-resetting
  * grid barrier; at most 128 workgroups, which this 256-CU part keeps co-resident) instead of three; NULL keeps the three launches.
  * Results are identical.
- * status: NULL, or a device-visible word: if the grid barrier is not passed within 2 s (a workgroup that never became resident, or a
- * pair of sync words lent twice) the kernel stores MI_EP_STATUS_LAYOUT_BARRIER there, sets the three count tables to -1 and returns;
+ * status: NULL, or a device-visible word: if the grid barrier is not passed within 2 s (a workgroup that never became resident) or the
+ * arrival count is seen above the grid size (a pair of sync words lent twice, or not zero when lent) the kernel stores MI_EP_STATUS_LAYOUT_BARRIER there, sets the three count tables to -1 and returns;
  * it never hangs and never returns plausible-looking garbage silently. */
 #define MI_EP_STATUS_LAYOUT_BARRIER 6000
 size_t mi_ep_dispatch_layout_workspace(int num_tokens, int num_topk, int num_experts);

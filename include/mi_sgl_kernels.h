@@ -49,8 +49,20 @@ const char *mi_sgl_kernels_version(void);
  *   kv_seq_lens int32 [batch]; block_table int32 [batch, bt_stride] (logical page -> physical block)
  * q_heads % kv_heads == 0; any page_size >= 1.  num_splits >= 1 partitions the KV range of every sequence
  * (flash-decoding).  `workspace` of mi_mla_decode_workspace() bytes (device memory, contents irrelevant) is needed when
- * num_splits > 1 or q_heads / kv_heads > 64.  Pass num_splits = 0 to let the library choose (mi_mla_decode_num_splits). */
+ * num_splits > 1 or q_heads / kv_heads > 64.  Pass num_splits = 0 to let the library choose (mi_mla_decode_num_splits).
+ * MI_MLA_SPLITS_PLANNED (what mi_mla_decode_num_splits returns for kv groups of 65..128 heads): no uniform split count at all -- one small
+ * launch in front of the kernel reads kv_seq_lens ON THE DEVICE (no host sync) and cuts every sequence into pieces of about
+ * (all tiles + fixed costs) / CUs, longest first; a batch of ragged lengths then runs at the pace of the average sequence, not of
+ * its longest.  Pass the same value to mi_mla_decode_workspace. */
+#define MI_MLA_SPLITS_PLANNED (-1)
 size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
+/* Introspection of the planned form (tests, tuning): byte offset of the work list inside a workspace sized with MI_MLA_SPLITS_PLANNED, and
+ * the number of concurrently running workgroups it was balanced for (the CU count).  Work-list words (int32):
+ *   [0] items incl. padding, [1] rounds, [2 + k] first item of round k (k < 16);  [32 + 2 s] rank of (sequence, kv head) pair s by
+ *   descending cost, [33 + 2 s] its piece count n_s;  then 4 words per item: pair (-1 = padding), first tile, end tile, k | n_s << 8
+ *   (tiles of 32 keys).  Item of piece k of the pair ranked r: word[2 + k] + r. */
+size_t mi_mla_decode_plan_offset(int batch, int q_heads);
+int mi_mla_decode_plan_workers(void);
 int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
 /* kv groups of more than 64 heads have two kernel forms: 8 waves per workgroup (two per SIMD, the default) and 4 (one per SIMD).
  * waves = 4 / 8 forces one for the calls that follow, 0 returns to the default (or MI_MLA_WIDE8).  Process-wide, not thread-safe:

@@ -39,12 +39,12 @@ __device__ __forceinline__ unsigned long long match_any_bits(unsigned key, bool 
 //     a grid barrier (B <= 128 co-resident workgroups; two self-resetting words in caller-owned zero-initialised memory), and each
 //     derives the running base of its units from the totals of the workgroups in front of it: three launches (4.9 + 6.2 + 6.9 us
 //     back to back at 4096 tokens) become one, and the [U][E] histograms / bases never travel through global memory.
-// -> true when every workgroup arrived; false after a 2 s spin (a workgroup that never became resident, or sync words shared with
-// another launch in flight): the caller must then NOT trust the other workgroups' totals -- it reports MI_EP_STATUS_LAYOUT_BARRIER
+// -> true when every workgroup arrived; false after a 2 s spin (a workgroup that never became resident) or when the arrival count is
+// seen ABOVE the grid size (sync words shared with another launch in flight): the caller must then NOT trust the other workgroups' totals -- it reports MI_EP_STATUS_LAYOUT_BARRIER
 // through `status` (the host's check_status raises) and poisons its outputs instead of writing plausible garbage.
-__device__ __forceinline__ bool layout_grid_barrier(uint32_t *sync, int B, int32_t *status)
+// (ok_s: one word of the caller's dynamic LDS -- a static __shared__ word here would add to the 160 KB the launcher asks for)
+__device__ __forceinline__ bool layout_grid_barrier(uint32_t *sync, int B, int32_t *status, int32_t *ok_s)
 {
-    __shared__ int ok_s;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -53,10 +53,14 @@ __device__ __forceinline__ bool layout_grid_barrier(uint32_t *sync, int B, int32
         bool ok = true;
         // relaxed polls, ONE acquire fence after the last arrival: an acquire load invalidates the XCD's L2 on every iteration, for every
         // workgroup of the XCD (tools/probes/ubench/launch_floor.hip: a flag hop between XCDs costs 0.4-0.7 us polled this way)
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)B) {
+        uint32_t seen;
+        while ((seen = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (uint32_t)B) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ull) { ok = false; break; }      // 2 s: never hang
         }
+        // more arrivals than this grid has workgroups: the pair of words is shared with another launch in flight (or was not zero when it
+        // was lent) -- some workgroups left before every total was published.  Same report as a timeout.
+        if (seen > (uint32_t)B) ok = false;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (!ok && status) report_status(status, kStatusLayoutBarrier);
         // the last workgroup to LEAVE the spin re-arms both words for the next launch that borrows this pair
@@ -64,10 +68,10 @@ __device__ __forceinline__ bool layout_grid_barrier(uint32_t *sync, int B, int32
             __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        ok_s = ok ? 1 : 0;
+        *ok_s = ok ? 1 : 0;
     }
     __syncthreads();
-    return ok_s != 0;
+    return *ok_s != 0;
 }
 
 // (a device function: the low-latency send kernel of dispatch.hip runs it in its first workgroup, B = 1, while the other workgroups
@@ -155,7 +159,7 @@ __device__ __forceinline__ void layout_small_body(
             mine[e] = s;
         }
         for (int r = tid; r < W; r += blockDim.x) mine[E + r] = rank_cnt[r];
-        if (!layout_grid_barrier(sync, B, status)) {
+        if (!layout_grid_barrier(sync, B, status, carry + 1)) {
             // barrier timed out: the tables of this launch cannot be formed.  The host learns through `status` (that is the contract);
             // the count tables are additionally set to -1 so that a caller who ignores it does not read plausible numbers.
             if (blk == B - 1) {

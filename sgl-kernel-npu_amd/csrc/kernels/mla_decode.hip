@@ -408,26 +408,33 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
     const int lane = threadIdx.x & 63;
     const int64_t bh = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (bh >= (int64_t)p.batch * p.q_heads) return;
-    const int S = p.num_splits;
     const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
     if (p.fix_only && p.fix_flags[b * p.kv_heads + h / p.group] == p.fix_epoch) {
         mla_recompute_head<BF16>(p, b, h, lane);
         return;
     }
+    // partial s of this head: slot (bh, s) of the uniform form, or -- planned form -- slot (item of piece s, head within the group)
+    int S = p.num_splits, rank = 0;
+    const int hg = h % p.group;
+    if (p.plan) {
+        const int32_t *info = p.plan + kPlanHdr + 2ll * (b * p.kv_heads + h / p.group);
+        rank = info[0], S = info[1];
+    }
     if (S == 1) return;
-    const float *ml = p.ws_ml + bh * S * 2;
+    auto slot = [&](int s) -> int64_t { return p.plan ? (int64_t)(p.plan[2 + s] + rank) * p.group + hg : bh * S + s; };
     float M = -INFINITY;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, ml[s * 2]);
+    for (int s = 0; s < S; ++s) M = fmaxf(M, p.ws_ml[slot(s) * 2]);
     float L = 0.f;
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.f;
     for (int s = 0; s < S; ++s) {
-        const float m = ml[s * 2];
+        const float *ml = p.ws_ml + slot(s) * 2;
+        const float m = ml[0];
         if (m == -INFINITY) continue;
         const float w = __builtin_amdgcn_exp2f(m - M);      // m is kept in the scaled log2 domain
-        L += w * ml[s * 2 + 1];
-        const float *po = p.ws_o + (bh * S + s) * kDN + lane * 8;
+        L += w * ml[1];
+        const float *po = p.ws_o + slot(s) * kDN + lane * 8;
         const f32x4 a = *(const f32x4 *)po, c = *(const f32x4 *)(po + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -444,6 +451,103 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
     *(u32x4 *)orow = w;
 }
 
+// The work list of the planned form (layout and rationale: mla_common.h).  One workgroup of 1024 threads; `tile` = keys per tile of the
+// kernel that will consume the list, `workers` = workgroups the chip runs at once (one per CU for the wide kernels).
+// Piece size: the smallest x (tiles per piece) for which sum_s n_s(x) <= workers, n_s(x) = ceil(tiles_s / x) capped so that a piece
+// keeps >= kPlanMinTiles tiles and a sequence <= kPlanMaxSplits pieces -- every piece then runs in the FIRST round of workgroups (a
+// list of more items than CUs leaves the last items to a second round: measured, a ragged C4 batch cut by "cost / average cost" made
+// 270 items and ran no faster than two uniform splits) and the longest piece is as short as that allows.  Found by a 16-way search, one
+// candidate per wave (the range shrinks sixteen-fold per round).
+__device__ __forceinline__ int plan_pieces(int tiles, int x)
+{
+    const int n = (tiles + x - 1) / x;
+    return max(1, min(n, min(kPlanMaxSplits, tiles / kPlanMinTiles)));
+}
+__global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restrict__ seq_lens, int batch, int kv_heads, int tile, int workers,
+                                                        int32_t *__restrict__ plan)
+{
+    __shared__ int s_tiles[kPlanSortMax];
+    __shared__ int s_cnt[kPlanMaxSplits], s_base[kPlanMaxSplits], s_cand[16];
+    __shared__ long long s_total;
+    __shared__ int s_max, s_lo, s_hi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seqs = batch * kv_heads;
+    const long long items_max = plan_items_max(seqs, workers);
+    int32_t *info = plan + kPlanHdr, *items = plan + kPlanHdr + 2ll * seqs;
+    if (tid == 0) s_total = 0, s_max = 0;
+    if (tid < kPlanMaxSplits) s_cnt[tid] = 0;
+    __syncthreads();
+    // batches of more sequences than the sort handles, or than the chip has CUs, run unsplit (one piece each: they fill the chip as they are)
+    const bool sorted = seqs <= kPlanSortMax;
+    const bool split = sorted && seqs < workers;
+    long long mine = 0;
+    int mx = 0;
+    for (int s = tid; s < seqs; s += blockDim.x) {
+        const int t = (max(seq_lens[s / kv_heads], 0) + tile - 1) / tile;
+        if (sorted) s_tiles[s] = t;
+        mine += t, mx = max(mx, t);
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64), mx = max(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0 && mine) atomicAdd((unsigned long long *)&s_total, (unsigned long long)mine), atomicMax(&s_max, mx);
+    for (long long i = tid; i < items_max; i += blockDim.x) items[4 * i] = -1;      // every slot starts as padding
+    __syncthreads();
+    int x = max(s_max, 1);                                                           // one piece per sequence
+    if (split) {
+        if (tid == 0) s_lo = max(1, (int)((s_total + workers - 1) / workers)), s_hi = max(s_max, 1);
+        __syncthreads();
+        while (s_lo < s_hi) {                                                        // (LDS values: the same for every thread)
+            const int lo = s_lo, hi = s_hi;
+            const int step = max(1, (hi - lo + 15) / 16);
+            const int xw = min(hi, lo + wave * step);                                // wave w's candidate; non-decreasing in w
+            int cnt = 0;
+            for (int s = lane; s < seqs; s += 64) cnt += plan_pieces(s_tiles[s], xw);
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if (lane == 0) s_cand[wave] = cnt;
+            __syncthreads();
+            if (tid == 0) {
+                int w = 0;
+                while (w < 16 && s_cand[w] > workers) ++w;                           // first feasible candidate; hi itself always is
+                s_hi = w < 16 ? min(hi, lo + w * step) : hi;
+                s_lo = w > 0 ? min(s_hi, min(hi, lo + (w - 1) * step) + 1) : lo;     // the candidate before it is not
+            }
+            __syncthreads();
+        }
+        x = s_hi;
+    }
+    for (int s = tid; s < seqs; s += blockDim.x) {
+        int n = 1, rank = s;
+        if (sorted) {
+            const int t = s_tiles[s];
+            n = split ? plan_pieces(t, x) : 1;
+            rank = 0;
+            for (int o = 0; o < seqs; ++o) rank += (s_tiles[o] > t) || (s_tiles[o] == t && o < s);
+            for (int k = 0; k < n; ++k) atomicAdd(&s_cnt[k], 1);
+        }
+        info[2 * s] = rank, info[2 * s + 1] = n;
+    }
+    if (!sorted && tid == 0) s_cnt[0] = seqs;
+    __syncthreads();
+    if (tid == 0) {
+        int rounds = 0, at = 0;
+        for (int k = 0; k < kPlanMaxSplits; ++k) rounds += s_cnt[k] > 0;
+        for (int k = kPlanMaxSplits - 1; k >= 0; --k) {                             // highest k first, every base a multiple of 8
+            s_base[k] = at;
+            at += (s_cnt[k] + 7) & ~7;
+        }
+        plan[0] = at, plan[1] = rounds;
+        for (int k = 0; k < kPlanMaxSplits; ++k) plan[2 + k] = s_base[k];
+    }
+    __syncthreads();
+    for (int s = tid; s < seqs; s += blockDim.x) {
+        const int tiles = (max(seq_lens[s / kv_heads], 0) + tile - 1) / tile, rank = info[2 * s], n = info[2 * s + 1];
+        const int per = (tiles + n - 1) / n;
+        for (int k = 0; k < n; ++k) {
+            int32_t *it = items + 4ll * (s_base[k] + rank);
+            it[1] = min(tiles, k * per), it[2] = min(tiles, (k + 1) * per), it[3] = k | (n << 8);
+            it[0] = s;
+        }
+    }
+}
+
 }  // namespace mi_sgl
 
 using namespace mi_sgl;
@@ -457,9 +561,31 @@ static size_t partial_bytes(int batch, int q_heads, int num_splits)
     return num_splits <= 1 ? 0 : (size_t)batch * q_heads * num_splits * (kDN + 2) * sizeof(float);
 }
 
+// workgroups the chip runs at once with one wide workgroup per CU (the plan's `workers`); 256 when no device answers
+static int plan_workers()
+{
+    static int cached[64];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 256;
+    if (!cached[d]) {
+        int n = 0;
+        cached[d] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[d];
+}
+// planned form: partials of plan_items_max items x (at most 128 heads); kv_heads is not an argument of the workspace query, so the
+// number of (sequence, kv head) pairs is bounded through the group size the planned form requires (65..128 heads)
+static long long planned_seqs_bound(int batch, int q_heads) { return (long long)batch * (q_heads / 65 > 1 ? q_heads / 65 : 1); }
+static size_t planned_partial_bytes(long long seqs, int workers) { return (size_t)plan_items_max(seqs, workers) * 128 * (kDN + 2) * sizeof(float); }
+
 extern "C" size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits)
 {
     if (batch <= 0 || q_heads <= 0) return 0;
+    if (num_splits == MI_MLA_SPLITS_PLANNED) {
+        const long long seqs = planned_seqs_bound(batch, q_heads);
+        const int workers = plan_workers();
+        return planned_partial_bytes(seqs, workers) + (size_t)batch * q_heads * sizeof(uint32_t) + plan_words(seqs, workers) * sizeof(int32_t);
+    }
     return partial_bytes(batch, q_heads, num_splits) + (size_t)batch * q_heads * sizeof(uint32_t);   // q_heads >= kv_heads
 }
 
@@ -471,9 +597,36 @@ static bool use_wide(int group)
     return allow && group > kHeadsPerBlock && MLA_WAVES == 4;
 }
 
+// introspection for tests and tuning: where the work list sits in a planned workspace, and the worker count it was built for
+extern "C" size_t mi_mla_decode_plan_offset(int batch, int q_heads)
+{
+    if (batch <= 0 || q_heads <= 0) return 0;
+    return planned_partial_bytes(planned_seqs_bound(batch, q_heads), plan_workers()) + (size_t)batch * q_heads * sizeof(uint32_t);
+}
+extern "C" int mi_mla_decode_plan_workers(void) { return plan_workers(); }
+
+static int g_wide_variant = 0;      // 0 = environment / default, 4 or 8 = forced (tests run both forms in one process)
+static bool wide8_selected()
+{
+    static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) ? 8 : 4) : 8;
+    return (g_wide_variant ? g_wide_variant : wide_env) == 8;
+}
+// the planned form serves the eight-wave wide kernel with one 128-head block per (sequence, kv head); MI_MLA_PLAN=0 keeps uniform splits
+static bool plan_applies(int group)
+{
+    static const bool allow = !(getenv("MI_MLA_PLAN") && atoi(getenv("MI_MLA_PLAN")) == 0);
+    return allow && use_wide(group) && group <= 128 && wide8_selected();
+}
+
+static int uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
 extern "C" int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
 {
     if (batch <= 0 || q_heads <= 0 || kv_heads <= 0 || max_seq_len <= 0) return 1;
+    if (plan_applies(q_heads / kv_heads)) return MI_MLA_SPLITS_PLANNED;
+    return uniform_splits(batch, q_heads, kv_heads, max_seq_len);
+}
+static int uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
+{
     const int group = q_heads / kv_heads;
     const int hpb = use_wide(group) ? 128 : kHeadsPerBlock, tile = use_wide(group) ? kWideTile : kTile;
     const long long wgs = (long long)batch * kv_heads * ((group + hpb - 1) / hpb);
@@ -486,7 +639,6 @@ extern "C" int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, in
     return s < 1 ? 1 : s;
 }
 
-static int g_wide_variant = 0;      // 0 = environment / default, 4 or 8 = forced (tests run both forms in one process)
 extern "C" int mi_mla_decode_select_wide(int waves)
 {
     if (waves != 0 && waves != 4 && waves != 8) return MI_SGL_EINVAL;
@@ -508,7 +660,8 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     if ((q_stride_h % 8) || (q_stride_b % 8) || (kn_stride_row % 8) || (kn_stride_blk % 8) || (kn_stride_h % 8) ||
         (kr_stride_row % 8) || (kr_stride_blk % 8) || (kr_stride_h % 8) || (o_stride_h % 8) || (o_stride_b % 8))
         return MI_SGL_EINVAL;      // 16-byte vector accesses
-    if (num_splits <= 0) num_splits = mi_mla_decode_num_splits(batch, q_heads, kv_heads, max_seq_len);
+    if (num_splits == 0) num_splits = mi_mla_decode_num_splits(batch, q_heads, kv_heads, max_seq_len);
+    if (num_splits < 0 && num_splits != MI_MLA_SPLITS_PLANNED) return MI_SGL_EINVAL;
     // the wide kernel addresses the cache with 32-bit block strides and 24-bit row strides (elements); anything else (blocks of 4 GB,
     // rows of 32 MB) goes to the 64-head kernel, which keeps the general int64 form
     auto fits = [](int64_t v, int bits) { return v >= 0 && v < (1ll << bits); };
@@ -517,15 +670,34 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
                         // row-in-block * row stride is formed with a 24 x 24 -> 32-bit multiply: the product must fit 32 bits too
                         fits((int64_t)(page_size - 1) * kn_stride_row, 32) && fits((int64_t)(page_size - 1) * kr_stride_row, 32);
     const bool wide = use_wide(q_heads / kv_heads) && narrow;
-    if ((num_splits > 1 || wide) && (!workspace || workspace_bytes < mi_mla_decode_workspace(batch, q_heads, num_splits)))
+    // planned form asked for but not served by this launch (four-wave kernel selected, > 128 heads per group, a page size that is not a
+    // power of two, cache strides that need the 64-head kernel): uniform splits, as many as the caller's workspace holds
+    bool planned = num_splits == MI_MLA_SPLITS_PLANNED;
+    if (planned && !(wide && plan_applies(q_heads / kv_heads) && (page_size & (page_size - 1)) == 0)) {
+        planned = false;
+        num_splits = uniform_splits(batch, q_heads, kv_heads, max_seq_len);
+        while (num_splits > 1 && mi_mla_decode_workspace(batch, q_heads, num_splits) > workspace_bytes) --num_splits;
+    }
+    if ((num_splits > 1 || wide) && (!workspace || workspace_bytes < mi_mla_decode_workspace(batch, q_heads, planned ? MI_MLA_SPLITS_PLANNED : num_splits)))
         return MI_SGL_EINVAL;
     MlaParams p;
+    p.plan = nullptr;
+    const long long seqs = (long long)batch * kv_heads;
+    const int workers = plan_workers();
     p.q = (const uint16_t *)q, p.k_nope = (const uint16_t *)k_nope, p.k_rope = (const uint16_t *)k_rope;
     p.out = (uint16_t *)out, p.seq_lens = kv_seq_lens, p.block_table = block_table;
     p.ws_o = (float *)workspace;
-    p.ws_ml = p.ws_o ? p.ws_o + (size_t)batch * q_heads * num_splits * kDN : nullptr;
+    p.ws_ml = p.ws_o ? p.ws_o + (planned ? (size_t)plan_items_max(seqs, workers) * (q_heads / kv_heads) : (size_t)batch * q_heads * num_splits) * kDN : nullptr;
     static uint32_t epoch = 0;
-    p.fix_flags = workspace ? (uint32_t *)((char *)workspace + partial_bytes(batch, q_heads, num_splits)) : nullptr;
+    // (planned: the partial area is sized for the workspace query's bound on the sequences, >= this call's)
+    const size_t part_bytes = planned ? planned_partial_bytes(planned_seqs_bound(batch, q_heads), workers) : partial_bytes(batch, q_heads, num_splits);
+    p.fix_flags = workspace ? (uint32_t *)((char *)workspace + part_bytes) : nullptr;
+    if (planned) {
+        int32_t *plan = (int32_t *)((char *)workspace + part_bytes + (size_t)batch * q_heads * sizeof(uint32_t));
+        mla_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, workers, plan);
+        p.plan = plan;
+        num_splits = 1;                                // per sequence now: the kernels read it from the list
+    }
     p.fix_epoch = ++epoch ? epoch : ++epoch;          // a stale word equal to the epoch only causes a redundant recompute
     p.fix_only = 0;
     p.arrive = p.fix_flags ? p.fix_flags + (size_t)batch * kv_heads : nullptr;       // inside the batch * q_heads flag words (wide: group > 64)
@@ -537,9 +709,8 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     // MI_MLA_WIDE8=0 or mi_mla_decode_select_wide(4)) -- same numerics contract, both under the whole test matrix; alternating in one
     // process at BASELINE C4 the eight-wave form is 1 % faster on full sequences (178.5 vs 180.5 us with the merge) and 4 % on ragged ones
     // (135.9 vs 141.4 us), DESIGN section 4.1
-    static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) ? 8 : 4) : 8;
-    const bool wide8 = (g_wide_variant ? g_wide_variant : wide_env) == 8;
-    p.inline_merge = wide && (wide8 ? num_splits == 1 : (num_splits <= inline_splits && num_splits <= 2));
+    const bool wide8 = wide8_selected();
+    p.inline_merge = !planned && wide && (wide8 ? num_splits == 1 : (num_splits <= inline_splits && num_splits <= 2));
     p.batch = batch, p.q_heads = q_heads, p.kv_heads = kv_heads, p.group = q_heads / kv_heads, p.page_size = page_size;
     p.bt_stride = bt_stride, p.num_splits = num_splits;
     p.q_sb = q_stride_b, p.q_sh = q_stride_h, p.kn_sblk = kn_stride_blk, p.kn_srow = kn_stride_row, p.kn_sh = kn_stride_h;
@@ -554,7 +725,8 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
         (void)hipFuncSetAttribute((const void *)mla_decode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     }
     if (wide) {
-        if (wide8) launch_mla_wide8(p, dtype, units, st);
+        if (planned) launch_mla_wide8(p, dtype, plan_items_max(seqs, workers), st);
+        else if (wide8) launch_mla_wide8(p, dtype, units, st);
         else launch_mla_wide(p, dtype, units, st);
         p.fix_only = 1;                                // the merge kernel also serves as the slow path for flagged sequences
     } else {

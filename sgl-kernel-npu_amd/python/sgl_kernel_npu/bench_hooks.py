@@ -41,18 +41,26 @@ def bench_mla_decode(steps=30, warmup=5):
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps
     dev_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
-    # the ragged copy of C4 (kv_seq_lens ~ U[1, 4096], same pages): about half the keys, but the longest sequence still sets the pace of
-    # its workgroups -- reported beside the headline, not part of it
+    # the ragged copy of C4 (kv_seq_lens ~ U[1, 4096], same pages): about half the keys -- reported beside the headline, not part of it.
+    # Default = the planned form (a device-built, length-aware work list: split counts per sequence, longest pieces first); the same
+    # batch with the uniform two splits of round 3 (the longest sequence sets the pace of its workgroups) is timed beside it.
     _, _, _, _, rlens = _mla_inputs(B, Hq, S, page, ragged=True)
-    for _ in range(warmup):
-        decode_mla(q, kn, kr, out, rlens, sm, page, bt)
-    ra, rb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ra.record()
-    for _ in range(steps):
-        decode_mla(q, kn, kr, out, rlens, sm, page, bt)
-    rb.record()
-    torch.cuda.synchronize()
-    r_ms = ra.elapsed_time(rb) / steps
+
+    def timed(ls, num_splits=0):          # 0 = the library's choice (the Python entry point's), n = uniform splits (torch op argument)
+        call = lambda: torch.ops.npu.decode_mla(q, kn, kr, out, ls, float(sm), int(page), bt, num_splits)
+        for _ in range(max(warmup // 4, 5)):
+            call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            call()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / steps
+
+    r_ms = timed(rlens)
+    r_ms_uniform = timed(rlens, num_splits=2)
+    ms_uniform = timed(lens, num_splits=2)
     r_bytes = float(rlens.sum().item()) * 576 * 2 + B * Hq * (576 + 512) * 2
     kv_bytes = float(lens.sum().item()) * 576 * 2
     io_bytes = B * Hq * (576 + 512) * 2
@@ -63,12 +71,14 @@ def bench_mla_decode(steps=30, warmup=5):
         "host_ms_per_step": wall * 1e3, "dtype": "bf16",
         "config": {"workload": "MLA paged decode, bs=128, q_heads=128, kv_heads=1, head_dim=576 (512+64), page_size=64, "
                                "seqlen=4096 (BASELINE C4)"},
-        "roofline": {"bound": "hbm", "kernel": "mla_decode_wide8_kernel + mla_merge_kernel (2 KV splits)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "mla_plan_kernel + mla_decode_wide8_kernel + mla_merge_kernel (device-built work list)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes": kv_bytes + io_bytes, "avg_launch_us": dev_ms * 1e3},
         "ragged": {"workload": "same batch, kv_seq_lens ~ U[1, 4096]", "ms_per_step": r_ms, "mean_seq_len": float(rlens.float().mean().item()),
-                   "achieved_GBps": r_bytes / (r_ms * 1e-3) / 1e9, "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-        "pmc_kernels": ["mla_decode_wide8_kernel<true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
+                   "achieved_GBps": r_bytes / (r_ms * 1e-3) / 1e9, "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "uniform_2_splits_ms_per_step": r_ms_uniform, "uniform_2_splits_frac": r_bytes / (r_ms_uniform * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        "uniform_2_splits_ms_per_step": ms_uniform,     # the full-length batch through num_splits = 2 (round 3's form), queued back to back
+        "pmc_kernels": ["mla_plan_kernel", "mla_decode_wide8_kernel<true, true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
         "mfma": {"achieved_TFLOPs": flops / (dev_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                  "frac": flops / (dev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
     }

@@ -824,3 +824,39 @@ def _gpu_tp_rmsnorm(rank, world, port, cfg):
     assert torch.allclose(k.cpu().float(), wk.float(), rtol=2 ** -6, atol=2 ** -6)
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# two get_dispatch_layout calls in flight on different streams of ONE Buffer (two-batch overlap): each cooperative launch
+# borrows its own pair of sync words from the Buffer's ring, so neither leaves the grid barrier on the other's arrivals
+# ----------------------------------------------------------------------------------------------
+def gpu_layout_two_streams_worker(rank, world, port, cfg):
+    run_guarded(_gpu_layout_two_streams, rank, world, port, cfg)
+
+
+def _gpu_layout_two_streams(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    torch.cuda.set_device(0)
+    group = _init(rank, world, port)
+    T, K, E, rounds = cfg
+    buf = deep_ep.Buffer(group, low_latency_mode=False)
+    rng = np.random.default_rng(11)
+    idx = [make_topk(rng, T + 256 * i, K, E, 0.1) for i in range(2)]
+    want = [O.dispatch_layout(i, E, world) for i in idx]
+    dev = [torch.from_numpy(i).cuda() for i in idx]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rnd in range(rounds):
+        got = [None, None]
+        for s in (0, 1):
+            with torch.cuda.stream(streams[s]):
+                for _ in range(4):                      # several launches queued per stream: the two streams' kernels interleave
+                    got[s] = buf.get_dispatch_layout(dev[s], E)
+        torch.cuda.synchronize()
+        for s in (0, 1):
+            per_rank, _, per_expert, is_in, _ = got[s]
+            assert np.array_equal(per_expert.cpu().numpy(), want[s]["num_tokens_per_expert"]), (rnd, s)
+            assert np.array_equal(per_rank.cpu().numpy(), want[s]["num_tokens_per_rank"]), (rnd, s)
+            assert np.array_equal(is_in.cpu().numpy().astype(bool), want[s]["is_token_in_rank"].astype(bool)), (rnd, s)
+    dist.destroy_process_group()

@@ -98,3 +98,9 @@ def test_split_qkv_tp_rmsnorm_rope_all_reduces_the_variance_across_ranks(world):
     """norm/split_qkv_tp_rmsnorm_rope.py with tp_world > 1: `world` processes hold the column shards of one row batch; the wrapper's
     dist.all_reduce between its two launches must make every shard normalise with the GLOBAL mean of squares."""
     _spawn(mp_workers.gpu_tp_rmsnorm_worker, world, (9, 512, 128, 64))
+
+
+def test_layout_calls_on_two_streams_do_not_share_barrier_words():
+    """get_dispatch_layout issued concurrently on two streams of one Buffer (4096 + 4352 tokens: both take the cooperative
+    one-launch form): every launch borrows its own sync-word pair from the Buffer's ring; all tables match the oracle."""
+    _spawn(mp_workers.gpu_layout_two_streams_worker, 1, (4096, 8, 256, 10))

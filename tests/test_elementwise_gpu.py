@@ -570,9 +570,32 @@ def _mla_pre_exact(z, eps=1e-6):
     return q0, q1, rms(k_nope, z["gamma2"]), (kp * c + rot(kp) * s_).squeeze(1)
 
 
-@pytest.mark.parametrize("N,Hq,hidden", [(1, 32, 7168), (16, 64, 7168), (31, 128, 7168), (31, 128, 6144), (70, 16, 2048),
-                                         (128, 128, 7168), (1024, 16, 7168), (200, 128, 7168)])
-def test_mla_preprocess(N, Hq, hidden):
+_MLA_PRE_MISS = {}          # measured fraction of elements outside the reference's atol = rtol = 1e-3, per (case, output)
+
+
+def _record_mla_pre_miss(key, frac):
+    """Keeps the measured miss fractions of a test session and mirrors them to gpurun_out/mla_pre_miss_fraction.json (the copy under
+    profiles/ is what DESIGN.md quotes); never fails the test."""
+    import json
+    import os
+    _MLA_PRE_MISS[key] = frac
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "mla_pre_miss_fraction.json"), "w") as f:
+            json.dump(_MLA_PRE_MISS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("N,Hq,hidden,dt", [(1, 32, 7168, torch.bfloat16), (16, 64, 7168, torch.bfloat16), (31, 128, 7168, torch.bfloat16),
+                                            (31, 128, 6144, torch.bfloat16), (70, 16, 2048, torch.bfloat16), (128, 128, 7168, torch.bfloat16),
+                                            (1024, 16, 7168, torch.bfloat16), (200, 128, 7168, torch.bfloat16),
+                                            # fp16 end to end (reference mla_preprocess_mix_fp16.hpp): same chain, half-precision I/O
+                                            (31, 128, 7168, torch.float16), (70, 16, 2048, torch.float16), (128, 128, 7168, torch.float16),
+                                            (200, 32, 6144, torch.float16)],
+                         ids=lambda v: str(v).replace("torch.", "") if isinstance(v, torch.dtype) else str(v))
+def test_mla_preprocess(N, Hq, hidden, dt):
     """torch.ops.npu.mla_preprocess vs the transcription of the reference golden (seed 42, shapes of
     tests/python/sgl_kernel_npu/test_mla_preprocess.py:487-498, plus the decode batch 128, the maximum 1024 tokens and a token
     count that is not a multiple of the 128-row block).
@@ -582,8 +605,8 @@ def test_mla_preprocess(N, Hq, hidden):
     sums inside the two RMSNorms and the BMM; a last-bit difference there moves a bf16 rounding (or, before GEMM2, an int8
     rounding) in a handful of elements.  So: (1) all but a vanishing fraction of the elements meet the reference's 1e-3,
     (2) the rest are bounded by what one flipped int8 step can do, (3) measured against the float64 evaluation of the same
-    network, the kernel is as accurate as the golden (mean absolute error, which a few flips do not dominate)."""
-    dt = torch.bfloat16
+    network, the kernel is as accurate as the golden (mean absolute error, which a few flips do not dominate).
+    The measured fraction of (1) per output is recorded (profiles/r04_mla_pre_miss_fraction.json) and the bar is set from it."""
     block_size, nblocks = 128, max(4, (N + 127) // 128 + 1)
     z = _mla_pre_inputs(N, Hq, hidden, dt)
     slots = torch.randperm(nblocks * block_size)[:N].to(torch.int32)
@@ -608,6 +631,7 @@ def test_mla_preprocess(N, Hq, hidden):
     for name, g, w, ex in zip(("q_out0", "q_out1", "k_nope", "k_pe"), got, want, exact):
         g64, w64 = g.double(), w.double()
         bad = ~torch.isclose(g64, w64, rtol=1e-3, atol=1e-3)
+        _record_mla_pre_miss(f"{N}x{Hq}x{hidden}_{str(dt).replace('torch.', '')}_{name}", bad.double().mean().item())
         assert bad.double().mean().item() <= 2e-3, (name, bad.double().mean().item())                 # (1)
         assert torch.allclose(g64, w64, rtol=2 ** -5, atol=5e-2), (name, (g64 - w64).abs().max().item())  # (2)
         err_k, err_o = (g64 - ex).abs().mean().item(), (w64 - ex).abs().mean().item()

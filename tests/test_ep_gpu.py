@@ -63,8 +63,9 @@ def test_dispatch_layout_bit_exact(T, K, E, W, drop, i32, coop):
 
 
 def test_dispatch_layout_barrier_timeout_is_reported():
-    """A grid barrier that cannot close (here: an arrival word preset so that the workgroups' arrivals wrap it to 0) must not return
-    plausible tables silently: after its 2 s bound the kernel stores MI_EP_STATUS_LAYOUT_BARRIER in the caller's status word and sets
+    """A grid barrier that cannot close properly (here: an arrival word that is not zero when lent -- the first workgroups see more
+    arrivals than the grid has workgroups, the last one sees the wrapped count and runs into the 2 s bound) must not return plausible
+    tables silently: the kernel stores MI_EP_STATUS_LAYOUT_BARRIER in the caller's status word and sets
     the count tables to -1; the pair of words re-arms itself, and the next launch that borrows it is correct again."""
     import ep_harness as Hh
     T, K, E, W = 4096, 8, 256, 8

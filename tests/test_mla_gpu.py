@@ -25,11 +25,13 @@ def lib():
         _lib.mi_mla_decode_workspace.restype = c_size_t
         _lib.mi_mla_decode_workspace.argtypes = [c_int, c_int, c_int]
         _lib.mi_mla_decode_num_splits.argtypes = [c_int] * 4
+        _lib.mi_mla_decode_plan_offset.restype = c_size_t
+        _lib.mi_mla_decode_plan_offset.argtypes = [c_int, c_int]
         _lib.mi_mla_decode.argtypes = [c_void_p] * 6 + [c_int] * 6 + [c_int64] * 10 + [c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]
     return _lib
 
 
-def run_mla(q, kn, kr, lens, bt, sm_scale, num_splits=0):
+def run_mla(q, kn, kr, lens, bt, sm_scale, num_splits=0, keep_ws=None):
     B, Hq, _ = q.shape
     Hkv = kn.shape[2]
     out = torch.empty((B, Hq, 512), dtype=q.dtype, device=q.device)
@@ -45,6 +47,8 @@ def run_mla(q, kn, kr, lens, bt, sm_scale, num_splits=0):
                          num_splits, ptr(ws), wsb, stream_ptr())
     assert rc == 0, rc
     torch.cuda.synchronize()
+    if keep_ws is not None:
+        keep_ws.append(ws)
     return out
 
 
@@ -60,8 +64,11 @@ def tol(dtype):
     return dict(atol=1e-3, rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -10)
 
 
+PLANNED = -1      # MI_MLA_SPLITS_PLANNED: the device-built, length-aware work list (eight-wave wide kernel; others fall back to uniform splits)
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "mla_ref_fp16_*.npz"))))
-@pytest.mark.parametrize("splits", [1, 3])
+@pytest.mark.parametrize("splits", [1, 3, PLANNED])
 def test_against_reference_kernel_outputs(path, splits, wide_variant):
     z = np.load(path)
     if wide_variant == 8 and z["q"].shape[1] // z["k_nope"].shape[2] <= 64:
@@ -84,7 +91,7 @@ CASES = [  # B, Hq, Hkv, S, page, ragged
 
 @pytest.mark.parametrize("B,Hq,Hkv,S,page,ragged", CASES)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("splits", [0, 1, 2])
+@pytest.mark.parametrize("splits", [0, 1, 2, PLANNED])
 def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits, wide_variant):
     if wide_variant == 8 and Hq // Hkv <= 64:
         pytest.skip("64-head kernel: one form")
@@ -162,7 +169,7 @@ def test_full_size_c4_vs_fp32(wide_variant):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("splits", [1, 2])
+@pytest.mark.parametrize("splits", [1, 2, PLANNED])
 def test_growing_scores_take_the_rescaling_path(dtype, splits, wide_variant):
     """128-head groups run a kernel that fixes the softmax reference at the first tile; sequences whose later scores
     outgrow it (here by ~90 nats) are flagged and recomputed by the rescaling kernel.  Mixed batch: one such sequence,
@@ -183,3 +190,95 @@ def test_growing_scores_take_the_rescaling_path(dtype, splits, wide_variant):
     got = run_mla(q.cuda(), kn.cuda(), kr.cuda(), lens.cuda(), bt.cuda(), sm, splits).cpu()
     assert torch.isfinite(got.float()).all()
     assert torch.allclose(got.float(), want.float(), rtol=2e-2, atol=2e-2), (got.float() - want.float()).abs().max()
+
+
+def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=16, sort_max=2048):
+    """The work list of the planned form restated on the host (sgl-kernel-npu_amd/csrc/kernels/mla_common.h, mla_plan_kernel): piece size
+    x = the smallest for which all pieces fit one round of workgroups; -> (n_items, base[k], rank[s], n[s], items {index: (pair, first
+    tile, end tile, k, n)})."""
+    seqs = len(lens) * kv_heads
+    tiles = [(max(int(lens[s // kv_heads]), 0) + tile - 1) // tile for s in range(seqs)]
+    pieces = lambda t, x: max(1, min((t + x - 1) // x, max_splits, t // min_tiles))
+    if seqs <= sort_max and seqs < workers:
+        x = next(x for x in range(max(1, (sum(tiles) + workers - 1) // workers), max(max(tiles), 1) + 1)
+                 if sum(pieces(t, x) for t in tiles) <= workers)
+        n = [pieces(t, x) for t in tiles]
+    else:
+        n = [1] * seqs
+    order = sorted(range(seqs), key=lambda s: (-tiles[s], s)) if seqs <= sort_max else list(range(seqs))
+    rank = [0] * seqs
+    for r, s in enumerate(order):
+        rank[s] = r
+    cnt = [sum(1 for s in range(seqs) if n[s] > k) for k in range(max_splits)]
+    base, at = [0] * max_splits, 0
+    for k in range(max_splits - 1, -1, -1):
+        base[k] = at
+        at += (cnt[k] + 7) & ~7
+    items = {}
+    for s in range(seqs):
+        per = (tiles[s] + n[s] - 1) // n[s]
+        for k in range(n[s]):
+            items[base[k] + rank[s]] = (s, min(tiles[s], k * per), min(tiles[s], (k + 1) * per), k, n[s])
+    return at, base, rank, n, items
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,S,page,kind", [(128, 128, 1, 4096, 64, "uniform"), (128, 128, 1, 4096, 64, "ragged"), (37, 128, 1, 3000, 16, "ragged"),
+                                                   (5, 256, 2, 9000, 64, "ragged"), (300, 128, 1, 700, 64, "ragged"), (16, 128, 1, 20000, 128, "one_long")])
+def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_splits(B, Hq, Hkv, S, page, kind):
+    """The device-built work list (length-aware split counts, longest pieces first, the pieces of a sequence on one XCD) against its host
+    restatement, word for word; structural properties (every tile of every sequence covered exactly once; padding only); and the
+    outputs of the planned launch against the same kernel with ONE piece per sequence (no merge at all): equal within the fp32
+    summation-order tolerance of a flash-decoding merge."""
+    L = lib()
+    assert L.mi_mla_decode_select_wide(8) == 0
+    try:
+        g = torch.Generator(device="cuda").manual_seed(B * 7 + S)
+        maxp = (S + page - 1) // page
+        nb = B * maxp
+        dt = torch.bfloat16
+        q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(dt)
+        kn = (torch.randn((nb, page, Hkv, 512), generator=g, device="cuda") * 0.5).to(dt)
+        kr = (torch.randn((nb, page, Hkv, 64), generator=g, device="cuda") * 0.5).to(dt)
+        bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+        if kind == "uniform":
+            lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+        elif kind == "ragged":
+            lens = torch.randint(0, S + 1, (B,), generator=g, device="cuda").to(torch.int32)      # zero-length sequences included
+        else:
+            lens = torch.randint(1, 300, (B,), generator=g, device="cuda").to(torch.int32)
+            lens[3] = S
+        keep = []
+        got = run_mla(q, kn, kr, lens, bt, 576 ** -0.5, PLANNED, keep_ws=keep)
+        one = run_mla(q, kn, kr, lens, bt, 576 ** -0.5, 1)
+        nz = lens.cpu() > 0
+        assert torch.allclose(got.float()[nz], one.float()[nz], rtol=2 ** -7, atol=2e-3), (got.float()[nz] - one.float()[nz]).abs().max()
+        # the work list itself
+        workers = L.mi_mla_decode_plan_workers()
+        off = L.mi_mla_decode_plan_offset(B, Hq)
+        seqs = B * Hkv
+        words = keep[0][off:].view(torch.int32).cpu().numpy()
+        n_items, base, rank, n, items = plan_reference(lens.cpu().tolist(), Hkv, workers)
+        assert words[0] == n_items and n_items % 8 == 0 and n_items <= seqs + workers + 8 * 16
+        if seqs < workers:
+            assert sum(n) <= workers, "every piece runs in the first round of workgroups"
+        assert list(words[2:18]) == base
+        info = words[32:32 + 2 * seqs].reshape(seqs, 2)
+        assert list(info[:, 0]) == rank and list(info[:, 1]) == n
+        it = words[32 + 2 * seqs:32 + 2 * seqs + 4 * n_items].reshape(n_items, 4)
+        covered = {}
+        for i in range(n_items):
+            if i in items:
+                s, t0, t1, k, ns = items[i]
+                assert tuple(it[i]) == (s, t0, t1, k | (ns << 8)), (i, tuple(it[i]), items[i])
+                covered.setdefault(s, []).append((t0, t1, i % 8))
+            else:
+                assert it[i][0] == -1, (i, tuple(it[i]))
+        for s in range(seqs):
+            pieces = sorted(covered[s])
+            tiles = (max(int(lens[s // Hkv]), 0) + 31) // 32
+            assert pieces[0][0] == 0 and pieces[-1][1] == tiles and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+            assert len({x[2] for x in pieces}) == 1, "the pieces of a sequence share blockIdx % 8"
+        if kind == "one_long":
+            assert n[3 * Hkv] > 4          # the one long sequence is cut into many pieces, the short ones stay whole
+    finally:
+        L.mi_mla_decode_select_wide(0)

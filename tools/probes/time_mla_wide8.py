@@ -7,7 +7,7 @@ import torch
 from sgl_kernel_npu.bench_hooks import _mla_inputs
 from capi import ptr, stream_ptr
 B, Hq, S, page = 128, 128, 4096, 64
-q, kn, kr, bt, lens = _mla_inputs(B, Hq, S, page)
+q, kn, kr, bt, lens = _mla_inputs(B, Hq, S, page, ragged=len(sys.argv) > 3)
 out = torch.empty((B, Hq, 512), dtype=torch.bfloat16, device="cuda")
 L = ctypes.CDLL(sys.argv[1])
 L.mi_mla_decode_workspace.restype = c_size_t
@@ -27,3 +27,17 @@ print("per tile [own vmcnt wait, barrier A + addresses, QK^T, softmax + publish,
 print("entry -> loop end: s_memtime ticks", round(m[6]), " s_memrealtime ticks", round(m[7]), " ratio", m[6] / max(m[7], 1))
 for w in range(8):
     print("wave", w, [round(v) for v in dbg[:, w, :6].mean(dim=0).tolist()])
+# workgroup-level stamps (100 MHz): [start, Q^T resident, loop end, exit] per workgroup, relative to the earliest start
+nwg = B * splits
+off = part + 2048 * 4 + 64 * 8 * 8 * 4
+st = ws[off: off + nwg * 32].view(torch.int64).reshape(nwg, 4).cpu().double()
+t0 = st[:, 0].min()
+st = (st - t0) / 100.0       # us
+import numpy as np
+a = st.numpy()
+pct = lambda v: [round(float(np.percentile(v, q)), 2) for q in (0, 50, 90, 100)]
+print("us since first workgroup start, percentiles [min, p50, p90, max]:")
+print("  start        ", pct(a[:, 0]))
+print("  Q^T resident ", pct(a[:, 1]), " prologue per WG", pct(a[:, 1] - a[:, 0]))
+print("  loop end     ", pct(a[:, 2]), " loop per WG    ", pct(a[:, 2] - a[:, 1]))
+print("  exit         ", pct(a[:, 3]), " epilogue per WG", pct(a[:, 3] - a[:, 2]))
