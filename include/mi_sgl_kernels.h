@@ -31,6 +31,7 @@ extern "C" {
 #define MI_SGL_OK 0
 #define MI_SGL_EINVAL (-1)
 #define MI_SGL_ELAUNCH (-2)
+#define MI_SGL_ENOTAPPLICABLE (-3)      /* a fast path that does not serve this shape: take the general one */
 
 #define MI_DTYPE_BF16 0
 #define MI_DTYPE_F16 1
@@ -266,6 +267,23 @@ int mi_mla_pre_mid(const int32_t *gemm1_i32, int num_partials, const int32_t *bi
  * q_nope_scale != NULL ([q_heads], I/O dtype; mode 2): q_out0 is int8 [tokens, q_heads, 512] = round(clamp(fp16(q * scale[h]))). */
 int mi_mla_pre_bmm_rope(const void *y, int tokens, int q_heads, const void *wuk_t, const void *cos, const void *sin, int dtype,
                         void *q_out0, void *q_out1, const void *q_nope_scale, void *stream);
+/* The WHOLE op in one launch (decode sizes): quantisation, GEMM1, the middle stage and the per-head stage run back to back inside one
+ * grid, separated by three grid barriers; stage outputs travel through the same caller-provided buffers as with the separate calls
+ * (a8 [tokens, hidden] int8, c1 [partials, tokens, 2112] int32, q8 [tokens, 1536] int8, tok0 / tok1 [tokens] float in per-token
+ * mode) and the results are bit-identical to them.  sync_words: mi_mla_preprocess_one_launch_sync_words() uint32 words of device
+ * memory, zero-initialised ONCE by the caller and lent to one call in flight at a time (the call counter that tags the barrier flags
+ * lives in them: nothing the host passes changes from call to call, so the launch can be captured in a graph and replayed).  Returns MI_SGL_ENOTAPPLICABLE when the grid (q_heads x token blocks) exceeds the
+ * number of CUs (all workgroups must be resident at once): issue the separate launches then.  A workgroup that is not joined by the
+ * others within 2 s traps (the launch fails loudly instead of hanging or returning partial results). */
+size_t mi_mla_preprocess_one_launch_sync_words(void);
+int mi_mla_preprocess_one_launch(const void *hidden, int tokens, int hidden_size, const void *quant_scale0, const int8_t *quant_offset0,
+                                 int8_t *a8, float *tok0, const int8_t *wdqkv, int32_t *c1, const int32_t *bias0, const float *descale0,
+                                 const void *gamma1, const void *beta1, const void *gamma2, const void *cos, const void *sin,
+                                 const int32_t *slotmapping, const void *quant_scale1, const int8_t *quant_offset1, float eps, int8_t *q8,
+                                 void *kv_cache, void *kv_cache_rope, float *tok1, int cache_mode, int block_size, const void *ctkv_scale,
+                                 const int8_t *wuq, int q_heads, const int32_t *bias1, const float *descale1, const void *wuk_t,
+                                 void *q_out0, void *q_out1, const void *q_nope_scale, int per_token, int dtype, uint32_t *sync_words,
+                                 void *stream);
 /* GEMM2 + per-head BMM + RoPE in one launch (what the op runs): bit-identical to mi_mla_pre_gemm_i8(mode 1, k = 1536) followed by
  * mi_mla_pre_bmm_rope; the GEMM2 output y never goes to global memory.  a [tokens, 1536] int8, wuq [q_heads*192, 1536] int8. */
 int mi_mla_pre_gemm2_bmm_rope(const int8_t *a, int tokens, const int8_t *wuq, int q_heads, const int32_t *bias, const float *descale,

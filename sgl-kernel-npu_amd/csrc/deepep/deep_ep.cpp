@@ -599,7 +599,10 @@ Buffer::intranode_dispatch(const at::Tensor &x, const std::optional<at::Tensor> 
     } else {
         // DeepEP's graph-friendly mode: worst-case sized outputs, no host sync, empty list (buffer.py:337-338,356-358)
         trt = num_worst_tokens;
-        real_max_bs = std::max<int64_t>(real_max_bs, num_worst_tokens);
+        // the largest per-rank batch is not read back in this mode; the caller's bound on the received ROWS (at most max_T * K rows
+        // from each of W ranks) bounds it: max_T <= num_worst_tokens / (K * W), rounded up.  (Taking the row bound itself for a token
+        // count made combine ask for K * W times the slot area it needs: C2 at one rank wanted 3.7 GB.)
+        real_max_bs = std::max<int64_t>(real_max_bs, ((int64_t)num_worst_tokens + (int64_t)K * W - 1) / ((int64_t)K * W));
     }
     const int64_t rows = trt == 0 ? 1 : trt;      // deep_ep.cpp:327-328
     if (guess >= rows) {

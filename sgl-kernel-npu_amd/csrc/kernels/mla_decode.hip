@@ -466,7 +466,7 @@ __device__ __forceinline__ int plan_pieces(int tiles, int x)
 __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restrict__ seq_lens, int batch, int kv_heads, int tile, int workers,
                                                         int32_t *__restrict__ plan)
 {
-    __shared__ int s_tiles[kPlanSortMax];
+    __shared__ int s_tiles[kPlanSortMax], s_rn[kPlanSortMax];      // tiles; rank | n << 16 (kept for the last pass)
     __shared__ int s_cnt[kPlanMaxSplits], s_base[kPlanMaxSplits], s_cand[16];
     __shared__ long long s_total;
     __shared__ int s_max, s_lo, s_hi;
@@ -523,6 +523,7 @@ __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restric
             for (int k = 0; k < n; ++k) atomicAdd(&s_cnt[k], 1);
         }
         info[2 * s] = rank, info[2 * s + 1] = n;
+        if (sorted) s_rn[s] = rank | (n << 16);
     }
     if (!sorted && tid == 0) s_cnt[0] = seqs;
     __syncthreads();
@@ -538,7 +539,8 @@ __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restric
     }
     __syncthreads();
     for (int s = tid; s < seqs; s += blockDim.x) {
-        const int tiles = (max(seq_lens[s / kv_heads], 0) + tile - 1) / tile, rank = info[2 * s], n = info[2 * s + 1];
+        const int tiles = sorted ? s_tiles[s] : (max(seq_lens[s / kv_heads], 0) + tile - 1) / tile;      // (no second trip to global memory)
+        const int rank = sorted ? (s_rn[s] & 0xFFFF) : s, n = sorted ? (s_rn[s] >> 16) : 1;
         const int per = (tiles + n - 1) / n;
         for (int k = 0; k < n; ++k) {
             int32_t *it = items + 4ll * (s_base[k] + rank);

@@ -122,6 +122,32 @@ __device__ __forceinline__ int wide_key(const WideCtx &c, int tile)
     return n < 0 ? 0 : n;
 }
 
+// Device-scope (sc1) accesses for the pair hand-off of the in-kernel merge (round 4): a write-through store is visible to a reader on any
+// XCD once the writer's vmcnt has drained -- no L2 write-back, no L2 invalidate.  Round 2's version published the partial with an
+// agent-scope release and read it behind an acquire fence and one load at a time: 202 us against 190-195 us for the separate merge launch.
+__device__ __forceinline__ void w4_st_sc1_x4(void *ptr, f32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void w4_ld_sc1_x4_batch8(f32x4 (&q)[8], const float *const (&a)[8])      // eight independent loads, then ONE wait
+{
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+        : "memory");
+}
+__device__ __forceinline__ float w4_ld_sc1_f32(const float *ptr)
+{
+    return __uint_as_float(__hip_atomic_load((const uint32_t *)ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void w4_st_sc1_f32(float *ptr, float v)
+{
+    __hip_atomic_store((uint32_t *)ptr, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // LDS-DMA issued through inline asm: the compiler then sees no vector-memory operation in the tile loop and places no
 // vmcnt wait of its own (with the builtin it put an `s_waitcnt vmcnt(0)` in front of the first transpose read of every
 // tile, i.e. the whole fill latency sat between QK and PV).  Ordering is explicit instead: one `s_waitcnt vmcnt(10)` per
@@ -485,7 +511,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // fills issued past the last tile
     __syncthreads();
-    if (threadIdx.x == 0 && *flag != 0) p.fix_flags[b * p.kv_heads + kvh] = p.fix_epoch;
+    if (threadIdx.x == 0 && *flag != 0)      // (device-scope store: the pair's second workgroup may read it during this launch)
+        __hip_atomic_store(p.fix_flags + b * p.kv_heads + kvh, p.fix_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- epilogue: wave w holds acc[dbl*4 + hb][4 rg + i] = O^T[d][head 32 hb + c32], d = 128 w + 64 (rg>>1) + 16 dbl + 8 (rg&1) + 4 kg + i;
     // the softmax statistics of a head live in the wave that owns it and reach the others through LDS
@@ -519,13 +546,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool finals = role != kFirst;                       // this workgroup writes output rows
     bool flagged = false;
     if (role == kSecond) {
-        // ONE lane polls (relaxed) and then acquires: an agent-scope acquire invalidates the XCD's L2, a release writes it
-        // back, and those operations serialise at the L2 -- issued by every wave of every workgroup they cost > 100 us here
+        // ONE lane polls (relaxed); no fence: the partner's partial was stored write-through (sc1) and is read with sc1 loads.  (With an
+        // agent-scope release / acquire pair instead -- an L2 write-back and an L2 invalidate per pair -- this lost to the merge launch.)
         if (threadIdx.x == 0) {
             while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (tag | 2u)) __builtin_amdgcn_s_sleep(4);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        __syncthreads();                                       // the other waves read the partner's partial with plain loads
+        __syncthreads();
     }
     if (p.inline_merge && finals)                              // own tiles (LDS flag) or the partner's (hand-off word)
         flagged = *flag != 0 || (role == kSecond && __hip_atomic_load(p.fix_flags + b * p.kv_heads + kvh, __ATOMIC_RELAXED,
@@ -568,20 +594,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < 8; ++j) {
                     const int hgx = hblk * 128 + hb * 32 + (it0 + j) * 2 + (lane >> 5);
                     const int64_t idx = ((int64_t)b * p.q_heads + kvh * p.group + min(hgx, p.group - 1)) * p.num_splits + split;
-                    if (hgx < p.group) *(f32x4 *)(p.ws_o + idx * kDN + wave * 128 + (lane & 31) * 4) = o8[j];
+                    if (hgx < p.group) {
+                        if (p.inline_merge) w4_st_sc1_x4(p.ws_o + idx * kDN + wave * 128 + (lane & 31) * 4, o8[j]);
+                        else *(f32x4 *)(p.ws_o + idx * kDN + wave * 128 + (lane & 31) * 4) = o8[j];
+                    }
                 }
             }
             if (wave == 0 && lane < 32) {                      // softmax statistics of the block's 32 heads: lane = head
                 const int hgx = hblk * 128 + hb * 32 + lane;
                 if (hgx < p.group) {
                     const int64_t idx = ((int64_t)b * p.q_heads + kvh * p.group + hgx) * p.num_splits + split;
-                    p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + lane];
-                    p.ws_ml[idx * 2 + 1] = lmb[hb * 32 + lane];
+                    w4_st_sc1_f32(p.ws_ml + idx * 2 + 0, lmb[128 + hb * 32 + lane]);
+                    w4_st_sc1_f32(p.ws_ml + idx * 2 + 1, lmb[hb * 32 + lane]);
                 }
             }
             continue;
         }
-#pragma unroll 4
+        f32x4 qp[16];                                          // second of a pair: the partner's rows, two batches of eight loads
+        if (role == kSecond) {
+#pragma unroll
+            for (int it0 = 0; it0 < 16; it0 += 8) {
+                const float *qa[8];
+                f32x4 q8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int hgx = min(hblk * 128 + hb * 32 + (it0 + j) * 2 + (lane >> 5), p.group - 1);
+                    const int64_t idp = ((int64_t)b * p.q_heads + kvh * p.group + hgx) * p.num_splits + (1 - split);
+                    qa[j] = p.ws_o + idp * kDN + wave * 128 + (lane & 31) * 4;
+                }
+                w4_ld_sc1_x4_batch8(q8, qa);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qp[it0 + j] = q8[j];
+            }
+        }
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int hl = it * 2 + (lane >> 5), ch = lane & 31;
             const int hgx = hblk * 128 + hb * 32 + hl;
@@ -595,12 +641,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float l_tot = l_h;
                 if (role == kSecond) {
                     const int64_t idp = idx - split + (1 - split);
-                    const float m_p = p.ws_ml[idp * 2 + 0], l_p = p.ws_ml[idp * 2 + 1];
+                    const float m_p = w4_ld_sc1_f32(p.ws_ml + idp * 2 + 0), l_p = w4_ld_sc1_f32(p.ws_ml + idp * 2 + 1);
                     const float mx = fmaxf(m_h, m_p);
                     const float w_s = m_h == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_h - mx);
                     const float w_p = m_p == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_p - mx);
                     l_tot = w_s * l_h + w_p * l_p;
-                    const f32x4 q = *(const f32x4 *)(p.ws_o + idp * kDN + wave * 128 + ch * 4);
+                    const f32x4 q = qp[it];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = w_s * o[e] + w_p * q[e];
                 }
@@ -620,7 +666,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (p.inline_merge && role == kFirst) {                    // partial (and the hand-off word, written above) complete -> mark
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores have left the CU
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(word, tag | 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // one L2 write-back
+        if (threadIdx.x == 0) __hip_atomic_store(word, tag | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the write-through stores have left
     }
 #ifdef MLAW_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

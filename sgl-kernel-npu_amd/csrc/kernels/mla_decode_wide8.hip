@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // path it allocates like the uniform form.  (Other page sizes take the uniform form.)
     int seq, hblk, t_begin, t_end;
     if constexpr (PLAN) {
-        if ((int)blockIdx.x >= p.plan[0]) return;
+        // (no separate check against the list's length: every slot behind it is padding, seq = -1)
         const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x);
         if (it.seq < 0) return;                                // padding of a round
         seq = it.seq, hblk = 0, t_begin = it.t_begin, t_end = it.t_end;

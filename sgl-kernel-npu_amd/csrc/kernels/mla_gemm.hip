@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "mi_sgl_kernels.h"
+#include "mla_pre_dev.h"
 
 namespace mi_sgl {
 
@@ -70,50 +71,60 @@ __device__ __forceinline__ void dma16(uint32_t dst, const void *vaddr)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(vaddr) : "memory");
 }
 
-// MODE 0: atomic int32 accumulate (split-K, blockIdx.y = chunk);  MODE 1: whole K, dequant epilogue into the I/O dtype
-template <int MODE, int BN, bool BF16>
-__global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict__ A, int M, int K, const int8_t *__restrict__ W, int N,
-                                                       int32_t *__restrict__ C, const int32_t *__restrict__ bias,
-                                                       const float *__restrict__ descale, const float *__restrict__ row_scale,
-                                                       uint16_t *__restrict__ Y)
+// MODE 0: one int32 partial product per K-chunk (split-K, by = chunk);  MODE 1: whole K, dequant epilogue into the I/O dtype.
+// NW waves x MT row tiles of 16 token rows = kBM rows per workgroup: (4, 2) in the stand-alone launch -- a weight fragment read from LDS
+// feeds two MFMAs --, (8, 1) inside the one-launch form, whose workgroups have eight waves (every wave must reach the barriers).
+// SC1: the partial products leave through device-scope (write-through) stores, for a consumer in the same launch.
+// PRE: the weight rows of the (first) K-chunk were requested by the caller (skinny_i8_issue_weights) before it did something else.
+template <int BN, int NW>
+__device__ __forceinline__ void skinny_i8_issue_weights(const int8_t *__restrict__ W, int N, int K, int n0, int k0, int klen, uint32_t lds_base)
 {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 4
+    for (int r = 0; r < BN / NW; ++r) {
+        const int row = wave * (BN / NW) + r;
+        const int8_t *src = W + (size_t)min(n0 + row, N - 1) * K + k0 + lane * 16;
+        if (lane * 16 < klen) dma16(lds_base + (uint32_t)(row * kRowStride), src);
+    }
+}
+template <int MODE, int BN, bool BF16, int NW, int MT, bool SC1, bool PRE = false>
+__device__ __forceinline__ void skinny_i8_body(const int8_t *__restrict__ A, int M, int K, const int8_t *__restrict__ W, int N,
+                                               int32_t *__restrict__ C, const int32_t *__restrict__ bias, const float *__restrict__ descale,
+                                               const float *__restrict__ row_scale, uint16_t *__restrict__ Y, int bx, int by, int bz,
+                                               uint8_t *lds /*[BN][kRowStride]*/)
+{
+    static_assert(NW * MT * 16 == kBM && BN % NW == 0, "row plan");
     constexpr int NT = BN / 16;                       // MFMA column tiles, all of them handled by every wave
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // [BN][kRowStride]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.z * kBM + wave * 32;
+    const int n0 = bx * BN, m0 = bz * kBM + wave * (MT * 16);
     const int chunks = (K + kKC - 1) / kKC;
-    const int c_begin = MODE == 0 ? blockIdx.y : 0, c_end = MODE == 0 ? blockIdx.y + 1 : chunks;
+    const int c_begin = MODE == 0 ? by : 0, c_end = MODE == 0 ? by + 1 : chunks;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
 
-    i32x4 acc[2][NT];
+    i32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = i32x4{0, 0, 0, 0};
 
-    const int8_t *arow[2];
+    const int8_t *arow[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) arow[mt] = A + (size_t)min(m0 + mt * 16 + c16, M - 1) * K + g * 16;      // rows past M: any valid row
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (size_t)min(m0 + mt * 16 + c16, M - 1) * K + g * 16;      // rows past M: any valid row
 
     for (int c = c_begin; c < c_end; ++c) {
         const int k0 = c * kKC;
         const int klen = min(kKC, K - k0);            // multiple of 64
-        // weights: wave w moves rows w*BN/4 ..; lane l < klen/16 carries 16 B of the row's chunk
-#pragma unroll 4
-        for (int r = 0; r < BN / 4; ++r) {
-            const int row = wave * (BN / 4) + r;
-            const int8_t *src = W + (size_t)min(n0 + row, N - 1) * K + k0 + lane * 16;
-            if (lane * 16 < klen) dma16(lds_base + (uint32_t)(row * kRowStride), src);
-        }
-        // activations of this wave's 32 token rows, straight into MFMA operand layout (L2-resident)
+        // weights: wave w moves rows w*BN/NW ..; lane l < klen/16 carries 16 B of the row's chunk
+        if (!(PRE && c == c_begin)) skinny_i8_issue_weights<BN, NW>(W, N, K, n0, k0, klen, lds_base);
+        // activations of this wave's token rows, straight into MFMA operand layout (L2-resident)
         // Every column tile of a K-chunk reads the SAME activation lines; started in the same order by every workgroup they all
         // queue on one L2 channel at a time.  Workgroup x starts its sweep x k-steps into the chunk (and wraps).
         const int nks = klen / 64;
-        const int rot = blockIdx.x % nks;
-        i32x4 af[2][kKC / 64];
+        const int rot = bx % nks;
+        i32x4 af[MT][kKC / 64];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int ks = 0; ks < kKC / 64; ++ks) {
                 const int kq = ks + rot < nks ? ks + rot : ks + rot - nks;
@@ -128,8 +139,8 @@ __global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const i32x4 bf = *(const i32x4 *)(lds + (nt * 16 + c16) * kRowStride + kq * 64 + g * 16);
-                acc[0][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0][ks], bf, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1][ks], bf, acc[1][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt][ks], bf, acc[mt][nt], 0, 0, 0);
             }
         }
         __syncthreads();                              // everybody is done with the stage before the next chunk lands
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict
 
     // lane holds C[row = m0 + mt*16 + 4g + r][col = n0 + nt*16 + c16]
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + mt * 16 + 4 * g + r;
@@ -149,7 +160,9 @@ __global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict
                 if (MODE == 0) {
                     // one partial product per K-chunk: C[chunk][row][col] (plain 64-byte-segment stores; device-scope atomics
                     // would have to leave the XCD-local L2 and ran 3x slower than the whole GEMM)
-                    C[((size_t)blockIdx.y * M + row) * N + col] = acc[mt][nt][r];
+                    int32_t *dst = C + ((size_t)by * M + row) * N + col;
+                    if constexpr (SC1) __hip_atomic_store(dst, acc[mt][nt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *dst = acc[mt][nt][r];
                 } else {
                     float y = (float)(acc[mt][nt][r] + (bias ? bias[col] : 0)) * descale[col];
                     if (row_scale) y = y * row_scale[row];      // per_token_quant_symm: the token's own scale (hpp:2273-2279)
@@ -157,6 +170,15 @@ __global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict
                 }
             }
         }
+}
+template <int MODE, int BN, bool BF16>
+__global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict__ A, int M, int K, const int8_t *__restrict__ W, int N,
+                                                       int32_t *__restrict__ C, const int32_t *__restrict__ bias,
+                                                       const float *__restrict__ descale, const float *__restrict__ row_scale,
+                                                       uint16_t *__restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // [BN][kRowStride]
+    skinny_i8_body<MODE, BN, BF16, 4, 2, false>(A, M, K, W, N, C, bias, descale, row_scale, Y, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
 }
 
 
@@ -412,24 +434,26 @@ __device__ __forceinline__ int ytile_off(int row, int col)
 // 2 of the 4 column tiles of every wuk_t eighth).  Same weight stream per workgroup, half the MFMAs and half the LDS operand reads:
 // 128 tokens x 128 heads become 256 workgroups (every CU) instead of 128, and batches of <= 64 tokens stop multiplying padding rows.
 // Accumulation order per output element is unchanged, so both forms are bit-identical.
-template <bool BF16, bool HALF>
-__global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__restrict__ A, int M, const int8_t *__restrict__ W, int Hq,
-                                                            const int32_t *__restrict__ bias, const float *__restrict__ descale,
-                                                            const float *__restrict__ row_scale, const uint16_t *__restrict__ wuk_t,
-                                                            const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
-                                                            uint16_t *__restrict__ out0, uint16_t *__restrict__ out1,
-                                                            const uint16_t *__restrict__ q_nope_scale)
+// (body: `h` = head, `bz` = token block; `lds` = the kF_Lds-byte ring.  PRE0: chunk 0 of the head's GEMM2 weights is already in ring
+//  slot 0 -- requested by the one-launch form in front of its earlier stages, tail_prefetch0 below.)
+template <bool BF16, bool HALF, bool PRE0>
+__device__ __forceinline__ void gemm2_bmm_rope_body(const int8_t *__restrict__ A, int M, const int8_t *__restrict__ W, int Hq,
+                                                    const int32_t *__restrict__ bias, const float *__restrict__ descale,
+                                                    const float *__restrict__ row_scale, const uint16_t *__restrict__ wuk_t,
+                                                    const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
+                                                    uint16_t *__restrict__ out0, uint16_t *__restrict__ out1,
+                                                    const uint16_t *__restrict__ q_nope_scale, const int h, const int bz, uint8_t *lds)
 {
     // 8 waves, one 16-row MFMA tile each (two waves per SIMD): a wave alone on its SIMD waits out every ds_read_b128 in front of the
     // two MFMAs it feeds -- the first version of this kernel, 4 waves x 32 rows with all 256 VGPRs taken by the activations, ran
     // 48 us, slower than the two launches it replaces
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // ring [3][192][256]; slot 0 later: y tile, then output tiles
+    // `lds`: ring [3][192][256]; slot 0 later: y tile, then output tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g = lane >> 4;
     constexpr int NT = HALF ? 6 : 12;                       // GEMM2 column tiles of this wave
     const int rt = HALF ? (wave & 3) : wave, ch = HALF ? (wave >> 2) : 0;      // row tile inside the workgroup, column half
     const int nt0 = ch * NT;
-    const int h = blockIdx.x, m0 = blockIdx.z * (HALF ? 64 : kBM) + rt * 16;
+    const int m0 = bz * (HALF ? 64 : kBM) + rt * 16;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
     uint8_t *ytile = lds + kF_Stage;                       // slot 1
     const int8_t *wh = W + (size_t)h * kF_Rows * kK2;
@@ -473,7 +497,12 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
         bsv[nt] = bias ? bias[h * kF_Rows + (nt0 + nt) * 16 + c16] : 0;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rsc[r] = row_scale ? row_scale[min(m0 + 4 * g + r, M - 1)] : 1.f;
+    for (int r = 0; r < 4; ++r) {
+        // (one-launch form: the scales were written in this launch by other workgroups, several to a cache line: device-scope loads)
+        if constexpr (PRE0)
+            rsc[r] = row_scale ? __uint_as_float(__hip_atomic_load((const uint32_t *)row_scale + min(m0 + 4 * g + r, M - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 1.f;
+        else rsc[r] = row_scale ? row_scale[min(m0 + 4 * g + r, M - 1)] : 1.f;
+    }
     // RoPE operands of this lane (row = lane / 4 of the wave's 16, 16 of the 64 positional columns): requested first, used last
     const int rrow = lane >> 2, rq = lane & 3;
     const bool rvalid = m0 + rrow < M;
@@ -496,7 +525,7 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     };
     F_STAMP(0)
     F_SPAN_AT(0)
-    issue_w(0, 0);
+    if constexpr (!PRE0) issue_w(0, 0);
     issue_a(0, afb[0]);
     issue_w(1, 1);
     issue_a(1, afb[1]);
@@ -680,6 +709,177 @@ __global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__res
     F_STAMP(21)
     F_SPAN_AT(1)
 }
+template <bool BF16, bool HALF>
+__global__ __launch_bounds__(512) void gemm2_bmm_rope_kernel(const int8_t *__restrict__ A, int M, const int8_t *__restrict__ W, int Hq,
+                                                            const int32_t *__restrict__ bias, const float *__restrict__ descale,
+                                                            const float *__restrict__ row_scale, const uint16_t *__restrict__ wuk_t,
+                                                            const uint16_t *__restrict__ cosv, const uint16_t *__restrict__ sinv,
+                                                            uint16_t *__restrict__ out0, uint16_t *__restrict__ out1,
+                                                            const uint16_t *__restrict__ q_nope_scale)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    gemm2_bmm_rope_body<BF16, HALF, false>(A, M, W, Hq, bias, descale, row_scale, wuk_t, cosv, sinv, out0, out1, q_nope_scale, (int)blockIdx.x,
+                                           (int)blockIdx.z, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The whole op in ONE launch (round 4; decode sizes: as many workgroups as the per-head stage has, all resident at once) -- BUILT,
+// BIT-IDENTICAL, NOT FASTER, therefore opt-in (MI_MLA_PRE_ONE_LAUNCH=1).
+// The four launches are four single-round kernels around three grid-wide dependencies (GEMM1 needs every quantised row; the middle
+// stage needs every K-chunk of a token; GEMM2 needs the whole normalised row).  Each boundary costs a launch (2.4 us on a stream,
+// profiles/r03_launch_floor.txt) plus a cold start.  Here the same stage bodies run back to back inside one grid, separated by grid
+// barriers; every workgroup requests the first 48 KB of its head's GEMM2 weights and the weight rows of its GEMM1 tile before anything
+// else; hand-off data between the stages (quantised rows, split-K partial products, requantised q, per-token scales) leaves through
+// device-scope write-through stores and is read once, by workgroups that have not touched those lines in this launch: no cache fence.
+// Stamps of all 256 workgroups at 128 tokens x 128 heads (100 MHz clock, us since the first workgroup's start; -DMEGA_TIMING):
+//   stage 0 done 3.2 | barrier passed 5.0-5.7 | GEMM1 done 13.6 | barrier 16.2-16.9 | middle done 23.8 (median 19.8: one token per
+//   workgroup, half of the workgroups idle) | barrier 25.9-26.7 | per-head stage done 42.3  -> 43 us on the device, the four launches'
+//   kernels sum to 43.6 us: a barrier costs what it replaces (1.8-2.6 us = the drain of the write-through stores + two flag hops against
+//   a 2.4 us launch), and what the stages themselves take is memory-latency chains (two dependent round trips each), not launch overhead.
+//   With the GEMM1 weights requested ahead of stage 0 GEMM1 shrinks 8.0 -> 6.1 us and stage 0 grows 2.0 -> 4.0 us (its loads queue behind the
+//   DMA).  Between events with a synchronisation per call: 53.0 us against 53.4 us for the four launches (same box).
+// All stage bodies are the stand-alone launches' (same arithmetic, same summation orders): the outputs are bit-identical, which the tests assert.
+struct MegaArgs {
+    // stage 0: quantisation of the hidden states (per tensor: scale0 / zp0; per token: tok0 out)
+    const uint16_t *x; int tokens, hidden; const uint16_t *qscale0; const int8_t *qoff0; int8_t *a8; float *tok0;
+    // stage 1: GEMM1 split-K
+    const int8_t *wdqkv; int32_t *c1; int parts;
+    // stage 2: middle
+    const int32_t *bias0; const float *descale0; const uint16_t *gamma1, *beta1, *gamma2, *cosv, *sinv; const int32_t *slotmapping;
+    const uint16_t *qscale1; const int8_t *qoff1; float eps; int8_t *q8; uint16_t *kv_cache, *kv_cache_rope; float *tok1; int cache_mode, block_size;
+    const uint16_t *ctkv_scale;
+    // stage 3: GEMM2 + BMM + RoPE per head
+    const int8_t *wuq; int q_heads; const int32_t *bias1; const float *descale1; const uint16_t *wuk_t; uint16_t *out0, *out1; const uint16_t *q_nope_scale;
+    // grid barriers: one flag word per workgroup and barrier + one "go" word per barrier, tagged with the call's epoch (never cleared)
+    uint32_t *flags; uint32_t epoch;
+    int per_token;
+};
+constexpr int kMegaMaxGrid = 1024, kMegaBarriers = 3;
+// The call's epoch is DEVICE-resident (a graph replay must not carry a host-side counter): every workgroup reads the count of completed
+// calls when it starts -- before it can arrive at the first barrier --, the gatherer bumps it after everybody has arrived at the last.
+__device__ __forceinline__ uint32_t mega_epoch(uint32_t *flags, uint32_t *lds_word)
+{
+    if (threadIdx.x == 0) *lds_word = __hip_atomic_load(flags + kMegaBarriers * (kMegaMaxGrid + 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __syncthreads();
+    return *(volatile uint32_t *)lds_word;
+}
+__device__ __forceinline__ void mega_barrier(const MegaArgs &p, int which)
+{
+    const int G = (int)(gridDim.x * gridDim.z), wg = (int)(blockIdx.x + gridDim.x * blockIdx.z);
+    uint32_t *mine = p.flags + which * (kMegaMaxGrid + 16), *go = mine + kMegaMaxGrid;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through stores have left the CU
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // Two hops: every workgroup raises its own flag, the first workgroup's first wave gathers them (lane l: flags l, l + 64, ...) and
+        // raises ONE word that the others watch; relaxed device-scope accesses only.  Measured (MEGA_TIMING, 256 workgroups): 1.8-2.6 us
+        // from the last workgroup's end of stage to the first workgroup past the barrier, the drain of the write-through stores
+        // included.  (One hop -- every workgroup watching all 256 flags -- is slower: 3.2-4.9 us, the polls load the memory system.)
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) __hip_atomic_store(mine + wg, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wg == 0) {
+            for (int i = (int)threadIdx.x; i < G; i += 64)
+                while (__hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();      // 2 s: a workgroup never became resident
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every lane has seen its flags (the wave reconverges behind the loops)
+            if (threadIdx.x == 0) {
+                if (which == kMegaBarriers - 1)                 // everybody read the call counter long ago: the next call's epoch is one higher
+                    __hip_atomic_store(p.flags + kMegaBarriers * (kMegaMaxGrid + 16), p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(go, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (threadIdx.x == 0) {
+            while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();
+            }
+        }
+    }
+    __syncthreads();
+}
+#ifdef MEGA_TIMING       // 100 MHz stamps per workgroup: start, after every stage and barrier (tools/probes/time_mla_pre_mega.py)
+__device__ unsigned long long g_mega_t[1024][8];
+#define MEGA_T(i) if (threadIdx.x == 0) g_mega_t[blockIdx.x + gridDim.x * blockIdx.z][i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define MEGA_T(i)
+#endif
+template <bool BF16, bool HALF>
+__global__ __launch_bounds__(512) void mla_pre_one_launch_kernel(MegaArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];          // kF_Lds bytes: the per-head stage's ring
+    const int G = (int)(gridDim.x * gridDim.z), wg = (int)(blockIdx.x + gridDim.x * blockIdx.z);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds);
+    MEGA_T(0)
+    // (per-tensor quantisation: this thread's eight hidden-state values are requested in front of the weight DMAs below -- vector-memory
+    //  results are waited for in issue order, so a load behind 22 DMA pieces would wait for all of them)
+    const long long n8 = (long long)p.tokens * p.hidden, i8 = ((long long)wg * 512 + tid) * 8;
+    uint4 xv0 = uint4{0, 0, 0, 0};
+    if (!p.per_token && i8 < n8) xv0 = *(const uint4 *)(p.x + i8);
+    // first of all: k-chunk 0 of this head's GEMM2 weights into ring slot 0 (the piece order of the per-head stage's issue_w(0, 0));
+    // the earlier stages keep their scratch behind it
+    {
+        const int h = (int)blockIdx.x, drow = lane >> 4, dpos = lane & 15, rot48 = (h * 11) % 48;
+        const int8_t *wh = p.wuq + (size_t)h * kF_Rows * kK2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int piece = wave * 6 + i + rot48;
+            piece = piece >= 48 ? piece - 48 : piece;
+            const int row = 4 * piece + drow;
+            dma16(lds_base + (uint32_t)(4 * piece * kF_Chunk), wh + (size_t)row * kK2 + ((dpos ^ (row & 15)) << 4));
+        }
+    }
+    uint8_t *scratch = lds + kF_Stage;                          // 96 KB behind slot 0 for the earlier stages
+    // ... and the weight rows of this workgroup's (first) GEMM1 tile: they do not depend on the quantised activations either
+    constexpr int kBN1 = 128;
+    const int gx1 = (2112 + kBN1 - 1) / kBN1, gy1 = p.parts, gz1 = (p.tokens + kBM - 1) / kBM;
+    const bool has_v = wg < gx1 * gy1 * gz1;
+    if (has_v) {
+        const int k0 = ((wg / gx1) % gy1) * kKC;
+        skinny_i8_issue_weights<kBN1, 8>(p.wdqkv, 2112, p.hidden, (wg % gx1) * kBN1, k0, min(kKC, p.hidden - k0), lds_base + (uint32_t)kF_Stage);
+    }
+    p.epoch = mega_epoch(p.flags, (uint32_t *)(lds + kF_Lds - 16));
+    // ---- stage 0: quantise the hidden states
+    if (p.per_token) {
+        for (int n = wg; n < p.tokens; n += G) pre_quant_token_body<BF16, 512, true>(p.x, p.hidden, p.a8, p.tok0, n, (float *)(lds + kF_Lds - 64));
+    } else {
+        const float scale = ldh<BF16>(p.qscale0[0]), zp = (float)p.qoff0[0];
+        if (i8 < n8) pre_quant_eight_loaded<BF16, true>(xv0, scale, zp, i8, p.a8);
+        for (long long i = i8 + (long long)G * 512 * 8; i < n8; i += (long long)G * 512 * 8) pre_quant_eight<BF16, true>(p.x, scale, zp, i, p.a8);
+    }
+    MEGA_T(1)
+    mega_barrier(p, 0);
+    MEGA_T(2)
+    // ---- stage 1: GEMM1, split-K: virtual workgroup v = (column tile, K-chunk, token block)
+    {
+        if (has_v)
+            skinny_i8_body<0, kBN1, BF16, 8, 1, true, true>(p.a8, p.tokens, p.hidden, p.wdqkv, 2112, p.c1, nullptr, nullptr, nullptr, nullptr, wg % gx1,
+                                                            (wg / gx1) % gy1, wg / (gx1 * gy1), scratch);
+        for (int v = wg + G; v < gx1 * gy1 * gz1; v += G)
+            skinny_i8_body<0, kBN1, BF16, 8, 1, true>(p.a8, p.tokens, p.hidden, p.wdqkv, 2112, p.c1, nullptr, nullptr, nullptr, nullptr, v % gx1,
+                                                      (v / gx1) % gy1, v / (gx1 * gy1), scratch);
+    }
+    MEGA_T(3)
+    mega_barrier(p, 1);
+    MEGA_T(4)
+    // ---- stage 2: the middle stage, one token per workgroup
+    {
+        float *f = (float *)scratch, *red = f + 2176;
+        for (int n = wg; n < p.tokens; n += G) {
+            pre_mid_body<BF16, 512, true, 16>(p.c1, p.parts, p.tokens, p.bias0, p.descale0, p.gamma1, p.beta1, p.gamma2, p.cosv, p.sinv, p.slotmapping,
+                                          p.qscale1, p.qoff1, p.eps, p.q8, p.kv_cache, p.kv_cache_rope, p.per_token ? p.tok0 : nullptr,
+                                          p.per_token ? p.tok1 : nullptr, p.cache_mode, p.block_size, p.ctkv_scale, n, f, red);
+            __syncthreads();
+        }
+    }
+    MEGA_T(5)
+    mega_barrier(p, 2);
+    MEGA_T(6)
+    // ---- stage 3: per head
+    gemm2_bmm_rope_body<BF16, HALF, true>(p.q8, p.tokens, p.wuq, p.q_heads, p.per_token ? nullptr : p.bias1, p.descale1, p.per_token ? p.tok1 : nullptr,
+                                          p.wuk_t, p.cosv, p.sinv, p.out0, p.out1, p.q_nope_scale, (int)blockIdx.x, (int)blockIdx.z, lds);
+    MEGA_T(7)
+}
 
 }  // namespace mi_sgl
 
@@ -794,3 +994,55 @@ extern "C" int mi_mla_pre_gemm2_bmm_rope(const int8_t *a, int tokens, const int8
 #undef MI_FUSED
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
+
+// The whole op in one launch (mla_pre_one_launch_kernel above).  -> MI_SGL_OK, or MI_SGL_ENOTAPPLICABLE when the shape is not served
+// (more workgroups than the chip runs at once, or than the barrier words hold): the caller then issues the four launches.
+extern "C" size_t mi_mla_preprocess_one_launch_sync_words(void) { return (size_t)kMegaBarriers * (kMegaMaxGrid + 16) + 16; }
+extern "C" int mi_mla_preprocess_one_launch(const void *hidden, int tokens, int hidden_size, const void *quant_scale0, const int8_t *quant_offset0,
+                                            int8_t *a8, float *tok0, const int8_t *wdqkv, int32_t *c1, const int32_t *bias0, const float *descale0,
+                                            const void *gamma1, const void *beta1, const void *gamma2, const void *cos, const void *sin,
+                                            const int32_t *slotmapping, const void *quant_scale1, const int8_t *quant_offset1, float eps, int8_t *q8,
+                                            void *kv_cache, void *kv_cache_rope, float *tok1, int cache_mode, int block_size, const void *ctkv_scale,
+                                            const int8_t *wuq, int q_heads, const int32_t *bias1, const float *descale1, const void *wuk_t,
+                                            void *q_out0, void *q_out1, const void *q_nope_scale, int per_token, int dtype, uint32_t *sync_words,
+                                            void *stream)
+{
+    if (tokens <= 0 || q_heads <= 0 || hidden_size <= 0 || hidden_size % 64 || (dtype != MI_DTYPE_BF16 && dtype != MI_DTYPE_F16) || !sync_words)
+        return MI_SGL_EINVAL;
+    if (!hidden || !a8 || !wdqkv || !c1 || !descale0 || !gamma1 || !beta1 || !gamma2 || !cos || !sin || !slotmapping || !q8 || !kv_cache ||
+        !kv_cache_rope || !wuq || !descale1 || !wuk_t || !q_out0 || !q_out1 || (per_token ? (!tok0 || !tok1) : (!quant_scale0 || !quant_offset0 || !quant_scale1 || !quant_offset1)) ||
+        cache_mode < 1 || cache_mode > 3 || (cache_mode != 1 && block_size <= 0) || (cache_mode == 2 && !ctkv_scale))
+        return MI_SGL_EINVAL;
+    static const int half_env = getenv("MI_MLA_PRE_HALF") ? atoi(getenv("MI_MLA_PRE_HALF")) : -1;
+    const bool half = half_env >= 0 ? half_env != 0 : (tokens <= 64 || (long long)q_heads * ((tokens + kBM - 1) / kBM) < 256);
+    const int gz = half ? (tokens + 63) / 64 : (tokens + kBM - 1) / kBM;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    // every workgroup waits for every other one at the barriers: all of them must be resident at once (one per CU: the ring takes the LDS)
+    if ((long long)q_heads * gz > cus || (long long)q_heads * gz > kMegaMaxGrid) return MI_SGL_ENOTAPPLICABLE;
+    MegaArgs p{};
+    p.x = (const uint16_t *)hidden, p.tokens = tokens, p.hidden = hidden_size, p.qscale0 = (const uint16_t *)quant_scale0, p.qoff0 = quant_offset0;
+    p.a8 = a8, p.tok0 = tok0, p.wdqkv = wdqkv, p.c1 = c1, p.parts = (hidden_size + kKC - 1) / kKC;
+    p.bias0 = bias0, p.descale0 = descale0, p.gamma1 = (const uint16_t *)gamma1, p.beta1 = (const uint16_t *)beta1, p.gamma2 = (const uint16_t *)gamma2;
+    p.cosv = (const uint16_t *)cos, p.sinv = (const uint16_t *)sin, p.slotmapping = slotmapping, p.qscale1 = (const uint16_t *)quant_scale1;
+    p.qoff1 = quant_offset1, p.eps = eps, p.q8 = q8, p.kv_cache = (uint16_t *)kv_cache, p.kv_cache_rope = (uint16_t *)kv_cache_rope, p.tok1 = tok1;
+    p.cache_mode = cache_mode, p.block_size = block_size, p.ctkv_scale = (const uint16_t *)ctkv_scale;
+    p.wuq = wuq, p.q_heads = q_heads, p.bias1 = bias1, p.descale1 = descale1, p.wuk_t = (const uint16_t *)wuk_t, p.out0 = (uint16_t *)q_out0;
+    p.out1 = (uint16_t *)q_out1, p.q_nope_scale = (const uint16_t *)q_nope_scale, p.flags = sync_words, p.epoch = 0, p.per_token = per_token ? 1 : 0;
+    dim3 grid(q_heads, 1, gz);
+#define MI_MEGA(B, H)                                                                                                              \
+    do {                                                                                                                            \
+        static PerDeviceOnce attr_once;                                                                                             \
+        if (attr_once.need())                                                                                                       \
+            (void)hipFuncSetAttribute((const void *)mla_pre_one_launch_kernel<B, H>, hipFuncAttributeMaxDynamicSharedMemorySize, kF_Lds); \
+        mla_pre_one_launch_kernel<B, H><<<grid, 512, kF_Lds, (hipStream_t)stream>>>(p);                                             \
+    } while (0)
+    if (dtype == MI_DTYPE_BF16) { if (half) MI_MEGA(true, true); else MI_MEGA(true, false); }
+    else { if (half) MI_MEGA(false, true); else MI_MEGA(false, false); }
+#undef MI_MEGA
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+#ifdef MEGA_TIMING
+extern "C" int mi_dbg_read_mega(unsigned long long *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mi_sgl::g_mega_t), sizeof(unsigned long long) * 1024 * 8); }
+#endif

@@ -763,8 +763,45 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     at::Tensor c1 = at::empty({parts, N, 2112}, at::dtype(at::kInt).device(dev));
     // per-token mode: every row is quantised against its own maximum and carries its scale to the dequant of the following GEMM
     at::Tensor tok0, tok1;
+    if (per_token) tok0 = at::empty({N}, at::dtype(at::kFloat).device(dev)), tok1 = at::empty({N}, at::dtype(at::kFloat).device(dev));
+    at::Tensor q8 = at::empty({N, 1536}, i8);
+    auto iptr = [](const at::Tensor &t) -> const int32_t * { return t.numel() ? t.data_ptr<int32_t>() : nullptr; };
+    // Opt-in (MI_MLA_PRE_ONE_LAUNCH=1), decode sizes: the whole op as ONE launch (stage bodies of the four launches behind grid barriers
+    // inside one grid; bit-identical; measured no faster than the four launches, csrc/kernels/mla_gemm.hip).  The barrier words come
+    // from a per-device ring: a buffer serves one call in flight, calls on different streams get different buffers.
+    const char *ol_env = getenv("MI_MLA_PRE_ONE_LAUNCH");      // read per call: the tests compare both forms in one process
+    const bool one_launch = ol_env && atoi(ol_env) != 0;
+    if (one_launch && N > 0) {
+        constexpr int kRing = 16;
+        static std::mutex mu;
+        static std::map<int, std::pair<at::Tensor, uint64_t>> rings;
+        const int64_t words = (int64_t)mi_mla_preprocess_one_launch_sync_words();
+        uint32_t *sync = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto &r = rings[dev.index()];
+            if (!r.first.defined()) r.first = at::zeros({kRing, words}, at::dtype(at::kInt).device(dev));
+            sync = (uint32_t *)r.first.data_ptr<int32_t>() + (r.second++ % kRing) * words;
+        }
+        at::Tensor wuk_t1 = prepared_wuk(wuk, hiddenState.scalar_type());
+        const int rc = mi_mla_preprocess_one_launch(
+            hiddenState.data_ptr(), (int)N, (int)hidden, per_token ? nullptr : quant_scale0.data_ptr(),
+            per_token ? nullptr : (const int8_t *)quant_offset0.data_ptr(), (int8_t *)a8.data_ptr(), per_token ? tok0.data_ptr<float>() : nullptr,
+            (const int8_t *)wdqkv.data_ptr(), c1.data_ptr<int32_t>(), iptr(bias0), descale0.data_ptr<float>(), gamma1.data_ptr(), beta1.data_ptr(),
+            gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(), per_token ? nullptr : quant_scale1.data_ptr(),
+            per_token ? nullptr : (const int8_t *)quant_offset1.data_ptr(), 1e-6f, (int8_t *)q8.data_ptr(), kv_cache.data_ptr(),
+            kv_cache_rope.data_ptr(), per_token ? tok1.data_ptr<float>() : nullptr, cmode_i, (int)block_size,
+            cmode_i == 2 ? ctkv_scale->data_ptr() : nullptr, (const int8_t *)wuq.data_ptr(), (int)Hq, per_token ? nullptr : iptr(bias1),
+            descale1.data_ptr<float>(), wuk_t1.data_ptr(), q_out0.data_ptr(), q_out1.data_ptr(), cmode_i == 2 ? q_nope_scale->data_ptr() : nullptr,
+            per_token ? 1 : 0, dt, sync, st);
+        TORCH_CHECK(rc == 0 || rc == MI_SGL_ENOTAPPLICABLE, "mi_mla_preprocess_one_launch failed with code ", rc);
+        if (rc == 0) {
+            if (kv_cache_out0.data_ptr() != kv_cache.data_ptr()) kv_cache_out0.copy_(kv_cache);
+            if (kv_cache_out1.data_ptr() != kv_cache_rope.data_ptr()) kv_cache_out1.copy_(kv_cache_rope);
+            return {q_out0, kv_cache_out0, q_out1, kv_cache_out1};
+        }
+    }
     if (per_token) {
-        tok0 = at::empty({N}, at::dtype(at::kFloat).device(dev)), tok1 = at::empty({N}, at::dtype(at::kFloat).device(dev));
         TORCH_CHECK(0 == mi_mla_pre_quant_token(hiddenState.data_ptr(), (int)N, (int)hidden, dt, (int8_t *)a8.data_ptr(), tok0.data_ptr<float>(), st),
                     "mi_mla_pre_quant_token failed");
     } else {
@@ -773,8 +810,6 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     }
     TORCH_CHECK(0 == mi_mla_pre_gemm_i8((const int8_t *)a8.data_ptr(), (int)N, (int)hidden, (const int8_t *)wdqkv.data_ptr(), 2112, 0,
                                         c1.data_ptr<int32_t>(), nullptr, nullptr, nullptr, nullptr, dt, st), "mi_mla_pre_gemm_i8 (GEMM1) failed");
-    at::Tensor q8 = at::empty({N, 1536}, i8);
-    auto iptr = [](const at::Tensor &t) -> const int32_t * { return t.numel() ? t.data_ptr<int32_t>() : nullptr; };
     TORCH_CHECK(0 == mi_mla_pre_mid(c1.data_ptr<int32_t>(), parts, iptr(bias0), descale0.data_ptr<float>(), gamma1.data_ptr(), beta1.data_ptr(),
                                     gamma2.data_ptr(), cos.data_ptr(), sin.data_ptr(), slotmapping.data_ptr<int32_t>(),
                                     per_token ? nullptr : quant_scale1.data_ptr(), per_token ? nullptr : (const int8_t *)quant_offset1.data_ptr(),

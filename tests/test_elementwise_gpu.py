@@ -643,6 +643,53 @@ def test_mla_preprocess(N, Hq, hidden, dt):
     assert not kv.view(-1, 512).cpu()[mask].any()
 
 
+@pytest.mark.parametrize("N,Hq,hidden,dt,qmode,cmode", [
+    (128, 128, 7168, torch.bfloat16, "per_tensor_quant_asymm", "krope_ctkv"),       # the decode batch: 256 workgroups, one per CU
+    (128, 128, 7168, torch.bfloat16, "per_token_quant_symm", "krope_ctkv"),
+    (31, 128, 7168, torch.float16, "per_tensor_quant_asymm", "nzcache"),
+    (64, 32, 6144, torch.bfloat16, "per_token_quant_symm", "int8_nzcache"),
+    (1, 16, 2048, torch.bfloat16, "per_tensor_quant_asymm", "krope_ctkv"),
+    (200, 32, 7168, torch.bfloat16, "per_tensor_quant_asymm", "krope_ctkv"),        # two token blocks per head
+])
+def test_mla_preprocess_one_launch_equals_four_launches(N, Hq, hidden, dt, qmode, cmode):
+    """The op as ONE launch (stage bodies behind grid barriers, the default at decode sizes) against the four launches
+    (MI_MLA_PRE_ONE_LAUNCH=0): every output and both caches bit for bit, repeatedly on the same buffers (the barrier words' epoch moves on)."""
+    import os
+    block_size, nblocks = 128, max(4, (N + 127) // 128 + 1)
+    z = _mla_pre_inputs(N, Hq, hidden, dt)
+    slots = torch.randperm(nblocks * block_size)[:N].to(torch.int32)
+    d = lambda t: t.cuda()
+    int8c = cmode == "int8_nzcache"
+    extra = dict(ctkv_scale=torch.tensor([0.07]).to(dt).cuda(), q_nope_scale=(torch.rand(Hq) * 0.5 + 0.5).to(dt).cuda()) if int8c else {}
+
+    def run():
+        kv = torch.zeros((nblocks, block_size, 1, 512), dtype=torch.int8 if int8c else dt, device="cuda")
+        kr = torch.zeros((nblocks, block_size, 1, 64), dtype=dt, device="cuda")
+        q0 = torch.empty((N, Hq, 512), dtype=torch.int8 if int8c else dt, device="cuda")
+        q1 = torch.empty((N, Hq, 64), dtype=dt, device="cuda")
+        torch.ops.npu.mla_preprocess(d(z["hid"]), d(z["gamma0"]), d(z["beta0"]), d(z["wdqkv"]), d(z["descale0"]), d(z["gamma1"]), d(z["beta1"]),
+                                     d(z["wuq"]), d(z["descale1"]), d(z["gamma2"]), d(z["cos"]), d(z["sin"]), d(z["wuk"]), kv, kr, d(slots),
+                                     d(z["qs0"]), d(z["qo0"]), d(z["bias0"]), d(z["qs1"]), d(z["qo1"]), d(z["bias1"]), cache_mode=cmode,
+                                     quant_mode=qmode, q_out0=q0, kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr, **extra)
+        torch.cuda.synchronize()
+        return q0, q1, kv, kr
+
+    old = os.environ.get("MI_MLA_PRE_ONE_LAUNCH")
+    try:
+        os.environ["MI_MLA_PRE_ONE_LAUNCH"] = "0"
+        want = run()
+        os.environ["MI_MLA_PRE_ONE_LAUNCH"] = "1"
+        for rep in range(3):
+            got = run()
+            for name, g, w in zip(("q_out0", "q_out1", "kv_cache", "kv_cache_rope"), got, want):
+                assert torch.equal(g, w), (name, rep)
+    finally:
+        if old is None:
+            os.environ.pop("MI_MLA_PRE_ONE_LAUNCH", None)
+        else:
+            os.environ["MI_MLA_PRE_ONE_LAUNCH"] = old
+
+
 def test_mla_preprocess_under_inference_mode_and_foreign_wuk_dtype():
     """Inference tensors carry no version counter (at::Tensor::_version() throws): the wuk re-layout cache must not ask for one.
     And a wuk stored in another dtype than the activations is converted inside the cache's make step, keyed on the caller's tensor:
