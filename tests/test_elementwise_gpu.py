@@ -632,7 +632,11 @@ def test_mla_preprocess(N, Hq, hidden, dt):
         g64, w64 = g.double(), w.double()
         bad = ~torch.isclose(g64, w64, rtol=1e-3, atol=1e-3)
         _record_mla_pre_miss(f"{N}x{Hq}x{hidden}_{str(dt).replace('torch.', '')}_{name}", bad.double().mean().item())
-        assert bad.double().mean().item() <= 2e-3, (name, bad.double().mean().item())                 # (1)
+        # (1) measured in round 4 (profiles/r04_mla_pre_miss_fraction.json, every case of this test): k_nope and k_pe meet the reference's
+        # bar on EVERY element; q_out0 / q_out1 miss it on <= 1.3e-5 of the elements except in the 1024-token case (1.3e-3 / 7.2e-4: one
+        # int8 step flipped in front of GEMM2 moves a whole output row of a head).  The bar follows the measurement with a margin.
+        bar = 0.0 if name in ("k_nope", "k_pe") else (2e-3 if N >= 512 else 1e-4)
+        assert bad.double().mean().item() <= bar, (name, bad.double().mean().item(), bar)
         assert torch.allclose(g64, w64, rtol=2 ** -5, atol=5e-2), (name, (g64 - w64).abs().max().item())  # (2)
         err_k, err_o = (g64 - ex).abs().mean().item(), (w64 - ex).abs().mean().item()
         assert err_k <= 1.05 * err_o + 1e-7, (name, err_k, err_o)                                       # (3)
