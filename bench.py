@@ -588,6 +588,13 @@ def fused_moe_section(buf, rank, world, T=4096):
         r = ev_stats(f, n=20, warm=20)
         return {"p50": r["p50_us"], "p99": r["p99_us"]}
 
+    def clocks():
+        # shader clock the chip held under the two grouped GEMMs of the LAST timed call (stamped by the kernels' first workgroup)
+        if not hasattr(buf.runtime, "get_gemm_clock"):
+            return {}
+        c = buf.runtime.get_gemm_clock()
+        return {"clk_gemm1": c[0][0], "clk_gemm2": c[2][0] or c[1][0]}
+
     def vendor_gemm():
         # calibration, not a target: what the vendor library's DENSE int8 GEMM (hipBLASLt through torch._int_mm, int32 output, no
         # epilogue, no grouping) reaches on this chip for GEMM1's shape -- the 3.9 POPS datasheet peak is not attainable in practice
@@ -596,7 +603,7 @@ def fused_moe_section(buf, rank, world, T=4096):
         r = ev_stats(lambda: torch._int_mm(a, wd), n=5, warm=3)
         return {"vendor": 2.0 * T * TOPK * HIDDEN * 2 * INTER / (r["p50_us"] * 1e-6) / 1e12}
 
-    res, err = _phases([first, profile, timed, vendor_gemm, validate])
+    res, err = _phases([first, profile, timed, clocks, vendor_gemm, validate])
     if err is not None:
         return {"error": err}
     finite = min(res.pop("finite"), res.pop("val_ok"))
@@ -609,6 +616,12 @@ def fused_moe_section(buf, rank, world, T=4096):
             "ms_p50": m["p50"] / 1e3, "ms_p99": m["p99"] / 1e3, "int8_TOPs_per_gpu": tops,
             "roofline": {"bound": "mfma", "achieved": tops, "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": tops / INT8_PEAK_TOPS,
                          "traffic": None},
+            # The datasheet peak assumes the 2.4 GHz shader clock; under dense INT8 MFMA issue the chip holds less (power management).
+            # Measured inside the two GEMM launches of the last timed call (s_memtime over s_memrealtime, first workgroup): the peak the
+            # chip could have delivered AT THAT CLOCK, and the GEMMs' own rate against it (whole-call frac stays against the datasheet).
+            "shader_clock_GHz": {"gemm1_swiglu": m.get("clk_gemm1"), "gemm2_push": m.get("clk_gemm2"), "nominal": 2.4},
+            "effective_peak_TOPs": (INT8_PEAK_TOPS * min(m["clk_gemm1"], 2.4) / 2.4) if m.get("clk_gemm1") else None,
+            "frac_of_effective_peak": (tops / (INT8_PEAK_TOPS * min(m["clk_gemm1"], 2.4) / 2.4)) if m.get("clk_gemm1") else None,
             "vendor_dense_int8_gemm_TOPs": m.get("vendor"),      # hipBLASLt dense GEMM of GEMM1's shape on the same GPU (calibration)
             "kernels_avg_us": st.get("prof", {}),
             # every rank: output finite AND 256 sampled tokens within the reference bar of the per-token evaluation (tests/fused_f64.py)

@@ -340,6 +340,10 @@ int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, cons
  * straight into slot t*topk+k of rank src's combine window, (src, t, k) = src_idx[3 r ..] -- the same destination and the
  * same bytes as mi_ep_moe_gemm2 followed by mi_ep_combine_push (the reference's fused op also sends from its GEMM2
  * epilogue: fused_deep_moe.h:336-427).  dst_base_host[W] = every rank's combine region for this call (host array). */
+/* Shader clock the chip held under the LAST launch of each grouped-GEMM form on the current device (synchronising read of three device
+ * words; a measurement aid): ghz3 / us3 [0] = GEMM1 + SwiGLU, [1] = GEMM2, [2] = GEMM2 + push: shader-clock ticks over 100 MHz reference
+ * ticks of the first workgroup's run, and that run's duration.  0 where the form has not run. */
+int mi_ep_moe_gemm_clock(double *ghz3, double *us3);
 int mi_ep_moe_gemm2_push(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,
                          int cum_stride, int num_local_experts, int rows_cap, int inter, int hidden, const int32_t *src_idx,
                          int topk, void *const *dst_base_host, int num_ranks, size_t slot_region_bytes, const uint64_t *epoch_ctr,

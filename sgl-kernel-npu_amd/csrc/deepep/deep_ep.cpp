@@ -251,6 +251,14 @@ bool Buffer::self_test(int64_t test_timeout_ms)
     return true;
 }
 
+std::vector<std::pair<double, double>> Buffer::get_gemm_clock() const
+{
+    HIP_CHECK(hipDeviceSynchronize());
+    double ghz[3], us[3];
+    MI_EP_CHECK(mi_ep_moe_gemm_clock(ghz, us));
+    return {{ghz[0], us[0]}, {ghz[1], us[1]}, {ghz[2], us[2]}};
+}
+
 void Buffer::require_available() const
 {
     if (!available)

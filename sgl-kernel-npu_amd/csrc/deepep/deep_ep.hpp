@@ -121,6 +121,8 @@ public:
     // MI355X: per-kernel device time (HIP events on the caller's stream) gathered between begin_profile/end_profile:
     // name -> (launch count, total milliseconds).  Valid after end_profile().
     std::vector<std::tuple<std::string, int64_t, double>> get_profile_summary() const { return profile_summary; }
+    // MI355X only: shader clock (GHz) and duration (us) of the first workgroup of the LAST grouped-GEMM launches {gemm1, gemm2, gemm2 + push}
+    std::vector<std::pair<double, double>> get_gemm_clock() const;
 
     // ---- kernel-level entry points used by the `alltoall` strategies (torch.distributed / RCCL moves the bytes,
     // these pack and unpack them).  Mirrors what the reference's AlltoAll strategies get from torch_npu routing ops

@@ -83,6 +83,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
             py::arg("profile_trace_dir") = "");
     MI_METHOD(buf, end_profile);
     MI_METHOD(buf, get_profile_summary);
+    MI_METHOD(buf, get_gemm_clock);
 
     // ---- MI355X only: pack / unpack kernels behind the RCCL `alltoall` strategies
     MI_METHOD(buf, a2a_dispatch_stage);

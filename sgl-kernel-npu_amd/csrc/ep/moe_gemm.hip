@@ -66,6 +66,7 @@ struct GemmArgs {
     int topk, W;
     Parity par;               // ping-pong half of the combine window (device-resident epoch, see ep_common.h)
     int slot_rows;            // rows one combine region holds: (t, k) outside it are dropped
+    int cols_padded;          // 0, or the column-tile count rounded up to a multiple of 8 (XCD-consistent column tiles, see the kernel)
 };
 
 // position (16-B units) of k-chunk `chunk` inside row `row` of a [rows][BKT B] tile.  A ds_read_b128 of 16 consecutive rows at one chunk
@@ -98,7 +99,7 @@ __device__ float g_gemm_dbg[256];
 // one (expert, m-tile) x 256-column tile; `slot` = index of the tile in (expert, row block) order.  Returns false when the slot lies
 // past the last tile (workgroup-uniform).
 template <int MODE, int MT, int BKT>
-__device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint8_t *lds, int end_first)
+__device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, int col_tile, uint8_t *lds, int end_first)
 {
     constexpr int BM = 64 * MT;
     constexpr int kStages = RingDepth<BKT, MT>::value;
@@ -155,7 +156,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
         rows = __builtin_amdgcn_readfirstlane(rows);
     }
     if (e < 0) return false;
-    const int n0 = blockIdx.x * BN;
+    const int n0 = col_tile * BN;
     const int8_t *wbase = p.w + (size_t)e * p.N * p.K;
     const int8_t *abase = p.a + (size_t)row0 * p.K;
 
@@ -386,7 +387,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
         const size_t grow = (size_t)row0 + lr;
         const u32x4 v = vrow[it];
         if (MODE == 0) {
-            float *orow = (float *)p.out + grow * (size_t)(p.N / 2) + (size_t)(blockIdx.x * 2 + f) * 64 + h * 32;
+            float *orow = (float *)p.out + grow * (size_t)(p.N / 2) + (size_t)(col_tile * 2 + f) * 64 + h * 32;
             *(u32x4 *)(orow + chunk * 4) = v;
         } else {
             const int col = n0 + wn * 64 + chunk * 8;
@@ -425,16 +426,38 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, uint
 // kStages - 1 stages already requested overlap the epilogue (the accumulators occupy the registers a second tile would need, so the
 // MFMA stream still stops for the ~11k-cycle epilogue), which buys back the pipeline fill (~5 % of a GEMM2 tile) and loses it again
 // to the ring bookkeeping inside the k-loop.
+// Shader clock under this kernel (always on: a handful of scalar instructions in ONE workgroup): the first workgroup stamps the shader-clock
+// counter and the 100 MHz reference around its whole run.  mi_ep_moe_gemm_clock() turns the last launch's pair into GHz -- the chip
+// does not hold its 2.4 GHz under dense INT8 MFMA issue, and the datasheet peak scales with the clock it does hold (bench.py reports the
+// achieved rate against that effective peak beside the datasheet one).
+__device__ unsigned long long g_gemm_clk[3][2];
 template <int MODE, int MT, int BKT>
 __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // kStages x (A BM x BKT + B 256 x BKT)
     const int lane0 = threadIdx.x & 63;
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    const unsigned long long c0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull, r0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // Which column tile and which worker of the pool this workgroup is.  The hardware deals workgroups to the 8 XCDs by their flat id; a
+    // column tile should always land on the same XCD (its weight tile then stays in that XCD's L2 for all row tiles of the expert).  With 16
+    // column tiles (GEMM1) the plain (x, y) grid does that; with 28 (GEMM2: 7168 / 256) flat id x + 28 y puts column x on XCD (x + 4 y) % 8,
+    // two XCDs per weight tile.  p.cols_padded = the column count rounded up to a multiple of 8: the flat id is cut by THAT, the surplus
+    // columns leave at once.
+    int col_tile = blockIdx.x, worker = blockIdx.y, workers = gridDim.y;
+    if (p.cols_padded) {
+        const int f = blockIdx.x + gridDim.x * blockIdx.y;
+        col_tile = f % p.cols_padded, worker = f / p.cols_padded, workers = (int)(gridDim.x * gridDim.y) / p.cols_padded;
+        if (col_tile * BN >= p.N || worker >= workers) return;
+    }
     const int end_first = lane0 < p.L ? p.cum[(lane0 + 1) * p.cum_stride - 1] : 0;     // end of expert `lane` (cumulative row count)
-    for (int slot = blockIdx.y;; slot += gridDim.y) {
-        if (!gemm_tile<MODE, MT, BKT>(p, slot, lds, end_first)) break;
+    for (int slot = worker;; slot += workers) {
+        if (!gemm_tile<MODE, MT, BKT>(p, slot, col_tile, lds, end_first)) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
         __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
+    }
+    if (stamp) {
+        g_gemm_clk[MODE][0] = __builtin_amdgcn_s_memtime() - c0;
+        g_gemm_clk[MODE][1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
 
@@ -507,9 +530,19 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
     }
     const int tiles_max = (p.M_cap + BM - 1) / BM + p.L;        // every expert may end in a partial tile
     const int gx = (p.N + BN - 1) / BN;
-    const int pool = 2048 / gx > 8 ? 2048 / gx : 8;             // ~8 workgroups per CU in flight over the launch; the rest is looped
-    dim3 grid(gx, tiles_max < pool ? tiles_max : pool);
-    grouped_gemm_i8_kernel<MODE, MT, BKT><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(p);
+    int pool = 2048 / gx > 8 ? 2048 / gx : 8;                   // ~8 workgroups per CU in flight over the launch; the rest is looped
+    pool = tiles_max < pool ? tiles_max : pool;
+    GemmArgs q = p;
+    // Opt-in (MI_GEMM_XCD_COLS=1).  Measured at C5 shapes, round 4 (tools/probes/gemm_xcd_ab.sh, counters FETCH_SIZE x 2 + WRITE_SIZE):
+    // GEMM2 moves 1.63 GB instead of 2.39 GB past its L2s (1.01 GB algorithmic) -- and takes 525 us instead of 482 us: 28 column tiles on 8
+    // XCDs are 4 + 4 + 4 + 4 + 3 + 3 + 3 + 3, the four-tile XCDs finish 14 % later, and the plain order's (x + 4 y) % 8 IS the balanced deal
+    // (every XCD 3.5 tiles on average, each weight tile on two XCDs).  The traffic past L2 is served by the 256 MB memory-side cache; it
+    // is not what the kernel waits for.  GEMM1 (16 column tiles) is unaffected: 802 us either way, 3.09 GB against 1.44 GB algorithmic.
+    static const bool xcd_cols = getenv("MI_GEMM_XCD_COLS") && atoi(getenv("MI_GEMM_XCD_COLS")) != 0;
+    q.cols_padded = (xcd_cols && gx % 8 != 0 && gx > 8) ? (gx + 7) / 8 * 8 : 0;
+    // (padded form: the same number of workers, gx' x pool flat ids cut into rows of gx')
+    dim3 grid(q.cols_padded ? q.cols_padded : gx, pool);
+    grouped_gemm_i8_kernel<MODE, MT, BKT><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(q);
 }
 
 struct PushArgs {
@@ -597,6 +630,17 @@ extern "C" int mi_ep_moe_gemm2_push(const int8_t *a, const float *a_scale, const
     }
     return gemm_launch(1, a, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, inter, hidden, nullptr,
                        rows_per_expert_hint, stream, &push);
+}
+
+extern "C" int mi_ep_moe_gemm_clock(double *ghz3, double *us3)
+{
+    unsigned long long h[3][2];
+    if (!ghz3 || !us3 || hipMemcpyFromSymbol(h, HIP_SYMBOL(mi_ep::g_gemm_clk), sizeof(h)) != hipSuccess) return MI_EP_EINVAL;
+    for (int m = 0; m < 3; ++m) {
+        us3[m] = (double)h[m][1] / 100.0;
+        ghz3[m] = h[m][1] ? (double)h[m][0] / ((double)h[m][1] * 10.0) : 0.0;      // ticks per 10 ns -> GHz
+    }
+    return MI_EP_OK;
 }
 
 #ifdef GEMM_TIMING

@@ -32,6 +32,11 @@ for name, K, N in (("gemm1", H, I2), ("gemm2", I2 // 2, H)):
         e.record(); torch.cuda.synchronize()
         best = min(best, s.elapsed_time(e) / 20 * 1e3)
     print(f"{name}: {best:.1f} us  {2 * M * K * N / best / 1e6:.0f} TOPS", flush=True)
+    if hasattr(L, "mi_ep_moe_gemm_clock"):
+        ghz, us = (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
+        L.mi_ep_moe_gemm_clock(ghz, us)
+        m = 0 if name == "gemm1" else 1
+        print(f"   shader clock under the kernel: {ghz[m]:.2f} GHz (first workgroup ran {us[m]:.0f} us)", flush=True)
     if hasattr(L, "mi_ep_gemm_dbg"):          # only in -DGEMM_TIMING builds
         import numpy as np
         buf = np.zeros(256, dtype=np.float32)
