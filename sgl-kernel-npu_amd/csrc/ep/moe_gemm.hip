@@ -115,6 +115,11 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, int 
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c16 = lane & 15;
+    // (Round 4, measured and dropped: wm = wave >> 2 -- the four row quarters of a column strip on one SIMD -- plus skipping the MFMAs of row
+    //  tiles without rows, so that an expert's last, partly filled tile loads all four SIMDs with what rows it has.  The mapping alone is
+    //  neutral; a wave-uniform test in front of the MFMA groups cost full tiles 7.5 %; with the k-loop duplicated -- plain for full tiles,
+    //  predicated for remainder tiles -- multinomial row counts gained 2 % in GEMM1 and lost 1-3 % elsewhere (tools/time_gemm.py, "ragged").
+    //  A remainder tile costs what a full one costs because its weight tile streams all the same: the k-tile time is the operand stream's.)
     const int wm = wave & 3, wn = wave >> 2;
     // which (expert, m-tile) is tile slot blockIdx.y?  64 experts per step: lane i reads the end of expert i, a wave scan of
     // the per-expert tile counts locates the slot.  (A serial walk over the experts -- one dependent scalar load each -- cost

@@ -11,12 +11,16 @@ sig = [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c
 L.mi_ep_moe_gemm1_swiglu.argtypes = sig
 L.mi_ep_moe_gemm2.argtypes = sig
 asc = torch.rand(M, device="cuda")
-cum = (torch.arange(1, E + 1, device="cuda", dtype=torch.int32) * (M // E)).contiguous()
-for name, K, N in (("gemm1", H, I2), ("gemm2", I2 // 2, H)):
+cum_u = (torch.arange(1, E + 1, device="cuda", dtype=torch.int32) * (M // E)).contiguous()
+# what routing produces: top-8 of 256 experts over 8 ranks -> multinomial row counts (every expert ends in a partial 256-row tile)
+gen = torch.Generator().manual_seed(3)
+cnt = torch.bincount(torch.multinomial(torch.ones(E), M, replacement=True, generator=gen), minlength=E)
+cum_r = torch.cumsum(cnt, 0).to(torch.int32).cuda().contiguous()
+for name, K, N, cum in (("gemm1", H, I2, cum_u), ("gemm2", I2 // 2, H, cum_u), ("gemm1 ragged", H, I2, cum_r), ("gemm2 ragged", I2 // 2, H, cum_r)):
     a = torch.randint(-8, 8, (M, K), dtype=torch.int8, device="cuda")
     w = torch.randint(-8, 8, (E, N, K), dtype=torch.int8, device="cuda")
     ws = torch.rand((E, N), device="cuda")
-    if name == "gemm1":
+    if name.startswith("gemm1"):
         out = torch.zeros((M, N // 2), dtype=torch.float32, device="cuda")
         f = lambda: L.mi_ep_moe_gemm1_swiglu(ptr(a), ptr(asc), ptr(w), ptr(ws), ptr(cum), 1, E, M, K, N, ptr(out), 0, stream_ptr())
     else:
@@ -35,7 +39,7 @@ for name, K, N in (("gemm1", H, I2), ("gemm2", I2 // 2, H)):
     if hasattr(L, "mi_ep_moe_gemm_clock"):
         ghz, us = (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
         L.mi_ep_moe_gemm_clock(ghz, us)
-        m = 0 if name == "gemm1" else 1
+        m = 0 if name.startswith("gemm1") else 1
         print(f"   shader clock under the kernel: {ghz[m]:.2f} GHz (first workgroup ran {us[m]:.0f} us)", flush=True)
     if hasattr(L, "mi_ep_gemm_dbg"):          # only in -DGEMM_TIMING builds
         import numpy as np
