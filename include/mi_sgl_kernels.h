@@ -57,6 +57,19 @@ const char *mi_sgl_kernels_version(void);
  * its longest.  Pass the same value to mi_mla_decode_workspace. */
 #define MI_MLA_SPLITS_PLANNED (-1)
 size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
+/* Plan once, run many: the work list of the planned form depends only on kv_seq_lens (contents), batch and kv_heads -- the attention layers
+ * of one decode step share it.  mi_mla_decode_build_plan: one small launch into caller memory of mi_mla_decode_plan_bytes();
+ * mi_mla_decode_with_plan = mi_mla_decode(num_splits = MI_MLA_SPLITS_PLANNED) without that launch (workspace as for that value; the plan
+ * must have been built from the same kv_seq_lens contents: a stale plan reads the wrong tile ranges).  MI_SGL_ENOTAPPLICABLE where the
+ * planned form does not serve the shape (kv groups outside 65..128 heads, page sizes that are not powers of two): call mi_mla_decode. */
+size_t mi_mla_decode_plan_bytes(int batch, int kv_heads);
+int mi_mla_decode_build_plan(const int32_t *kv_seq_lens, int batch, int kv_heads, void *plan, size_t plan_bytes, void *stream);
+int mi_mla_decode_with_plan(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
+                            const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
+                            int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk, int64_t kn_stride_row,
+                            int64_t kn_stride_h, int64_t kr_stride_blk, int64_t kr_stride_row, int64_t kr_stride_h,
+                            int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype, const void *plan, void *workspace,
+                            size_t workspace_bytes, void *stream);
 /* Introspection of the planned form (tests, tuning): byte offset of the work list inside a workspace sized with MI_MLA_SPLITS_PLANNED, and
  * the number of concurrently running workgroups it was balanced for (the CU count).  Work-list words (int32):
  *   [0] items incl. padding, [1] rounds, [2 + k] first item of round k (k < 16);  [32 + 2 s] rank of (sequence, kv head) pair s by

@@ -463,6 +463,11 @@ __device__ __forceinline__ int plan_pieces(int tiles, int x)
     const int n = (tiles + x - 1) / x;
     return max(1, min(n, min(kPlanMaxSplits, tiles / kPlanMinTiles)));
 }
+#ifdef PLAN_TIMING
+#define PLAN_T(i) if (threadIdx.x == 0) ((volatile int32_t *)plan)[20 + (i)] = (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFF);
+#else
+#define PLAN_T(i)
+#endif
 __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restrict__ seq_lens, int batch, int kv_heads, int tile, int workers,
                                                         int32_t *__restrict__ plan)
 {
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seqs = batch * kv_heads;
     const long long items_max = plan_items_max(seqs, workers);
     int32_t *info = plan + kPlanHdr, *items = plan + kPlanHdr + 2ll * seqs;
+    PLAN_T(0)
     if (tid == 0) s_total = 0, s_max = 0;
     if (tid < kPlanMaxSplits) s_cnt[tid] = 0;
     __syncthreads();
@@ -490,6 +496,7 @@ __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restric
     if (lane == 0 && mine) atomicAdd((unsigned long long *)&s_total, (unsigned long long)mine), atomicMax(&s_max, mx);
     for (long long i = tid; i < items_max; i += blockDim.x) items[4 * i] = -1;      // every slot starts as padding
     __syncthreads();
+    PLAN_T(1)
     int x = max(s_max, 1);                                                           // one piece per sequence
     if (split) {
         if (tid == 0) s_lo = max(1, (int)((s_total + workers - 1) / workers)), s_hi = max(s_max, 1);
@@ -513,18 +520,36 @@ __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restric
         }
         x = s_hi;
     }
-    for (int s = tid; s < seqs; s += blockDim.x) {
-        int n = 1, rank = s;
-        if (sorted) {
-            const int t = s_tiles[s];
-            n = split ? plan_pieces(t, x) : 1;
-            rank = 0;
-            for (int o = 0; o < seqs; ++o) rank += (s_tiles[o] > t) || (s_tiles[o] == t && o < s);
+    PLAN_T(2)
+    if (sorted) {
+        // rank of a sequence = how many are longer (ties: lower index first).  Thread (s, part): the workgroup's threads are dealt over the
+        // sequences, `parts` threads per sequence, each comparing a slice of the others; the partial counts meet in LDS.  (One thread per
+        // sequence walking all the others, or one wave per sequence with ballots, took 3.7 us of the kernel's 8-9: serial LDS round trips.)
+        int pad = 1;
+        while (pad < seqs) pad <<= 1;
+        const int parts = max(1, (int)blockDim.x / pad);          // power of two
+        for (int s = tid; s < seqs; s += blockDim.x) s_rn[s] = 0;
+        __syncthreads();
+        for (int i = tid; i < pad * parts; i += blockDim.x) {      // (one pass when the batch has <= 1024 sequences; parts = 1 beyond)
+            const int s = i & (pad - 1), part = i / pad;
+            if (s < seqs) {
+                const int t = s_tiles[s], per = (seqs + parts - 1) / parts;
+                int c = 0;
+                for (int o = part * per; o < min(seqs, (part + 1) * per); ++o) c += (s_tiles[o] > t) || (s_tiles[o] == t && o < s);
+                if (c) atomicAdd(&s_rn[s], c);
+            }
+        }
+        __syncthreads();
+        for (int s = tid; s < seqs; s += blockDim.x) {
+            const int rank = s_rn[s], n = split ? plan_pieces(s_tiles[s], x) : 1;
+            info[2 * s] = rank, info[2 * s + 1] = n;
+            s_rn[s] = rank | (n << 16);
             for (int k = 0; k < n; ++k) atomicAdd(&s_cnt[k], 1);
         }
-        info[2 * s] = rank, info[2 * s + 1] = n;
-        if (sorted) s_rn[s] = rank | (n << 16);
+    } else {
+        for (int s = tid; s < seqs; s += blockDim.x) info[2 * s] = s, info[2 * s + 1] = 1;
     }
+    PLAN_T(3)
     if (!sorted && tid == 0) s_cnt[0] = seqs;
     __syncthreads();
     if (tid == 0) {
@@ -548,6 +573,7 @@ __global__ __launch_bounds__(1024) void mla_plan_kernel(const int32_t *__restric
             it[0] = s;
         }
     }
+    PLAN_T(4)
 }
 
 }  // namespace mi_sgl
@@ -648,12 +674,59 @@ extern "C" int mi_mla_decode_select_wide(int waves)
     return MI_SGL_OK;
 }
 
+// A work list for mi_mla_decode_with_plan: built once from kv_seq_lens (one small launch), valid for every call on the same kv_seq_lens
+// CONTENTS, batch and kv_heads -- the 61 attention layers of a decode step share one.
+extern "C" size_t mi_mla_decode_plan_bytes(int batch, int kv_heads)
+{
+    if (batch <= 0 || kv_heads <= 0) return 0;
+    return plan_words((long long)batch * kv_heads, plan_workers()) * sizeof(int32_t);
+}
+extern "C" int mi_mla_decode_build_plan(const int32_t *kv_seq_lens, int batch, int kv_heads, void *plan, size_t plan_bytes, void *stream)
+{
+    if (batch <= 0 || kv_heads <= 0 || !kv_seq_lens || !plan || plan_bytes < mi_mla_decode_plan_bytes(batch, kv_heads)) return MI_SGL_EINVAL;
+    mla_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, plan_workers(), (int32_t *)plan);
+    return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+}
+
+static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
+                           const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
+                           int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk,
+                           int64_t kn_stride_row, int64_t kn_stride_h, int64_t kr_stride_blk, int64_t kr_stride_row,
+                           int64_t kr_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype,
+                           int num_splits, void *workspace, size_t workspace_bytes, void *stream, const int32_t *ready_plan);
 extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
                              const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
                              int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk,
                              int64_t kn_stride_row, int64_t kn_stride_h, int64_t kr_stride_blk, int64_t kr_stride_row,
                              int64_t kr_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype,
                              int num_splits, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return mla_decode_impl(q, k_nope, k_rope, out, kv_seq_lens, block_table, batch, q_heads, kv_heads, page_size, bt_stride, max_seq_len, q_stride_b,
+                           q_stride_h, kn_stride_blk, kn_stride_row, kn_stride_h, kr_stride_blk, kr_stride_row, kr_stride_h, o_stride_b, o_stride_h,
+                           sm_scale, dtype, num_splits, workspace, workspace_bytes, stream, nullptr);
+}
+// mi_mla_decode in the planned form with a work list the caller built earlier (mi_mla_decode_build_plan): no plan launch in front of the
+// kernel.  workspace as for num_splits = MI_MLA_SPLITS_PLANNED.  Returns MI_SGL_ENOTAPPLICABLE where the planned form does not apply
+// (kv groups outside 65..128 heads, page sizes that are not powers of two, the four-wave kernel selected): call mi_mla_decode.
+extern "C" int mi_mla_decode_with_plan(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
+                                       const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
+                                       int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk,
+                                       int64_t kn_stride_row, int64_t kn_stride_h, int64_t kr_stride_blk, int64_t kr_stride_row,
+                                       int64_t kr_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype,
+                                       const void *plan, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!plan) return MI_SGL_EINVAL;
+    return mla_decode_impl(q, k_nope, k_rope, out, kv_seq_lens, block_table, batch, q_heads, kv_heads, page_size, bt_stride, max_seq_len, q_stride_b,
+                           q_stride_h, kn_stride_blk, kn_stride_row, kn_stride_h, kr_stride_blk, kr_stride_row, kr_stride_h, o_stride_b, o_stride_h,
+                           sm_scale, dtype, MI_MLA_SPLITS_PLANNED, workspace, workspace_bytes, stream, (const int32_t *)plan);
+}
+
+static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
+                           const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
+                           int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk,
+                           int64_t kn_stride_row, int64_t kn_stride_h, int64_t kr_stride_blk, int64_t kr_stride_row,
+                           int64_t kr_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, int dtype,
+                           int num_splits, void *workspace, size_t workspace_bytes, void *stream, const int32_t *ready_plan)
 {
     if (batch < 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads || page_size <= 0 || bt_stride <= 0) return MI_SGL_EINVAL;
     if (batch == 0) return MI_SGL_OK;
@@ -676,6 +749,7 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     // power of two, cache strides that need the 64-head kernel): uniform splits, as many as the caller's workspace holds
     bool planned = num_splits == MI_MLA_SPLITS_PLANNED;
     if (planned && !(wide && plan_applies(q_heads / kv_heads) && (page_size & (page_size - 1)) == 0)) {
+        if (ready_plan) return MI_SGL_ENOTAPPLICABLE;
         planned = false;
         num_splits = uniform_splits(batch, q_heads, kv_heads, max_seq_len);
         while (num_splits > 1 && mi_mla_decode_workspace(batch, q_heads, num_splits) > workspace_bytes) --num_splits;
@@ -696,8 +770,8 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
     p.fix_flags = workspace ? (uint32_t *)((char *)workspace + part_bytes) : nullptr;
     if (planned) {
         int32_t *plan = (int32_t *)((char *)workspace + part_bytes + (size_t)batch * q_heads * sizeof(uint32_t));
-        mla_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, workers, plan);
-        p.plan = plan;
+        if (!ready_plan) mla_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, workers, plan);
+        p.plan = ready_plan ? ready_plan : plan;
         num_splits = 1;                                // per sequence now: the kernels read it from the list
     }
     p.fix_epoch = ++epoch ? epoch : ++epoch;          // a stale word equal to the epoch only causes a redundant recompute

@@ -71,6 +71,49 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
     TORCH_CHECK(rc == 0, "mi_mla_decode failed with code ", rc);
 }
 
+// MI355X extension (plan once, run many): the length-aware work list of decode_mla depends only on kv_seq_lens -- the attention layers of a
+// decode step share it.  decode_mla_plan builds it (one small launch, no host sync); decode_mla_planned is decode_mla with that list
+// instead of a plan launch of its own.  Where the planned form does not serve the shape, the planned call runs plain decode_mla.
+at::Tensor decode_mla_plan(const at::Tensor &kv_seq_lens, int64_t num_kv_heads)
+{
+    const c10::DeviceGuard device_guard(kv_seq_lens.device());
+    TORCH_CHECK(kv_seq_lens.scalar_type() == at::kInt && kv_seq_lens.is_contiguous() && kv_seq_lens.dim() == 1, "decode_mla_plan: kv_seq_lens must be int32 [batch]");
+    const int B = (int)kv_seq_lens.size(0);
+    const size_t bytes = mi_mla_decode_plan_bytes(B, (int)num_kv_heads);
+    at::Tensor plan = at::empty({(int64_t)std::max<size_t>(bytes / 4, 4)}, at::dtype(at::kInt).device(kv_seq_lens.device()));
+    if (B > 0)
+        TORCH_CHECK(0 == mi_mla_decode_build_plan(kv_seq_lens.data_ptr<int>(), B, (int)num_kv_heads, plan.data_ptr(), bytes, cur_stream()),
+                    "mi_mla_decode_build_plan failed");
+    return plan;
+}
+void decode_mla_planned(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::Tensor &k_rope_buffer, at::Tensor &att_out,
+                        const at::Tensor &kv_seq_lens, double sm_scale, int64_t page_size, const at::Tensor &block_table, const at::Tensor &plan)
+{
+    const c10::DeviceGuard device_guard(q.device());
+    TORCH_CHECK(q.dim() == 3 && k_nope_buffer.dim() == 4 && k_rope_buffer.dim() == 4 && att_out.dim() == 3 && block_table.dim() == 2, "decode_mla: bad ranks");
+    const int B = (int)q.size(0), Hq = (int)q.size(1), Hkv = (int)k_nope_buffer.size(2);
+    TORCH_CHECK(plan.scalar_type() == at::kInt && plan.is_contiguous() && (size_t)plan.numel() * 4 >= mi_mla_decode_plan_bytes(B, Hkv),
+                "decode_mla_planned: plan does not belong to this batch / kv head count");
+    const bool shapes_ok = k_nope_buffer.size(3) == 512 && k_rope_buffer.size(3) == 64 && q.size(2) == 576 && att_out.size(2) == 512 &&
+                           q.stride(2) == 1 && k_nope_buffer.stride(3) == 1 && k_rope_buffer.stride(3) == 1 && att_out.stride(2) == 1 &&
+                           k_nope_buffer.size(1) == page_size && k_rope_buffer.size(1) == page_size && kv_seq_lens.scalar_type() == at::kInt &&
+                           block_table.scalar_type() == at::kInt && kv_seq_lens.is_contiguous() && block_table.stride(1) == 1 && Hq % Hkv == 0;
+    if (shapes_ok && B > 0) {
+        const int max_len = (int)std::min<int64_t>(block_table.size(1) * page_size, INT32_MAX);
+        const size_t wsb = mi_mla_decode_workspace(B, Hq, MI_MLA_SPLITS_PLANNED);
+        at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(q.device()));
+        const int rc = mi_mla_decode_with_plan(q.data_ptr(), k_nope_buffer.data_ptr(), k_rope_buffer.data_ptr(), att_out.data_ptr(),
+                                               kv_seq_lens.data_ptr<int>(), block_table.data_ptr<int>(), B, Hq, Hkv, (int)page_size,
+                                               (int)block_table.stride(0), max_len, q.stride(0), q.stride(1), k_nope_buffer.stride(0),
+                                               k_nope_buffer.stride(1), k_nope_buffer.stride(2), k_rope_buffer.stride(0), k_rope_buffer.stride(1),
+                                               k_rope_buffer.stride(2), att_out.stride(0), att_out.stride(1), (float)sm_scale, dtype_code(q),
+                                               plan.data_ptr(), ws.data_ptr(), wsb, cur_stream());
+        if (rc == 0) return;
+        TORCH_CHECK(rc == MI_SGL_ENOTAPPLICABLE, "mi_mla_decode_with_plan failed with code ", rc);
+    }
+    decode_mla(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, sm_scale, page_size, block_table, 0);      // all checks live there
+}
+
 // Paged GQA decode with a separate V cache; argument meaning of decode_gqa (decode_attention.py:378-387); writes att_out in place.
 // A DeepSeek-style cache where V is the first 512 columns of the 576-wide K rows (the reference special-cases Lk == 576,
 // :404-407, and its test builds exactly that view, test_decode_attention.py:74) goes to the MLA kernel, which reads each K
@@ -848,6 +891,9 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("sgl_kernel_npu_version() -> str", &sglang::npu_kernel::sgl_kernel_npu_version);
     m.def("decode_mla(Tensor q, Tensor k_nope_buffer, Tensor k_rope_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
           "float sm_scale, int page_size, Tensor block_table, int num_splits=0) -> ()");
+    m.def("decode_mla_plan(Tensor kv_seq_lens, int num_kv_heads=1) -> Tensor");
+    m.def("decode_mla_planned(Tensor q, Tensor k_nope_buffer, Tensor k_rope_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
+          "float sm_scale, int page_size, Tensor block_table, Tensor plan) -> ()");
     m.def("decode_gqa(Tensor q, Tensor k_buffer, Tensor v_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
           "float sm_scale, int page_size, Tensor block_table, int num_splits=0) -> ()");
     m.def("mla_preprocess(Tensor hiddenState, Tensor gamma0, Tensor beta0, Tensor wdqkv, "
@@ -902,6 +948,8 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
 TORCH_LIBRARY_IMPL(npu, CUDA, m)
 {
     m.impl("decode_mla", TORCH_FN(sglang::npu_kernel::decode_mla));
+    m.impl("decode_mla_plan", TORCH_FN(sglang::npu_kernel::decode_mla_plan));
+    m.impl("decode_mla_planned", TORCH_FN(sglang::npu_kernel::decode_mla_planned));
     m.impl("decode_gqa", TORCH_FN(sglang::npu_kernel::decode_gqa));
     m.impl("mla_preprocess", TORCH_FN(sglang::npu_kernel::mla_preprocess));
     m.impl("swiglu_quant", TORCH_FN(sglang::npu_kernel::swiglu_quant));

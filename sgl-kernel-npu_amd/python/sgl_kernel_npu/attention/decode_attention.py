@@ -9,12 +9,25 @@ import torch
 import sgl_kernel_npu  # noqa: F401  (loads the operator library)
 
 
-def decode_mla(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, sm_scale, page_size, block_table):
+def decode_mla(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, sm_scale, page_size, block_table, plan=None):
     """q [B, Hq, 576]; k_nope_buffer [blocks, page, Hkv, 512]; k_rope_buffer [blocks, page, Hkv, 64];
-    att_out [B, Hq, 512] (written in place); kv_seq_lens int32 [B]; block_table int32 [B, max_pages]."""
+    att_out [B, Hq, 512] (written in place); kv_seq_lens int32 [B]; block_table int32 [B, max_pages].
+    plan (MI355X extension, optional): the work list decode_mla_plan(kv_seq_lens) returned -- the attention layers of one decode step
+    share it, and the call then does without its own plan launch.  It must come from the same kv_seq_lens contents."""
+    if plan is not None:
+        torch.ops.npu.decode_mla_planned(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, float(sm_scale), int(page_size),
+                                         block_table, plan)
+        return att_out
     torch.ops.npu.decode_mla(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, float(sm_scale), int(page_size),
                              block_table, 0)
     return att_out
+
+
+def decode_mla_plan(kv_seq_lens, num_kv_heads=1):
+    """MI355X extension: the length-aware work list of decode_mla for this batch (one small launch, no host sync): how many pieces every
+    sequence is cut into so that all pieces fit one round of workgroups, longest first.  Pass it as decode_mla(..., plan=...) to every
+    layer of the step."""
+    return torch.ops.npu.decode_mla_plan(kv_seq_lens, int(num_kv_heads))
 
 
 def decode_gqa(q, k_buffer, v_buffer, att_out, kv_seq_lens, sm_scale, page_size, block_table):

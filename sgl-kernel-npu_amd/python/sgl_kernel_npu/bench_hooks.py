@@ -58,7 +58,23 @@ def bench_mla_decode(steps=30, warmup=5):
         torch.cuda.synchronize()
         return a.elapsed_time(b) / steps
 
+    def timed_shared_plan(ls):            # plan once, run many: what the layers of one decode step pay when the step builds the list once
+        from sgl_kernel_npu.attention.decode_attention import decode_mla_plan
+        plan = decode_mla_plan(ls, 1)
+        call = lambda: decode_mla(q, kn, kr, out, ls, sm, page, bt, plan=plan)
+        for _ in range(max(warmup // 4, 5)):
+            call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            call()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / steps
+
     r_ms = timed(rlens)
+    r_ms_shared = timed_shared_plan(rlens)
+    ms_shared = timed_shared_plan(lens)
     r_ms_uniform = timed(rlens, num_splits=2)
     ms_uniform = timed(lens, num_splits=2)
     r_bytes = float(rlens.sum().item()) * 576 * 2 + B * Hq * (576 + 512) * 2
@@ -76,7 +92,10 @@ def bench_mla_decode(steps=30, warmup=5):
                      "algorithmic_bytes": kv_bytes + io_bytes, "avg_launch_us": dev_ms * 1e3},
         "ragged": {"workload": "same batch, kv_seq_lens ~ U[1, 4096]", "ms_per_step": r_ms, "mean_seq_len": float(rlens.float().mean().item()),
                    "achieved_GBps": r_bytes / (r_ms * 1e-3) / 1e9, "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "shared_plan_ms_per_step": r_ms_shared, "shared_plan_frac": r_bytes / (r_ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                    "uniform_2_splits_ms_per_step": r_ms_uniform, "uniform_2_splits_frac": r_bytes / (r_ms_uniform * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        # the same batch with the work list built ONCE outside the loop (decode_mla_plan; the layers of a decode step share it) and passed in
+        "shared_plan_ms_per_step": ms_shared, "shared_plan_frac": (kv_bytes + io_bytes) / (ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "uniform_2_splits_ms_per_step": ms_uniform,     # the full-length batch through num_splits = 2 (round 3's form), queued back to back
         "pmc_kernels": ["mla_plan_kernel", "mla_decode_wide8_kernel<true, true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
         "mfma": {"achieved_TFLOPs": flops / (dev_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,

@@ -282,3 +282,29 @@ def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_spl
             assert n[3 * Hkv] > 4          # the one long sequence is cut into many pieces, the short ones stay whole
     finally:
         L.mi_mla_decode_select_wide(0)
+
+
+def test_plan_once_run_many_equals_the_per_call_plan():
+    """decode_mla_plan + decode_mla(..., plan=...) (the work list built once and shared by calls on the same kv_seq_lens) against the
+    default call that builds its own list: the same bits, on a ragged batch; a shape the planned form does not serve (16 heads) falls back
+    to the plain call."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sgl-kernel-npu_amd", "python"))
+    from sgl_kernel_npu.attention.decode_attention import decode_mla, decode_mla_plan
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for B, Hq, S, page in ((48, 128, 3000, 64), (6, 16, 500, 64)):
+        maxp = (S + page - 1) // page
+        nb = B * maxp
+        q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(torch.bfloat16)
+        kn = (torch.randn((nb, page, 1, 512), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+        kr = (torch.randn((nb, page, 1, 64), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+        bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+        lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+        want = torch.empty((B, Hq, 512), dtype=torch.bfloat16, device="cuda")
+        decode_mla(q, kn, kr, want, lens, 576 ** -0.5, page, bt)
+        plan = decode_mla_plan(lens, 1)
+        for _ in range(3):
+            got = torch.empty_like(want)
+            decode_mla(q, kn, kr, got, lens, 576 ** -0.5, page, bt, plan=plan)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
