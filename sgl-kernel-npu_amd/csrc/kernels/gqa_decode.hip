@@ -13,7 +13,10 @@
 // ds_read_b64_tr_b16, B = P^T = the S^T accumulator layout packed in place) -- no cross-lane traffic between the GEMMs.
 // LDS rows are padded to an odd number of 32-byte units, which makes both read patterns conflict-free.
 // Flash-decoding split over the KV range + a merge kernel fill the 256 CUs for small batch x kv_heads.
+#include <algorithm>
+
 #include "device_once.h"
+#include "decode_plan.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -80,6 +83,9 @@ struct GqaParams {
     int sinks_dtype;
     int window;                 // -1 = all keys
     const int32_t *bt_rows;     // [batch] block-table row of every query row; null = row b
+    // round 4: the length-aware work list of decode_plan.h (null = uniform num_splits): unit = item, its tile range and piece index come from
+    // the list, its partial lives at slot (item, head of the group)
+    const int32_t *plan;
 };
 __device__ __forceinline__ float gqa_sink_l2(const GqaParams &p, int head)      // the sink logit in the kernel's log2 domain (NOT scaled by sm_scale)
 {
@@ -127,18 +133,27 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;         // sibling head blocks of a unit share an XCD (L2 reuse)
     const int unit = (jj / head_blocks) * 8 + xcd;
     const int hblk = jj % head_blocks;
-    if (unit >= p.batch * p.kv_heads * p.num_splits) return;
-    const int split = unit % p.num_splits;
-    const int kvh = (unit / p.num_splits) % p.kv_heads;
-    const int b = unit / (p.num_splits * p.kv_heads);
-    const int seq_len = p.seq_lens[b];
-    const int ntiles = (seq_len + TILE - 1) / TILE;
-    // sliding window: keys [start_kv, seq_len) (sinks_attention.py:35-39); the splits share the tiles from the window's first one on
-    const int start_kv = (p.window >= 0 && seq_len > p.window) ? seq_len - p.window : 0;
-    const int first_tile = start_kv / TILE;
-    const int tps = (ntiles - first_tile + p.num_splits - 1) / p.num_splits;
-    const int t_begin = first_tile + split * tps;
-    const int t_end = min(ntiles, t_begin + tps);
+    int split, nsplits, kvh, b, t_begin, t_end, seq_len, start_kv = 0;
+    if (p.plan) {
+        if (unit >= p.plan[0]) return;                           // (the grid is rounded up to rows of 8 workgroups)
+        const mi_sgl::PlanItem it = mi_sgl::plan_item(p.plan, (long long)p.batch * p.kv_heads, unit);
+        if (it.seq < 0) return;                                  // padding of a round
+        split = it.k, nsplits = it.n, kvh = it.seq % p.kv_heads, b = it.seq / p.kv_heads, t_begin = it.t_begin, t_end = it.t_end;
+        seq_len = p.seq_lens[b];
+    } else {
+        if (unit >= p.batch * p.kv_heads * p.num_splits) return;
+        split = unit % p.num_splits, nsplits = p.num_splits;
+        kvh = (unit / p.num_splits) % p.kv_heads;
+        b = unit / (p.num_splits * p.kv_heads);
+        seq_len = p.seq_lens[b];
+        const int ntiles = (seq_len + TILE - 1) / TILE;
+        // sliding window: keys [start_kv, seq_len) (sinks_attention.py:35-39); the splits share the tiles from the window's first one on
+        start_kv = (p.window >= 0 && seq_len > p.window) ? seq_len - p.window : 0;
+        const int first_tile = start_kv / TILE;
+        const int tps = (ntiles - first_tile + p.num_splits - 1) / p.num_splits;
+        t_begin = first_tile + split * tps;
+        t_end = min(ntiles, t_begin + tps);
+    }
     const int64_t bt_row = p.bt_rows ? p.bt_rows[b] : b;
 
     // Q^T fragments: lane (g, c16) holds q[head][ks*32 + g*8 .. +8] of head block hb
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
     for (int hb = 0; hb < HB; ++hb) {
         if (hg[hb] >= p.group) continue;
         const int head = kvh * p.group + hg[hb];
-        if (p.num_splits == 1) {
+        if (nsplits == 1) {
             float inv;
             if (p.sinks) {                                        // l += exp(sink - max) with the sink inside the max (:78-80)
                 const float sk = gqa_sink_l2(p, head);
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
                 *(uint2 *)(orow + dt * 16) = uint2{w0, w1};
             }
         } else {
-            const int64_t idx = ((int64_t)b * p.q_heads + head) * p.num_splits + split;
+            const int64_t idx = p.plan ? (int64_t)unit * p.group + hg[hb] : ((int64_t)b * p.q_heads + head) * p.num_splits + split;
             float *po = p.ws_o + idx * DVP + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) *(f32x4 *)(po + dt * 16) = acc[hb][dt];
@@ -363,25 +378,33 @@ __global__ __launch_bounds__(256) void gqa_merge_kernel(GqaParams p, int dvp)
     const int lane = threadIdx.x & 63;
     const int64_t bh = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (bh >= (int64_t)p.batch * p.q_heads) return;
-    const int S = p.num_splits;
-    const float *ml = p.ws_ml + bh * S * 2;
     const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
+    // partial s of this head: slot (bh, s), or -- planned form -- slot (item of piece s, head within the group)
+    int S = p.num_splits, rank = 0;
+    if (p.plan) {
+        const int32_t *info = p.plan + mi_sgl::kPlanHdr + 2ll * (b * p.kv_heads + h / p.group);
+        rank = info[0], S = info[1];
+        if (S == 1) return;                                   // the piece wrote the output row itself
+    }
+    auto slot = [&](int s) -> int64_t { return p.plan ? (int64_t)(p.plan[2 + s] + rank) * p.group + h % p.group : bh * S + s; };
     float M = -INFINITY;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, ml[s * 2]);
+    for (int s = 0; s < S; ++s) M = fmaxf(M, p.ws_ml[slot(s) * 2]);
     const float sk = p.sinks ? gqa_sink_l2(p, h) : -INFINITY;
     M = fmaxf(M, sk);
     float L = p.sinks ? __builtin_amdgcn_exp2f(sk - M) : 0.f;
-    for (int s = 0; s < S; ++s)
-        if (ml[s * 2] != -INFINITY) L += __builtin_amdgcn_exp2f(ml[s * 2] - M) * ml[s * 2 + 1];
+    for (int s = 0; s < S; ++s) {
+        const float *ml = p.ws_ml + slot(s) * 2;
+        if (ml[0] != -INFINITY) L += __builtin_amdgcn_exp2f(ml[0] - M) * ml[1];
+    }
     const float inv = L > 0.f ? 1.f / L : 0.f;
     uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
     for (int d = lane * 4; d < p.lv; d += 256) {
         f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < S; ++s) {
-            const float m = ml[s * 2];
+            const float m = p.ws_ml[slot(s) * 2];
             if (m == -INFINITY) continue;
             const float w = __builtin_amdgcn_exp2f(m - M);
-            o += w * *(const f32x4 *)(p.ws_o + (bh * S + s) * dvp + d);
+            o += w * *(const f32x4 *)(p.ws_o + slot(s) * dvp + d);
         }
         *(uint2 *)(orow + d) = uint2{pack2<BF16>(o[0] * inv, o[1] * inv), pack2<BF16>(o[2] * inv, o[3] * inv)};
     }
@@ -431,8 +454,35 @@ static int heads_per_wg(const Shape &s, int group) { return (s.dkp == 576 || gro
 
 using namespace mi_gqa;
 
+// ---- the planned form (decode_plan.h): a device-built, length-aware work list instead of one split count for every sequence.  Served for
+// plain decode (no sinks, no sliding window, no per-row block tables); MI_GQA_PLAN=0 keeps uniform splits.
+static int gqa_cus()
+{
+    static int cached[64];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 256;
+    if (!cached[d]) {
+        int n = 0;
+        cached[d] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[d];
+}
+constexpr int kGqaMaxWgPerCu = 4;
+// rows of partials a planned workspace holds: (items) x (heads of a group) <= batch * q_heads + (workers + padding) * q_heads
+static size_t gqa_plan_rows_cap(int batch, int q_heads) { return (size_t)batch * q_heads + (size_t)(gqa_cus() * kGqaMaxWgPerCu + 8 * mi_sgl::kPlanMaxSplits) * q_heads; }
+static size_t gqa_plan_words_cap(int batch, int q_heads) { return mi_sgl::plan_words((long long)batch * q_heads, gqa_cus() * kGqaMaxWgPerCu); }
+static bool gqa_plan_allowed()
+{
+    static const bool allow = !(getenv("MI_GQA_PLAN") && atoi(getenv("MI_GQA_PLAN")) == 0);
+    return allow;
+}
+
 extern "C" size_t mi_gqa_decode_workspace(int batch, int q_heads, int v_dim, int num_splits)
 {
+    if (num_splits == MI_MLA_SPLITS_PLANNED) {
+        if (batch <= 0 || q_heads <= 0) return 0;
+        return gqa_plan_rows_cap(batch, q_heads) * (512 + 2) * sizeof(float) + gqa_plan_words_cap(batch, q_heads) * sizeof(int32_t);
+    }
     if (num_splits <= 1) return 0;
     const Shape *s = pick_shape(8, v_dim);
     if (!s) return 0;
@@ -444,6 +494,11 @@ extern "C" int mi_gqa_decode_num_splits(int batch, int q_heads, int kv_heads, in
 {
     if (batch <= 0 || q_heads <= 0 || kv_heads <= 0 || max_seq_len <= 0) return 1;
     const long long wgs = (long long)batch * kv_heads * ((q_heads / kv_heads + 127) / 128);
+    // (The planned form -- num_splits = MI_MLA_SPLITS_PLANNED, decode_plan.h -- is served but never chosen here.  Measured on Llama-70B-shaped
+    //  decode (64 / 8 heads, d = 128; tools/probes/gqa_plan_ab.py): 16 sequences x 8192 keys 113.9 us planned vs 105.0 us with four uniform
+    //  splits (ragged 65.1 vs 64.2); 64 x 4096 208 vs 190 us (ragged 144 vs 118-130).  This kernel's workgroups are light and two to three
+    //  share a CU, so uniform splits already balance; "all pieces in one round" -- right for the MLA kernels, one heavy workgroup per CU --
+    //  leaves 512 sequences on 512 slots unsplit and pays a plan launch and a merge launch for nothing.)
     const int ntiles = (max_seq_len + 63) / 64;
     int s = (int)((512 + wgs - 1) / wgs);              // about two workgroups per CU
     const int cap = ntiles / 4 > 1 ? ntiles / 4 : 1;   // keep >= 4 tiles (256 keys) per split
@@ -470,13 +525,27 @@ static int gqa_decode_impl(const void *q, const void *k, const void *v, void *ou
     if ((q_stride_h % 8) || (q_stride_b % 8) || (k_stride_row % 8) || (k_stride_blk % 8) || (k_stride_h % 8) || (v_stride_row % 8) ||
         (v_stride_blk % 8) || (v_stride_h % 8) || (o_stride_h % 4) || (o_stride_b % 4))
         return MI_SGL_EINVAL;      // 16-byte loads, 8-byte stores
-    if (num_splits <= 0) num_splits = mi_gqa_decode_num_splits(batch, q_heads, kv_heads, max_seq_len);
-    if (num_splits > 1 && (!workspace || workspace_bytes < mi_gqa_decode_workspace(batch, q_heads, v_dim, num_splits))) return MI_SGL_EINVAL;
+    if (num_splits == 0) num_splits = mi_gqa_decode_num_splits(batch, q_heads, kv_heads, max_seq_len);
+    if (num_splits < 0 && num_splits != MI_MLA_SPLITS_PLANNED) return MI_SGL_EINVAL;
+    bool planned = num_splits == MI_MLA_SPLITS_PLANNED;
+    if (planned && (sinks || window >= 0 || bt_rows || !gqa_plan_allowed())) {
+        // the planned form does not serve this call: uniform splits, as many as the caller's workspace holds
+        planned = false;
+        const long long wgs = (long long)batch * kv_heads * ((q_heads / kv_heads + 127) / 128);
+        const int ntiles = (max_seq_len + 63) / 64, cap = ntiles / 4 > 1 ? ntiles / 4 : 1;
+        num_splits = (int)std::min<long long>(std::min<long long>((512 + wgs - 1) / wgs, cap), 64);
+        if (num_splits < 1) num_splits = 1;
+        while (num_splits > 1 && mi_gqa_decode_workspace(batch, q_heads, v_dim, num_splits) > workspace_bytes) --num_splits;
+    }
+    if ((num_splits > 1 || planned) &&
+        (!workspace || workspace_bytes < mi_gqa_decode_workspace(batch, q_heads, v_dim, planned ? MI_MLA_SPLITS_PLANNED : num_splits)))
+        return MI_SGL_EINVAL;
     GqaParams p;
+    p.plan = nullptr;
     p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v;
     p.out = (uint16_t *)out, p.seq_lens = kv_seq_lens, p.block_table = block_table;
     p.ws_o = (float *)workspace;
-    p.ws_ml = p.ws_o ? p.ws_o + (size_t)batch * q_heads * num_splits * shape->dvp : nullptr;
+    p.ws_ml = p.ws_o ? p.ws_o + (planned ? gqa_plan_rows_cap(batch, q_heads) : (size_t)batch * q_heads * num_splits) * shape->dvp : nullptr;
     p.batch = batch, p.q_heads = q_heads, p.kv_heads = kv_heads, p.group = q_heads / kv_heads, p.page_size = page_size;
     p.bt_stride = bt_stride, p.num_splits = num_splits, p.lk = k_dim, p.lv = v_dim;
     p.q_sb = q_stride_b, p.q_sh = q_stride_h, p.k_sblk = k_stride_blk, p.k_srow = k_stride_row, p.k_sh = k_stride_h;
@@ -486,13 +555,24 @@ static int gqa_decode_impl(const void *q, const void *k, const void *v, void *ou
     hipStream_t st = (hipStream_t)stream;
     const int hpw = heads_per_wg(*shape, p.group);
     const int head_blocks = (p.group + hpw - 1) / hpw;
-    const long long units = (long long)batch * kv_heads * num_splits;
+    long long units = (long long)batch * kv_heads * num_splits;
+    if (planned) {
+        // workgroups the chip runs at once: as many per CU as the LDS of this shape allows; a (sequence, kv head) piece is head_blocks of them
+        const size_t lds = 2 * (size_t)shape->tile * ((size_t)shape->dkp * 2 + 32 + (size_t)shape->dvp * 2 + 32);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(kGqaMaxWgPerCu, (160 * 1024) / lds));
+        const int workers = std::max(1, gqa_cus() * per_cu / head_blocks);
+        int32_t *plan = (int32_t *)(p.ws_ml + gqa_plan_rows_cap(batch, q_heads) * 2);
+        mi_sgl::decode_plan_kernel<<<1, 1024, 0, st>>>(kv_seq_lens, batch, kv_heads, shape->tile, workers, plan);
+        p.plan = plan;
+        p.num_splits = num_splits = 1;
+        units = mi_sgl::plan_items_max((long long)batch * kv_heads, workers);
+    }
     dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
     bool ok;
     if (dtype == MI_DTYPE_BF16) ok = hpw == 64 ? launch_shape<true, 1>(*shape, p, grid, st) : launch_shape<true, 2>(*shape, p, grid, st);
     else ok = hpw == 64 ? launch_shape<false, 1>(*shape, p, grid, st) : launch_shape<false, 2>(*shape, p, grid, st);
     if (!ok) return MI_SGL_EINVAL;
-    if (num_splits > 1) {
+    if (num_splits > 1 || planned) {
         const long long bh = (long long)batch * q_heads;
         const int blocks = (int)((bh + 3) / 4);
         if (dtype == MI_DTYPE_BF16) gqa_merge_kernel<true><<<blocks, 256, 0, st>>>(p, shape->dvp);

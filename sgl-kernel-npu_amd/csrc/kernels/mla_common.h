@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "decode_plan.h"
+
 namespace mi_sgl {
 
 constexpr int kDN = 512, kDR = 64, kTile = 64;
@@ -35,42 +37,9 @@ struct MlaParams {
     // arrive[...]; the second one merges and, if the sequence is flagged, recomputes -- no merge launch
     uint32_t *arrive;         // [batch * kv_heads * head_blocks], values are tagged with fix_epoch (no clearing needed)
     int inline_merge;
-    // Length-aware work list built on the device by mla_plan_kernel (mla_decode.hip), NULL = the uniform num_splits form.  Layout below.
+    // Length-aware work list built on the device by decode_plan_kernel (decode_plan.h), NULL = the uniform num_splits form.  Layout below.
     const int32_t *plan;
 };
-
-// ---- the planned form (wide kernels, kv groups of 65..128 heads) -------------------------------------------------------------------
-// A launch with per-sequence lengths far apart (a serving batch) runs at the pace of its longest sequence when every sequence is cut
-// into the same number of splits.  The plan cuts each (sequence, kv head) into n_s = ceil(tiles_s / x) pieces, x = the smallest piece
-// size for which all pieces together are no more than the chip runs at once (one workgroup per CU), and orders the pieces longest
-// first.  One workgroup per piece ("item"); the partial of item i lives at slot i of the workspace.
-//   words [0, kPlanHdr)                 n_items (padding included), n_rounds, base[k] for k < kPlanMaxSplits
-//   words [kPlanHdr, + 2 seqs)          per sequence: rank (position by descending cost), n_s
-//   words [.., + 4 items_max)           per item: seq (-1 = padding), first tile, end tile, k | n_s << 8
-// Item index of piece k of the sequence ranked r: base[k] + r.  n_s never increases with the rank, so the sequences with more than
-// k pieces are exactly the ranks below cnt_k; rounds are stored highest k first (the pieces of the longest sequences lead, the short
-// unsplit sequences come last: longest-processing-time-first for the hardware's in-order dispatch) and every base[k] is a multiple of
-// 8: all pieces of a sequence have the same index mod 8, i.e. run on one XCD (dispatch convention), where Q^T and the partials meet in L2.
-constexpr int kPlanHdr = 32, kPlanMaxSplits = 16, kPlanMinTiles = 8, kPlanSortMax = 2048;
-__host__ __device__ inline long long plan_items_max(long long seqs, int workers) { return seqs + workers + 8 * kPlanMaxSplits; }
-__host__ __device__ inline size_t plan_words(long long seqs, int workers)
-{
-    return (size_t)kPlanHdr + 2 * (size_t)seqs + 4 * (size_t)plan_items_max(seqs, workers);
-}
-struct PlanItem {
-    int seq, t_begin, t_end, k, n;
-};
-__device__ __forceinline__ PlanItem plan_item(const int32_t *plan, long long seqs, int item)      // wave-uniform
-{
-    const int32_t *it = plan + kPlanHdr + 2 * seqs + 4ll * item;
-    PlanItem r;
-    r.seq = __builtin_amdgcn_readfirstlane(it[0]);
-    r.t_begin = __builtin_amdgcn_readfirstlane(it[1]);
-    r.t_end = __builtin_amdgcn_readfirstlane(it[2]);
-    const int kn = __builtin_amdgcn_readfirstlane(it[3]);
-    r.k = kn & 0xFF, r.n = kn >> 8;
-    return r;
-}
 
 template <bool BF16>
 __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)

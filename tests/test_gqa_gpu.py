@@ -75,8 +75,11 @@ def check(got, want, exact, dtype):
     assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-2)
 
 
+PLANNED = -1      # MI_MLA_SPLITS_PLANNED: the device-built, length-aware work list (decode_plan.h)
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "gqa_ref_fp16_*.npz"))))
-@pytest.mark.parametrize("splits", [1, 2])
+@pytest.mark.parametrize("splits", [1, 2, PLANNED])
 def test_against_reference_kernel_outputs(path, splits):
     z = np.load(path)
     t = lambda key: torch.from_numpy(z[key]).cuda()
@@ -102,7 +105,7 @@ CASES = [  # B, Hq, Hkv, Lk, Lv, S, page, ragged, v_is_view
 
 @pytest.mark.parametrize("B,Hq,Hkv,Lk,Lv,S,page,ragged,view", CASES)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("splits", [0, 1, 3])
+@pytest.mark.parametrize("splits", [0, 1, 3, PLANNED])
 def test_against_oracle(B, Hq, Hkv, Lk, Lv, S, page, ragged, view, dtype, splits):
     torch.manual_seed(1)
     maxp = (S + page - 1) // page
@@ -290,3 +293,30 @@ def test_fia_blockq_sparse_prefill(total_q, topk1, block_size, Hq, D, dtype):
         tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
         err = (got.cpu().float() - want.float()).abs()
         assert bool((err <= tol * want.float().abs().amax(dim=-1, keepdim=True) + 1e-5).all()), float(err.max())
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D,S,page,kind", [(64, 64, 8, 128, 4096, 64, "ragged"), (16, 64, 8, 128, 6000, 16, "ragged"), (8, 256, 1, 128, 3000, 64, "ragged"),
+                                                   (24, 32, 4, 64, 9000, 128, "one_long"), (4, 16, 2, 256, 2000, 64, "uniform")])
+def test_planned_work_list_and_outputs_match_one_piece_per_sequence(B, Hq, Hkv, D, S, page, kind):
+    """decode_gqa with the device-built work list (pieces per sequence by length, longest first) against the same kernel with ONE piece per
+    sequence: equal within the fp32 summation-order tolerance of a flash-decoding merge; zero-length sequences included."""
+    g = torch.Generator(device="cuda").manual_seed(B + S)
+    maxp = (S + page - 1) // page
+    nb = B * maxp
+    dt = torch.bfloat16
+    q = torch.randn((B, Hq, D), generator=g, device="cuda").to(dt)
+    k = (torch.randn((nb, page, Hkv, D), generator=g, device="cuda") * 0.5).to(dt)
+    v = (torch.randn((nb, page, Hkv, D), generator=g, device="cuda") * 0.5).to(dt)
+    bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+    if kind == "uniform":
+        lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    elif kind == "ragged":
+        lens = torch.randint(0, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+    else:
+        lens = torch.randint(1, 200, (B,), generator=g, device="cuda").to(torch.int32)
+        lens[1] = S
+    got = run_gqa(q, k, v, lens, bt, D ** -0.5, PLANNED)
+    one = run_gqa(q, k, v, lens, bt, D ** -0.5, 1)
+    nz = lens.cpu() > 0
+    assert not torch.isnan(got.float()[nz]).any()
+    assert torch.allclose(got.float()[nz], one.float()[nz], rtol=2 ** -7, atol=2e-3), (got.float()[nz] - one.float()[nz]).abs().max()

@@ -193,7 +193,7 @@ def test_growing_scores_take_the_rescaling_path(dtype, splits, wide_variant):
 
 
 def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=16, sort_max=2048):
-    """The work list of the planned form restated on the host (sgl-kernel-npu_amd/csrc/kernels/mla_common.h, mla_plan_kernel): piece size
+    """The work list of the planned form restated on the host (sgl-kernel-npu_amd/csrc/kernels/decode_plan.h, decode_plan_kernel): piece size
     x = the smallest for which all pieces fit one round of workgroups; -> (n_items, base[k], rank[s], n[s], items {index: (pair, first
     tile, end tile, k, n)})."""
     seqs = len(lens) * kv_heads

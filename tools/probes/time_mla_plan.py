@@ -1,4 +1,4 @@
-"""Scratch: phase stamps of mla_plan_kernel (library built with -DPLAN_TIMING, LD_PRELOADed): C4 uniform and ragged lengths."""
+"""Scratch: phase stamps of decode_plan_kernel (library built with -DPLAN_TIMING, LD_PRELOADed): C4 uniform and ragged lengths."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "sgl-kernel-npu_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))

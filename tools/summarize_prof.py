@@ -37,7 +37,7 @@ def by_grid(rnd, stats_dir, out_dir):
         except (KeyError, ValueError):
             continue
     ours = ("stage", "pull", "combine", "layout", "notify", "signal", "mla", "swiglu", "rms", "rope", "ll_", "grouped_gemm", "rowquant",
-            "skinny", "bmm_rope", "pre_", "gqa", "gemm2", "selftest", "add_", "split_")
+            "skinny", "bmm_rope", "pre_", "gqa", "gemm2", "selftest", "add_", "split_", "decode_plan")
     rows = sorted(((k, v) for k, v in agg.items() if k[0].startswith(ours)), key=lambda kv: (kv[0][0], -kv[0][1][0] * max(kv[0][1][1], 1)))
     with open(os.path.join(out_dir, f"r{rnd}_kernel_stats_by_grid.csv"), "w") as o:
         o.write("kernel,grid_threads_x,grid_y,grid_z,workgroup_x,calls,avg_ns,p50_ns,min_ns,max_ns\n")
@@ -68,7 +68,7 @@ def main():
         out = {}
         for k, v in agg.items():
             if not (k.startswith(("stage", "pull", "combine", "layout", "notify", "mla", "swiglu", "rms", "rope", "ll_", "grouped_gemm",
-                                  "rowquant", "skinny", "bmm_rope", "pre_"))):
+                                  "rowquant", "skinny", "bmm_rope", "pre_", "decode_plan"))):
                 continue
             # the same kernel runs at several problem sizes in one bench (C2-size and decode-size launches): price the LARGEST size
             # only -- launches within 20 % of the kernel's biggest counter value -- which is the one bench.py's roofline quotes
