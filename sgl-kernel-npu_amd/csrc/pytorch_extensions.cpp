@@ -817,7 +817,8 @@ std::tuple<at::Tensor &, at::Tensor &, at::Tensor &, at::Tensor &> mla_preproces
     if (one_launch && N > 0) {
         constexpr int kRing = 16;
         static std::mutex mu;
-        static std::map<int, std::pair<at::Tensor, uint64_t>> rings;
+        // (never destroyed: a static tensor freed at process exit would outlive the HIP context)
+        static auto &rings = *new std::map<int, std::pair<at::Tensor, uint64_t>>();
         const int64_t words = (int64_t)mi_mla_preprocess_one_launch_sync_words();
         uint32_t *sync = nullptr;
         {

@@ -65,3 +65,23 @@ def test_compact_staging_geometry_and_capacity_check():
     MI_EP_EINVAL = lib.mi_ep_dispatch_stage_compact(dummy, dummy, 0, dummy, dummy, cap + 1, K, H, 256, 0, 1, dummy, region, None, region, None)
     assert MI_EP_EINVAL != 0
     assert lib.mi_ep_dispatch_stage_compact(dummy, dummy, 0, dummy, dummy, 0, K, H, 256, 0, 1, dummy, region, None, region, None) == 0   # T = 0
+
+
+def test_planned_decode_workspace_sizes_are_host_callable():
+    """MI_MLA_SPLITS_PLANNED (-1) is passed to the workspace queries like a split count; the sizes are pure host arithmetic (256 workers when
+    no device answers): partial slots for (sequences + workers + padding) items of 128 heads + flag words + the work list."""
+    lib = load("libmi_sgl_kernels.so")
+    for f in (lib.mi_mla_decode_workspace, lib.mi_mla_decode_plan_bytes, lib.mi_mla_decode_plan_offset, lib.mi_gqa_decode_workspace):
+        f.restype = ctypes.c_size_t
+    B, Hq = 128, 128
+    workers = lib.mi_mla_decode_plan_workers()
+    assert workers >= 1
+    items = B + workers + 8 * 16
+    plan_bytes = lib.mi_mla_decode_plan_bytes(B, 1)
+    assert plan_bytes == (32 + 2 * B + 4 * items) * 4
+    off = lib.mi_mla_decode_plan_offset(B, Hq)
+    assert off == items * 128 * 514 * 4 + B * Hq * 4
+    assert lib.mi_mla_decode_workspace(B, Hq, -1) == off + plan_bytes
+    assert lib.mi_mla_decode_workspace(B, Hq, 2) == B * Hq * 2 * 514 * 4 + B * Hq * 4          # the uniform form is unchanged
+    assert lib.mi_mla_decode_workspace(0, Hq, -1) == 0 and lib.mi_mla_decode_plan_bytes(0, 1) == 0
+    assert lib.mi_gqa_decode_workspace(64, 64, 128, -1) > lib.mi_gqa_decode_workspace(64, 64, 128, 4) > 0
