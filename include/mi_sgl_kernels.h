@@ -51,7 +51,7 @@ const char *mi_sgl_kernels_version(void);
  * q_heads % kv_heads == 0; any page_size >= 1.  num_splits >= 1 partitions the KV range of every sequence
  * (flash-decoding).  `workspace` of mi_mla_decode_workspace() bytes (device memory, contents irrelevant) is needed when
  * num_splits > 1 or q_heads / kv_heads > 64.  Pass num_splits = 0 to let the library choose (mi_mla_decode_num_splits).
- * MI_MLA_SPLITS_PLANNED (what mi_mla_decode_num_splits returns for kv groups of 65..128 heads): no uniform split count at all -- one small
+ * MI_MLA_SPLITS_PLANNED (what mi_mla_decode_num_splits returns for kv groups of up to 128 heads): no uniform split count at all -- one small
  * launch in front of the kernel reads kv_seq_lens ON THE DEVICE (no host sync) and cuts every sequence into pieces of about
  * (all tiles + fixed costs) / CUs, longest first; a batch of ragged lengths then runs at the pace of the average sequence, not of
  * its longest.  Pass the same value to mi_mla_decode_workspace. */
@@ -61,7 +61,8 @@ size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
  * of one decode step share it.  mi_mla_decode_build_plan: one small launch into caller memory of mi_mla_decode_plan_bytes();
  * mi_mla_decode_with_plan = mi_mla_decode(num_splits = MI_MLA_SPLITS_PLANNED) without that launch (workspace as for that value; the plan
  * must have been built from the same kv_seq_lens contents: a stale plan reads the wrong tile ranges).  MI_SGL_ENOTAPPLICABLE where the
- * planned form does not serve the shape (kv groups outside 65..128 heads, page sizes that are not powers of two): call mi_mla_decode. */
+ * planned form does not serve the shape (kv groups of more than 128 heads; for groups of 65..128 heads, page sizes that are not powers of
+ * two): call mi_mla_decode.  One list serves every head count: it counts 32-key tiles and its pieces start on even tiles. */
 size_t mi_mla_decode_plan_bytes(int batch, int kv_heads);
 int mi_mla_decode_build_plan(const int32_t *kv_seq_lens, int batch, int kv_heads, void *plan, size_t plan_bytes, void *stream);
 int mi_mla_decode_with_plan(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
@@ -74,7 +75,7 @@ int mi_mla_decode_with_plan(const void *q, const void *k_nope, const void *k_rop
  * the number of concurrently running workgroups it was balanced for (the CU count).  Work-list words (int32):
  *   [0] items incl. padding, [1] rounds, [2 + k] first item of round k (k < 16);  [32 + 2 s] rank of (sequence, kv head) pair s by
  *   descending cost, [33 + 2 s] its piece count n_s;  then 4 words per item: pair (-1 = padding), first tile, end tile, k | n_s << 8
- *   (tiles of 32 keys).  Item of piece k of the pair ranked r: word[2 + k] + r. */
+ *   (tiles of 32 keys, pieces start on even tiles).  Item of piece k of the pair ranked r: word[2 + k] + r. */
 size_t mi_mla_decode_plan_offset(int batch, int q_heads);
 int mi_mla_decode_plan_workers(void);
 int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);

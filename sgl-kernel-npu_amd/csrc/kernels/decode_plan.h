@@ -39,7 +39,8 @@ __device__ __forceinline__ PlanItem plan_item(const int32_t *plan, long long seq
 }
 
 // The work list of the planned form (layout and rationale above).  One workgroup of 1024 threads; `tile` = keys per tile of the
-// kernel that will consume the list, `workers` = workgroups the chip runs at once (one per CU for the wide kernels).
+// kernel that will consume the list, `workers` = workgroups the chip runs at once (one per CU for the wide kernels); pieces start on
+// multiples of `align` tiles (MLA: 2 -- the list is in 32-key tiles and also serves the 64-head kernel, whose tiles are 64 keys).
 // Piece size: the smallest x (tiles per piece) for which sum_s n_s(x) <= workers, n_s(x) = ceil(tiles_s / x) capped so that a piece
 // keeps >= kPlanMinTiles tiles and a sequence <= kPlanMaxSplits pieces -- every piece then runs in the FIRST round of workgroups (a
 // list of more items than CUs leaves the last items to a second round: measured, a ragged C4 batch cut by "cost / average cost" made
@@ -55,8 +56,8 @@ __device__ __forceinline__ int plan_pieces(int tiles, int x)
 #else
 #define PLAN_T(i)
 #endif
-static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t *__restrict__ seq_lens, int batch, int kv_heads, int tile, int workers,
-                                                        int32_t *__restrict__ plan)
+static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t *__restrict__ seq_lens, int batch, int kv_heads, int tile, int align,
+                                                                  int workers, int32_t *__restrict__ plan)
 {
     __shared__ int s_tiles[kPlanSortMax], s_rn[kPlanSortMax];      // tiles; rank | n << 16 (kept for the last pass)
     __shared__ int s_cnt[kPlanMaxSplits], s_base[kPlanMaxSplits], s_cand[16];
@@ -153,7 +154,7 @@ static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t 
     for (int s = tid; s < seqs; s += blockDim.x) {
         const int tiles = sorted ? s_tiles[s] : (max(seq_lens[s / kv_heads], 0) + tile - 1) / tile;      // (no second trip to global memory)
         const int rank = sorted ? (s_rn[s] & 0xFFFF) : s, n = sorted ? (s_rn[s] >> 16) : 1;
-        const int per = (tiles + n - 1) / n;
+        const int per = ((tiles + n - 1) / n + align - 1) / align * align;      // (trailing pieces may come out empty: a partial of weight 0)
         for (int k = 0; k < n; ++k) {
             int32_t *it = items + 4ll * (s_base[k] + rank);
             it[1] = min(tiles, k * per), it[2] = min(tiles, (k + 1) * per), it[3] = k | (n << 8);

@@ -562,7 +562,7 @@ static int gqa_decode_impl(const void *q, const void *k, const void *v, void *ou
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(kGqaMaxWgPerCu, (160 * 1024) / lds));
         const int workers = std::max(1, gqa_cus() * per_cu / head_blocks);
         int32_t *plan = (int32_t *)(p.ws_ml + gqa_plan_rows_cap(batch, q_heads) * 2);
-        mi_sgl::decode_plan_kernel<<<1, 1024, 0, st>>>(kv_seq_lens, batch, kv_heads, shape->tile, workers, plan);
+        mi_sgl::decode_plan_kernel<<<1, 1024, 0, st>>>(kv_seq_lens, batch, kv_heads, shape->tile, 1, workers, plan);
         p.plan = plan;
         p.num_splits = num_splits = 1;
         units = mi_sgl::plan_items_max((long long)batch * kv_heads, workers);

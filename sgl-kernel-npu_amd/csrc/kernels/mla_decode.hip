@@ -189,15 +189,29 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int unit = (j / head_blocks) * 8 + xcd;
     const int hblk = j % head_blocks;
-    if (unit >= p.batch * p.kv_heads * p.num_splits) return;
-    const int split = unit % p.num_splits;
-    const int kvh = (unit / p.num_splits) % p.kv_heads;
-    const int b = unit / (p.num_splits * p.kv_heads);
+    // planned form (groups of <= 64 heads, one head block): workgroup = item of the work list, its partial at slot (item, head in group)
+    int split, kvh, b, t_begin, t_end, nsp = p.num_splits;
+    if (p.plan) {
+        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, blockIdx.x);
+        if (it.seq < 0) return;
+        b = it.seq / p.kv_heads, kvh = it.seq % p.kv_heads, split = it.k, nsp = it.n;
+        // the list counts 32-key tiles; pieces start on even ones, except an empty trailing piece clamped to an odd tile count: rounding
+        // its start up as well keeps it empty
+        constexpr int r = kTile / kWideTile;
+        t_begin = (it.t_begin + r - 1) / r, t_end = (it.t_end + r - 1) / r;
+    } else {
+        if (unit >= p.batch * p.kv_heads * p.num_splits) return;
+        split = unit % p.num_splits;
+        kvh = (unit / p.num_splits) % p.kv_heads;
+        b = unit / (p.num_splits * p.kv_heads);
+    }
     const int seq_len = p.seq_lens[b];
-    const int ntiles = (seq_len + kTile - 1) / kTile;
-    const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
-    const int t_begin = split * tps;
-    const int t_end = min(ntiles, t_begin + tps);
+    if (!p.plan) {
+        const int ntiles = (seq_len + kTile - 1) / kTile;
+        const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
+        t_begin = split * tps;
+        t_end = min(ntiles, t_begin + tps);
+    }
     const int dhalf = wave / kHeadWaves;                         // which slice of the 512 output dims this wave accumulates
     const int hg = hblk * kHeadsPerBlock + (wave % kHeadWaves) * 16 + c16;      // head inside the kv group
     const bool head_ok = hg < p.group;
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
     if (kDmaInterleaved) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy fill issued under the last tile
     // ---- epilogue: lane holds O^T[d = dt*16 + 4g + r][head c16]
     if (!head_ok) return;
-    if (p.num_splits == 1) {
+    if (nsp == 1) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)head * p.o_sh + 4 * g + dhalf * kAccTiles * 16;
 #pragma unroll
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
             *(uint2 *)(orow + dt * 16) = uint2{w0, w1};
         }
     } else {
-        const int64_t idx = ((int64_t)b * p.q_heads + head) * p.num_splits + split;
+        const int64_t idx = p.plan ? (int64_t)blockIdx.x * p.group + hg : ((int64_t)b * p.q_heads + head) * p.num_splits + split;
         float *po = p.ws_o + idx * kDN + 4 * g + dhalf * kAccTiles * 16;
 #pragma unroll
         for (int dt = 0; dt < kAccTiles; ++dt) *(f32x4 *)(po + dt * 16) = acc[dt];
@@ -476,10 +490,15 @@ static int plan_workers()
     }
     return cached[d];
 }
-// planned form: partials of plan_items_max items x (at most 128 heads); kv_heads is not an argument of the workspace query, so the
-// number of (sequence, kv head) pairs is bounded through the group size the planned form requires (65..128 heads)
-static long long planned_seqs_bound(int batch, int q_heads) { return (long long)batch * (q_heads / 65 > 1 ? q_heads / 65 : 1); }
-static size_t planned_partial_bytes(long long seqs, int workers) { return (size_t)plan_items_max(seqs, workers) * 128 * (kDN + 2) * sizeof(float); }
+// planned form: one partial row per (item, head of its kv group).  kv_heads is not an argument of the workspace query; for any kv_heads
+// the rows are items * group <= (seqs + workers + pad) * group = batch * q_heads + (workers + pad) * group, and the planned form serves
+// groups of <= 128 heads; the list itself is sized for the most (sequence, kv head) pairs the query allows, batch * q_heads
+static long long planned_seqs_bound(int batch, int q_heads) { return (long long)batch * q_heads; }
+static long long planned_rows_cap(int batch, int q_heads, int workers)
+{
+    return (long long)batch * q_heads + (plan_items_max(0, workers)) * (long long)(q_heads < 128 ? q_heads : 128);
+}
+static size_t planned_partial_bytes(int batch, int q_heads, int workers) { return (size_t)planned_rows_cap(batch, q_heads, workers) * (kDN + 2) * sizeof(float); }
 
 extern "C" size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits)
 {
@@ -487,7 +506,7 @@ extern "C" size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits
     if (num_splits == MI_MLA_SPLITS_PLANNED) {
         const long long seqs = planned_seqs_bound(batch, q_heads);
         const int workers = plan_workers();
-        return planned_partial_bytes(seqs, workers) + (size_t)batch * q_heads * sizeof(uint32_t) + plan_words(seqs, workers) * sizeof(int32_t);
+        return planned_partial_bytes(batch, q_heads, workers) + (size_t)batch * q_heads * sizeof(uint32_t) + plan_words(seqs, workers) * sizeof(int32_t);
     }
     return partial_bytes(batch, q_heads, num_splits) + (size_t)batch * q_heads * sizeof(uint32_t);   // q_heads >= kv_heads
 }
@@ -504,7 +523,7 @@ static bool use_wide(int group)
 extern "C" size_t mi_mla_decode_plan_offset(int batch, int q_heads)
 {
     if (batch <= 0 || q_heads <= 0) return 0;
-    return planned_partial_bytes(planned_seqs_bound(batch, q_heads), plan_workers()) + (size_t)batch * q_heads * sizeof(uint32_t);
+    return planned_partial_bytes(batch, q_heads, plan_workers()) + (size_t)batch * q_heads * sizeof(uint32_t);
 }
 extern "C" int mi_mla_decode_plan_workers(void) { return plan_workers(); }
 
@@ -514,11 +533,13 @@ static bool wide8_selected()
     static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) ? 8 : 4) : 8;
     return (g_wide_variant ? g_wide_variant : wide_env) == 8;
 }
-// the planned form serves the eight-wave wide kernel with one 128-head block per (sequence, kv head); MI_MLA_PLAN=0 keeps uniform splits
+// the planned form serves one workgroup per (sequence, kv head) piece: the eight-wave wide kernel with one 128-head block, or the 64-head
+// kernel with one head block (groups of <= 64 heads: the 16-head shards of a TP-8 deployment); MI_MLA_PLAN=0 keeps uniform splits
 static bool plan_applies(int group)
 {
     static const bool allow = !(getenv("MI_MLA_PLAN") && atoi(getenv("MI_MLA_PLAN")) == 0);
-    return allow && use_wide(group) && group <= 128 && wide8_selected();
+    if (!allow) return false;
+    return use_wide(group) ? (group <= 128 && wide8_selected()) : group <= kHeadsPerBlock;
 }
 
 static int uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
@@ -559,7 +580,7 @@ extern "C" size_t mi_mla_decode_plan_bytes(int batch, int kv_heads)
 extern "C" int mi_mla_decode_build_plan(const int32_t *kv_seq_lens, int batch, int kv_heads, void *plan, size_t plan_bytes, void *stream)
 {
     if (batch <= 0 || kv_heads <= 0 || !kv_seq_lens || !plan || plan_bytes < mi_mla_decode_plan_bytes(batch, kv_heads)) return MI_SGL_EINVAL;
-    decode_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, plan_workers(), (int32_t *)plan);
+    decode_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, kTile / kWideTile, plan_workers(), (int32_t *)plan);
     return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
 }
 
@@ -582,7 +603,8 @@ extern "C" int mi_mla_decode(const void *q, const void *k_nope, const void *k_ro
 }
 // mi_mla_decode in the planned form with a work list the caller built earlier (mi_mla_decode_build_plan): no plan launch in front of the
 // kernel.  workspace as for num_splits = MI_MLA_SPLITS_PLANNED.  Returns MI_SGL_ENOTAPPLICABLE where the planned form does not apply
-// (kv groups outside 65..128 heads, page sizes that are not powers of two, the four-wave kernel selected): call mi_mla_decode.
+// (kv groups of more than 128 heads; for groups of 65..128: page sizes that are not powers of two, the four-wave kernel selected): call
+// mi_mla_decode.
 extern "C" int mi_mla_decode_with_plan(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
                                        const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
                                        int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk,
@@ -623,7 +645,9 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
     // planned form asked for but not served by this launch (four-wave kernel selected, > 128 heads per group, a page size that is not a
     // power of two, cache strides that need the 64-head kernel): uniform splits, as many as the caller's workspace holds
     bool planned = num_splits == MI_MLA_SPLITS_PLANNED;
-    if (planned && !(wide && plan_applies(q_heads / kv_heads) && (page_size & (page_size - 1)) == 0)) {
+    const int group = q_heads / kv_heads;
+    const bool plan_ok = plan_applies(group) && (use_wide(group) ? wide && (page_size & (page_size - 1)) == 0 : true);
+    if (planned && !plan_ok) {
         if (ready_plan) return MI_SGL_ENOTAPPLICABLE;
         planned = false;
         num_splits = uniform_splits(batch, q_heads, kv_heads, max_seq_len);
@@ -638,14 +662,14 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
     p.q = (const uint16_t *)q, p.k_nope = (const uint16_t *)k_nope, p.k_rope = (const uint16_t *)k_rope;
     p.out = (uint16_t *)out, p.seq_lens = kv_seq_lens, p.block_table = block_table;
     p.ws_o = (float *)workspace;
-    p.ws_ml = p.ws_o ? p.ws_o + (planned ? (size_t)plan_items_max(seqs, workers) * (q_heads / kv_heads) : (size_t)batch * q_heads * num_splits) * kDN : nullptr;
+    p.ws_ml = p.ws_o ? p.ws_o + (planned ? (size_t)planned_rows_cap(batch, q_heads, workers) : (size_t)batch * q_heads * num_splits) * kDN : nullptr;
     static uint32_t epoch = 0;
     // (planned: the partial area is sized for the workspace query's bound on the sequences, >= this call's)
-    const size_t part_bytes = planned ? planned_partial_bytes(planned_seqs_bound(batch, q_heads), workers) : partial_bytes(batch, q_heads, num_splits);
+    const size_t part_bytes = planned ? planned_partial_bytes(batch, q_heads, workers) : partial_bytes(batch, q_heads, num_splits);
     p.fix_flags = workspace ? (uint32_t *)((char *)workspace + part_bytes) : nullptr;
     if (planned) {
         int32_t *plan = (int32_t *)((char *)workspace + part_bytes + (size_t)batch * q_heads * sizeof(uint32_t));
-        if (!ready_plan) decode_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, workers, plan);
+        if (!ready_plan) decode_plan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(kv_seq_lens, batch, kv_heads, kWideTile, kTile / kWideTile, workers, plan);
         p.plan = ready_plan ? ready_plan : plan;
         num_splits = 1;                                // per sequence now: the kernels read it from the list
     }
@@ -683,7 +707,7 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
     } else {
         const int head_blocks = (p.group + kHeadsPerBlock - 1) / kHeadsPerBlock;
         const int nwaves = kHeadWaves * kDSplit;      // head waves beyond the group size only help with the DMA
-        dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
+        dim3 grid((unsigned)(planned ? plan_items_max(seqs, workers) : ((units + 7) / 8) * 8 * head_blocks));
         const size_t lds = 2 * (size_t)kBufBytes;
         if (dtype == MI_DTYPE_BF16) mla_decode_kernel<true><<<grid, 64 * nwaves, lds, st>>>(p);
         else mla_decode_kernel<false><<<grid, 64 * nwaves, lds, st>>>(p);

@@ -77,6 +77,27 @@ def bench_mla_decode(steps=30, warmup=5):
     ms_shared = timed_shared_plan(lens)
     r_ms_uniform = timed(rlens, num_splits=2)
     ms_uniform = timed(lens, num_splits=2)
+    # the same cache read by a 16-head shard (TP 8 of the 128 heads: what one rank of a tensor-parallel deployment runs), the 64-head
+    # kernel: planned (default) against two uniform splits
+    q16 = q[:, :16].contiguous()
+    out16 = torch.empty((B, 16, 512), dtype=torch.bfloat16, device="cuda")
+
+    def timed16(ls, num_splits=0):
+        call = lambda: torch.ops.npu.decode_mla(q16, kn, kr, out16, ls, float(sm), int(page), bt, num_splits)
+        for _ in range(max(warmup // 4, 5)):
+            call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            call()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / steps
+
+    shard = {"workload": "the C4 cache read by a 16-head shard (TP 8), 64-head kernel", "ms_per_step": timed16(lens), "ragged_ms_per_step": timed16(rlens),
+             "uniform_2_splits_ms_per_step": timed16(lens, 2), "ragged_uniform_2_splits_ms_per_step": timed16(rlens, 2)}
+    shard["frac"] = (float(lens.sum().item()) * 1152 + B * 16 * 2176) / (shard["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    shard["ragged_frac"] = (float(rlens.sum().item()) * 1152 + B * 16 * 2176) / (shard["ragged_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
     r_bytes = float(rlens.sum().item()) * 576 * 2 + B * Hq * (576 + 512) * 2
     kv_bytes = float(lens.sum().item()) * 576 * 2
     io_bytes = B * Hq * (576 + 512) * 2
@@ -96,6 +117,7 @@ def bench_mla_decode(steps=30, warmup=5):
                    "uniform_2_splits_ms_per_step": r_ms_uniform, "uniform_2_splits_frac": r_bytes / (r_ms_uniform * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         # the same batch with the work list built ONCE outside the loop (decode_mla_plan; the layers of a decode step share it) and passed in
         "shared_plan_ms_per_step": ms_shared, "shared_plan_frac": (kv_bytes + io_bytes) / (ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "tp8_shard": shard,
         "uniform_2_splits_ms_per_step": ms_uniform,     # the full-length batch through num_splits = 2 (round 3's form), queued back to back
         "pmc_kernels": ["decode_plan_kernel", "mla_decode_wide8_kernel<true, true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
         "mfma": {"achieved_TFLOPs": flops / (dev_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,

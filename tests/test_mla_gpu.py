@@ -192,7 +192,7 @@ def test_growing_scores_take_the_rescaling_path(dtype, splits, wide_variant):
     assert torch.allclose(got.float(), want.float(), rtol=2e-2, atol=2e-2), (got.float() - want.float()).abs().max()
 
 
-def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=16, sort_max=2048):
+def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=16, sort_max=2048, align=2):
     """The work list of the planned form restated on the host (sgl-kernel-npu_amd/csrc/kernels/decode_plan.h, decode_plan_kernel): piece size
     x = the smallest for which all pieces fit one round of workgroups; -> (n_items, base[k], rank[s], n[s], items {index: (pair, first
     tile, end tile, k, n)})."""
@@ -216,14 +216,17 @@ def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=16,
         at += (cnt[k] + 7) & ~7
     items = {}
     for s in range(seqs):
-        per = (tiles[s] + n[s] - 1) // n[s]
+        per = ((tiles[s] + n[s] - 1) // n[s] + align - 1) // align * align      # pieces start on even tiles: the list also serves 64-key tiles
         for k in range(n[s]):
             items[base[k] + rank[s]] = (s, min(tiles[s], k * per), min(tiles[s], (k + 1) * per), k, n[s])
     return at, base, rank, n, items
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,S,page,kind", [(128, 128, 1, 4096, 64, "uniform"), (128, 128, 1, 4096, 64, "ragged"), (37, 128, 1, 3000, 16, "ragged"),
-                                                   (5, 256, 2, 9000, 64, "ragged"), (300, 128, 1, 700, 64, "ragged"), (16, 128, 1, 20000, 128, "one_long")])
+                                                   (5, 256, 2, 9000, 64, "ragged"), (300, 128, 1, 700, 64, "ragged"), (16, 128, 1, 20000, 128, "one_long"),
+                                                   # groups of <= 64 heads (TP shards): the 64-head kernel reads the same list, any page size
+                                                   (128, 16, 1, 4096, 64, "ragged"), (9, 64, 4, 3000, 16, "ragged"), (40, 32, 1, 5000, 48, "ragged"),
+                                                   (16, 8, 1, 20000, 128, "one_long"), (3, 128, 8, 4500, 64, "ragged")])
 def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_splits(B, Hq, Hkv, S, page, kind):
     """The device-built work list (length-aware split counts, longest pieces first, the pieces of a sequence on one XCD) against its host
     restatement, word for word; structural properties (every tile of every sequence covered exactly once; padding only); and the
@@ -277,6 +280,7 @@ def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_spl
             pieces = sorted(covered[s])
             tiles = (max(int(lens[s // Hkv]), 0) + 31) // 32
             assert pieces[0][0] == 0 and pieces[-1][1] == tiles and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+            assert all(a[0] % 2 == 0 or a[0] == a[1] == tiles for a in pieces), "pieces start on 64-key boundaries (empty trailing ones: at the end)"
             assert len({x[2] for x in pieces}) == 1, "the pieces of a sequence share blockIdx % 8"
         if kind == "one_long":
             assert n[3 * Hkv] > 4          # the one long sequence is cut into many pieces, the short ones stay whole
@@ -286,13 +290,13 @@ def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_spl
 
 def test_plan_once_run_many_equals_the_per_call_plan():
     """decode_mla_plan + decode_mla(..., plan=...) (the work list built once and shared by calls on the same kv_seq_lens) against the
-    default call that builds its own list: the same bits, on a ragged batch; a shape the planned form does not serve (16 heads) falls back
-    to the plain call."""
+    default call that builds its own list: the same bits, on ragged batches of 128-head and of 16-head (TP shard) calls -- ONE list format
+    serves both kernels; a shape the planned form does not serve (256 heads on one kv head) falls back to the plain call."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sgl-kernel-npu_amd", "python"))
     from sgl_kernel_npu.attention.decode_attention import decode_mla, decode_mla_plan
     g = torch.Generator(device="cuda").manual_seed(21)
-    for B, Hq, S, page in ((48, 128, 3000, 64), (6, 16, 500, 64)):
+    for B, Hq, S, page in ((48, 128, 3000, 64), (48, 16, 3000, 64), (6, 256, 500, 64)):
         maxp = (S + page - 1) // page
         nb = B * maxp
         q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(torch.bfloat16)
