@@ -712,7 +712,7 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
         if (dtype == MI_DTYPE_BF16) mla_decode_kernel<true><<<grid, 64 * nwaves, lds, st>>>(p);
         else mla_decode_kernel<false><<<grid, 64 * nwaves, lds, st>>>(p);
     }
-    if ((num_splits > 1 || wide) && !p.inline_merge) {
+    if ((num_splits > 1 || wide || planned) && !p.inline_merge) {
         const long long bh = (long long)batch * q_heads;
         const int blocks = (int)((bh + 3) / 4);
         if (dtype == MI_DTYPE_BF16) mla_merge_kernel<true><<<blocks, 256, 0, st>>>(p);
