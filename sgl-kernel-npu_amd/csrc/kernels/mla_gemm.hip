@@ -171,6 +171,10 @@ __device__ __forceinline__ void skinny_i8_body(const int8_t *__restrict__ A, int
             }
         }
 }
+// (Round 4, measured and dropped: GEMM1 workgroups of 64 columns x 2 chunks or 32 columns x 4 chunks -- the same 64 KB of weights per
+//  workgroup, all chunks requested up front, one partial product per GROUP of chunks, so the partials shrink from 15 MB to 7.6 / 4.3 MB and
+//  pre_mid sums them in one round trip.  The whole op, queued back to back at 128 tokens: 42.5 us against 43.0 (two chunks), 50 us (four: every
+//  workgroup then reads four times the activation rows from L2).  The partial products are not what GEMM1 + pre_mid wait for.)
 template <int MODE, int BN, bool BF16>
 __global__ __launch_bounds__(256) void skinny_i8_kernel(const int8_t *__restrict__ A, int M, int K, const int8_t *__restrict__ W, int N,
                                                        int32_t *__restrict__ C, const int32_t *__restrict__ bias,
