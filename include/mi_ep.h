@@ -278,6 +278,19 @@ int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32
 int mi_ep_combine_pack(const void *x, const int32_t *send_head, int num_ranks, int num_local_experts, int hidden,
                        int rows_hint, void *packed, int32_t *rows_per_src, void *stream);
 
+/* ---- shared-expert ranks (MOE_SHARED_EXPERT_RANK_NUM = S > 0; reference deep_ep.cpp:62,866-874,1219-1220) --------------------------
+ * The first S ranks hold ONE expert each (the shared expert), the other W - S ranks L = num_moe_experts / (W - S) routed experts each;
+ * every token with at least one active selection also goes to shared rank (my_rank mod S) at its position among those tokens, triple
+ * k = K (moe_distribute_dispatch_v2.h:555-604,748-779,918-960), and the combine adds that row unweighted behind the K weighted ones
+ * (moe_distribute_combine_v2.h:1219-1235).  This call renames the experts so that the ordinary kernels do exactly that with
+ * num_experts = W * L and num_topk = K + 1: idx_out [T, K+1] int32 -- routed expert e -> S*L + e, the shared selection (my_rank mod S) * L
+ * (or -1 for a token without an active selection), invalid ids -> -1; weights_out [T, K+1] (NULL: not needed) = topk_weights (NULL: ones)
+ * with 1.0f in the last column (x * 1.0f is exact: the same bits as the reference's plain add).  Shared ranks use local slot 0 only:
+ * their packed rows, counts [0, W) and row total are those of the reference's single local expert. */
+int mi_ep_shared_expert_map(const void *topk_idx, int idx_is_i32, const float *topk_weights, int num_tokens, int num_topk,
+                            int num_moe_experts, int num_ranks, int shared_ranks, int my_rank, int32_t *idx_out, float *weights_out,
+                            void *stream);
+
 /* ---- A5 low-latency dispatch -------------------------------------------------------------------
  * Window of a rank: rows [L][W][max_tokens] of mi_ep_dispatch_row_bytes(), counts granules
  * uint64 [L*W] {epoch<<32|count}.

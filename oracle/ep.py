@@ -490,6 +490,102 @@ def low_latency_dispatch(xs_bits: Sequence[np.ndarray], topk_idxs: Sequence[np.n
 
 
 # --------------------------------------------------------------------------------------
+# A5 / A6 with shared-expert ranks (MOE_SHARED_EXPERT_RANK_NUM = S > 0).  PARITY UNPINNED: the reference's tests run this mode
+# (tests/python/deepep/test_low_latency.py:385-389) but assert nothing about the shared ranks' rows; restated from the kernels.
+# --------------------------------------------------------------------------------------
+def low_latency_dispatch_shared(xs_bits: Sequence[np.ndarray], topk_idxs: Sequence[np.ndarray],
+                                num_max_dispatch_tokens_per_rank: int, num_experts: int, quant, shared_expert_rank_num: int,
+                                expert_token_nums_type: int = 1) -> List[LLDispatchResult]:
+    """Reference: host csrc/deepep/deep_ep.cpp:866-874 (num_local_experts = 1 and M = global_bs / S on a shared rank, E / (W - S)
+    experts and M = global_bs * min(K, L) on the others); kernel moe_distribute_dispatch_v2.h
+      :555-604  SendToSharedExpert: every ACTIVE token (at least one selected expert, :748-779) of rank r goes to shared rank r mod S
+                (one shared expert: rankNumPerSharedExpert = S), window region of source r, position = index among the active tokens,
+                triple (token, k = K)
+      :650-696  routed expert e lives on rank S + e / L (toRankId = dstExpertId / moeExpertNumPerRank + sharedExpertRankNum)
+      :918-960  counts: a shared rank receives activeMaskBsCnt from every source with the same residue, nothing from the others."""
+    W, S = len(xs_bits), int(shared_expert_rank_num)
+    assert 0 < S < W and W % S == 0
+    E = int(num_experts)
+    L = E // (W - S)
+    H = int(xs_bits[0].shape[1])
+    K = int(topk_idxs[0].shape[1])
+    MT = int(num_max_dispatch_tokens_per_rank)
+    pre = []
+    for r in range(W):
+        x = np.ascontiguousarray(xs_bits[r]).view(np.uint16)
+        pre.append(_quant_rows(x, quant, None) if quant else (x, None))
+    out = []
+    for me in range(W):
+        shared = me < S
+        nl = 1 if shared else L
+        M = MT * W // S if shared else W * MT * min(K, L)
+        rx = np.zeros((M, H), (np.uint8 if quant == "fp8" else np.int8) if quant else np.uint16)
+        rs = np.zeros(M, np.float32) if quant else None
+        tri, rng, per_e, pos = [], np.zeros(nl * W, np.int32), np.zeros(nl, np.int64), 0
+        for le in range(nl):
+            for src in range(W):
+                ti = np.asarray(topk_idxs[src], np.int64)
+                if shared:
+                    active = ((ti >= 0) & (ti < E)).any(axis=1)
+                    tt = np.nonzero(active)[0] if src % S == me else np.zeros(0, np.int64)
+                    kk = np.full(tt.size, K, np.int64)
+                else:
+                    tt, kk = np.nonzero(ti == (me - S) * L + le)
+                c = tt.size
+                if c:
+                    rx[pos:pos + c] = pre[src][0][tt]
+                    if quant:
+                        rs[pos:pos + c] = pre[src][1][tt]
+                    tri.append(np.stack([np.full(c, src, np.int32), tt.astype(np.int32), kk.astype(np.int32)], 1))
+                pos += c
+                per_e[le] += c
+                rng[le * W + src] = pos
+        prc = (np.cumsum(per_e) if expert_token_nums_type == 0 else per_e).astype(np.int64)
+        src_info = np.concatenate(tri).reshape(-1) if tri else np.zeros(0, np.int32)
+        out.append(LLDispatchResult(rx, rs, prc, src_info, rng, pos))
+    return out
+
+
+def low_latency_combine_shared(xs_bits: Sequence[np.ndarray], src_idx: Sequence[np.ndarray], total_rows: Sequence[int],
+                               topk_idxs: Sequence[np.ndarray], topk_weights: Sequence[np.ndarray], num_experts: int) -> List[np.ndarray]:
+    """moe_distribute_combine_v2.h: every expert-side row goes to slot t * (K + 1) + k of its source rank (:885); the owner adds the K
+    routed rows, each times its weight, k ascending (:1192-1218, as weighted_reduce), THEN the shared expert's row (slot K) unweighted
+    (:1219-1235), and rounds to bf16 (:1252)."""
+    W = len(xs_bits)
+    H = int(xs_bits[0].shape[1])
+    E = int(num_experts)
+    slots = []
+    for r in range(W):
+        T, K = topk_idxs[r].shape
+        slots.append(np.zeros((T * (K + 1), H), np.uint16))
+    for r in range(W):
+        n = int(total_rows[r])
+        if n == 0:
+            continue
+        tri = np.asarray(src_idx[r], np.int32).reshape(-1, 3)[:n]
+        x = np.ascontiguousarray(xs_bits[r]).view(np.uint16)[:n]
+        for src in range(W):
+            m = tri[:, 0] == src
+            if m.any():
+                K = topk_idxs[src].shape[1]
+                slots[src][tri[m, 1].astype(np.int64) * (K + 1) + tri[m, 2]] = x[m]
+    out = []
+    for r in range(W):
+        ti = np.asarray(topk_idxs[r], np.int64)
+        T, K = ti.shape
+        w = np.asarray(topk_weights[r], np.float32)
+        valid = (ti >= 0) & (ti < E)
+        rows = bf16_bits_to_f32(slots[r]).reshape(T, K + 1, H)
+        acc = np.zeros((T, H), np.float32)
+        for k in range(K):
+            prod = (rows[:, k, :] * w[:, k][:, None]).astype(np.float32)
+            acc = np.where(valid[:, k][:, None], (acc + prod).astype(np.float32), acc)
+        acc = np.where(valid.any(axis=1)[:, None], (acc + rows[:, K, :]).astype(np.float32), acc)
+        out.append(f32_to_bf16_bits_rne(acc))
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # closed-form goldens asserted by the reference tests (used to pin this oracle)
 # --------------------------------------------------------------------------------------
 def golden_combined(x_bits: np.ndarray, topk_idx: np.ndarray, topk_weights: np.ndarray) -> np.ndarray:
@@ -554,20 +650,25 @@ def moe_gemm2(q_i8: np.ndarray, q_scale: np.ndarray, w_i8: np.ndarray, w_scale: 
 
 
 def fused_deep_moe(xs_bits, topk_idxs, topk_weights, w13, w13_scale, w2, w2_scale, num_max_dispatch_tokens_per_rank,
-                   num_experts) -> List[np.ndarray]:
+                   num_experts, shared_expert_rank_num: int = 0) -> List[np.ndarray]:
     """All ranks' fused_deep_moe.  w13[r] int8 [L, 2I, H] / w13_scale[r] f32 [L, 2I] in ORIGINAL column order (first half gate,
     second half up; the permutation only changes where a column sits, not the math), w2[r] int8 [L, H, I], w2_scale[r] f32 [L, H].
     Arithmetic: INT8 per-token dispatch without epsilon; d = (float(c) * w_scale[col]) * tok_scale[row]
     (block_epilogue_per_token_dequant_swiglu.h:250-269); v = up * gate / (1 + exp(-gate)); q = rint((v*127) * (1/rowmax)),
     scale = rowmax/127 (...swiglu_quant_multistage_workspace.h:199-265); y = bf16((float(c2) * w2_scale[col]) * scale[row]);
-    combine as A6.  Returns bf16 bits per rank."""
+    combine as A6.  Returns bf16 bits per rank.  shared_expert_rank_num = S > 0 (deep_ep.cpp:1219-1220): ranks < S hold one expert
+    (w13[r] has L = 1), the others num_experts / (W - S); dispatch / combine as low_latency_dispatch_shared / low_latency_combine_shared."""
     W = len(xs_bits)
     E = int(num_experts)
-    L = E // W
-    disp = low_latency_dispatch(xs_bits, topk_idxs, num_max_dispatch_tokens_per_rank, E, quant=True)
+    S = int(shared_expert_rank_num)
+    if S:
+        disp = low_latency_dispatch_shared(xs_bits, topk_idxs, num_max_dispatch_tokens_per_rank, E, True, S)
+    else:
+        disp = low_latency_dispatch(xs_bits, topk_idxs, num_max_dispatch_tokens_per_rank, E, quant=True)
     ys = []
     for r in range(W):
         d = disp[r]
+        L = int(w13[r].shape[0])
         H = d.packed_recv_x.shape[1]
         y = np.zeros((d.packed_recv_x.shape[0], H), np.uint16)
         start = 0
@@ -579,4 +680,6 @@ def fused_deep_moe(xs_bits, topk_idxs, topk_weights, w13, w13_scale, w2, w2_scal
                 y[start:end] = moe_gemm2(q, sc, w2[r][le], w2_scale[r][le])
             start = end
         ys.append(y)
+    if S:
+        return low_latency_combine_shared(ys, [d.src_info for d in disp], [d.total for d in disp], topk_idxs, topk_weights, E)
     return combine(ys, [d.src_info for d in disp], [d.total for d in disp], topk_idxs, topk_weights, E)

@@ -78,15 +78,17 @@ Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t n
     HIP_CHECK(hipGetDevice(&device_id));
     timeout_ms = get_value_from_env("DEEPEP_TIMEOUT_MS", 30000);
     // Host-runtime env knobs of the reference that change the data layout (deep_ep.cpp:62,866-874,939,1076-1079):
-    //  * MOE_SHARED_EXPERT_RANK_NUM > 0 turns the first ranks into shared-expert ranks (num_local_experts becomes
-    //    num_experts / (W - S), one slab per shared rank).  That layout is not built here: refuse it loudly instead of
-    //    silently computing a different expert-to-rank map than the caller's model expects.
+    //  * MOE_SHARED_EXPERT_RANK_NUM = S > 0 turns the first S ranks into shared-expert ranks (one local expert each; the others hold
+    //    num_experts / (W - S)); low_latency_dispatch / low_latency_combine / fused_deep_moe follow it (shared_view below), the
+    //    normal-mode ops ignore it as in the reference (deep_ep.cpp:684).  S must divide W: a shared rank's receive bound is
+    //    global_bs / S rows (deep_ep.cpp:870), which only holds when every shared rank serves W / S sources.
     //  * MOE_ENABLE_TOPK_NEG_ONE=1 makes the reference pass x_active_mask = (topk_idx >= 0) so that -1 selections are
     //    skipped; without it -1 is outside the reference's contract.  Here ids < 0 (and >= num_experts) are ALWAYS skipped by
     //    every kernel (layout, stage, reduce), i.e. both settings of the knob behave like "1"; the value is validated only.
-    const int shared_expert_rank_num = get_value_from_env("MOE_SHARED_EXPERT_RANK_NUM", 0);
-    EP_HOST_ASSERT_S(shared_expert_rank_num == 0, "MOE_SHARED_EXPERT_RANK_NUM=", shared_expert_rank_num,
-                     " is not supported on MI355X: shared-expert ranks are not part of this build, run the shared expert outside deep_ep");
+    shared_expert_rank_num = get_value_from_env("MOE_SHARED_EXPERT_RANK_NUM", 0);
+    EP_HOST_ASSERT_S(shared_expert_rank_num >= 0 && shared_expert_rank_num < num_ranks &&
+                         (shared_expert_rank_num == 0 || num_ranks % shared_expert_rank_num == 0),
+                     "MOE_SHARED_EXPERT_RANK_NUM=", shared_expert_rank_num, " must be in [0, num_ranks) and divide num_ranks (", num_ranks, ")");
     const int enable_neg_one = get_value_from_env("MOE_ENABLE_TOPK_NEG_ONE", 0);
     EP_HOST_ASSERT_S(enable_neg_one == 0 || enable_neg_one == 1, "MOE_ENABLE_TOPK_NEG_ONE must be 0 or 1, got ", enable_neg_one);
 
@@ -721,12 +723,33 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
             std::nullopt, std::nullopt};
 }
 
+// Shared-expert ranks: the routing table the kernels see (include/mi_ep.h, mi_ep_shared_expert_map).  S == 0: the caller's own table.
+Buffer::SharedView Buffer::shared_view(const at::Tensor &topk_idx, const float *weights, bool want_weights, int64_t num_experts,
+                                       hipStream_t st) const
+{
+    const int W = (int)num_ranks, S = (int)shared_expert_rank_num, T = (int)topk_idx.size(0), K = (int)topk_idx.size(1);
+    SharedView v;
+    if (S == 0) {
+        EP_HOST_ASSERT(num_experts % num_ranks == 0);
+        v.idx = topk_idx, v.E = (int)num_experts, v.K = K, v.L = v.local_experts = (int)num_experts / W;
+        return v;
+    }
+    EP_HOST_ASSERT_S(num_experts % (W - S) == 0, "num_experts (", num_experts, ") must be a multiple of the ", W - S, " routed-expert ranks");
+    EP_HOST_ASSERT_S(K + 1 <= MI_EP_MAX_TOPK, "num_topk + the shared selection must be <= ", MI_EP_MAX_TOPK);
+    v.L = (int)num_experts / (W - S), v.E = W * v.L, v.K = K + 1, v.local_experts = rank < S ? 1 : v.L;
+    v.idx = at::empty({T, K + 1}, at::dtype(at::kInt).device(topk_idx.device()));
+    if (want_weights) v.weights = at::empty({T, K + 1}, at::dtype(at::kFloat).device(topk_idx.device()));
+    MI_EP_CHECK(mi_ep_shared_expert_map(topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, weights, T, K, (int)num_experts, W, S, (int)rank,
+                                        v.idx.data_ptr<int>(), want_weights ? v.weights.data_ptr<float>() : nullptr, st));
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // A5  low_latency_dispatch  (reference deep_ep.cpp:850-1012)
 // ------------------------------------------------------------------------------------------------
 std::tuple<at::Tensor, std::optional<at::Tensor>, at::Tensor, at::Tensor, at::Tensor, std::optional<EventHandle>,
            std::optional<std::function<void()>>>
-Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, const std::optional<at::Tensor> &,
+Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_user, const std::optional<at::Tensor> &,
                              int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts, bool, bool, bool, bool, bool,
                              bool, const std::string &quant_mode_name)
 {
@@ -734,11 +757,14 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
     EP_HOST_ASSERT(low_latency_mode);
     EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
     EP_HOST_ASSERT(num_max_dispatch_tokens_per_rank >= x.size(0));
-    EP_HOST_ASSERT(topk_idx.dim() == 2 and topk_idx.is_contiguous() and topk_idx.size(0) == x.size(0));
-    EP_HOST_ASSERT(topk_idx.scalar_type() == at::kLong or topk_idx.scalar_type() == at::kInt);
-    EP_HOST_ASSERT(num_experts % num_ranks == 0);
-    const int T = (int)x.size(0), H = (int)x.size(1), K = (int)topk_idx.size(1);
-    const int W = (int)num_ranks, E = (int)num_experts, L = E / W, MT = (int)num_max_dispatch_tokens_per_rank;
+    EP_HOST_ASSERT(topk_idx_user.dim() == 2 and topk_idx_user.is_contiguous() and topk_idx_user.size(0) == x.size(0));
+    EP_HOST_ASSERT(topk_idx_user.scalar_type() == at::kLong or topk_idx_user.scalar_type() == at::kInt);
+    const int T = (int)x.size(0), H = (int)x.size(1), K_user = (int)topk_idx_user.size(1);
+    const int W = (int)num_ranks, MT = (int)num_max_dispatch_tokens_per_rank, S = (int)shared_expert_rank_num;
+    // shared-expert ranks: the kernels see K + 1 selections over W * L expert slots (shared_view); outputs keep the reference's shapes
+    const SharedView sv = shared_view(topk_idx_user, nullptr, false, num_experts, cur_stream());
+    const at::Tensor &topk_idx = sv.idx;
+    const int E = sv.E, K = sv.K, L = sv.L;
     int qm;
     if (quant_mode_name == "int8") qm = MI_EP_QUANT_INT8_NOEPS;
     else if (quant_mode_name == "pertoken_fp8_e4m3") qm = MI_EP_QUANT_FP8_E4M3;
@@ -755,8 +781,10 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
                      " bytes per region, have ", region_bytes, "; raise DEEPEP_WINDOW_BYTES");
     check_status("low_latency_dispatch");
     ++profile_calls;
-    const int64_t num_max_tokens = (int64_t)MT * W * std::min(K, L);       // deep_ep.cpp:867-873
-    const int64_t max_size = std::max<int64_t>((int64_t)T * K, num_max_tokens * 128);   // deep_ep.cpp:875
+    // deep_ep.cpp:866-874: a shared rank receives global_bs / S rows at most, a routed-expert rank global_bs * min(K, L) (the shared
+    // selection never lands there)
+    const int64_t num_max_tokens = S > 0 && rank < S ? (int64_t)MT * W / S : (int64_t)MT * W * std::min(K_user, L);
+    const int64_t max_size = std::max<int64_t>((int64_t)T * K_user, num_max_tokens * 128);   // deep_ep.cpp:875
     auto dev = x.device();
     auto i32 = at::dtype(at::kInt).device(dev);
     const int count_type = get_value_from_env("MOE_EXPERT_TOKEN_NUMS_TYPE", 1);
@@ -814,6 +842,10 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
                                      (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(), ep_recv_count.data_ptr<int>(),
                                      rows_capacity, ctr, region_bytes, (size_t)kLLCountsParityBytes, status_dev, timeout_ms, st)); }
     real_max_bs = std::max<int64_t>(real_max_bs, MT);
+    if (sv.local_experts != L) {      // a shared rank: its single local expert is slot 0 (deep_ep.cpp:869-871: num_local_experts = 1)
+        packed_recv_count = packed_recv_count.narrow(0, 0, sv.local_experts);
+        ep_recv_count = ep_recv_count.narrow(0, 0, (int64_t)sv.local_experts * W);
+    }
     return {packed_recv_x, packed_recv_x_scales, packed_recv_count, expand_idx, ep_recv_count, std::nullopt,
             std::function<void()>([] {})};
 }
@@ -822,21 +854,25 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx, co
 // A6  low_latency_combine  (reference deep_ep.cpp:1014-1087)
 // ------------------------------------------------------------------------------------------------
 std::tuple<at::Tensor, std::optional<EventHandle>, std::optional<std::function<void()>>>
-Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx, const at::Tensor &topk_weights,
+Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx_user, const at::Tensor &topk_weights_user,
                             const at::Tensor &src_info, const at::Tensor &layout_range,
                             int64_t num_max_dispatch_tokens_per_rank, int64_t num_experts, const at::Tensor &, bool, bool,
                             bool, const std::optional<at::Tensor> &)
 {
     require_available();
     EP_HOST_ASSERT(x.dim() == 2 and x.is_contiguous() and x.scalar_type() == at::kBFloat16);
-    EP_HOST_ASSERT(num_max_dispatch_tokens_per_rank >= topk_idx.size(0));
-    EP_HOST_ASSERT(topk_idx.dim() == 2 and topk_idx.is_contiguous());
-    EP_HOST_ASSERT(topk_idx.scalar_type() == at::kLong or topk_idx.scalar_type() == at::kInt);
-    EP_HOST_ASSERT(topk_weights.dim() == 2 and topk_weights.is_contiguous() and topk_weights.scalar_type() == at::kFloat);
-    EP_HOST_ASSERT(topk_weights.size(0) == topk_idx.size(0) and topk_weights.size(1) == topk_idx.size(1));
+    EP_HOST_ASSERT(num_max_dispatch_tokens_per_rank >= topk_idx_user.size(0));
+    EP_HOST_ASSERT(topk_idx_user.dim() == 2 and topk_idx_user.is_contiguous());
+    EP_HOST_ASSERT(topk_idx_user.scalar_type() == at::kLong or topk_idx_user.scalar_type() == at::kInt);
+    EP_HOST_ASSERT(topk_weights_user.dim() == 2 and topk_weights_user.is_contiguous() and topk_weights_user.scalar_type() == at::kFloat);
+    EP_HOST_ASSERT(topk_weights_user.size(0) == topk_idx_user.size(0) and topk_weights_user.size(1) == topk_idx_user.size(1));
     EP_HOST_ASSERT(src_info.scalar_type() == at::kInt and layout_range.scalar_type() == at::kInt);
-    const int K = (int)topk_idx.size(1), H = (int)x.size(1);
-    const int W = (int)num_ranks, E = (int)num_experts;
+    // shared-expert ranks: K + 1 slots per token, the last one the shared expert's row with weight 1 (moe_distribute_combine_v2.h:1219-1235)
+    const SharedView sv = shared_view(topk_idx_user, topk_weights_user.data_ptr<float>(), true, num_experts, cur_stream());
+    const at::Tensor &topk_idx = sv.idx;
+    const at::Tensor &topk_weights = shared_expert_rank_num > 0 ? sv.weights : topk_weights_user;
+    const int K = sv.K, H = (int)x.size(1);
+    const int W = (int)num_ranks, E = sv.E;
     const size_t cb = mi_ep_combine_row_bytes(H);
     EP_HOST_ASSERT_S((size_t)num_max_dispatch_tokens_per_rank * K * cb <= region_bytes, "combine window too small; raise DEEPEP_WINDOW_BYTES");
     check_status("low_latency_combine");
@@ -954,15 +990,21 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
                                            const at::Tensor &topk_weights, int64_t num_max_dispatch_tokens_per_rank,
                                            int64_t num_experts)
 {
-    const int W = (int)num_ranks, E = (int)num_experts, L = E / W, H = (int)x.size(1), T = (int)x.size(0), K = (int)expert_ids.size(1);
+    const int W = (int)num_ranks, H = (int)x.size(1), T = (int)x.size(0), K_user = (int)expert_ids.size(1), S = (int)shared_expert_rank_num;
     const int N1 = (int)w1.size(1), I = N1 / 2;
-    EP_HOST_ASSERT(w1.is_contiguous() and w2.is_contiguous() and w1.size(0) == L and w2.size(0) == L);
-    EP_HOST_ASSERT(w1.size(2) == H and w2.size(1) == H and w2.size(2) == I);
-    EP_HOST_ASSERT(s1.numel() == (int64_t)L * N1 and s2.numel() == (int64_t)L * H);
-    EP_HOST_ASSERT_S(H % 128 == 0 && I % 128 == 0, "hidden (", H, ") and intermediate (", I, ") must be multiples of 128");
-    EP_HOST_ASSERT(topk_weights.size(0) == T and topk_weights.size(1) == K);
-    const int64_t MT = num_max_dispatch_tokens_per_rank;
     hipStream_t st = cur_stream();
+    EP_HOST_ASSERT(topk_weights.size(0) == T and topk_weights.size(1) == K_user);
+    // shared-expert ranks (deep_ep.cpp:1219-1220): a shared rank runs ONE expert over every token of its W / S sources, the routed ranks
+    // their L experts; the kernels see K + 1 selections over W * L expert slots (shared_view), Lw = this rank's local experts
+    const SharedView sv = shared_view(expert_ids, topk_weights.data_ptr<float>(), true, num_experts, st);
+    const int E = sv.E, L = sv.L, K = sv.K, Lw = sv.local_experts;
+    const at::Tensor &ids = sv.idx;
+    const float *weights = S > 0 ? sv.weights.data_ptr<float>() : topk_weights.data_ptr<float>();
+    EP_HOST_ASSERT(w1.is_contiguous() and w2.is_contiguous() and w1.size(0) == Lw and w2.size(0) == Lw);
+    EP_HOST_ASSERT(w1.size(2) == H and w2.size(1) == H and w2.size(2) == I);
+    EP_HOST_ASSERT(s1.numel() == (int64_t)Lw * N1 and s2.numel() == (int64_t)Lw * H);
+    EP_HOST_ASSERT_S(H % 128 == 0 && I % 128 == 0, "hidden (", H, ") and intermediate (", I, ") must be multiples of 128");
+    const int64_t MT = num_max_dispatch_tokens_per_rank;
     auto dev = x.device();
 
     // Dispatch leg.  Decode-size batches take the low-latency slabs (rows straight into the destination's (expert, source)
@@ -979,11 +1021,11 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     } else {
         check_status("fused_deep_moe");
         ++profile_calls;
-        const Layout lay = run_layout(expert_ids, E);
-        DispatchExchange ex = dispatch_exchange(x, expert_ids, lay, E, MI_EP_QUANT_INT8_NOEPS, false, nullptr, st);
-        const int64_t rows_cap = std::max<int64_t>(1, MT * W * std::min(K, L));         // worst case (deep_ep.cpp:867-873)
+        const Layout lay = run_layout(ids, E);
+        DispatchExchange ex = dispatch_exchange(x, ids, lay, E, MI_EP_QUANT_INT8_NOEPS, false, nullptr, st);
+        const int64_t rows_cap = std::max<int64_t>(1, S > 0 && rank < S ? MT * W / S : MT * W * std::min(K_user, L));   // worst case (deep_ep.cpp:866-874)
         dispatch_pull(ex, H, K, L, MI_EP_QUANT_INT8_NOEPS, rows_cap, x.options(), rx, rs, src_info, st);
-        layout_range = ex.nt.recv_count;
+        layout_range = Lw != L ? ex.nt.recv_count.narrow(0, 0, (int64_t)Lw * W) : ex.nt.recv_count;
         real_max_bs = std::max<int64_t>(real_max_bs, MT);
     }
     const int M = (int)rx.size(0);
@@ -992,12 +1034,13 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     at::Tensor sc2 = at::empty({M}, at::dtype(at::kFloat).device(dev));
     const int32_t *cum = layout_range.data_ptr<int>();
     // expected rows per local expert under balanced routing (all ranks send about T tokens x K): picks the GEMM tile shape
-    const int rows_hint = (int)std::max<int64_t>(1, (int64_t)T * K * W / std::max(1, E));
+    const int rows_hint = S > 0 && rank < S ? std::max(1, T * (W / S))
+                                            : (int)std::max<int64_t>(1, (int64_t)T * K_user * W / std::max<int64_t>(1, num_experts));
     { ProfScope ps_(this, "moe_gemm1_swiglu", st);
       MI_EP_CHECK(mi_ep_moe_gemm1_swiglu((const int8_t *)rx.data_ptr(), rs.data_ptr<float>(), (const int8_t *)w1.data_ptr(),
-                                         s1.data_ptr<float>(), cum, W, L, M, H, N1, v.data_ptr<float>(), rows_hint, st)); }
+                                         s1.data_ptr<float>(), cum, W, Lw, M, H, N1, v.data_ptr<float>(), rows_hint, st)); }
     { ProfScope ps_(this, "moe_rowquant", st);
-      MI_EP_CHECK(mi_ep_moe_rowquant(v.data_ptr<float>(), cum + (L * W - 1), M, I, (int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), st)); }
+      MI_EP_CHECK(mi_ep_moe_rowquant(v.data_ptr<float>(), cum + (Lw * W - 1), M, I, (int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), st)); }
     // GEMM2 writes every bf16 row straight into its owner's combine slot (the push of low_latency_combine fused into the GEMM
     // epilogue: no dense [M, H] intermediate, one pass over 2*M*H bytes less), then the usual signal / wait / weighted sum
     const size_t cb = mi_ep_combine_row_bytes(H);
@@ -1005,9 +1048,9 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     auto dst_peers = peer_family_bases(kCombine);
     { ProfScope ps_(this, "moe_gemm2_push", st);
       MI_EP_CHECK(mi_ep_moe_gemm2_push((const int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), (const int8_t *)w2.data_ptr(),
-                                       s2.data_ptr<float>(), cum, W, L, M, I, H, src_info.data_ptr<int>(), K, dst_peers.data(), W,
+                                       s2.data_ptr<float>(), cum, W, Lw, M, I, H, src_info.data_ptr<int>(), K, dst_peers.data(), W,
                                        region_bytes, epoch_ctr(kCombine), region_bytes, rows_hint, st)); }
-    at::Tensor combined = combine_finish(expert_ids, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st);
+    at::Tensor combined = combine_finish(ids, weights, H, E, x.options(), "ll_combine_reduce", st);
     return {combined, layout_range};
 }
 
@@ -1033,7 +1076,8 @@ std::vector<at::Tensor> Buffer::fused_deep_moe(const at::Tensor &x, const at::Te
 {
     require_available();
     fused_common_checks(x, expert_ids, gmm1_permuted_weight, gmm2_weight, quant_mode, expert_scales_optional, "fused_deep_moe");
-    const int W = (int)num_ranks, L = (int)num_experts / W, H = (int)x.size(1);
+    const int W = (int)num_ranks, S = (int)shared_expert_rank_num, H = (int)x.size(1);
+    const int L = S > 0 ? (rank < S ? 1 : (int)num_experts / (W - S)) : (int)num_experts / W;      // deep_ep.cpp:1219-1220
     EP_HOST_ASSERT(gmm1_permuted_weight.size(0) == L and gmm2_weight.size(0) == L);
     at::Tensor w1 = gmm1_permuted_weight, w2 = gmm2_weight;
     if (w1.size(2) != H) {                       // reference logical shape [L, H, 2I]
@@ -1063,6 +1107,8 @@ std::vector<at::Tensor> Buffer::dispatch_ffn_combine(const at::Tensor &x, const 
                                                      int64_t num_experts, int64_t quant_mode)
 {
     require_available();
+    EP_HOST_ASSERT_S(shared_expert_rank_num == 0, "dispatch_ffn_combine does not take shared-expert ranks (the reference passes none either, ",
+                     "deep_ep.cpp:1254-1287); use fused_deep_moe or the low-latency ops");
     EP_HOST_ASSERT(max_output_size > 0);
     EP_HOST_ASSERT_S(weight1.scalar_type() == at::kChar, "BF16 mode not yet supported for dispatch_ffn_combine");
     fused_common_checks(x, expert_ids, weight1, weight2, quant_mode, expert_scales, "dispatch_ffn_combine");

@@ -206,6 +206,14 @@ private:
     uint64_t selftest_epoch = 0;           // (dispatch / combine / low-latency call counters live on the device: epoch_ctr())
     Layout stash;                          // hidden state coupling of the reference (deep_ep.cpp:170-172,321)
     int64_t real_max_bs = 0;
+    // MOE_SHARED_EXPERT_RANK_NUM (reference deep_ep.cpp:62): the first S ranks hold the shared expert; low-latency ops and fused_deep_moe only
+    int64_t shared_expert_rank_num = 0;
+    // the (K+1)-selection view of a routing table under shared-expert ranks (mi_ep_shared_expert_map); E / K / L of the renamed experts
+    struct SharedView {
+        at::Tensor idx, weights;
+        int E = 0, K = 0, L = 0, local_experts = 0;
+    };
+    SharedView shared_view(const at::Tensor &topk_idx, const float *weights, bool want_weights, int64_t num_experts, hipStream_t st) const;
     int64_t profile_skip = 0, profile_active = 0, profile_calls = 0;
     bool profiling = false;
     std::string profile_dir;

@@ -301,3 +301,41 @@ extern "C" int mi_ep_dispatch_layout(const void *topk_idx, int idx_is_i32, int T
     }
     return launch_status();
 }
+
+// ---- shared-expert ranks (MOE_SHARED_EXPERT_RANK_NUM = S > 0) ------------------------------------------------------------------------
+// Reference: the first S ranks of the group hold ONE expert each (the shared expert), the other W - S ranks hold L = E / (W - S) routed
+// experts each (deep_ep.cpp:866-874, 1219-1220); every token that has at least one active selection is ALSO sent to shared rank
+// (my_rank mod S), at its position among those tokens, with k = K in its triple (moe_distribute_dispatch_v2.h:555-604, 748-779, 918-960),
+// and the combine adds that row unweighted after the K weighted ones (moe_distribute_combine_v2.h:1219-1235).  Here that is a renaming of
+// experts in front of the ordinary kernels: W ranks x L expert slots, routed expert e -> slot S*L + e (rank S + e / L, local e mod L), the
+// shared expert of rank s -> slot s*L (shared ranks use local slot 0 only), as a (K+1)-th selection of weight 1 (x * 1.0f is exact).
+template <bool I32>
+__global__ __launch_bounds__(256) void shared_expert_map_kernel(const void *__restrict__ topk_idx, const float *__restrict__ w_in, int T, int K, int E, int S,
+                                                                int L, int my_rank, int32_t *__restrict__ idx_out, float *__restrict__ w_out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+        const long long e = I32 ? (long long)((const int32_t *)topk_idx)[(size_t)t * K + k] : ((const long long *)topk_idx)[(size_t)t * K + k];
+        const bool ok = e >= 0 && e < E;
+        any |= ok;
+        idx_out[(size_t)t * (K + 1) + k] = ok ? (int32_t)(e + (long long)S * L) : -1;
+        if (w_out) w_out[(size_t)t * (K + 1) + k] = w_in ? w_in[(size_t)t * K + k] : 1.0f;
+    }
+    idx_out[(size_t)t * (K + 1) + K] = any ? (my_rank % S) * L : -1;
+    if (w_out) w_out[(size_t)t * (K + 1) + K] = 1.0f;
+}
+
+extern "C" int mi_ep_shared_expert_map(const void *topk_idx, int idx_is_i32, const float *topk_weights, int T, int K, int E, int W, int S,
+                                       int my_rank, int32_t *idx_out, float *weights_out, void *stream)
+{
+    if (T < 0 || K <= 0 || K >= MI_EP_MAX_TOPK || E <= 0 || S <= 0 || S >= W || E % (W - S) || my_rank < 0 || my_rank >= W) return MI_EP_EINVAL;
+    if (T == 0) return MI_EP_OK;
+    if (!topk_idx || !idx_out) return MI_EP_EINVAL;
+    const int L = E / (W - S);
+    hipStream_t s = (hipStream_t)stream;
+    if (idx_is_i32) shared_expert_map_kernel<true><<<(T + 255) / 256, 256, 0, s>>>(topk_idx, topk_weights, T, K, E, S, L, my_rank, idx_out, weights_out);
+    else shared_expert_map_kernel<false><<<(T + 255) / 256, 256, 0, s>>>(topk_idx, topk_weights, T, K, E, S, L, my_rank, idx_out, weights_out);
+    return launch_status();
+}

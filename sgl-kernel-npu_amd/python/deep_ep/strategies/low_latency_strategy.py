@@ -101,6 +101,8 @@ class AllToAllLowLatencyCommStrategy(LowLatencyEPCommStrategy):
             raise ValueError(f"{quant_mode} is not supported on this device, please use int8, pertoken_fp8_e4m3 or bf16 instead.")
         import os
 
+        if int(os.getenv("MOE_SHARED_EXPERT_RANK_NUM", "0")) != 0:
+            raise ValueError("MOE_SHARED_EXPERT_RANK_NUM is served by the default (window) low-latency strategy only")
         topk_ids = topk_idx.int()
         W = self.group_size
         L = num_experts // W

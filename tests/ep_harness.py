@@ -49,6 +49,8 @@ def _lib():
     lib.mi_ep_ll_dispatch_layout_send.restype = c_int
     lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
     lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, I, V, I, V]
+    lib.mi_ep_shared_expert_map.argtypes = [V, I, V, I, I, I, I, I, I, V, V, V]
+    lib.mi_ep_shared_expert_map.restype = c_int
     for n in ("mi_ep_dispatch_layout mi_ep_signal mi_ep_wait mi_ep_notify_post mi_ep_notify_wait mi_ep_notify_tables "
               "mi_ep_dispatch_stage mi_ep_dispatch_pull mi_ep_dispatch_stage_compact mi_ep_dispatch_pull_indexed mi_ep_dispatch_pull_local mi_ep_combine_push mi_ep_combine_reduce mi_ep_ll_dispatch_send "
               "mi_ep_ll_post_counts mi_ep_ll_dispatch_recv").split():

@@ -860,3 +860,89 @@ def _gpu_layout_two_streams(rank, world, port, cfg):
             assert np.array_equal(per_rank.cpu().numpy(), want[s]["num_tokens_per_rank"]), (rnd, s)
             assert np.array_equal(is_in.cpu().numpy().astype(bool), want[s]["is_token_in_rank"].astype(bool)), (rnd, s)
     dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU: shared-expert ranks (MOE_SHARED_EXPERT_RANK_NUM = S): low-latency dispatch / combine bit for bit against the kernel restatement,
+# fused_deep_moe at the reference bar
+# ----------------------------------------------------------------------------------------------
+def gpu_shared_expert_worker(rank, world, port, cfg):
+    run_guarded(_gpu_shared_expert, rank, world, port, cfg)
+
+
+def _gpu_shared_expert(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits, bf16_bits_to_f32
+    torch.cuda.set_device(0)
+    W, S, T, H, K, E, drop, quant, I = cfg
+    os.environ["MOE_SHARED_EXPERT_RANK_NUM"] = str(S)
+    group = _init(rank, world, port)
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(768 << 20))
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "20000")
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    L = E // (W - S)
+    nl = 1 if rank < S else L
+    for it in range(2):
+        xs, idxs, ws = make_inputs(W, T, H, K, E, drop, seed=300 + it)
+        if drop > 0:
+            idxs[W - 1][0, :] = -1            # a token without any active selection: it does not go to the shared expert either
+        x = bits_to_torch(xs[rank]).cuda()
+        ti = torch.from_numpy(idxs[rank]).cuda()
+        if it == 1:
+            ti = ti.int()
+        MT = T + W
+        llw = O.low_latency_dispatch_shared(xs, idxs, MT, E, quant, S)
+        rx, cnt, h, _, hook = buf.low_latency_dispatch(x, ti, MT, E, use_fp8=quant)
+        hook()
+        me = llw[rank]
+        # shapes of the reference host (deep_ep.cpp:866-874,914-917): one local expert and global_bs / S rows on a shared rank
+        assert cnt.shape == (nl,) and h[1].shape == (nl * W,)
+        assert (rx[0] if quant else rx).shape[0] == (MT * W // S if rank < S else MT * W * min(K, L))
+        assert np.array_equal(cnt.cpu().numpy(), me.packed_recv_count), (cnt.cpu().numpy(), me.packed_recv_count)
+        assert np.array_equal(h[1].cpu().numpy(), me.layout_range)
+        nn = me.total
+        assert np.array_equal(h[0].cpu().numpy()[:3 * nn], me.src_info)
+        if quant:
+            assert np.array_equal(rx[0].cpu().numpy()[:nn], me.packed_recv_x[:nn])
+            assert np.array_equal(rx[1].cpu().numpy()[:nn], me.packed_recv_x_scales[:nn])
+            yl = bits_to_torch(O.per_token_cast_back(me.packed_recv_x, me.packed_recv_x_scales)).cuda()
+        else:
+            assert np.array_equal(torch_to_bits(rx)[:nn], me.packed_recv_x[:nn])
+            yl = rx
+        yls = [O.per_token_cast_back(w.packed_recv_x, w.packed_recv_x_scales) if quant else w.packed_recv_x for w in llw]
+        wabs = [np.abs(w_) for w_ in ws]
+        want = O.low_latency_combine_shared(yls, [w.src_info for w in llw], [w.total for w in llw], idxs, wabs, E)
+        outl, _, hook = buf.low_latency_combine(yl, ti, torch.from_numpy(wabs[rank]).cuda(), h)
+        hook()
+        assert np.array_equal(torch_to_bits(outl), want[rank]), "LL combine with a shared expert mismatch"
+    if I:
+        rng = np.random.default_rng(11)
+        xs, idxs, _ = make_inputs(W, T, H, K, E, drop, seed=9)
+        xs = [x[:T] for x in xs]
+        idxs = [i[:T] for i in idxs]
+        ws = [np.abs(rng.standard_normal((T, K))).astype(np.float32) for _ in range(W)]
+        nls = [1 if r < S else L for r in range(W)]
+        w13 = [rng.integers(-16, 16, (n, 2 * I, H)).astype(np.int8) for n in nls]
+        w2 = [rng.integers(-16, 16, (n, H, I)).astype(np.int8) for n in nls]
+        s13 = [(rng.random((n, 2 * I)) * 4e-4 + 1.5e-3).astype(np.float32) for n in nls]
+        s2 = [(rng.random((n, H)) * 4e-4 + 1.5e-3).astype(np.float32) for n in nls]
+        want = O.fused_deep_moe(xs, idxs, ws, w13, s13, w2, s2, T, E, shared_expert_rank_num=S)[rank]
+        perm = O.permute_fusion_cols(2 * I)
+        w13_p = torch.from_numpy(np.ascontiguousarray(w13[rank][:, perm, :])).cuda()
+        s13_p = torch.from_numpy(np.ascontiguousarray(s13[rank][:, perm])).cuda()
+        x = bits_to_torch(xs[rank]).cuda()
+        ti = torch.from_numpy(idxs[rank]).cuda()
+        tw = torch.from_numpy(ws[rank]).cuda()
+        ll = O.low_latency_dispatch_shared(xs, idxs, T, E, True, S)[rank]
+        for _ in range(2):
+            out, ep_recv_count = buf.fused_deep_moe(x, ti, tw, w13_p, s13_p, torch.from_numpy(w2[rank]).cuda(), torch.from_numpy(s2[rank]).cuda(), T, E)
+        assert np.array_equal(ep_recv_count.cpu().numpy(), ll.layout_range)
+        got = bf16_bits_to_f32(torch_to_bits(out))
+        ref = bf16_bits_to_f32(want)
+        assert O.calc_diff(got, ref) < 1e-5, O.calc_diff(got, ref)
+        denom = np.maximum(np.abs(ref), 1e-2)
+        assert np.mean(np.abs(got - ref) / denom) < 4e-4, np.mean(np.abs(got - ref) / denom)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()

@@ -104,3 +104,20 @@ def test_layout_calls_on_two_streams_do_not_share_barrier_words():
     """get_dispatch_layout issued concurrently on two streams of one Buffer (4096 + 4352 tokens: both take the cooperative
     one-launch form): every launch borrows its own sync-word pair from the Buffer's ring; all tables match the oracle."""
     _spawn(mp_workers.gpu_layout_two_streams_worker, 1, (4096, 8, 256, 10))
+
+
+@pytest.mark.parametrize("cfg", [
+    # W, S (shared-expert ranks), T, H, K, E (routed experts), drop, quant, I (0: no fused_deep_moe leg)
+    (2, 1, 24, 512, 2, 4, 0.0, True, 128),
+    (4, 1, 33, 1024, 4, 12, 0.2, True, 0),
+    (4, 2, 40, 512, 4, 8, 0.1, False, 128),
+    (8, 2, 16, 2048, 8, 48, 0.1, True, 0),
+    (8, 4, 12, 512, 7, 16, 0.3, True, 256),
+    (2, 1, 600, 512, 2, 4, 0.0, True, 128),       # more than 512 tokens: fused_deep_moe takes the prefill-size exchange branch
+])
+def test_shared_expert_ranks(cfg):
+    """MOE_SHARED_EXPERT_RANK_NUM = S (reference deep_ep.cpp:62,866-874,1219-1220): the first S ranks hold the shared expert and receive
+    every active token of the sources with their residue; the others hold E / (W - S) routed experts.  Low-latency dispatch (rows, scales,
+    triples with k = K, counts, output shapes) and combine (K weighted rows, then the shared row unweighted) bit for bit against the
+    restatement of the kernels; fused_deep_moe with per-rank expert counts at the reference's bar."""
+    _spawn(mp_workers.gpu_shared_expert_worker, cfg[0], cfg)

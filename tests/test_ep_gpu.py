@@ -443,3 +443,36 @@ def test_fp8_e4m3_dispatch_bit_exact(W, T, H, K, E, drop, active, mode):
     comb_got = h.combine([dev_bf16(y) for y in ys], tris, totals, dev_idx, [torch.from_numpy(w_).cuda() for w_ in ws])
     for r in range(W):
         assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r]), r
+
+
+@pytest.mark.parametrize("T,K,E,W,S,rank,i32,with_w", [(33, 4, 12, 4, 1, 2, False, True), (1, 8, 48, 8, 2, 5, True, False), (700, 2, 4, 2, 1, 0, False, True),
+                                                      (64, 7, 16, 8, 4, 7, True, True)])
+def test_shared_expert_map_renames_experts(T, K, E, W, S, rank, i32, with_w):
+    """mi_ep_shared_expert_map (MOE_SHARED_EXPERT_RANK_NUM; reference deep_ep.cpp:866-874, moe_distribute_dispatch_v2.h:555-604,650-696):
+    routed expert e -> slot S*L + e (rank S + e / L), the shared selection (rank mod S) * L for tokens with an active selection, -1
+    otherwise; weights copied with 1.0 appended (NULL in: ones); bad arguments are refused."""
+    import ep_harness as Hh
+    from capi import ptr, stream_ptr
+    lib, ck = Hh.lib, Hh.ck
+    L_ = E // (W - S)
+    rng = np.random.default_rng(T + K)
+    idx = rng.integers(-2, E + 2, (T, K))
+    if T > 2:
+        idx[1, :] = -1
+    w = rng.standard_normal((T, K)).astype(np.float32)
+    ti = torch.from_numpy(idx.astype(np.int32 if i32 else np.int64)).cuda()
+    tw = torch.from_numpy(w).cuda()
+    out = torch.full((T, K + 1), 7, dtype=torch.int32, device="cuda")
+    wout = torch.zeros((T, K + 1), dtype=torch.float32, device="cuda")
+    L = lib()
+    ck(L.mi_ep_shared_expert_map(ptr(ti), int(i32), ptr(tw) if with_w else None, T, K, E, W, S, rank, ptr(out), ptr(wout), stream_ptr()))
+    torch.cuda.synchronize()
+    ok = (idx >= 0) & (idx < E)
+    want = np.concatenate([np.where(ok, idx + S * L_, -1), np.where(ok.any(axis=1), (rank % S) * L_, -1)[:, None]], axis=1)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(wout.cpu().numpy(), np.concatenate([w if with_w else np.ones_like(w), np.ones((T, 1), np.float32)], axis=1))
+    # every renamed id lands on the rank the reference sends it to
+    dst = want[:, :K][ok] // L_
+    assert np.array_equal(dst, idx[ok] // L_ + S)
+    for bad in ((T, K, E, W, 0), (T, K, E, W, W), (T, K, E * (W - S) + 1, W, S) if W - S > 1 else (T, K, 0, W, S), (T, 16, E, W, S)):
+        assert L.mi_ep_shared_expert_map(ptr(ti), int(i32), None, bad[0], bad[1], bad[2], bad[3], bad[4], 0, ptr(out), None, stream_ptr()) == -1

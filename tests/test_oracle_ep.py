@@ -188,6 +188,57 @@ def test_low_latency_dispatch_contract(W, T, K, E, quant, drop):
     assert all(np.array_equal(a.packed_recv_x, b.packed_recv_x) for a, b in zip(res, res2))
 
 
+@pytest.mark.parametrize("W,S,T,K,E,quant,drop", [(2, 1, 9, 2, 4, True, 0.0), (4, 2, 17, 4, 8, False, 0.3), (8, 2, 12, 8, 48, True, 0.2),
+                                                  (8, 4, 5, 3, 8, True, 0.5)])
+def test_shared_expert_ranks_equal_a_renaming_of_experts_over_the_pinned_functions(W, S, T, K, E, quant, drop):
+    """MOE_SHARED_EXPERT_RANK_NUM: no reference test holds a vector for the shared ranks' rows (PARITY UNPINNED), so the direct restatement
+    of the kernels (low_latency_dispatch_shared / low_latency_combine_shared) is tied to the PINNED functions here: with W * L expert
+    slots, routed expert e renamed S*L + e and the shared expert of rank r as a (K+1)-th selection (r mod S) * L of weight 1, the pinned
+    low_latency_dispatch / combine must give the same rows, triples, counts and sums -- and the counts must be what the reference
+    kernel's SetStatus writes (moe_distribute_dispatch_v2.h:918-960)."""
+    H = 64
+    rng = np.random.default_rng(5 + W + S)
+    Ts = [T + r for r in range(W)]
+    xs = [_rand_bf16(rng, (t, H)) for t in Ts]
+    idxs = [make_topk(rng, t, K, E, drop) for t in Ts]
+    idxs[0][0, :] = -1                                   # a token without an active selection
+    ws = [np.abs(rng.standard_normal((t, K))).astype(np.float32) for t in Ts]
+    L = E // (W - S)
+    MT = max(Ts)
+    got = ep.low_latency_dispatch_shared(xs, idxs, MT, E, quant, S)
+    ren, wren = [], []
+    for r in range(W):
+        ok = (idxs[r] >= 0) & (idxs[r] < E)
+        shared = np.where(ok.any(axis=1), (r % S) * L, -1)[:, None]
+        ren.append(np.concatenate([np.where(ok, idxs[r] + S * L, -1), shared], axis=1).astype(np.int64))
+        wren.append(np.concatenate([ws[r], np.ones((Ts[r], 1), np.float32)], axis=1))
+    via = ep.low_latency_dispatch(xs, ren, MT, W * L, quant)
+    active = [int(((i >= 0) & (i < E)).any(axis=1).sum()) for i in idxs]
+    for r in range(W):
+        nl = 1 if r < S else L
+        n = got[r].total
+        assert got[r].layout_range.shape == (nl * W,) and got[r].packed_recv_count.shape == (nl,)
+        assert np.array_equal(got[r].layout_range, via[r].layout_range[:nl * W]) and n == via[r].total
+        assert np.array_equal(got[r].packed_recv_count, via[r].packed_recv_count[:nl])
+        assert np.array_equal(got[r].src_info, via[r].src_info) and np.array_equal(got[r].packed_recv_x[:n], via[r].packed_recv_x[:n])
+        if quant:
+            assert np.array_equal(got[r].packed_recv_x_scales[:n], via[r].packed_recv_x_scales[:n])
+        assert got[r].packed_recv_x.shape[0] == (MT * W // S if r < S else MT * W * min(K, L))        # deep_ep.cpp:866-874
+        if r < S:       # SetStatus: activeMaskBsCnt from every source of the same residue, 0 from the others
+            per_src = np.diff(np.concatenate([[0], got[r].layout_range]))
+            assert per_src.tolist() == [active[src] if src % S == r else 0 for src in range(W)]
+            assert (got[r].src_info.reshape(-1, 3)[:, 2] == K).all()
+    ys = [ep.per_token_cast_back(g.packed_recv_x, g.packed_recv_x_scales) if quant else g.packed_recv_x for g in got]
+    a = ep.low_latency_combine_shared(ys, [g.src_info for g in got], [g.total for g in got], idxs, ws, E)
+    b = ep.combine(ys, [g.src_info for g in got], [g.total for g in got], ren, wren, W * L)
+    for r in range(W):
+        assert np.array_equal(a[r], b[r])
+        # every active token comes back as x * (sum of its weights + 1): the shared expert's copy is added unweighted
+        act = ((idxs[r] >= 0) & (idxs[r] < E))
+        want = bf16_bits_to_f32(xs[r]) * (np.where(act, ws[r], 0).sum(axis=1) + act.any(axis=1))[:, None]
+        assert ep.calc_diff(bf16_bits_to_f32(a[r]), want) < (3e-3 if quant else 1e-5)
+
+
 # ---- committed fixtures (tests/golden/ep_case_*.npz, generated by tests/golden/gen_ep_golden.py) freeze the oracle ---------
 import glob as _glob
 import os as _os
