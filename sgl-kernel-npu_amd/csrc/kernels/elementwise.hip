@@ -10,6 +10,7 @@
 // sizes up to 8192; reductions are wave shuffles (+ one LDS hop across waves).  Algorithmic bytes are listed per op.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mi_sgl_kernels.h"
 
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(256) void split_qkvgate_gemma_kernel(
 // per lane, v_cvt_pk_bf16_f32, DPP for the head reduction and the RoPE partner, two groups per wave (58 VGPRs, 8 waves per SIMD).
 // Measured and dropped: a grid-stride loop over 2048 workgroups (31.8), NEOX / NORM as template parameters plus a copy path for
 // all-V groups (31.5), sharing one sin / cos load between the groups of a wave (31.4; with the selection deferred to the use: 36).
+// (round 4, same box: 1 item per wave 139 us at 16384 x 8192, 2 items 118, 4 items 118; non-temporal loads and stores 114)
 constexpr int kVecUnroll = 2;
 
 // MROPE (norm/split_qkv_rmsnorm_mrope.py:57-333; golden tests/python/sgl_kernel_npu/test_split_qkv_rmsnorm_mrope.py:7-110): `sin` is
@@ -475,17 +477,24 @@ __device__ __forceinline__ int mrope_section_of(const MropeSections &m, int o)
     // offsets behind the three sections take cos = sin = 0 (the reference masks w to [t + h, t + h + w), :157-163)
     return o < m.sec0 ? 0 : (o < m.sec0 + m.sec1 ? 1 : (o < m.sec0 + m.sec1 + m.sec2 ? 2 : 3));
 }
-template <bool BF16, bool MROPE>
+// FAST: the instance for the shape every Llama / Qwen-style caller has -- heads of 128, the whole head rotated, rotate-half, norm weights
+// present, plain (not Gemma, not gated) -- with those facts as compile-time constants and NO per-lane branches: V heads run the same
+// arithmetic as Q / K heads and keep their input words at the final select.  The general instance is VALU-bound (about 370 vector
+// instructions per 16 B of every lane, a quarter of them moves and selects around the `normed` / `roped` branches: 4.5 TB/s).
+template <bool BF16, bool MROPE, bool FAST = false>
 __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ sin, const uint16_t *__restrict__ cos, int rows, int q_hidden,
-    int kv_hidden, int head_dim, int rope_dim, int has_norm, float eps, const uint16_t *__restrict__ qw,
-    const uint16_t *__restrict__ kw, const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kb, int neox,
-    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v, uint16_t *__restrict__ gate, int gemma, MropeSections ms)
+    int kv_hidden, int head_dim_p, int rope_dim_p, int has_norm_p, float eps, const uint16_t *__restrict__ qw,
+    const uint16_t *__restrict__ kw, const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kb, int neox_p,
+    uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v, uint16_t *__restrict__ gate, int gemma_p, MropeSections ms)
 {
+    static_assert(!(FAST && MROPE), "the fast instance serves the plain form");
+    const int head_dim = FAST ? 128 : head_dim_p, rope_dim = FAST ? 128 : rope_dim_p;
+    const int has_norm = FAST ? 1 : has_norm_p, neox = FAST ? 1 : neox_p, gemma = FAST ? 0 : gemma_p;
     // gate != nullptr: the gated Gemma form (split_qkv_rmsnorm_rope.py:441-745) -- the row is q_heads pairs [q head | gate head], then K,
     // then V, i.e. still one head-sized item every head_dim elements; odd items of the first 2 q_heads are gates (copied like V).
     // gemma: the norm weight is w + 1 and the scale rsqrt(mean + eps) (:468, :499-503)
-    const bool gated = gate != nullptr;
+    const bool gated = FAST ? false : gate != nullptr;
     const int lane = threadIdx.x & 63;
     const int gl = head_dim >> 3;                      // lanes per head (8 .. 32), a power of two
     const int gl_shift = 31 - __builtin_clz(gl);
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
         h[u] = (int)(hglobal - r32 * (uint32_t)heads_total);
         active[u] = row[u] < rows;
         const bool is_v = h[u] >= q_items + kv_heads || (gated && h[u] < q_items && (h[u] & 1)), is_q = h[u] < q_items;
-        const bool normed = active[u] && !is_v;
+        const bool normed = FAST ? active[u] : (active[u] && !is_v);      // FAST: V heads load (and compute) like the others
         xr[u] = active[u] ? *(const u32x4 *)(qkv + row[u] * total_hidden + (long long)h[u] * head_dim + j * 8) : zero4;
         wr[u] = (has_norm && normed) ? *(const u32x4 *)((is_q ? qw : kw) + j * 8) : zero4;
         br[u] = (has_norm && normed && qb) ? *(const u32x4 *)((is_q ? qb : kb) + j * 8) : zero4;
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             ss += dpp_f32<0x141>(ss);                       // row_half_mirror: the other quad of the 8-lane group
             if (gl >= 16) ss += dpp_f32<0x140>(ss);         // row_mirror: the other half of the 16-lane row
             if (gl == 32) ss += __shfl_xor(ss, 16, 64);
-            if (active[u] && !is_v) {
+            if (FAST || (active[u] && !is_v)) {
                 // rsqrt where the reference kernel says tl.rsqrt (gemma :500, position cache :101), 1 / sqrt where it says so (mrope :202)
                 const float rstd = (gemma || (MROPE && ms.mode == 1)) ? rsqrtf(ss / (float)head_dim + eps) : 1.0f / sqrtf(ss / (float)head_dim + eps);
                 float wv[8];
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) px[e] = __shfl(x[e], partner & 63, 64);
             }
-            if (active[u] && !is_v && roped) {
+            if (FAST || (active[u] && !is_v && roped)) {
                 float sv[8], cv[8];
                 if (MROPE) {
 #pragma unroll
@@ -812,7 +821,17 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
         (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox, (uint16_t *)q,   \
         (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, MropeSections{0, 0, 0, 0, 0, nullptr, 0, 0, 0, 0, 0})
-        if (dtype == MI_DTYPE_BF16) MI_VEC(true); else MI_VEC(false);
+        // the common shape -- heads of 128 rotated whole, rotate-half, norm weights -- has its own branch-free instance
+        const bool fast = head_dim == 128 && rope_dim == 128 && neox && has_norm;
+#define MI_VEC_FAST(B)                                                                                                              \
+    split_qkv_rmsnorm_rope_vec_kernel<B, false, true><<<blocks, 256, 0, st>>>(                                                      \
+        (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
+        (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox, (uint16_t *)q,   \
+        (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, MropeSections{0, 0, 0, 0, 0, nullptr, 0, 0, 0, 0, 0})
+        static const bool allow_fast = !(getenv("MI_SPLIT_QKV_FAST") && atoi(getenv("MI_SPLIT_QKV_FAST")) == 0);
+        if (fast && allow_fast) { if (dtype == MI_DTYPE_BF16) MI_VEC_FAST(true); else MI_VEC_FAST(false); }
+        else if (dtype == MI_DTYPE_BF16) MI_VEC(true); else MI_VEC(false);
+#undef MI_VEC_FAST
 #undef MI_VEC
         return launch_ok();
     }
