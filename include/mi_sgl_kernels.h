@@ -73,9 +73,10 @@ int mi_mla_decode_with_plan(const void *q, const void *k_nope, const void *k_rop
                             size_t workspace_bytes, void *stream);
 /* Introspection of the planned form (tests, tuning): byte offset of the work list inside a workspace sized with MI_MLA_SPLITS_PLANNED, and
  * the number of concurrently running workgroups it was balanced for (the CU count).  Work-list words (int32):
- *   [0] items incl. padding, [1] rounds, [2 + k] first item of round k (k < 16);  [32 + 2 s] rank of (sequence, kv head) pair s by
- *   descending cost, [33 + 2 s] its piece count n_s;  then 4 words per item: pair (-1 = padding), first tile, end tile, k | n_s << 8
- *   (tiles of 32 keys, pieces start on even tiles).  Item of piece k of the pair ranked r: word[2 + k] + r. */
+ *   [0] items, [1] piece size (tiles);  [16 + 2 s] first item of (sequence, kv head) pair s, [17 + 2 s] its piece count n_s;  then 4 words
+ *   per item: pair (-1 = behind the list), first tile, end tile, k | n_s << 8 (tiles of 32 keys, pieces start on even tiles).  The pieces of a
+ *   pair are consecutive items (item of piece k: first + k), pairs in order of descending length: any run of items spreads evenly over the
+ *   XCDs (workgroup i runs on XCD i mod 8). */
 size_t mi_mla_decode_plan_offset(int batch, int q_heads);
 int mi_mla_decode_plan_workers(void);
 int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);

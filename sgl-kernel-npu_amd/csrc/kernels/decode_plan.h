@@ -8,21 +8,28 @@ namespace mi_sgl {
 // ---- the planned form ---------------------------------------------------------------------------------------------------------------
 // A launch with per-sequence lengths far apart (a serving batch) runs at the pace of its longest sequence when every sequence is cut
 // into the same number of splits.  The plan cuts each (sequence, kv head) into n_s = ceil(tiles_s / x) pieces, x = the smallest piece
-// size for which all pieces together are no more than the chip runs at once (one workgroup per CU), and orders the pieces longest
-// first.  One workgroup per piece ("item"); the partial of item i lives at slot i of the workspace.
-//   words [0, kPlanHdr)                 n_items (padding included), n_rounds, base[k] for k < kPlanMaxSplits
-//   words [kPlanHdr, + 2 seqs)          per sequence: rank (position by descending cost), n_s
-//   words [.., + 4 items_max)           per item: seq (-1 = padding), first tile, end tile, k | n_s << 8
-// Item index of piece k of the sequence ranked r: base[k] + r.  n_s never increases with the rank, so the sequences with more than
-// k pieces are exactly the ranks below cnt_k; rounds are stored highest k first (the pieces of the longest sequences lead, the short
-// unsplit sequences come last: longest-processing-time-first for the hardware's in-order dispatch) and every base[k] is a multiple of
-// 8: all pieces of a sequence have the same index mod 8, i.e. run on one XCD (dispatch convention), where Q^T and the partials meet in L2.
-constexpr int kPlanHdr = 32, kPlanMaxSplits = 16, kPlanMinTiles = 8, kPlanSortMax = 2048;
-__host__ __device__ inline long long plan_items_max(long long seqs, int workers) { return seqs + workers + 8 * kPlanMaxSplits; }
+// size for which all pieces together are no more than the chip runs at once (one workgroup per CU), and lists the pieces sequence by
+// sequence, longest sequence first.  One workgroup per piece ("item"); the partial of item i lives at slot i of the workspace.
+//   words [0, kPlanHdr)                 n_items, piece size x (tiles)
+//   words [kPlanHdr, + 2 seqs)          per sequence: first item, n_s
+//   words [.., + 4 items_max)           per item: seq (-1 = behind the list), first tile, end tile, k | n_s << 8
+// Item of piece k of sequence s: first[s] + k.  The pieces of a sequence are CONSECUTIVE items: the hardware deals workgroup i to XCD
+// i mod 8, so any run of items spreads evenly over the XCDs, and "all pieces in one round of workgroups" holds per XCD as well.  (The first
+// layout kept the pieces of a sequence on one XCD -- rounds of equal piece index, every round padded to a multiple of 8 -- so that Q^T
+// and the partials of a sequence met in one L2.  It cost more than it gave: a sequence cut into 64 pieces ran on the 32 CUs of ONE XCD
+// (batch 4 x 32k keys, 16 heads: 88 us against 49 for 64 uniform splits); with the pieces walking over the XCDs the piece COUNTS per XCD
+// still differed by up to n_longest - n_shortest, and an XCD with 35 of 256 pieces runs three of them in a second round (batch 64 x
+// U[1, 8192] keys: 152 us against 133 for four uniform splits, although the longest piece was 40 tiles against 64); and the padding --
+// up to 7 items per round, 64 rounds -- put two empty workgroups in front of every real one for batches of a few long sequences.)
+// Longest sequence first: longest-processing-time-first for the hardware's in-order dispatch, for the lists that are not cut at all.
+// (64 pieces at most: a handful of very long sequences must still be able to fill the chip, as the uniform form's cap of 64 splits lets them.)
+constexpr int kPlanHdr = 16, kPlanMaxSplits = 64, kPlanMinTiles = 8, kPlanSortMax = 2048;
+__host__ __device__ inline long long plan_items_max(long long seqs, int workers) { return (seqs + workers + 7) / 8 * 8; }
 __host__ __device__ inline size_t plan_words(long long seqs, int workers)
 {
     return (size_t)kPlanHdr + 2 * (size_t)seqs + 4 * (size_t)plan_items_max(seqs, workers);
 }
+__device__ __forceinline__ int plan_item_index(const int32_t *plan, int seq, int k) { return plan[kPlanHdr + 2ll * seq] + k; }
 struct PlanItem {
     int seq, t_begin, t_end, k, n;
 };
@@ -52,15 +59,15 @@ __device__ __forceinline__ int plan_pieces(int tiles, int x)
     return max(1, min(n, min(kPlanMaxSplits, tiles / kPlanMinTiles)));
 }
 #ifdef PLAN_TIMING
-#define PLAN_T(i) if (threadIdx.x == 0) ((volatile int32_t *)plan)[20 + (i)] = (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFF);
+#define PLAN_T(i) if (threadIdx.x == 0) ((volatile int32_t *)plan)[8 + (i)] = (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFF);
 #else
 #define PLAN_T(i)
 #endif
 static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t *__restrict__ seq_lens, int batch, int kv_heads, int tile, int align,
                                                                   int workers, int32_t *__restrict__ plan)
 {
-    __shared__ int s_tiles[kPlanSortMax], s_rn[kPlanSortMax];      // tiles; rank | n << 16 (kept for the last pass)
-    __shared__ int s_cnt[kPlanMaxSplits], s_base[kPlanMaxSplits], s_cand[16];
+    __shared__ int s_tiles[kPlanSortMax], s_rank[kPlanSortMax], s_first[kPlanSortMax];      // tiles; rank; pieces by rank, then their exclusive sum
+    __shared__ int s_cand[16], s_wsum[16];
     __shared__ long long s_total;
     __shared__ int s_max, s_lo, s_hi;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seqs = batch * kv_heads;
@@ -68,7 +75,6 @@ static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t 
     int32_t *info = plan + kPlanHdr, *items = plan + kPlanHdr + 2ll * seqs;
     PLAN_T(0)
     if (tid == 0) s_total = 0, s_max = 0;
-    if (tid < kPlanMaxSplits) s_cnt[tid] = 0;
     __syncthreads();
     // batches of more sequences than the sort handles, or than the chip has CUs, run unsplit (one piece each: they fill the chip as they are)
     const bool sorted = seqs <= kPlanSortMax;
@@ -82,7 +88,7 @@ static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t 
     }
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64), mx = max(mx, __shfl_xor(mx, o, 64));
     if (lane == 0 && mine) atomicAdd((unsigned long long *)&s_total, (unsigned long long)mine), atomicMax(&s_max, mx);
-    for (long long i = tid; i < items_max; i += blockDim.x) items[4 * i] = -1;      // every slot starts as padding
+    for (long long i = tid; i < items_max; i += blockDim.x) items[4 * i] = -1;      // every slot starts as "behind the list"
     __syncthreads();
     PLAN_T(1)
     int x = max(s_max, 1);                                                           // one piece per sequence
@@ -109,14 +115,26 @@ static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t 
         x = s_hi;
     }
     PLAN_T(2)
-    if (sorted) {
-        // rank of a sequence = how many are longer (ties: lower index first).  Thread (s, part): the workgroup's threads are dealt over the
-        // sequences, `parts` threads per sequence, each comparing a slice of the others; the partial counts meet in LDS.  (One thread per
-        // sequence walking all the others, or one wave per sequence with ballots, took 3.7 us of the kernel's 8-9: serial LDS round trips.)
+    if (!sorted) {
+        // more sequences than the sort takes: the list is the batch in its own order, one piece each
+        for (int s = tid; s < seqs; s += blockDim.x) {
+            const int tiles = (max(seq_lens[s / kv_heads], 0) + tile - 1) / tile;
+            info[2 * s] = s, info[2 * s + 1] = 1;
+            int32_t *it = items + 4ll * s;
+            it[1] = 0, it[2] = tiles, it[3] = 0 | (1 << 8);
+            it[0] = s;
+        }
+        if (tid == 0) plan[0] = seqs, plan[1] = x;
+        return;
+    }
+    // rank of a sequence = how many are longer (ties: lower index first).  Thread (s, part): the workgroup's threads are dealt over the
+    // sequences, `parts` threads per sequence, each comparing a slice of the others; the partial counts meet in LDS.  (One thread per
+    // sequence walking all the others, or one wave per sequence with ballots, took 3.7 us of the kernel's 8-9: serial LDS round trips.)
+    {
         int pad = 1;
         while (pad < seqs) pad <<= 1;
         const int parts = max(1, (int)blockDim.x / pad);          // power of two
-        for (int s = tid; s < seqs; s += blockDim.x) s_rn[s] = 0;
+        for (int s = tid; s < kPlanSortMax; s += blockDim.x) s_rank[s] = 0, s_first[s] = 0;
         __syncthreads();
         for (int i = tid; i < pad * parts; i += blockDim.x) {      // (one pass when the batch has <= 1024 sequences; parts = 1 beyond)
             const int s = i & (pad - 1), part = i / pad;
@@ -124,39 +142,38 @@ static __global__ __launch_bounds__(1024) void decode_plan_kernel(const int32_t 
                 const int t = s_tiles[s], per = (seqs + parts - 1) / parts;
                 int c = 0;
                 for (int o = part * per; o < min(seqs, (part + 1) * per); ++o) c += (s_tiles[o] > t) || (s_tiles[o] == t && o < s);
-                if (c) atomicAdd(&s_rn[s], c);
+                if (c) atomicAdd(&s_rank[s], c);
             }
         }
         __syncthreads();
-        for (int s = tid; s < seqs; s += blockDim.x) {
-            const int rank = s_rn[s], n = split ? plan_pieces(s_tiles[s], x) : 1;
-            info[2 * s] = rank, info[2 * s + 1] = n;
-            s_rn[s] = rank | (n << 16);
-            for (int k = 0; k < n; ++k) atomicAdd(&s_cnt[k], 1);
-        }
-    } else {
-        for (int s = tid; s < seqs; s += blockDim.x) info[2 * s] = s, info[2 * s + 1] = 1;
     }
-    PLAN_T(3)
-    if (!sorted && tid == 0) s_cnt[0] = seqs;
+    // pieces per sequence, filed by rank; their exclusive prefix sum = the first item of the sequence of that rank
+    for (int s = tid; s < seqs; s += blockDim.x) s_first[s_rank[s]] = split ? plan_pieces(s_tiles[s], x) : 1;      // (ranks are a permutation)
     __syncthreads();
-    if (tid == 0) {
-        int rounds = 0, at = 0;
-        for (int k = 0; k < kPlanMaxSplits; ++k) rounds += s_cnt[k] > 0;
-        for (int k = kPlanMaxSplits - 1; k >= 0; --k) {                             // highest k first, every base a multiple of 8
-            s_base[k] = at;
-            at += (s_cnt[k] + 7) & ~7;
+    PLAN_T(3)
+    {
+        // block-wide exclusive scan of s_first[0 .. 2048): two consecutive entries per thread, wave scans, 16 wave totals
+        const int a = s_first[2 * tid], b = s_first[2 * tid + 1];
+        int incl = a + b;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
         }
-        plan[0] = at, plan[1] = rounds;
-        for (int k = 0; k < kPlanMaxSplits; ++k) plan[2 + k] = s_base[k];
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += s_wsum[w];
+        const int excl = off + incl - (a + b);
+        s_first[2 * tid] = excl, s_first[2 * tid + 1] = excl + a;
+        if (tid == 1023) plan[0] = excl + a + b, plan[1] = x;
     }
     __syncthreads();
     for (int s = tid; s < seqs; s += blockDim.x) {
-        const int tiles = sorted ? s_tiles[s] : (max(seq_lens[s / kv_heads], 0) + tile - 1) / tile;      // (no second trip to global memory)
-        const int rank = sorted ? (s_rn[s] & 0xFFFF) : s, n = sorted ? (s_rn[s] >> 16) : 1;
+        const int tiles = s_tiles[s], n = split ? plan_pieces(tiles, x) : 1, first = s_first[s_rank[s]];
+        info[2 * s] = first, info[2 * s + 1] = n;
         const int per = ((tiles + n - 1) / n + align - 1) / align * align;      // (trailing pieces may come out empty: a partial of weight 0)
         for (int k = 0; k < n; ++k) {
-            int32_t *it = items + 4ll * (s_base[k] + rank);
+            int32_t *it = items + 4ll * (first + k);
             it[1] = min(tiles, k * per), it[2] = min(tiles, (k + 1) * per), it[3] = k | (n << 8);
             it[0] = s;
         }

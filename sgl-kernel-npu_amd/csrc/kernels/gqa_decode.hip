@@ -380,13 +380,13 @@ __global__ __launch_bounds__(256) void gqa_merge_kernel(GqaParams p, int dvp)
     if (bh >= (int64_t)p.batch * p.q_heads) return;
     const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
     // partial s of this head: slot (bh, s), or -- planned form -- slot (item of piece s, head within the group)
-    int S = p.num_splits, rank = 0;
+    int S = p.num_splits, first = 0;
     if (p.plan) {
         const int32_t *info = p.plan + mi_sgl::kPlanHdr + 2ll * (b * p.kv_heads + h / p.group);
-        rank = info[0], S = info[1];
+        first = info[0], S = info[1];
         if (S == 1) return;                                   // the piece wrote the output row itself
     }
-    auto slot = [&](int s) -> int64_t { return p.plan ? (int64_t)(p.plan[2 + s] + rank) * p.group + h % p.group : bh * S + s; };
+    auto slot = [&](int s) -> int64_t { return p.plan ? (int64_t)(first + s) * p.group + h % p.group : bh * S + s; };
     float M = -INFINITY;
     for (int s = 0; s < S; ++s) M = fmaxf(M, p.ws_ml[slot(s) * 2]);
     const float sk = p.sinks ? gqa_sink_l2(p, h) : -INFINITY;
@@ -469,7 +469,7 @@ static int gqa_cus()
 }
 constexpr int kGqaMaxWgPerCu = 4;
 // rows of partials a planned workspace holds: (items) x (heads of a group) <= batch * q_heads + (workers + padding) * q_heads
-static size_t gqa_plan_rows_cap(int batch, int q_heads) { return (size_t)batch * q_heads + (size_t)(gqa_cus() * kGqaMaxWgPerCu + 8 * mi_sgl::kPlanMaxSplits) * q_heads; }
+static size_t gqa_plan_rows_cap(int batch, int q_heads) { return (size_t)batch * q_heads + (size_t)(gqa_cus() * kGqaMaxWgPerCu + 8) * q_heads; }
 static size_t gqa_plan_words_cap(int batch, int q_heads) { return mi_sgl::plan_words((long long)batch * q_heads, gqa_cus() * kGqaMaxWgPerCu); }
 static bool gqa_plan_allowed()
 {

@@ -427,33 +427,71 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
         mla_recompute_head<BF16>(p, b, h, lane);
         return;
     }
-    // partial s of this head: slot (bh, s) of the uniform form, or -- planned form -- slot (item of piece s, head within the group)
-    int S = p.num_splits, rank = 0;
+    // partial s of this head: slot (bh, s) of the uniform form, or -- planned form -- slot (first item of the sequence + s, head within the group)
+    int S = p.num_splits, first = 0;
     const int hg = h % p.group;
     if (p.plan) {
         const int32_t *info = p.plan + kPlanHdr + 2ll * (b * p.kv_heads + h / p.group);
-        rank = info[0], S = info[1];
+        first = info[0], S = info[1];
     }
+    S = __builtin_amdgcn_readfirstlane(S);                  // the same for every lane of the wave: one (sequence, head) per wave
     if (S == 1) return;
-    auto slot = [&](int s) -> int64_t { return p.plan ? (int64_t)(p.plan[2 + s] + rank) * p.group + hg : bh * S + s; };
-    float M = -INFINITY;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, p.ws_ml[slot(s) * 2]);
+    auto slot = [&](int s) -> int64_t { return p.plan ? (int64_t)(first + s) * p.group + hg : bh * S + s; };
     float L = 0.f;
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float *ml = p.ws_ml + slot(s) * 2;
-        const float m = ml[0];
-        if (m == -INFINITY) continue;
-        const float w = __builtin_amdgcn_exp2f(m - M);      // m is kept in the scaled log2 domain
-        L += w * ml[1];
-        const float *po = p.ws_o + slot(s) * kDN + lane * 8;
-        const f32x4 a = *(const f32x4 *)po, c = *(const f32x4 *)(po + 4);
+    if (S <= 64) {
+        // One piece per LANE for the bookkeeping: lane s fetches piece s's slot (planned form: one load of base[s]), its maximum and its
+        // sum in parallel; the rows are then added in piece order -- the same products and the same order as the plain loop below, whose
+        // two dependent loads per piece and pass (base[s], then the word behind it) cost ~1 us per piece: a sequence cut into 64 pieces
+        // merged in 140 us, now in 8.
+        const int64_t my = lane < S ? slot(lane) : 0;
+        const float m = lane < S ? p.ws_ml[my * 2] : -INFINITY, l = lane < S ? p.ws_ml[my * 2 + 1] : 0.f;
+        float M = m;
+        for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+        const float w = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - M);      // m is kept in the scaled log2 domain
+        const int my_lo = (int)(my & 0xFFFFFFFFll), my_hi = (int)(my >> 32);
+        for (int s0 = 0; s0 < S; s0 += 4) {
+            f32x4 a[4], c[4];
+            float ws[4], ls[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            o[j] += w * a[j];
-            o[4 + j] += w * c[j];
+            for (int u = 0; u < 4; ++u) {                   // four rows requested together (wave-uniform conditions)
+                const int s = min(s0 + u, S - 1);
+                ws[u] = s0 + u < S ? __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), s)) : 0.f;
+                ls[u] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(l), s));
+                const int64_t sl = ((int64_t)__builtin_amdgcn_readlane(my_hi, s) << 32) | (uint32_t)__builtin_amdgcn_readlane(my_lo, s);
+                const float *po = p.ws_o + sl * kDN + lane * 8;
+                if (ws[u] != 0.f) a[u] = *(const f32x4 *)po, c[u] = *(const f32x4 *)(po + 4);
+                else a[u] = c[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ws[u] == 0.f) continue;                 // an empty piece (m = -inf), or behind the last one
+                L += ws[u] * ls[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] += ws[u] * a[u][j];
+                    o[4 + j] += ws[u] * c[u][j];
+                }
+            }
+        }
+    } else {
+        float M = -INFINITY;
+        for (int s = 0; s < S; ++s) M = fmaxf(M, p.ws_ml[slot(s) * 2]);
+        for (int s = 0; s < S; ++s) {
+            const float *ml = p.ws_ml + slot(s) * 2;
+            const float m = ml[0];
+            if (m == -INFINITY) continue;
+            const float w = __builtin_amdgcn_exp2f(m - M);
+            L += w * ml[1];
+            const float *po = p.ws_o + slot(s) * kDN + lane * 8;
+            const f32x4 a = *(const f32x4 *)po, c = *(const f32x4 *)(po + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] += w * a[j];
+                o[4 + j] += w * c[j];
+            }
         }
     }
     const float inv = L > 0.f ? 1.f / L : 0.f;

@@ -76,15 +76,15 @@ def test_planned_decode_workspace_sizes_are_host_callable():
     B, Hq = 128, 128
     workers = lib.mi_mla_decode_plan_workers()
     assert workers >= 1
-    items = B + workers + 8 * 16
+    items = (B + workers + 7) // 8 * 8
     plan_bytes = lib.mi_mla_decode_plan_bytes(B, 1)
-    assert plan_bytes == (32 + 2 * B + 4 * items) * 4
+    assert plan_bytes == (16 + 2 * B + 4 * items) * 4
     off = lib.mi_mla_decode_plan_offset(B, Hq)
     assert off == items * 128 * 514 * 4 + B * Hq * 4
     # kv_heads is not an argument of the workspace query: the list area is sized for the most (sequence, kv head) pairs, batch * q_heads
-    assert lib.mi_mla_decode_workspace(B, Hq, -1) == off + (32 + 2 * B * Hq + 4 * (B * Hq + workers + 8 * 16)) * 4 >= off + plan_bytes
+    assert lib.mi_mla_decode_workspace(B, Hq, -1) == off + (16 + 2 * B * Hq + 4 * ((B * Hq + workers + 7) // 8 * 8)) * 4 >= off + plan_bytes
     # a 16-head shard: rows = batch * q_heads + (workers + padding) items of 16 heads
-    assert lib.mi_mla_decode_plan_offset(B, 16) == (B * 16 + (workers + 8 * 16) * 16) * 514 * 4 + B * 16 * 4
+    assert lib.mi_mla_decode_plan_offset(B, 16) == (B * 16 + ((workers + 7) // 8 * 8) * 16) * 514 * 4 + B * 16 * 4
     assert lib.mi_mla_decode_workspace(B, Hq, 2) == B * Hq * 2 * 514 * 4 + B * Hq * 4          # the uniform form is unchanged
     assert lib.mi_mla_decode_workspace(0, Hq, -1) == 0 and lib.mi_mla_decode_plan_bytes(0, 1) == 0
     assert lib.mi_gqa_decode_workspace(64, 64, 128, -1) > lib.mi_gqa_decode_workspace(64, 64, 128, 4) > 0

@@ -192,13 +192,14 @@ def test_growing_scores_take_the_rescaling_path(dtype, splits, wide_variant):
     assert torch.allclose(got.float(), want.float(), rtol=2e-2, atol=2e-2), (got.float() - want.float()).abs().max()
 
 
-def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=16, sort_max=2048, align=2):
+def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=64, sort_max=2048, align=2):
     """The work list of the planned form restated on the host (sgl-kernel-npu_amd/csrc/kernels/decode_plan.h, decode_plan_kernel): piece size
-    x = the smallest for which all pieces fit one round of workgroups; -> (n_items, base[k], rank[s], n[s], items {index: (pair, first
-    tile, end tile, k, n)})."""
+    x = the smallest for which all pieces fit one round of workgroups; the pieces of a (sequence, kv head) pair are consecutive items, pairs
+    in order of descending length (ties: lower index first).  -> (n_items, x, first[s], n[s], items {index: (pair, first tile, end tile, k, n)})."""
     seqs = len(lens) * kv_heads
     tiles = [(max(int(lens[s // kv_heads]), 0) + tile - 1) // tile for s in range(seqs)]
     pieces = lambda t, x: max(1, min((t + x - 1) // x, max_splits, t // min_tiles))
+    x = max(max(tiles), 1)
     if seqs <= sort_max and seqs < workers:
         x = next(x for x in range(max(1, (sum(tiles) + workers - 1) // workers), max(max(tiles), 1) + 1)
                  if sum(pieces(t, x) for t in tiles) <= workers)
@@ -206,27 +207,25 @@ def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=16,
     else:
         n = [1] * seqs
     order = sorted(range(seqs), key=lambda s: (-tiles[s], s)) if seqs <= sort_max else list(range(seqs))
-    rank = [0] * seqs
-    for r, s in enumerate(order):
-        rank[s] = r
-    cnt = [sum(1 for s in range(seqs) if n[s] > k) for k in range(max_splits)]
-    base, at = [0] * max_splits, 0
-    for k in range(max_splits - 1, -1, -1):
-        base[k] = at
-        at += (cnt[k] + 7) & ~7
+    first, at = [0] * seqs, 0
+    for s in order:
+        first[s] = at
+        at += n[s]
     items = {}
     for s in range(seqs):
         per = ((tiles[s] + n[s] - 1) // n[s] + align - 1) // align * align      # pieces start on even tiles: the list also serves 64-key tiles
         for k in range(n[s]):
-            items[base[k] + rank[s]] = (s, min(tiles[s], k * per), min(tiles[s], (k + 1) * per), k, n[s])
-    return at, base, rank, n, items
+            items[first[s] + k] = (s, min(tiles[s], k * per), min(tiles[s], (k + 1) * per), k, n[s])
+    return at, x, first, n, items
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,S,page,kind", [(128, 128, 1, 4096, 64, "uniform"), (128, 128, 1, 4096, 64, "ragged"), (37, 128, 1, 3000, 16, "ragged"),
                                                    (5, 256, 2, 9000, 64, "ragged"), (300, 128, 1, 700, 64, "ragged"), (16, 128, 1, 20000, 128, "one_long"),
                                                    # groups of <= 64 heads (TP shards): the 64-head kernel reads the same list, any page size
                                                    (128, 16, 1, 4096, 64, "ragged"), (9, 64, 4, 3000, 16, "ragged"), (40, 32, 1, 5000, 48, "ragged"),
-                                                   (16, 8, 1, 20000, 128, "one_long"), (3, 128, 8, 4500, 64, "ragged")])
+                                                   (16, 8, 1, 20000, 128, "one_long"), (3, 128, 8, 4500, 64, "ragged"),
+                                                   # a handful of very long sequences: up to 64 pieces each, so that they still fill the chip
+                                                   (4, 128, 1, 33000, 64, "uniform"), (2, 16, 1, 50000, 64, "ragged")])
 def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_splits(B, Hq, Hkv, S, page, kind):
     """The device-built work list (length-aware split counts, longest pieces first, the pieces of a sequence on one XCD) against its host
     restatement, word for word; structural properties (every tile of every sequence covered exactly once; padding only); and the
@@ -260,28 +259,36 @@ def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_spl
         off = L.mi_mla_decode_plan_offset(B, Hq)
         seqs = B * Hkv
         words = keep[0][off:].view(torch.int32).cpu().numpy()
-        n_items, base, rank, n, items = plan_reference(lens.cpu().tolist(), Hkv, workers)
-        assert words[0] == n_items and n_items % 8 == 0 and n_items <= seqs + workers + 8 * 16
+        n_items, x, first, n, items = plan_reference(lens.cpu().tolist(), Hkv, workers)
+        items_max = (seqs + workers + 7) // 8 * 8
+        assert words[0] == n_items == sum(n) and n_items <= items_max and words[1] == x
         if seqs < workers:
-            assert sum(n) <= workers, "every piece runs in the first round of workgroups"
-        assert list(words[2:18]) == base
-        info = words[32:32 + 2 * seqs].reshape(seqs, 2)
-        assert list(info[:, 0]) == rank and list(info[:, 1]) == n
-        it = words[32 + 2 * seqs:32 + 2 * seqs + 4 * n_items].reshape(n_items, 4)
+            assert n_items <= workers, "every piece runs in the first round of workgroups"
+            # ... on every XCD too: workgroup i runs on XCD i mod 8, and the items are the indices 0 .. n_items - 1
+            assert max(sum(1 for i in items if i % 8 == xcd) for xcd in range(8)) <= (workers + 7) // 8
+        info = words[16:16 + 2 * seqs].reshape(seqs, 2)
+        assert list(info[:, 0]) == first and list(info[:, 1]) == n
+        it = words[16 + 2 * seqs:16 + 2 * seqs + 4 * items_max].reshape(items_max, 4)
         covered = {}
-        for i in range(n_items):
+        for i in range(items_max):
             if i in items:
                 s, t0, t1, k, ns = items[i]
                 assert tuple(it[i]) == (s, t0, t1, k | (ns << 8)), (i, tuple(it[i]), items[i])
-                covered.setdefault(s, []).append((t0, t1, i % 8))
+                covered.setdefault(s, []).append((t0, t1, i, k))
             else:
                 assert it[i][0] == -1, (i, tuple(it[i]))
+        tiles_of = lambda s: (max(int(lens[s // Hkv]), 0) + 31) // 32
         for s in range(seqs):
-            pieces = sorted(covered[s])
-            tiles = (max(int(lens[s // Hkv]), 0) + 31) // 32
+            pieces = sorted(covered[s], key=lambda p_: p_[3])
+            tiles = tiles_of(s)
             assert pieces[0][0] == 0 and pieces[-1][1] == tiles and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
             assert all(a[0] % 2 == 0 or a[0] == a[1] == tiles for a in pieces), "pieces start on 64-key boundaries (empty trailing ones: at the end)"
-            assert len({x[2] for x in pieces}) == 1, "the pieces of a sequence share blockIdx % 8"
+            assert [p_[2] for p_ in pieces] == list(range(first[s], first[s] + n[s])), "the pieces of a sequence are consecutive items"
+        if seqs <= 2048:
+            by_first = sorted(range(seqs), key=lambda s: first[s])
+            assert all(tiles_of(a) >= tiles_of(b) for a, b in zip(by_first, by_first[1:])), "longest sequence first"
+        if B * Hkv <= 4 and kind == "uniform":
+            assert sum(n) > workers // 2 and max(n) > 16, "few long sequences are cut into enough pieces to fill the chip"
         if kind == "one_long":
             assert n[3 * Hkv] > 4          # the one long sequence is cut into many pieces, the short ones stay whole
     finally:

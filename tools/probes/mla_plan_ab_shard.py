@@ -6,7 +6,7 @@ import torch
 import sgl_kernel_npu  # noqa: F401
 from sgl_kernel_npu.bench_hooks import _mla_inputs
 
-B, Hq, S, page = int(os.environ.get("AB_B", 128)), int(os.environ.get("AB_HQ", 16)), 4096, 64
+B, Hq, S, page = int(os.environ.get("AB_B", 128)), int(os.environ.get("AB_HQ", 16)), int(os.environ.get("AB_S", 4096)), 64
 q, kn, kr, bt, lens = _mla_inputs(B, Hq, S, page)
 _, _, _, _, rlens = _mla_inputs(B, Hq, S, page, ragged=True)
 g = torch.Generator(device="cuda").manual_seed(3)
@@ -34,5 +34,5 @@ def t(ls, n, reps=50):
 for name, ls in (("full", lens), ("ragged", rlens), ("skewed", skew)):
     byts = float(ls.sum().item()) * 1152 + B * Hq * 2176
     for rnd in range(2):
-        row = {n: t(ls, n) for n in (0, 1, 2, 3, 4)}
+        row = {n: t(ls, n) for n in (0, 1, 2, 4, 16, 64)}
         print(name, "round", rnd, " ".join(f"{'planned' if n == 0 else f'{n} splits'}: {us:.1f} us ({byts / us / 8e6:.3f})" for n, us in row.items()), flush=True)

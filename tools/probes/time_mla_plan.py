@@ -14,5 +14,5 @@ for ragged in (False, True):
     for _ in range(20):
         assert L.mi_mla_decode_build_plan(ptr(lens), 128, 1, ptr(plan), ctypes.c_size_t(nb), stream_ptr()) == 0
     torch.cuda.synchronize()
-    t = plan[20:25].cpu().tolist()
+    t = plan[8:13].cpu().tolist()
     print("ragged" if ragged else "uniform", "us between stamps [entry->totals, ->piece size, ->ranks, ->bases, ->end]:", [round((b - a) / 100.0, 2) for a, b in zip(t, t[1:])], "total", (t[4] - t[0]) / 100.0)
