@@ -59,7 +59,7 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
     TORCH_CHECK(Hq % Hkv == 0 && k_rope_buffer.size(2) == Hkv, "decode_mla: head counts");
     const int max_len = (int)std::min<int64_t>(block_table.size(1) * page_size, INT32_MAX);   // upper bound, no host sync
     int splits = (int)num_splits;
-    if (splits <= 0) splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
+    if (splits == 0) splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
     const size_t wsb = mi_mla_decode_workspace(B, Hq, splits);
     at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(q.device()));
     const int rc = mi_mla_decode(q.data_ptr(), k_nope_buffer.data_ptr(), k_rope_buffer.data_ptr(), att_out.data_ptr(),
@@ -143,7 +143,7 @@ void decode_gqa(const at::Tensor &q, const at::Tensor &k_buffer, const at::Tenso
                                v_buffer.stride(0) == k_buffer.stride(0) && v_buffer.stride(1) == k_buffer.stride(1) &&
                                v_buffer.stride(2) == k_buffer.stride(2);
     if (v_is_k_prefix) {
-        if (splits <= 0) splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
+        if (splits == 0) splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
         const size_t wsb = mi_mla_decode_workspace(B, Hq, splits);
         at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(q.device()));
         const char *kb = (const char *)k_buffer.data_ptr();
@@ -155,7 +155,7 @@ void decode_gqa(const at::Tensor &q, const at::Tensor &k_buffer, const at::Tenso
         TORCH_CHECK(rc == 0, "mi_mla_decode failed with code ", rc);
         return;
     }
-    if (splits <= 0) splits = mi_gqa_decode_num_splits(B, Hq, Hkv, max_len);
+    if (splits == 0) splits = mi_gqa_decode_num_splits(B, Hq, Hkv, max_len);
     const size_t wsb = mi_gqa_decode_workspace(B, Hq, Lv, splits);
     at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(q.device()));
     const int rc = mi_gqa_decode(q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), att_out.data_ptr(), kv_seq_lens.data_ptr<int>(),

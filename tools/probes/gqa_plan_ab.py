@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "sgl-kernel-npu_amd", "python"))
 import torch
 import sgl_kernel_npu  # noqa: F401
 page, D = 64, 128
-for B, Hq, Hkv, S in ((16, 64, 8, 8192), (64, 64, 8, 4096), (256, 64, 8, 4096)):
+for B, Hq, Hkv, S in ((4, 64, 8, 32768), (16, 64, 8, 8192), (64, 64, 8, 4096), (256, 64, 8, 4096)):
     g = torch.Generator(device="cuda").manual_seed(1)
     maxp = S // page
     nb = B * maxp
@@ -31,6 +31,6 @@ for B, Hq, Hkv, S in ((16, 64, 8, 8192), (64, 64, 8, 4096), (256, 64, 8, 4096)):
 
     for name, ls in (("full", full), ("ragged", rag)):
         byts = float(ls.sum().item()) * Hkv * D * 2 * 2
-        row = {n: t(ls, n) for n in (-1, 1, 2, 4)}
-        print(f"B={B} {name}:", " ".join(f"{'planned' if n < 0 else f'{n} splits'} {us:.1f} us ({byts / us / 1e6:.2f} TB/s)" for n, us in row.items()), flush=True)
+        row = {n: t(ls, n) for n in (-1, 0, 1, 2, 4, 8)}
+        print(f"B={B} {name}:", " ".join(f"{'planned' if n < 0 else ('library' if n == 0 else f'{n} splits')} {us:.1f} us ({byts / us / 1e6:.2f} TB/s)" for n, us in row.items()), flush=True)
     del q, k, v, bt, out
