@@ -225,7 +225,9 @@ def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=64,
                                                    (128, 16, 1, 4096, 64, "ragged"), (9, 64, 4, 3000, 16, "ragged"), (40, 32, 1, 5000, 48, "ragged"),
                                                    (16, 8, 1, 20000, 128, "one_long"), (3, 128, 8, 4500, 64, "ragged"),
                                                    # a handful of very long sequences: up to 64 pieces each, so that they still fill the chip
-                                                   (4, 128, 1, 33000, 64, "uniform"), (2, 16, 1, 50000, 64, "ragged")])
+                                                   (4, 128, 1, 33000, 64, "uniform"), (2, 16, 1, 50000, 64, "ragged"),
+                                                   # more sequences than the list sorts (2048): batch order, one piece each
+                                                   (2100, 16, 1, 130, 16, "ragged"), (1100, 128, 2, 100, 32, "ragged")])
 def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_splits(B, Hq, Hkv, S, page, kind):
     """The device-built work list (length-aware split counts, longest pieces first, the pieces of a sequence on one XCD) against its host
     restatement, word for word; structural properties (every tile of every sequence covered exactly once; padding only); and the
