@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
         if (it.seq < 0) return;                                  // padding of a round
         split = it.k, nsplits = it.n, kvh = it.seq % p.kv_heads, b = it.seq / p.kv_heads, t_begin = it.t_begin, t_end = it.t_end;
         seq_len = p.seq_lens[b];
+        const int ntiles = (seq_len + TILE - 1) / TILE;          // clamped to the sequence as it is now; the last piece runs to its end
+        t_begin = min(t_begin, ntiles);
+        t_end = split == nsplits - 1 ? ntiles : min(t_end, ntiles);
     } else {
         if (unit >= p.batch * p.kv_heads * p.num_splits) return;
         split = unit % p.num_splits, nsplits = p.num_splits;

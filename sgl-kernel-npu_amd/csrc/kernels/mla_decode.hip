@@ -206,6 +206,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) __attribute__((amdgpu_waves_per_eu(
         b = unit / (p.num_splits * p.kv_heads);
     }
     const int seq_len = p.seq_lens[b];
+    if (p.plan) {      // pieces clamped to the tiles the sequence has NOW, the last one running to their end (a stale list costs balance only)
+        const int ntiles = (seq_len + kTile - 1) / kTile;
+        t_begin = min(t_begin, ntiles);
+        t_end = split == nsp - 1 ? ntiles : min(t_end, ntiles);
+    }
     if (!p.plan) {
         const int ntiles = (seq_len + kTile - 1) / kTile;
         const int tps = (ntiles + p.num_splits - 1) / p.num_splits;

@@ -189,6 +189,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int kvh = seq % p.kv_heads;
     const int b = seq / p.kv_heads;
     const int seq_len = p.seq_lens[b];
+    if constexpr (PLAN) {
+        // the list only decides WHO reads which tiles: the pieces are clamped to the sequence's tiles as they are NOW and the last piece
+        // runs to their end, so a list built from older lengths (a step ago, or another batch in the same buffer) costs balance, never
+        // correctness
+        const int ntiles = (seq_len + k8T - 1) / k8T;
+        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x);
+        t_begin = min(t_begin, ntiles);
+        t_end = it.k == it.n - 1 ? ntiles : min(t_end, ntiles);
+    }
     if constexpr (!PLAN) {
         const int split = ((blockIdx.x >> 3) / head_blocks) % p.num_splits;
         const int ntiles = (seq_len + k8T - 1) / k8T;

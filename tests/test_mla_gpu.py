@@ -321,3 +321,13 @@ def test_plan_once_run_many_equals_the_per_call_plan():
             decode_mla(q, kn, kr, got, lens, 576 ** -0.5, page, bt, plan=plan)
             torch.cuda.synchronize()
             assert torch.equal(got, want)
+        # a STALE list (built from other lengths: the previous step's, or another batch that lived in the same buffer) costs balance, never
+        # correctness: the pieces are clamped to the tiles every sequence has now and the last piece runs to their end
+        for other in (torch.clamp(lens - 37, min=0), torch.clamp(lens + 150, max=S), torch.randint(0, S + 1, (B,), generator=g, device="cuda").to(torch.int32)):
+            want2 = torch.empty_like(want)
+            decode_mla(q, kn, kr, want2, other, 576 ** -0.5, page, bt)
+            got2 = torch.empty_like(want)
+            decode_mla(q, kn, kr, got2, other, 576 ** -0.5, page, bt, plan=plan)
+            torch.cuda.synchronize()
+            nz = other.cpu() > 0
+            assert torch.allclose(got2.float()[nz], want2.float()[nz], rtol=2 ** -7, atol=2e-3), (got2.float()[nz] - want2.float()[nz]).abs().max()
