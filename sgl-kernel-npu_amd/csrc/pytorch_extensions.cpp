@@ -36,6 +36,39 @@ static int dtype_code3(const at::Tensor &t)        // the row statistics / scali
 
 std::string sgl_kernel_npu_version() { return std::string("sgl-kernel-npu_amd 0.1 (") + mi_sgl_kernels_version() + ")"; }
 
+at::Tensor decode_mla_plan(const at::Tensor &kv_seq_lens, int64_t num_kv_heads);
+void decode_mla_planned(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::Tensor &k_rope_buffer, at::Tensor &att_out,
+                        const at::Tensor &kv_seq_lens, double sm_scale, int64_t page_size, const at::Tensor &block_table, const at::Tensor &plan);
+
+// The attention layers of a decode step call decode_mla with the SAME kv_seq_lens tensor: the work list of the planned form is built by
+// the first of them and reused by the others (the reference signature has no plan argument, so a drop-in caller gets "plan once, run
+// many" this way).  One entry per device: the kv_seq_lens tensor itself (held, so its storage cannot be recycled under the entry), its
+// version counter (an in-place write through torch rebuilds the list), kv head count and stream.  Writes that bypass the version counter
+// (a raw-pointer kernel) leave a stale list in place -- which the kernels tolerate by construction (pieces are clamped to the current
+// lengths, the last piece runs to their end): stale costs balance, never correctness.  Inference tensors carry no version counter and are
+// not cached.  MI_MLA_PLAN_CACHE=0 turns the reuse off; num_splits = -1 asks for the planned form with a list of its own.
+struct MlaPlanCacheEntry {
+    at::Tensor lens, plan;
+    uint32_t version = 0;
+    int64_t kv_heads = 0;
+    void *stream = nullptr;
+};
+static at::Tensor cached_mla_plan(const at::Tensor &kv_seq_lens, int64_t kv_heads)
+{
+    static std::mutex mu;
+    static auto &entries = *new std::map<int, MlaPlanCacheEntry>();      // (never destroyed: tensors must not outlive the HIP context at exit)
+    void *st = cur_stream();
+    const uint32_t ver = kv_seq_lens._version();
+    std::lock_guard<std::mutex> lk(mu);
+    MlaPlanCacheEntry &e = entries[kv_seq_lens.device().index()];
+    if (e.lens.defined() && e.lens.data_ptr() == kv_seq_lens.data_ptr() && e.lens.numel() == kv_seq_lens.numel() && e.version == ver &&
+        e.kv_heads == kv_heads && e.stream == st)
+        return e.plan;
+    e.plan = decode_mla_plan(kv_seq_lens, kv_heads);
+    e.lens = kv_seq_lens, e.version = ver, e.kv_heads = kv_heads, e.stream = st;
+    return e.plan;
+}
+
 // Paged MLA decode, same argument meaning as the reference Python entry point decode_mla
 // (python/sgl_kernel_npu/sgl_kernel_npu/attention/decode_attention.py:166-175); writes att_out in place.
 void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::Tensor &k_rope_buffer, at::Tensor &att_out,
@@ -59,7 +92,14 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
     TORCH_CHECK(Hq % Hkv == 0 && k_rope_buffer.size(2) == Hkv, "decode_mla: head counts");
     const int max_len = (int)std::min<int64_t>(block_table.size(1) * page_size, INT32_MAX);   // upper bound, no host sync
     int splits = (int)num_splits;
-    if (splits == 0) splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
+    if (splits == 0) {
+        splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
+        static const bool reuse = !(getenv("MI_MLA_PLAN_CACHE") && atoi(getenv("MI_MLA_PLAN_CACHE")) == 0);
+        if (splits == MI_MLA_SPLITS_PLANNED && reuse && B > 0 && !kv_seq_lens.is_inference()) {
+            decode_mla_planned(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, sm_scale, page_size, block_table, cached_mla_plan(kv_seq_lens, Hkv));
+            return;
+        }
+    }
     const size_t wsb = mi_mla_decode_workspace(B, Hq, splits);
     at::Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 16)}, at::dtype(at::kByte).device(q.device()));
     const int rc = mi_mla_decode(q.data_ptr(), k_nope_buffer.data_ptr(), k_rope_buffer.data_ptr(), att_out.data_ptr(),
@@ -111,7 +151,8 @@ void decode_mla_planned(const at::Tensor &q, const at::Tensor &k_nope_buffer, co
         if (rc == 0) return;
         TORCH_CHECK(rc == MI_SGL_ENOTAPPLICABLE, "mi_mla_decode_with_plan failed with code ", rc);
     }
-    decode_mla(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, sm_scale, page_size, block_table, 0);      // all checks live there
+    // all checks live there; -1: the planned form with a list of its own where it applies, uniform splits where it does not (never back here)
+    decode_mla(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens, sm_scale, page_size, block_table, MI_MLA_SPLITS_PLANNED);
 }
 
 // Paged GQA decode with a separate V cache; argument meaning of decode_gqa (decode_attention.py:378-387); writes att_out in place.

@@ -33,9 +33,14 @@ def bench_mla_decode(steps=30, warmup=5):
         decode_mla(q, kn, kr, out, lens, sm, page, bt)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # The timed calls are the attention layers of decode steps of 61 layers (DeepSeek-V3): the layers of a step pass the same kv_seq_lens
+    # tensor and share one work list (built by the step's first layer, csrc/pytorch_extensions.cpp: cached_mla_plan); a new step -- an
+    # in-place write to kv_seq_lens, here at the first timed call and every 61 calls -- rebuilds it INSIDE the timed region.
     t0 = time.perf_counter()
-    for a, b in evs:
+    for i, (a, b) in enumerate(evs):
         a.record()
+        if i % 61 == 0:
+            lens.add_(0)
         decode_mla(q, kn, kr, out, lens, sm, page, bt)
         b.record()
     torch.cuda.synchronize()
@@ -46,13 +51,15 @@ def bench_mla_decode(steps=30, warmup=5):
     # batch with the uniform two splits of round 3 (the longest sequence sets the pace of its workgroups) is timed beside it.
     _, _, _, _, rlens = _mla_inputs(B, Hq, S, page, ragged=True)
 
-    def timed(ls, num_splits=0):          # 0 = the library's choice (the Python entry point's), n = uniform splits (torch op argument)
+    def timed(ls, num_splits=0):          # 0 = the library's choice (the Python entry point's), -1 = a list per call, n = uniform splits
         call = lambda: torch.ops.npu.decode_mla(q, kn, kr, out, ls, float(sm), int(page), bt, num_splits)
         for _ in range(max(warmup // 4, 5)):
             call()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(steps):
+        for i in range(steps):
+            if i % 61 == 0:
+                ls.add_(0)                # a new decode step: the shared list is rebuilt inside the timed region
             call()
         b.record()
         torch.cuda.synchronize()
@@ -73,6 +80,8 @@ def bench_mla_decode(steps=30, warmup=5):
         return a.elapsed_time(b) / steps
 
     r_ms = timed(rlens)
+    ms_per_call_plan = timed(lens, num_splits=-1)           # every call builds its own list (no sharing between layers)
+    r_ms_per_call_plan = timed(rlens, num_splits=-1)
     r_ms_shared = timed_shared_plan(rlens)
     ms_shared = timed_shared_plan(lens)
     r_ms_uniform = timed(rlens, num_splits=2)
@@ -88,7 +97,9 @@ def bench_mla_decode(steps=30, warmup=5):
             call()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(steps):
+        for i in range(steps):
+            if i % 61 == 0:
+                ls.add_(0)
             call()
         b.record()
         torch.cuda.synchronize()
@@ -113,9 +124,12 @@ def bench_mla_decode(steps=30, warmup=5):
                      "algorithmic_bytes": kv_bytes + io_bytes, "avg_launch_us": dev_ms * 1e3},
         "ragged": {"workload": "same batch, kv_seq_lens ~ U[1, 4096]", "ms_per_step": r_ms, "mean_seq_len": float(rlens.float().mean().item()),
                    "achieved_GBps": r_bytes / (r_ms * 1e-3) / 1e9, "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "per_call_plan_ms_per_step": r_ms_per_call_plan,
                    "shared_plan_ms_per_step": r_ms_shared, "shared_plan_frac": r_bytes / (r_ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                    "uniform_2_splits_ms_per_step": r_ms_uniform, "uniform_2_splits_frac": r_bytes / (r_ms_uniform * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         # the same batch with the work list built ONCE outside the loop (decode_mla_plan; the layers of a decode step share it) and passed in
+        "per_call_plan_ms_per_step": ms_per_call_plan,      # num_splits = -1: no sharing between the layers of a step
+        "plan_sharing": "the layers of a decode step (61 calls on one kv_seq_lens tensor) share one work list, rebuilt inside the timed region at every step",
         "shared_plan_ms_per_step": ms_shared, "shared_plan_frac": (kv_bytes + io_bytes) / (ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "tp8_shard": shard,
         "uniform_2_splits_ms_per_step": ms_uniform,     # the full-length batch through num_splits = 2 (round 3's form), queued back to back

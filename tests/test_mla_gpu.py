@@ -321,6 +321,18 @@ def test_plan_once_run_many_equals_the_per_call_plan():
             decode_mla(q, kn, kr, got, lens, 576 ** -0.5, page, bt, plan=plan)
             torch.cuda.synchronize()
             assert torch.equal(got, want)
+        # the default call shares the list between calls on the SAME kv_seq_lens tensor (the layers of a step); an in-place write to the
+        # tensor (a new step) rebuilds it: always the bits of a call that builds its own list (num_splits = -1)
+        for step in range(3):
+            if step:
+                lens.copy_(torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32))
+            own = torch.empty_like(want)
+            torch.ops.npu.decode_mla(q, kn, kr, own, lens, 576 ** -0.5, page, bt, -1)
+            for _ in range(3):
+                got = torch.empty_like(want)
+                decode_mla(q, kn, kr, got, lens, 576 ** -0.5, page, bt)
+                torch.cuda.synchronize()
+                assert torch.equal(got, own), step
         # a STALE list (built from other lengths: the previous step's, or another batch that lived in the same buffer) costs balance, never
         # correctness: the pieces are clamped to the tiles every sequence has now and the last piece runs to their end
         for other in (torch.clamp(lens - 37, min=0), torch.clamp(lens + 150, max=S), torch.randint(0, S + 1, (B,), generator=g, device="cuda").to(torch.int32)):
