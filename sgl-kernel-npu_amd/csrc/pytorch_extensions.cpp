@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 
+#include <hip/hip_runtime_api.h>
 #include <ATen/ATen.h>
 #include <c10/util/string_view.h>
 #include <c10/core/DeviceGuard.h>
@@ -52,6 +53,7 @@ struct MlaPlanCacheEntry {
     uint32_t version = 0;
     int64_t kv_heads = 0;
     void *stream = nullptr;
+    unsigned long long capture = 0;      // id of the stream capture the list was built in (0: built eagerly)
 };
 static at::Tensor cached_mla_plan(const at::Tensor &kv_seq_lens, int64_t kv_heads)
 {
@@ -59,13 +61,18 @@ static at::Tensor cached_mla_plan(const at::Tensor &kv_seq_lens, int64_t kv_head
     static auto &entries = *new std::map<int, MlaPlanCacheEntry>();      // (never destroyed: tensors must not outlive the HIP context at exit)
     void *st = cur_stream();
     const uint32_t ver = kv_seq_lens._version();
+    // a list built while a graph is being captured has no contents until the graph runs: it serves the calls of the SAME capture only (the
+    // layers of the captured step), never an eager call or another capture
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    unsigned long long cap = 0;
+    if (hipStreamGetCaptureInfo((hipStream_t)st, &cap_status, &cap) != hipSuccess || cap_status != hipStreamCaptureStatusActive) cap = 0;
     std::lock_guard<std::mutex> lk(mu);
     MlaPlanCacheEntry &e = entries[kv_seq_lens.device().index()];
     if (e.lens.defined() && e.lens.data_ptr() == kv_seq_lens.data_ptr() && e.lens.numel() == kv_seq_lens.numel() && e.version == ver &&
-        e.kv_heads == kv_heads && e.stream == st)
+        e.kv_heads == kv_heads && e.stream == st && e.capture == cap)
         return e.plan;
     e.plan = decode_mla_plan(kv_seq_lens, kv_heads);
-    e.lens = kv_seq_lens, e.version = ver, e.kv_heads = kv_heads, e.stream = st;
+    e.lens = kv_seq_lens, e.version = ver, e.kv_heads = kv_heads, e.stream = st, e.capture = cap;
     return e.plan;
 }
 

@@ -343,3 +343,50 @@ def test_plan_once_run_many_equals_the_per_call_plan():
             torch.cuda.synchronize()
             nz = other.cpu() > 0
             assert torch.allclose(got2.float()[nz], want2.float()[nz], rtol=2 ** -7, atol=2e-3), (got2.float()[nz] - want2.float()[nz]).abs().max()
+
+
+def test_decode_mla_in_a_captured_graph_shares_the_list_inside_the_capture_only():
+    """Three decode_mla calls (layers of a step) captured in one HIP graph: the first builds the work list inside the graph, the others reuse
+    it; every replay follows the CURRENT contents of kv_seq_lens (written in place between replays), and an eager call between capture
+    and first replay does not pick up the captured (still empty) list."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sgl-kernel-npu_amd", "python"))
+    from sgl_kernel_npu.attention.decode_attention import decode_mla
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, Hq, S, page = 24, 128, 2500, 64
+    maxp = (S + page - 1) // page
+    nb = B * maxp
+    q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(torch.bfloat16)
+    kn = (torch.randn((nb, page, 1, 512), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    kr = (torch.randn((nb, page, 1, 64), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+    lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+    outs = [torch.empty((B, Hq, 512), dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for o in outs:                                   # warm-up outside the capture (allocations, kernel attributes)
+            decode_mla(q, kn, kr, o, lens, 576 ** -0.5, page, bt)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for o in outs:
+            decode_mla(q, kn, kr, o, lens, 576 ** -0.5, page, bt)
+    # eager call before the first replay: its own list, not the captured one
+    eager = torch.empty_like(outs[0])
+    decode_mla(q, kn, kr, eager, lens, 576 ** -0.5, page, bt)
+    own = torch.empty_like(outs[0])
+    torch.ops.npu.decode_mla(q, kn, kr, own, lens, 576 ** -0.5, page, bt, -1)
+    torch.cuda.synchronize()
+    assert torch.equal(eager, own)
+    for step in range(3):
+        if step:
+            lens.copy_(torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32))
+        for o in outs:
+            o.fill_(7.0)
+        graph.replay()
+        torch.ops.npu.decode_mla(q, kn, kr, own, lens, 576 ** -0.5, page, bt, -1)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, own), step
