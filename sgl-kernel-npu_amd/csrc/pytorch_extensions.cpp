@@ -190,6 +190,11 @@ void decode_gqa(const at::Tensor &q, const at::Tensor &k_buffer, const at::Tenso
     const bool v_is_k_prefix = Lk == 576 && Lv == 512 && v_buffer.data_ptr() == k_buffer.data_ptr() &&
                                v_buffer.stride(0) == k_buffer.stride(0) && v_buffer.stride(1) == k_buffer.stride(1) &&
                                v_buffer.stride(2) == k_buffer.stride(2);
+    if (v_is_k_prefix && splits == 0 && k_buffer.size(1) == page_size) {
+        // the library's choice: exactly decode_mla on the two column ranges of the K rows (the layers of a step then share its work list too)
+        decode_mla(q, k_buffer.narrow(3, 0, 512), k_buffer.narrow(3, 512, 64), att_out, kv_seq_lens, sm_scale, page_size, block_table, 0);
+        return;
+    }
     if (v_is_k_prefix) {
         if (splits == 0) splits = mi_mla_decode_num_splits(B, Hq, Hkv, max_len);
         const size_t wsb = mi_mla_decode_workspace(B, Hq, splits);
