@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gqa_decode_kernel(GqaParams p)
     if (p.plan) {
         if (unit >= p.plan[0]) return;                           // (the grid is rounded up to rows of 8 workgroups)
         const mi_sgl::PlanItem it = mi_sgl::plan_item(p.plan, (long long)p.batch * p.kv_heads, unit);
-        if (it.seq < 0) return;                                  // padding of a round
+        if (it.seq < 0) return;                                  // behind the list
         split = it.k, nsplits = it.n, kvh = it.seq % p.kv_heads, b = it.seq / p.kv_heads, t_begin = it.t_begin, t_end = it.t_end;
         seq_len = p.seq_lens[b];
         const int ntiles = (seq_len + TILE - 1) / TILE;          // clamped to the sequence as it is now; the last piece runs to its end

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int c32 = lane & 31, kg = lane >> 5;                 // P.V role: head c32 of a 32-head block, key half kg
     const int head_blocks = (p.group + 127) / 128;
     // workgroups b % 8 run on XCD b % 8: the num_splits workgroups of a (sequence, kv head) share an XCD (their partials meet in its L2)
-    // PLAN (template): workgroup = item of the device-built work list (mla_common.h); the pieces of a sequence share blockIdx % 8 (an
-    // XCD).  A template parameter, not a run-time branch, and power-of-two page sizes only: the kernel sits at the edge of the register
+    // PLAN (template): workgroup = item of the device-built work list (decode_plan.h; the pieces of a sequence are consecutive items).
+    // A template parameter, not a run-time branch, and power-of-two page sizes only: the kernel sits at the edge of the register
     // file.  The uniform form re-derives its tile range from kernel arguments; this one LOADS it, so those scalars stay live across the
     // tile loop -- together with the scalars of the any-page-size division path they no longer fit, the overflow goes to a vector register
     // and four Q^T fragments to scratch (a scratch reload waits vmcnt(0), i.e. for every DMA piece in flight).  Without the division
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (PLAN) {
         // (no separate check against the list's length: every slot behind it is padding, seq = -1)
         const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x);
-        if (it.seq < 0) return;                                // padding of a round
+        if (it.seq < 0) return;                                // behind the list
         seq = it.seq, hblk = 0, t_begin = it.t_begin, t_end = it.t_end;
     } else {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;

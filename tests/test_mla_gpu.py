@@ -229,7 +229,7 @@ def plan_reference(lens, kv_heads, workers, tile=32, min_tiles=8, max_splits=64,
                                                    # more sequences than the list sorts (2048): batch order, one piece each
                                                    (2100, 16, 1, 130, 16, "ragged"), (1100, 128, 2, 100, 32, "ragged")])
 def test_planned_work_list_matches_its_restatement_and_outputs_match_uniform_splits(B, Hq, Hkv, S, page, kind):
-    """The device-built work list (length-aware split counts, longest pieces first, the pieces of a sequence on one XCD) against its host
+    """The device-built work list (length-aware split counts, the pieces of a sequence consecutive, sequences longest first) against its host
     restatement, word for word; structural properties (every tile of every sequence covered exactly once; padding only); and the
     outputs of the planned launch against the same kernel with ONE piece per sequence (no merge at all): equal within the fp32
     summation-order tolerance of a flash-decoding merge."""
