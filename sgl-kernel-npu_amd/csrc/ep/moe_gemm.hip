@@ -543,6 +543,9 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
     // XCDs are 4 + 4 + 4 + 4 + 3 + 3 + 3 + 3, the four-tile XCDs finish 14 % later, and the plain order's (x + 4 y) % 8 IS the balanced deal
     // (every XCD 3.5 tiles on average, each weight tile on two XCDs).  The traffic past L2 is served by the 256 MB memory-side cache; it
     // is not what the kernel waits for.  GEMM1 (16 column tiles) is unaffected: 802 us either way, 3.09 GB against 1.44 GB algorithmic.
+    // (A balanced variant -- the surplus column slots 28 .. 31, on XCDs 4 .. 7, taking every second (expert, row block) of columns 24 .. 27,
+    //  3.5 columns per XCD -- was measured too: GEMM2 522 us uniform / 569 us with multinomial row counts against 482-490 / 537 for the plain
+    //  order, fabric traffic 2.25 GB against 2.61 GB.  Consistency costs time even when the deal is even.)
     static const bool xcd_cols = getenv("MI_GEMM_XCD_COLS") && atoi(getenv("MI_GEMM_XCD_COLS")) != 0;
     q.cols_padded = (xcd_cols && gx % 8 != 0 && gx > 8) ? (gx + 7) / 8 * 8 : 0;
     // (padded form: the same number of workers, gx' x pool flat ids cut into rows of gx')
