@@ -323,6 +323,64 @@ def xgmi_projection(pairs_to, tokens_to, kernels_us, small_us, hidden, ep=8, me=
                        "MI_EP_PUSH_STRIDE deal); HBM-side kernel times from ep8_proxy on this GPU; unmeasured on xGMI"}
 
 
+def xgmi_measured(world, rank, transport, tokens_to, pairs_to, rows_from, kernel_us, hidden):
+    """Cross-GPU bytes of this rank per step, per leg and per link (= per peer: one xGMI link each), over the
+    MEASURED duration of the kernel that moves them (HIP events).  Pure arithmetic: CPU-tested in tests/test_bench_cpu.py."""
+    row = hidden + 16
+    peers = [d for d in range(world) if d != rank]
+    if transport == "push":       # sender writes one row per (token, destination rank) + 8 B per pair
+        disp_link = [tokens_to[d] * row + pairs_to[d] * 8 for d in peers]
+        disp_kernel = "dispatch_stage_push"
+    else:                         # receiver reads one row + one index entry per received row
+        disp_link = [rows_from[s] * (row + 8) for s in peers]
+        disp_kernel = "dispatch_pull"
+    t_disp = kernel_us.get(disp_kernel, 0.0) * 1e-6
+    comb_link = [rows_from[s] * hidden * 2 for s in peers]      # rows pushed back to their source rank
+    t_comb = kernel_us.get("combine_push", 0.0) * 1e-6
+    peak = XGMI_LINK_GBPS * (world - 1)
+    xg = {"peak_GBps": peak, "link_GBps": XGMI_LINK_GBPS, "links": world - 1, "dispatch_transport": transport,
+          "dispatch_kernel": disp_kernel, "dispatch_bytes": sum(disp_link), "combine_bytes": sum(comb_link),
+          "dispatch_max_link_bytes": max(disp_link), "combine_max_link_bytes": max(comb_link)}
+    if t_disp:
+        xg["dispatch_us"] = t_disp * 1e6
+        xg["dispatch_GBps"] = sum(disp_link) / t_disp / 1e9
+        xg["dispatch_frac"] = xg["dispatch_GBps"] / peak
+        xg["dispatch_max_link_frac"] = max(disp_link) / t_disp / 1e9 / XGMI_LINK_GBPS
+    if t_comb:
+        xg["combine_us"] = t_comb * 1e6
+        xg["combine_GBps"] = sum(comb_link) / t_comb / 1e9
+        xg["combine_frac"] = xg["combine_GBps"] / peak
+        xg["combine_max_link_frac"] = max(comb_link) / t_comb / 1e9 / XGMI_LINK_GBPS
+    if t_disp and t_comb:         # both link-facing legs together: the figure north_star's ">= 70 % of per-GPU xGMI peak" is read against
+        xg["legs_GBps"] = (sum(disp_link) + sum(comb_link)) / (t_disp + t_comb) / 1e9
+        xg["legs_frac"] = xg["legs_GBps"] / peak
+    return xg
+
+
+def xgmi_roofline(xg, projection, hbm_side, timing):
+    """The top-level `roofline` of an N > 1 line: the exchange is xGMI-bound, so the dominant kernel is the link-facing leg that takes
+    longer (normally combine_push: 2H bytes per selection against H + 16 per (token, rank)), priced against (N - 1) links x 153 GB/s,
+    with the busiest link's own fraction and the projection the N = 1 line stated in advance beside it -- measured vs projected in one
+    object.  The HBM-side figure of the same step (the N = 1 line's roofline kernel) is kept as `hbm_side`.  None when no leg was timed."""
+    legs = [l for l in ("dispatch", "combine") if l + "_GBps" in xg]
+    if not legs:
+        return None
+    leg = max(legs, key=lambda l: xg[l + "_us"])
+    r = {"bound": "xgmi", "kernel": "combine_push" if leg == "combine" else xg["dispatch_kernel"], "achieved": xg[leg + "_GBps"],
+         "peak": xg["peak_GBps"], "unit": "GB/s", "frac": xg[leg + "_frac"], "max_link_frac": xg[leg + "_max_link_frac"],
+         "algorithmic_bytes": xg[leg + "_bytes"], "avg_launch_us": xg[leg + "_us"], "traffic": None, "timing": timing,
+         "peak_source": f"{xg['links']} xGMI links x {xg['link_GBps']} GB/s per direction (MI355X_MICROARCH.md)",
+         "both_legs": {"achieved": xg.get("legs_GBps"), "frac": xg.get("legs_frac"), "target_frac": 0.70},
+         "hbm_side": hbm_side}
+    if projection is not None:
+        pl = projection["legs"]["combine_push" if leg == "combine" else "dispatch_push"]
+        r["projected"] = {"leg_us": pl["projected_us"], "busiest_link_us": pl["busiest_link_us"], "bound": pl["bound"],
+                          "frac_during_legs": projection["projected_xgmi_frac_during_legs"],
+                          "step_ms": projection["projected_step_ms"], "ep": projection["ep"],
+                          "measured_over_projected": xg[leg + "_us"] / pl["projected_us"] if pl["projected_us"] else None}
+    return r
+
+
 # (N = 1: every received row is one of this rank's own tokens, so the whole pull is the token-wise pull_local_kernel)
 PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, 1>", "dispatch_pull": "pull_local_kernel<false, true>",
                     "combine_push": "combine_push_kernel", "combine_reduce": "combine_reduce_kernel<false, 8>"}
@@ -833,30 +891,7 @@ def main():
         result["kernels"] = {k: dict(per[k], GBps=kb(k) / (per[k]["avg_us"] * 1e-6) / 1e9) for k in bulk}
         result["kernels"].update({k: per[k] for k in per if k not in bulk})
         if world > 1:
-            # cross-GPU bytes of this rank per step, per leg and per link (= per peer: one xGMI link each)
-            row = HIDDEN + 16
-            peers = [d for d in range(world) if d != rank]
-            if best == "push":        # sender writes one row per (token, destination rank) + 8 B per pair
-                disp_link = [tokens_to[d] * row + pairs_to[d] * 8 for d in peers]
-                t_disp = per.get("dispatch_stage_push", {}).get("avg_us", 0) * 1e-6
-            else:                     # receiver reads one row + one index entry per received row
-                disp_link = [rows_from[s] * (row + 8) for s in peers]
-                t_disp = per.get("dispatch_pull", {}).get("avg_us", 0) * 1e-6
-            comb_link = [rows_from[s] * HIDDEN * 2 for s in peers]      # rows pushed back to their source rank
-            t_comb = per.get("combine_push", {}).get("avg_us", 0) * 1e-6
-            peak = XGMI_LINK_GBPS * (world - 1)
-            xg = {"peak_GBps": peak, "link_GBps": XGMI_LINK_GBPS, "dispatch_transport": best,
-                  "dispatch_bytes": sum(disp_link), "combine_bytes": sum(comb_link),
-                  "dispatch_max_link_bytes": max(disp_link), "combine_max_link_bytes": max(comb_link)}
-            if t_disp:
-                xg["dispatch_GBps"] = sum(disp_link) / t_disp / 1e9
-                xg["dispatch_frac"] = xg["dispatch_GBps"] / peak
-                xg["dispatch_max_link_frac"] = max(disp_link) / t_disp / 1e9 / XGMI_LINK_GBPS
-            if t_comb:
-                xg["combine_GBps"] = sum(comb_link) / t_comb / 1e9
-                xg["combine_frac"] = xg["combine_GBps"] / peak
-                xg["combine_max_link_frac"] = max(comb_link) / t_comb / 1e9 / XGMI_LINK_GBPS
-            result["xgmi"] = xg
+            result["xgmi"] = xgmi_measured(world, rank, best, tokens_to, pairs_to, rows_from, {k: v["avg_us"] for k, v in per.items()}, HIDDEN)
     if proxy is not None:
         if "prof" in proxy:
             perp = {k: ms / n * 1e3 for k, (n, ms) in proxy.pop("prof").items() if n}
@@ -874,10 +909,16 @@ def main():
             nosync["what"] = ("same K steps through dispatch(num_worst_tokens=T*K*W): worst-case sized outputs, no host read of the "
                               "receive count between dispatch and combine (the headline's dispatch reads it: one pinned-word spin per step)")
         result["no_host_sync"] = nosync
-    if world == 1 and proxy is not None and "kernels" in proxy:
-        p8, t8 = routing_stats(topk_idx, 8, 0)
+    if proxy is not None and "kernels" in proxy:
+        # N = 1: this rank's routing as if its experts were spread over 8 ranks, stated in advance; N > 1: the run's own routing
+        ep, me = (8, 0) if world == 1 else (world, rank)
+        p8, t8 = routing_stats(topk_idx, ep, me)
         result["xgmi_projection"] = xgmi_projection(p8, t8, {k: v["avg_us"] for k, v in proxy["kernels"].items()},
-                                                    proxy.get("small_launches_us", {}), HIDDEN)
+                                                    proxy.get("small_launches_us", {}), HIDDEN, ep=ep, me=me)
+    if world > 1 and "xgmi" in result and "roofline" in result:
+        xr = xgmi_roofline(result["xgmi"], result.get("xgmi_projection"), result["roofline"], result["roofline"]["timing"])
+        if xr is not None:
+            result["roofline"] = xr
     if args.dry_run_8:
         result["dry_run_single_device"] = True       # every rank ran on cuda:0: plumbing only, not a measurement
     result.update(extra)

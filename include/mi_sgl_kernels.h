@@ -59,8 +59,11 @@ const char *mi_sgl_kernels_version(void);
 size_t mi_mla_decode_workspace(int batch, int q_heads, int num_splits);
 /* Plan once, run many: the work list of the planned form depends only on kv_seq_lens (contents), batch and kv_heads -- the attention layers
  * of one decode step share it.  mi_mla_decode_build_plan: one small launch into caller memory of mi_mla_decode_plan_bytes();
- * mi_mla_decode_with_plan = mi_mla_decode(num_splits = MI_MLA_SPLITS_PLANNED) without that launch (workspace as for that value; the plan
- * must have been built from the same kv_seq_lens contents: a stale plan reads the wrong tile ranges).  MI_SGL_ENOTAPPLICABLE where the
+ * mi_mla_decode_with_plan = mi_mla_decode(num_splits = MI_MLA_SPLITS_PLANNED) without that launch (workspace as for that value).  HARD
+ * requirements on the plan: built for the SAME batch * kv_heads (the item offsets inside the list depend on that count and are not
+ * checked by the kernels) on the same device (same worker count).  Soft: the kv_seq_lens contents -- every consumer clamps its piece to
+ * the tiles its sequence has NOW and the last piece of a sequence runs to their end, so a plan built from other lengths costs balance,
+ * never correctness.  MI_SGL_ENOTAPPLICABLE where the
  * planned form does not serve the shape (kv groups of more than 128 heads; for groups of 65..128 heads, page sizes that are not powers of
  * two): call mi_mla_decode.  One list serves every head count: it counts 32-key tiles and its pieces start on even tiles. */
 size_t mi_mla_decode_plan_bytes(int batch, int kv_heads);
@@ -79,7 +82,11 @@ int mi_mla_decode_with_plan(const void *q, const void *k_nope, const void *k_rop
  *   XCDs (workgroup i runs on XCD i mod 8). */
 size_t mi_mla_decode_plan_offset(int batch, int q_heads);
 int mi_mla_decode_plan_workers(void);
+/* NOTE (API change since 0.1-r4): returns MI_MLA_SPLITS_PLANNED (-1) for kv groups of up to 128 heads -- a value to pass back to
+ * mi_mla_decode / mi_mla_decode_workspace, NOT a positive count to loop over; any other negative num_splits is MI_SGL_EINVAL.  Callers
+ * that need a positive uniform count call mi_mla_decode_uniform_splits. */
 int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
+int mi_mla_decode_uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
 /* kv groups of more than 64 heads have two kernel forms: 8 waves per workgroup (two per SIMD, the default) and 4 (one per SIMD).
  * waves = 4 / 8 forces one for the calls that follow, 0 returns to the default (or MI_MLA_WIDE8).  Process-wide, not thread-safe:
  * a test / tuning knob, results do not depend on it beyond fp32 summation order. */

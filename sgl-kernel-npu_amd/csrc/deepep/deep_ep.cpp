@@ -295,6 +295,11 @@ void Buffer::check_status(const char *where)
     const int32_t s = __atomic_load_n(status_host, __ATOMIC_ACQUIRE);
     if (s != 0) {
         __atomic_store_n(status_host, 0, __ATOMIC_RELEASE);
+        if (s == MI_EP_STATUS_LAYOUT_BARRIER) {
+            // a barrier that did not close never re-armed its pair of sync words: clear the whole ring (behind everything queued on this
+            // stream) so the pair does not hand a non-zero count to the launch that borrows it 32 layout calls later
+            (void)hipMemsetAsync(window + kOffEpochs + 512, 0, 32 * 8, cur_stream());
+        }
         throw EPException("Timeout", __FILE__, __LINE__,
                           ep_concat(where, ": a peer did not arrive within DEEPEP_TIMEOUT_MS=", timeout_ms, " (code ", s,
                                     ", rank ", rank, ")"));

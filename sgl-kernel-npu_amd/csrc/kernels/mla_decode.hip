@@ -592,6 +592,13 @@ extern "C" int mi_mla_decode_num_splits(int batch, int q_heads, int kv_heads, in
     if (plan_applies(q_heads / kv_heads)) return MI_MLA_SPLITS_PLANNED;
     return uniform_splits(batch, q_heads, kv_heads, max_seq_len);
 }
+// positive uniform split count (what mi_mla_decode_num_splits returned before the planned form existed): for callers that size their
+// own loops / workspaces by it
+extern "C" int mi_mla_decode_uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
+{
+    if (batch <= 0 || q_heads <= 0 || kv_heads <= 0 || max_seq_len <= 0) return 1;
+    return uniform_splits(batch, q_heads, kv_heads, max_seq_len);
+}
 static int uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
 {
     const int group = q_heads / kv_heads;

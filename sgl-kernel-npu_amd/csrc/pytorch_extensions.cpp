@@ -43,36 +43,60 @@ void decode_mla_planned(const at::Tensor &q, const at::Tensor &k_nope_buffer, co
 
 // The attention layers of a decode step call decode_mla with the SAME kv_seq_lens tensor: the work list of the planned form is built by
 // the first of them and reused by the others (the reference signature has no plan argument, so a drop-in caller gets "plan once, run
-// many" this way).  One entry per device: the kv_seq_lens tensor itself (held, so its storage cannot be recycled under the entry), its
-// version counter (an in-place write through torch rebuilds the list), kv head count and stream.  Writes that bypass the version counter
-// (a raw-pointer kernel) leave a stale list in place -- which the kernels tolerate by construction (pieces are clamped to the current
-// lengths, the last piece runs to their end): stale costs balance, never correctness.  Inference tensors carry no version counter and are
-// not cached.  MI_MLA_PLAN_CACHE=0 turns the reuse off; num_splits = -1 asks for the planned form with a list of its own.
+// many" this way).  One entry per device: a WEAK reference to the kv_seq_lens tensor's storage (the entry pins neither the tensor nor its
+// allocator block: when the caller drops the tensor -- a model reload -- the reference expires and the next call rebuilds; while it is
+// alive the bytes cannot have been recycled for another tensor; views of one buffer -- a padded kv_seq_lens cut to the batch -- share it), its data pointer and version counter (an in-place write through torch rebuilds
+// the list), kv head count and stream.  Writes that bypass the version counter (a raw-pointer kernel, a graph replay) leave a stale list
+// in place -- which the kernels tolerate by construction (pieces are clamped to the current lengths, the last piece runs to their end):
+// stale costs balance, never correctness.  Inference tensors carry no version counter and are not cached.  MI_MLA_PLAN_CACHE=0 turns the
+// reuse off; num_splits = -1 asks for the planned form with a list of its own; torch.ops.npu.clear_mla_plan_cache() drops every entry
+// (the only thing an entry owns is its list: batch * kv_heads * 8 B + 1 KB of device memory).
 struct MlaPlanCacheEntry {
-    at::Tensor lens, plan;
+    c10::weak_intrusive_ptr<c10::StorageImpl> lens{c10::intrusive_ptr<c10::StorageImpl>()};
+    const void *lens_ptr = nullptr;
+    int64_t lens_numel = 0;
+    at::Tensor plan;
     uint32_t version = 0;
     int64_t kv_heads = 0;
     void *stream = nullptr;
     unsigned long long capture = 0;      // id of the stream capture the list was built in (0: built eagerly)
 };
+static std::mutex g_plan_mu;
+static std::map<int, MlaPlanCacheEntry> &plan_entries()
+{
+    static auto &entries = *new std::map<int, MlaPlanCacheEntry>();      // (never destroyed: tensors must not outlive the HIP context at exit)
+    return entries;
+}
+void clear_mla_plan_cache()
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    plan_entries().clear();
+}
 static at::Tensor cached_mla_plan(const at::Tensor &kv_seq_lens, int64_t kv_heads)
 {
-    static std::mutex mu;
-    static auto &entries = *new std::map<int, MlaPlanCacheEntry>();      // (never destroyed: tensors must not outlive the HIP context at exit)
     void *st = cur_stream();
     const uint32_t ver = kv_seq_lens._version();
     // a list built while a graph is being captured has no contents until the graph runs: it serves the calls of the SAME capture only (the
     // layers of the captured step), never an eager call or another capture
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     unsigned long long cap = 0;
-    if (hipStreamGetCaptureInfo((hipStream_t)st, &cap_status, &cap) != hipSuccess || cap_status != hipStreamCaptureStatusActive) cap = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    MlaPlanCacheEntry &e = entries[kv_seq_lens.device().index()];
-    if (e.lens.defined() && e.lens.data_ptr() == kv_seq_lens.data_ptr() && e.lens.numel() == kv_seq_lens.numel() && e.version == ver &&
+    if (hipStreamGetCaptureInfo((hipStream_t)st, &cap_status, &cap) != hipSuccess) {
+        (void)hipGetLastError();         // a failed query must not sit in the thread's last-error slot: the plan launch checks it right after
+        cap = 0;
+    } else if (cap_status != hipStreamCaptureStatusActive) {
+        cap = 0;
+    }
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    MlaPlanCacheEntry &e = plan_entries()[kv_seq_lens.device().index()];
+    // same storage, still alive (expired once the caller dropped every tensor on it), same bytes, unmodified through torch
+    const bool alive = e.lens_ptr != nullptr && e.lens._unsafe_get_target() == kv_seq_lens.storage().unsafeGetStorageImpl() && !e.lens.expired();
+    if (alive && e.lens_ptr == kv_seq_lens.data_ptr() && e.lens_numel == kv_seq_lens.numel() && e.version == ver &&
         e.kv_heads == kv_heads && e.stream == st && e.capture == cap)
         return e.plan;
     e.plan = decode_mla_plan(kv_seq_lens, kv_heads);
-    e.lens = kv_seq_lens, e.version = ver, e.kv_heads = kv_heads, e.stream = st, e.capture = cap;
+    e.lens = kv_seq_lens.storage().getWeakStorageImpl();
+    e.lens_ptr = kv_seq_lens.data_ptr(), e.lens_numel = kv_seq_lens.numel();
+    e.version = ver, e.kv_heads = kv_heads, e.stream = st, e.capture = cap;
     return e.plan;
 }
 
@@ -97,6 +121,13 @@ void decode_mla(const at::Tensor &q, const at::Tensor &k_nope_buffer, const at::
     TORCH_CHECK(block_table.stride(1) == 1, "decode_mla: block_table rows must be contiguous");
     const int B = (int)q.size(0), Hq = (int)q.size(1), Hkv = (int)k_nope_buffer.size(2);
     TORCH_CHECK(Hq % Hkv == 0 && k_rope_buffer.size(2) == Hkv, "decode_mla: head counts");
+    // The batch is q's (as in the reference, decode_attention.py:178); a longer (padded, graph-static) kv_seq_lens is cut to it HERE: the
+    // work list's item offsets depend on the (sequence, kv head) pair count, so list builder and consumers must agree on it.
+    TORCH_CHECK(kv_seq_lens.dim() == 1 && kv_seq_lens.size(0) >= B, "decode_mla: kv_seq_lens must be [batch] with batch >= q.size(0)");
+    if (kv_seq_lens.size(0) > B) {
+        decode_mla(q, k_nope_buffer, k_rope_buffer, att_out, kv_seq_lens.narrow(0, 0, B), sm_scale, page_size, block_table, num_splits);
+        return;
+    }
     const int max_len = (int)std::min<int64_t>(block_table.size(1) * page_size, INT32_MAX);   // upper bound, no host sync
     int splits = (int)num_splits;
     if (splits == 0) {
@@ -139,8 +170,12 @@ void decode_mla_planned(const at::Tensor &q, const at::Tensor &k_nope_buffer, co
     const c10::DeviceGuard device_guard(q.device());
     TORCH_CHECK(q.dim() == 3 && k_nope_buffer.dim() == 4 && k_rope_buffer.dim() == 4 && att_out.dim() == 3 && block_table.dim() == 2, "decode_mla: bad ranks");
     const int B = (int)q.size(0), Hq = (int)q.size(1), Hkv = (int)k_nope_buffer.size(2);
-    TORCH_CHECK(plan.scalar_type() == at::kInt && plan.is_contiguous() && (size_t)plan.numel() * 4 >= mi_mla_decode_plan_bytes(B, Hkv),
+    // exact size: the list's item offsets depend on batch * kv heads (the size is strictly increasing in it), so a list built for a larger
+    // batch must be refused, not read with the wrong offsets
+    TORCH_CHECK(plan.scalar_type() == at::kInt && plan.is_contiguous() &&
+                    (size_t)plan.numel() * 4 == std::max<size_t>(mi_mla_decode_plan_bytes(B, Hkv), 16),
                 "decode_mla_planned: plan does not belong to this batch / kv head count");
+    TORCH_CHECK(kv_seq_lens.dim() == 1 && kv_seq_lens.size(0) == B, "decode_mla_planned: kv_seq_lens must be [q.size(0)]");
     const bool shapes_ok = k_nope_buffer.size(3) == 512 && k_rope_buffer.size(3) == 64 && q.size(2) == 576 && att_out.size(2) == 512 &&
                            q.stride(2) == 1 && k_nope_buffer.stride(3) == 1 && k_rope_buffer.stride(3) == 1 && att_out.stride(2) == 1 &&
                            k_nope_buffer.size(1) == page_size && k_rope_buffer.size(1) == page_size && kv_seq_lens.scalar_type() == at::kInt &&
@@ -946,6 +981,7 @@ TORCH_LIBRARY_FRAGMENT(npu, m)
     m.def("decode_mla(Tensor q, Tensor k_nope_buffer, Tensor k_rope_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
           "float sm_scale, int page_size, Tensor block_table, int num_splits=0) -> ()");
     m.def("decode_mla_plan(Tensor kv_seq_lens, int num_kv_heads=1) -> Tensor");
+    m.def("clear_mla_plan_cache", &sglang::npu_kernel::clear_mla_plan_cache);      // no tensor arguments: catch-all kernel
     m.def("decode_mla_planned(Tensor q, Tensor k_nope_buffer, Tensor k_rope_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "
           "float sm_scale, int page_size, Tensor block_table, Tensor plan) -> ()");
     m.def("decode_gqa(Tensor q, Tensor k_buffer, Tensor v_buffer, Tensor(a!) att_out, Tensor kv_seq_lens, "

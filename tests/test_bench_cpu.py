@@ -71,3 +71,39 @@ def test_xgmi_projection_arithmetic():
     # a leg whose HBM-side kernel is slower than its link time is HBM-bound
     p3 = B.xgmi_projection(pairs, toks, dict(kern, combine_push=900.0), {}, H)
     assert p3["legs"]["combine_push"]["bound"] == "hbm" and p3["legs"]["combine_push"]["projected_us"] == 900.0
+
+
+def test_multi_gpu_line_names_the_xgmi_leg():
+    """At world > 1 the top-level roofline is the link-facing leg (bound "xgmi", peak = 7 x 153 GB/s), measured beside projected; reference
+    bandwidth convention: tests/python/deepep/test_intranode.py:447-448,530-534 (bytes moved over the kernel's time)."""
+    B = _bench()
+    H, W = 7168, 8
+    pairs, toks = [4096] * W, [2687] * W
+    rows_from = [4096] * W
+    kern_us = {"dispatch_stage_push": 150.0, "dispatch_pull": 73.0, "combine_push": 420.0, "combine_reduce": 86.0, "layout": 10.0}
+    xg = B.xgmi_measured(W, 3, "push", toks, pairs, rows_from, kern_us, H)
+    assert xg["peak_GBps"] == 7 * 153.0 and xg["links"] == 7
+    assert xg["dispatch_bytes"] == 7 * (2687 * (H + 16) + 4096 * 8) and xg["combine_bytes"] == 7 * 4096 * 2 * H
+    assert abs(xg["combine_GBps"] - xg["combine_bytes"] / 420e-6 / 1e9) < 1e-6
+    assert abs(xg["combine_max_link_frac"] - 4096 * 2 * H / 420e-6 / 1e9 / 153.0) < 1e-9
+    assert abs(xg["legs_GBps"] - (xg["dispatch_bytes"] + xg["combine_bytes"]) / 570e-6 / 1e9) < 1e-6
+    proj = B.xgmi_projection(pairs, toks, {"dispatch_stage": 17.0, "dispatch_pull": 73.0, "combine_push": 154.0, "combine_reduce": 86.0},
+                             {}, H, ep=W, me=3)
+    hbm = {"bound": "hbm", "kernel": "combine_reduce", "frac": 0.7, "timing": "t"}
+    r = B.xgmi_roofline(xg, proj, hbm, "t")
+    assert r["bound"] == "xgmi" and r["kernel"] == "combine_push" and r["peak"] == 7 * 153.0 and r["unit"] == "GB/s"
+    assert r["achieved"] == xg["combine_GBps"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["max_link_frac"] == xg["combine_max_link_frac"] and r["hbm_side"] is hbm and r["traffic"] is None
+    assert r["both_legs"]["frac"] == xg["legs_frac"] and r["both_legs"]["target_frac"] == 0.70
+    pl = proj["legs"]["combine_push"]
+    assert r["projected"]["leg_us"] == pl["projected_us"] and abs(r["projected"]["measured_over_projected"] - 420.0 / pl["projected_us"]) < 1e-12
+    # the pull transport prices the receiver's reads; a dispatch leg slower than the combine leg becomes the roofline kernel
+    xg2 = B.xgmi_measured(W, 0, "pull", toks, pairs, rows_from, dict(kern_us, dispatch_pull=900.0), H)
+    assert xg2["dispatch_kernel"] == "dispatch_pull" and xg2["dispatch_bytes"] == 7 * 4096 * (H + 16 + 8)
+    r2 = B.xgmi_roofline(xg2, None, hbm, "t")
+    assert r2["kernel"] == "dispatch_pull" and "projected" not in r2
+    # no timed leg: no xGMI roofline (the caller keeps the HBM one)
+    assert B.xgmi_roofline(B.xgmi_measured(W, 0, "push", toks, pairs, rows_from, {}, H), proj, hbm, "t") is None
+    # W = 2: one link
+    xg3 = B.xgmi_measured(2, 1, "push", [100, 50], [300, 200], [250, 222], {"combine_push": 10.0, "dispatch_stage_push": 5.0}, H)
+    assert xg3["peak_GBps"] == 153.0 and xg3["combine_bytes"] == 250 * 2 * H and xg3["dispatch_bytes"] == 100 * (H + 16) + 300 * 8

@@ -390,3 +390,88 @@ def test_decode_mla_in_a_captured_graph_shares_the_list_inside_the_capture_only(
         torch.cuda.synchronize()
         for o in outs:
             assert torch.equal(o, own), step
+
+
+def test_padded_kv_seq_lens_and_foreign_plans():
+    """The batch is q's (reference decode_attention.py:178): a kv_seq_lens longer than q.size(0) (padded / graph-static buffer) is cut to the
+    batch before the work list is built -- list builder and consumers must agree on the (sequence, kv head) pair count the item offsets are
+    derived from --, a list built for ANOTHER batch size is refused instead of read with the wrong offsets, and the plan cache neither pins the
+    caller's tensor nor survives clear_mla_plan_cache()."""
+    import gc
+    import sys
+    import weakref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sgl-kernel-npu_amd", "python"))
+    from sgl_kernel_npu.attention.decode_attention import decode_mla, decode_mla_plan
+    g = torch.Generator(device="cuda").manual_seed(77)
+    B, Hq, S, page, PAD = 20, 128, 1500, 64, 64
+    maxp = (S + page - 1) // page
+    nb = B * maxp
+    q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(torch.bfloat16)
+    kn = (torch.randn((nb, page, 1, 512), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    kr = (torch.randn((nb, page, 1, 64), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+    padded = torch.full((PAD,), 10 ** 6, dtype=torch.int32, device="cuda")        # garbage behind the batch must never be read as lengths
+    padded[:B] = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+    want = torch.empty((B, Hq, 512), dtype=torch.bfloat16, device="cuda")
+    decode_mla(q, kn, kr, want, padded[:B].clone(), 576 ** -0.5, page, bt)
+    for _ in range(3):                                    # the cut view shares storage + version counter: calls 2, 3 reuse the list
+        got = torch.empty_like(want)
+        decode_mla(q, kn, kr, got, padded, 576 ** -0.5, page, bt)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    big = decode_mla_plan(padded, 1)                      # a list for 64 pairs is not a list for 20
+    with pytest.raises(RuntimeError, match="plan does not belong"):
+        torch.ops.npu.decode_mla_planned(q, kn, kr, torch.empty_like(want), padded[:B].contiguous(), 576 ** -0.5, page, bt, big)
+    # the cache holds a weak reference: dropping the lengths tensor frees its storage
+    lens = padded[:B].clone()
+    decode_mla(q, kn, kr, torch.empty_like(want), lens, 576 ** -0.5, page, bt)
+    torch.cuda.synchronize()
+    probe = weakref.ref(lens.untyped_storage())
+    del lens
+    gc.collect()
+    assert probe() is None, "the plan cache kept the caller's kv_seq_lens alive"
+    torch.ops.npu.clear_mla_plan_cache()
+    got = torch.empty_like(want)
+    decode_mla(q, kn, kr, got, padded, 576 ** -0.5, page, bt)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert lib().mi_mla_decode_uniform_splits(B, Hq, 1, S) >= 1
+
+
+def test_graph_replay_with_lengths_crossing_piece_boundaries():
+    """A graph that captured decode_mla WITH a list built eagerly replays that list forever: it is as stale as the lengths written between
+    replays make it.  Sequences that grow or shrink ACROSS the piece boundaries of the captured list (half, double, one key, a ramp, just
+    over / under a boundary) still produce the result of a call that builds its own list (fp32 summation order differs with the piece
+    cut: tolerance of the stale-list test above)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sgl-kernel-npu_amd", "python"))
+    from sgl_kernel_npu.attention.decode_attention import decode_mla, decode_mla_plan
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, Hq, S, page = 16, 128, 4096, 64
+    maxp = S // page
+    nb = B * maxp
+    q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(torch.bfloat16)
+    kn = (torch.randn((nb, page, 1, 512), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    kr = (torch.randn((nb, page, 1, 64), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+    lens = torch.full((B,), 2048, dtype=torch.int32, device="cuda")
+    out = torch.empty((B, Hq, 512), dtype=torch.bfloat16, device="cuda")
+    plan = decode_mla_plan(lens, 1)                       # 16 sequences x 64 tiles on 256 workers: 16 pieces of 4 tiles each
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        decode_mla(q, kn, kr, out, lens, 576 ** -0.5, page, bt, plan=plan)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        decode_mla(q, kn, kr, out, lens, 576 ** -0.5, page, bt, plan=plan)
+    own = torch.empty_like(out)
+    for new in (torch.full((B,), 1024), torch.full((B,), 4096), torch.full((B,), 1), torch.arange(B) * 256 + 1,
+                torch.full((B,), 2048 + 31), torch.full((B,), 2048 - 33), torch.full((B,), 2048)):
+        lens.copy_(new.to(torch.int32).cuda())
+        out.fill_(3.0)
+        graph.replay()
+        torch.ops.npu.decode_mla(q, kn, kr, own, lens, 576 ** -0.5, page, bt, -1)
+        torch.cuda.synchronize()
+        assert torch.allclose(out.float(), own.float(), rtol=2 ** -7, atol=2e-3), (int(new[0]), (out.float() - own.float()).abs().max())
