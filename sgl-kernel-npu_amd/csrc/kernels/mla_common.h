@@ -118,6 +118,8 @@ constexpr int kWideTile = 32;
 void launch_mla_wide(const MlaParams &p, int dtype, long long units, hipStream_t st);
 // eight-wave form (mla_decode_wide8.hip): two waves per SIMD; the default for kv groups of more than 64 heads
 void launch_mla_wide8(const MlaParams &p, int dtype, long long units, hipStream_t st);
+// the same work split with one scalar block id per tile and three tiles in flight (mla_decode_wide8s.hip); power-of-two pages of >= 32 keys
+void launch_mla_wide8s(const MlaParams &p, int dtype, long long units, hipStream_t st);
 
 // Slow path behind the wide kernel (mla_decode_wide.hip): a sequence whose scores outgrew the fixed softmax reference is
 // recomputed here, one wave per (b, head), with plain loads and fp32 VALU math -- exact two-pass softmax (max first), P

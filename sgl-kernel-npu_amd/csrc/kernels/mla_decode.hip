@@ -570,12 +570,16 @@ extern "C" size_t mi_mla_decode_plan_offset(int batch, int q_heads)
 }
 extern "C" int mi_mla_decode_plan_workers(void) { return plan_workers(); }
 
-static int g_wide_variant = 0;      // 0 = environment / default, 4 or 8 = forced (tests run both forms in one process)
-static bool wide8_selected()
+static int g_wide_variant = 0;      // 0 = environment / default; 4, 8 or 9 = forced (tests run every form in one process)
+static int wide_variant()
 {
-    static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) ? 8 : 4) : 8;
-    return (g_wide_variant ? g_wide_variant : wide_env) == 8;
+    // MI_MLA_WIDE8 = 0: four waves; 1: eight waves, per-key block ids through an LDS ring (mla_decode_wide8.hip; any page size); 2 (default):
+    // eight waves, one scalar block id per tile and three tiles in flight (mla_decode_wide8s.hip; power-of-two pages of >= 32 keys, other
+    // page sizes take the ring kernel)
+    static const int wide_env = getenv("MI_MLA_WIDE8") ? (atoi(getenv("MI_MLA_WIDE8")) == 0 ? 4 : atoi(getenv("MI_MLA_WIDE8")) == 1 ? 8 : 9) : 9;
+    return g_wide_variant ? g_wide_variant : wide_env;
 }
+static bool wide8_selected() { return wide_variant() >= 8; }
 // the planned form serves one workgroup per (sequence, kv head) piece: the eight-wave wide kernel with one 128-head block, or the 64-head
 // kernel with one head block (groups of <= 64 heads: the 16-head shards of a TP-8 deployment); MI_MLA_PLAN=0 keeps uniform splits
 static bool plan_applies(int group)
@@ -615,7 +619,7 @@ static int uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
 
 extern "C" int mi_mla_decode_select_wide(int waves)
 {
-    if (waves != 0 && waves != 4 && waves != 8) return MI_SGL_EINVAL;
+    if (waves != 0 && waves != 4 && waves != 8 && waves != 9) return MI_SGL_EINVAL;
     g_wide_variant = waves;
     return MI_SGL_OK;
 }
@@ -750,8 +754,9 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
         (void)hipFuncSetAttribute((const void *)mla_decode_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     }
     if (wide) {
-        if (planned) launch_mla_wide8(p, dtype, plan_items_max(seqs, workers), st);
-        else if (wide8) launch_mla_wide8(p, dtype, units, st);
+        const bool scalar_ids = wide_variant() == 9 && (page_size & (page_size - 1)) == 0 && page_size >= kWideTile;
+        if (planned) (scalar_ids ? launch_mla_wide8s : launch_mla_wide8)(p, dtype, plan_items_max(seqs, workers), st);
+        else if (wide8) (scalar_ids ? launch_mla_wide8s : launch_mla_wide8)(p, dtype, units, st);
         else launch_mla_wide(p, dtype, units, st);
         p.fix_only = 1;                                // the merge kernel also serves as the slow path for flagged sequences
     } else {

@@ -52,9 +52,10 @@ def run_mla(q, kn, kr, lens, bt, sm_scale, num_splits=0, keep_ws=None):
     return out
 
 
-@pytest.fixture(params=[4, 8], ids=["wide4", "wide8"])
+@pytest.fixture(params=[4, 8, 9], ids=["wide4", "wide8", "wide8q"])
 def wide_variant(request):
-    """Both forms of the > 64-heads-per-group kernel (mla_decode_wide.hip, mla_decode_wide8.hip) for the cases that reach them."""
+    """The three forms of the > 64-heads-per-group kernel (mla_decode_wide.hip, mla_decode_wide8.hip, mla_decode_wide8q.hip: 9 = eight
+    waves, three KV slots, Q^T tail in LDS -- the default; page sizes that are not powers of two take the four-slot kernel there)."""
     assert lib().mi_mla_decode_select_wide(request.param) == 0
     yield request.param
     lib().mi_mla_decode_select_wide(0)
@@ -71,7 +72,7 @@ PLANNED = -1      # MI_MLA_SPLITS_PLANNED: the device-built, length-aware work l
 @pytest.mark.parametrize("splits", [1, 3, PLANNED])
 def test_against_reference_kernel_outputs(path, splits, wide_variant):
     z = np.load(path)
-    if wide_variant == 8 and z["q"].shape[1] // z["k_nope"].shape[2] <= 64:
+    if wide_variant >= 8 and z["q"].shape[1] // z["k_nope"].shape[2] <= 64:
         pytest.skip("64-head kernel: one form")
     t = lambda k: torch.from_numpy(z[k]).cuda()
     got = run_mla(t("q"), t("k_nope"), t("k_rope"), t("kv_seq_lens"), t("block_table"), float(z["sm_scale"]), splits)
@@ -93,7 +94,7 @@ CASES = [  # B, Hq, Hkv, S, page, ragged
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("splits", [0, 1, 2, PLANNED])
 def test_against_oracle(B, Hq, Hkv, S, page, ragged, dtype, splits, wide_variant):
-    if wide_variant == 8 and Hq // Hkv <= 64:
+    if wide_variant >= 8 and Hq // Hkv <= 64:
         pytest.skip("64-head kernel: one form")
     torch.manual_seed(2)
     maxp = (S + page - 1) // page
