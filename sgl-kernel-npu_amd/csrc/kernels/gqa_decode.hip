@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "gqa_wide.h"
 #include "mi_sgl_kernels.h"
 
 namespace mi_gqa {
@@ -543,6 +544,51 @@ static int gqa_decode_impl(const void *q, const void *k, const void *v, void *ou
     if ((num_splits > 1 || planned) &&
         (!workspace || workspace_bytes < mi_gqa_decode_workspace(batch, q_heads, v_dim, planned ? MI_MLA_SPLITS_PLANNED : num_splits)))
         return MI_SGL_EINVAL;
+    // Large kv groups (more than 64 query heads per kv head) with head dims up to (288, 256): the eight-wave LDS-DMA kernel of
+    // gqa_decode_wide.hip -- one heavy workgroup per CU, so the split count is the MLA kernels' (fill the CUs once), never more than asked for.
+    if (!sinks && window < 0 && !bt_rows &&
+        mi_gqa_wide::applies(q_heads / kv_heads, k_dim, v_dim, page_size, k_stride_blk, k_stride_row, v_stride_blk, v_stride_row)) {
+        mi_gqa_wide::Params w;
+        w.q = (const uint16_t *)q, w.k = (const uint16_t *)k, w.v = (const uint16_t *)v, w.out = (uint16_t *)out;
+        w.seq_lens = kv_seq_lens, w.block_table = block_table;
+        w.batch = batch, w.q_heads = q_heads, w.kv_heads = kv_heads, w.group = q_heads / kv_heads, w.page_size = page_size;
+        w.bt_stride = bt_stride, w.lk = k_dim, w.lv = v_dim;
+        w.q_sb = q_stride_b, w.q_sh = q_stride_h, w.k_sblk = k_stride_blk, w.k_srow = k_stride_row, w.k_sh = k_stride_h;
+        w.v_sblk = v_stride_blk, w.v_srow = v_stride_row, w.v_sh = v_stride_h, w.o_sb = o_stride_b, w.o_sh = o_stride_h;
+        w.sm_scale = sm_scale, w.plan = nullptr;
+        const int head_blocks = (w.group + 127) / 128;
+        hipStream_t st = (hipStream_t)stream;
+        if (!planned) {
+            const long long wgs = (long long)batch * kv_heads * head_blocks;
+            const int ntiles = (max_seq_len + mi_gqa_wide::kTile - 1) / mi_gqa_wide::kTile, cap = ntiles / 8 > 1 ? ntiles / 8 : 1;   // >= 256 keys per split
+            const int fill = (int)std::min<long long>(std::min<long long>((gqa_cus() + wgs - 1) / wgs, cap), 64);
+            num_splits = std::max(1, std::min(num_splits, fill));
+        }
+        w.num_splits = num_splits;
+        w.ws_o = (float *)workspace;
+        w.ws_ml = w.ws_o ? w.ws_o + (planned ? gqa_plan_rows_cap(batch, q_heads) : (size_t)batch * q_heads * num_splits) * mi_gqa_wide::kDVP : nullptr;
+        long long units = (long long)batch * kv_heads * num_splits;
+        if (planned) {
+            const int workers = std::max(1, gqa_cus() / head_blocks);
+            int32_t *plan = (int32_t *)(w.ws_ml + gqa_plan_rows_cap(batch, q_heads) * 2);
+            mi_sgl::decode_plan_kernel<<<1, 1024, 0, st>>>(kv_seq_lens, batch, kv_heads, mi_gqa_wide::kTile, 1, workers, plan);
+            w.plan = plan;
+            w.num_splits = num_splits = 1;
+            units = mi_sgl::plan_items_max((long long)batch * kv_heads, workers);
+        }
+        mi_gqa_wide::launch(w, dtype, units, st);
+        if (num_splits > 1 || planned) {
+            GqaParams m{};                                       // the merge kernel reads the partial layout the wide kernel wrote (row = kDVP floats)
+            m.out = (uint16_t *)out, m.ws_o = w.ws_o, m.ws_ml = w.ws_ml, m.batch = batch, m.q_heads = q_heads, m.kv_heads = kv_heads;
+            m.group = w.group, m.num_splits = num_splits, m.lv = v_dim, m.o_sb = o_stride_b, m.o_sh = o_stride_h, m.plan = w.plan;
+            m.sinks = nullptr, m.window = -1, m.bt_rows = nullptr;
+            const long long bh = (long long)batch * q_heads;
+            const int blocks = (int)((bh + 3) / 4);
+            if (dtype == MI_DTYPE_BF16) gqa_merge_kernel<true><<<blocks, 256, 0, st>>>(m, mi_gqa_wide::kDVP);
+            else gqa_merge_kernel<false><<<blocks, 256, 0, st>>>(m, mi_gqa_wide::kDVP);
+        }
+        return hipGetLastError() == hipSuccess ? MI_SGL_OK : MI_SGL_ELAUNCH;
+    }
     GqaParams p;
     p.plan = nullptr;
     p.q = (const uint16_t *)q, p.k = (const uint16_t *)k, p.v = (const uint16_t *)v;

@@ -1,0 +1,454 @@
+// Paged GQA decode for large kv groups: ALL (up to 128) query heads of a kv head in one workgroup, head dims up to (288, 256) -- the
+// reference test's own (batch, 128 q heads, 1 kv head, 288 / 256) shape (tests/python/sgl_kernel_npu/test_decode_attention.py:239-244),
+// which the generic kernel (gqa_decode.hip: four waves, register-staged 64-key tiles, one tile in flight) ran at 0.15 of HBM.
+// Reference replaced: python/sgl_kernel_npu/sgl_kernel_npu/attention/decode_attention.py:233-450 (same math: fp32 scores, softmax in
+// fp32, P rounded to the cache dtype before P.V, out = acc / l).
+//
+// Structure = mla_decode_wide8s.hip with a separate V tile: eight waves (two per SIMD), 32-key tiles filled by LDS-DMA
+// (global_load_lds_dwordx4, one cache row per instruction: 36 lanes of a 288-dim K row, 32 of a 256-dim V row) into a ring of four slots of
+// K[32][608 B] + V[32][544 B] (rows padded by 32 B: both operand fetch patterns are conflict-free); a tile lies inside ONE page
+// (power-of-two pages of >= 32 keys), so its block id is one scalar load and every row address scalar arithmetic; two tiles in flight.
+//   QK^T + softmax by HEAD: wave w owns heads 16 w .. +15; S^T[32 keys, 16 heads] = K . Q^T, 9 k-steps x 2 key blocks on
+//     v_mfma_f32_16x16x32 (A = K rows, ds_read_b128; B = Q^T, 36 registers).
+//   P . V by OUTPUT DIMENSION: wave w owns 32 of the 256 dims for all 128 heads (4 accumulator blocks of 32 dims x 32 heads on
+//     v_mfma_f32_32x32x16, 64 registers); P^T crosses from the head owners to the dimension owners through an 8 KB LDS buffer.
+// Per tile and CU: 1088 MFMA cycles against ~3700 cycles of fill at the rate the memory system sustains -- HBM-bound by construction.
+// Softmax: ONLINE with a lazy reference.  The reference m of a head moves only when a tile's maximum exceeds it by more than 8 (log2
+// domain: P <= 256 fits both cache dtypes and fp32 sums with room to spare); the head's owner then publishes alpha = 2^(m_old - m_new)
+// for the dimension owners, who rescale their accumulators behind the tile's second barrier -- for random data that happens in the first
+// tiles only, and a tile in which no head moved costs one broadcast LDS read.  Exact in exact arithmetic (any reference cancels in acc / l).
+#include "device_once.h"
+#include "decode_plan.h"
+#include "gqa_wide.h"
+#include "mi_sgl_kernels.h"
+
+#ifndef GQAW_DMA_EVERY
+#define GQAW_DMA_EVERY 2       // 18 QK^T MFMAs per tile and wave, 8 (4 for a V view) DMA operations
+#endif
+
+namespace mi_gqa_wide {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kT = kTile, kSlots = 4, kLead = 2;
+constexpr int KS = kDKP * 2 + 32, VS = kDVP * 2 + 32;                      // 608, 544 bytes per LDS row
+constexpr int kSlotBytes = kT * (KS + VS);                                 // 36864
+constexpr int kVOff = kT * KS;                                             // V tile inside a slot
+constexpr int kPxOff = kSlots * kSlotBytes;                                // P^T exchange buffer [head block 4][k-step 2][lane 64] x 16 B
+constexpr int kPxBytes = 8192;
+constexpr int kAlphaOff = kPxOff + kPxBytes;                               // float alpha[128]: accumulator rescale of a head in the current tile
+constexpr int kMovedOff = kAlphaOff + 512;                                 // uint32 moved[8]: tile + 1 of the last tile in which wave w moved a reference
+constexpr int kLds = kMovedOff + 32;                                       // 156192
+constexpr int kQS = kDKP / 32;                                             // 9 k-steps
+constexpr float kLazy = 8.0f;
+static_assert(kLds <= 160 * 1024, "LDS budget");
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)
+{
+    if constexpr (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c)
+{
+    if constexpr (BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <bool BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi)
+{
+    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+// maxima / sums over the four 16-lane rows of a wave (lanes of one head): v_permlane16_swap / v_permlane32_swap, no LDS round trip
+__device__ __forceinline__ float max_over_rows(float x)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    u32x2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_over_rows(float x)
+{
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    u32x2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// LDS-DMA through inline asm (no compiler-tracked vector memory operation in the tile loop; ordering = the explicit s_waitcnt at the top
+// of a tile).  M0 = wave-uniform LDS destination; active lane l: 16 B from sbase + voff -> dst + 16 l.
+__device__ __forceinline__ void dma16(uint32_t dst, const void *sbase, uint32_t voff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t opaque(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+struct Ctx {
+    const Params *p;
+    int b, seq_len, wave, ntiles, page_shift;
+    uint32_t lane16;
+    const uint16_t *k_base, *v_base;
+};
+struct TileAt {
+    const uint16_t *k, *v;             // first row of the tile in the K / V cache
+    int last;                          // index (0..31) of the tile's last valid key (rows behind it re-read that row: finite bytes under P = 0)
+};
+__device__ __forceinline__ int tile_clamped(const Ctx &c, int tile) { return min(tile, c.ntiles - 1); }
+__device__ __forceinline__ const int32_t *block_id_ptr(const Ctx &c, int tile)
+{
+    return c.p->block_table + ((int64_t)c.b * c.p->bt_stride + ((tile_clamped(c, tile) * kT) >> c.page_shift));
+}
+// the block id of a tile: a scalar load the compiler does not see (see mla_decode_wide8s.hip: a load it tracks would wait vmcnt(0))
+__device__ __forceinline__ int block_id_request(const Ctx &c, int tile)
+{
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(block_id_ptr(c, tile)) : "memory");
+    return v;
+}
+__device__ __forceinline__ void block_id_wait(int &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)::"memory"); }
+__device__ __forceinline__ TileAt tile_of(const Ctx &c, int tile, int blk)
+{
+    const int t = tile_clamped(c, tile);
+    const uint32_t row0 = (uint32_t)(t * kT) & (uint32_t)(c.p->page_size - 1);
+    TileAt r;
+    r.k = c.k_base + ((int64_t)blk * c.p->k_sblk + (int64_t)((uint64_t)row0 * (uint64_t)c.p->k_srow));
+    r.v = c.v_base + ((int64_t)blk * c.p->v_sblk + (int64_t)((uint64_t)row0 * (uint64_t)c.p->v_srow));
+    r.last = min(kT - 1, c.seq_len - 1 - t * kT);
+    return r;
+}
+// operation idx 0..3: K row wave + 8 idx; 4..7: V row wave + 8 (idx - 4) (none when V is a column prefix of the K rows: the P.V operand is
+// then read from the K tile, like the MLA kernels do).  One cache row per instruction; `slot` = LDS byte address
+__device__ __forceinline__ void issue_op(const Ctx &c, const TileAt &tl, uint32_t slot, int idx)
+{
+    const int r = c.wave + 8 * (idx & 3), row = __builtin_amdgcn_readfirstlane(min(r, tl.last));      // (keeps the address arithmetic scalar)
+    if (idx < 4) {
+        if (c.lane16 < (uint32_t)c.p->lk * 2u) dma16(slot + (uint32_t)(r * KS), tl.k + (int64_t)row * c.p->k_srow, c.lane16);
+    } else {
+        if (c.lane16 < (uint32_t)c.p->lv * 2u) dma16(slot + (uint32_t)(kVOff + r * VS), tl.v + (int64_t)row * c.p->v_srow, c.lane16);
+    }
+}
+
+template <int N> struct SlotTag { static constexpr int value = N; };
+
+// VIEW: the V cache is the first lv columns of the K rows (same pointer and strides -- the reference test builds exactly that,
+// test_decode_attention.py:74): one fill serves both GEMMs
+template <bool BF16, bool VIEW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gqa_decode_wide_kernel(Params p)
+{
+    constexpr int kOps = VIEW ? 4 : 8;                          // DMA operations per wave and tile: 4 K rows (+ 4 V rows)
+    constexpr int VSx = VIEW ? KS : VS, kVBase = VIEW ? 0 : kVOff;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h16 = lane & 15, g = lane >> 4;                  // QK^T / softmax role: head h16 of the wave's 16, key group g
+    const int c32 = lane & 31, kg = lane >> 5;                 // P.V role: head c32 of a 32-head block, key half kg
+    const int head_blocks = (p.group + 127) / 128;
+    // sibling head blocks of a unit share an XCD (workgroup i runs on XCD i mod 8): the second reader of a tile hits that XCD's L2
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int unit = (jj / head_blocks) * 8 + xcd, hblk = jj % head_blocks;
+    int split, nsplits, seq, t_begin, t_end;
+    if (p.plan) {
+        const mi_sgl::PlanItem it = mi_sgl::plan_item(p.plan, (long long)p.batch * p.kv_heads, unit);
+        if (unit >= __builtin_amdgcn_readfirstlane(p.plan[0]) || it.seq < 0) return;      // behind the list
+        seq = it.seq, split = it.k, nsplits = it.n, t_begin = it.t_begin, t_end = it.t_end;
+    } else {
+        if (unit >= p.batch * p.kv_heads * p.num_splits) return;
+        split = unit % p.num_splits, nsplits = p.num_splits, seq = unit / p.num_splits;
+        t_begin = t_end = 0;
+    }
+    const int kvh = seq % p.kv_heads, b = seq / p.kv_heads;
+    const int seq_len = __builtin_amdgcn_readfirstlane(p.seq_lens[b]);
+    const int ntiles = (seq_len + kT - 1) / kT;
+    if (p.plan) {                                               // clamped to the sequence as it is now; the last piece runs to its end
+        t_begin = min(t_begin, ntiles);
+        t_end = split == nsplits - 1 ? ntiles : min(t_end, ntiles);
+    } else {
+        const int tps = (ntiles + p.num_splits - 1) / p.num_splits;
+        t_begin = split * tps;
+        t_end = min(ntiles, t_begin + tps);
+    }
+    const int hg = hblk * 128 + wave * 16 + h16;
+    const bool head_ok = hg < p.group;
+    const bool wave_active = hblk * 128 + wave * 16 < p.group;  // wave-uniform; idle waves still feed the DMA and own a P.V slice
+    const int head = kvh * p.group + hg;
+    if (__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds) != 0u) __builtin_trap();
+    const Ctx cx{&p, b, seq_len, wave, ntiles, __builtin_ctz(p.page_size), (uint32_t)lane * 16u, p.k + (int64_t)kvh * p.k_sh, p.v + (int64_t)kvh * p.v_sh};
+
+    // head dims below the padded (288, 256): the pad columns of the slots are never a DMA target and must read as zero under the zero tail of
+    // Q^T (K) -- a stale NaN times zero is NaN -- and as anything finite under the discarded output dims (V)
+    if (p.lk < kDKP || p.lv < kDVP) {
+        for (int i = threadIdx.x * 16; i < kSlots * kSlotBytes; i += 512 * 16) *(u32x4 *)(lds + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
+    int blk_next = 0;                                           // block id of tile t + lead, t = the tile at whose top it is read
+    if (t_begin < t_end) {                                      // prologue: tiles t_begin, t_begin + 1 -> slots 0, 1, before the Q^T loads
+        int id0 = block_id_request(cx, t_begin), id1 = block_id_request(cx, t_begin + 1);
+        blk_next = block_id_request(cx, t_begin + kLead);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id0), "+s"(id1), "+s"(blk_next)::"memory");
+        const int ids[kLead] = {id0, id1};
+#pragma unroll
+        for (int d = 0; d < kLead; ++d) {
+            const TileAt tl = tile_of(cx, t_begin + d, ids[d]);
+#pragma unroll
+            for (int i = 0; i < kOps; ++i) issue_op(cx, tl, (uint32_t)(d * kSlotBytes), i);
+        }
+    }
+    // Q^T fragments (B operand of 16x16x32): lane (h16, g) holds q[head][32 ks + 8 g .. +8], zero behind lk
+    s16x8 qf[kQS];
+    {
+        const uint16_t *qrow = p.q + (int64_t)b * p.q_sb + (int64_t)(head_ok ? head : 0) * p.q_sh;
+#pragma unroll
+        for (int ks = 0; ks < kQS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            qf[ks] = (head_ok && d < p.lk) ? *(const s16x8 *)(qrow + d) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float m_ref = -INFINITY, l_run = 0.f;
+    if (threadIdx.x < 8) ((uint32_t *)(lds + kMovedOff))[threadIdx.x] = 0;
+    const float cs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.sm_scale * 1.4426950408889634f)));
+    __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): Q^T resident (and the prologue fill): nothing the compiler tracks is pending
+    __syncthreads();                                            // moved[] cleared before anybody reads it
+
+    const uint32_t lane16 = cx.lane16;
+    // ---- O^T[d, head] += V^T . P^T: wave w owns dims 128 (w >> 2) + 16 (w & 3) + {0..15, 64..79}: MFMA row m = dim 128 (w >> 2) + 64 (m >> 4)
+    // + 16 (w & 3) + (m & 15) (the 32-lane transposed fetch then tiles the 64 banks under the 544- and the 608-byte row stride); accumulator block hb =
+    // those 32 dims x heads 32 hb .. +31.  Starts behind barrier B.
+    const int c16 = lane & 15, q16 = (lane >> 4) & 1;
+    const uint32_t v_lane = (uint32_t)(kVBase + (4 * kg + (c16 >> 2)) * VSx + (wave >> 2) * 256 + (wave & 3) * 32 + q16 * 128 + (c16 & 3) * 8);
+    auto pv = [&](auto slot_tag, int t) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        // references that moved in this tile: rescale the accumulators of those heads first (wave-uniform test, one broadcast read)
+        {
+            const u32x4 m0 = *(const u32x4 *)(lds + kMovedOff), m1 = *(const u32x4 *)(lds + kMovedOff + 16);
+            const uint32_t mv[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+#pragma unroll
+            for (int hb = 0; hb < 4; ++hb) {
+                // (the two waves of a head block move independently: the alpha entries of the one that did not move are stale)
+                const bool lo_moved = __builtin_amdgcn_readfirstlane(mv[2 * hb]) == (uint32_t)(t + 1);
+                const bool hi_moved = __builtin_amdgcn_readfirstlane(mv[2 * hb + 1]) == (uint32_t)(t + 1);
+                if (lo_moved || hi_moved) {
+                    const float a = ((c32 < 16) ? lo_moved : hi_moved) ? ((const float *)(lds + kAlphaOff))[hb * 32 + c32] : 1.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[hb][r] *= a;
+                }
+            }
+        }
+        const uint8_t *vlo = lds + SLOT * kSlotBytes + v_lane;
+        const uint8_t *pb = lds + kPxOff + opaque(lane16);
+        auto lda = [&](int kk) -> s16x8 {                      // keys 16 kk + {4 kg + 0..3, 8 + 4 kg + 0..3}
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + kk * 16 * VSx));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + kk * 16 * VSx + 8 * VSx));
+            return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto ldp = [&](int hb, int kk) -> s16x8 { return *(const s16x8 *)(pb + (hb * 2 + kk) * 1024); };
+        const s16x8 a0 = lda(0), a1 = lda(1);
+        s16x8 pf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pf[i] = ldp(i & 3, i >> 2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i & 3] = mfma32<BF16>(i < 4 ? a0 : a1, pf[i], acc[i & 3]);
+    };
+    // top of tile t: this wave's operations of t have landed (the 8 of tile t + 1 may be in flight), barrier A: tile t complete in LDS,
+    // everybody done with tile t - 1 and with the exchange buffer
+    auto tile_top = [&](int t) -> TileAt {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps * (kLead - 1)) : "memory");
+        __syncthreads();
+        return tile_of(cx, t + kLead, blk_next);
+    };
+    auto pv_and_next_id = [&](auto slot_tag, int t) {
+        int id = block_id_request(cx, t + 1 + kLead);
+        pv(slot_tag, t);
+        block_id_wait(id);
+        blk_next = id;
+    };
+    const int hbw = wave >> 1;                                  // exchange-buffer coordinates of this wave's P^T pieces: consumer lane
+    const int lc = (g & 1) * 32 + (wave & 1) * 16 + h16;        // (kg = g & 1, c32 = 16 (w & 1) + h16), half g >> 1 of its 16 bytes
+    const uint32_t pdst_off = (uint32_t)(kPxOff + (hbw * 2 * 64 + lc) * 16 + (g >> 1) * 8);
+    const uint32_t a_lane = (uint32_t)(h16 * KS + g * 16);
+
+    auto body = [&](auto slot_tag, int t) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr uint32_t nslot = (uint32_t)(((SLOT + kLead) % kSlots) * kSlotBytes);
+        const TileAt tl = tile_top(t);
+        if (!wave_active) {                                     // no heads of its own: DMA share, P = 0 (written once, below), P.V slice
+#pragma unroll
+            for (int i = 0; i < kOps; ++i) issue_op(cx, tl, nslot, i);
+            asm volatile("s_barrier" ::: "memory");              // barrier B
+            pv_and_next_id(slot_tag, t);
+            return;
+        }
+        // ---- S^T[key, head] = K . Q^T: 9 k-steps x 2 key blocks of 16, operand fragments three MFMAs ahead, a DMA operation every
+        // GQAW_DMA_EVERY MFMAs (0: all of them in front of the first MFMA)
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const uint8_t *abase = lds + SLOT * kSlotBytes + a_lane;
+            auto lda = [&](int step) -> s16x8 { return *(const s16x8 *)(abase + (step & 1) * 16 * KS + (step >> 1) * 64); };
+            constexpr int kAhead = 3, kRing = kAhead + 1, kEvery = GQAW_DMA_EVERY;
+            if constexpr (kEvery == 0)
+#pragma unroll
+                for (int i = 0; i < kOps; ++i) issue_op(cx, tl, nslot, i);
+            s16x8 af[kRing];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pre = 0; pre < kAhead; ++pre) af[pre] = lda(pre);
+#pragma unroll
+            for (int step = 0; step < 2 * kQS; ++step) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + kAhead < 2 * kQS) af[(step + kAhead) % kRing] = lda(step + kAhead);
+                __builtin_amdgcn_sched_barrier(0);
+                if (step & 1) s1 = mfma16<BF16>(af[step % kRing], qf[step >> 1], s1);
+                else s0 = mfma16<BF16>(af[step % kRing], qf[step >> 1], s0);
+                if constexpr (kEvery > 0)
+                    if (step % kEvery == kEvery - 1 && step / kEvery < kOps) issue_op(cx, tl, nslot, step / kEvery);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // lane (h16, g) holds head h16, keys 16 kb + 4 g + i.  Only the tile that crosses seq_len needs the mask.
+        if ((t + 1) * kT > seq_len) {
+            const int kbase = t * kT + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (kbase + i >= seq_len) s0[i] = -INFINITY;
+                if (kbase + 16 + i >= seq_len) s1[i] = -INFINITY;
+            }
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        tmax = max_over_rows(tmax) * cs;                        // sm_scale > 0: max commutes with the scaling; a tile below the end holds a key
+        const bool move = tmax > m_ref + kLazy || m_ref == -INFINITY;
+        if (__any(move)) {
+            const float a = move ? (m_ref == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_ref - tmax)) : 1.f;
+            if (move) m_ref = tmax;
+            l_run *= a;
+            if (t != t_begin) {                                 // (first tile: the accumulators are zero, nobody needs alpha)
+                if (g == 0) ((float *)(lds + kAlphaOff))[wave * 16 + h16] = a;
+                if (lane == 0) ((uint32_t *)(lds + kMovedOff))[wave] = (uint32_t)(t + 1);
+            }
+        }
+        const float nm = -m_ref;
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], cs, nm));
+            e[4 + i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], cs, nm));
+        }
+        l_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+        uint8_t *pdst = lds + pdst_off;
+        *(uint2 *)(pdst) = uint2{pack2<BF16>(e[0], e[1]), pack2<BF16>(e[2], e[3])};
+        *(uint2 *)(pdst + 1024) = uint2{pack2<BF16>(e[4], e[5]), pack2<BF16>(e[6], e[7])};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");                   // barrier B: P^T(t), alpha, moved complete
+        pv_and_next_id(slot_tag, t);
+    };
+    if (!wave_active) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) *(uint2 *)(lds + pdst_off + kb * 1024) = uint2{0u, 0u};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int t = t_begin; t < t_end;) {
+        body(SlotTag<0>{}, t);
+        if (++t >= t_end) break;
+        body(SlotTag<1>{}, t);
+        if (++t >= t_end) break;
+        body(SlotTag<2>{}, t);
+        if (++t >= t_end) break;
+        body(SlotTag<3>{}, t);
+        ++t;
+    }
+    l_run = sum_over_rows(l_run);                               // the four key groups of a head
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // fills issued past the last tile
+    __syncthreads();
+
+    // ---- epilogue: acc[hb][4 rq + i] = O^T[d][head 32 hb + c32], d = 128 (w >> 2) + 64 (rq >> 1) + 16 (w & 3) + 8 (rq & 1) + 4 kg + i; the
+    // softmax statistics of a head live in the wave that owns it and reach the others through LDS
+    float *lmb = (float *)(lds + kPxOff);                      // [0..127] l, [128..255] m
+    if (g == 0) {
+        lmb[wave * 16 + h16] = wave_active ? l_run : 0.f;
+        lmb[128 + wave * 16 + h16] = wave_active ? m_ref : -INFINITY;
+    }
+    __syncthreads();
+    const int dbase = (wave >> 2) * 128 + (wave & 3) * 16 + 4 * kg;
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+        const int hgx = hblk * 128 + hb * 32 + c32;
+        if (hgx >= p.group) continue;
+        const int headx = kvh * p.group + hgx;
+        if (nsplits == 1) {
+            const float l_h = lmb[hb * 32 + c32];
+            const float inv = l_h > 0.f ? 1.f / l_h : 0.f;
+            uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
+                if (d >= p.lv) continue;                       // lv % 8 == 0: the 4 dims are in or out together
+                *(uint2 *)(orow + d) = uint2{pack2<BF16>(acc[hb][4 * rq + 0] * inv, acc[hb][4 * rq + 1] * inv),
+                                            pack2<BF16>(acc[hb][4 * rq + 2] * inv, acc[hb][4 * rq + 3] * inv)};
+            }
+        } else {
+            const int64_t idx = p.plan ? (int64_t)unit * p.group + hgx : ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
+            float *po = p.ws_o + idx * kDVP;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
+                *(f32x4 *)(po + d) = f32x4{acc[hb][4 * rq + 0], acc[hb][4 * rq + 1], acc[hb][4 * rq + 2], acc[hb][4 * rq + 3]};
+            }
+            if (wave == 0 && kg == 0) {
+                p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + c32];
+                p.ws_ml[idx * 2 + 1] = lmb[hb * 32 + c32];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool applies(int group, int lk, int lv, int page_size, int64_t k_sblk, int64_t k_srow, int64_t v_sblk, int64_t v_srow)
+{
+    static const bool allow = !(getenv("MI_GQA_WIDE") && atoi(getenv("MI_GQA_WIDE")) == 0);
+    auto fits = [](int64_t v, int bits) { return v >= 0 && v < (1ll << bits); };
+    return allow && group > 64 && lk > 192 && lk <= kDKP && lv <= kDVP && (lk % 8) == 0 && (lv % 8) == 0 && (page_size & (page_size - 1)) == 0 &&
+           page_size >= kTile && fits(k_sblk, 40) && fits(v_sblk, 40) && fits(k_srow, 31) && fits(v_srow, 31);
+}
+
+void launch(const Params &p, int dtype, long long units, hipStream_t st)
+{
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    }
+    const int head_blocks = (p.group + 127) / 128;
+    dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
+    const bool view = p.v == p.k && p.v_sblk == p.k_sblk && p.v_srow == p.k_srow && p.v_sh == p.k_sh && p.lv <= p.lk;
+    if (dtype == MI_DTYPE_BF16) {
+        if (view) gqa_decode_wide_kernel<true, true><<<grid, 512, kLds, st>>>(p);
+        else gqa_decode_wide_kernel<true, false><<<grid, 512, kLds, st>>>(p);
+    } else {
+        if (view) gqa_decode_wide_kernel<false, true><<<grid, 512, kLds, st>>>(p);
+        else gqa_decode_wide_kernel<false, false><<<grid, 512, kLds, st>>>(p);
+    }
+}
+
+}  // namespace mi_gqa_wide

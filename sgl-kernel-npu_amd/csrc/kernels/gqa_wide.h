@@ -1,0 +1,29 @@
+// Paged GQA decode for LARGE kv groups (65..128 query heads per kv head and workgroup) with head dims up to (288, 256): gqa_decode_wide.hip.
+// The generic kernel (gqa_decode.hip) serves everything else.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi_gqa_wide {
+
+constexpr int kTile = 32;             // keys per tile (the unit of the work list)
+constexpr int kDKP = 288, kDVP = 256; // padded head dims of the one instance
+
+struct Params {
+    const uint16_t *q, *k, *v;
+    uint16_t *out;
+    const int32_t *seq_lens, *block_table;
+    float *ws_o;      // [rows][kDVP] fp32 partial (unnormalised) outputs
+    float *ws_ml;     // [rows][2]    softmax reference (scaled log2 domain), sum
+    int batch, q_heads, kv_heads, group, page_size, bt_stride, num_splits, lk, lv;
+    int64_t q_sb, q_sh, k_sblk, k_srow, k_sh, v_sblk, v_srow, v_sh, o_sb, o_sh;
+    float sm_scale;
+    const int32_t *plan;          // decode_plan.h work list in 32-key tiles; null = uniform num_splits
+};
+
+// applies to: 64 < group, lk <= 288, lv <= 256 (multiples of 8), power-of-two pages of >= 32 keys, row strides whose in-page offsets fit 32 bits
+bool applies(int group, int lk, int lv, int page_size, int64_t k_sblk, int64_t k_srow, int64_t v_sblk, int64_t v_srow);
+// units: (sequence, kv head, split) triples of the uniform form, or the work list's item bound
+void launch(const Params &p, int dtype, long long units, hipStream_t st);
+
+}  // namespace mi_gqa_wide

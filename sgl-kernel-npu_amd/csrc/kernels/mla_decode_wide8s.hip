@@ -137,7 +137,7 @@ __device__ __forceinline__ void issue_piece(const CtxS &c, const TileS &tl, uint
     if (!prologue) return;
 #endif
     if (idx < 4) {
-        const int row = min(c.wave + 8 * idx, tl.last);
+        const int row = __builtin_amdgcn_readfirstlane(min(c.wave + 8 * idx, tl.last));      // (keeps the address arithmetic scalar)
         dma16(slot + (uint32_t)((c.wave + 8 * idx) * kNopeStride), tl.kn + (uint32_t)row * c.kn_srow, c.lane16);
     } else {
         const uint32_t lane = opaque(c.lane16) >> 4;

@@ -100,6 +100,12 @@ CASES = [  # B, Hq, Hkv, Lk, Lv, S, page, ragged, v_is_view
     (1, 40, 1, 192, 128, 333, 64, False, False),      # group of 40: partially filled head blocks
     (2, 16, 2, 256, 256, 1, 64, False, False),        # single key
     (1, 256, 1, 128, 128, 140, 64, False, False),     # group > 128: two workgroups per unit
+    # large kv groups with dims in (192, 288] x <= 256 on power-of-two pages >= 32: the eight-wave kernel of gqa_decode_wide.hip
+    (3, 128, 1, 288, 256, 700, 64, True, False),      # independent V cache, several tiles per split, ragged
+    (2, 96, 1, 256, 256, 330, 32, True, False),       # 96 heads: two idle head waves; K rows narrower than the padded 288 (zeroed pad columns)
+    (1, 256, 2, 288, 128, 200, 64, True, False),      # two kv heads of 128; V narrower than the padded 256
+    (2, 200, 1, 224, 200, 97, 128, True, False),      # two head blocks (128 + 72 heads), odd dims (multiples of 8), S < page
+    (2, 128, 1, 288, 256, 1, 64, False, True),        # a single key
 ]
 
 
@@ -320,3 +326,55 @@ def test_planned_work_list_and_outputs_match_one_piece_per_sequence(B, Hq, Hkv, 
     nz = lens.cpu() > 0
     assert not torch.isnan(got.float()[nz]).any()
     assert torch.allclose(got.float()[nz], one.float()[nz], rtol=2 ** -7, atol=2e-3), (got.float()[nz] - one.float()[nz]).abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("splits", [1, 2, PLANNED])
+def test_wide_kernel_moves_its_softmax_reference(dtype, splits):
+    """gqa_decode_wide.hip keeps a LAZY softmax reference per head (it moves only when a tile's maximum exceeds it by > 8 in the log2 domain, the
+    head's owner then publishes the accumulator rescale for the dimension owners).  Scores that keep growing along the sequence -- and heads
+    that grow at different rates, so that in most tiles only SOME waves move -- must still give the exact softmax."""
+    torch.manual_seed(4)
+    B, Hq, Lk, Lv, S, page = 2, 128, 288, 256, 640, 64
+    maxp = S // page
+    q = torch.randn((B, Hq, Lk)).to(dtype)
+    k = torch.randn((B * maxp, page, 1, Lk)).to(dtype)
+    v = torch.randn((B * maxp, page, 1, Lv)).to(dtype)
+    bt = torch.arange(B * maxp, dtype=torch.int32).reshape(B, maxp)
+    lens = torch.tensor([S, S - 75], dtype=torch.int32)
+    # key n of a sequence gets a component along a fixed direction that grows with n; head h looks along it with weight ~ h
+    u = torch.randn(Lk)
+    u /= u.norm()
+    ramp = torch.linspace(0, 60, S)
+    kk = k.float().reshape(B, S, Lk) + ramp[None, :, None] * u[None, None, :]
+    k = kk.reshape(B * maxp, page, 1, Lk).to(dtype)
+    q = (q.float() + (torch.arange(Hq).float()[None, :, None] / Hq * 6.0) * u[None, None, :]).to(dtype)
+    sm = 1.0 / Lk ** 0.5
+    want = OK.decode_gqa(q, k, v, lens, bt, sm)
+    got = run_gqa(q.cuda(), k.cuda(), v.cuda(), lens.cuda(), bt.cuda(), sm, splits).cpu()
+    assert not torch.isnan(got.float()).any()
+    check(got, want, exact_fp64(q, k, v, lens, bt, sm), dtype)
+
+
+def test_wide_kernel_full_size_vs_fp32():
+    """The reference test's own shape at serving size (test_decode_attention.py:242: 128 q heads on 1 kv head, 288 / 256): batch 128, 4096 keys,
+    ragged, random page table; sampled rows against an fp32 evaluation on the GPU."""
+    B, Hq, D, Dv, S, page = 128, 128, 288, 256, 4096, 64
+    maxp = S // page
+    nb = B * maxp
+    g = torch.Generator(device="cuda").manual_seed(6)
+    q = torch.randn((B, Hq, D), generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn((nb, page, 1, D), generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn((nb, page, 1, Dv), generator=g, device="cuda").to(torch.bfloat16)
+    bt = torch.randperm(nb, device="cuda").to(torch.int32).reshape(B, maxp)
+    lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+    lens[0] = S
+    for splits in (0, PLANNED):
+        got = run_gqa(q, k, v, lens, bt, D ** -0.5, splits)
+        for b in (0, 57, 127):
+            L = int(lens[b])
+            idx = bt[b, :(L + page - 1) // page].long()
+            K = k[idx, :, 0].reshape(-1, D)[:L].float()
+            V = v[idx, :, 0].reshape(-1, Dv)[:L].float()
+            ref = torch.softmax((q[b].float() @ K.T) * D ** -0.5, -1) @ V
+            assert torch.allclose(got[b].float(), ref, atol=1e-3, rtol=2 ** -7), (splits, b, (got[b].float() - ref).abs().max())
