@@ -33,7 +33,10 @@ def test_bench_two_ranks_one_gpu():
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["strategy"] == "default" and d["validated_round_trip"] is True
-    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+    # N > 1: the top-level roofline is the link-facing leg (the HBM-side kernel of the N = 1 line rides along as `hbm_side`)
+    rf = d["roofline"]
+    assert rf["bound"] == "xgmi" and rf["unit"] == "GB/s" and rf["peak"] > 0 and rf["achieved"] > 0 and 0 < rf["frac"]
+    assert rf["kernel"] in ("combine_push", d["xgmi"]["dispatch_kernel"]) and rf["hbm_side"]["bound"] == "hbm"
     # N > 1: both dispatch transports timed with the same K steps, the cross-GPU legs priced per leg and per link, C3 / C5 emitted
     assert set(d["transports"]) == {"push", "pull"} and d["config"]["dispatch_transport"] in ("push", "pull")
     assert {"dispatch_frac", "combine_frac", "dispatch_max_link_bytes", "combine_max_link_bytes"} <= set(d["xgmi"])
