@@ -91,6 +91,12 @@ int mi_mla_decode_uniform_splits(int batch, int q_heads, int kv_heads, int max_s
  * waves = 4 / 8 forces one for the calls that follow, 0 returns to the default (or MI_MLA_WIDE8).  Process-wide, not thread-safe:
  * a test / tuning knob, results do not depend on it beyond fp32 summation order. */
 int mi_mla_decode_select_wide(int waves);
+/* Sequences the work list (or num_splits = 2) cuts in exactly TWO pieces finish between their two workgroups: each publishes its partial,
+ * waits (bounded) for the other's and writes one half of the output dimensions itself -- the merge launch finds nothing to do for them
+ * (BASELINE C4: batch 128 on 256 CUs).  Same sums in the same order as the merge kernel: bit-identical outputs.  mode 0 / 1 = off / on
+ * for the calls that follow, -1 = default (on; MI_MLA_PAIR=0 in the environment turns it off), 2 = on with the second piece withholding
+ * its word, so the first runs into its bounded wait and the merge kernel does the work (a test of that path).  Process-wide knob. */
+int mi_mla_decode_set_pair(int mode);
 int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *out, const int32_t *kv_seq_lens,
                   const int32_t *block_table, int batch, int q_heads, int kv_heads, int page_size, int bt_stride,
                   int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t kn_stride_blk, int64_t kn_stride_row,

@@ -37,6 +37,12 @@ struct MlaParams {
     // arrive[...]; the second one merges and, if the sequence is flagged, recomputes -- no merge launch
     uint32_t *arrive;         // [batch * kv_heads * head_blocks], values are tagged with fix_epoch (no clearing needed)
     int inline_merge;
+    // eight-wave scalar-id kernel, sequences cut in TWO pieces (BASELINE C4): the two workgroups publish their partials, meet at
+    // pair_flags[2 seq + piece] and each finishes one half of the output dimensions itself (mla_decode_wide8s.hip); the merge kernel
+    // skips such a sequence and re-arms its two words.  NULL = every cut sequence goes through the merge kernel.
+    uint64_t *pair_flags;     // [batch * kv_heads][2], a word holds pair_tag once its piece's partial is visible
+    uint64_t pair_tag;        // never 0; a scrambled call number (first use of an uninitialised workspace: 2^-64 per word)
+    int pair_withhold;        // test hook: piece 1 never raises its word, so piece 0 runs into the bounded wait (the merge kernel's turn)
     // Length-aware work list built on the device by decode_plan_kernel (decode_plan.h), NULL = the uniform num_splits form.  Layout below.
     const int32_t *plan;
 };
@@ -70,6 +76,10 @@ __device__ __forceinline__ uint16_t cvt_out(float f)
         if ((x & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC0u;
         return (uint16_t)((x + 0x7FFFu + ((x >> 16) & 1u)) >> 16);
     } else {
+        // the fp32 value is rounded to fp32 FIRST, then to fp16, wherever this is called: left alone the compiler folds a preceding
+        // multiplication into v_fma_mixlo_f16 (one rounding) in some kernels and not in others (v_mul + v_cvt_pk_f16_f32), and the
+        // same sums then differ by an fp16 ulp in a few elements per million between the in-kernel and the merge-kernel finish
+        asm volatile("" : "+v"(f));
         _Float16 a = (_Float16)f;
         return __builtin_bit_cast(uint16_t, a);
     }

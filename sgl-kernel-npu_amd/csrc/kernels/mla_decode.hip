@@ -428,6 +428,9 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
     const int64_t bh = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (bh >= (int64_t)p.batch * p.q_heads) return;
     const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
+    // the meeting words of the sequence's two pieces (mla_decode_wide8s.hip) are re-armed here, behind the launch that used them: the
+    // next call -- or the next replay of a captured one, which carries the same tag -- finds them clear
+    if (p.pair_flags && h % p.group == 0 && lane < 2) p.pair_flags[((int64_t)b * p.kv_heads + h / p.group) * 2 + lane] = 0ull;
     if (p.fix_only && p.fix_flags[b * p.kv_heads + h / p.group] == p.fix_epoch) {
         mla_recompute_head<BF16>(p, b, h, lane);
         return;
@@ -452,7 +455,12 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
         // two dependent loads per piece and pass (base[s], then the word behind it) cost ~1 us per piece: a sequence cut into 64 pieces
         // merged in 140 us, now in 8.
         const int64_t my = lane < S ? slot(lane) : 0;
-        const float m = lane < S ? p.ws_ml[my * 2] : -INFINITY, l = lane < S ? p.ws_ml[my * 2 + 1] : 0.f;
+        const float m = lane < S ? p.ws_ml[my * 2] : -INFINITY;
+        float l = lane < S ? p.ws_ml[my * 2 + 1] : 0.f;
+        // two pieces: piece hg / 64 finished this head itself (mla_decode_wide8s.hip) if its sum carries the mark (the sign); without the
+        // mark (the partner did not show up in time) both partials of the head are complete in the workspace: merge as usual
+        if (p.pair_flags && S == 2 && ((__ballot(__float_as_uint(l) >> 31) >> (hg >> 6)) & 1ull)) return;
+        l = fabsf(l);
         float M = m;
         for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
         const float w = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - M);      // m is kept in the scaled log2 domain
@@ -617,6 +625,14 @@ static int uniform_splits(int batch, int q_heads, int kv_heads, int max_seq_len)
     return s < 1 ? 1 : s;
 }
 
+static int g_pair_mode = -1;        // -1 = environment / default (on); 0 = off, 1 = on, 2 = on with piece 1 withholding its word (tests)
+extern "C" int mi_mla_decode_set_pair(int mode)
+{
+    if (mode < -1 || mode > 2) return MI_SGL_EINVAL;
+    g_pair_mode = mode;
+    return MI_SGL_OK;
+}
+
 extern "C" int mi_mla_decode_select_wide(int waves)
 {
     if (waves != 0 && waves != 4 && waves != 8 && waves != 9) return MI_SGL_EINVAL;
@@ -730,6 +746,7 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
     p.fix_epoch = ++epoch ? epoch : ++epoch;          // a stale word equal to the epoch only causes a redundant recompute
     p.fix_only = 0;
     p.arrive = p.fix_flags ? p.fix_flags + (size_t)batch * kv_heads : nullptr;       // inside the batch * q_heads flag words (wide: group > 64)
+    p.pair_flags = nullptr, p.pair_tag = 0, p.pair_withhold = 0;
     // The wide kernel finishes a one-split launch itself (slow path included): no second launch.  With two splits its
     // in-kernel merge is correct (MI_MLA_INLINE_MERGE=2 enables it) but measured 202 us against 195 us for the separate
     // merge launch at C4: the agent-scope release / acquire each pair needs costs an L2 write-back and an L2 invalidate.
@@ -755,6 +772,16 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
     }
     if (wide) {
         const bool scalar_ids = wide_variant() == 9 && (page_size & (page_size - 1)) == 0 && page_size >= kWideTile;
+        // sequences in two pieces finish between their two workgroups (mla_decode_wide8s.hip; MI_MLA_PAIR=0: through the merge kernel
+        // like every other split count).  The meeting words live in the flag area behind the per-sequence recompute words: groups of
+        // 65..128 heads leave >= 64 words per sequence there, the pair takes four (+ one for alignment).
+        static const bool pair_env = !(getenv("MI_MLA_PAIR") && atoi(getenv("MI_MLA_PAIR")) == 0);
+        const bool pair_on = g_pair_mode < 0 ? pair_env : g_pair_mode != 0;
+        p.pair_withhold = g_pair_mode == 2;
+        if (pair_on && scalar_ids && wide8 && p.group <= 128 && (planned || num_splits == 2) && p.arrive) {
+            p.pair_flags = (uint64_t *)(((uintptr_t)p.arrive + 7) & ~(uintptr_t)7);
+            p.pair_tag = (uint64_t)p.fix_epoch * 0x9E3779B97F4A7C15ull;      // odd multiplier, epoch != 0: never 0
+        }
         if (planned) (scalar_ids ? launch_mla_wide8s : launch_mla_wide8)(p, dtype, plan_items_max(seqs, workers), st);
         else if (wide8) (scalar_ids ? launch_mla_wide8s : launch_mla_wide8)(p, dtype, units, st);
         else launch_mla_wide(p, dtype, units, st);

@@ -81,6 +81,27 @@ __device__ __forceinline__ float fma_s(float a, float s, float c)
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c));
     return r;
 }
+// 16-byte write-through store (leaves the XCD's L2 at once: another workgroup sees it behind this wave's vmcnt drain, no release fence)
+__device__ __forceinline__ void st_sc1_x4(float *ptr, f32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+// 16-byte loads of rows another workgroup wrote through (sc1: served past this CU's L1): "=v" loads, then ONE wait statement naming
+// every destination before the first use (the compiler does not count these loads)
+__device__ __forceinline__ f32x4 ld_sc1_x4(const float *ptr)
+{
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld_sc1_wait(f32x4 (&r)[8])
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+}
+__device__ __forceinline__ void st_agent_f32(float *ptr, float v)
+{
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // a per-lane value the optimiser must re-derive where it is used: keeps loop invariants from being hoisted into registers of their own
 __device__ __forceinline__ uint32_t opaque(uint32_t v)
 {
@@ -150,6 +171,13 @@ __device__ __forceinline__ void issue_piece(const CtxS &c, const TileS &tl, uint
 
 template <int N> struct SlotTag { static constexpr int value = N; };
 
+#ifdef MLA8S_STAMPS          // timing probe: 100 MHz stamps of the epilogue's steps, one row per workgroup (tools/probes/time_mla_pair.py)
+__device__ unsigned long long g_mla8s_stamp[1024][8];
+#define MLA8S_STAMP(i) do { if (lane == 0 && blockIdx.x < 1024) g_mla8s_stamp[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MLA8S_STAMP(i) do { } while (0)
+#endif
+
 template <bool BF16, bool PLAN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mla_decode_wide8s_kernel(MlaParams p)
 {
@@ -173,6 +201,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int kvh = seq % p.kv_heads;
     const int b = seq / p.kv_heads;
+    if (wave == 0) MLA8S_STAMP(0);
     const int seq_len = __builtin_amdgcn_readfirstlane(p.seq_lens[b]);
     const int ntiles = (seq_len + kST - 1) / kST;
     if constexpr (PLAN) {
@@ -424,6 +453,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         l_run += __shfl_xor(l_run, 32, 64);
     }
     const float m_run = (wave_active && t_begin < t_end) ? -nm : -INFINITY;
+    if (wave == 0) MLA8S_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // fills issued past the last tile
     __syncthreads();
     const bool flagged_local = *(volatile uint32_t *)(lds + kSFlagOff) != 0;
@@ -437,17 +467,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         lmb[128 + wave * 16 + h16] = m_run;
     }
     __syncthreads();
-    int nsplits, pmul;
-    int64_t pbase;
+    int nsplits, pmul, piece;
+    int64_t pbase, pbase_partner;
     if constexpr (PLAN) {
-        nsplits = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x).n;
+        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x);
+        nsplits = it.n, piece = it.k;
         pmul = 1, pbase = ((int64_t)blockIdx.x - kvh) * p.group;
+        pbase_partner = pbase + (piece == 0 ? p.group : -p.group);       // the pieces of a sequence are consecutive items
     } else {
-        nsplits = p.num_splits;
-        pmul = p.num_splits, pbase = (int64_t)b * p.q_heads * p.num_splits + ((blockIdx.x >> 3) / head_blocks) % p.num_splits;
+        nsplits = p.num_splits, piece = ((blockIdx.x >> 3) / head_blocks) % p.num_splits;
+        pmul = p.num_splits, pbase = (int64_t)b * p.q_heads * p.num_splits + piece;
+        pbase_partner = pbase + (piece == 0 ? 1 : -1);
     }
     auto pslot = [&](int headx) -> int64_t { return pbase + (int64_t)headx * pmul; };
     const bool finals = nsplits == 1;                          // this workgroup writes output rows itself (no merge launch)
+    // a sequence in TWO pieces: each workgroup publishes the partial rows of the OTHER piece's heads, then finishes its own heads (piece 0:
+    // head blocks 0 and 1, piece 1: blocks 2 and 3) from its accumulators and the partner's rows (below); the merge launch finds nothing
+    // to do for it
+    const bool pair = p.pair_flags != nullptr && nsplits == 2 && head_blocks == 1;
     if (finals && flagged_local) {                             // outgrown softmax reference: exact slow path, one head per wave at a time
         for (int i = 0; i < 16; ++i) {
             const int hg2 = hblk * 128 + wave * 16 + i;
@@ -460,9 +497,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int kEpiRow = 64 * 4 + 16;
     uint8_t *const tile = lds + wave * (32 * kEpiRow);
     const int dcol0 = (wave >> 1) * 128 + (wave & 1) * 32;      // global dim of tile column 0; columns 32.. are 64 dims further
-#pragma unroll
-    for (int hb = 0; hb < 4; ++hb) {                           // static accumulator indices: keep this loop unrolled
-        if (hblk * 128 + hb * 32 >= p.group) continue;
+    // o8[it] = four consecutive dims (tile chunk lane & 15) of head 4 it + (lane >> 4) of head block hb
+    auto transpose_block = [&](auto hb_tag, f32x4 (&o8)[8]) {
+        constexpr int hb = decltype(hb_tag)::value;            // static accumulator indices
 #pragma unroll
         for (int dl = 0; dl < 2; ++dl)
 #pragma unroll
@@ -472,38 +509,171 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 *(f32x4 *)(tile + c32 * kEpiRow + col * 4) = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
             }
         // wave-private tile: LDS operations of one wave complete in order, no barrier
-        f32x4 o8[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) o8[it] = *(const f32x4 *)(tile + (it * 4 + (lane >> 4)) * kEpiRow + (lane & 15) * 16);
+    };
+    const int ch = lane & 15;
+    const int dlane = dcol0 + (ch >> 3) * 64 + (ch & 7) * 4;     // this lane's four dims of a row
+    // kind 0: output rows (this workgroup holds the whole sum), 1: partial rows, 2: partial rows written through (the pair's export)
+    auto rows_out = [&](auto hb_tag, int kind) {
+        constexpr int hb = decltype(hb_tag)::value;
+        if (hblk * 128 + hb * 32 >= p.group) return;
+        f32x4 o8[8];
+        transpose_block(hb_tag, o8);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int hl = it * 4 + (lane >> 4), ch = lane & 15;
+            const int hl = it * 4 + (lane >> 4);
             const int hgx = hblk * 128 + hb * 32 + hl;
-            const int d = dcol0 + (ch >> 3) * 64 + (ch & 7) * 4;
             const int headx = kvh * p.group + min(hgx, p.group - 1);
             if (hgx >= p.group) continue;
-            if (finals) {
+            if (kind == 0) {
                 const float l_h = lmb[hb * 32 + hl];
                 const float inv = l_h > 0.f ? 1.f / l_h : 0.f;
                 const uint32_t w0 = (uint32_t)cvt_out<BF16>(o8[it][0] * inv) | ((uint32_t)cvt_out<BF16>(o8[it][1] * inv) << 16);
                 const uint32_t w1 = (uint32_t)cvt_out<BF16>(o8[it][2] * inv) | ((uint32_t)cvt_out<BF16>(o8[it][3] * inv) << 16);
-                *(uint2 *)(p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + d) = uint2{w0, w1};
+                *(uint2 *)(p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + dlane) = uint2{w0, w1};
+            } else if (kind == 2) {
+                st_sc1_x4(p.ws_o + pslot(headx) * kDN + dlane, o8[it]);      // visible to the partner behind a vmcnt drain, no release fence
             } else {
-                *(f32x4 *)(p.ws_o + pslot(headx) * kDN + d) = o8[it];
+                *(f32x4 *)(p.ws_o + pslot(headx) * kDN + dlane) = o8[it];
             }
         }
-        if (!finals && wave == 0 && lane < 32) {               // softmax statistics of the block's 32 heads: lane = head
-            const int hgx = hblk * 128 + hb * 32 + lane;
+    };
+    // softmax statistics of the workgroup's heads: [m, l] per partial row (one lane per head)
+    if (!finals && wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int hgx = hblk * 128 + r * 64 + lane;
             if (hgx < p.group) {
                 const int64_t idx = pslot(kvh * p.group + hgx);
-                p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + lane];
-                p.ws_ml[idx * 2 + 1] = lmb[hb * 32 + lane];
+                st_agent_f32(p.ws_ml + idx * 2 + 0, lmb[128 + r * 64 + lane]);
+                st_agent_f32(p.ws_ml + idx * 2 + 1, lmb[r * 64 + lane]);
             }
         }
     }
+    if (!pair) {
+        const int kind = finals ? 0 : 1;
+        rows_out(SlotTag<0>{}, kind);
+        rows_out(SlotTag<1>{}, kind);
+        rows_out(SlotTag<2>{}, kind);
+        rows_out(SlotTag<3>{}, kind);
+        if (wave == 0) MLA8S_STAMP(2);
+        return;
+    }
+
+    // ---- the pair.  Export (all eight waves: every wave holds 64 dims of every head): the rows of the partner's heads, written through.
+    // "My rows are visible" -> the partner's word (bounded wait) -> own heads = w0 a0 + w1 a1 in piece order, exactly the merge kernel's
+    // sums, from the own accumulators and the partner's rows (write-through stores are read with sc1 loads: no acquire).  A partner that
+    // does not show up in time (not resident: more items than the chip runs at once) costs nothing but the wait: this workgroup then
+    // writes the rows of its own heads as well and leaves them unmarked -- both partials of those heads are in the workspace and the merge
+    // kernel, which skips only heads whose piece carries the mark, does the work.
+    if (piece == 0) rows_out(SlotTag<2>{}, 2), rows_out(SlotTag<3>{}, 2);
+    else rows_out(SlotTag<0>{}, 2), rows_out(SlotTag<1>{}, 2);
+    if (wave == 0) MLA8S_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave: its write-through stores have left
+    __syncthreads();
+    if (wave == 0) MLA8S_STAMP(3);
+    uint32_t *const ok_word = (uint32_t *)(lmb + 256);
+    const int64_t fbase = ((int64_t)b * p.kv_heads + kvh) * 2;
+    if (threadIdx.x == 0) {
+        if (!(p.pair_withhold && piece == 1))
+            __hip_atomic_store(p.pair_flags + fbase + piece, p.pair_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        uint32_t ok = 1;
+        while (__hip_atomic_load(p.pair_flags + fbase + (piece ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pair_tag) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000ull) {      // 200 us at 100 MHz
+                ok = 0;
+                break;
+            }
+        }
+        *ok_word = ok;
+    }
+    __syncthreads();
+    if (wave == 0) MLA8S_STAMP(4);
+    if (flagged_local) return;                                 // (the merge kernel recomputes the sequence)
+    if (*(volatile uint32_t *)ok_word == 0) {
+        if (piece == 0) rows_out(SlotTag<0>{}, 1), rows_out(SlotTag<1>{}, 1);
+        else rows_out(SlotTag<2>{}, 1), rows_out(SlotTag<3>{}, 1);
+        return;
+    }
+    // "this piece finishes its heads": the sign of their sums (nobody else reads those words before the merge kernel)
+    if (wave == 0) {
+        const int hgx = piece * 64 + lane;
+        if (hgx < p.group) st_agent_f32(p.ws_ml + pslot(kvh * p.group + hgx) * 2 + 1, -lmb[hgx]);
+    }
+    // the partner's rows of this workgroup's heads: 16 write-through-coherent loads per lane, all in flight before the first use
+    const float *const prow = p.ws_o + pbase_partner * kDN;    // + head * pmul * kDN + dim
+    f32x4 pr[2][8];
+    auto partner_rows = [&](int hb, f32x4 (&r)[8]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int hgx = min(hb * 32 + it * 4 + (lane >> 4), p.group - 1);
+            r[it] = ld_sc1_x4(prow + (int64_t)(kvh * p.group + hgx) * pmul * kDN + dlane);
+        }
+    };
+    partner_rows(piece * 2, pr[0]);
+    partner_rows(piece * 2 + 1, pr[1]);
+    // the partner's statistics of those heads (64 heads, lane = head) -> wave-private LDS
+    float *const pml = lmb + 512 + wave * 128;
+    {
+        const int hgx = min(piece * 64 + lane, p.group - 1);
+        const int64_t idx = pbase_partner + (int64_t)(kvh * p.group + hgx) * pmul;
+        pml[lane * 2 + 0] = __hip_atomic_load(p.ws_ml + idx * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pml[lane * 2 + 1] = __hip_atomic_load(p.ws_ml + idx * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ld_sc1_wait(pr[0]);
+    ld_sc1_wait(pr[1]);
+    auto finish = [&](auto hb_tag, const f32x4 (&r)[8]) {
+        constexpr int hb = decltype(hb_tag)::value;
+        if (hb * 32 >= p.group) return;
+        f32x4 o8[8];
+        transpose_block(hb_tag, o8);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int hl = it * 4 + (lane >> 4);
+            const int hgx = hb * 32 + hl;
+            if (hgx >= p.group) continue;
+            const int headx = kvh * p.group + hgx;
+            const int hp = hgx - piece * 64;                   // index into the partner's statistics
+            const float m_own = lmb[128 + hgx], l_own = lmb[hgx], m_par = pml[hp * 2], l_par = pml[hp * 2 + 1];
+            const float m0 = piece == 0 ? m_own : m_par, m1 = piece == 0 ? m_par : m_own;
+            const float l0 = piece == 0 ? l_own : l_par, l1 = piece == 0 ? l_par : l_own;
+            const f32x4 a0 = piece == 0 ? o8[it] : r[it], a1 = piece == 0 ? r[it] : o8[it];
+            const float M = fmaxf(m0, m1);
+            const float w0 = m0 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m0 - M);
+            const float w1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - M);
+            float L = 0.f;
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (w0 != 0.f) {
+                L += w0 * l0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += w0 * a0[j];
+            }
+            if (w1 != 0.f) {
+                L += w1 * l1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += w1 * a1[j];
+            }
+            const float inv = L > 0.f ? 1.f / L : 0.f;
+            const uint32_t x0 = (uint32_t)cvt_out<BF16>(o[0] * inv) | ((uint32_t)cvt_out<BF16>(o[1] * inv) << 16);
+            const uint32_t x1 = (uint32_t)cvt_out<BF16>(o[2] * inv) | ((uint32_t)cvt_out<BF16>(o[3] * inv) << 16);
+            *(uint2 *)(p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + dlane) = uint2{x0, x1};
+        }
+    };
+    if (piece == 0) finish(SlotTag<0>{}, pr[0]), finish(SlotTag<1>{}, pr[1]);
+    else finish(SlotTag<2>{}, pr[0]), finish(SlotTag<3>{}, pr[1]);
+#ifdef MLA8S_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 0) MLA8S_STAMP(6);
+#endif
 }
 
 }  // namespace
+
+#ifdef MLA8S_STAMPS
+extern "C" int mi_mla8s_stamps(void *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mla8s_stamp), sizeof(unsigned long long) * 1024 * 8); }
+#endif
 
 void launch_mla_wide8s(const MlaParams &p, int dtype, long long units, hipStream_t st)
 {

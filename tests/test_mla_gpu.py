@@ -476,3 +476,108 @@ def test_graph_replay_with_lengths_crossing_piece_boundaries():
         torch.ops.npu.decode_mla(q, kn, kr, own, lens, 576 ** -0.5, page, bt, -1)
         torch.cuda.synchronize()
         assert torch.allclose(out.float(), own.float(), rtol=2 ** -7, atol=2e-3), (int(new[0]), (out.float() - own.float()).abs().max())
+
+
+def _pair_inputs(B, Hq, S, page, dtype, ragged, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    maxp = (S + page - 1) // page
+    nb = B * maxp
+    q = torch.randn((B, Hq, 576), generator=g, device="cuda").to(dtype)
+    kn = (torch.randn((nb, page, 1, 512), generator=g, device="cuda") * 0.5).to(dtype)
+    kr = (torch.randn((nb, page, 1, 64), generator=g, device="cuda") * 0.5).to(dtype)
+    bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    if ragged:
+        lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+    return q, kn, kr, lens, bt
+
+
+# B, Hq, S, page, dtype, ragged, num_splits -- batches the list (or num_splits = 2) cuts into two pieces per sequence: BASELINE C4's shape
+# at a quarter of its length, a ragged copy (sequences of one, two and three pieces side by side: uneven arrival), a partly filled head
+# block in fp16, the uniform two-split form on a small batch, pages of 32 keys
+PAIR_CASES = [(128, 128, 1024, 64, torch.bfloat16, False, PLANNED), (128, 128, 1500, 64, torch.bfloat16, True, PLANNED),
+              (100, 96, 700, 128, torch.float16, True, PLANNED), (5, 128, 900, 64, torch.bfloat16, True, 2),
+              (120, 128, 640, 32, torch.float16, False, PLANNED)]
+
+
+@pytest.mark.parametrize("B,Hq,S,page,dtype,ragged,splits", PAIR_CASES)
+def test_two_piece_sequences_finish_between_their_workgroups(B, Hq, S, page, dtype, ragged, splits):
+    """Sequences in two pieces finish inside the kernel (each workgroup: one half of the output dimensions, mla_decode_wide8s.hip);
+    the same sums in the same order as the merge kernel, so the outputs are THE BITS of the run with the pair finish off -- also when
+    the second piece withholds its word and the first runs into its bounded wait (mode 2: the merge kernel does the work), and over
+    repeated calls on one workspace (the meeting words are re-armed by the merge kernel)."""
+    L = lib()
+    L.mi_mla_decode_set_pair.argtypes = [c_int]
+    q, kn, kr, lens, bt = _pair_inputs(B, Hq, S, page, dtype, ragged, 5)
+    sm = 576 ** -0.5
+    try:
+        assert L.mi_mla_decode_select_wide(9) == 0
+        assert L.mi_mla_decode_set_pair(0) == 0
+        want = run_mla(q, kn, kr, lens, bt, sm, splits)
+        assert L.mi_mla_decode_set_pair(1) == 0
+        keep = []
+        got = run_mla(q, kn, kr, lens, bt, sm, splits, keep_ws=keep)
+        assert torch.equal(got, want), (got.float() - want.float()).abs().max()
+        # the same workspace again and again (words re-armed), with other queries in between
+        ws = keep[0]
+        for rep in range(3):
+            q2 = (q.float() * (1.0 + 0.25 * rep)).to(dtype)
+            L.mi_mla_decode_set_pair(0)
+            want2 = run_mla(q2, kn, kr, lens, bt, sm, splits)
+            L.mi_mla_decode_set_pair(1)
+            out = torch.empty_like(want2)
+            rc = L.mi_mla_decode(ptr(q2), ptr(kn), ptr(kr), ptr(out), ptr(lens), ptr(bt), B, Hq, 1, page, bt.stride(0), S, q2.stride(0), q2.stride(1),
+                                 kn.stride(0), kn.stride(1), kn.stride(2), kr.stride(0), kr.stride(1), kr.stride(2), out.stride(0), out.stride(1),
+                                 sm, 0 if dtype == torch.bfloat16 else 1, splits, ptr(ws), ws.numel(), stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.equal(out, want2), rep
+        assert L.mi_mla_decode_set_pair(2) == 0
+        got = run_mla(q, kn, kr, lens, bt, sm, splits)
+        assert torch.equal(got, want), "bounded wait -> merge kernel"
+        # ... and the words a timed-out call left behind do not leak into the next one
+        assert L.mi_mla_decode_set_pair(1) == 0
+        got = run_mla(q, kn, kr, lens, bt, sm, splits)
+        assert torch.equal(got, want)
+    finally:
+        L.mi_mla_decode_set_pair(-1)
+        L.mi_mla_decode_select_wide(0)
+
+
+def test_pair_finish_in_a_replayed_graph():
+    """The pair finish inside a captured graph: every replay carries the same tag, the meeting words are re-armed by the merge kernel
+    of the replay before -- outputs follow the inputs written between replays, bit for bit the eager result with the pair finish off."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sgl-kernel-npu_amd", "python"))
+    from sgl_kernel_npu.attention.decode_attention import decode_mla, decode_mla_plan
+    L = lib()
+    L.mi_mla_decode_set_pair.argtypes = [c_int]
+    B, Hq, S, page = 128, 128, 1024, 64
+    q, kn, kr, lens, bt = _pair_inputs(B, Hq, S, page, torch.bfloat16, False, 11)
+    out = torch.empty((B, Hq, 512), dtype=torch.bfloat16, device="cuda")
+    plan = decode_mla_plan(lens, 1)
+    try:
+        L.mi_mla_decode_set_pair(1)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            decode_mla(q, kn, kr, out, lens, 576 ** -0.5, page, bt, plan=plan)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            decode_mla(q, kn, kr, out, lens, 576 ** -0.5, page, bt, plan=plan)
+        for rep in range(4):
+            q.copy_((torch.randn(q.shape, device="cuda") * (1 + rep)).to(torch.bfloat16))
+            out.fill_(7.0)
+            graph.replay()
+            torch.cuda.synchronize()
+            got = out.clone()
+            L.mi_mla_decode_set_pair(0)
+            want = torch.empty_like(out)
+            decode_mla(q, kn, kr, want, lens, 576 ** -0.5, page, bt, plan=plan)
+            torch.cuda.synchronize()
+            L.mi_mla_decode_set_pair(1)
+            assert torch.equal(got, want), rep
+    finally:
+        L.mi_mla_decode_set_pair(-1)
