@@ -102,6 +102,12 @@ __device__ __forceinline__ void st_agent_f32(float *ptr, float v)
 {
     __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // a per-lane value the optimiser must re-derive where it is used: keeps loop invariants from being hoisted into registers of their own
 __device__ __forceinline__ uint32_t opaque(uint32_t v)
 {
@@ -174,8 +180,12 @@ template <int N> struct SlotTag { static constexpr int value = N; };
 #ifdef MLA8S_STAMPS          // timing probe: 100 MHz stamps of the epilogue's steps, one row per workgroup (tools/probes/time_mla_pair.py)
 __device__ unsigned long long g_mla8s_stamp[1024][8];
 #define MLA8S_STAMP(i) do { if (lane == 0 && blockIdx.x < 1024) g_mla8s_stamp[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ float g_mla8s_phase[256][8][8];     // shader clocks per tile and wave: [own fill wait, barrier A, QK^T, softmax + publish, barrier B, P.V, loop total, tiles]
+// (sums kept in LDS behind the exchange buffer: accumulators in registers pushed the kernel into scratch)
+#define MLA8S_TICK(i) do { const uint32_t c1_ = (uint32_t)__builtin_amdgcn_s_memtime(); if (lane == 0) __hip_atomic_fetch_add((uint32_t *)(lds + kSLds) + wave * 8 + (i), c1_ - c0_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); c0_ = c1_; } while (0)
 #else
 #define MLA8S_STAMP(i) do { } while (0)
+#define MLA8S_TICK(i) do { } while (0)
 #endif
 
 template <bool BF16, bool PLAN>
@@ -268,24 +278,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // accumulator block dl * 4 + hb = those 32 dims (dbl = 2 (w & 1) + dl) x heads 32 hb .. +31.  Starts behind barrier B.
     const int c16 = lane & 15, q16 = (lane >> 4) & 1;
     const uint32_t v_lane = (uint32_t)((4 * kg + (c16 >> 2)) * kNopeStride + (wave >> 1) * 256 + q16 * 128 + (wave & 1) * 64 + (c16 & 3) * 8);
-    auto pv = [&](auto slot_tag) {
+    // V fragment of step `step` of the tile in slot SLOT (keys 16 kk + {4 kg + 0..3, 8 + 4 kg + 0..3}, step = kk * 2 + dl); fragment 0 is
+    // requested by the caller AHEAD of barrier B (the tile has been complete since barrier A: only P^T needs that barrier)
+    auto v_frag = [&](auto slot_tag, int step) -> s16x8 {
         constexpr int SLOT = decltype(slot_tag)::value;
         const uint8_t *vlo = lds + SLOT * kSSlotBytes + v_lane;
+        const int off = (step >> 1) * 16 * kNopeStride + (step & 1) * 32;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + off + 8 * kNopeStride));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto pv = [&](auto slot_tag, s16x8 af0, auto &&under_first_reads) {
         const uint8_t *pb = lds + kPxOff + opaque(lane16);
-        auto lda = [&](int step) -> s16x8 {                    // step = kk * 2 + dl: keys 16 kk + {4 kg + 0..3, 8 + 4 kg + 0..3}
-            const int off = (step >> 1) * 16 * kNopeStride + (step & 1) * 32;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + off));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + off + 8 * kNopeStride));
-            return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        };
+        auto lda = [&](int step) -> s16x8 { return v_frag(slot_tag, step); };
         auto ldp = [&](int hb, int kk) -> s16x8 { return *(const s16x8 *)(pb + (hb * 2 + kk) * 1024); };
         // 16 MFMAs in the order (kk, dl, hb); operands requested ahead: V fragments one step (4 MFMAs), P fragments three MFMAs
         s16x8 af[2], pfr[4];
         __builtin_amdgcn_sched_barrier(0);
-        af[0] = lda(0);
+        af[0] = af0;
         pfr[0] = ldp(0, 0);
         pfr[1] = ldp(1, 0);
         pfr[2] = ldp(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        under_first_reads();                                   // VALU work that waits for nothing: runs while the first P^T fragments travel
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int step = i >> 2, hb = i & 3;               // step = kk * 2 + dl
@@ -312,12 +327,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
     };
     // P(t) . V(t) with the block id of tile t + 4 fetched in its shadow
-    auto pv_and_next_id = [&](auto slot_tag, int t) {
+    auto pv_and_next_id = [&](auto slot_tag, int t, s16x8 af0, auto &&under_first_reads) {
 #ifndef MLA8S_NO_DMA
         int id = block_id_request(cx, t + 1 + kSLead);
 #endif
 #ifndef MLA8S_NO_PV
-        pv(slot_tag);
+        pv(slot_tag, af0, under_first_reads);
+#else
+        under_first_reads();
 #endif
 #ifndef MLA8S_NO_DMA
         block_id_wait(id);
@@ -337,8 +354,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             constexpr uint32_t nslot = (uint32_t)(((SLOT + kSLead) % kSSlots) * kSSlotBytes);
 #pragma unroll
             for (int i = 0; i < 5; ++i) issue_piece(cx, tl, nslot, i);
+            const s16x8 af0 = v_frag(slot_tag, 0);
             asm volatile("s_barrier" ::: "memory");              // barrier B
-            pv_and_next_id(slot_tag, t);
+            pv_and_next_id(slot_tag, t, af0, [] {});
         };
         for (int t = t_begin; t < t_end;) {
             idle(SlotTag<0>{}, t);
@@ -388,10 +406,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    constexpr float kGuard = BF16 ? 64.0f : 11.0f;
+    constexpr float kGuardP = BF16 ? 0x1p64f : 0x1p11f;         // largest P (relative to the softmax reference) the accumulators are sized for
     if (wave_active) {
+#ifdef MLA8S_STAMPS
+        uint32_t c0_ = 0;
+        if (lane < 8) ((uint32_t *)(lds + kSLds))[wave * 8 + lane] = 0;
+        const uint32_t t_loop0_ = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
         auto body = [&](auto slot_tag, int t) {
+#ifdef MLA8S_STAMPS
+            c0_ = (uint32_t)__builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (kSLead - 1)) : "memory");
+            MLA8S_TICK(0);
+#endif
             const TileS tl = tile_top(t);
+            MLA8S_TICK(1);
             f32x4 s0, s1;
 #ifdef MLA8S_NO_QK           // timing probe: fill + softmax + P.V only
             s0 = s1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -402,6 +431,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #else
             qk(slot_tag, tl, s0, s1);
 #endif
+            MLA8S_TICK(2);
             // lane (h16, g) holds head h16, keys 16 kb + 4 g + i.  Only the tile that crosses seq_len needs the mask.
             if ((t + 1) * kST > seq_len) {
                 asm volatile("" ::: "memory");
@@ -413,31 +443,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (kbase + 16 + i >= seq_len) s1[i] = ninf;
                 }
             }
-            float tmax = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
             if (t == t_begin) {                           // the softmax reference of this head: first tile's maximum over all 32 keys
+                float tmax = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
                 const int self4 = (int)(opaque(lane16) >> 2);  // 4 x lane: byte index of ds_bpermute
                 tmax = fmaxf(tmax, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(self4 ^ 64, __builtin_bit_cast(int, tmax))));
                 tmax = fmaxf(tmax, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(self4 ^ 128, __builtin_bit_cast(int, tmax))));
                 nm = -(tmax * cs);                             // sm_scale > 0: max commutes with the scaling; a tile below seq_len's end
                                                                // always holds a key, so the reference is finite
-            } else if (__any(tmax * cs > kGuard - nm)) {         // = m + kGuard, the four-slot kernel's bits
-#if !defined(MLA8S_NO_DMA) && !defined(MLA8S_NO_QK) && !defined(MLA8S_NO_PV)
-                *(uint32_t *)(lds + kSFlagOff) = opaque(1u);
-#endif
             }
+            // The critical path of the phase is scores -> exp2 -> P^T in LDS -> barrier B; everything else of the softmax (the running sum, the
+            // largest P of the tile for the outgrown-reference check) runs behind the LDS write, the check itself behind barrier B while
+            // the first P^T fragments of the P.V phase travel.
             float e[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 e[i] = __builtin_amdgcn_exp2f(fma_s(s0[i], cs, nm));
                 e[4 + i] = __builtin_amdgcn_exp2f(fma_s(s1[i], cs, nm));
             }
-            l_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
             uint8_t *pdst = lds + kPxOff + pdst_off;
             *(uint2 *)(pdst) = uint2{pack2<BF16>(e[0], e[1]), pack2<BF16>(e[2], e[3])};
             *(uint2 *)(pdst + 1024) = uint2{pack2<BF16>(e[4], e[5]), pack2<BF16>(e[6], e[7])};
+            const s16x8 af0 = v_frag(slot_tag, 0);             // first V fragment of the P.V phase: in flight across barrier B
+            l_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+            // P >= 0: float order = order of the bit patterns (v_max3_u32, no NaN canonicalisation in front of every operand)
+            const uint32_t emax = max3u(max3u(__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2])),
+                                        max3u(__float_as_uint(e[3]), __float_as_uint(e[4]), __float_as_uint(e[5])),
+                                        max(__float_as_uint(e[6]), __float_as_uint(e[7])));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MLA8S_TICK(3);
             asm volatile("s_barrier" ::: "memory");               // barrier B: P^T(t) complete
-            pv_and_next_id(slot_tag, t);
+            MLA8S_TICK(4);
+            pv_and_next_id(slot_tag, t, af0, [&] {
+                // a P above 2^kGuard (the first tile's are <= 1): the reference has been outgrown, the sequence is recomputed exactly
+                if (__any(emax > __float_as_uint(kGuardP))) {
+#if !defined(MLA8S_NO_DMA) && !defined(MLA8S_NO_QK) && !defined(MLA8S_NO_PV)
+                    *(uint32_t *)(lds + kSFlagOff) = opaque(1u);
+#endif
+                }
+            });
+            MLA8S_TICK(5);
         };
         for (int t = t_begin; t < t_end;) {
             body(SlotTag<0>{}, t);
@@ -449,6 +493,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             body(SlotTag<3>{}, t);
             ++t;
         }
+#ifdef MLA8S_STAMPS
+        if (lane == 0 && blockIdx.x < 256) {
+            for (int i = 0; i < 6; ++i) g_mla8s_phase[blockIdx.x][wave][i] = (float)((volatile uint32_t *)(lds + kSLds))[wave * 8 + i] / (float)max(1, t_end - t_begin);
+            g_mla8s_phase[blockIdx.x][wave][6] = (float)((uint32_t)__builtin_amdgcn_s_memtime() - t_loop0_);
+            g_mla8s_phase[blockIdx.x][wave][7] = (float)(t_end - t_begin);
+        }
+#endif
         l_run += __shfl_xor(l_run, 16, 64);                    // the four key groups of a head
         l_run += __shfl_xor(l_run, 32, 64);
     }
@@ -672,27 +723,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }  // namespace
 
 #ifdef MLA8S_STAMPS
+extern "C" int mi_mla8s_phases(void *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mla8s_phase), sizeof(float) * 256 * 8 * 8); }
 extern "C" int mi_mla8s_stamps(void *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mla8s_stamp), sizeof(unsigned long long) * 1024 * 8); }
 #endif
 
+#ifdef MLA8S_STAMPS
+#define MLA8S_LDS (kSLds + 256)
+#else
+#define MLA8S_LDS kSLds
+#endif
 void launch_mla_wide8s(const MlaParams &p, int dtype, long long units, hipStream_t st)
 {
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
-        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
-        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
-        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
+        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLA8S_LDS);
+        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLA8S_LDS);
+        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLA8S_LDS);
+        (void)hipFuncSetAttribute((const void *)mla_decode_wide8s_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLA8S_LDS);
     }
     const int head_blocks = (p.group + 127) / 128;
     const long long seqs = p.plan ? 0 : units / p.num_splits;  // (sequence, kv head) pairs, 8 per grid row of XCDs
     dim3 grid(p.plan ? (unsigned)units : (unsigned)(((seqs + 7) / 8) * 8 * p.num_splits * head_blocks));
     if (p.plan) {
-        if (dtype == MI_DTYPE_BF16) mla_decode_wide8s_kernel<true, true><<<grid, 512, kSLds, st>>>(p);
-        else mla_decode_wide8s_kernel<false, true><<<grid, 512, kSLds, st>>>(p);
+        if (dtype == MI_DTYPE_BF16) mla_decode_wide8s_kernel<true, true><<<grid, 512, MLA8S_LDS, st>>>(p);
+        else mla_decode_wide8s_kernel<false, true><<<grid, 512, MLA8S_LDS, st>>>(p);
     } else {
-        if (dtype == MI_DTYPE_BF16) mla_decode_wide8s_kernel<true, false><<<grid, 512, kSLds, st>>>(p);
-        else mla_decode_wide8s_kernel<false, false><<<grid, 512, kSLds, st>>>(p);
+        if (dtype == MI_DTYPE_BF16) mla_decode_wide8s_kernel<true, false><<<grid, 512, MLA8S_LDS, st>>>(p);
+        else mla_decode_wide8s_kernel<false, false><<<grid, 512, MLA8S_LDS, st>>>(p);
     }
 }
 

@@ -41,6 +41,13 @@ for ragged in (False, True):
         st = (st - t0) / 100.0
         pct = lambda v: [round(float(np.percentile(v, q)), 2) for q in (0, 50, 90, 100)]
         print("ragged" if ragged else "full", "pair" if mode else "merge", "us/call", round(a.elapsed_time(b) * 10, 1))
+        ph = np.zeros((256, 8, 8), dtype=np.float32)
+        assert L.mi_mla8s_phases(ph.ctypes.data_as(c_void_p)) == 0
+        m = ph.mean(axis=(0, 1))
+        print("   per tile and wave [own fill wait, barrier A, QK^T, softmax + publish, barrier B, P.V] shader clocks:", [int(v) for v in m[:6]], "sum", int(m[:6].sum()),
+              " loop", int(m[6]), "clocks /", int(m[7]), "tiles")
+        for w in range(8):
+            print("      wave", w, [int(v) for v in ph[:, w, :6].mean(axis=0)])
         names = ["start", "loop end", "stores issued", "drained+barrier", "flag seen", "acquired", "second pass done"]
         for i in range(1, 7 if mode else 3):
             print(f"   {names[i]:18s} at {pct(st[:, i])}   step {pct(st[:, i] - st[:, i - 1])}")
