@@ -47,6 +47,7 @@ constexpr int BN = 256, BK = 64;
 // waits out its operand reads.  Carrying the next k-step's fragments across the barrier needs a second fragment set (32 VGPRs) next
 // to 64 accumulators inside the 128-register budget of 16 waves per CU.
 template <int BKT, int MT> struct RingDepth { static constexpr int value = BKT == 128 ? (MT == 4 ? 2 : 3) : 4; };
+constexpr int ring_bytes(int bkt, int mt) { return (bkt == 128 ? (mt == 4 ? 2 : 3) : 4) * (64 * mt + 256) * bkt; }
 constexpr int kGemmThreads = 1024;
 constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -98,32 +99,14 @@ __device__ float g_gemm_dbg[256];
 // tokens x 32 experts; a 2-deep ring of 128-byte k-tiles, two workgroups per CU, gave 185 / 121 us).
 // one (expert, m-tile) x 256-column tile; `slot` = index of the tile in (expert, row block) order.  Returns false when the slot lies
 // past the last tile (workgroup-uniform).
-template <int MODE, int MT, int BKT>
-__device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, int col_tile, uint8_t *lds, int end_first)
+// Which (expert, row block) is tile slot `tile_slot`?  Row blocks are 256 rows (the prefill tile) or 64 (the decode tile); 64 experts per
+// step: lane i reads the end of expert i, a wave scan of the per-expert tile counts locates the slot.  (A serial walk over the experts --
+// one dependent scalar load each -- cost up to ~15 us per workgroup for the last experts, a third of a GEMM2 tile.)  Returns false when
+// the slot lies past the last tile (workgroup-uniform).
+template <int BM>
+__device__ __forceinline__ bool find_tile(const GemmArgs &p, int tile_slot, int end_first, int &e_out, int &row0_out, int &rows_out)
 {
-    constexpr int BM = 64 * MT;
-    constexpr int kStages = RingDepth<BKT, MT>::value;
-    constexpr int kStageBytes = (BM + BN) * BKT;
-    constexpr int kPieceRows = 1024 / BKT;            // rows one DMA instruction (64 lanes x 16 B) covers
-    constexpr int kChunks = BKT / 16;                 // 16-B chunks per row
-    constexpr int kAPieces = BM / kPieceRows;         // DMA instructions for the A tile of a stage
-    constexpr int kAPerWave = (kAPieces + 15) / 16;   // A pieces per wave: wave w issues pieces w, w + 16, ... below kAPieces
-    constexpr int kBPerWave = BN / kPieceRows / 16;   // B pieces every wave issues per stage
-    static_assert((kAPieces <= 16 || kAPieces % 16 == 0) && kBPerWave >= 1, "DMA plan");
-#ifdef GEMM_TIMING
-    const uint64_t t_entry = __builtin_amdgcn_s_memtime();
-#endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, c16 = lane & 15;
-    // (Round 4, measured and dropped: wm = wave >> 2 -- the four row quarters of a column strip on one SIMD -- plus skipping the MFMAs of row
-    //  tiles without rows, so that an expert's last, partly filled tile loads all four SIMDs with what rows it has.  The mapping alone is
-    //  neutral; a wave-uniform test in front of the MFMA groups cost full tiles 7.5 %; with the k-loop duplicated -- plain for full tiles,
-    //  predicated for remainder tiles -- multinomial row counts gained 2 % in GEMM1 and lost 1-3 % elsewhere (tools/time_gemm.py, "ragged").
-    //  A remainder tile costs what a full one costs because its weight tile streams all the same: the k-tile time is the operand stream's.)
-    const int wm = wave & 3, wn = wave >> 2;
-    // which (expert, m-tile) is tile slot blockIdx.y?  64 experts per step: lane i reads the end of expert i, a wave scan of
-    // the per-expert tile counts locates the slot.  (A serial walk over the experts -- one dependent scalar load each -- cost
-    // up to ~15 us per workgroup for the last experts, a third of a GEMM2 tile.)
+    const int lane = threadIdx.x & 63;
     int e = -1, row0 = 0, rows = 0;
     {
         int slot = tile_slot, start = 0;                    // wave-uniform
@@ -156,11 +139,38 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, int 
                 start = __shfl(end, last, 64);
             }
         }
-        e = __builtin_amdgcn_readfirstlane(e);
-        row0 = __builtin_amdgcn_readfirstlane(row0);
-        rows = __builtin_amdgcn_readfirstlane(rows);
     }
-    if (e < 0) return false;
+    e_out = __builtin_amdgcn_readfirstlane(e);
+    row0_out = __builtin_amdgcn_readfirstlane(row0);
+    rows_out = __builtin_amdgcn_readfirstlane(rows);
+    return e_out >= 0;
+}
+
+// one (expert, row block of `rows` <= 64 MT rows starting at row0) x 256-column tile
+template <int MODE, int MT, int BKT>
+__device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, int rows, int col_tile, uint8_t *lds)
+{
+    constexpr int BM = 64 * MT;
+    constexpr int kStages = RingDepth<BKT, MT>::value;
+    constexpr int kStageBytes = (BM + BN) * BKT;
+    constexpr int kPieceRows = 1024 / BKT;            // rows one DMA instruction (64 lanes x 16 B) covers
+    constexpr int kChunks = BKT / 16;                 // 16-B chunks per row
+    constexpr int kAPieces = BM / kPieceRows;         // DMA instructions for the A tile of a stage
+    constexpr int kAPerWave = (kAPieces + 15) / 16;   // A pieces per wave: wave w issues pieces w, w + 16, ... below kAPieces
+    constexpr int kBPerWave = BN / kPieceRows / 16;   // B pieces every wave issues per stage
+    static_assert((kAPieces <= 16 || kAPieces % 16 == 0) && kBPerWave >= 1, "DMA plan");
+#ifdef GEMM_TIMING
+    const uint64_t t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    // (Round 4, measured and dropped: wm = wave >> 2 -- the four row quarters of a column strip on one SIMD -- plus skipping the MFMAs of row
+    //  tiles without rows, so that an expert's last, partly filled tile loads all four SIMDs with what rows it has.  The mapping alone is
+    //  neutral; a wave-uniform test in front of the MFMA groups cost full tiles 7.5 %; with the k-loop duplicated -- plain for full tiles,
+    //  predicated for remainder tiles -- multinomial row counts gained 2 % in GEMM1 and lost 1-3 % elsewhere (tools/time_gemm.py, "ragged").
+    //  A remainder tile costs what a full one costs because its weight tile streams all the same: the k-tile time is the operand stream's.
+    //  Round 5: an expert's last row block of <= 128 rows runs as a 64- or 128-row tile instead -- grouped_gemm_i8_kernel.)
+    const int wm = wave & 3, wn = wave >> 2;
     const int n0 = col_tile * BN;
     const int8_t *wbase = p.w + (size_t)e * p.N * p.K;
     const int8_t *abase = p.a + (size_t)row0 * p.K;
@@ -355,7 +365,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, int 
     // must not move the 16-byte loads below above the stores above (different types: type-based alias analysis would allow it; an
     // 8-rows-at-a-time variant of this epilogue produced wrong rows exactly that way)
     asm volatile("" ::: "memory");
-    if (!wave_cols_ok) return true;
+    if (!wave_cols_ok) return;
     // MODE 2: where do this lane's rows go?  The (src, t, k) triples and, from them, the slot addresses are requested in ONE batch for all 8
     // row groups (after the transposition, when the accumulators are dead and the registers are free), two dependent round trips in all.
     // (Loaded inside the store loop, each of the 8 row groups paid both round trips in front of its store: GEMM2's epilogue cost
@@ -418,7 +428,6 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs &p, int tile_slot, int 
         g_gemm_dbg[(blockIdx.y * 16 + wave) * 4 + 3] = (float)(__builtin_amdgcn_s_memtime() - t_epi);
     }
 #endif
-    return true;
 }
 
 // The grid's y dimension is a POOL of tile workers, not one workgroup per possible tile: with worst-case sized buffers (fused_deep_moe
@@ -456,7 +465,16 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
     }
     const int end_first = lane0 < p.L ? p.cum[(lane0 + 1) * p.cum_stride - 1] : 0;     // end of expert `lane` (cumulative row count)
     for (int slot = worker;; slot += workers) {
-        if (!gemm_tile<MODE, MT, BKT>(p, slot, col_tile, lds, end_first)) break;
+        int e, row0, rows;
+        if (!find_tile<64 * MT>(p, slot, end_first, e, row0, rows)) break;
+        // An expert's LAST row block is whatever is left of its rows.  Under multinomial routing about half the experts of a prefill batch
+        // end in a block of a few dozen rows (1024 +- 30 rows per expert at C5: 4 full blocks and a fifth of <= 64 rows), and a 256-row
+        // tile pays for it in full -- its weight tile streams all the same and the MFMAs multiply padding.  Blocks of <= 64 / <= 128 rows
+        // run as the 64- / 128-row tile (a fifth / three eighths less operand stream per k-tile, a quarter / half of the MFMAs).  Same
+        // products, same epilogue: bit-identical.
+        if (MT == 4 && BKT == 128 && rows <= 64) gemm_tile<MODE, 1, BKT>(p, e, row0, rows, col_tile, lds);
+        else if (MT == 4 && BKT == 128 && rows <= 128) gemm_tile<MODE, 2, BKT>(p, e, row0, rows, col_tile, lds);
+        else gemm_tile<MODE, MT, BKT>(p, e, row0, rows, col_tile, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
         __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
     }
@@ -527,8 +545,12 @@ template <int MODE, int MT, int BKT>
 static void gemm_launch_one(const GemmArgs &p, void *stream)
 {
     constexpr int BM = 64 * MT;
-    constexpr int ring = RingDepth<BKT, MT>::value * (BM + BN) * BKT, epi = 16 * 16 * MT * kEpiRowBytes;      // operand ring | epilogue tiles of 16 waves
+    // operand ring | epilogue tiles of 16 waves; the 256-row kernel with 128-byte k-tiles also runs 64- and 128-row tiles (the last row
+    // block of an expert): their rings are three stages deep, the 128-row one (3 x 48 KB) is the largest
+    constexpr int ring0 = ring_bytes(BKT, MT), ring = (MT == 4 && BKT == 128 && ring_bytes(BKT, 2) > ring0) ? ring_bytes(BKT, 2) : ring0;
+    constexpr int epi = 16 * 16 * MT * kEpiRowBytes;
     constexpr int lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute((const void *)grouped_gemm_i8_kernel<MODE, MT, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -99,6 +99,9 @@ ORACLE_CASES = [
     ([97, 33], 1024, 384, 1, 97),                 # 2I = 768 = 3 x 256-column tiles, I not a multiple of 256
     ([5, 0, 1, 70, 33], 256, 192, 1, 16),         # GEMM2's K = 192 is no multiple of 128: 64-row tile with 64-byte k-tiles
     ([300, 1, 257], 256, 192, 1, 512),            # the same K on the 256-row tile (GEMM1: 128-byte k-tiles, GEMM2: 64-byte k-tiles)
+    # the 256-row kernel runs an expert's last row block of <= 64 / <= 128 rows as a 64- / 128-row tile: every class of remainder, at the edges
+    ([356, 65, 128, 129, 64, 320, 0, 577], 512, 256, 1, 512),
+    ([1040, 1000, 1088, 1089, 1024], 1024, 512, 2, 1024),
 ]
 
 
