@@ -571,7 +571,7 @@ static int gqa_decode_impl(const void *q, const void *k, const void *v, void *ou
         if (planned) {
             const int workers = std::max(1, gqa_cus() / head_blocks);
             int32_t *plan = (int32_t *)(w.ws_ml + gqa_plan_rows_cap(batch, q_heads) * 2);
-            mi_sgl::decode_plan_kernel<<<1, 1024, 0, st>>>(kv_seq_lens, batch, kv_heads, mi_gqa_wide::kTile, 1, workers, plan);
+            mi_sgl::decode_plan_kernel<<<1, 1024, 0, st>>>(kv_seq_lens, batch, kv_heads, mi_gqa_wide::tile_keys(w), 1, workers, plan);
             w.plan = plan;
             w.num_splits = num_splits = 1;
             units = mi_sgl::plan_items_max((long long)batch * kv_heads, workers);

@@ -46,18 +46,29 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kT = kTile, kSlots = 4, kLead = 2;
+constexpr int kLead = 2;
 constexpr int KS = kDKP * 2 + 32, VS = kDVP * 2 + 32;                      // 608, 544 bytes per LDS row
-constexpr int kSlotBytes = kT * (KS + VS);                                 // 36864
-constexpr int kVOff = kT * KS;                                             // V tile inside a slot
-constexpr int kPxOff = kSlots * kSlotBytes;                                // P^T exchange buffer [head block 4][k-step 2][lane 64] x 16 B
-constexpr int kPxBytes = 8192;
-constexpr int kAlphaOff = kPxOff + kPxBytes;                               // float alpha[128]: accumulator rescale of a head in the current tile
-constexpr int kMovedOff = kAlphaOff + 512;                                 // uint32 moved[8]: tile + 1 of the last tile in which wave w moved a reference
-constexpr int kLds = kMovedOff + 32;                                       // 156192
+// T = keys per tile.  32: four slots of K[32][608 B] + V[32][544 B].  64 (V a column prefix of K, pages of >= 64 keys): three slots of
+// K[64][608 B] -- the P.V operand is read from the K tile, and a tile of twice the keys halves what a tile costs besides its MFMAs (two
+// barriers, the softmax's latency chain, the list / block-id bookkeeping), which is most of the loop at these head dims: 1088 MFMA cycles
+// per 32 keys against ~3300 measured.  Two tiles in flight either way (a fill goes to the slot of the tile before the one being multiplied).
+template <int T>
+struct Geo {
+    static constexpr int kKB = T / 16;                                      // key blocks of 16 (QK^T accumulators per wave, P.V k-steps)
+    static constexpr int kSlots = T == 64 ? 3 : 4;
+    static constexpr int kSlotBytes = T == 64 ? T * KS : T * (KS + VS);     // 38912 | 36864
+    static constexpr int kVOff = T * KS;                                    // V tile inside a slot (T = 32)
+    static constexpr int kPxOff = kSlots * kSlotBytes;                      // P^T exchange buffer [head block 4][k-step kKB][lane 64] x 16 B
+    static constexpr int kPxBytes = 128 * T * 2;
+    static constexpr int kAlphaOff = kPxOff + kPxBytes;                     // float alpha[128]: accumulator rescale of a head in the current tile
+    static constexpr int kMovedOff = kAlphaOff + 512;                       // uint32 moved[8]: tile + 1 of the last tile in which wave w moved a reference
+    static constexpr int kLds = kMovedOff + 32;                             // 156192 | 133664
+    static constexpr int kRows = T / 8;                                     // K (and V) rows a wave fetches per tile
+    static_assert(kLds <= 160 * 1024, "LDS budget");
+    static_assert((kLead + 1) % kSlots == 0 || kSlots == 4, "the fill of tile t + lead goes to the slot of tile t - 1");
+};
 constexpr int kQS = kDKP / 32;                                             // 9 k-steps
 constexpr float kLazy = 8.0f;
-static_assert(kLds <= 160 * 1024, "LDS budget");
 
 template <bool BF16>
 __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c)
@@ -117,20 +128,24 @@ struct TileAt {
     int last;                          // index (0..31) of the tile's last valid key (rows behind it re-read that row: finite bytes under P = 0)
 };
 __device__ __forceinline__ int tile_clamped(const Ctx &c, int tile) { return min(tile, c.ntiles - 1); }
+template <int T>
 __device__ __forceinline__ const int32_t *block_id_ptr(const Ctx &c, int tile)
 {
-    return c.p->block_table + ((int64_t)c.b * c.p->bt_stride + ((tile_clamped(c, tile) * kT) >> c.page_shift));
+    return c.p->block_table + ((int64_t)c.b * c.p->bt_stride + ((tile_clamped(c, tile) * T) >> c.page_shift));
 }
 // the block id of a tile: a scalar load the compiler does not see (see mla_decode_wide8s.hip: a load it tracks would wait vmcnt(0))
+template <int T>
 __device__ __forceinline__ int block_id_request(const Ctx &c, int tile)
 {
     int v;
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(block_id_ptr(c, tile)) : "memory");
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(block_id_ptr<T>(c, tile)) : "memory");
     return v;
 }
 __device__ __forceinline__ void block_id_wait(int &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)::"memory"); }
+template <int T>
 __device__ __forceinline__ TileAt tile_of(const Ctx &c, int tile, int blk)
 {
+    constexpr int kT = T;
     const int t = tile_clamped(c, tile);
     const uint32_t row0 = (uint32_t)(t * kT) & (uint32_t)(c.p->page_size - 1);
     TileAt r;
@@ -139,15 +154,17 @@ __device__ __forceinline__ TileAt tile_of(const Ctx &c, int tile, int blk)
     r.last = min(kT - 1, c.seq_len - 1 - t * kT);
     return r;
 }
-// operation idx 0..3: K row wave + 8 idx; 4..7: V row wave + 8 (idx - 4) (none when V is a column prefix of the K rows: the P.V operand is
+// operation idx 0 .. T / 8 - 1: K row wave + 8 idx; the next T / 8: V rows (none when V is a column prefix of the K rows: the P.V operand is
 // then read from the K tile, like the MLA kernels do).  One cache row per instruction; `slot` = LDS byte address
+template <int T>
 __device__ __forceinline__ void issue_op(const Ctx &c, const TileAt &tl, uint32_t slot, int idx)
 {
-    const int r = c.wave + 8 * (idx & 3), row = __builtin_amdgcn_readfirstlane(min(r, tl.last));      // (keeps the address arithmetic scalar)
-    if (idx < 4) {
+    constexpr int kRows = Geo<T>::kRows;
+    const int r = c.wave + 8 * (idx % kRows), row = __builtin_amdgcn_readfirstlane(min(r, tl.last));      // (keeps the address arithmetic scalar)
+    if (idx < kRows) {
         if (c.lane16 < (uint32_t)c.p->lk * 2u) dma16(slot + (uint32_t)(r * KS), tl.k + (int64_t)row * c.p->k_srow, c.lane16);
     } else {
-        if (c.lane16 < (uint32_t)c.p->lv * 2u) dma16(slot + (uint32_t)(kVOff + r * VS), tl.v + (int64_t)row * c.p->v_srow, c.lane16);
+        if (c.lane16 < (uint32_t)c.p->lv * 2u) dma16(slot + (uint32_t)(Geo<T>::kVOff + r * VS), tl.v + (int64_t)row * c.p->v_srow, c.lane16);
     }
 }
 
@@ -155,10 +172,14 @@ template <int N> struct SlotTag { static constexpr int value = N; };
 
 // VIEW: the V cache is the first lv columns of the K rows (same pointer and strides -- the reference test builds exactly that,
 // test_decode_attention.py:74): one fill serves both GEMMs
-template <bool BF16, bool VIEW>
+template <bool BF16, bool VIEW, int T>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gqa_decode_wide_kernel(Params p)
 {
-    constexpr int kOps = VIEW ? 4 : 8;                          // DMA operations per wave and tile: 4 K rows (+ 4 V rows)
+    static_assert(T == 32 || (T == 64 && VIEW), "64-key tiles: V is read from the K tile");
+    using G = Geo<T>;
+    constexpr int kT = T, kKB = G::kKB, kSlots = G::kSlots, kSlotBytes = G::kSlotBytes, kVOff = G::kVOff, kPxOff = G::kPxOff;
+    constexpr int kAlphaOff = G::kAlphaOff, kMovedOff = G::kMovedOff;
+    constexpr int kOps = VIEW ? G::kRows : 2 * G::kRows;        // DMA operations per wave and tile: the K rows (+ the V rows)
     constexpr int VSx = VIEW ? KS : VS, kVBase = VIEW ? 0 : kVOff;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -204,15 +225,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     int blk_next = 0;                                           // block id of tile t + lead, t = the tile at whose top it is read
     if (t_begin < t_end) {                                      // prologue: tiles t_begin, t_begin + 1 -> slots 0, 1, before the Q^T loads
-        int id0 = block_id_request(cx, t_begin), id1 = block_id_request(cx, t_begin + 1);
-        blk_next = block_id_request(cx, t_begin + kLead);
+        int id0 = block_id_request<T>(cx, t_begin), id1 = block_id_request<T>(cx, t_begin + 1);
+        blk_next = block_id_request<T>(cx, t_begin + kLead);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(id0), "+s"(id1), "+s"(blk_next)::"memory");
         const int ids[kLead] = {id0, id1};
 #pragma unroll
         for (int d = 0; d < kLead; ++d) {
-            const TileAt tl = tile_of(cx, t_begin + d, ids[d]);
+            const TileAt tl = tile_of<T>(cx, t_begin + d, ids[d]);
 #pragma unroll
-            for (int i = 0; i < kOps; ++i) issue_op(cx, tl, (uint32_t)(d * kSlotBytes), i);
+            for (int i = 0; i < kOps; ++i) issue_op<T>(cx, tl, (uint32_t)(d * kSlotBytes), i);
         }
     }
     // Q^T fragments (B operand of 16x16x32): lane (h16, g) holds q[head][32 ks + 8 g .. +8], zero behind lk
@@ -267,30 +288,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + kk * 16 * VSx + 8 * VSx));
             return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
-        auto ldp = [&](int hb, int kk) -> s16x8 { return *(const s16x8 *)(pb + (hb * 2 + kk) * 1024); };
-        const s16x8 a0 = lda(0), a1 = lda(1);
-        s16x8 pf[8];
+        auto ldp = [&](int hb, int kk) -> s16x8 { return *(const s16x8 *)(pb + (hb * kKB + kk) * 1024); };
+        s16x8 a[kKB], pf[4 * kKB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pf[i] = ldp(i & 3, i >> 2);
+        for (int kk = 0; kk < kKB; ++kk) a[kk] = lda(kk);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i & 3] = mfma32<BF16>(i < 4 ? a0 : a1, pf[i], acc[i & 3]);
+        for (int i = 0; i < 4 * kKB; ++i) pf[i] = ldp(i & 3, i >> 2);
+#pragma unroll
+        for (int i = 0; i < 4 * kKB; ++i) acc[i & 3] = mfma32<BF16>(a[i >> 2], pf[i], acc[i & 3]);
     };
     // top of tile t: this wave's operations of t have landed (the 8 of tile t + 1 may be in flight), barrier A: tile t complete in LDS,
     // everybody done with tile t - 1 and with the exchange buffer
     auto tile_top = [&](int t) -> TileAt {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps * (kLead - 1)) : "memory");
         __syncthreads();
-        return tile_of(cx, t + kLead, blk_next);
+        return tile_of<T>(cx, t + kLead, blk_next);
     };
     auto pv_and_next_id = [&](auto slot_tag, int t) {
-        int id = block_id_request(cx, t + 1 + kLead);
+        int id = block_id_request<T>(cx, t + 1 + kLead);
         pv(slot_tag, t);
         block_id_wait(id);
         blk_next = id;
     };
     const int hbw = wave >> 1;                                  // exchange-buffer coordinates of this wave's P^T pieces: consumer lane
     const int lc = (g & 1) * 32 + (wave & 1) * 16 + h16;        // (kg = g & 1, c32 = 16 (w & 1) + h16), half g >> 1 of its 16 bytes
-    const uint32_t pdst_off = (uint32_t)(kPxOff + (hbw * 2 * 64 + lc) * 16 + (g >> 1) * 8);
+    const uint32_t pdst_off = (uint32_t)(kPxOff + (hbw * kKB * 64 + lc) * 16 + (g >> 1) * 8);      // + 1024 per key block
     const uint32_t a_lane = (uint32_t)(h16 * KS + g * 16);
 
     auto body = [&](auto slot_tag, int t) {
@@ -299,34 +321,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const TileAt tl = tile_top(t);
         if (!wave_active) {                                     // no heads of its own: DMA share, P = 0 (written once, below), P.V slice
 #pragma unroll
-            for (int i = 0; i < kOps; ++i) issue_op(cx, tl, nslot, i);
+            for (int i = 0; i < kOps; ++i) issue_op<T>(cx, tl, nslot, i);
             asm volatile("s_barrier" ::: "memory");              // barrier B
             pv_and_next_id(slot_tag, t);
             return;
         }
         // ---- S^T[key, head] = K . Q^T: 9 k-steps x 2 key blocks of 16, operand fragments three MFMAs ahead, a DMA operation every
         // GQAW_DMA_EVERY MFMAs (0: all of them in front of the first MFMA)
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc[kKB];
+#pragma unroll
+        for (int kb = 0; kb < kKB; ++kb) sc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
             const uint8_t *abase = lds + SLOT * kSlotBytes + a_lane;
-            auto lda = [&](int step) -> s16x8 { return *(const s16x8 *)(abase + (step & 1) * 16 * KS + (step >> 1) * 64); };
+            auto lda = [&](int step) -> s16x8 { return *(const s16x8 *)(abase + (step % kKB) * 16 * KS + (step / kKB) * 64); };
             constexpr int kAhead = 3, kRing = kAhead + 1, kEvery = GQAW_DMA_EVERY;
             if constexpr (kEvery == 0)
 #pragma unroll
-                for (int i = 0; i < kOps; ++i) issue_op(cx, tl, nslot, i);
+                for (int i = 0; i < kOps; ++i) issue_op<T>(cx, tl, nslot, i);
             s16x8 af[kRing];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pre = 0; pre < kAhead; ++pre) af[pre] = lda(pre);
 #pragma unroll
-            for (int step = 0; step < 2 * kQS; ++step) {
+            for (int step = 0; step < kKB * kQS; ++step) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (step + kAhead < 2 * kQS) af[(step + kAhead) % kRing] = lda(step + kAhead);
+                if (step + kAhead < kKB * kQS) af[(step + kAhead) % kRing] = lda(step + kAhead);
                 __builtin_amdgcn_sched_barrier(0);
-                if (step & 1) s1 = mfma16<BF16>(af[step % kRing], qf[step >> 1], s1);
-                else s0 = mfma16<BF16>(af[step % kRing], qf[step >> 1], s0);
+                sc[step % kKB] = mfma16<BF16>(af[step % kRing], qf[step / kKB], sc[step % kKB]);
                 if constexpr (kEvery > 0)
-                    if (step % kEvery == kEvery - 1 && step / kEvery < kOps) issue_op(cx, tl, nslot, step / kEvery);
+                    if (step % kEvery == kEvery - 1 && step / kEvery < kOps) issue_op<T>(cx, tl, nslot, step / kEvery);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -334,12 +357,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if ((t + 1) * kT > seq_len) {
             const int kbase = t * kT + 4 * g;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (kbase + i >= seq_len) s0[i] = -INFINITY;
-                if (kbase + 16 + i >= seq_len) s1[i] = -INFINITY;
-            }
+            for (int kb = 0; kb < kKB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (kbase + 16 * kb + i >= seq_len) sc[kb][i] = -INFINITY;
         }
-        float tmax = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        float tmax = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+#pragma unroll
+        for (int kb = 1; kb < kKB; ++kb) tmax = fmaxf(tmax, fmaxf(fmaxf(sc[kb][0], sc[kb][1]), fmaxf(sc[kb][2], sc[kb][3])));
         tmax = max_over_rows(tmax) * cs;                        // sm_scale > 0: max commutes with the scaling; a tile below the end holds a key
         const bool move = tmax > m_ref + kLazy || m_ref == -INFINITY;
         if (__any(move)) {
@@ -352,23 +377,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         const float nm = -m_ref;
-        float e[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], cs, nm));
-            e[4 + i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], cs, nm));
-        }
-        l_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
         uint8_t *pdst = lds + pdst_off;
-        *(uint2 *)(pdst) = uint2{pack2<BF16>(e[0], e[1]), pack2<BF16>(e[2], e[3])};
-        *(uint2 *)(pdst + 1024) = uint2{pack2<BF16>(e[4], e[5]), pack2<BF16>(e[6], e[7])};
+#pragma unroll
+        for (int kp = 0; kp < kKB; kp += 2) {                   // key blocks in pairs: the sums of a 32-key tile keep their order
+            float e[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kp][i], cs, nm));
+                e[4 + i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kp + 1][i], cs, nm));
+            }
+            l_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+            *(uint2 *)(pdst + kp * 1024) = uint2{pack2<BF16>(e[0], e[1]), pack2<BF16>(e[2], e[3])};
+            *(uint2 *)(pdst + (kp + 1) * 1024) = uint2{pack2<BF16>(e[4], e[5]), pack2<BF16>(e[6], e[7])};
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");                   // barrier B: P^T(t), alpha, moved complete
         pv_and_next_id(slot_tag, t);
     };
     if (!wave_active) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) *(uint2 *)(lds + pdst_off + kb * 1024) = uint2{0u, 0u};
+        for (int kb = 0; kb < kKB; ++kb) *(uint2 *)(lds + pdst_off + kb * 1024) = uint2{0u, 0u};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     for (int t = t_begin; t < t_end;) {
@@ -377,8 +405,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         body(SlotTag<1>{}, t);
         if (++t >= t_end) break;
         body(SlotTag<2>{}, t);
-        if (++t >= t_end) break;
-        body(SlotTag<3>{}, t);
+        if constexpr (kSlots == 4) {
+            if (++t >= t_end) break;
+            body(SlotTag<3>{}, t);
+        }
         ++t;
     }
     l_run = sum_over_rows(l_run);                               // the four key groups of a head
@@ -436,25 +466,38 @@ bool applies(int group, int lk, int lv, int page_size, int64_t k_sblk, int64_t k
            page_size >= kTile && fits(k_sblk, 40) && fits(v_sblk, 40) && fits(k_srow, 31) && fits(v_srow, 31);
 }
 
+static bool is_view(const Params &p) { return p.v == p.k && p.v_sblk == p.k_sblk && p.v_srow == p.k_srow && p.v_sh == p.k_sh && p.lv <= p.lk; }
+// keys per tile of the instance that serves `p` (the unit of its work list): 64 when V is a column prefix of K and a page holds a tile
+int tile_keys(const Params &p)
+{
+    static const bool allow64 = !(getenv("MI_GQA_WIDE_T64") && atoi(getenv("MI_GQA_WIDE_T64")) == 0);
+    return allow64 && is_view(p) && p.page_size >= 64 ? 64 : 32;
+}
+
 void launch(const Params &p, int dtype, long long units, hipStream_t st)
 {
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
-        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+#define MI_GQAW_ATTR(B, V, T) (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<B, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<T>::kLds)
+        MI_GQAW_ATTR(true, false, 32); MI_GQAW_ATTR(false, false, 32); MI_GQAW_ATTR(true, true, 32); MI_GQAW_ATTR(false, true, 32);
+        MI_GQAW_ATTR(true, true, 64); MI_GQAW_ATTR(false, true, 64);
+#undef MI_GQAW_ATTR
     }
     const int head_blocks = (p.group + 127) / 128;
     dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
-    const bool view = p.v == p.k && p.v_sblk == p.k_sblk && p.v_srow == p.k_srow && p.v_sh == p.k_sh && p.lv <= p.lk;
+    const bool view = is_view(p);
+    const int tile = tile_keys(p);
+#define MI_GQAW_LAUNCH(B, V, T) gqa_decode_wide_kernel<B, V, T><<<grid, 512, Geo<T>::kLds, st>>>(p)
     if (dtype == MI_DTYPE_BF16) {
-        if (view) gqa_decode_wide_kernel<true, true><<<grid, 512, kLds, st>>>(p);
-        else gqa_decode_wide_kernel<true, false><<<grid, 512, kLds, st>>>(p);
+        if (tile == 64) MI_GQAW_LAUNCH(true, true, 64);
+        else if (view) MI_GQAW_LAUNCH(true, true, 32);
+        else MI_GQAW_LAUNCH(true, false, 32);
     } else {
-        if (view) gqa_decode_wide_kernel<false, true><<<grid, 512, kLds, st>>>(p);
-        else gqa_decode_wide_kernel<false, false><<<grid, 512, kLds, st>>>(p);
+        if (tile == 64) MI_GQAW_LAUNCH(false, true, 64);
+        else if (view) MI_GQAW_LAUNCH(false, true, 32);
+        else MI_GQAW_LAUNCH(false, false, 32);
     }
+#undef MI_GQAW_LAUNCH
 }
 
 }  // namespace mi_gqa_wide

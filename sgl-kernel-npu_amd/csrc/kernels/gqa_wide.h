@@ -6,7 +6,7 @@
 
 namespace mi_gqa_wide {
 
-constexpr int kTile = 32;             // keys per tile (the unit of the work list)
+constexpr int kTile = 32;             // keys per tile of the general instance (tile_keys(): what a given call's work list counts in)
 constexpr int kDKP = 288, kDVP = 256; // padded head dims of the one instance
 
 struct Params {
@@ -18,11 +18,13 @@ struct Params {
     int batch, q_heads, kv_heads, group, page_size, bt_stride, num_splits, lk, lv;
     int64_t q_sb, q_sh, k_sblk, k_srow, k_sh, v_sblk, v_srow, v_sh, o_sb, o_sh;
     float sm_scale;
-    const int32_t *plan;          // decode_plan.h work list in 32-key tiles; null = uniform num_splits
+    const int32_t *plan;          // decode_plan.h work list in tiles of tile_keys() keys; null = uniform num_splits
 };
 
 // applies to: 64 < group, lk <= 288, lv <= 256 (multiples of 8), power-of-two pages of >= 32 keys, row strides whose in-page offsets fit 32 bits
 bool applies(int group, int lk, int lv, int page_size, int64_t k_sblk, int64_t k_srow, int64_t v_sblk, int64_t v_srow);
+// keys per tile for this call: 64 when V is a column prefix of the K rows and pages hold >= 64 keys, else 32 (needs k, v, strides, lk, lv, page_size)
+int tile_keys(const Params &p);
 // units: (sequence, kv head, split) triples of the uniform form, or the work list's item bound
 void launch(const Params &p, int dtype, long long units, hipStream_t st);
 

@@ -106,6 +106,11 @@ CASES = [  # B, Hq, Hkv, Lk, Lv, S, page, ragged, v_is_view
     (1, 256, 2, 288, 128, 200, 64, True, False),      # two kv heads of 128; V narrower than the padded 256
     (2, 200, 1, 224, 200, 97, 128, True, False),      # two head blocks (128 + 72 heads), odd dims (multiples of 8), S < page
     (2, 128, 1, 288, 256, 1, 64, False, True),        # a single key
+    # V a column prefix of K (the reference test's own construction) on pages of >= 64 keys: the 64-key-tile instance (three slots, P.V from the K tile)
+    (3, 128, 1, 288, 256, 700, 64, True, True),       # several tiles per split, ragged, the last tile partly filled
+    (2, 96, 1, 256, 224, 330, 64, True, True),        # 96 heads (two idle head waves), dims below the padded (288, 256)
+    (1, 256, 2, 288, 128, 450, 128, True, True),      # two kv heads of 128 q heads
+    (2, 128, 1, 288, 256, 330, 32, True, True),       # pages of 32 keys: the view form on 32-key tiles
 ]
 
 
@@ -330,7 +335,8 @@ def test_planned_work_list_and_outputs_match_one_piece_per_sequence(B, Hq, Hkv, 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("splits", [1, 2, PLANNED])
-def test_wide_kernel_moves_its_softmax_reference(dtype, splits):
+@pytest.mark.parametrize("view", [False, True], ids=["own_v", "v_view"])
+def test_wide_kernel_moves_its_softmax_reference(dtype, splits, view):
     """gqa_decode_wide.hip keeps a LAZY softmax reference per head (it moves only when a tile's maximum exceeds it by > 8 in the log2 domain, the
     head's owner then publishes the accumulator rescale for the dimension owners).  Scores that keep growing along the sequence -- and heads
     that grow at different rates, so that in most tiles only SOME waves move -- must still give the exact softmax."""
@@ -350,22 +356,26 @@ def test_wide_kernel_moves_its_softmax_reference(dtype, splits):
     k = kk.reshape(B * maxp, page, 1, Lk).to(dtype)
     q = (q.float() + (torch.arange(Hq).float()[None, :, None] / Hq * 6.0) * u[None, None, :]).to(dtype)
     sm = 1.0 / Lk ** 0.5
+    if view:                                          # (the 64-key-tile instance: V = the first Lv columns of K)
+        v = k[..., :Lv]
     want = OK.decode_gqa(q, k, v, lens, bt, sm)
-    got = run_gqa(q.cuda(), k.cuda(), v.cuda(), lens.cuda(), bt.cuda(), sm, splits).cpu()
+    kc = k.cuda()
+    got = run_gqa(q.cuda(), kc, kc[..., :Lv] if view else v.cuda(), lens.cuda(), bt.cuda(), sm, splits).cpu()
     assert not torch.isnan(got.float()).any()
     check(got, want, exact_fp64(q, k, v, lens, bt, sm), dtype)
 
 
-def test_wide_kernel_full_size_vs_fp32():
+@pytest.mark.parametrize("view", [False, True], ids=["own_v", "v_view"])
+def test_wide_kernel_full_size_vs_fp32(view):
     """The reference test's own shape at serving size (test_decode_attention.py:242: 128 q heads on 1 kv head, 288 / 256): batch 128, 4096 keys,
-    ragged, random page table; sampled rows against an fp32 evaluation on the GPU."""
+    ragged, random page table; sampled rows against an fp32 evaluation on the GPU.  v_view: V = k[..., :256] as the reference test builds it."""
     B, Hq, D, Dv, S, page = 128, 128, 288, 256, 4096, 64
     maxp = S // page
     nb = B * maxp
     g = torch.Generator(device="cuda").manual_seed(6)
     q = torch.randn((B, Hq, D), generator=g, device="cuda").to(torch.bfloat16)
     k = torch.randn((nb, page, 1, D), generator=g, device="cuda").to(torch.bfloat16)
-    v = torch.randn((nb, page, 1, Dv), generator=g, device="cuda").to(torch.bfloat16)
+    v = k[..., :Dv] if view else torch.randn((nb, page, 1, Dv), generator=g, device="cuda").to(torch.bfloat16)
     bt = torch.randperm(nb, device="cuda").to(torch.int32).reshape(B, maxp)
     lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
     lens[0] = S

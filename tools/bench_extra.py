@@ -171,9 +171,16 @@ def main():
         bt = torch.randperm(nb, device="cuda").to(torch.int32).reshape(Bq, Sq // page)
         lens = torch.full((Bq,), Sq, dtype=torch.int32, device="cuda")
         o = torch.empty((Bq, Hq, Dv), device="cuda", dtype=torch.bfloat16)
-        t = ev_time(lambda: decode_gqa(q, kc, vc, o, lens, D ** -0.5, page, bt), n=20, warm=3)
+        # MFMA-heavy decode kernels: 200 warm-up calls let the clocks settle (bench.py times MLA decode the same way); `queued_us` = 100 calls
+        # queued back to back (what the layers of a decode step see), p50 / p99 / min = single calls with a synchronisation after each
+        call = lambda: decode_gqa(q, kc, vc, o, lens, D ** -0.5, page, bt)
+        t = ev_time(call, n=30, warm=200)
+        a, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(100): call()
+        b2.record(); torch.cuda.synchronize()
         kv_bytes = Bq * Sq * Hkv * (D if D != Dv else D + Dv) * 2
-        out[name] = dict(t, GBps=kv_bytes / t["p50_us"] / 1e3)
+        out[name] = dict(t, GBps=kv_bytes / t["p50_us"] / 1e3, queued_us=a.elapsed_time(b2) * 10.0, v_is_view_of_k=bool(D != Dv))
     # ---- mla_preprocess (decode: 128 tokens, DeepSeek-V3 shapes: hidden 7168, 128 heads)
     N, Hh = 128, 128
     dt = torch.bfloat16
