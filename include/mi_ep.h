@@ -266,6 +266,15 @@ int mi_ep_dispatch_stage_push(const void *x, const void *topk_idx, int idx_is_i3
 int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
                        int hidden, int num_topk, void *const *dst_base_host, int num_ranks, size_t slot_region_bytes,
                        const uint64_t *epoch_ctr, size_t parity_stride, int my_rank, int32_t *local_row, void *stream);
+/* push + "my rows are pushed" + the wait for every expert rank in ONE launch (mi_ep_combine_push followed by mi_ep_signal_wait with
+ * epoch_ctr): every workgroup writes its rows through the caches, drains and counts itself in at *arrive_word (a device word of the
+ * rank's own control area: zero before the first call; the kernel re-arms it); the last workgroup to arrive raises this rank's flag at
+ * every owner, waits (bounded by timeout_ms, reported through *status) for every expert rank's and completes the family's call counter.
+ * Same bytes in the same slots.  One call in flight per arrive_word. */
+int mi_ep_combine_push_signal_wait(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int hidden, int num_topk,
+                                   void *const *dst_base_host, int num_ranks, size_t slot_region_bytes, uint64_t *epoch_ctr,
+                                   size_t parity_stride, int my_rank, int32_t *local_row, uint64_t *const *peer_flags_host,
+                                   const uint64_t *my_flags, uint32_t *arrive_word, int32_t *status, int timeout_ms, void *stream);
 int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                          const int32_t *send_data_offset, const int32_t *send_token_idx_small, int num_tokens,
                          int num_topk, int hidden, int num_experts, void *out, const uint64_t *epoch_ctr, size_t parity_stride,
@@ -321,6 +330,22 @@ int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_counts, uint3
                            void *packed_recv_x, float *packed_recv_x_scales, int64_t *packed_recv_count,
                            int32_t *src_info, int32_t *layout_range, int rows_capacity /* rows packed_recv_x holds; 0 = L*W*max_tokens */,
                            int32_t *status, int timeout_ms, void *stream);
+/* Layout + send + the count exchange in ONE launch, then the packing launch: two launches per low-latency dispatch instead of three.
+ * mi_ep_ll_dispatch_layout_send_counts = mi_ep_ll_dispatch_layout_send whose workgroups count themselves in at *arrive_word (a device
+ * word of the rank's own control area: zero before the first call; the kernel re-arms it) once their rows -- written through the caches
+ * -- have drained; the last one to arrive posts this rank's per-expert counts, collects everybody's (bounded by timeout_ms, reported
+ * through *status), leaves the cumulative counts in layout_range [L*W] and packed_recv_count [L], and completes the family's call
+ * counter (epoch_ctr: required).  mi_ep_ll_pack = the packing half of mi_ep_ll_post_recv.  Same rows, tables and bytes. */
+int mi_ep_ll_dispatch_layout_send_counts(const void *x, const void *topk_idx, int idx_is_i32, int num_tokens, int num_topk, int hidden,
+                                         int num_experts, int num_ranks, int my_rank, int max_tokens, int quant_mode, void *const *peer_rows_host,
+                                         uint64_t *epoch_ctr, size_t parity_stride, int32_t *num_tokens_per_rank,
+                                         int32_t *num_tokens_per_expert, int32_t *is_token_in_rank, int32_t *send_token_idx_small,
+                                         int32_t *send_data_offset, uint64_t *const *peer_counts_host, const uint64_t *my_counts,
+                                         size_t counts_parity_stride, int count_type, int32_t *layout_range, int64_t *packed_recv_count,
+                                         uint32_t *arrive_word, int32_t *status, int timeout_ms, void *stream);
+int mi_ep_ll_pack(const void *my_rows, const int32_t *layout_range, int num_ranks, int num_local_experts, int max_tokens, int hidden,
+                  int quant_mode, void *packed_recv_x, float *packed_recv_x_scales, int32_t *src_info, int rows_capacity,
+                  const uint64_t *epoch_ctr, size_t rows_parity_stride, void *stream);
 /* ll_post_counts fused into the receive (one rank per process): the counts workgroup posts this rank's counts, collects
  * everybody's, scans them; the packing kernel follows.  Two launches instead of three. */
 int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32_t *num_tokens_per_expert, int my_rank, const void *my_rows,

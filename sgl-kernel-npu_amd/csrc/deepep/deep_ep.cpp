@@ -717,14 +717,20 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
     // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
     // rows whose token lives on this rank stay where they are: the push only records their row number, the reduce reads x
     auto local_row = combine_local_rows(topk_idx);
-    { ProfScope ps_(this, "combine_push", st);
-      MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1), (int)x.size(0), H, K,
-                                     dst_peers.data(), W, region_bytes, epoch_ctr(kCombine), region_bytes, (int)rank,
-                                     local_row.defined() ? local_row.data_ptr<int>() : nullptr, st)); }
-    if (combine_send_cost_stats.has_value())
+    bool signalled = false;
+    // (with send-cost statistics asked for, the push stays a launch of its own: the statistic is the time until the rows are out)
+    if (combine_send_cost_stats.has_value()) {
+        ProfScope ps_(this, "combine_push", st);
+        MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1), (int)x.size(0), H, K,
+                                       dst_peers.data(), W, region_bytes, epoch_ctr(kCombine), region_bytes, (int)rank,
+                                       local_row.defined() ? local_row.data_ptr<int>() : nullptr, st));
         MI_EP_CHECK(mi_ep_elapsed_add(combine_send_cost_stats->data_ptr<int>(), W, (const uint64_t *)t_start.data_ptr(), st));
+    } else {
+        combine_push_rows(x, src_idx.data_ptr<int>(), send_head.data_ptr<int>() + (E - 1), (int)x.size(0), H, K, local_row, "combine_push", st,
+                          signalled);
+    }
     return {combine_finish(topk_idx, topk_weights.has_value() ? topk_weights->data_ptr<float>() : nullptr, H, E, x.options(),
-                           "combine_reduce", st, x, local_row),
+                           "combine_reduce", st, x, local_row, signalled),
             std::nullopt, std::nullopt};
 }
 
@@ -800,6 +806,8 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
     // side by side; a send wave counts its slab position itself in an LDS copy of the routing table (mi_ep_ll_dispatch_layout_send).
     static const bool fused_send = get_value_from_env("MI_EP_LL_FUSED", 1) != 0;
     Layout lay;
+    at::Tensor counts_buf;
+    bool counts_done = false;
     if (fused_send && T <= 1024 && (size_t)16 * E <= 16384 && E % 2 == 0) {
         lay.T = T, lay.K = K, lay.E = E;
         // the five layout tables carved out of ONE allocation (each at::empty costs ~1-2 us of host time in front of the first launch)
@@ -812,11 +820,31 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
         lay.is_token_in_rank = take((int64_t)T * W).view({T, W});
         lay.send_token_idx_small = take((int64_t)T * K).view({T, K});
         lay.send_data_offset = take(E);
+        // ... and, opt-in (MI_EP_LL_FUSED_COUNTS=1), the count exchange in the same launch: its last workgroup to finish posts and
+        // collects the counts, two launches per dispatch instead of three.  Built, bit-exact, and SLOWER on one GPU: 25.4 against 22.7 us
+        // per call (pair in a graph of ten: 31.7 against 27.0) -- every workgroup pays a drain + a device-scope arrival, the layout
+        // workgroup a release, the rows go through the caches to HBM instead of waiting in L2 for the packing launch; the kernel boundary
+        // it saves costs less than that (MI355X_MICROARCH.md: ~1.5 us).  Left off, like the combine side of the same idea (combine_push_rows).
+        static const bool fused_counts = get_value_from_env("MI_EP_LL_FUSED_COUNTS", 0) != 0;
+        if (fused_counts) {
+            counts_buf = at::empty({(int64_t)L * W + 2 * (int64_t)L + 2}, i32);      // ep_recv_count [L*W] | packed_recv_count [L] (int64, 8-byte aligned)
+            auto cnt_peers0 = peer_ptrs((size_t)kOffLLCounts);
+            const int64_t off64 = ((int64_t)L * W + 1) / 2 * 2;
+            ProfScope ps_(this, "ll_dispatch_layout_send_counts", st);
+            MI_EP_CHECK(mi_ep_ll_dispatch_layout_send_counts(
+                x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, T, K, H, E, W, (int)rank, MT, qm, row_peers.data(), ctr,
+                region_bytes, lay.num_tokens_per_rank.data_ptr<int>(), lay.num_tokens_per_expert.data_ptr<int>(),
+                lay.is_token_in_rank.data_ptr<int>(), lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(),
+                (uint64_t *const *)cnt_peers0.data(), (const uint64_t *)(window + kOffLLCounts), (size_t)kLLCountsParityBytes, count_type,
+                counts_buf.data_ptr<int>(), (int64_t *)(counts_buf.data_ptr<int>() + off64), arrive_word(), status_dev, timeout_ms, st));
+            counts_done = true;
+        } else {
         ProfScope ps_(this, "ll_dispatch_layout_send", st);
         MI_EP_CHECK(mi_ep_ll_dispatch_layout_send(x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, T, K, H, E, W, (int)rank,
                                                   MT, qm, row_peers.data(), ctr, region_bytes, lay.num_tokens_per_rank.data_ptr<int>(),
                                                   lay.num_tokens_per_expert.data_ptr<int>(), lay.is_token_in_rank.data_ptr<int>(),
                                                   lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(), st));
+        }
     } else {
         lay = run_layout(topk_idx, E);
         ProfScope ps_(this, "ll_dispatch_send", st);
@@ -835,11 +863,24 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
         packed_recv_x_scales = at::empty({num_max_tokens}, at::dtype(at::kFloat).device(dev));
     }
     auto expand_idx = at::empty({max_size}, i32);
-    auto ep_recv_count = at::empty({(int64_t)L * W}, i32);
-    auto packed_recv_count = at::empty({L}, at::dtype(at::kLong).device(dev));
+    at::Tensor ep_recv_count, packed_recv_count;
+    if (counts_done) {                                          // (views of the buffer the first launch filled)
+        const int64_t off64 = ((int64_t)L * W + 1) / 2 * 2;
+        ep_recv_count = counts_buf.narrow(0, 0, (int64_t)L * W);
+        packed_recv_count = counts_buf.narrow(0, off64, 2 * (int64_t)L).view(at::kLong);
+    } else {
+        ep_recv_count = at::empty({(int64_t)L * W}, i32);
+        packed_recv_count = at::empty({L}, at::dtype(at::kLong).device(dev));
+    }
     auto cnt_peers = peer_ptrs((size_t)kOffLLCounts);
     // rows the output tensors hold (and src_info / 3): the packing kernel never writes past them, whatever the counts say
     const int rows_capacity = (int)std::min<int64_t>(num_max_tokens, max_size / 3);
+    if (counts_done) {
+        ProfScope ps_(this, "ll_dispatch_recv", st);
+        MI_EP_CHECK(mi_ep_ll_pack(family_base(kLLDispatch), ep_recv_count.data_ptr<int>(), W, L, MT, H, qm, packed_recv_x.data_ptr(),
+                                  qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(), expand_idx.data_ptr<int>(),
+                                  rows_capacity, ctr, region_bytes, st));
+    } else
     { ProfScope ps_(this, "ll_dispatch_recv", st);
       MI_EP_CHECK(mi_ep_ll_post_recv((uint64_t *const *)cnt_peers.data(), lay.num_tokens_per_expert.data_ptr<int>(), (int)rank,
                                      family_base(kLLDispatch), (const uint64_t *)(window + kOffLLCounts), 0, W, L, MT, H, qm, count_type,
@@ -885,13 +926,11 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx_user
     auto dst_peers = peer_family_bases(kCombine);
     // valid packed rows = layout_range[L*W-1], read on device
     auto local_row = combine_local_rows(topk_idx);
-    { ProfScope ps_(this, "ll_combine_push", st);
-      MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
-                                     (int)std::min<int64_t>(x.size(0), src_info.numel() / 3), H, K, dst_peers.data(), W, region_bytes,
-                                     epoch_ctr(kCombine), region_bytes, (int)rank,
-                                     local_row.defined() ? local_row.data_ptr<int>() : nullptr, st)); }
+    bool signalled = false;
+    combine_push_rows(x, src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
+                      (int)std::min<int64_t>(x.size(0), src_info.numel() / 3), H, K, local_row, "ll_combine_push", st, signalled);
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
-    return {combine_finish(topk_idx, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st, x, local_row),
+    return {combine_finish(topk_idx, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st, x, local_row, signalled),
             std::nullopt, std::function<void()>([] {})};
 }
 
@@ -922,12 +961,42 @@ at::Tensor Buffer::combine_local_rows(const at::Tensor &topk_idx) const
     return at::empty({topk_idx.numel()}, at::dtype(at::kInt).device(topk_idx.device()));
 }
 
+// Device words the fused push counts its workgroups in at (control area, zeroed at creation, re-armed by the kernel): dealt from a ring of
+// 16, so that calls of one Buffer that overlap on two streams (two-batch overlap) never share one; a captured call keeps its word, and
+// the replays of one graph serialise on its stream.
+uint32_t *Buffer::arrive_word() { return (uint32_t *)(window + kOffEpochs + 1024) + 2 * (arrive_calls++ % 16); }
+
+void Buffer::combine_push_rows(const at::Tensor &x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int H, int K,
+                               const at::Tensor &local_row, const char *name, hipStream_t st, bool &signalled)
+{
+    // Opt-in (MI_EP_COMBINE_FUSED=1).  Measured on one GPU, same box, alternating: a lone low-latency combine 13.1-13.3 us against
+    // 13.5-16.0 for the three launches, but the dispatch + combine pair inside a captured graph of ten 28.7 against 27.2 us -- where a
+    // kernel boundary costs ~1.3 us, 256 workgroups arriving at one word and a tail that waits inside the push cost more than the launch
+    // they replace; the normal-mode step is unchanged (0.164-0.167 against 0.163-0.165 ms).  Off by default.
+    static const bool fused = get_value_from_env("MI_EP_COMBINE_FUSED", 0) != 0;
+    const int W = (int)num_ranks;
+    auto dst_peers = peer_family_bases(kCombine);
+    int32_t *lr = local_row.defined() ? local_row.data_ptr<int>() : nullptr;
+    ProfScope ps_(this, name, st);
+    if (fused) {
+        auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
+        MI_EP_CHECK(mi_ep_combine_push_signal_wait(x.data_ptr(), src_idx, total_rows_dev, rows_hint, H, K, dst_peers.data(), W, region_bytes,
+                                                   epoch_ctr(kCombine), region_bytes, (int)rank, lr, (uint64_t *const *)flag_peers.data(),
+                                                   (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), arrive_word(),
+                                                   status_dev, timeout_ms, st));
+        signalled = true;
+    } else {
+        MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx, total_rows_dev, rows_hint, H, K, dst_peers.data(), W, region_bytes,
+                                       epoch_ctr(kCombine), region_bytes, (int)rank, lr, st));
+    }
+}
+
 at::Tensor Buffer::combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
-                                  const char *reduce_name, hipStream_t st, const at::Tensor &x_local, const at::Tensor &local_row)
+                                  const char *reduce_name, hipStream_t st, const at::Tensor &x_local, const at::Tensor &local_row, bool signalled)
 {
     const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), W = (int)num_ranks;
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
-    { ProfScope ps_(this, "combine_signal_wait", st);
+    if (!signalled) { ProfScope ps_(this, "combine_signal_wait", st);
       MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
                                     (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, 0,
                                     epoch_ctr(kCombine), status_dev, timeout_ms, st)); }

@@ -238,7 +238,12 @@ private:
                        at::Tensor &rx, at::Tensor &rs, at::Tensor &src_idx, hipStream_t st);
     at::Tensor combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
                               const char *reduce_name, hipStream_t st, const at::Tensor &x_local = at::Tensor(),
-                              const at::Tensor &local_row = at::Tensor());
+                              const at::Tensor &local_row = at::Tensor(), bool signalled = false);
+    // push + signal + wait in one launch (mi_ep_combine_push_signal_wait); MI_EP_COMBINE_FUSED=0: the separate signal_wait launch
+    void combine_push_rows(const at::Tensor &x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int H, int K,
+                           const at::Tensor &local_row, const char *name, hipStream_t st, bool &signalled);
+    uint32_t *arrive_word();
+    uint64_t arrive_calls = 0;
     at::Tensor combine_local_rows(const at::Tensor &topk_idx) const;
     struct LocalRowEntry {
         at::Tensor src_idx, rows;

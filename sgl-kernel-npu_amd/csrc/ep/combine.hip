@@ -21,10 +21,24 @@ namespace mi_ep {
 
 constexpr int kPushWaves = 4;
 
+// "My rows are pushed" raised from INSIDE the push launch (TAIL): every workgroup writes its rows through (sc0 sc1), drains, and counts
+// itself in at a device word of the rank's control area; the last one to arrive does what signal_wait_kernel does in a launch of its
+// own -- raise this rank's flag at every owner, wait (bounded) for every expert rank's, complete the family's call counter -- and
+// re-arms the word.  One launch and one kernel boundary less per combine (low-latency: three launches -> two).
+struct PushTail {
+    uint32_t *arrive;             // zero between calls (control area: zeroed at creation, re-armed by the last arriver)
+    PeerPtrs flag_peers;          // every rank's combine flag group
+    const uint64_t *my_flags;
+    uint64_t *epoch_bump;         // the family's completed-call counter (also this call's epoch source: counter + 1)
+    int32_t *status;
+    uint64_t timeout_ticks;
+};
+
+template <bool TAIL>
 __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     const uint8_t *__restrict__ x, const int32_t *__restrict__ src_idx, const int32_t *__restrict__ total_dev,
     int rows_hint, int row_bytes /*2H*/, size_t slot_stride, int K, int W, PeerPtrs dsts, Parity par, int slot_rows, int my_rank,
-    int32_t *__restrict__ local_row, unsigned deal_stride)
+    int32_t *__restrict__ local_row, unsigned deal_stride, PushTail tail)
 {
     // never trust the device-side count beyond the rows the caller's tensor holds
     const int total = total_dev ? min(*total_dev, rows_hint) : rows_hint;
@@ -62,7 +76,41 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
             // straight-line groups of whole 1 KB pieces (copy_row, ep_common.h): loads back to back, then the (possibly remote) stores.
             // (nontemporal stores were measured: the push slows 159 -> 183 us, the reduce that follows speeds up 137 -> 122 us because
             //  fewer dirty lines are left behind -- a wash for the step)
-            copy_row<true, false>(s16, d16, n16, lane);
+            if (TAIL) copy_row_wt<true>(s16, d16, n16, lane);
+            else copy_row<true, false>(s16, d16, n16, lane);
+        }
+    }
+    if (TAIL) {
+        __shared__ uint32_t last_s;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave: its write-through stores are performed
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // (the local_row words, plain stores read by the NEXT launch, need nothing: the kernel boundary publishes them)
+            const uint32_t old = __hip_atomic_fetch_add(tail.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_s = old == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (last_s == 0) return;
+        // the last workgroup: everybody's rows are out.  One wave: signal + wait (signal_wait_kernel, sync.hip), then re-arm.
+        if (threadIdx.x < kWave) {
+            const int s = threadIdx.x;
+            const uint64_t epoch = *tail.epoch_bump + 1ull;
+            if (s < W) {
+                sys_store_u64((uint64_t *)tail.flag_peers.p[s] + my_rank, epoch);
+                const uint64_t t0 = ticks_100mhz();
+                while (sys_load_u64(tail.my_flags + s) < epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (ticks_100mhz() - t0 > tail.timeout_ticks) {
+                        report_status(tail.status, 1 + s);
+                        break;
+                    }
+                }
+            }
+            // one wave: every lane has read the counter before lane 0 moves it (wave-level program order)
+            if (s == 0) {
+                *tail.epoch_bump = epoch;
+                __hip_atomic_store(tail.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -241,32 +289,63 @@ extern "C" int mi_ep_combine_pack(const void *x, const int32_t *send_head, int W
 
 extern "C" size_t mi_ep_combine_row_bytes(int hidden) { return ((size_t)hidden * 2 + 15) / 16 * 16; }
 
-extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
-                                  int H, int K, void *const *dst_base_host, int W, size_t slot_region_bytes,
-                                  const uint64_t *epoch_ctr, size_t parity_stride, int my_rank, int32_t *local_row, void *stream)
+static int combine_push_launch(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int H, int K,
+                               void *const *dst_base_host, int W, size_t slot_region_bytes, const uint64_t *epoch_ctr, size_t parity_stride,
+                               int my_rank, int32_t *local_row, const PushTail *tail, void *stream)
 {
     if (H <= 0 || H % 8 || K <= 0 || K > MI_EP_MAX_TOPK || W <= 0 || W > MI_EP_MAX_RANKS || !dst_base_host ||
         (local_row && (my_rank < 0 || my_rank >= W)))
         return MI_EP_EINVAL;
-    if (rows_hint <= 0) return MI_EP_OK;
-    if (!x || !src_idx) return MI_EP_EINVAL;
+    if (rows_hint <= 0 && !tail) return MI_EP_OK;
+    if (rows_hint > 0 && (!x || !src_idx)) return MI_EP_EINVAL;
     PeerPtrs pp;
     for (int i = 0; i < W; ++i) {
         if (!dst_base_host[i]) return MI_EP_EINVAL;
         pp.p[i] = dst_base_host[i];
     }
-    long long blocks = ((long long)rows_hint + kPushWaves - 1) / kPushWaves;        // one row per wave until the chip is full
+    long long blocks = ((long long)std::max(rows_hint, 1) + kPushWaves - 1) / kPushWaves;        // one row per wave until the chip is full
     static const long long cap = getenv("MI_EP_PUSH_BLOCKS") ? atoll(getenv("MI_EP_PUSH_BLOCKS")) : 256 * 8;
     if (blocks > cap) blocks = cap;
     // MI_EP_PUSH_STRIDE: 1 = rows in order (the W = 1 form), odd > 1 = scattered deal (default 257 at W > 1, see the kernel)
     static const long long stride_env = getenv("MI_EP_PUSH_STRIDE") ? atoll(getenv("MI_EP_PUSH_STRIDE")) : 0;
     unsigned deal_stride = stride_env > 0 ? (unsigned)stride_env | 1u : (W > 1 ? 257u : 1u);
-    combine_push_kernel<<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
-        (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp,
-        make_parity(epoch_ctr, 1, parity_stride),
-        slot_region_bytes ? (int)std::min<size_t>(slot_region_bytes / mi_ep_combine_row_bytes(H), 0x7FFFFFFF) : 0x7FFFFFFF, my_rank,
-        local_row, deal_stride);
+    const Parity par = make_parity(epoch_ctr, 1, parity_stride);
+    const int slot_rows = slot_region_bytes ? (int)std::min<size_t>(slot_region_bytes / mi_ep_combine_row_bytes(H), 0x7FFFFFFF) : 0x7FFFFFFF;
+    if (tail)
+        combine_push_kernel<true><<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
+            (const uint8_t *)x, src_idx, total_rows_dev, std::max(rows_hint, 0), H * 2, mi_ep_combine_row_bytes(H), K, W, pp, par, slot_rows, my_rank,
+            local_row, deal_stride, *tail);
+    else
+        combine_push_kernel<false><<<(int)blocks, kWave * kPushWaves, 0, (hipStream_t)stream>>>(
+            (const uint8_t *)x, src_idx, total_rows_dev, rows_hint, H * 2, mi_ep_combine_row_bytes(H), K, W, pp, par, slot_rows, my_rank, local_row,
+            deal_stride, PushTail{});
     return launch_status();
+}
+
+extern "C" int mi_ep_combine_push(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint,
+                                  int H, int K, void *const *dst_base_host, int W, size_t slot_region_bytes,
+                                  const uint64_t *epoch_ctr, size_t parity_stride, int my_rank, int32_t *local_row, void *stream)
+{
+    return combine_push_launch(x, src_idx, total_rows_dev, rows_hint, H, K, dst_base_host, W, slot_region_bytes, epoch_ctr, parity_stride, my_rank,
+                               local_row, nullptr, stream);
+}
+
+extern "C" int mi_ep_combine_push_signal_wait(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int H, int K,
+                                              void *const *dst_base_host, int W, size_t slot_region_bytes, uint64_t *epoch_ctr,
+                                              size_t parity_stride, int my_rank, int32_t *local_row, uint64_t *const *peer_flags_host,
+                                              const uint64_t *my_flags, uint32_t *arrive_word, int32_t *status, int timeout_ms, void *stream)
+{
+    if (!epoch_ctr || !peer_flags_host || !my_flags || !arrive_word || !status || W <= 0 || W > MI_EP_MAX_RANKS || my_rank < 0 || my_rank >= W)
+        return MI_EP_EINVAL;
+    PushTail tail{};
+    tail.arrive = arrive_word, tail.my_flags = my_flags, tail.epoch_bump = epoch_ctr, tail.status = status;
+    tail.timeout_ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_flags_host[i]) return MI_EP_EINVAL;
+        tail.flag_peers.p[i] = peer_flags_host[i];
+    }
+    return combine_push_launch(x, src_idx, total_rows_dev, rows_hint, H, K, dst_base_host, W, slot_region_bytes, epoch_ctr, parity_stride, my_rank,
+                               local_row, &tail, stream);
 }
 
 extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,

@@ -93,6 +93,13 @@ __device__ __forceinline__ void route(const LLGeom &ll, int e, int small, const 
 // send_token_idx_small holds -- from a copy of the batch's routing table in LDS (<= 8192 ids; every workgroup loads it once, one id
 // per thread), 64 pairs per step: compare, ballot, popcount.  No wave waits for the layout workgroup; the row is loaded and quantised
 // first, so the count runs under the row's memory latency.
+// buffer descriptor over one window row (wave-uniform base): the write-through stores of the one-launch low-latency form go through it
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(void *row, int bytes)
+{
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)row >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)row);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)base, 0, bytes, 0x00020000);
+}
 struct LateIdx {
     const int32_t *ids;        // LDS: expert id of pair p = t * K + k, -1 = no selection; NULL: the layout ran in an earlier launch
     int kpart;                 // the selection this wave sends
@@ -246,14 +253,26 @@ __device__ __forceinline__ void stage_int8_body(
         const int slot = __builtin_amdgcn_readlane(slot_l, k);      // k is wave-uniform: v_readlane instead of an LDS round trip
         const int drank = __builtin_amdgcn_readlane(dst_l, k);
         uint8_t *row = (uint8_t *)dsts.p[drank] + poff + (size_t)slot * stride;
+        const u32x4 meta = u32x4{__float_as_uint(scale_out), (uint32_t)t, (uint32_t)k, (uint32_t)my_rank};
+        if (LATE) {
+            // one-launch low-latency form: the rows are announced to their owners from INSIDE this launch (ll_layout_send_kernel's tail), so
+            // they are written through the caches (sc0 sc1) -- the announcing workgroup then needs no release fence, only every wave's drain
+            const __amdgpu_buffer_rsrc_t d = row_rsrc(row, H + MI_EP_ROW_META_BYTES);
+#pragma unroll
+            for (int it = 0; it < kMaxItems; ++it) {
+                const int item = it * kWave + lane;
+                if (item < nitems) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, q[it]), d, item * 16, 0, 17);
+            }
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, meta), d, H, 0, 17);
+            continue;
+        }
         u32x4 *dst = (u32x4 *)row;
 #pragma unroll
         for (int it = 0; it < kMaxItems; ++it) {
             const int item = it * kWave + lane;
             if (item < nitems) dst[item] = q[it];
         }
-        if (lane == 0)
-            *(u32x4 *)(row + H) = u32x4{__float_as_uint(scale_out), (uint32_t)t, (uint32_t)k, (uint32_t)my_rank};
+        if (lane == 0) *(u32x4 *)(row + H) = meta;
     }
 }
 
@@ -317,13 +336,24 @@ __device__ __forceinline__ void stage_bf16_body(
         const int slot = __builtin_amdgcn_readlane(slot_l, k);      // k is wave-uniform: v_readlane instead of an LDS round trip
         const int drank = __builtin_amdgcn_readlane(dst_l, k);
         uint8_t *row = (uint8_t *)dsts.p[drank] + poff + (size_t)slot * stride;
+        const u32x4 meta = u32x4{0u, (uint32_t)t, (uint32_t)k, (uint32_t)my_rank};
+        if (LATE) {                                     // written through the caches: see stage_int8_body
+            const __amdgpu_buffer_rsrc_t d = row_rsrc(row, H * 2 + MI_EP_ROW_META_BYTES);
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                const int item = it * kWave + lane;
+                if (item < nitems) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, raw[it]), d, item * 16, 0, 17);
+            }
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, meta), d, H * 2, 0, 17);
+            continue;
+        }
         u32x4 *dst = (u32x4 *)row;
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int item = it * kWave + lane;
             if (item < nitems) dst[item] = raw[it];
         }
-        if (lane == 0) *(u32x4 *)(row + (size_t)H * 2) = u32x4{0u, (uint32_t)t, (uint32_t)k, (uint32_t)my_rank};
+        if (lane == 0) *(u32x4 *)(row + (size_t)H * 2) = meta;
     }
 }
 template <bool I32>
@@ -336,6 +366,83 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
                                 (int)(blockIdx.x * kStageWaves + threadIdx.x / kWave), LateIdx{nullptr, 0});
 }
 
+// The count exchange of a low-latency dispatch, run by ONE workgroup (of any size up to 1024 threads): post this rank's per-expert counts
+// to every peer (optional), wait (bounded) for the L*W count granules of this call's epoch, inclusive cumsum in idx-i order, per-expert
+// counts, and complete the family's call counter.  c = LDS, L*W + 16 words.
+__device__ __forceinline__ void ll_counts_body(int32_t *c, const PeerPtrs &count_peers, const int32_t *__restrict__ my_counts_out /*[E] or null*/,
+                                               int my_rank, const uint64_t *__restrict__ granules_base, uint64_t ep64,
+                                               size_t counts_parity_stride, uint64_t *epoch_bump, int L, int W, int count_type,
+                                               int32_t *__restrict__ layout_range, int64_t *__restrict__ packed_recv_count, int32_t *status,
+                                               uint64_t timeout_ticks)
+{
+    const int LW = L * W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t *wave_tot = c + LW;
+    // this call's epoch (device-resident counter + 1, or the explicit value) and the ping-pong half of the count granules
+    const uint32_t epoch = (uint32_t)ep64;
+    const size_t cpoff = (size_t)(ep64 & 1ull) * counts_parity_stride;
+    const uint64_t *granules = (const uint64_t *)((const uint8_t *)granules_base + cpoff);
+    // optional fused post (one rank per process): this rank's per-expert counts to every peer, then collect everybody's
+    if (my_counts_out) {
+        for (int i = tid; i < LW; i += blockDim.x) {
+            const int d = i / L, le = i % L;
+            sys_store_u64_relaxed((uint64_t *)((uint8_t *)count_peers.p[d] + cpoff) + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)my_counts_out[d * L + le]);
+        }
+    }
+    const uint64_t t0 = ticks_100mhz();
+    for (int i = tid; i < LW; i += blockDim.x) {
+        uint64_t g;
+        while (((g = sys_load_u64(granules + i)) >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                report_status(status, 2000 + i);
+                g = 0;
+                break;
+            }
+        }
+        c[i] = (int32_t)(uint32_t)g;
+    }
+    __syncthreads();
+    // inclusive scan of c[0..LW): each thread owns a contiguous chunk, wave scan of the chunk sums, then wave offsets
+    const int per = (LW + blockDim.x - 1) / blockDim.x;
+    const int b0 = min(LW, tid * per), b1 = min(LW, b0 + per);
+    int32_t sum = 0;
+    for (int i = b0; i < b1; ++i) sum += c[i];
+    const int32_t inc = wave_incl_scan_i32(sum);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int32_t run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    for (int i = b0; i < b1; ++i) {
+        run += c[i];
+        c[i] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < LW; i += blockDim.x) layout_range[i] = c[i];
+    for (int le = tid; le < L; le += blockDim.x) {
+        const int32_t end = c[(le + 1) * W - 1], beg = le ? c[le * W - 1] : 0;
+        packed_recv_count[le] = (count_type == 0) ? (int64_t)end : (int64_t)(end - beg);
+    }
+    // the call is now "complete" as far as later kernels of the family are concerned: they read the counter with add = 0
+    if (epoch_bump && tid == 0) *epoch_bump = ep64;
+}
+
+// The count exchange raised from INSIDE the layout + send launch (ll_layout_send_kernel with a tail): every workgroup -- the send
+// workgroups after their write-through rows have drained, the layout workgroup after an agent-scope release of its tables -- counts
+// itself in at a device word of the rank's control area; the last one to arrive runs ll_counts_body and re-arms the word.  One launch
+// and one kernel boundary less per low-latency dispatch (three launches -> two).
+struct LLTail {
+    uint32_t *arrive;             // NULL: no tail (the count exchange is a launch of its own)
+    PeerPtrs count_peers;
+    const uint64_t *granules_base;
+    size_t counts_parity_stride;
+    uint64_t *epoch_bump;         // the family's completed-call counter (this call's epoch = counter + 1)
+    int L, count_type;
+    int32_t *layout_range;
+    int64_t *packed_recv_count;
+    int32_t *status;
+    uint64_t timeout_ticks;
+};
+
 // Low-latency dispatch, layout + send in ONE launch of 1024-thread workgroups: workgroup 0 computes the layout tables of the batch
 // (<= 1024 tokens: one workgroup of layout_small_body; the count exchange that follows needs num_tokens_per_expert, the handle the rest);
 // workgroups 1.. are the send waves, one per (token, selection), which route themselves from an LDS copy of the routing table (above).
@@ -345,32 +452,58 @@ template <bool I32, int QM, int UT>
 __global__ __launch_bounds__(1024) void ll_layout_send_kernel(
     const uint16_t *__restrict__ x, const void *__restrict__ topk_idx, int T, int K, int H, int E, int W, int nbits, int my_rank, PeerPtrs dsts,
     LLGeom ll, Parity par, int32_t *__restrict__ num_tokens_per_rank, int32_t *__restrict__ num_tokens_per_expert,
-    int32_t *__restrict__ is_token_in_rank, int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset, int send_waves)
+    int32_t *__restrict__ is_token_in_rank, int32_t *__restrict__ send_token_idx_small, int32_t *__restrict__ send_data_offset, int send_waves,
+    LLTail tail)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     if (blockIdx.x == 0) {
         layout_small_body<I32, UT>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank,
                                    send_token_idx_small, send_data_offset, nullptr, nullptr, smem, 1, 0);
-        return;
+        if (!tail.arrive) return;
+    } else {
+        const int npairs = T * K;
+        for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+            const long long e = ld_idx<I32>(topk_idx, i);
+            smem[i] = (e >= 0 && e < E) ? (int32_t)e : -1;
+        }
+        __syncthreads();
+        // kLLSendWaves send waves per workgroup (the rest only helped to load the table): 1024 pairs on 64 workgroups of 16 sending waves left three
+        // quarters of the CUs idle and ran 12.4 us; spread over 256 workgroups the rows stream from all of them
+        const int wave = (int)(threadIdx.x / kWave);
+        const int wid = (int)(blockIdx.x - 1) * send_waves + wave;
+        if (wave < send_waves && wid < npairs) {
+            const LateIdx late{smem, wid % K};
+            if (QM == MI_EP_QUANT_NONE)
+                stage_bf16_body<I32, true>(x, topk_idx, nullptr, nullptr, T, K, H, E, my_rank, dsts, ll, K, (size_t)0, PushGeom{0, 0}, par, wid, late);
+            else
+                stage_int8_body<I32, QM == MI_EP_QUANT_NONE ? MI_EP_QUANT_INT8 : QM, true>(x, topk_idx, nullptr, nullptr, T, K, H, E, my_rank, dsts, ll, K,
+                                                                                            (size_t)0, PushGeom{0, 0}, par, wid, late);
+        }
+        if (!tail.arrive) return;
     }
-    const int npairs = T * K;
-    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
-        const long long e = ld_idx<I32>(topk_idx, i);
-        smem[i] = (e >= 0 && e < E) ? (int32_t)e : -1;
+    // ---- tail: count this workgroup in; the last one runs the count exchange
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every wave: its (write-through) stores are performed
+    __syncthreads();
+    uint32_t *const last_s = (uint32_t *)smem;                  // (the routing table / layout tables are done with)
+    if (threadIdx.x == 0) {
+        // the layout workgroup's tables were plain stores: release them to the device (num_tokens_per_expert is read by the tail, possibly
+        // on another XCD; the other tables by later launches)
+        if (blockIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const uint32_t old = __hip_atomic_fetch_add(tail.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *last_s = old == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
-    // kLLSendWaves send waves per workgroup (the rest only helped to load the table): 1024 pairs on 64 workgroups of 16 sending waves left three
-    // quarters of the CUs idle and ran 12.4 us; spread over 256 workgroups the rows stream from all of them
-    const int wave = (int)(threadIdx.x / kWave);
-    if (wave >= send_waves) return;
-    const int wid = (int)(blockIdx.x - 1) * send_waves + wave;
-    if (wid >= npairs) return;
-    const LateIdx late{smem, wid % K};
-    if (QM == MI_EP_QUANT_NONE)
-        stage_bf16_body<I32, true>(x, topk_idx, nullptr, nullptr, T, K, H, E, my_rank, dsts, ll, K, (size_t)0, PushGeom{0, 0}, par, wid, late);
-    else
-        stage_int8_body<I32, QM == MI_EP_QUANT_NONE ? MI_EP_QUANT_INT8 : QM, true>(x, topk_idx, nullptr, nullptr, T, K, H, E, my_rank, dsts, ll, K,
-                                                                                    (size_t)0, PushGeom{0, 0}, par, wid, late);
+    if (*(volatile uint32_t *)last_s == 0) return;
+    __syncthreads();                                            // (everybody has read the word before the body reuses the LDS)
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // num_tokens_per_expert as the layout workgroup wrote it
+    __syncthreads();
+    const uint64_t ep64 = *tail.epoch_bump + 1ull;
+    ll_counts_body(smem, tail.count_peers, num_tokens_per_expert, my_rank, tail.granules_base, ep64, tail.counts_parity_stride, tail.epoch_bump,
+                   tail.L, W, tail.count_type, tail.layout_range, tail.packed_recv_count, tail.status, tail.timeout_ticks);
+    if (threadIdx.x == 0) __hip_atomic_store(tail.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -807,7 +940,7 @@ __global__ void ll_post_counts_kernel(PeerPtrs peers, const int32_t *__restrict_
         sys_store_u64_relaxed(g + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)cnt[d * L + le]);
 }
 
-// one workgroup: wait for the L*W count granules, inclusive cumsum in idx-i order, per-expert counts
+// one workgroup: wait for the L*W count granules, inclusive cumsum in idx-i order, per-expert counts (ll_counts_body, above)
 __global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, const int32_t *__restrict__ my_counts_out /*[E] or null*/,
                                                         int my_rank, const uint64_t *__restrict__ granules_base, EpochRef er,
                                                         size_t counts_parity_stride, uint64_t *epoch_bump, int L, int W,
@@ -815,57 +948,9 @@ __global__ __launch_bounds__(256) void ll_counts_kernel(PeerPtrs count_peers, co
                                                         int64_t *__restrict__ packed_recv_count, int32_t *status,
                                                         uint64_t timeout_ticks)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t c[];   // [L*W] counts -> inclusive cumsum, then [4] wave totals
-    const int LW = L * W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int32_t *wave_tot = c + LW;
-    // this call's epoch (device-resident counter + 1, or the explicit value) and the ping-pong half of the count granules
-    const uint64_t ep64 = epoch_of(er);
-    const uint32_t epoch = (uint32_t)ep64;
-    const size_t cpoff = (size_t)(ep64 & 1ull) * counts_parity_stride;
-    const uint64_t *granules = (const uint64_t *)((const uint8_t *)granules_base + cpoff);
-    // optional fused post (one rank per process): this rank's per-expert counts to every peer, then collect everybody's
-    if (my_counts_out) {
-        for (int i = tid; i < LW; i += blockDim.x) {
-            const int d = i / L, le = i % L;
-            sys_store_u64_relaxed((uint64_t *)((uint8_t *)count_peers.p[d] + cpoff) + (size_t)le * W + my_rank, ((uint64_t)epoch << 32) | (uint32_t)my_counts_out[d * L + le]);
-        }
-    }
-    const uint64_t t0 = ticks_100mhz();
-    for (int i = tid; i < LW; i += blockDim.x) {
-        uint64_t g;
-        while (((g = sys_load_u64(granules + i)) >> 32) != epoch) {
-            __builtin_amdgcn_s_sleep(4);
-            if (ticks_100mhz() - t0 > timeout_ticks) {
-                report_status(status, 2000 + i);
-                g = 0;
-                break;
-            }
-        }
-        c[i] = (int32_t)(uint32_t)g;
-    }
-    __syncthreads();
-    // inclusive scan of c[0..LW): each thread owns a contiguous chunk, wave scan of the chunk sums, then wave offsets
-    const int per = (LW + blockDim.x - 1) / blockDim.x;
-    const int b0 = tid * per, b1 = min(LW, b0 + per);
-    int32_t sum = 0;
-    for (int i = b0; i < b1; ++i) sum += c[i];
-    const int32_t inc = wave_incl_scan_i32(sum);
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    int32_t run = inc - sum;
-    for (int w = 0; w < wave; ++w) run += wave_tot[w];
-    for (int i = b0; i < b1; ++i) {
-        run += c[i];
-        c[i] = run;
-    }
-    __syncthreads();
-    for (int i = tid; i < LW; i += blockDim.x) layout_range[i] = c[i];
-    for (int le = tid; le < L; le += blockDim.x) {
-        const int32_t end = c[(le + 1) * W - 1], beg = le ? c[le * W - 1] : 0;
-        packed_recv_count[le] = (count_type == 0) ? (int64_t)end : (int64_t)(end - beg);
-    }
-    // the call is now "complete" as far as later kernels of the family are concerned: they read the counter with add = 0
-    if (epoch_bump && tid == 0) *epoch_bump = ep64;
+    extern __shared__ __attribute__((aligned(16))) int32_t c[];   // [L*W] counts -> inclusive cumsum, then [16] wave totals
+    ll_counts_body(c, count_peers, my_counts_out, my_rank, granules_base, epoch_of(er), counts_parity_stride, epoch_bump, L, W, count_type,
+                   layout_range, packed_recv_count, status, timeout_ticks);
 }
 
 }  // namespace mi_ep
@@ -914,11 +999,11 @@ extern "C" int mi_ep_ll_dispatch_send(const void *x, const void *topk_idx, int i
     return launch_status();
 }
 
-extern "C" int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx, int idx_is_i32, int T, int K, int H, int E, int W, int my_rank,
-                                            int max_tokens, int quant_mode, void *const *peer_rows_host, const uint64_t *epoch_ctr,
-                                            size_t parity_stride, int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
-                                            int32_t *is_token_in_rank, int32_t *send_token_idx_small, int32_t *send_data_offset,
-                                            void *stream)
+static int ll_layout_send_launch(const void *x, const void *topk_idx, int idx_is_i32, int T, int K, int H, int E, int W, int my_rank,
+                                 int max_tokens, int quant_mode, void *const *peer_rows_host, const uint64_t *epoch_ctr,
+                                 size_t parity_stride, int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
+                                 int32_t *is_token_in_rank, int32_t *send_token_idx_small, int32_t *send_data_offset, const LLTail *tail_in,
+                                 void *stream)
 {
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 16 || H > MI_EP_MAX_HIDDEN || E <= 0 || W <= 0 ||
         W > MI_EP_MAX_RANKS || E % W || T > max_tokens || !peer_rows_host || !num_tokens_per_rank || !num_tokens_per_expert ||
@@ -942,7 +1027,9 @@ extern "C" int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx
     const int send_waves = send_waves_env >= 1 && send_waves_env <= 16 ? send_waves_env : kLLSendWaves;
     const int blocks = 1 + (int)(((long long)T * K + send_waves - 1) / send_waves);       // the layout workgroup + the send workgroups
     // dynamic LDS: the layout workgroup's tables, or the send workgroups' copy of the routing table (int32 per pair)
-    const size_t lds = std::max(layout_small_lds_bytes(E, W, ut), (size_t)T * K * sizeof(int32_t));
+    const LLTail tail = tail_in ? *tail_in : LLTail{};
+    // dynamic LDS: the layout workgroup's tables, the send workgroups' copy of the routing table (int32 per pair), the tail's counts
+    const size_t lds = std::max(std::max(layout_small_lds_bytes(E, W, ut), (size_t)T * K * sizeof(int32_t)), tail_in ? (size_t)(E + 16) * 4 : (size_t)0);
     const uint16_t *xp = (const uint16_t *)x;
     static PerDeviceOnce attr_once;
 #define MI_EP_LLS_ATTR(I32, QM, UT) (void)hipFuncSetAttribute((const void *)ll_layout_send_kernel<I32, QM, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
@@ -956,7 +1043,7 @@ extern "C" int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx
 #define MI_EP_LLS(I32, QM, UT)                                                                                                         \
     ll_layout_send_kernel<I32, QM, UT><<<blocks, 1024, lds, s>>>(xp, topk_idx, T, K, H, E, W, nbits, my_rank, pp, ll, par,              \
                                                                   num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank,         \
-                                                                  send_token_idx_small, send_data_offset, send_waves)
+                                                                  send_token_idx_small, send_data_offset, send_waves, tail)
 #define MI_EP_LLS_Q(QM)                                                                                       \
     do {                                                                                                      \
         if (ut == 16) { if (idx_is_i32) MI_EP_LLS(true, QM, 16); else MI_EP_LLS(false, QM, 16); }             \
@@ -971,6 +1058,65 @@ extern "C" int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx
     }
 #undef MI_EP_LLS_Q
 #undef MI_EP_LLS
+    return launch_status();
+}
+
+extern "C" int mi_ep_ll_dispatch_layout_send(const void *x, const void *topk_idx, int idx_is_i32, int T, int K, int H, int E, int W, int my_rank,
+                                            int max_tokens, int quant_mode, void *const *peer_rows_host, const uint64_t *epoch_ctr,
+                                            size_t parity_stride, int32_t *num_tokens_per_rank, int32_t *num_tokens_per_expert,
+                                            int32_t *is_token_in_rank, int32_t *send_token_idx_small, int32_t *send_data_offset,
+                                            void *stream)
+{
+    return ll_layout_send_launch(x, topk_idx, idx_is_i32, T, K, H, E, W, my_rank, max_tokens, quant_mode, peer_rows_host, epoch_ctr, parity_stride,
+                                 num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank, send_token_idx_small, send_data_offset, nullptr,
+                                 stream);
+}
+
+// layout + send + the count exchange in ONE launch (the tail of ll_layout_send_kernel); mi_ep_ll_pack then fills the outputs
+extern "C" int mi_ep_ll_dispatch_layout_send_counts(const void *x, const void *topk_idx, int idx_is_i32, int T, int K, int H, int E, int W,
+                                                   int my_rank, int max_tokens, int quant_mode, void *const *peer_rows_host,
+                                                   uint64_t *epoch_ctr, size_t parity_stride, int32_t *num_tokens_per_rank,
+                                                   int32_t *num_tokens_per_expert, int32_t *is_token_in_rank, int32_t *send_token_idx_small,
+                                                   int32_t *send_data_offset, uint64_t *const *peer_counts_host, const uint64_t *my_counts,
+                                                   size_t counts_parity_stride, int count_type, int32_t *layout_range,
+                                                   int64_t *packed_recv_count, uint32_t *arrive_word, int32_t *status, int timeout_ms,
+                                                   void *stream)
+{
+    if (!epoch_ctr || !peer_counts_host || !my_counts || !layout_range || !packed_recv_count || !arrive_word || !status || W <= 0 ||
+        W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048)
+        return MI_EP_EINVAL;
+    LLTail tail{};
+    tail.arrive = arrive_word, tail.granules_base = my_counts, tail.counts_parity_stride = counts_parity_stride, tail.epoch_bump = epoch_ctr;
+    tail.L = E / W, tail.count_type = count_type, tail.layout_range = layout_range, tail.packed_recv_count = packed_recv_count;
+    tail.status = status, tail.timeout_ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_counts_host[i]) return MI_EP_EINVAL;
+        tail.count_peers.p[i] = peer_counts_host[i];
+    }
+    return ll_layout_send_launch(x, topk_idx, idx_is_i32, T, K, H, E, W, my_rank, max_tokens, quant_mode, peer_rows_host, epoch_ctr, parity_stride,
+                                 num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank, send_token_idx_small, send_data_offset, &tail,
+                                 stream);
+}
+
+// the packing half of mi_ep_ll_post_recv on its own: rows from this rank's slabs into the packed outputs, by the cumulative counts the
+// count exchange left in layout_range (device); epoch_ctr = the family's call counter, already completed for this call (add = 0)
+extern "C" int mi_ep_ll_pack(const void *my_rows, const int32_t *layout_range, int W, int L, int max_tokens, int H, int quant_mode,
+                             void *packed_recv_x, float *packed_recv_x_scales, int32_t *src_info, int rows_capacity, const uint64_t *epoch_ctr,
+                             size_t rows_parity_stride, void *stream)
+{
+    if (!my_rows || !layout_range || !packed_recv_x || !src_info || W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || L * W > 2048 || H <= 0 || H % 16 ||
+        max_tokens <= 0)
+        return MI_EP_EINVAL;
+    PeerPtrs pp;
+    for (int i = 0; i < W; ++i) pp.p[i] = const_cast<void *>(my_rows);
+    const int cap = rows_capacity > 0 ? rows_capacity : L * W * max_tokens;      // rows the caller's output buffers hold
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    long long blocks = ((long long)L * W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    pull_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)L * W * 4, (hipStream_t)stream>>>(pp, layout_range, nullptr, max_tokens, W, L * W, payload,
+                                                                                         (uint8_t *)packed_recv_x, packed_recv_x_scales, src_info,
+                                                                                         cap, make_parity(epoch_ctr, 0, rows_parity_stride));
     return launch_status();
 }
 
@@ -999,7 +1145,7 @@ extern "C" int mi_ep_ll_dispatch_recv(const void *my_rows, const uint64_t *my_co
     hipStream_t s = (hipStream_t)stream;
     const uint64_t ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
     PeerPtrs none{};
-    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(none, nullptr, 0, my_counts, EpochRef{nullptr, epoch}, 0, nullptr, L, W,
+    ll_counts_kernel<<<1, 256, (size_t)(L * W + 16) * 4, s>>>(none, nullptr, 0, my_counts, EpochRef{nullptr, epoch}, 0, nullptr, L, W,
                                                             count_type, layout_range, packed_recv_count, status, ticks);
     const int cap = rows_capacity > 0 ? rows_capacity : L * W * max_tokens;      // rows the caller's output buffers hold
     PeerPtrs pp;
@@ -1041,7 +1187,7 @@ extern "C" int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32
     // only ONE workgroup ever spins on the peers (a chip full of spinning workgroups would starve whatever else has to run
     // for the posts to happen when several processes share the GPU); the packing kernel follows on the stream
     const EpochRef er = epoch_ctr ? EpochRef{epoch_ctr, 1} : EpochRef{nullptr, epoch};
-    ll_counts_kernel<<<1, 256, (size_t)(L * W + 4) * 4, s>>>(cp, num_tokens_per_expert, my_rank, my_counts, er,
+    ll_counts_kernel<<<1, 256, (size_t)(L * W + 16) * 4, s>>>(cp, num_tokens_per_expert, my_rank, my_counts, er,
                                                             epoch_ctr ? counts_parity_stride : 0, epoch_ctr, L, W, count_type,
                                                             layout_range, packed_recv_count, status, ticks);
     const int cap = rows_capacity > 0 ? rows_capacity : L * W * max_tokens;      // rows the caller's output buffers hold

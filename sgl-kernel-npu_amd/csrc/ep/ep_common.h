@@ -110,6 +110,49 @@ __device__ __forceinline__ void copy_row(const u32x4 *s16, u32x4 *d16, int n16, 
     }
 }
 
+// The same copy with WRITE-THROUGH stores (sc0 sc1: the bytes leave every cache level on their way to the destination, local or remote):
+// for rows that another workgroup of the SAME launch announces to a peer -- the announcing lane then needs no release fence, only this
+// wave's vmcnt drain before the workgroup counts itself in (combine_push_kernel's tail).  Stores through a buffer descriptor on the
+// wave-uniform row base: the compiler counts them (raw_buffer_store aux: sc0 = 1, sc1 = 16).
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int wt_u32x4;
+template <int N, bool NTL>
+__device__ __forceinline__ void copy_pieces_wt(const u32x4 *s, __amdgpu_buffer_rsrc_t d, uint32_t off)
+{
+    u32x4 v[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = NTL ? __builtin_nontemporal_load(s + u * kWave) : s[u * kWave];
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, v[u]), d, (int)(off + (uint32_t)u * (kWave * 16u)), 0, 17);
+}
+template <bool NTL>
+__device__ __forceinline__ void copy_row_wt(const u32x4 *s16, void *d_row /* wave-uniform */, int n16, int lane)
+{
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)d_row >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)d_row);
+    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)base, 0, n16 * 16, 0x00020000);
+    const int nfull = n16 / kWave;
+    const u32x4 *s = s16 + lane;
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    int c = 0;
+    for (; c + 8 <= nfull; c += 8) copy_pieces_wt<8, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u));
+    switch (nfull - c) {
+        case 7: copy_pieces_wt<7, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u)); break;
+        case 6: copy_pieces_wt<6, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u)); break;
+        case 5: copy_pieces_wt<5, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u)); break;
+        case 4: copy_pieces_wt<4, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u)); break;
+        case 3: copy_pieces_wt<3, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u)); break;
+        case 2: copy_pieces_wt<2, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u)); break;
+        case 1: copy_pieces_wt<1, NTL>(s + c * kWave, d, l16 + (uint32_t)c * (kWave * 16u)); break;
+        default: break;
+    }
+    const int tail = nfull * kWave + lane;
+    if (tail < n16) {
+        const u32x4 v = NTL ? __builtin_nontemporal_load(s16 + tail) : s16[tail];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, v), d, tail * 16, 0, 17);
+    }
+}
+
 // 8-byte words other GPUs write/poll: always system-scope atomics, never plain accesses.
 __device__ __forceinline__ void sys_store_u64(uint64_t *p, uint64_t v)
 {

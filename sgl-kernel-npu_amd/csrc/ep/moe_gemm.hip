@@ -68,6 +68,7 @@ struct GemmArgs {
     Parity par;               // ping-pong half of the combine window (device-resident epoch, see ep_common.h)
     int slot_rows;            // rows one combine region holds: (t, k) outside it are dropped
     int cols_padded;          // 0, or the column-tile count rounded up to a multiple of 8 (XCD-consistent column tiles, see the kernel)
+    int small_last;           // an expert's last row block of <= 64 / <= 128 rows runs as a 64- / 128-row tile (MI_GEMM_SMALL_LAST=0: as a 256-row tile)
 };
 
 // position (16-B units) of k-chunk `chunk` inside row `row` of a [rows][BKT B] tile.  A ds_read_b128 of 16 consecutive rows at one chunk
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
         // tile pays for it in full -- its weight tile streams all the same and the MFMAs multiply padding.  Blocks of <= 64 / <= 128 rows
         // run as the 64- / 128-row tile (a fifth / three eighths less operand stream per k-tile, a quarter / half of the MFMAs).  Same
         // products, same epilogue: bit-identical.
-        if (MT == 4 && BKT == 128 && rows <= 64) gemm_tile<MODE, 1, BKT>(p, e, row0, rows, col_tile, lds);
-        else if (MT == 4 && BKT == 128 && rows <= 128) gemm_tile<MODE, 2, BKT>(p, e, row0, rows, col_tile, lds);
+        if (MT == 4 && BKT == 128 && p.small_last && rows <= 64) gemm_tile<MODE, 1, BKT>(p, e, row0, rows, col_tile, lds);
+        else if (MT == 4 && BKT == 128 && p.small_last && rows <= 128) gemm_tile<MODE, 2, BKT>(p, e, row0, rows, col_tile, lds);
         else gemm_tile<MODE, MT, BKT>(p, e, row0, rows, col_tile, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
         __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
@@ -568,6 +569,8 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
     // (A balanced variant -- the surplus column slots 28 .. 31, on XCDs 4 .. 7, taking every second (expert, row block) of columns 24 .. 27,
     //  3.5 columns per XCD -- was measured too: GEMM2 522 us uniform / 569 us with multinomial row counts against 482-490 / 537 for the plain
     //  order, fabric traffic 2.25 GB against 2.61 GB.  Consistency costs time even when the deal is even.)
+    static const bool small_last = !(getenv("MI_GEMM_SMALL_LAST") && atoi(getenv("MI_GEMM_SMALL_LAST")) == 0);
+    q.small_last = small_last;
     static const bool xcd_cols = getenv("MI_GEMM_XCD_COLS") && atoi(getenv("MI_GEMM_XCD_COLS")) != 0;
     q.cols_padded = (xcd_cols && gx % 8 != 0 && gx > 8) ? (gx + 7) / 8 * 8 : 0;
     // (padded form: the same number of workers, gx' x pool flat ids cut into rows of gx')

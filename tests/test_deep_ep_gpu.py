@@ -69,6 +69,26 @@ def test_low_latency_calls_replay_in_a_captured_graph(cfg):
     _spawn(mp_workers.gpu_graph_worker, cfg[0], cfg)
 
 
+@pytest.mark.parametrize("forms", [("1", "1"), ("0", "0"), ("1", "0")], ids=["tails", "launches", "dispatch_tail_only"])
+@pytest.mark.parametrize("cfg", [(2, 24, 512, 128, 4, 8, 2), (4, 17, 1024, 128, 8, 32, 2)])
+def test_low_latency_launch_forms(cfg, forms):
+    """The count exchange of a low-latency dispatch and the "rows pushed" signal + wait of a combine, each either as the TAIL of the
+    launch in front of it (the last workgroup to arrive does it: MI_EP_LL_FUSED_COUNTS / MI_EP_COMBINE_FUSED = 1) or as a launch of its
+    own (= 0): same rows, tables and sums, bit-exact against the oracle, eagerly and replayed from a captured graph."""
+    import os
+    keep = {k: os.environ.get(k) for k in ("MI_EP_LL_FUSED_COUNTS", "MI_EP_COMBINE_FUSED")}
+    os.environ["MI_EP_LL_FUSED_COUNTS"], os.environ["MI_EP_COMBINE_FUSED"] = forms
+    try:
+        _spawn(mp_workers.gpu_graph_worker, cfg[0], cfg)
+        _spawn(mp_workers.gpu_buffer_worker, cfg[0], (cfg[0], 40, 1024, 8, 64, 0.3, True, "default", 2))
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("cfg", [(1, 40, 512, 128, 4, 8), (2, 33, 512, 128, 4, 8)])      # W, T, H, I, K, E
 def test_every_call_works_under_inference_mode(cfg):
     _spawn(mp_workers.gpu_inference_mode_worker, cfg[0], cfg)
