@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint8_t *const tile = lds + wave * (32 * kEpiRow);
     const int dcol0 = (wave >> 1) * 128 + (wave & 1) * 32;      // global dim of tile column 0; columns 32.. are 64 dims further
     // o8[it] = four consecutive dims (tile chunk lane & 15) of head 4 it + (lane >> 4) of head block hb
-    auto transpose_block = [&](auto hb_tag, f32x4 (&o8)[8]) {
+    auto tile_write = [&](auto hb_tag) {
         constexpr int hb = decltype(hb_tag)::value;            // static accumulator indices
 #pragma unroll
         for (int dl = 0; dl < 2; ++dl)
@@ -559,6 +559,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const f32x16 &a = acc[dl * 4 + hb];
                 *(f32x4 *)(tile + c32 * kEpiRow + col * 4) = f32x4{a[4 * rg + 0], a[4 * rg + 1], a[4 * rg + 2], a[4 * rg + 3]};
             }
+    };
+    auto transpose_block = [&](auto hb_tag, f32x4 (&o8)[8]) {
+        tile_write(hb_tag);
         // wave-private tile: LDS operations of one wave complete in order, no barrier
 #pragma unroll
         for (int it = 0; it < 8; ++it) o8[it] = *(const f32x4 *)(tile + (it * 4 + (lane >> 4)) * kEpiRow + (lane & 15) * 16);
@@ -653,63 +656,72 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int hgx = piece * 64 + lane;
         if (hgx < p.group) st_agent_f32(p.ws_ml + pslot(kvh * p.group + hgx) * 2 + 1, -lmb[hgx]);
     }
-    // the partner's rows of this workgroup's heads: 16 write-through-coherent loads per lane, all in flight before the first use
+    // The partner's rows of this workgroup's heads: 16 write-through-coherent loads per lane, all in flight before the first use.  Lane
+    // mapping of the finish: head 8 it + (lane >> 3) of a head block, EIGHT consecutive dims (lane & 7) of the wave's 64 -- one 16-byte
+    // output store per lane and head (the four-dim mapping of the export needs twice as many, and the store tail is issue-bound).
+    const int ch8 = lane & 7;
+    const int dlane8 = dcol0 + (ch8 >> 2) * 64 + (ch8 & 3) * 8;
     const float *const prow = p.ws_o + pbase_partner * kDN;    // + head * pmul * kDN + dim
-    f32x4 pr[2][8];
+    f32x4 pr[2][8];                                            // [head block of the pair][2 it + half]
     auto partner_rows = [&](int hb, f32x4 (&r)[8]) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int hgx = min(hb * 32 + it * 4 + (lane >> 4), p.group - 1);
-            r[it] = ld_sc1_x4(prow + (int64_t)(kvh * p.group + hgx) * pmul * kDN + dlane);
+        for (int it = 0; it < 4; ++it) {
+            const int hgx = min(hb * 32 + it * 8 + (lane >> 3), p.group - 1);
+            const float *src = prow + (int64_t)(kvh * p.group + hgx) * pmul * kDN + dlane8;
+            r[2 * it] = ld_sc1_x4(src);
+            r[2 * it + 1] = ld_sc1_x4(src + 4);
         }
     };
     partner_rows(piece * 2, pr[0]);
     partner_rows(piece * 2 + 1, pr[1]);
-    // the partner's statistics of those heads (64 heads, lane = head) -> wave-private LDS
-    float *const pml = lmb + 512 + wave * 128;
+    // the weights of the workgroup's 64 heads, once per head (lane = head) instead of once per (head, dims) item: both pieces' statistics ->
+    // [w0, w1, 1 / L] in piece order, exactly the merge kernel's arithmetic, through a wave-private LDS table
+    float *const wts = (float *)(lds + 8 * (32 * kEpiRow)) + wave * 256;
     {
         const int hgx = min(piece * 64 + lane, p.group - 1);
         const int64_t idx = pbase_partner + (int64_t)(kvh * p.group + hgx) * pmul;
-        pml[lane * 2 + 0] = __hip_atomic_load(p.ws_ml + idx * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pml[lane * 2 + 1] = __hip_atomic_load(p.ws_ml + idx * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float m_par = __hip_atomic_load(p.ws_ml + idx * 2 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float l_par = __hip_atomic_load(p.ws_ml + idx * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float m_own = lmb[128 + hgx], l_own = lmb[hgx];
+        const float m0 = piece == 0 ? m_own : m_par, m1 = piece == 0 ? m_par : m_own;
+        const float l0 = piece == 0 ? l_own : l_par, l1 = piece == 0 ? l_par : l_own;
+        const float M = fmaxf(m0, m1);
+        const float w0 = m0 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m0 - M);
+        const float w1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - M);
+        float L = 0.f;
+        if (w0 != 0.f) L += w0 * l0;
+        if (w1 != 0.f) L += w1 * l1;
+        *(f32x4 *)(wts + lane * 4) = f32x4{w0, w1, L > 0.f ? 1.f / L : 0.f, 0.f};
     }
     ld_sc1_wait(pr[0]);
     ld_sc1_wait(pr[1]);
     auto finish = [&](auto hb_tag, const f32x4 (&r)[8]) {
         constexpr int hb = decltype(hb_tag)::value;
         if (hb * 32 >= p.group) return;
-        f32x4 o8[8];
-        transpose_block(hb_tag, o8);
+        tile_write(hb_tag);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int hl = it * 4 + (lane >> 4);
+        for (int it = 0; it < 4; ++it) {
+            const int hl = it * 8 + (lane >> 3);
             const int hgx = hb * 32 + hl;
+            const f32x4 own_lo = *(const f32x4 *)(tile + hl * kEpiRow + ch8 * 32), own_hi = *(const f32x4 *)(tile + hl * kEpiRow + ch8 * 32 + 16);
+            const f32x4 wt = *(const f32x4 *)(wts + (min(hgx, p.group - 1) - piece * 64) * 4);
             if (hgx >= p.group) continue;
             const int headx = kvh * p.group + hgx;
-            const int hp = hgx - piece * 64;                   // index into the partner's statistics
-            const float m_own = lmb[128 + hgx], l_own = lmb[hgx], m_par = pml[hp * 2], l_par = pml[hp * 2 + 1];
-            const float m0 = piece == 0 ? m_own : m_par, m1 = piece == 0 ? m_par : m_own;
-            const float l0 = piece == 0 ? l_own : l_par, l1 = piece == 0 ? l_par : l_own;
-            const f32x4 a0 = piece == 0 ? o8[it] : r[it], a1 = piece == 0 ? r[it] : o8[it];
-            const float M = fmaxf(m0, m1);
-            const float w0 = m0 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m0 - M);
-            const float w1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - M);
-            float L = 0.f;
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (w0 != 0.f) {
-                L += w0 * l0;
+            const float w0 = wt[0], w1 = wt[1], inv = wt[2];
+            float o[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] += w0 * a0[j];
-            }
-            if (w1 != 0.f) {
-                L += w1 * l1;
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] += w1 * a1[j];
+            for (int j = 0; j < 4; ++j) {                      // w0 a0 + w1 a1 in piece order, a term of weight 0 skipped (the merge kernel's sums)
+                const float a0l = piece == 0 ? own_lo[j] : r[2 * it][j], a0h = piece == 0 ? own_hi[j] : r[2 * it + 1][j];
+                const float a1l = piece == 0 ? r[2 * it][j] : own_lo[j], a1h = piece == 0 ? r[2 * it + 1][j] : own_hi[j];
+                if (w0 != 0.f) o[j] += w0 * a0l, o[4 + j] += w0 * a0h;
+                if (w1 != 0.f) o[j] += w1 * a1l, o[4 + j] += w1 * a1h;
             }
-            const float inv = L > 0.f ? 1.f / L : 0.f;
-            const uint32_t x0 = (uint32_t)cvt_out<BF16>(o[0] * inv) | ((uint32_t)cvt_out<BF16>(o[1] * inv) << 16);
-            const uint32_t x1 = (uint32_t)cvt_out<BF16>(o[2] * inv) | ((uint32_t)cvt_out<BF16>(o[3] * inv) << 16);
-            *(uint2 *)(p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + dlane) = uint2{x0, x1};
+            u32x4 x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = (uint32_t)cvt_out<BF16>(o[2 * j] * inv) | ((uint32_t)cvt_out<BF16>(o[2 * j + 1] * inv) << 16);
+            *(u32x4 *)(p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh + dlane8) = x;
         }
     };
     if (piece == 0) finish(SlotTag<0>{}, pr[0]), finish(SlotTag<1>{}, pr[1]);
