@@ -26,6 +26,16 @@
 #ifndef MLA8S_LEAD
 #define MLA8S_LEAD 2           // tiles requested ahead of the one being multiplied (<= slots - 1); 1, 2, 3 measured: 178 / 176 / 177 us at C4
 #endif
+#ifndef MLA8S_DMA_POLICY
+#define MLA8S_DMA_POLICY " nt" // cache policy of the KV fill (read once): nontemporal.  One process, alternating, C4: "" 173.9 / 106.2 us (full / ragged),
+                               // " nt" 172.3 / 104.8, " sc1" 173.6 / 105.7, " sc0 sc1" 173.8 / 105.7
+#endif
+#ifndef MLA8S_DMA_PLACE
+#define MLA8S_DMA_PLACE 0      // where a tile's five fill pieces are issued: 0 = spread over the QK^T MFMAs, 1 = in the softmax (VALU-only) phase, 2 = at the head of P.V
+#endif
+#ifndef MLA8S_PRIO
+#define MLA8S_PRIO 0           // 1: s_setprio 1 for the younger wave of each SIMD (waves 4..7) for the whole loop
+#endif
 #ifndef MLA8S_AHEAD
 #define MLA8S_AHEAD 2          // K operand fragments in flight in front of the QK^T MFMA that consumes them
 #endif
@@ -72,7 +82,7 @@ __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c)
 // ordering is the explicit s_waitcnt at the top of a tile).  M0 = wave-uniform LDS destination; lane l: 16 B from sbase + voff -> dst + 16 l.
 __device__ __forceinline__ void dma16(uint32_t dst, const void *sbase, uint32_t voff)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MLA8S_DMA_POLICY ::"s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 // a * s + c with the wave-uniform factor read from its scalar register (the compiler keeps a vector copy of it across the loop otherwise)
 __device__ __forceinline__ float fma_s(float a, float s, float c)
@@ -167,6 +177,9 @@ __device__ __forceinline__ void issue_piece(const CtxS &c, const TileS &tl, uint
         const int row = __builtin_amdgcn_readfirstlane(min(c.wave + 8 * idx, tl.last));      // (keeps the address arithmetic scalar)
         dma16(slot + (uint32_t)((c.wave + 8 * idx) * kNopeStride), tl.kn + (uint32_t)row * c.kn_srow, c.lane16);
     } else {
+#ifdef MLA8S_NO_ROPE         // timing probe: the fill without its rope pieces (results are garbage)
+        if (!prologue) return;
+#endif
         const uint32_t lane = opaque(c.lane16) >> 4;
         const uint32_t key = (uint32_t)c.wave * 4u + ((lane >> 3) & 3u);
         const uint32_t chunk = (lane & 7u) ^ (key & 7u);
@@ -400,12 +413,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             else if (step == 1) mfma16_first<BF16>(s1, af[1 % kRing], qf[0]);
             else if (step & 1) mfma16_acc<BF16>(s1, af[step % kRing], qf[step >> 1]);
             else mfma16_acc<BF16>(s0, af[step % kRing], qf[step >> 1]);
+#if MLA8S_DMA_PLACE == 0
             if (step % 7 == 3) issue_piece(cx, tl, nslot, (step / 7 + 4) % 5);          // steps 3, 10, 17, 24, 31 -> pieces 4, 0, 1, 2, 3
+#endif
         }
         mfma16_settle(s0, s1);
         __builtin_amdgcn_sched_barrier(0);
     };
 
+#if MLA8S_PRIO == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     constexpr float kGuardP = BF16 ? 0x1p64f : 0x1p11f;         // largest P (relative to the softmax reference) the accumulators are sized for
     if (wave_active) {
 #ifdef MLA8S_STAMPS
@@ -464,6 +482,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *(uint2 *)(pdst) = uint2{pack2<BF16>(e[0], e[1]), pack2<BF16>(e[2], e[3])};
             *(uint2 *)(pdst + 1024) = uint2{pack2<BF16>(e[4], e[5]), pack2<BF16>(e[6], e[7])};
             const s16x8 af0 = v_frag(slot_tag, 0);             // first V fragment of the P.V phase: in flight across barrier B
+#if MLA8S_DMA_PLACE == 1
+            {
+                constexpr uint32_t nslot1 = (uint32_t)(((decltype(slot_tag)::value + kSLead) % kSSlots) * kSSlotBytes);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) issue_piece(cx, tl, nslot1, (i + 4) % 5);
+            }
+#endif
             l_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
             // P >= 0: float order = order of the bit patterns (v_max3_u32, no NaN canonicalisation in front of every operand)
             const uint32_t emax = max3u(max3u(__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2])),
@@ -474,6 +499,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("s_barrier" ::: "memory");               // barrier B: P^T(t) complete
             MLA8S_TICK(4);
             pv_and_next_id(slot_tag, t, af0, [&] {
+#if MLA8S_DMA_PLACE == 2
+                {
+                    constexpr uint32_t nslot2 = (uint32_t)(((decltype(slot_tag)::value + kSLead) % kSSlots) * kSSlotBytes);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) issue_piece(cx, tl, nslot2, (i + 4) % 5);
+                }
+#endif
                 // a P above 2^kGuard (the first tile's are <= 1): the reference has been outgrown, the sequence is recomputed exactly
                 if (__any(emax > __float_as_uint(kGuardP))) {
 #if !defined(MLA8S_NO_DMA) && !defined(MLA8S_NO_QK) && !defined(MLA8S_NO_PV)
