@@ -17,6 +17,16 @@
 //     177 us, and the fill-only loop 151 / 147 / 148 -- the fill is bound by what the memory system delivers to this access pattern
 //     (604 MB in ~117 us of loop = 5.2 TB/s against 6.2 TB/s for the streaming microbenchmark, profiles/r03_cu_fetch_rate.txt), not by latency;
 //   * the tile loop is unrolled by the four slots: every LDS address is lane base + compile-time constant, DMA destinations are literals.
+// What bounds the loop, round 5 (the stamp probe below, -DMLA8S_STAMPS, and the ablation switches): with the fill nontemporal the fill + softmax
+// + barriers alone run 117 us at C4 (6.5 TB/s in the loop), everything but the fill 136 us, both together 173 us -- and the SHADER CLOCK
+// under the three is 2.39, 2.07 and 1.84 GHz (s_memtime against the 100 MHz counter over each workgroup's loop): MFMA + LDS operand reads
+// + the HBM stream at once put the chip at its power limit, so cycles saved inside the tile come back as a lower clock.  Consistently,
+// nothing that only re-times the tile moved the end-to-end time: the fill pieces under QK^T / in the softmax phase / at the head of P.V
+// (175-177 us), static priority for the younger wave of each SIMD, a P.V that lags one tile with the softmax of tile u - 1 interleaved
+// behind the QK^T MFMAs of tile u (no softmax phase at all: built to full parity -- 338 tests, bit-identical -- 172.3 vs 171.2 us, ragged
+// 106.7 vs 104.4 with its extra drain iteration; `git show` of the commit that records this line has the loop).  What would move it is
+// energy per tile: the QK^T operand traffic (every wave reads the whole 36 KB K tile, 288 KB per tile and CU, for 16x16x32 MFMAs that
+// use an operand fragment once).
 // Numerics, softmax reference (first tile's maximum, flagged sequences recomputed by the merge kernel), work list, partial-row layout and
 // epilogue: as mla_decode_wide8.hip, same MFMA shapes and summation order (bit-identical results).
 #include "device_once.h"
@@ -225,6 +235,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int kvh = seq % p.kv_heads;
     const int b = seq / p.kv_heads;
     if (wave == 0) MLA8S_STAMP(0);
+#ifdef MLA8S_STAMPS
+    const uint64_t clk0_ = __builtin_amdgcn_s_memtime();
+#endif
     const int seq_len = __builtin_amdgcn_readfirstlane(p.seq_lens[b]);
     const int ntiles = (seq_len + kST - 1) / kST;
     if constexpr (PLAN) {
@@ -537,6 +550,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const float m_run = (wave_active && t_begin < t_end) ? -nm : -INFINITY;
     if (wave == 0) MLA8S_STAMP(1);
+#ifdef MLA8S_STAMPS
+    if (wave == 0 && lane == 0 && blockIdx.x < 1024) g_mla8s_stamp[blockIdx.x][7] = __builtin_amdgcn_s_memtime() - clk0_;      // shader clocks, start -> loop end
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // fills issued past the last tile
     __syncthreads();
     const bool flagged_local = *(volatile uint32_t *)(lds + kSFlagOff) != 0;

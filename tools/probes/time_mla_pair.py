@@ -44,10 +44,14 @@ for ragged in (False, True):
         ph = np.zeros((256, 8, 8), dtype=np.float32)
         assert L.mi_mla8s_phases(ph.ctypes.data_as(c_void_p)) == 0
         m = ph.mean(axis=(0, 1))
+        if m[7] == 0:
+            m[7] = 1
         print("   per tile and wave [own fill wait, barrier A, QK^T, softmax + publish, barrier B, P.V] shader clocks:", [int(v) for v in m[:6]], "sum", int(m[:6].sum()),
               " loop", int(m[6]), "clocks /", int(m[7]), "tiles")
         for w in range(8):
             print("      wave", w, [int(v) for v in ph[:, w, :6].mean(axis=0)])
+        ghz = host[:256, 7].astype(np.float64) / np.maximum((host[:256, 1].astype(np.float64) - host[:256, 0].astype(np.float64)) * 10.0, 1.0)
+        print("   shader clock, start -> loop end (GHz) [min, p50, max]:", [round(float(np.percentile(ghz, q)), 3) for q in (0, 50, 100)])
         names = ["start", "loop end", "stores issued", "drained+barrier", "flag seen", "acquired", "second pass done"]
         for i in range(1, 7 if mode else 3):
             print(f"   {names[i]:18s} at {pct(st[:, i])}   step {pct(st[:, i] - st[:, i - 1])}")
