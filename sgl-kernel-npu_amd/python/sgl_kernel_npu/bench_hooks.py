@@ -119,7 +119,7 @@ def bench_mla_decode(steps=30, warmup=5):
         "host_ms_per_step": wall * 1e3, "dtype": "bf16",
         "config": {"workload": "MLA paged decode, bs=128, q_heads=128, kv_heads=1, head_dim=576 (512+64), page_size=64, "
                                "seqlen=4096 (BASELINE C4)"},
-        "roofline": {"bound": "hbm", "kernel": "decode_plan_kernel + mla_decode_wide8_kernel + mla_merge_kernel (device-built work list)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "decode_plan_kernel (once per 61-call step) + mla_decode_wide8s_kernel (two-piece sequences finish in the kernel) + mla_merge_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes": kv_bytes + io_bytes, "avg_launch_us": dev_ms * 1e3},
         "ragged": {"workload": "same batch, kv_seq_lens ~ U[1, 4096]", "ms_per_step": r_ms, "mean_seq_len": float(rlens.float().mean().item()),
@@ -133,7 +133,7 @@ def bench_mla_decode(steps=30, warmup=5):
         "shared_plan_ms_per_step": ms_shared, "shared_plan_frac": (kv_bytes + io_bytes) / (ms_shared * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "tp8_shard": shard,
         "uniform_2_splits_ms_per_step": ms_uniform,     # the full-length batch through num_splits = 2 (round 3's form), queued back to back
-        "pmc_kernels": ["decode_plan_kernel", "mla_decode_wide8_kernel<true, true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
+        "pmc_kernels": ["decode_plan_kernel", "mla_decode_wide8s_kernel<true, true>", "mla_merge_kernel<true>"],     # launches of one step (bench.py looks up their PMC traffic)
         "mfma": {"achieved_TFLOPs": flops / (dev_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                  "frac": flops / (dev_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
     }

@@ -18,7 +18,7 @@ cd "$REPO"
 python - "$OUT" "$RND" <<'PY'
 import csv, glob, json, os, re, sys, collections
 out, rnd = sys.argv[1], sys.argv[2]
-want = ("mla_decode_wide_kernel", "mla_decode_wide8_kernel", "mla_merge_kernel", "grouped_gemm_i8_kernel", "rowquant_kernel")
+want = ("mla_decode_wide_kernel", "mla_decode_wide8_kernel", "mla_decode_wide8s_kernel", "mla_merge_kernel", "gqa_decode_wide_kernel", "grouped_gemm_i8_kernel", "rowquant_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(out, "p*", "*", "*counter_collection.csv"))):
@@ -39,7 +39,7 @@ for k, cs in sorted(agg.items()):
     c = {n: med(v) for n, v in cs.items()}
     d = {"launches": max(len(v) for v in cs.values()), "duration_us_under_pmc": (med(dur[k]) or 0) / 1e3, "counters_median": c}
     # waves that share a SIMD while the kernel runs (one workgroup per CU in all of them): 256 threads -> 1, 512 -> 2, 1024 -> 4
-    wps = 2 if "wide8" in k else (4 if k.startswith("grouped_gemm") else 1)
+    wps = 2 if ("wide8" in k or k.startswith("gqa_decode_wide")) else (4 if k.startswith("grouped_gemm") else 1)
     der = {}
     if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("SQ_WAVE_CYCLES"):
         per_wave = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"])

@@ -1,4 +1,5 @@
-"""Scratch: four-wave vs eight-wave wide MLA kernel at BASELINE C4, alternating in ONE process (same box, same clocks)."""
+"""Scratch: four-wave vs eight-wave (8: block-id ring, 9: scalar block ids) wide MLA kernels at BASELINE C4, alternating in ONE process
+(same box, same clocks); num_splits 0 = each form's default (planned list for the eight-wave forms, two uniform splits for four waves)."""
 import ctypes, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, os.path.join(ROOT, "sgl-kernel-npu_amd", "python"))
@@ -11,9 +12,9 @@ for ragged in (False, True):
     out = torch.empty((128, 128, 512), dtype=torch.bfloat16, device="cuda")
     f = lambda: torch.ops.npu.decode_mla(q, kn, kr, out, lens, 576 ** -0.5, 64, bt, 0)
     for _ in range(300): f()
-    res = {4: [], 8: []}
+    res = {4: [], 8: [], 9: []}
     for rep in range(6):
-        for waves in (4, 8):
+        for waves in (4, 8, 9):
             lib.mi_mla_decode_select_wide(waves)
             for _ in range(20): f()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
