@@ -25,8 +25,8 @@
 // (175-177 us), static priority for the younger wave of each SIMD, a P.V that lags one tile with the softmax of tile u - 1 interleaved
 // behind the QK^T MFMAs of tile u (no softmax phase at all: built to full parity -- 338 tests, bit-identical -- 172.3 vs 171.2 us, ragged
 // 106.7 vs 104.4 with its extra drain iteration; `git show` of the commit that records this line has the loop).  What would move it is
-// energy per tile: the QK^T operand traffic (every wave reads the whole 36 KB K tile, 288 KB per tile and CU, for 16x16x32 MFMAs that
-// use an operand fragment once).
+// energy per tile -- and the LDS operand traffic is not the big part of it: with every second K fragment of QK^T not read at all
+// (-DMLA8S_HALF_QK_READS: 288 -> 144 KB of LDS reads per tile and CU, what a k-split QK^T on 32x32x16 would read) the kernel gains 3 %.
 // Numerics, softmax reference (first tile's maximum, flagged sequences recomputed by the merge kernel), work list, partial-row layout and
 // epilogue: as mla_decode_wide8.hip, same MFMA shapes and summation order (bit-identical results).
 #include "device_once.h"
@@ -420,7 +420,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int step = 0; step < 36; ++step) {
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MLA8S_HALF_QK_READS   // timing probe: every second K fragment is not read (the MFMA takes a stale one; results are garbage) -- what would half the
+                             // QK^T operand traffic be worth?  176.3 -> 171.0 us at C4 (merge form), QK^T 1748 -> 1602 clocks per tile: 3 %, the
+                             // ceiling of a k-split QK^T on 32x32x16 before its partial-sum exchange and third barrier are paid for.
+            if (step + kAhead < 36 && !((step + kAhead) & 1)) af[(step + kAhead) % kRing] = lda(step + kAhead);
+#else
             if (step + kAhead < 36) af[(step + kAhead) % kRing] = lda(step + kAhead);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (step == 0) mfma16_first<BF16>(s0, af[0], qf[0]);
             else if (step == 1) mfma16_first<BF16>(s1, af[1 % kRing], qf[0]);
