@@ -263,9 +263,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // those 32 dims x heads 32 hb .. +31.  Starts behind barrier B.
     const int c16 = lane & 15, q16 = (lane >> 4) & 1;
     const uint32_t v_lane = (uint32_t)(kVBase + (4 * kg + (c16 >> 2)) * VSx + (wave >> 2) * 256 + (wave & 3) * 32 + q16 * 128 + (c16 & 3) * 8);
-    auto pv = [&](auto slot_tag, int t) {
+    // V^T fragment kk of the tile in slot SLOT (keys 16 kk + {4 kg + 0..3, 8 + 4 kg + 0..3}); the tile has been complete since barrier A, so
+    // the caller requests all of them AHEAD of barrier B (only P^T, alpha and moved[] need that barrier)
+    auto v_frag = [&](auto slot_tag, int kk) -> s16x8 {
         constexpr int SLOT = decltype(slot_tag)::value;
-        // references that moved in this tile: rescale the accumulators of those heads first (wave-uniform test, one broadcast read)
+        const uint8_t *vlo = lds + SLOT * kSlotBytes + v_lane;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + kk * 16 * VSx));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + kk * 16 * VSx + 8 * VSx));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto pv = [&](int t, const s16x8 (&a)[kKB]) {
+        const uint8_t *pb = lds + kPxOff + opaque(lane16);
+        auto ldp = [&](int hb, int kk) -> s16x8 { return *(const s16x8 *)(pb + (hb * kKB + kk) * 1024); };
+        // the P^T fragments are requested first; the test for moved references (one broadcast read, wave-uniform) runs while they travel
+        s16x8 pf[8];                                           // a ring of eight: fragment i + 8 is requested behind the MFMA that read fragment i
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pf[i] = ldp(i & 3, i >> 2);
+        // references that moved in this tile: rescale the accumulators of those heads before the tile's products are added
         {
             const u32x4 m0 = *(const u32x4 *)(lds + kMovedOff), m1 = *(const u32x4 *)(lds + kMovedOff + 16);
             const uint32_t mv[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
@@ -275,27 +289,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bool lo_moved = __builtin_amdgcn_readfirstlane(mv[2 * hb]) == (uint32_t)(t + 1);
                 const bool hi_moved = __builtin_amdgcn_readfirstlane(mv[2 * hb + 1]) == (uint32_t)(t + 1);
                 if (lo_moved || hi_moved) {
-                    const float a = ((c32 < 16) ? lo_moved : hi_moved) ? ((const float *)(lds + kAlphaOff))[hb * 32 + c32] : 1.f;
+                    const float al = ((c32 < 16) ? lo_moved : hi_moved) ? ((const float *)(lds + kAlphaOff))[hb * 32 + c32] : 1.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[hb][r] *= a;
+                    for (int r = 0; r < 16; ++r) acc[hb][r] *= al;
                 }
             }
         }
-        const uint8_t *vlo = lds + SLOT * kSlotBytes + v_lane;
-        const uint8_t *pb = lds + kPxOff + opaque(lane16);
-        auto lda = [&](int kk) -> s16x8 {                      // keys 16 kk + {4 kg + 0..3, 8 + 4 kg + 0..3}
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + kk * 16 * VSx));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(vlo + kk * 16 * VSx + 8 * VSx));
-            return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        };
-        auto ldp = [&](int hb, int kk) -> s16x8 { return *(const s16x8 *)(pb + (hb * kKB + kk) * 1024); };
-        s16x8 a[kKB], pf[4 * kKB];
 #pragma unroll
-        for (int kk = 0; kk < kKB; ++kk) a[kk] = lda(kk);
-#pragma unroll
-        for (int i = 0; i < 4 * kKB; ++i) pf[i] = ldp(i & 3, i >> 2);
-#pragma unroll
-        for (int i = 0; i < 4 * kKB; ++i) acc[i & 3] = mfma32<BF16>(a[i >> 2], pf[i], acc[i & 3]);
+        for (int i = 0; i < 4 * kKB; ++i) {
+            acc[i & 3] = mfma32<BF16>(a[i >> 2], pf[i & 7], acc[i & 3]);
+            if (i + 8 < 4 * kKB) pf[i & 7] = ldp((i + 8) & 3, (i + 8) >> 2);
+        }
     };
     // top of tile t: this wave's operations of t have landed (the 8 of tile t + 1 may be in flight), barrier A: tile t complete in LDS,
     // everybody done with tile t - 1 and with the exchange buffer
@@ -304,9 +308,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         return tile_of<T>(cx, t + kLead, blk_next);
     };
-    auto pv_and_next_id = [&](auto slot_tag, int t) {
+    auto pv_and_next_id = [&](int t, const s16x8 (&a)[kKB]) {
         int id = block_id_request<T>(cx, t + 1 + kLead);
-        pv(slot_tag, t);
+        pv(t, a);
         block_id_wait(id);
         blk_next = id;
     };
@@ -322,8 +326,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!wave_active) {                                     // no heads of its own: DMA share, P = 0 (written once, below), P.V slice
 #pragma unroll
             for (int i = 0; i < kOps; ++i) issue_op<T>(cx, tl, nslot, i);
+            s16x8 av[kKB];
+#pragma unroll
+            for (int kk = 0; kk < kKB; ++kk) av[kk] = v_frag(slot_tag, kk);
             asm volatile("s_barrier" ::: "memory");              // barrier B
-            pv_and_next_id(slot_tag, t);
+            pv_and_next_id(t, av);
             return;
         }
         // ---- S^T[key, head] = K . Q^T: 9 k-steps x 2 key blocks of 16, operand fragments three MFMAs ahead, a DMA operation every
@@ -377,7 +384,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         const float nm = -m_ref;
+        // scores -> exp2 -> P^T in LDS is the phase's critical path; the running sum follows the LDS writes, the V^T fragments of the P.V
+        // phase are requested ahead of barrier B
         uint8_t *pdst = lds + pdst_off;
+        float esum[kKB / 2];
 #pragma unroll
         for (int kp = 0; kp < kKB; kp += 2) {                   // key blocks in pairs: the sums of a 32-key tile keep their order
             float e[8];
@@ -386,13 +396,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 e[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kp][i], cs, nm));
                 e[4 + i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kp + 1][i], cs, nm));
             }
-            l_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
             *(uint2 *)(pdst + kp * 1024) = uint2{pack2<BF16>(e[0], e[1]), pack2<BF16>(e[2], e[3])};
             *(uint2 *)(pdst + (kp + 1) * 1024) = uint2{pack2<BF16>(e[4], e[5]), pack2<BF16>(e[6], e[7])};
+            esum[kp / 2] = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
         }
+        s16x8 av[kKB];
+#pragma unroll
+        for (int kk = 0; kk < kKB; ++kk) av[kk] = v_frag(slot_tag, kk);
+#pragma unroll
+        for (int kp = 0; kp < kKB / 2; ++kp) l_run += esum[kp];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");                   // barrier B: P^T(t), alpha, moved complete
-        pv_and_next_id(slot_tag, t);
+        pv_and_next_id(t, av);
     };
     if (!wave_active) {
 #pragma unroll
