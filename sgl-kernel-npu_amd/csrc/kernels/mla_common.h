@@ -42,6 +42,9 @@ struct MlaParams {
     // skips such a sequence and re-arms its two words.  NULL = every cut sequence goes through the merge kernel.
     uint64_t *pair_flags;     // [batch * kv_heads][2], a word holds pair_tag once its piece's partial is visible
     uint64_t pair_tag;        // never 0; a scrambled call number (first use of an uninitialised workspace: 2^-64 per word)
+    uint64_t *need_merge;     // one word behind the pair words: holds pair_tag when some workgroup of this launch left work for the merge kernel (a
+                              // sequence in three or more pieces, a pair that did not meet, an outgrown softmax reference); otherwise every
+                              // merge workgroup leaves after ONE load instead of the list lookup + statistics round trips per head
     int pair_withhold;        // test hook: piece 1 never raises its word, so piece 0 runs into the bounded wait (the merge kernel's turn)
     // Length-aware work list built on the device by decode_plan_kernel (decode_plan.h), NULL = the uniform num_splits form.  Layout below.
     const int32_t *plan;

@@ -431,6 +431,9 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p)
     // the meeting words of the sequence's two pieces (mla_decode_wide8s.hip) are re-armed here, behind the launch that used them: the
     // next call -- or the next replay of a captured one, which carries the same tag -- finds them clear
     if (p.pair_flags && h % p.group == 0 && lane < 2) p.pair_flags[((int64_t)b * p.kv_heads + h / p.group) * 2 + lane] = 0ull;
+    // nothing left for this launch (every sequence finished in the kernel: BASELINE C4's two pieces per sequence, or one piece each):
+    // one load per wave instead of the list lookup and the statistics round trips
+    if (p.need_merge && __hip_atomic_load(p.need_merge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pair_tag) return;
     if (p.fix_only && p.fix_flags[b * p.kv_heads + h / p.group] == p.fix_epoch) {
         mla_recompute_head<BF16>(p, b, h, lane);
         return;
@@ -746,7 +749,7 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
     p.fix_epoch = ++epoch ? epoch : ++epoch;          // a stale word equal to the epoch only causes a redundant recompute
     p.fix_only = 0;
     p.arrive = p.fix_flags ? p.fix_flags + (size_t)batch * kv_heads : nullptr;       // inside the batch * q_heads flag words (wide: group > 64)
-    p.pair_flags = nullptr, p.pair_tag = 0, p.pair_withhold = 0;
+    p.pair_flags = nullptr, p.pair_tag = 0, p.pair_withhold = 0, p.need_merge = nullptr;
     // The wide kernel finishes a one-split launch itself (slow path included): no second launch.  With two splits its
     // in-kernel merge is correct (MI_MLA_INLINE_MERGE=2 enables it) but measured 202 us against 195 us for the separate
     // merge launch at C4: the agent-scope release / acquire each pair needs costs an L2 write-back and an L2 invalidate.
@@ -780,6 +783,7 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
         p.pair_withhold = g_pair_mode == 2;
         if (pair_on && scalar_ids && wide8 && p.group <= 128 && (planned || num_splits == 2) && p.arrive) {
             p.pair_flags = (uint64_t *)(((uintptr_t)p.arrive + 7) & ~(uintptr_t)7);
+            p.need_merge = p.pair_flags + 2 * (size_t)batch * kv_heads;
             p.pair_tag = (uint64_t)p.fix_epoch * 0x9E3779B97F4A7C15ull;      // odd multiplier, epoch != 0: never 0
         }
         if (planned) (scalar_ids ? launch_mla_wide8s : launch_mla_wide8)(p, dtype, plan_items_max(seqs, workers), st);

@@ -659,7 +659,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
+    auto leave_to_merge_kernel = [&]() {
+        if (threadIdx.x == 0 && p.need_merge) __hip_atomic_store(p.need_merge, p.pair_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     if (!pair) {
+        if (!finals) leave_to_merge_kernel();
         const int kind = finals ? 0 : 1;
         rows_out(SlotTag<0>{}, kind);
         rows_out(SlotTag<1>{}, kind);
@@ -699,8 +703,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
     if (wave == 0) MLA8S_STAMP(4);
-    if (flagged_local) return;                                 // (the merge kernel recomputes the sequence)
+    if (flagged_local) {                                       // (the merge kernel recomputes the sequence)
+        leave_to_merge_kernel();
+        return;
+    }
     if (*(volatile uint32_t *)ok_word == 0) {
+        leave_to_merge_kernel();
         if (piece == 0) rows_out(SlotTag<0>{}, 1), rows_out(SlotTag<1>{}, 1);
         else rows_out(SlotTag<2>{}, 1), rows_out(SlotTag<3>{}, 1);
         return;
