@@ -441,6 +441,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, in
 // kStages - 1 stages already requested overlap the epilogue (the accumulators occupy the registers a second tile would need, so the
 // MFMA stream still stops for the ~11k-cycle epilogue), which buys back the pipeline fill (~5 % of a GEMM2 tile) and loses it again
 // to the ring bookkeeping inside the k-loop.
+// Measured and dropped (round 5): the same idea with the k-loop left alone -- between a tile's k-loop and its epilogue the worker looks up its
+// NEXT tile and requests stage 0 of its ring (the epilogue's transposition tiles moved above the first stage, the 256-row tile through
+// them in two passes); bit-exact, and no change at all: GEMM1 823.5 / 823.5 us, GEMM2 487.9 / 489.1, multinomial counts 895.9 / 901.2 and
+// 530.4 / 533.7 (tools/time_gemm.py, one box).  The first k-tile's round trip is not what a tile waits for; like the MLA loop these
+// kernels run at the chip's power limit (1.8-2.0 GHz, below), where re-timing a tile moves nothing.
 // Shader clock under this kernel (always on: a handful of scalar instructions in ONE workgroup): the first workgroup stamps the shader-clock
 // counter and the 100 MHz reference around its whole run.  mi_ep_moe_gemm_clock() turns the last launch's pair into GHz -- the chip
 // does not hold its 2.4 GHz under dense INT8 MFMA issue, and the datasheet peak scales with the clock it does hold (bench.py reports the
