@@ -497,7 +497,10 @@ def _pair_inputs(B, Hq, S, page, dtype, ragged, seed):
 # block in fp16, the uniform two-split form on a small batch, pages of 32 keys
 PAIR_CASES = [(128, 128, 1024, 64, torch.bfloat16, False, PLANNED), (128, 128, 1500, 64, torch.bfloat16, True, PLANNED),
               (100, 96, 700, 128, torch.float16, True, PLANNED), (5, 128, 900, 64, torch.bfloat16, True, 2),
-              (120, 128, 640, 32, torch.float16, False, PLANNED)]
+              (120, 128, 640, 32, torch.float16, False, PLANNED),
+              # more workgroups than CUs: 200 sequences x two uniform splits = 400 workgroups (a piece may meet a partner that is not
+              # resident yet: the bounded wait, then the merge kernel -- or simply a late partner), and the list form of the same batch
+              (200, 128, 700, 64, torch.bfloat16, True, 2), (200, 128, 1100, 64, torch.bfloat16, True, PLANNED)]
 
 
 @pytest.mark.parametrize("B,Hq,S,page,dtype,ragged,splits", PAIR_CASES)
