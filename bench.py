@@ -398,7 +398,8 @@ def pmc_traffic(kernel):
         return None
     try:
         k = json.load(open(files[-1]))["kernels"].get(PMC_KERNEL_NAMES.get(kernel, kernel))
-        return k["hbm_bytes_per_launch"] if k else None
+        # (the MLA merge launch: the one behind a headline-size decode launch, not the largest of the run -- tools/summarize_prof.py)
+        return k.get("hbm_bytes_per_launch_behind_headline_decode", k["hbm_bytes_per_launch"]) if k else None
     except Exception:  # noqa: BLE001
         return None
 
