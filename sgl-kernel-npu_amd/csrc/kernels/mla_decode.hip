@@ -784,7 +784,7 @@ static int mla_decode_impl(const void *q, const void *k_nope, const void *k_rope
         if (pair_on && scalar_ids && wide8 && p.group <= 128 && (planned || num_splits == 2) && p.arrive) {
             p.pair_flags = (uint64_t *)(((uintptr_t)p.arrive + 7) & ~(uintptr_t)7);
             p.need_merge = p.pair_flags + 2 * (size_t)batch * kv_heads;
-            p.pair_tag = (uint64_t)p.fix_epoch * 0x9E3779B97F4A7C15ull;      // odd multiplier, epoch != 0: never 0
+            p.pair_tag = ((uint64_t)p.fix_epoch * 0x9E3779B97F4A7C15ull) | 8ull;      // never 0 above the three bits that carry the XCC id
         }
         if (planned) (scalar_ids ? launch_mla_wide8s : launch_mla_wide8)(p, dtype, plan_items_max(seqs, workers), st);
         else if (wide8) (scalar_ids ? launch_mla_wide8s : launch_mla_wide8)(p, dtype, units, st);

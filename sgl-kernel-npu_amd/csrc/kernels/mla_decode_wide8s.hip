@@ -220,8 +220,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int c32 = lane & 31, kg = lane >> 5;                 // P.V role: head c32 of a 32-head block, key half kg
     const int head_blocks = (p.group + 127) / 128;
     int seq, hblk, t_begin, t_end;
+    // PLAN: which item of the list this workgroup takes.  The hardware deals workgroup i to XCD i mod 8; inside every run of 16 workgroups,
+    // workgroups r and r + 8 -- one XCD -- take the items 2 (r mod 8) and 2 (r mod 8) + 1: the two pieces of a sequence that starts on an even
+    // item share an L2 (Q^T crosses from memory once; the rows the pair finish exchanges are read back from that L2 instead of HBM), and
+    // any run of items still spreads evenly over the XCDs.  Nothing but traffic depends on the placement being what is assumed here: the
+    // pair finish checks it.  (Time: unchanged, 176.6 us either way -- the hand-off is not bound by the fabric; HBM traffic: see DESIGN.)
+    const int item_ix = PLAN && ((blockIdx.x | 15u) < gridDim.x) ? (int)((blockIdx.x & ~15u) + ((blockIdx.x & 7u) << 1) + ((blockIdx.x >> 3) & 1u)) : (int)blockIdx.x;
     if constexpr (PLAN) {
-        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x);
+        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, item_ix);
         if (it.seq < 0) return;                                // behind the list
         seq = it.seq, hblk = 0, t_begin = it.t_begin, t_end = it.t_end;
     } else {
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (PLAN) {
         // the list only decides WHO reads which tiles: pieces are clamped to the sequence's tiles as they are NOW, the last piece runs to
         // their end -- a stale list costs balance, never correctness
-        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x);
+        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, item_ix);
         t_begin = min(t_begin, ntiles);
         t_end = it.k == it.n - 1 ? ntiles : min(t_end, ntiles);
     } else {
@@ -573,12 +579,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
     int nsplits, pmul, piece;
+    bool near = true;                                          // (uniform form: the splits of a sequence are dealt to one XCD)
     int64_t pbase, pbase_partner;
     if constexpr (PLAN) {
-        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, (int)blockIdx.x);
+        const PlanItem it = plan_item(p.plan, (long long)p.batch * p.kv_heads, item_ix);
         nsplits = it.n, piece = it.k;
-        pmul = 1, pbase = ((int64_t)blockIdx.x - kvh) * p.group;
+        pmul = 1, pbase = ((int64_t)item_ix - kvh) * p.group;
         pbase_partner = pbase + (piece == 0 ? p.group : -p.group);       // the pieces of a sequence are consecutive items
+        // partner expected on this XCD: the pair starts on an even item of a full run of 16 workgroups
+        near = ((item_ix - piece) & 1) == 0 && ((blockIdx.x | 15u) < gridDim.x);
     } else {
         nsplits = p.num_splits, piece = ((blockIdx.x >> 3) / head_blocks) % p.num_splits;
         pmul = p.num_splits, pbase = (int64_t)b * p.q_heads * p.num_splits + piece;
@@ -679,8 +688,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // does not show up in time (not resident: more items than the chip runs at once) costs nothing but the wait: this workgroup then
     // writes the rows of its own heads as well and leaves them unmarked -- both partials of those heads are in the workspace and the merge
     // kernel, which skips only heads whose piece carries the mark, does the work.
-    if (piece == 0) rows_out(SlotTag<2>{}, 2), rows_out(SlotTag<3>{}, 2);
-    else rows_out(SlotTag<0>{}, 2), rows_out(SlotTag<1>{}, 2);
+    // Partner expected on this XCD (`near`): plain stores -- the rows wait in the shared L2 for the partner's sc1 (L1-bypassing) loads and do
+    // not have to come back from HBM; otherwise write-through.  Both workgroups publish their XCC id with the meeting word: a pair that
+    // expected to be neighbours and is not (placement is the hardware's business) takes the bounded wait's way out -- the merge kernel, for
+    // which the kernel boundary makes every row visible.
+    const int xkind = near ? 1 : 2;
+    if (piece == 0) rows_out(SlotTag<2>{}, xkind), rows_out(SlotTag<3>{}, xkind);
+    else rows_out(SlotTag<0>{}, xkind), rows_out(SlotTag<1>{}, xkind);
     if (wave == 0) MLA8S_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave: its write-through stores have left
     __syncthreads();
@@ -688,17 +702,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint32_t *const ok_word = (uint32_t *)(lmb + 256);
     const int64_t fbase = ((int64_t)b * p.kv_heads + kvh) * 2;
     if (threadIdx.x == 0) {
+        const uint64_t xcc = (uint64_t)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // HW_REG_XCC_ID[3:0]
+        const uint64_t tag = p.pair_tag & ~7ull;
         if (!(p.pair_withhold && piece == 1))
-            __hip_atomic_store(p.pair_flags + fbase + piece, p.pair_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.pair_flags + fbase + piece, tag | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         uint32_t ok = 1;
-        while (__hip_atomic_load(p.pair_flags + fbase + (piece ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pair_tag) {
+        uint64_t seen;
+        while (((seen = __hip_atomic_load(p.pair_flags + fbase + (piece ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~7ull) != tag) {
             __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memrealtime() - t0 > 20000ull) {      // 200 us at 100 MHz
                 ok = 0;
                 break;
             }
         }
+        if (ok && near && (seen & 7ull) != xcc) ok = 0;       // expected neighbours on different XCDs: plain rows may not be visible here
         *ok_word = ok;
     }
     __syncthreads();
