@@ -29,7 +29,8 @@
 #include "mi_sgl_kernels.h"
 
 #ifndef GQAW_DMA_EVERY
-#define GQAW_DMA_EVERY 2       // 18 QK^T MFMAs per tile and wave, 8 (4 for a V view) DMA operations
+#define GQAW_DMA_EVERY (-2)    // a fill operation every n-th QK^T MFMA; -2: spread evenly over the tile's MFMAs (MFMAs / operations: 4 for the view
+                               // forms, 2 with a V tile of its own); 0: all in front of the first MFMA; -1: all in the softmax phase (probes)
 #endif
 
 namespace mi_gqa_wide {
@@ -157,8 +158,11 @@ __device__ __forceinline__ TileAt tile_of(const Ctx &c, int tile, int blk)
 // operation idx 0 .. T / 8 - 1: K row wave + 8 idx; the next T / 8: V rows (none when V is a column prefix of the K rows: the P.V operand is
 // then read from the K tile, like the MLA kernels do).  One cache row per instruction; `slot` = LDS byte address
 template <int T>
-__device__ __forceinline__ void issue_op(const Ctx &c, const TileAt &tl, uint32_t slot, int idx)
+__device__ __forceinline__ void issue_op(const Ctx &c, const TileAt &tl, uint32_t slot, int idx, bool prologue = false)
 {
+#ifdef GQAW_NO_DMA           // timing probe: the tile loop without its fill (results are garbage)
+    if (!prologue) return;
+#endif
     constexpr int kRows = Geo<T>::kRows;
     const int r = c.wave + 8 * (idx % kRows), row = __builtin_amdgcn_readfirstlane(min(r, tl.last));      // (keeps the address arithmetic scalar)
     if (idx < kRows) {
@@ -170,16 +174,29 @@ __device__ __forceinline__ void issue_op(const Ctx &c, const TileAt &tl, uint32_
 
 template <int N> struct SlotTag { static constexpr int value = N; };
 
+#ifdef GQAW_STAMPS           // timing probe: shader clocks per phase, summed per wave in LDS behind the kernel's own area (tools/probes/gqa_wide_phases.py)
+__device__ float g_gqaw_phase[256][8][8];
+#define GQAW_TICK(i) do { const uint32_t c1_ = (uint32_t)__builtin_amdgcn_s_memtime(); if (lane == 0) __hip_atomic_fetch_add((uint32_t *)(lds + G::kLds) + wave * 8 + (i), c1_ - c0_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); c0_ = c1_; } while (0)
+#else
+#define GQAW_TICK(i) do { } while (0)
+#endif
+
 // VIEW: the V cache is the first lv columns of the K rows (same pointer and strides -- the reference test builds exactly that,
 // test_decode_attention.py:74): one fill serves both GEMMs
-template <bool BF16, bool VIEW, int T>
+// PACK (64-key view form with full-width K rows, lk = 288): a tile's K rows are contiguous in the cache (one page) and 608 bytes apart in the
+// slot, so the slot is filled as 38 LINEAR 1 KiB pieces -- lane l of piece j fetches the 16 bytes that belong at LDS byte 1024 j + 16 l
+// (row = chunk / 38, column = chunk % 38; the two pad columns of a row re-fetch its last chunk) -- five operations per wave and tile
+// instead of eight row operations that use 36 of their 64 lanes.  Tiles that end inside the sequence's last keys take the row form.
+template <bool BF16, bool VIEW, int T, bool PACK = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gqa_decode_wide_kernel(Params p)
 {
     static_assert(T == 32 || (T == 64 && VIEW), "64-key tiles: V is read from the K tile");
+    static_assert(!PACK || (T == 64 && VIEW), "linear fill: the 64-key view form");
     using G = Geo<T>;
     constexpr int kT = T, kKB = G::kKB, kSlots = G::kSlots, kSlotBytes = G::kSlotBytes, kVOff = G::kVOff, kPxOff = G::kPxOff;
     constexpr int kAlphaOff = G::kAlphaOff, kMovedOff = G::kMovedOff;
-    constexpr int kOps = VIEW ? G::kRows : 2 * G::kRows;        // DMA operations per wave and tile: the K rows (+ the V rows)
+    constexpr int kRowOps = VIEW ? G::kRows : 2 * G::kRows;     // row form: the K rows (+ the V rows) of a wave
+    constexpr int kOps = PACK ? 5 : kRowOps;                    // DMA operations per wave and tile (what the vmcnt arithmetic counts)
     constexpr int VSx = VIEW ? KS : VS, kVBase = VIEW ? 0 : kVOff;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -216,6 +233,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int head = kvh * p.group + hg;
     if (__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)lds) != 0u) __builtin_trap();
     const Ctx cx{&p, b, seq_len, wave, ntiles, __builtin_ctz(p.page_size), (uint32_t)lane * 16u, p.k + (int64_t)kvh * p.k_sh, p.v + (int64_t)kvh * p.v_sh};
+    // linear pieces of this wave: j = wave + 8 i (38 pieces; waves 6 and 7 repeat their fourth piece as the fifth: every wave issues kOps)
+    uint32_t voffp[PACK ? 5 : 1];
+    if constexpr (PACK) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int jj = wave + 8 * i < 38 ? wave + 8 * i : wave + 24;
+            const uint32_t c = (uint32_t)(64 * jj + lane), row = (c * 1725u) >> 16, col = c - 38u * row;      // c / 38 exactly for c < 2432
+            voffp[i] = row * (uint32_t)(p.k_srow * 2) + min(col, 35u) * 16u;
+        }
+    }
+    // fill operation i (0 .. kOps - 1) of the tile `tl` into the slot at LDS byte `slot`
+    auto issue = [&](const TileAt &tl, uint32_t slot, int i, bool prologue = false) {
+        if constexpr (PACK) {
+            if (tl.last == kT - 1) {
+#ifdef GQAW_NO_DMA
+                if (!prologue) return;
+#endif
+                const int jj = wave + 8 * i < 38 ? wave + 8 * i : wave + 24;
+                dma16(slot + (uint32_t)(jj * 1024), tl.k, voffp[i]);
+            } else if (i < 4) {                                 // a tile that ends in the sequence's last keys: the row form (clamped rows), two per call
+                issue_op<T>(cx, tl, slot, 2 * i, prologue);
+                issue_op<T>(cx, tl, slot, 2 * i + 1, prologue);
+            }
+        } else {
+            issue_op<T>(cx, tl, slot, i, prologue);
+        }
+    };
 
     // head dims below the padded (288, 256): the pad columns of the slots are never a DMA target and must read as zero under the zero tail of
     // Q^T (K) -- a stale NaN times zero is NaN -- and as anything finite under the discarded output dims (V)
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int d = 0; d < kLead; ++d) {
             const TileAt tl = tile_of<T>(cx, t_begin + d, ids[d]);
 #pragma unroll
-            for (int i = 0; i < kOps; ++i) issue_op<T>(cx, tl, (uint32_t)(d * kSlotBytes), i);
+            for (int i = 0; i < kOps; ++i) issue(tl, (uint32_t)(d * kSlotBytes), i, true);
         }
     }
     // Q^T fragments (B operand of 16x16x32): lane (h16, g) holds q[head][32 ks + 8 g .. +8], zero behind lk
@@ -319,13 +363,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint32_t pdst_off = (uint32_t)(kPxOff + (hbw * kKB * 64 + lc) * 16 + (g >> 1) * 8);      // + 1024 per key block
     const uint32_t a_lane = (uint32_t)(h16 * KS + g * 16);
 
+#ifdef GQAW_STAMPS
+    uint32_t c0_ = 0;
+    if (lane < 8) ((uint32_t *)(lds + G::kLds))[wave * 8 + lane] = 0;
+    const uint64_t clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     auto body = [&](auto slot_tag, int t) {
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr uint32_t nslot = (uint32_t)(((SLOT + kLead) % kSlots) * kSlotBytes);
+#ifdef GQAW_STAMPS
+        c0_ = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
         const TileAt tl = tile_top(t);
+        GQAW_TICK(0);
         if (!wave_active) {                                     // no heads of its own: DMA share, P = 0 (written once, below), P.V slice
 #pragma unroll
-            for (int i = 0; i < kOps; ++i) issue_op<T>(cx, tl, nslot, i);
+            for (int i = 0; i < kOps; ++i) issue(tl, nslot, i);
             s16x8 av[kKB];
 #pragma unroll
             for (int kk = 0; kk < kKB; ++kk) av[kk] = v_frag(slot_tag, kk);
@@ -341,10 +394,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const uint8_t *abase = lds + SLOT * kSlotBytes + a_lane;
             auto lda = [&](int step) -> s16x8 { return *(const s16x8 *)(abase + (step % kKB) * 16 * KS + (step / kKB) * 64); };
-            constexpr int kAhead = 3, kRing = kAhead + 1, kEvery = GQAW_DMA_EVERY;
+            constexpr int kAhead = 3, kRing = kAhead + 1, kEvery = GQAW_DMA_EVERY == -2 ? (kKB * kQS) / kOps : GQAW_DMA_EVERY;
+            static_assert(kEvery <= 0 || kEvery * kOps <= kKB * kQS, "every operation of a tile is issued inside its QK^T");
             if constexpr (kEvery == 0)
 #pragma unroll
-                for (int i = 0; i < kOps; ++i) issue_op<T>(cx, tl, nslot, i);
+                for (int i = 0; i < kOps; ++i) issue(tl, nslot, i);
             s16x8 af[kRing];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -356,10 +410,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
                 sc[step % kKB] = mfma16<BF16>(af[step % kRing], qf[step / kKB], sc[step % kKB]);
                 if constexpr (kEvery > 0)
-                    if (step % kEvery == kEvery - 1 && step / kEvery < kOps) issue_op<T>(cx, tl, nslot, step / kEvery);
+                    if (step % kEvery == kEvery - 1 && step / kEvery < kOps) issue(tl, nslot, step / kEvery);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        GQAW_TICK(1);
         // lane (h16, g) holds head h16, keys 16 kb + 4 g + i.  Only the tile that crosses seq_len needs the mask.
         if ((t + 1) * kT > seq_len) {
             const int kbase = t * kT + 4 * g;
@@ -403,11 +458,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         s16x8 av[kKB];
 #pragma unroll
         for (int kk = 0; kk < kKB; ++kk) av[kk] = v_frag(slot_tag, kk);
+        if constexpr (GQAW_DMA_EVERY == -1)
+#pragma unroll
+            for (int i = 0; i < kOps; ++i) issue(tl, nslot, i);
 #pragma unroll
         for (int kp = 0; kp < kKB / 2; ++kp) l_run += esum[kp];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GQAW_TICK(2);
         asm volatile("s_barrier" ::: "memory");                   // barrier B: P^T(t), alpha, moved complete
+        GQAW_TICK(3);
         pv_and_next_id(t, av);
+        GQAW_TICK(4);
     };
     if (!wave_active) {
 #pragma unroll
@@ -426,6 +487,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         ++t;
     }
+#ifdef GQAW_STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        for (int i = 0; i < 5; ++i) g_gqaw_phase[blockIdx.x][wave][i] = (float)((volatile uint32_t *)(lds + G::kLds))[wave * 8 + i] / (float)max(1, t_end - t_begin);
+        g_gqaw_phase[blockIdx.x][wave][5] = (float)(__builtin_amdgcn_s_memtime() - clk0_);
+        g_gqaw_phase[blockIdx.x][wave][6] = (float)(__builtin_amdgcn_s_memrealtime() - rt0_);
+        g_gqaw_phase[blockIdx.x][wave][7] = (float)(t_end - t_begin);
+    }
+#endif
     l_run = sum_over_rows(l_run);                               // the four key groups of a head
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // fills issued past the last tile
     __syncthreads();
@@ -481,6 +550,12 @@ bool applies(int group, int lk, int lv, int page_size, int64_t k_sblk, int64_t k
            page_size >= kTile && fits(k_sblk, 40) && fits(v_sblk, 40) && fits(k_srow, 31) && fits(v_srow, 31);
 }
 
+#ifdef GQAW_STAMPS
+extern "C" int mi_gqaw_phases(void *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gqaw_phase), sizeof(float) * 256 * 8 * 8); }
+#define GQAW_LDS_EXTRA 256
+#else
+#define GQAW_LDS_EXTRA 0
+#endif
 static bool is_view(const Params &p) { return p.v == p.k && p.v_sblk == p.k_sblk && p.v_srow == p.k_srow && p.v_sh == p.k_sh && p.lv <= p.lk; }
 // keys per tile of the instance that serves `p` (the unit of its work list): 64 when V is a column prefix of K and a page holds a tile
 int tile_keys(const Params &p)
@@ -493,22 +568,29 @@ void launch(const Params &p, int dtype, long long units, hipStream_t st)
 {
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
-#define MI_GQAW_ATTR(B, V, T) (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<B, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<T>::kLds)
+#define MI_GQAW_ATTR(B, V, T) (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<B, V, T>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<T>::kLds + GQAW_LDS_EXTRA)
         MI_GQAW_ATTR(true, false, 32); MI_GQAW_ATTR(false, false, 32); MI_GQAW_ATTR(true, true, 32); MI_GQAW_ATTR(false, true, 32);
         MI_GQAW_ATTR(true, true, 64); MI_GQAW_ATTR(false, true, 64);
+        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<true, true, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::kLds + GQAW_LDS_EXTRA);
+        (void)hipFuncSetAttribute((const void *)gqa_decode_wide_kernel<false, true, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<64>::kLds + GQAW_LDS_EXTRA);
 #undef MI_GQAW_ATTR
     }
     const int head_blocks = (p.group + 127) / 128;
     dim3 grid((unsigned)(((units + 7) / 8) * 8 * head_blocks));
     const bool view = is_view(p);
     const int tile = tile_keys(p);
-#define MI_GQAW_LAUNCH(B, V, T) gqa_decode_wide_kernel<B, V, T><<<grid, 512, Geo<T>::kLds, st>>>(p)
+    // linear fill of the 64-key view form: full-width K rows whose in-tile byte offsets fit the 32-bit lane offset (MI_GQA_WIDE_PACK=0: row form)
+    static const bool allow_pack = !(getenv("MI_GQA_WIDE_PACK") && atoi(getenv("MI_GQA_WIDE_PACK")) == 0);
+    const bool pack = allow_pack && tile == 64 && p.lk == kDKP && p.k_srow * 2 * 64 < (1ll << 31);
+#define MI_GQAW_LAUNCH(B, V, T) gqa_decode_wide_kernel<B, V, T><<<grid, 512, Geo<T>::kLds + GQAW_LDS_EXTRA, st>>>(p)
     if (dtype == MI_DTYPE_BF16) {
-        if (tile == 64) MI_GQAW_LAUNCH(true, true, 64);
+        if (tile == 64 && pack) gqa_decode_wide_kernel<true, true, 64, true><<<grid, 512, Geo<64>::kLds + GQAW_LDS_EXTRA, st>>>(p);
+        else if (tile == 64) MI_GQAW_LAUNCH(true, true, 64);
         else if (view) MI_GQAW_LAUNCH(true, true, 32);
         else MI_GQAW_LAUNCH(true, false, 32);
     } else {
-        if (tile == 64) MI_GQAW_LAUNCH(false, true, 64);
+        if (tile == 64 && pack) gqa_decode_wide_kernel<false, true, 64, true><<<grid, 512, Geo<64>::kLds + GQAW_LDS_EXTRA, st>>>(p);
+        else if (tile == 64) MI_GQAW_LAUNCH(false, true, 64);
         else if (view) MI_GQAW_LAUNCH(false, true, 32);
         else MI_GQAW_LAUNCH(false, false, 32);
     }
