@@ -112,6 +112,12 @@ int mi_mla_decode(const void *q, const void *k_nope, const void *k_rope, void *o
  * num_splits as for mi_mla_decode. */
 size_t mi_gqa_decode_workspace(int batch, int q_heads, int v_dim, int num_splits);
 int mi_gqa_decode_num_splits(int batch, int q_heads, int kv_heads, int max_seq_len);
+/* Large kv groups (65..128 query heads per kv head, head dims <= (288, 256): the kernel of gqa_decode_wide.hip): sequences cut in exactly TWO
+ * pieces (num_splits = 2, or by the work list) finish between their two workgroups as in mi_mla_decode_set_pair -- same sums in the same
+ * order as the merge kernel, bit-identical outputs; the meeting words live in the workspace mi_gqa_decode_workspace() sizes.  mode 0 / 1 =
+ * off / on for the calls that follow, -1 = default (on; MI_GQA_PAIR=0 in the environment turns it off), 2 = on with the second piece
+ * withholding its word (a test of the bounded wait and the merge kernel's take-over).  Process-wide knob. */
+int mi_gqa_decode_set_pair(int mode);
 int mi_gqa_decode(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
                   const int32_t *block_table, int batch, int q_heads, int kv_heads, int k_dim, int v_dim, int page_size,
                   int bt_stride, int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_blk,

@@ -87,6 +87,10 @@ struct GqaParams {
     // round 4: the length-aware work list of decode_plan.h (null = uniform num_splits): unit = item, its tile range and piece index come from
     // the list, its partial lives at slot (item, head of the group)
     const int32_t *plan;
+    // two-piece sequences finished by their own workgroups (gqa_decode_wide.hip): the merge kernel re-arms the meeting words, returns at once
+    // when need_merge does not carry this launch's tag, and skips heads whose finishing piece marked its sum (sign bit); null = plain merge
+    uint64_t *pair_flags = nullptr, *need_merge = nullptr;
+    uint64_t pair_tag = 0;
 };
 __device__ __forceinline__ float gqa_sink_l2(const GqaParams &p, int head)      // the sink logit in the kernel's log2 domain (NOT scaled by sm_scale)
 {
@@ -383,6 +387,11 @@ __global__ __launch_bounds__(256) void gqa_merge_kernel(GqaParams p, int dvp)
     const int64_t bh = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (bh >= (int64_t)p.batch * p.q_heads) return;
     const int b = (int)(bh / p.q_heads), h = (int)(bh % p.q_heads);
+    // the meeting words of the sequence's two pieces (gqa_decode_wide.hip) are re-armed here, behind the launch that used them: the next
+    // call -- or the next replay of a captured one, which carries the same tag -- finds them clear
+    if (p.pair_flags && h % p.group == 0 && lane < 2) p.pair_flags[((int64_t)b * p.kv_heads + h / p.group) * 2 + lane] = 0ull;
+    // every sequence finished in the decode kernel (two pieces each, or one): one load per wave instead of the statistics round trips
+    if (p.need_merge && __hip_atomic_load(p.need_merge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.pair_tag) return;
     // partial s of this head: slot (bh, s), or -- planned form -- slot (item of piece s, head within the group)
     int S = p.num_splits, first = 0;
     if (p.plan) {
@@ -391,14 +400,20 @@ __global__ __launch_bounds__(256) void gqa_merge_kernel(GqaParams p, int dvp)
         if (S == 1) return;                                   // the piece wrote the output row itself
     }
     auto slot = [&](int s) -> int64_t { return p.plan ? (int64_t)(first + s) * p.group + h % p.group : bh * S + s; };
+    // two pieces: piece (head within the group) / 64 finished this head itself if its sum carries the mark (the sign); without the mark
+    // (its partner did not show up in time) both partials of the head are complete in the workspace: merge as usual
+    const bool marks = p.pair_flags != nullptr && S == 2;
+    if (marks && (__float_as_uint(p.ws_ml[slot((h % p.group) >> 6) * 2 + 1]) >> 31)) return;
+    auto sum_of = [&](int s) -> float { const float l = p.ws_ml[slot(s) * 2 + 1]; return marks ? fabsf(l) : l; };
     float M = -INFINITY;
     for (int s = 0; s < S; ++s) M = fmaxf(M, p.ws_ml[slot(s) * 2]);
     const float sk = p.sinks ? gqa_sink_l2(p, h) : -INFINITY;
     M = fmaxf(M, sk);
     float L = p.sinks ? __builtin_amdgcn_exp2f(sk - M) : 0.f;
+    // (explicit fused multiply-adds: gqa_decode_wide.hip's pair finish forms the same sums in the same order and must round the same way)
     for (int s = 0; s < S; ++s) {
-        const float *ml = p.ws_ml + slot(s) * 2;
-        if (ml[0] != -INFINITY) L += __builtin_amdgcn_exp2f(ml[0] - M) * ml[1];
+        const float m = p.ws_ml[slot(s) * 2];
+        if (m != -INFINITY) L = __builtin_fmaf(__builtin_amdgcn_exp2f(m - M), sum_of(s), L);
     }
     const float inv = L > 0.f ? 1.f / L : 0.f;
     uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)h * p.o_sh;
@@ -408,7 +423,9 @@ __global__ __launch_bounds__(256) void gqa_merge_kernel(GqaParams p, int dvp)
             const float m = p.ws_ml[slot(s) * 2];
             if (m == -INFINITY) continue;
             const float w = __builtin_amdgcn_exp2f(m - M);
-            o += w * *(const f32x4 *)(p.ws_o + slot(s) * dvp + d);
+            const f32x4 a = *(const f32x4 *)(p.ws_o + slot(s) * dvp + d);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(w, a[i], o[i]);
         }
         *(uint2 *)(orow + d) = uint2{pack2<BF16>(o[0] * inv, o[1] * inv), pack2<BF16>(o[2] * inv, o[3] * inv)};
     }
@@ -511,6 +528,14 @@ extern "C" int mi_gqa_decode_num_splits(int batch, int q_heads, int kv_heads, in
     return s < 1 ? 1 : s;
 }
 
+static int g_gqa_pair_mode = -1;    // -1 = environment / default (on); 0 = off, 1 = on, 2 = on with piece 1 withholding its word (tests)
+extern "C" int mi_gqa_decode_set_pair(int mode)
+{
+    if (mode < -1 || mode > 2) return MI_SGL_EINVAL;
+    g_gqa_pair_mode = mode;
+    return MI_SGL_OK;
+}
+
 static int gqa_decode_impl(const void *q, const void *k, const void *v, void *out, const int32_t *kv_seq_lens,
                              const int32_t *block_table, int batch, int q_heads, int kv_heads, int k_dim, int v_dim, int page_size,
                              int bt_stride, int max_seq_len, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_blk,
@@ -576,9 +601,28 @@ static int gqa_decode_impl(const void *q, const void *k, const void *v, void *ou
             w.num_splits = num_splits = 1;
             units = mi_sgl::plan_items_max((long long)batch * kv_heads, workers);
         }
+        // Two-piece sequences finish between their two workgroups (gqa_wide.h): the meeting words live behind the partial area / the work list,
+        // inside what mi_gqa_decode_workspace() sizes for 512-float rows (this kernel's are 256); tagged per call, re-armed by the merge kernel
+        w.pair_flags = nullptr, w.need_merge = nullptr, w.pair_tag = 0, w.pair_withhold = 0;
+        static const bool pair_env = !(getenv("MI_GQA_PAIR") && atoi(getenv("MI_GQA_PAIR")) == 0);
+        const bool pair_on = g_gqa_pair_mode < 0 ? pair_env : g_gqa_pair_mode != 0;
+        if (pair_on && head_blocks == 1 && (planned || num_splits == 2)) {
+            const char *area = planned ? (const char *)(w.plan + gqa_plan_words_cap(batch, q_heads))
+                                       : (const char *)(w.ws_ml + (size_t)batch * q_heads * num_splits * 2);
+            uint64_t *flags = (uint64_t *)(((uintptr_t)area + 7) & ~(uintptr_t)7);
+            const size_t words = 2 * (size_t)batch * kv_heads + 1;
+            if ((const char *)(flags + words) <= (const char *)workspace + workspace_bytes) {
+                static uint32_t epoch = 0;
+                const uint32_t e = ++epoch ? epoch : ++epoch;
+                w.pair_flags = flags, w.need_merge = flags + (words - 1);
+                w.pair_tag = ((uint64_t)e * 0x9E3779B97F4A7C15ull) | 1ull;      // never 0
+                w.pair_withhold = g_gqa_pair_mode == 2;
+            }
+        }
         mi_gqa_wide::launch(w, dtype, units, st);
         if (num_splits > 1 || planned) {
             GqaParams m{};                                       // the merge kernel reads the partial layout the wide kernel wrote (row = kDVP floats)
+            m.pair_flags = w.pair_flags, m.need_merge = w.need_merge, m.pair_tag = w.pair_tag;
             m.out = (uint16_t *)out, m.ws_o = w.ws_o, m.ws_ml = w.ws_ml, m.batch = batch, m.q_heads = q_heads, m.kv_heads = kv_heads;
             m.group = w.group, m.num_splits = num_splits, m.lv = v_dim, m.o_sb = o_stride_b, m.o_sh = o_stride_h, m.plan = w.plan;
             m.sinks = nullptr, m.window = -1, m.bt_rows = nullptr;

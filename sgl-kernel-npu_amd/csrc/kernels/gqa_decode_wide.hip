@@ -117,6 +117,24 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v)
     asm volatile("" : "+v"(v));
     return v;
 }
+// rows handed to the partner workgroup of a two-piece sequence: write-through stores (visible device-wide behind a vmcnt drain, no release
+// fence), read back with loads served past the CU's L1 (no acquire); the compiler does not count these loads: ONE wait names every destination
+__device__ __forceinline__ void st_sc1_x4(float *ptr, f32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 ld_sc1_x4(const float *ptr)
+{
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld_sc1_wait(f32x4 (&r)[8])
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+}
+__device__ __forceinline__ void st_agent_f32(float *ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent_f32(const float *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct Ctx {
     const Params *p;
@@ -507,35 +525,174 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         lmb[128 + wave * 16 + h16] = wave_active ? m_ref : -INFINITY;
     }
     __syncthreads();
-    const int dbase = (wave >> 2) * 128 + (wave & 3) * 16 + 4 * kg;
+    // the lane's roles are derived AGAIN from a thread id the optimiser cannot match with the prologue's: otherwise 4 kg and friends are kept in
+    // vector registers across the tile loop, which runs at the register limit (the pair finish below cost two spills inside the loop)
+    uint32_t tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, c32_e = tid_e & 31, kg_e = (tid_e >> 5) & 1;
+    const int dbase = (wave >> 2) * 128 + (wave & 3) * 16 + 4 * kg_e;
+    // the pair words are read from the kernel argument segment HERE (an address the optimiser cannot see through): fetched with the other
+    // arguments in the prologue they stay in scalar registers for the whole tile loop, which has none to spare (spills into the loop)
+    const __attribute__((address_space(4))) Params *kp = (const __attribute__((address_space(4))) Params *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    uint64_t *const pair_flags = kp->pair_flags, *const need_merge = kp->need_merge;
+    const uint64_t pair_tag = kp->pair_tag;
+    const bool pair = pair_flags != nullptr && nsplits == 2 && head_blocks == 1;
+    // partial row of (head of the group, piece): the work list's items of a sequence are consecutive, piece k at first + k
+    auto prow = [&](int hgx, int s) -> int64_t {
+        return p.plan ? (int64_t)(unit - split + s) * p.group + hgx : ((int64_t)b * p.q_heads + kvh * p.group + hgx) * nsplits + s;
+    };
+    auto leave_to_merge_kernel = [&]() {
+        if (tid_e == 0 && need_merge) __hip_atomic_store(need_merge, pair_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (!pair) {
+        if (nsplits > 1) leave_to_merge_kernel();
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+            const int hgx = hblk * 128 + hb * 32 + c32_e;
+            if (hgx >= p.group) continue;
+            const int headx = kvh * p.group + hgx;
+            if (nsplits == 1) {
+                const float l_h = lmb[hb * 32 + c32_e];
+                const float inv = l_h > 0.f ? 1.f / l_h : 0.f;
+                uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
+                    if (d >= p.lv) continue;                   // lv % 8 == 0: the 4 dims are in or out together
+                    *(uint2 *)(orow + d) = uint2{pack2<BF16>(acc[hb][4 * rq + 0] * inv, acc[hb][4 * rq + 1] * inv),
+                                                pack2<BF16>(acc[hb][4 * rq + 2] * inv, acc[hb][4 * rq + 3] * inv)};
+                }
+            } else {
+                const int64_t idx = p.plan ? (int64_t)unit * p.group + hgx : ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
+                float *po = p.ws_o + idx * kDVP;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
+                    *(f32x4 *)(po + d) = f32x4{acc[hb][4 * rq + 0], acc[hb][4 * rq + 1], acc[hb][4 * rq + 2], acc[hb][4 * rq + 3]};
+                }
+                if (wave == 0 && kg_e == 0) {
+                    p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + c32_e];
+                    p.ws_ml[idx * 2 + 1] = lmb[hb * 32 + c32_e];
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- the pair: a sequence in exactly two pieces (BASELINE-shaped batches: 128 sequences on 256 CUs).  Piece s finishes heads 64 s ..
+    // 64 s + 63 of the group.  Export (all eight waves: every wave holds 32 dims of every head): the partner's heads, written through, and the
+    // statistics of all heads.  "My rows are visible" -> the partner's word (bounded wait) -> own heads = w0 a0 + w1 a1 in piece order, exactly
+    // gqa_merge_kernel's sums, from the own accumulators and the partner's rows.  A partner that does not show up in time (not resident: more
+    // items than the chip runs at once) costs nothing but the wait: this workgroup then writes the rows of its own heads as well and leaves
+    // them unmarked -- both partials of those heads are in the workspace, and the merge kernel, which skips only marked heads, does the work.
+    const int piece = split;
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int hgx = r * 64 + lane_e;
+            if (hgx < p.group) {
+                st_agent_f32(p.ws_ml + prow(hgx, piece) * 2 + 0, lmb[128 + hgx]);
+                st_agent_f32(p.ws_ml + prow(hgx, piece) * 2 + 1, lmb[hgx]);
+            }
+        }
+    }
+    auto rows_out = [&](int first_hb, bool through) {           // head blocks first_hb, first_hb + 1 (wave-uniform) of this piece's partial
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+            if ((hb >> 1) != (first_hb >> 1)) continue;
+            const int hgx = hb * 32 + c32_e;
+            if (hgx >= p.group) continue;
+            float *po = p.ws_o + prow(hgx, piece) * kDVP;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
+                const f32x4 v = f32x4{acc[hb][4 * rq + 0], acc[hb][4 * rq + 1], acc[hb][4 * rq + 2], acc[hb][4 * rq + 3]};
+                if (through) st_sc1_x4(po + d, v);
+                else *(f32x4 *)(po + d) = v;
+            }
+        }
+    };
+    rows_out(2 * (piece ^ 1), true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave: its write-through stores have left
+    __syncthreads();
+    uint32_t *const ok_word = (uint32_t *)(lmb + 256);
+    const int64_t fbase = ((int64_t)b * p.kv_heads + kvh) * 2;
+    if (tid_e == 0) {
+        if (!(kp->pair_withhold && piece == 1))
+            __hip_atomic_store(pair_flags + fbase + piece, pair_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        uint32_t ok = 1;
+        while (__hip_atomic_load(pair_flags + fbase + (piece ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pair_tag) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000ull) {      // 200 us at 100 MHz
+                ok = 0;
+                break;
+            }
+        }
+        *ok_word = ok;
+    }
+    __syncthreads();
+    if (*(volatile uint32_t *)ok_word == 0) {
+        leave_to_merge_kernel();
+        rows_out(2 * piece, false);
+        return;
+    }
+    // "this piece finishes its heads": the sign of their sums (nobody reads those words before the merge kernel)
+    if (wave == 0) {
+        const int hgx = piece * 64 + lane_e;
+        if (hgx < p.group) st_agent_f32(p.ws_ml + prow(hgx, piece) * 2 + 1, -lmb[hgx]);
+    }
+    // the partner's statistics and rows of this lane_e's two heads (head block 2 piece + j, head c32_e), everything in flight before the first use
+    float m_par[2], l_par[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int hgx = min(piece * 64 + j * 32 + c32_e, p.group - 1);
+        m_par[j] = ld_agent_f32(p.ws_ml + prow(hgx, piece ^ 1) * 2 + 0);
+        l_par[j] = ld_agent_f32(p.ws_ml + prow(hgx, piece ^ 1) * 2 + 1);
+    }
+    f32x4 pr[8];                                                // [j][rq]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int hgx = min(piece * 64 + j * 32 + c32_e, p.group - 1);
+        const float *src = p.ws_o + prow(hgx, piece ^ 1) * kDVP;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) pr[j * 4 + rq] = ld_sc1_x4(src + dbase + (rq >> 1) * 64 + (rq & 1) * 8);
+    }
+    ld_sc1_wait(pr);
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
-        const int hgx = hblk * 128 + hb * 32 + c32;
+        if ((hb >> 1) != piece) continue;
+        const int j = hb & 1;
+        const int hgx = hb * 32 + c32_e;
         if (hgx >= p.group) continue;
-        const int headx = kvh * p.group + hgx;
-        if (nsplits == 1) {
-            const float l_h = lmb[hb * 32 + c32];
-            const float inv = l_h > 0.f ? 1.f / l_h : 0.f;
-            uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)headx * p.o_sh;
+        const float m_own = lmb[128 + hgx], l_own = lmb[hgx];
+        const float m0 = piece == 0 ? m_own : m_par[j], m1 = piece == 0 ? m_par[j] : m_own;
+        const float l0 = piece == 0 ? l_own : l_par[j], l1 = piece == 0 ? l_par[j] : l_own;
+        // gqa_merge_kernel's arithmetic for two pieces, operation by operation
+        float M = -INFINITY;
+        M = fmaxf(M, m0);
+        M = fmaxf(M, m1);
+        const float w0 = __builtin_amdgcn_exp2f(m0 - M), w1 = __builtin_amdgcn_exp2f(m1 - M);
+        float L = 0.f;
+        if (m0 != -INFINITY) L = __builtin_fmaf(w0, l0, L);
+        if (m1 != -INFINITY) L = __builtin_fmaf(w1, l1, L);
+        const float inv = L > 0.f ? 1.f / L : 0.f;
+        uint16_t *orow = p.out + (int64_t)b * p.o_sb + (int64_t)(kvh * p.group + hgx) * p.o_sh;
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
-                if (d >= p.lv) continue;                       // lv % 8 == 0: the 4 dims are in or out together
-                *(uint2 *)(orow + d) = uint2{pack2<BF16>(acc[hb][4 * rq + 0] * inv, acc[hb][4 * rq + 1] * inv),
-                                            pack2<BF16>(acc[hb][4 * rq + 2] * inv, acc[hb][4 * rq + 3] * inv)};
-            }
-        } else {
-            const int64_t idx = p.plan ? (int64_t)unit * p.group + hgx : ((int64_t)b * p.q_heads + headx) * p.num_splits + split;
-            float *po = p.ws_o + idx * kDVP;
+        for (int rq = 0; rq < 4; ++rq) {
+            const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
+            if (d >= p.lv) continue;
+            float o[4];
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int d = dbase + (rq >> 1) * 64 + (rq & 1) * 8;
-                *(f32x4 *)(po + d) = f32x4{acc[hb][4 * rq + 0], acc[hb][4 * rq + 1], acc[hb][4 * rq + 2], acc[hb][4 * rq + 3]};
+            for (int i = 0; i < 4; ++i) {
+                const float own = acc[hb][4 * rq + i], par = pr[j * 4 + rq][i];
+                const float a0 = piece == 0 ? own : par, a1 = piece == 0 ? par : own;
+                o[i] = 0.f;
+                if (m0 != -INFINITY) o[i] = __builtin_fmaf(w0, a0, o[i]);
+                if (m1 != -INFINITY) o[i] = __builtin_fmaf(w1, a1, o[i]);
             }
-            if (wave == 0 && kg == 0) {
-                p.ws_ml[idx * 2 + 0] = lmb[128 + hb * 32 + c32];
-                p.ws_ml[idx * 2 + 1] = lmb[hb * 32 + c32];
-            }
+            *(uint2 *)(orow + d) = uint2{pack2<BF16>(o[0] * inv, o[1] * inv), pack2<BF16>(o[2] * inv, o[3] * inv)};
         }
     }
 }

@@ -19,6 +19,13 @@ struct Params {
     int64_t q_sb, q_sh, k_sblk, k_srow, k_sh, v_sblk, v_srow, v_sh, o_sb, o_sh;
     float sm_scale;
     const int32_t *plan;          // decode_plan.h work list in tiles of tile_keys() keys; null = uniform num_splits
+    // Sequences in exactly TWO pieces finish between their two workgroups (as in mla_decode_wide8s.hip): piece s exports the rows of the
+    // other piece's heads (64 .. 127 | 0 .. 63) written through, posts pair_tag in pair_flags[2 (b kv_heads + kvh) + s], waits (bounded) for
+    // the partner's word and writes the outputs of its own 64 heads -- the merge kernel's sums in the merge kernel's order.  need_merge
+    // (one word) receives pair_tag whenever a workgroup leaves partials for the merge launch.  null = every piece leaves its partials.
+    uint64_t *pair_flags, *need_merge;
+    uint64_t pair_tag;
+    int pair_withhold;            // tests: piece 1 keeps its word back, piece 0 runs into the bounded wait
 };
 
 // applies to: 64 < group, lk <= 288, lv <= 256 (multiples of 8), power-of-two pages of >= 32 keys, row strides whose in-page offsets fit 32 bits

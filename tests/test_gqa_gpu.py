@@ -388,3 +388,113 @@ def test_wide_kernel_full_size_vs_fp32(view):
             V = v[idx, :, 0].reshape(-1, Dv)[:L].float()
             ref = torch.softmax((q[b].float() @ K.T) * D ** -0.5, -1) @ V
             assert torch.allclose(got[b].float(), ref, atol=1e-3, rtol=2 ** -7), (splits, b, (got[b].float() - ref).abs().max())
+
+
+def _wide_pair_inputs(B, Hq, Lk, Lv, S, page, dtype, ragged, view, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    maxp = (S + page - 1) // page
+    nb = B * maxp
+    q = torch.randn((B, Hq, Lk), generator=g, device="cuda").to(dtype)
+    k = (torch.randn((nb, page, 1, Lk), generator=g, device="cuda") * 0.7).to(dtype)
+    v = k[..., :Lv] if view else (torch.randn((nb, page, 1, Lv), generator=g, device="cuda") * 0.7).to(dtype)
+    bt = torch.randperm(nb, generator=g, device="cuda").to(torch.int32).reshape(B, maxp)
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    if ragged:
+        lens = torch.randint(1, S + 1, (B,), generator=g, device="cuda").to(torch.int32)
+    return q, k, v, lens, bt
+
+
+def _run_gqa_ws(q, k, v, lens, bt, sm, splits, max_len, ws=None):
+    B, Hq, Lk = q.shape
+    Hkv, Lv = k.shape[2], v.shape[3]
+    L = lib()
+    if ws is None:
+        ws = torch.empty(max(L.mi_gqa_decode_workspace(B, Hq, Lv, splits), 16), dtype=torch.uint8, device=q.device)
+    out = torch.full((B, Hq, Lv), float("nan"), dtype=q.dtype, device=q.device)
+    rc = L.mi_gqa_decode(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lens), ptr(bt), B, Hq, Hkv, Lk, Lv, k.shape[1], bt.stride(0), max_len,
+                         q.stride(0), q.stride(1), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1), v.stride(2),
+                         out.stride(0), out.stride(1), sm, 0 if q.dtype == torch.bfloat16 else 1, splits, ptr(ws), ws.numel(), stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return out, ws
+
+
+# B, Hq, Lk, Lv, S, page, dtype, ragged, view, num_splits -- batches the uniform form (num_splits = 2: what the library picks for the reference
+# shape at batch 128) or the work list cuts into two pieces per sequence: the reference test's shape at a quarter of its length, a ragged
+# copy (lists with sequences of one, two and three pieces side by side), a partly filled second head half in fp16 with V a cache of its own and
+# 32-key pages, narrower head dims, and more workgroups than CUs (a piece may meet a partner that is not resident yet: the bounded wait, then the
+# merge kernel -- or simply a late partner)
+WIDE_PAIR_CASES = [(128, 128, 288, 256, 1024, 64, torch.bfloat16, False, True, 2), (128, 128, 288, 256, 1500, 64, torch.bfloat16, True, True, 2),
+                   (128, 128, 288, 256, 1500, 64, torch.bfloat16, True, True, PLANNED), (100, 96, 288, 256, 700, 32, torch.float16, True, False, PLANNED),
+                   (7, 72, 256, 192, 900, 128, torch.float16, True, False, 2), (200, 128, 288, 256, 700, 64, torch.bfloat16, True, True, 2),
+                   (200, 128, 288, 256, 1100, 64, torch.float16, True, True, PLANNED)]
+
+
+@pytest.mark.parametrize("B,Hq,Lk,Lv,S,page,dtype,ragged,view,splits", WIDE_PAIR_CASES)
+def test_wide_kernel_two_piece_sequences_finish_between_their_workgroups(B, Hq, Lk, Lv, S, page, dtype, ragged, view, splits):
+    """Sequences in two pieces finish inside gqa_decode_wide.hip (each workgroup: 64 of the group's heads) with the merge kernel's sums in the
+    merge kernel's order: the outputs are THE BITS of the run with the pair finish off -- also when the second piece withholds its word and the
+    first runs into its bounded wait (mode 2: the merge kernel does the work), and over repeated calls on one workspace (the meeting words are
+    re-armed by the merge kernel)."""
+    L = lib()
+    L.mi_gqa_decode_set_pair.argtypes = [c_int]
+    q, k, v, lens, bt = _wide_pair_inputs(B, Hq, Lk, Lv, S, page, dtype, ragged, view, 5)
+    sm = Lk ** -0.5
+    try:
+        assert L.mi_gqa_decode_set_pair(0) == 0
+        want, _ = _run_gqa_ws(q, k, v, lens, bt, sm, splits, S)
+        assert not torch.isnan(want.float()).any()
+        assert L.mi_gqa_decode_set_pair(1) == 0
+        got, ws = _run_gqa_ws(q, k, v, lens, bt, sm, splits, S)
+        assert torch.equal(got, want), (got.float() - want.float()).abs().max()
+        for rep in range(3):                                   # the same workspace again and again, with other queries in between
+            q2 = (q.float() * (1.0 + 0.25 * rep)).to(dtype)
+            L.mi_gqa_decode_set_pair(0)
+            want2, _ = _run_gqa_ws(q2, k, v, lens, bt, sm, splits, S)
+            L.mi_gqa_decode_set_pair(1)
+            got2, _ = _run_gqa_ws(q2, k, v, lens, bt, sm, splits, S, ws=ws)
+            assert torch.equal(got2, want2), rep
+        assert L.mi_gqa_decode_set_pair(2) == 0
+        got, _ = _run_gqa_ws(q, k, v, lens, bt, sm, splits, S, ws=ws)
+        assert torch.equal(got, want), "bounded wait -> merge kernel"
+        assert L.mi_gqa_decode_set_pair(1) == 0                # the words a timed-out call left behind do not leak into the next one
+        got, _ = _run_gqa_ws(q, k, v, lens, bt, sm, splits, S, ws=ws)
+        assert torch.equal(got, want)
+    finally:
+        L.mi_gqa_decode_set_pair(-1)
+
+
+def test_wide_kernel_pair_finish_in_a_replayed_graph():
+    """The pair finish of gqa_decode_wide.hip inside a captured graph: every replay carries the same tag, the meeting words are re-armed by the
+    merge kernel of the replay before -- outputs follow the inputs written between replays, bit for bit the eager result with the finish off."""
+    import sgl_kernel_npu.attention.decode_attention  # noqa: F401  (registers torch.ops.npu.decode_gqa)
+    L = lib()
+    L.mi_gqa_decode_set_pair.argtypes = [c_int]
+    B, Hq, D, Dv, S, page = 128, 128, 288, 256, 1024, 64
+    q, k, v, lens, bt = _wide_pair_inputs(B, Hq, D, Dv, S, page, torch.bfloat16, False, True, 11)
+    out = torch.empty((B, Hq, Dv), dtype=torch.bfloat16, device="cuda")
+    try:
+        L.mi_gqa_decode_set_pair(1)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            torch.ops.npu.decode_gqa(q, k, v, out, lens, D ** -0.5, page, bt, 0)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            torch.ops.npu.decode_gqa(q, k, v, out, lens, D ** -0.5, page, bt, 0)
+        for rep in range(4):
+            q.copy_((torch.randn(q.shape, device="cuda") * (1 + rep)).to(torch.bfloat16))
+            out.fill_(7.0)
+            graph.replay()
+            torch.cuda.synchronize()
+            got = out.clone()
+            L.mi_gqa_decode_set_pair(0)
+            want = torch.empty_like(out)
+            torch.ops.npu.decode_gqa(q, k, v, want, lens, D ** -0.5, page, bt, 0)
+            torch.cuda.synchronize()
+            L.mi_gqa_decode_set_pair(1)
+            assert torch.equal(got, want), rep
+    finally:
+        L.mi_gqa_decode_set_pair(-1)
