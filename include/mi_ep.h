@@ -56,10 +56,14 @@ extern "C" {
 #define MI_EP_MAX_TOPK 16
 #define MI_EP_MAX_HIDDEN 8192 /* reference limit, cam_moe_dispatch_normal_tiling.cc:75-87 */
 #define MI_EP_ROW_META_BYTES 16 /* {f32 scale, i32 token, i32 k, i32 src_rank} appended to every staged row */
+/* distance between staged rows: payload + meta rounded up to whole 128-byte lines, so that every row starts on a line (the grouped GEMM of
+ * fused_deep_moe reads staged rows in place, 128 bytes of K per request: rows 7184 bytes apart cost it 5 %, mi_ep_moe_gemm1_swiglu_rows) */
+#define MI_EP_ROW_STRIDE(payload_bytes) ((((size_t)(payload_bytes)) + MI_EP_ROW_META_BYTES + 127) & ~(size_t)127)
 
 #define MI_EP_OK 0
 #define MI_EP_EINVAL (-1)
 #define MI_EP_ELAUNCH (-2)
+#define MI_EP_ESIZE (-3)        /* a layout does not fit an addressing limit of the kernel asked for; the caller takes the general path */
 
 /* payload modes of the dispatch kernels */
 #define MI_EP_QUANT_NONE 0      /* bf16 rows */
@@ -72,7 +76,7 @@ extern "C" {
 /* library / build identification ("gfx950") */
 const char *mi_ep_version(void);
 
-/* bytes of one staged dispatch row: hidden * (1 or 2) + MI_EP_ROW_META_BYTES */
+/* distance between staged dispatch rows: MI_EP_ROW_STRIDE(hidden * (1 or 2)); the meta words sit right behind the payload */
 size_t mi_ep_dispatch_row_bytes(int hidden, int quant_mode);
 /* bytes of one combine slot row: hidden * 2 rounded up to 16 */
 size_t mi_ep_combine_row_bytes(int hidden);
@@ -204,7 +208,7 @@ int mi_ep_dispatch_pull(const void *const *src_base_host, const int32_t *recv_co
  * quantised and written ONCE -- row t of `region` = payload | {scale, t, 0, my_rank} -- instead of once per (t, k); the
  * expert-sorted order travels as an index of K * 8 bytes per token: entry send_data_offset[e] + send_token_idx_small[t,k]
  * = {t, k} (u32 pairs) at byte mi_ep_dispatch_index_offset(...) of the region.  Staging writes T*(H+16) + T*K*8 bytes
- * instead of T*K*(H+16); the received rows, scales and (src, t, k) triples are identical to stage + pull
+ * instead of T*K*(H+16) (rows MI_EP_ROW_STRIDE apart); the received rows, scales and (src, t, k) triples are identical to stage + pull
  * (reference contract: cam_moe_dispatch_normal.h:717-760).  `region_bytes` (the same on every rank) fixes the index offset
  * and the token capacity, index_offset / row_bytes; stage_compact returns MI_EP_EINVAL when T exceeds it.
  * pull_indexed: row r of segment i = (le, src), position j, is token row index[pull_offset[i] + j].t of src_base[src]. */
@@ -218,6 +222,15 @@ int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, const int32_t 
                                 size_t region_bytes, void *recv_x, float *recv_x_scales, int32_t *recv_src_idx,
                                 const uint64_t *epoch_ctr, size_t parity_stride /* consume side: half *epoch_ctr & 1 */,
                                 int skip_src /* -1, or a source rank whose rows mi_ep_dispatch_pull_local writes */, void *stream);
+/* pull_indexed without the copy (fused_deep_moe, prefill sizes): for every receive row r < rows_cap the byte offset of its STAGED row from
+ * *a_base_out (the lowest source base; the ping-pong half is inside the offset), its scale and its (src, t, k) triple -- what
+ * mi_ep_moe_gemm1_swiglu_rows multiplies in place.  All sources must be local memory (push transport, or num_ranks == 1); MI_EP_ESIZE when
+ * a staged row could lie 4 GiB or more above the lowest base (the caller then gathers with pull_local / pull_indexed as before).
+ * Reference: the MIX kernel multiplies rows where the dispatch left them, csrc/deepep/ops/op_kernel/fused_deep_moe.h:336-427. */
+int mi_ep_dispatch_resolve_rows(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset, int num_ranks,
+                                int num_local_experts, int hidden, int num_topk, int quant_mode, int rows_cap, size_t region_bytes,
+                                const void **a_base_out, uint32_t *row_offsets, float *recv_x_scales, int32_t *recv_src_idx,
+                                const uint64_t *epoch_ctr, size_t parity_stride /* consume side: half *epoch_ctr & 1 */, void *stream);
 /* The rows whose token lives on this rank, token by token: the staged row of token t (`my_rows` = the own region for the pull
  * transport, the own source slab for push; half 0) is read once and stored to each selection (t, k) served by this rank's experts,
  * at output row recv_count[le * W + me] - num_tokens_per_expert[me * L + le] + send_token_idx_small[t, k] -- the rows, scales and
@@ -369,6 +382,12 @@ int mi_ep_ll_post_recv(uint64_t *const *peer_counts_host, const int32_t *num_tok
 int mi_ep_moe_gemm1_swiglu(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale,
                            const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap, int hidden,
                            int two_i, float *out, int rows_per_expert_hint, void *stream);
+/* gemm1_swiglu over rows that were never gathered: row r of the packed order is the `hidden` int8 bytes at a_base + a_row_offsets[r]
+ * (16-byte aligned byte offsets below 4 GiB; rows >= the cumulative total are not read) -- the staged token rows of a dispatch, one per
+ * TOKEN and shared by its K selections, addressed through mi_ep_dispatch_resolve_rows' table.  Same products, same outputs. */
+int mi_ep_moe_gemm1_swiglu_rows(const void *a_base, const uint32_t *a_row_offsets, const float *a_scale, const int8_t *w,
+                                const float *w_scale, const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap,
+                                int hidden, int two_i, float *out, int rows_per_expert_hint, void *stream);
 int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_cap, int inter, int8_t *q, float *scale,
                        void *stream);
 int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,

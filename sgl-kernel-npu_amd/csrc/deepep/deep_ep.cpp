@@ -1086,7 +1086,8 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     // instead of one per (token, k) -- 31 MB instead of 235 MB of staging at 4096 tokens -- and a window of T rows per source
     // instead of L x W x max_tokens slabs (7.5 GB at EP = 8 x 4096 tokens, which no window holds).  Both produce the same packed
     // rows in (local expert, source rank) order, the same triples and the same inclusive counts.
-    at::Tensor rx, rs, src_info, layout_range;
+    at::Tensor rx, rs, src_info, layout_range, a_rows;
+    const void *a_base = nullptr;
     const size_t ll_bytes = (size_t)L * W * MT * mi_ep_dispatch_row_bytes(H, MI_EP_QUANT_INT8_NOEPS);
     if (MT <= 512 && ll_bytes <= region_bytes) {
         std::optional<at::Tensor> none;
@@ -1098,11 +1099,26 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
         const Layout lay = run_layout(ids, E);
         DispatchExchange ex = dispatch_exchange(x, ids, lay, E, MI_EP_QUANT_INT8_NOEPS, false, nullptr, st);
         const int64_t rows_cap = std::max<int64_t>(1, S > 0 && rank < S ? MT * W / S : MT * W * std::min(K_user, L));   // worst case (deep_ep.cpp:866-874)
-        dispatch_pull(ex, H, K, L, MI_EP_QUANT_INT8_NOEPS, rows_cap, x.options(), rx, rs, src_info, st);
+        // GEMM1 multiplies the staged rows WHERE THEY ARE (one row per token, shared by its K selections) when every source is local memory
+        // -- own region at one rank, the source slabs of the own window under the push transport --: a table of row offsets instead of the
+        // K-fold gathered copy.  MI_EP_FUSED_GATHER=0 / set_fused_rows_in_place(false), remote sources (pull transport) or a window wider than 32 bits: gather as before.
+        if (fused_rows_in_place && (ex.push || W == 1)) {
+            a_rows = at::empty({rows_cap}, at::dtype(at::kInt).device(dev));
+            rs = at::empty({rows_cap}, at::dtype(at::kFloat).device(dev));
+            src_info = at::empty({rows_cap * 3}, at::dtype(at::kInt).device(dev));
+            ProfScope ps_(this, "dispatch_resolve_rows", st);
+            const int rc = mi_ep_dispatch_resolve_rows((const void *const *)ex.src_bases.data(), ex.nt.recv_count.data_ptr<int>(),
+                                                       ex.nt.pull_offset.data_ptr<int>(), W, L, H, K, MI_EP_QUANT_INT8_NOEPS, (int)rows_cap,
+                                                       ex.slab_bytes, &a_base, (uint32_t *)a_rows.data_ptr<int>(), rs.data_ptr<float>(),
+                                                       src_info.data_ptr<int>(), epoch_ctr(kDispatch), region_bytes, st);
+            if (rc == MI_EP_ESIZE) a_rows = at::Tensor(), a_base = nullptr;
+            else MI_EP_CHECK(rc);
+        }
+        if (!a_rows.defined()) dispatch_pull(ex, H, K, L, MI_EP_QUANT_INT8_NOEPS, rows_cap, x.options(), rx, rs, src_info, st);
         layout_range = Lw != L ? ex.nt.recv_count.narrow(0, 0, (int64_t)Lw * W) : ex.nt.recv_count;
         real_max_bs = std::max<int64_t>(real_max_bs, MT);
     }
-    const int M = (int)rx.size(0);
+    const int M = (int)(a_rows.defined() ? a_rows.size(0) : rx.size(0));
     at::Tensor v = at::empty({M, I}, at::dtype(at::kFloat).device(dev));
     at::Tensor q2 = at::empty({M, I}, at::dtype(at::kChar).device(dev));
     at::Tensor sc2 = at::empty({M}, at::dtype(at::kFloat).device(dev));
@@ -1111,8 +1127,12 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
     const int rows_hint = S > 0 && rank < S ? std::max(1, T * (W / S))
                                             : (int)std::max<int64_t>(1, (int64_t)T * K_user * W / std::max<int64_t>(1, num_experts));
     { ProfScope ps_(this, "moe_gemm1_swiglu", st);
-      MI_EP_CHECK(mi_ep_moe_gemm1_swiglu((const int8_t *)rx.data_ptr(), rs.data_ptr<float>(), (const int8_t *)w1.data_ptr(),
-                                         s1.data_ptr<float>(), cum, W, Lw, M, H, N1, v.data_ptr<float>(), rows_hint, st)); }
+      if (a_rows.defined())
+          MI_EP_CHECK(mi_ep_moe_gemm1_swiglu_rows(a_base, (const uint32_t *)a_rows.data_ptr<int>(), rs.data_ptr<float>(), (const int8_t *)w1.data_ptr(),
+                                                  s1.data_ptr<float>(), cum, W, Lw, M, H, N1, v.data_ptr<float>(), rows_hint, st));
+      else
+          MI_EP_CHECK(mi_ep_moe_gemm1_swiglu((const int8_t *)rx.data_ptr(), rs.data_ptr<float>(), (const int8_t *)w1.data_ptr(),
+                                             s1.data_ptr<float>(), cum, W, Lw, M, H, N1, v.data_ptr<float>(), rows_hint, st)); }
     { ProfScope ps_(this, "moe_rowquant", st);
       MI_EP_CHECK(mi_ep_moe_rowquant(v.data_ptr<float>(), cum + (Lw * W - 1), M, I, (int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), st)); }
     // GEMM2 writes every bf16 row straight into its owner's combine slot (the push of low_latency_combine fused into the GEMM

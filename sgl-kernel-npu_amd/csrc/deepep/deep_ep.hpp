@@ -42,6 +42,10 @@ public:
     void set_dispatch_transport(const std::string &name);
     void set_local_row_paths(bool dispatch_local, bool combine_local);
     std::vector<bool> get_local_row_paths() const { return {dispatch_local_rows, combine_local_rows_enabled}; }
+    // MI355X only: fused_deep_moe / dispatch_ffn_combine at prefill sizes multiply the staged token rows in place (a row-offset table) instead
+    // of a K-fold gathered copy; default from MI_EP_FUSED_GATHER (0 = gather).  Results are identical either way.
+    void set_fused_rows_in_place(bool on) { fused_rows_in_place = on; }
+    bool get_fused_rows_in_place() const { return fused_rows_in_place; }
     std::string get_dispatch_transport() const { return dispatch_transport == kTransportPush ? "push" : "pull"; }
     bool self_test(int64_t test_timeout_ms);     // collective: every rank calls it after sync()
     bool is_available() const { return available; }
@@ -255,6 +259,7 @@ private:
     // defaults from MI_EP_DISPATCH_LOCAL / MI_EP_COMBINE_LOCAL (0 = off), see set_local_row_paths()
     bool dispatch_local_rows = !(getenv("MI_EP_DISPATCH_LOCAL") && atoi(getenv("MI_EP_DISPATCH_LOCAL")) == 0);
     bool combine_local_rows_enabled = !(getenv("MI_EP_COMBINE_LOCAL") && atoi(getenv("MI_EP_COMBINE_LOCAL")) == 0);
+    bool fused_rows_in_place = !(getenv("MI_EP_FUSED_GATHER") && atoi(getenv("MI_EP_FUSED_GATHER")) == 0);
     // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
     std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
                                        const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,

@@ -55,6 +55,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     MI_METHOD(buf, get_dispatch_transport);
     MI_METHOD(buf, set_local_row_paths);
     MI_METHOD(buf, get_local_row_paths);
+    MI_METHOD(buf, set_fused_rows_in_place);
+    MI_METHOD(buf, get_fused_rows_in_place);
     MI_METHOD(buf, get_num_rdma_ranks);
     MI_METHOD(buf, get_rdma_rank);
     MI_METHOD(buf, get_notify_send_data);

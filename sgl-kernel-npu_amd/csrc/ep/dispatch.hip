@@ -139,7 +139,7 @@ __device__ __forceinline__ void stage_int8_body(
     const int t = wid / ksplit, kpart = wid - t * ksplit;
     if (t >= T) return;
     const int nitems = H / 16;
-    const size_t stride = (size_t)H + MI_EP_ROW_META_BYTES;
+    const size_t stride = MI_EP_ROW_STRIDE(H);
     // the row is requested before the routing is known (a token that selects nothing is the rare case): behind the routing's two
     // dependent loads (expert id, then slot and segment offset) the 14 KB of the row started one to two round trips late
     const u32x4 *src = (const u32x4 *)(x + (size_t)t * H);
@@ -298,7 +298,7 @@ __device__ __forceinline__ void stage_bf16_body(
     const int t = wid / ksplit, kpart = wid - t * ksplit;
     if (t >= T) return;
     const int nitems = H / 8;
-    const size_t stride = (size_t)H * 2 + MI_EP_ROW_META_BYTES;
+    const size_t stride = MI_EP_ROW_STRIDE((size_t)H * 2);
     long long e_l = -1;
     int slot_l = 0, dst_l = 0;
     if (lane < K) {
@@ -521,7 +521,7 @@ __device__ __forceinline__ void pull_body(
     const int total = min(cum[LW - 1], row_capacity);      // never write past the caller's buffers
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
-    const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
+    const size_t stride = MI_EP_ROW_STRIDE(payload_bytes);
     const int n16 = payload_bytes / 16;
     // rows are dealt to waves round-robin over the whole grid: a decode-size exchange (1 K rows) still spreads over every CU,
     // a prefill-size one gives each wave a few rows a grid-width apart
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
     const int total = min(cum[LW - 1], row_capacity);
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
-    const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
+    const size_t stride = MI_EP_ROW_STRIDE(payload_bytes);
     const int n16 = payload_bytes / 16;
     const long long nw = (long long)gridDim.x * kPullWaves;
     auto entry = [&](long long r, int &src) -> uint2 {          // wave-uniform
@@ -658,6 +658,48 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_indexed_kernel(
     }
 }
 
+// pull_indexed_kernel WITHOUT the copy: where does receive row r live?  One LANE per row: its (source, token row) through the same search and
+// index entry, written as the byte offset of the staged row from `base` (the lowest source base; the ping-pong half is part of the offset)
+// together with the row's scale and (src, t, k) triple.  The grouped GEMM of fused_deep_moe then reads the staged rows in place
+// (mi_ep_moe_gemm1_swiglu_rows): a token's row is staged once and read by its K selections out of L2 / the memory-side cache, and the
+// K-fold copy (235 MB written and read back at 4096 tokens x top-8) is never made.  Sources must be LOCAL memory within 4 GiB of `base`.
+__global__ __launch_bounds__(256) void resolve_rows_kernel(
+    PeerPtrs srcs, const uint8_t *__restrict__ base, const int32_t *__restrict__ recv_count, const int32_t *__restrict__ pull_offset, int W,
+    int LW, int payload_bytes, size_t idx_off, size_t idx_entries, uint32_t *__restrict__ row_off, float *__restrict__ recv_scales,
+    int32_t *__restrict__ recv_src_idx, int row_capacity, Parity par)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t cum[];    // [LW] inclusive cumsum
+    for (int i = threadIdx.x; i < LW; i += blockDim.x) cum[i] = recv_count[i];
+    __syncthreads();
+    const size_t poff = parity_off(par);
+    const int total = min(cum[LW - 1], row_capacity);
+    const size_t stride = MI_EP_ROW_STRIDE(payload_bytes);
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < row_capacity; r += (long long)gridDim.x * blockDim.x) {
+        if (r >= total) {                                        // rows behind the total are never multiplied; keep their table entries tame
+            row_off[r] = 0;
+            continue;
+        }
+        int lo = 0, hi = LW - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] > r) hi = mid; else lo = mid + 1;
+        }
+        const int j = (int)(r - (lo ? cum[lo - 1] : 0));
+        const int src = lo % W;
+        const uint8_t *sb = (const uint8_t *)srcs.p[src] + poff;
+        // a corrupt count / offset / entry must not turn into a wild read: the index holds idx_entries entries, token rows live below it
+        const size_t pos = min((size_t)max(pull_offset[lo] + j, 0), idx_entries - 1);
+        const uint2 e = ((const uint2 *)(sb + idx_off))[pos];
+        const size_t trow = min((size_t)e.x, idx_off / stride - 1);
+        const uint8_t *srow = sb + trow * stride;
+        row_off[r] = (uint32_t)(size_t)(srow - base);
+        if (recv_scales) recv_scales[r] = *(const float *)(srow + payload_bytes);
+        recv_src_idx[r * 3 + 0] = src;
+        recv_src_idx[r * 3 + 1] = (int32_t)e.x;
+        recv_src_idx[r * 3 + 2] = (int32_t)e.y;
+    }
+}
+
 // Receive rows whose token lives on THIS rank, written token by token instead of row by row: the staged row of token t (own region
 // or own source slab) is read ONCE and stored to each of its selections served by this rank's experts -- output row
 // start(le, me) + send_token_idx_small[t, k], start = recv_count[le * W + me] - num_tokens_per_expert[me * L + le] -- with the same
@@ -675,7 +717,7 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_local_kernel(
     if (t >= T) return;
     // the first part of the row is requested before the routing is known (a token without a selection on this rank is the rare case at
     // the sizes where this kernel matters): the routing costs three dependent loads
-    const size_t stride = (size_t)payload_bytes + MI_EP_ROW_META_BYTES;
+    const size_t stride = MI_EP_ROW_STRIDE(payload_bytes);
     const uint8_t *srow = my_rows + parity_off(par) + (size_t)t * stride;
     const u32x4 *s16 = (const u32x4 *)srow;
     const int n16 = payload_bytes / 16;
@@ -744,7 +786,7 @@ using namespace mi_ep;
 
 extern "C" size_t mi_ep_dispatch_row_bytes(int hidden, int quant_mode)
 {
-    return (size_t)hidden * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1) + MI_EP_ROW_META_BYTES;
+    return MI_EP_ROW_STRIDE((size_t)hidden * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1));
 }
 
 extern "C" size_t mi_ep_dispatch_index_offset(int hidden, int quant_mode, int topk, size_t region_bytes)
@@ -894,6 +936,37 @@ extern "C" int mi_ep_dispatch_pull_indexed(const void *const *src_base_host, con
     const int nt_from = pull_nt_from_row(rows_hint, payload);
     if (nt_from != 0x7fffffff) MI_EP_PULL_INDEXED(true); else MI_EP_PULL_INDEXED(false);
 #undef MI_EP_PULL_INDEXED
+    return launch_status();
+}
+
+extern "C" int mi_ep_dispatch_resolve_rows(const void *const *src_base_host, const int32_t *recv_count, const int32_t *pull_offset, int W,
+                                           int L, int H, int K, int quant_mode, int rows_cap, size_t region_bytes, const void **a_base_out,
+                                           uint32_t *row_offsets, float *recv_x_scales, int32_t *recv_src_idx, const uint64_t *epoch_ctr,
+                                           size_t parity_stride, void *stream)
+{
+    if (!src_base_host || !recv_count || !pull_offset || W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || H <= 0 || H % 16 || K <= 0 ||
+        K > MI_EP_MAX_TOPK || !row_offsets || !recv_src_idx || !a_base_out)
+        return MI_EP_EINVAL;
+    const size_t idx_off = mi_ep_dispatch_index_offset(H, quant_mode, K, region_bytes);
+    if (idx_off == 0) return MI_EP_EINVAL;
+    PeerPtrs pp;
+    const uint8_t *lo = nullptr, *hi = nullptr;
+    for (int i = 0; i < W; ++i) {
+        if (!src_base_host[i]) return MI_EP_EINVAL;
+        pp.p[i] = const_cast<void *>(src_base_host[i]);
+        const uint8_t *b = (const uint8_t *)src_base_host[i];
+        if (!lo || b < lo) lo = b;
+        if (!hi || b > hi) hi = b;
+    }
+    // every staged row (either ping-pong half) must lie within 32 bits of the lowest base
+    if ((size_t)(hi - lo) + (epoch_ctr ? parity_stride : 0) + idx_off > 0xFFFFFFFFull) return MI_EP_ESIZE;
+    *a_base_out = lo;
+    if (rows_cap <= 0) return MI_EP_OK;
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    const int blocks = std::min((rows_cap + 255) / 256, 2048);
+    resolve_rows_kernel<<<blocks, 256, (size_t)L * W * sizeof(int32_t), (hipStream_t)stream>>>(
+        pp, lo, recv_count, pull_offset, W, L * W, payload, idx_off, (idx_off / mi_ep_dispatch_row_bytes(H, quant_mode)) * (size_t)K, row_offsets,
+        recv_x_scales, recv_src_idx, rows_cap, make_parity(epoch_ctr, 0, parity_stride));
     return launch_status();
 }
 

@@ -53,7 +53,9 @@ constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
-    const int8_t *a;          // [M_cap, K]
+    const int8_t *a;          // [M_cap, K]; with a_rows: the base the row offsets count from
+    const uint32_t *a_rows;   // null, or [M_cap] byte offsets of the activation rows from `a` (16-byte aligned): the rows are read where a
+                              // dispatch staged them (one row per TOKEN, shared by its K selections) instead of from a gathered copy
     const float *a_scale;     // [M_cap]
     const int8_t *w;          // [L, N, K]
     const float *w_scale;     // [L, N]
@@ -174,7 +176,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, in
     const int wm = wave & 3, wn = wave >> 2;
     const int n0 = col_tile * BN;
     const int8_t *wbase = p.w + (size_t)e * p.N * p.K;
-    const int8_t *abase = p.a + (size_t)row0 * p.K;
+    const int8_t *abase = p.a_rows ? p.a : p.a + (size_t)row0 * p.K;
 
     // ---- DMA plan: one instruction moves kPieceRows rows x BKT bytes (1 KB); wave w issues A piece w (if there is one) and B pieces
     // w, w + 16, ...
@@ -184,8 +186,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, in
         const int row = kPieceRows * wave + lane / kChunks;
         const int chunk = swz_pos<BKT>(row, lane % kChunks);                      // swizzle on the source side (an involution)
 #pragma unroll
-        for (int j = 0; j < kAPerWave; ++j)                                       // rows past the group: any valid row
-            offA[j] = (uint32_t)min(row + j * 16 * kPieceRows, rows - 1) * (uint32_t)p.K + chunk * 16;
+        for (int j = 0; j < kAPerWave; ++j) {                                     // rows past the group: any valid row
+            const int r = min(row + j * 16 * kPieceRows, rows - 1);
+            offA[j] = (p.a_rows ? p.a_rows[row0 + r] : (uint32_t)r * (uint32_t)p.K) + chunk * 16;
+        }
 #pragma unroll
         for (int j = 0; j < kBPerWave; ++j) {
             const int brow = row + j * 16 * kPieceRows;                           // 128 rows further: the same swizzle term
@@ -594,14 +598,14 @@ struct PushArgs {
 
 static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *cum,
                        int cum_stride, int L, int M_cap, int K, int N, void *out, int rows_per_expert_hint, void *stream,
-                       const PushArgs *push = nullptr)
+                       const PushArgs *push = nullptr, const uint32_t *a_rows = nullptr)
 {
     if (!a || !a_scale || !w || !w_scale || !cum || (!out && !push) || L <= 0 || L > 1024 || M_cap <= 0 || K <= 0 || K % BK || N <= 0 ||
         N % 128 || cum_stride <= 0)
         return MI_EP_EINVAL;
     GemmArgs p{};
     p.a = a, p.a_scale = a_scale, p.w = w, p.w_scale = w_scale, p.cum = cum, p.cum_stride = cum_stride, p.L = L, p.M_cap = M_cap;
-    p.K = K, p.N = N, p.out = out;
+    p.K = K, p.N = N, p.out = out, p.a_rows = a_rows;
     const bool small = rows_per_expert_hint > 0 && rows_per_expert_hint <= 96;      // decode-size groups
     if (push) {
         p.src_idx = push->src_idx, p.dsts = push->dsts, p.slot_stride = push->slot_stride, p.topk = push->topk, p.W = push->W;
@@ -631,6 +635,15 @@ extern "C" int mi_ep_moe_gemm1_swiglu(const int8_t *a, const float *a_scale, con
 {
     return gemm_launch(0, a, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, hidden, two_i, out,
                        rows_per_expert_hint, stream);
+}
+
+extern "C" int mi_ep_moe_gemm1_swiglu_rows(const void *a_base, const uint32_t *a_row_offsets, const float *a_scale, const int8_t *w,
+                                           const float *w_scale, const int32_t *row_cumsum, int cum_stride, int num_local_experts,
+                                           int rows_cap, int hidden, int two_i, float *out, int rows_per_expert_hint, void *stream)
+{
+    if (!a_row_offsets) return MI_EP_EINVAL;
+    return gemm_launch(0, (const int8_t *)a_base, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, hidden, two_i,
+                       out, rows_per_expert_hint, stream, nullptr, a_row_offsets);
 }
 
 extern "C" int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_cap, int inter, int8_t *q, float *scale,

@@ -359,6 +359,15 @@ def _gpu_fused_moe(rank, world, port, cfg):
     denom = np.maximum(np.abs(ref), 1e-2)
     assert diff < 1e-5, diff
     assert np.mean(np.abs(got - ref) / denom) < 4e-4, np.mean(np.abs(got - ref) / denom)   # reference: avg_diff < 4e-4 (:470)
+    # prefill-size batches multiply the staged token rows in place (row-offset table, mi_ep_dispatch_resolve_rows +
+    # mi_ep_moe_gemm1_swiglu_rows); with the K-fold gathered copy instead the output must be the same BITS
+    if layout != "ffn" and hasattr(buf.runtime, "set_fused_rows_in_place"):
+        assert buf.runtime.get_fused_rows_in_place()
+        buf.runtime.set_fused_rows_in_place(False)
+        out2, cnt2 = buf.fused_deep_moe(x, ti, tw, w13_p, s13_p, w2_t, torch.from_numpy(s2[rank]).cuda(), T, E)
+        buf.runtime.set_fused_rows_in_place(True)
+        out3, _ = buf.fused_deep_moe(x, ti, tw, w13_p, s13_p, w2_t, torch.from_numpy(s2[rank]).cuda(), T, E)
+        assert torch.equal(out2, out) and torch.equal(out3, out) and torch.equal(cnt2, ep_recv_count)
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

@@ -26,8 +26,8 @@ def test_row_geometry_helpers_are_host_callable():
     lib.mi_ep_dispatch_row_bytes.restype = ctypes.c_size_t
     lib.mi_ep_combine_row_bytes.restype = ctypes.c_size_t
     lib.mi_ep_version.restype = ctypes.c_char_p
-    assert lib.mi_ep_dispatch_row_bytes(7168, 1) == 7168 + 16
-    assert lib.mi_ep_dispatch_row_bytes(7168, 0) == 14336 + 16
+    assert lib.mi_ep_dispatch_row_bytes(7168, 1) == 7168 + 128          # payload + 16 B of meta, rounded up to whole 128-byte lines
+    assert lib.mi_ep_dispatch_row_bytes(7168, 0) == 14336 + 128
     assert lib.mi_ep_combine_row_bytes(7168) == 14336
     assert b"gfx950" in lib.mi_ep_version()
 
@@ -52,7 +52,7 @@ def test_compact_staging_geometry_and_capacity_check():
     import ep_harness
     lib = ep_harness.lib()          # ONE set of argtypes for the whole suite: the 16-argument form of include/mi_ep.h
     assert len(lib.mi_ep_dispatch_stage_compact.argtypes) == 16
-    H, K, rb = 7168, 8, 7168 + 16
+    H, K, rb = 7168, 8, 7168 + 128          # rows start on 128-byte lines (MI_EP_ROW_STRIDE)
     region = 1 << 30
     off = lib.mi_ep_dispatch_index_offset(H, 1, K, region)
     cap = off // rb
