@@ -33,4 +33,8 @@ for _ in range(200):
     a.record(); f(); b.record(); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b) * 1e3)
 ts.sort()
-print("mla_preprocess %s us p50 %.1f min %.1f" % (mode, ts[len(ts) // 2], ts[0]))
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(200): f()
+b.record(); torch.cuda.synchronize()
+print("mla_preprocess %s us p50 %.1f min %.1f queued %.1f" % (mode, ts[len(ts) // 2], ts[0], a.elapsed_time(b) * 1e3 / 200))
