@@ -288,6 +288,22 @@ int mi_ep_combine_push_signal_wait(const void *x, const int32_t *src_idx, const 
                                    void *const *dst_base_host, int num_ranks, size_t slot_region_bytes, uint64_t *epoch_ctr,
                                    size_t parity_stride, int my_rank, int32_t *local_row, uint64_t *const *peer_flags_host,
                                    const uint64_t *my_flags, uint32_t *arrive_word, int32_t *status, int timeout_ms, void *stream);
+/* The TWO-launch combine (the reference waits per token for the rows it sums, moe_distribute_combine_v2.h:952-1002): mi_ep_combine_push_flagged =
+ * mi_ep_combine_push whose waves write their rows through the caches and, once a row's stores have drained, raise the row's flag word at
+ * its owner -- uint32 [2 halves, row_flags_parity_stride bytes apart][slot rows] in every rank's control area, word t * K + k of the half
+ * (*epoch_ctr + 1) & 1, value = the low 32 bits of that epoch (tags, never cleared); mi_ep_combine_reduce_flagged = mi_ep_combine_reduce
+ * whose waves wait (bounded by timeout_ms, code 3000 + k through *status) for the words of their token's valid, non-local selections before
+ * they read the rows.  The push leaves the call's epoch at *cur_epoch_word (a word of the rank's own control area, the same for both calls; it
+ * is launched even without rows), the reduce takes epoch and ping-pong half from there and completes *epoch_ctr.
+ * No "rows pushed" flag exchange, no single-workgroup launch between the two; same bytes in the same slots, same sum. */
+int mi_ep_combine_push_flagged(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int hidden, int num_topk,
+                               void *const *dst_base_host, int num_ranks, size_t slot_region_bytes, const uint64_t *epoch_ctr,
+                               size_t parity_stride, int my_rank, int32_t *local_row, uint32_t *const *peer_row_flags_host,
+                               size_t row_flags_parity_stride, uint64_t *cur_epoch_word, void *stream);
+int mi_ep_combine_reduce_flagged(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights, int num_tokens, int num_topk,
+                                 int hidden, int num_experts, void *out, uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
+                                 const int32_t *local_row, int local_rows, int my_rank, int num_ranks, const uint32_t *my_row_flags,
+                                 size_t row_flags_parity_stride, const uint64_t *cur_epoch_word, int32_t *status, int timeout_ms, void *stream);
 int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                          const int32_t *send_data_offset, const int32_t *send_token_idx_small, int num_tokens,
                          int num_topk, int hidden, int num_experts, void *out, const uint64_t *epoch_ctr, size_t parity_stride,
@@ -356,6 +372,25 @@ int mi_ep_ll_dispatch_layout_send_counts(const void *x, const void *topk_idx, in
                                          int32_t *send_data_offset, uint64_t *const *peer_counts_host, const uint64_t *my_counts,
                                          size_t counts_parity_stride, int count_type, int32_t *layout_range, int64_t *packed_recv_count,
                                          uint32_t *arrive_word, int32_t *status, int timeout_ms, void *stream);
+/* The TWO-launch low-latency dispatch with nothing between the launches.  mi_ep_ll_dispatch_layout_send_tagged = mi_ep_ll_dispatch_layout_send
+ * whose layout workgroup posts this rank's per-expert counts to every peer's count granules as soon as it has them (half (*epoch_ctr + 1) & 1,
+ * granule = epoch << 32 | count) and leaves the call's epoch at *cur_epoch_word (own control area), and whose send waves write every row's
+ * payload through the caches, drain, and only then its meta -- word 3 = src_rank | tag << 8, tag = epoch % 0xFFFFFF + 1: nobody waits in this
+ * launch.  mi_ep_ll_wait_pack = the count exchange's collecting half + mi_ep_ll_pack in one launch of <= 512 workgroups: each collects the L * W
+ * granules of the epoch at *cur_epoch_word (bounded by timeout_ms; code 2000 + i through *status), scans them, and packs its rows, waiting
+ * per row for the tag (code 2500 + ..); workgroup 0 writes layout_range / packed_recv_count and completes *epoch_ctr.  Same rows, tables and
+ * bytes as the three-launch form (src_info word 0 = the meta word's low 8 bits).  Reference: per-token arrival state instead of a global
+ * barrier, moe_distribute_dispatch_v2.h:1477-1490. */
+int mi_ep_ll_dispatch_layout_send_tagged(const void *x, const void *topk_idx, int idx_is_i32, int num_tokens, int num_topk, int hidden,
+                                         int num_experts, int num_ranks, int my_rank, int max_tokens, int quant_mode, void *const *peer_rows_host,
+                                         const uint64_t *epoch_ctr, size_t parity_stride, int32_t *num_tokens_per_rank,
+                                         int32_t *num_tokens_per_expert, int32_t *is_token_in_rank, int32_t *send_token_idx_small,
+                                         int32_t *send_data_offset, uint64_t *const *peer_counts_host, size_t counts_parity_stride,
+                                         uint64_t *cur_epoch_word, void *stream);
+int mi_ep_ll_wait_pack(const void *my_rows, const uint64_t *my_counts, size_t counts_parity_stride, int num_ranks, int num_local_experts,
+                       int max_tokens, int hidden, int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales,
+                       int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int rows_capacity, const uint64_t *cur_epoch_word,
+                       uint64_t *epoch_ctr, size_t rows_parity_stride, int32_t *status, int timeout_ms, void *stream);
 int mi_ep_ll_pack(const void *my_rows, const int32_t *layout_range, int num_ranks, int num_local_experts, int max_tokens, int hidden,
                   int quant_mode, void *packed_recv_x, float *packed_recv_x_scales, int32_t *src_info, int rows_capacity,
                   const uint64_t *epoch_ctr, size_t rows_parity_stride, void *stream);

@@ -29,6 +29,10 @@ constexpr int64_t kOffNotify = 64 << 10;           // 2 parities x W x (E+1) u64
 constexpr int64_t kNotifyParityBytes = 1100 << 10;
 constexpr int64_t kOffLLCounts = kOffNotify + 2 * kNotifyParityBytes;   // 2 parities x 2048 u64
 constexpr int64_t kLLCountsParityBytes = 2048 * 8;
+// row flags of the two-launch combine (mi_ep_combine_push_flagged): 2 halves x 131072 uint32, word t * K + k of a rank's combine slots
+constexpr int64_t kOffRowFlags = 2560 << 10;
+constexpr int64_t kRowFlagsParityBytes = 512 << 10;
+static_assert(kOffLLCounts + 2 * kLLCountsParityBytes <= kOffRowFlags && kOffRowFlags + 2 * kRowFlagsParityBytes <= kCtrlBytes, "control area layout");
 enum Family { kDispatch = 0, kCombine = 1, kLLDispatch = 2 };
 enum FlagGroup { kFlagDispatch = 0, kFlagCombine = 1, kFlagSelfTestAck = 6, kFlagSelfTest = 7 };
 constexpr int kMaxTotalTokens = 131072;            // reference MAX_TOTAL_TOKENS (deep_ep.cpp:37)
@@ -717,7 +721,7 @@ Buffer::intranode_combine(const at::Tensor &x, const at::Tensor &topk_idx, const
     // total rows = send_head[E-1] (cam_moe_combine_normal.h:225), read on device
     // rows whose token lives on this rank stay where they are: the push only records their row number, the reduce reads x
     auto local_row = combine_local_rows(topk_idx);
-    bool signalled = false;
+    int signalled = 0;
     // (with send-cost statistics asked for, the push stays a launch of its own: the statistic is the time until the rows are out)
     if (combine_send_cost_stats.has_value()) {
         ProfScope ps_(this, "combine_push", st);
@@ -807,7 +811,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
     static const bool fused_send = get_value_from_env("MI_EP_LL_FUSED", 1) != 0;
     Layout lay;
     at::Tensor counts_buf;
-    bool counts_done = false;
+    bool counts_done = false, tagged_rows = false;
     if (fused_send && T <= 1024 && (size_t)16 * E <= 16384 && E % 2 == 0) {
         lay.T = T, lay.K = K, lay.E = E;
         // the five layout tables carved out of ONE allocation (each at::empty costs ~1-2 us of host time in front of the first launch)
@@ -825,8 +829,25 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
         // per call (pair in a graph of ten: 31.7 against 27.0) -- every workgroup pays a drain + a device-scope arrival, the layout
         // workgroup a release, the rows go through the caches to HBM instead of waiting in L2 for the packing launch; the kernel boundary
         // it saves costs less than that (MI355X_MICROARCH.md: ~1.5 us).  Left off, like the combine side of the same idea (combine_push_rows).
-        static const bool fused_counts = get_value_from_env("MI_EP_LL_FUSED_COUNTS", 0) != 0;
-        if (fused_counts) {
+        // MI_EP_LL_FUSED_COUNTS=2: TWO launches with nothing between them -- the layout workgroup posts the counts at the head of the send launch,
+        // the send waves tag their rows (meta word written behind the drained payload), and the packing launch collects counts and rows itself
+        // (mi_ep_ll_dispatch_layout_send_tagged / mi_ep_ll_wait_pack): no workgroup of the send launch waits for another.
+        // One GPU, same box, alternating (bench.py's low-latency section, two runs each): queued dispatch 20.0-22.3 -> 17.6-18.2 us, replayed
+        // 24.6-24.8 -> 23.4-23.6; with the two-launch combine (combine_push_rows) the dispatch + combine pair in a graph of ten
+        // 26.4-26.7 -> 22.7-22.8 us.  Default; 0 = three launches, 1 = the last-arriver tail below.
+        // (ranks that share a GPU default to three launches: deep_ep.hpp, get_local_device_bus_id)
+        const int ll_form = ll_launch_form("MI_EP_LL_FUSED_COUNTS");
+        const bool fused_counts = ll_form == 1;
+        if (ll_form == 2) {
+            auto cnt_peers0 = peer_ptrs((size_t)kOffLLCounts);
+            ProfScope ps_(this, "ll_dispatch_layout_send", st);
+            MI_EP_CHECK(mi_ep_ll_dispatch_layout_send_tagged(
+                x.data_ptr(), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, T, K, H, E, W, (int)rank, MT, qm, row_peers.data(), ctr,
+                region_bytes, lay.num_tokens_per_rank.data_ptr<int>(), lay.num_tokens_per_expert.data_ptr<int>(),
+                lay.is_token_in_rank.data_ptr<int>(), lay.send_token_idx_small.data_ptr<int>(), lay.send_data_offset.data_ptr<int>(),
+                (uint64_t *const *)cnt_peers0.data(), (size_t)kLLCountsParityBytes, (uint64_t *)(window + kOffEpochs + 1024 + 136), st));
+            tagged_rows = true;
+        } else if (fused_counts) {
             counts_buf = at::empty({(int64_t)L * W + 2 * (int64_t)L + 2}, i32);      // ep_recv_count [L*W] | packed_recv_count [L] (int64, 8-byte aligned)
             auto cnt_peers0 = peer_ptrs((size_t)kOffLLCounts);
             const int64_t off64 = ((int64_t)L * W + 1) / 2 * 2;
@@ -875,7 +896,15 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
     auto cnt_peers = peer_ptrs((size_t)kOffLLCounts);
     // rows the output tensors hold (and src_info / 3): the packing kernel never writes past them, whatever the counts say
     const int rows_capacity = (int)std::min<int64_t>(num_max_tokens, max_size / 3);
-    if (counts_done) {
+    if (tagged_rows) {
+        ProfScope ps_(this, "ll_dispatch_recv", st);
+        MI_EP_CHECK(mi_ep_ll_wait_pack(family_base(kLLDispatch), (const uint64_t *)(window + kOffLLCounts), (size_t)kLLCountsParityBytes, W, L, MT, H,
+                                       qm, count_type, packed_recv_x.data_ptr(),
+                                       qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(),
+                                       (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(), ep_recv_count.data_ptr<int>(),
+                                       rows_capacity, (const uint64_t *)(window + kOffEpochs + 1024 + 136), ctr, region_bytes, status_dev,
+                                       timeout_ms, st));
+    } else if (counts_done) {
         ProfScope ps_(this, "ll_dispatch_recv", st);
         MI_EP_CHECK(mi_ep_ll_pack(family_base(kLLDispatch), ep_recv_count.data_ptr<int>(), W, L, MT, H, qm, packed_recv_x.data_ptr(),
                                   qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(), expand_idx.data_ptr<int>(),
@@ -926,9 +955,11 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx_user
     auto dst_peers = peer_family_bases(kCombine);
     // valid packed rows = layout_range[L*W-1], read on device
     auto local_row = combine_local_rows(topk_idx);
-    bool signalled = false;
+    int signalled = 0;
+    // (the per-row flag form needs a flag word per slot on EVERY rank: decided from num_max_dispatch_tokens_per_rank, which the ranks share)
+    const bool flag_words_ok = (int64_t)num_max_dispatch_tokens_per_rank * K <= kRowFlagsParityBytes / 4;
     combine_push_rows(x, src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
-                      (int)std::min<int64_t>(x.size(0), src_info.numel() / 3), H, K, local_row, "ll_combine_push", st, signalled);
+                      (int)std::min<int64_t>(x.size(0), src_info.numel() / 3), H, K, local_row, "ll_combine_push", st, signalled, flag_words_ok);
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
     return {combine_finish(topk_idx, topk_weights.data_ptr<float>(), H, E, x.options(), "ll_combine_reduce", st, x, local_row, signalled),
             std::nullopt, std::function<void()>([] {})};
@@ -964,27 +995,53 @@ at::Tensor Buffer::combine_local_rows(const at::Tensor &topk_idx) const
 // Device words the fused push counts its workgroups in at (control area, zeroed at creation, re-armed by the kernel): dealt from a ring of
 // 16, so that calls of one Buffer that overlap on two streams (two-batch overlap) never share one; a captured call keeps its word, and
 // the replays of one graph serialise on its stream.
+std::string Buffer::get_local_device_bus_id() const
+{
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, device_id) != hipSuccess) return std::string("device-") + std::to_string(device_id);
+    return std::string(id);
+}
+
+int Buffer::ll_launch_form(const char *env_name) const
+{
+    const char *e = getenv(env_name);
+    if (e && *e) return atoi(e);
+    return ranks_share_device ? 0 : 2;
+}
+
 uint32_t *Buffer::arrive_word() { return (uint32_t *)(window + kOffEpochs + 1024) + 2 * (arrive_calls++ % 16); }
 
 void Buffer::combine_push_rows(const at::Tensor &x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int H, int K,
-                               const at::Tensor &local_row, const char *name, hipStream_t st, bool &signalled)
+                               const at::Tensor &local_row, const char *name, hipStream_t st, int &signalled, bool may_flag_rows)
 {
-    // Opt-in (MI_EP_COMBINE_FUSED=1).  Measured on one GPU, same box, alternating: a lone low-latency combine 13.1-13.3 us against
-    // 13.5-16.0 for the three launches, but the dispatch + combine pair inside a captured graph of ten 28.7 against 27.2 us -- where a
-    // kernel boundary costs ~1.3 us, 256 workgroups arriving at one word and a tail that waits inside the push cost more than the launch
-    // they replace; the normal-mode step is unchanged (0.164-0.167 against 0.163-0.165 ms).  Off by default.
-    static const bool fused = get_value_from_env("MI_EP_COMBINE_FUSED", 0) != 0;
+    // MI_EP_COMBINE_FUSED: how the owners learn that their rows have arrived.
+    //   2 (default where every rank owns its GPU -- ranks sharing one keep 0, deep_ep.hpp; low-latency combine only, may_flag_rows): TWO launches without any exchange between them -- every pushed row raises its own
+    //     flag word at its owner, the reduce waits per selection (mi_ep_combine_push_flagged / mi_ep_combine_reduce_flagged; the reference's
+    //     per-token wait, moe_distribute_combine_v2.h:952-1002).  One GPU, same box, alternating: a lone combine 13.4-13.6 -> 11.1-11.5 us,
+    //     replayed 20.4 -> 18.2-18.5, the dispatch + combine pair in a graph of ten 26.6-27.0 -> 24.6-24.7 us.
+    //   0: three launches (push, the single-wave "rows pushed" signal + wait, reduce) -- what every other combine uses.
+    //   1: the signal + wait as the TAIL of the push (last workgroup to arrive): a lone low-latency combine 13.1-13.3 us against 13.5-16.0 for
+    //     the three launches, but the pair inside a captured graph of ten 28.7 against 27.2 us (256 workgroups arriving at one word and a
+    //     tail that waits inside the push cost more than the ~1.3 us boundary they replace); normal-mode step unchanged.
+    const int fused_form = ll_launch_form("MI_EP_COMBINE_FUSED");
+    const bool fused = fused_form == 1;
     const int W = (int)num_ranks;
     auto dst_peers = peer_family_bases(kCombine);
     int32_t *lr = local_row.defined() ? local_row.data_ptr<int>() : nullptr;
     ProfScope ps_(this, name, st);
-    if (fused) {
+    if (fused_form == 2 && may_flag_rows) {
+        auto row_flag_peers = peer_ptrs((size_t)kOffRowFlags);
+        MI_EP_CHECK(mi_ep_combine_push_flagged(x.data_ptr(), src_idx, total_rows_dev, rows_hint, H, K, dst_peers.data(), W, region_bytes,
+                                               epoch_ctr(kCombine), region_bytes, (int)rank, lr, (uint32_t *const *)row_flag_peers.data(),
+                                               (size_t)kRowFlagsParityBytes, (uint64_t *)(window + kOffEpochs + 1024 + 128), st));
+        signalled = 2;
+    } else if (fused) {
         auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
         MI_EP_CHECK(mi_ep_combine_push_signal_wait(x.data_ptr(), src_idx, total_rows_dev, rows_hint, H, K, dst_peers.data(), W, region_bytes,
                                                    epoch_ctr(kCombine), region_bytes, (int)rank, lr, (uint64_t *const *)flag_peers.data(),
                                                    (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), arrive_word(),
                                                    status_dev, timeout_ms, st));
-        signalled = true;
+        signalled = 1;
     } else {
         MI_EP_CHECK(mi_ep_combine_push(x.data_ptr(), src_idx, total_rows_dev, rows_hint, H, K, dst_peers.data(), W, region_bytes,
                                        epoch_ctr(kCombine), region_bytes, (int)rank, lr, st));
@@ -992,10 +1049,22 @@ void Buffer::combine_push_rows(const at::Tensor &x, const int32_t *src_idx, cons
 }
 
 at::Tensor Buffer::combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
-                                  const char *reduce_name, hipStream_t st, const at::Tensor &x_local, const at::Tensor &local_row, bool signalled)
+                                  const char *reduce_name, hipStream_t st, const at::Tensor &x_local, const at::Tensor &local_row, int signalled)
 {
     const int T = (int)topk_idx.size(0), K = (int)topk_idx.size(1), W = (int)num_ranks;
     auto flag_peers = peer_ptrs((size_t)(kOffFlags + kFlagCombine * kFlagGroupSlots * 8));
+    if (signalled == 2) {                        // rows with flags: the reduce waits for them itself and completes the call counter
+        auto combined_x = at::empty({T, H}, opts);
+        const bool use_local = local_row.defined() && x_local.defined() && x_local.size(0) > 0;
+        ProfScope ps_(this, reduce_name, st);
+        MI_EP_CHECK(mi_ep_combine_reduce_flagged(family_base(kCombine), topk_idx.data_ptr(), topk_idx.scalar_type() == at::kInt, topk_weights, T, K,
+                                                 H, E, combined_x.data_ptr(), epoch_ctr(kCombine), region_bytes,
+                                                 use_local ? x_local.data_ptr() : nullptr, use_local ? local_row.data_ptr<int>() : nullptr,
+                                                 use_local ? (int)x_local.size(0) : 0, (int)rank, W,
+                                                 (const uint32_t *)(window + kOffRowFlags), (size_t)kRowFlagsParityBytes,
+                                                 (const uint64_t *)(window + kOffEpochs + 1024 + 128), status_dev, timeout_ms, st));
+        return combined_x;
+    }
     if (!signalled) { ProfScope ps_(this, "combine_signal_wait", st);
       MI_EP_CHECK(mi_ep_signal_wait((uint64_t *const *)flag_peers.data(),
                                     (const uint64_t *)(window + kOffFlags + kFlagCombine * kFlagGroupSlots * 8), W, (int)rank, 0,

@@ -29,6 +29,13 @@ public:
     // buffer.py:67-83; here Python all-gathers these handles over the ProcessGroup, like upstream DeepEP's
     // get_local_ipc_handle()/sync()).
     int get_local_device_id() const { return device_id; }
+    // PCI bus id of this rank's GPU ("0000:05:00.0"): the bootstrap compares them -- a device index says nothing under per-process
+    // HIP_VISIBLE_DEVICES.  Ranks that SHARE a GPU (the one-GPU test / dry-run setups) keep the low-latency calls on their three-launch forms:
+    // the consuming launches of the two-launch forms wait for rows inside many workgroups, which is fine when every rank owns its GPU (the
+    // producing launches run elsewhere) and can starve the producers of the other ranks when they all queue on one.
+    std::string get_local_device_bus_id() const;
+    void set_ranks_share_device(bool shared) { ranks_share_device = shared; }
+    bool get_ranks_share_device() const { return ranks_share_device; }
     // The window is kNumSegs allocations (control area + one per family, each below the 2 GiB that hipIpcOpenMemHandle can map).
     std::string get_local_ipc_handle() const;         // kNumSegs x hipIpcMemHandle_t bytes
     std::vector<int64_t> get_local_window_ptrs() const;      // the kNumSegs segment bases
@@ -242,12 +249,16 @@ private:
                        at::Tensor &rx, at::Tensor &rs, at::Tensor &src_idx, hipStream_t st);
     at::Tensor combine_finish(const at::Tensor &topk_idx, const float *topk_weights, int H, int E, const at::TensorOptions &opts,
                               const char *reduce_name, hipStream_t st, const at::Tensor &x_local = at::Tensor(),
-                              const at::Tensor &local_row = at::Tensor(), bool signalled = false);
+                              const at::Tensor &local_row = at::Tensor(), int signalled = 0);
     // push + signal + wait in one launch (mi_ep_combine_push_signal_wait); MI_EP_COMBINE_FUSED=0: the separate signal_wait launch
     void combine_push_rows(const at::Tensor &x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int H, int K,
-                           const at::Tensor &local_row, const char *name, hipStream_t st, bool &signalled);
+                           const at::Tensor &local_row, const char *name, hipStream_t st, int &signalled, bool may_flag_rows = false);
     uint32_t *arrive_word();
     uint64_t arrive_calls = 0;
+    bool ranks_share_device = false;
+    // launch form of the low-latency dispatch / combine: the env value if set, else 2 (two launches, nothing between them) when every rank owns
+    // its GPU and 0 (three launches) when ranks share one
+    int ll_launch_form(const char *env_name) const;
     at::Tensor combine_local_rows(const at::Tensor &topk_idx) const;
     struct LocalRowEntry {
         at::Tensor src_idx, rows;

@@ -42,6 +42,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 
     // ---- MI355X only: symmetric-window bootstrap over hipIpc (replaces the HCCL window lookup by communicator name)
     MI_METHOD(buf, get_local_device_id);
+    MI_METHOD(buf, get_local_device_bus_id);
+    MI_METHOD(buf, set_ranks_share_device);
+    MI_METHOD(buf, get_ranks_share_device);
     MI_METHOD(buf, get_local_window_ptrs);
     MI_METHOD(buf, get_window_bytes);
     buf.def("get_local_ipc_handle", [](const Buffer &b) { return py::bytes(b.get_local_ipc_handle()); });

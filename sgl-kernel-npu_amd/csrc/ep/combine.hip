@@ -32,6 +32,12 @@ struct PushTail {
     uint64_t *epoch_bump;         // the family's completed-call counter (also this call's epoch source: counter + 1)
     int32_t *status;
     uint64_t timeout_ticks;
+    // FLAGGED form (arrive == NULL, row_flag_peers set): no tail at all -- every wave raises the flag word of ITS row at the row's owner once
+    // the row's write-through stores have drained (the reference's per-token arrival state, moe_distribute_combine_v2.h:952-1002); the
+    // owner's reduce waits per selection (combine_reduce_kernel<.., FLAGGED>).  Words are tagged with the call's epoch, never cleared.
+    PeerPtrs row_flag_peers;      // every rank's row-flag area: uint32 [2 halves][slot rows]
+    size_t row_flags_parity_stride;
+    uint64_t *cur_epoch;          // FLAGGED: the push leaves this call's epoch here for the reduce (which then completes the call counter)
 };
 
 template <bool TAIL>
@@ -42,6 +48,7 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
 {
     // never trust the device-side count beyond the rows the caller's tensor holds
     const int total = total_dev ? min(*total_dev, rows_hint) : rows_hint;
+    if (TAIL && tail.cur_epoch && blockIdx.x == 0 && threadIdx.x == 0) *tail.cur_epoch = *tail.epoch_bump + 1ull;
     const size_t poff = parity_off(par);
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
@@ -78,9 +85,19 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
             //  fewer dirty lines are left behind -- a wash for the step)
             if (TAIL) copy_row_wt<true>(s16, d16, n16, lane);
             else copy_row<true, false>(s16, d16, n16, lane);
+            if (TAIL && !tail.arrive) {
+                // FLAGGED: the row is at its owner (write-through stores, drained) before its flag says so
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const uint64_t ep64 = *tail.epoch_bump + 1ull;
+                    uint32_t *fl = (uint32_t *)((uint8_t *)tail.row_flag_peers.p[src] + (size_t)(ep64 & 1ull) * tail.row_flags_parity_stride) +
+                                   ((size_t)t * K + k);
+                    __hip_atomic_store(fl, (uint32_t)ep64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
     }
-    if (TAIL) {
+    if (TAIL && tail.arrive) {
         __shared__ uint32_t last_s;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave: its write-through stores are performed
         __syncthreads();
@@ -115,12 +132,22 @@ __global__ __launch_bounds__(kWave * kPushWaves) void combine_push_kernel(
     }
 }
 
-template <bool I32, int KMAX>
-__global__ __launch_bounds__(256) void combine_reduce_kernel(
+// FLAGGED (the two-launch combine): the rows were pushed by mi_ep_combine_push_flagged; a wave waits (bounded) for the flag words of ITS token's
+// selections before it reads their rows, and the last workgroup of the launch to finish completes the family's call counter.
+struct ReduceFlags {
+    const uint32_t *row_flags;    // this rank's row-flag area (both halves)
+    size_t parity_stride;
+    const uint64_t *cur_epoch;    // this call's epoch, left by the push launch (nothing in this launch reads the completed-call counter ...
+    uint64_t *epoch_bump;         // ... so its first workgroup completes it without waiting for anybody)
+    int32_t *status;
+    uint64_t timeout_ticks;
+};
+template <bool I32, int KMAX, bool FLAGGED>
+__device__ __forceinline__ void combine_reduce_body(
     const uint8_t *__restrict__ slots, size_t slot_stride, const void *__restrict__ topk_idx,
     const float *__restrict__ topk_w, const int32_t *__restrict__ send_off, const int32_t *__restrict__ idx_small,
-    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out, Parity par, const uint8_t *__restrict__ x_local,
-    const int32_t *__restrict__ local_row, int local_rows, int my_rank, int experts_per_rank)
+    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out, const Parity &par, const uint8_t *__restrict__ x_local,
+    const int32_t *__restrict__ local_row, int local_rows, int my_rank, int experts_per_rank, const ReduceFlags &rf)
 {
     slots += parity_off(par);
     const int lane = lane_id();
@@ -145,9 +172,31 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
         if (send_off && valid_l) slot_l = (long long)send_off[e] + idx_small[tk];
         if (valid_l) base_l = slots + (size_t)(int)slot_l * slot_stride;
         // selections served by this rank's own experts were not pushed: their rows are read from the expert output itself
-        if (x_local && valid_l && (int)((uint32_t)e / (uint32_t)experts_per_rank) == my_rank)      // 0 <= e < E: 32-bit division
+        bool local_l = false;
+        if (x_local && valid_l && (int)((uint32_t)e / (uint32_t)experts_per_rank) == my_rank) {    // 0 <= e < E: 32-bit division
             base_l = x_local + (size_t)min(max(local_row[tk], 0), local_rows - 1) * ((size_t)H * 2);       // never read outside x, whatever the handle says
+            local_l = true;
+        }
+        if constexpr (FLAGGED) {
+            // the row of selection (t, lane) has landed when its flag word carries this call's epoch (bounded wait: a missing row is reported
+            // and the slot is summed as it is)
+            if (valid_l && !local_l) {
+                const uint64_t ep64 = *rf.cur_epoch;
+                const uint32_t *fl = (const uint32_t *)((const uint8_t *)rf.row_flags + (size_t)(ep64 & 1ull) * rf.parity_stride) + tk;
+                const uint64_t t0 = ticks_100mhz();
+                while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (uint32_t)ep64) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (ticks_100mhz() - t0 > rf.timeout_ticks) {
+                        report_status(rf.status, 3000 + lane);
+                        break;
+                    }
+                }
+            }
+        }
     }
+    // (FLAGGED: the row loads below are issued after the flag loads above have returned -- the wait loop's exit depends on them; no cache
+    //  holds these lines: the launch touches a row only behind its flag.  An acquire fence here -- a cache invalidate per wave -- doubled the launch.)
+    if constexpr (FLAGGED) asm volatile("" ::: "memory");
     const unsigned long long vmask = __ballot(valid_l);
     const uint64_t base_bits = (uint64_t)(uintptr_t)base_l;
     const int base_lo = (int)(uint32_t)base_bits, base_hi = (int)(uint32_t)(base_bits >> 32);
@@ -199,6 +248,20 @@ __global__ __launch_bounds__(256) void combine_reduce_kernel(
         for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) chunk(c, std::true_type{});
     } else {
         for (int c = seg0 * kWave + lane; c < nchunks; c += segs_per_token * kWave) chunk(c, std::false_type{});
+    }
+}
+
+template <bool I32, int KMAX, bool FLAGGED = false>
+__global__ __launch_bounds__(256) void combine_reduce_kernel(
+    const uint8_t *__restrict__ slots, size_t slot_stride, const void *__restrict__ topk_idx,
+    const float *__restrict__ topk_w, const int32_t *__restrict__ send_off, const int32_t *__restrict__ idx_small,
+    int T, int K, int H, int E, int segs_per_token, uint16_t *__restrict__ out, Parity par, const uint8_t *__restrict__ x_local,
+    const int32_t *__restrict__ local_row, int local_rows, int my_rank, int experts_per_rank, ReduceFlags rf)
+{
+    combine_reduce_body<I32, KMAX, FLAGGED>(slots, slot_stride, topk_idx, topk_w, send_off, idx_small, T, K, H, E, segs_per_token, out, par, x_local,
+                                            local_row, local_rows, my_rank, experts_per_rank, rf);
+    if constexpr (FLAGGED) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *rf.epoch_bump = *rf.cur_epoch;
     }
 }
 
@@ -348,18 +411,73 @@ extern "C" int mi_ep_combine_push_signal_wait(const void *x, const int32_t *src_
                                local_row, &tail, stream);
 }
 
+// the push of the two-launch combine: mi_ep_combine_push whose waves raise the flag word of every row they have written at the row's owner
+extern "C" int mi_ep_combine_push_flagged(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int H, int K,
+                                          void *const *dst_base_host, int W, size_t slot_region_bytes, const uint64_t *epoch_ctr,
+                                          size_t parity_stride, int my_rank, int32_t *local_row, uint32_t *const *peer_row_flags_host,
+                                          size_t row_flags_parity_stride, uint64_t *cur_epoch_word, void *stream)
+{
+    if (!epoch_ctr || !peer_row_flags_host || !cur_epoch_word || W <= 0 || W > MI_EP_MAX_RANKS || my_rank < 0 || my_rank >= W || H <= 0 || H % 8 ||
+        row_flags_parity_stride < sizeof(uint32_t))
+        return MI_EP_EINVAL;
+    // (a call without rows still launches one workgroup: it leaves the call's epoch for the reduce)
+    // a slot without a flag word is no slot: (t, k) past the words of a half are dropped like those past the region
+    const size_t flagged_bytes = (row_flags_parity_stride / sizeof(uint32_t)) * mi_ep_combine_row_bytes(H);
+    slot_region_bytes = slot_region_bytes ? std::min(slot_region_bytes, flagged_bytes) : flagged_bytes;
+    PushTail tail{};
+    tail.epoch_bump = const_cast<uint64_t *>(epoch_ctr), tail.row_flags_parity_stride = row_flags_parity_stride, tail.cur_epoch = cur_epoch_word;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_row_flags_host[i]) return MI_EP_EINVAL;
+        tail.row_flag_peers.p[i] = peer_row_flags_host[i];
+    }
+    return combine_push_launch(x, src_idx, total_rows_dev, rows_hint, H, K, dst_base_host, W, slot_region_bytes, epoch_ctr, parity_stride, my_rank,
+                               local_row, &tail, stream);
+}
+
+static int combine_reduce_launch(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
+                                 const int32_t *send_data_offset, const int32_t *send_token_idx_small, int T, int K,
+                                 int H, int E, void *out, const uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
+                                 const int32_t *local_row, int local_rows, int my_rank, int num_ranks, const ReduceFlags *rf, void *stream);
+
 extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                                     const int32_t *send_data_offset, const int32_t *send_token_idx_small, int T, int K,
                                     int H, int E, void *out, const uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
                                     const int32_t *local_row, int local_rows, int my_rank, int num_ranks, void *stream)
+{
+    return combine_reduce_launch(slots, topk_idx, idx_is_i32, topk_weights, send_data_offset, send_token_idx_small, T, K, H, E, out, epoch_ctr,
+                                 parity_stride, x_local, local_row, local_rows, my_rank, num_ranks, nullptr, stream);
+}
+
+// the reduce of the two-launch combine: waits per selection for the row flags mi_ep_combine_push_flagged raises, completes the call counter
+extern "C" int mi_ep_combine_reduce_flagged(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights, int T, int K, int H,
+                                            int E, void *out, uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
+                                            const int32_t *local_row, int local_rows, int my_rank, int num_ranks, const uint32_t *my_row_flags,
+                                            size_t row_flags_parity_stride, const uint64_t *cur_epoch_word, int32_t *status, int timeout_ms,
+                                            void *stream)
+{
+    if (!epoch_ctr || !my_row_flags || !cur_epoch_word || !status || T < 0 || K <= 0 ||
+        (unsigned long long)T * (unsigned long long)K > row_flags_parity_stride / sizeof(uint32_t))
+        return MI_EP_EINVAL;
+    ReduceFlags rf{};
+    rf.row_flags = my_row_flags, rf.parity_stride = row_flags_parity_stride, rf.epoch_bump = epoch_ctr, rf.cur_epoch = cur_epoch_word, rf.status = status;
+    rf.timeout_ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
+    // (the ping-pong half comes from the epoch word the push left, not from the completed-call counter this launch moves)
+    return combine_reduce_launch(slots, topk_idx, idx_is_i32, topk_weights, nullptr, nullptr, T, K, H, E, out, cur_epoch_word, parity_stride, x_local,
+                                 local_row, local_rows, my_rank, num_ranks, &rf, stream);
+}
+
+static int combine_reduce_launch(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
+                                 const int32_t *send_data_offset, const int32_t *send_token_idx_small, int T, int K,
+                                 int H, int E, void *out, const uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
+                                 const int32_t *local_row, int local_rows, int my_rank, int num_ranks, const ReduceFlags *rf, void *stream)
 {
     if ((send_data_offset == nullptr) != (send_token_idx_small == nullptr)) return MI_EP_EINVAL;
     if (x_local && (!local_row || local_rows <= 0 || num_ranks <= 0 || E % num_ranks || my_rank < 0 || my_rank >= num_ranks ||
                     send_data_offset))
         return MI_EP_EINVAL;
     if (T < 0 || K <= 0 || K > MI_EP_MAX_TOPK || H <= 0 || H % 8 || E <= 0) return MI_EP_EINVAL;
-    if (T == 0) return MI_EP_OK;
-    if (!slots || !topk_idx || !out) return MI_EP_EINVAL;
+    if (T == 0 && !rf) return MI_EP_OK;           // (flagged form: an empty batch still completes the call counter -- one idle workgroup)
+    if (T > 0 && (!slots || !topk_idx || !out)) return MI_EP_EINVAL;
     const int nchunks = H / 8;
     const int max_segs = (nchunks + kWave - 1) / kWave;
     // one wave per (token, 512-element segment) at every size: measured at C2 (4096 tokens) 95.8 us against 103 us with one wave
@@ -368,20 +486,29 @@ extern "C" int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int
     static const long long target = getenv("MI_EP_REDUCE_WAVES") ? atoll(getenv("MI_EP_REDUCE_WAVES")) : (1ll << 40);
     while (segs < max_segs && (long long)T * segs < target) segs <<= 1;
     if (segs > max_segs) segs = max_segs;
+    // flagged form: the waves WAIT for rows -- keep the launch to ~1024 workgroups (half the chip's slots), so that a chip shared by several
+    // processes (the one-GPU test setups) always has room for the launches that produce those rows
+    if (rf) while (segs > 1 && (long long)T * segs > 4096) segs >>= 1;
     const long long waves = (long long)T * segs;
     if (waves > 0x7fffffffll) return MI_EP_EINVAL;          // the kernel's wave index is 32 bits wide
     const int wpb = 4;
-    const long long blocks = (waves + wpb - 1) / wpb;
+    const long long blocks = std::max<long long>((waves + wpb - 1) / wpb, 1);
     hipStream_t s = (hipStream_t)stream;
     const Parity par = make_parity(epoch_ctr, 0, parity_stride);
+    const ReduceFlags rfv = rf ? *rf : ReduceFlags{};
     // top-k <= 8 (DeepSeek-V3) gets its own instantiation: half the row registers, twice the waves per SIMD
-#define MI_EP_REDUCE(I32, KMAX)                                                                                                    \
-    combine_reduce_kernel<I32, KMAX><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H), topk_idx, \
+#define MI_EP_REDUCE(I32, KMAX, FL)                                                                                                \
+    combine_reduce_kernel<I32, KMAX, FL><<<(int)blocks, kWave * wpb, 0, s>>>((const uint8_t *)slots, mi_ep_combine_row_bytes(H), topk_idx, \
                                                                          topk_weights, send_data_offset, send_token_idx_small, T, K, H,  \
                                                                          E, segs, (uint16_t *)out, par, (const uint8_t *)x_local,   \
-                                                                         local_row, local_rows, my_rank, x_local ? E / num_ranks : 1)
-    if (K <= 8) { if (idx_is_i32) MI_EP_REDUCE(true, 8); else MI_EP_REDUCE(false, 8); }
-    else { if (idx_is_i32) MI_EP_REDUCE(true, MI_EP_MAX_TOPK); else MI_EP_REDUCE(false, MI_EP_MAX_TOPK); }
+                                                                         local_row, local_rows, my_rank, x_local ? E / num_ranks : 1, rfv)
+#define MI_EP_REDUCE_K(FL)                                                                                                          \
+    do {                                                                                                                            \
+        if (K <= 8) { if (idx_is_i32) MI_EP_REDUCE(true, 8, FL); else MI_EP_REDUCE(false, 8, FL); }                                 \
+        else { if (idx_is_i32) MI_EP_REDUCE(true, MI_EP_MAX_TOPK, FL); else MI_EP_REDUCE(false, MI_EP_MAX_TOPK, FL); }              \
+    } while (0)
+    if (rf) MI_EP_REDUCE_K(true); else MI_EP_REDUCE_K(false);
+#undef MI_EP_REDUCE_K
 #undef MI_EP_REDUCE
     return launch_status();
 }

@@ -103,7 +103,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(void *row, int bytes)
 struct LateIdx {
     const int32_t *ids;        // LDS: expert id of pair p = t * K + k, -1 = no selection; NULL: the layout ran in an earlier launch
     int kpart;                 // the selection this wave sends
+    uint32_t tag;              // != 0 (tagged rows, mi_ep_ll_dispatch_layout_send_tagged): the row's meta word 3 = src_rank | tag << 8, written
+                               // only when the row's payload has drained -- the receiver waits for the tag instead of for a count exchange
 };
+// 24-bit, never zero: the tag of the call with epoch `ep64` (a slab half is rewritten every second call, so a stale row carries another tag)
+__device__ __forceinline__ uint32_t ll_row_tag(uint64_t ep64) { return (uint32_t)(ep64 % 0xFFFFFFull) + 1u; }
 template <bool I32, bool LATE>
 __device__ __forceinline__ void route_token(const LLGeom &ll, const void *topk_idx, const int32_t *idx_small, const int32_t *send_off, int t,
                                             int K, int E, int my_rank, const LateIdx &late, long long &e_l, int &slot_l, int &dst_l)
@@ -263,7 +267,12 @@ __device__ __forceinline__ void stage_int8_body(
                 const int item = it * kWave + lane;
                 if (item < nitems) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, q[it]), d, item * 16, 0, 17);
             }
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, meta), d, H, 0, 17);
+            u32x4 m = meta;
+            if (late.tag) {                                 // tagged rows: the payload is at its owner before the meta word says so
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                m[3] = (uint32_t)my_rank | (late.tag << 8);
+            }
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, m), d, H, 0, 17);
             continue;
         }
         u32x4 *dst = (u32x4 *)row;
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_int8_kernel(
     PushGeom pg, Parity par)
 {
     stage_int8_body<I32, QM, false>(x, topk_idx, idx_small, send_off, T, K, H, E, my_rank, dsts, ll, ksplit, idx_off, pg, par,
-                                    (int)(blockIdx.x * kStageWaves + threadIdx.x / kWave), LateIdx{nullptr, 0});
+                                    (int)(blockIdx.x * kStageWaves + threadIdx.x / kWave), LateIdx{nullptr, 0, 0u});
 }
 
 // stage, BF16 (no quantisation): item = one 16-B chunk
@@ -344,7 +353,12 @@ __device__ __forceinline__ void stage_bf16_body(
                 const int item = it * kWave + lane;
                 if (item < nitems) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, raw[it]), d, item * 16, 0, 17);
             }
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, meta), d, H * 2, 0, 17);
+            u32x4 m = meta;
+            if (late.tag) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                m[3] = (uint32_t)my_rank | (late.tag << 8);
+            }
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, m), d, H * 2, 0, 17);
             continue;
         }
         u32x4 *dst = (u32x4 *)row;
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(kWave * kStageWaves) void stage_bf16_kernel(
     PushGeom pg, Parity par)
 {
     stage_bf16_body<I32, false>(x, topk_idx, idx_small, send_off, T, K, H, E, my_rank, dsts, ll, ksplit, idx_off, pg, par,
-                                (int)(blockIdx.x * kStageWaves + threadIdx.x / kWave), LateIdx{nullptr, 0});
+                                (int)(blockIdx.x * kStageWaves + threadIdx.x / kWave), LateIdx{nullptr, 0, 0u});
 }
 
 // The count exchange of a low-latency dispatch, run by ONE workgroup (of any size up to 1024 threads): post this rank's per-expert counts
@@ -441,6 +455,10 @@ struct LLTail {
     int64_t *packed_recv_count;
     int32_t *status;
     uint64_t timeout_ticks;
+    // TAGGED form (arrive == NULL, cur_epoch set; mi_ep_ll_dispatch_layout_send_tagged): nobody waits for anybody in this launch -- the layout
+    // workgroup posts this rank's per-expert counts to the peers as soon as it has them and leaves the call's epoch at *cur_epoch, the send
+    // waves tag their rows; the packing launch (ll_wait_pack_kernel) collects counts and rows itself.
+    uint64_t *cur_epoch;
 };
 
 // Low-latency dispatch, layout + send in ONE launch of 1024-thread workgroups: workgroup 0 computes the layout tables of the batch
@@ -459,6 +477,18 @@ __global__ __launch_bounds__(1024) void ll_layout_send_kernel(
     if (blockIdx.x == 0) {
         layout_small_body<I32, UT>(topk_idx, T, K, E, W, nbits, num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank,
                                    send_token_idx_small, send_data_offset, nullptr, nullptr, smem, 1, 0);
+        if (tail.cur_epoch) {
+            __syncthreads();                                    // num_tokens_per_expert as this workgroup wrote it
+            const uint64_t ep64 = *tail.epoch_bump + 1ull;
+            const size_t cpoff = (size_t)(ep64 & 1ull) * tail.counts_parity_stride;
+            const int L = tail.L;
+            for (int i = threadIdx.x; i < L * W; i += blockDim.x) {
+                const int d = i / L, le = i % L;
+                sys_store_u64_relaxed((uint64_t *)((uint8_t *)tail.count_peers.p[d] + cpoff) + (size_t)le * W + my_rank,
+                                      ((uint64_t)(uint32_t)ep64 << 32) | (uint32_t)num_tokens_per_expert[d * L + le]);
+            }
+            if (threadIdx.x == 0) *tail.cur_epoch = ep64;
+        }
         if (!tail.arrive) return;
     } else {
         const int npairs = T * K;
@@ -472,7 +502,7 @@ __global__ __launch_bounds__(1024) void ll_layout_send_kernel(
         const int wave = (int)(threadIdx.x / kWave);
         const int wid = (int)(blockIdx.x - 1) * send_waves + wave;
         if (wave < send_waves && wid < npairs) {
-            const LateIdx late{smem, wid % K};
+            const LateIdx late{smem, wid % K, tail.cur_epoch ? ll_row_tag(*tail.epoch_bump + 1ull) : 0u};
             if (QM == MI_EP_QUANT_NONE)
                 stage_bf16_body<I32, true>(x, topk_idx, nullptr, nullptr, T, K, H, E, my_rank, dsts, ll, K, (size_t)0, PushGeom{0, 0}, par, wid, late);
             else
@@ -591,6 +621,99 @@ __global__ __launch_bounds__(kWave * kPullWaves) void pull_kernel(
     __syncthreads();
     pull_body(srcs, cum, pull_offset, seg_capacity, W, LW, payload_bytes, recv_x, recv_scales, recv_src_idx, row_capacity,
               parity_off(par));
+}
+
+// The packing launch of the TAGGED low-latency dispatch: every workgroup collects the L*W count granules itself (they were posted at the head
+// of the peers' send launches), scans them, and packs rows [0, total) -- waiting (bounded) for the tag in each row's meta word before it
+// copies the row.  Workgroup 0 writes the tables and completes the call counter (nothing in this launch reads it: epoch and ping-pong halves
+// come from *cur_epoch, left by this rank's own send launch).
+__global__ __launch_bounds__(kWave * kPullWaves) void ll_wait_pack_kernel(
+    const uint8_t *__restrict__ my_rows, const uint64_t *__restrict__ granules_base, size_t counts_parity_stride, size_t rows_parity_stride,
+    const uint64_t *__restrict__ cur_epoch, uint64_t *epoch_bump, int seg_capacity, int W, int L, int payload_bytes, int count_type,
+    uint8_t *__restrict__ recv_x, float *__restrict__ recv_scales, int32_t *__restrict__ recv_src_idx, int32_t *__restrict__ layout_range,
+    int64_t *__restrict__ packed_recv_count, int row_capacity, int32_t *status, uint64_t timeout_ticks)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t c[];       // [LW] counts -> inclusive cumsum, [16] wave totals
+    const int LW = L * W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t ep64 = *cur_epoch;
+    const uint32_t epoch = (uint32_t)ep64, tag = ll_row_tag(ep64);
+    const uint64_t *granules = (const uint64_t *)((const uint8_t *)granules_base + (size_t)(ep64 & 1ull) * counts_parity_stride);
+    const uint64_t t0 = ticks_100mhz();
+    for (int i = tid; i < LW; i += blockDim.x) {
+        uint64_t g;
+        while (((g = sys_load_u64(granules + i)) >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (ticks_100mhz() - t0 > timeout_ticks) {
+                if (blockIdx.x == 0) report_status(status, 2000 + i);
+                g = 0;
+                break;
+            }
+        }
+        c[i] = (int32_t)(uint32_t)g;
+    }
+    __syncthreads();
+    {   // inclusive scan of c[0..LW) (as ll_counts_body)
+        int32_t *wave_tot = c + LW;
+        const int per = (LW + (int)blockDim.x - 1) / (int)blockDim.x;
+        const int b0 = min(LW, tid * per), b1 = min(LW, b0 + per);
+        int32_t sum = 0;
+        for (int i = b0; i < b1; ++i) sum += c[i];
+        const int32_t inc = wave_incl_scan_i32(sum);
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        int32_t run = inc - sum;
+        for (int w = 0; w < wave; ++w) run += wave_tot[w];
+        for (int i = b0; i < b1; ++i) {
+            run += c[i];
+            c[i] = run;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < LW; i += blockDim.x) layout_range[i] = c[i];
+        for (int le = tid; le < L; le += blockDim.x) {
+            const int32_t end = c[(le + 1) * W - 1], beg = le ? c[le * W - 1] : 0;
+            packed_recv_count[le] = (count_type == 0) ? (int64_t)end : (int64_t)(end - beg);
+        }
+        if (tid == 0) *epoch_bump = ep64;
+    }
+    // rows (pull_body with the tag wait in front of every row)
+    const int total = min(c[LW - 1], row_capacity);
+    const size_t stride = MI_EP_ROW_STRIDE(payload_bytes), poff = (size_t)(ep64 & 1ull) * rows_parity_stride;
+    const int n16 = payload_bytes / 16;
+#pragma unroll 1
+    for (long long r = (long long)blockIdx.x * kPullWaves + wave; r < total; r += (long long)gridDim.x * kPullWaves) {
+        int lo = 0, hi = LW - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] > r) hi = mid; else lo = mid + 1;
+        }
+        const int i = lo;
+        const int j = (int)(r - (i ? c[i - 1] : 0));
+        const uint8_t *srow = my_rows + poff + ((size_t)i * seg_capacity + j) * stride;
+        if (lane == 0) {
+            const uint32_t *m3 = (const uint32_t *)(srow + payload_bytes) + 3;
+            while ((__hip_atomic_load(m3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 8) != tag) {
+                __builtin_amdgcn_s_sleep(2);
+                if (ticks_100mhz() - t0 > timeout_ticks) {
+                    report_status(status, 2500 + i % 400);
+                    break;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");                     // the wave reconverges behind lane 0's wait: the row is read after its tag was seen
+        copy_row<true, false>((const u32x4 *)srow, (u32x4 *)(recv_x + (size_t)r * payload_bytes), n16, lane);
+        if (lane == 0) {
+            const uint32_t *mw = (const uint32_t *)(srow + payload_bytes);      // (read like the tag: past every cache)
+            u32x4 m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m[q] = __hip_atomic_load(mw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (recv_scales) recv_scales[r] = __uint_as_float(m[0]);
+            recv_src_idx[r * 3 + 0] = (int32_t)(m[3] & 0xFFu);
+            recv_src_idx[r * 3 + 1] = (int32_t)m[1];
+            recv_src_idx[r * 3 + 2] = (int32_t)m[2];
+        }
+    }
 }
 
 // pull for compact staging (mi_ep_dispatch_stage_compact): output row r of segment (le, src), position j, is token row
@@ -1169,6 +1292,48 @@ extern "C" int mi_ep_ll_dispatch_layout_send_counts(const void *x, const void *t
     return ll_layout_send_launch(x, topk_idx, idx_is_i32, T, K, H, E, W, my_rank, max_tokens, quant_mode, peer_rows_host, epoch_ctr, parity_stride,
                                  num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank, send_token_idx_small, send_data_offset, &tail,
                                  stream);
+}
+
+// layout + send with TAGGED rows and the counts posted from the head of the launch (no count exchange launch: mi_ep_ll_wait_pack follows)
+extern "C" int mi_ep_ll_dispatch_layout_send_tagged(const void *x, const void *topk_idx, int idx_is_i32, int T, int K, int H, int E, int W,
+                                                   int my_rank, int max_tokens, int quant_mode, void *const *peer_rows_host,
+                                                   const uint64_t *epoch_ctr, size_t parity_stride, int32_t *num_tokens_per_rank,
+                                                   int32_t *num_tokens_per_expert, int32_t *is_token_in_rank, int32_t *send_token_idx_small,
+                                                   int32_t *send_data_offset, uint64_t *const *peer_counts_host, size_t counts_parity_stride,
+                                                   uint64_t *cur_epoch_word, void *stream)
+{
+    if (!epoch_ctr || !peer_counts_host || !cur_epoch_word || W <= 0 || W > MI_EP_MAX_RANKS || E <= 0 || E % W || E > 2048) return MI_EP_EINVAL;
+    LLTail tail{};
+    tail.counts_parity_stride = counts_parity_stride, tail.epoch_bump = const_cast<uint64_t *>(epoch_ctr), tail.L = E / W, tail.cur_epoch = cur_epoch_word;
+    for (int i = 0; i < W; ++i) {
+        if (!peer_counts_host[i]) return MI_EP_EINVAL;
+        tail.count_peers.p[i] = peer_counts_host[i];
+    }
+    return ll_layout_send_launch(x, topk_idx, idx_is_i32, T, K, H, E, W, my_rank, max_tokens, quant_mode, peer_rows_host, epoch_ctr, parity_stride,
+                                 num_tokens_per_rank, num_tokens_per_expert, is_token_in_rank, send_token_idx_small, send_data_offset, &tail,
+                                 stream);
+}
+
+// the packing launch behind mi_ep_ll_dispatch_layout_send_tagged: collects the counts, waits per row for its tag, completes *epoch_ctr
+extern "C" int mi_ep_ll_wait_pack(const void *my_rows, const uint64_t *my_counts, size_t counts_parity_stride, int W, int L, int max_tokens, int H,
+                                  int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales, int64_t *packed_recv_count,
+                                  int32_t *src_info, int32_t *layout_range, int rows_capacity, const uint64_t *cur_epoch_word, uint64_t *epoch_ctr,
+                                  size_t rows_parity_stride, int32_t *status, int timeout_ms, void *stream)
+{
+    if (!my_rows || !my_counts || !packed_recv_x || !packed_recv_count || !src_info || !layout_range || !cur_epoch_word || !epoch_ctr || !status ||
+        W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || L * W > 2048 || H <= 0 || H % 16 || max_tokens <= 0)
+        return MI_EP_EINVAL;
+    const int cap = rows_capacity > 0 ? rows_capacity : L * W * max_tokens;
+    const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
+    // the waves of this launch WAIT for rows: at most 512 workgroups (a quarter of the chip's slots), the rows are grid-strided
+    long long blocks = ((long long)L * W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    ll_wait_pack_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)(L * W + 16) * 4, (hipStream_t)stream>>>(
+        (const uint8_t *)my_rows, my_counts, counts_parity_stride, rows_parity_stride, cur_epoch_word, epoch_ctr, max_tokens, W, L, payload, count_type,
+        (uint8_t *)packed_recv_x, packed_recv_x_scales, src_info, layout_range, packed_recv_count, cap, status,
+        (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull);
+    return launch_status();
 }
 
 // the packing half of mi_ep_ll_post_recv on its own: rows from this rank's slabs into the packed outputs, by the cumulative counts the

@@ -80,10 +80,15 @@ class Buffer:
         if not all(fine):        # coarse-grained window (DEEPEP_WINDOW_FINEGRAINED=0): peers' stores are not kernel-visible
             warnings.warn(f"[deep_ep rank {self.rank}] window is not fine-grained; using the alltoall strategies")
             return False
+        bus = rt.get_local_device_bus_id() if hasattr(rt, "get_local_device_bus_id") else str(rt.get_local_device_id())
         me = (socket.gethostname(), os.getpid(), rt.get_local_device_id(), bytes(rt.get_local_ipc_handle()),
-              list(rt.get_local_window_ptrs()))
+              list(rt.get_local_window_ptrs()), bus)
         everyone = [None] * self.group_size
         dist.all_gather_object(everyone, me, group=self.group)
+        # several ranks on ONE GPU (test / dry-run setups): the low-latency calls keep their three-launch forms there -- the consuming
+        # launches of the two-launch forms wait for rows in many workgroups, which needs the producers to run on GPUs of their own
+        if hasattr(rt, "set_ranks_share_device"):
+            rt.set_ranks_share_device(len({(h[0], h[5]) for h in everyone}) < self.group_size)
 
         def agree(ok: bool) -> bool:
             """Every rank reports; the step counts only if it worked everywhere.  (Also the barrier between the steps: a rank

@@ -69,12 +69,15 @@ def test_low_latency_calls_replay_in_a_captured_graph(cfg):
     _spawn(mp_workers.gpu_graph_worker, cfg[0], cfg)
 
 
-@pytest.mark.parametrize("forms", [("1", "1"), ("0", "0"), ("1", "0")], ids=["tails", "launches", "dispatch_tail_only"])
+@pytest.mark.parametrize("forms", [("1", "1"), ("0", "0"), ("1", "0"), ("0", "2"), ("2", "2"), ("2", "0")],
+                         ids=["tails", "launches", "dispatch_tail_only", "combine_row_flags", "tagged_rows_and_row_flags", "dispatch_tagged_rows_only"])
 @pytest.mark.parametrize("cfg", [(2, 24, 512, 128, 4, 8, 2), (4, 17, 1024, 128, 8, 32, 2)])
 def test_low_latency_launch_forms(cfg, forms):
     """The count exchange of a low-latency dispatch and the "rows pushed" signal + wait of a combine, each either as the TAIL of the
     launch in front of it (the last workgroup to arrive does it: MI_EP_LL_FUSED_COUNTS / MI_EP_COMBINE_FUSED = 1) or as a launch of its
-    own (= 0): same rows, tables and sums, bit-exact against the oracle, eagerly and replayed from a captured graph."""
+    own (= 0): same rows, tables and sums, bit-exact against the oracle, eagerly and replayed from a captured graph.  MI_EP_COMBINE_FUSED = 2:
+    the two-launch combine whose pushed rows raise their own flag words and whose reduce waits per selection (no exchange in between);
+    MI_EP_LL_FUSED_COUNTS = 2: the two-launch dispatch whose rows carry the call's tag and whose packing launch collects counts and rows itself."""
     import os
     keep = {k: os.environ.get(k) for k in ("MI_EP_LL_FUSED_COUNTS", "MI_EP_COMBINE_FUSED")}
     os.environ["MI_EP_LL_FUSED_COUNTS"], os.environ["MI_EP_COMBINE_FUSED"] = forms
