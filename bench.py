@@ -383,7 +383,7 @@ def xgmi_roofline(xg, projection, hbm_side, timing):
 
 # (N = 1: every received row is one of this rank's own tokens, so the whole pull is the token-wise pull_local_kernel)
 PMC_KERNEL_NAMES = {"dispatch_stage": "stage_int8_kernel<false, 1>", "dispatch_pull": "pull_local_kernel<false, true>",
-                    "combine_push": "combine_push_kernel<false>", "combine_reduce": "combine_reduce_kernel<false, 8>"}
+                    "combine_push": "combine_push_kernel<false>", "combine_reduce": "combine_reduce_kernel<false, 8, false>"}
 
 
 def pmc_traffic(kernel):

@@ -210,6 +210,54 @@ def _gpu_buffer(rank, world, port, cfg):
 
 
 # ----------------------------------------------------------------------------------------------
+# GPU: low-latency pair with a rank that has NO tokens (and ragged batches on the others), every launch form
+# ----------------------------------------------------------------------------------------------
+def gpu_ll_empty_rank_worker(rank, world, port, cfg):
+    run_guarded(_gpu_ll_empty_rank, rank, world, port, cfg)
+
+
+def _gpu_ll_empty_rank(rank, world, port, cfg):
+    import deep_ep
+    from oracle import ep as O
+    from oracle.bf16 import bits_to_torch, torch_to_bits
+    torch.cuda.set_device(0)
+    W, T0, H, K, E, quant, forms = cfg
+    os.environ["MI_EP_LL_FUSED_COUNTS"], os.environ["MI_EP_COMBINE_FUSED"] = forms
+    group = _init(rank, world, port, "gloo")
+    os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(256 << 20))
+    os.environ.setdefault("DEEPEP_TIMEOUT_MS", "20000")
+    buf = deep_ep.Buffer(group, low_latency_mode=True)
+    xs, idxs, ws = make_inputs(W, T0, H, K, E, 0.2)          # rank r has T0 + r tokens: T0 = 0 leaves rank 0 without any
+    x, ti = bits_to_torch(xs[rank]).cuda(), torch.from_numpy(idxs[rank]).cuda()
+    MT = T0 + W
+    wabs = [np.abs(w_) for w_ in ws]
+    llw = O.low_latency_dispatch(xs, idxs, MT, E, quant)
+    yls = [O.per_token_cast_back(w.packed_recv_x, w.packed_recv_x_scales) if quant else w.packed_recv_x for w in llw]
+    llc_want = O.combine(yls, [w.src_info for w in llw], [w.total for w in llw], idxs, wabs, E)
+    for it in range(3):          # three calls: both ping-pong halves and a reused one
+        rx, cnt, h, _, hook = buf.low_latency_dispatch(x, ti, MT, E, use_fp8=quant)
+        hook()
+        assert np.array_equal(cnt.cpu().numpy(), llw[rank].packed_recv_count), it
+        assert np.array_equal(h[1].cpu().numpy(), llw[rank].layout_range), it
+        nn = llw[rank].total
+        assert np.array_equal(h[0].cpu().numpy()[:3 * nn], llw[rank].src_info), it
+        if quant:
+            assert np.array_equal(rx[0].cpu().numpy()[:nn], llw[rank].packed_recv_x[:nn]), it
+            assert np.array_equal(rx[1].cpu().numpy()[:nn], llw[rank].packed_recv_x_scales[:nn]), it
+            yl = bits_to_torch(O.per_token_cast_back(llw[rank].packed_recv_x, llw[rank].packed_recv_x_scales)).cuda()
+        else:
+            assert np.array_equal(torch_to_bits(rx)[:nn], llw[rank].packed_recv_x[:nn]), it
+            yl = rx
+        outl, _, hook = buf.low_latency_combine(yl, ti, torch.from_numpy(wabs[rank]).cuda(), h)
+        hook()
+        assert tuple(outl.shape) == (xs[rank].shape[0], H)
+        assert np.array_equal(torch_to_bits(outl), llc_want[rank]), (it, "LL combine mismatch")
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
 # GPU: BASELINE C2 at full size through deep_ep.Buffer: 8 processes (one GPU here, 8 GPUs in production), 4096 tokens per rank
 # ----------------------------------------------------------------------------------------------
 def gpu_c2_size_worker(rank, world, port, cfg):

@@ -92,6 +92,14 @@ def test_low_latency_launch_forms(cfg, forms):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("forms", [("0", "0"), ("2", "2"), ("1", "1")], ids=["three_launches", "two_launches", "tails"])
+@pytest.mark.parametrize("cfg", [(1, 0, 512, 4, 8, True), (2, 0, 1024, 4, 8, True), (4, 0, 512, 8, 32, False)])      # W, T of rank 0, H, K, E, quant
+def test_low_latency_pair_with_a_rank_without_tokens(cfg, forms):
+    """Rank r brings T + r tokens, rank 0 none at all: its send launch still posts its (zero) counts and leaves the call's epoch, its combine
+    launches still complete the call counter -- in every launch form, three calls in a row (both ping-pong halves), bit-exact."""
+    _spawn(mp_workers.gpu_ll_empty_rank_worker, cfg[0], cfg + (forms,))
+
+
 @pytest.mark.parametrize("cfg", [(1, 40, 512, 128, 4, 8), (2, 33, 512, 128, 4, 8)])      # W, T, H, I, K, E
 def test_every_call_works_under_inference_mode(cfg):
     _spawn(mp_workers.gpu_inference_mode_worker, cfg[0], cfg)
