@@ -295,7 +295,9 @@ int mi_ep_combine_push_signal_wait(const void *x, const int32_t *src_idx, const 
  * whose waves wait (bounded by timeout_ms, code 3000 + k through *status) for the words of their token's valid, non-local selections before
  * they read the rows.  The push leaves the call's epoch at *cur_epoch_word (a word of the rank's own control area, the same for both calls; it
  * is launched even without rows), the reduce takes epoch and ping-pong half from there and completes *epoch_ctr.
- * No "rows pushed" flag exchange, no single-workgroup launch between the two; same bytes in the same slots, same sum. */
+ * No "rows pushed" flag exchange, no single-workgroup launch between the two; same bytes in the same slots, same sum.
+ * max_blocks (here and in mi_ep_ll_wait_pack): 0, or a cap on the workgroups of the WAITING launch -- for ranks that share one GPU (test setups):
+ * two waiting workgroups of one process on every CU kept another process's 1024-thread send workgroups from starting (64 is safe). */
 int mi_ep_combine_push_flagged(const void *x, const int32_t *src_idx, const int32_t *total_rows_dev, int rows_hint, int hidden, int num_topk,
                                void *const *dst_base_host, int num_ranks, size_t slot_region_bytes, const uint64_t *epoch_ctr,
                                size_t parity_stride, int my_rank, int32_t *local_row, uint32_t *const *peer_row_flags_host,
@@ -303,7 +305,8 @@ int mi_ep_combine_push_flagged(const void *x, const int32_t *src_idx, const int3
 int mi_ep_combine_reduce_flagged(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights, int num_tokens, int num_topk,
                                  int hidden, int num_experts, void *out, uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
                                  const int32_t *local_row, int local_rows, int my_rank, int num_ranks, const uint32_t *my_row_flags,
-                                 size_t row_flags_parity_stride, const uint64_t *cur_epoch_word, int32_t *status, int timeout_ms, void *stream);
+                                 size_t row_flags_parity_stride, const uint64_t *cur_epoch_word, int32_t *status, int timeout_ms, int max_blocks,
+                                 void *stream);
 int mi_ep_combine_reduce(const void *slots, const void *topk_idx, int idx_is_i32, const float *topk_weights,
                          const int32_t *send_data_offset, const int32_t *send_token_idx_small, int num_tokens,
                          int num_topk, int hidden, int num_experts, void *out, const uint64_t *epoch_ctr, size_t parity_stride,
@@ -390,7 +393,7 @@ int mi_ep_ll_dispatch_layout_send_tagged(const void *x, const void *topk_idx, in
 int mi_ep_ll_wait_pack(const void *my_rows, const uint64_t *my_counts, size_t counts_parity_stride, int num_ranks, int num_local_experts,
                        int max_tokens, int hidden, int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales,
                        int64_t *packed_recv_count, int32_t *src_info, int32_t *layout_range, int rows_capacity, const uint64_t *cur_epoch_word,
-                       uint64_t *epoch_ctr, size_t rows_parity_stride, int32_t *status, int timeout_ms, void *stream);
+                       uint64_t *epoch_ctr, size_t rows_parity_stride, int32_t *status, int timeout_ms, int max_blocks, void *stream);
 int mi_ep_ll_pack(const void *my_rows, const int32_t *layout_range, int num_ranks, int num_local_experts, int max_tokens, int hidden,
                   int quant_mode, void *packed_recv_x, float *packed_recv_x_scales, int32_t *src_info, int rows_capacity,
                   const uint64_t *epoch_ctr, size_t rows_parity_stride, void *stream);

@@ -903,7 +903,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
                                        qm == MI_EP_QUANT_NONE ? nullptr : packed_recv_x_scales.data_ptr<float>(),
                                        (int64_t *)packed_recv_count.data_ptr(), expand_idx.data_ptr<int>(), ep_recv_count.data_ptr<int>(),
                                        rows_capacity, (const uint64_t *)(window + kOffEpochs + 1024 + 136), ctr, region_bytes, status_dev,
-                                       timeout_ms, st));
+                                       timeout_ms, ranks_share_device ? 64 : 0, st));
     } else if (counts_done) {
         ProfScope ps_(this, "ll_dispatch_recv", st);
         MI_EP_CHECK(mi_ep_ll_pack(family_base(kLLDispatch), ep_recv_count.data_ptr<int>(), W, L, MT, H, qm, packed_recv_x.data_ptr(),
@@ -1062,7 +1062,8 @@ at::Tensor Buffer::combine_finish(const at::Tensor &topk_idx, const float *topk_
                                                  use_local ? x_local.data_ptr() : nullptr, use_local ? local_row.data_ptr<int>() : nullptr,
                                                  use_local ? (int)x_local.size(0) : 0, (int)rank, W,
                                                  (const uint32_t *)(window + kOffRowFlags), (size_t)kRowFlagsParityBytes,
-                                                 (const uint64_t *)(window + kOffEpochs + 1024 + 128), status_dev, timeout_ms, st));
+                                                 (const uint64_t *)(window + kOffEpochs + 1024 + 128), status_dev, timeout_ms,
+                                                 ranks_share_device ? 64 : 0, st));
         return combined_x;
     }
     if (!signalled) { ProfScope ps_(this, "combine_signal_wait", st);

@@ -141,6 +141,7 @@ struct ReduceFlags {
     uint64_t *epoch_bump;         // ... so its first workgroup completes it without waiting for anybody)
     int32_t *status;
     uint64_t timeout_ticks;
+    int max_blocks;               // host side only: > 0 caps the launch (ranks sharing one GPU)
 };
 template <bool I32, int KMAX, bool FLAGGED>
 __device__ __forceinline__ void combine_reduce_body(
@@ -453,7 +454,7 @@ extern "C" int mi_ep_combine_reduce_flagged(const void *slots, const void *topk_
                                             int E, void *out, uint64_t *epoch_ctr, size_t parity_stride, const void *x_local,
                                             const int32_t *local_row, int local_rows, int my_rank, int num_ranks, const uint32_t *my_row_flags,
                                             size_t row_flags_parity_stride, const uint64_t *cur_epoch_word, int32_t *status, int timeout_ms,
-                                            void *stream)
+                                            int max_blocks, void *stream)
 {
     if (!epoch_ctr || !my_row_flags || !cur_epoch_word || !status || T < 0 || K <= 0 ||
         (unsigned long long)T * (unsigned long long)K > row_flags_parity_stride / sizeof(uint32_t))
@@ -461,6 +462,7 @@ extern "C" int mi_ep_combine_reduce_flagged(const void *slots, const void *topk_
     ReduceFlags rf{};
     rf.row_flags = my_row_flags, rf.parity_stride = row_flags_parity_stride, rf.epoch_bump = epoch_ctr, rf.cur_epoch = cur_epoch_word, rf.status = status;
     rf.timeout_ticks = (uint64_t)(timeout_ms > 0 ? timeout_ms : 10000) * 100000ull;
+    rf.max_blocks = max_blocks;
     // (the ping-pong half comes from the epoch word the push left, not from the completed-call counter this launch moves)
     return combine_reduce_launch(slots, topk_idx, idx_is_i32, topk_weights, nullptr, nullptr, T, K, H, E, out, cur_epoch_word, parity_stride, x_local,
                                  local_row, local_rows, my_rank, num_ranks, &rf, stream);
@@ -488,7 +490,7 @@ static int combine_reduce_launch(const void *slots, const void *topk_idx, int id
     if (segs > max_segs) segs = max_segs;
     // flagged form: the waves WAIT for rows -- keep the launch to ~1024 workgroups (half the chip's slots), so that a chip shared by several
     // processes (the one-GPU test setups) always has room for the launches that produce those rows
-    if (rf) while (segs > 1 && (long long)T * segs > 4096) segs >>= 1;
+    if (rf) while (segs > 1 && (long long)T * segs > 4ll * (rf->max_blocks > 0 ? rf->max_blocks : 1024)) segs >>= 1;
     const long long waves = (long long)T * segs;
     if (waves > 0x7fffffffll) return MI_EP_EINVAL;          // the kernel's wave index is 32 bits wide
     const int wpb = 4;

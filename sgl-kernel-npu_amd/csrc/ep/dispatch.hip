@@ -1318,7 +1318,7 @@ extern "C" int mi_ep_ll_dispatch_layout_send_tagged(const void *x, const void *t
 extern "C" int mi_ep_ll_wait_pack(const void *my_rows, const uint64_t *my_counts, size_t counts_parity_stride, int W, int L, int max_tokens, int H,
                                   int quant_mode, int count_type, void *packed_recv_x, float *packed_recv_x_scales, int64_t *packed_recv_count,
                                   int32_t *src_info, int32_t *layout_range, int rows_capacity, const uint64_t *cur_epoch_word, uint64_t *epoch_ctr,
-                                  size_t rows_parity_stride, int32_t *status, int timeout_ms, void *stream)
+                                  size_t rows_parity_stride, int32_t *status, int timeout_ms, int max_blocks, void *stream)
 {
     if (!my_rows || !my_counts || !packed_recv_x || !packed_recv_count || !src_info || !layout_range || !cur_epoch_word || !epoch_ctr || !status ||
         W <= 0 || W > MI_EP_MAX_RANKS || L <= 0 || L * W > 2048 || H <= 0 || H % 16 || max_tokens <= 0)
@@ -1327,7 +1327,13 @@ extern "C" int mi_ep_ll_wait_pack(const void *my_rows, const uint64_t *my_counts
     const int payload = H * (quant_mode == MI_EP_QUANT_NONE ? 2 : 1);
     // the waves of this launch WAIT for rows: at most 512 workgroups (a quarter of the chip's slots), the rows are grid-strided
     long long blocks = ((long long)L * W * max_tokens + kPullRowsPerBlock - 1) / kPullRowsPerBlock;
-    if (blocks > 512) blocks = 512;
+    // MI_EP_LL_WAIT_BLOCKS (measurement / shared-GPU setups): with two PROCESSES on one GPU, 512 waiting workgroups of one (two on every CU) keep
+    // the other's 1024-thread send workgroups from starting -- (2 ranks, 300 tokens, H = 2048) timed out in half of the runs and took 9-30 s in
+    // the others; capped at 64 the same case runs in 2 s every time, and a longer sleep between polls changes nothing (it is placement, not
+    // polling traffic).  Ranks that share a GPU therefore default to the three-launch form (deep_ep.hpp); one rank per GPU has no such peer.
+    static const long long cap_env = getenv("MI_EP_LL_WAIT_BLOCKS") ? atoll(getenv("MI_EP_LL_WAIT_BLOCKS")) : 512;
+    if (blocks > cap_env) blocks = cap_env;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;      // (the caller knows that ranks share this GPU)
     if (blocks < 1) blocks = 1;
     ll_wait_pack_kernel<<<(int)blocks, kWave * kPullWaves, (size_t)(L * W + 16) * 4, (hipStream_t)stream>>>(
         (const uint8_t *)my_rows, my_counts, counts_parity_stride, rows_parity_stride, cur_epoch_word, epoch_ctr, max_tokens, W, L, payload, count_type,
