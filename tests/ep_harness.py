@@ -49,6 +49,15 @@ def _lib():
     lib.mi_ep_ll_dispatch_layout_send.restype = c_int
     lib.mi_ep_ll_post_counts.argtypes = [V, V, I, I, I, c_uint32, V]
     lib.mi_ep_ll_dispatch_recv.argtypes = [V, V, c_uint32, I, I, I, I, I, I, V, V, V, V, V, I, V, I, V]
+    # two-launch low-latency forms (tagged rows / row flags)
+    lib.mi_ep_ll_dispatch_layout_send_tagged.argtypes = [V, V, I, I, I, I, I, I, I, I, I, V, V, c_size_t, V, V, V, V, V, V, c_size_t, V, V]
+    lib.mi_ep_ll_dispatch_layout_send_tagged.restype = c_int
+    lib.mi_ep_ll_wait_pack.argtypes = [V, V, c_size_t, I, I, I, I, I, I, V, V, V, V, V, I, V, V, c_size_t, V, I, I, V]
+    lib.mi_ep_ll_wait_pack.restype = c_int
+    lib.mi_ep_combine_push_flagged.argtypes = [V, V, V, I, I, I, V, I, c_size_t, V, c_size_t, I, V, V, c_size_t, V, V]
+    lib.mi_ep_combine_push_flagged.restype = c_int
+    lib.mi_ep_combine_reduce_flagged.argtypes = [V, V, I, V, I, I, I, I, V, V, c_size_t, V, V, I, I, I, V, c_size_t, V, V, I, I, V]
+    lib.mi_ep_combine_reduce_flagged.restype = c_int
     lib.mi_ep_shared_expert_map.argtypes = [V, I, V, I, I, I, I, I, I, V, V, V]
     lib.mi_ep_shared_expert_map.restype = c_int
     for n in ("mi_ep_dispatch_layout mi_ep_signal mi_ep_wait mi_ep_notify_post mi_ep_notify_wait mi_ep_notify_tables "
@@ -311,6 +320,93 @@ class InProcEP:
         torch.cuda.synchronize()
         for r in range(W):
             assert int(self.status[r][0].item()) == 0
+        return outs
+
+
+    # ---- the two-launch low-latency forms through the C-ABI: device-resident call counters, ping-pong halves, no exchange launch.
+    # Every rank's producing launch is queued before any consuming launch (one stream): the consumers find their rows there, the waits
+    # they contain are exercised by the multi-process tests.
+    def _two_launch_state(self):
+        if not hasattr(self, "tl"):
+            W, L, K, H, MT = self.W, self.L, self.K, self.H, self.max_tokens
+            u8 = dict(dtype=torch.uint8, device=self.dev)
+            u64 = dict(dtype=torch.int64, device=self.dev)
+            rb = max(lib().mi_ep_dispatch_row_bytes(H, QUANT_NONE), lib().mi_ep_dispatch_row_bytes(H, QUANT_INT8))
+            rows_half = L * W * MT * rb
+            cb = lib().mi_ep_combine_row_bytes(H)
+            comb_half = max(MT * K, 1) * cb
+            self.tl = dict(rows_half=rows_half, cnt_half=L * W * 8, comb_half=comb_half, flag_half=max(MT * K, 1) * 4,
+                           rows=[torch.zeros(2 * rows_half, **u8) for _ in range(W)], cnts=[torch.zeros(2 * L * W, **u64) for _ in range(W)],
+                           comb=[torch.zeros(2 * comb_half, **u8) for _ in range(W)],
+                           flags=[torch.zeros(2 * max(MT * K, 1), dtype=torch.int32, device=self.dev) for _ in range(W)],
+                           ll_ctr=[torch.zeros(1, **u64) for _ in range(W)], ll_cur=[torch.zeros(1, **u64) for _ in range(W)],
+                           cb_ctr=[torch.zeros(1, **u64) for _ in range(W)], cb_cur=[torch.zeros(1, **u64) for _ in range(W)])
+        return self.tl
+
+    def ll_dispatch_tagged(self, xs, topk_idxs, quant_mode, count_type=1):
+        W, E, L, K, H, MT = self.W, self.E, self.L, self.K, self.H, self.max_tokens
+        L_ = lib()
+        tl = self._two_launch_state()
+        st = stream_ptr()
+        row_ptrs = ptr_array([t.data_ptr() for t in tl["rows"]])
+        cnt_ptrs = ptr_array([t.data_ptr() for t in tl["cnts"]])
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        keep = []
+        for r in range(W):
+            T = xs[r].shape[0]
+            f = dict(num_tokens_per_rank=torch.empty(W, **i32), num_tokens_per_expert=torch.empty(E, **i32),
+                     is_token_in_rank=torch.empty((max(T, 1), W), **i32), send_token_idx_small=torch.full((max(T, 1), K), -9, **i32),
+                     send_data_offset=torch.empty(E, **i32))
+            ck(L_.mi_ep_ll_dispatch_layout_send_tagged(ptr(xs[r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32), T, K, H, E, W, r, MT,
+                                                       quant_mode, row_ptrs, ptr(tl["ll_ctr"][r]), tl["rows_half"], ptr(f["num_tokens_per_rank"]),
+                                                       ptr(f["num_tokens_per_expert"]), ptr(f["is_token_in_rank"]), ptr(f["send_token_idx_small"]),
+                                                       ptr(f["send_data_offset"]), cnt_ptrs, tl["cnt_half"], ptr(tl["ll_cur"][r]), st))
+            keep.append(f)
+        outs = []
+        M = W * MT * min(K, L)
+        for r in range(W):
+            if quant_mode == QUANT_NONE:
+                px, ps = torch.zeros((M, H), dtype=torch.bfloat16, device=self.dev), None
+            else:
+                px, ps = torch.zeros((M, H), dtype=torch.int8, device=self.dev), torch.zeros(M, dtype=torch.float32, device=self.dev)
+            prc = torch.zeros(L, dtype=torch.int64, device=self.dev)
+            src_info = torch.zeros(max(xs[r].shape[0] * K, M * 128), **i32)
+            rng = torch.zeros(L * W, **i32)
+            ck(L_.mi_ep_ll_wait_pack(ptr(tl["rows"][r]), ptr(tl["cnts"][r]), tl["cnt_half"], W, L, MT, H, quant_mode, count_type, ptr(px), ptr(ps),
+                                     ptr(prc), ptr(src_info), ptr(rng), M, ptr(tl["ll_cur"][r]), ptr(tl["ll_ctr"][r]), tl["rows_half"],
+                                     ptr(self.status[r]), 2000, 0, st))
+            outs.append(dict(packed_recv_x=px, packed_recv_x_scales=ps, packed_recv_count=prc, src_info=src_info, layout_range=rng, layout=keep[r]))
+        torch.cuda.synchronize()
+        for r in range(W):
+            assert int(self.status[r][0].item()) == 0, self.status[r].tolist()
+        calls = [int(t.item()) for t in tl["ll_ctr"]]
+        assert len(set(calls)) == 1 and calls[0] == int(tl["ll_cur"][0].item()), (calls, "every rank completed its call counter")
+        return outs
+
+    def combine_flagged(self, ys, src_idxs, totals, topk_idxs, topk_weights):
+        W, E, K, H = self.W, self.E, self.K, self.H
+        L_ = lib()
+        tl = self._two_launch_state()
+        st = stream_ptr()
+        dst_ptrs = ptr_array([t.data_ptr() for t in tl["comb"]])
+        flag_ptrs = ptr_array([t.data_ptr() for t in tl["flags"]])
+        local_rows = [torch.full((max(topk_idxs[r].numel(), 1),), -1, dtype=torch.int32, device=self.dev) for r in range(W)]
+        for r in range(W):
+            ck(L_.mi_ep_combine_push_flagged(ptr(ys[r]), ptr(src_idxs[r]), None, int(totals[r]), H, K, dst_ptrs, W, tl["comb_half"], ptr(tl["cb_ctr"][r]),
+                                             tl["comb_half"], r, ptr(local_rows[r]), flag_ptrs, tl["flag_half"], ptr(tl["cb_cur"][r]), st))
+        outs = []
+        for r in range(W):
+            T = topk_idxs[r].shape[0]
+            out = torch.empty((T, H), dtype=torch.bfloat16, device=self.dev)
+            loc = int(totals[r]) > 0
+            ck(L_.mi_ep_combine_reduce_flagged(ptr(tl["comb"][r]), ptr(topk_idxs[r]), int(topk_idxs[r].dtype == torch.int32), ptr(topk_weights[r]), T, K, H,
+                                               E, ptr(out), ptr(tl["cb_ctr"][r]), tl["comb_half"], ptr(ys[r]) if loc else None,
+                                               ptr(local_rows[r]) if loc else None, int(ys[r].shape[0]) if loc else 0, r, W, ptr(tl["flags"][r]),
+                                               tl["flag_half"], ptr(tl["cb_cur"][r]), ptr(self.status[r]), 2000, 0, st))
+            outs.append(out)
+        torch.cuda.synchronize()
+        for r in range(W):
+            assert int(self.status[r][0].item()) == 0, self.status[r].tolist()
         return outs
 
 

@@ -356,6 +356,47 @@ def test_kernels_reproduce_committed_fixtures(path):
         assert np.array_equal(ll[r]["src_info"].cpu().numpy()[:3 * n], z[f"ll_src_info{r}"])
 
 
+@pytest.mark.parametrize("W,T,H,K,E,drop", LL_CASES)
+@pytest.mark.parametrize("quant", [False, True])
+def test_low_latency_two_launch_forms_bit_exact(W, T, H, K, E, drop, quant):
+    """mi_ep_ll_dispatch_layout_send_tagged + mi_ep_ll_wait_pack and mi_ep_combine_push_flagged + mi_ep_combine_reduce_flagged through the
+    C-ABI: same tables, rows and sums as the oracle, three calls in a row on one set of windows (device-resident call counters, both ping-pong
+    halves, tags and flag words of earlier calls left in place)."""
+    import ep_harness as Hh
+    rng = np.random.default_rng(W * 79 + T)
+    h = Hh.InProcEP(W, E, T, K, H)
+    qm = Hh.QUANT_INT8_NOEPS if quant else Hh.QUANT_NONE
+    for call in range(3):
+        Ts = [T] * W
+        if T > 1:
+            Ts[0] = T - 1
+        if T == 3 or call == 1:
+            Ts[-1] = 0                                  # a rank that sends nothing
+        xs = [rand_bits(rng, (t, H), 2.0) for t in Ts]
+        idxs = [make_topk(rng, t, K, E, drop) for t in Ts]
+        ws = [np.abs(rng.standard_normal((t, K))).astype(np.float32) for t in Ts]
+        dev_idx = [torch.from_numpy(i).int().cuda() for i in idxs]
+        got = h.ll_dispatch_tagged([dev_bf16(x) for x in xs], dev_idx, qm, 1)
+        want = O.low_latency_dispatch(xs, idxs, T, E, quant, expert_token_nums_type=1)
+        for r in range(W):
+            g, w = got[r], want[r]
+            n = w.total
+            assert np.array_equal(g["layout_range"].cpu().numpy(), w.layout_range), (call, r)
+            assert np.array_equal(g["packed_recv_count"].cpu().numpy(), w.packed_recv_count), (call, r)
+            assert np.array_equal(g["src_info"].cpu().numpy()[:3 * n], w.src_info), (call, r)
+            if quant:
+                assert np.array_equal(g["packed_recv_x"].cpu().numpy()[:n], w.packed_recv_x[:n]), (call, r)
+                assert np.array_equal(g["packed_recv_x_scales"].cpu().numpy()[:n].view(np.uint32), w.packed_recv_x_scales[:n].view(np.uint32))
+            else:
+                assert np.array_equal(torch_to_bits(g["packed_recv_x"])[:n], w.packed_recv_x[:n]), (call, r)
+        ys_np = [O.per_token_cast_back(w.packed_recv_x, w.packed_recv_x_scales) if quant else w.packed_recv_x for w in want]
+        comb_want = O.combine(ys_np, [w.src_info for w in want], [w.total for w in want], idxs, ws, E)
+        comb_got = h.combine_flagged([dev_bf16(y) for y in ys_np], [g["src_info"] for g in got], [w.total for w in want], dev_idx,
+                                     [torch.from_numpy(w_).cuda() for w_ in ws])
+        for r in range(W):
+            assert np.array_equal(torch_to_bits(comb_got[r]), comb_want[r]), (call, r)
+
+
 # ---- start-up self-test of mapped windows (C-ABI): W simulated ranks, one stream each (a rank's check kernel waits for its peers') ------
 def _selftest_run(W, rounds, first_epoch, state, bad_rank=None, stale_rank=None):
     import ep_harness as Hh
