@@ -129,6 +129,24 @@ size_t mi_ep_selftest_bytes(int num_ranks);
 int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host, const uint64_t *my_flags,
                    uint64_t *const *peer_acks_host, const uint64_t *my_acks, int num_ranks, int my_rank, uint64_t first_epoch,
                    int rounds, uint32_t tag, int32_t *status, int timeout_ms, void *stream);
+/* Second leg: the IN-LAUNCH hand-off of the two-launch low-latency forms (mi_ep_ll_dispatch_layout_send_tagged + mi_ep_ll_wait_pack,
+ * mi_ep_combine_push_flagged + mi_ep_combine_reduce_flagged; reference: the per-token flag waits of moe_distribute_combine_v2.h:952-1002 and
+ * moe_distribute_dispatch_v2.h:1159-1171).  One launch per round: producer workgroups write 4 KiB rows into every peer's scratch with
+ * write-through stores, drain, then store the row's tag (meta word behind the payload) or raise its flag word in the peer's row-flag area;
+ * consumer workgroups of the same launch poll that word (relaxed, system scope) and read the payload with system-scope loads -- the very
+ * instruction sequences of those kernels.  Rounds alternate between two halves `rows_half_stride` / `flags_half_stride` bytes apart, so round
+ * r + 2 revisits the addresses of round r under a fresh pattern, and every checked row is read once more with ordinary loads so that its
+ * lines stay in the reader's caches.  `rounds` >= 4 covers both halves twice.  Scratch: mi_ep_selftest_inlaunch_bytes(W) bytes per half of
+ * every rank's rows, mi_ep_selftest_inlaunch_flag_words(W) uint32 per half of its flag words.  Epochs continue those of mi_ep_selftest on the
+ * same ack words.  skip_payload_from_round >= 0 (test hook): from that round on this rank raises tags / flags WITHOUT rewriting the
+ * payload -- what a stale line looks like to its consumers.  status[0]: 0 = pass, 1 + s = rank s never arrived, 6000 + s = stale / corrupt
+ * payload behind a tag from s, 7000 + s = the same behind a flag word. */
+size_t mi_ep_selftest_inlaunch_bytes(int num_ranks);
+size_t mi_ep_selftest_inlaunch_flag_words(int num_ranks);
+int mi_ep_selftest_inlaunch(void *const *peer_rows_host, size_t rows_half_stride, uint32_t *const *peer_row_flags_host,
+                            size_t flags_half_stride, uint64_t *const *peer_acks_host, const uint64_t *my_acks, int num_ranks, int my_rank,
+                            uint64_t first_epoch, int rounds, uint32_t tag, int skip_payload_from_round, int32_t *status, int timeout_ms,
+                            void *stream);
 
 /* ---- A2 notify ------------------------------------------------------------------------------
  * Counts all-gather through windows.  Every rank owns `uint64_t notify[W][E+1]` granules

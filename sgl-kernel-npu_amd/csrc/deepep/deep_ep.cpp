@@ -257,6 +257,44 @@ bool Buffer::self_test(int64_t test_timeout_ms)
     return true;
 }
 
+bool Buffer::self_test_in_launch(int64_t test_timeout_ms, int64_t skip_payload_from_round)
+{
+    require_available();
+    if (num_ranks == 1) return true;
+    hipStream_t st = cur_stream();
+    constexpr int kRounds = 4;                           // both ping-pong halves twice: every address is rewritten under a reader's caches
+    const uint64_t ep = selftest_epoch + 1;
+    selftest_epoch += kRounds;
+    const int W = (int)num_ranks;
+    const size_t row_bytes = mi_ep_selftest_inlaunch_bytes(W), flag_words = mi_ep_selftest_inlaunch_flag_words(W);
+    EP_HOST_ASSERT(row_bytes <= region_bytes && flag_words * 4 <= (size_t)kRowFlagsParityBytes);
+    // scratch: the head of both halves of the low-latency segment (unused before the first call) and the LAST words of both halves of the
+    // row-flag area (the combine indexes it by t * K + k from 0); both are cleared again below
+    auto rows = peer_family_bases(kLLDispatch);
+    const size_t flag_off = (size_t)kRowFlagsParityBytes - flag_words * 4;
+    auto flag_peers = peer_ptrs((size_t)kOffRowFlags + flag_off);
+    auto ack_peers = peer_ptrs((size_t)(kOffFlags + kFlagSelfTestAck * kFlagGroupSlots * 8));
+    MI_EP_CHECK(mi_ep_selftest_inlaunch(rows.data(), region_bytes, (uint32_t *const *)flag_peers.data(), (size_t)kRowFlagsParityBytes,
+                                        (uint64_t *const *)ack_peers.data(),
+                                        (const uint64_t *)(window + kOffFlags + kFlagSelfTestAck * kFlagGroupSlots * 8), W, (int)rank, ep, kRounds,
+                                        (uint32_t)(0x1A7C0000u + ep), (int)skip_payload_from_round, status_dev, (int)test_timeout_ms, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    // (this rank's consumers have checked -- or given up on -- every row and word its peers write: its scratch can be cleared.  The tags and
+    //  flag words left there must not meet a call of the product whose epoch happens to match.)
+    for (int h = 0; h < 2; ++h) {
+        HIP_CHECK(hipMemsetAsync(family_base(kLLDispatch) + (size_t)h * region_bytes, 0, row_bytes, st));
+        HIP_CHECK(hipMemsetAsync(window + kOffRowFlags + (size_t)h * kRowFlagsParityBytes + flag_off, 0, flag_words * 4, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    const int32_t code = __atomic_load_n(status_host, __ATOMIC_ACQUIRE);
+    if (code != 0) {
+        __atomic_store_n(status_host, 0, __ATOMIC_RELEASE);
+        std::fprintf(stderr, "[deep_ep rank %lld] in-launch hand-off self-test failed with code %d\n", (long long)rank, code);
+        return false;
+    }
+    return true;
+}
+
 std::vector<std::pair<double, double>> Buffer::get_gemm_clock() const
 {
     HIP_CHECK(hipDeviceSynchronize());
@@ -812,6 +850,11 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
     Layout lay;
     at::Tensor counts_buf;
     bool counts_done = false, tagged_rows = false;
+    last_ll_call_was_combine = false;
+    // The TAGGED wire form (rows carry a tag, no count exchange launch) changes what the receivers wait for, so it is chosen from values every
+    // rank shares -- the batch bound MT, E, the env -- never from this rank's own T: a rank with T > 1024 beside ranks with T <= 1024 would
+    // otherwise send plain rows to receivers that wait for tags.  (MT <= 1024 implies T <= 1024: the one-launch layout + send fits.)
+    const bool tagged_form = fused_send && ll_launch_form("MI_EP_LL_FUSED_COUNTS") == 2 && MT <= 1024 && (size_t)16 * E <= 16384 && E % 2 == 0;
     if (fused_send && T <= 1024 && (size_t)16 * E <= 16384 && E % 2 == 0) {
         lay.T = T, lay.K = K, lay.E = E;
         // the five layout tables carved out of ONE allocation (each at::empty costs ~1-2 us of host time in front of the first launch)
@@ -838,7 +881,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
         // (ranks that share a GPU default to three launches: deep_ep.hpp, get_local_device_bus_id)
         const int ll_form = ll_launch_form("MI_EP_LL_FUSED_COUNTS");
         const bool fused_counts = ll_form == 1;
-        if (ll_form == 2) {
+        if (tagged_form) {
             auto cnt_peers0 = peer_ptrs((size_t)kOffLLCounts);
             ProfScope ps_(this, "ll_dispatch_layout_send", st);
             MI_EP_CHECK(mi_ep_ll_dispatch_layout_send_tagged(
@@ -957,7 +1000,9 @@ Buffer::low_latency_combine(const at::Tensor &x, const at::Tensor &topk_idx_user
     auto local_row = combine_local_rows(topk_idx);
     int signalled = 0;
     // (the per-row flag form needs a flag word per slot on EVERY rank: decided from num_max_dispatch_tokens_per_rank, which the ranks share)
-    const bool flag_words_ok = (int64_t)num_max_dispatch_tokens_per_rank * K <= kRowFlagsParityBytes / 4;
+    // (the last words of each half are the start-up self-test's: self_test_in_launch)
+    const bool flag_words_ok = (int64_t)num_max_dispatch_tokens_per_rank * K <=
+                               kRowFlagsParityBytes / 4 - (int64_t)mi_ep_selftest_inlaunch_flag_words(MI_EP_MAX_RANKS);
     combine_push_rows(x, src_info.data_ptr<int>(), layout_range.data_ptr<int>() + (layout_range.numel() - 1),
                       (int)std::min<int64_t>(x.size(0), src_info.numel() / 3), H, K, local_row, "ll_combine_push", st, signalled, flag_words_ok);
     // the `out=` argument is accepted and a fresh tensor is returned, as in the reference (deep_ep.cpp:1057)
@@ -1005,8 +1050,9 @@ std::string Buffer::get_local_device_bus_id() const
 int Buffer::ll_launch_form(const char *env_name) const
 {
     const char *e = getenv(env_name);
-    if (e && *e) return atoi(e);
-    return ranks_share_device ? 0 : 2;
+    const int form = e && *e ? atoi(e) : (ranks_share_device ? 0 : 2);
+    // the in-launch hand-off did not pass its start-up test on some rank: three launches, whatever was asked for
+    return form == 2 && !two_launch_forms_ok ? 0 : form;
 }
 
 uint32_t *Buffer::arrive_word() { return (uint32_t *)(window + kOffEpochs + 1024) + 2 * (arrive_calls++ % 16); }
@@ -1023,7 +1069,9 @@ void Buffer::combine_push_rows(const at::Tensor &x, const int32_t *src_idx, cons
     //   1: the signal + wait as the TAIL of the push (last workgroup to arrive): a lone low-latency combine 13.1-13.3 us against 13.5-16.0 for
     //     the three launches, but the pair inside a captured graph of ten 28.7 against 27.2 us (256 workgroups arriving at one word and a
     //     tail that waits inside the push cost more than the ~1.3 us boundary they replace); normal-mode step unchanged.
-    const int fused_form = ll_launch_form("MI_EP_COMBINE_FUSED");
+    int fused_form = ll_launch_form("MI_EP_COMBINE_FUSED");
+    if (fused_form == 2 && may_flag_rows && last_ll_call_was_combine) fused_form = 0;      // see last_ll_call_was_combine (deep_ep.hpp)
+    if (may_flag_rows) last_ll_call_was_combine = true;
     const bool fused = fused_form == 1;
     const int W = (int)num_ranks;
     auto dst_peers = peer_family_bases(kCombine);

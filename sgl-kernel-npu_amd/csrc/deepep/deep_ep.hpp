@@ -55,6 +55,19 @@ public:
     bool get_fused_rows_in_place() const { return fused_rows_in_place; }
     std::string get_dispatch_transport() const { return dispatch_transport == kTransportPush ? "push" : "pull"; }
     bool self_test(int64_t test_timeout_ms);     // collective: every rank calls it after sync()
+    // Second leg (collective, after self_test passed everywhere): the in-launch hand-off the two-launch low-latency forms rest on
+    // (mi_ep_selftest_inlaunch: tag / flag word behind a drained write-through payload, polled and read inside one launch, four rounds over
+    // both ping-pong halves).  skip_payload_from_round >= 0 is the test hook of the same name.  A failure anywhere makes deep_ep.Buffer call
+    // set_two_launch_forms(false) on every rank: the low-latency calls then keep their three-launch forms (kernel boundaries carry the
+    // ordering), not the alltoall strategies.
+    bool self_test_in_launch(int64_t test_timeout_ms, int64_t skip_payload_from_round);
+    void set_two_launch_forms(bool ok) { two_launch_forms_ok = ok; }
+    bool get_two_launch_forms() const { return two_launch_forms_ok; }
+    // the form the NEXT low_latency_dispatch / low_latency_combine would take (0 three launches, 1 tail-fused, 2 two launches)
+    std::vector<int64_t> get_low_latency_launch_forms() const
+    {
+        return {ll_launch_form("MI_EP_LL_FUSED_COUNTS"), last_ll_call_was_combine ? 0 : ll_launch_form("MI_EP_COMBINE_FUSED")};
+    }
     bool is_available() const { return available; }
     // false only when DEEPEP_WINDOW_FINEGRAINED=0 forced a coarse-grained window: peers' stores are then not guaranteed to
     // become visible inside a running kernel, so deep_ep.Buffer selects the alltoall (RCCL) strategies for W > 1.
@@ -256,6 +269,12 @@ private:
     uint32_t *arrive_word();
     uint64_t arrive_calls = 0;
     bool ranks_share_device = false;
+    bool two_launch_forms_ok = true;       // cleared when the in-launch self-test leg failed on any rank
+    // A two-launch combine is only safe behind a dispatch: its reduce waits for the ranks that serve ITS tokens, not for everybody, so with
+    // two combines back to back a rank that waits on nobody could run a call ahead and rewrite a ping-pong half its owner still reduces.
+    // The dispatch's count exchange is all-to-all and closes that; a combine that directly follows another combine on this Buffer takes the
+    // three-launch form (whose signal / wait is all-to-all).  Every rank makes the same calls, so every rank switches together.
+    bool last_ll_call_was_combine = false;
     // launch form of the low-latency dispatch / combine: the env value if set, else 2 (two launches, nothing between them) when every rank owns
     // its GPU and 0 (three launches) when ranks share one
     int ll_launch_form(const char *env_name) const;

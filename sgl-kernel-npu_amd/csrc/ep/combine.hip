@@ -195,8 +195,10 @@ __device__ __forceinline__ void combine_reduce_body(
             }
         }
     }
-    // (FLAGGED: the row loads below are issued after the flag loads above have returned -- the wait loop's exit depends on them; no cache
-    //  holds these lines: the launch touches a row only behind its flag.  An acquire fence here -- a cache invalidate per wave -- doubled the launch.)
+    // (FLAGGED: the row loads below are issued after the flag loads above have returned -- the wait loop's exit depends on them -- and are
+    //  SYSTEM-scope loads like the poll (ld_sys_b128): slot rows are 16-byte aligned, so a neighbour's read, or this half's use two calls ago,
+    //  may have left a line of this row in a cache, which a plain / nontemporal load could be answered from.  An acquire fence here instead
+    //  -- a cache invalidate per wave -- doubled the launch.)
     if constexpr (FLAGGED) asm volatile("" ::: "memory");
     const unsigned long long vmask = __ballot(valid_l);
     const uint64_t base_bits = (uint64_t)(uintptr_t)base_l;
@@ -216,14 +218,21 @@ __device__ __forceinline__ void combine_reduce_body(
     // Two elements per VALU instruction (v_pk_mul_f32, v_pk_add_f32: separately rounded, as the scalar pair was) and the hardware bf16
     // rounding: a wave instruction takes 4 cycles on the 16-lane SIMDs, and the scalar form kept them ~40 % busy (104 -> 93 us at C2).
     // read-once stream: nontemporal loads keep the 0.47 GB of slots out of L2/MALL (measured 141 -> 102 us at C2)
+    __amdgpu_buffer_rsrc_t rs[FLAGGED ? KMAX : 1];
+    if constexpr (FLAGGED) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) rs[k] = sys_row_rsrc(rowp[k], H * 2);
+    }
     auto chunk = [&](int c, auto all_tag) {
         constexpr bool ALL = decltype(all_tag)::value;
         u32x4 v[KMAX];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
+        for (int k = 0; k < KMAX; ++k) {
             // unconditional in both paths: an absent / invalid selection re-reads a row that is always there (base_l above) and is skipped in
             // the sum -- under the wave-uniform condition each load got its own block and its own vmcnt(0)
-            v[k] = __builtin_nontemporal_load((gptr)(uintptr_t)(rowp[k] + (uint32_t)c * 16u));
+            if constexpr (FLAGGED) v[k] = ld_sys_b128(rs[k], (uint32_t)c * 16u);
+            else v[k] = __builtin_nontemporal_load((gptr)(uintptr_t)(rowp[k] + (uint32_t)c * 16u));
+        }
         f32x2 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = f32x2{0.f, 0.f};

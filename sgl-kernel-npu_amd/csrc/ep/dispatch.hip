@@ -702,7 +702,8 @@ __global__ __launch_bounds__(kWave * kPullWaves) void ll_wait_pack_kernel(
             }
         }
         asm volatile("" ::: "memory");                     // the wave reconverges behind lane 0's wait: the row is read after its tag was seen
-        copy_row<true, false>((const u32x4 *)srow, (u32x4 *)(recv_x + (size_t)r * payload_bytes), n16, lane);
+        // (system-scope loads, like the poll: a line of this slab half kept by some cache since the call before last must not answer)
+        copy_row_sys<false>(srow, (u32x4 *)(recv_x + (size_t)r * payload_bytes), n16, lane);
         if (lane == 0) {
             const uint32_t *mw = (const uint32_t *)(srow + payload_bytes);      // (read like the tag: past every cache)
             u32x4 m;

@@ -153,6 +153,60 @@ __device__ __forceinline__ void copy_row_wt(const u32x4 *s16, void *d_row /* wav
     }
 }
 
+// Rows that a PEER announces from inside its own launch (a tag / flag word stored behind the drained write-through payload) and that a
+// wave of a RUNNING launch reads right after it saw that word: the payload is read with SYSTEM-scope loads (sc0 sc1, the scope of the
+// poll itself), through a buffer descriptor on the wave-uniform row base.  No cache level may answer such a load with a line it kept
+// from an earlier call on the same ping-pong half (or, where neighbouring rows share a 128-byte line, from a neighbour's read), which a
+// plain / nontemporal load does not promise; no acquire fence (a cache invalidate per wave) is needed either.  aux: sc0 = 1, sc1 = 16.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sys_row_rsrc(const void *row /* wave-uniform */, int bytes)
+{
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)(uintptr_t)row >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)row);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ld_sys_b128(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 17));
+}
+template <int N, bool NTS>
+__device__ __forceinline__ void copy_pieces_sys(__amdgpu_buffer_rsrc_t s, uint32_t off, u32x4 *d)
+{
+    u32x4 v[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = ld_sys_b128(s, off + (uint32_t)u * (kWave * 16u));
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        if (NTS) __builtin_nontemporal_store(v[u], d + u * kWave);
+        else d[u * kWave] = v[u];
+    }
+}
+template <bool NTS>
+__device__ __forceinline__ void copy_row_sys(const void *s_row /* wave-uniform */, u32x4 *d16, int n16, int lane)
+{
+    const __amdgpu_buffer_rsrc_t s = sys_row_rsrc(s_row, n16 * 16);
+    const int nfull = n16 / kWave;
+    u32x4 *d = d16 + lane;
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    int c = 0;
+    for (; c + 8 <= nfull; c += 8) copy_pieces_sys<8, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave);
+    switch (nfull - c) {
+        case 7: copy_pieces_sys<7, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave); break;
+        case 6: copy_pieces_sys<6, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave); break;
+        case 5: copy_pieces_sys<5, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave); break;
+        case 4: copy_pieces_sys<4, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave); break;
+        case 3: copy_pieces_sys<3, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave); break;
+        case 2: copy_pieces_sys<2, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave); break;
+        case 1: copy_pieces_sys<1, NTS>(s, l16 + (uint32_t)c * (kWave * 16u), d + c * kWave); break;
+        default: break;
+    }
+    const int tail = nfull * kWave + lane;
+    if (tail < n16) {
+        const u32x4 v = ld_sys_b128(s, (uint32_t)tail * 16u);
+        if (NTS) __builtin_nontemporal_store(v, d16 + tail);
+        else d16[tail] = v;
+    }
+}
+
 // 8-byte words other GPUs write/poll: always system-scope atomics, never plain accesses.
 __device__ __forceinline__ void sys_store_u64(uint64_t *p, uint64_t v)
 {

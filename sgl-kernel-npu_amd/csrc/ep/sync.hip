@@ -570,6 +570,160 @@ extern "C" int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer
     return launch_status();
 }
 
+// ---- start-up self-test, second leg: the IN-LAUNCH hand-off of the two-launch low-latency forms -----------------------------------------
+// What mi_ep_selftest above cannot show: its checks run in a launch of their own, behind a kernel boundary.  The two-launch low-latency forms
+// hand rows over INSIDE running launches (dispatch.hip: stage_*_body LATE + tag / ll_wait_pack_kernel; combine.hip: combine_push_kernel
+// FLAGGED / combine_reduce_body FLAGGED; the reference's per-token flag wait, moe_distribute_combine_v2.h:952-1002,
+// moe_distribute_dispatch_v2.h:1159-1171):
+//   producer wave   row payload with write-through stores (sc0 sc1, 16 B per lane, buffer descriptor)  ->  s_waitcnt vmcnt(0)  ->  one lane:
+//                   the tag in the row's meta word (same store flavour, "tagged" rows) or the row's flag word in the owner's control area
+//                   (relaxed system-scope store, "flagged" rows)
+//   consumer wave   one lane polls that word (relaxed, system scope), the wave then reads the payload with system-scope loads (ld_sys_b128)
+// This leg runs exactly those instruction sequences: one launch per round whose workgroups [0, W) produce for rank d and [W, 2W) consume from
+// rank s, kILRows tagged rows (128-byte aligned, 16 B of meta behind the payload) and kILRows flagged rows (16-byte aligned: neighbours share
+// cache lines) per pair, rounds alternating between the two ping-pong halves so that round r + 2 rewrites the addresses of round r under a
+// fresh pattern.  After checking a row the consumer reads it once more with ORDINARY loads and keeps nothing: the lines stay in its L1 / L2
+// the way any earlier reader may have left them, and the next visit must not be answered from there.  A producer starts round r only when
+// its consumer has acknowledged round r - 1 (nobody's rows are rewritten under a reader).
+// status[0]: 1 + s gate / word never arrived from rank s, 6000 + s stale or corrupt TAGGED payload from s, 7000 + s the same for a FLAGGED row.
+namespace mi_ep {
+constexpr int kILRows = 8;
+constexpr int kILPayload = 4096;
+constexpr int kILTagStride = kILPayload + 128;
+constexpr int kILFlagStride = kILPayload + 16;
+constexpr size_t kILPairBytes = (size_t)kILRows * (kILTagStride + kILFlagStride);
+struct InLaunchTest {
+    PeerPtrs rows, flags, acks;
+    const uint64_t *my_acks;
+    size_t rows_half_stride, flags_half_stride;
+    int W, my_rank;
+    uint64_t epoch;
+    uint32_t tag;
+    int skip_payload;          // test hook: this producer raises tags / flags without rewriting the payload (what a stale line looks like)
+};
+__device__ __forceinline__ uint32_t il_tag24(uint32_t tag, uint64_t epoch) { return ((tag ^ (uint32_t)epoch * 0x9E37u) & 0xFFFFFFu) | 1u; }
+__global__ __launch_bounds__(256) void selftest_inlaunch_kernel(InLaunchTest a, int32_t *status, uint64_t timeout_ticks)
+{
+    __shared__ int bad;
+    const int W = a.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t half = (size_t)(a.epoch & 1ull);
+    const uint64_t t0 = ticks_100mhz();
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    if ((int)blockIdx.x < W) {                                  // ---- producer for rank d
+        const int d = blockIdx.x;
+        if (tid == 0) {
+            while (sys_load_u64(a.my_acks + d) < a.epoch - 1) {
+                __builtin_amdgcn_s_sleep(8);
+                if (ticks_100mhz() - t0 > timeout_ticks) {
+                    report_status(status, 1 + d);
+                    bad = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (bad) return;
+        uint8_t *base = (uint8_t *)a.rows.p[d] + half * a.rows_half_stride + (size_t)a.my_rank * kILPairBytes;
+        for (int row = wave; row < 2 * kILRows; row += (int)blockDim.x / kWave) {
+            const bool flagged = row >= kILRows;
+            uint8_t *rp = flagged ? base + (size_t)kILRows * kILTagStride + (size_t)(row - kILRows) * kILFlagStride : base + (size_t)row * kILTagStride;
+            const __amdgpu_buffer_rsrc_t rs = sys_row_rsrc(rp, kILPayload + 16);
+            if (!a.skip_payload) {
+#pragma unroll
+                for (int u = 0; u < kILPayload / (kWave * 16); ++u) {
+                    const int i = (u * kWave + lane) * 4 + row * (kILPayload / 4);
+                    const u32x4 v = u32x4{selftest_word(a.tag, a.my_rank, d, i), selftest_word(a.tag, a.my_rank, d, i + 1),
+                                          selftest_word(a.tag, a.my_rank, d, i + 2), selftest_word(a.tag, a.my_rank, d, i + 3)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, v), rs, (u * kWave + lane) * 16, 0, 17);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the payload is at its owner before the word below says so
+            if (lane == 0) {
+                if (!flagged) {
+                    const u32x4 m = u32x4{a.tag, (uint32_t)row, 0u, (uint32_t)a.my_rank | (il_tag24(a.tag, a.epoch) << 8)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wt_u32x4, m), rs, kILPayload, 0, 17);
+                } else {
+                    uint32_t *fl = (uint32_t *)((uint8_t *)a.flags.p[d] + half * a.flags_half_stride) + a.my_rank * kILRows + (row - kILRows);
+                    __hip_atomic_store(fl, (uint32_t)a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        return;
+    }
+    // ---- consumer of rank s
+    const int s = (int)blockIdx.x - W;
+    const uint8_t *base = (const uint8_t *)a.rows.p[a.my_rank] + half * a.rows_half_stride + (size_t)s * kILPairBytes;
+    for (int row = wave; row < 2 * kILRows; row += (int)blockDim.x / kWave) {
+        const bool flagged = row >= kILRows;
+        const uint8_t *rp = flagged ? base + (size_t)kILRows * kILTagStride + (size_t)(row - kILRows) * kILFlagStride : base + (size_t)row * kILTagStride;
+        int late = 0;
+        if (lane == 0) {
+            const uint32_t *word = flagged ? (const uint32_t *)((const uint8_t *)a.flags.p[a.my_rank] + half * a.flags_half_stride) + s * kILRows + (row - kILRows)
+                                           : (const uint32_t *)(rp + kILPayload) + 3;
+            const uint32_t want = flagged ? (uint32_t)a.epoch : il_tag24(a.tag, a.epoch);
+            for (;;) {
+                const uint32_t w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((flagged ? w : w >> 8) == want) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (ticks_100mhz() - t0 > timeout_ticks) {
+                    report_status(status, 1 + s);
+                    late = 1;
+                    break;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");                         // the wave reconverges behind lane 0's wait: the row is read after its word was seen
+        if (__builtin_amdgcn_readfirstlane(late)) continue;
+        const __amdgpu_buffer_rsrc_t rs = sys_row_rsrc(rp, kILPayload);
+        u32x4 v[kILPayload / (kWave * 16)];
+#pragma unroll
+        for (int u = 0; u < kILPayload / (kWave * 16); ++u) v[u] = ld_sys_b128(rs, (uint32_t)(u * kWave + lane) * 16u);
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < kILPayload / (kWave * 16); ++u) {
+            const int i = (u * kWave + lane) * 4 + row * (kILPayload / 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ok = ok && v[u][j] == selftest_word(a.tag, s, a.my_rank, i + j);
+        }
+        if (!ok) report_status(status, (flagged ? 7000 : 6000) + s);
+        // leave the row's lines in this CU's L1 and this XCD's L2 as an ordinary reader would (nothing is kept from the loads)
+#pragma unroll
+        for (int u = 0; u < kILPayload / (kWave * 16); ++u) {
+            u32x4 w = ((const u32x4 *)rp)[u * kWave + lane];
+            asm volatile("" ::"v"(w));
+        }
+    }
+    __syncthreads();                                           // every wave's reads are done before the producer may rewrite these rows
+    if (tid == 0) sys_store_u64((uint64_t *)a.acks.p[s] + a.my_rank, a.epoch);
+}
+}  // namespace mi_ep
+
+extern "C" size_t mi_ep_selftest_inlaunch_bytes(int num_ranks) { return (size_t)num_ranks * mi_ep::kILPairBytes; }
+extern "C" size_t mi_ep_selftest_inlaunch_flag_words(int num_ranks) { return (size_t)num_ranks * mi_ep::kILRows; }
+
+extern "C" int mi_ep_selftest_inlaunch(void *const *peer_rows_host, size_t rows_half_stride, uint32_t *const *peer_row_flags_host,
+                                       size_t flags_half_stride, uint64_t *const *peer_acks_host, const uint64_t *my_acks, int W, int my_rank,
+                                       uint64_t first_epoch, int rounds, uint32_t tag, int skip_payload_from_round, int32_t *status,
+                                       int timeout_ms, void *stream)
+{
+    mi_ep::InLaunchTest a{};
+    if (fill_peers(a.rows, (const void *const *)peer_rows_host, W) || fill_peers(a.flags, (const void *const *)peer_row_flags_host, W) ||
+        fill_peers(a.acks, (const void *const *)peer_acks_host, W) || !my_acks || !status || my_rank < 0 || my_rank >= W || first_epoch == 0 ||
+        rounds < 1 || rounds > 16 || rows_half_stride < mi_ep_selftest_inlaunch_bytes(W) ||
+        flags_half_stride < mi_ep_selftest_inlaunch_flag_words(W) * 4)
+        return MI_EP_EINVAL;
+    a.my_acks = my_acks, a.rows_half_stride = rows_half_stride, a.flags_half_stride = flags_half_stride, a.W = W, a.my_rank = my_rank;
+    const uint64_t ticks = ms_to_ticks(timeout_ms);
+    for (int r = 0; r < rounds; ++r) {
+        a.epoch = first_epoch + (uint64_t)r;
+        a.tag = tag + (uint32_t)r * 0x01000193u;
+        a.skip_payload = skip_payload_from_round >= 0 && r >= skip_payload_from_round;
+        mi_ep::selftest_inlaunch_kernel<<<2 * W, 256, 0, (hipStream_t)stream>>>(a, status, ticks);
+    }
+    return launch_status();
+}
+
 // ---- diagnose helpers (only launched when the caller passes a stats tensor) -------------------------------------------
 namespace mi_ep {
 __global__ void timestamp_kernel(uint64_t *dst) { *dst = ticks_100mhz(); }

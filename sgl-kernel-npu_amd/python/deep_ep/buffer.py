@@ -119,8 +119,32 @@ class Buffer:
                 ok = False
             if not ok:
                 warnings.warn(f"[deep_ep rank {self.rank}] window self-test failed; using the alltoall strategies")
-            return agree(ok)
+            if not agree(ok):
+                return False
+            self._check_in_launch_handoff(agree)
         return True
+
+    def _check_in_launch_handoff(self, agree) -> None:
+        """Second leg of the start-up self-test: the hand-off the TWO-launch low-latency forms rest on (a tag / flag word stored behind a
+        drained write-through payload, polled and read inside one running launch -- `mi_ep_selftest_inlaunch`, four rounds over both
+        ping-pong halves).  If it fails on any rank, every rank keeps the low-latency calls on their three-launch forms, where kernel
+        boundaries carry the ordering; the windows themselves passed the first leg, so the strategies stay as they are."""
+        rt = self.runtime
+        if not hasattr(rt, "self_test_in_launch"):
+            return
+        # test hook: the named rank raises its tags / flags without rewriting the payload from round 1 on (what a stale line looks like)
+        inject = os.getenv("DEEPEP_SELF_TEST_STALE_RANK")
+        skip_from = 1 if inject is not None and int(inject) == self.rank else -1
+        try:
+            ok = bool(rt.self_test_in_launch(int(os.getenv("DEEPEP_SELF_TEST_TIMEOUT_MS", "10000")), skip_from))
+        except Exception as e:  # noqa: BLE001
+            warnings.warn(f"[deep_ep rank {self.rank}] in-launch hand-off self-test raised ({e})")
+            ok = False
+        everywhere = agree(ok)
+        rt.set_two_launch_forms(everywhere)
+        if not everywhere:
+            warnings.warn(f"[deep_ep rank {self.rank}] in-launch hand-off self-test failed"
+                          f"{'' if ok else ' on this rank'}; low-latency dispatch / combine use their three-launch forms")
 
     def _init_normal_strategy(self, strategy):
         if isinstance(strategy, NormalStrategy):

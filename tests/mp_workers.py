@@ -221,15 +221,46 @@ def _gpu_ll_empty_rank(rank, world, port, cfg):
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits
     torch.cuda.set_device(0)
-    W, T0, H, K, E, quant, forms = cfg
-    os.environ["MI_EP_LL_FUSED_COUNTS"], os.environ["MI_EP_COMBINE_FUSED"] = forms
+    W, T0, H, K, E, quant, forms = cfg[:7]
+    # optional 8th entry: stale_rank (that rank fails the in-launch self-test leg for everybody: DEEPEP_SELF_TEST_STALE_RANK), own_gpu (pretend
+    # every rank owns its GPU: default forms, waiting launches uncapped), tokens (per-rank token counts) + max_tokens, repeat_combine
+    extra = cfg[7] if len(cfg) > 7 else {}
+    if forms is not None:
+        os.environ["MI_EP_LL_FUSED_COUNTS"], os.environ["MI_EP_COMBINE_FUSED"] = forms
+    else:
+        os.environ.pop("MI_EP_LL_FUSED_COUNTS", None), os.environ.pop("MI_EP_COMBINE_FUSED", None)
+    if "stale_rank" in extra:
+        os.environ["DEEPEP_SELF_TEST_STALE_RANK"] = str(extra["stale_rank"])
     group = _init(rank, world, port, "gloo")
     os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(256 << 20))
     os.environ.setdefault("DEEPEP_TIMEOUT_MS", "20000")
-    buf = deep_ep.Buffer(group, low_latency_mode=True)
-    xs, idxs, ws = make_inputs(W, T0, H, K, E, 0.2)          # rank r has T0 + r tokens: T0 = 0 leaves rank 0 without any
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        buf = deep_ep.Buffer(group, low_latency_mode=True)
+    if extra.get("own_gpu"):
+        buf.runtime.set_ranks_share_device(False)
+    if "stale_rank" in extra and W > 1:
+        # the windows passed their first leg, the in-launch hand-off did not: the low-latency calls keep the window strategies on their
+        # three-launch forms, whatever the env asks for, and the Buffer said so
+        assert buf.p2p_available and not buf.runtime.get_two_launch_forms()
+        assert list(buf.runtime.get_low_latency_launch_forms()) == [0, 0]
+        assert any("three-launch forms" in str(c.message) for c in caught), [str(c.message) for c in caught]
+    elif W > 1:
+        assert buf.runtime.get_two_launch_forms()
+        if extra.get("own_gpu") and forms is None:
+            assert list(buf.runtime.get_low_latency_launch_forms()) == [2, 2]
+    if "tokens" in extra:
+        from oracle.bf16 import f32_to_bf16_bits_rne
+        rng = np.random.default_rng(4321)
+        xs = [f32_to_bf16_bits_rne((rng.standard_normal((t, H)) * 2).astype(np.float32)) for t in extra["tokens"]]
+        idxs = [make_topk(rng, t, K, E, 0.2) for t in extra["tokens"]]
+        ws = [rng.standard_normal((t, K)).astype(np.float32) for t in extra["tokens"]]
+        MT = extra["max_tokens"]
+    else:
+        xs, idxs, ws = make_inputs(W, T0, H, K, E, 0.2)          # rank r has T0 + r tokens: T0 = 0 leaves rank 0 without any
+        MT = T0 + W
     x, ti = bits_to_torch(xs[rank]).cuda(), torch.from_numpy(idxs[rank]).cuda()
-    MT = T0 + W
     wabs = [np.abs(w_) for w_ in ws]
     llw = O.low_latency_dispatch(xs, idxs, MT, E, quant)
     yls = [O.per_token_cast_back(w.packed_recv_x, w.packed_recv_x_scales) if quant else w.packed_recv_x for w in llw]
@@ -252,6 +283,15 @@ def _gpu_ll_empty_rank(rank, world, port, cfg):
         hook()
         assert tuple(outl.shape) == (xs[rank].shape[0], H)
         assert np.array_equal(torch_to_bits(outl), llc_want[rank]), (it, "LL combine mismatch")
+        if extra.get("repeat_combine"):
+            # a second combine on the same handle, no dispatch in between: it takes the three-launch form on every rank (a two-launch
+            # combine is only safe behind a dispatch's all-to-all count exchange) and returns the same sums
+            if W > 1 and forms is not None and forms[1] == "2":
+                assert list(buf.runtime.get_low_latency_launch_forms())[1] == 0
+            for rep in range(2):
+                outl2, _, hook = buf.low_latency_combine(yl, ti, torch.from_numpy(wabs[rank]).cuda(), h)
+                hook()
+                assert np.array_equal(torch_to_bits(outl2), llc_want[rank]), (it, rep, "repeated LL combine mismatch")
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

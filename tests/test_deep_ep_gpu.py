@@ -92,12 +92,38 @@ def test_low_latency_launch_forms(cfg, forms):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("forms", [("0", "0"), ("2", "2"), ("1", "1")], ids=["three_launches", "two_launches", "tails"])
+@pytest.mark.parametrize("forms", [("0", "0"), ("2", "2"), ("1", "1"), ("2", "0"), ("0", "2")],
+                         ids=["three_launches", "two_launches", "tails", "tagged_dispatch_three_launch_combine", "three_launch_dispatch_flagged_combine"])
 @pytest.mark.parametrize("cfg", [(1, 0, 512, 4, 8, True), (2, 0, 1024, 4, 8, True), (4, 0, 512, 8, 32, False)])      # W, T of rank 0, H, K, E, quant
 def test_low_latency_pair_with_a_rank_without_tokens(cfg, forms):
     """Rank r brings T + r tokens, rank 0 none at all: its send launch still posts its (zero) counts and leaves the call's epoch, its combine
-    launches still complete the call counter -- in every launch form, three calls in a row (both ping-pong halves), bit-exact."""
+    launches still complete the call counter -- in every launch form and both mixed pairs, three calls in a row (both ping-pong halves),
+    bit-exact."""
     _spawn(mp_workers.gpu_ll_empty_rank_worker, cfg[0], cfg + (forms,))
+
+
+@pytest.mark.parametrize("cfg", [(2, 24, 1024, 4, 8, True), (4, 9, 512, 8, 32, False)])
+def test_two_launch_forms_uncapped_as_on_a_node(cfg):
+    """The forms an 8-GPU node takes by default, taken here the same way: no env, the runtime told that every rank owns its GPU (default forms
+    2 / 2 selected by the start-up self-test's second leg, waiting launches not capped at 64 workgroups); the batches are small enough for both
+    processes' grids to be resident together.  Plus two extra combines per call on the same handle (they fall back to three launches)."""
+    _spawn(mp_workers.gpu_ll_empty_rank_worker, cfg[0], cfg + (None, {"own_gpu": True, "repeat_combine": True}))
+
+
+@pytest.mark.parametrize("forms", [("2", "2"), None], ids=["forms_forced_by_env", "default_forms"])
+def test_failed_in_launch_self_test_falls_back_to_three_launches(forms):
+    """One rank fails the second self-test leg (its tags / flags arrive in front of a payload that was not rewritten: codes 6000 + s /
+    7000 + s at its consumers): EVERY rank reports three-launch forms -- even against MI_EP_LL_FUSED_COUNTS / MI_EP_COMBINE_FUSED = 2 --,
+    the window strategies stay, and the dispatch + combine pair is bit-exact."""
+    _spawn(mp_workers.gpu_ll_empty_rank_worker, 2, (2, 5, 512, 4, 8, True, forms, {"stale_rank": 1, "own_gpu": forms is None}))
+
+
+def test_tagged_wire_form_is_chosen_from_shared_values_only():
+    """num_max_dispatch_tokens_per_rank = 1200 with 1100 tokens on rank 0 and 20 on rank 1, two-launch forms asked for: the TAGGED dispatch rows
+    need the one-launch layout + send (<= 1024 tokens), which rank 0 cannot take -- so NO rank may wait for tags.  The form follows the shared
+    bound (1200 > 1024: plain rows + count exchange everywhere), not each rank's own T; the pair is bit-exact instead of timing out."""
+    _spawn(mp_workers.gpu_ll_empty_rank_worker, 2,
+           (2, 0, 512, 4, 8, True, ("2", "2"), {"tokens": [1100, 20], "max_tokens": 1200}))
 
 
 @pytest.mark.parametrize("cfg", [(1, 40, 512, 128, 4, 8), (2, 33, 512, 128, 4, 8)])      # W, T, H, I, K, E

@@ -429,6 +429,51 @@ def _selftest_run(W, rounds, first_epoch, state, bad_rank=None, stale_rank=None)
     return [int(s[0]) for s in status]
 
 
+def _selftest_inlaunch_run(W, rounds, first_epoch, state, stale_rank=None, stale_from=1):
+    """mi_ep_selftest_inlaunch on the state of _selftest_run (same ack words, epochs continue): W simulated ranks, one stream each."""
+    import ep_harness as Hh
+    from ctypes import c_int, c_size_t, c_uint32, c_uint64, c_void_p
+    from capi import ptr, ptr_array
+    L_ = Hh.lib()
+    for fn in (L_.mi_ep_selftest_inlaunch_bytes, L_.mi_ep_selftest_inlaunch_flag_words):
+        fn.restype, fn.argtypes = c_size_t, [c_int]
+    L_.mi_ep_selftest_inlaunch.restype = c_int
+    L_.mi_ep_selftest_inlaunch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int, c_uint64, c_int, c_uint32,
+                                           c_int, c_void_p, c_int, c_void_p]
+    nb, nw = L_.mi_ep_selftest_inlaunch_bytes(W), L_.mi_ep_selftest_inlaunch_flag_words(W)
+    if "il_rows" not in state:
+        state.update(il_rows=[torch.zeros(2 * nb, dtype=torch.uint8, device="cuda") for _ in range(W)],
+                     il_flags=[torch.zeros(2 * nw, dtype=torch.int32, device="cuda") for _ in range(W)])
+    status = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(W)]
+    torch.cuda.synchronize()
+    rows_p, flags_p, acks_p = ptr_array([t.data_ptr() for t in state["il_rows"]]), ptr_array([t.data_ptr() for t in state["il_flags"]]), \
+        ptr_array([t.data_ptr() for t in state["acks"]])
+    for r in range(W):
+        rc = L_.mi_ep_selftest_inlaunch(rows_p, nb, flags_p, nw * 4, acks_p, ptr(state["acks"][r]), W, r, first_epoch, rounds,
+                                        0x1A7C0000 + first_epoch, stale_from if r == stale_rank else -1, ptr(status[r]), 2000,
+                                        c_void_p(state["streams"][r].cuda_stream))
+        assert rc == 0
+    torch.cuda.synchronize()
+    return [int(s[0]) for s in status]
+
+
+@pytest.mark.parametrize("W", [2])
+def test_window_selftest_in_launch_handoff_leg(W):
+    """mi_ep_selftest_inlaunch: tag / flag word behind a drained write-through payload, polled and read with system-scope loads inside ONE launch
+    (the hand-off of the two-launch low-latency forms), four rounds over both ping-pong halves on the same addresses; a second call continues;
+    a rank that raises its words WITHOUT rewriting the payload -- a stale line, as its consumers see it -- is reported as 6000 + s (tagged
+    row) or 7000 + s (flagged row) by every rank that consumes from it (itself included) and nobody reports the healthy rank; rounds before the
+    injection pass."""
+    state = {}
+    assert _selftest_run(W, 2, 1, state) == [0] * W                    # (first leg: leaves the ack words at epoch 2)
+    assert _selftest_inlaunch_run(W, 4, 3, state) == [0] * W
+    assert _selftest_inlaunch_run(W, 4, 7, state) == [0] * W
+    codes = _selftest_inlaunch_run(W, 4, 11, state, stale_rank=1, stale_from=2)
+    assert codes[0] in (6001, 7001), codes
+    assert codes[1] in (6001, 7001), codes      # (a rank also produces for and consumes from itself: rank 1 sees its own stale rows; nobody names rank 0)
+    assert _selftest_inlaunch_run(W, 2, 15, state) == [0] * W          # and the scratch is usable again afterwards
+
+
 @pytest.mark.parametrize("W", [2])      # in ONE process two simulated ranks get their own hardware queues; more would share one (the runtime maps streams
 def test_window_selftest_rounds_and_failure_codes(W):      # onto 4 queues) and a spinning check kernel would block its peer's post behind it.
                                                            # W = 4, 8: every multi-process deep_ep.Buffer test runs the self-test at start-up.
