@@ -139,8 +139,8 @@ int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer_flags_host
  * lines stay in the reader's caches.  `rounds` >= 4 covers both halves twice.  Scratch: mi_ep_selftest_inlaunch_bytes(W) bytes per half of
  * every rank's rows, mi_ep_selftest_inlaunch_flag_words(W) uint32 per half of its flag words.  Epochs continue those of mi_ep_selftest on the
  * same ack words.  skip_payload_from_round >= 0 (test hook): from that round on this rank raises tags / flags WITHOUT rewriting the
- * payload -- what a stale line looks like to its consumers.  status[0]: 0 = pass, 1 + s = rank s never arrived, 6000 + s = stale / corrupt
- * payload behind a tag from s, 7000 + s = the same behind a flag word. */
+ * payload -- what a stale line looks like to its consumers.  status[0]: 0 = pass, 1 + s = rank s never arrived, 7000 + s = stale / corrupt
+ * payload behind a tag from s, 7500 + s = the same behind a flag word. */
 size_t mi_ep_selftest_inlaunch_bytes(int num_ranks);
 size_t mi_ep_selftest_inlaunch_flag_words(int num_ranks);
 int mi_ep_selftest_inlaunch(void *const *peer_rows_host, size_t rows_half_stride, uint32_t *const *peer_row_flags_host,
@@ -444,6 +444,21 @@ int mi_ep_moe_gemm1_swiglu(const int8_t *a, const float *a_scale, const int8_t *
 int mi_ep_moe_gemm1_swiglu_rows(const void *a_base, const uint32_t *a_row_offsets, const float *a_scale, const int8_t *w,
                                 const float *w_scale, const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap,
                                 int hidden, int two_i, float *out, int rows_per_expert_hint, void *stream);
+/* gemm1_swiglu + rowquant in ONE launch (the reference requantises in GEMM1's epilogue as well: block_epilogue_per_token_dequant_swiglu.h:250-269,
+ * grouped_matmul_slice_m_per_token_dequant_swiglu_quant_multistage_workspace.h:199-265): the two_i / 256 column-tile workgroups of a row block
+ * exchange their rows' maxima (one atomicMax per row and workgroup + an arrival count, bounded wait) and quantise their SwiGLU values from
+ * registers -- q and q_scale carry the bits mi_ep_moe_gemm1_swiglu + mi_ep_moe_rowquant produce, no fp32 [rows, inter] intermediate exists.
+ * a_row_offsets NULL: a_base is the dense int8 [rows, hidden]; else as mi_ep_moe_gemm1_swiglu_rows.  two_i must be a multiple of 256.
+ * zeroed_words: mi_ep_moe_requant_words(rows_cap, L) uint32 that are ZERO when the launch starts (one memset per call).  xcds: the value
+ * mi_ep_moe_probe_xcds() returned on this device (how workgroups are dealt to XCDs; 1 assumes nothing about placement).  status: a
+ * device-visible word, MI_EP_STATUS_GEMM_ROWMAX is stored there if a row block's column tiles did not all arrive within timeout_ms. */
+#define MI_EP_STATUS_GEMM_ROWMAX 9000
+size_t mi_ep_moe_requant_words(int rows_cap, int num_local_experts);
+int mi_ep_moe_probe_xcds(void *stream);
+int mi_ep_moe_gemm1_swiglu_quant(const void *a_base, const uint32_t *a_row_offsets, const float *a_scale, const int8_t *w,
+                                 const float *w_scale, const int32_t *row_cumsum, int cum_stride, int num_local_experts, int rows_cap,
+                                 int hidden, int two_i, int8_t *q, float *q_scale, uint32_t *zeroed_words, int xcds, int32_t *status,
+                                 int timeout_ms, int rows_per_expert_hint, void *stream);
 int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_cap, int inter, int8_t *q, float *scale,
                        void *stream);
 int mi_ep_moe_gemm2(const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *row_cumsum,

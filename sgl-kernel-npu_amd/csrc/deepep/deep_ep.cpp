@@ -147,6 +147,9 @@ Buffer::Buffer(int64_t rank, int64_t num_ranks, int64_t num_nvl_bytes, int64_t n
     std::memset(status_host, 0, sizeof(int32_t) * 4);
     HIP_CHECK(hipHostGetDevicePointer((void **)&summary_dev, summary_host, 0));
     HIP_CHECK(hipHostGetDevicePointer((void **)&status_dev, status_host, 0));
+    // how this device deals workgroups to its XCDs (8 on an MI355X: block b on XCD b % 8; 1 = nothing assumed): the requantising GEMM1 of
+    // fused_deep_moe forms its workers from it (moe_gemm.hip)
+    gemm_xcds = mi_ep_moe_probe_xcds(nullptr);
     peer_seg.assign((size_t)num_ranks, std::array<uint8_t *, kNumSegs>{});
     peer_opened.assign((size_t)num_ranks, false);
     for (int sg = 0; sg < kNumSegs; ++sg) peer_seg[(size_t)rank][(size_t)sg] = seg_base[sg];
@@ -337,6 +340,7 @@ void Buffer::check_status(const char *where)
     const int32_t s = __atomic_load_n(status_host, __ATOMIC_ACQUIRE);
     if (s != 0) {
         __atomic_store_n(status_host, 0, __ATOMIC_RELEASE);
+        if (s == MI_EP_STATUS_GEMM_ROWMAX) fused_requant = false;      // the column tiles of a row block never met: two launches from now on
         if (s == MI_EP_STATUS_LAYOUT_BARRIER) {
             // a barrier that did not close never re-armed its pair of sync words: clear the whole ring (behind everything queued on this
             // stream) so the pair does not hand a non-zero count to the launch that borrows it 32 layout calls later
@@ -1237,13 +1241,27 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
         real_max_bs = std::max<int64_t>(real_max_bs, MT);
     }
     const int M = (int)(a_rows.defined() ? a_rows.size(0) : rx.size(0));
-    at::Tensor v = at::empty({M, I}, at::dtype(at::kFloat).device(dev));
+    // opt-in (MI_EP_FUSED_REQUANT=1 / set_fused_requant(true)): GEMM1 requantises its rows in its own epilogue (the reference's structure,
+    // block_epilogue_per_token_dequant_swiglu.h:250-269): no fp32 [M, I] intermediate, no rowquant launch; same bits, not faster (deep_ep.hpp)
+    const bool requant_in_gemm1 = fused_requant && N1 % 256 == 0;
+    at::Tensor v = requant_in_gemm1 ? at::Tensor() : at::empty({M, I}, at::dtype(at::kFloat).device(dev));
     at::Tensor q2 = at::empty({M, I}, at::dtype(at::kChar).device(dev));
     at::Tensor sc2 = at::empty({M}, at::dtype(at::kFloat).device(dev));
     const int32_t *cum = layout_range.data_ptr<int>();
     // expected rows per local expert under balanced routing (all ranks send about T tokens x K): picks the GEMM tile shape
     const int rows_hint = S > 0 && rank < S ? std::max(1, T * (W / S))
                                             : (int)std::max<int64_t>(1, (int64_t)T * K_user * W / std::max<int64_t>(1, num_experts));
+    if (requant_in_gemm1) {
+        const int64_t words = (int64_t)mi_ep_moe_requant_words(M, Lw);
+        at::Tensor rq = at::empty({words}, at::dtype(at::kInt).device(dev));
+        HIP_CHECK(hipMemsetAsync(rq.data_ptr(), 0, (size_t)words * 4, st));
+        ProfScope ps_(this, "moe_gemm1_swiglu_quant", st);
+        MI_EP_CHECK(mi_ep_moe_gemm1_swiglu_quant(a_rows.defined() ? a_base : rx.data_ptr(),
+                                                 a_rows.defined() ? (const uint32_t *)a_rows.data_ptr<int>() : nullptr, rs.data_ptr<float>(),
+                                                 (const int8_t *)w1.data_ptr(), s1.data_ptr<float>(), cum, W, Lw, M, H, N1, (int8_t *)q2.data_ptr(),
+                                                 sc2.data_ptr<float>(), (uint32_t *)rq.data_ptr<int>(), gemm_xcds, status_dev, timeout_ms, rows_hint,
+                                                 st));
+    } else {
     { ProfScope ps_(this, "moe_gemm1_swiglu", st);
       if (a_rows.defined())
           MI_EP_CHECK(mi_ep_moe_gemm1_swiglu_rows(a_base, (const uint32_t *)a_rows.data_ptr<int>(), rs.data_ptr<float>(), (const int8_t *)w1.data_ptr(),
@@ -1253,6 +1271,7 @@ std::vector<at::Tensor> Buffer::fused_core(const at::Tensor &x, const at::Tensor
                                              s1.data_ptr<float>(), cum, W, Lw, M, H, N1, v.data_ptr<float>(), rows_hint, st)); }
     { ProfScope ps_(this, "moe_rowquant", st);
       MI_EP_CHECK(mi_ep_moe_rowquant(v.data_ptr<float>(), cum + (Lw * W - 1), M, I, (int8_t *)q2.data_ptr(), sc2.data_ptr<float>(), st)); }
+    }
     // GEMM2 writes every bf16 row straight into its owner's combine slot (the push of low_latency_combine fused into the GEMM
     // epilogue: no dense [M, H] intermediate, one pass over 2*M*H bytes less), then the usual signal / wait / weighted sum
     const size_t cb = mi_ep_combine_row_bytes(H);

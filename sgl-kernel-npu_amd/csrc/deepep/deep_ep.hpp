@@ -51,6 +51,13 @@ public:
     std::vector<bool> get_local_row_paths() const { return {dispatch_local_rows, combine_local_rows_enabled}; }
     // MI355X only: fused_deep_moe / dispatch_ffn_combine at prefill sizes multiply the staged token rows in place (a row-offset table) instead
     // of a K-fold gathered copy; default from MI_EP_FUSED_GATHER (0 = gather).  Results are identical either way.
+    // MI355X only: GEMM1 of fused_deep_moe / dispatch_ffn_combine requantises its rows in its epilogue (mi_ep_moe_gemm1_swiglu_quant) instead
+    // of writing fp32 rows for a rowquant launch.  Results are identical either way.  OPT-IN (MI_EP_FUSED_REQUANT=1): at BASELINE C5 it measured
+    // 1.586-1.591 ms against 1.575-1.583 for the two launches on the same box -- the 16 column-tile workgroups of a row block then run in
+    // lockstep, and the sum over tiles of the slowest of 16 costs what the rowquant launch and its fp32 round trip cost.
+    void set_fused_requant(bool on) { fused_requant = on; }
+    bool get_fused_requant() const { return fused_requant; }
+    int get_gemm_xcds() const { return gemm_xcds; }
     void set_fused_rows_in_place(bool on) { fused_rows_in_place = on; }
     bool get_fused_rows_in_place() const { return fused_rows_in_place; }
     std::string get_dispatch_transport() const { return dispatch_transport == kTransportPush ? "push" : "pull"; }
@@ -290,6 +297,8 @@ private:
     bool dispatch_local_rows = !(getenv("MI_EP_DISPATCH_LOCAL") && atoi(getenv("MI_EP_DISPATCH_LOCAL")) == 0);
     bool combine_local_rows_enabled = !(getenv("MI_EP_COMBINE_LOCAL") && atoi(getenv("MI_EP_COMBINE_LOCAL")) == 0);
     bool fused_rows_in_place = !(getenv("MI_EP_FUSED_GATHER") && atoi(getenv("MI_EP_FUSED_GATHER")) == 0);
+    bool fused_requant = getenv("MI_EP_FUSED_REQUANT") && atoi(getenv("MI_EP_FUSED_REQUANT")) != 0;
+    int gemm_xcds = 1;
     // fused paths: shared launch chain + one-off weight re-layout cache (keyed by storage pointer and kind)
     std::vector<at::Tensor> fused_core(const at::Tensor &x, const at::Tensor &expert_ids, const at::Tensor &w1,
                                        const at::Tensor &s1, const at::Tensor &w2, const at::Tensor &s2,

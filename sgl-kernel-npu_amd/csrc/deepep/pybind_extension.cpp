@@ -54,6 +54,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     MI_METHOD(buf, is_available);
     MI_METHOD(buf, is_window_fine_grained);
     MI_METHOD(buf, self_test);
+    MI_METHOD(buf, set_fused_requant);
+    MI_METHOD(buf, get_fused_requant);
+    MI_METHOD(buf, get_gemm_xcds);
     MI_METHOD(buf, self_test_in_launch);
     MI_METHOD(buf, set_two_launch_forms);
     MI_METHOD(buf, get_two_launch_forms);

@@ -50,6 +50,7 @@ template <int BKT, int MT> struct RingDepth { static constexpr int value = BKT =
 constexpr int ring_bytes(int bkt, int mt) { return (bkt == 128 ? (mt == 4 ? 2 : 3) : 4) * (64 * mt + 256) * bkt; }
 constexpr int kGemmThreads = 1024;
 constexpr int kEpiRowBytes = 144;      // epilogue transpose tile: 128-byte rows + 16 B (see the epilogue)
+constexpr int kRqCols = 16;            // requantising GEMM1: words per row in the exchange line (one per 256-column tile: two_i <= 4096)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
@@ -71,6 +72,15 @@ struct GemmArgs {
     int slot_rows;            // rows one combine region holds: (t, k) outside it are dropped
     int cols_padded;          // 0, or the column-tile count rounded up to a multiple of 8 (XCD-consistent column tiles, see the kernel)
     int small_last;           // an expert's last row block of <= 64 / <= 128 rows runs as a 64- / 128-row tile (MI_GEMM_SMALL_LAST=0: as a 256-row tile)
+    // mode 3 (GEMM1 with the per-row requantisation in its epilogue, see gemm_tile): int8 [M_cap, N/2] + float [M_cap] out, and the words the
+    // column tiles of a row block meet at -- all zero when the launch starts (one memset per call: rq_words)
+    int8_t *q_out;
+    float *q_scale;
+    uint32_t *rq_rowmax;      // [M_cap][kRqCols] exchange lines: word c of row r = bits of column tile c's max |v| of that row | 0x80000000
+    uint32_t *rq_tickets;     // [8] workgroups started per XCD (see grouped_gemm_i8_kernel)
+    int rq_xcds;              // XCDs the workgroups are dealt to round-robin (verified at start-up: mi_ep_moe_probe_xcds); 1 = one ticket for all
+    int32_t *status;
+    uint64_t timeout_ticks;
 };
 
 // position (16-B units) of k-chunk `chunk` inside row `row` of a [rows][BKT B] tile.  A ds_read_b128 of 16 consecutive rows at one chunk
@@ -151,8 +161,9 @@ __device__ __forceinline__ bool find_tile(const GemmArgs &p, int tile_slot, int 
 
 // one (expert, row block of `rows` <= 64 MT rows starting at row0) x 256-column tile
 template <int MODE, int MT, int BKT>
-__device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, int rows, int col_tile, uint8_t *lds)
+__device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, int rows, int col_tile, uint8_t *lds, int tile_slot = 0)
 {
+    constexpr bool SWIGLU = MODE == 0 || MODE == 3;   // GEMM1: fusion tiles of 64 gate | 64 up columns; MODE 3 also requantises the rows
     constexpr int BM = 64 * MT;
     constexpr int kStages = RingDepth<BKT, MT>::value;
     constexpr int kStageBytes = (BM + BN) * BKT;
@@ -223,7 +234,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, in
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             int brow;
-            if (MODE == 0) brow = (wn >> 1) * 128 + (nt >> 1) * 64 + (wn & 1) * 32 + (nt & 1) * 16 + c16;   // nt 0,1 gate; 2,3 up
+            if (SWIGLU) brow = (wn >> 1) * 128 + (nt >> 1) * 64 + (wn & 1) * 32 + (nt & 1) * 16 + c16;   // nt 0,1 gate; 2,3 up
             else brow = wn * 64 + nt * 16 + c16;
             boff[ks][nt] = BM * BKT + swz<BKT>(brow, 4 * ks + g);
         }
@@ -323,15 +334,120 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, in
     __syncthreads();                                        // every wave is done reading the ring (and nothing is in flight)
     uint8_t *tile = lds + wave * (kWaveRows * kRowBytes);
     const int f = wn >> 1, h = wn & 1;                      // MODE 0: fusion tile f (128 columns: 64 gate | 64 up), half h
-    const bool wave_cols_ok = MODE == 0 ? (n0 + f * 128 < p.N) : (n0 + wn * 64 < p.N);
+    const bool wave_cols_ok = SWIGLU ? (n0 + f * 128 < p.N) : (n0 + wn * 64 < p.N);
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 wsv[4];                                           // weight scales of this lane's columns: n-tile nt, columns 4g .. 4g+3
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         int col;                                            // first of the four columns, relative to n0
-        if (MODE == 0) col = f * 128 + (nt >> 1) * 64 + h * 32 + (nt & 1) * 16 + 4 * g;      // nt 0,1 gate; 2,3 up
+        if (SWIGLU) col = f * 128 + (nt >> 1) * 64 + h * 32 + (nt & 1) * 16 + 4 * g;      // nt 0,1 gate; 2,3 up
         else col = wn * 64 + nt * 16 + 4 * g;
         wsv[nt] = wave_cols_ok ? *(const f32x4 *)(ws + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (MODE == 3) {
+        // ---- GEMM1 with the per-row requantisation in the epilogue (the reference requantises in GEMM1's epilogue too:
+        // block_epilogue_per_token_dequant_swiglu.h:250-269, ...swiglu_quant_multistage_workspace.h:199-265).  A row's maximum spans all N / 256
+        // column tiles of its row block, i.e. N / 256 workgroups: each keeps its SwiGLU values in registers (32 per lane), posts its rows'
+        // maxima into the rows' exchange lines (one word per column tile), waits (bounded) until the other column tiles' words are there,
+        // then quantises from the registers with the final maxima -- the same values, the same formula as rowquant_kernel, so the
+        // same bits -- and writes int8 rows instead of fp32 ones.  No fp32 intermediate crosses HBM and there is no rowquant launch.
+        // Forward progress: the workgroups that share a row block were formed at their start (grouped_gemm_i8_kernel) and walk the same tile
+        // slots in the same order, so a waiter only ever waits for workgroups that are already running.
+        float *part = (float *)lds;                          // [4 column quarters][BM] row maxima of this workgroup's waves
+        float *invs = part + 4 * BM;                         // [BM] 1 / row maximum (0 for an all-zero row)
+        uint8_t *qt = lds + 8192;                            // [BM] rows x 128 int8 (+ 16 B: kEpiRowBytes), the workgroup's output tile
+        f32x4 v[MT][2];
+        float rmax[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rl = mt * 16 + c16;
+            const float as = p.a_scale[(size_t)row0 + min(wm * kWaveRows + rl, rows - 1)];
+            float m = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gate = ((float)acc[mt][nt][r] * wsv[nt][r]) * as;
+                    const float up = ((float)acc[mt][nt + 2][r] * wsv[nt + 2][r]) * as;
+                    v[mt][nt][r] = up * (gate * __builtin_amdgcn_rcpf(1.0f + __expf(-gate)));      // (as MODE 0 below)
+                    m = fmaxf(m, fabsf(v[mt][nt][r]));
+                }
+            }
+            // over the four 16-lane rows of the wave (lanes c16, c16 + 16, c16 + 32, c16 + 48 hold the same matrix row)
+            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+            u32x2v sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            rmax[mt] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) part[wn * BM + wm * kWaveRows + mt * 16 + c16] = rmax[mt];
+        }
+        __syncthreads();
+        if (tid < BM) {
+            // Thread r owns row r of the block.  Its word of the row's exchange line -- 16 words, one per column tile -- is the maximum of this
+            // workgroup's 128 columns with the SIGN bit set: |v| >= 0, so the bit is free, and a word that is still zero has not been posted
+            // (the line is its own flag: one device-scope store, no counter, no second round trip).  Then it polls the line until every
+            // column tile's word is there.
+            float amax = 0.f;
+            if (tid < rows) {
+                const float m = fmaxf(fmaxf(part[tid], part[BM + tid]), fmaxf(part[2 * BM + tid], part[3 * BM + tid]));
+                uint32_t *line = p.rq_rowmax + ((size_t)row0 + tid) * kRqCols;
+                __hip_atomic_store(line + col_tile, __float_as_uint(m) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int ncols = p.N / BN;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)p.rq_rowmax, 0, 0x7FFFFFFF, 0x00020000);
+                const uint32_t off = (uint32_t)(row0 + tid) * (kRqCols * 4u);
+                const uint64_t t0 = ticks_100mhz();
+                for (;;) {
+                    asm volatile("" ::: "memory");             // (the line is re-read every round)
+                    u32x4 w[kRqCols / 4];
+#pragma unroll
+                    for (int j = 0; j < kRqCols / 4; ++j)
+                        w[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16u * j), 0, 16));     // sc1
+                    uint32_t all = 0x80000000u, mx = 0u;
+#pragma unroll
+                    for (int j = 0; j < kRqCols; ++j) {
+                        const uint32_t x = j < ncols ? w[j / 4][j % 4] : 0x80000000u;
+                        all &= x;
+                        mx = max(mx, x & 0x7FFFFFFFu);
+                    }
+                    if (all) {
+                        amax = __uint_as_float(mx);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    if (ticks_100mhz() - t0 > p.timeout_ticks) {
+                        report_status(p.status, MI_EP_STATUS_GEMM_ROWMAX);
+                        break;
+                    }
+                }
+                if (col_tile == 0) p.q_scale[(size_t)row0 + tid] = amax / 127.0f;
+            }
+            invs[tid] = amax > 0.f ? 1.0f / amax : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int lr = wm * kWaveRows + mt * 16 + c16;
+            const float inv = invs[lr];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int a = (int)rintf((v[mt][nt][0] * 127.0f) * inv), b = (int)rintf((v[mt][nt][1] * 127.0f) * inv);
+                const int c = (int)rintf((v[mt][nt][2] * 127.0f) * inv), d = (int)rintf((v[mt][nt][3] * 127.0f) * inv);
+                *(uint32_t *)(qt + lr * kEpiRowBytes + f * 64 + h * 32 + nt * 16 + 4 * g) =
+                    (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24);
+            }
+        }
+        __syncthreads();
+        // whole 128-byte pieces of the int8 rows: a wave-store covers 8 rows
+        for (int it = wave; it < BM / 8; it += 16) {
+            const int lr = it * 8 + (lane >> 3), chunk = lane & 7;
+            if (lr < rows)
+                *(u32x4 *)(p.q_out + ((size_t)row0 + lr) * (size_t)(p.N / 2) + (size_t)col_tile * 128 + chunk * 16) =
+                    *(const u32x4 *)(qt + lr * kEpiRowBytes + chunk * 16);
+        }
+        return;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -473,6 +589,29 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
         col_tile = f % p.cols_padded, worker = f / p.cols_padded, workers = (int)(gridDim.x * gridDim.y) / p.cols_padded;
         if (col_tile * BN >= p.N || worker >= workers) return;
     }
+#ifdef GEMM_SCRAMBLE      // measurement only: what column tile -> XCD consistency is worth (1: none at all; 2: a quarter of the workers off by 3)
+    if (GEMM_SCRAMBLE == 1) col_tile = (col_tile + worker) % (int)gridDim.x;
+    else if ((worker & 3) == 0) col_tile = (col_tile + 3) % (int)gridDim.x;
+#endif
+    if constexpr (MODE == 3) {
+        // The column tiles of a row block wait for each other in the epilogue, so WHICH workgroups form a worker (one per column tile, walking
+        // the same tile slots) is decided when they start, not by their block ids: the n-th workgroup to start on XCD x takes column tile
+        // x + X (n mod c) of worker n / c (X XCDs, c = column tiles per XCD).  A waiter then only waits for workgroups that are running or
+        // that the hardware starts next on a free CU of their XCD, whatever the dispatch order; and a column tile stays on one XCD (its
+        // weight tile in that L2 for all row blocks of the expert: without that GEMM1 is 10 % slower, tools/time_gemm.py + -DGEMM_SCRAMBLE=1).
+        // The one thing assumed is that the XCDs get equal shares of the grid (block b on XCD b mod X: mi_ep_moe_probe_xcds checks it at
+        // start-up and rq_xcds = 1 -- one ticket for all, no placement assumed -- is used when it does not hold); every wait is bounded.
+        __shared__ int s_col, s_worker;
+        if (threadIdx.x == 0) {
+            const int X = p.rq_xcds, cpx = (int)gridDim.x / X;
+            const int xcc = X > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) % X : 0;      // HW_REG_XCC_ID[3:0]
+            const int n = (int)__hip_atomic_fetch_add(p.rq_tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_col = xcc + X * (n % cpx), s_worker = n / cpx;
+        }
+        __syncthreads();
+        col_tile = s_col, worker = s_worker;
+        if (worker >= workers) return;                      // (more workgroups on this XCD than its share: nothing is left for them)
+    }
     const int end_first = lane0 < p.L ? p.cum[(lane0 + 1) * p.cum_stride - 1] : 0;     // end of expert `lane` (cumulative row count)
     for (int slot = worker;; slot += workers) {
         int e, row0, rows;
@@ -482,15 +621,15 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
         // tile pays for it in full -- its weight tile streams all the same and the MFMAs multiply padding.  Blocks of <= 64 / <= 128 rows
         // run as the 64- / 128-row tile (a fifth / three eighths less operand stream per k-tile, a quarter / half of the MFMAs).  Same
         // products, same epilogue: bit-identical.
-        if (MT == 4 && BKT == 128 && p.small_last && rows <= 64) gemm_tile<MODE, 1, BKT>(p, e, row0, rows, col_tile, lds);
-        else if (MT == 4 && BKT == 128 && p.small_last && rows <= 128) gemm_tile<MODE, 2, BKT>(p, e, row0, rows, col_tile, lds);
-        else gemm_tile<MODE, MT, BKT>(p, e, row0, rows, col_tile, lds);
+        if (MT == 4 && BKT == 128 && p.small_last && rows <= 64) gemm_tile<MODE, 1, BKT>(p, e, row0, rows, col_tile, lds, slot);
+        else if (MT == 4 && BKT == 128 && p.small_last && rows <= 128) gemm_tile<MODE, 2, BKT>(p, e, row0, rows, col_tile, lds, slot);
+        else gemm_tile<MODE, MT, BKT>(p, e, row0, rows, col_tile, lds, slot);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
         __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
     }
     if (stamp) {
-        g_gemm_clk[MODE][0] = __builtin_amdgcn_s_memtime() - c0;
-        g_gemm_clk[MODE][1] = __builtin_amdgcn_s_memrealtime() - r0;
+        g_gemm_clk[MODE % 3][0] = __builtin_amdgcn_s_memtime() - c0;      // (mode 3 is GEMM1 too)
+        g_gemm_clk[MODE % 3][1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
 
@@ -558,7 +697,7 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
     // operand ring | epilogue tiles of 16 waves; the 256-row kernel with 128-byte k-tiles also runs 64- and 128-row tiles (the last row
     // block of an expert): their rings are three stages deep, the 128-row one (3 x 48 KB) is the largest
     constexpr int ring0 = ring_bytes(BKT, MT), ring = (MT == 4 && BKT == 128 && ring_bytes(BKT, 2) > ring0) ? ring_bytes(BKT, 2) : ring0;
-    constexpr int epi = 16 * 16 * MT * kEpiRowBytes;
+    constexpr int epi = MODE == 3 ? 8192 + 256 * kEpiRowBytes : 16 * 16 * MT * kEpiRowBytes;      // mode 3: maxima + the workgroup's int8 tile
     constexpr int lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
@@ -596,11 +735,20 @@ struct PushArgs {
     int slot_rows;
 };
 
+struct RequantArgs {
+    int8_t *q;
+    float *scale;
+    uint32_t *words;          // mi_ep_moe_requant_words(rows_cap, L) zeroed uint32
+    int xcds;
+    int32_t *status;
+    int timeout_ms;
+};
+
 static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const int8_t *w, const float *w_scale, const int32_t *cum,
                        int cum_stride, int L, int M_cap, int K, int N, void *out, int rows_per_expert_hint, void *stream,
-                       const PushArgs *push = nullptr, const uint32_t *a_rows = nullptr)
+                       const PushArgs *push = nullptr, const uint32_t *a_rows = nullptr, const RequantArgs *rq = nullptr)
 {
-    if (!a || !a_scale || !w || !w_scale || !cum || (!out && !push) || L <= 0 || L > 1024 || M_cap <= 0 || K <= 0 || K % BK || N <= 0 ||
+    if (!a || !a_scale || !w || !w_scale || !cum || (!out && !push && !rq) || L <= 0 || L > 1024 || M_cap <= 0 || K <= 0 || K % BK || N <= 0 ||
         N % 128 || cum_stride <= 0)
         return MI_EP_EINVAL;
     GemmArgs p{};
@@ -611,6 +759,15 @@ static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const in
         p.src_idx = push->src_idx, p.dsts = push->dsts, p.slot_stride = push->slot_stride, p.topk = push->topk, p.W = push->W;
         p.par = push->par, p.slot_rows = push->slot_rows;
         mode = 2;
+    }
+    if (rq) {
+        const int gx = N / BN;
+        if (!rq->q || !rq->scale || !rq->words || !rq->status || N % BN || gx > kRqCols || rq->xcds < 1 || rq->xcds > 8) return MI_EP_EINVAL;
+        // (fewer column tiles than XCDs, or not a multiple: one ticket for all workgroups)
+        p.q_out = rq->q, p.q_scale = rq->scale, p.rq_xcds = gx % rq->xcds == 0 ? rq->xcds : 1, p.status = rq->status;
+        p.rq_tickets = rq->words, p.rq_rowmax = rq->words + 16;      // (lines 64-byte aligned)
+        p.timeout_ticks = (uint64_t)(rq->timeout_ms > 0 ? rq->timeout_ms : 10000) * 100000ull;
+        mode = 3;
     }
     const bool wide_k = small && K % 128 == 0;             // decode tile with whole 128-byte lines per request
     static const bool wide_big_env = !(getenv("MI_GEMM_WIDE_K") && atoi(getenv("MI_GEMM_WIDE_K")) == 0);      // 0: 64-byte k-tiles (A/B runs)
@@ -624,6 +781,7 @@ static int gemm_launch(int mode, const int8_t *a, const float *a_scale, const in
     } while (0)
     if (mode == 0) MI_GEMM_DISPATCH(0);
     else if (mode == 1) MI_GEMM_DISPATCH(1);
+    else if (mode == 3) MI_GEMM_DISPATCH(3);
     else MI_GEMM_DISPATCH(2);
 #undef MI_GEMM_DISPATCH
     return launch_status();
@@ -644,6 +802,46 @@ extern "C" int mi_ep_moe_gemm1_swiglu_rows(const void *a_base, const uint32_t *a
     if (!a_row_offsets) return MI_EP_EINVAL;
     return gemm_launch(0, (const int8_t *)a_base, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, hidden, two_i,
                        out, rows_per_expert_hint, stream, nullptr, a_row_offsets);
+}
+
+extern "C" size_t mi_ep_moe_requant_words(int rows_cap, int num_local_experts)
+{
+    (void)num_local_experts;
+    return (size_t)16 + (size_t)rows_cap * kRqCols;
+}
+
+extern "C" int mi_ep_moe_gemm1_swiglu_quant(const void *a_base, const uint32_t *a_row_offsets, const float *a_scale, const int8_t *w,
+                                            const float *w_scale, const int32_t *row_cumsum, int cum_stride, int num_local_experts,
+                                            int rows_cap, int hidden, int two_i, int8_t *q, float *q_scale, uint32_t *zeroed_words, int xcds,
+                                            int32_t *status, int timeout_ms, int rows_per_expert_hint, void *stream)
+{
+    RequantArgs rq{q, q_scale, zeroed_words, xcds, status, timeout_ms};
+    return gemm_launch(0, (const int8_t *)a_base, a_scale, w, w_scale, row_cumsum, cum_stride, num_local_experts, rows_cap, hidden, two_i,
+                       nullptr, rows_per_expert_hint, stream, nullptr, a_row_offsets, &rq);
+}
+
+// Which XCD does block b of a grid run on?  64 one-wave blocks write their HW_REG_XCC_ID; the answer the requantising GEMM1 relies on for
+// SPEED and for equal shares is "b mod X".  Returns X (8 on an MI355X in SPX mode, 1 on a single-XCD partition), or 1 -- no placement
+// assumed -- when the observed ids do not follow that rule.
+namespace mi_ep {
+__global__ void probe_xcc_kernel(int32_t *out) { if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15); }
+}
+extern "C" int mi_ep_moe_probe_xcds(void *stream)
+{
+    int32_t *dev = nullptr, host[64];
+    if (hipMalloc((void **)&dev, sizeof(host)) != hipSuccess) return 1;
+    int X = 1;
+    mi_ep::probe_xcc_kernel<<<64, 64, 0, (hipStream_t)stream>>>(dev);
+    if (hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+        hipStreamSynchronize((hipStream_t)stream) == hipSuccess) {
+        for (int cand = 8; cand > 1 && X == 1; cand >>= 1) {
+            bool ok = true;
+            for (int b = 0; b < 64 && ok; ++b) ok = host[b] == b % cand;
+            if (ok) X = cand;
+        }
+    }
+    (void)hipFree(dev);
+    return X;
 }
 
 extern "C" int mi_ep_moe_rowquant(const float *v, const int32_t *total_rows_dev, int rows_cap, int inter, int8_t *q, float *scale,

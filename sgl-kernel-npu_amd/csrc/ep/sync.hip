@@ -585,7 +585,7 @@ extern "C" int mi_ep_selftest(void *const *peer_rows_host, uint64_t *const *peer
 // fresh pattern.  After checking a row the consumer reads it once more with ORDINARY loads and keeps nothing: the lines stay in its L1 / L2
 // the way any earlier reader may have left them, and the next visit must not be answered from there.  A producer starts round r only when
 // its consumer has acknowledged round r - 1 (nobody's rows are rewritten under a reader).
-// status[0]: 1 + s gate / word never arrived from rank s, 6000 + s stale or corrupt TAGGED payload from s, 7000 + s the same for a FLAGGED row.
+// status[0]: 1 + s gate / word never arrived from rank s, 7000 + s stale or corrupt TAGGED payload from s, 7500 + s the same for a FLAGGED row.
 namespace mi_ep {
 constexpr int kILRows = 8;
 constexpr int kILPayload = 4096;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void selftest_inlaunch_kernel(InLaunchTest a, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) ok = ok && v[u][j] == selftest_word(a.tag, s, a.my_rank, i + j);
         }
-        if (!ok) report_status(status, (flagged ? 7000 : 6000) + s);
+        if (!ok) report_status(status, (flagged ? 7500 : 7000) + s);
         // leave the row's lines in this CU's L1 and this XCD's L2 as an ordinary reader would (nothing is kept from the loads)
 #pragma unroll
         for (int u = 0; u < kILPayload / (kWave * 16); ++u) {

@@ -52,6 +52,23 @@ def test_fused_deep_moe(cfg):
     _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)
 
 
+@pytest.mark.parametrize("cfg", [(1, 1024, 7168, 2048, 8, 8, "native"), (2, 640, 512, 128, 4, 8, "native"), (2, 24, 512, 256, 4, 8, "ffn"),
+                                 (4, 16, 1024, 128, 8, 32, "native")])
+def test_fused_deep_moe_with_the_requantisation_in_gemm1(cfg):
+    """MI_EP_FUSED_REQUANT=1: GEMM1 requantises its rows in its epilogue (no fp32 intermediate, no rowquant launch) -- the reference's
+    structure, opt-in here; same checks as test_fused_deep_moe, prefill- and decode-size legs, one to four processes on one GPU."""
+    import os
+    keep = os.environ.get("MI_EP_FUSED_REQUANT")
+    os.environ["MI_EP_FUSED_REQUANT"] = "1"
+    try:
+        _spawn(mp_workers.gpu_fused_moe_worker, cfg[0], cfg)
+    finally:
+        if keep is None:
+            os.environ.pop("MI_EP_FUSED_REQUANT", None)
+        else:
+            os.environ["MI_EP_FUSED_REQUANT"] = keep
+
+
 def test_fused_deep_moe_c5_size_eight_processes():
     """BASELINE C5 through deep_ep.Buffer: eight processes with hipIpc-mapped windows, 4096 tokens per rank, DeepSeek-V3 expert
     shapes, 32 local experts per rank; 256 sampled tokens per rank against the per-token float64 evaluation."""
@@ -112,8 +129,8 @@ def test_two_launch_forms_uncapped_as_on_a_node(cfg):
 
 @pytest.mark.parametrize("forms", [("2", "2"), None], ids=["forms_forced_by_env", "default_forms"])
 def test_failed_in_launch_self_test_falls_back_to_three_launches(forms):
-    """One rank fails the second self-test leg (its tags / flags arrive in front of a payload that was not rewritten: codes 6000 + s /
-    7000 + s at its consumers): EVERY rank reports three-launch forms -- even against MI_EP_LL_FUSED_COUNTS / MI_EP_COMBINE_FUSED = 2 --,
+    """One rank fails the second self-test leg (its tags / flags arrive in front of a payload that was not rewritten: codes 7000 + s /
+    7500 + s at its consumers): EVERY rank reports three-launch forms -- even against MI_EP_LL_FUSED_COUNTS / MI_EP_COMBINE_FUSED = 2 --,
     the window strategies stay, and the dispatch + combine pair is bit-exact."""
     _spawn(mp_workers.gpu_ll_empty_rank_worker, 2, (2, 5, 512, 4, 8, True, forms, {"stale_rank": 1, "own_gpu": forms is None}))
 

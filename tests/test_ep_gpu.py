@@ -461,16 +461,16 @@ def _selftest_inlaunch_run(W, rounds, first_epoch, state, stale_rank=None, stale
 def test_window_selftest_in_launch_handoff_leg(W):
     """mi_ep_selftest_inlaunch: tag / flag word behind a drained write-through payload, polled and read with system-scope loads inside ONE launch
     (the hand-off of the two-launch low-latency forms), four rounds over both ping-pong halves on the same addresses; a second call continues;
-    a rank that raises its words WITHOUT rewriting the payload -- a stale line, as its consumers see it -- is reported as 6000 + s (tagged
-    row) or 7000 + s (flagged row) by every rank that consumes from it (itself included) and nobody reports the healthy rank; rounds before the
+    a rank that raises its words WITHOUT rewriting the payload -- a stale line, as its consumers see it -- is reported as 7000 + s (tagged
+    row) or 7500 + s (flagged row) by every rank that consumes from it (itself included) and nobody reports the healthy rank; rounds before the
     injection pass."""
     state = {}
     assert _selftest_run(W, 2, 1, state) == [0] * W                    # (first leg: leaves the ack words at epoch 2)
     assert _selftest_inlaunch_run(W, 4, 3, state) == [0] * W
     assert _selftest_inlaunch_run(W, 4, 7, state) == [0] * W
     codes = _selftest_inlaunch_run(W, 4, 11, state, stale_rank=1, stale_from=2)
-    assert codes[0] in (6001, 7001), codes
-    assert codes[1] in (6001, 7001), codes      # (a rank also produces for and consumes from itself: rank 1 sees its own stale rows; nobody names rank 0)
+    assert codes[0] in (7001, 7501), codes
+    assert codes[1] in (7001, 7501), codes      # (a rank also produces for and consumes from itself: rank 1 sees its own stale rows; nobody names rank 0)
     assert _selftest_inlaunch_run(W, 2, 15, state) == [0] * W          # and the scratch is usable again afterwards
 
 

@@ -37,7 +37,12 @@ def lib():
         L.mi_ep_moe_gemm2_push.argtypes = [V, V, V, V, V, I, I, I, I, I, V, I, V, I, ctypes.c_size_t, V, ctypes.c_size_t, I, V]
         L.mi_ep_combine_row_bytes.restype = ctypes.c_size_t
         L.mi_ep_combine_row_bytes.argtypes = [I]
-        for n in ("mi_ep_moe_gemm1_swiglu", "mi_ep_moe_rowquant", "mi_ep_moe_gemm2", "mi_ep_moe_gemm2_push"):
+        L.mi_ep_moe_gemm1_swiglu_quant.argtypes = [V, V, V, V, V, V, I, I, I, I, I, V, V, V, I, V, I, I, V]
+        L.mi_ep_moe_requant_words.restype = ctypes.c_size_t
+        L.mi_ep_moe_requant_words.argtypes = [I, I]
+        L.mi_ep_moe_probe_xcds.argtypes = [V]
+        for n in ("mi_ep_moe_gemm1_swiglu", "mi_ep_moe_rowquant", "mi_ep_moe_gemm2", "mi_ep_moe_gemm2_push", "mi_ep_moe_gemm1_swiglu_quant",
+                  "mi_ep_moe_probe_xcds"):
             getattr(L, n).restype = c_int
         _LIB = L
     return _LIB
@@ -78,6 +83,21 @@ def run_rowquant(v, total_dev, rows_cap, I):
     sc = torch.zeros(rows_cap, dtype=torch.float32, device=v.device)
     ck(lib().mi_ep_moe_rowquant(ptr(v), ptr(total_dev), rows_cap, I, ptr(q), ptr(sc), stream_ptr()))
     return q, sc
+
+
+def run_gemm1_quant(a, a_scale, w_perm, ws_perm, cum, stride, L, rows_cap, H, two_i, hint, xcds=None, row_offsets=None):
+    """GEMM1 with the requantisation in its epilogue (mi_ep_moe_gemm1_swiglu_quant): q, scale and the status word."""
+    Lb = lib()
+    q = torch.zeros((rows_cap, two_i // 2), dtype=torch.int8, device=a.device)
+    sc = torch.zeros(rows_cap, dtype=torch.float32, device=a.device)
+    words = torch.zeros(Lb.mi_ep_moe_requant_words(rows_cap, L), dtype=torch.int32, device=a.device)      # (zero at launch: the contract)
+    status = torch.zeros(4, dtype=torch.int32, device=a.device)
+    if xcds is None:
+        xcds = Lb.mi_ep_moe_probe_xcds(stream_ptr())
+    ck(Lb.mi_ep_moe_gemm1_swiglu_quant(ptr(a), ptr(row_offsets) if row_offsets is not None else None, ptr(a_scale), ptr(w_perm), ptr(ws_perm),
+                                       ptr(cum), stride, L, rows_cap, H, two_i, ptr(q), ptr(sc), ptr(words), xcds, ptr(status), 5000, hint,
+                                       stream_ptr()))
+    return q, sc, status
 
 
 def run_gemm2(q, sc, w2, s2, cum, stride, L, rows_cap, I, H, hint):
@@ -124,6 +144,22 @@ def test_moe_gemm_chain_vs_oracle(counts, H, I, stride, hint):
     total_dev = torch.tensor([total], dtype=torch.int32, device=dev)
     q, sc = run_rowquant(v, total_dev, rows_cap, I)
     y = run_gemm2(q, sc, t(w2), t(s2), cum, stride, L, rows_cap, I, H, hint)
+    if (2 * I) % 256 == 0:
+        # the requantisation in GEMM1's epilogue: the bits of the two launches, with the probed XCD count and with "no placement assumed",
+        # from the dense rows and through a row-offset table (rows 128-byte aligned, in another order)
+        for xcds in (None, 1):
+            q_f, sc_f, st_f = run_gemm1_quant(t(a), t(a_scale), t(w13[:, perm, :]), t(s13[:, perm]), cum, stride, L, rows_cap, H, 2 * I, hint, xcds)
+            assert int(st_f[0]) == 0
+            assert torch.equal(q_f[:total], q[:total]) and torch.equal(sc_f[:total].view(torch.int32), sc[:total].view(torch.int32)), xcds
+            assert not bool(q_f[total:].any()) and not bool(sc_f[total:].any()), "rows past the last expert were written"
+        stride_b = (H + 127) // 128 * 128 + 128
+        order = rng.permutation(rows_cap)
+        scattered = np.zeros((rows_cap, stride_b), np.int8)
+        scattered[order, :H] = a
+        offs = t((order.astype(np.int64) * stride_b).astype(np.uint32).view(np.int32))
+        q_r, sc_r, st_r = run_gemm1_quant(t(scattered), t(a_scale), t(w13[:, perm, :]), t(s13[:, perm]), cum, stride, L, rows_cap, H, 2 * I, hint,
+                                          None, offs)
+        assert int(st_r[0]) == 0 and torch.equal(q_r[:total], q[:total]) and torch.equal(sc_r[:total].view(torch.int32), sc[:total].view(torch.int32))
     torch.cuda.synchronize()
     v_h, q_h, sc_h, y_h = v.cpu().numpy(), q.cpu().numpy(), sc.cpu().numpy(), torch_to_bits(y)
     assert np.isnan(v_h[total:]).all(), "rows past the last expert were written"
@@ -200,6 +236,11 @@ def test_moe_gemm_c5_shapes_exact(hint):
     total_dev = torch.tensor([total], dtype=torch.int32, device=dev)
     q, sc = run_rowquant(v, total_dev, rows_cap, I)
     y = run_gemm2(q, sc, w2, s2, cum, stride, L, rows_cap, I, H, hint)
+    for rep in range(3):        # GEMM1 with the requantisation in its epilogue: the same bits, every time (the workers form at run time)
+        q_f, sc_f, st_f = run_gemm1_quant(a, a_scale, w13p, s13p, cum, stride, L, rows_cap, H, 2 * I, hint)
+        assert int(st_f[0]) == 0
+        assert torch.equal(q_f[:total], q[:total]) and torch.equal(sc_f[:total].view(torch.int32), sc[:total].view(torch.int32)), rep
+        assert not bool(q_f[total:].any())
     torch.cuda.synchronize()
     assert bool(torch.isnan(v[total:]).all())
     assert not bool(y[total:].any())

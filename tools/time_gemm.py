@@ -16,11 +16,39 @@ cum_u = (torch.arange(1, E + 1, device="cuda", dtype=torch.int32) * (M // E)).co
 gen = torch.Generator().manual_seed(3)
 cnt = torch.bincount(torch.multinomial(torch.ones(E), M, replacement=True, generator=gen), minlength=E)
 cum_r = torch.cumsum(cnt, 0).to(torch.int32).cuda().contiguous()
-for name, K, N, cum in (("gemm1", H, I2, cum_u), ("gemm2", I2 // 2, H, cum_u), ("gemm1 ragged", H, I2, cum_r), ("gemm2 ragged", I2 // 2, H, cum_r)):
+has_q = hasattr(L, "mi_ep_moe_gemm1_swiglu_quant")
+if has_q:
+    L.mi_ep_moe_gemm1_swiglu_quant.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [ctypes.c_int] * 5 + [c_vp, c_vp, c_vp, ctypes.c_int, c_vp,
+                                                                                                  ctypes.c_int, ctypes.c_int, c_vp]
+    L.mi_ep_moe_requant_words.restype = ctypes.c_size_t
+    L.mi_ep_moe_rowquant.argtypes = [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp]
+    XCDS = int(os.environ.get("XCDS", L.mi_ep_moe_probe_xcds(None)))
+    print("xcds", XCDS)
+cases = [("gemm1", H, I2, cum_u), ("gemm2", I2 // 2, H, cum_u), ("gemm1 ragged", H, I2, cum_r), ("gemm2 ragged", I2 // 2, H, cum_r)]
+if has_q:
+    cases += [("gemm1+rowquant", H, I2, cum_u), ("gemm1q", H, I2, cum_u), ("gemm1+rowquant ragged", H, I2, cum_r), ("gemm1q ragged", H, I2, cum_r)]
+for name, K, N, cum in cases:
     a = torch.randint(-8, 8, (M, K), dtype=torch.int8, device="cuda")
     w = torch.randint(-8, 8, (E, N, K), dtype=torch.int8, device="cuda")
     ws = torch.rand((E, N), device="cuda")
-    if name.startswith("gemm1"):
+    if name.startswith("gemm1q"):
+        q = torch.zeros((M, N // 2), dtype=torch.int8, device="cuda")
+        qs = torch.zeros(M, device="cuda")
+        words = torch.zeros(L.mi_ep_moe_requant_words(M, E), dtype=torch.int32, device="cuda")
+        status = torch.zeros(4, dtype=torch.int32, device="cuda")
+        def f():
+            words.zero_()
+            return L.mi_ep_moe_gemm1_swiglu_quant(ptr(a), None, ptr(asc), ptr(w), ptr(ws), ptr(cum), 1, E, M, K, N, ptr(q), ptr(qs), ptr(words), XCDS,
+                                                  ptr(status), 5000, 0, stream_ptr())
+    elif name.startswith("gemm1+rowquant"):
+        out = torch.zeros((M, N // 2), dtype=torch.float32, device="cuda")
+        q = torch.zeros((M, N // 2), dtype=torch.int8, device="cuda")
+        qs = torch.zeros(M, device="cuda")
+        tot = torch.tensor([M], dtype=torch.int32, device="cuda")
+        def f():
+            L.mi_ep_moe_gemm1_swiglu(ptr(a), ptr(asc), ptr(w), ptr(ws), ptr(cum), 1, E, M, K, N, ptr(out), 0, stream_ptr())
+            return L.mi_ep_moe_rowquant(ptr(out), ptr(tot), M, N // 2, ptr(q), ptr(qs), stream_ptr())
+    elif name.startswith("gemm1"):
         out = torch.zeros((M, N // 2), dtype=torch.float32, device="cuda")
         f = lambda: L.mi_ep_moe_gemm1_swiglu(ptr(a), ptr(asc), ptr(w), ptr(ws), ptr(cum), 1, E, M, K, N, ptr(out), 0, stream_ptr())
     else:
