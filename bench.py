@@ -682,7 +682,12 @@ def fused_moe_section(buf, rank, world, T=4096):
             "effective_peak_TOPs": (INT8_PEAK_TOPS * min(m["clk_gemm1"], 2.4) / 2.4) if m.get("clk_gemm1") else None,
             "frac_of_effective_peak": (tops / (INT8_PEAK_TOPS * min(m["clk_gemm1"], 2.4) / 2.4)) if m.get("clk_gemm1") else None,
             "vendor_dense_int8_gemm_TOPs": m.get("vendor"),      # hipBLASLt dense GEMM of GEMM1's shape on the same GPU (calibration)
+            # ISOLATED, event-timed launches (a second pass with a HIP event pair around every launch: the chain is serialised and every
+            # kernel starts behind an event): their sum exceeds the queued call's ms_p50 -- `kernels_sum_over_call` says by how much -- and
+            # the per-kernel durations that are comparable with profiles/ are rocprofv3's (profiles/rNN_kernel_stats_by_grid.csv)
             "kernels_avg_us": st.get("prof", {}),
+            "kernels_timing": "isolated, event-timed",
+            "kernels_sum_over_call": (sum(st.get("prof", {}).values()) / m["p50"]) if st.get("prof") else None,
             # every rank: output finite AND 256 sampled tokens within the reference bar of the per-token evaluation (tests/fused_f64.py)
             "validated": bool(fin.item() > 0), "validation": {"samples_per_rank": 256, "avg_diff_max": m["val_avg"], "calc_diff_max": m["val_calc"],
                                                               "bar": {"avg_diff": 4e-4, "calc_diff": 1e-5}}}

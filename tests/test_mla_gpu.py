@@ -52,9 +52,9 @@ def run_mla(q, kn, kr, lens, bt, sm_scale, num_splits=0, keep_ws=None):
     return out
 
 
-@pytest.fixture(params=[4, 8, 9], ids=["wide4", "wide8", "wide8q"])
+@pytest.fixture(params=[4, 8, 9], ids=["wide4", "wide8", "wide8s"])
 def wide_variant(request):
-    """The three forms of the > 64-heads-per-group kernel (mla_decode_wide.hip, mla_decode_wide8.hip, mla_decode_wide8q.hip: 9 = eight
+    """The three forms of the > 64-heads-per-group kernel (mla_decode_wide.hip, mla_decode_wide8.hip, mla_decode_wide8s.hip: 9 = eight
     waves, three KV slots, Q^T tail in LDS -- the default; page sizes that are not powers of two take the four-slot kernel there)."""
     assert lib().mi_mla_decode_select_wide(request.param) == 0
     yield request.param

@@ -10,7 +10,8 @@ import sgl_kernel_npu
 q, kn, kr, bt, lens = _mla_inputs(128, 128, 4096, 64)
 out = torch.empty((128, 128, 512), dtype=torch.bfloat16, device="cuda")
 lib = ctypes.CDLL(os.path.join(ROOT, "sgl-kernel-npu_amd", "lib", "libmi_sgl_kernels.so"), mode=ctypes.RTLD_GLOBAL)
-for waves in (4, 8, 9):      # four waves | eight waves, block-id ring | eight waves, scalar block ids (the default)
+ONLY_FUSED = os.environ.get("PMC_ONLY_FUSED") == "1"          # tools/probes/gemm_traffic_ab.sh: the C5 leg alone
+for waves in (() if ONLY_FUSED else (4, 8, 9)):      # four waves | eight waves, block-id ring | eight waves, scalar block ids (the default)
     lib.mi_mla_decode_select_wide(waves)
     for _ in range(40):
         torch.ops.npu.decode_mla(q, kn, kr, out, lens, 576 ** -0.5, 64, bt, 0)
@@ -23,7 +24,7 @@ gq = torch.randn((128, 128, 288), device="cuda").to(torch.bfloat16)
 gbt = torch.randperm(128 * 64, device="cuda").to(torch.int32).reshape(128, 64)
 gl = torch.full((128,), 4096, dtype=torch.int32, device="cuda")
 go = torch.empty((128, 128, 256), dtype=torch.bfloat16, device="cuda")
-for _ in range(40):
+for _ in range(0 if ONLY_FUSED else 40):
     decode_gqa(gq, gk, gk[..., :256], go, gl, 288 ** -0.5, 64, gbt)
 torch.cuda.synchronize()
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29581")
