@@ -175,14 +175,19 @@ def check_round_trip(out, x, topk_w):
     return float(1 - 2 * (a * b).sum() / (a * a + b * b).sum())
 
 
-def ev_stats(fn, n=50, warm=10):
-    """Per-call device time of fn() from HIP events on the current stream -> dict(p50_us, p99_us, min_us)."""
+def ev_stats(fn, n=50, warm=10, pre=None):
+    """Per-call device time of fn() from HIP events on the current stream -> dict(p50_us, p99_us, min_us).  pre(): an UNTIMED call queued in
+    front of every timed one (the start event is recorded behind it)."""
     for _ in range(warm):
+        if pre:
+            pre()
         fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(n):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if pre:
+            pre()
         a.record()
         fn()
         b.record()
@@ -192,14 +197,18 @@ def ev_stats(fn, n=50, warm=10):
     return {"p50_us": ts[len(ts) // 2], "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "min_us": ts[0]}
 
 
-def queued_stats(fn, n=200, warm=10):
+def queued_stats(fn, n=200, warm=10, pre=None):
     """As ev_stats, but the n calls are queued without a host synchronisation in between (one at the end): the GPU never idles between
     calls, as in a serving loop that streams layers, so its clocks stay up and launch latency hides behind the previous call."""
     for _ in range(warm):
+        if pre:
+            pre()
         fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     host = []
     for a, b in evs:
+        if pre:
+            pre()
         a.record()
         h0 = time.perf_counter()
         fn()
@@ -552,13 +561,19 @@ def low_latency_section(buf, rank, world):
         d = ev_stats(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True), n=200)
         return {"d50": d["p50_us"], "d99": d["p99_us"]}
 
+    # A combine is timed BEHIND an untimed dispatch, as it runs in a decode step: a combine that directly follows another combine takes
+    # the three-launch form (its two-launch form is only safe behind a dispatch's all-to-all count exchange, deep_ep.hpp), which is what a
+    # loop of lone combines would time.  (The lone captured combine of graph_combine below IS that three-launch form.)
+    def redispatch():
+        _, _, st["handle"], _, _ = buf.low_latency_dispatch(x, idx, T, E, use_fp8=True)
+
     def time_combine():
-        c = ev_stats(lambda: buf.low_latency_combine(st["y"], idx, w, st["handle"]), n=200)
+        c = ev_stats(lambda: buf.low_latency_combine(st["y"], idx, w, st["handle"]), n=200, pre=redispatch)
         return {"c50": c["p50_us"], "c99": c["p99_us"]}
 
     def queued():               # the same calls queued back to back (no host synchronisation between calls)
         d = queued_stats(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
-        c = queued_stats(lambda: buf.low_latency_combine(st["y"], idx, w, st["handle"]))
+        c = queued_stats(lambda: buf.low_latency_combine(st["y"], idx, w, st["handle"]), pre=redispatch)
         return {"qd50": d["p50_us"], "qd99": d["p99_us"], "qc50": c["p50_us"], "qc99": c["p99_us"],
                 "qdh50": d["host_enqueue_us_p50"], "qdhmax": d["host_enqueue_us_max"], "qdhslow": d["host_enqueue_us_of_slowest_sample"],
                 "qdslowi": d["slowest_sample_index"]}
@@ -603,6 +618,8 @@ def low_latency_section(buf, rank, world):
                              "pair_us_p50_in_graph_of_10": m["gp50"], "pair_us_p99_in_graph_of_10": m["gp99"]},
             # reference byte convention (tests/python/deepep/test_low_latency.py:310-322)
             "dispatch_GBps": n_sel * (HIDDEN + HIDDEN // 128 * 4 + 16) / m["d50"] / 1e3, "combine_GBps": n_sel * HIDDEN * 2 / m["c50"] / 1e3,
+            # launch forms of the timed dispatch / of a combine behind a dispatch (0 three launches, 2 two launches: deep_ep.hpp)
+            "launch_forms": list(buf.runtime.get_low_latency_default_forms()) if hasattr(buf.runtime, "get_low_latency_default_forms") else None,
             "validated_round_trip": m["bad"] == 0.0, "reference_A3_us": {"dispatch": 132, "combine": 126}}
 
 

@@ -70,7 +70,12 @@ public:
     bool self_test_in_launch(int64_t test_timeout_ms, int64_t skip_payload_from_round);
     void set_two_launch_forms(bool ok) { two_launch_forms_ok = ok; }
     bool get_two_launch_forms() const { return two_launch_forms_ok; }
-    // the form the NEXT low_latency_dispatch / low_latency_combine would take (0 three launches, 1 tail-fused, 2 two launches)
+    // the forms of a dispatch and of a combine behind a dispatch (0 three launches, 1 tail-fused, 2 two launches) ...
+    std::vector<int64_t> get_low_latency_default_forms() const
+    {
+        return {ll_launch_form("MI_EP_LL_FUSED_COUNTS"), ll_launch_form("MI_EP_COMBINE_FUSED")};
+    }
+    // ... and the forms the NEXT low_latency_dispatch / low_latency_combine would take (a combine behind a combine: three launches)
     std::vector<int64_t> get_low_latency_launch_forms() const
     {
         return {ll_launch_form("MI_EP_LL_FUSED_COUNTS"), last_ll_call_was_combine ? 0 : ll_launch_form("MI_EP_COMBINE_FUSED")};

@@ -61,6 +61,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     MI_METHOD(buf, set_two_launch_forms);
     MI_METHOD(buf, get_two_launch_forms);
     MI_METHOD(buf, get_low_latency_launch_forms);
+    MI_METHOD(buf, get_low_latency_default_forms);
     MI_METHOD(buf, set_dispatch_transport);
     MI_METHOD(buf, get_dispatch_transport);
     MI_METHOD(buf, set_local_row_paths);

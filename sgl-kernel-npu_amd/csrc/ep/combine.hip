@@ -230,7 +230,13 @@ __device__ __forceinline__ void combine_reduce_body(
         for (int k = 0; k < KMAX; ++k) {
             // unconditional in both paths: an absent / invalid selection re-reads a row that is always there (base_l above) and is skipped in
             // the sum -- under the wave-uniform condition each load got its own block and its own vmcnt(0)
+#if defined(MI_COMBINE_FLAGGED_NT)          // timing probe only: the loads the unflagged form uses
+            if constexpr (FLAGGED) v[k] = __builtin_nontemporal_load((gptr)(uintptr_t)(rowp[k] + (uint32_t)c * 16u));
+#elif defined(MI_COMBINE_FLAGGED_SC1)       // timing probe only: device-scope instead of system-scope loads
+            if constexpr (FLAGGED) v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], (int)((uint32_t)c * 16u), 0, 16));
+#else
             if constexpr (FLAGGED) v[k] = ld_sys_b128(rs[k], (uint32_t)c * 16u);
+#endif
             else v[k] = __builtin_nontemporal_load((gptr)(uintptr_t)(rowp[k] + (uint32_t)c * 16u));
         }
         f32x2 acc[4];
