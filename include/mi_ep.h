@@ -38,9 +38,13 @@
  *
  * Cross-rank data movement is one-sided through "windows": every rank owns a buffer that all
  * peers can address (hipIpc-mapped over xGMI, or plain pointers when several ranks live in one
- * process).  A kernel never spins on a peer inside a data-moving launch: hand-offs are
- * post-kernel -> mi_ep_signal -> (peer) mi_ep_wait -> consume-kernel, so kernel boundaries carry the
- * release/acquire and only the 8-byte flag words need system-scope atomics.
+ * process).  Normal mode, the fused ops and the three-launch low-latency forms never spin on a peer
+ * inside a data-moving launch: hand-offs are post-kernel -> mi_ep_signal -> (peer) mi_ep_wait ->
+ * consume-kernel, so kernel boundaries carry the release/acquire and only the 8-byte flag words
+ * need system-scope atomics.  The two-launch low-latency forms (mi_ep_ll_dispatch_layout_send_tagged +
+ * mi_ep_ll_wait_pack, mi_ep_combine_push_flagged + mi_ep_combine_reduce_flagged) hand rows over inside
+ * running launches: write-through payload, drain, tag / flag word; consumer: system-scope poll, then
+ * system-scope payload loads; mi_ep_selftest_inlaunch checks exactly that.
  */
 #ifndef MI_EP_H_
 #define MI_EP_H_

@@ -14,7 +14,13 @@ def ev_time(fn, n=30, warm=5):
         a.record(); fn(); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e3)
     ts.sort()
-    return {"p50_us": ts[len(ts) // 2], "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "min_us": ts[0]}
+    # the same call queued back to back (no synchronisation in between): a lone event-timed launch carries ~5 us of launch latency between its
+    # two events, a fifth of a 30-us streaming kernel; `queued_us` is what a layer stream sees
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(50): fn()
+    b.record(); torch.cuda.synchronize()
+    return {"p50_us": ts[len(ts) // 2], "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "min_us": ts[0], "queued_us": a.elapsed_time(b) * 1e3 / 50}
 
 def main():
     torch.cuda.set_device(0)
@@ -36,7 +42,14 @@ def main():
     (rx, rs), cnt, handle, _, _ = buf.low_latency_dispatch(x, idx, T, E, use_fp8=True)
     y = (rx.float() * rs[:, None]).to(torch.bfloat16)
     out["ll_dispatch_128tok"] = ev_time(lambda: buf.low_latency_dispatch(x, idx, T, E, use_fp8=True))
+    # (behind a dispatch, as in a decode step: a combine that directly follows another combine takes the three-launch form, deep_ep.hpp)
+    def pair_combine():
+        (_, _), _, h2, _, _ = buf.low_latency_dispatch(x, idx, T, E, use_fp8=True)
+        return buf.low_latency_combine(y, idx, w, h2)
+    tp = ev_time(pair_combine)
+    out["ll_dispatch_combine_pair_128tok"] = tp
     out["ll_combine_128tok"] = ev_time(lambda: buf.low_latency_combine(y, idx, w, handle))
+    out["ll_combine_128tok"]["note"] = "a combine behind a combine: the three-launch form; the two-launch form is inside ll_dispatch_combine_pair_128tok"
     # ---- C5 shapes per rank: fused_deep_moe, DeepSeek-V3 (H=7168, 2I=4096), 32 local experts
     I = 2048
     w13 = torch.randint(-16, 16, (E, 2 * I, H), generator=g, device="cuda", dtype=torch.int8)
@@ -219,6 +232,9 @@ def main():
                                      quant_mode="per_tensor_quant_asymm", q_out0=q0, kv_cache_out0=kv, q_out1=q1, kv_cache_out1=kr)
     t = ev_time(f_cold, n=36, warm=12)
     out["mla_preprocess_128tok_cold_weights"] = dict(t, weight_GBps=wbytes / t["p50_us"] / 1e3)
+    for v in out.values():      # bandwidth at the queued rate beside the single-call one
+        if isinstance(v, dict) and v.get("GBps") and v.get("queued_us") and v.get("p50_us"):
+            v["GBps_queued"] = v["GBps"] * v["p50_us"] / v["queued_us"]
     print(json.dumps(out))
 
 main()
