@@ -39,6 +39,18 @@ constexpr int kMaxTotalTokens = 131072;            // reference MAX_TOTAL_TOKENS
 
 hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
 
+// id of the graph capture `st` is recording into, 0 when it is not capturing
+uint64_t capture_id_of(hipStream_t st)
+{
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(st, &status, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return status == hipStreamCaptureStatusActive ? (uint64_t)id + 1 : 0;
+}
+
 int quant_mode_of(bool use_quant, const std::string &quant_type)
 {
     if (!use_quant) return MI_EP_QUANT_NONE;
@@ -855,6 +867,7 @@ Buffer::low_latency_dispatch(const at::Tensor &x, const at::Tensor &topk_idx_use
     at::Tensor counts_buf;
     bool counts_done = false, tagged_rows = false;
     last_ll_call_was_combine = false;
+    last_ll_dispatch_capture = capture_id_of(cur_stream());
     // The TAGGED wire form (rows carry a tag, no count exchange launch) changes what the receivers wait for, so it is chosen from values every
     // rank shares -- the batch bound MT, E, the env -- never from this rank's own T: a rank with T > 1024 beside ranks with T <= 1024 would
     // otherwise send plain rows to receivers that wait for tags.  (MT <= 1024 implies T <= 1024: the one-launch layout + send fits.)
@@ -1074,7 +1087,9 @@ void Buffer::combine_push_rows(const at::Tensor &x, const int32_t *src_idx, cons
     //     the three launches, but the pair inside a captured graph of ten 28.7 against 27.2 us (256 workgroups arriving at one word and a
     //     tail that waits inside the push cost more than the ~1.3 us boundary they replace); normal-mode step unchanged.
     int fused_form = ll_launch_form("MI_EP_COMBINE_FUSED");
-    if (fused_form == 2 && may_flag_rows && last_ll_call_was_combine) fused_form = 0;      // see last_ll_call_was_combine (deep_ep.hpp)
+    // see last_ll_call_was_combine (deep_ep.hpp); and a combine recorded into a graph WITHOUT its dispatch in the same capture would be
+    // replayed combine after combine: three launches as well
+    if (fused_form == 2 && may_flag_rows && (last_ll_call_was_combine || capture_id_of(st) != last_ll_dispatch_capture)) fused_form = 0;
     if (may_flag_rows) last_ll_call_was_combine = true;
     const bool fused = fused_form == 1;
     const int W = (int)num_ranks;

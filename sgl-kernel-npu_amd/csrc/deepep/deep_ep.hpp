@@ -287,6 +287,7 @@ private:
     // The dispatch's count exchange is all-to-all and closes that; a combine that directly follows another combine on this Buffer takes the
     // three-launch form (whose signal / wait is all-to-all).  Every rank makes the same calls, so every rank switches together.
     bool last_ll_call_was_combine = false;
+    uint64_t last_ll_dispatch_capture = 0;      // graph capture the last low_latency_dispatch was recorded into (0: it ran eagerly)
     // launch form of the low-latency dispatch / combine: the env value if set, else 2 (two launches, nothing between them) when every rank owns
     // its GPU and 0 (three launches) when ranks share one
     int ll_launch_form(const char *env_name) const;

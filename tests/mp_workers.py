@@ -292,6 +292,26 @@ def _gpu_ll_empty_rank(rank, world, port, cfg):
                 outl2, _, hook = buf.low_latency_combine(yl, ti, torch.from_numpy(wabs[rank]).cuda(), h)
                 hook()
                 assert np.array_equal(torch_to_bits(outl2), llc_want[rank]), (it, rep, "repeated LL combine mismatch")
+    if extra.get("capture_lone_combine") and xs[rank].shape[0] > 0:
+        # a combine recorded into a graph WITHOUT its dispatch is replayed combine after combine: it must have been captured in the
+        # three-launch form (whose signal / wait is all-to-all), and every replay returns the same sums
+        rx, cnt, h, _, hook = buf.low_latency_dispatch(x, ti, MT, E, use_fp8=quant)
+        hook()
+        wt = torch.from_numpy(wabs[rank]).cuda()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            buf.low_latency_combine(yl, ti, wt, h)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outg, _, _ = buf.low_latency_combine(yl, ti, wt, h)
+        for rep in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(torch_to_bits(outg), llc_want[rank]), (rep, "replayed lone combine mismatch")
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

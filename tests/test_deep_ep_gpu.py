@@ -123,8 +123,9 @@ def test_low_latency_pair_with_a_rank_without_tokens(cfg, forms):
 def test_two_launch_forms_uncapped_as_on_a_node(cfg):
     """The forms an 8-GPU node takes by default, taken here the same way: no env, the runtime told that every rank owns its GPU (default forms
     2 / 2 selected by the start-up self-test's second leg, waiting launches not capped at 64 workgroups); the batches are small enough for both
-    processes' grids to be resident together.  Plus two extra combines per call on the same handle (they fall back to three launches)."""
-    _spawn(mp_workers.gpu_ll_empty_rank_worker, cfg[0], cfg + (None, {"own_gpu": True, "repeat_combine": True}))
+    processes' grids to be resident together.  Plus two extra combines per call on the same handle (they fall back to three launches) and a lone
+    combine captured in a graph and replayed three times (captured without its dispatch: three launches as well)."""
+    _spawn(mp_workers.gpu_ll_empty_rank_worker, cfg[0], cfg + (None, {"own_gpu": True, "repeat_combine": True, "capture_lone_combine": True}))
 
 
 @pytest.mark.parametrize("forms", [("2", "2"), None], ids=["forms_forced_by_env", "default_forms"])
