@@ -1063,3 +1063,60 @@ def _gpu_shared_expert(rank, world, port, cfg):
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU / gloo: the host side of the start-up check of the two-launch low-latency forms (deep_ep/buffer.py::_check_in_launch_handoff)
+# ----------------------------------------------------------------------------------------------
+def cpu_handoff_check_worker(rank, world, port, cfg):
+    run_guarded(_cpu_handoff_check, rank, world, port, cfg)
+
+
+def _cpu_handoff_check(rank, world, port, cfg):
+    import warnings
+    import deep_ep
+    failing_rank, raises = cfg
+    group = _init(rank, world, port)
+
+    class Stub:                      # what the check needs of deep_ep_cpp.Buffer
+        def __init__(self):
+            self.forms = None
+            self.args = None
+
+        def self_test_in_launch(self, timeout_ms, skip_from):
+            self.args = (timeout_ms, skip_from)
+            if raises and rank == failing_rank:
+                raise RuntimeError("device lost")
+            return rank != failing_rank
+
+        def set_two_launch_forms(self, ok):
+            self.forms = ok
+
+    buf = object.__new__(deep_ep.Buffer)
+    buf.runtime, buf.rank, buf.group, buf.group_size = Stub(), rank, group, world
+
+    def agree(ok):
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok), group=group)
+        return all(flags)
+
+    os.environ.pop("DEEPEP_SELF_TEST_STALE_RANK", None)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        buf._check_in_launch_handoff(agree)
+    # one rank failing (or raising) switches EVERY rank to the three-launch forms, and every rank says so
+    assert buf.runtime.forms is (failing_rank is None)
+    assert buf.runtime.args[1] == -1
+    said = [str(c.message) for c in caught]
+    assert (failing_rank is None) == (not any("three-launch forms" in m for m in said)), said
+    if failing_rank is not None:
+        assert any(("on this rank" in m) == (rank == failing_rank) for m in said if "three-launch forms" in m), said
+    # the test hook reaches the named rank only
+    os.environ["DEEPEP_SELF_TEST_STALE_RANK"] = "1"
+    buf.runtime = Stub()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        buf._check_in_launch_handoff(agree)
+    assert buf.runtime.args[1] == (1 if rank == 1 else -1)
+    dist.barrier()
+    dist.destroy_process_group()

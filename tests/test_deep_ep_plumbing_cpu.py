@@ -34,6 +34,13 @@ def test_alltoall_strategy_over_gloo(cfg):
     _spawn(mp_workers.cpu_alltoall_worker, cfg[0], cfg)
 
 
+@pytest.mark.parametrize("cfg", [(None, False), (1, False), (0, True)], ids=["passes", "rank1_fails", "rank0_raises"])
+def test_in_launch_handoff_check_switches_every_rank(cfg):
+    """deep_ep/buffer.py::_check_in_launch_handoff over gloo, world_size 2, with a stub runtime: a pass keeps the two-launch forms, one rank
+    failing or raising makes EVERY rank call set_two_launch_forms(False) and warn; DEEPEP_SELF_TEST_STALE_RANK reaches the named rank only."""
+    _spawn(mp_workers.cpu_handoff_check_worker, 2, cfg)
+
+
 def test_strategy_registry_and_errors():
     import deep_ep
     from deep_ep.ep_strategy import StrategyMap, get_normal_strategy, get_low_latency_strategy
