@@ -147,7 +147,7 @@ def test_moe_gemm_chain_vs_oracle(counts, H, I, stride, hint):
     if (2 * I) % 256 == 0:
         # the requantisation in GEMM1's epilogue: the bits of the two launches, with the probed XCD count and with "no placement assumed",
         # from the dense rows and through a row-offset table (rows 128-byte aligned, in another order)
-        for xcds in (None, 1):
+        for xcds in (None, 1, 2, 4):        # (2, 4: the ticket groups a partitioned device would form; the launcher falls back to 1 when gx % xcds != 0)
             q_f, sc_f, st_f = run_gemm1_quant(t(a), t(a_scale), t(w13[:, perm, :]), t(s13[:, perm]), cum, stride, L, rows_cap, H, 2 * I, hint, xcds)
             assert int(st_f[0]) == 0
             assert torch.equal(q_f[:total], q[:total]) and torch.equal(sc_f[:total].view(torch.int32), sc[:total].view(torch.int32)), xcds
