@@ -31,6 +31,17 @@ def make_inputs(W, T, H, K, E, drop, seed=1234):
     return xs, idxs, ws
 
 
+def _set_device(rank):
+    """The GPU a worker process runs on.  Default: cuda:0 for every rank (W processes share one GPU, windows mapped through hipIpc -- what the
+    one-GPU test boxes offer).  MI_TEST_DEVICE_PER_RANK=1 on a multi-GPU node: rank r takes GPU r mod device_count, so the same parity tests run with
+    every rank's window behind its own GPU and the peers' stores crossing xGMI -- the first thing to run when a node is available
+    (`MI_TEST_DEVICE_PER_RANK=1 python -m pytest tests/test_deep_ep_gpu.py -m gpu -x -q`)."""
+    n = torch.cuda.device_count()
+    dev = rank % n if (os.environ.get("MI_TEST_DEVICE_PER_RANK") == "1" and n > 1) else 0
+    torch.cuda.set_device(dev)
+    return dev
+
+
 def _init(rank, world, port, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -117,7 +128,7 @@ def _gpu_buffer(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T, H, K, E, drop, quant, strategy, iters = cfg
     # RCCL refuses several ranks on one GPU, so the multi-process cases bootstrap over gloo; the alltoall strategy
     # needs a real RCCL group for its device collectives and is exercised at world size 1 here
@@ -220,7 +231,7 @@ def _gpu_ll_empty_rank(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T0, H, K, E, quant, forms = cfg[:7]
     # optional 8th entry: stale_rank (that rank fails the in-launch self-test leg for everybody: DEEPEP_SELF_TEST_STALE_RANK), own_gpu (pretend
     # every rank owns its GPU: default forms, waiting launches uncapped), tokens (per-rank token counts) + max_tokens, repeat_combine
@@ -336,7 +347,7 @@ def _gpu_c2_size(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import torch_to_bits
-    torch.cuda.set_device(0)
+    _set_device(rank)
     import faulthandler
     import time
     W, T, H, K, E = cfg
@@ -418,7 +429,7 @@ def _gpu_fused_moe(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits, bf16_bits_to_f32
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T, H, I, K, E, layout = cfg
     group = _init(rank, world, port)
     os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(1 << 30))
@@ -494,7 +505,7 @@ def _gpu_fused_c5(rank, world, port, cfg):
     import faulthandler
     import deep_ep
     import fused_f64 as F
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T, H, I, K, L, samples = cfg
     E = L * W
     faulthandler.dump_traceback_later(420, exit=True)
@@ -550,7 +561,7 @@ def _gpu_inference_mode(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T, H, I, K, E = cfg
     L = E // W
     group = _init(rank, world, port)
@@ -622,7 +633,7 @@ def _gpu_fp8(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T, H, K, E, drop = cfg
     group = _init(rank, world, port)
     os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(512 << 20))
@@ -681,7 +692,7 @@ def gpu_timeout_worker(rank, world, port, cfg):
 def _gpu_timeout(rank, world, port, cfg):
     import time
     import deep_ep
-    torch.cuda.set_device(0)
+    _set_device(rank)
     os.environ["DEEPEP_TIMEOUT_MS"] = "300"
     os.environ.setdefault("DEEPEP_WINDOW_BYTES", str(256 << 20))
     group = _init(rank, world, port, "gloo")
@@ -720,7 +731,7 @@ def _gpu_long_seq(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T, H, K, E, drop, quant, rounds, per_round = cfg
     os.environ["DEEPEP_NORMAL_LONG_SEQ_ROUND"] = str(rounds)
     os.environ["DEEPEP_NORMAL_LONG_SEQ_PER_ROUND_TOKENS"] = str(per_round)
@@ -805,7 +816,7 @@ def _gpu_graph(rank, world, port, cfg):
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits, bf16_bits_to_f32
     faulthandler.dump_traceback_later(200, exit=True)
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, T, H, I, K, E, replays = cfg
     L = E // W
     group = _init(rank, world, port)
@@ -918,7 +929,7 @@ def _gpu_tp_rmsnorm(rank, world, port, cfg):
     from sgl_kernel_npu.norm.split_qkv_tp_rmsnorm_rope import split_qkv_tp_rmsnorm_rope
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    _set_device(rank)
     B, qh, kvh, hd = cfg                                   # per-rank shard sizes
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(1234)                # the same full tensors on every rank
@@ -954,7 +965,7 @@ def gpu_layout_two_streams_worker(rank, world, port, cfg):
 def _gpu_layout_two_streams(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
-    torch.cuda.set_device(0)
+    _set_device(rank)
     group = _init(rank, world, port)
     T, K, E, rounds = cfg
     buf = deep_ep.Buffer(group, low_latency_mode=False)
@@ -991,7 +1002,7 @@ def _gpu_shared_expert(rank, world, port, cfg):
     import deep_ep
     from oracle import ep as O
     from oracle.bf16 import bits_to_torch, torch_to_bits, bf16_bits_to_f32
-    torch.cuda.set_device(0)
+    _set_device(rank)
     W, S, T, H, K, E, drop, quant, I = cfg
     os.environ["MOE_SHARED_EXPERT_RANK_NUM"] = str(S)
     group = _init(rank, world, port)
