@@ -717,8 +717,9 @@ static void gemm_launch_one(const GemmArgs &p, void *stream)
     // (A balanced variant -- the surplus column slots 28 .. 31, on XCDs 4 .. 7, taking every second (expert, row block) of columns 24 .. 27,
     //  3.5 columns per XCD -- was measured too: GEMM2 522 us uniform / 569 us with multinomial row counts against 482-490 / 537 for the plain
     //  order, fabric traffic 2.25 GB against 2.61 GB.  Consistency costs time even when the deal is even.)
-    static const bool small_last = !(getenv("MI_GEMM_SMALL_LAST") && atoi(getenv("MI_GEMM_SMALL_LAST")) == 0);
-    q.small_last = small_last;
+    // MI_GEMM_SMALL_LAST: 0 never, 1 (default) both GEMMs, 2 GEMM1 only (A/B of GEMM2's fabric traffic: profiles/r06_gemm_traffic_ab.txt)
+    static const int small_last = getenv("MI_GEMM_SMALL_LAST") ? atoi(getenv("MI_GEMM_SMALL_LAST")) : 1;
+    q.small_last = small_last == 1 || (small_last == 2 && (MODE == 0 || MODE == 3));
     static const bool xcd_cols = getenv("MI_GEMM_XCD_COLS") && atoi(getenv("MI_GEMM_XCD_COLS")) != 0;
     q.cols_padded = (xcd_cols && gx % 8 != 0 && gx > 8) ? (gx + 7) / 8 * 8 : 0;
     // (padded form: the same number of workers, gx' x pool flat ids cut into rows of gx')
