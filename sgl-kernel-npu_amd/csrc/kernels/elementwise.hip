@@ -488,7 +488,8 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     const uint16_t *__restrict__ kw, const uint16_t *__restrict__ qb, const uint16_t *__restrict__ kb, int neox_p,
     uint16_t *__restrict__ q, uint16_t *__restrict__ k, uint16_t *__restrict__ v, uint16_t *__restrict__ gate, int gemma_p, MropeSections ms)
 {
-    static_assert(!(FAST && MROPE), "the fast instance serves the plain form");
+    // (FAST && MROPE: the same branch-free instance with the row's cos / sin pairs from the LDS table below -- the launcher guarantees the
+    //  table form applies: at least 8 head-sized items per row, so a workgroup's heads span at most kMropeRows rows)
     const int head_dim = FAST ? 128 : head_dim_p, rope_dim = FAST ? 128 : rope_dim_p;
     const int has_norm = FAST ? 1 : has_norm_p, neox = FAST ? 1 : neox_p, gemma = FAST ? 0 : gemma_p;
     // gate != nullptr: the gated Gemma form (split_qkv_rmsnorm_rope.py:441-745) -- the row is q_heads pairs [q head | gate head], then K,
@@ -513,15 +514,31 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     int h[kVecUnroll];
     bool active[kVecUnroll];
     u32x4 xr[kVecUnroll], wr[kVecUnroll], br[kVecUnroll], sr[kVecUnroll], cr[kVecUnroll];
-    float cvf[MROPE ? kVecUnroll : 1][8], svf[MROPE ? kVecUnroll : 1][8];      // MROPE: cos / sin of this lane's eight elements, selected at load time
+    float cvf[(MROPE || FAST) ? kVecUnroll : 1][8], svf[(MROPE || FAST) ? kVecUnroll : 1][8];      // MROPE / FAST: cos / sin of this lane's eight elements
     // MROPE with sections (mode 0): every head of a row rotates with the SAME selected cos / sin, and a workgroup's 4 x kVecUnroll x
     // heads_per_wave heads span one or two rows (up to kMropeRows) -- so the workgroup selects each row's rope_dim / 2 pairs ONCE into LDS
     // (one thread per (row, offset): two 2-byte loads from the offset's section) and every lane reads its eight pairs from there.  Read per
     // lane, the six 16-byte section vectors were 96 bytes of L2 traffic and ~100 selects for every 16 bytes of the row: 2.3 TB/s at 4096 x 8192.
     constexpr int kMropeRows = 8, kMropeHalf = 128;
-    __shared__ float mrope_tab[MROPE ? kMropeRows * 2 * kMropeHalf : 1];
+    __shared__ float mrope_tab[(MROPE || FAST) ? kMropeRows * 2 * kMropeHalf : 1];
     bool mrope_lds = false;
     uint32_t mrope_row0 = 0;
+    if (FAST && !MROPE) {
+        // the plain form's FAST instance takes its cos / sin from the same kind of table: entry o < rope_dim (= 128) of row r = cos / sin[row][o],
+        // one thread per (row, o) -- instead of two 16-byte vectors per lane and head (the table forms of mrope / position cache ran FASTER than
+        // the plain form until it got this: 24.7-25.4 against 26.4 us at 4096 x 8192)
+        const uint32_t hg0 = (uint32_t)blockIdx.x * 4u * kVecUnroll * heads_per_wave, hcount = 4u * kVecUnroll * heads_per_wave;
+        mrope_row0 = hg0 / (uint32_t)heads_total;
+        const uint32_t row_last = min((hg0 + hcount - 1u) / (uint32_t)heads_total, (uint32_t)rows - 1u);
+        const int nrows = min((int)row_last - (int)mrope_row0 + 1, kMropeRows);
+        for (int idx = threadIdx.x; idx < nrows * rope_dim; idx += 256) {
+            const int r = idx / rope_dim, o = idx - r * rope_dim;
+            const long long src = (long long)(mrope_row0 + r) * rope_dim + o;
+            mrope_tab[(r * 2 + 0) * kMropeHalf + o] = ld16<BF16>(cos[src]);
+            mrope_tab[(r * 2 + 1) * kMropeHalf + o] = ld16<BF16>(sin[src]);
+        }
+        __syncthreads();
+    }
     if (MROPE) {
         const uint32_t hg0 = (uint32_t)blockIdx.x * 4u * kVecUnroll * heads_per_wave, hcount = 4u * kVecUnroll * heads_per_wave;
         mrope_row0 = hg0 / (uint32_t)heads_total;
@@ -569,7 +586,18 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
         xr[u] = active[u] ? *(const u32x4 *)(qkv + row[u] * total_hidden + (long long)h[u] * head_dim + j * 8) : zero4;
         wr[u] = (has_norm && normed) ? *(const u32x4 *)((is_q ? qw : kw) + j * 8) : zero4;
         br[u] = (has_norm && normed && qb) ? *(const u32x4 *)((is_q ? qb : kb) + j * 8) : zero4;
-        if (MROPE) {
+        if (MROPE && FAST) {
+            sr[u] = zero4, cr[u] = zero4;
+            const int o0 = (j * 8) % half;
+            const int rr = min(max((int)(row[u] - mrope_row0), 0), kMropeRows - 1);      // (inactive lanes read a row of the table, unused)
+            const float *tc = mrope_tab + (rr * 2) * kMropeHalf + o0;
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                const f32x4_t c4 = *(const f32x4_t *)(tc + e), s4 = *(const f32x4_t *)(tc + kMropeHalf + e);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cvf[u][e + i] = c4[i], svf[u][e + i] = s4[i];
+            }
+        } else if (MROPE) {
             sr[u] = zero4, cr[u] = zero4;
 #pragma unroll
             for (int e = 0; e < 8; ++e) cvf[u][e] = 0.f, svf[u][e] = 0.f;
@@ -624,6 +652,16 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
                     cvf[u][e] = sec == 0 ? c3[0][e] : (sec == 1 ? c3[1][e] : (sec == 2 ? c3[2][e] : 0.0f));
                     svf[u][e] = sec == 0 ? s3[0][e] : (sec == 1 ? s3[1][e] : (sec == 2 ? s3[2][e] : 0.0f));
                 }
+            }
+        } else if (FAST) {
+            sr[u] = zero4, cr[u] = zero4;
+            const int rr = min(max((int)(row[u] - mrope_row0), 0), kMropeRows - 1);
+            const float *tc = mrope_tab + (rr * 2) * kMropeHalf + j * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                const f32x4_t c4 = *(const f32x4_t *)(tc + e), s4 = *(const f32x4_t *)(tc + kMropeHalf + e);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cvf[u][e + i] = c4[i], svf[u][e + i] = s4[i];
             }
         } else if (neox) {
             sr[u] = (normed && roped) ? *(const u32x4 *)(sin + row[u] * (long long)rope_dim + j * 8) : zero4;
@@ -691,7 +729,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             }
             if (FAST || (active[u] && !is_v && roped)) {
                 float sv[8], cv[8];
-                if (MROPE) {
+                if (MROPE || FAST) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sv[e] = svf[u][e], cv[e] = cvf[u][e];
                 } else {
@@ -872,7 +910,7 @@ extern "C" int mi_split_qkv_rmsnorm_rope(const void *qkv, const void *sin, const
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, neox, (uint16_t *)q,   \
         (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, MropeSections{0, 0, 0, 0, 0, nullptr, 0, 0, 0, 0, 0})
         // the common shape -- heads of 128 rotated whole, rotate-half, norm weights -- has its own branch-free instance
-        const bool fast = head_dim == 128 && rope_dim == 128 && neox && has_norm;
+        const bool fast = head_dim == 128 && rope_dim == 128 && neox && has_norm && heads_total >= 8;      // (>= 8 items per row: the cos / sin table form)
 #define MI_VEC_FAST(B)                                                                                                              \
     split_qkv_rmsnorm_rope_vec_kernel<B, false, true><<<blocks, 256, 0, st>>>(                                                      \
         (const uint16_t *)qkv, (const uint16_t *)sin, (const uint16_t *)cos, rows, q_hidden, kv_hidden, head_dim, rope_dim, has_norm, eps, \
@@ -963,12 +1001,16 @@ extern "C" int mi_split_qkv_rmsnorm_mrope(const void *qkv, const void *cos_sin, 
     const int vblocks = (int)((vwaves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     const MropeSections ms{sec_t, sec_h, sec_w, sections_interleaved ? 1 : 0, 0, nullptr, 0, 0, 0, 0, 0};
-#define MI_MVEC(B)                                                                                                                     \
-    split_qkv_rmsnorm_rope_vec_kernel<B, true><<<vblocks, 256, 0, st>>>(                                                               \
+#define MI_MVEC(B, F)                                                                                                                  \
+    split_qkv_rmsnorm_rope_vec_kernel<B, true, F><<<vblocks, 256, 0, st>>>(                                                            \
         (const uint16_t *)qkv, (const uint16_t *)cos_sin, (const uint16_t *)nullptr, rows, q_hidden, kv_hidden, head_dim, rope_dim, 1, eps, \
         (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, 1, (uint16_t *)q,    \
         (uint16_t *)k, (uint16_t *)v, (uint16_t *)gate, 0, ms)
-    if (dtype == MI_DTYPE_BF16) MI_MVEC(true); else MI_MVEC(false);
+    // heads of 128 rotated whole, plain (not gated), enough items per row for the LDS table: the branch-free instance (MI_SPLIT_QKV_FAST=0: the general one)
+    static const bool allow_fast = !(getenv("MI_SPLIT_QKV_FAST") && atoi(getenv("MI_SPLIT_QKV_FAST")) == 0);
+    const bool fast = allow_fast && head_dim == 128 && rope_dim == 128 && !gate && items_total >= 8;
+    if (fast) { if (dtype == MI_DTYPE_BF16) MI_MVEC(true, true); else MI_MVEC(false, true); }
+    else if (dtype == MI_DTYPE_BF16) MI_MVEC(true, false); else MI_MVEC(false, false);
 #undef MI_MVEC
     return launch_ok();
 }
@@ -996,12 +1038,15 @@ extern "C" int mi_split_qkv_rmsnorm_rope_pos_cache(const void *qkv, const void *
     const int vblocks = (int)((vwaves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     const MropeSections ms{0, 0, 0, 0, 1, positions, pos_is_i64 ? 1 : 0, max_seq, cache_stride0, cache_dtype, cast_norm ? 1 : 0};
-#define MI_PVEC(B)                                                                                                                     \
-    split_qkv_rmsnorm_rope_vec_kernel<B, true><<<vblocks, 256, 0, st>>>(                                                               \
+#define MI_PVEC(B, F)                                                                                                                  \
+    split_qkv_rmsnorm_rope_vec_kernel<B, true, F><<<vblocks, 256, 0, st>>>(                                                            \
         (const uint16_t *)qkv, (const uint16_t *)cos_sin_cache, (const uint16_t *)nullptr, rows, q_hidden, kv_hidden, head_dim, rope_dim, \
         has_norm, eps, (const uint16_t *)q_weight, (const uint16_t *)k_weight, (const uint16_t *)q_bias, (const uint16_t *)k_bias, 1,   \
         (uint16_t *)q, (uint16_t *)k, (uint16_t *)v, (uint16_t *)nullptr, 0, ms)
-    if (dtype == MI_DTYPE_BF16) MI_PVEC(true); else MI_PVEC(false);
+    static const bool allow_fast = !(getenv("MI_SPLIT_QKV_FAST") && atoi(getenv("MI_SPLIT_QKV_FAST")) == 0);
+    const bool fast = allow_fast && head_dim == 128 && rope_dim == 128 && has_norm && items_total >= 8;
+    if (fast) { if (dtype == MI_DTYPE_BF16) MI_PVEC(true, true); else MI_PVEC(false, true); }
+    else if (dtype == MI_DTYPE_BF16) MI_PVEC(true, false); else MI_PVEC(false, false);
 #undef MI_PVEC
     return launch_ok();
 }

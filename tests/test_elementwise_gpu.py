@@ -251,6 +251,7 @@ def test_split_qkv_tp_rmsnorm_rope_two_launch_form_with_a_foreign_variance():
     (65, 2, 1, 256, 128, [48, 40, 40], False, False, True),
     (33, 16, 2, 128, 128, [24, 20, 20], True, False, False),      # Qwen2.5-VL / Qwen3-VL head shapes
     (33, 16, 2, 128, 128, [16, 24, 24], False, True, True),
+    (33, 16, 2, 128, 128, [24, 20, 20], False, False, True),      # the branch-free instance (heads of 128 rotated whole, not gated) with biases
     (5, 4, 4, 64, 32, [8, 4, 4], False, False, False),
     (9, 4, 2, 128, 128, [16, 16, 16], False, False, False),       # sections end before rope_dim / 2: offsets 48..63 take cos = sin = 0 (kernel :157-163)
 ])
