@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     int h[kVecUnroll];
     bool active[kVecUnroll];
     u32x4 xr[kVecUnroll], wr[kVecUnroll], br[kVecUnroll], sr[kVecUnroll], cr[kVecUnroll];
-    float cvf[(MROPE || FAST) ? kVecUnroll : 1][8], svf[(MROPE || FAST) ? kVecUnroll : 1][8];      // MROPE / FAST: cos / sin of this lane's eight elements
+    float cvf[(MROPE && !FAST) ? kVecUnroll : 1][8], svf[(MROPE && !FAST) ? kVecUnroll : 1][8];      // MROPE (general instance): cos / sin of this lane's eight elements
     // MROPE with sections (mode 0): every head of a row rotates with the SAME selected cos / sin, and a workgroup's 4 x kVecUnroll x
     // heads_per_wave heads span one or two rows (up to kMropeRows) -- so the workgroup selects each row's rope_dim / 2 pairs ONCE into LDS
     // (one thread per (row, offset): two 2-byte loads from the offset's section) and every lane reads its eight pairs from there.  Read per
@@ -523,6 +523,16 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
     __shared__ float mrope_tab[(MROPE || FAST) ? kMropeRows * 2 * kMropeHalf : 1];
     bool mrope_lds = false;
     uint32_t mrope_row0 = 0;
+    // FAST: the norm weights and biases of a 128-wide head are 16 chunks of 16 bytes each, the same for every head of the launch: staged once
+    // per workgroup as well (threads 0..63: q weight | k weight | q bias | k bias), read from LDS per head instead of from global memory
+    __shared__ u32x4 wtab[FAST ? 64 : 1];
+    if (FAST) {
+        if (threadIdx.x < 64) {
+            const int which = threadIdx.x >> 4, c = threadIdx.x & 15;
+            const uint16_t *srcp = which == 0 ? qw : (which == 1 ? kw : (which == 2 ? qb : kb));
+            wtab[threadIdx.x] = srcp ? *(const u32x4 *)(srcp + c * 8) : zero4;
+        }
+    }
     if (FAST && !MROPE) {
         // the plain form's FAST instance takes its cos / sin from the same kind of table: entry o < rope_dim (= 128) of row r = cos / sin[row][o],
         // one thread per (row, o) -- instead of two 16-byte vectors per lane and head (the table forms of mrope / position cache ran FASTER than
@@ -570,6 +580,8 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
                 mrope_tab[(r * 2 + 1) * kMropeHalf + o] = svv;
             }
             __syncthreads();
+        } else if (FAST) {
+            __syncthreads();                                 // (wtab; the launcher only picks FAST where the table form applies)
         }
     }
 #pragma unroll
@@ -584,19 +596,14 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
         const bool is_v = h[u] >= q_items + kv_heads || (gated && h[u] < q_items && (h[u] & 1)), is_q = h[u] < q_items;
         const bool normed = FAST ? active[u] : (active[u] && !is_v);      // FAST: V heads load (and compute) like the others
         xr[u] = active[u] ? *(const u32x4 *)(qkv + row[u] * total_hidden + (long long)h[u] * head_dim + j * 8) : zero4;
-        wr[u] = (has_norm && normed) ? *(const u32x4 *)((is_q ? qw : kw) + j * 8) : zero4;
-        br[u] = (has_norm && normed && qb) ? *(const u32x4 *)((is_q ? qb : kb) + j * 8) : zero4;
-        if (MROPE && FAST) {
-            sr[u] = zero4, cr[u] = zero4;
-            const int o0 = (j * 8) % half;
-            const int rr = min(max((int)(row[u] - mrope_row0), 0), kMropeRows - 1);      // (inactive lanes read a row of the table, unused)
-            const float *tc = mrope_tab + (rr * 2) * kMropeHalf + o0;
-#pragma unroll
-            for (int e = 0; e < 8; e += 4) {
-                const f32x4_t c4 = *(const f32x4_t *)(tc + e), s4 = *(const f32x4_t *)(tc + kMropeHalf + e);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cvf[u][e + i] = c4[i], svf[u][e + i] = s4[i];
-            }
+        if (FAST) {
+            wr[u] = br[u] = zero4;          // (read from wtab where they are used)
+        } else {
+            wr[u] = (has_norm && normed) ? *(const u32x4 *)((is_q ? qw : kw) + j * 8) : zero4;
+            br[u] = (has_norm && normed && qb) ? *(const u32x4 *)((is_q ? qb : kb) + j * 8) : zero4;
+        }
+        if (FAST) {
+            sr[u] = zero4, cr[u] = zero4;       // (the cos / sin pairs are read from the LDS table where they are used: 32 registers less)
         } else if (MROPE) {
             sr[u] = zero4, cr[u] = zero4;
 #pragma unroll
@@ -653,16 +660,6 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
                     svf[u][e] = sec == 0 ? s3[0][e] : (sec == 1 ? s3[1][e] : (sec == 2 ? s3[2][e] : 0.0f));
                 }
             }
-        } else if (FAST) {
-            sr[u] = zero4, cr[u] = zero4;
-            const int rr = min(max((int)(row[u] - mrope_row0), 0), kMropeRows - 1);
-            const float *tc = mrope_tab + (rr * 2) * kMropeHalf + j * 8;
-#pragma unroll
-            for (int e = 0; e < 8; e += 4) {
-                const f32x4_t c4 = *(const f32x4_t *)(tc + e), s4 = *(const f32x4_t *)(tc + kMropeHalf + e);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cvf[u][e + i] = c4[i], svf[u][e + i] = s4[i];
-            }
         } else if (neox) {
             sr[u] = (normed && roped) ? *(const u32x4 *)(sin + row[u] * (long long)rope_dim + j * 8) : zero4;
             cr[u] = (normed && roped) ? *(const u32x4 *)(cos + row[u] * (long long)rope_dim + j * 8) : zero4;
@@ -695,7 +692,8 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
                 // rsqrt where the reference kernel says tl.rsqrt (gemma :500, position cache :101), 1 / sqrt where it says so (mrope :202)
                 const float rstd = (gemma || (MROPE && ms.mode == 1)) ? rsqrtf(ss / (float)head_dim + eps) : 1.0f / sqrtf(ss / (float)head_dim + eps);
                 float wv[8];
-                unpack8<BF16>(wr[u], wv);
+                if (FAST) unpack8<BF16>(wtab[(is_q ? 0 : 16) + j], wv);
+                else unpack8<BF16>(wr[u], wv);
                 if (gemma) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) wv[e] = wv[e] + 1.0f;
@@ -704,7 +702,8 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
                 for (int e = 0; e < 8; ++e) x[e] = (x[e] * rstd) * wv[e];
                 if (qb) {
                     float bv[8];
-                    unpack8<BF16>(br[u], bv);
+                    if (FAST) unpack8<BF16>(wtab[(is_q ? 32 : 48) + j], bv);
+                    else unpack8<BF16>(br[u], bv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = x[e] + bv[e];
                 }
@@ -729,7 +728,19 @@ __global__ __launch_bounds__(256) void split_qkv_rmsnorm_rope_vec_kernel(
             }
             if (FAST || (active[u] && !is_v && roped)) {
                 float sv[8], cv[8];
-                if (MROPE || FAST) {
+                if (FAST) {
+                    // entry of this lane's eight elements: mrope / position cache tables hold rope_dim / 2 pairs (offset p mod rope_dim / 2), the plain
+                    // form's rope_dim pairs; inactive lanes read a row of the table, unused
+                    const int o0 = MROPE ? (j * 8) % half : j * 8;
+                    const int rr = min(max((int)(row[u] - mrope_row0), 0), kMropeRows - 1);
+                    const float *tc = mrope_tab + (rr * 2) * kMropeHalf + o0;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 4) {
+                        const f32x4_t c4 = *(const f32x4_t *)(tc + e), s4 = *(const f32x4_t *)(tc + kMropeHalf + e);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cv[e + i] = c4[i], sv[e + i] = s4[i];
+                    }
+                } else if (MROPE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sv[e] = svf[u][e], cv[e] = cvf[u][e];
                 } else {

@@ -10,7 +10,8 @@ OUT=$REPO/gpurun_out/pmc_r$RND
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
-for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+# (the last two passes: fabric-side traffic of the same launches -- the kernels bench.py does not run, e.g. the wide GQA kernel, get their FETCH / WRITE here)
+for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/p$i" -- python "$REPO/tools/probes/pmc_workload.py" > /dev/null 2>&1
 done
@@ -48,6 +49,8 @@ for k, cs in sorted(agg.items()):
         der["mfma_busy_fraction_of_simd_time"] = per_wave * wps
     if c.get("SQ_LDS_IDX_ACTIVE"):
         der["lds_bank_conflict_over_lds_active"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
+        der["hbm_side_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0      # gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md)
     if c.get("SQ_WAVE_CYCLES"):
         for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
             if c.get(n) is not None:
