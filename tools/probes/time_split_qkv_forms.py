@@ -31,3 +31,22 @@ for name, f in forms.items():
         b.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) / 200 * 1e3)
     print(f"{name}: {best:.1f} us  {B * 8192 * 4 / best / 1e6:.2f} TB/s", flush=True)
+# fused_rope_qk_mqa (A13): MLA-sized q [T, 128, 192] with the first 64 dims rotated, one shared key head; and a pure-rope shape [T, 128, 64]
+from sgl_kernel_npu.norm.fused_rope_qk_mqa import fused_rope_qk_mqa
+for (T, Hq, Hk, D, R) in ((4096, 128, 1, 192, 64), (4096, 128, 1, 64, 64), (128, 128, 1, 192, 64)):
+    qq = torch.randn((T, Hq, D), device="cuda").to(torch.bfloat16)
+    kk = torch.randn((T, Hk, D), device="cuda").to(torch.bfloat16)
+    cs = torch.rand((T, R), device="cuda").to(torch.bfloat16)
+    for neox in (True, False):
+        f = lambda: fused_rope_qk_mqa(qq, kk, cs, R, neox)
+        for _ in range(20): f()
+        torch.cuda.synchronize()
+        best = 1e9
+        for rep in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(100): f()
+            b.record(); torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) / 100 * 1e3)
+        byts = T * (Hq + Hk) * D * 4
+        print(f"fused_rope_qk_mqa T={T} Hq={Hq} D={D} R={R} neox={neox}: {best:.1f} us  {byts / best / 1e6:.2f} TB/s", flush=True)
