@@ -869,6 +869,62 @@ __global__ __launch_bounds__(256) void rope_qk_mqa_kernel(const uint16_t *__rest
     }
     for (int i = R + lane; i < D; i += 64) dst[i] = src[i];
 }
+// Vectorised form: a lane owns 8 consecutive elements (16 bytes) of a head; a head is D / 8 lanes, heads and tokens are laid end to end over
+// the grid.  Rotate-half: the partner chunk (R / 2 elements away) is loaded by the lane itself -- an L1 / L2 hit of the line its neighbour
+// lane reads -- so no cross-lane traffic and any D; interleaved pairs live inside the lane's own chunk.  cos / sin: 16 (8) bytes each per
+// lane from the token's row.  Same op-by-op arithmetic as the scalar kernel above (which keeps serving D % 8 != 0, R % 16 != 0 or unaligned
+// strides): bit-identical outputs.  The scalar kernel moved 2 bytes per lane and instruction: 1.6-2.3 TB/s at 4096 tokens x 128 heads.
+template <bool BF16>
+__global__ __launch_bounds__(256) void rope_qk_mqa_vec_kernel(const uint16_t *__restrict__ q, const uint16_t *__restrict__ k,
+                                                             const uint16_t *__restrict__ cos_sin, long long lanes_total, int Hq, int Hk, int D,
+                                                             int R, int neox, long long q_st, long long q_sh, long long k_st, long long k_sh,
+                                                             long long cs_st, uint16_t *__restrict__ oq, uint16_t *__restrict__ ok)
+{
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= lanes_total) return;
+    // lanes of a head: rotate-half -- one per PAIR of chunks (elements e0 .. e0 + 7 and their partners R / 2 further: both halves of the
+    // rotation from two loads, nothing read twice), then one per copied chunk; interleaved -- one per chunk
+    const int half = R >> 1;
+    const uint32_t rot_lanes = (uint32_t)(neox ? half : R) >> 3, lph = rot_lanes + ((uint32_t)(D - R) >> 3), H = (uint32_t)(Hq + Hk);
+    const uint32_t hg = (uint32_t)(gid / lph), j = (uint32_t)(gid - (long long)hg * lph);      // head (token-major), lane inside the head
+    const uint32_t t = hg / H, h = hg - t * H;
+    const bool is_q = h < (uint32_t)Hq;
+    const uint16_t *src = is_q ? q + (long long)t * q_st + (long long)h * q_sh : k + (long long)t * k_st + (long long)(h - Hq) * k_sh;
+    uint16_t *dst = is_q ? oq + ((long long)t * Hq + h) * (long long)D : ok + ((long long)t * Hk + (h - Hq)) * (long long)D;
+    if (j >= rot_lanes) {                                 // behind the rotated part: copied
+        const int e0 = R + (int)(j - rot_lanes) * 8;
+        *(u32x4 *)(dst + e0) = *(const u32x4 *)(src + e0);
+        return;
+    }
+    const int e0 = (int)j * 8;
+    const uint16_t *cs = cos_sin + (long long)t * cs_st;
+    auto r = [](float f) -> float { return ld16<BF16>(st16<BF16>(f)); };
+    if (neox) {
+        const u32x4 x1v = *(const u32x4 *)(src + e0), x2v = *(const u32x4 *)(src + e0 + half);
+        const u32x4 cv = *(const u32x4 *)(cs + e0), sv = *(const u32x4 *)(cs + half + e0);
+        float x1[8], x2[8], c[8], sn[8], o1[8], o2[8];
+        unpack8<BF16>(x1v, x1), unpack8<BF16>(x2v, x2), unpack8<BF16>(cv, c), unpack8<BF16>(sv, sn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o1[e] = r(x1[e] * c[e]) - r(x2[e] * sn[e]);
+            o2[e] = r(x1[e] * sn[e]) + r(x2[e] * c[e]);
+        }
+        *(u32x4 *)(dst + e0) = pack8<BF16>(o1);
+        *(u32x4 *)(dst + e0 + half) = pack8<BF16>(o2);
+    } else {
+        float x[8], o[8];
+        unpack8<BF16>(*(const u32x4 *)(src + e0), x);
+        const u32x2 cw = *(const u32x2 *)(cs + (e0 >> 1)), sw = *(const u32x2 *)(cs + half + (e0 >> 1));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float c = ld16<BF16>((cw[p >> 1] >> (16 * (p & 1))) & 0xFFFFu), sn = ld16<BF16>((sw[p >> 1] >> (16 * (p & 1))) & 0xFFFFu);
+            const float x1 = x[2 * p], x2 = x[2 * p + 1];
+            o[2 * p] = r(x1 * c) - r(x2 * sn);
+            o[2 * p + 1] = r(x1 * sn) + r(x2 * c);
+        }
+        *(u32x4 *)(dst + e0) = pack8<BF16>(o);
+    }
+}
 }  // namespace
 
 extern "C" int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin, int tokens, int q_heads, int k_heads, int head_dim,
@@ -880,9 +936,30 @@ extern "C" int mi_rope_qk_mqa(const void *q, const void *k, const void *cos_sin,
         return MI_SGL_EINVAL;
     if (tokens == 0) return MI_SGL_OK;
     if (!q || !k || !cos_sin || !out_q || !out_k) return MI_SGL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        // 16-byte lanes when the shapes allow it: whole chunks (D % 8), the rotated part ending on a chunk and -- rotate-half -- its halves too,
+        // every row 16-byte aligned
+        const bool aligned = !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos_sin | (uintptr_t)out_q | (uintptr_t)out_k) & 15) &&
+                             !((q_stride_t | q_stride_h | k_stride_t | k_stride_h | cs_stride_t) & 7);
+        const long long chunks = (long long)tokens * (q_heads + k_heads) * (((neox ? rope_dim / 2 : rope_dim) + head_dim - rope_dim) / 8);      // lanes
+        static const bool allow_vec = !(getenv("MI_ROPE_QK_VEC") && atoi(getenv("MI_ROPE_QK_VEC")) == 0);
+        if (allow_vec && aligned && head_dim % 8 == 0 && rope_dim % (neox ? 16 : 8) == 0 && (long long)tokens * (q_heads + k_heads) < (1ll << 31) &&
+            chunks / 256 < (1ll << 31) - 1) {
+            const int vblocks = (int)((chunks + 255) / 256);
+            if (dtype == MI_DTYPE_BF16)
+                rope_qk_mqa_vec_kernel<true><<<vblocks, 256, 0, st>>>((const uint16_t *)q, (const uint16_t *)k, (const uint16_t *)cos_sin, chunks, q_heads,
+                                                                    k_heads, head_dim, rope_dim, neox, q_stride_t, q_stride_h, k_stride_t, k_stride_h,
+                                                                    cs_stride_t, (uint16_t *)out_q, (uint16_t *)out_k);
+            else
+                rope_qk_mqa_vec_kernel<false><<<vblocks, 256, 0, st>>>((const uint16_t *)q, (const uint16_t *)k, (const uint16_t *)cos_sin, chunks, q_heads,
+                                                                     k_heads, head_dim, rope_dim, neox, q_stride_t, q_stride_h, k_stride_t, k_stride_h,
+                                                                     cs_stride_t, (uint16_t *)out_q, (uint16_t *)out_k);
+            return launch_ok();
+        }
+    }
     const long long waves = (long long)tokens * (q_heads + k_heads);
     const int blocks = (int)((waves + 3) / 4);
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == MI_DTYPE_BF16)
         rope_qk_mqa_kernel<true><<<blocks, 256, 0, st>>>((const uint16_t *)q, (const uint16_t *)k, (const uint16_t *)cos_sin, tokens,
                                                         q_heads, k_heads, head_dim, rope_dim, neox, q_stride_t, q_stride_h,

@@ -947,7 +947,9 @@ def test_mla_pre_bmm_rope(M, Hq, dtype, code):
 
 
 @pytest.mark.parametrize("T,Hq,Hk,D,R", [(32, 8, 1, 64, 32), (32, 8, 1, 32, 32), (17, 16, 1, 128, 64), (64, 32, 1, 128, 64),
-                                         (5, 128, 1, 192, 64)])       # reference cases (test_fused_rope_qk_mqa.py:64-71) + MLA-sized
+                                         (5, 128, 1, 192, 64),        # reference cases (test_fused_rope_qk_mqa.py:64-71) + MLA-sized
+                                         (300, 128, 1, 192, 64),      # many workgroups of the 16-byte-lane kernel, heads straddling them
+                                         (7, 4, 1, 40, 20)])          # R % 16 != 0: the scalar kernel
 @pytest.mark.parametrize("neox", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_fused_rope_qk_mqa(T, Hq, Hk, D, R, neox, dtype):
