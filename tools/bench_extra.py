@@ -171,6 +171,15 @@ def main():
     posb = torch.randint(0, 8192, (B,), device="cuda")
     t = ev_time(lambda: split_qkv_rmsnorm_rope_pos_cache_half_npu(xt, posb, cache, 6144, 1024, 128, eps=1e-6, q_weight=hw, k_weight=hw))
     out["split_qkv_rmsnorm_rope_pos_cache_4096x8192"] = dict(t, GBps=B * 8192 * 4 / t["p50_us"] / 1e3)
+    # ---- fused_rope_qk_mqa (A13): MLA-sized q [T, 128, 192] with the first 64 dims rotated + one shared key head; and a pure-rope shape
+    from sgl_kernel_npu.norm.fused_rope_qk_mqa import fused_rope_qk_mqa
+    for (Tq, Dq, Rq) in ((4096, 192, 64), (4096, 64, 64)):
+        qq = torch.randn((Tq, 128, Dq), device="cuda").to(torch.bfloat16)
+        kk = torch.randn((Tq, 1, Dq), device="cuda").to(torch.bfloat16)
+        csq = torch.rand((Tq, Rq), device="cuda").to(torch.bfloat16)
+        t = ev_time(lambda: fused_rope_qk_mqa(qq, kk, csq, Rq, True))
+        out[f"fused_rope_qk_mqa_{Tq}x129x{Dq}_r{Rq}_neox"] = dict(t, GBps=Tq * 129 * Dq * 4 / t["p50_us"] / 1e3)
+        del qq, kk, csq
     # ---- paged GQA decode (HBM-bound): Llama-70B-like (64 q / 8 kv heads, D=128) and the reference's 288/256 config
     from sgl_kernel_npu.attention.decode_attention import decode_gqa
     for name, Bq, Hq, Hkv, D, Dv, Sq in (("gqa_decode_b64_h64kv8_d128_s4096", 64, 64, 8, 128, 128, 4096),
