@@ -73,7 +73,7 @@ struct GemmArgs {
     int cols_padded;          // 0, or the column-tile count rounded up to a multiple of 8 (XCD-consistent column tiles, see the kernel)
     int small_last;           // an expert's last row block of <= 64 / <= 128 rows runs as a 64- / 128-row tile (MI_GEMM_SMALL_LAST=0: as a 256-row tile)
     // mode 3 (GEMM1 with the per-row requantisation in its epilogue, see gemm_tile): int8 [M_cap, N/2] + float [M_cap] out, and the words the
-    // column tiles of a row block meet at -- all zero when the launch starts (one memset per call: rq_words)
+    // column tiles of a row block meet at -- all zero when the launch starts (one memset per call: mi_ep_moe_requant_words)
     int8_t *q_out;
     float *q_scale;
     uint32_t *rq_rowmax;      // [M_cap][kRqCols] exchange lines: word c of row r = bits of column tile c's max |v| of that row | 0x80000000
@@ -161,7 +161,7 @@ __device__ __forceinline__ bool find_tile(const GemmArgs &p, int tile_slot, int 
 
 // one (expert, row block of `rows` <= 64 MT rows starting at row0) x 256-column tile
 template <int MODE, int MT, int BKT>
-__device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, int rows, int col_tile, uint8_t *lds, int tile_slot = 0)
+__device__ __forceinline__ void gemm_tile(const GemmArgs &p, int e, int row0, int rows, int col_tile, uint8_t *lds)
 {
     constexpr bool SWIGLU = MODE == 0 || MODE == 3;   // GEMM1: fusion tiles of 64 gate | 64 up columns; MODE 3 also requantises the rows
     constexpr int BM = 64 * MT;
@@ -621,9 +621,9 @@ __global__ __launch_bounds__(kGemmThreads) void grouped_gemm_i8_kernel(GemmArgs 
         // tile pays for it in full -- its weight tile streams all the same and the MFMAs multiply padding.  Blocks of <= 64 / <= 128 rows
         // run as the 64- / 128-row tile (a fifth / three eighths less operand stream per k-tile, a quarter / half of the MFMAs).  Same
         // products, same epilogue: bit-identical.
-        if (MT == 4 && BKT == 128 && p.small_last && rows <= 64) gemm_tile<MODE, 1, BKT>(p, e, row0, rows, col_tile, lds, slot);
-        else if (MT == 4 && BKT == 128 && p.small_last && rows <= 128) gemm_tile<MODE, 2, BKT>(p, e, row0, rows, col_tile, lds, slot);
-        else gemm_tile<MODE, MT, BKT>(p, e, row0, rows, col_tile, lds, slot);
+        if (MT == 4 && BKT == 128 && p.small_last && rows <= 64) gemm_tile<MODE, 1, BKT>(p, e, row0, rows, col_tile, lds);
+        else if (MT == 4 && BKT == 128 && p.small_last && rows <= 128) gemm_tile<MODE, 2, BKT>(p, e, row0, rows, col_tile, lds);
+        else gemm_tile<MODE, MT, BKT>(p, e, row0, rows, col_tile, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's stores are out before the ring is refilled ...
         __syncthreads();                                         // ... and every wave is done with its epilogue tile in LDS
     }
